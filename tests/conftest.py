@@ -1,0 +1,50 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line(
+        'markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def arrays_from_golden(g, which='in'):
+    """Rebuild pysph_amd ParticleArrays from a golden file's stored state."""
+    from pysph_amd.particle_array import ParticleArray
+    names = []
+    for key in g.files:
+        parts = key.split('/')
+        if parts[0] == which and parts[1] not in names:
+            names.append(parts[1])
+    out = []
+    for name in names:
+        props = {}
+        for key in g.files:
+            parts = key.split('/')
+            if parts[0] == which and parts[1] == name:
+                props[parts[2]] = g[key].copy()
+        pa = ParticleArray(name=name, **props)
+        nreal = 'nreal/%s' % name
+        if nreal in g.files:
+            pa.set_num_real_particles(int(g[nreal]))
+        out.append(pa)
+    return out
+
+
+@pytest.fixture(scope='session')
+def oracle():
+    from oracle import oracle as orc
+    orc.lib()
+    return orc

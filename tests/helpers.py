@@ -1,0 +1,48 @@
+"""Shared builders for the parity tests (equation sets named like the
+reference's schemes)."""
+import numpy as np
+
+from pysph_amd import kernels as K
+from pysph_amd.equations import Group, SummationDensity
+from pysph_amd.scheme import WCSPHScheme, TVFScheme
+from pysph_amd.examples import dam_break_3d as db
+
+WC_OUT = ['rho', 'p', 'cs', 'arho', 'au', 'av', 'aw', 'ax', 'ay', 'az',
+          'dt_cfl', 'dt_force']
+TVF_OUT = ['rho', 'V', 'p', 'au', 'av', 'aw', 'auhat', 'avhat', 'awhat']
+
+
+def golden_case(name, g):
+    """(equations, kernel, dim, output props) matching make_golden.py."""
+    if name == 'wcsph_dam_dx0.1':
+        dx = float(g['meta/dx'])
+        s = db.create_scheme(dx)
+        return s.get_equations(), K.WendlandQuintic(dim=3), 3, WC_OUT
+    if name == 'wcsph_cube_varh':
+        dx = float(g['meta/dx'])
+        s = WCSPHScheme(['fluid'], [], dim=3, rho0=1000.0, c0=10.0,
+                        h0=1.2 * dx, hdx=1.2, gx=0.5, gy=-0.25, gz=-9.81,
+                        alpha=1.0, beta=1.0, gamma=7.0,
+                        tensile_correction=True, summation_density=True)
+        return s.get_equations(), K.CubicSpline(dim=3), 3, WC_OUT
+    if name == 'sd_1d_line':
+        eqs = [Group(equations=[SummationDensity(dest='fluid',
+                                                 sources=['fluid'])])]
+        return eqs, K.CubicSpline(dim=1), 1, ['rho']
+    if name == 'tvf_cube':
+        dx = float(g['meta/dx'])
+        s = TVFScheme(['fluid'], [], dim=3, rho0=1.0, c0=10.0, nu=0.01,
+                      p0=100.0, pb=100.0, h0=dx, gx=0.1, alpha=0.2)
+        return s.get_equations(), K.QuinticSpline(dim=3), 3, TVF_OUT
+    raise KeyError(name)
+
+
+def rel_err(a, b, scale=None):
+    """max |a-b| / scale, scale = max|b| of the field unless given (mixed
+    abs/rel measure: accelerations near cancellation are judged against the
+    field's magnitude, SURVEY.md section 7 'Hard parts')."""
+    a = np.asarray(a, dtype=float)
+    b = np.asarray(b, dtype=float)
+    if scale is None:
+        scale = max(np.max(np.abs(b)), 1e-300) if b.size else 1.0
+    return float(np.max(np.abs(a - b)) / scale) if b.size else 0.0

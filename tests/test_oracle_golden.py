@@ -1,0 +1,113 @@
+"""Pin the C oracle (oracle/sph_oracle.c) against the golden vectors made by
+executing the reference's own Python classes (tests/golden/make_golden.py).
+
+Bar: BIT-EXACT.  The oracle is compiled without fp contraction and the
+goldens are CPython float arithmetic, so every output must be identical."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, arrays_from_golden
+from helpers import golden_case
+
+CASES = ['sd_1d_line', 'wcsph_cube_varh', 'tvf_cube', 'wcsph_dam_dx0.1']
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_oracle_matches_reference_bitwise(oracle, case):
+    g = load_golden(case + '.npz')
+    arrays = arrays_from_golden(g, 'in')
+    eqs, kernel, dim, outs = golden_case(case, g)
+    nnps = oracle.OracleNNPS(dim, arrays, radius_scale=kernel.radius_scale)
+    nnps.update()
+    assert nnps.cell_size == float(g['nnps/cell_size'])
+    assert np.array_equal(nnps.xmin, g['nnps/xmin'])
+    assert np.array_equal(nnps.xmax, g['nnps/xmax'])
+    assert np.array_equal(nnps.ncells_per_dim, g['nnps/ncells_per_dim'])
+    assert nnps.n_cells == int(g['nnps/n_cells'])
+    ev = oracle.OracleEval(arrays, eqs, kernel, nthreads=3)
+    ev.set_nnps(nnps)
+    ev.compute(float(g['t']), float(g['dt']))
+    for pa in arrays:
+        for prop in pa.properties:
+            key = 'out/%s/%s' % (pa.name, prop)
+            if key in g.files:
+                assert np.array_equal(pa.properties[prop], g[key]), \
+                    (pa.name, prop)
+
+
+@pytest.mark.parametrize('case', ['sd_1d_line', 'wcsph_cube_varh',
+                                  'wcsph_dam_dx0.1'])
+def test_oracle_neighbour_order_matches_reference(oracle, case):
+    """Neighbour lists in the reference's traversal order (cell shifts x
+    outer..z inner, LIFO inside a cell; linked_list_nnps.pyx:160-190)."""
+    g = load_golden(case + '.npz')
+    arrays = arrays_from_golden(g, 'in')
+    eqs, kernel, dim, outs = golden_case(case, g)
+    names = [pa.name for pa in arrays]
+    nnps = oracle.OracleNNPS(dim, arrays, radius_scale=kernel.radius_scale)
+    nnps.update()
+    pairs = set(k.split('/')[1] + '/' + k.split('/')[2]
+                for k in g.files if k.startswith('nbrs/'))
+    assert pairs
+    for pr in pairs:
+        s, d = pr.split('/')
+        start, idx = nnps.get_csr(names.index(s), names.index(d), nthreads=2)
+        assert np.array_equal(start, g['nbrs/%s/start' % pr])
+        assert np.array_equal(idx, g['nbrs/%s/idx' % pr])
+
+
+def test_known_neighbour_counts_1d(oracle):
+    """test_acceleration_eval.py:341 -- SimpleEquation sums m=1 over the
+    neighbours of the 10-particle line: [3,4,5,5,5,5,5,5,4,3]."""
+    g = load_golden('sd_1d_line.npz')
+    arrays = arrays_from_golden(g, 'in')
+    nnps = oracle.OracleNNPS(1, arrays, radius_scale=2.0)
+    nnps.update()
+    start, idx = nnps.get_csr(0, 0)
+    assert list(np.diff(start.astype(int))) == [3, 4, 5, 5, 5, 5, 5, 5, 4, 3]
+    # test_acceleration_eval.py:737-741: rho ~ [7.357, 9, ..., 9, 7.357]
+    rho = g['out/fluid/rho']
+    assert np.allclose(rho, [7.357, 9.0, 9., 9., 9., 9., 9., 9., 9., 7.357],
+                       atol=1e-2)
+
+
+def test_oracle_brute_force_agrees(oracle):
+    """Every NNPS is compared to brute force (test_nnps.py:379-412)."""
+    g = load_golden('wcsph_cube_varh.npz')
+    arrays = arrays_from_golden(g, 'in')
+    nnps = oracle.OracleNNPS(3, arrays, radius_scale=2.0)
+    nnps.update()
+    for i in range(0, arrays[0].get_number_of_particles(), 7):
+        a = np.sort(nnps.get_nearest_particles(0, 0, i))
+        b = nnps.brute_force_neighbors(0, 0, i)
+        assert np.array_equal(a, b)
+
+
+def test_oracle_kernels_bitwise(oracle):
+    from pysph_amd import kernels as K
+    g = load_golden('kernels.npz')
+    for cls, dims in ((K.CubicSpline, (1, 2, 3)), (K.WendlandQuintic, (2, 3)),
+                      (K.QuinticSpline, (1, 2, 3)), (K.Gaussian, (1, 2, 3))):
+        for dim in dims:
+            k = cls(dim=dim)
+            key = '%s/%d/' % (cls.__name__, dim)
+            # the boundary scalars themselves must equal the reference's
+            assert k.fac == float(g[key + 'fac'])
+            assert k.get_deltap() == float(g[key + 'deltap'])
+            assert k.radius_scale == float(g[key + 'radius_scale'])
+            h, r, xij = g[key + 'h'], g[key + 'r'], g[key + 'xij']
+            for i in range(h.size):
+                assert oracle.kernel_w(k, r[i], h[i]) == g[key + 'w'][i]
+                assert oracle.kernel_dwdq(k, r[i], h[i]) == g[key + 'dwdq'][i]
+                gr = oracle.kernel_gradient(k, list(xij[i]), r[i], h[i])
+                assert gr == list(g[key + 'grad'][i])
+            # host-side numpy helpers agree to rounding
+            assert np.allclose(k.kernel(rij=r, h=h), g[key + 'w'],
+                               rtol=1e-12, atol=1e-30)
+
+
+def test_wendland_w0_analytic():
+    """test_kernel.py:445: Wendland 3D W(0) = 21/(16 pi) / h^3."""
+    from pysph_amd import kernels as K
+    k = K.WendlandQuintic(dim=3)
+    assert abs(float(k.kernel(rij=0.0, h=1.0)) - 21.0 / (16 * np.pi)) < 1e-15
