@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""Benchmark of the SPH acceleration-eval hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one resident particle set:
+``nnps.update()`` (bounds, cell keys, radix sort, cell ranges) followed by
+``AccelerationEval.compute()`` (EOS + pack + fused WCSPH pair kernel), exactly
+what ``Integrator.compute_accelerations`` runs (pysph/sph/integrator.py:274-286).
+Inputs are already in HBM when the timed region starts.
+
+Workload (BASELINE.json metric): WCSPH, dam-break parameter set
+(WendlandQuintic, hdx 1.3, alpha 0.25, gamma 7, c0 = 10 sqrt(2 g 0.55),
+gz = -9.81), synthetic uniform 3-D distribution "S-cube" of SURVEY.md 8(d):
+159^3 = 4.02 M particles per GPU, jitter U(+-0.1 dx), seeded.  For N > 1 the
+domain is N such cubes side by side along x (weak scaling), slab-decomposed one
+cube per rank, with a ghost-particle halo exchange on RCCL (torch.distributed
+nccl) before every step.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+ALGO_BYTES_PAIR = 160.0      # pair-loop kernel, fp64, per particle-update
+ALGO_BYTES_UPDATE = 184.0    # whole compute() (EOS + pair pass)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def make_cube(n1, x_offset=0.0, seed=1234, hdx=1.3, nx=None):
+    from pysph_amd.particle_array import get_particle_array_wcsph
+    from pysph_amd.examples import dam_break_3d as db
+    rng = np.random.default_rng(seed)
+    dx = 1.0 / n1
+    nx = nx or n1
+    gx = np.arange(nx) * dx + x_offset
+    g = np.arange(n1) * dx
+    x, y, z = [a.ravel().copy() for a in np.meshgrid(gx, g, g, indexing='ij')]
+    n = x.size
+    for a in (x, y, z):
+        a += 0.1 * dx * rng.uniform(-1, 1, n)
+    pa = get_particle_array_wcsph(
+        name='fluid', x=x, y=y, z=z, h=hdx * dx * np.ones(n),
+        m=db.ro * dx ** 3 * np.ones(n),
+        rho=db.ro * (1 + 0.01 * rng.uniform(-1, 1, n)),
+        u=0.1 * db.c0 * rng.uniform(-1, 1, n),
+        v=0.1 * db.c0 * rng.uniform(-1, 1, n),
+        w=0.1 * db.c0 * rng.uniform(-1, 1, n))
+    return pa, dx
+
+
+def cube_equations(dx, hdx=1.3):
+    from pysph_amd.scheme import WCSPHScheme
+    from pysph_amd.examples import dam_break_3d as db
+    s = WCSPHScheme(['fluid'], [], dim=3, rho0=db.ro, c0=db.c0, h0=hdx * dx,
+                    hdx=hdx, gz=-9.81, alpha=db.alpha, beta=db.beta,
+                    gamma=db.gamma)
+    return s.get_equations()
+
+
+def cpu_baseline(n1=100, target_seconds=15.0):
+    """The oracle ("port": C/OpenMP restatement of the reference's Cython path)
+    timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    from pysph_amd import kernels as K
+    cores = os.cpu_count() or 1
+    pa, dx = make_cube(n1, seed=99)
+    eqs = cube_equations(dx)
+    nn = orc.OracleNNPS(3, [pa], 2.0)
+    ev = orc.OracleEval([pa], eqs, K.WendlandQuintic(dim=3), nthreads=cores)
+    ev.set_nnps(nn)
+
+    def one():
+        t0 = time.perf_counter()
+        nn.update()
+        ev.compute(0.0, 1e-5)
+        return time.perf_counter() - t0
+    t_first = one()            # also warms the OpenMP pool
+    reps = int(max(1, min(10, target_seconds / max(t_first, 1e-3))))
+    ts = [one() for _ in range(reps)]
+    t = float(np.median(ts))
+    n = n1 ** 3
+    return {'value': n / t, 'unit': 'particle-updates/s', 'cores': cores,
+            'kind': 'port',
+            'sample': 'S-cube %d^3=%d particles, WCSPH db set, fp64, '
+                      'nnps.update+compute, median of %d passes (OpenMP '
+                      'schedule(dynamic,64), %d threads)' % (n1, n, reps, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--n1', type=int, default=159, help='lattice side per GPU')
+    ap.add_argument('--variant', type=int, default=1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-n1', type=int, default=100)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    from pysph_amd import device as dev
+    from pysph_amd import kernels as K
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.nnps import HipNNPS
+
+    tstream = torch.cuda.Stream()      # kernels, copies and RCCL share it
+    torch.cuda.set_stream(tstream)
+    ctx = dev.HipContext(local_rank, tstream.cuda_stream)
+    ctx.set_option('pair_variant', args.variant)
+
+    n1 = args.n1
+    pa, dx = make_cube(n1, x_offset=float(rank), seed=1234 + rank)
+    n_local = pa.get_number_of_particles()
+    eqs = cube_equations(dx)
+    kernel = K.WendlandQuintic(dim=3)
+
+    dev.attach(pa, ctx).push()          # everything resident in HBM
+    halo = None
+    if world > 1:
+        from pysph_amd.parallel import SlabHalo
+        halo = SlabHalo(pa, ctx, rank, world, axis=0,
+                        width=kernel.radius_scale * 1.3 * dx,
+                        lo=float(rank), hi=float(rank + 1))
+    a_eval = AccelerationEval([pa], eqs, kernel)
+    SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+    nnps = HipNNPS(3, [pa], radius_scale=kernel.radius_scale, ctx=ctx,
+                   sync=False)
+    a_eval.set_nnps(nnps)
+
+    def step():
+        if halo is not None:
+            halo.exchange()
+        nnps.update()
+        a_eval.compute(0.0, 1e-5)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.timer_enable(True)
+    ctx.timer_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.timer_enable(False)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    timers = {k: ctx.timer_get(k) for k in ('nnps', 'pack', 'eos', 'pair')}
+    pair_ms, pair_launches = timers['pair']
+    n_total = n_local * world          # real particles only (ghosts are extra work)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n_total * args.steps / elapsed
+
+    if rank == 0:
+        pair_avg_s = pair_ms / max(pair_launches, 1) * 1e-3
+        achieved = ALGO_BYTES_PAIR * n_local / pair_avg_s / 1e9 if pair_avg_s > 0 else 0.0
+        out = {
+            'metric': 'particle-updates/sec (nnps.update + AccelerationEval.compute), '
+                      'WCSPH 3D, fp64',
+            'value': value, 'unit': 'particle-updates/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {
+                'workload': 'S-cube WCSPH dam-break parameter set '
+                            '(WendlandQuintic, hdx 1.3), %d^3 = %d particles '
+                            'per GPU, jitter 0.1dx, seed 1234' % (n1, n_local),
+                'particles_per_gpu': n_local, 'pair_variant': args.variant,
+                'parallelism': 'slab%d' % world if world > 1 else 'single',
+            },
+            'roofline': {
+                'bound': 'hbm', 'kernel': 'k_pair_%s<FamWCSPH,WendlandQuintic>' %
+                ('tiled' if args.variant else 'direct'),
+                'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                'algorithmic_bytes_per_particle': ALGO_BYTES_PAIR,
+                'avg_kernel_ms': pair_avg_s * 1e3,
+            },
+            'kernel_ms_per_step': {k: v[0] / args.steps for k, v in timers.items()},
+            'algorithmic_GBs_whole_update': ALGO_BYTES_UPDATE * value / 1e9,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(args.cpu_n1)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,193 @@
+/*
+ * sphhip.h -- C-ABI of libsphhip.so, the MI355X (gfx950) SPH acceleration-eval
+ * backend.  Plain pointers and sizes only; every function returns 0 on success
+ * or a negative sph_status (message via sph_last_error()).  No exceptions cross
+ * the boundary.  A context belongs to one GPU and one host thread.
+ *
+ * What each entry point replaces in the reference (pypr/pysph; paths relative
+ * to the reference root) is cited at its declaration.  The reference-side
+ * binding a maintainer would add is shown in INTEGRATION.md.
+ */
+#ifndef SPHHIP_H
+#define SPHHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPH_MAX_ARRAYS 8
+#define SPH_MAX_PAR 16
+#define SPH_MAX_EQS 64
+
+typedef struct sph_ctx sph_ctx;
+
+enum sph_status {
+    SPH_OK = 0,
+    SPH_ERR_HIP = -1,          /* a HIP runtime call failed */
+    SPH_ERR_ARG = -2,          /* bad argument */
+    SPH_ERR_CELLS = -3,        /* LinkedListNNPS: bad number of cells (linked_list_nnps.pyx:307-343) */
+    SPH_ERR_UNSUPPORTED = -4,  /* equation / kernel combination without a hand-written kernel */
+    SPH_ERR_MISSING_PROP = -5, /* a property needed by an equation was never registered */
+    SPH_ERR_STATE = -6         /* e.g. eval before nnps update */
+};
+
+/* Particle properties with device storage (all fp64, SoA).  Names via
+ * sph_prop_id(); mirrors the property names of pysph/base/utils.py:36-39,
+ * 152-155 (WCSPH) and get_particle_array_tvf_fluid.                      */
+enum sph_prop {
+    SPH_X, SPH_Y, SPH_Z, SPH_U, SPH_V, SPH_W, SPH_H, SPH_M, SPH_RHO, SPH_P, SPH_CS,
+    SPH_ARHO, SPH_AU, SPH_AV, SPH_AW, SPH_AX, SPH_AY, SPH_AZ, SPH_DT_CFL, SPH_DT_FORCE,
+    SPH_VOL /* 'V' */, SPH_UHAT, SPH_VHAT, SPH_WHAT, SPH_AUHAT, SPH_AVHAT, SPH_AWHAT,
+    SPH_X0, SPH_Y0, SPH_Z0, SPH_U0, SPH_V0, SPH_W0, SPH_RHO0,
+    SPH_PROP_COUNT
+};
+
+/* pysph/base/kernels.py class -> id */
+enum sph_kernel_kind {
+    SPH_K_CUBIC_SPLINE = 1,     /* kernels.py:29 */
+    SPH_K_WENDLAND_QUINTIC = 2, /* kernels.py:274 */
+    SPH_K_QUINTIC_SPLINE = 3,   /* kernels.py:1050 */
+    SPH_K_GAUSSIAN = 4          /* kernels.py:830 */
+};
+
+/* Kernel object fields copied by value, as the generated Cython does
+ * (acceleration_eval_cython_helper.py:240-245).                          */
+typedef struct {
+    int kind;
+    int dim;
+    double fac;
+    double radius_scale;
+    double deltap;
+} sph_kernel;
+
+/* Equation class -> id; `par` order listed per id (equation __init__ args). */
+enum sph_eq_kind {
+    SPH_EQ_TAIT_EOS = 1,              /* wc/basic.py:9      par: rho0 c0 gamma p0 */
+    SPH_EQ_TAIT_EOS_HG = 2,           /* wc/basic.py:68     par: rho0 c0 gamma */
+    SPH_EQ_CONTINUITY = 3,            /* basic_equations.py:177 */
+    SPH_EQ_MOMENTUM = 4,              /* wc/basic.py:129    par: c0 alpha beta gx gy gz tensile */
+    SPH_EQ_XSPH = 5,                  /* basic_equations.py:260  par: eps */
+    SPH_EQ_SUMMATION_DENSITY = 6,     /* basic_equations.py:19 */
+    SPH_EQ_TVF_SUMMATION_DENSITY = 7, /* wc/transport_velocity.py:24 */
+    SPH_EQ_TVF_STATE_EQUATION = 8,    /* :190  par: p0 rho0 b */
+    SPH_EQ_TVF_MOM_PRESSURE = 9,      /* :219  par: pb gx gy gz tdamp */
+    SPH_EQ_TVF_MOM_VISCOSITY = 10,    /* :328  par: nu */
+    SPH_EQ_TVF_MOM_ART_VISCOSITY = 11,/* :389  par: c0 alpha */
+    SPH_EQ_TVF_MOM_ART_STRESS = 12,   /* :439 */
+    SPH_EQ_ISOTHERMAL_EOS = 13,       /* basic_equations.py:151  par: rho0 c0 p0 */
+    SPH_EQ_MONAGHAN_ART_VISCOSITY = 14/* basic_equations.py:195  par: alpha beta */
+};
+
+/* One Equation(dest, sources) instance: pysph/sph/equation.py:392-420. */
+typedef struct {
+    int kind;
+    int dest;                  /* array id */
+    int nsrc;                  /* 0: equation without sources */
+    int src[SPH_MAX_ARRAYS];   /* array ids, user order */
+    double par[SPH_MAX_PAR];
+} sph_equation;
+
+/* One (leaf) Group: pysph/sph/equation.py:457-561.  `pre/post/condition/
+ * iterate/update_nnps` are host-side control and stay in the Python caller. */
+typedef struct {
+    int real;                  /* loop over real particles only */
+    long start_idx;            /* D_START_IDX  (acceleration_eval_cython_helper.py:263-268) */
+    long stop_idx;             /* < 0: None -> dst.size(real) */
+    int neq;
+    const sph_equation *eqs;
+} sph_group;
+
+/* ---------------------------------------------------------------------- */
+/* context                                                                  */
+/* ---------------------------------------------------------------------- */
+/* `stream`: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or
+ * NULL for a stream owned by the context.  All kernels of this context are
+ * launched on it.                                                          */
+int sph_ctx_create(int device, void *stream, sph_ctx **out);
+int sph_ctx_destroy(sph_ctx *ctx);
+int sph_ctx_synchronize(sph_ctx *ctx);
+const char *sph_last_error(void);
+const char *sph_version(void);
+int sph_prop_id(const char *name); /* -1 if unknown */
+
+/* ---------------------------------------------------------------------- */
+/* device mirror of the host ParticleArrays                                 */
+/* replaces DeviceHelper.push/pull/resize (pysph/base/device_helper.py:200, */
+/* :219, :130) -- the host keeps owning the numpy/cyarray buffers.          */
+/* ---------------------------------------------------------------------- */
+/* (Re)size array `array_id` to n particles of which the first n_real are
+ * real (particle_array.pyx:423).  Existing device data is preserved up to
+ * min(old, new).                                                           */
+int sph_array_resize(sph_ctx *ctx, int array_id, size_t n, size_t n_real);
+int sph_array_size(sph_ctx *ctx, int array_id, size_t *n, size_t *n_real);
+/* Make sure property `prop` has device storage (zero-filled when created). */
+int sph_array_ensure_prop(sph_ctx *ctx, int array_id, int prop);
+/* host -> device / device -> host of n doubles starting at particle `offset`. */
+int sph_array_push(sph_ctx *ctx, int array_id, int prop, const double *host, size_t offset, size_t n);
+int sph_array_pull(sph_ctx *ctx, int array_id, int prop, double *host, size_t offset, size_t n);
+/* Raw device pointer of a property (device-resident pipelines, RCCL halos). */
+int sph_array_device_ptr(sph_ctx *ctx, int array_id, int prop, void **dptr);
+
+/* ---------------------------------------------------------------------- */
+/* neighbour search                                                         */
+/* replaces DomainManager._compute_cell_size_for_binning                    */
+/* (pysph/base/nnps_base.pyx:942-978), NNPS.update/_compute_bounds          */
+/* (:1471-1575), LinkedListNNPS._refresh/_bin                               */
+/* (pysph/base/linked_list_nnps.pyx:235-383).                               */
+/* ---------------------------------------------------------------------- */
+/* Bin every particle of the listed arrays on one common grid.  cell_size<=0:
+ * radius_scale*max(h) as the reference does.  `bounds` (6 doubles
+ * xmin,ymin,zmin,xmax,ymax,zmax) overrides the computed, 1%-padded bounds
+ * when non-NULL (multi-GPU runs share the global grid).                    */
+int sph_nnps_update(sph_ctx *ctx, int dim, int narrays, const int *array_ids,
+                    double radius_scale, double cell_size, const double *bounds);
+/* d8: cell_size hmin xmin[3] xmax[3];  i4: ncx ncy ncz n_cells             */
+int sph_nnps_info(sph_ctx *ctx, double *d8, long *i4);
+/* min/max of x,y,z,h over the listed arrays, no padding (out: 8 doubles
+ * xmin ymin zmin hmin xmax ymax zmax hmax) -- NNPS._compute_bounds input.  */
+int sph_nnps_minmax(sph_ctx *ctx, int narrays, const int *array_ids, double *out8);
+/* Neighbour lists as CSR, replacing NNPS.get_nearest_particles
+ * (nnps_base.pyx:1290-1323) / GPUNeighborCache (gpu_nnps_base.pyx:54-117).
+ * Pass 1 (nbrs==NULL): fills start[0..nd] (exclusive scan of the counts) and
+ * *total.  Pass 2: fills nbrs[total]; each list is sorted ascending.  Host
+ * buffers.                                                                 */
+int sph_nnps_get_csr(sph_ctx *ctx, int src, int dst, uint32_t *start, uint32_t *nbrs, size_t *total);
+/* Permutation of array `array_id` into cell order (sorted -> original
+ * index), n entries: get_spatially_ordered_indices
+ * (linked_list_nnps.pyx:198-209).                                          */
+int sph_nnps_get_order(sph_ctx *ctx, int array_id, uint32_t *perm);
+
+/* ---------------------------------------------------------------------- */
+/* acceleration evaluation                                                  */
+/* replaces one leaf-group block of the generated AccelerationEval.compute  */
+/* (pysph/sph/acceleration_eval_cython.mako:10-154), including the          */
+/* destination/source regrouping of MegaGroup                               */
+/* (pysph/sph/acceleration_eval.py:94-162).                                 */
+/* ---------------------------------------------------------------------- */
+int sph_eval_group(sph_ctx *ctx, const sph_kernel *kernel, const sph_group *group,
+                   double t, double dt);
+/* max over the first n_real particles of a property (dt_cfl, dt_force:
+ * pysph/sph/integrator.py:161-200).                                        */
+int sph_reduce_max(sph_ctx *ctx, int array_id, int prop, double *out);
+
+/* pair-kernel variant: 0 = per-lane cell walk (direct), 1 = LDS-tiled
+ * two-phase (default).                                                      */
+int sph_set_option(sph_ctx *ctx, const char *key, long value);
+
+/* ---------------------------------------------------------------------- */
+/* timing (replaces compyle.profile's ProfileContext keys,                  */
+/* acceleration_eval_cython.mako:14-144): accumulated hipEvent time per     */
+/* kernel class since the last reset.                                       */
+/* ---------------------------------------------------------------------- */
+int sph_timer_enable(sph_ctx *ctx, int on);
+int sph_timer_reset(sph_ctx *ctx);
+/* keys: "nnps", "pack", "eos", "pair", "scatter"; out: total ms and launches */
+int sph_timer_get(sph_ctx *ctx, const char *key, double *ms, long *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

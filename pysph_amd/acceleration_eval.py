@@ -1,0 +1,382 @@
+"""The drop-in boundary: ``AccelerationEval`` and its HIP compiled object.
+
+Reference interfaces mirrored here (pypr/pysph):
+
+* ``AccelerationEval(particle_arrays, equations, kernel, mode, backend)`` with
+  ``compute / set_nnps / update_particle_arrays / set_compiled_object``
+  -- pysph/sph/acceleration_eval.py:166-248;
+* ``MegaGroup`` regrouping ``{dest: (eqs_with_no_source, sources, all_eqs)}``
+  -- acceleration_eval.py:94-162;
+* the ``c_acceleration_eval`` protocol ``compute(t, dt)``, ``set_nnps(nnps)``,
+  ``update_particle_arrays(arrays)`` implemented by the generated Cython class
+  (acceleration_eval_cython.mako:197-363) and by ``GPUAccelerationEval``
+  (acceleration_eval_gpu_helper.py:204-335) -- here ``HipAccelerationEval``;
+* the helper protocol ``SPHCompiler`` drives: ``Helper(a_eval)``,
+  ``get_code()``, ``compile(code)``, ``setup_compiled_module(module)``
+  (sph_compiler.py:27-59) -- here ``AccelerationEvalHipHelper``.
+
+``HipAccelerationEval`` accepts either this package's spec objects or a real
+``pysph.sph.acceleration_eval.AccelerationEval`` (it only reads
+``particle_arrays``, ``equation_groups``/``mega_groups`` and ``kernel``), see
+INTEGRATION.md.
+
+Group control flow that is host-side in the reference stays host-side here:
+``pre/post/condition`` callbacks, ``iterate`` with ``converged()``,
+``update_nnps`` and ``py_initialize`` / ``reduce`` hooks
+(acceleration_eval_cython.mako:291-363).
+"""
+import ctypes as C
+from collections import OrderedDict, defaultdict
+
+from . import device as dev
+from .equations import Group, MultiStageEquations, resolve_equation
+from .kernels import kernel_id
+from .particle_array import has_prop
+
+
+def group_equations(equations):
+    """acceleration_eval.py:14-28."""
+    only_groups = [x for x in equations if hasattr(x, 'has_subgroups')]
+    if only_groups and len(only_groups) != len(equations):
+        raise ValueError('All elements must be Groups if you use groups.')
+    if not only_groups:
+        return [Group(equations)]
+    return equations
+
+
+def check_equation_array_properties(equation, particle_arrays):
+    """acceleration_eval.py:32-73: RuntimeError when a destination/source array
+    or one of the properties the equation touches is missing."""
+    arrays = dict((pa.name, pa) for pa in particle_arrays)
+    kind, vals, dprops, sprops = resolve_equation(equation)
+    if equation.dest not in arrays:
+        raise RuntimeError("ERROR: Equation %s has invalid dest: '%s'" %
+                           (equation.name, equation.dest))
+    for src in (equation.sources or []):
+        if src not in arrays:
+            raise RuntimeError("ERROR: Equation %s has invalid source: '%s'" %
+                               (equation.name, src))
+    missing = defaultdict(set)
+    for p in dprops:
+        if not has_prop(arrays[equation.dest], p):
+            missing[equation.dest].add(p)
+    for src in (equation.sources or []):
+        for p in sprops:
+            if not has_prop(arrays[src], p):
+                missing[src].add(p)
+    if missing:
+        msg = 'ERROR: Missing array properties for equation: %s\n' % equation.name
+        for name, props in missing.items():
+            msg += "Array '%s' missing properties %s.\n" % (name, sorted(props))
+        raise RuntimeError(msg)
+
+
+class MegaGroup(object):
+    """acceleration_eval.py:94-162."""
+
+    def __init__(self, group, group_cls=Group):
+        self._orig_group = group
+        self.Group = group_cls
+        for key in ('real', 'update_nnps', 'iterate', 'pre', 'post',
+                    'max_iterations', 'min_iterations', 'has_subgroups',
+                    'condition', 'start_idx', 'stop_idx', 'name'):
+            setattr(self, key, getattr(group, key))
+        self.data = self._make_data(group)
+
+    def _make_data(self, group):
+        if group.has_subgroups:
+            return [MegaGroup(g, self.Group) for g in group.equations]
+        dests = OrderedDict()
+        for eq in group.equations:
+            if eq.dest not in dests:
+                dests[eq.dest] = ([], OrderedDict(), [])
+            no_src, sources, all_eqs = dests[eq.dest]
+            if eq not in all_eqs:
+                all_eqs.append(eq)
+            if eq.no_source:
+                no_src.append(eq)
+            else:
+                for s in eq.sources:
+                    sources.setdefault(s, []).append(eq)
+        return dests
+
+
+class AccelerationEval(object):
+    """acceleration_eval.py:166-248 (backend is always the HIP one here)."""
+
+    def __init__(self, particle_arrays, equations, kernel, mode='serial',
+                 backend='hip'):
+        assert backend in ('hip', '', None)
+        self.backend = 'hip'
+        self.particle_arrays = particle_arrays
+        self.equation_groups = group_equations(equations)
+        self.kernel = kernel
+        self.nnps = None
+        self.mode = mode
+        all_eqs = []
+        for g in self.equation_groups:
+            if g.has_subgroups:
+                for sg in g.equations:
+                    all_eqs.extend(sg.equations)
+            else:
+                all_eqs.extend(g.equations)
+        self.all_equations = all_eqs
+        for eq in all_eqs:
+            check_equation_array_properties(eq, particle_arrays)
+        self.mega_groups = [MegaGroup(g) for g in self.equation_groups]
+        self.c_acceleration_eval = None
+
+    def compute(self, t, dt):
+        self.c_acceleration_eval.compute(t, dt)
+
+    def set_compiled_object(self, c_acceleration_eval):
+        self.c_acceleration_eval = c_acceleration_eval
+
+    def set_nnps(self, nnps):
+        self.nnps = nnps
+        self.c_acceleration_eval.set_nnps(nnps)
+
+    def update_particle_arrays(self, particle_arrays):
+        self.c_acceleration_eval.update_particle_arrays(particle_arrays)
+
+
+def make_acceleration_evals(particle_arrays, equations, kernel, mode='serial',
+                            backend='hip'):
+    """acceleration_eval.py:76-90."""
+    groups = equations.groups if isinstance(equations, MultiStageEquations) \
+        else [equations]
+    return [AccelerationEval(particle_arrays, g, kernel, mode, backend)
+            for g in groups]
+
+
+class _CGroup(object):
+    """One leaf group marshalled for ``sph_eval_group``."""
+
+    def __init__(self, group, array_ids, arrays):
+        self.group = group
+        eqs = group.equations
+        self.ceqs = (dev.SphEquation * max(len(eqs), 1))()
+        self.inputs = defaultdict(set)    # array name -> props read
+        self.outputs = defaultdict(set)   # array name -> props written
+        for i, eq in enumerate(eqs):
+            kind, vals, dprops, sprops = resolve_equation(eq)
+            ce = self.ceqs[i]
+            ce.kind = kind
+            ce.dest = array_ids[eq.dest]
+            srcs = eq.sources or []
+            ce.nsrc = len(srcs)
+            for k, s in enumerate(srcs):
+                ce.src[k] = array_ids[s]
+            for k, v in enumerate(vals):
+                ce.par[k] = v
+            self.inputs[eq.dest].update(dprops)
+            self.outputs[eq.dest].update(dprops)
+            for s in srcs:
+                self.inputs[s].update(sprops)
+        self.cg = dev.SphGroup()
+        self.cg.real = 1 if group.real else 0
+        self.cg.neq = len(eqs)
+        self.cg.eqs = self.ceqs
+        self._arrays = arrays
+
+    def refresh_range(self):
+        g = self.group
+        dest = self._arrays[g.equations[0].dest] if g.equations else None
+
+        def resolve(v, default):
+            if v is None:
+                return default
+            if isinstance(v, str):  # property/constant name: first value
+                from .particle_array import get_npy
+                return int(get_npy(dest, v)[0])
+            return int(v)
+        self.cg.start_idx = resolve(g.start_idx, 0)
+        self.cg.stop_idx = resolve(g.stop_idx, -1)
+
+
+class HipAccelerationEval(object):
+    """The compiled object behind ``AccelerationEval.set_compiled_object``.
+
+    sync='auto'   (default) host arrays are authoritative, as with the Cython
+                  backend: inputs are pushed before and outputs pulled after
+                  every ``compute``;
+    sync='manual' device-resident state, as with the reference's GPU backends
+                  (explicit ``pa.gpu.push()/pull()``, cf.
+                  test_acceleration_eval.py:178-191).
+    """
+
+    def __init__(self, a_eval, ctx=None, sync='auto'):
+        self.a_eval = a_eval
+        self.ctx = ctx or dev.get_context()
+        self.lib = self.ctx.lib
+        self.sync = sync
+        self.nnps = None
+        k = a_eval.kernel
+        self.ckernel = dev.SphKernel(kernel_id(k), int(k.dim), float(k.fac),
+                                     float(k.radius_scale),
+                                     float(k.get_deltap()))
+        self._setup(list(a_eval.particle_arrays))
+
+    def _setup(self, arrays):
+        self.particle_arrays = arrays
+        self.arrays = OrderedDict((pa.name, pa) for pa in arrays)
+        self.helpers = OrderedDict(
+            (pa.name, dev.attach(pa, self.ctx)) for pa in arrays)
+        ids = dict((n, h.array_id) for n, h in self.helpers.items())
+        groups = getattr(self.a_eval, 'equation_groups', None)
+        if groups is None:
+            groups = group_equations(self.a_eval.equations)
+        self.plan = [self._plan_group(g, ids) for g in groups]
+        self.inputs = defaultdict(set)
+        self.outputs = defaultdict(set)
+        for cg in self._leaves(self.plan):
+            for n, p in cg.inputs.items():
+                self.inputs[n].update(p)
+            for n, p in cg.outputs.items():
+                self.outputs[n].update(p)
+
+    def _plan_group(self, g, ids):
+        if g.has_subgroups:
+            return (g, [self._plan_group(sg, ids) for sg in g.equations])
+        return (g, _CGroup(g, ids, self.arrays))
+
+    def _leaves(self, plan):
+        for g, item in plan:
+            if isinstance(item, list):
+                for leaf in self._leaves(item):
+                    yield leaf
+            else:
+                yield item
+
+    # -- c_acceleration_eval protocol ---------------------------------------
+    def set_nnps(self, nnps):
+        self.nnps = nnps
+
+    def update_particle_arrays(self, particle_arrays):
+        self._setup(list(particle_arrays))
+
+    def compute(self, t, dt):
+        if self.nnps is None:
+            raise RuntimeError('HipAccelerationEval.compute: call set_nnps first')
+        if self.sync == 'auto':
+            self.push_inputs()
+        for entry in self.plan:
+            self._run(entry, t, dt)
+        if self.sync == 'auto':
+            self.pull_outputs()
+
+    # -- data movement --------------------------------------------------------
+    def push_inputs(self):
+        for name, props in self.inputs.items():
+            pa = self.arrays[name]
+            have = [p for p in sorted(props) if has_prop(pa, p)]
+            self.helpers[name].push(*have)
+
+    def pull_outputs(self):
+        for name, props in self.outputs.items():
+            pa = self.arrays[name]
+            out = [p for p in sorted(props)
+                   if has_prop(pa, p) and p not in ('x', 'y', 'z', 'h', 'm',
+                                                    'u', 'v', 'w', 'uhat',
+                                                    'vhat', 'what')]
+            self.helpers[name].pull(*out)
+
+    # -- group execution (acceleration_eval_cython.mako:291-363) -------------
+    def _run(self, entry, t, dt):
+        g, item = entry
+        if g.condition is not None and not g.condition(t, dt):
+            return
+        if g.iterate:
+            count = 1
+            while True:
+                self._run_once(g, item, t, dt)
+                done = self._converged(g)
+                if count >= g.min_iterations and \
+                        (done or count == g.max_iterations):
+                    break
+                count += 1
+        else:
+            self._run_once(g, item, t, dt)
+
+    def _converged(self, g):
+        ok = True
+        for eq in self._group_equations(g):
+            ok &= eq.converged() > 0
+        return ok
+
+    def _group_equations(self, g):
+        if g.has_subgroups:
+            for sg in g.equations:
+                for eq in self._group_equations(sg):
+                    yield eq
+        else:
+            for eq in g.equations:
+                yield eq
+
+    def _run_once(self, g, item, t, dt):
+        if g.pre:
+            g.pre()
+        if isinstance(item, list):
+            for sub in item:
+                sg = sub[0]
+                if sg.condition is not None and not sg.condition(t, dt):
+                    continue
+                self._run_once(sg, sub[1], t, dt)
+        else:
+            for eq in g.equations:
+                if hasattr(eq, 'py_initialize'):
+                    eq.py_initialize(self.arrays[eq.dest], t, dt)
+            item.refresh_range()
+            dev._check(self.lib.sph_eval_group(
+                self.ctx._h, C.byref(self.ckernel), C.byref(item.cg), t, dt))
+            for eq in g.equations:
+                if hasattr(eq, 'reduce'):
+                    eq.reduce(self.arrays[eq.dest], t, dt)
+        if g.update_nnps:
+            self.nnps.update_domain()
+            self.nnps.update()
+        if g.post:
+            g.post()
+
+
+class AccelerationEvalHipHelper(object):
+    """Helper with the protocol ``SPHCompiler`` expects
+    (sph_compiler.py:27-59; Cython twin:
+    acceleration_eval_cython_helper.py:113-181).  Nothing is generated or
+    compiled at run time: the kernels are prebuilt in libsphhip.so."""
+
+    def __init__(self, acceleration_eval, ctx=None, sync='auto'):
+        self.object = acceleration_eval
+        self.ctx = ctx
+        self.sync = sync
+
+    def get_code(self):
+        return '# HIP backend: hand-written kernels in libsphhip.so\n'
+
+    def compile(self, code):
+        dev.load_library()
+        return None
+
+    def setup_compiled_module(self, module=None):
+        obj = HipAccelerationEval(self.object, ctx=self.ctx, sync=self.sync)
+        self.object.set_compiled_object(obj)
+        return obj
+
+
+class SPHCompiler(object):
+    """sph_compiler.py:1-94 for the HIP backend (acceleration evals only)."""
+
+    def __init__(self, acceleration_evals, integrator=None, ctx=None,
+                 sync='auto'):
+        if not isinstance(acceleration_evals, (list, tuple)):
+            acceleration_evals = [acceleration_evals]
+        if integrator is not None:
+            raise NotImplementedError('HIP integrator stage kernels: next round')
+        self.acceleration_evals = list(acceleration_evals)
+        self.helpers = [AccelerationEvalHipHelper(a, ctx, sync)
+                        for a in self.acceleration_evals]
+
+    def compile(self):
+        for h in self.helpers:
+            h.compile(h.get_code())
+            h.setup_compiled_module(None)

@@ -1,0 +1,262 @@
+// sph_ctx.hip -- context, device mirror of the host ParticleArrays, timers.
+//
+// Replaces the reference's DeviceHelper (pysph/base/device_helper.py:47-672:
+// push/pull/resize of `pa.gpu`) with an explicit host<->HIP buffer table:
+// the Python host keeps owning the numpy buffers and decides when to move data.
+#include "sph_internal.h"
+
+static thread_local char g_err[1024] = "";
+
+void sph_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+int DevBuf::reserve(size_t need, bool keep, hipStream_t stream)
+{
+    if (need <= bytes) return SPH_OK;
+    size_t nb = need + need / 4 + 256;
+    void *np = nullptr;
+    HIP_TRY(hipMalloc(&np, nb));
+    if (keep && ptr && bytes) {
+        HIP_TRY(hipMemcpyAsync(np, ptr, bytes, hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    if (ptr) (void)hipFree(ptr);
+    ptr = np;
+    bytes = nb;
+    return SPH_OK;
+}
+
+void DevBuf::release()
+{
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+}
+
+ScopedTimer::ScopedTimer(sph_ctx *ctx, int k) : c(ctx), key(k)
+{
+    if (!c->timers_on) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+    (void)hipEventRecord(a, c->stream);
+}
+
+ScopedTimer::~ScopedTimer()
+{
+    if (!a) return;
+    (void)hipEventRecord(b, c->stream);
+    c->timers[key].pending.emplace_back(a, b);
+}
+
+static const char *PROP_NAMES[SPH_PROP_COUNT] = {
+    "x", "y", "z", "u", "v", "w", "h", "m", "rho", "p", "cs",
+    "arho", "au", "av", "aw", "ax", "ay", "az", "dt_cfl", "dt_force",
+    "V", "uhat", "vhat", "what", "auhat", "avhat", "awhat",
+    "x0", "y0", "z0", "u0", "v0", "w0", "rho0"};
+
+extern "C" {
+
+const char *sph_last_error(void) { return g_err; }
+const char *sph_version(void) { return "sphhip 0.1 (gfx950)"; }
+
+int sph_prop_id(const char *name)
+{
+    for (int i = 0; i < SPH_PROP_COUNT; i++)
+        if (strcmp(name, PROP_NAMES[i]) == 0) return i;
+    return -1;
+}
+
+int sph_ctx_create(int device, void *stream, sph_ctx **out)
+{
+    if (!out) { sph_set_error("sph_ctx_create: out is NULL"); return SPH_ERR_ARG; }
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) {
+        sph_set_error("sph_ctx_create: device %d not available (%d visible)", device, ndev);
+        return SPH_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(device));
+    sph_ctx *c = new sph_ctx();
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    HIP_TRY(hipHostMalloc((void **)&c->pinned, 64 * sizeof(double), hipHostMallocDefault));
+    *out = c;
+    return SPH_OK;
+}
+
+int sph_ctx_destroy(sph_ctx *c)
+{
+    if (!c) return SPH_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &A : c->arr) {
+        for (auto &p : A.prop) if (p) (void)hipFree(p);
+        A.keys.release(); A.keys_sorted.release(); A.idx.release(); A.perm.release();
+        A.cell_start.release();
+    }
+    for (DevBuf *b : {&c->cub_tmp, &c->red_part, &c->red_out, &c->posh, &c->aux, &c->dkeys, &c->dperm,
+                      &c->tmp_u32a, &c->tmp_u32b})
+        b->release();
+    for (auto &t : c->timers)
+        for (auto &pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SPH_OK;
+}
+
+int sph_ctx_synchronize(sph_ctx *c)
+{
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+static int check_array(sph_ctx *c, int id, const char *who)
+{
+    if (!c) { sph_set_error("%s: ctx is NULL", who); return SPH_ERR_ARG; }
+    if (id < 0 || id >= SPH_MAX_ARRAYS) { sph_set_error("%s: bad array id %d", who, id); return SPH_ERR_ARG; }
+    return SPH_OK;
+}
+
+int sph_array_resize(sph_ctx *c, int id, size_t n, size_t n_real)
+{
+    SPH_TRY(check_array(c, id, "sph_array_resize"));
+    if (n_real > n) { sph_set_error("sph_array_resize: n_real %zu > n %zu", n_real, n); return SPH_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    DevArray &A = c->arr[id];
+    A.used = true;
+    if (n > A.cap) {
+        size_t ncap = n + n / 8 + 64;
+        for (int p = 0; p < SPH_PROP_COUNT; p++) {
+            if (!A.prop[p]) continue;
+            double *np = nullptr;
+            HIP_TRY(hipMalloc((void **)&np, ncap * sizeof(double)));
+            HIP_TRY(hipMemsetAsync(np, 0, ncap * sizeof(double), c->stream));
+            if (A.n) HIP_TRY(hipMemcpyAsync(np, A.prop[p], A.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipFree(A.prop[p]));
+            A.prop[p] = np;
+        }
+        A.cap = ncap;
+    }
+    if (n != A.n) c->nnps_valid = false;
+    A.n = n;
+    A.n_real = n_real;
+    return SPH_OK;
+}
+
+int sph_array_size(sph_ctx *c, int id, size_t *n, size_t *n_real)
+{
+    SPH_TRY(check_array(c, id, "sph_array_size"));
+    if (n) *n = c->arr[id].n;
+    if (n_real) *n_real = c->arr[id].n_real;
+    return SPH_OK;
+}
+
+int sph_array_ensure_prop(sph_ctx *c, int id, int prop)
+{
+    SPH_TRY(check_array(c, id, "sph_array_ensure_prop"));
+    if (prop < 0 || prop >= SPH_PROP_COUNT) { sph_set_error("bad property id %d", prop); return SPH_ERR_ARG; }
+    DevArray &A = c->arr[id];
+    if (!A.used) { sph_set_error("array %d was never sized (sph_array_resize)", id); return SPH_ERR_STATE; }
+    if (A.prop[prop]) return SPH_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    size_t cap = A.cap ? A.cap : 64;
+    A.cap = cap;
+    HIP_TRY(hipMalloc((void **)&A.prop[prop], cap * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(A.prop[prop], 0, cap * sizeof(double), c->stream));
+    return SPH_OK;
+}
+
+int sph_array_push(sph_ctx *c, int id, int prop, const double *host, size_t offset, size_t n)
+{
+    SPH_TRY(sph_array_ensure_prop(c, id, prop));
+    DevArray &A = c->arr[id];
+    if (offset + n > A.n) { sph_set_error("sph_array_push: %zu+%zu > n=%zu", offset, n, A.n); return SPH_ERR_ARG; }
+    if (n == 0) return SPH_OK;
+    HIP_TRY(hipMemcpyAsync(A.prop[prop] + offset, host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    // pageable host memory: the runtime has staged the data once this returns
+    // only after a sync; keep the call synchronous so Python may reuse `host`.
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (prop == SPH_X || prop == SPH_Y || prop == SPH_Z || prop == SPH_H) c->nnps_valid = false;
+    return SPH_OK;
+}
+
+int sph_array_pull(sph_ctx *c, int id, int prop, double *host, size_t offset, size_t n)
+{
+    SPH_TRY(check_array(c, id, "sph_array_pull"));
+    DevArray &A = c->arr[id];
+    if (prop < 0 || prop >= SPH_PROP_COUNT || !A.prop[prop]) {
+        sph_set_error("sph_array_pull: array %d has no device copy of property %d", id, prop);
+        return SPH_ERR_MISSING_PROP;
+    }
+    if (offset + n > A.n) { sph_set_error("sph_array_pull: %zu+%zu > n=%zu", offset, n, A.n); return SPH_ERR_ARG; }
+    if (n == 0) return SPH_OK;
+    HIP_TRY(hipMemcpyAsync(host, A.prop[prop] + offset, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_array_device_ptr(sph_ctx *c, int id, int prop, void **dptr)
+{
+    SPH_TRY(sph_array_ensure_prop(c, id, prop));
+    *dptr = c->arr[id].prop[prop];
+    return SPH_OK;
+}
+
+int sph_set_option(sph_ctx *c, const char *key, long value)
+{
+    if (strcmp(key, "pair_variant") == 0) { c->pair_variant = value; return SPH_OK; }
+    if (strcmp(key, "invalidate_nnps") == 0) { c->nnps_valid = false; return SPH_OK; }
+    sph_set_error("sph_set_option: unknown key '%s'", key);
+    return SPH_ERR_ARG;
+}
+
+int sph_timer_enable(sph_ctx *c, int on) { c->timers_on = on != 0; return SPH_OK; }
+
+static int timer_drain(sph_ctx *c)
+{
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto &t : c->timers) {
+        for (auto &pr : t.pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { t.ms += ms; t.count++; }
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        t.pending.clear();
+    }
+    return SPH_OK;
+}
+
+int sph_timer_reset(sph_ctx *c)
+{
+    SPH_TRY(timer_drain(c));
+    for (auto &t : c->timers) { t.ms = 0; t.count = 0; }
+    return SPH_OK;
+}
+
+int sph_timer_get(sph_ctx *c, const char *key, double *ms, long *count)
+{
+    static const char *names[T_COUNT] = {"nnps", "pack", "eos", "pair", "scatter"};
+    SPH_TRY(timer_drain(c));
+    for (int i = 0; i < T_COUNT; i++)
+        if (strcmp(key, names[i]) == 0) {
+            if (ms) *ms = c->timers[i].ms;
+            if (count) *count = c->timers[i].count;
+            return SPH_OK;
+        }
+    sph_set_error("sph_timer_get: unknown key '%s'", key);
+    return SPH_ERR_ARG;
+}
+
+} // extern "C"

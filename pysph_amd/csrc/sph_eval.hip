@@ -1,0 +1,893 @@
+// sph_eval.hip -- AccelerationEval.compute on the device.
+//
+// Replaces one leaf-group block of the code the reference generates from
+// pysph/sph/acceleration_eval_cython.mako:10-154 (initialize -> no-source
+// loops -> per-source [neighbours -> precomputed symbols -> Equation.loop] ->
+// post_loop), with the destination/source regrouping of MegaGroup
+// (pysph/sph/acceleration_eval.py:94-162) done here on the host.
+//
+// Design (gfx950, fp64, no MFMA -- an irregular gather, not a contraction):
+//   * every array taking part in a (dest, sources) block is gathered into
+//     cell order as packed records: posh = {x,y,z,h} (32 B) and an
+//     equation-family specific `aux` record -> all pair-loop reads are
+//     contiguous runs (a row of cells along x is one run);
+//   * one fused kernel per destination does initialize + ALL sources + post_loop
+//     with the sums held in registers and ONE write per output;
+//   * variant 1 (default) is two-phase per 64-particle wavefront: phase 1
+//     streams 64-candidate tiles through LDS and tests all of them against the
+//     wave's destinations in packed fp32 (conservative margin), recording a
+//     64-bit hit mask per lane per tile; phase 2 lets every lane walk its own
+//     hit bits (ctz) so the expensive fp64 pair arithmetic runs at
+//     ~mean/max-neighbour-count lane utilisation instead of the ~15 % hit rate;
+//     the exact fp64 criterion of the reference (r2 < (k h_i)^2 or r2 < (k h_j)^2,
+//     linked_list_nnps.pyx:176-184) decides membership in phase 2;
+//   * variant 0 is the plain per-lane 27-cell walk (kept as cross-check).
+#include "sph_internal.h"
+#include "sph_kernels.h"
+
+#include <cfloat>
+#include <cmath>
+
+// ---------------------------------------------------------------------------
+// exact (non-contracted) squared distance: must round like the reference's
+// norm2 (nnps_base.pxd:36-37) so that neighbour SETS are identical.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double r2_exact(double dx, double dy, double dz)
+{
+    return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+}
+
+// ---------------------------------------------------------------------------
+// equations without sources (elementwise)
+// ---------------------------------------------------------------------------
+struct EosArgs {
+    int kind;
+    double par[SPH_MAX_PAR];
+    double *rho, *p, *cs;
+    size_t start, stop;
+};
+
+__global__ __launch_bounds__(256) void k_nosrc(EosArgs a)
+{
+    size_t i = a.start + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.stop) return;
+    switch (a.kind) {
+    case SPH_EQ_TAIT_EOS: { // wc/basic.py:60-65
+        double rho0 = a.par[0], c0 = a.par[1], gamma = a.par[2], p0 = a.par[3];
+        double ratio = a.rho[i] * (1.0 / rho0);
+        double tmp = pow(ratio, gamma);
+        a.p[i] = p0 + (rho0 * c0 * c0 / gamma) * (tmp - 1.0);
+        a.cs[i] = c0 * pow(ratio, 0.5 * (gamma - 1.0));
+        break;
+    }
+    case SPH_EQ_TAIT_EOS_HG: { // wc/basic.py:118-126
+        double rho0 = a.par[0], c0 = a.par[1], gamma = a.par[2];
+        double r = a.rho[i];
+        if (r < rho0) { r = rho0; a.rho[i] = r; }
+        double ratio = r * (1.0 / rho0);
+        double tmp = pow(ratio, gamma);
+        a.p[i] = (rho0 * c0 * c0 / gamma) * (tmp - 1.0);
+        a.cs[i] = c0 * pow(ratio, 0.5 * (gamma - 1.0));
+        break;
+    }
+    case SPH_EQ_TVF_STATE_EQUATION: // transport_velocity.py:215-216
+        a.p[i] = a.par[0] * (a.rho[i] / a.par[1] - a.par[2]);
+        break;
+    case SPH_EQ_ISOTHERMAL_EOS: // basic_equations.py:175-176
+        a.p[i] = a.par[2] + (a.par[1] * a.par[1]) * (a.rho[i] - a.par[0]);
+        break;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// equation families
+// ---------------------------------------------------------------------------
+enum { F_CONT = 1, F_MOM = 2, F_XSPH = 4, F_TENSILE = 8,               // WCSPH
+       F_SD = 1, F_TVFSD = 2,                                           // density
+       F_TP = 1, F_TVISC = 2, F_TAV = 4, F_TAS = 8 };                   // TVF force
+
+struct KernelConst {
+    double sigma;  // kernel.fac
+    double deltap; // kernel.get_deltap()
+    int dim;
+};
+
+#define MAX_AUX 12
+struct PackArgs {
+    const uint32_t *perm;
+    size_t n;
+    size_t off;
+    const double *x, *y, *z, *h;
+    int na;                       // doubles in the aux record
+    const double *src[MAX_AUX];   // nullptr -> 0.0
+    int derived;                  // 1: aux[7] = 1/(rho*rho) with rho = aux[4]; 2: aux[10]=1/V^2 (V = aux[8])
+    double4 *posh;
+    double *aux;
+};
+
+__global__ __launch_bounds__(256) void k_pack(PackArgs a)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    uint32_t o = a.perm[i];
+    double4 ph;
+    ph.x = a.x[o]; ph.y = a.y[o]; ph.z = a.z[o]; ph.w = a.h[o];
+    a.posh[a.off + i] = ph;
+    double *dst = a.aux + (a.off + i) * (size_t)a.na;
+    double v[MAX_AUX];
+#pragma unroll
+    for (int k = 0; k < MAX_AUX; k++) v[k] = (k < a.na && a.src[k]) ? a.src[k][o] : 0.0;
+    if (a.derived == 1) v[7] = 1.0 / (v[4] * v[4]);                 // rhoj21, wc/basic.py:211
+    if (a.derived == 2) { double Vj = 1. / v[8]; v[10] = Vj * Vj; } // Vj2, transport_velocity.py:303-306
+#pragma unroll
+    for (int k = 0; k < MAX_AUX; k++) if (k < a.na) dst[k] = v[k];
+}
+
+struct SrcDesc {
+    const uint32_t *cell_start;
+    uint32_t off;    // offset of this source's segment in the packed buffers
+    uint32_t flags;  // equations acting for this (dest, source) pair
+};
+
+template <class Fam> struct PairArgs {
+    int nsrc;
+    SrcDesc src[SPH_MAX_ARRAYS];
+    const double4 *posh;
+    const double *aux;
+    uint32_t d_off, nd;
+    const uint32_t *d_keys, *d_perm;
+    uint32_t d_start, d_stop;
+    int nc[3];
+    double xmin[3];
+    double cell_size;
+    double radius_scale;
+    KernelConst k;
+    uint32_t dflags; // union of the source flags
+    double t;
+    typename Fam::Params p;
+};
+
+// per-pair geometry shared by all families
+struct PairGeom {
+    double xij[3];
+    double r2, rij, hij, h1, q, fac;
+};
+
+template <int KK> __device__ __forceinline__ void pair_geom(PairGeom &g, const double4 &pi, const double4 &pj, double r2,
+                                                            const KernelConst &k)
+{
+    g.xij[0] = pi.x - pj.x; g.xij[1] = pi.y - pj.y; g.xij[2] = pi.z - pj.z; // equation.py:205-212
+    g.r2 = r2;                           // R2IJ  :226-233
+    g.rij = sqrt(r2);                    // RIJ   :235
+    g.hij = 0.5 * (pi.w + pj.w);         // HIJ   :192
+    g.h1 = 1.0 / g.hij;
+    g.q = g.rij * g.h1;
+    g.fac = kernel_norm(k.sigma, g.h1, k.dim);
+}
+template <int KK> __device__ __forceinline__ double pair_w(const PairGeom &g) { return SphKernel<KK>::w(g.q) * g.fac; }
+// GRADIENT(XIJ, RIJ, HIJ, DWIJ): kernels.py:126-137 -> tmp with grad = tmp * xij
+template <int KK> __device__ __forceinline__ double pair_gradfac(const PairGeom &g)
+{
+    double wdash = SphKernel<KK>::dw(g.q) * g.fac;
+    return g.rij > 1e-12 ? wdash * g.h1 / g.rij : 0.0;
+}
+
+// ---- WCSPH: Continuity + Momentum + XSPH (wc/basic.py, basic_equations.py) --
+struct FamWCSPH {
+    static constexpr int NA = 8; // u v w m rho p cs rho21
+    struct Params {
+        double c0, alpha, beta, gx, gy, gz, eps;
+        double *arho, *au, *av, *aw, *ax, *ay, *az, *dt_cfl, *dt_force;
+    };
+    struct Dest {
+        double u, v, w, rho, p, cs, tmpi;
+        double arho, au, av, aw, ax, ay, az, dt_cfl;
+    };
+    static __device__ __forceinline__ void load(Dest &D, const double *a)
+    {
+        D.u = a[0]; D.v = a[1]; D.w = a[2]; D.rho = a[4]; D.p = a[5]; D.cs = a[6];
+        D.tmpi = D.p * a[7]; // tmpi = d_p*rhoi21, wc/basic.py:210,233
+        D.arho = D.au = D.av = D.aw = D.ax = D.ay = D.az = D.dt_cfl = 0.0;
+    }
+    template <int KK, class A>
+    static __device__ __forceinline__ void pair(Dest &D, const double4 &pi, const double4 &pj, double r2,
+                                                const double *__restrict__ s, uint32_t fl, const A &a)
+    {
+        PairGeom g;
+        pair_geom<KK>(g, pi, pj, r2, a.k);
+        double tg = pair_gradfac<KK>(g);
+        double dw0 = tg * g.xij[0], dw1 = tg * g.xij[1], dw2 = tg * g.xij[2];
+        double vij0 = D.u - s[0], vij1 = D.v - s[1], vij2 = D.w - s[2]; // VIJ equation.py:214-223
+        double mj = s[3];
+        if (fl & F_CONT) { // basic_equations.py:187-192
+            double vijdotdwij = dw0 * vij0 + dw1 * vij1 + dw2 * vij2;
+            D.arho += mj * vijdotdwij;
+        }
+        if (fl & (F_MOM | F_XSPH)) {
+            double rhoij1 = 1.0 / (0.5 * (D.rho + s[4])); // RHOIJ, RHOIJ1 equation.py:196-199
+            double wij = 0.0;
+            if (fl & (F_XSPH | F_TENSILE)) wij = pair_w<KK>(g);
+            if (fl & F_MOM) { // wc/basic.py:204-259
+                double vijdotxij = vij0 * g.xij[0] + vij1 * g.xij[1] + vij2 * g.xij[2];
+                double piij = 0.0;
+                if (vijdotxij < 0) {
+                    double cij = 0.5 * (D.cs + s[6]);
+                    double eps = 0.01 * g.hij * g.hij; // EPS equation.py:194
+                    double muij = (g.hij * vijdotxij) / (r2 + eps);
+                    piij = -a.p.alpha * cij * muij + a.p.beta * muij * muij;
+                    piij = piij * rhoij1;
+                }
+                if (r2 > 1e-12) {
+                    double dtc = fabs(g.hij * vijdotxij / r2) + a.p.c0;
+                    D.dt_cfl = fmax(dtc, D.dt_cfl);
+                }
+                double tmpj = s[5] * s[7];
+                double tmp = D.tmpi + tmpj;
+                if (fl & F_TENSILE) {
+                    // WDP = KERNEL(XIJ, DELTAP*HIJ, HIJ)  equation.py:243-246
+                    double qd = (a.k.deltap * g.hij) * g.h1;
+                    double wdp = SphKernel<KK>::w(qd) * g.fac;
+                    double fij = wij / wdp;
+                    fij = fij * fij;
+                    fij = fij * fij;
+                    double Ri = D.p > 0 ? 0.01 * D.tmpi : 0.2 * fabs(D.tmpi);
+                    double Rj = s[5] > 0 ? 0.01 * tmpj : 0.2 * fabs(tmpj);
+                    tmp = (D.tmpi + tmpj) + (Ri + Rj) * fij;
+                }
+                double f = -mj * (tmp + piij);
+                D.au += f * dw0;
+                D.av += f * dw1;
+                D.aw += f * dw2;
+            }
+            if (fl & F_XSPH) { // basic_equations.py:290-295
+                double tmp = -a.p.eps * mj * wij * rhoij1;
+                D.ax += tmp * vij0;
+                D.ay += tmp * vij1;
+                D.az += tmp * vij2;
+            }
+        }
+    }
+    template <class A> static __device__ __forceinline__ void finish(Dest &D, const A &a, uint32_t o)
+    {
+        if (a.dflags & F_CONT) a.p.arho[o] = D.arho;
+        if (a.dflags & F_MOM) { // post_loop wc/basic.py:261-271
+            double au = D.au + a.p.gx, av = D.av + a.p.gy, aw = D.aw + a.p.gz;
+            a.p.au[o] = au; a.p.av[o] = av; a.p.aw[o] = aw;
+            a.p.dt_cfl[o] = D.dt_cfl;
+            a.p.dt_force[o] = au * au + av * av + aw * aw;
+        }
+        if (a.dflags & F_XSPH) { // post_loop basic_equations.py:297-300
+            a.p.ax[o] = D.ax + D.u; a.p.ay[o] = D.ay + D.v; a.p.az[o] = D.az + D.w;
+        }
+    }
+};
+
+// ---- density summations (basic_equations.py:19-29, transport_velocity.py:24-58)
+struct FamDensity {
+    static constexpr int NA = 1; // m
+    struct Params { double *rho, *V; };
+    struct Dest { double m, rho, V; };
+    static __device__ __forceinline__ void load(Dest &D, const double *a) { D.m = a[0]; D.rho = 0.0; D.V = 0.0; }
+    template <int KK, class A>
+    static __device__ __forceinline__ void pair(Dest &D, const double4 &pi, const double4 &pj, double r2,
+                                                const double *__restrict__ s, uint32_t fl, const A &a)
+    {
+        PairGeom g;
+        pair_geom<KK>(g, pi, pj, r2, a.k);
+        double wij = pair_w<KK>(g);
+        if (fl & F_SD) D.rho += s[0] * wij;
+        if (fl & F_TVFSD) { D.V += wij; D.rho += D.m * wij; }
+    }
+    template <class A> static __device__ __forceinline__ void finish(Dest &D, const A &a, uint32_t o)
+    {
+        a.p.rho[o] = D.rho;
+        if (a.dflags & F_TVFSD) a.p.V[o] = D.V;
+    }
+};
+
+// ---- TVF momentum terms (transport_velocity.py:219-545) -------------------
+struct FamTVF {
+    static constexpr int NA = 12; // u v w uhat vhat what rho p V m Vj2 pad
+    struct Params {
+        double pb, gx, gy, gz, tdamp, nu, c0, alpha;
+        double *au, *av, *aw, *auhat, *avhat, *awhat;
+    };
+    struct Dest {
+        double u, v, w, uh, vh, wh, rho, p, Vi2, mi1;
+        double au, av, aw, auh, avh, awh;
+    };
+    static __device__ __forceinline__ void load(Dest &D, const double *a)
+    {
+        D.u = a[0]; D.v = a[1]; D.w = a[2]; D.uh = a[3]; D.vh = a[4]; D.wh = a[5];
+        D.rho = a[6]; D.p = a[7]; D.Vi2 = a[10]; D.mi1 = 1.0 / a[9];
+        D.au = D.av = D.aw = D.auh = D.avh = D.awh = 0.0;
+    }
+    template <int KK, class A>
+    static __device__ __forceinline__ void pair(Dest &D, const double4 &pi, const double4 &pj, double r2,
+                                                const double *__restrict__ s, uint32_t fl, const A &a)
+    {
+        PairGeom g;
+        pair_geom<KK>(g, pi, pj, r2, a.k);
+        double tg = pair_gradfac<KK>(g);
+        double dw0 = tg * g.xij[0], dw1 = tg * g.xij[1], dw2 = tg * g.xij[2];
+        double rhoj = s[6], Vj2 = s[10];
+        double vsum = D.Vi2 + Vj2;
+        double vij0 = D.u - s[0], vij1 = D.v - s[1], vij2 = D.w - s[2];
+        if (fl & F_TP) { // :290-320
+            double pij = rhoj * D.p + D.rho * s[7];
+            pij /= (rhoj + D.rho);
+            double tmp = -pij * D.mi1 * vsum;
+            D.au += tmp * dw0; D.av += tmp * dw1; D.aw += tmp * dw2;
+            tmp = -a.p.pb * D.mi1 * vsum;
+            D.auh += tmp * dw0; D.avh += tmp * dw1; D.awh += tmp * dw2;
+        }
+        if (fl & F_TAV) { // :420-436
+            double vijdotrij = vij0 * g.xij[0] + vij1 * g.xij[1] + vij2 * g.xij[2];
+            double piij = 0.0;
+            if (vijdotrij < 0) {
+                double eps = 0.01 * g.hij * g.hij;
+                double muij = (g.hij * vijdotrij) / (r2 + eps);
+                piij = -a.p.alpha * a.p.c0 * muij;
+                piij = s[9] * piij * (1.0 / (0.5 * (D.rho + rhoj)));
+            }
+            D.au += -piij * dw0; D.av += -piij * dw1; D.aw += -piij * dw2;
+        }
+        if (fl & F_TVISC) { // :363-384
+            double etai = a.p.nu * D.rho, etaj = a.p.nu * rhoj;
+            double etaij = 2 * (etai * etaj) / (etai + etaj);
+            double Fij = dw0 * g.xij[0] + dw1 * g.xij[1] + dw2 * g.xij[2];
+            double eps = 0.01 * g.hij * g.hij;
+            double tmp = D.mi1 * vsum * etaij * Fij / (r2 + eps);
+            D.au += tmp * vij0; D.av += tmp * vij1; D.aw += tmp * vij2;
+        }
+        if (fl & F_TAS) { // :473-545
+            double ui = D.u, vi = D.v, wi = D.w, uj = s[0], vj = s[1], wj = s[2];
+            double du_i = D.uh - ui, dv_i = D.vh - vi, dw_i = D.wh - wi;
+            double du_j = s[3] - uj, dv_j = s[4] - vj, dw_j = s[5] - wj;
+            double ri = D.rho, rj = rhoj;
+            double Ax = 0.5 * ((ri * ui * du_i + rj * uj * du_j) * dw0 + (ri * ui * dv_i + rj * uj * dv_j) * dw1 +
+                               (ri * ui * dw_i + rj * uj * dw_j) * dw2);
+            double Ay = 0.5 * ((ri * vi * du_i + rj * vj * du_j) * dw0 + (ri * vi * dv_i + rj * vj * dv_j) * dw1 +
+                               (ri * vi * dw_i + rj * vj * dw_j) * dw2);
+            double Az = 0.5 * ((ri * wi * du_i + rj * wj * du_j) * dw0 + (ri * wi * dv_i + rj * wj * dv_j) * dw1 +
+                               (ri * wi * dw_i + rj * wj * dw_j) * dw2);
+            double tmp = D.mi1 * vsum;
+            D.au += tmp * Ax; D.av += tmp * Ay; D.aw += tmp * Az;
+        }
+    }
+    template <class A> static __device__ __forceinline__ void finish(Dest &D, const A &a, uint32_t o)
+    {
+        double damp = 1.0; // post_loop :322-325
+        if (a.t < a.p.tdamp) damp = 0.5 * (sin((-0.5 + a.t / a.p.tdamp) * M_PI) + 1.0);
+        double gx = (a.dflags & F_TP) ? a.p.gx * damp : 0.0;
+        double gy = (a.dflags & F_TP) ? a.p.gy * damp : 0.0;
+        double gz = (a.dflags & F_TP) ? a.p.gz * damp : 0.0;
+        a.p.au[o] = D.au + gx; a.p.av[o] = D.av + gy; a.p.aw[o] = D.aw + gz;
+        if (a.dflags & F_TP) { a.p.auhat[o] = D.auh; a.p.avhat[o] = D.avh; a.p.awhat[o] = D.awh; }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// variant 0: per-lane walk over the 3x3 rows of cells (x-contiguous ranges)
+// ---------------------------------------------------------------------------
+template <class Fam, int KK> __global__ __launch_bounds__(256) void k_pair_direct(PairArgs<Fam> a)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.nd) return;
+    uint32_t o = a.d_perm[i];
+    if (o < a.d_start || o >= a.d_stop) return;
+    double4 pi = a.posh[a.d_off + i];
+    typename Fam::Dest D;
+    Fam::load(D, a.aux + (size_t)(a.d_off + i) * Fam::NA);
+    uint32_t key = a.d_keys[i];
+    int cx = key % a.nc[0];
+    int t = key / a.nc[0];
+    int cy = t % a.nc[1], cz = t / a.nc[1];
+    double hi2 = a.radius_scale * pi.w;
+    hi2 *= hi2;
+    for (int s = 0; s < a.nsrc; s++) {
+        const SrcDesc sd = a.src[s];
+        for (int oz = -1; oz <= 1; oz++)
+            for (int oy = -1; oy <= 1; oy++) {
+                int yy = cy + oy, zz = cz + oz;
+                if (yy < 0 || yy >= a.nc[1] || zz < 0 || zz >= a.nc[2]) continue;
+                int xa = max(cx - 1, 0), xb = min(cx + 1, a.nc[0] - 1);
+                uint32_t row = (uint32_t)(a.nc[0] * (yy + a.nc[1] * zz));
+                uint32_t j0 = sd.cell_start[row + xa], j1 = sd.cell_start[row + xb + 1];
+                for (uint32_t j = j0; j < j1; j++) {
+                    double4 pj = a.posh[sd.off + j];
+                    double hj2 = a.radius_scale * pj.w;
+                    hj2 *= hj2;
+                    double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+                    if ((r2 < hi2) || (r2 < hj2))
+                        Fam::template pair<KK>(D, pi, pj, r2, a.aux + (size_t)(sd.off + j) * Fam::NA, sd.flags, a);
+                }
+            }
+    }
+    Fam::finish(D, a, o);
+}
+
+// ---------------------------------------------------------------------------
+// variant 1: one wavefront = 64 consecutive (cell-ordered) destinations;
+// LDS candidate tiles + fp32 prefilter + per-lane hit bitmasks + fp64 pair phase
+// ---------------------------------------------------------------------------
+#define TILE 64
+#define MAXCH 18
+
+template <class Fam, int KK> __global__ __launch_bounds__(64) void k_pair_tiled(PairArgs<Fam> a)
+{
+    __shared__ float4 tile[TILE];
+    __shared__ unsigned long long masks[MAXCH][64];
+    __shared__ uint32_t chbase[MAXCH];
+    __shared__ uint32_t chflags[MAXCH];
+
+    const int lane = threadIdx.x;
+    const uint32_t i = blockIdx.x * 64 + lane;
+    const bool valid = i < a.nd;
+    const uint32_t ic = valid ? i : a.nd - 1;
+    const uint32_t o = a.d_perm[ic];
+    const bool active = valid && o >= a.d_start && o < a.d_stop;
+    const double4 pi = a.posh[a.d_off + ic];
+    typename Fam::Dest D;
+    Fam::load(D, a.aux + (size_t)(a.d_off + ic) * Fam::NA);
+    const uint32_t key = a.d_keys[ic];
+    const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
+    const int cx = key % ncx;
+    const int row = key / ncx;
+    double hi2 = a.radius_scale * pi.w;
+    hi2 *= hi2;
+    const double hi_r = a.radius_scale * pi.w;
+
+    const int row_first = __builtin_amdgcn_readfirstlane(row);
+    const int row_last = __builtin_amdgcn_readlane(row, 63);
+    int nch = 0;
+
+    auto phase2 = [&]() {
+        int c = 0;
+        unsigned long long m = nch > 0 ? masks[0][lane] : 0ull;
+        for (;;) {
+            while (m == 0 && c + 1 < nch) { ++c; m = masks[c][lane]; }
+            bool has = m != 0;
+            if (!__any(has)) break;
+            if (has) {
+                int kbit = __builtin_ctzll(m);
+                m &= m - 1;
+                uint32_t jg = chbase[c] + kbit;
+                double4 pj = a.posh[jg];
+                double hj2 = a.radius_scale * pj.w;
+                hj2 *= hj2;
+                double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+                if ((r2 < hi2) || (r2 < hj2))
+                    Fam::template pair<KK>(D, pi, pj, r2, a.aux + (size_t)jg * Fam::NA, chflags[c], a);
+            }
+        }
+        nch = 0;
+        __syncthreads();
+    };
+
+    for (int R = row_first; R <= row_last; R++) {
+        const bool inseg = active && row == R;
+        const unsigned long long segm = __ballot(inseg);
+        if (segm == 0) continue;
+        const int fl = __builtin_ctzll(segm), ll = 63 - __builtin_clzll(segm);
+        const int cxa = __builtin_amdgcn_readlane(cx, fl), cxb = __builtin_amdgcn_readlane(cx, ll);
+        const int cyR = R % ncy, czR = R / ncy;
+        const int xa = max(cxa - 1, 0), xb = min(cxb + 1, ncx - 1);
+        // local origin of this segment; fp32 coordinates are relative to it
+        const double ox = a.xmin[0] + a.cell_size * xa;
+        const double oy = a.xmin[1] + a.cell_size * (cyR - 1);
+        const double oz = a.xmin[2] + a.cell_size * (czR - 1);
+        // conservative slack for the fp32 test: coordinates up to L from the
+        // origin carry <= 2^-23 L rounding each; three axes, two operands.
+        const double L = a.cell_size * (double)max(xb - xa + 2, 4);
+        const float slack = (float)(L * 1.5e-6);
+        const float fx = (float)(pi.x - ox), fy = (float)(pi.y - oy), fz = (float)(pi.z - oz);
+        float hif = (float)hi_r * 1.000001f + slack;
+        const float hi2f = hif * hif;
+
+        for (int s = 0; s < a.nsrc; s++) {
+            const SrcDesc sd = a.src[s];
+            for (int dz = -1; dz <= 1; dz++)
+                for (int dy = -1; dy <= 1; dy++) {
+                    const int yy = cyR + dy, zz = czR + dz;
+                    if (yy < 0 || yy >= ncy || zz < 0 || zz >= ncz) continue;
+                    const uint32_t rowb = (uint32_t)(ncx * (yy + ncy * zz));
+                    const uint32_t j0 = sd.cell_start[rowb + xa], j1 = sd.cell_start[rowb + xb + 1];
+                    for (uint32_t jb = j0; jb < j1; jb += TILE) {
+                        const uint32_t j = jb + lane;
+                        float4 tj = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.f);
+                        if (j < j1) {
+                            const double4 pj = a.posh[sd.off + j];
+                            float hjf = (float)(a.radius_scale * pj.w) * 1.000001f + slack;
+                            tj = make_float4((float)(pj.x - ox), (float)(pj.y - oy), (float)(pj.z - oz), hjf * hjf);
+                        }
+                        tile[lane] = tj;
+                        __syncthreads();
+                        unsigned long long m = 0;
+                        if (inseg) {
+                            const int cnt = min((int)(j1 - jb), TILE);
+                            const int cnt8 = (cnt + 7) & ~7;
+                            for (int k0 = 0; k0 < cnt8; k0 += 8) {
+                                unsigned mm = 0;
+#pragma unroll
+                                for (int k = 0; k < 8; k++) {
+                                    const float4 tk = tile[k0 + k];
+                                    const float ex = fx - tk.x, ey = fy - tk.y, ez = fz - tk.z;
+                                    const float r2 = ex * ex + ey * ey + ez * ez;
+                                    const bool hit = (r2 < hi2f) | (r2 < tk.w);
+                                    mm |= hit ? (1u << k) : 0u;
+                                }
+                                m |= (unsigned long long)mm << k0;
+                            }
+                        }
+                        masks[nch][lane] = m;
+                        if (lane == 0) { chbase[nch] = sd.off + jb; chflags[nch] = sd.flags; }
+                        nch++;
+                        __syncthreads();
+                        if (nch == MAXCH) phase2();
+                    }
+                }
+        }
+    }
+    phase2();
+    if (active) Fam::finish(D, a, o);
+}
+
+// ---------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------
+static bool is_nosrc_kind(int k)
+{
+    return k == SPH_EQ_TAIT_EOS || k == SPH_EQ_TAIT_EOS_HG || k == SPH_EQ_TVF_STATE_EQUATION ||
+           k == SPH_EQ_ISOTHERMAL_EOS;
+}
+
+static int need_prop(sph_ctx *c, int id, int prop, const char *who)
+{
+    if (!c->arr[id].prop[prop]) {
+        sph_set_error("%s: array %d has no device copy of a required property (id %d); push it first", who, id, prop);
+        return SPH_ERR_MISSING_PROP;
+    }
+    return SPH_OK;
+}
+
+static int run_nosrc(sph_ctx *c, const sph_equation &e, size_t start, size_t stop)
+{
+    if (stop <= start) return SPH_OK;
+    DevArray &A = c->arr[e.dest];
+    EosArgs a;
+    a.kind = e.kind;
+    memcpy(a.par, e.par, sizeof a.par);
+    SPH_TRY(need_prop(c, e.dest, SPH_RHO, "EOS"));
+    SPH_TRY(sph_array_ensure_prop(c, e.dest, SPH_P));
+    a.rho = A.prop[SPH_RHO];
+    a.p = A.prop[SPH_P];
+    a.cs = nullptr;
+    if (e.kind == SPH_EQ_TAIT_EOS || e.kind == SPH_EQ_TAIT_EOS_HG) {
+        SPH_TRY(sph_array_ensure_prop(c, e.dest, SPH_CS));
+        a.cs = A.prop[SPH_CS];
+    }
+    a.start = start;
+    a.stop = stop;
+    ScopedTimer tm(c, T_EOS);
+    hipLaunchKernelGGL(k_nosrc, dim3(div_up(stop - start, 256)), dim3(256), 0, c->stream, a);
+    return SPH_OK;
+}
+
+enum Family { FAM_NONE, FAM_WCSPH, FAM_DENSITY, FAM_TVF };
+
+static int eq_family(int kind, uint32_t *flag)
+{
+    switch (kind) {
+    case SPH_EQ_CONTINUITY: *flag = F_CONT; return FAM_WCSPH;
+    case SPH_EQ_MOMENTUM: *flag = F_MOM; return FAM_WCSPH;
+    case SPH_EQ_XSPH: *flag = F_XSPH; return FAM_WCSPH;
+    case SPH_EQ_SUMMATION_DENSITY: *flag = F_SD; return FAM_DENSITY;
+    case SPH_EQ_TVF_SUMMATION_DENSITY: *flag = F_TVFSD; return FAM_DENSITY;
+    case SPH_EQ_TVF_MOM_PRESSURE: *flag = F_TP; return FAM_TVF;
+    case SPH_EQ_TVF_MOM_VISCOSITY: *flag = F_TVISC; return FAM_TVF;
+    case SPH_EQ_TVF_MOM_ART_VISCOSITY: *flag = F_TAV; return FAM_TVF;
+    case SPH_EQ_TVF_MOM_ART_STRESS: *flag = F_TAS; return FAM_TVF;
+    default: return FAM_NONE;
+    }
+}
+
+struct PackPlan {
+    int na;
+    int props[MAX_AUX]; // sph_prop or -1
+    int derived;
+};
+
+static PackPlan pack_plan(int fam)
+{
+    PackPlan p;
+    for (auto &v : p.props) v = -1;
+    p.derived = 0;
+    if (fam == FAM_WCSPH) {
+        p.na = 8;
+        int pr[8] = {SPH_U, SPH_V, SPH_W, SPH_M, SPH_RHO, SPH_P, SPH_CS, -1};
+        for (int k = 0; k < 8; k++) p.props[k] = pr[k];
+        p.derived = 1;
+    } else if (fam == FAM_DENSITY) {
+        p.na = 1;
+        p.props[0] = SPH_M;
+    } else {
+        p.na = 12;
+        int pr[12] = {SPH_U, SPH_V, SPH_W, SPH_UHAT, SPH_VHAT, SPH_WHAT, SPH_RHO, SPH_P, SPH_VOL, SPH_M, -1, -1};
+        for (int k = 0; k < 12; k++) p.props[k] = pr[k];
+        p.derived = 2;
+    }
+    return p;
+}
+
+// which aux slots a family really needs given the union of flags (others may be absent -> 0)
+static bool slot_required(int fam, uint32_t flags, int prop)
+{
+    if (fam == FAM_WCSPH) {
+        if (prop == SPH_M || prop == SPH_U || prop == SPH_V || prop == SPH_W) return true;
+        if (prop == SPH_RHO) return flags & (F_MOM | F_XSPH);
+        if (prop == SPH_P || prop == SPH_CS) return flags & F_MOM;
+        return false;
+    }
+    if (fam == FAM_DENSITY) return prop == SPH_M;
+    if (fam == FAM_TVF) {
+        if (prop == SPH_UHAT || prop == SPH_VHAT || prop == SPH_WHAT) return flags & F_TAS;
+        return true;
+    }
+    return false;
+}
+
+static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fam, uint32_t flags)
+{
+    DevArray &A = c->arr[id];
+    if (A.n == 0) return SPH_OK;
+    PackArgs pa;
+    pa.perm = A.perm.as<uint32_t>();
+    pa.n = A.n;
+    pa.off = off;
+    pa.x = A.prop[SPH_X]; pa.y = A.prop[SPH_Y]; pa.z = A.prop[SPH_Z]; pa.h = A.prop[SPH_H];
+    pa.na = pl.na;
+    for (int k = 0; k < MAX_AUX; k++) {
+        pa.src[k] = nullptr;
+        if (k < pl.na && pl.props[k] >= 0) {
+            pa.src[k] = A.prop[pl.props[k]];
+            if (!pa.src[k] && slot_required(fam, flags, pl.props[k])) return need_prop(c, id, pl.props[k], "pair loop");
+        }
+    }
+    pa.derived = pl.derived;
+    pa.posh = c->posh.as<double4>();
+    pa.aux = c->aux.as<double>();
+    hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, pa);
+    return SPH_OK;
+}
+
+template <class Fam> static void launch_pair(sph_ctx *c, int kk, const PairArgs<Fam> &a)
+{
+    if (a.nd == 0) return;
+    const bool tiled = c->pair_variant != 0;
+    dim3 gt(div_up(a.nd, 64)), bt(64), gd(div_up(a.nd, 256)), bd(256);
+#define LAUNCH(K)                                                                        \
+    if (tiled) hipLaunchKernelGGL((k_pair_tiled<Fam, K>), gt, bt, 0, c->stream, a);    \
+    else hipLaunchKernelGGL((k_pair_direct<Fam, K>), gd, bd, 0, c->stream, a)
+    switch (kk) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 3: LAUNCH(3); break;
+    case 4: LAUNCH(4); break;
+    }
+#undef LAUNCH
+}
+
+template <class Fam>
+static void fill_common(sph_ctx *c, PairArgs<Fam> &a, const sph_kernel *K, double t)
+{
+    a.posh = c->posh.as<double4>();
+    a.aux = c->aux.as<double>();
+    for (int k = 0; k < 3; k++) { a.nc[k] = c->nc[k]; a.xmin[k] = c->xmin[k]; }
+    a.cell_size = c->cell_size;
+    a.radius_scale = c->radius_scale;
+    a.k.sigma = K->fac;
+    a.k.deltap = K->deltap;
+    a.k.dim = K->dim;
+    a.t = t;
+}
+
+static int ensure_out(sph_ctx *c, int id, std::initializer_list<int> props)
+{
+    for (int p : props) SPH_TRY(sph_array_ensure_prop(c, id, p));
+    return SPH_OK;
+}
+
+extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *g, double t, double dt)
+{
+    (void)dt;
+    if (!c || !K || !g) { sph_set_error("sph_eval_group: NULL argument"); return SPH_ERR_ARG; }
+    if (g->neq > SPH_MAX_EQS) { sph_set_error("sph_eval_group: too many equations"); return SPH_ERR_ARG; }
+    if (K->kind < 1 || K->kind > 4) { sph_set_error("sph_eval_group: unknown kernel kind %d", K->kind); return SPH_ERR_UNSUPPORTED; }
+    HIP_TRY(hipSetDevice(c->device));
+
+    // destinations in first-appearance order (acceleration_eval.py:126-131)
+    int dests[SPH_MAX_ARRAYS], ndest = 0;
+    for (int i = 0; i < g->neq; i++) {
+        int d = g->eqs[i].dest;
+        if (d < 0 || d >= SPH_MAX_ARRAYS || !c->arr[d].used) { sph_set_error("equation %d: bad dest array %d", i, d); return SPH_ERR_ARG; }
+        bool seen = false;
+        for (int j = 0; j < ndest; j++) seen |= dests[j] == d;
+        if (!seen) dests[ndest++] = d;
+    }
+    for (int di = 0; di < ndest; di++) {
+        const int dst = dests[di];
+        DevArray &D = c->arr[dst];
+        // NP_DEST / D_START_IDX (acceleration_eval_cython_helper.py:259-280)
+        size_t start = g->start_idx > 0 ? (size_t)g->start_idx : 0;
+        size_t stop = g->stop_idx >= 0 ? (size_t)g->stop_idx : (g->real ? D.n_real : D.n);
+        if (stop > D.n) stop = D.n;
+
+        // 1. equations without sources run first (mako :50-58)
+        for (int i = 0; i < g->neq; i++) {
+            const sph_equation &e = g->eqs[i];
+            if (e.dest != dst || e.nsrc != 0) continue;
+            if (!is_nosrc_kind(e.kind)) { sph_set_error("equation kind %d needs sources", e.kind); return SPH_ERR_UNSUPPORTED; }
+            SPH_TRY(run_nosrc(c, e, start, stop));
+        }
+
+        // 2. sources in first-appearance order with their equation flags (acceleration_eval.py:136-151)
+        int srcs[SPH_MAX_ARRAYS], nsrcs = 0;
+        uint32_t sflags[SPH_MAX_ARRAYS] = {};
+        int fam = FAM_NONE;
+        const sph_equation *eq_of[16] = {};
+        for (int i = 0; i < g->neq; i++) {
+            const sph_equation &e = g->eqs[i];
+            if (e.dest != dst || e.nsrc == 0) continue;
+            uint32_t flag = 0;
+            int f = eq_family(e.kind, &flag);
+            if (f == FAM_NONE) { sph_set_error("equation kind %d has no hand-written pair kernel", e.kind); return SPH_ERR_UNSUPPORTED; }
+            if (fam != FAM_NONE && f != fam) {
+                sph_set_error("group mixes equation families on destination %d (kinds are fused per family)", dst);
+                return SPH_ERR_UNSUPPORTED;
+            }
+            fam = f;
+            if (eq_of[e.kind]) {
+                sph_set_error("equation kind %d appears twice for destination %d in one group", e.kind, dst);
+                return SPH_ERR_UNSUPPORTED;
+            }
+            eq_of[e.kind] = &e;
+            for (int k = 0; k < e.nsrc; k++) {
+                int s = e.src[k], pos = -1;
+                if (s < 0 || s >= SPH_MAX_ARRAYS || !c->arr[s].used) { sph_set_error("bad source array %d", s); return SPH_ERR_ARG; }
+                for (int j = 0; j < nsrcs; j++) if (srcs[j] == s) pos = j;
+                if (pos < 0) { pos = nsrcs; srcs[nsrcs++] = s; }
+                sflags[pos] |= flag;
+            }
+        }
+        if (fam == FAM_NONE) continue;
+        if (!c->nnps_valid) { sph_set_error("sph_eval_group: neighbour grid is stale; call sph_nnps_update"); return SPH_ERR_STATE; }
+        if (D.nnps_slot < 0) { sph_set_error("destination array %d is not part of the neighbour grid", dst); return SPH_ERR_STATE; }
+        uint32_t dflags = 0;
+        for (int j = 0; j < nsrcs; j++) {
+            dflags |= sflags[j];
+            if (c->arr[srcs[j]].nnps_slot < 0) { sph_set_error("source array %d is not part of the neighbour grid", srcs[j]); return SPH_ERR_STATE; }
+        }
+        if (fam == FAM_WCSPH && eq_of[SPH_EQ_MOMENTUM] && eq_of[SPH_EQ_MOMENTUM]->par[6] != 0.0) {
+            dflags |= F_TENSILE;
+            for (int j = 0; j < nsrcs; j++) if (sflags[j] & F_MOM) sflags[j] |= F_TENSILE;
+        }
+
+        // 3. pack destination + sources into cell order
+        size_t total = 0, off_of[SPH_MAX_ARRAYS];
+        bool dest_is_src = false;
+        for (int j = 0; j < nsrcs; j++) { off_of[j] = total; total += c->arr[srcs[j]].n; dest_is_src |= srcs[j] == dst; }
+        size_t d_off = total;
+        if (!dest_is_src) total += D.n;
+        else for (int j = 0; j < nsrcs; j++) if (srcs[j] == dst) d_off = off_of[j];
+        if (total >= (1ull << 32)) { sph_set_error("too many particles for 32-bit packed indices"); return SPH_ERR_ARG; }
+        PackPlan pl = pack_plan(fam);
+        SPH_TRY(c->posh.reserve((total + 64) * sizeof(double4)));
+        SPH_TRY(c->aux.reserve((total + 64) * sizeof(double) * pl.na));
+        {
+            ScopedTimer tm(c, T_PACK);
+            for (int j = 0; j < nsrcs; j++) SPH_TRY(pack_array(c, srcs[j], off_of[j], pl, fam, dflags));
+            if (!dest_is_src) SPH_TRY(pack_array(c, dst, d_off, pl, fam, dflags));
+        }
+
+        // 4. fused pair kernel
+        ScopedTimer tm(c, T_PAIR);
+        if (fam == FAM_WCSPH) {
+            PairArgs<FamWCSPH> a;
+            memset(&a, 0, sizeof a);
+            fill_common(c, a, K, t);
+            const sph_equation *me = eq_of[SPH_EQ_MOMENTUM], *xe = eq_of[SPH_EQ_XSPH];
+            if (me) { a.p.c0 = me->par[0]; a.p.alpha = me->par[1]; a.p.beta = me->par[2]; a.p.gx = me->par[3]; a.p.gy = me->par[4]; a.p.gz = me->par[5]; }
+            if (xe) a.p.eps = xe->par[0];
+            if (dflags & F_CONT) { SPH_TRY(ensure_out(c, dst, {SPH_ARHO})); a.p.arho = D.prop[SPH_ARHO]; }
+            if (dflags & F_MOM) {
+                SPH_TRY(ensure_out(c, dst, {SPH_AU, SPH_AV, SPH_AW, SPH_DT_CFL, SPH_DT_FORCE}));
+                a.p.au = D.prop[SPH_AU]; a.p.av = D.prop[SPH_AV]; a.p.aw = D.prop[SPH_AW];
+                a.p.dt_cfl = D.prop[SPH_DT_CFL]; a.p.dt_force = D.prop[SPH_DT_FORCE];
+            }
+            if (dflags & F_XSPH) {
+                SPH_TRY(ensure_out(c, dst, {SPH_AX, SPH_AY, SPH_AZ}));
+                a.p.ax = D.prop[SPH_AX]; a.p.ay = D.prop[SPH_AY]; a.p.az = D.prop[SPH_AZ];
+            }
+            a.nsrc = nsrcs;
+            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j]};
+            a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
+            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
+            a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
+            launch_pair<FamWCSPH>(c, K->kind, a);
+        } else if (fam == FAM_DENSITY) {
+            PairArgs<FamDensity> a;
+            memset(&a, 0, sizeof a);
+            fill_common(c, a, K, t);
+            SPH_TRY(ensure_out(c, dst, {SPH_RHO}));
+            a.p.rho = D.prop[SPH_RHO];
+            if (dflags & F_TVFSD) { SPH_TRY(ensure_out(c, dst, {SPH_VOL})); a.p.V = D.prop[SPH_VOL]; }
+            if ((dflags & F_SD) && (dflags & F_TVFSD)) { sph_set_error("both SummationDensity flavours on one destination"); return SPH_ERR_UNSUPPORTED; }
+            a.nsrc = nsrcs;
+            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j]};
+            a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
+            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
+            a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
+            launch_pair<FamDensity>(c, K->kind, a);
+        } else {
+            PairArgs<FamTVF> a;
+            memset(&a, 0, sizeof a);
+            fill_common(c, a, K, t);
+            const sph_equation *pe = eq_of[SPH_EQ_TVF_MOM_PRESSURE], *ve = eq_of[SPH_EQ_TVF_MOM_VISCOSITY],
+                               *ae = eq_of[SPH_EQ_TVF_MOM_ART_VISCOSITY];
+            if (pe) { a.p.pb = pe->par[0]; a.p.gx = pe->par[1]; a.p.gy = pe->par[2]; a.p.gz = pe->par[3]; a.p.tdamp = pe->par[4]; }
+            if (ve) a.p.nu = ve->par[0];
+            if (ae) { a.p.c0 = ae->par[0]; a.p.alpha = ae->par[1]; }
+            SPH_TRY(ensure_out(c, dst, {SPH_AU, SPH_AV, SPH_AW}));
+            a.p.au = D.prop[SPH_AU]; a.p.av = D.prop[SPH_AV]; a.p.aw = D.prop[SPH_AW];
+            if (dflags & F_TP) {
+                SPH_TRY(ensure_out(c, dst, {SPH_AUHAT, SPH_AVHAT, SPH_AWHAT}));
+                a.p.auhat = D.prop[SPH_AUHAT]; a.p.avhat = D.prop[SPH_AVHAT]; a.p.awhat = D.prop[SPH_AWHAT];
+            }
+            a.nsrc = nsrcs;
+            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j]};
+            a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
+            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
+            a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
+            launch_pair<FamTVF>(c, K->kind, a);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return SPH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// max reduction (adaptive time step inputs: integrator.py:161-200)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_max(const double *__restrict__ v, size_t n, double *__restrict__ part)
+{
+    double m = -DBL_MAX;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        m = fmax(m, v[i]);
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+    __shared__ double s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmax(fmax(s[0], s[1]), fmax(s[2], s[3]));
+}
+
+extern "C" int sph_reduce_max(sph_ctx *c, int id, int prop, double *out)
+{
+    if (id < 0 || id >= SPH_MAX_ARRAYS || prop < 0 || prop >= SPH_PROP_COUNT || !c->arr[id].prop[prop]) {
+        sph_set_error("sph_reduce_max: array %d has no device property %d", id, prop);
+        return SPH_ERR_MISSING_PROP;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    DevArray &A = c->arr[id];
+    size_t n = A.n_real;
+    if (n == 0) { *out = -DBL_MAX; return SPH_OK; }
+    int nb = (int)std::min<size_t>(512, (n + 255) / 256);
+    SPH_TRY(c->red_part.reserve(1024 * sizeof(double)));
+    hipLaunchKernelGGL(k_max, dim3(nb), dim3(256), 0, c->stream, A.prop[prop], n, c->red_part.as<double>());
+    hipLaunchKernelGGL(k_max, dim3(1), dim3(256), 0, c->stream, c->red_part.as<double>(), (size_t)nb,
+                       c->red_part.as<double>() + 512);
+    HIP_TRY(hipMemcpyAsync(c->pinned, c->red_part.as<double>() + 512, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = c->pinned[0];
+    return SPH_OK;
+}

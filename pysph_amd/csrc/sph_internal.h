@@ -1,0 +1,104 @@
+// sph_internal.h -- private declarations shared by the libsphhip translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sphhip.h"
+
+void sph_set_error(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                              \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) {                                                    \
+            sph_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr,             \
+                          hipGetErrorString(_e));                                  \
+            return SPH_ERR_HIP;                                                    \
+        }                                                                          \
+    } while (0)
+
+#define SPH_TRY(expr)                \
+    do {                             \
+        int _rc = (expr);            \
+        if (_rc != SPH_OK) return _rc; \
+    } while (0)
+
+// A growable device buffer.
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t need, bool keep = false, hipStream_t stream = nullptr);
+    void release();
+    template <class T> T *as() const { return static_cast<T *>(ptr); }
+};
+
+// Device mirror of one host ParticleArray + its cell-list state.
+struct DevArray {
+    bool used = false;
+    size_t n = 0, n_real = 0, cap = 0;
+    double *prop[SPH_PROP_COUNT] = {};
+    // neighbour-search state (valid after sph_nnps_update)
+    DevBuf keys, keys_sorted, idx, perm; // uint32 each; perm: sorted position -> original index
+    DevBuf cell_start;                   // uint32[n_cells + 1]
+    int nnps_slot = -1;                  // position in the last sph_nnps_update list
+};
+
+enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_SCATTER, T_COUNT };
+
+struct Timer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double ms = 0;
+    long count = 0;
+};
+
+struct sph_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DevArray arr[SPH_MAX_ARRAYS];
+
+    // grid of the last sph_nnps_update
+    bool nnps_valid = false;
+    int dim = 3;
+    int narrays = 0;
+    int ids[SPH_MAX_ARRAYS] = {};
+    double radius_scale = 2.0, cell_size = 0, hmin = 0;
+    double xmin[3] = {}, xmax[3] = {};
+    int nc[3] = {1, 1, 1};
+    long n_cells = 0;
+    bool uniform_h = false; // hmin == hmax over all arrays
+    double h_uniform = 0;
+
+    // scratch
+    DevBuf cub_tmp, red_part, red_out, posh, aux, dkeys, dperm, tmp_u32a, tmp_u32b;
+    double *pinned = nullptr; // small pinned host buffer (64 doubles)
+
+    // options
+    long pair_variant = 1;
+    long block_sorted_outputs = 0;
+
+    // timers
+    bool timers_on = false;
+    Timer timers[T_COUNT];
+};
+
+struct ScopedTimer {
+    sph_ctx *c;
+    int key;
+    hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(sph_ctx *ctx, int k);
+    ~ScopedTimer();
+};
+
+// nnps.hip
+int nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *out8);
+
+// eval.hip helpers
+static inline unsigned div_up(size_t a, unsigned b) { return (unsigned)((a + b - 1) / b); }

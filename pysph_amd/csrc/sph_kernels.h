@@ -1,0 +1,81 @@
+// sph_kernels.h -- SPH smoothing kernels as device functions.
+//
+// Hand-written equivalents of the kernel classes in pysph/base/kernels.py
+// (CubicSpline :29-163, WendlandQuintic :274-380, QuinticSpline :1050-1210,
+// Gaussian :830-930).  The polynomial forms and branch conditions are the
+// reference's; what changes is that h1 = 1/h, q and the normalisation
+// fac = sigma * h1^dim are computed ONCE per pair and shared by W, dW/dq and
+// the gradient (the reference recomputes them in every method).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+template <int KIND> struct SphKernel;
+
+// kernels.py:73-79: fac = self.fac*h1 | *h1*h1 | *h1*h1*h1
+template <class R> __device__ __forceinline__ R kernel_norm(R sigma, R h1, int dim)
+{
+    R f = sigma * h1;
+    if (dim > 1) f *= h1;
+    if (dim > 2) f *= h1;
+    return f;
+}
+
+template <> struct SphKernel<1> { // CubicSpline
+    template <class R> static __device__ __forceinline__ R w(R q)
+    {
+        R t2 = R(2) - q;
+        R a = R(0.25) * t2 * t2 * t2;
+        R b = R(1) - R(1.5) * q * q * (R(1) - R(0.5) * q);
+        return q > R(2) ? R(0) : (q > R(1) ? a : b);
+    }
+    template <class R> static __device__ __forceinline__ R dw(R q)
+    {
+        R t2 = R(2) - q;
+        R a = R(-0.75) * t2 * t2;
+        R b = R(-3) * q * (R(1) - R(0.75) * q);
+        return q > R(2) ? R(0) : (q > R(1) ? a : b);
+    }
+};
+
+template <> struct SphKernel<2> { // WendlandQuintic
+    template <class R> static __device__ __forceinline__ R w(R q)
+    {
+        R t = R(1) - R(0.5) * q;
+        R v = t * t * t * t * (R(2) * q + R(1));
+        return q < R(2) ? v : R(0);
+    }
+    template <class R> static __device__ __forceinline__ R dw(R q)
+    {
+        R t = R(1) - R(0.5) * q;
+        R v = R(-5) * q * t * t * t;
+        return q < R(2) ? v : R(0);
+    }
+};
+
+template <> struct SphKernel<3> { // QuinticSpline
+    template <class R> static __device__ __forceinline__ R w(R q)
+    {
+        R t3 = R(3) - q, t2 = R(2) - q, t1 = R(1) - q;
+        R v = t3 * t3 * t3 * t3 * t3;
+        if (q <= R(2)) v -= R(6) * t2 * t2 * t2 * t2 * t2;
+        if (q <= R(1)) v += R(15) * t1 * t1 * t1 * t1 * t1;
+        return q > R(3) ? R(0) : v;
+    }
+    template <class R> static __device__ __forceinline__ R dw(R q)
+    {
+        R t3 = R(3) - q, t2 = R(2) - q, t1 = R(1) - q;
+        R v = R(-5) * t3 * t3 * t3 * t3;
+        if (q <= R(2)) v += R(30) * t2 * t2 * t2 * t2;
+        if (q <= R(1)) v -= R(75) * t1 * t1 * t1 * t1;
+        return q > R(3) ? R(0) : v;
+    }
+};
+
+template <> struct SphKernel<4> { // Gaussian
+    template <class R> static __device__ __forceinline__ R w(R q) { return q < R(3) ? exp(-q * q) : R(0); }
+    template <class R> static __device__ __forceinline__ R dw(R q)
+    {
+        return q < R(3) ? R(-2) * q * exp(-q * q) : R(0);
+    }
+};

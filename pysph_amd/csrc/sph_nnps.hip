@@ -1,0 +1,412 @@
+// sph_nnps.hip -- cell-list neighbour search on the device.
+//
+// Reference behaviour being replaced (pypr/pysph):
+//   DomainManager._compute_cell_size_for_binning  pysph/base/nnps_base.pyx:942-978
+//   NNPS.update / _compute_bounds                  pysph/base/nnps_base.pyx:1471-1575
+//   LinkedListNNPS._get_number_of_cells/_refresh   pysph/base/linked_list_nnps.pyx:293-383
+//   LinkedListNNPS._bin (serial push-front list)   pysph/base/linked_list_nnps.pyx:235-286
+//
+// MI355X design: instead of head/next linked lists (pointer chasing, serial
+// build) every array is radix-sorted by flattened cell id; a cell is then the
+// contiguous range [cell_start[c], cell_start[c+1]) of the sorted order, and a
+// row of cells along x is one contiguous range -- what the pair kernels stream.
+// The grid itself (bounds, 1 % padding, cell size, cells per dimension, error
+// conditions) is computed on the host in the reference's exact arithmetic.
+#include "sph_internal.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+// ---------------------------------------------------------------------------
+// min/max of x, y, z, h
+// ---------------------------------------------------------------------------
+__device__ inline double wave_min(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ inline double wave_max(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// part[block][8] = {xmin ymin zmin hmin xmax ymax zmax hmax}
+__global__ __launch_bounds__(256) void k_minmax(const double *__restrict__ x, const double *__restrict__ y,
+                                                const double *__restrict__ z, const double *__restrict__ h,
+                                                size_t n, double *__restrict__ part)
+{
+    double mn[4] = {DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX};
+    double mx[4] = {-DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX};
+    const double *p[4] = {x, y, z, h};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            double v = p[k][i];
+            mn[k] = fmin(mn[k], v);
+            mx[k] = fmax(mx[k], v);
+        }
+    }
+    __shared__ double s[4][8];
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        double a = wave_min(mn[k]), b = wave_max(mx[k]);
+        if (lane == 0) { s[wv][k] = a; s[wv][4 + k] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        int k = threadIdx.x;
+        double v = s[0][k];
+        for (int w = 1; w < 4; w++) v = (k < 4) ? fmin(v, s[w][k]) : fmax(v, s[w][k]);
+        part[(size_t)blockIdx.x * 8 + k] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_minmax_final(const double *__restrict__ part, int nblocks, double *__restrict__ out)
+{
+    int k = threadIdx.x & 7;
+    double v = (k < 4) ? DBL_MAX : -DBL_MAX;
+    for (int b = threadIdx.x >> 3; b < nblocks; b += 8) {
+        double w = part[(size_t)b * 8 + k];
+        v = (k < 4) ? fmin(v, w) : fmax(v, w);
+    }
+    // combine the 8 lane-groups (lanes k, k+8, ..., k+56)
+    for (int o = 8; o < 64; o <<= 1) {
+        double w = __shfl_xor(v, o, 64);
+        v = (k < 4) ? fmin(v, w) : fmax(v, w);
+    }
+    if (threadIdx.x < 8) out[k] = v;
+}
+
+int nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *out8)
+{
+    const int BLOCKS = 1024;
+    SPH_TRY(c->red_part.reserve((size_t)narrays * BLOCKS * 8 * sizeof(double)));
+    SPH_TRY(c->red_out.reserve(8 * sizeof(double)));
+    int nb_total = 0;
+    for (int a = 0; a < narrays; a++) {
+        DevArray &A = c->arr[ids[a]];
+        if (A.n == 0) continue;
+        for (int p : {SPH_X, SPH_Y, SPH_Z, SPH_H})
+            if (!A.prop[p]) {
+                sph_set_error("nnps: array %d has no device copy of x/y/z/h", ids[a]);
+                return SPH_ERR_MISSING_PROP;
+            }
+        int nb = (int)std::min<size_t>(BLOCKS, (A.n + 255) / 256);
+        hipLaunchKernelGGL(k_minmax, dim3(nb), dim3(256), 0, c->stream, A.prop[SPH_X], A.prop[SPH_Y],
+                           A.prop[SPH_Z], A.prop[SPH_H], A.n, c->red_part.as<double>() + (size_t)nb_total * 8);
+        nb_total += nb;
+    }
+    if (nb_total == 0) {
+        for (int k = 0; k < 4; k++) { out8[k] = DBL_MAX; out8[4 + k] = -DBL_MAX; }
+        return SPH_OK;
+    }
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(64), 0, c->stream, c->red_part.as<double>(), nb_total,
+                       c->red_out.as<double>());
+    HIP_TRY(hipMemcpyAsync(c->pinned, c->red_out.ptr, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(out8, c->pinned, 8 * sizeof(double));
+    return SPH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// cell keys, sort, cell ranges
+// ---------------------------------------------------------------------------
+struct GridDesc {
+    double xmin[3];
+    double cell_size;
+    int nc[3];
+};
+
+// nnps_base.pxd:39-57 real_to_int = <int>floor(real_val/step), flatten_raw :83-96
+__global__ __launch_bounds__(256) void k_cell_keys(const double *__restrict__ x, const double *__restrict__ y,
+                                                   const double *__restrict__ z, size_t n, GridDesc g,
+                                                   uint32_t *__restrict__ keys, uint32_t *__restrict__ idx)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int cx = (int)floor((x[i] - g.xmin[0]) / g.cell_size);
+    int cy = (int)floor((y[i] - g.xmin[1]) / g.cell_size);
+    int cz = (int)floor((z[i] - g.xmin[2]) / g.cell_size);
+    cx = min(max(cx, 0), g.nc[0] - 1);
+    cy = min(max(cy, 0), g.nc[1] - 1);
+    cz = min(max(cz, 0), g.nc[2] - 1);
+    keys[i] = (uint32_t)(cx + g.nc[0] * (cy + g.nc[1] * cz));
+    idx[i] = (uint32_t)i;
+}
+
+// cell_start[c] = first sorted position whose key >= c, for c in [0, n_cells].
+// Every entry is written exactly once (no atomics, no scan).
+__global__ __launch_bounds__(256) void k_cell_start(const uint32_t *__restrict__ skeys, size_t n, uint32_t n_cells,
+                                                    uint32_t *__restrict__ cell_start)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    long k0 = (i == 0) ? -1 : (long)skeys[i - 1];
+    long k1 = (i == n) ? (long)n_cells : (long)skeys[i];
+    for (long cidx = k0 + 1; cidx <= k1; cidx++) cell_start[cidx] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_fill_u32(uint32_t *p, size_t n, uint32_t v)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+static int bits_for(long n_cells)
+{
+    int b = 1;
+    while ((1L << b) < n_cells) b++;
+    return b;
+}
+
+extern "C" int sph_nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *out8)
+{
+    if (!c || narrays < 1 || narrays > SPH_MAX_ARRAYS) { sph_set_error("sph_nnps_minmax: bad arguments"); return SPH_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    return nnps_minmax(c, narrays, ids, out8);
+}
+
+extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids, double radius_scale,
+                               double cell_size_in, const double *bounds)
+{
+    if (!c || narrays < 1 || narrays > SPH_MAX_ARRAYS || dim < 1 || dim > 3) {
+        sph_set_error("sph_nnps_update: bad arguments");
+        return SPH_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    ScopedTimer tm(c, T_NNPS);
+    c->nnps_valid = false;
+    for (int a = 0; a < narrays; a++) {
+        if (ids[a] < 0 || ids[a] >= SPH_MAX_ARRAYS || !c->arr[ids[a]].used) {
+            sph_set_error("sph_nnps_update: array id %d not registered", ids[a]);
+            return SPH_ERR_ARG;
+        }
+    }
+    double mm[8];
+    SPH_TRY(nnps_minmax(c, narrays, ids, mm));
+
+    // DomainManager._compute_cell_size_for_binning (nnps_base.pyx:942-978)
+    double hmax = -1.0, hmin = DBL_MAX;
+    if (mm[7] > hmax) hmax = mm[7];
+    if (mm[3] < hmin) hmin = mm[3];
+    double cell_size = radius_scale * hmax;
+    c->hmin = radius_scale * hmin;
+    if (cell_size < 1e-6) cell_size = 1.0;
+    if (cell_size_in > 0) cell_size = cell_size_in;
+    c->uniform_h = (hmin == hmax);
+    c->h_uniform = hmax;
+
+    // NNPS._compute_bounds (nnps_base.pyx:1520-1575)
+    double xmax = fmax(mm[4], -1e100), ymax = fmax(mm[5], -1e100), zmax = fmax(mm[6], -1e100);
+    double xmin = fmin(mm[0], 1e100), ymin = fmin(mm[1], 1e100), zmin = fmin(mm[2], 1e100);
+    double lx = xmax - xmin, ly = ymax - ymin, lz = zmax - zmin;
+    xmin -= lx * 0.01; ymin -= ly * 0.01; zmin -= lz * 0.01;
+    xmax += lx * 0.01; ymax += ly * 0.01; zmax += lz * 0.01;
+    const double eps = 1e-12;
+    if (fabs(xmax - xmin) < eps && fabs(ymax - ymin) < eps && fabs(zmax - zmin) < eps) {
+        xmin -= 0.5; xmax += 0.5;
+        ymin -= 0.5; ymax += 0.5;
+        zmin -= 0.5; zmax += 0.5;
+    }
+    if (bounds) {
+        xmin = bounds[0]; ymin = bounds[1]; zmin = bounds[2];
+        xmax = bounds[3]; ymax = bounds[4]; zmax = bounds[5];
+    }
+
+    // LinkedListNNPS._get_number_of_cells (linked_list_nnps.pyx:293-326)
+    double cell_size1 = 1. / cell_size;
+    int ncx = (int)ceil(cell_size1 * (xmax - xmin));
+    int ncy = (int)ceil(cell_size1 * (ymax - ymin));
+    int ncz = (int)ceil(cell_size1 * (zmax - zmin));
+    if (ncx < 0 || ncy < 0 || ncz < 0) {
+        sph_set_error("LinkedListNNPS: Number of cells is negative (%d, %d, %d).", ncx, ncy, ncz);
+        return SPH_ERR_CELLS;
+    }
+    ncx = ncx == 0 ? 1 : ncx;
+    ncy = ncy == 0 ? 1 : ncy;
+    ncz = ncz == 0 ? 1 : ncz;
+    long n_cells = ncx;
+    if (dim == 2) n_cells = (long)ncx * ncy;
+    if (dim == 3) n_cells = (long)ncx * ncy * ncz;
+    // _count_occupied_cells (:328-343)
+    if (n_cells < 0 || n_cells > (1L << 28)) {
+        sph_set_error("ERROR: LinkedListNNPS requires too many cells (%ld).", n_cells);
+        return SPH_ERR_CELLS;
+    }
+    // The reference indexes head[] with the full 3-D flattened id even when
+    // dim < 3; particles of a dim<3 problem lie in one z (and y) plane so the
+    // id stays < n_cells.  Keys here use the same flattening; the table is
+    // sized for the full product so that a stray plane cannot overflow it.
+    long n_cells_alloc = (long)ncx * ncy * ncz;
+    if (n_cells_alloc > (1L << 28)) {
+        sph_set_error("ERROR: LinkedListNNPS requires too many cells (%ld).", n_cells_alloc);
+        return SPH_ERR_CELLS;
+    }
+
+    c->dim = dim;
+    c->narrays = narrays;
+    c->radius_scale = radius_scale;
+    c->cell_size = cell_size;
+    c->xmin[0] = xmin; c->xmin[1] = ymin; c->xmin[2] = zmin;
+    c->xmax[0] = xmax; c->xmax[1] = ymax; c->xmax[2] = zmax;
+    c->nc[0] = ncx; c->nc[1] = ncy; c->nc[2] = ncz;
+    c->n_cells = n_cells_alloc;
+    for (auto &A : c->arr) A.nnps_slot = -1;
+
+    GridDesc g;
+    for (int k = 0; k < 3; k++) { g.xmin[k] = c->xmin[k]; g.nc[k] = c->nc[k]; }
+    g.cell_size = cell_size;
+    int end_bit = bits_for(n_cells_alloc);
+
+    for (int a = 0; a < narrays; a++) {
+        c->ids[a] = ids[a];
+        DevArray &A = c->arr[ids[a]];
+        A.nnps_slot = a;
+        size_t n = A.n;
+        SPH_TRY(A.keys.reserve((n + 1) * 4));
+        SPH_TRY(A.keys_sorted.reserve((n + 1) * 4));
+        SPH_TRY(A.idx.reserve((n + 1) * 4));
+        SPH_TRY(A.perm.reserve((n + 1) * 4));
+        SPH_TRY(A.cell_start.reserve(((size_t)n_cells_alloc + 1) * 4));
+        if (n == 0) {
+            hipLaunchKernelGGL(k_fill_u32, dim3(div_up(n_cells_alloc + 1, 256)), dim3(256), 0, c->stream,
+                               A.cell_start.as<uint32_t>(), (size_t)n_cells_alloc + 1, 0u);
+            continue;
+        }
+        hipLaunchKernelGGL(k_cell_keys, dim3(div_up(n, 256)), dim3(256), 0, c->stream, A.prop[SPH_X], A.prop[SPH_Y],
+                           A.prop[SPH_Z], n, g, A.keys.as<uint32_t>(), A.idx.as<uint32_t>());
+        size_t tmp_bytes = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, A.keys.as<uint32_t>(), A.keys_sorted.as<uint32_t>(),
+                                                   A.idx.as<uint32_t>(), A.perm.as<uint32_t>(), (int)n, 0, end_bit,
+                                                   c->stream));
+        SPH_TRY(c->cub_tmp.reserve(tmp_bytes));
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.ptr, tmp_bytes, A.keys.as<uint32_t>(),
+                                                   A.keys_sorted.as<uint32_t>(), A.idx.as<uint32_t>(),
+                                                   A.perm.as<uint32_t>(), (int)n, 0, end_bit, c->stream));
+        hipLaunchKernelGGL(k_cell_start, dim3(div_up(n + 1, 256)), dim3(256), 0, c->stream, A.keys_sorted.as<uint32_t>(),
+                           n, (uint32_t)n_cells_alloc, A.cell_start.as<uint32_t>());
+    }
+    HIP_TRY(hipGetLastError());
+    c->nnps_valid = true;
+    return SPH_OK;
+}
+
+extern "C" int sph_nnps_info(sph_ctx *c, double *d8, long *i4)
+{
+    if (!c->nnps_valid) { sph_set_error("sph_nnps_info: call sph_nnps_update first"); return SPH_ERR_STATE; }
+    d8[0] = c->cell_size; d8[1] = c->hmin;
+    for (int k = 0; k < 3; k++) { d8[2 + k] = c->xmin[k]; d8[5 + k] = c->xmax[k]; }
+    i4[0] = c->nc[0]; i4[1] = c->nc[1]; i4[2] = c->nc[2];
+    // n_cells as the reference reports it (dim-aware, linked_list_nnps.pyx:321-325)
+    long ncells = c->nc[0];
+    if (c->dim == 2) ncells = (long)c->nc[0] * c->nc[1];
+    if (c->dim == 3) ncells = (long)c->nc[0] * c->nc[1] * c->nc[2];
+    i4[3] = ncells;
+    return SPH_OK;
+}
+
+extern "C" int sph_nnps_get_order(sph_ctx *c, int id, uint32_t *perm)
+{
+    if (!c->nnps_valid || c->arr[id].nnps_slot < 0) { sph_set_error("sph_nnps_get_order: array not binned"); return SPH_ERR_STATE; }
+    DevArray &A = c->arr[id];
+    if (A.n == 0) return SPH_OK;
+    HIP_TRY(hipMemcpyAsync(perm, A.perm.ptr, A.n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// neighbour lists (query API; the pair kernels never materialise these)
+// LinkedListNNPS.find_nearest_neighbors  linked_list_nnps.pyx:92-196
+// ---------------------------------------------------------------------------
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_csr(const double *__restrict__ dx, const double *__restrict__ dy,
+                                             const double *__restrict__ dz, const double *__restrict__ dh, size_t nd,
+                                             const double *__restrict__ sx, const double *__restrict__ sy,
+                                             const double *__restrict__ sz, const double *__restrict__ sh,
+                                             const uint32_t *__restrict__ sperm, const uint32_t *__restrict__ scell_start,
+                                             GridDesc g, double radius_scale, uint32_t *__restrict__ start,
+                                             uint32_t *__restrict__ nbrs)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nd) return;
+    double x = dx[i], y = dy[i], z = dz[i];
+    int cx = (int)floor((x - g.xmin[0]) / g.cell_size);
+    int cy = (int)floor((y - g.xmin[1]) / g.cell_size);
+    int cz = (int)floor((z - g.xmin[2]) / g.cell_size);
+    double hi2 = radius_scale * dh[i];
+    hi2 *= hi2;
+    uint32_t count = 0;
+    uint32_t base = FILL ? start[i] : 0;
+    for (int oz = -1; oz <= 1; oz++)
+        for (int oy = -1; oy <= 1; oy++) {
+            int yy = cy + oy, zz = cz + oz;
+            if (yy < 0 || yy >= g.nc[1] || zz < 0 || zz >= g.nc[2]) continue;
+            int xa = max(cx - 1, 0), xb = min(cx + 1, g.nc[0] - 1);
+            if (xa > xb) continue;
+            uint32_t row = (uint32_t)(g.nc[0] * (yy + g.nc[1] * zz));
+            uint32_t j0 = scell_start[row + xa], j1 = scell_start[row + xb + 1];
+            for (uint32_t j = j0; j < j1; j++) {
+                uint32_t s = sperm[j];
+                double hj2 = radius_scale * sh[s];
+                hj2 *= hj2;
+                double ex = sx[s] - x, ey = sy[s] - y, ez = sz[s] - z;
+                double r2 = ex * ex + ey * ey + ez * ez;
+                if ((r2 < hi2) || (r2 < hj2)) {
+                    if (FILL) nbrs[base + count] = s;
+                    count++;
+                }
+            }
+        }
+    if (!FILL) start[i] = count;
+}
+
+extern "C" int sph_nnps_get_csr(sph_ctx *c, int src, int dst, uint32_t *start, uint32_t *nbrs, size_t *total)
+{
+    if (!c->nnps_valid) { sph_set_error("sph_nnps_get_csr: call sph_nnps_update first"); return SPH_ERR_STATE; }
+    if (src < 0 || src >= SPH_MAX_ARRAYS || dst < 0 || dst >= SPH_MAX_ARRAYS || c->arr[src].nnps_slot < 0 ||
+        c->arr[dst].nnps_slot < 0) {
+        sph_set_error("sph_nnps_get_csr: arrays %d/%d are not part of the current grid", src, dst);
+        return SPH_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    DevArray &S = c->arr[src], &D = c->arr[dst];
+    size_t nd = D.n;
+    GridDesc g;
+    for (int k = 0; k < 3; k++) { g.xmin[k] = c->xmin[k]; g.nc[k] = c->nc[k]; }
+    g.cell_size = c->cell_size;
+    SPH_TRY(c->tmp_u32a.reserve((nd + 1) * 4));
+    uint32_t *d_start = c->tmp_u32a.as<uint32_t>();
+    if (!nbrs) {
+        if (nd)
+            hipLaunchKernelGGL(k_csr<false>, dim3(div_up(nd, 256)), dim3(256), 0, c->stream, D.prop[SPH_X], D.prop[SPH_Y],
+                               D.prop[SPH_Z], D.prop[SPH_H], nd, S.prop[SPH_X], S.prop[SPH_Y], S.prop[SPH_Z],
+                               S.prop[SPH_H], S.perm.as<uint32_t>(), S.cell_start.as<uint32_t>(), g, c->radius_scale,
+                               d_start, (uint32_t *)nullptr);
+        std::vector<uint32_t> cnt(nd);
+        if (nd) HIP_TRY(hipMemcpyAsync(cnt.data(), d_start, nd * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        start[0] = 0;
+        for (size_t i = 0; i < nd; i++) start[i + 1] = start[i] + cnt[i];
+        *total = start[nd];
+        return SPH_OK;
+    }
+    size_t tot = start[nd];
+    SPH_TRY(c->tmp_u32b.reserve((tot + 1) * 4));
+    HIP_TRY(hipMemcpyAsync(d_start, start, (nd + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    if (nd)
+        hipLaunchKernelGGL(k_csr<true>, dim3(div_up(nd, 256)), dim3(256), 0, c->stream, D.prop[SPH_X], D.prop[SPH_Y],
+                           D.prop[SPH_Z], D.prop[SPH_H], nd, S.prop[SPH_X], S.prop[SPH_Y], S.prop[SPH_Z], S.prop[SPH_H],
+                           S.perm.as<uint32_t>(), S.cell_start.as<uint32_t>(), g, c->radius_scale, d_start,
+                           c->tmp_u32b.as<uint32_t>());
+    if (tot) HIP_TRY(hipMemcpyAsync(nbrs, c->tmp_u32b.ptr, tot * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < nd; i++) std::sort(nbrs + start[i], nbrs + start[i + 1]);
+    if (total) *total = tot;
+    return SPH_OK;
+}

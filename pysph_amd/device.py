@@ -1,0 +1,274 @@
+"""ctypes binding of ``libsphhip.so`` + the device mirror of a ParticleArray.
+
+``HipDeviceHelper`` plays the role of the reference's ``DeviceHelper``
+(pysph/base/device_helper.py:47-672, reached as ``pa.gpu``): ``push`` /
+``pull`` / ``resize`` / ``max`` with the same names and argument meaning, but
+over an explicit host<->HIP buffer table behind the C-ABI
+(``include/sphhip.h``) instead of compyle arrays.
+
+There is NO CPU fallback: if the shared library cannot be loaded, or no GPU is
+visible, constructing a context raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .particle_array import get_npy
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsphhip.so')
+
+MAX_ARRAYS = 8
+MAX_PAR = 16
+
+
+class SphKernel(C.Structure):
+    _fields_ = [('kind', C.c_int), ('dim', C.c_int), ('fac', C.c_double),
+                ('radius_scale', C.c_double), ('deltap', C.c_double)]
+
+
+class SphEquation(C.Structure):
+    _fields_ = [('kind', C.c_int), ('dest', C.c_int), ('nsrc', C.c_int),
+                ('src', C.c_int * MAX_ARRAYS), ('par', C.c_double * MAX_PAR)]
+
+
+class SphGroup(C.Structure):
+    _fields_ = [('real', C.c_int), ('start_idx', C.c_long),
+                ('stop_idx', C.c_long), ('neq', C.c_int),
+                ('eqs', C.POINTER(SphEquation))]
+
+
+# every symbol include/sphhip.h declares, with its ctypes signature
+_P = C.c_void_p
+_PD = C.POINTER(C.c_double)
+_PU = C.POINTER(C.c_uint32)
+SIGNATURES = {
+    'sph_ctx_create': (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
+    'sph_ctx_destroy': (C.c_int, [_P]),
+    'sph_ctx_synchronize': (C.c_int, [_P]),
+    'sph_last_error': (C.c_char_p, []),
+    'sph_version': (C.c_char_p, []),
+    'sph_prop_id': (C.c_int, [C.c_char_p]),
+    'sph_array_resize': (C.c_int, [_P, C.c_int, C.c_size_t, C.c_size_t]),
+    'sph_array_size': (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t),
+                                 C.POINTER(C.c_size_t)]),
+    'sph_array_ensure_prop': (C.c_int, [_P, C.c_int, C.c_int]),
+    'sph_array_push': (C.c_int, [_P, C.c_int, C.c_int, _PD, C.c_size_t,
+                                 C.c_size_t]),
+    'sph_array_pull': (C.c_int, [_P, C.c_int, C.c_int, _PD, C.c_size_t,
+                                 C.c_size_t]),
+    'sph_array_device_ptr': (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
+    'sph_nnps_update': (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                  C.c_double, C.c_double, _PD]),
+    'sph_nnps_info': (C.c_int, [_P, _PD, C.POINTER(C.c_long)]),
+    'sph_nnps_minmax': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), _PD]),
+    'sph_nnps_get_csr': (C.c_int, [_P, C.c_int, C.c_int, _PU, _PU,
+                                   C.POINTER(C.c_size_t)]),
+    'sph_nnps_get_order': (C.c_int, [_P, C.c_int, _PU]),
+    'sph_eval_group': (C.c_int, [_P, C.POINTER(SphKernel),
+                                 C.POINTER(SphGroup), C.c_double, C.c_double]),
+    'sph_reduce_max': (C.c_int, [_P, C.c_int, C.c_int, _PD]),
+    'sph_set_option': (C.c_int, [_P, C.c_char_p, C.c_long]),
+    'sph_timer_enable': (C.c_int, [_P, C.c_int]),
+    'sph_timer_reset': (C.c_int, [_P]),
+    'sph_timer_get': (C.c_int, [_P, C.c_char_p, _PD, C.POINTER(C.c_long)]),
+}
+
+_LIB = None
+
+
+class SphError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """dlopen libsphhip.so and bind every declared symbol.  Raises if the
+    extension has not been built -- there is no fallback path."""
+    global _LIB
+    if _LIB is None:
+        path = path or LIB_PATH
+        if not os.path.exists(path):
+            raise SphError(
+                'HIP extension %s is missing: run `python -c "import '
+                '__graft_entry__ as g; g.build()"` (or make -C pysph_amd/csrc)'
+                % path)
+        lib = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if not exported
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise SphError('libsphhip error %d: %s' %
+                       (rc, load_library().sph_last_error().decode()))
+
+
+def prop_id(name):
+    pid = load_library().sph_prop_id(name.encode())
+    return pid
+
+
+class HipContext(object):
+    """One GPU, one stream, up to 8 particle arrays (``sph_ctx``)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        self._h = _P()
+        _check(self.lib.sph_ctx_create(device, stream, C.byref(self._h)))
+        self.device = device
+        self._ids = {}
+
+    def array_id(self, name):
+        if name not in self._ids:
+            if len(self._ids) >= MAX_ARRAYS:
+                raise SphError('at most %d particle arrays' % MAX_ARRAYS)
+            self._ids[name] = len(self._ids)
+        return self._ids[name]
+
+    def synchronize(self):
+        _check(self.lib.sph_ctx_synchronize(self._h))
+
+    def set_option(self, key, value):
+        _check(self.lib.sph_set_option(self._h, key.encode(), int(value)))
+
+    # timers ----------------------------------------------------------
+    def timer_enable(self, on=True):
+        _check(self.lib.sph_timer_enable(self._h, int(on)))
+
+    def timer_reset(self):
+        _check(self.lib.sph_timer_reset(self._h))
+
+    def timer_get(self, key):
+        ms = C.c_double()
+        cnt = C.c_long()
+        _check(self.lib.sph_timer_get(self._h, key.encode(), C.byref(ms),
+                                      C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def close(self):
+        if self._h:
+            self.lib.sph_ctx_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_DEFAULT_CTX = {}
+
+
+def get_context(device=0, stream=None):
+    """Process-wide default context per device."""
+    key = (device, stream)
+    if key not in _DEFAULT_CTX:
+        _DEFAULT_CTX[key] = HipContext(device, stream)
+    return _DEFAULT_CTX[key]
+
+
+def _as_f64(arr, name):
+    if arr.dtype != np.float64:
+        raise SphError('property %s: the HIP backend mirrors fp64 arrays '
+                       '(got %s)' % (name, arr.dtype))
+    return np.ascontiguousarray(arr)
+
+
+class HipDeviceHelper(object):
+    """``pa.gpu`` for the HIP backend (DeviceHelper API subset:
+    device_helper.py:130 resize, :200 pull, :219 push, :170 max)."""
+
+    def __init__(self, pa, ctx=None):
+        self._pa = pa
+        self.ctx = ctx or get_context()
+        self.lib = self.ctx.lib
+        self.array_id = self.ctx.array_id(pa.name)
+        self._n = -1
+        self.resize(pa.get_number_of_particles())
+
+    def get_number_of_particles(self, real=False):
+        n, nr = C.c_size_t(), C.c_size_t()
+        _check(self.lib.sph_array_size(self.ctx._h, self.array_id,
+                                       C.byref(n), C.byref(nr)))
+        return nr.value if real else n.value
+
+    def resize(self, n=None):
+        pa = self._pa
+        n = pa.get_number_of_particles() if n is None else n
+        nreal = min(pa.get_number_of_particles(True), n)
+        _check(self.lib.sph_array_resize(self.ctx._h, self.array_id, n, nreal))
+        self._n = n
+
+    def _sync_size(self):
+        pa = self._pa
+        n = pa.get_number_of_particles()
+        nreal = pa.get_number_of_particles(True)
+        if n != self._n or nreal != self.get_number_of_particles(True):
+            self.resize(n)
+
+    def push(self, *props):
+        """host -> device.  No args: every fp64 property the device knows."""
+        pa = self._pa
+        self._sync_size()
+        if not props:
+            props = [p for p in pa.properties if prop_id(p) >= 0]
+        for p in props:
+            pid = prop_id(p)
+            if pid < 0:
+                raise SphError('property %r has no device mirror' % p)
+            arr = _as_f64(get_npy(pa, p), p)
+            _check(self.lib.sph_array_push(
+                self.ctx._h, self.array_id, pid,
+                arr.ctypes.data_as(_PD), 0, arr.size))
+
+    def pull(self, *props):
+        """device -> host, into the host array's own buffer."""
+        pa = self._pa
+        if not props:
+            props = [p for p in pa.properties if prop_id(p) >= 0]
+        for p in props:
+            pid = prop_id(p)
+            if pid < 0:
+                raise SphError('property %r has no device mirror' % p)
+            arr = get_npy(pa, p)
+            if arr.dtype != np.float64 or not arr.flags.c_contiguous:
+                raise SphError('pull(%s): host array must be contiguous fp64'
+                               % p)
+            _check(self.lib.sph_array_pull(
+                self.ctx._h, self.array_id, pid, arr.ctypes.data_as(_PD), 0,
+                min(arr.size, self._n)))
+
+    def max(self, prop):
+        out = C.c_double()
+        _check(self.lib.sph_reduce_max(self.ctx._h, self.array_id,
+                                       prop_id(prop), C.byref(out)))
+        return out.value
+
+    def device_ptr(self, prop):
+        ptr = _P()
+        _check(self.lib.sph_array_device_ptr(self.ctx._h, self.array_id,
+                                             prop_id(prop), C.byref(ptr)))
+        return ptr.value
+
+
+_HELPERS = {}
+
+
+def attach(pa, ctx=None):
+    """Give a particle array its device mirror (``pa.gpu``)."""
+    gpu = getattr(pa, 'gpu', None)
+    if not isinstance(gpu, HipDeviceHelper):
+        gpu = _HELPERS.get(id(pa))
+    if not isinstance(gpu, HipDeviceHelper) or (ctx and gpu.ctx is not ctx):
+        gpu = HipDeviceHelper(pa, ctx)
+        try:
+            pa.gpu = gpu
+        except AttributeError:  # a ParticleArray type without a settable gpu
+            _HELPERS[id(pa)] = gpu
+    return gpu

@@ -1,0 +1,148 @@
+"""Neighbour search front-end with the reference's ``LinkedListNNPS`` surface.
+
+Mirrors the Python-visible protocol of ``pysph.base.nnps.LinkedListNNPS``
+(pysph/base/linked_list_nnps.pyx:28-90 constructor, nnps_base.pyx:1430-1510
+``update`` / ``update_domain`` / ``set_context`` / ``get_nearest_particles``,
+attributes of nnps_base.pxd:279-371): same constructor arguments, same
+attribute names (``cell_size, hmin, xmin, xmax, n_cells, ncells_per_dim,
+particles, dim, radius_scale``), same error for a bad cell count
+(``RuntimeError``, linked_list_nnps.pyx:307-343).
+
+The data structure behind it is the device-side sorted cell list built by
+``sph_nnps_update`` (csrc/sph_nnps.hip); neighbour *lists* are only
+materialised by the query methods here -- the pair kernels never need them.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import device as dev
+
+_XYZH = ('x', 'y', 'z', 'h')
+
+
+class HipNNPS(object):
+    def __init__(self, dim, particles, radius_scale=2.0, ghost_layers=1,
+                 domain=None, fixed_h=False, cache=False, sort_gids=False,
+                 ctx=None, sync=True):
+        """`sync`: push x, y, z, h of every array from the host before each
+        ``update()`` (drop-in behaviour: the host owns the data).  With
+        ``sync=False`` the positions already on the device are used
+        (device-resident pipelines)."""
+        if domain is not None:
+            raise NotImplementedError(
+                'HipNNPS: periodic/mirror DomainManager is not implemented yet')
+        self.dim = dim
+        self.particles = list(particles)
+        self.narrays = len(self.particles)
+        self.radius_scale = float(radius_scale)
+        self.ghost_layers = ghost_layers
+        self.fixed_h = fixed_h
+        self.use_cache = cache
+        self.sort_gids = sort_gids
+        self.domain = None
+        self.sync = sync
+        self.ctx = ctx or dev.get_context()
+        self.lib = self.ctx.lib
+        self.helpers = [dev.attach(pa, self.ctx) for pa in self.particles]
+        self.src_index = self.dst_index = 0
+        self.cell_size = self.hmin = 0.0
+        self.xmin = np.zeros(3)
+        self.xmax = np.zeros(3)
+        self.ncells_per_dim = np.ones(3, dtype=np.int32)
+        self.n_cells = 0
+        self.bounds = None       # optional fixed global bounds (multi-GPU)
+        self.cell_size_override = -1.0
+        self.update()
+
+    # -- reference protocol ----------------------------------------------
+    def set_context(self, src_index, dst_index):
+        self.src_index, self.dst_index = src_index, dst_index
+
+    def set_in_parallel(self, in_parallel):
+        pass
+
+    def set_use_cache(self, use_cache):
+        self.use_cache = use_cache
+
+    def update_domain(self):
+        """DomainManager.update: only the cell size depends on it here and
+        that is recomputed inside ``update`` (nnps_base.pyx:450-483,942)."""
+
+    def update(self):
+        if self.sync:
+            for h in self.helpers:
+                h.push(*_XYZH)
+        else:
+            for h in self.helpers:
+                h._sync_size()
+        ids = (C.c_int * self.narrays)(*[h.array_id for h in self.helpers])
+        b = None
+        if self.bounds is not None:
+            b = (C.c_double * 6)(*self.bounds)
+        rc = self.lib.sph_nnps_update(self.ctx._h, self.dim, self.narrays, ids,
+                                      self.radius_scale,
+                                      self.cell_size_override, b)
+        if rc == -3:  # SPH_ERR_CELLS -> the reference raises RuntimeError
+            raise RuntimeError(self.lib.sph_last_error().decode())
+        dev._check(rc)
+        d8 = (C.c_double * 8)()
+        i4 = (C.c_long * 4)()
+        dev._check(self.lib.sph_nnps_info(self.ctx._h, d8, i4))
+        self.cell_size, self.hmin = d8[0], d8[1]
+        self.xmin = np.array(d8[2:5])
+        self.xmax = np.array(d8[5:8])
+        self.ncells_per_dim = np.array(i4[0:3], dtype=np.int32)
+        self.n_cells = int(i4[3])
+
+    def get_csr(self, src_index, dst_index):
+        """(start[nd+1], nbrs) with each list sorted ascending."""
+        nd = self.particles[dst_index].get_number_of_particles()
+        start = np.zeros(nd + 1, dtype=np.uint32)
+        total = C.c_size_t()
+        s, d = self.helpers[src_index].array_id, self.helpers[dst_index].array_id
+        sp = start.ctypes.data_as(dev._PU)
+        dev._check(self.lib.sph_nnps_get_csr(self.ctx._h, s, d, sp, None,
+                                             C.byref(total)))
+        nbrs = np.empty(max(total.value, 1), dtype=np.uint32)
+        dev._check(self.lib.sph_nnps_get_csr(
+            self.ctx._h, s, d, sp, nbrs.ctypes.data_as(dev._PU),
+            C.byref(total)))
+        return start, nbrs[:total.value]
+
+    def get_nearest_particles(self, src_index, dst_index, d_idx, nbrs=None):
+        """Neighbours of destination particle `d_idx` (ascending ids; the
+        reference returns cell-traversal order unless sort_gids)."""
+        key = (src_index, dst_index)
+        if getattr(self, '_csr_key', None) != key:
+            self._csr = self.get_csr(src_index, dst_index)
+            self._csr_key = key
+        start, idx = self._csr
+        out = idx[start[d_idx]:start[d_idx + 1]].copy()
+        if nbrs is not None and hasattr(nbrs, 'set_data'):
+            nbrs.set_data(out)
+        return out
+
+    def get_spatially_ordered_indices(self, pa_index):
+        n = self.particles[pa_index].get_number_of_particles()
+        perm = np.empty(max(n, 1), dtype=np.uint32)
+        dev._check(self.lib.sph_nnps_get_order(
+            self.ctx._h, self.helpers[pa_index].array_id,
+            perm.ctypes.data_as(dev._PU)))
+        return perm[:n]
+
+    def spatially_order_particles(self, pa_index):
+        """Reorder the HOST array into cell order (nnps_base.pyx:1615-1629)."""
+        pa = self.particles[pa_index]
+        order = self.get_spatially_ordered_indices(pa_index).astype(np.int64)
+        for name, arr in pa.properties.items():
+            stride = pa.stride.get(name, 1)
+            if stride == 1:
+                arr[...] = arr[order]
+            else:
+                arr[...] = arr.reshape(-1, stride)[order].ravel()
+        self._csr_key = None
+
+
+# name used by reference scripts: ``from pysph.base.nnps import LinkedListNNPS``
+LinkedListNNPS = HipNNPS
