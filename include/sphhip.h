@@ -173,6 +173,27 @@ int sph_eval_group(sph_ctx *ctx, const sph_kernel *kernel, const sph_group *grou
  * pysph/sph/integrator.py:161-200).                                        */
 int sph_reduce_max(sph_ctx *ctx, int array_id, int prop, double *out);
 
+/* ---------------------------------------------------------------------- */
+/* ghost-particle halos (slab decomposition, one process per GPU)           */
+/* replaces ParallelManager.compute_remote_particles / remote_exchange_data */
+/* (pysph/parallel/parallel_manager.pyx:1159-1243, :159-210); the transport */
+/* itself is RCCL send/recv issued by the Python host (torch.distributed).  */
+/* ---------------------------------------------------------------------- */
+/* Select the REAL particles of `array_id` whose coordinate along `axis`
+ * (0,1,2) is < lo_cut (side 0) or >= hi_cut (side 1), in ascending index
+ * order (deterministic).  counts[2] receives the two list lengths.         */
+int sph_halo_select(sph_ctx *ctx, int array_id, int axis, double lo_cut, double hi_cut, size_t *counts);
+/* Gather `nprops` properties of the particles selected for `side` into the
+ * device buffer dst, laid out [nprops][count]; `shift` is added to the
+ * `axis` coordinate (periodic wrap, nnps_base.pyx:841-856).                */
+int sph_halo_pack(sph_ctx *ctx, int array_id, int side, int nprops, const int *props, int axis,
+                  double shift, void *dst_device);
+/* Append `count` ghost particles (tag Remote: sources only) behind the
+ * current ones from a device buffer laid out [nprops][count].  n grows,
+ * n_real is unchanged.  Drop them again with sph_array_resize(n_real).      */
+int sph_halo_append(sph_ctx *ctx, int array_id, int nprops, const int *props, const void *src_device,
+                    size_t count);
+
 /* pair-kernel variant: 0 = per-lane cell walk (direct), 1 = LDS-tiled
  * two-phase (default).                                                      */
 int sph_set_option(sph_ctx *ctx, const char *key, long value);

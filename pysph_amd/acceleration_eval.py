@@ -267,9 +267,13 @@ class HipAccelerationEval(object):
 
     # -- data movement --------------------------------------------------------
     def push_inputs(self):
+        # positions and h were pushed by nnps.update() (HipNNPS sync=True) and
+        # define the cell grid: re-pushing them would invalidate it
+        skip = ('x', 'y', 'z', 'h') if getattr(self.nnps, 'sync', False) else ()
         for name, props in self.inputs.items():
             pa = self.arrays[name]
-            have = [p for p in sorted(props) if has_prop(pa, p)]
+            have = [p for p in sorted(props)
+                    if has_prop(pa, p) and p not in skip]
             self.helpers[name].push(*have)
 
     def pull_outputs(self):

@@ -216,6 +216,7 @@ int sph_array_device_ptr(sph_ctx *c, int id, int prop, void **dptr)
 int sph_set_option(sph_ctx *c, const char *key, long value)
 {
     if (strcmp(key, "pair_variant") == 0) { c->pair_variant = value; return SPH_OK; }
+    if (strcmp(key, "ablate") == 0) { c->ablate = value; return SPH_OK; }
     if (strcmp(key, "invalidate_nnps") == 0) { c->nnps_valid = false; return SPH_OK; }
     sph_set_error("sph_set_option: unknown key '%s'", key);
     return SPH_ERR_ARG;

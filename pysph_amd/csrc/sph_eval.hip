@@ -143,6 +143,7 @@ template <class Fam> struct PairArgs {
     double radius_scale;
     KernelConst k;
     uint32_t dflags; // union of the source flags
+    int ablate;      // profiling only: 1 = skip pair arithmetic, 2 = skip phase 2
     double t;
     typename Fam::Params p;
 };
@@ -443,6 +444,7 @@ template <class Fam, int KK> __global__ __launch_bounds__(64) void k_pair_tiled(
     int nch = 0;
 
     auto phase2 = [&]() {
+        if (a.ablate == 2) { nch = 0; __syncthreads(); return; }
         int c = 0;
         unsigned long long m = nch > 0 ? masks[0][lane] : 0ull;
         for (;;) {
@@ -457,7 +459,7 @@ template <class Fam, int KK> __global__ __launch_bounds__(64) void k_pair_tiled(
                 double hj2 = a.radius_scale * pj.w;
                 hj2 *= hj2;
                 double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-                if ((r2 < hi2) || (r2 < hj2))
+                if (((r2 < hi2) || (r2 < hj2)) && a.ablate != 1)
                     Fam::template pair<KK>(D, pi, pj, r2, a.aux + (size_t)jg * Fam::NA, chflags[c], a);
             }
         }
@@ -690,6 +692,7 @@ static void fill_common(sph_ctx *c, PairArgs<Fam> &a, const sph_kernel *K, doubl
     a.k.deltap = K->deltap;
     a.k.dim = K->dim;
     a.t = t;
+    a.ablate = (int)c->ablate;
 }
 
 static int ensure_out(sph_ctx *c, int id, std::initializer_list<int> props)

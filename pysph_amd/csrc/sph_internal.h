@@ -82,6 +82,7 @@ struct sph_ctx {
 
     // options
     long pair_variant = 1;
+    long ablate = 0;
     long block_sorted_outputs = 0;
 
     // timers

@@ -68,6 +68,12 @@ SIGNATURES = {
     'sph_nnps_get_order': (C.c_int, [_P, C.c_int, _PU]),
     'sph_eval_group': (C.c_int, [_P, C.POINTER(SphKernel),
                                  C.POINTER(SphGroup), C.c_double, C.c_double]),
+    'sph_halo_select': (C.c_int, [_P, C.c_int, C.c_int, C.c_double,
+                                  C.c_double, C.POINTER(C.c_size_t)]),
+    'sph_halo_pack': (C.c_int, [_P, C.c_int, C.c_int, C.c_int,
+                                C.POINTER(C.c_int), C.c_int, C.c_double, _P]),
+    'sph_halo_append': (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                  _P, C.c_size_t]),
     'sph_reduce_max': (C.c_int, [_P, C.c_int, C.c_int, _PD]),
     'sph_set_option': (C.c_int, [_P, C.c_char_p, C.c_long]),
     'sph_timer_enable': (C.c_int, [_P, C.c_int]),
@@ -190,6 +196,9 @@ class HipDeviceHelper(object):
         self.lib = self.ctx.lib
         self.array_id = self.ctx.array_id(pa.name)
         self._n = -1
+        # True when the device holds extra (ghost) particles the host array
+        # does not have: sizes are then managed by the halo exchange
+        self.managed = False
         self.resize(pa.get_number_of_particles())
 
     def get_number_of_particles(self, real=False):
@@ -206,6 +215,8 @@ class HipDeviceHelper(object):
         self._n = n
 
     def _sync_size(self):
+        if self.managed:
+            return
         pa = self._pa
         n = pa.get_number_of_particles()
         nreal = pa.get_number_of_particles(True)
