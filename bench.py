@@ -114,8 +114,9 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--n1', type=int, default=159, help='lattice side per GPU')
-    ap.add_argument('--variant', type=int, default=1)
+    ap.add_argument('--variant', type=int, default=2)
     ap.add_argument('--ablate', type=int, default=0, help='profiling only')
+    ap.add_argument('--opt', action='append', default=[], help='key=value library option')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-n1', type=int, default=100)
     args = ap.parse_args()
@@ -145,6 +146,9 @@ def main():
     ctx.set_option('pair_variant', args.variant)
     if args.ablate:
         ctx.set_option('ablate', args.ablate)
+    for kv in args.opt:
+        k, v = kv.split('=')
+        ctx.set_option(k, int(v))
 
     n1 = args.n1
     pa, dx = make_cube(n1, x_offset=float(rank), seed=1234 + rank)
@@ -218,7 +222,7 @@ def main():
             },
             'roofline': {
                 'bound': 'hbm', 'kernel': 'k_pair_%s<FamWCSPH,WendlandQuintic>' %
-                ('tiled' if args.variant else 'direct'),
+                ('direct', 'tiled', 'wg')[args.variant],
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                 'algorithmic_bytes_per_particle': ALGO_BYTES_PAIR,

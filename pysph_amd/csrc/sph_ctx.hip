@@ -103,6 +103,8 @@ int sph_ctx_destroy(sph_ctx *c)
         A.keys.release(); A.keys_sorted.release(); A.idx.release(); A.perm.release();
         A.cell_start.release();
     }
+    for (auto &H : c->halo)
+        for (int s = 0; s < 2; s++) { H.flag[s].release(); H.pos[s].release(); H.list[s].release(); }
     for (DevBuf *b : {&c->cub_tmp, &c->red_part, &c->red_out, &c->posh, &c->aux, &c->dkeys, &c->dperm,
                       &c->tmp_u32a, &c->tmp_u32b})
         b->release();
@@ -216,6 +218,8 @@ int sph_array_device_ptr(sph_ctx *c, int id, int prop, void **dptr)
 int sph_set_option(sph_ctx *c, const char *key, long value)
 {
     if (strcmp(key, "pair_variant") == 0) { c->pair_variant = value; return SPH_OK; }
+    if (strcmp(key, "wpe") == 0) { c->wpe = value; return SPH_OK; }
+    if (strcmp(key, "uniform_h") == 0) { c->use_uniform_h = value; return SPH_OK; }
     if (strcmp(key, "ablate") == 0) { c->ablate = value; return SPH_OK; }
     if (strcmp(key, "invalidate_nnps") == 0) { c->nnps_valid = false; return SPH_OK; }
     sph_set_error("sph_set_option: unknown key '%s'", key);

@@ -100,9 +100,11 @@ struct PackArgs {
     const double *x, *y, *z, *h;
     int na;                       // doubles in the aux record
     const double *src[MAX_AUX];   // nullptr -> 0.0
-    int derived;                  // 1: aux[7] = 1/(rho*rho) with rho = aux[4]; 2: aux[10]=1/V^2 (V = aux[8])
+    int derived;                  // 1: aux[5] = p/(rho*rho) (p = aux[7], rho = aux[4]); 2: aux[10] = 1/V^2 (V = aux[8])
     double4 *posh;
     double *aux;
+    double *rec;                  // non-null: interleaved records [x y z h aux... pad], nr doubles each
+    int nr;
 };
 
 __global__ __launch_bounds__(256) void k_pack(PackArgs a)
@@ -112,15 +114,23 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
     uint32_t o = a.perm[i];
     double4 ph;
     ph.x = a.x[o]; ph.y = a.y[o]; ph.z = a.z[o]; ph.w = a.h[o];
-    a.posh[a.off + i] = ph;
-    double *dst = a.aux + (a.off + i) * (size_t)a.na;
+    double *dst;
+    if (a.rec) {
+        double *r = a.rec + (a.off + i) * (size_t)a.nr;
+        *reinterpret_cast<double4 *>(r) = ph;
+        dst = r + 4;
+    } else {
+        a.posh[a.off + i] = ph;
+        dst = a.aux + (a.off + i) * (size_t)a.na;
+    }
     double v[MAX_AUX];
 #pragma unroll
     for (int k = 0; k < MAX_AUX; k++) v[k] = (k < a.na && a.src[k]) ? a.src[k][o] : 0.0;
-    if (a.derived == 1) v[7] = 1.0 / (v[4] * v[4]);                 // rhoj21, wc/basic.py:211
+    if (a.derived == 1) v[5] = v[4] != 0.0 ? v[7] * (1.0 / (v[4] * v[4])) : 0.0; // tmpj = p*rhoj21, wc/basic.py:211,234
     if (a.derived == 2) { double Vj = 1. / v[8]; v[10] = Vj * Vj; } // Vj2, transport_velocity.py:303-306
 #pragma unroll
     for (int k = 0; k < MAX_AUX; k++) if (k < a.na) dst[k] = v[k];
+    if (a.rec && (a.na & 1)) dst[a.na] = 0.0;
 }
 
 struct SrcDesc {
@@ -134,6 +144,7 @@ template <class Fam> struct PairArgs {
     SrcDesc src[SPH_MAX_ARRAYS];
     const double4 *posh;
     const double *aux;
+    const double *rec; // variant 2: interleaved records, Fam::NR doubles each
     uint32_t d_off, nd;
     const uint32_t *d_keys, *d_perm;
     uint32_t d_start, d_stop;
@@ -145,37 +156,82 @@ template <class Fam> struct PairArgs {
     uint32_t dflags; // union of the source flags
     int ablate;      // profiling only: 1 = skip pair arithmetic, 2 = skip phase 2
     double t;
+    // constants of the uniform-h specialisation (hmin == hmax over all arrays)
+    double hu, h1u, facu, epsu, hr2u;
     typename Fam::Params p;
 };
+
+// ---------------------------------------------------------------------------
+// fast fp64 reciprocal / square root: hardware estimate + two Newton steps
+// (error ~1 ulp; no div_scale/div_fixup range handling -- operands here are
+// densities, distances and smoothing lengths, far from the fp64 range limits).
+// The 1e-10 parity budget (BASELINE.json) absorbs the ~1e-16 differences.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double fast_rcp(double d)
+{
+    double x = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    return x;
+}
+// s = sqrt(a), rs = 1/sqrt(a); a == 0 -> s = rs = 0
+__device__ __forceinline__ void fast_sqrt_rsqrt(double a, double &s, double &rs)
+{
+    double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    bool ok = a > 1e-290;
+    s = ok ? g : 0.0;
+    rs = ok ? h + h : 0.0;
+}
 
 // per-pair geometry shared by all families
 struct PairGeom {
     double xij[3];
-    double r2, rij, hij, h1, q, fac;
+    double r2, rij, rinv, hij, h1, q, fac, eps;
 };
 
-template <int KK> __device__ __forceinline__ void pair_geom(PairGeom &g, const double4 &pi, const double4 &pj, double r2,
-                                                            const KernelConst &k)
+// UH: every particle has the same h -> HIJ, 1/HIJ, the kernel normalisation
+// and EPS are launch constants.
+template <int KK, bool UH, class A>
+__device__ __forceinline__ void pair_geom(PairGeom &g, const double4 &pi, const double4 &pj, double r2, const A &a)
 {
-    g.xij[0] = pi.x - pj.x; g.xij[1] = pi.y - pj.y; g.xij[2] = pi.z - pj.z; // equation.py:205-212
-    g.r2 = r2;                           // R2IJ  :226-233
-    g.rij = sqrt(r2);                    // RIJ   :235
-    g.hij = 0.5 * (pi.w + pj.w);         // HIJ   :192
-    g.h1 = 1.0 / g.hij;
+    g.xij[0] = pi.x - pj.x; g.xij[1] = pi.y - pj.y; g.xij[2] = pi.z - pj.z; // XIJ equation.py:205-212
+    g.r2 = r2;                                                               // R2IJ :226-233
+    fast_sqrt_rsqrt(r2, g.rij, g.rinv);                                      // RIJ  :235
+    if (UH) {
+        g.hij = a.hu; g.h1 = a.h1u; g.fac = a.facu; g.eps = a.epsu;
+    } else {
+        g.hij = 0.5 * (pi.w + pj.w);                                         // HIJ  :192
+        g.h1 = fast_rcp(g.hij);
+        g.fac = kernel_norm(a.k.sigma, g.h1, a.k.dim);
+        g.eps = 0.01 * g.hij * g.hij;                                        // EPS  :194
+    }
     g.q = g.rij * g.h1;
-    g.fac = kernel_norm(k.sigma, g.h1, k.dim);
 }
 template <int KK> __device__ __forceinline__ double pair_w(const PairGeom &g) { return SphKernel<KK>::w(g.q) * g.fac; }
-// GRADIENT(XIJ, RIJ, HIJ, DWIJ): kernels.py:126-137 -> tmp with grad = tmp * xij
+// GRADIENT(XIJ, RIJ, HIJ, DWIJ) (kernels.py:126-137) returns tmp*xij with
+// tmp = dwdq*h1/rij; here tmp only.  dw(q)/rij = dwq(q)*h1 when the kernel has
+// a closed form for dw/q.
 template <int KK> __device__ __forceinline__ double pair_gradfac(const PairGeom &g)
 {
-    double wdash = SphKernel<KK>::dw(g.q) * g.fac;
-    return g.rij > 1e-12 ? wdash * g.h1 / g.rij : 0.0;
+    double t;
+    if (SphKernel<KK>::HAS_DWQ) t = SphKernel<KK>::dwq(g.q) * (g.fac * g.h1 * g.h1);
+    else t = SphKernel<KK>::dw(g.q) * (g.fac * g.h1) * g.rinv;
+    return g.rij > 1e-12 ? t : 0.0;
 }
 
 // ---- WCSPH: Continuity + Momentum + XSPH (wc/basic.py, basic_equations.py) --
 struct FamWCSPH {
-    static constexpr int NA = 8; // u v w m rho p cs rho21
+    static constexpr int NA = 8; // u v w m rho tmpj(=p/rho^2) cs p
+    static constexpr int NR = 12; // x y z h + NA
     struct Params {
         double c0, alpha, beta, gx, gy, gz, eps;
         double *arho, *au, *av, *aw, *ax, *ay, *az, *dt_cfl, *dt_force;
@@ -186,65 +242,67 @@ struct FamWCSPH {
     };
     static __device__ __forceinline__ void load(Dest &D, const double *a)
     {
-        D.u = a[0]; D.v = a[1]; D.w = a[2]; D.rho = a[4]; D.p = a[5]; D.cs = a[6];
-        D.tmpi = D.p * a[7]; // tmpi = d_p*rhoi21, wc/basic.py:210,233
+        D.u = a[0]; D.v = a[1]; D.w = a[2]; D.rho = a[4]; D.tmpi = a[5]; D.cs = a[6]; D.p = a[7];
         D.arho = D.au = D.av = D.aw = D.ax = D.ay = D.az = D.dt_cfl = 0.0;
     }
-    template <int KK, class A>
+    // The algebra below is the reference's (cited per term) regrouped so that a
+    // pair costs one rsqrt and one reciprocal:  DWIJ = tg*XIJ  =>
+    //   DWIJ.VIJ = tg*(XIJ.VIJ),   f*DWIJ = (f*tg)*XIJ,
+    //   1/(R2IJ+EPS) and 1/RHOIJ from one reciprocal of their product,
+    //   1/R2IJ = rinv^2.
+    template <int KK, bool UH, class A>
     static __device__ __forceinline__ void pair(Dest &D, const double4 &pi, const double4 &pj, double r2,
-                                                const double *__restrict__ s, uint32_t fl, const A &a)
+                                                const double (&s)[NA], uint32_t fl, const A &a)
     {
         PairGeom g;
-        pair_geom<KK>(g, pi, pj, r2, a.k);
-        double tg = pair_gradfac<KK>(g);
-        double dw0 = tg * g.xij[0], dw1 = tg * g.xij[1], dw2 = tg * g.xij[2];
-        double vij0 = D.u - s[0], vij1 = D.v - s[1], vij2 = D.w - s[2]; // VIJ equation.py:214-223
-        double mj = s[3];
-        if (fl & F_CONT) { // basic_equations.py:187-192
-            double vijdotdwij = dw0 * vij0 + dw1 * vij1 + dw2 * vij2;
-            D.arho += mj * vijdotdwij;
-        }
+        pair_geom<KK, UH>(g, pi, pj, r2, a);
+        const double tg = pair_gradfac<KK>(g);
+        const double vij0 = D.u - s[0], vij1 = D.v - s[1], vij2 = D.w - s[2]; // VIJ equation.py:214-223
+        const double vdotx = vij0 * g.xij[0] + vij1 * g.xij[1] + vij2 * g.xij[2];
+        const double mj = s[3];
+        if (fl & F_CONT) D.arho = fma(mj * tg, vdotx, D.arho); // basic_equations.py:187-192
         if (fl & (F_MOM | F_XSPH)) {
-            double rhoij1 = 1.0 / (0.5 * (D.rho + s[4])); // RHOIJ, RHOIJ1 equation.py:196-199
+            const double rhoij = 0.5 * (D.rho + s[4]); // RHOIJ equation.py:196
+            double rhoij1;                              // RHOIJ1 :199
             double wij = 0.0;
             if (fl & (F_XSPH | F_TENSILE)) wij = pair_w<KK>(g);
             if (fl & F_MOM) { // wc/basic.py:204-259
-                double vijdotxij = vij0 * g.xij[0] + vij1 * g.xij[1] + vij2 * g.xij[2];
-                double piij = 0.0;
-                if (vijdotxij < 0) {
-                    double cij = 0.5 * (D.cs + s[6]);
-                    double eps = 0.01 * g.hij * g.hij; // EPS equation.py:194
-                    double muij = (g.hij * vijdotxij) / (r2 + eps);
-                    piij = -a.p.alpha * cij * muij + a.p.beta * muij * muij;
-                    piij = piij * rhoij1;
-                }
-                if (r2 > 1e-12) {
-                    double dtc = fabs(g.hij * vijdotxij / r2) + a.p.c0;
-                    D.dt_cfl = fmax(dtc, D.dt_cfl);
-                }
-                double tmpj = s[5] * s[7];
+                const double re = r2 + g.eps;
+                const double tt = fast_rcp(re * rhoij);
+                const double inv_re = rhoij * tt;
+                rhoij1 = re * tt;
+                const double hv = g.hij * vdotx;
+                const double muij = hv * inv_re;
+                const double cij = 0.5 * (D.cs + s[6]);
+                double piij = (a.p.beta * muij - a.p.alpha * cij) * muij * rhoij1;
+                piij = vdotx < 0 ? piij : 0.0;
+                const double dtc = fabs(hv * (g.rinv * g.rinv)) + a.p.c0;
+                D.dt_cfl = r2 > 1e-12 ? fmax(dtc, D.dt_cfl) : D.dt_cfl;
+                const double tmpj = s[5];
                 double tmp = D.tmpi + tmpj;
                 if (fl & F_TENSILE) {
                     // WDP = KERNEL(XIJ, DELTAP*HIJ, HIJ)  equation.py:243-246
-                    double qd = (a.k.deltap * g.hij) * g.h1;
-                    double wdp = SphKernel<KK>::w(qd) * g.fac;
-                    double fij = wij / wdp;
+                    const double qd = (a.k.deltap * g.hij) * g.h1;
+                    const double wdp = SphKernel<KK>::w(qd) * g.fac;
+                    double fij = wij * fast_rcp(wdp);
                     fij = fij * fij;
                     fij = fij * fij;
-                    double Ri = D.p > 0 ? 0.01 * D.tmpi : 0.2 * fabs(D.tmpi);
-                    double Rj = s[5] > 0 ? 0.01 * tmpj : 0.2 * fabs(tmpj);
+                    const double Ri = D.p > 0 ? 0.01 * D.tmpi : 0.2 * fabs(D.tmpi);
+                    const double Rj = s[7] > 0 ? 0.01 * tmpj : 0.2 * fabs(tmpj);
                     tmp = (D.tmpi + tmpj) + (Ri + Rj) * fij;
                 }
-                double f = -mj * (tmp + piij);
-                D.au += f * dw0;
-                D.av += f * dw1;
-                D.aw += f * dw2;
+                const double ft = -mj * (tmp + piij) * tg;
+                D.au = fma(ft, g.xij[0], D.au);
+                D.av = fma(ft, g.xij[1], D.av);
+                D.aw = fma(ft, g.xij[2], D.aw);
+            } else {
+                rhoij1 = fast_rcp(rhoij);
             }
             if (fl & F_XSPH) { // basic_equations.py:290-295
-                double tmp = -a.p.eps * mj * wij * rhoij1;
-                D.ax += tmp * vij0;
-                D.ay += tmp * vij1;
-                D.az += tmp * vij2;
+                const double tmp = -a.p.eps * mj * wij * rhoij1;
+                D.ax = fma(tmp, vij0, D.ax);
+                D.ay = fma(tmp, vij1, D.ay);
+                D.az = fma(tmp, vij2, D.az);
             }
         }
     }
@@ -266,15 +324,16 @@ struct FamWCSPH {
 // ---- density summations (basic_equations.py:19-29, transport_velocity.py:24-58)
 struct FamDensity {
     static constexpr int NA = 1; // m
+    static constexpr int NR = 6;  // x y z h m pad
     struct Params { double *rho, *V; };
     struct Dest { double m, rho, V; };
     static __device__ __forceinline__ void load(Dest &D, const double *a) { D.m = a[0]; D.rho = 0.0; D.V = 0.0; }
-    template <int KK, class A>
+    template <int KK, bool UH, class A>
     static __device__ __forceinline__ void pair(Dest &D, const double4 &pi, const double4 &pj, double r2,
-                                                const double *__restrict__ s, uint32_t fl, const A &a)
+                                                const double (&s)[NA], uint32_t fl, const A &a)
     {
         PairGeom g;
-        pair_geom<KK>(g, pi, pj, r2, a.k);
+        pair_geom<KK, UH>(g, pi, pj, r2, a);
         double wij = pair_w<KK>(g);
         if (fl & F_SD) D.rho += s[0] * wij;
         if (fl & F_TVFSD) { D.V += wij; D.rho += D.m * wij; }
@@ -289,6 +348,7 @@ struct FamDensity {
 // ---- TVF momentum terms (transport_velocity.py:219-545) -------------------
 struct FamTVF {
     static constexpr int NA = 12; // u v w uhat vhat what rho p V m Vj2 pad
+    static constexpr int NR = 16; // x y z h + NA
     struct Params {
         double pb, gx, gy, gz, tdamp, nu, c0, alpha;
         double *au, *av, *aw, *auhat, *avhat, *awhat;
@@ -303,12 +363,12 @@ struct FamTVF {
         D.rho = a[6]; D.p = a[7]; D.Vi2 = a[10]; D.mi1 = 1.0 / a[9];
         D.au = D.av = D.aw = D.auh = D.avh = D.awh = 0.0;
     }
-    template <int KK, class A>
+    template <int KK, bool UH, class A>
     static __device__ __forceinline__ void pair(Dest &D, const double4 &pi, const double4 &pj, double r2,
-                                                const double *__restrict__ s, uint32_t fl, const A &a)
+                                                const double (&s)[NA], uint32_t fl, const A &a)
     {
         PairGeom g;
-        pair_geom<KK>(g, pi, pj, r2, a.k);
+        pair_geom<KK, UH>(g, pi, pj, r2, a);
         double tg = pair_gradfac<KK>(g);
         double dw0 = tg * g.xij[0], dw1 = tg * g.xij[1], dw2 = tg * g.xij[2];
         double rhoj = s[6], Vj2 = s[10];
@@ -316,7 +376,7 @@ struct FamTVF {
         double vij0 = D.u - s[0], vij1 = D.v - s[1], vij2 = D.w - s[2];
         if (fl & F_TP) { // :290-320
             double pij = rhoj * D.p + D.rho * s[7];
-            pij /= (rhoj + D.rho);
+            pij *= fast_rcp(rhoj + D.rho);
             double tmp = -pij * D.mi1 * vsum;
             D.au += tmp * dw0; D.av += tmp * dw1; D.aw += tmp * dw2;
             tmp = -a.p.pb * D.mi1 * vsum;
@@ -326,19 +386,17 @@ struct FamTVF {
             double vijdotrij = vij0 * g.xij[0] + vij1 * g.xij[1] + vij2 * g.xij[2];
             double piij = 0.0;
             if (vijdotrij < 0) {
-                double eps = 0.01 * g.hij * g.hij;
-                double muij = (g.hij * vijdotrij) / (r2 + eps);
+                double muij = (g.hij * vijdotrij) * fast_rcp(r2 + g.eps);
                 piij = -a.p.alpha * a.p.c0 * muij;
-                piij = s[9] * piij * (1.0 / (0.5 * (D.rho + rhoj)));
+                piij = s[9] * piij * fast_rcp(0.5 * (D.rho + rhoj));
             }
             D.au += -piij * dw0; D.av += -piij * dw1; D.aw += -piij * dw2;
         }
         if (fl & F_TVISC) { // :363-384
             double etai = a.p.nu * D.rho, etaj = a.p.nu * rhoj;
-            double etaij = 2 * (etai * etaj) / (etai + etaj);
+            double etaij = 2 * (etai * etaj) * fast_rcp(etai + etaj);
             double Fij = dw0 * g.xij[0] + dw1 * g.xij[1] + dw2 * g.xij[2];
-            double eps = 0.01 * g.hij * g.hij;
-            double tmp = D.mi1 * vsum * etaij * Fij / (r2 + eps);
+            double tmp = D.mi1 * vsum * etaij * Fij * fast_rcp(r2 + g.eps);
             D.au += tmp * vij0; D.av += tmp * vij1; D.aw += tmp * vij2;
         }
         if (fl & F_TAS) { // :473-545
@@ -371,7 +429,13 @@ struct FamTVF {
 // ---------------------------------------------------------------------------
 // variant 0: per-lane walk over the 3x3 rows of cells (x-contiguous ranges)
 // ---------------------------------------------------------------------------
-template <class Fam, int KK> __global__ __launch_bounds__(256) void k_pair_direct(PairArgs<Fam> a)
+template <class Fam> __device__ __forceinline__ void load_aux(double (&s)[Fam::NA], const double *__restrict__ p)
+{
+#pragma unroll
+    for (int k = 0; k < Fam::NA; k++) s[k] = p[k];
+}
+
+template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256) void k_pair_direct(PairArgs<Fam> a)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.nd) return;
@@ -400,8 +464,11 @@ template <class Fam, int KK> __global__ __launch_bounds__(256) void k_pair_direc
                     double hj2 = a.radius_scale * pj.w;
                     hj2 *= hj2;
                     double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-                    if ((r2 < hi2) || (r2 < hj2))
-                        Fam::template pair<KK>(D, pi, pj, r2, a.aux + (size_t)(sd.off + j) * Fam::NA, sd.flags, a);
+                    if ((r2 < hi2) || (r2 < hj2)) {
+                        double sj[Fam::NA];
+                        load_aux<Fam>(sj, a.aux + (size_t)(sd.off + j) * Fam::NA);
+                        Fam::template pair<KK, UH>(D, pi, pj, r2, sj, sd.flags, a);
+                    }
                 }
             }
     }
@@ -415,7 +482,7 @@ template <class Fam, int KK> __global__ __launch_bounds__(256) void k_pair_direc
 #define TILE 64
 #define MAXCH 18
 
-template <class Fam, int KK> __global__ __launch_bounds__(64) void k_pair_tiled(PairArgs<Fam> a)
+template <class Fam, int KK, bool UH, int WPE> __global__ __launch_bounds__(64, WPE) void k_pair_tiled(PairArgs<Fam> a)
 {
     __shared__ float4 tile[TILE];
     __shared__ unsigned long long masks[MAXCH][64];
@@ -435,32 +502,56 @@ template <class Fam, int KK> __global__ __launch_bounds__(64) void k_pair_tiled(
     const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
     const int cx = key % ncx;
     const int row = key / ncx;
-    double hi2 = a.radius_scale * pi.w;
-    hi2 *= hi2;
     const double hi_r = a.radius_scale * pi.w;
+    const double hi2 = UH ? a.hr2u : hi_r * hi_r;
 
     const int row_first = __builtin_amdgcn_readfirstlane(row);
     const int row_last = __builtin_amdgcn_readlane(row, 63);
     int nch = 0;
 
+    // ---- phase 2: every lane walks its own hit bits; the next hit's record is
+    // fetched while the current pair is being computed (two register stages)
+    struct Hit {
+        bool has;
+        uint32_t fl;
+        double4 pj;
+        double s[Fam::NA];
+    };
+    int cur_c = 0;
+    unsigned long long cur_m = 0;
+    auto fetch = [&](Hit &h) {
+        while (cur_m == 0 && cur_c + 1 < nch) { ++cur_c; cur_m = masks[cur_c][lane]; }
+        h.has = cur_m != 0;
+        if (h.has) {
+            const int kbit = __builtin_ctzll(cur_m);
+            cur_m &= cur_m - 1;
+            const uint32_t jg = chbase[cur_c] + kbit;
+            h.fl = chflags[cur_c];
+            h.pj = a.posh[jg];
+            load_aux<Fam>(h.s, a.aux + (size_t)jg * Fam::NA);
+        }
+    };
+    auto compute = [&](const Hit &h) {
+        if (h.has) {
+            double hj2 = hi2;
+            if (!UH) { hj2 = a.radius_scale * h.pj.w; hj2 *= hj2; }
+            const double r2 = r2_exact(pi.x - h.pj.x, pi.y - h.pj.y, pi.z - h.pj.z);
+            if (((r2 < hi2) || (r2 < hj2)) && a.ablate != 1)
+                Fam::template pair<KK, UH>(D, pi, h.pj, r2, h.s, h.fl, a);
+        }
+    };
     auto phase2 = [&]() {
-        if (a.ablate == 2) { nch = 0; __syncthreads(); return; }
-        int c = 0;
-        unsigned long long m = nch > 0 ? masks[0][lane] : 0ull;
-        for (;;) {
-            while (m == 0 && c + 1 < nch) { ++c; m = masks[c][lane]; }
-            bool has = m != 0;
-            if (!__any(has)) break;
-            if (has) {
-                int kbit = __builtin_ctzll(m);
-                m &= m - 1;
-                uint32_t jg = chbase[c] + kbit;
-                double4 pj = a.posh[jg];
-                double hj2 = a.radius_scale * pj.w;
-                hj2 *= hj2;
-                double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-                if (((r2 < hi2) || (r2 < hj2)) && a.ablate != 1)
-                    Fam::template pair<KK>(D, pi, pj, r2, a.aux + (size_t)jg * Fam::NA, chflags[c], a);
+        if (a.ablate != 2 && nch > 0) {
+            cur_c = 0;
+            cur_m = masks[0][lane];
+            Hit A, B;
+            fetch(A);
+            while (__any(A.has)) {
+                fetch(B);
+                compute(A);
+                if (!__any(B.has)) break;
+                fetch(A);
+                compute(B);
             }
         }
         nch = 0;
@@ -480,11 +571,11 @@ template <class Fam, int KK> __global__ __launch_bounds__(64) void k_pair_tiled(
         const double oy = a.xmin[1] + a.cell_size * (cyR - 1);
         const double oz = a.xmin[2] + a.cell_size * (czR - 1);
         // conservative slack for the fp32 test: coordinates up to L from the
-        // origin carry <= 2^-23 L rounding each; three axes, two operands.
+        // origin carry <= 2^-24 L rounding each (see DESIGN.md "prefilter")
         const double L = a.cell_size * (double)max(xb - xa + 2, 4);
         const float slack = (float)(L * 1.5e-6);
         const float fx = (float)(pi.x - ox), fy = (float)(pi.y - oy), fz = (float)(pi.z - oz);
-        float hif = (float)hi_r * 1.000001f + slack;
+        const float hif = (float)hi_r * 1.000001f + slack;
         const float hi2f = hif * hif;
 
         for (int s = 0; s < a.nsrc; s++) {
@@ -516,7 +607,7 @@ template <class Fam, int KK> __global__ __launch_bounds__(64) void k_pair_tiled(
                                     const float4 tk = tile[k0 + k];
                                     const float ex = fx - tk.x, ey = fy - tk.y, ez = fz - tk.z;
                                     const float r2 = ex * ex + ey * ey + ez * ez;
-                                    const bool hit = (r2 < hi2f) | (r2 < tk.w);
+                                    const bool hit = UH ? (r2 < hi2f) : ((r2 < hi2f) | (r2 < tk.w));
                                     mm |= hit ? (1u << k) : 0u;
                                 }
                                 m |= (unsigned long long)mm << k0;
@@ -534,6 +625,160 @@ template <class Fam, int KK> __global__ __launch_bounds__(64) void k_pair_tiled(
     phase2();
     if (active) Fam::finish(D, a, o);
 }
+
+// ---------------------------------------------------------------------------
+// variant 2 (default): one workgroup = 256 consecutive (cell-ordered)
+// destinations = 4 wavefronts.  For each of the 3x3 neighbouring rows of cells
+// the whole x-range of candidate records the workgroup needs (~290 records of
+// 96 B for WCSPH) is staged ONCE into LDS with coalesced 16-B loads; each
+// wavefront then
+//   phase 1: tests its own sub-range of the tile against its 64 destinations
+//            in fp32 (conservative slack), LDS broadcast reads, one hit bit per
+//            candidate per lane kept in two 64-bit registers;
+//   phase 2: every lane walks its own hit bits and reads the full fp64 record
+//            from LDS (no global gather), applies the reference's exact fp64
+//            criterion and runs the fused pair arithmetic.
+// HBM/L2 traffic per destination drops to ~1 KB (vs ~7 KB of per-pair gathers).
+// ---------------------------------------------------------------------------
+#define TCAP 320  // records per LDS tile
+#define SUBW 128  // candidates per phase-1/phase-2 round of one wavefront
+
+template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256) void k_pair_wg(PairArgs<Fam> a)
+{
+    constexpr int NR = Fam::NR;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *lrec = reinterpret_cast<double *>(smem);                       // TCAP * NR doubles
+    float4 *ftile = reinterpret_cast<float4 *>(smem + (size_t)TCAP * NR * 8); // TCAP
+    int *wx = reinterpret_cast<int *>(smem + (size_t)TCAP * NR * 8 + (size_t)(TCAP + 8) * 16); // [4][2] + [2]
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint32_t i = blockIdx.x * 256 + t;
+    const bool valid = i < a.nd;
+    const uint32_t ic = valid ? i : a.nd - 1;
+    const uint32_t o = a.d_perm[ic];
+    const bool active = valid && o >= a.d_start && o < a.d_stop;
+    const double *drec = a.rec + (size_t)(a.d_off + ic) * NR;
+    const double4 pi = *reinterpret_cast<const double4 *>(drec);
+    typename Fam::Dest D;
+    Fam::load(D, drec + 4);
+    const uint32_t key = a.d_keys[ic];
+    const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
+    const int cx = key % ncx;
+    const int row = key / ncx;
+    const double hi_r = a.radius_scale * pi.w;
+    const double hi2 = UH ? a.hr2u : hi_r * hi_r;
+
+    if (t == 0) wx[8] = row;
+    if (t == 255) wx[9] = row;
+    __syncthreads();
+    const int row_first = wx[8], row_last = wx[9];
+
+    for (int R = row_first; R <= row_last; R++) {
+        const bool inseg = active && row == R;
+        const unsigned long long segm = __ballot(inseg);
+        int cxa_w = 0x7fffffff, cxb_w = -1;
+        if (segm) {
+            cxa_w = __builtin_amdgcn_readlane(cx, __builtin_ctzll(segm));
+            cxb_w = __builtin_amdgcn_readlane(cx, 63 - __builtin_clzll(segm));
+        }
+        __syncthreads(); // previous iteration's readers of wx are done
+        if (lane == 0) { wx[2 * wv] = cxa_w; wx[2 * wv + 1] = cxb_w; }
+        __syncthreads();
+        const int cxa = min(min(wx[0], wx[2]), min(wx[4], wx[6]));
+        const int cxb = max(max(wx[1], wx[3]), max(wx[5], wx[7]));
+        if (cxb < 0) continue; // nothing to do in this row (uniform over the workgroup)
+        const int cyR = R % ncy, czR = R / ncy;
+        const int xa = max(cxa - 1, 0), xb = min(cxb + 1, ncx - 1);
+        const int wxa = max(cxa_w - 1, 0), wxb = min(cxb_w + 1, ncx - 1);
+        // fp32 coordinates are relative to this row segment's origin
+        const double ox = a.xmin[0] + a.cell_size * xa;
+        const double oy = a.xmin[1] + a.cell_size * (cyR - 1);
+        const double oz = a.xmin[2] + a.cell_size * (czR - 1);
+        const double L = a.cell_size * (double)max(xb - xa + 2, 4);
+        const float slack = (float)(L * 1.5e-6);
+        const float fx = (float)(pi.x - ox), fy = (float)(pi.y - oy), fz = (float)(pi.z - oz);
+        const float hif = (float)hi_r * 1.000001f + slack;
+        const float hi2f = hif * hif;
+
+        for (int s = 0; s < a.nsrc; s++) {
+            const SrcDesc sd = a.src[s];
+            for (int dz = -1; dz <= 1; dz++)
+                for (int dy = -1; dy <= 1; dy++) {
+                    const int yy = cyR + dy, zz = czR + dz;
+                    if (yy < 0 || yy >= ncy || zz < 0 || zz >= ncz) continue;
+                    const uint32_t rowb = (uint32_t)(ncx * (yy + ncy * zz));
+                    const uint32_t j0 = sd.cell_start[rowb + xa], j1 = sd.cell_start[rowb + xb + 1];
+                    uint32_t wj0 = 0, wj1 = 0;
+                    if (segm) { wj0 = sd.cell_start[rowb + wxa]; wj1 = sd.cell_start[rowb + wxb + 1]; }
+                    for (uint32_t tb = j0; tb < j1; tb += TCAP) {
+                        const int tn = (int)min((uint32_t)TCAP, j1 - tb);
+                        // ---- stage tn records: coalesced 16-B pieces, global -> LDS
+                        {
+                            const double2 *g = reinterpret_cast<const double2 *>(a.rec + (size_t)(sd.off + tb) * NR);
+                            double2 *l = reinterpret_cast<double2 *>(lrec);
+                            const int np = tn * (NR / 2);
+                            for (int q = t; q < np; q += 256) l[q] = g[q];
+                        }
+                        __syncthreads();
+                        // ---- fp32 prefilter tile
+                        for (int r = t; r < tn; r += 256) {
+                            const double4 pj = *reinterpret_cast<const double4 *>(lrec + (size_t)r * NR);
+                            const float hjf = (float)(a.radius_scale * pj.w) * 1.000001f + slack;
+                            ftile[r] = make_float4((float)(pj.x - ox), (float)(pj.y - oy), (float)(pj.z - oz), hjf * hjf);
+                        }
+                        __syncthreads();
+                        // ---- this wavefront's sub-range of the tile
+                        const int k_lo = (int)(max(wj0, tb) - tb);
+                        const int k_hi = (int)min((long)wj1 - (long)tb, (long)tn);
+                        for (int kb = k_lo; kb < k_hi; kb += SUBW) {
+                            const int kn = min(SUBW, k_hi - kb);
+                            unsigned long long m0 = 0, m1 = 0;
+                            if (inseg) {
+                                for (int k0 = 0; k0 < kn; k0 += 8) {
+                                    unsigned mm = 0;
+#pragma unroll
+                                    for (int k = 0; k < 8; k++) {
+                                        // reads past kn stay inside the LDS tile allocation (TCAP + 8 slots)
+                                        const float4 tk = ftile[kb + k0 + k];
+                                        const float ex = fx - tk.x, ey = fy - tk.y, ez = fz - tk.z;
+                                        const float r2 = ex * ex + ey * ey + ez * ez;
+                                        bool hit = UH ? (r2 < hi2f) : ((r2 < hi2f) | (r2 < tk.w));
+                                        hit &= (k0 + k) < kn;
+                                        mm |= hit ? (1u << k) : 0u;
+                                    }
+                                    if (k0 < 64) m0 |= (unsigned long long)mm << k0;
+                                    else m1 |= (unsigned long long)mm << (k0 - 64);
+                                }
+                            }
+                            if (a.ablate == 2) continue;
+                            while (__any((m0 | m1) != 0)) {
+                                if ((m0 | m1) != 0) {
+                                    int kbit;
+                                    if (m0) { kbit = __builtin_ctzll(m0); m0 &= m0 - 1; }
+                                    else { kbit = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
+                                    const double *rj = lrec + (size_t)(kb + kbit) * NR;
+                                    const double4 pj = *reinterpret_cast<const double4 *>(rj);
+                                    double hj2 = hi2;
+                                    if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
+                                    const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+                                    if (((r2 < hi2) || (r2 < hj2)) && a.ablate != 1) {
+                                        double sj[Fam::NA];
+#pragma unroll
+                                        for (int k = 0; k < Fam::NA; k++) sj[k] = rj[4 + k];
+                                        Fam::template pair<KK, UH>(D, pi, pj, r2, sj, sd.flags, a);
+                                    }
+                                }
+                            }
+                        }
+                        __syncthreads(); // tile is overwritten next
+                    }
+                }
+        }
+    }
+    if (active) Fam::finish(D, a, o);
+}
+
+template <class Fam> static size_t wg_lds_bytes() { return (size_t)TCAP * Fam::NR * 8 + (size_t)(TCAP + 8) * 16 + 64; }
 
 // ---------------------------------------------------------------------------
 // host driver
@@ -607,7 +852,7 @@ static PackPlan pack_plan(int fam)
     p.derived = 0;
     if (fam == FAM_WCSPH) {
         p.na = 8;
-        int pr[8] = {SPH_U, SPH_V, SPH_W, SPH_M, SPH_RHO, SPH_P, SPH_CS, -1};
+        int pr[8] = {SPH_U, SPH_V, SPH_W, SPH_M, SPH_RHO, -1, SPH_CS, SPH_P};
         for (int k = 0; k < 8; k++) p.props[k] = pr[k];
         p.derived = 1;
     } else if (fam == FAM_DENSITY) {
@@ -659,6 +904,9 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
     pa.derived = pl.derived;
     pa.posh = c->posh.as<double4>();
     pa.aux = c->aux.as<double>();
+    pa.rec = nullptr;
+    pa.nr = 4 + ((pl.na + 1) & ~1);
+    if (c->pair_variant == 2) pa.rec = c->posh.as<double>();
     hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, pa);
     return SPH_OK;
 }
@@ -667,10 +915,30 @@ template <class Fam> static void launch_pair(sph_ctx *c, int kk, const PairArgs<
 {
     if (a.nd == 0) return;
     const bool tiled = c->pair_variant != 0;
+    const bool uh = c->uniform_h && c->use_uniform_h;
+    if (c->pair_variant == 2) {
+        dim3 g2(div_up(a.nd, 256)), b2(256);
+        size_t lds = wg_lds_bytes<Fam>();
+#define LAUNCH2(K)                                                                               \
+        if (uh) hipLaunchKernelGGL((k_pair_wg<Fam, K, true>), g2, b2, lds, c->stream, a);        \
+        else hipLaunchKernelGGL((k_pair_wg<Fam, K, false>), g2, b2, lds, c->stream, a)
+        switch (kk) {
+        case 1: LAUNCH2(1); break;
+        case 2: LAUNCH2(2); break;
+        case 3: LAUNCH2(3); break;
+        case 4: LAUNCH2(4); break;
+        }
+#undef LAUNCH2
+        return;
+    }
     dim3 gt(div_up(a.nd, 64)), bt(64), gd(div_up(a.nd, 256)), bd(256);
-#define LAUNCH(K)                                                                        \
-    if (tiled) hipLaunchKernelGGL((k_pair_tiled<Fam, K>), gt, bt, 0, c->stream, a);    \
-    else hipLaunchKernelGGL((k_pair_direct<Fam, K>), gd, bd, 0, c->stream, a)
+#define LAUNCH(K)                                                                                \
+    if (tiled && uh && c->wpe == 4) hipLaunchKernelGGL((k_pair_tiled<Fam, K, true, 4>), gt, bt, 0, c->stream, a);   \
+    else if (tiled && uh && c->wpe == 3) hipLaunchKernelGGL((k_pair_tiled<Fam, K, true, 3>), gt, bt, 0, c->stream, a);   \
+    else if (tiled && uh) hipLaunchKernelGGL((k_pair_tiled<Fam, K, true, 2>), gt, bt, 0, c->stream, a);   \
+    else if (tiled) hipLaunchKernelGGL((k_pair_tiled<Fam, K, false, 2>), gt, bt, 0, c->stream, a);   \
+    else if (uh) hipLaunchKernelGGL((k_pair_direct<Fam, K, true>), gd, bd, 0, c->stream, a);      \
+    else hipLaunchKernelGGL((k_pair_direct<Fam, K, false>), gd, bd, 0, c->stream, a)
     switch (kk) {
     case 1: LAUNCH(1); break;
     case 2: LAUNCH(2); break;
@@ -685,6 +953,7 @@ static void fill_common(sph_ctx *c, PairArgs<Fam> &a, const sph_kernel *K, doubl
 {
     a.posh = c->posh.as<double4>();
     a.aux = c->aux.as<double>();
+    a.rec = c->posh.as<double>();
     for (int k = 0; k < 3; k++) { a.nc[k] = c->nc[k]; a.xmin[k] = c->xmin[k]; }
     a.cell_size = c->cell_size;
     a.radius_scale = c->radius_scale;
@@ -693,6 +962,14 @@ static void fill_common(sph_ctx *c, PairArgs<Fam> &a, const sph_kernel *K, doubl
     a.k.dim = K->dim;
     a.t = t;
     a.ablate = (int)c->ablate;
+    // uniform-h constants, computed as the general path would per pair
+    a.hu = 0.5 * (c->h_uniform + c->h_uniform);
+    a.h1u = 1.0 / a.hu;
+    a.facu = K->fac * a.h1u;
+    if (K->dim > 1) a.facu *= a.h1u;
+    if (K->dim > 2) a.facu *= a.h1u;
+    a.epsu = 0.01 * a.hu * a.hu;
+    a.hr2u = (c->radius_scale * c->h_uniform) * (c->radius_scale * c->h_uniform);
 }
 
 static int ensure_out(sph_ctx *c, int id, std::initializer_list<int> props)
@@ -785,7 +1062,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         else for (int j = 0; j < nsrcs; j++) if (srcs[j] == dst) d_off = off_of[j];
         if (total >= (1ull << 32)) { sph_set_error("too many particles for 32-bit packed indices"); return SPH_ERR_ARG; }
         PackPlan pl = pack_plan(fam);
-        SPH_TRY(c->posh.reserve((total + 64) * sizeof(double4)));
+        SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * (c->pair_variant == 2 ? 4 + ((pl.na + 1) & ~1) : 4)));
         SPH_TRY(c->aux.reserve((total + 64) * sizeof(double) * pl.na));
         {
             ScopedTimer tm(c, T_PACK);

@@ -37,11 +37,6 @@ __global__ __launch_bounds__(256) void k_halo_gather(const double *__restrict__ 
     dst[i] = src[list[i]] + shift;
 }
 
-struct HaloState {
-    DevBuf flag[2], pos[2], list[2];
-    size_t count[2] = {0, 0};
-};
-static HaloState g_halo[SPH_MAX_ARRAYS]; // per array id (one context per process in multi-GPU runs)
 
 extern "C" int sph_halo_select(sph_ctx *c, int id, int axis, double lo_cut, double hi_cut, size_t *counts)
 {
@@ -51,7 +46,7 @@ extern "C" int sph_halo_select(sph_ctx *c, int id, int axis, double lo_cut, doub
     }
     HIP_TRY(hipSetDevice(c->device));
     DevArray &A = c->arr[id];
-    HaloState &H = g_halo[id];
+    HaloState &H = c->halo[id];
     size_t n = A.n_real;
     counts[0] = counts[1] = 0;
     H.count[0] = H.count[1] = 0;
@@ -96,7 +91,7 @@ extern "C" int sph_halo_pack(sph_ctx *c, int id, int side, int nprops, const int
     }
     HIP_TRY(hipSetDevice(c->device));
     DevArray &A = c->arr[id];
-    HaloState &H = g_halo[id];
+    HaloState &H = c->halo[id];
     size_t cnt = H.count[side];
     if (cnt == 0) return SPH_OK;
     for (int k = 0; k < nprops; k++) {

@@ -50,6 +50,12 @@ struct DevArray {
     int nnps_slot = -1;                  // position in the last sph_nnps_update list
 };
 
+// ghost selection lists of one array (sph_halo.hip)
+struct HaloState {
+    DevBuf flag[2], pos[2], list[2];
+    size_t count[2] = {0, 0};
+};
+
 enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_SCATTER, T_COUNT };
 
 struct Timer {
@@ -63,6 +69,7 @@ struct sph_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     DevArray arr[SPH_MAX_ARRAYS];
+    HaloState halo[SPH_MAX_ARRAYS];
 
     // grid of the last sph_nnps_update
     bool nnps_valid = false;
@@ -81,8 +88,10 @@ struct sph_ctx {
     double *pinned = nullptr; // small pinned host buffer (64 doubles)
 
     // options
-    long pair_variant = 1;
+    long pair_variant = 2;
     long ablate = 0;
+    long use_uniform_h = 1;
+    long wpe = 2;
     long block_sorted_outputs = 0;
 
     // timers

@@ -22,6 +22,8 @@ template <class R> __device__ __forceinline__ R kernel_norm(R sigma, R h1, int d
 }
 
 template <> struct SphKernel<1> { // CubicSpline
+    static constexpr bool HAS_DWQ = false;
+    template <class R> static __device__ __forceinline__ R dwq(R) { return R(0); }
     template <class R> static __device__ __forceinline__ R w(R q)
     {
         R t2 = R(2) - q;
@@ -39,6 +41,12 @@ template <> struct SphKernel<1> { // CubicSpline
 };
 
 template <> struct SphKernel<2> { // WendlandQuintic
+    static constexpr bool HAS_DWQ = true; // dw/q = -5 (1 - q/2)^3: no division by r needed
+    template <class R> static __device__ __forceinline__ R dwq(R q)
+    {
+        R t = R(1) - R(0.5) * q;
+        return q < R(2) ? R(-5) * t * t * t : R(0);
+    }
     template <class R> static __device__ __forceinline__ R w(R q)
     {
         R t = R(1) - R(0.5) * q;
@@ -54,6 +62,8 @@ template <> struct SphKernel<2> { // WendlandQuintic
 };
 
 template <> struct SphKernel<3> { // QuinticSpline
+    static constexpr bool HAS_DWQ = false;
+    template <class R> static __device__ __forceinline__ R dwq(R) { return R(0); }
     template <class R> static __device__ __forceinline__ R w(R q)
     {
         R t3 = R(3) - q, t2 = R(2) - q, t1 = R(1) - q;
@@ -73,6 +83,8 @@ template <> struct SphKernel<3> { // QuinticSpline
 };
 
 template <> struct SphKernel<4> { // Gaussian
+    static constexpr bool HAS_DWQ = true; // dw/q = -2 exp(-q^2)
+    template <class R> static __device__ __forceinline__ R dwq(R q) { return q < R(3) ? R(-2) * exp(-q * q) : R(0); }
     template <class R> static __device__ __forceinline__ R w(R q) { return q < R(3) ? exp(-q * q) : R(0); }
     template <class R> static __device__ __forceinline__ R dw(R q)
     {

@@ -253,7 +253,7 @@ class HipDeviceHelper(object):
                                % p)
             _check(self.lib.sph_array_pull(
                 self.ctx._h, self.array_id, pid, arr.ctypes.data_as(_PD), 0,
-                min(arr.size, self._n)))
+                min(arr.size, self.get_number_of_particles())))
 
     def max(self, prop):
         out = C.c_double()

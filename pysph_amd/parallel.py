@@ -127,17 +127,14 @@ class SlabHalo(object):
         nbrs = self.neighbours()
         if not nbrs:
             return
-        # 1. counts handshake (8-byte messages)
+        # 1. counts handshake: one tiny all_gather of (n_lo, n_hi) per rank
         send_cnt = {0: n_lo, 1: n_hi}
-        cnt_out = {s: ops.int_tensor([send_cnt[s]]) for s, _, _ in nbrs}
-        cnt_in = {s: ops.int_tensor([0]) for s, _, _ in nbrs}
-        reqs = []
-        for s, peer, _ in nbrs:
-            reqs.append(dist.P2POp(dist.isend, cnt_out[s], peer))
-            reqs.append(dist.P2POp(dist.irecv, cnt_in[s], peer))
-        for w in dist.batch_isend_irecv(reqs):
-            w.wait()
-        recv_cnt = {s: int(cnt_in[s].item()) for s, _, _ in nbrs}
+        mine = ops.int_tensor([n_lo, n_hi])
+        allc = ops.int_tensor([0] * (2 * self.world))
+        dist.all_gather_into_tensor(allc, mine)
+        allc = [int(v) for v in allc.cpu()]
+        # what peer sends to me: its hi list if it is my lo neighbour, else lo
+        recv_cnt = {s: allc[2 * peer + (1 - s)] for s, peer, _ in nbrs}
         # 2. payloads: one flat [nprops][count] buffer per neighbour
         out_buf = {s: ops.pack(s, send_cnt[s], shift) for s, _, shift in nbrs}
         in_buf = {s: ops.new_buffer(recv_cnt[s]) for s, _, _ in nbrs}

@@ -18,7 +18,7 @@ TOL = 1e-10
 CASES = ['sd_1d_line', 'wcsph_cube_varh', 'tvf_cube', 'wcsph_dam_dx0.1']
 
 
-def make_eval(arrays, eqs, kernel, dim, variant=1, sync='auto'):
+def make_eval(arrays, eqs, kernel, dim, variant=2, sync='auto'):
     from pysph_amd import device as dev
     from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
     from pysph_amd.nnps import HipNNPS
@@ -31,7 +31,7 @@ def make_eval(arrays, eqs, kernel, dim, variant=1, sync='auto'):
     return a_eval, nnps, ctx
 
 
-@pytest.mark.parametrize('variant', [0, 1])
+@pytest.mark.parametrize('variant', [0, 1, 2])
 @pytest.mark.parametrize('case', CASES)
 def test_golden_parity(case, variant):
     g = load_golden(case + '.npz')
@@ -103,7 +103,7 @@ def _copy_arrays(arrays):
     return out
 
 
-@pytest.mark.parametrize('variant', [0, 1])
+@pytest.mark.parametrize('variant', [0, 1, 2])
 def test_dam_break_27k_vs_oracle(oracle, variant):
     """BASELINE config 1: dam_break_3d, dx=0.04 (9360+15152+160 particles)."""
     from pysph_amd.examples import dam_break_3d as db
@@ -158,7 +158,8 @@ def cube_equations(dx, hdx=1.3):
     return s.get_equations()
 
 
-@pytest.mark.parametrize('variant,varh', [(0, 0.0), (1, 0.0), (1, 0.2)])
+@pytest.mark.parametrize('variant,varh', [(0, 0.0), (1, 0.0), (1, 0.2),
+                                          (2, 0.0), (2, 0.2)])
 def test_cube_100k_vs_oracle(oracle, variant, varh):
     from pysph_amd import kernels as K
     pa, dx = make_cube(46, varh=varh)
@@ -191,16 +192,17 @@ def test_full_size_1m_properties():
     eqs = cube_equations(dx)
     kernel = K.WendlandQuintic(dim=3)
     res = {}
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         q = _copy_arrays([pa])
         a_eval, nnps, ctx = make_eval(q, eqs, kernel, 3, variant)
         a_eval.compute(0.0, 1e-5)
         res[variant] = q[0]
         ctx.close()
     for prop in WC_OUT:
-        a, b = res[0].properties[prop], res[1].properties[prop]
-        assert np.all(np.isfinite(a))
-        assert rel_err(a, b) < 1e-12, prop
+        a, b, c = (res[v].properties[prop] for v in (0, 1, 2))
+        assert np.all(np.isfinite(c))
+        assert rel_err(a, c) < 1e-12, prop
+        assert rel_err(b, c) < 1e-12, prop
 
 
 def test_group_semantics_real_start_stop(oracle):
@@ -302,7 +304,7 @@ def test_edge_cases_empty_single_and_2d(oracle):
     ref = _copy_arrays([pa])
     eqs = [Group(equations=[SummationDensity(dest='fluid', sources=['fluid'])])]
     kernel = K.WendlandQuintic(dim=2)
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         q = _copy_arrays([pa])
         a_eval, nnps, ctx = make_eval(q, eqs, kernel, 2, variant)
         a_eval.compute(0.0, 0.1)
@@ -354,3 +356,62 @@ def test_dt_reductions_on_device():
     a_eval.compute(0.0, 1e-5)
     assert pa.gpu.max('dt_cfl') == pa.dt_cfl.max()
     assert pa.gpu.max('dt_force') == pa.dt_force.max()
+
+
+def test_halo_device_ops_two_slabs_one_gpu(oracle):
+    """Device side of the multi-GPU path on ONE GPU: two
+    contexts play two slab ranks; ghosts are selected/packed/appended by the
+    HIP halo kernels (sph_halo_select/pack/append) and handed over as torch
+    buffers (what RCCL send/recv would move).  Real-particle results of both
+    slabs must equal the single-domain oracle, matched by global index."""
+    import torch
+    from pysph_amd import device as dev
+    from pysph_amd import kernels as K
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.nnps import HipNNPS
+    from pysph_amd.parallel import DeviceHaloOps, WCSPH_HALO_PROPS
+    from pysph_amd.particle_array import ParticleArray
+    full, dx = make_cube(24)
+    kernel = K.WendlandQuintic(dim=3)
+    eqs = cube_equations(dx)
+    width = kernel.radius_scale * 1.3 * dx
+    x = full.x
+    parts = [np.nonzero(x < 0.5)[0], np.nonzero(x >= 0.5)[0]]
+    ranks = []
+    for r, own in enumerate(parts):
+        pa = ParticleArray(name='fluid', **{k: v[own].copy() for k, v in
+                                            full.properties.items()})
+        ctx = dev.HipContext(0)
+        dev.attach(pa, ctx).push()
+        ops = DeviceHaloOps(pa, ctx, WCSPH_HALO_PROPS, 0)
+        lo, hi = (-1e30, 0.5) if r == 0 else (0.5, 1e30)
+        ops.drop_ghosts()
+        n_lo, n_hi = ops.select(lo + width, hi - width)
+        ranks.append(dict(pa=pa, ctx=ctx, ops=ops, own=own, n=(n_lo, n_hi)))
+    # rank 0 sends its hi list to rank 1, rank 1 its lo list to rank 0
+    assert ranks[0]['n'][0] == 0 and ranks[1]['n'][1] == 0
+    b01 = ranks[0]['ops'].pack(1, ranks[0]['n'][1], 0.0)
+    b10 = ranks[1]['ops'].pack(0, ranks[1]['n'][0], 0.0)
+    torch.cuda.synchronize()
+    ranks[1]['ops'].append(b01, ranks[0]['n'][1])
+    ranks[0]['ops'].append(b10, ranks[1]['n'][0])
+    assert ranks[0]['n'][1] > 0 and ranks[1]['n'][0] > 0
+    onn = oracle.OracleNNPS(3, [full], 2.0)
+    onn.update()
+    oev = oracle.OracleEval([full], eqs, kernel, nthreads=4)
+    oev.set_nnps(onn)
+    oev.compute(0.0, 1e-5)
+    for rk in ranks:
+        pa, ctx = rk['pa'], rk['ctx']
+        a_eval = AccelerationEval([pa], eqs, kernel)
+        SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+        nnps = HipNNPS(3, [pa], radius_scale=2.0, ctx=ctx, sync=False)
+        a_eval.set_nnps(nnps)
+        a_eval.compute(0.0, 1e-5)
+        nreal = pa.get_number_of_particles()
+        assert pa.gpu.get_number_of_particles() > nreal       # ghosts present
+        assert pa.gpu.get_number_of_particles(True) == nreal
+        pa.gpu.pull(*WC_OUT)
+        for prop in WC_OUT:
+            e = rel_err(pa.properties[prop], full.properties[prop][rk['own']])
+            assert e < TOL, (prop, e)
