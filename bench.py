@@ -114,7 +114,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--n1', type=int, default=159, help='lattice side per GPU')
-    ap.add_argument('--variant', type=int, default=2)
+    ap.add_argument('--variant', type=int, default=3)
     ap.add_argument('--ablate', type=int, default=0, help='profiling only')
     ap.add_argument('--opt', action='append', default=[], help='key=value library option')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -222,7 +222,7 @@ def main():
             },
             'roofline': {
                 'bound': 'hbm', 'kernel': 'k_pair_%s<FamWCSPH,WendlandQuintic>' %
-                ('direct', 'tiled', 'wg')[args.variant],
+                ('direct', 'tiled', 'wg', 'agg')[args.variant],
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                 'algorithmic_bytes_per_particle': ALGO_BYTES_PAIR,

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
     if (a.derived == 2) { double Vj = 1. / v[8]; v[10] = Vj * Vj; } // Vj2, transport_velocity.py:303-306
 #pragma unroll
     for (int k = 0; k < MAX_AUX; k++) if (k < a.na) dst[k] = v[k];
-    if (a.rec && (a.na & 1)) dst[a.na] = 0.0;
+    if (a.rec) for (int k = 4 + a.na; k < a.nr; k++) dst[k - 4] = 0.0;
 }
 
 struct SrcDesc {
@@ -231,7 +231,7 @@ template <int KK> __device__ __forceinline__ double pair_gradfac(const PairGeom 
 // ---- WCSPH: Continuity + Momentum + XSPH (wc/basic.py, basic_equations.py) --
 struct FamWCSPH {
     static constexpr int NA = 8; // u v w m rho tmpj(=p/rho^2) cs p
-    static constexpr int NR = 12; // x y z h + NA
+    static constexpr int NR = 12; // x y z h + NA (128-B padded records measured slower: larger L2 footprint)
     struct Params {
         double c0, alpha, beta, gx, gy, gz, eps;
         double *arho, *au, *av, *aw, *ax, *ay, *az, *dt_cfl, *dt_force;
@@ -427,6 +427,20 @@ struct FamTVF {
 };
 
 // ---------------------------------------------------------------------------
+// XCD-aware block remap (MI355X: 8 XCDs, block b runs on XCD b % 8, each XCD
+// has a private 4 MiB L2).  Consecutive tiles of the cell-ordered destination
+// array share their 3x3 neighbour rows, so give every XCD one CONTIGUOUS chunk
+// of tiles: the rows a workgroup gathers from are then already in its XCD's L2.
+// Placement only affects speed, never results.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nb)
+{
+    const uint32_t xcd = b & 7u, idx = b >> 3;
+    const uint32_t base = nb >> 3, rem = nb & 7u;
+    return xcd * base + min(xcd, rem) + idx;
+}
+
+// ---------------------------------------------------------------------------
 // variant 0: per-lane walk over the 3x3 rows of cells (x-contiguous ranges)
 // ---------------------------------------------------------------------------
 template <class Fam> __device__ __forceinline__ void load_aux(double (&s)[Fam::NA], const double *__restrict__ p)
@@ -490,7 +504,7 @@ template <class Fam, int KK, bool UH, int WPE> __global__ __launch_bounds__(64, 
     __shared__ uint32_t chflags[MAXCH];
 
     const int lane = threadIdx.x;
-    const uint32_t i = blockIdx.x * 64 + lane;
+    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * 64 + lane;
     const bool valid = i < a.nd;
     const uint32_t ic = valid ? i : a.nd - 1;
     const uint32_t o = a.d_perm[ic];
@@ -652,7 +666,7 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256) void k_p
     int *wx = reinterpret_cast<int *>(smem + (size_t)TCAP * NR * 8 + (size_t)(TCAP + 8) * 16); // [4][2] + [2]
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const uint32_t i = blockIdx.x * 256 + t;
+    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * 256 + t;
     const bool valid = i < a.nd;
     const uint32_t ic = valid ? i : a.nd - 1;
     const uint32_t o = a.d_perm[ic];
@@ -778,6 +792,206 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256) void k_p
     if (active) Fam::finish(D, a, o);
 }
 
+// ---------------------------------------------------------------------------
+// variant 3 (default): aggregated two-phase kernel.
+//   workgroup = 256 consecutive cell-ordered destinations (4 wave64).
+//   For every neighbouring row of cells the workgroup stages only the fp32
+//   positions of the row's candidate range (SoA, ~4 KB) plus the cell_start
+//   slice into LDS.  Phase 1: each LANE tests just the candidates of ITS OWN
+//   3 cells (two per packed-fp32 instruction) and stores a <=96-bit hit mask
+//   per row in its private LDS column.  After all 3x3 rows of a source are
+//   done, phase 2 lets every lane walk the hit bits of ALL rows back to back
+//   (simulated lane utilisation 0.94 instead of 0.44 for row-by-row
+//   processing), gathering the fp64 record of each hit, applying the
+//   reference's exact criterion and the fused pair arithmetic.
+// ---------------------------------------------------------------------------
+#define ACAP 352   // candidates per LDS position tile
+#define AQ 9       // mask slots per thread (one source's 3x3 rows)
+#define AMAXLEN 96 // hit bits kept per row and lane; longer ranges take the slow tail
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256, 4) void k_pair_agg(PairArgs<Fam> a)
+{
+    constexpr int NR = Fam::NR;
+    __shared__ __attribute__((aligned(16))) float tx[ACAP + 8], ty[ACAP + 8], tz[ACAP + 8];
+    __shared__ __attribute__((aligned(16))) float tw[UH ? 8 : ACAP + 8];
+    __shared__ uint32_t csl[72];
+    __shared__ unsigned long long mlo[AQ][256];
+    __shared__ uint32_t mhi[AQ][256];
+    __shared__ unsigned short mofs[AQ][256];
+    __shared__ uint32_t qbase[AQ];
+    __shared__ int wx[10];
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * 256 + t;
+    const bool valid = i < a.nd;
+    const uint32_t ic = valid ? i : a.nd - 1;
+    const uint32_t o = a.d_perm[ic];
+    const bool active = valid && o >= a.d_start && o < a.d_stop;
+    const double *drec = a.rec + (size_t)(a.d_off + ic) * NR;
+    const double4 pi = *reinterpret_cast<const double4 *>(drec);
+    typename Fam::Dest D;
+    Fam::load(D, drec + 4);
+    const uint32_t key = a.d_keys[ic];
+    const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
+    const int cx = key % ncx;
+    const int row = key / ncx;
+    const double hi_r = a.radius_scale * pi.w;
+    const double hi2 = UH ? a.hr2u : hi_r * hi_r;
+
+    if (t == 0) wx[8] = row;
+    if (t == 255) wx[9] = row;
+    __syncthreads();
+    const int row_first = wx[8], row_last = wx[9];
+
+    // exact criterion + pair arithmetic for one candidate record
+    auto do_pair = [&](uint32_t jg, uint32_t flags) {
+        const double *rj = a.rec + (size_t)jg * NR;
+        const double4 pj = *reinterpret_cast<const double4 *>(rj);
+        double sj[Fam::NA];
+#pragma unroll
+        for (int k = 0; k < Fam::NA; k++) sj[k] = rj[4 + k];
+        double hj2 = hi2;
+        if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
+        const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+        if (((r2 < hi2) || (r2 < hj2)) && a.ablate != 1) Fam::template pair<KK, UH>(D, pi, pj, r2, sj, flags, a);
+    };
+
+    for (int R = row_first; R <= row_last; R++) {
+        const bool inseg = active && row == R;
+        const unsigned long long segm = __ballot(inseg);
+        int cxa_w = 0x7fffffff, cxb_w = -1;
+        if (segm) {
+            cxa_w = __builtin_amdgcn_readlane(cx, __builtin_ctzll(segm));
+            cxb_w = __builtin_amdgcn_readlane(cx, 63 - __builtin_clzll(segm));
+        }
+        __syncthreads();
+        if (lane == 0) { wx[2 * wv] = cxa_w; wx[2 * wv + 1] = cxb_w; }
+        __syncthreads();
+        const int cxa = min(min(wx[0], wx[2]), min(wx[4], wx[6]));
+        const int cxb = max(max(wx[1], wx[3]), max(wx[5], wx[7]));
+        if (cxb < 0) continue;
+        const int cyR = R % ncy, czR = R / ncy;
+        const int xa = max(cxa - 1, 0), xb = min(cxb + 1, ncx - 1);
+        const int ncs = xb - xa + 2; // cell_start entries needed: cells xa..xb and the end
+        // fp32 coordinates relative to this row segment's origin
+        const double ox = a.xmin[0] + a.cell_size * xa;
+        const double oy = a.xmin[1] + a.cell_size * (cyR - 1);
+        const double oz = a.xmin[2] + a.cell_size * (czR - 1);
+        const double L = a.cell_size * (double)max(xb - xa + 2, 4);
+        const float slack = (float)(L * 1.5e-6);
+        const float fxs = (float)(pi.x - ox), fys = (float)(pi.y - oy), fzs = (float)(pi.z - oz);
+        const f2 fx = {fxs, fxs}, fy = {fys, fys}, fz = {fzs, fzs};
+        const float hif = (float)hi_r * 1.000001f + slack;
+        const float hi2f = hif * hif;
+        const int mycl = max(cx - 1, xa) - xa, mych = min(cx + 1, xb) + 1 - xa;
+
+        for (int s = 0; s < a.nsrc; s++) {
+            const SrcDesc sd = a.src[s];
+            int nq = 0;
+            // ---- phase 2 over the slots filled so far (per wavefront, no barrier needed:
+            // every thread only touches its own mask column)
+            auto phase2 = [&]() {
+                if (a.ablate != 2 && nq > 0) {
+                    int q = 0;
+                    unsigned long long m0 = mlo[0][t];
+                    uint32_t m1 = mhi[0][t];
+                    for (;;) {
+                        while (m0 == 0 && m1 == 0 && q + 1 < nq) { ++q; m0 = mlo[q][t]; m1 = mhi[q][t]; }
+                        const bool has = (m0 != 0) || (m1 != 0);
+                        if (!__any(has)) break;
+                        if (has) {
+                            int bit;
+                            if (m0) { bit = __builtin_ctzll(m0); m0 &= m0 - 1; }
+                            else { bit = 64 + __builtin_ctz(m1); m1 &= m1 - 1; }
+                            do_pair(qbase[q] + mofs[q][t] + bit, sd.flags);
+                        }
+                    }
+                }
+                nq = 0;
+            };
+            for (int dz = -1; dz <= 1; dz++)
+                for (int dy = -1; dy <= 1; dy++) {
+                    const int yy = cyR + dy, zz = czR + dz;
+                    if (yy < 0 || yy >= ncy || zz < 0 || zz >= ncz) continue;
+                    const uint32_t rowb = (uint32_t)(ncx * (yy + ncy * zz));
+                    const uint32_t j0 = sd.cell_start[rowb + xa], j1 = sd.cell_start[rowb + xb + 1];
+                    for (uint32_t tb = j0; tb < j1; tb += ACAP) {
+                        const int tn = (int)min((uint32_t)ACAP, j1 - tb);
+                        __syncthreads(); // previous tile's readers are done
+                        for (int q = t; q < ncs && q < 72; q += 256) csl[q] = sd.cell_start[rowb + xa + q];
+                        for (int k = t; k < tn + 8; k += 256) {
+                            float vx = 3.0e18f, vy = 3.0e18f, vz = 3.0e18f, vw = 0.f;
+                            if (k < tn) {
+                                const double4 pj = *reinterpret_cast<const double4 *>(a.rec + (size_t)(sd.off + tb + k) * NR);
+                                vx = (float)(pj.x - ox); vy = (float)(pj.y - oy); vz = (float)(pj.z - oz);
+                                const float hjf = (float)(a.radius_scale * pj.w) * 1.000001f + slack;
+                                vw = hjf * hjf;
+                            }
+                            tx[k] = vx; ty[k] = vy; tz[k] = vz;
+                            if (!UH) tw[k] = vw;
+                        }
+                        __syncthreads();
+                        // ---- my own candidate range inside this tile (3 cells), even-aligned start
+                        int s0 = 0, len = 0;
+                        if (inseg) {
+                            int lo, hi;
+                            if (ncs <= 72) { lo = (int)(csl[mycl] - tb); hi = (int)(csl[mych] - tb); }
+                            else { lo = (int)(sd.cell_start[rowb + xa + mycl] - tb); hi = (int)(sd.cell_start[rowb + xa + mych] - tb); }
+                            lo = max(lo, 0); hi = min(hi, tn);
+                            s0 = lo & ~1;
+                            len = hi - s0;
+                        }
+                        const int lenc = min(len, AMAXLEN);
+                        unsigned long long m0 = 0;
+                        uint32_t m1 = 0;
+                        for (int k0 = 0; __any(k0 < lenc); k0 += 8) {
+                            unsigned mm = 0;
+#pragma unroll
+                            for (int p = 0; p < 4; p++) {
+                                const int idx = min(s0 + k0 + 2 * p, tn + 6); // stays inside the padded tile
+                                const f2 X = *reinterpret_cast<const f2 *>(&tx[idx]);
+                                const f2 Y = *reinterpret_cast<const f2 *>(&ty[idx]);
+                                const f2 Z = *reinterpret_cast<const f2 *>(&tz[idx]);
+                                const f2 ex = fx - X, ey = fy - Y, ez = fz - Z;
+                                const f2 r2 = ex * ex + ey * ey + ez * ez;
+                                bool h0, h1;
+                                if (UH) { h0 = r2.x < hi2f; h1 = r2.y < hi2f; }
+                                else {
+                                    const f2 W = *reinterpret_cast<const f2 *>(&tw[idx]);
+                                    h0 = (r2.x < hi2f) | (r2.x < W.x);
+                                    h1 = (r2.y < hi2f) | (r2.y < W.y);
+                                }
+                                h0 &= (k0 + 2 * p) < lenc;
+                                h1 &= (k0 + 2 * p + 1) < lenc;
+                                mm |= (h0 ? (1u << (2 * p)) : 0u) | (h1 ? (2u << (2 * p)) : 0u);
+                            }
+                            if (k0 < 64) m0 |= (unsigned long long)mm << k0;
+                            else m1 |= mm << (k0 - 64);
+                        }
+                        mlo[nq][t] = m0;
+                        mhi[nq][t] = m1;
+                        mofs[nq][t] = (unsigned short)s0;
+                        if (t == 0) qbase[nq] = sd.off + tb;
+                        // ---- rare: a lane's 3-cell range is longer than AMAXLEN -> exact tail, in place
+                        if (__any(len > AMAXLEN)) {
+                            for (int k = AMAXLEN; k < len; k++) do_pair(sd.off + tb + s0 + k, sd.flags);
+                        }
+                        nq++;
+                        if (nq == AQ) {
+                            __syncthreads(); // qbase visible
+                            phase2();
+                        }
+                    }
+                }
+            __syncthreads(); // qbase visible
+            phase2();
+        }
+    }
+    if (active) Fam::finish(D, a, o);
+}
+
 template <class Fam> static size_t wg_lds_bytes() { return (size_t)TCAP * Fam::NR * 8 + (size_t)(TCAP + 8) * 16 + 64; }
 
 // ---------------------------------------------------------------------------
@@ -840,6 +1054,7 @@ static int eq_family(int kind, uint32_t *flag)
 }
 
 struct PackPlan {
+    int nr; // doubles per interleaved record (== Fam::NR)
     int na;
     int props[MAX_AUX]; // sph_prop or -1
     int derived;
@@ -851,14 +1066,17 @@ static PackPlan pack_plan(int fam)
     for (auto &v : p.props) v = -1;
     p.derived = 0;
     if (fam == FAM_WCSPH) {
+        p.nr = FamWCSPH::NR;
         p.na = 8;
         int pr[8] = {SPH_U, SPH_V, SPH_W, SPH_M, SPH_RHO, -1, SPH_CS, SPH_P};
         for (int k = 0; k < 8; k++) p.props[k] = pr[k];
         p.derived = 1;
     } else if (fam == FAM_DENSITY) {
+        p.nr = FamDensity::NR;
         p.na = 1;
         p.props[0] = SPH_M;
     } else {
+        p.nr = FamTVF::NR;
         p.na = 12;
         int pr[12] = {SPH_U, SPH_V, SPH_W, SPH_UHAT, SPH_VHAT, SPH_WHAT, SPH_RHO, SPH_P, SPH_VOL, SPH_M, -1, -1};
         for (int k = 0; k < 12; k++) p.props[k] = pr[k];
@@ -905,8 +1123,8 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
     pa.posh = c->posh.as<double4>();
     pa.aux = c->aux.as<double>();
     pa.rec = nullptr;
-    pa.nr = 4 + ((pl.na + 1) & ~1);
-    if (c->pair_variant == 2) pa.rec = c->posh.as<double>();
+    pa.nr = pl.nr;
+    if (c->pair_variant >= 2) pa.rec = c->posh.as<double>();
     hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, pa);
     return SPH_OK;
 }
@@ -916,6 +1134,20 @@ template <class Fam> static void launch_pair(sph_ctx *c, int kk, const PairArgs<
     if (a.nd == 0) return;
     const bool tiled = c->pair_variant != 0;
     const bool uh = c->uniform_h && c->use_uniform_h;
+    if (c->pair_variant == 3) {
+        dim3 g2(div_up(a.nd, 256)), b2(256);
+#define LAUNCH3(K)                                                                           \
+        if (uh) hipLaunchKernelGGL((k_pair_agg<Fam, K, true>), g2, b2, 0, c->stream, a);     \
+        else hipLaunchKernelGGL((k_pair_agg<Fam, K, false>), g2, b2, 0, c->stream, a)
+        switch (kk) {
+        case 1: LAUNCH3(1); break;
+        case 2: LAUNCH3(2); break;
+        case 3: LAUNCH3(3); break;
+        case 4: LAUNCH3(4); break;
+        }
+#undef LAUNCH3
+        return;
+    }
     if (c->pair_variant == 2) {
         dim3 g2(div_up(a.nd, 256)), b2(256);
         size_t lds = wg_lds_bytes<Fam>();
@@ -1062,7 +1294,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         else for (int j = 0; j < nsrcs; j++) if (srcs[j] == dst) d_off = off_of[j];
         if (total >= (1ull << 32)) { sph_set_error("too many particles for 32-bit packed indices"); return SPH_ERR_ARG; }
         PackPlan pl = pack_plan(fam);
-        SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * (c->pair_variant == 2 ? 4 + ((pl.na + 1) & ~1) : 4)));
+        SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * (c->pair_variant >= 2 ? pl.nr : 4)));
         SPH_TRY(c->aux.reserve((total + 64) * sizeof(double) * pl.na));
         {
             ScopedTimer tm(c, T_PACK);

@@ -88,7 +88,7 @@ struct sph_ctx {
     double *pinned = nullptr; // small pinned host buffer (64 doubles)
 
     // options
-    long pair_variant = 2;
+    long pair_variant = 3;
     long ablate = 0;
     long use_uniform_h = 1;
     long wpe = 2;

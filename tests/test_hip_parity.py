@@ -18,7 +18,7 @@ TOL = 1e-10
 CASES = ['sd_1d_line', 'wcsph_cube_varh', 'tvf_cube', 'wcsph_dam_dx0.1']
 
 
-def make_eval(arrays, eqs, kernel, dim, variant=2, sync='auto'):
+def make_eval(arrays, eqs, kernel, dim, variant=3, sync='auto'):
     from pysph_amd import device as dev
     from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
     from pysph_amd.nnps import HipNNPS
@@ -31,7 +31,7 @@ def make_eval(arrays, eqs, kernel, dim, variant=2, sync='auto'):
     return a_eval, nnps, ctx
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3])
 @pytest.mark.parametrize('case', CASES)
 def test_golden_parity(case, variant):
     g = load_golden(case + '.npz')
@@ -103,7 +103,7 @@ def _copy_arrays(arrays):
     return out
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3])
 def test_dam_break_27k_vs_oracle(oracle, variant):
     """BASELINE config 1: dam_break_3d, dx=0.04 (9360+15152+160 particles)."""
     from pysph_amd.examples import dam_break_3d as db
@@ -159,7 +159,7 @@ def cube_equations(dx, hdx=1.3):
 
 
 @pytest.mark.parametrize('variant,varh', [(0, 0.0), (1, 0.0), (1, 0.2),
-                                          (2, 0.0), (2, 0.2)])
+                                          (2, 0.0), (2, 0.2), (3, 0.0), (3, 0.2)])
 def test_cube_100k_vs_oracle(oracle, variant, varh):
     from pysph_amd import kernels as K
     pa, dx = make_cube(46, varh=varh)
@@ -192,17 +192,17 @@ def test_full_size_1m_properties():
     eqs = cube_equations(dx)
     kernel = K.WendlandQuintic(dim=3)
     res = {}
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):
         q = _copy_arrays([pa])
         a_eval, nnps, ctx = make_eval(q, eqs, kernel, 3, variant)
         a_eval.compute(0.0, 1e-5)
         res[variant] = q[0]
         ctx.close()
     for prop in WC_OUT:
-        a, b, c = (res[v].properties[prop] for v in (0, 1, 2))
-        assert np.all(np.isfinite(c))
-        assert rel_err(a, c) < 1e-12, prop
-        assert rel_err(b, c) < 1e-12, prop
+        a, b, c, d = (res[v].properties[prop] for v in (0, 1, 2, 3))
+        assert np.all(np.isfinite(d))
+        for other in (a, b, c):
+            assert rel_err(other, d) < 1e-12, prop
 
 
 def test_group_semantics_real_start_stop(oracle):
@@ -304,7 +304,7 @@ def test_edge_cases_empty_single_and_2d(oracle):
     ref = _copy_arrays([pa])
     eqs = [Group(equations=[SummationDensity(dest='fluid', sources=['fluid'])])]
     kernel = K.WendlandQuintic(dim=2)
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):
         q = _copy_arrays([pa])
         a_eval, nnps, ctx = make_eval(q, eqs, kernel, 2, variant)
         a_eval.compute(0.0, 0.1)
