@@ -179,10 +179,17 @@ int sph_reduce_max(sph_ctx *ctx, int array_id, int prop, double *out);
 /* (pysph/parallel/parallel_manager.pyx:1159-1243, :159-210); the transport */
 /* itself is RCCL send/recv issued by the Python host (torch.distributed).  */
 /* ---------------------------------------------------------------------- */
-/* Select the REAL particles of `array_id` whose coordinate along `axis`
- * (0,1,2) is < lo_cut (side 0) or >= hi_cut (side 1), in ascending index
- * order (deterministic).  counts[2] receives the two list lengths.         */
-int sph_halo_select(sph_ctx *ctx, int array_id, int axis, double lo_cut, double hi_cut, size_t *counts);
+/* Select particles of `array_id` by their coordinate v along `axis` (0,1,2),
+ * in ascending index order (deterministic); counts[2] receives the lengths of
+ * the "lo" (side 0) and "hi" (side 1) lists.
+ *   mode 0 (slab faces):    lo: v <  p0          hi: v >= p1
+ *   mode 1 (periodic box):  lo: (v - p0) <= p2   hi: (p1 - v) <= p2
+ *     -- the tests of CPUDomainManager._create_ghosts_periodic
+ *        (pysph/base/nnps_base.pyx:805-817) with p0/p1 = domain min/max and
+ *        p2 = n_layers*cell_size.
+ * `upto`: consider the first `upto` particles (0: the real particles only).  */
+int sph_halo_select(sph_ctx *ctx, int array_id, int axis, int mode, double p0, double p1, double p2,
+                    size_t upto, size_t *counts);
 /* Gather `nprops` properties of the particles selected for `side` into the
  * device buffer dst, laid out [nprops][count]; `shift` is added to the
  * `axis` coordinate (periodic wrap, nnps_base.pyx:841-856).                */
@@ -193,6 +200,14 @@ int sph_halo_pack(sph_ctx *ctx, int array_id, int side, int nprops, const int *p
  * n_real is unchanged.  Drop them again with sph_array_resize(n_real).      */
 int sph_halo_append(sph_ctx *ctx, int array_id, int nprops, const int *props, const void *src_device,
                     size_t count);
+
+/* Box-wrap the first n_real particles along `axis` into [vmin, vmax]:
+ * v < vmin -> v + translate; v > vmax -> v - translate
+ * (CPUDomainManager._box_wrap_periodic, pysph/base/nnps_base.pyx:699-748).   */
+int sph_domain_box_wrap(sph_ctx *ctx, int array_id, int axis, double vmin, double vmax, double translate);
+/* Ids of the properties that currently have device storage (out: up to
+ * SPH_PROP_COUNT ints, *n receives the count).                              */
+int sph_array_props(sph_ctx *ctx, int array_id, int *out, int *n);
 
 /* pair-kernel variant: 0 = per-lane cell walk (direct), 1 = LDS-tiled
  * two-phase (default).                                                      */

@@ -10,15 +10,31 @@
 
 #include <hipcub/hipcub.hpp>
 
-__global__ __launch_bounds__(256) void k_halo_flags(const double *__restrict__ coord, size_t n, double lo_cut,
-                                                    double hi_cut, uint32_t *__restrict__ flo,
+__global__ __launch_bounds__(256) void k_halo_flags(const double *__restrict__ coord, size_t n, int mode, double p0,
+                                                    double p1, double p2, uint32_t *__restrict__ flo,
                                                     uint32_t *__restrict__ fhi)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double v = coord[i];
-    flo[i] = v < lo_cut ? 1u : 0u;
-    fhi[i] = v >= hi_cut ? 1u : 0u;
+    if (mode == 0) {
+        flo[i] = v < p0 ? 1u : 0u;
+        fhi[i] = v >= p1 ? 1u : 0u;
+    } else { // nnps_base.pyx:805-817
+        flo[i] = (v - p0) <= p2 ? 1u : 0u;
+        fhi[i] = (p1 - v) <= p2 ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_box_wrap(double *__restrict__ coord, size_t n, double vmin, double vmax,
+                                                  double translate)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v = coord[i];
+    if (v < vmin) v = v + translate;
+    if (v > vmax) v = v - translate;
+    coord[i] = v;
 }
 
 __global__ __launch_bounds__(256) void k_halo_scatter(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos,
@@ -38,7 +54,8 @@ __global__ __launch_bounds__(256) void k_halo_gather(const double *__restrict__ 
 }
 
 
-extern "C" int sph_halo_select(sph_ctx *c, int id, int axis, double lo_cut, double hi_cut, size_t *counts)
+extern "C" int sph_halo_select(sph_ctx *c, int id, int axis, int mode, double p0, double p1, double p2, size_t upto,
+                               size_t *counts)
 {
     if (!c || id < 0 || id >= SPH_MAX_ARRAYS || axis < 0 || axis > 2 || !counts) {
         sph_set_error("sph_halo_select: bad arguments");
@@ -47,7 +64,7 @@ extern "C" int sph_halo_select(sph_ctx *c, int id, int axis, double lo_cut, doub
     HIP_TRY(hipSetDevice(c->device));
     DevArray &A = c->arr[id];
     HaloState &H = c->halo[id];
-    size_t n = A.n_real;
+    size_t n = upto ? (upto < A.n ? upto : A.n) : A.n_real;
     counts[0] = counts[1] = 0;
     H.count[0] = H.count[1] = 0;
     if (n == 0) return SPH_OK;
@@ -57,7 +74,7 @@ extern "C" int sph_halo_select(sph_ctx *c, int id, int axis, double lo_cut, doub
         SPH_TRY(H.flag[s].reserve((n + 1) * 4));
         SPH_TRY(H.pos[s].reserve((n + 1) * 4));
     }
-    hipLaunchKernelGGL(k_halo_flags, dim3(div_up(n, 256)), dim3(256), 0, c->stream, coord, n, lo_cut, hi_cut,
+    hipLaunchKernelGGL(k_halo_flags, dim3(div_up(n, 256)), dim3(256), 0, c->stream, coord, n, mode, p0, p1, p2,
                        H.flag[0].as<uint32_t>(), H.flag[1].as<uint32_t>());
     uint32_t *pin = (uint32_t *)c->pinned;
     for (int s = 0; s < 2; s++) {
@@ -119,5 +136,27 @@ extern "C" int sph_halo_append(sph_ctx *c, int id, int nprops, const int *props,
         HIP_TRY(hipMemcpyAsync(A.prop[props[k]] + n0, (const double *)src + (size_t)k * count, count * sizeof(double),
                                hipMemcpyDeviceToDevice, c->stream));
     c->nnps_valid = false;
+    return SPH_OK;
+}
+
+extern "C" int sph_domain_box_wrap(sph_ctx *c, int id, int axis, double vmin, double vmax, double translate)
+{
+    if (!c || id < 0 || id >= SPH_MAX_ARRAYS || axis < 0 || axis > 2) { sph_set_error("sph_domain_box_wrap: bad arguments"); return SPH_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    DevArray &A = c->arr[id];
+    if (A.n_real == 0) return SPH_OK;
+    if (!A.prop[SPH_X + axis]) { sph_set_error("sph_domain_box_wrap: no device coordinates"); return SPH_ERR_MISSING_PROP; }
+    hipLaunchKernelGGL(k_box_wrap, dim3(div_up(A.n_real, 256)), dim3(256), 0, c->stream, A.prop[SPH_X + axis], A.n_real,
+                       vmin, vmax, translate);
+    c->nnps_valid = false;
+    return SPH_OK;
+}
+
+extern "C" int sph_array_props(sph_ctx *c, int id, int *out, int *n)
+{
+    if (!c || id < 0 || id >= SPH_MAX_ARRAYS || !out || !n) { sph_set_error("sph_array_props: bad arguments"); return SPH_ERR_ARG; }
+    int k = 0;
+    for (int p = 0; p < SPH_PROP_COUNT; p++) if (c->arr[id].prop[p]) out[k++] = p;
+    *n = k;
     return SPH_OK;
 }

@@ -68,8 +68,13 @@ SIGNATURES = {
     'sph_nnps_get_order': (C.c_int, [_P, C.c_int, _PU]),
     'sph_eval_group': (C.c_int, [_P, C.POINTER(SphKernel),
                                  C.POINTER(SphGroup), C.c_double, C.c_double]),
-    'sph_halo_select': (C.c_int, [_P, C.c_int, C.c_int, C.c_double,
-                                  C.c_double, C.POINTER(C.c_size_t)]),
+    'sph_halo_select': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_double,
+                                  C.c_double, C.c_double, C.c_size_t,
+                                  C.POINTER(C.c_size_t)]),
+    'sph_domain_box_wrap': (C.c_int, [_P, C.c_int, C.c_int, C.c_double,
+                                      C.c_double, C.c_double]),
+    'sph_array_props': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int),
+                                  C.POINTER(C.c_int)]),
     'sph_halo_pack': (C.c_int, [_P, C.c_int, C.c_int, C.c_int,
                                 C.POINTER(C.c_int), C.c_int, C.c_double, _P]),
     'sph_halo_append': (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int),

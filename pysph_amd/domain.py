@@ -1,0 +1,184 @@
+"""Periodic domains: ghost-image particles for the neighbour search.
+
+Mirrors ``DomainManager(xmin, xmax, ymin, ymax, zmin, zmax, periodic_in_x,
+periodic_in_y, periodic_in_z, n_layers)`` and its ``update()``
+(pysph/base/nnps_base.pyx:227-290, CPUDomainManager :425-483):
+
+    remove the ghosts of the previous call -> box-wrap real particles
+    (:699-748) -> create image copies of every particle within
+    ``n_layers * cell_size`` of a periodic face, axis by axis, corner images
+    included (:751-940); images are tagged Ghost and sit behind the real
+    particles (sources only).
+
+Two implementations with the same interface:
+
+* ``DomainManager``     host arrays are authoritative (``sync='auto'``): the
+  ghost bookkeeping is done on the host ParticleArray exactly where the
+  reference does it (``Integrator.update_domain`` -> ``nnps.update_domain()``);
+* ``HipDomainManager``  device-resident state (``sync='manual'``): the same
+  steps run as HIP kernels through ``sph_domain_box_wrap`` /
+  ``sph_halo_select(mode=1)`` / ``sph_halo_pack`` / ``sph_halo_append`` -- the
+  ghost copy is the multi-GPU halo copy with a coordinate shift.
+
+Mirror (reflecting) boundaries are not implemented (not used by the
+BASELINE configs) and raise.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import device as dev
+from .particle_array import ParticleTAGS
+
+
+class _DomainBase(object):
+    def __init__(self, xmin=-1000., xmax=1000., ymin=0., ymax=0., zmin=0.,
+                 zmax=0., periodic_in_x=False, periodic_in_y=False,
+                 periodic_in_z=False, n_layers=2.0, props=None,
+                 mirror_in_x=False, mirror_in_y=False, mirror_in_z=False):
+        if mirror_in_x or mirror_in_y or mirror_in_z:
+            raise NotImplementedError('mirror boundaries are not implemented')
+        for lo, hi in ((xmin, xmax), (ymin, ymax), (zmin, zmax)):
+            if hi < lo:
+                raise ValueError('Invalid domain limits')   # _check_limits
+        self.lims = [(float(xmin), float(xmax)), (float(ymin), float(ymax)),
+                     (float(zmin), float(zmax))]
+        self.periodic = [bool(periodic_in_x), bool(periodic_in_y),
+                         bool(periodic_in_z)]
+        self.is_periodic = any(self.periodic)
+        self.n_layers = float(n_layers)
+        self.props = props
+        self.translate = [hi - lo for lo, hi in self.lims]
+        self.radius_scale = 2.0
+        self.cell_size = 1.0
+        self.particles = []
+
+    # attributes the reference exposes
+    xmin = property(lambda self: self.lims[0][0])
+    xmax = property(lambda self: self.lims[0][1])
+    ymin = property(lambda self: self.lims[1][0])
+    ymax = property(lambda self: self.lims[1][1])
+    zmin = property(lambda self: self.lims[2][0])
+    zmax = property(lambda self: self.lims[2][1])
+
+    def set_particles(self, particles, radius_scale):
+        self.particles = list(particles)
+        self.radius_scale = float(radius_scale)
+
+
+class DomainManager(_DomainBase):
+    """Host-side periodic ghosts on the ParticleArrays (sync='auto')."""
+
+    def _cell_size(self):
+        # _compute_cell_size_for_binning (nnps_base.pyx:942-978)
+        hmax = -1.0
+        for pa in self.particles:
+            h = pa.properties['h']
+            if h.size:
+                hmax = max(hmax, float(h.max()))
+        cs = self.radius_scale * hmax
+        return 1.0 if cs < 1e-6 else cs
+
+    def update(self):
+        if not self.is_periodic:
+            return
+        for pa in self.particles:
+            if pa.get_number_of_particles() != pa.get_number_of_particles(True):
+                pa.remove_tagged_particles(ParticleTAGS.Ghost)
+        self.cell_size = self._cell_size()
+        width = self.n_layers * self.cell_size
+        for pa in self.particles:
+            nreal = pa.get_number_of_particles(True)
+            for ax, name in enumerate('xyz'):
+                if not self.periodic[ax]:
+                    continue
+                lo, hi = self.lims[ax]
+                v = pa.properties[name]
+                v[v < lo] += self.translate[ax]
+                v[v > hi] -= self.translate[ax]
+            for ax, name in enumerate('xyz'):
+                if not self.periodic[ax]:
+                    continue
+                lo, hi = self.lims[ax]
+                v = pa.properties[name]
+                low = np.nonzero((v - lo) <= width)[0]
+                high = np.nonzero((hi - v) <= width)[0]
+                for idx, shift in ((low, self.translate[ax]),
+                                   (high, -self.translate[ax])):
+                    if idx.size == 0:
+                        continue
+                    g = pa.extract_particles(idx)
+                    g.properties[name] += shift
+                    pa.append_parray(g, tag=ParticleTAGS.Ghost)
+                    pa.set_num_real_particles(nreal)
+
+
+class HipDomainManager(_DomainBase):
+    """Device-resident periodic ghosts (sync='manual')."""
+
+    def __init__(self, *args, **kw):
+        ctx = kw.pop('ctx', None)
+        _DomainBase.__init__(self, *args, **kw)
+        self.ctx = ctx or dev.get_context()
+        self.lib = self.ctx.lib
+
+    def set_particles(self, particles, radius_scale):
+        _DomainBase.set_particles(self, particles, radius_scale)
+        self.helpers = [dev.attach(pa, self.ctx) for pa in self.particles]
+        for h in self.helpers:
+            h.managed = True
+
+    def _hmax(self):
+        ids = (C.c_int * len(self.helpers))(*[h.array_id for h in self.helpers])
+        out = (C.c_double * 8)()
+        dev._check(self.lib.sph_nnps_minmax(self.ctx._h, len(self.helpers),
+                                            ids, out))
+        return out[7]
+
+    def update(self):
+        if not self.is_periodic:
+            return
+        lib, ctx = self.lib, self.ctx._h
+        for h in self.helpers:
+            nreal = h.get_number_of_particles(True)
+            dev._check(lib.sph_array_resize(ctx, h.array_id, nreal, nreal))
+        cs = self.radius_scale * self._hmax()
+        self.cell_size = 1.0 if cs < 1e-6 else cs
+        width = self.n_layers * self.cell_size
+        import torch
+        device = torch.device('cuda', self.ctx.device)
+        for h in self.helpers:
+            aid = h.array_id
+            pr = (C.c_int * 64)()
+            npr = C.c_int()
+            dev._check(lib.sph_array_props(ctx, aid, pr, C.byref(npr)))
+            nprops = npr.value
+            for ax in range(3):
+                if self.periodic[ax]:
+                    lo, hi = self.lims[ax]
+                    dev._check(lib.sph_domain_box_wrap(ctx, aid, ax, lo, hi,
+                                                       self.translate[ax]))
+            for ax in range(3):
+                if not self.periodic[ax]:
+                    continue
+                lo, hi = self.lims[ax]
+                counts = (C.c_size_t * 2)()
+                n_all = h.get_number_of_particles()
+                dev._check(lib.sph_halo_select(ctx, aid, ax, 1, lo, hi, width,
+                                               n_all, counts))
+                bufs = []
+                for side, shift in ((0, self.translate[ax]),
+                                    (1, -self.translate[ax])):
+                    cnt = int(counts[side])
+                    buf = torch.empty(max(cnt * nprops, 1), dtype=torch.float64,
+                                      device=device)
+                    if cnt:
+                        dev._check(lib.sph_halo_pack(
+                            ctx, aid, side, nprops, pr, ax, shift,
+                            C.c_void_p(buf.data_ptr())))
+                    bufs.append((buf, cnt))
+                for buf, cnt in bufs:
+                    if cnt:
+                        dev._check(lib.sph_halo_append(
+                            ctx, aid, nprops, pr, C.c_void_p(buf.data_ptr()),
+                            cnt))

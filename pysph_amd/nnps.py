@@ -29,9 +29,6 @@ class HipNNPS(object):
         ``update()`` (drop-in behaviour: the host owns the data).  With
         ``sync=False`` the positions already on the device are used
         (device-resident pipelines)."""
-        if domain is not None:
-            raise NotImplementedError(
-                'HipNNPS: periodic/mirror DomainManager is not implemented yet')
         self.dim = dim
         self.particles = list(particles)
         self.narrays = len(self.particles)
@@ -40,7 +37,7 @@ class HipNNPS(object):
         self.fixed_h = fixed_h
         self.use_cache = cache
         self.sort_gids = sort_gids
-        self.domain = None
+        self.domain = domain
         self.sync = sync
         self.ctx = ctx or dev.get_context()
         self.lib = self.ctx.lib
@@ -53,6 +50,9 @@ class HipNNPS(object):
         self.n_cells = 0
         self.bounds = None       # optional fixed global bounds (multi-GPU)
         self.cell_size_override = -1.0
+        if self.domain is not None:
+            self.domain.set_particles(self.particles, self.radius_scale)
+            self.domain.update()       # LinkedListNNPS.__init__: linked_list_nnps.pyx:88
         self.update()
 
     # -- reference protocol ----------------------------------------------
@@ -66,8 +66,11 @@ class HipNNPS(object):
         self.use_cache = use_cache
 
     def update_domain(self):
-        """DomainManager.update: only the cell size depends on it here and
-        that is recomputed inside ``update`` (nnps_base.pyx:450-483,942)."""
+        """DomainManager.update (nnps_base.pyx:450-483): periodic ghosts; the
+        cell size itself is recomputed inside ``update``."""
+        if self.domain is not None:
+            self.domain.update()
+            self._csr_key = None
 
     def update(self):
         if self.sync:

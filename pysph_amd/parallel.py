@@ -60,7 +60,7 @@ class DeviceHaloOps(object):
     def select(self, lo_cut, hi_cut):
         counts = (C.c_size_t * 2)()
         dev._check(self.lib.sph_halo_select(self.ctx._h, self.id, self.axis,
-                                            lo_cut, hi_cut, counts))
+                                            0, lo_cut, hi_cut, 0.0, 0, counts))
         return int(counts[0]), int(counts[1])
 
     def new_buffer(self, count):

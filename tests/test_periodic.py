@@ -1,0 +1,171 @@
+"""Periodic DomainManager (reference tests
+pysph/base/tests/test_domain_manager.py:100-118, test_periodic_nnps.py)."""
+import numpy as np
+import pytest
+
+from helpers import rel_err
+
+
+def lattice(n1, dim=3, hdx=1.0, name='fluid', jitter=0.0, seed=3):
+    from pysph_amd.particle_array import get_particle_array_tvf_fluid
+    dx = 1.0 / n1
+    g = (np.arange(n1) + 0.5) * dx
+    if dim == 2:
+        x, y = [a.ravel().copy() for a in np.meshgrid(g, g, indexing='ij')]
+        z = np.zeros_like(x)
+    else:
+        x, y, z = [a.ravel().copy() for a in np.meshgrid(g, g, g, indexing='ij')]
+    n = x.size
+    rng = np.random.default_rng(seed)
+    if jitter:
+        x += jitter * dx * rng.uniform(-1, 1, n)
+        y += jitter * dx * rng.uniform(-1, 1, n)
+        if dim == 3:
+            z += jitter * dx * rng.uniform(-1, 1, n)
+    pa = get_particle_array_tvf_fluid(
+        name=name, x=x, y=y, z=z, h=hdx * dx * np.ones(n),
+        m=dx ** dim * np.ones(n), rho=np.ones(n))
+    return pa, dx
+
+
+def test_host_periodic_ghosts_lattice_density(oracle):
+    """Uniform lattice in a periodic box: every particle sees the same
+    neighbourhood, so summation density is identical for all particles and the
+    number density matches 1/vol (test_domain_manager.py:100-118)."""
+    from pysph_amd import kernels as K
+    from pysph_amd.domain import DomainManager
+    from pysph_amd.equations import Group, TVFSummationDensity
+    pa, dx = lattice(12, dim=2, hdx=1.2)
+    kernel = K.QuinticSpline(dim=2)
+    dom = DomainManager(xmin=0, xmax=1, ymin=0, ymax=1, periodic_in_x=True,
+                        periodic_in_y=True)
+    dom.set_particles([pa], kernel.radius_scale)
+    dom.update()
+    n, nreal = pa.get_number_of_particles(), pa.get_number_of_particles(True)
+    assert nreal == 144 and n > nreal
+    assert np.all(pa.tag[:nreal] == 0) and np.all(pa.tag[nreal:] == 2)
+    dom.update()                                   # idempotent
+    assert pa.get_number_of_particles() == n
+    eqs = [Group(equations=[TVFSummationDensity(dest='fluid', sources=['fluid'])])]
+    nn = oracle.OracleNNPS(2, [pa], kernel.radius_scale)
+    nn.update()
+    ev = oracle.OracleEval([pa], eqs, kernel)
+    ev.set_nnps(nn)
+    ev.compute(0.0, 0.1)
+    V, rho = pa.V[:nreal], pa.rho[:nreal]
+    assert np.max(np.abs(1.0 / V - dx ** 2)) < 1e-5 * dx ** 2 * 10
+    assert np.max(np.abs(V - V[0])) < 1e-11 * V[0]
+    assert np.max(np.abs(rho - pa.m[:nreal] * V)) < 1e-14
+
+
+def test_box_wrap_host():
+    from pysph_amd.domain import DomainManager
+    pa, dx = lattice(6, dim=2)
+    pa.x[0] = -0.01
+    pa.y[1] = 1.02
+    dom = DomainManager(xmin=0, xmax=1, ymin=0, ymax=1, periodic_in_x=True,
+                        periodic_in_y=True)
+    dom.set_particles([pa], 3.0)
+    dom.update()
+    assert abs(pa.x[0] - 0.99) < 1e-15 and abs(pa.y[1] - 0.02) < 1e-15
+
+
+@pytest.mark.gpu
+def test_tvf_periodic_taylor_green_vs_oracle(oracle):
+    """BASELINE config 3 at test size: periodic unit cube, TVF equation set
+    (taylor_green.py parameters: rho0 1, c0 10, p0 = pb = 100, nu 0.01),
+    QuinticSpline.  Host-side ghosts (sync='auto')."""
+    from pysph_amd import kernels as K
+    from pysph_amd.domain import DomainManager
+    from pysph_amd.scheme import TVFScheme
+    from test_hip_parity import make_eval, _copy_arrays
+    from pysph_amd import device as dev
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.nnps import HipNNPS
+    pa, dx = lattice(12, dim=3, hdx=1.0, jitter=0.05)
+    x, y = pa.x, pa.y
+    pa.u[:] = -np.cos(2 * np.pi * x) * np.sin(2 * np.pi * y)
+    pa.v[:] = np.sin(2 * np.pi * x) * np.cos(2 * np.pi * y)
+    pa.uhat[:] = pa.u * 1.01
+    pa.vhat[:] = pa.v * 0.99
+    kernel = K.QuinticSpline(dim=3)
+    eqs = TVFScheme(['fluid'], [], dim=3, rho0=1.0, c0=10.0, nu=0.01, p0=100.0,
+                    pb=100.0, h0=dx).get_equations()
+    ref = _copy_arrays([pa])
+    kw = dict(xmin=0, xmax=1, ymin=0, ymax=1, zmin=0, zmax=1, periodic_in_x=True,
+              periodic_in_y=True, periodic_in_z=True)
+    # oracle on host-ghosted arrays
+    dref = DomainManager(**kw)
+    dref.set_particles(ref, kernel.radius_scale)
+    dref.update()
+    onn = oracle.OracleNNPS(3, ref, kernel.radius_scale)
+    onn.update()
+    oev = oracle.OracleEval(ref, eqs, kernel, nthreads=4)
+    oev.set_nnps(onn)
+    oev.compute(0.0, 1e-4)
+    # HIP, host DomainManager
+    ctx = dev.HipContext(0)
+    a_eval = AccelerationEval([pa], eqs, kernel)
+    SPHCompiler(a_eval, ctx=ctx).compile()
+    nnps = HipNNPS(3, [pa], radius_scale=kernel.radius_scale, ctx=ctx,
+                   domain=DomainManager(**kw))
+    a_eval.set_nnps(nnps)
+    a_eval.compute(0.0, 1e-4)
+    nreal = pa.get_number_of_particles(True)
+    assert pa.get_number_of_particles() == ref[0].get_number_of_particles()
+    for prop in ('rho', 'V', 'p', 'au', 'av', 'aw', 'auhat', 'avhat', 'awhat'):
+        e = rel_err(pa.properties[prop][:nreal], ref[0].properties[prop][:nreal])
+        assert e < 1e-10, (prop, e)
+    # summation density (real=False group) also filled the ghosts
+    assert rel_err(pa.rho, ref[0].rho) < 1e-10
+
+
+@pytest.mark.gpu
+def test_device_domain_manager_matches_host(oracle):
+    """HipDomainManager (device-resident ghosts) creates the same ghost SET as
+    the host DomainManager and the evaluation agrees."""
+    from pysph_amd import kernels as K
+    from pysph_amd import device as dev
+    from pysph_amd.domain import DomainManager, HipDomainManager
+    from pysph_amd.scheme import TVFScheme
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.nnps import HipNNPS
+    from test_hip_parity import _copy_arrays
+    pa, dx = lattice(10, dim=3, hdx=1.0, jitter=0.05)
+    pa.x[3] = -0.004           # needs box-wrapping
+    pa.u[:] = np.sin(2 * np.pi * pa.y)
+    kernel = K.QuinticSpline(dim=3)
+    eqs = TVFScheme(['fluid'], [], dim=3, rho0=1.0, c0=10.0, nu=0.01, p0=100.0,
+                    pb=100.0, h0=dx).get_equations()
+    kw = dict(xmin=0, xmax=1, ymin=0, ymax=1, zmin=0, zmax=1, periodic_in_x=True,
+              periodic_in_y=True, periodic_in_z=True)
+    ref = _copy_arrays([pa])
+    dref = DomainManager(**kw)
+    dref.set_particles(ref, kernel.radius_scale)
+    dref.update()
+    onn = oracle.OracleNNPS(3, ref, kernel.radius_scale)
+    onn.update()
+    oev = oracle.OracleEval(ref, eqs, kernel, nthreads=4)
+    oev.set_nnps(onn)
+    oev.compute(0.0, 1e-4)
+
+    ctx = dev.HipContext(0)
+    nreal = pa.get_number_of_particles()
+    dev.attach(pa, ctx).push()
+    a_eval = AccelerationEval([pa], eqs, kernel)
+    SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+    nnps = HipNNPS(3, [pa], radius_scale=kernel.radius_scale, ctx=ctx,
+                   domain=HipDomainManager(ctx=ctx, **kw), sync=False)
+    a_eval.set_nnps(nnps)
+    assert pa.gpu.get_number_of_particles() == ref[0].get_number_of_particles()
+    assert pa.gpu.get_number_of_particles(True) == nreal
+    a_eval.compute(0.0, 1e-4)
+    nnps.update_domain()       # again: ghosts are dropped and rebuilt
+    nnps.update()
+    a_eval.compute(0.0, 1e-4)
+    assert pa.gpu.get_number_of_particles() == ref[0].get_number_of_particles()
+    pa.gpu.pull('x', 'rho', 'V', 'p', 'au', 'av', 'aw', 'auhat', 'avhat', 'awhat')
+    assert abs(pa.x[3] - 0.996) < 1e-15
+    for prop in ('rho', 'V', 'p', 'au', 'av', 'aw', 'auhat', 'avhat', 'awhat'):
+        e = rel_err(pa.properties[prop][:nreal], ref[0].properties[prop][:nreal])
+        assert e < 1e-10, (prop, e)
