@@ -41,7 +41,7 @@ enum sph_prop {
     SPH_X, SPH_Y, SPH_Z, SPH_U, SPH_V, SPH_W, SPH_H, SPH_M, SPH_RHO, SPH_P, SPH_CS,
     SPH_ARHO, SPH_AU, SPH_AV, SPH_AW, SPH_AX, SPH_AY, SPH_AZ, SPH_DT_CFL, SPH_DT_FORCE,
     SPH_VOL /* 'V' */, SPH_UHAT, SPH_VHAT, SPH_WHAT, SPH_AUHAT, SPH_AVHAT, SPH_AWHAT,
-    SPH_X0, SPH_Y0, SPH_Z0, SPH_U0, SPH_V0, SPH_W0, SPH_RHO0,
+    SPH_X0, SPH_Y0, SPH_Z0, SPH_U0, SPH_V0, SPH_W0, SPH_RHO0, SPH_VMAG2,
     SPH_PROP_COUNT
 };
 
@@ -209,6 +209,22 @@ int sph_domain_box_wrap(sph_ctx *ctx, int array_id, int axis, double vmin, doubl
  * SPH_PROP_COUNT ints, *n receives the count).                              */
 int sph_array_props(sph_ctx *ctx, int array_id, int *out, int *n);
 
+/* ---------------------------------------------------------------------- */
+/* integrator stage sweeps (the caller either side of the hot path)         */
+/* replaces the generated per-particle stage loops                          */
+/* (pysph/sph/integrator_cython.mako:87-113) for the steppers of            */
+/* pysph/sph/integrator_step.py; stage 0 = initialize, 1 = stage1, 2 = stage2;*/
+/* real particles only.                                                     */
+/* ---------------------------------------------------------------------- */
+enum sph_stepper {
+    SPH_STEP_WCSPH = 1, /* WCSPHStep            integrator_step.py:38-93  */
+    SPH_STEP_TVF = 2    /* TransportVelocityStep integrator_step.py:257-299 */
+};
+int sph_integrate_stage(sph_ctx *ctx, int array_id, int stepper, int stage, double dt);
+/* min over the first n_real particles of a property (h_minimum,
+ * pysph/sph/integrator.py:150-160).                                        */
+int sph_reduce_min(sph_ctx *ctx, int array_id, int prop, double *out);
+
 /* pair-kernel variant: 0 = per-lane cell walk (direct), 1 = LDS-tiled
  * two-phase (default).                                                      */
 int sph_set_option(sph_ctx *ctx, const char *key, long value);
@@ -220,7 +236,7 @@ int sph_set_option(sph_ctx *ctx, const char *key, long value);
 /* ---------------------------------------------------------------------- */
 int sph_timer_enable(sph_ctx *ctx, int on);
 int sph_timer_reset(sph_ctx *ctx);
-/* keys: "nnps", "pack", "eos", "pair", "scatter"; out: total ms and launches */
+/* keys: "nnps", "pack", "eos", "pair", "stage"; out: total ms and launches */
 int sph_timer_get(sph_ctx *ctx, const char *key, double *ms, long *count);
 
 #ifdef __cplusplus

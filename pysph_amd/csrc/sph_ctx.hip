@@ -56,7 +56,7 @@ static const char *PROP_NAMES[SPH_PROP_COUNT] = {
     "x", "y", "z", "u", "v", "w", "h", "m", "rho", "p", "cs",
     "arho", "au", "av", "aw", "ax", "ay", "az", "dt_cfl", "dt_force",
     "V", "uhat", "vhat", "what", "auhat", "avhat", "awhat",
-    "x0", "y0", "z0", "u0", "v0", "w0", "rho0"};
+    "x0", "y0", "z0", "u0", "v0", "w0", "rho0", "vmag2"};
 
 extern "C" {
 
@@ -252,7 +252,7 @@ int sph_timer_reset(sph_ctx *c)
 
 int sph_timer_get(sph_ctx *c, const char *key, double *ms, long *count)
 {
-    static const char *names[T_COUNT] = {"nnps", "pack", "eos", "pair", "scatter"};
+    static const char *names[T_COUNT] = {"nnps", "pack", "eos", "pair", "stage"};
     SPH_TRY(timer_drain(c));
     for (int i = 0; i < T_COUNT; i++)
         if (strcmp(key, names[i]) == 0) {

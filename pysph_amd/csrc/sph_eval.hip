@@ -1371,11 +1371,11 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
 // ---------------------------------------------------------------------------
 // max reduction (adaptive time step inputs: integrator.py:161-200)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_max(const double *__restrict__ v, size_t n, double *__restrict__ part)
+__global__ __launch_bounds__(256) void k_max(const double *__restrict__ v, size_t n, double *__restrict__ part, double sgn)
 {
     double m = -DBL_MAX;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        m = fmax(m, v[i]);
+        m = fmax(m, sgn * v[i]);
     for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
     __shared__ double s[4];
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
@@ -1383,7 +1383,12 @@ __global__ __launch_bounds__(256) void k_max(const double *__restrict__ v, size_
     if (threadIdx.x == 0) part[blockIdx.x] = fmax(fmax(s[0], s[1]), fmax(s[2], s[3]));
 }
 
-extern "C" int sph_reduce_max(sph_ctx *c, int id, int prop, double *out)
+static int reduce_minmax(sph_ctx *c, int id, int prop, double *out, bool want_max);
+
+extern "C" int sph_reduce_max(sph_ctx *c, int id, int prop, double *out) { return reduce_minmax(c, id, prop, out, true); }
+extern "C" int sph_reduce_min(sph_ctx *c, int id, int prop, double *out) { return reduce_minmax(c, id, prop, out, false); }
+
+static int reduce_minmax(sph_ctx *c, int id, int prop, double *out, bool want_max)
 {
     if (id < 0 || id >= SPH_MAX_ARRAYS || prop < 0 || prop >= SPH_PROP_COUNT || !c->arr[id].prop[prop]) {
         sph_set_error("sph_reduce_max: array %d has no device property %d", id, prop);
@@ -1392,14 +1397,15 @@ extern "C" int sph_reduce_max(sph_ctx *c, int id, int prop, double *out)
     HIP_TRY(hipSetDevice(c->device));
     DevArray &A = c->arr[id];
     size_t n = A.n_real;
-    if (n == 0) { *out = -DBL_MAX; return SPH_OK; }
+    const double sgn = want_max ? 1.0 : -1.0;
+    if (n == 0) { *out = want_max ? -DBL_MAX : DBL_MAX; return SPH_OK; }
     int nb = (int)std::min<size_t>(512, (n + 255) / 256);
     SPH_TRY(c->red_part.reserve(1024 * sizeof(double)));
-    hipLaunchKernelGGL(k_max, dim3(nb), dim3(256), 0, c->stream, A.prop[prop], n, c->red_part.as<double>());
+    hipLaunchKernelGGL(k_max, dim3(nb), dim3(256), 0, c->stream, A.prop[prop], n, c->red_part.as<double>(), sgn);
     hipLaunchKernelGGL(k_max, dim3(1), dim3(256), 0, c->stream, c->red_part.as<double>(), (size_t)nb,
-                       c->red_part.as<double>() + 512);
+                       c->red_part.as<double>() + 512, 1.0);
     HIP_TRY(hipMemcpyAsync(c->pinned, c->red_part.as<double>() + 512, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    *out = c->pinned[0];
+    *out = sgn * c->pinned[0];
     return SPH_OK;
 }

@@ -56,7 +56,7 @@ struct HaloState {
     size_t count[2] = {0, 0};
 };
 
-enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_SCATTER, T_COUNT };
+enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_STAGE, T_COUNT };
 
 struct Timer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;

@@ -80,6 +80,9 @@ SIGNATURES = {
     'sph_halo_append': (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int),
                                   _P, C.c_size_t]),
     'sph_reduce_max': (C.c_int, [_P, C.c_int, C.c_int, _PD]),
+    'sph_reduce_min': (C.c_int, [_P, C.c_int, C.c_int, _PD]),
+    'sph_integrate_stage': (C.c_int, [_P, C.c_int, C.c_int, C.c_int,
+                                      C.c_double]),
     'sph_set_option': (C.c_int, [_P, C.c_char_p, C.c_long]),
     'sph_timer_enable': (C.c_int, [_P, C.c_int]),
     'sph_timer_reset': (C.c_int, [_P]),
@@ -263,6 +266,12 @@ class HipDeviceHelper(object):
     def max(self, prop):
         out = C.c_double()
         _check(self.lib.sph_reduce_max(self.ctx._h, self.array_id,
+                                       prop_id(prop), C.byref(out)))
+        return out.value
+
+    def min(self, prop):
+        out = C.c_double()
+        _check(self.lib.sph_reduce_min(self.ctx._h, self.array_id,
                                        prop_id(prop), C.byref(out)))
         return out.value
 

@@ -237,8 +237,41 @@ def case_kernels():
     print('wrote', path)
 
 
+def case_steppers():
+    """The reference's stepper methods (integrator_step.py:38-93, 257-299)
+    executed as plain Python on 24 random particles."""
+    from inspect import getfullargspec
+    from pysph.sph.integrator_step import WCSPHStep, TransportVelocityStep
+    rng = np.random.default_rng(17)
+    n = 24
+    names = ['x', 'y', 'z', 'u', 'v', 'w', 'rho', 'x0', 'y0', 'z0', 'u0', 'v0',
+             'w0', 'rho0', 'au', 'av', 'aw', 'ax', 'ay', 'az', 'arho', 'uhat',
+             'vhat', 'what', 'auhat', 'avhat', 'awhat', 'vmag2']
+    base = {k: rng.uniform(-1, 1, n) for k in names}
+    out = {'in/' + k: v.copy() for k, v in base.items()}
+    dt = 0.0123
+    out['dt'] = np.array(dt)
+
+    def run(step, methods, tag):
+        st = {k: [float(x) for x in v] for k, v in base.items()}
+        for meth in methods:
+            f = getattr(step, meth)
+            args = [a for a in getfullargspec(f).args if a != 'self']
+            for i in range(n):
+                ns = dict(('d_' + k, v) for k, v in st.items())
+                ns.update(d_idx=i, dt=dt, t=0.0)
+                f(*[ns[a] for a in args])
+            for k, v in st.items():
+                out['%s/%s/%s' % (tag, meth, k)] = np.array(v)
+    run(WCSPHStep(), ['initialize', 'stage1', 'stage2'], 'wcsph')
+    run(TransportVelocityStep(), ['stage1', 'stage2'], 'tvf')
+    path = os.path.join(HERE, 'steppers.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['kernels', 'sd_1d', 'wcsph_cube_varh', 'tvf_cube',
-                             'wcsph_dam']
+                             'wcsph_dam', 'steppers']
     for w in which:
         globals()['case_' + w]()

@@ -1,0 +1,123 @@
+"""Integrator stage kernels + device-resident time stepping."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from helpers import rel_err
+
+STEP_PROPS = ['x', 'y', 'z', 'u', 'v', 'w', 'rho', 'x0', 'y0', 'z0', 'u0', 'v0',
+              'w0', 'rho0', 'au', 'av', 'aw', 'ax', 'ay', 'az', 'arho', 'uhat',
+              'vhat', 'what', 'auhat', 'avhat', 'awhat', 'vmag2']
+
+
+def _pa_from(g):
+    from pysph_amd.particle_array import ParticleArray
+    return ParticleArray(name='fluid', **{k: g['in/' + k].copy()
+                                          for k in STEP_PROPS})
+
+
+def test_oracle_steppers_match_reference_bitwise():
+    """numpy stepper restatement vs the reference's WCSPHStep /
+    TransportVelocityStep methods (golden): bit-exact."""
+    from oracle import steppers as S
+    g = load_golden('steppers.npz')
+    dt = float(g['dt'])
+    pa = _pa_from(g)
+    S.wcsph_initialize(pa)
+    for k in STEP_PROPS:
+        assert np.array_equal(pa.properties[k], g['wcsph/initialize/' + k]), k
+    S.wcsph_stage(pa, dt, 1)
+    for k in STEP_PROPS:
+        assert np.array_equal(pa.properties[k], g['wcsph/stage1/' + k]), k
+    S.wcsph_stage(pa, dt, 2)
+    for k in STEP_PROPS:
+        assert np.array_equal(pa.properties[k], g['wcsph/stage2/' + k]), k
+    pa = _pa_from(g)
+    S.tvf_stage1(pa, dt)
+    for k in STEP_PROPS:
+        assert np.array_equal(pa.properties[k], g['tvf/stage1/' + k]), k
+    S.tvf_stage2(pa, dt)
+    for k in STEP_PROPS:
+        assert np.array_equal(pa.properties[k], g['tvf/stage2/' + k]), k
+
+
+def test_integrator_api_surface():
+    from pysph_amd.integrator import (Integrator, EPECIntegrator, WCSPHStep,
+                                      TransportVelocityStep)
+    with pytest.raises(ValueError):
+        Integrator(fluid=object())
+    i = EPECIntegrator(fluid=WCSPHStep(), solid=WCSPHStep())
+    assert sorted(i.steppers) == ['fluid', 'solid']
+    assert TransportVelocityStep()._kind == 2
+
+
+@pytest.mark.gpu
+def test_stage_kernels_match_reference_golden():
+    """sph_integrate_stage vs the reference stepper methods (golden vectors).
+    fp contraction (fma) may differ in the last bit: tolerance 4 ulp."""
+    import ctypes as C
+    from pysph_amd import device as dev
+    g = load_golden('steppers.npz')
+    dt = float(g['dt'])
+    for kind, tag, stages in ((1, 'wcsph', [(0, 'initialize'), (1, 'stage1'), (2, 'stage2')]),
+                              (2, 'tvf', [(1, 'stage1'), (2, 'stage2')])):
+        pa = _pa_from(g)
+        ctx = dev.HipContext(0)
+        gpu = dev.attach(pa, ctx)
+        gpu.push()
+        for st, name in stages:
+            dev._check(ctx.lib.sph_integrate_stage(ctx._h, gpu.array_id, kind, st, dt))
+            gpu.pull()
+            for k in STEP_PROPS:
+                ref = g['%s/%s/%s' % (tag, name, k)]
+                assert np.allclose(pa.properties[k], ref, rtol=1e-15, atol=1e-16), (tag, name, k)
+
+
+@pytest.mark.gpu
+def test_epec_steps_device_resident_vs_oracle(oracle):
+    """Three EPEC steps of the WCSPH cube with everything device-resident
+    (one push, one pull) against the CPU oracle loop; also the adaptive
+    time-step reductions (integrator.py:161-200)."""
+    from oracle import steppers as S
+    from pysph_amd import device as dev
+    from pysph_amd import kernels as K
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.integrator import EPECIntegrator, WCSPHStep, setup_integrator
+    from pysph_amd.nnps import HipNNPS
+    from test_hip_parity import make_cube, cube_equations, _copy_arrays
+    pa, dx = make_cube(16)
+    ref = _copy_arrays([pa])
+    eqs = cube_equations(dx)
+    kernel = K.WendlandQuintic(dim=3)
+    dt = 0.25 * 1.3 * dx / 32.85
+    ctx = dev.HipContext(0)
+    dev.attach(pa, ctx).push()
+    a_eval = AccelerationEval([pa], eqs, kernel)
+    SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+    nnps = HipNNPS(3, [pa], radius_scale=2.0, ctx=ctx, sync=False)
+    a_eval.set_nnps(nnps)
+    integ = EPECIntegrator(fluid=WCSPHStep())
+    setup_integrator(integ, a_eval, nnps)
+    calls = []
+    integ.set_post_stage_callback(lambda t, dt_, stage: calls.append((t, stage)))
+    onn = oracle.OracleNNPS(3, ref, 2.0)
+    oev = oracle.OracleEval(ref, eqs, kernel, nthreads=4)
+    oev.set_nnps(onn)
+    t = 0.0
+    for _ in range(3):
+        integ.step(t, dt)
+        S.epec_step(ref, onn, oev, t, dt)
+        t += dt
+    assert len(calls) == 6 and calls[0][1] == 1 and calls[1][1] == 2
+    assert abs(calls[0][0] - 0.5 * dt) < 1e-18
+    pa.gpu.pull()
+    for prop in ('x', 'y', 'z', 'u', 'v', 'w', 'rho', 'au', 'av', 'aw', 'arho'):
+        e = rel_err(pa.properties[prop], ref[0].properties[prop])
+        assert e < 1e-10, (prop, e)
+    # adaptive dt from device reductions == host formula on the oracle state
+    got = integ.compute_time_step(dt, 0.3)
+    r = ref[0]
+    hmin = r.h.min()
+    want = 0.3 * min(hmin / r.dt_cfl.max(),
+                     np.sqrt(hmin / np.sqrt(r.dt_force.max())))
+    assert abs(got - want) < 1e-9 * want
