@@ -117,6 +117,8 @@ def main():
     ap.add_argument('--variant', type=int, default=3)
     ap.add_argument('--ablate', type=int, default=0, help='profiling only')
     ap.add_argument('--opt', action='append', default=[], help='key=value library option')
+    ap.add_argument('--no-reorder', action='store_true',
+                    help='skip Solver.reorder_particles() before timing')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-n1', type=int, default=100)
     args = ap.parse_args()
@@ -168,6 +170,12 @@ def main():
     nnps = HipNNPS(3, [pa], radius_scale=kernel.radius_scale, ctx=ctx,
                    sync=False)
     a_eval.set_nnps(nnps)
+    if not args.no_reorder:
+        # what the reference's Solver does for its GPU backends before the first
+        # step and every 50 steps (solver.py:296-302, application.py:1157-1161):
+        # put the particles in cell order so gathers/scatters coalesce
+        nnps.spatially_order_particles(0)
+        nnps.update()
 
     def step():
         if halo is not None:
@@ -218,6 +226,7 @@ def main():
                             '(WendlandQuintic, hdx 1.3), %d^3 = %d particles '
                             'per GPU, jitter 0.1dx, seed 1234' % (n1, n_local),
                 'particles_per_gpu': n_local, 'pair_variant': args.variant,
+                'spatially_ordered': not args.no_reorder,
                 'parallelism': 'slab%d' % world if world > 1 else 'single',
             },
             'roofline': {

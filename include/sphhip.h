@@ -160,6 +160,14 @@ int sph_nnps_get_csr(sph_ctx *ctx, int src, int dst, uint32_t *start, uint32_t *
  * (linked_list_nnps.pyx:198-209).                                          */
 int sph_nnps_get_order(sph_ctx *ctx, int array_id, uint32_t *perm);
 
+/* Physically reorder EVERY device property of `array_id` into the cell order
+ * of the last sph_nnps_update (new[i] = old[perm[i]]): the device-resident
+ * form of NNPS.spatially_order_particles (pysph/base/nnps_base.pyx:1615-1629),
+ * which the reference's Solver runs before the first step and every
+ * reorder_freq (=50 on GPU backends) steps (pysph/solver/solver.py:296-302,
+ * application.py:1157-1161).  Invalidates the grid: update afterwards.      */
+int sph_nnps_reorder_array(sph_ctx *ctx, int array_id);
+
 /* ---------------------------------------------------------------------- */
 /* acceleration evaluation                                                  */
 /* replaces one leaf-group block of the generated AccelerationEval.compute  */

@@ -114,23 +114,29 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
     uint32_t o = a.perm[i];
     double4 ph;
     ph.x = a.x[o]; ph.y = a.y[o]; ph.z = a.z[o]; ph.w = a.h[o];
-    double *dst;
-    if (a.rec) {
-        double *r = a.rec + (a.off + i) * (size_t)a.nr;
-        *reinterpret_cast<double4 *>(r) = ph;
-        dst = r + 4;
-    } else {
-        a.posh[a.off + i] = ph;
-        dst = a.aux + (a.off + i) * (size_t)a.na;
-    }
     double v[MAX_AUX];
 #pragma unroll
     for (int k = 0; k < MAX_AUX; k++) v[k] = (k < a.na && a.src[k]) ? a.src[k][o] : 0.0;
     if (a.derived == 1) v[5] = v[4] != 0.0 ? v[7] * (1.0 / (v[4] * v[4])) : 0.0; // tmpj = p*rhoj21, wc/basic.py:211,234
     if (a.derived == 2) { double Vj = 1. / v[8]; v[10] = Vj * Vj; } // Vj2, transport_velocity.py:303-306
+    if (a.rec) {
+        // 32-B stores: every store covers whole sectors of the record
+        double4 *r = reinterpret_cast<double4 *>(a.rec + (a.off + i) * (size_t)a.nr);
+        r[0] = ph;
+        const int n4 = (a.nr - 4) / 4;
 #pragma unroll
-    for (int k = 0; k < MAX_AUX; k++) if (k < a.na) dst[k] = v[k];
-    if (a.rec) for (int k = 4 + a.na; k < a.nr; k++) dst[k - 4] = 0.0;
+        for (int q = 0; q < MAX_AUX / 4; q++)
+            if (q < n4) r[1 + q] = make_double4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        if ((a.nr - 4) & 3) { // 16-B tail (density family: 6 doubles)
+            double2 *t2 = reinterpret_cast<double2 *>(a.rec + (a.off + i) * (size_t)a.nr + 4 + 4 * n4);
+            *t2 = make_double2(v[4 * n4], v[4 * n4 + 1]);
+        }
+    } else {
+        a.posh[a.off + i] = ph;
+        double *dst = a.aux + (a.off + i) * (size_t)a.na;
+#pragma unroll
+        for (int k = 0; k < MAX_AUX; k++) if (k < a.na) dst[k] = v[k];
+    }
 }
 
 struct SrcDesc {

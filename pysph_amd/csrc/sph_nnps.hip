@@ -410,3 +410,43 @@ extern "C" int sph_nnps_get_csr(sph_ctx *c, int src, int dst, uint32_t *start, u
     if (total) *total = tot;
     return SPH_OK;
 }
+
+// ---------------------------------------------------------------------------
+// physical reorder into cell order
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_f64(const double *__restrict__ src, const uint32_t *__restrict__ perm,
+                                                    size_t n, double *__restrict__ dst)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[perm[i]];
+}
+
+extern "C" int sph_nnps_reorder_array(sph_ctx *c, int id)
+{
+    if (!c || id < 0 || id >= SPH_MAX_ARRAYS) { sph_set_error("sph_nnps_reorder_array: bad arguments"); return SPH_ERR_ARG; }
+    if (!c->nnps_valid || c->arr[id].nnps_slot < 0) { sph_set_error("sph_nnps_reorder_array: array not binned"); return SPH_ERR_STATE; }
+    HIP_TRY(hipSetDevice(c->device));
+    DevArray &A = c->arr[id];
+    if (A.n == 0) return SPH_OK;
+    if (A.n_real != A.n) {
+        // real particles must stay first (particle_array.pyx:1092): ghosts are
+        // transient (halo / periodic images) and are rebuilt after a reorder
+        sph_set_error("sph_nnps_reorder_array: drop ghost particles first (n=%zu, n_real=%zu)", A.n, A.n_real);
+        return SPH_ERR_STATE;
+    }
+    double *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&tmp, A.cap * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(tmp, 0, A.cap * sizeof(double), c->stream));
+    for (int p = 0; p < SPH_PROP_COUNT; p++) {
+        if (!A.prop[p]) continue;
+        hipLaunchKernelGGL(k_gather_f64, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, A.prop[p], A.perm.as<uint32_t>(),
+                           A.n, tmp);
+        double *old = A.prop[p];
+        A.prop[p] = tmp;
+        tmp = old;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(tmp));
+    c->nnps_valid = false;
+    return SPH_OK;
+}

@@ -66,6 +66,7 @@ SIGNATURES = {
     'sph_nnps_get_csr': (C.c_int, [_P, C.c_int, C.c_int, _PU, _PU,
                                    C.POINTER(C.c_size_t)]),
     'sph_nnps_get_order': (C.c_int, [_P, C.c_int, _PU]),
+    'sph_nnps_reorder_array': (C.c_int, [_P, C.c_int]),
     'sph_eval_group': (C.c_int, [_P, C.POINTER(SphKernel),
                                  C.POINTER(SphGroup), C.c_double, C.c_double]),
     'sph_halo_select': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_double,

@@ -135,7 +135,15 @@ class HipNNPS(object):
         return perm[:n]
 
     def spatially_order_particles(self, pa_index):
-        """Reorder the HOST array into cell order (nnps_base.pyx:1615-1629)."""
+        """Reorder the particles into cell order (nnps_base.pyx:1615-1629).
+        Host arrays when they are authoritative (sync=True); otherwise the
+        device-resident properties are permuted in place.  As in the reference
+        (solver.py:296-302) the caller must ``update()`` afterwards."""
+        if not self.sync:
+            dev._check(self.lib.sph_nnps_reorder_array(
+                self.ctx._h, self.helpers[pa_index].array_id))
+            self._csr_key = None
+            return
         pa = self.particles[pa_index]
         order = self.get_spatially_ordered_indices(pa_index).astype(np.int64)
         for name, arr in pa.properties.items():

@@ -415,3 +415,38 @@ def test_halo_device_ops_two_slabs_one_gpu(oracle):
         for prop in WC_OUT:
             e = rel_err(pa.properties[prop], full.properties[prop][rk['own']])
             assert e < TOL, (prop, e)
+
+
+def test_device_reorder_keeps_results(oracle):
+    """NNPS.spatially_order_particles on device-resident state
+    (nnps_base.pyx:1615-1629; solver.py:296-302): properties are permuted by
+    the cell order, results are unchanged when matched through that order."""
+    from pysph_amd import device as dev
+    from pysph_amd import kernels as K
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.nnps import HipNNPS
+    pa, dx = make_cube(20)
+    ref = _copy_arrays([pa])
+    eqs = cube_equations(dx)
+    kernel = K.WendlandQuintic(dim=3)
+    ctx = dev.HipContext(0)
+    dev.attach(pa, ctx).push()
+    a_eval = AccelerationEval([pa], eqs, kernel)
+    SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+    nnps = HipNNPS(3, [pa], radius_scale=2.0, ctx=ctx, sync=False)
+    a_eval.set_nnps(nnps)
+    order = nnps.get_spatially_ordered_indices(0).astype(np.int64)
+    nnps.spatially_order_particles(0)
+    nnps.update()
+    order2 = nnps.get_spatially_ordered_indices(0)
+    assert np.array_equal(order2, np.arange(order.size))   # already sorted now
+    a_eval.compute(0.0, 1e-5)
+    pa.gpu.pull()
+    onn = oracle.OracleNNPS(3, ref, 2.0)
+    onn.update()
+    oev = oracle.OracleEval(ref, eqs, kernel, nthreads=4)
+    oev.set_nnps(onn)
+    oev.compute(0.0, 1e-5)
+    assert np.array_equal(pa.x, ref[0].x[order])
+    for prop in WC_OUT:
+        assert rel_err(pa.properties[prop], ref[0].properties[prop][order]) < TOL, prop
