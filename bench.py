@@ -211,6 +211,18 @@ def main():
     value = n_total * args.steps / elapsed
 
     if rank == 0:
+        # HBM bytes per launch of the dominant kernel come from a separate
+        # rocprofv3 --pmc run of this same command (profiles/); only quoted when
+        # the configuration matches the profiled one, else null
+        traffic = None
+        try:
+            pt = json.load(open(os.path.join(REPO, 'profiles', 'pmc_traffic.json')))
+            c = pt['config']
+            if (c['n1'], c['variant'], c['spatially_ordered']) == \
+                    (n1, args.variant, not args.no_reorder) and world == 1:
+                traffic = pt['bytes_per_launch']
+        except Exception:
+            traffic = None
         pair_avg_s = pair_ms / max(pair_launches, 1) * 1e-3
         achieved = ALGO_BYTES_PAIR * n_local / pair_avg_s / 1e9 if pair_avg_s > 0 else 0.0
         out = {
@@ -233,7 +245,7 @@ def main():
                 'bound': 'hbm', 'kernel': 'k_pair_%s<FamWCSPH,WendlandQuintic>' %
                 ('direct', 'tiled', 'wg', 'agg')[args.variant],
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                 'algorithmic_bytes_per_particle': ALGO_BYTES_PAIR,
                 'avg_kernel_ms': pair_avg_s * 1e3,
             },
