@@ -42,6 +42,13 @@ enum sph_prop {
     SPH_ARHO, SPH_AU, SPH_AV, SPH_AW, SPH_AX, SPH_AY, SPH_AZ, SPH_DT_CFL, SPH_DT_FORCE,
     SPH_VOL /* 'V' */, SPH_UHAT, SPH_VHAT, SPH_WHAT, SPH_AUHAT, SPH_AVHAT, SPH_AWHAT,
     SPH_X0, SPH_Y0, SPH_Z0, SPH_U0, SPH_V0, SPH_W0, SPH_RHO0, SPH_VMAG2,
+    /* elastic solids (pysph/sph/solid_mech/basic.py:34-60) */
+    SPH_E, SPH_AE, SPH_E0,
+    SPH_V00, SPH_V01, SPH_V02, SPH_V10, SPH_V11, SPH_V12, SPH_V20, SPH_V21, SPH_V22,
+    SPH_S00, SPH_S01, SPH_S02, SPH_S11, SPH_S12, SPH_S22,
+    SPH_AS00, SPH_AS01, SPH_AS02, SPH_AS11, SPH_AS12, SPH_AS22,
+    SPH_R00, SPH_R01, SPH_R02, SPH_R11, SPH_R12, SPH_R22,
+    SPH_S000, SPH_S010, SPH_S020, SPH_S110, SPH_S120, SPH_S220,
     SPH_PROP_COUNT
 };
 
@@ -78,7 +85,13 @@ enum sph_eq_kind {
     SPH_EQ_TVF_MOM_ART_VISCOSITY = 11,/* :389  par: c0 alpha */
     SPH_EQ_TVF_MOM_ART_STRESS = 12,   /* :439 */
     SPH_EQ_ISOTHERMAL_EOS = 13,       /* basic_equations.py:151  par: rho0 c0 p0 */
-    SPH_EQ_MONAGHAN_ART_VISCOSITY = 14/* basic_equations.py:195  par: alpha beta */
+    SPH_EQ_MONAGHAN_ART_VISCOSITY = 14,/* basic_equations.py:195  par: alpha beta */
+    SPH_EQ_VELOCITY_GRADIENT_3D = 15, /* basic_equations.py:101 */
+    SPH_EQ_VELOCITY_GRADIENT_2D = 16, /* basic_equations.py:63 */
+    SPH_EQ_HOOKES_DEVIATORIC_STRESS_RATE = 17, /* solid_mech/basic.py:390  par: G (= d_G[0]) */
+    SPH_EQ_MOMENTUM_WITH_STRESS = 18, /* solid_mech/basic.py:245  par: wdeltap n (= d_wdeltap[0], d_n[0]) */
+    SPH_EQ_MONAGHAN_ART_STRESS = 19,  /* solid_mech/basic.py:104  par: eps */
+    SPH_EQ_SOLID_ISOTHERMAL_EOS = 21  /* solid_mech/basic.py:93   par: c0_ref rho_ref */
 };
 
 /* One Equation(dest, sources) instance: pysph/sph/equation.py:392-420. */
@@ -226,7 +239,8 @@ int sph_array_props(sph_ctx *ctx, int array_id, int *out, int *n);
 /* ---------------------------------------------------------------------- */
 enum sph_stepper {
     SPH_STEP_WCSPH = 1, /* WCSPHStep            integrator_step.py:38-93  */
-    SPH_STEP_TVF = 2    /* TransportVelocityStep integrator_step.py:257-299 */
+    SPH_STEP_TVF = 2,   /* TransportVelocityStep integrator_step.py:257-299 */
+    SPH_STEP_SOLID_MECH = 3 /* SolidMechStep       integrator_step.py:173-255 */
 };
 int sph_integrate_stage(sph_ctx *ctx, int array_id, int stepper, int stage, double dt);
 /* min over the first n_real particles of a property (h_minimum,

@@ -56,6 +56,14 @@ EQS = {
     'MomentumEquationArtificialStress': (12, ()),
     'IsothermalEOS': (13, ('rho0', 'c0', 'p0')),
     'MonaghanArtificialViscosity': (14, ('alpha', 'beta')),
+    'VelocityGradient3D': (15, ()),
+    'VelocityGradient2D': (16, ()),
+    # '@name' = first value of the destination array's constant `name`
+    # (d_G[0], d_wdeltap[0], d_n[0], d_c0_ref[0], d_rho_ref[0])
+    'HookesDeviatoricStressRate': (17, ('@G',)),
+    'MomentumEquationWithStress': (18, ('@wdeltap', '@n')),
+    'MonaghanArtificialStress': (19, ('eps',)),
+    'SolidIsothermalEOS': (21, ('@c0_ref', '@rho_ref')),
 }
 
 
@@ -119,6 +127,7 @@ def lib():
         L.orc_kernel_gradient.argtypes = [C.POINTER(_Kernel),
                                           C.POINTER(C.c_double), C.c_double,
                                           C.c_double, C.POINTER(C.c_double)]
+        L.orc_eigen3.argtypes = [C.POINTER(C.c_double)] * 3
         L.orc_last_error.restype = C.c_char_p
         _LIB = L
     return _LIB
@@ -219,6 +228,8 @@ def _eq_name(eq):
     name = type(eq).__name__
     if name == 'SummationDensity' and 'transport_velocity' in type(eq).__module__:
         name = 'TVFSummationDensity'
+    if name == 'IsothermalEOS' and 'solid_mech' in type(eq).__module__:
+        name = 'SolidIsothermalEOS'
     return name
 
 
@@ -249,8 +260,12 @@ class OracleEval(object):
                 ce[ei].nsrc = len(srcs)
                 for k, s in enumerate(srcs):
                     ce[ei].src[k] = names.index(s)
+                dest_pa = self.particle_arrays[names.index(eq.dest)]
                 for k, p in enumerate(pars):
-                    ce[ei].par[k] = float(getattr(eq, p))
+                    if p.startswith('@'):
+                        ce[ei].par[k] = float(np.ravel(dest_pa.constants[p[1:]])[0])
+                    else:
+                        ce[ei].par[k] = float(getattr(eq, p))
             self._keep.append(ce)
             cg[gi].real = 1 if g.real else 0
             cg[gi].start_idx = self._idx(g.start_idx, g, 0)
@@ -297,3 +312,13 @@ def kernel_gradient(kernel, xij, rij, h):
     g = (C.c_double * 3)()
     lib().orc_kernel_gradient(C.byref(k), x, rij, h, g)
     return [g[0], g[1], g[2]]
+
+
+def eigen3(a):
+    """linalg3.eigen_decomposition restatement: returns (d[3], V[3,3])."""
+    A = np.ascontiguousarray(a, dtype=float).ravel()
+    V = np.zeros(9)
+    d = np.zeros(3)
+    P = C.POINTER(C.c_double)
+    lib().orc_eigen3(A.ctypes.data_as(P), V.ctypes.data_as(P), d.ctypes.data_as(P))
+    return d, V.reshape(3, 3)

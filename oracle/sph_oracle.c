@@ -434,6 +434,175 @@ typedef struct {
     double XIJ[3], VIJ[3], DWIJ[3];
 } pair_t;
 
+
+/* ------------------------------------------------------------------ */
+/* 3x3 symmetric eigen-decomposition: pysph/base/linalg3.pyx:259-560    */
+/* (EISPACK tred2 + tql2 as the reference carries them), operation order */
+/* kept so results match the compiled reference bit for bit.            */
+/* ------------------------------------------------------------------ */
+#define EN 3
+static inline double hypot2(double x, double y) { return sqrt(x * x + y * y); } /* linalg3.pyx:30-31 */
+
+static void eig_tred2(double V[EN][EN], double *d, double *e) /* linalg3.pyx:259-378 */
+{
+    int i, j, k;
+    double scale, f, g, h, hh;
+    for (j = 0; j < EN; j++) d[j] = V[EN - 1][j];
+    for (i = EN - 1; i > 0; i--) {
+        scale = 0.0; h = 0.0;
+        for (k = 0; k < i; k++) scale += fabs(d[k]);
+        if (scale == 0.0) {
+            e[i] = d[i - 1];
+            for (j = 0; j < i; j++) { d[j] = V[i - 1][j]; V[i][j] = 0.0; V[j][i] = 0.0; }
+        } else {
+            for (k = 0; k < i; k++) { d[k] /= scale; h += d[k] * d[k]; }
+            f = d[i - 1];
+            g = sqrt(h);
+            if (f > 0) g = -g;
+            e[i] = scale * g;
+            h = h - f * g;
+            d[i - 1] = f - g;
+            for (j = 0; j < i; j++) e[j] = 0.0;
+            for (j = 0; j < i; j++) {
+                f = d[j];
+                V[j][i] = f;
+                g = e[j] + V[j][j] * f;
+                for (k = j + 1; k < i; k++) { g += V[k][j] * d[k]; e[k] += V[k][j] * f; }
+                e[j] = g;
+            }
+            f = 0.0;
+            for (j = 0; j < i; j++) { e[j] /= h; f += e[j] * d[j]; }
+            hh = f / (h + h);
+            for (j = 0; j < i; j++) e[j] -= hh * d[j];
+            for (j = 0; j < i; j++) {
+                f = d[j]; g = e[j];
+                for (k = j; k < i; k++) V[k][j] -= (f * e[k] + g * d[k]);
+                d[j] = V[i - 1][j];
+                V[i][j] = 0.0;
+            }
+        }
+        d[i] = h;
+    }
+    for (i = 0; i < EN - 1; i++) {
+        V[EN - 1][i] = V[i][i];
+        V[i][i] = 1.0;
+        h = d[i + 1];
+        if (h != 0.0) {
+            for (k = 0; k < i + 1; k++) d[k] = V[k][i + 1] / h;
+            for (j = 0; j < i + 1; j++) {
+                g = 0.0;
+                for (k = 0; k < i + 1; k++) g += V[k][i + 1] * V[k][j];
+                for (k = 0; k < i + 1; k++) V[k][j] -= g * d[k];
+            }
+        }
+        for (k = 0; k < i + 1; k++) V[k][i + 1] = 0.0;
+    }
+    for (j = 0; j < EN; j++) { d[j] = V[EN - 1][j]; V[EN - 1][j] = 0.0; }
+    V[EN - 1][EN - 1] = 1.0;
+    e[0] = 0.0;
+}
+
+static void eig_tql2(double V[EN][EN], double *d, double *e) /* linalg3.pyx:381-500 */
+{
+    int i, j, k, l, m;
+    double f, tst1, eps, g, h, p, r, dl1, c, c2, c3, el1, s, s2;
+    for (i = 1; i < EN; i++) e[i - 1] = e[i];
+    e[EN - 1] = 0.0;
+    f = 0.0; tst1 = 0.0;
+    eps = pow(2.0, -52.0);
+    for (l = 0; l < EN; l++) {
+        tst1 = fmax(tst1, fabs(d[l]) + fabs(e[l]));
+        m = l;
+        while (m < EN) {
+            if (fabs(e[m]) <= eps * tst1) break;
+            m += 1;
+        }
+        if (m > l) {
+            int cont = 1;
+            while (cont) {
+                g = d[l];
+                p = (d[l + 1] - g) / (2.0 * e[l]);
+                r = hypot2(p, 1.0);
+                if (p < 0) r = -r;
+                d[l] = e[l] / (p + r);
+                d[l + 1] = e[l] * (p + r);
+                dl1 = d[l + 1];
+                h = g - d[l];
+                for (i = l + 2; i < EN; i++) d[i] -= h;
+                f += h;
+                p = d[m];
+                c = 1.0; c2 = c; c3 = c;
+                el1 = e[l + 1];
+                s = 0.0; s2 = 0.0;
+                for (i = m - 1; i > l - 1; i--) {
+                    c3 = c2; c2 = c; s2 = s;
+                    g = c * e[i];
+                    h = c * p;
+                    r = hypot2(p, e[i]);
+                    e[i + 1] = s * r;
+                    s = e[i] / r;
+                    c = p / r;
+                    p = c * d[i] - s * g;
+                    d[i + 1] = h + s * (c * g + s * d[i]);
+                    for (k = 0; k < EN; k++) {
+                        h = V[k][i + 1];
+                        V[k][i + 1] = s * V[k][i] + c * h;
+                        V[k][i] = c * V[k][i] - s * h;
+                    }
+                }
+                p = -s * s2 * c3 * el1 * e[l] / dl1;
+                e[l] = s * p;
+                d[l] = c * p;
+                cont = fabs(e[l]) > eps * tst1;
+            }
+        }
+        d[l] += f;
+        e[l] = 0.0;
+    }
+    for (i = 0; i < EN - 1; i++) {
+        k = i; p = d[i];
+        for (j = i + 1; j < EN; j++) if (d[j] < p) { k = j; p = d[j]; }
+        if (k != i) {
+            d[k] = d[i]; d[i] = p;
+            for (j = 0; j < EN; j++) { p = V[j][i]; V[j][i] = V[j][k]; V[j][k] = p; }
+        }
+    }
+}
+
+/* linalg3.pyx:509-536 */
+static void eigen_decomposition(double A[EN][EN], double V[EN][EN], double *d)
+{
+    double e[EN];
+    double s = 0.0;
+    int i, j;
+    for (i = 0; i < EN; i++)
+        for (j = 0; j < EN; j++) { V[i][j] = A[i][j]; s += fabs(V[i][j]); }
+    if (s == 0) {
+        for (i = 0; i < 3; i++) { d[i] = 0.0; for (j = 0; j < 3; j++) V[i][j] = (i == j); }
+    } else {
+        for (i = 0; i < EN; i++) for (j = 0; j < EN; j++) V[i][j] /= s;
+        eig_tred2(V, d, e);
+        eig_tql2(V, d, e);
+        for (i = 0; i < EN; i++) d[i] *= s;
+    }
+}
+
+/* P*A*P.T with A diagonal: linalg3.pyx:220-234 */
+static void transform_diag_inv(const double *A, double P[3][3], double res[3][3])
+{
+    int i, j, k;
+    for (i = 0; i < 3; i++) for (j = 0; j < 3; j++) res[i][j] = 0.0;
+    for (i = 0; i < 3; i++) for (j = 0; j < 3; j++) for (k = 0; k < 3; k++) res[i][j] += P[i][k] * A[k] * P[j][k];
+}
+
+void orc_eigen3(const double *A9, double *V9, double *d3)
+{
+    double A[3][3], V[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A[i][j] = A9[3 * i + j];
+    eigen_decomposition(A, V, d3);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) V9[3 * i + j] = V[i][j];
+}
+
 /* ------------------------------------------------------------------ */
 /* equations                                                            */
 /* ------------------------------------------------------------------ */
@@ -463,7 +632,20 @@ static void eq_initialize(const orc_equation *e, const orc_array *D, long d_idx)
     case OE_TVF_MOM_ART_VISCOSITY:
     case OE_TVF_MOM_ART_STRESS:
     case OE_MONAGHAN_ART_VISCOSITY:
+    case OE_MOMENTUM_WITH_STRESS: /* solid_mech/basic.py:262-265 */
         DP(OP_AU)[d_idx] = 0.0; DP(OP_AV)[d_idx] = 0.0; DP(OP_AW)[d_idx] = 0.0;
+        break;
+    case OE_VELOCITY_GRADIENT_2D: /* basic_equations.py:82-86 */
+        DP(OP_V00)[d_idx] = 0.0; DP(OP_V01)[d_idx] = 0.0; DP(OP_V10)[d_idx] = 0.0; DP(OP_V11)[d_idx] = 0.0;
+        break;
+    case OE_VELOCITY_GRADIENT_3D: /* basic_equations.py:115-128 */
+        DP(OP_V00)[d_idx] = 0.0; DP(OP_V01)[d_idx] = 0.0; DP(OP_V02)[d_idx] = 0.0;
+        DP(OP_V10)[d_idx] = 0.0; DP(OP_V11)[d_idx] = 0.0; DP(OP_V12)[d_idx] = 0.0;
+        DP(OP_V20)[d_idx] = 0.0; DP(OP_V21)[d_idx] = 0.0; DP(OP_V22)[d_idx] = 0.0;
+        break;
+    case OE_HOOKES_DEVIATORIC_STRESS_RATE: /* solid_mech/basic.py:409-416 */
+        DP(OP_AS00)[d_idx] = 0.0; DP(OP_AS01)[d_idx] = 0.0; DP(OP_AS02)[d_idx] = 0.0;
+        DP(OP_AS11)[d_idx] = 0.0; DP(OP_AS12)[d_idx] = 0.0; DP(OP_AS22)[d_idx] = 0.0;
         break;
     default: break;
     }
@@ -500,6 +682,54 @@ static void eq_loop_nosrc(const orc_equation *e, const orc_array *D, long d_idx)
     case OE_ISOTHERMAL_EOS: { /* basic_equations.py:151-176; par rho0 c0 p0 */
         double c02 = par[1] * par[1];
         DP(OP_P)[d_idx] = par[2] + c02 * (DP(OP_RHO)[d_idx] - par[0]);
+        break;
+    }
+    case OE_SOLID_ISOTHERMAL_EOS: /* solid_mech/basic.py:100-101; par c0_ref rho_ref */
+        DP(OP_P)[d_idx] = par[0] * par[0] * (DP(OP_RHO)[d_idx] - par[1]);
+        break;
+    case OE_MONAGHAN_ART_STRESS: { /* solid_mech/basic.py:170-242; par eps */
+        double rhoi = DP(OP_RHO)[d_idx];
+        double rhoi21 = 1. / (rhoi * rhoi);
+        double R[3][3], Rab[3][3], S[3][3], V[3], rd[3];
+        S[0][0] = DP(OP_S00)[d_idx] - DP(OP_P)[d_idx];
+        S[1][1] = DP(OP_S11)[d_idx] - DP(OP_P)[d_idx];
+        S[2][2] = DP(OP_S22)[d_idx] - DP(OP_P)[d_idx];
+        S[1][2] = DP(OP_S12)[d_idx]; S[2][1] = DP(OP_S12)[d_idx];
+        S[0][2] = DP(OP_S02)[d_idx]; S[2][0] = DP(OP_S02)[d_idx];
+        S[0][1] = DP(OP_S01)[d_idx]; S[1][0] = DP(OP_S01)[d_idx];
+        eigen_decomposition(S, R, V);
+        for (int k = 0; k < 3; k++) rd[k] = V[k] > 0 ? -par[0] * V[k] * rhoi21 : 0;
+        transform_diag_inv(rd, R, Rab);
+        DP(OP_R00)[d_idx] = Rab[0][0]; DP(OP_R11)[d_idx] = Rab[1][1]; DP(OP_R22)[d_idx] = Rab[2][2];
+        DP(OP_R12)[d_idx] = Rab[1][2]; DP(OP_R02)[d_idx] = Rab[0][2]; DP(OP_R01)[d_idx] = Rab[0][1];
+        break;
+    }
+    case OE_HOOKES_DEVIATORIC_STRESS_RATE: { /* solid_mech/basic.py:418-505; par G */
+        double v00 = DP(OP_V00)[d_idx], v01 = DP(OP_V01)[d_idx], v02 = DP(OP_V02)[d_idx];
+        double v10 = DP(OP_V10)[d_idx], v11 = DP(OP_V11)[d_idx], v12 = DP(OP_V12)[d_idx];
+        double v20 = DP(OP_V20)[d_idx], v21 = DP(OP_V21)[d_idx], v22 = DP(OP_V22)[d_idx];
+        double s00 = DP(OP_S00)[d_idx], s01 = DP(OP_S01)[d_idx], s02 = DP(OP_S02)[d_idx];
+        double s10 = s01, s11 = DP(OP_S11)[d_idx], s12 = DP(OP_S12)[d_idx];
+        double s20 = s02, s21 = s12, s22 = DP(OP_S22)[d_idx];
+        double eps00 = v00, eps01 = 0.5 * (v01 + v10), eps02 = 0.5 * (v02 + v20);
+        double eps11 = v11, eps12 = 0.5 * (v12 + v21), eps22 = v22;
+        double omega00 = 0.0, omega01 = 0.5 * (v01 - v10), omega02 = 0.5 * (v02 - v20);
+        double omega10 = -omega01, omega11 = 0.0, omega12 = 0.5 * (v12 - v21);
+        double omega20 = -omega02, omega21 = -omega12, omega22 = 0.0;
+        double tmp = 2.0 * par[0];
+        double trace = 1.0 / 3.0 * (eps00 + eps11 + eps22);
+        DP(OP_AS00)[d_idx] = tmp * (eps00 - trace) + (s00 * omega00 + s01 * omega01 + s02 * omega02) +
+                             (s00 * omega00 + s10 * omega01 + s20 * omega02);
+        DP(OP_AS01)[d_idx] = tmp * (eps01) + (s00 * omega10 + s01 * omega11 + s02 * omega12) +
+                             (s01 * omega00 + s11 * omega01 + s21 * omega02);
+        DP(OP_AS02)[d_idx] = tmp * eps02 + (s00 * omega20 + s01 * omega21 + s02 * omega22) +
+                             (s02 * omega00 + s12 * omega01 + s22 * omega02);
+        DP(OP_AS11)[d_idx] = tmp * (eps11 - trace) + (s10 * omega10 + s11 * omega11 + s12 * omega12) +
+                             (s01 * omega10 + s11 * omega11 + s21 * omega12);
+        DP(OP_AS12)[d_idx] = tmp * eps12 + (s10 * omega20 + s11 * omega21 + s12 * omega22) +
+                             (s02 * omega10 + s12 * omega11 + s22 * omega12);
+        DP(OP_AS22)[d_idx] = tmp * (eps22 - trace) + (s20 * omega20 + s21 * omega21 + s22 * omega22) +
+                             (s02 * omega20 + s12 * omega21 + s22 * omega22);
         break;
     }
     default: break;
@@ -633,6 +863,67 @@ static void eq_loop(const orc_equation *e, const orc_array *D, const orc_array *
         DP(OP_AW)[d_idx] += tmp * Az;
         break;
     }
+    case OE_VELOCITY_GRADIENT_2D: { /* basic_equations.py:88-98 */
+        double tmp = SP(OP_M)[s_idx] / SP(OP_RHO)[s_idx];
+        DP(OP_V00)[d_idx] += tmp * -VIJ[0] * DWIJ[0];
+        DP(OP_V01)[d_idx] += tmp * -VIJ[0] * DWIJ[1];
+        DP(OP_V10)[d_idx] += tmp * -VIJ[1] * DWIJ[0];
+        DP(OP_V11)[d_idx] += tmp * -VIJ[1] * DWIJ[1];
+        break;
+    }
+    case OE_VELOCITY_GRADIENT_3D: { /* basic_equations.py:130-148 */
+        double tmp = SP(OP_M)[s_idx] / SP(OP_RHO)[s_idx];
+        DP(OP_V00)[d_idx] += tmp * -VIJ[0] * DWIJ[0];
+        DP(OP_V01)[d_idx] += tmp * -VIJ[0] * DWIJ[1];
+        DP(OP_V02)[d_idx] += tmp * -VIJ[0] * DWIJ[2];
+        DP(OP_V10)[d_idx] += tmp * -VIJ[1] * DWIJ[0];
+        DP(OP_V11)[d_idx] += tmp * -VIJ[1] * DWIJ[1];
+        DP(OP_V12)[d_idx] += tmp * -VIJ[1] * DWIJ[2];
+        DP(OP_V20)[d_idx] += tmp * -VIJ[2] * DWIJ[0];
+        DP(OP_V21)[d_idx] += tmp * -VIJ[2] * DWIJ[1];
+        DP(OP_V22)[d_idx] += tmp * -VIJ[2] * DWIJ[2];
+        break;
+    }
+    case OE_MOMENTUM_WITH_STRESS: { /* solid_mech/basic.py:267-387; par wdeltap n */
+        double pa = DP(OP_P)[d_idx], pb = SP(OP_P)[s_idx];
+        double rhoa = DP(OP_RHO)[d_idx], rhob = SP(OP_RHO)[s_idx];
+        double rhoa21 = 1. / (rhoa * rhoa), rhob21 = 1. / (rhob * rhob);
+        double s00a = DP(OP_S00)[d_idx], s01a = DP(OP_S01)[d_idx], s02a = DP(OP_S02)[d_idx];
+        double s10a = s01a, s11a = DP(OP_S11)[d_idx], s12a = DP(OP_S12)[d_idx];
+        double s20a = s02a, s21a = s12a, s22a = DP(OP_S22)[d_idx];
+        double s00b = SP(OP_S00)[s_idx], s01b = SP(OP_S01)[s_idx], s02b = SP(OP_S02)[s_idx];
+        double s10b = s01b, s11b = SP(OP_S11)[s_idx], s12b = SP(OP_S12)[s_idx];
+        double s20b = s02b, s21b = s12b, s22b = SP(OP_S22)[s_idx];
+        double r00a = DP(OP_R00)[d_idx], r01a = DP(OP_R01)[d_idx], r02a = DP(OP_R02)[d_idx];
+        double r11a = DP(OP_R11)[d_idx], r12a = DP(OP_R12)[d_idx], r22a = DP(OP_R22)[d_idx];
+        double r00b = SP(OP_R00)[s_idx], r01b = SP(OP_R01)[s_idx], r02b = SP(OP_R02)[s_idx];
+        double r11b = SP(OP_R11)[s_idx], r12b = SP(OP_R12)[s_idx], r22b = SP(OP_R22)[s_idx];
+        s00a = s00a - pa; s00b = s00b - pb;
+        s11a = s11a - pa; s11b = s11b - pb;
+        s22a = s22a - pa; s22b = s22b - pb;
+        double as00, as01, as02, as10, as11, as12, as20, as21, as22;
+        if (par[0] > 0.) {
+            double fab = P->WIJ / par[0];
+            fab = pow(fab, par[1]);
+            as00 = fab * (r00a + r00b); as01 = fab * (r01a + r01b); as02 = fab * (r02a + r02b);
+            as10 = as01; as11 = fab * (r11a + r11b); as12 = fab * (r12a + r12b);
+            as20 = as02; as21 = as12; as22 = fab * (r22a + r22b);
+        } else {
+            as00 = 0.0; as01 = 0.0; as02 = 0.0; as10 = as01; as11 = 0.0; as12 = 0.0;
+            as20 = as02; as21 = as12; as22 = 0.0;
+        }
+        double mb = SP(OP_M)[s_idx];
+        DP(OP_AU)[d_idx] += (mb * (s00a * rhoa21 + s00b * rhob21 + as00) * DWIJ[0] +
+                             mb * (s01a * rhoa21 + s01b * rhob21 + as01) * DWIJ[1] +
+                             mb * (s02a * rhoa21 + s02b * rhob21 + as02) * DWIJ[2]);
+        DP(OP_AV)[d_idx] += (mb * (s10a * rhoa21 + s10b * rhob21 + as10) * DWIJ[0] +
+                             mb * (s11a * rhoa21 + s11b * rhob21 + as11) * DWIJ[1] +
+                             mb * (s12a * rhoa21 + s12b * rhob21 + as12) * DWIJ[2]);
+        DP(OP_AW)[d_idx] += (mb * (s20a * rhoa21 + s20b * rhob21 + as20) * DWIJ[0] +
+                             mb * (s21a * rhoa21 + s21b * rhob21 + as21) * DWIJ[1] +
+                             mb * (s22a * rhoa21 + s22b * rhob21 + as22) * DWIJ[2]);
+        break;
+    }
     case OE_MONAGHAN_ART_VISCOSITY: { /* basic_equations.py:236-257; par alpha beta */
         double vijdotxij = VIJ[0] * XIJ[0] + VIJ[1] * XIJ[1] + VIJ[2] * XIJ[2];
         double piij = 0.0;
@@ -686,7 +977,9 @@ static int eq_has(int kind, int what) /* what: 0 initialize, 1 loop, 2 post_loop
 {
     switch (kind) {
     case OE_TAIT_EOS: case OE_TAIT_EOS_HG: case OE_TVF_STATE_EQUATION: case OE_ISOTHERMAL_EOS:
+    case OE_SOLID_ISOTHERMAL_EOS: case OE_MONAGHAN_ART_STRESS:
         return what == 1;
+    case OE_HOOKES_DEVIATORIC_STRESS_RATE: return what != 2;
     case OE_MOMENTUM: case OE_XSPH: case OE_TVF_MOM_PRESSURE: return 1;
     default: return what != 2;
     }

@@ -69,7 +69,8 @@ enum orc_eq_kind {
     OE_HOOKES_DEVIATORIC_STRESS_RATE, /* par: G (shear modulus) */
     OE_MOMENTUM_WITH_STRESS,    /* par: wdeltap n */
     OE_MONAGHAN_ART_STRESS,     /* par: eps */
-    OE_ENERGY_WITH_STRESS       /* par: alpha beta eta */
+    OE_ENERGY_WITH_STRESS,      /* par: alpha beta eta */
+    OE_SOLID_ISOTHERMAL_EOS     /* solid_mech/basic.py:93-101  par: c0_ref rho_ref */
 };
 
 typedef struct {
@@ -131,6 +132,9 @@ double orc_kernel_w(const orc_kernel *, double rij, double h);
 double orc_kernel_dwdq(const orc_kernel *, double rij, double h);
 void orc_kernel_gradient(const orc_kernel *, const double *xij, double rij,
                          double h, double *grad);
+
+/* linalg3.eigen_decomposition on a row-major 3x3 (KAT hook) */
+void orc_eigen3(const double *A9, double *V9, double *d3);
 
 const char *orc_last_error(void);
 

@@ -85,3 +85,26 @@ def pec_step_tvf(arrays, nnps, ev, t, dt, domain=None):
         tvf_stage2(pa, dt)
     if domain is not None:
         domain.update()
+
+
+_SM = [('x', 'x0', 'ax'), ('y', 'y0', 'ay'), ('z', 'z0', 'az'), ('u', 'u0', 'au'),
+       ('v', 'v0', 'av'), ('w', 'w0', 'aw'), ('rho', 'rho0', 'arho'),
+       ('e', 'e0', 'ae'), ('s00', 's000', 'as00'), ('s01', 's010', 'as01'),
+       ('s02', 's020', 'as02'), ('s11', 's110', 'as11'), ('s12', 's120', 'as12'),
+       ('s22', 's220', 'as22')]
+
+
+def solid_initialize(pa):
+    """SolidMechStep.initialize  pysph/sph/integrator_step.py:175-197"""
+    n = pa.get_number_of_particles(True)
+    for q, q0, _ in _SM:
+        pa.properties[q0][:n] = pa.properties[q][:n]
+
+
+def solid_stage(pa, dt, stage):
+    """SolidMechStep.stage1 (:199-226) / stage2 (:228-255)"""
+    n = pa.get_number_of_particles(True)
+    p = pa.properties
+    f = 0.5 * dt if stage == 1 else dt
+    for q, q0, aq in _SM:
+        p[q][:n] = p[q0][:n] + f * p[aq][:n]

@@ -158,6 +158,7 @@ class _CGroup(object):
         self.ceqs = (dev.SphEquation * max(len(eqs), 1))()
         self.inputs = defaultdict(set)    # array name -> props read
         self.outputs = defaultdict(set)   # array name -> props written
+        self._const_params = []
         for i, eq in enumerate(eqs):
             kind, vals, dprops, sprops = resolve_equation(eq)
             ce = self.ceqs[i]
@@ -168,7 +169,10 @@ class _CGroup(object):
             for k, s in enumerate(srcs):
                 ce.src[k] = array_ids[s]
             for k, v in enumerate(vals):
-                ce.par[k] = v
+                if isinstance(v, str):           # '@const' -> read every compute
+                    self._const_params.append((i, k, eq.dest, v[1:]))
+                else:
+                    ce.par[k] = v
             self.inputs[eq.dest].update(dprops)
             self.outputs[eq.dest].update(dprops)
             for s in srcs:
@@ -180,6 +184,9 @@ class _CGroup(object):
         self._arrays = arrays
 
     def refresh_range(self):
+        from .particle_array import get_npy as _get
+        for i, k, dest, cname in self._const_params:
+            self.ceqs[i].par[k] = float(_get(self._arrays[dest], cname)[0])
         g = self.group
         dest = self._arrays[g.equations[0].dest] if g.equations else None
 
@@ -273,14 +280,15 @@ class HipAccelerationEval(object):
         for name, props in self.inputs.items():
             pa = self.arrays[name]
             have = [p for p in sorted(props)
-                    if has_prop(pa, p) and p not in skip]
+                    if p in pa.properties and dev.prop_id(p) >= 0
+                    and p not in skip]
             self.helpers[name].push(*have)
 
     def pull_outputs(self):
         for name, props in self.outputs.items():
             pa = self.arrays[name]
             out = [p for p in sorted(props)
-                   if has_prop(pa, p) and p not in ('x', 'y', 'z', 'h', 'm',
+                   if p in pa.properties and dev.prop_id(p) >= 0 and p not in ('x', 'y', 'z', 'h', 'm',
                                                     'u', 'v', 'w', 'uhat',
                                                     'vhat', 'what')]
             self.helpers[name].pull(*out)

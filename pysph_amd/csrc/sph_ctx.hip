@@ -56,7 +56,13 @@ static const char *PROP_NAMES[SPH_PROP_COUNT] = {
     "x", "y", "z", "u", "v", "w", "h", "m", "rho", "p", "cs",
     "arho", "au", "av", "aw", "ax", "ay", "az", "dt_cfl", "dt_force",
     "V", "uhat", "vhat", "what", "auhat", "avhat", "awhat",
-    "x0", "y0", "z0", "u0", "v0", "w0", "rho0", "vmag2"};
+    "x0", "y0", "z0", "u0", "v0", "w0", "rho0", "vmag2",
+    "e", "ae", "e0",
+    "v00", "v01", "v02", "v10", "v11", "v12", "v20", "v21", "v22",
+    "s00", "s01", "s02", "s11", "s12", "s22",
+    "as00", "as01", "as02", "as11", "as12", "as22",
+    "r00", "r01", "r02", "r11", "r12", "r22",
+    "s000", "s010", "s020", "s110", "s120", "s220"};
 
 extern "C" {
 

@@ -45,7 +45,45 @@ struct EosArgs {
     double par[SPH_MAX_PAR];
     double *rho, *p, *cs;
     size_t start, stop;
+    double *q[SPH_PROP_COUNT]; // every device property of the destination (elastic equations)
 };
+
+// Symmetric 3x3 eigen-decomposition by cyclic Jacobi rotations.  The reference
+// uses EISPACK tred2/tql2 (pysph/base/linalg3.pyx:259-536); what the caller
+// needs is the matrix function V f(lambda) V^T, which does not depend on the
+// eigen-solver, its ordering or sign conventions -- only on its accuracy.
+__device__ inline void jacobi_eigen3(double A[3][3], double V[3][3], double d[3])
+{
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 12; sweep++) {
+        double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        double diag = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
+        if (off <= 1e-300 || off <= 1e-18 * diag) break;
+#pragma unroll
+        for (int pq = 0; pq < 3; pq++) {
+            const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+            double apq = A[p][q];
+            if (apq == 0.0) continue;
+            double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+            double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            A[p][p] -= t * apq;
+            A[q][q] += t * apq;
+            A[p][q] = A[q][p] = 0.0;
+            const int r = 3 - p - q;
+            double arp = A[r][p], arq = A[r][q];
+            A[r][p] = A[p][r] = c * arp - s * arq;
+            A[r][q] = A[q][r] = s * arp + c * arq;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                double vkp = V[k][p], vkq = V[k][q];
+                V[k][p] = c * vkp - s * vkq;
+                V[k][q] = s * vkp + c * vkq;
+            }
+        }
+    }
+    d[0] = A[0][0]; d[1] = A[1][1]; d[2] = A[2][2];
+}
 
 __global__ __launch_bounds__(256) void k_nosrc(EosArgs a)
 {
@@ -76,12 +114,71 @@ __global__ __launch_bounds__(256) void k_nosrc(EosArgs a)
     case SPH_EQ_ISOTHERMAL_EOS: // basic_equations.py:175-176
         a.p[i] = a.par[2] + (a.par[1] * a.par[1]) * (a.rho[i] - a.par[0]);
         break;
+    case SPH_EQ_SOLID_ISOTHERMAL_EOS: // solid_mech/basic.py:100-101; par c0_ref rho_ref
+        a.p[i] = a.par[0] * a.par[0] * (a.rho[i] - a.par[1]);
+        break;
+    case SPH_EQ_MONAGHAN_ART_STRESS: { // solid_mech/basic.py:170-242; par eps
+        double **q = a.q;
+        const double rhoi = a.rho[i], rhoi21 = 1. / (rhoi * rhoi), pr = a.p[i];
+        double S[3][3], R[3][3], lam[3], rd[3];
+        S[0][0] = q[SPH_S00][i] - pr; S[1][1] = q[SPH_S11][i] - pr; S[2][2] = q[SPH_S22][i] - pr;
+        S[0][1] = S[1][0] = q[SPH_S01][i];
+        S[0][2] = S[2][0] = q[SPH_S02][i];
+        S[1][2] = S[2][1] = q[SPH_S12][i];
+        // same scaling as linalg3.eigen_decomposition (:520-536): tiny matrices stay accurate
+        double sc = 0.0;
+        for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) sc += fabs(S[r][cc]);
+        if (sc == 0.0) {
+            lam[0] = lam[1] = lam[2] = 0.0;
+            for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) R[r][cc] = (r == cc);
+        } else {
+            for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) S[r][cc] /= sc;
+            jacobi_eigen3(S, R, lam);
+            for (int k = 0; k < 3; k++) lam[k] *= sc;
+        }
+        for (int k = 0; k < 3; k++) rd[k] = lam[k] > 0 ? -a.par[0] * lam[k] * rhoi21 : 0.0;
+        // transform_diag_inv: R diag(rd) R^T  (linalg3.pyx:220-234)
+        double Rab[3][3];
+        for (int r = 0; r < 3; r++)
+            for (int cc = r; cc < 3; cc++) {
+                double t = 0.0;
+                for (int k = 0; k < 3; k++) t += R[r][k] * rd[k] * R[cc][k];
+                Rab[r][cc] = t;
+            }
+        q[SPH_R00][i] = Rab[0][0]; q[SPH_R11][i] = Rab[1][1]; q[SPH_R22][i] = Rab[2][2];
+        q[SPH_R12][i] = Rab[1][2]; q[SPH_R02][i] = Rab[0][2]; q[SPH_R01][i] = Rab[0][1];
+        break;
+    }
+    case SPH_EQ_HOOKES_DEVIATORIC_STRESS_RATE: { // solid_mech/basic.py:418-505; par G
+        double **q = a.q;
+        const double v00 = q[SPH_V00][i], v01 = q[SPH_V01][i], v02 = q[SPH_V02][i];
+        const double v10 = q[SPH_V10][i], v11 = q[SPH_V11][i], v12 = q[SPH_V12][i];
+        const double v20 = q[SPH_V20][i], v21 = q[SPH_V21][i], v22 = q[SPH_V22][i];
+        const double s00 = q[SPH_S00][i], s01 = q[SPH_S01][i], s02 = q[SPH_S02][i];
+        const double s11 = q[SPH_S11][i], s12 = q[SPH_S12][i], s22 = q[SPH_S22][i];
+        const double s10 = s01, s20 = s02, s21 = s12;
+        const double eps00 = v00, eps01 = 0.5 * (v01 + v10), eps02 = 0.5 * (v02 + v20);
+        const double eps11 = v11, eps12 = 0.5 * (v12 + v21), eps22 = v22;
+        const double omega01 = 0.5 * (v01 - v10), omega02 = 0.5 * (v02 - v20), omega12 = 0.5 * (v12 - v21);
+        const double omega10 = -omega01, omega20 = -omega02, omega21 = -omega12;
+        const double tmp = 2.0 * a.par[0];
+        const double trace = 1.0 / 3.0 * (eps00 + eps11 + eps22);
+        q[SPH_AS00][i] = tmp * (eps00 - trace) + (s01 * omega01 + s02 * omega02) + (s10 * omega01 + s20 * omega02);
+        q[SPH_AS01][i] = tmp * eps01 + (s00 * omega10 + s02 * omega12) + (s11 * omega01 + s21 * omega02);
+        q[SPH_AS02][i] = tmp * eps02 + (s00 * omega20 + s01 * omega21) + (s12 * omega01 + s22 * omega02);
+        q[SPH_AS11][i] = tmp * (eps11 - trace) + (s10 * omega10 + s12 * omega12) + (s01 * omega10 + s21 * omega12);
+        q[SPH_AS12][i] = tmp * eps12 + (s10 * omega20 + s11 * omega21) + (s02 * omega10 + s22 * omega12);
+        q[SPH_AS22][i] = tmp * (eps22 - trace) + (s20 * omega20 + s21 * omega21) + (s02 * omega20 + s12 * omega21);
+        break;
+    }
     }
 }
 
 // ---------------------------------------------------------------------------
 // equation families
 // ---------------------------------------------------------------------------
+enum { F_VG2 = 1, F_VG3 = 2,                                            // velocity gradient
+       F_ECONT = 1, F_ESTRESS = 2, F_EAV = 4, F_EXSPH = 8 };            // elastic rates
 enum { F_CONT = 1, F_MOM = 2, F_XSPH = 4, F_TENSILE = 8,               // WCSPH
        F_SD = 1, F_TVFSD = 2,                                           // density
        F_TP = 1, F_TVISC = 2, F_TAV = 4, F_TAS = 8 };                   // TVF force
@@ -92,7 +189,7 @@ struct KernelConst {
     int dim;
 };
 
-#define MAX_AUX 12
+#define MAX_AUX 20
 struct PackArgs {
     const uint32_t *perm;
     size_t n;
@@ -100,7 +197,8 @@ struct PackArgs {
     const double *x, *y, *z, *h;
     int na;                       // doubles in the aux record
     const double *src[MAX_AUX];   // nullptr -> 0.0
-    int derived;                  // 1: aux[5] = p/(rho*rho) (p = aux[7], rho = aux[4]); 2: aux[10] = 1/V^2 (V = aux[8])
+    int derived;                  // 1: aux[5] = p/(rho*rho) (p = aux[7], rho = aux[4]); 2: aux[10] = 1/V^2 (V = aux[8]);
+                                  // 3: aux[6..11] = (s_ij - p delta_ij)/rho^2 (p = aux[18], rho = aux[4])
     double4 *posh;
     double *aux;
     double *rec;                  // non-null: interleaved records [x y z h aux... pad], nr doubles each
@@ -116,9 +214,15 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
     ph.x = a.x[o]; ph.y = a.y[o]; ph.z = a.z[o]; ph.w = a.h[o];
     double v[MAX_AUX];
 #pragma unroll
-    for (int k = 0; k < MAX_AUX; k++) v[k] = (k < a.na && a.src[k]) ? a.src[k][o] : 0.0;
+    for (int k = 0; k < MAX_AUX; k++) v[k] = ((k < a.na || (a.derived == 3 && k == 18)) && a.src[k]) ? a.src[k][o] : 0.0;
     if (a.derived == 1) v[5] = v[4] != 0.0 ? v[7] * (1.0 / (v[4] * v[4])) : 0.0; // tmpj = p*rhoj21, wc/basic.py:211,234
     if (a.derived == 2) { double Vj = 1. / v[8]; v[10] = Vj * Vj; } // Vj2, transport_velocity.py:303-306
+    if (a.derived == 3) { // (sigma_ij)/rho^2 with sigma = s - p I: solid_mech/basic.py:281-283,333-339,367-378
+        const double r21 = 1. / (v[4] * v[4]), pr = v[18];
+        v[6] = (v[6] - pr) * r21; v[7] *= r21; v[8] *= r21;
+        v[9] = (v[9] - pr) * r21; v[10] *= r21; v[11] = (v[11] - pr) * r21;
+        v[18] = 0.0;
+    }
     if (a.rec) {
         // 32-B stores: every store covers whole sectors of the record
         double4 *r = reinterpret_cast<double4 *>(a.rec + (a.off + i) * (size_t)a.nr);
@@ -429,6 +533,122 @@ struct FamTVF {
         double gz = (a.dflags & F_TP) ? a.p.gz * damp : 0.0;
         a.p.au[o] = D.au + gx; a.p.av[o] = D.av + gy; a.p.aw[o] = D.aw + gz;
         if (a.dflags & F_TP) { a.p.auhat[o] = D.auh; a.p.avhat[o] = D.avh; a.p.awhat[o] = D.awh; }
+    }
+};
+
+// ---- velocity gradient (basic_equations.py:63-148) -------------------------
+struct FamVGrad {
+    static constexpr int NA = 6; // u v w m rho pad
+    static constexpr int NR = 10;
+    struct Params { double *v[9]; };
+    struct Dest { double u, v, w; double g[9]; };
+    static __device__ __forceinline__ void load(Dest &D, const double *a)
+    {
+        D.u = a[0]; D.v = a[1]; D.w = a[2];
+        for (int k = 0; k < 9; k++) D.g[k] = 0.0;
+    }
+    template <int KK, bool UH, class A>
+    static __device__ __forceinline__ void pair(Dest &D, const double4 &pi, const double4 &pj, double r2,
+                                                const double (&s)[NA], uint32_t fl, const A &a)
+    {
+        PairGeom g;
+        pair_geom<KK, UH>(g, pi, pj, r2, a);
+        const double tg = pair_gradfac<KK>(g);
+        const double dw[3] = {tg * g.xij[0], tg * g.xij[1], tg * g.xij[2]};
+        const double tmp = s[3] * fast_rcp(s[4]); // m/rho
+        const double nv[3] = {-(D.u - s[0]), -(D.v - s[1]), -(D.w - s[2])};
+        const int n = (fl & F_VG3) ? 3 : 2;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                if (i < n && j < n) D.g[3 * i + j] += tmp * nv[i] * dw[j];
+    }
+    template <class A> static __device__ __forceinline__ void finish(Dest &D, const A &a, uint32_t o)
+    {
+        const int n = (a.dflags & F_VG3) ? 3 : 2;
+        for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) a.p.v[3 * i + j][o] = D.g[3 * i + j];
+    }
+};
+
+// ---- elastic rates: Continuity + MomentumEquationWithStress +
+//      MonaghanArtificialViscosity + XSPH  (solid_mech/basic.py:245-387,
+//      basic_equations.py:177-300) -------------------------------------------
+struct FamElastic {
+    static constexpr int NA = 18; // u v w m rho cs | t00 t01 t02 t11 t12 t22 (= sigma/rho^2) | r00 r01 r02 r11 r12 r22
+    static constexpr int NR = 22;
+    struct Params {
+        double wdeltap, n, alpha, beta, eps;
+        double *arho, *au, *av, *aw, *ax, *ay, *az;
+    };
+    struct Dest {
+        double u, v, w, rho, cs, t[6], r[6];
+        double arho, au, av, aw, ax, ay, az;
+    };
+    static __device__ __forceinline__ void load(Dest &D, const double *a)
+    {
+        D.u = a[0]; D.v = a[1]; D.w = a[2]; D.rho = a[4]; D.cs = a[5];
+        for (int k = 0; k < 6; k++) { D.t[k] = a[6 + k]; D.r[k] = a[12 + k]; }
+        D.arho = D.au = D.av = D.aw = D.ax = D.ay = D.az = 0.0;
+    }
+    template <int KK, bool UH, class A>
+    static __device__ __forceinline__ void pair(Dest &D, const double4 &pi, const double4 &pj, double r2,
+                                                const double (&s)[NA], uint32_t fl, const A &a)
+    {
+        PairGeom g;
+        pair_geom<KK, UH>(g, pi, pj, r2, a);
+        const double tg = pair_gradfac<KK>(g);
+        const double dw0 = tg * g.xij[0], dw1 = tg * g.xij[1], dw2 = tg * g.xij[2];
+        const double vij0 = D.u - s[0], vij1 = D.v - s[1], vij2 = D.w - s[2];
+        const double vdotx = vij0 * g.xij[0] + vij1 * g.xij[1] + vij2 * g.xij[2];
+        const double mj = s[3];
+        if (fl & F_ECONT) D.arho = fma(mj * tg, vdotx, D.arho);
+        double wij = 0.0;
+        if (fl & (F_ESTRESS | F_EXSPH)) wij = pair_w<KK>(g);
+        if (fl & F_ESTRESS) { // solid_mech/basic.py:267-387
+            double fab = 0.0;
+            if (a.p.wdeltap > 0.) {
+                const double f = wij * fast_rcp(a.p.wdeltap);
+                if (a.p.n == 4.0) { const double f2 = f * f; fab = f2 * f2; }
+                else if (a.p.n == 2.0) fab = f * f;
+                else if (a.p.n == 1.0) fab = f;
+                else fab = pow(f, a.p.n);
+            }
+            const double a00 = D.t[0] + s[6] + fab * (D.r[0] + s[12]);
+            const double a01 = D.t[1] + s[7] + fab * (D.r[1] + s[13]);
+            const double a02 = D.t[2] + s[8] + fab * (D.r[2] + s[14]);
+            const double a11 = D.t[3] + s[9] + fab * (D.r[3] + s[15]);
+            const double a12 = D.t[4] + s[10] + fab * (D.r[4] + s[16]);
+            const double a22 = D.t[5] + s[11] + fab * (D.r[5] + s[17]);
+            D.au += mj * (a00 * dw0 + a01 * dw1 + a02 * dw2);
+            D.av += mj * (a01 * dw0 + a11 * dw1 + a12 * dw2);
+            D.aw += mj * (a02 * dw0 + a12 * dw1 + a22 * dw2);
+        }
+        if (fl & (F_EAV | F_EXSPH)) {
+            const double rhoij = 0.5 * (D.rho + s[4]);
+            double rhoij1;
+            if (fl & F_EAV) { // basic_equations.py:236-257
+                const double re = r2 + g.eps;
+                const double tt = fast_rcp(re * rhoij);
+                rhoij1 = re * tt;
+                const double muij = (g.hij * vdotx) * (rhoij * tt);
+                const double cij = 0.5 * (D.cs + s[5]);
+                double piij = (a.p.beta * muij - a.p.alpha * cij) * muij * rhoij1;
+                piij = vdotx < 0 ? piij : 0.0;
+                const double f = -mj * piij;
+                D.au = fma(f, dw0, D.au); D.av = fma(f, dw1, D.av); D.aw = fma(f, dw2, D.aw);
+            } else rhoij1 = fast_rcp(rhoij);
+            if (fl & F_EXSPH) { // basic_equations.py:290-295
+                const double tmp = -a.p.eps * mj * wij * rhoij1;
+                D.ax = fma(tmp, vij0, D.ax); D.ay = fma(tmp, vij1, D.ay); D.az = fma(tmp, vij2, D.az);
+            }
+        }
+    }
+    template <class A> static __device__ __forceinline__ void finish(Dest &D, const A &a, uint32_t o)
+    {
+        if (a.dflags & F_ECONT) a.p.arho[o] = D.arho;
+        if (a.dflags & (F_ESTRESS | F_EAV)) { a.p.au[o] = D.au; a.p.av[o] = D.av; a.p.aw[o] = D.aw; }
+        if (a.dflags & F_EXSPH) { a.p.ax[o] = D.ax + D.u; a.p.ay[o] = D.ay + D.v; a.p.az[o] = D.az + D.w; }
     }
 };
 
@@ -1006,7 +1226,8 @@ template <class Fam> static size_t wg_lds_bytes() { return (size_t)TCAP * Fam::N
 static bool is_nosrc_kind(int k)
 {
     return k == SPH_EQ_TAIT_EOS || k == SPH_EQ_TAIT_EOS_HG || k == SPH_EQ_TVF_STATE_EQUATION ||
-           k == SPH_EQ_ISOTHERMAL_EOS;
+           k == SPH_EQ_ISOTHERMAL_EOS || k == SPH_EQ_SOLID_ISOTHERMAL_EOS || k == SPH_EQ_MONAGHAN_ART_STRESS ||
+           k == SPH_EQ_HOOKES_DEVIATORIC_STRESS_RATE;
 }
 
 static int need_prop(sph_ctx *c, int id, int prop, const char *who)
@@ -1036,15 +1257,37 @@ static int run_nosrc(sph_ctx *c, const sph_equation &e, size_t start, size_t sto
     }
     a.start = start;
     a.stop = stop;
+    if (e.kind == SPH_EQ_MONAGHAN_ART_STRESS) {
+        for (int p : {SPH_S00, SPH_S01, SPH_S02, SPH_S11, SPH_S12, SPH_S22}) SPH_TRY(need_prop(c, e.dest, p, "MonaghanArtificialStress"));
+        for (int p : {SPH_R00, SPH_R01, SPH_R02, SPH_R11, SPH_R12, SPH_R22}) SPH_TRY(sph_array_ensure_prop(c, e.dest, p));
+    }
+    if (e.kind == SPH_EQ_HOOKES_DEVIATORIC_STRESS_RATE) {
+        for (int p : {SPH_S00, SPH_S01, SPH_S02, SPH_S11, SPH_S12, SPH_S22}) SPH_TRY(need_prop(c, e.dest, p, "HookesDeviatoricStressRate"));
+        for (int p : {SPH_V00, SPH_V01, SPH_V02, SPH_V10, SPH_V11, SPH_V12, SPH_V20, SPH_V21, SPH_V22, SPH_AS00, SPH_AS01, SPH_AS02,
+                      SPH_AS11, SPH_AS12, SPH_AS22})
+            SPH_TRY(sph_array_ensure_prop(c, e.dest, p));
+    }
+    for (int k = 0; k < SPH_PROP_COUNT; k++) a.q[k] = A.prop[k];
+    a.rho = A.prop[SPH_RHO];
+    a.p = A.prop[SPH_P];
     ScopedTimer tm(c, T_EOS);
     hipLaunchKernelGGL(k_nosrc, dim3(div_up(stop - start, 256)), dim3(256), 0, c->stream, a);
     return SPH_OK;
 }
 
-enum Family { FAM_NONE, FAM_WCSPH, FAM_DENSITY, FAM_TVF };
+enum Family { FAM_NONE, FAM_WCSPH, FAM_DENSITY, FAM_TVF, FAM_VGRAD, FAM_ELASTIC };
 
-static int eq_family(int kind, uint32_t *flag)
+static int eq_family(int kind, uint32_t *flag, bool elastic)
 {
+    if (elastic) {
+        switch (kind) {
+        case SPH_EQ_CONTINUITY: *flag = F_ECONT; return FAM_ELASTIC;
+        case SPH_EQ_MOMENTUM_WITH_STRESS: *flag = F_ESTRESS; return FAM_ELASTIC;
+        case SPH_EQ_MONAGHAN_ART_VISCOSITY: *flag = F_EAV; return FAM_ELASTIC;
+        case SPH_EQ_XSPH: *flag = F_EXSPH; return FAM_ELASTIC;
+        default: break;
+        }
+    }
     switch (kind) {
     case SPH_EQ_CONTINUITY: *flag = F_CONT; return FAM_WCSPH;
     case SPH_EQ_MOMENTUM: *flag = F_MOM; return FAM_WCSPH;
@@ -1055,6 +1298,8 @@ static int eq_family(int kind, uint32_t *flag)
     case SPH_EQ_TVF_MOM_VISCOSITY: *flag = F_TVISC; return FAM_TVF;
     case SPH_EQ_TVF_MOM_ART_VISCOSITY: *flag = F_TAV; return FAM_TVF;
     case SPH_EQ_TVF_MOM_ART_STRESS: *flag = F_TAS; return FAM_TVF;
+    case SPH_EQ_VELOCITY_GRADIENT_2D: *flag = F_VG2; return FAM_VGRAD;
+    case SPH_EQ_VELOCITY_GRADIENT_3D: *flag = F_VG3; return FAM_VGRAD;
     default: return FAM_NONE;
     }
 }
@@ -1081,6 +1326,18 @@ static PackPlan pack_plan(int fam)
         p.nr = FamDensity::NR;
         p.na = 1;
         p.props[0] = SPH_M;
+    } else if (fam == FAM_VGRAD) {
+        p.nr = FamVGrad::NR;
+        p.na = 6;
+        int pr[6] = {SPH_U, SPH_V, SPH_W, SPH_M, SPH_RHO, -1};
+        for (int k = 0; k < 6; k++) p.props[k] = pr[k];
+    } else if (fam == FAM_ELASTIC) {
+        p.nr = FamElastic::NR;
+        p.na = 18;
+        int pr[19] = {SPH_U, SPH_V, SPH_W, SPH_M, SPH_RHO, SPH_CS, SPH_S00, SPH_S01, SPH_S02, SPH_S11, SPH_S12, SPH_S22,
+                      SPH_R00, SPH_R01, SPH_R02, SPH_R11, SPH_R12, SPH_R22, SPH_P};
+        for (int k = 0; k < 19; k++) p.props[k] = pr[k];
+        p.derived = 3;
     } else {
         p.nr = FamTVF::NR;
         p.na = 12;
@@ -1101,6 +1358,15 @@ static bool slot_required(int fam, uint32_t flags, int prop)
         return false;
     }
     if (fam == FAM_DENSITY) return prop == SPH_M;
+    if (fam == FAM_VGRAD) return true;
+    if (fam == FAM_ELASTIC) {
+        if (prop == SPH_U || prop == SPH_V || prop == SPH_W || prop == SPH_M) return true;
+        if (prop == SPH_RHO) return flags & (F_ESTRESS | F_EAV | F_EXSPH);
+        if (prop == SPH_CS) return flags & F_EAV;
+        if (prop == SPH_P) return flags & F_ESTRESS;
+        if (prop >= SPH_S00 && prop <= SPH_S22) return flags & F_ESTRESS;
+        return false; // r_ij default to 0 when absent
+    }
     if (fam == FAM_TVF) {
         if (prop == SPH_UHAT || prop == SPH_VHAT || prop == SPH_WHAT) return flags & F_TAS;
         return true;
@@ -1120,7 +1386,7 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
     pa.na = pl.na;
     for (int k = 0; k < MAX_AUX; k++) {
         pa.src[k] = nullptr;
-        if (k < pl.na && pl.props[k] >= 0) {
+        if ((k < pl.na || (pl.derived == 3 && k == 18)) && pl.props[k] >= 0) {
             pa.src[k] = A.prop[pl.props[k]];
             if (!pa.src[k] && slot_required(fam, flags, pl.props[k])) return need_prop(c, id, pl.props[k], "pair loop");
         }
@@ -1253,12 +1519,20 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         int srcs[SPH_MAX_ARRAYS], nsrcs = 0;
         uint32_t sflags[SPH_MAX_ARRAYS] = {};
         int fam = FAM_NONE;
-        const sph_equation *eq_of[16] = {};
+        const sph_equation *eq_of[32] = {};
+        bool elastic = false;
+        for (int i = 0; i < g->neq; i++) {
+            const sph_equation &e = g->eqs[i];
+            if (e.dest == dst && e.nsrc > 0 &&
+                (e.kind == SPH_EQ_MOMENTUM_WITH_STRESS || e.kind == SPH_EQ_MONAGHAN_ART_VISCOSITY))
+                elastic = true;
+        }
         for (int i = 0; i < g->neq; i++) {
             const sph_equation &e = g->eqs[i];
             if (e.dest != dst || e.nsrc == 0) continue;
+            if (e.kind < 0 || e.kind >= 32) { sph_set_error("bad equation kind %d", e.kind); return SPH_ERR_ARG; }
             uint32_t flag = 0;
-            int f = eq_family(e.kind, &flag);
+            int f = eq_family(e.kind, &flag, elastic);
             if (f == FAM_NONE) { sph_set_error("equation kind %d has no hand-written pair kernel", e.kind); return SPH_ERR_UNSUPPORTED; }
             if (fam != FAM_NONE && f != fam) {
                 sph_set_error("group mixes equation families on destination %d (kinds are fused per family)", dst);
@@ -1347,6 +1621,46 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
             a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
             launch_pair<FamDensity>(c, K->kind, a);
+        } else if (fam == FAM_VGRAD) {
+            PairArgs<FamVGrad> a;
+            memset(&a, 0, sizeof a);
+            fill_common(c, a, K, t);
+            static const int vp[9] = {SPH_V00, SPH_V01, SPH_V02, SPH_V10, SPH_V11, SPH_V12, SPH_V20, SPH_V21, SPH_V22};
+            if ((dflags & F_VG2) && (dflags & F_VG3)) { sph_set_error("both VelocityGradient2D and 3D on one destination"); return SPH_ERR_UNSUPPORTED; }
+            for (int k = 0; k < 9; k++) {
+                const bool used = (dflags & F_VG3) || (k == 0 || k == 1 || k == 3 || k == 4);
+                if (used) { SPH_TRY(sph_array_ensure_prop(c, dst, vp[k])); a.p.v[k] = D.prop[vp[k]]; }
+            }
+            a.nsrc = nsrcs;
+            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j]};
+            a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
+            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
+            a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
+            launch_pair<FamVGrad>(c, K->kind, a);
+        } else if (fam == FAM_ELASTIC) {
+            PairArgs<FamElastic> a;
+            memset(&a, 0, sizeof a);
+            fill_common(c, a, K, t);
+            const sph_equation *se = eq_of[SPH_EQ_MOMENTUM_WITH_STRESS], *ae = eq_of[SPH_EQ_MONAGHAN_ART_VISCOSITY],
+                               *xe = eq_of[SPH_EQ_XSPH];
+            if (se) { a.p.wdeltap = se->par[0]; a.p.n = se->par[1]; }
+            if (ae) { a.p.alpha = ae->par[0]; a.p.beta = ae->par[1]; }
+            if (xe) a.p.eps = xe->par[0];
+            if (dflags & F_ECONT) { SPH_TRY(ensure_out(c, dst, {SPH_ARHO})); a.p.arho = D.prop[SPH_ARHO]; }
+            if (dflags & (F_ESTRESS | F_EAV)) {
+                SPH_TRY(ensure_out(c, dst, {SPH_AU, SPH_AV, SPH_AW}));
+                a.p.au = D.prop[SPH_AU]; a.p.av = D.prop[SPH_AV]; a.p.aw = D.prop[SPH_AW];
+            }
+            if (dflags & F_EXSPH) {
+                SPH_TRY(ensure_out(c, dst, {SPH_AX, SPH_AY, SPH_AZ}));
+                a.p.ax = D.prop[SPH_AX]; a.p.ay = D.prop[SPH_AY]; a.p.az = D.prop[SPH_AZ];
+            }
+            a.nsrc = nsrcs;
+            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j]};
+            a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
+            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
+            a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
+            launch_pair<FamElastic>(c, K->kind, a);
         } else {
             PairArgs<FamTVF> a;
             memset(&a, 0, sizeof a);

@@ -35,6 +35,21 @@ __global__ __launch_bounds__(256) void k_stage(StageArgs a)
             p[SPH_Z][i] = p[SPH_Z0][i] + f * p[SPH_AZ][i];
             p[SPH_RHO][i] = p[SPH_RHO0][i] + f * p[SPH_ARHO][i];
         }
+    } else if (a.stepper == SPH_STEP_SOLID_MECH) { // integrator_step.py:175-255
+        constexpr int q[]  = {SPH_X, SPH_Y, SPH_Z, SPH_U, SPH_V, SPH_W, SPH_RHO, SPH_E,
+                                 SPH_S00, SPH_S01, SPH_S02, SPH_S11, SPH_S12, SPH_S22};
+        constexpr int q0[] = {SPH_X0, SPH_Y0, SPH_Z0, SPH_U0, SPH_V0, SPH_W0, SPH_RHO0, SPH_E0,
+                                 SPH_S000, SPH_S010, SPH_S020, SPH_S110, SPH_S120, SPH_S220};
+        constexpr int aq[] = {SPH_AX, SPH_AY, SPH_AZ, SPH_AU, SPH_AV, SPH_AW, SPH_ARHO, SPH_AE,
+                                 SPH_AS00, SPH_AS01, SPH_AS02, SPH_AS11, SPH_AS12, SPH_AS22};
+        if (a.stage == 0) {
+#pragma unroll
+            for (int k = 0; k < 14; k++) p[q0[k]][i] = p[q[k]][i];
+        } else {
+            const double f = a.stage == 1 ? dtb2 : dt;
+#pragma unroll
+            for (int k = 0; k < 14; k++) p[q[k]][i] = p[q0[k]][i] + f * p[aq[k]][i];
+        }
     } else if (a.stepper == SPH_STEP_TVF) {
         if (a.stage == 1) { // :268-285
             double u = p[SPH_U][i] + dtb2 * p[SPH_AU][i];
@@ -69,8 +84,16 @@ extern "C" int sph_integrate_stage(sph_ctx *c, int id, int stepper, int stage, d
     static const int tv1[] = {SPH_X, SPH_Y, SPH_Z, SPH_U, SPH_V, SPH_W, SPH_AU, SPH_AV, SPH_AW, SPH_UHAT, SPH_VHAT, SPH_WHAT,
                               SPH_AUHAT, SPH_AVHAT, SPH_AWHAT, -1};
     static const int tv2[] = {SPH_U, SPH_V, SPH_W, SPH_AU, SPH_AV, SPH_AW, SPH_VMAG2, -1};
+    static const int sm0[] = {SPH_X, SPH_Y, SPH_Z, SPH_U, SPH_V, SPH_W, SPH_RHO, SPH_E, SPH_S00, SPH_S01, SPH_S02, SPH_S11, SPH_S12, SPH_S22,
+                              SPH_X0, SPH_Y0, SPH_Z0, SPH_U0, SPH_V0, SPH_W0, SPH_RHO0, SPH_E0, SPH_S000, SPH_S010, SPH_S020, SPH_S110,
+                              SPH_S120, SPH_S220, -1};
+    static const int sm1[] = {SPH_X, SPH_Y, SPH_Z, SPH_U, SPH_V, SPH_W, SPH_RHO, SPH_E, SPH_S00, SPH_S01, SPH_S02, SPH_S11, SPH_S12, SPH_S22,
+                              SPH_X0, SPH_Y0, SPH_Z0, SPH_U0, SPH_V0, SPH_W0, SPH_RHO0, SPH_E0, SPH_S000, SPH_S010, SPH_S020, SPH_S110,
+                              SPH_S120, SPH_S220, SPH_AX, SPH_AY, SPH_AZ, SPH_AU, SPH_AV, SPH_AW, SPH_ARHO, SPH_AE, SPH_AS00, SPH_AS01,
+                              SPH_AS02, SPH_AS11, SPH_AS12, SPH_AS22, -1};
     const int *need = nullptr;
     if (stepper == SPH_STEP_WCSPH) need = stage == 0 ? wc0 : wc1;
+    else if (stepper == SPH_STEP_SOLID_MECH) need = stage == 0 ? sm0 : sm1;
     else if (stepper == SPH_STEP_TVF) { if (stage == 0) return SPH_OK; need = stage == 1 ? tv1 : tv2; }
     else { sph_set_error("sph_integrate_stage: unknown stepper %d", stepper); return SPH_ERR_UNSUPPORTED; }
     for (const int *q = need; *q >= 0; q++) SPH_TRY(sph_array_ensure_prop(c, id, *q));
@@ -80,6 +103,6 @@ extern "C" int sph_integrate_stage(sph_ctx *c, int id, int stepper, int stage, d
     for (int k = 0; k < SPH_PROP_COUNT; k++) a.p[k] = A.prop[k];
     ScopedTimer tm(c, T_STAGE);
     hipLaunchKernelGGL(k_stage, dim3(div_up(A.n_real, 256)), dim3(256), 0, c->stream, a);
-    if (stepper == SPH_STEP_WCSPH ? stage > 0 : stage == 1) c->nnps_valid = false; // positions moved
+    if (stepper == SPH_STEP_TVF ? stage == 1 : stage > 0) c->nnps_valid = false; // positions moved
     return SPH_OK;
 }

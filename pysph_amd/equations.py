@@ -276,7 +276,7 @@ EQUATION_TABLE = OrderedDict([
 
 # equations that have no neighbour loop
 NO_SOURCE_KINDS = (EQ_TAIT_EOS, EQ_TAIT_EOS_HG, EQ_TVF_STATE_EQUATION,
-                   EQ_ISOTHERMAL_EOS)
+                   EQ_ISOTHERMAL_EOS, 17, 19, 21)
 
 
 def resolve_equation(eq):
@@ -286,10 +286,18 @@ def resolve_equation(eq):
     name = type(eq).__name__
     if name == 'SummationDensity' and 'transport_velocity' in type(eq).__module__:
         name = 'TVFSummationDensity'
+    if name == 'IsothermalEOS' and 'solid_mech' in type(eq).__module__:
+        name = 'SolidIsothermalEOS'
+    if name not in EQUATION_TABLE:
+        try:   # the elastic family registers itself on import
+            from . import solid_mech  # noqa: F401
+        except ImportError:
+            pass
     if name not in EQUATION_TABLE:
         raise NotImplementedError(
             'HIP backend: equation %s has no hand-written kernel; supported: %s'
             % (name, ', '.join(EQUATION_TABLE)))
     kind, params, dprops, sprops = EQUATION_TABLE[name]
-    vals = [float(getattr(eq, p)) for p in params]
+    # '@name' parameters are array constants resolved at compute time
+    vals = [p if p.startswith('@') else float(getattr(eq, p)) for p in params]
     return kind, vals, dprops, sprops

@@ -35,7 +35,12 @@ def arrays_from_golden(g, which='in'):
             parts = key.split('/')
             if parts[0] == which and parts[1] == name:
                 props[parts[2]] = g[key].copy()
-        pa = ParticleArray(name=name, **props)
+        consts = {}
+        for key in g.files:
+            parts = key.split('/')
+            if parts[0] == 'const' and parts[1] == name:
+                consts[parts[2]] = g[key].copy()
+        pa = ParticleArray(name=name, constants=consts, **props)
         nreal = 'nreal/%s' % name
         if nreal in g.files:
             pa.set_num_real_particles(int(g[nreal]))

@@ -237,6 +237,138 @@ def case_kernels():
     print('wrote', path)
 
 
+def _import_solid_mech():
+    """pysph.sph.solid_mech.basic imports pysph.base.utils (-> cyarray, absent)
+    only for a particle-array factory; give it a placeholder module.  The one
+    compiled helper its equations need, linalg3.eigen_decomposition /
+    transform_diag_inv, is the reference's own linalg3.pyx built into
+    oracle/_ref (oracle/build_ref.sh)."""
+    import types
+    if 'pysph.base.utils' not in sys.modules:
+        m = types.ModuleType('pysph.base.utils')
+        m.get_particle_array = lambda *a, **k: None
+        sys.modules['pysph.base.utils'] = m
+    sys.path.insert(0, os.path.join(REPO, 'oracle', '_ref'))
+    import linalg3
+    from pysph.sph.solid_mech import basic as sm
+
+    def loop(self, d_idx, d_rho, d_p, d_s00, d_s01, d_s02, d_s11, d_s12, d_s22,
+             d_r00, d_r01, d_r02, d_r11, d_r12, d_r22):
+        # solid_mech/basic.py:170-242 with the cython-only matrix declarations
+        # replaced by numpy arrays; eigen solver = compiled reference code
+        rhoi = d_rho[d_idx]
+        rhoi21 = 1. / (rhoi * rhoi)
+        p = d_p[d_idx]
+        S = np.array([[d_s00[d_idx] - p, d_s01[d_idx], d_s02[d_idx]],
+                      [d_s01[d_idx], d_s11[d_idx] - p, d_s12[d_idx]],
+                      [d_s02[d_idx], d_s12[d_idx], d_s22[d_idx] - p]])
+        V, R = linalg3.py_eigen_decompose_eispack(S)
+        rd = np.zeros(3)
+        for k in range(3):
+            rd[k] = -self.eps * V[k] * rhoi21 if V[k] > 0 else 0
+        Rab = linalg3.py_transform_diag_inv(rd, np.ascontiguousarray(R))
+        d_r00[d_idx] = float(Rab[0][0]); d_r11[d_idx] = float(Rab[1][1])
+        d_r22[d_idx] = float(Rab[2][2]); d_r12[d_idx] = float(Rab[1][2])
+        d_r02[d_idx] = float(Rab[0][2]); d_r01[d_idx] = float(Rab[0][1])
+    sm.MonaghanArtificialStress.loop = loop
+    return sm
+
+
+EL_PROPS = ['x', 'y', 'z', 'u', 'v', 'w', 'h', 'm', 'rho', 'p', 'cs',
+            'arho', 'au', 'av', 'aw', 'ax', 'ay', 'az',
+            'v00', 'v01', 'v02', 'v10', 'v11', 'v12', 'v20', 'v21', 'v22',
+            's00', 's01', 's02', 's11', 's12', 's22',
+            'as00', 'as01', 'as02', 'as11', 'as12', 'as22',
+            'r00', 'r01', 'r02', 'r11', 'r12', 'r22']
+
+
+def _elastic_case(fname, dim, n1, seed):
+    sm = _import_solid_mech()
+    from pysph.sph.basic_equations import (
+        ContinuityEquation, MonaghanArtificialViscosity, XSPHCorrection,
+        VelocityGradient2D, VelocityGradient3D)
+    rng = np.random.default_rng(seed)
+    dx = 1.0 / n1
+    g = (np.arange(n1) + 0.5) * dx
+    if dim == 2:
+        x, y = [a.ravel() for a in np.meshgrid(g, g, indexing='ij')]
+        z = np.zeros_like(x)
+    else:
+        x, y, z = [a.ravel() for a in np.meshgrid(g, g, g, indexing='ij')]
+    n = x.size
+    hdx = 1.3
+    rho0, E, nu = 1.2, 1e4, 0.3975           # rings.py parameters scaled
+    G = E / (2. * (1. + nu))
+    c0 = np.sqrt(E / (3 * (1. - 2 * nu) * rho0))
+    kernel = CubicSpline(dim=dim)
+    props = {k: rng.uniform(-1, 1, n) for k in EL_PROPS}
+    props.update(
+        x=x + 0.1 * dx * rng.uniform(-1, 1, n),
+        y=y + 0.1 * dx * rng.uniform(-1, 1, n),
+        z=(z + 0.1 * dx * rng.uniform(-1, 1, n)) if dim == 3 else z,
+        h=hdx * dx * np.ones(n), m=rho0 * dx ** dim * np.ones(n),
+        rho=rho0 * (1 + 0.02 * rng.uniform(-1, 1, n)),
+        cs=c0 * np.ones(n))
+    if dim == 2:
+        props['w'] = np.zeros(n)
+    for k in ('s00', 's01', 's02', 's11', 's12', 's22'):
+        props[k] = 0.05 * E * rng.uniform(-1, 1, n)
+    consts = dict(wdeltap=[kernel.kernel(rij=dx, h=hdx * dx)], n=[4.0], G=[G],
+                  E=[E], nu=[nu], rho_ref=[rho0], c0_ref=[c0])
+    VG = VelocityGradient2D if dim == 2 else VelocityGradient3D
+    eqs = [
+        Group(equations=[
+            sm.IsothermalEOS('solid', sources=None),
+            VG(dest='solid', sources=['solid']),
+            sm.MonaghanArtificialStress(dest='solid', sources=None, eps=0.3)]),
+        Group(equations=[
+            ContinuityEquation(dest='solid', sources=['solid']),
+            sm.MomentumEquationWithStress(dest='solid', sources=['solid']),
+            MonaghanArtificialViscosity(dest='solid', sources=['solid'],
+                                        alpha=1.0, beta=1.0),
+            sm.HookesDeviatoricStressRate(dest='solid', sources=None),
+            XSPHCorrection(dest='solid', sources=['solid'], eps=0.5)]),
+    ]
+    pas = [ListPA('solid', props, n, constants=consts)]
+    out = {}
+    for k, v in pas[0].properties.items():
+        out['in/solid/%s' % k] = np.array(v)
+    out['nreal/solid'] = np.array(n)
+    for k, v in consts.items():
+        out['const/solid/%s' % k] = np.array(v, dtype=float)
+    a_eval = AccelerationEval(pas, eqs, kernel)
+    nnps = PyLinkedListNNPS(dim, pas, radius_scale=kernel.radius_scale)
+    nnps.update()
+    check_nnps(nnps)
+    RefEval(a_eval, nnps).compute(0.0, 1e-4)
+    for k, v in pas[0].properties.items():
+        out['out/solid/%s' % k] = np.array(v)
+    out['nnps/cell_size'] = np.array(nnps.cell_size)
+    out['nnps/xmin'] = np.array(nnps.xmin)
+    out['nnps/xmax'] = np.array(nnps.xmax)
+    out['nnps/ncells_per_dim'] = np.array(nnps.nc)
+    out['nnps/n_cells'] = np.array(nnps.n_cells)
+    out['t'] = np.array(0.0)
+    out['dt'] = np.array(1e-4)
+    out['meta/dx'] = np.array(dx)
+    out['meta/dim'] = np.array(dim)
+    path = os.path.join(HERE, fname)
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB')
+
+
+def case_elastic_2d():
+    """ElasticSolidsScheme equation set (solid_mech/basic.py:604-651) on a 2-D
+    block, CubicSpline(dim=2): the reference's own equation classes; eigen
+    solver = the reference's compiled linalg3."""
+    _elastic_case('elastic_2d.npz', 2, 14, 5)
+
+
+def case_elastic_3d():
+    """Same set with VelocityGradient3D (what BASELINE config 5 needs)."""
+    _elastic_case('elastic_3d.npz', 3, 7, 6)
+
+
 def case_steppers():
     """The reference's stepper methods (integrator_step.py:38-93, 257-299)
     executed as plain Python on 24 random particles."""
@@ -244,9 +376,13 @@ def case_steppers():
     from pysph.sph.integrator_step import WCSPHStep, TransportVelocityStep
     rng = np.random.default_rng(17)
     n = 24
+    from pysph.sph.integrator_step import SolidMechStep
     names = ['x', 'y', 'z', 'u', 'v', 'w', 'rho', 'x0', 'y0', 'z0', 'u0', 'v0',
              'w0', 'rho0', 'au', 'av', 'aw', 'ax', 'ay', 'az', 'arho', 'uhat',
-             'vhat', 'what', 'auhat', 'avhat', 'awhat', 'vmag2']
+             'vhat', 'what', 'auhat', 'avhat', 'awhat', 'vmag2',
+             'e', 'ae', 'e0', 's00', 's01', 's02', 's11', 's12', 's22',
+             'as00', 'as01', 'as02', 'as11', 'as12', 'as22',
+             's000', 's010', 's020', 's110', 's120', 's220']
     base = {k: rng.uniform(-1, 1, n) for k in names}
     out = {'in/' + k: v.copy() for k, v in base.items()}
     dt = 0.0123
@@ -265,6 +401,7 @@ def case_steppers():
                 out['%s/%s/%s' % (tag, meth, k)] = np.array(v)
     run(WCSPHStep(), ['initialize', 'stage1', 'stage2'], 'wcsph')
     run(TransportVelocityStep(), ['stage1', 'stage2'], 'tvf')
+    run(SolidMechStep(), ['initialize', 'stage1', 'stage2'], 'solid')
     path = os.path.join(HERE, 'steppers.npz')
     np.savez_compressed(path, **out)
     print('wrote', path)
@@ -272,6 +409,6 @@ def case_steppers():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['kernels', 'sd_1d', 'wcsph_cube_varh', 'tvf_cube',
-                             'wcsph_dam', 'steppers']
+                             'wcsph_dam', 'steppers', 'elastic_2d', 'elastic_3d']
     for w in which:
         globals()['case_' + w]()

@@ -9,6 +9,9 @@ from pysph_amd.examples import dam_break_3d as db
 
 WC_OUT = ['rho', 'p', 'cs', 'arho', 'au', 'av', 'aw', 'ax', 'ay', 'az',
           'dt_cfl', 'dt_force']
+EL_OUT = ['p', 'v00', 'v01', 'v02', 'v10', 'v11', 'v12', 'v20', 'v21', 'v22',
+          'r00', 'r01', 'r02', 'r11', 'r12', 'r22', 'arho', 'au', 'av', 'aw',
+          'ax', 'ay', 'az', 'as00', 'as01', 'as02', 'as11', 'as12', 'as22']
 TVF_OUT = ['rho', 'V', 'p', 'au', 'av', 'aw', 'auhat', 'avhat', 'awhat']
 
 
@@ -34,6 +37,11 @@ def golden_case(name, g):
         s = TVFScheme(['fluid'], [], dim=3, rho0=1.0, c0=10.0, nu=0.01,
                       p0=100.0, pb=100.0, h0=dx, gx=0.1, alpha=0.2)
         return s.get_equations(), K.QuinticSpline(dim=3), 3, TVF_OUT
+    if name in ('elastic_2d', 'elastic_3d'):
+        from pysph_amd.solid_mech import ElasticSolidsScheme
+        dim = int(g['meta/dim'])
+        s = ElasticSolidsScheme(['solid'], [], dim=dim)
+        return s.get_equations(), K.CubicSpline(dim=dim), dim, EL_OUT
     raise KeyError(name)
 
 

@@ -30,6 +30,7 @@ def test_library_exports_every_declared_symbol():
 def test_property_and_enum_tables_agree():
     from pysph_amd import device as dev
     from pysph_amd import equations as E
+    from pysph_amd import solid_mech as SM
     hdr = open(os.path.join(REPO, 'include', 'sphhip.h')).read()
     for name in ['x', 'y', 'z', 'u', 'v', 'w', 'h', 'm', 'rho', 'p', 'cs',
                  'arho', 'au', 'av', 'aw', 'ax', 'ay', 'az', 'dt_cfl',
@@ -37,7 +38,9 @@ def test_property_and_enum_tables_agree():
         assert dev.prop_id(name) >= 0
     assert dev.prop_id('x') == 0 and dev.prop_id('nonsense') == -1
     for cname, val in re.findall(r'(SPH_EQ_[A-Z_]+)\s*=\s*(\d+)', hdr):
-        py = getattr(E, cname[4:])
+        py = getattr(E, cname[4:], None)
+        if py is None:
+            py = getattr(SM, cname[4:])
         assert py == int(val), cname
 
 

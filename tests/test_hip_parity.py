@@ -15,7 +15,8 @@ from helpers import golden_case, rel_err, WC_OUT
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-10
-CASES = ['sd_1d_line', 'wcsph_cube_varh', 'tvf_cube', 'wcsph_dam_dx0.1']
+CASES = ['sd_1d_line', 'wcsph_cube_varh', 'tvf_cube', 'wcsph_dam_dx0.1',
+         'elastic_2d', 'elastic_3d']
 
 
 def make_eval(arrays, eqs, kernel, dim, variant=3, sync='auto'):

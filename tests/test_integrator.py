@@ -7,7 +7,10 @@ from helpers import rel_err
 
 STEP_PROPS = ['x', 'y', 'z', 'u', 'v', 'w', 'rho', 'x0', 'y0', 'z0', 'u0', 'v0',
               'w0', 'rho0', 'au', 'av', 'aw', 'ax', 'ay', 'az', 'arho', 'uhat',
-              'vhat', 'what', 'auhat', 'avhat', 'awhat', 'vmag2']
+              'vhat', 'what', 'auhat', 'avhat', 'awhat', 'vmag2',
+              'e', 'ae', 'e0', 's00', 's01', 's02', 's11', 's12', 's22',
+              'as00', 'as01', 'as02', 'as11', 'as12', 'as22',
+              's000', 's010', 's020', 's110', 's120', 's220']
 
 
 def _pa_from(g):
@@ -32,6 +35,16 @@ def test_oracle_steppers_match_reference_bitwise():
     S.wcsph_stage(pa, dt, 2)
     for k in STEP_PROPS:
         assert np.array_equal(pa.properties[k], g['wcsph/stage2/' + k]), k
+    pa = _pa_from(g)
+    S.solid_initialize(pa)
+    for k in STEP_PROPS:
+        assert np.array_equal(pa.properties[k], g['solid/initialize/' + k]), k
+    S.solid_stage(pa, dt, 1)
+    for k in STEP_PROPS:
+        assert np.array_equal(pa.properties[k], g['solid/stage1/' + k]), k
+    S.solid_stage(pa, dt, 2)
+    for k in STEP_PROPS:
+        assert np.array_equal(pa.properties[k], g['solid/stage2/' + k]), k
     pa = _pa_from(g)
     S.tvf_stage1(pa, dt)
     for k in STEP_PROPS:
@@ -60,7 +73,8 @@ def test_stage_kernels_match_reference_golden():
     g = load_golden('steppers.npz')
     dt = float(g['dt'])
     for kind, tag, stages in ((1, 'wcsph', [(0, 'initialize'), (1, 'stage1'), (2, 'stage2')]),
-                              (2, 'tvf', [(1, 'stage1'), (2, 'stage2')])):
+                              (2, 'tvf', [(1, 'stage1'), (2, 'stage2')]),
+                              (3, 'solid', [(0, 'initialize'), (1, 'stage1'), (2, 'stage2')])):
         pa = _pa_from(g)
         ctx = dev.HipContext(0)
         gpu = dev.attach(pa, ctx)

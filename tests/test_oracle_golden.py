@@ -9,7 +9,8 @@ import pytest
 from conftest import load_golden, arrays_from_golden
 from helpers import golden_case
 
-CASES = ['sd_1d_line', 'wcsph_cube_varh', 'tvf_cube', 'wcsph_dam_dx0.1']
+CASES = ['sd_1d_line', 'wcsph_cube_varh', 'tvf_cube', 'wcsph_dam_dx0.1',
+         'elastic_2d', 'elastic_3d']
 
 
 @pytest.mark.parametrize('case', CASES)
