@@ -114,6 +114,10 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--n1', type=int, default=159, help='lattice side per GPU')
+    ap.add_argument('--workload', default='cube',
+                    choices=['cube', 'dam_break', 'taylor_green', 'elastic'],
+                    help='cube = S-cube WCSPH (headline); others: BASELINE configs 2/3/5')
+    ap.add_argument('--dx', type=float, default=0.0087, help='dam_break spacing')
     ap.add_argument('--variant', type=int, default=3)
     ap.add_argument('--ablate', type=int, default=0, help='profiling only')
     ap.add_argument('--opt', action='append', default=[], help='key=value library option')
@@ -153,33 +157,105 @@ def main():
         ctx.set_option(k, int(v))
 
     n1 = args.n1
-    pa, dx = make_cube(n1, x_offset=float(rank), seed=1234 + rank)
-    n_local = pa.get_number_of_particles()
-    eqs = cube_equations(dx)
-    kernel = K.WendlandQuintic(dim=3)
+    domain = None
+    algo_pair = ALGO_BYTES_PAIR
+    if args.workload == 'cube':
+        pa, dx = make_cube(n1, x_offset=float(rank), seed=1234 + rank)
+        arrays = [pa]
+        eqs = cube_equations(dx)
+        kernel = K.WendlandQuintic(dim=3)
+        wname = ('S-cube WCSPH dam-break parameter set (WendlandQuintic, hdx 1.3), '
+                 '%d^3 = %d particles per GPU, jitter 0.1dx, seed 1234' %
+                 (n1, pa.get_number_of_particles()))
+    elif args.workload == 'dam_break':
+        from pysph_amd.examples import dam_break_3d as db
+        if world > 1:
+            raise SystemExit('dam_break workload: single GPU only in this round')
+        arrays = db.create_particles(args.dx)
+        dx = args.dx
+        eqs = db.create_scheme(dx).get_equations()
+        kernel = db.create_kernel()
+        wname = ('3D dam break (dam_break_3d.py geometry), dx=%g: %s' % (
+            dx, ', '.join('%s %d' % (a.name, a.get_number_of_particles())
+                          for a in arrays)))
+    elif args.workload == 'taylor_green':
+        from pysph_amd.domain import HipDomainManager
+        from pysph_amd.particle_array import get_particle_array_tvf_fluid
+        from pysph_amd.scheme import TVFScheme
+        if world > 1:
+            raise SystemExit('taylor_green workload: single GPU only in this round')
+        dx = 1.0 / n1
+        g = (np.arange(n1) + 0.5) * dx
+        x, y, z = [a.ravel().copy() for a in np.meshgrid(g, g, g, indexing='ij')]
+        pa = get_particle_array_tvf_fluid(
+            name='fluid', x=x, y=y, z=z, h=dx * np.ones(x.size),
+            m=dx ** 3 * np.ones(x.size), rho=np.ones(x.size),
+            u=-np.cos(2 * np.pi * x) * np.sin(2 * np.pi * y),
+            v=np.sin(2 * np.pi * x) * np.cos(2 * np.pi * y))
+        pa.uhat[:] = pa.u
+        pa.vhat[:] = pa.v
+        arrays = [pa]
+        eqs = TVFScheme(['fluid'], [], dim=3, rho0=1.0, c0=10.0, nu=0.01,
+                        p0=100.0, pb=100.0, h0=dx).get_equations()
+        kernel = K.QuinticSpline(dim=3)
+        domain = HipDomainManager(ctx=ctx, xmin=0, xmax=1, ymin=0, ymax=1, zmin=0,
+                                  zmax=1, periodic_in_x=True, periodic_in_y=True,
+                                  periodic_in_z=True)
+        algo_pair = 160.0   # force pass: 112 R + 48 W (SURVEY 8d TVF pass 2)
+        wname = ('Taylor-Green 3D TVF (taylor_green.py parameters), periodic unit '
+                 'cube %d^3 = %d particles, QuinticSpline hdx 1.0' % (n1, x.size))
+    else:
+        from pysph_amd.solid_mech import (ElasticSolidsScheme,
+                                          get_particle_array_elastic_dynamics)
+        if world > 1:
+            raise SystemExit('elastic workload: single GPU only in this round')
+        dx = 1.0 / n1
+        g = (np.arange(n1) + 0.5) * dx
+        x, y, z = [a.ravel().copy() for a in np.meshgrid(g, g, g, indexing='ij')]
+        rng = np.random.default_rng(7)
+        E, nu, rho0 = 1e7, 0.3975, 1.2            # rings.py:21-38
+        kernel = K.CubicSpline(dim=3)
+        h0 = 1.3 * dx
+        pa = get_particle_array_elastic_dynamics(
+            name='solid', x=x, y=y, z=z, h=h0 * np.ones(x.size),
+            m=rho0 * dx ** 3 * np.ones(x.size), rho=rho0 * np.ones(x.size),
+            u=1e-2 * rng.uniform(-1, 1, x.size),
+            constants=dict(E=E, nu=nu, rho_ref=rho0, n=4,
+                           wdeltap=float(kernel.kernel(rij=dx, h=h0))))
+        arrays = [pa]
+        eqs = ElasticSolidsScheme(['solid'], [], dim=3).get_equations()
+        algo_pair = 8.0 * (22 + 7)
+        wname = ('Elastic solid block (Gray 2001 equation set, rings.py material), '
+                 '%d^3 = %d particles, CubicSpline hdx 1.3, fp64' % (n1, x.size))
+    pa = arrays[0]
+    n_local = sum(a.get_number_of_particles() for a in arrays)
 
-    dev.attach(pa, ctx).push()          # everything resident in HBM
+    for a in arrays:
+        dev.attach(a, ctx).push()       # everything resident in HBM
     halo = None
     if world > 1:
         from pysph_amd.parallel import SlabHalo
         halo = SlabHalo(pa, ctx, rank, world, axis=0,
                         width=kernel.radius_scale * 1.3 * dx,
                         lo=float(rank), hi=float(rank + 1))
-    a_eval = AccelerationEval([pa], eqs, kernel)
+    a_eval = AccelerationEval(arrays, eqs, kernel)
     SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
-    nnps = HipNNPS(3, [pa], radius_scale=kernel.radius_scale, ctx=ctx,
-                   sync=False)
+    nnps = HipNNPS(3, arrays, radius_scale=kernel.radius_scale, ctx=ctx,
+                   sync=False, domain=domain)
     a_eval.set_nnps(nnps)
-    if not args.no_reorder:
+    if not args.no_reorder and domain is None:
         # what the reference's Solver does for its GPU backends before the first
         # step and every 50 steps (solver.py:296-302, application.py:1157-1161):
         # put the particles in cell order so gathers/scatters coalesce
-        nnps.spatially_order_particles(0)
-        nnps.update()
+        for i in range(len(arrays)):
+            nnps.spatially_order_particles(i)
+            nnps.update()
 
     def step():
         if halo is not None:
             halo.exchange()
+        if domain is not None:
+            nnps.update_domain()        # periodic ghosts are rebuilt every step
         nnps.update()
         a_eval.compute(0.0, 1e-5)
 
@@ -219,12 +295,16 @@ def main():
             pt = json.load(open(os.path.join(REPO, 'profiles', 'pmc_traffic.json')))
             c = pt['config']
             if (c['n1'], c['variant'], c['spatially_ordered']) == \
-                    (n1, args.variant, not args.no_reorder) and world == 1:
+                    (n1, args.variant, not args.no_reorder) and world == 1 \
+                    and args.workload == 'cube':
                 traffic = pt['bytes_per_launch']
         except Exception:
             traffic = None
         pair_avg_s = pair_ms / max(pair_launches, 1) * 1e-3
-        achieved = ALGO_BYTES_PAIR * n_local / pair_avg_s / 1e9 if pair_avg_s > 0 else 0.0
+        # several pair launches per step for multi-destination sets: bytes of ONE
+        # step / total pair-kernel time of one step
+        pair_step_s = pair_ms / args.steps * 1e-3
+        achieved = algo_pair * n_local / pair_step_s / 1e9 if pair_step_s > 0 else 0.0
         out = {
             'metric': 'particle-updates/sec (nnps.update + AccelerationEval.compute), '
                       'WCSPH 3D, fp64',
@@ -234,9 +314,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
             'data': 'synthetic',
             'config': {
-                'workload': 'S-cube WCSPH dam-break parameter set '
-                            '(WendlandQuintic, hdx 1.3), %d^3 = %d particles '
-                            'per GPU, jitter 0.1dx, seed 1234' % (n1, n_local),
+                'workload': wname,
                 'particles_per_gpu': n_local, 'pair_variant': args.variant,
                 'spatially_ordered': not args.no_reorder,
                 'parallelism': 'slab%d' % world if world > 1 else 'single',
@@ -246,7 +324,7 @@ def main():
                 ('direct', 'tiled', 'wg', 'agg')[args.variant],
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                'algorithmic_bytes_per_particle': ALGO_BYTES_PAIR,
+                'algorithmic_bytes_per_particle': algo_pair,
                 'avg_kernel_ms': pair_avg_s * 1e3,
             },
             'kernel_ms_per_step': {k: v[0] / args.steps for k, v in timers.items()},

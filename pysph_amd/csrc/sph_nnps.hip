@@ -139,16 +139,21 @@ __global__ __launch_bounds__(256) void k_cell_keys(const double *__restrict__ x,
     idx[i] = (uint32_t)i;
 }
 
-// cell_start[c] = first sorted position whose key >= c, for c in [0, n_cells].
-// Every entry is written exactly once (no atomics, no scan).
+// cell_start[c] = first sorted position whose key >= c, for c in [0, n_cells]:
+// one thread per cell, lower_bound over the sorted keys (no atomics, no scan,
+// cost independent of how sparsely an array occupies the grid).
 __global__ __launch_bounds__(256) void k_cell_start(const uint32_t *__restrict__ skeys, size_t n, uint32_t n_cells,
                                                     uint32_t *__restrict__ cell_start)
 {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n) return;
-    long k0 = (i == 0) ? -1 : (long)skeys[i - 1];
-    long k1 = (i == n) ? (long)n_cells : (long)skeys[i];
-    for (long cidx = k0 + 1; cidx <= k1; cidx++) cell_start[cidx] = (uint32_t)i;
+    size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_cells) return;
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+        size_t mid = (lo + hi) >> 1;
+        if (skeys[mid] < (uint32_t)c) lo = mid + 1;
+        else hi = mid;
+    }
+    cell_start[c] = (uint32_t)lo;
 }
 
 __global__ __launch_bounds__(256) void k_fill_u32(uint32_t *p, size_t n, uint32_t v)
@@ -288,8 +293,8 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.ptr, tmp_bytes, A.keys.as<uint32_t>(),
                                                    A.keys_sorted.as<uint32_t>(), A.idx.as<uint32_t>(),
                                                    A.perm.as<uint32_t>(), (int)n, 0, end_bit, c->stream));
-        hipLaunchKernelGGL(k_cell_start, dim3(div_up(n + 1, 256)), dim3(256), 0, c->stream, A.keys_sorted.as<uint32_t>(),
-                           n, (uint32_t)n_cells_alloc, A.cell_start.as<uint32_t>());
+        hipLaunchKernelGGL(k_cell_start, dim3(div_up((size_t)n_cells_alloc + 1, 256)), dim3(256), 0, c->stream,
+                           A.keys_sorted.as<uint32_t>(), n, (uint32_t)n_cells_alloc, A.cell_start.as<uint32_t>());
     }
     HIP_TRY(hipGetLastError());
     c->nnps_valid = true;
