@@ -203,6 +203,9 @@ struct PackArgs {
     double *aux;
     double *rec;                  // non-null: interleaved records [x y z h aux... pad], nr doubles each
     int nr;
+    float4 *fpos;                 // non-null: fp32 {x-xmin, y-ymin, z-zmin, radius_scale*h} for the prefilter tiles
+    double gmin[3];
+    double radius_scale;
 };
 
 __global__ __launch_bounds__(256) void k_pack(PackArgs a)
@@ -223,6 +226,9 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
         v[9] = (v[9] - pr) * r21; v[10] *= r21; v[11] = (v[11] - pr) * r21;
         v[18] = 0.0;
     }
+    if (a.fpos)
+        a.fpos[a.off + i] = make_float4((float)(ph.x - a.gmin[0]), (float)(ph.y - a.gmin[1]), (float)(ph.z - a.gmin[2]),
+                                        (float)(a.radius_scale * ph.w));
     if (a.rec) {
         // 32-B stores: every store covers whole sectors of the record
         double4 *r = reinterpret_cast<double4 *>(a.rec + (a.off + i) * (size_t)a.nr);
@@ -255,6 +261,8 @@ template <class Fam> struct PairArgs {
     const double4 *posh;
     const double *aux;
     const double *rec; // variant 2: interleaved records, Fam::NR doubles each
+    const float4 *fpos; // variant 3: fp32 grid-relative positions + radius_scale*h (prefilter only)
+    double dom_extent;  // largest grid extent: bounds the fp32 rounding of fpos
     uint32_t d_off, nd;
     const uint32_t *d_keys, *d_perm;
     uint32_t d_start, d_stop;
@@ -1101,13 +1109,16 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256, 4) void 
         const int cyR = R % ncy, czR = R / ncy;
         const int xa = max(cxa - 1, 0), xb = min(cxb + 1, ncx - 1);
         const int ncs = xb - xa + 2; // cell_start entries needed: cells xa..xb and the end
-        // fp32 coordinates relative to this row segment's origin
-        const double ox = a.xmin[0] + a.cell_size * xa;
-        const double oy = a.xmin[1] + a.cell_size * (cyR - 1);
-        const double oz = a.xmin[2] + a.cell_size * (czR - 1);
-        const double L = a.cell_size * (double)max(xb - xa + 2, 4);
+        // fp32 coordinates: grid-relative positions (fpos, rounded once from
+        // fp64) minus this row segment's origin; every value carries at most
+        // 2^-24 * dom_extent of rounding, covered by `slack`
+        const float oxf = (float)(a.cell_size * xa);
+        const float oyf = (float)(a.cell_size * (cyR - 1));
+        const float ozf = (float)(a.cell_size * (czR - 1));
+        const double L = fmax(a.cell_size * (double)max(xb - xa + 2, 4), a.dom_extent);
         const float slack = (float)(L * 1.5e-6);
-        const float fxs = (float)(pi.x - ox), fys = (float)(pi.y - oy), fzs = (float)(pi.z - oz);
+        const float4 fpi = a.fpos[a.d_off + ic];
+        const float fxs = fpi.x - oxf, fys = fpi.y - oyf, fzs = fpi.z - ozf;
         const f2 fx = {fxs, fxs}, fy = {fys, fys}, fz = {fzs, fzs};
         const float hif = (float)hi_r * 1.000001f + slack;
         const float hi2f = hif * hif;
@@ -1150,9 +1161,9 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256, 4) void 
                         for (int k = t; k < tn + 8; k += 256) {
                             float vx = 3.0e18f, vy = 3.0e18f, vz = 3.0e18f, vw = 0.f;
                             if (k < tn) {
-                                const double4 pj = *reinterpret_cast<const double4 *>(a.rec + (size_t)(sd.off + tb + k) * NR);
-                                vx = (float)(pj.x - ox); vy = (float)(pj.y - oy); vz = (float)(pj.z - oz);
-                                const float hjf = (float)(a.radius_scale * pj.w) * 1.000001f + slack;
+                                const float4 fj = a.fpos[sd.off + tb + k];
+                                vx = fj.x - oxf; vy = fj.y - oyf; vz = fj.z - ozf;
+                                const float hjf = fj.w * 1.000001f + slack;
                                 vw = hjf * hjf;
                             }
                             tx[k] = vx; ty[k] = vy; tz[k] = vz;
@@ -1216,6 +1227,229 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256, 4) void 
         }
     }
     if (active) Fam::finish(D, a, o);
+}
+
+// ---------------------------------------------------------------------------
+// variant 4: LDS-resident records, OPPOSITE neighbour rows processed together.
+//   Like variant 2 every candidate record a workgroup (256 destinations) needs
+//   is staged once into LDS with coalesced loads, so phase 2 never gathers from
+//   L1/L2.  The lane-utilisation problem of row-by-row processing (a destination
+//   near the low-y face of its cell has many neighbours in row dy=-1 and few in
+//   dy=+1) is removed by keeping the two opposite rows (dy,dz) / (-dy,-dz)
+//   resident at the same time and walking their hit bits in ONE loop: the two
+//   counts are complementary (simulated utilisation 0.65 vs 0.44).  Phase 1 uses
+//   per-lane candidate ranges (own 3 cells) on fp32 SoA tiles like variant 3.
+// ---------------------------------------------------------------------------
+#define PCAP 304
+
+template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256) void k_pair_rows2(PairArgs<Fam> a)
+{
+    constexpr int NR = Fam::NR;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *lrecA = reinterpret_cast<double *>(smem);
+    double *lrecB = lrecA + (size_t)PCAP * NR;
+    float *tx = reinterpret_cast<float *>(lrecB + (size_t)PCAP * NR);
+    float *ty = tx + (PCAP + 8), *tz = ty + (PCAP + 8), *tw = tz + (PCAP + 8);
+    uint32_t *csl = reinterpret_cast<uint32_t *>(tw + (PCAP + 8));
+    int *wx = reinterpret_cast<int *>(csl + 72);
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * 256 + t;
+    const bool valid = i < a.nd;
+    const uint32_t ic = valid ? i : a.nd - 1;
+    const uint32_t o = a.d_perm[ic];
+    const bool active = valid && o >= a.d_start && o < a.d_stop;
+    const double *drec = a.rec + (size_t)(a.d_off + ic) * NR;
+    const double4 pi = *reinterpret_cast<const double4 *>(drec);
+    typename Fam::Dest D;
+    Fam::load(D, drec + 4);
+    const uint32_t key = a.d_keys[ic];
+    const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
+    const int cx = key % ncx;
+    const int row = key / ncx;
+    const double hi_r = a.radius_scale * pi.w;
+    const double hi2 = UH ? a.hr2u : hi_r * hi_r;
+
+    if (t == 0) wx[8] = row;
+    if (t == 255) wx[9] = row;
+    __syncthreads();
+    const int row_first = wx[8], row_last = wx[9];
+
+    for (int R = row_first; R <= row_last; R++) {
+        const bool inseg = active && row == R;
+        const unsigned long long segm = __ballot(inseg);
+        int cxa_w = 0x7fffffff, cxb_w = -1;
+        if (segm) {
+            cxa_w = __builtin_amdgcn_readlane(cx, __builtin_ctzll(segm));
+            cxb_w = __builtin_amdgcn_readlane(cx, 63 - __builtin_clzll(segm));
+        }
+        __syncthreads();
+        if (lane == 0) { wx[2 * wv] = cxa_w; wx[2 * wv + 1] = cxb_w; }
+        __syncthreads();
+        const int cxa = min(min(wx[0], wx[2]), min(wx[4], wx[6]));
+        const int cxb = max(max(wx[1], wx[3]), max(wx[5], wx[7]));
+        if (cxb < 0) continue;
+        const int cyR = R % ncy, czR = R / ncy;
+        const int xa = max(cxa - 1, 0), xb = min(cxb + 1, ncx - 1);
+        const int ncs = xb - xa + 2;
+        const float oxf = (float)(a.cell_size * xa);
+        const float oyf = (float)(a.cell_size * (cyR - 1));
+        const float ozf = (float)(a.cell_size * (czR - 1));
+        const double L = fmax(a.cell_size * (double)max(xb - xa + 2, 4), a.dom_extent);
+        const float slack = (float)(L * 1.5e-6);
+        const float4 fpi = a.fpos[a.d_off + ic];
+        const float fxs = fpi.x - oxf, fys = fpi.y - oyf, fzs = fpi.z - ozf;
+        const f2 fx = {fxs, fxs}, fy = {fys, fys}, fz = {fzs, fzs};
+        const float hif = (float)hi_r * 1.000001f + slack;
+        const float hi2f = hif * hif;
+        const int mycl = max(cx - 1, xa) - xa, mych = min(cx + 1, xb) + 1 - xa;
+
+        for (int s = 0; s < a.nsrc; s++) {
+            const SrcDesc sd = a.src[s];
+            // stage one row piece (records -> lrec, fp32 positions -> tx/ty/tz, cell_start slice)
+            // and run phase 1 on it for this lane; returns the hit mask (<= 96 bits) and s0
+            auto stage_and_test = [&](double *lrec, uint32_t rowb, uint32_t tb, int tn, unsigned long long &m0,
+                                      uint32_t &m1, int &s0) {
+                __syncthreads(); // previous users of the fp32 tile / this record buffer are done
+                {
+                    const double2 *g = reinterpret_cast<const double2 *>(a.rec + (size_t)(sd.off + tb) * NR);
+                    double2 *l = reinterpret_cast<double2 *>(lrec);
+                    const int np = tn * (NR / 2);
+                    for (int q = t; q < np; q += 256) l[q] = g[q];
+                }
+                for (int q = t; q < ncs && q < 72; q += 256) csl[q] = sd.cell_start[rowb + xa + q];
+                for (int k = t; k < tn + 8; k += 256) {
+                    float vx = 3.0e18f, vy = 3.0e18f, vz = 3.0e18f, vw = 0.f;
+                    if (k < tn) {
+                        const float4 fj = a.fpos[sd.off + tb + k];
+                        vx = fj.x - oxf; vy = fj.y - oyf; vz = fj.z - ozf;
+                        const float hjf = fj.w * 1.000001f + slack;
+                        vw = hjf * hjf;
+                    }
+                    tx[k] = vx; ty[k] = vy; tz[k] = vz;
+                    if (!UH) tw[k] = vw;
+                }
+                __syncthreads();
+                s0 = 0;
+                int len = 0;
+                if (inseg) {
+                    int lo, hi;
+                    if (ncs <= 72) { lo = (int)(csl[mycl] - tb); hi = (int)(csl[mych] - tb); }
+                    else { lo = (int)(sd.cell_start[rowb + xa + mycl] - tb); hi = (int)(sd.cell_start[rowb + xa + mych] - tb); }
+                    lo = max(lo, 0); hi = min(hi, tn);
+                    s0 = lo & ~1;
+                    len = hi - s0;
+                }
+                const int lenc = min(len, AMAXLEN);
+                m0 = 0; m1 = 0;
+                for (int k0 = 0; __any(k0 < lenc); k0 += 8) {
+                    unsigned mm = 0;
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        const int idx = min(s0 + k0 + 2 * p, tn + 6);
+                        const f2 X = *reinterpret_cast<const f2 *>(&tx[idx]);
+                        const f2 Y = *reinterpret_cast<const f2 *>(&ty[idx]);
+                        const f2 Z = *reinterpret_cast<const f2 *>(&tz[idx]);
+                        const f2 ex = fx - X, ey = fy - Y, ez = fz - Z;
+                        const f2 r2 = ex * ex + ey * ey + ez * ez;
+                        bool h0, h1;
+                        if (UH) { h0 = r2.x < hi2f; h1 = r2.y < hi2f; }
+                        else {
+                            const f2 W = *reinterpret_cast<const f2 *>(&tw[idx]);
+                            h0 = (r2.x < hi2f) | (r2.x < W.x);
+                            h1 = (r2.y < hi2f) | (r2.y < W.y);
+                        }
+                        h0 &= (k0 + 2 * p) < lenc;
+                        h1 &= (k0 + 2 * p + 1) < lenc;
+                        mm |= (h0 ? (1u << (2 * p)) : 0u) | (h1 ? (2u << (2 * p)) : 0u);
+                    }
+                    if (k0 < 64) m0 |= (unsigned long long)mm << k0;
+                    else m1 |= mm << (k0 - 64);
+                }
+                // rare long ranges: set the remaining candidates' bits unconditionally is not
+                // possible (mask is 96 bits) -> exact tail from the LDS records
+                if (__any(len > AMAXLEN)) {
+                    for (int k = AMAXLEN; k < len; k++) {
+                        const double *rj = lrec + (size_t)(s0 + k) * NR;
+                        const double4 pj = *reinterpret_cast<const double4 *>(rj);
+                        double hj2 = hi2;
+                        if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
+                        const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+                        if ((r2 < hi2) || (r2 < hj2)) {
+                            double sj[Fam::NA];
+#pragma unroll
+                            for (int q = 0; q < Fam::NA; q++) sj[q] = rj[4 + q];
+                            Fam::template pair<KK, UH>(D, pi, pj, r2, sj, sd.flags, a);
+                        }
+                    }
+                }
+            };
+            auto one_hit = [&](const double *lrec, int idx) {
+                const double *rj = lrec + (size_t)idx * NR;
+                const double4 pj = *reinterpret_cast<const double4 *>(rj);
+                double hj2 = hi2;
+                if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
+                const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+                if (((r2 < hi2) || (r2 < hj2)) && a.ablate != 1) {
+                    double sj[Fam::NA];
+#pragma unroll
+                    for (int q = 0; q < Fam::NA; q++) sj[q] = rj[4 + q];
+                    Fam::template pair<KK, UH>(D, pi, pj, r2, sj, sd.flags, a);
+                }
+            };
+            // row groups: centre alone, then the four opposite pairs
+            for (int gidx = 0; gidx < 5; gidx++) {
+                static const int GDY[5] = {0, -1, 0, -1, -1}, GDZ[5] = {0, 0, -1, -1, 1};
+                const int dyA = GDY[gidx], dzA = GDZ[gidx];
+                const int yyA = cyR + dyA, zzA = czR + dzA, yyB = cyR - dyA, zzB = czR - dzA;
+                const bool okA = yyA >= 0 && yyA < ncy && zzA >= 0 && zzA < ncz;
+                const bool okB = gidx > 0 && yyB >= 0 && yyB < ncy && zzB >= 0 && zzB < ncz;
+                const uint32_t rowA = okA ? (uint32_t)(ncx * (yyA + ncy * zzA)) : 0u;
+                const uint32_t rowB = okB ? (uint32_t)(ncx * (yyB + ncy * zzB)) : 0u;
+                uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+                if (okA) { a0 = sd.cell_start[rowA + xa]; a1 = sd.cell_start[rowA + xb + 1]; }
+                if (okB) { b0 = sd.cell_start[rowB + xa]; b1 = sd.cell_start[rowB + xb + 1]; }
+                const uint32_t npa = (a1 - a0 + PCAP - 1) / PCAP, npb = (b1 - b0 + PCAP - 1) / PCAP;
+                const uint32_t npc = max(npa, npb);
+                for (uint32_t pc = 0; pc < npc; pc++) {
+                    unsigned long long mA0 = 0, mB0 = 0;
+                    uint32_t mA1 = 0, mB1 = 0;
+                    int sA = 0, sB = 0;
+                    if (pc < npa) {
+                        const uint32_t tb = a0 + pc * PCAP;
+                        stage_and_test(lrecA, rowA, tb, (int)min((uint32_t)PCAP, a1 - tb), mA0, mA1, sA);
+                    }
+                    if (pc < npb) {
+                        const uint32_t tb = b0 + pc * PCAP;
+                        stage_and_test(lrecB, rowB, tb, (int)min((uint32_t)PCAP, b1 - tb), mB0, mB1, sB);
+                    }
+                    if (a.ablate == 2) continue;
+                    // ---- phase 2: both rows' hits in one loop, records from LDS
+                    for (;;) {
+                        const bool hasA = (mA0 | mA1) != 0, hasB = (mB0 | mB1) != 0;
+                        if (!__any(hasA || hasB)) break;
+                        if (hasA) {
+                            int bit;
+                            if (mA0) { bit = __builtin_ctzll(mA0); mA0 &= mA0 - 1; }
+                            else { bit = 64 + __builtin_ctz(mA1); mA1 &= mA1 - 1; }
+                            one_hit(lrecA, sA + bit);
+                        } else if (hasB) {
+                            int bit;
+                            if (mB0) { bit = __builtin_ctzll(mB0); mB0 &= mB0 - 1; }
+                            else { bit = 64 + __builtin_ctz(mB1); mB1 &= mB1 - 1; }
+                            one_hit(lrecB, sB + bit);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (active) Fam::finish(D, a, o);
+}
+
+template <class Fam> static size_t rows2_lds_bytes()
+{
+    return (size_t)2 * PCAP * Fam::NR * 8 + (size_t)4 * (PCAP + 8) * 4 + 72 * 4 + 64;
 }
 
 template <class Fam> static size_t wg_lds_bytes() { return (size_t)TCAP * Fam::NR * 8 + (size_t)(TCAP + 8) * 16 + 64; }
@@ -1396,7 +1630,11 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
     pa.aux = c->aux.as<double>();
     pa.rec = nullptr;
     pa.nr = pl.nr;
+    pa.fpos = nullptr;
+    for (int k = 0; k < 3; k++) pa.gmin[k] = c->xmin[k];
+    pa.radius_scale = c->radius_scale;
     if (c->pair_variant >= 2) pa.rec = c->posh.as<double>();
+    if (c->pair_variant >= 3) pa.fpos = c->fposb.as<float4>();
     hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, pa);
     return SPH_OK;
 }
@@ -1406,6 +1644,28 @@ template <class Fam> static void launch_pair(sph_ctx *c, int kk, const PairArgs<
     if (a.nd == 0) return;
     const bool tiled = c->pair_variant != 0;
     const bool uh = c->uniform_h && c->use_uniform_h;
+    if (c->pair_variant == 4) {
+        dim3 g2(div_up(a.nd, 256)), b2(256);
+        size_t lds = rows2_lds_bytes<Fam>();
+#define LAUNCH4(K)                                                                                  \
+        if (uh) {                                                                                   \
+            (void)hipFuncSetAttribute((const void *)k_pair_rows2<Fam, K, true>,                     \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+            hipLaunchKernelGGL((k_pair_rows2<Fam, K, true>), g2, b2, lds, c->stream, a);            \
+        } else {                                                                                    \
+            (void)hipFuncSetAttribute((const void *)k_pair_rows2<Fam, K, false>,                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+            hipLaunchKernelGGL((k_pair_rows2<Fam, K, false>), g2, b2, lds, c->stream, a);           \
+        }
+        switch (kk) {
+        case 1: LAUNCH4(1); break;
+        case 2: LAUNCH4(2); break;
+        case 3: LAUNCH4(3); break;
+        case 4: LAUNCH4(4); break;
+        }
+#undef LAUNCH4
+        return;
+    }
     if (c->pair_variant == 3) {
         dim3 g2(div_up(a.nd, 256)), b2(256);
 #define LAUNCH3(K)                                                                           \
@@ -1458,6 +1718,8 @@ static void fill_common(sph_ctx *c, PairArgs<Fam> &a, const sph_kernel *K, doubl
     a.posh = c->posh.as<double4>();
     a.aux = c->aux.as<double>();
     a.rec = c->posh.as<double>();
+    a.fpos = c->fposb.as<float4>();
+    a.dom_extent = fmax(fmax(c->xmax[0] - c->xmin[0], c->xmax[1] - c->xmin[1]), c->xmax[2] - c->xmin[2]);
     for (int k = 0; k < 3; k++) { a.nc[k] = c->nc[k]; a.xmin[k] = c->xmin[k]; }
     a.cell_size = c->cell_size;
     a.radius_scale = c->radius_scale;
@@ -1576,6 +1838,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         PackPlan pl = pack_plan(fam);
         SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * (c->pair_variant >= 2 ? pl.nr : 4)));
         SPH_TRY(c->aux.reserve((total + 64) * sizeof(double) * pl.na));
+        if (c->pair_variant >= 3) SPH_TRY(c->fposb.reserve((total + 64) * sizeof(float4)));
         {
             ScopedTimer tm(c, T_PACK);
             for (int j = 0; j < nsrcs; j++) SPH_TRY(pack_array(c, srcs[j], off_of[j], pl, fam, dflags));
