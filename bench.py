@@ -321,7 +321,7 @@ def main():
             },
             'roofline': {
                 'bound': 'hbm', 'kernel': 'k_pair_%s<FamWCSPH,WendlandQuintic>' %
-                ('direct', 'tiled', 'wg', 'agg', 'rows2')[args.variant],
+                {0: 'direct', 2: 'wg', 3: 'agg'}[args.variant],
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                 'algorithmic_bytes_per_particle': algo_pair,

@@ -247,8 +247,9 @@ int sph_integrate_stage(sph_ctx *ctx, int array_id, int stepper, int stage, doub
  * pysph/sph/integrator.py:150-160).                                        */
 int sph_reduce_min(sph_ctx *ctx, int array_id, int prop, double *out);
 
-/* pair-kernel variant: 0 = per-lane cell walk (direct), 1 = LDS-tiled
- * two-phase (default).                                                      */
+/* options: "pair_variant" 3 = aggregated two-phase kernel (default),
+ * 2 = row-by-row LDS record tiles, 0 = per-lane cell walk (cross-checks);
+ * "uniform_h" 0/1 = allow the hmin==hmax specialisation; "ablate" (profiling). */
 int sph_set_option(sph_ctx *ctx, const char *key, long value);
 
 /* ---------------------------------------------------------------------- */

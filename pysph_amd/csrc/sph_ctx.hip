@@ -223,8 +223,11 @@ int sph_array_device_ptr(sph_ctx *c, int id, int prop, void **dptr)
 
 int sph_set_option(sph_ctx *c, const char *key, long value)
 {
-    if (strcmp(key, "pair_variant") == 0) { c->pair_variant = value; return SPH_OK; }
-    if (strcmp(key, "wpe") == 0) { c->wpe = value; return SPH_OK; }
+    if (strcmp(key, "pair_variant") == 0) {
+        if (value != 0 && value != 2 && value != 3) { sph_set_error("pair_variant must be 0 (direct), 2 (row tiles) or 3 (aggregated)"); return SPH_ERR_ARG; }
+        c->pair_variant = value;
+        return SPH_OK;
+    }
     if (strcmp(key, "uniform_h") == 0) { c->use_uniform_h = value; return SPH_OK; }
     if (strcmp(key, "ablate") == 0) { c->ablate = value; return SPH_OK; }
     if (strcmp(key, "invalidate_nnps") == 0) { c->nnps_valid = false; return SPH_OK; }

@@ -8,20 +8,21 @@
 //
 // Design (gfx950, fp64, no MFMA -- an irregular gather, not a contraction):
 //   * every array taking part in a (dest, sources) block is gathered into
-//     cell order as packed records: posh = {x,y,z,h} (32 B) and an
-//     equation-family specific `aux` record -> all pair-loop reads are
+//     cell order as packed records {x,y,z,h | equation-family aux} (+ a compact
+//     fp32 position array for the prefilter) -> all pair-loop reads are
 //     contiguous runs (a row of cells along x is one run);
 //   * one fused kernel per destination does initialize + ALL sources + post_loop
-//     with the sums held in registers and ONE write per output;
-//   * variant 1 (default) is two-phase per 64-particle wavefront: phase 1
-//     streams 64-candidate tiles through LDS and tests all of them against the
-//     wave's destinations in packed fp32 (conservative margin), recording a
-//     64-bit hit mask per lane per tile; phase 2 lets every lane walk its own
-//     hit bits (ctz) so the expensive fp64 pair arithmetic runs at
-//     ~mean/max-neighbour-count lane utilisation instead of the ~15 % hit rate;
-//     the exact fp64 criterion of the reference (r2 < (k h_i)^2 or r2 < (k h_j)^2,
-//     linked_list_nnps.pyx:176-184) decides membership in phase 2;
-//   * variant 0 is the plain per-lane 27-cell walk (kept as cross-check).
+//     with the sums held in registers and ONE write per output, no atomics;
+//   * three schedules of the same arithmetic, selectable for cross-checking:
+//       variant 3 (default) k_pair_agg : aggregated two-phase kernel,
+//       variant 2           k_pair_wg  : row-by-row LDS record tiles,
+//       variant 0           k_pair_direct : plain per-lane 27-cell walk;
+//     (two further schedules were measured and dropped: 64-candidate LDS
+//     tiles per wavefront with per-pair gathers, and LDS-resident opposite
+//     row pairs -- see DESIGN.md section 4);
+//   * the exact fp64 criterion of the reference (r2 < (k h_i)^2 or r2 < (k h_j)^2,
+//     linked_list_nnps.pyx:176-184) decides neighbourhood in every schedule;
+//     the fp32 test in front of it is a conservative superset filter.
 #include "sph_internal.h"
 #include "sph_kernels.h"
 
@@ -724,158 +725,7 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256) void k_p
 }
 
 // ---------------------------------------------------------------------------
-// variant 1: one wavefront = 64 consecutive (cell-ordered) destinations;
-// LDS candidate tiles + fp32 prefilter + per-lane hit bitmasks + fp64 pair phase
-// ---------------------------------------------------------------------------
-#define TILE 64
-#define MAXCH 18
-
-template <class Fam, int KK, bool UH, int WPE> __global__ __launch_bounds__(64, WPE) void k_pair_tiled(PairArgs<Fam> a)
-{
-    __shared__ float4 tile[TILE];
-    __shared__ unsigned long long masks[MAXCH][64];
-    __shared__ uint32_t chbase[MAXCH];
-    __shared__ uint32_t chflags[MAXCH];
-
-    const int lane = threadIdx.x;
-    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * 64 + lane;
-    const bool valid = i < a.nd;
-    const uint32_t ic = valid ? i : a.nd - 1;
-    const uint32_t o = a.d_perm[ic];
-    const bool active = valid && o >= a.d_start && o < a.d_stop;
-    const double4 pi = a.posh[a.d_off + ic];
-    typename Fam::Dest D;
-    Fam::load(D, a.aux + (size_t)(a.d_off + ic) * Fam::NA);
-    const uint32_t key = a.d_keys[ic];
-    const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
-    const int cx = key % ncx;
-    const int row = key / ncx;
-    const double hi_r = a.radius_scale * pi.w;
-    const double hi2 = UH ? a.hr2u : hi_r * hi_r;
-
-    const int row_first = __builtin_amdgcn_readfirstlane(row);
-    const int row_last = __builtin_amdgcn_readlane(row, 63);
-    int nch = 0;
-
-    // ---- phase 2: every lane walks its own hit bits; the next hit's record is
-    // fetched while the current pair is being computed (two register stages)
-    struct Hit {
-        bool has;
-        uint32_t fl;
-        double4 pj;
-        double s[Fam::NA];
-    };
-    int cur_c = 0;
-    unsigned long long cur_m = 0;
-    auto fetch = [&](Hit &h) {
-        while (cur_m == 0 && cur_c + 1 < nch) { ++cur_c; cur_m = masks[cur_c][lane]; }
-        h.has = cur_m != 0;
-        if (h.has) {
-            const int kbit = __builtin_ctzll(cur_m);
-            cur_m &= cur_m - 1;
-            const uint32_t jg = chbase[cur_c] + kbit;
-            h.fl = chflags[cur_c];
-            h.pj = a.posh[jg];
-            load_aux<Fam>(h.s, a.aux + (size_t)jg * Fam::NA);
-        }
-    };
-    auto compute = [&](const Hit &h) {
-        if (h.has) {
-            double hj2 = hi2;
-            if (!UH) { hj2 = a.radius_scale * h.pj.w; hj2 *= hj2; }
-            const double r2 = r2_exact(pi.x - h.pj.x, pi.y - h.pj.y, pi.z - h.pj.z);
-            if (((r2 < hi2) || (r2 < hj2)) && a.ablate != 1)
-                Fam::template pair<KK, UH>(D, pi, h.pj, r2, h.s, h.fl, a);
-        }
-    };
-    auto phase2 = [&]() {
-        if (a.ablate != 2 && nch > 0) {
-            cur_c = 0;
-            cur_m = masks[0][lane];
-            Hit A, B;
-            fetch(A);
-            while (__any(A.has)) {
-                fetch(B);
-                compute(A);
-                if (!__any(B.has)) break;
-                fetch(A);
-                compute(B);
-            }
-        }
-        nch = 0;
-        __syncthreads();
-    };
-
-    for (int R = row_first; R <= row_last; R++) {
-        const bool inseg = active && row == R;
-        const unsigned long long segm = __ballot(inseg);
-        if (segm == 0) continue;
-        const int fl = __builtin_ctzll(segm), ll = 63 - __builtin_clzll(segm);
-        const int cxa = __builtin_amdgcn_readlane(cx, fl), cxb = __builtin_amdgcn_readlane(cx, ll);
-        const int cyR = R % ncy, czR = R / ncy;
-        const int xa = max(cxa - 1, 0), xb = min(cxb + 1, ncx - 1);
-        // local origin of this segment; fp32 coordinates are relative to it
-        const double ox = a.xmin[0] + a.cell_size * xa;
-        const double oy = a.xmin[1] + a.cell_size * (cyR - 1);
-        const double oz = a.xmin[2] + a.cell_size * (czR - 1);
-        // conservative slack for the fp32 test: coordinates up to L from the
-        // origin carry <= 2^-24 L rounding each (see DESIGN.md "prefilter")
-        const double L = a.cell_size * (double)max(xb - xa + 2, 4);
-        const float slack = (float)(L * 1.5e-6);
-        const float fx = (float)(pi.x - ox), fy = (float)(pi.y - oy), fz = (float)(pi.z - oz);
-        const float hif = (float)hi_r * 1.000001f + slack;
-        const float hi2f = hif * hif;
-
-        for (int s = 0; s < a.nsrc; s++) {
-            const SrcDesc sd = a.src[s];
-            for (int dz = -1; dz <= 1; dz++)
-                for (int dy = -1; dy <= 1; dy++) {
-                    const int yy = cyR + dy, zz = czR + dz;
-                    if (yy < 0 || yy >= ncy || zz < 0 || zz >= ncz) continue;
-                    const uint32_t rowb = (uint32_t)(ncx * (yy + ncy * zz));
-                    const uint32_t j0 = sd.cell_start[rowb + xa], j1 = sd.cell_start[rowb + xb + 1];
-                    for (uint32_t jb = j0; jb < j1; jb += TILE) {
-                        const uint32_t j = jb + lane;
-                        float4 tj = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.f);
-                        if (j < j1) {
-                            const double4 pj = a.posh[sd.off + j];
-                            float hjf = (float)(a.radius_scale * pj.w) * 1.000001f + slack;
-                            tj = make_float4((float)(pj.x - ox), (float)(pj.y - oy), (float)(pj.z - oz), hjf * hjf);
-                        }
-                        tile[lane] = tj;
-                        __syncthreads();
-                        unsigned long long m = 0;
-                        if (inseg) {
-                            const int cnt = min((int)(j1 - jb), TILE);
-                            const int cnt8 = (cnt + 7) & ~7;
-                            for (int k0 = 0; k0 < cnt8; k0 += 8) {
-                                unsigned mm = 0;
-#pragma unroll
-                                for (int k = 0; k < 8; k++) {
-                                    const float4 tk = tile[k0 + k];
-                                    const float ex = fx - tk.x, ey = fy - tk.y, ez = fz - tk.z;
-                                    const float r2 = ex * ex + ey * ey + ez * ez;
-                                    const bool hit = UH ? (r2 < hi2f) : ((r2 < hi2f) | (r2 < tk.w));
-                                    mm |= hit ? (1u << k) : 0u;
-                                }
-                                m |= (unsigned long long)mm << k0;
-                            }
-                        }
-                        masks[nch][lane] = m;
-                        if (lane == 0) { chbase[nch] = sd.off + jb; chflags[nch] = sd.flags; }
-                        nch++;
-                        __syncthreads();
-                        if (nch == MAXCH) phase2();
-                    }
-                }
-        }
-    }
-    phase2();
-    if (active) Fam::finish(D, a, o);
-}
-
-// ---------------------------------------------------------------------------
-// variant 2 (default): one workgroup = 256 consecutive (cell-ordered)
+// variant 2: one workgroup = 256 consecutive (cell-ordered)
 // destinations = 4 wavefronts.  For each of the 3x3 neighbouring rows of cells
 // the whole x-range of candidate records the workgroup needs (~290 records of
 // 96 B for WCSPH) is staged ONCE into LDS with coalesced 16-B loads; each
@@ -1229,229 +1079,6 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256, 4) void 
     if (active) Fam::finish(D, a, o);
 }
 
-// ---------------------------------------------------------------------------
-// variant 4: LDS-resident records, OPPOSITE neighbour rows processed together.
-//   Like variant 2 every candidate record a workgroup (256 destinations) needs
-//   is staged once into LDS with coalesced loads, so phase 2 never gathers from
-//   L1/L2.  The lane-utilisation problem of row-by-row processing (a destination
-//   near the low-y face of its cell has many neighbours in row dy=-1 and few in
-//   dy=+1) is removed by keeping the two opposite rows (dy,dz) / (-dy,-dz)
-//   resident at the same time and walking their hit bits in ONE loop: the two
-//   counts are complementary (simulated utilisation 0.65 vs 0.44).  Phase 1 uses
-//   per-lane candidate ranges (own 3 cells) on fp32 SoA tiles like variant 3.
-// ---------------------------------------------------------------------------
-#define PCAP 304
-
-template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256) void k_pair_rows2(PairArgs<Fam> a)
-{
-    constexpr int NR = Fam::NR;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *lrecA = reinterpret_cast<double *>(smem);
-    double *lrecB = lrecA + (size_t)PCAP * NR;
-    float *tx = reinterpret_cast<float *>(lrecB + (size_t)PCAP * NR);
-    float *ty = tx + (PCAP + 8), *tz = ty + (PCAP + 8), *tw = tz + (PCAP + 8);
-    uint32_t *csl = reinterpret_cast<uint32_t *>(tw + (PCAP + 8));
-    int *wx = reinterpret_cast<int *>(csl + 72);
-
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * 256 + t;
-    const bool valid = i < a.nd;
-    const uint32_t ic = valid ? i : a.nd - 1;
-    const uint32_t o = a.d_perm[ic];
-    const bool active = valid && o >= a.d_start && o < a.d_stop;
-    const double *drec = a.rec + (size_t)(a.d_off + ic) * NR;
-    const double4 pi = *reinterpret_cast<const double4 *>(drec);
-    typename Fam::Dest D;
-    Fam::load(D, drec + 4);
-    const uint32_t key = a.d_keys[ic];
-    const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
-    const int cx = key % ncx;
-    const int row = key / ncx;
-    const double hi_r = a.radius_scale * pi.w;
-    const double hi2 = UH ? a.hr2u : hi_r * hi_r;
-
-    if (t == 0) wx[8] = row;
-    if (t == 255) wx[9] = row;
-    __syncthreads();
-    const int row_first = wx[8], row_last = wx[9];
-
-    for (int R = row_first; R <= row_last; R++) {
-        const bool inseg = active && row == R;
-        const unsigned long long segm = __ballot(inseg);
-        int cxa_w = 0x7fffffff, cxb_w = -1;
-        if (segm) {
-            cxa_w = __builtin_amdgcn_readlane(cx, __builtin_ctzll(segm));
-            cxb_w = __builtin_amdgcn_readlane(cx, 63 - __builtin_clzll(segm));
-        }
-        __syncthreads();
-        if (lane == 0) { wx[2 * wv] = cxa_w; wx[2 * wv + 1] = cxb_w; }
-        __syncthreads();
-        const int cxa = min(min(wx[0], wx[2]), min(wx[4], wx[6]));
-        const int cxb = max(max(wx[1], wx[3]), max(wx[5], wx[7]));
-        if (cxb < 0) continue;
-        const int cyR = R % ncy, czR = R / ncy;
-        const int xa = max(cxa - 1, 0), xb = min(cxb + 1, ncx - 1);
-        const int ncs = xb - xa + 2;
-        const float oxf = (float)(a.cell_size * xa);
-        const float oyf = (float)(a.cell_size * (cyR - 1));
-        const float ozf = (float)(a.cell_size * (czR - 1));
-        const double L = fmax(a.cell_size * (double)max(xb - xa + 2, 4), a.dom_extent);
-        const float slack = (float)(L * 1.5e-6);
-        const float4 fpi = a.fpos[a.d_off + ic];
-        const float fxs = fpi.x - oxf, fys = fpi.y - oyf, fzs = fpi.z - ozf;
-        const f2 fx = {fxs, fxs}, fy = {fys, fys}, fz = {fzs, fzs};
-        const float hif = (float)hi_r * 1.000001f + slack;
-        const float hi2f = hif * hif;
-        const int mycl = max(cx - 1, xa) - xa, mych = min(cx + 1, xb) + 1 - xa;
-
-        for (int s = 0; s < a.nsrc; s++) {
-            const SrcDesc sd = a.src[s];
-            // stage one row piece (records -> lrec, fp32 positions -> tx/ty/tz, cell_start slice)
-            // and run phase 1 on it for this lane; returns the hit mask (<= 96 bits) and s0
-            auto stage_and_test = [&](double *lrec, uint32_t rowb, uint32_t tb, int tn, unsigned long long &m0,
-                                      uint32_t &m1, int &s0) {
-                __syncthreads(); // previous users of the fp32 tile / this record buffer are done
-                {
-                    const double2 *g = reinterpret_cast<const double2 *>(a.rec + (size_t)(sd.off + tb) * NR);
-                    double2 *l = reinterpret_cast<double2 *>(lrec);
-                    const int np = tn * (NR / 2);
-                    for (int q = t; q < np; q += 256) l[q] = g[q];
-                }
-                for (int q = t; q < ncs && q < 72; q += 256) csl[q] = sd.cell_start[rowb + xa + q];
-                for (int k = t; k < tn + 8; k += 256) {
-                    float vx = 3.0e18f, vy = 3.0e18f, vz = 3.0e18f, vw = 0.f;
-                    if (k < tn) {
-                        const float4 fj = a.fpos[sd.off + tb + k];
-                        vx = fj.x - oxf; vy = fj.y - oyf; vz = fj.z - ozf;
-                        const float hjf = fj.w * 1.000001f + slack;
-                        vw = hjf * hjf;
-                    }
-                    tx[k] = vx; ty[k] = vy; tz[k] = vz;
-                    if (!UH) tw[k] = vw;
-                }
-                __syncthreads();
-                s0 = 0;
-                int len = 0;
-                if (inseg) {
-                    int lo, hi;
-                    if (ncs <= 72) { lo = (int)(csl[mycl] - tb); hi = (int)(csl[mych] - tb); }
-                    else { lo = (int)(sd.cell_start[rowb + xa + mycl] - tb); hi = (int)(sd.cell_start[rowb + xa + mych] - tb); }
-                    lo = max(lo, 0); hi = min(hi, tn);
-                    s0 = lo & ~1;
-                    len = hi - s0;
-                }
-                const int lenc = min(len, AMAXLEN);
-                m0 = 0; m1 = 0;
-                for (int k0 = 0; __any(k0 < lenc); k0 += 8) {
-                    unsigned mm = 0;
-#pragma unroll
-                    for (int p = 0; p < 4; p++) {
-                        const int idx = min(s0 + k0 + 2 * p, tn + 6);
-                        const f2 X = *reinterpret_cast<const f2 *>(&tx[idx]);
-                        const f2 Y = *reinterpret_cast<const f2 *>(&ty[idx]);
-                        const f2 Z = *reinterpret_cast<const f2 *>(&tz[idx]);
-                        const f2 ex = fx - X, ey = fy - Y, ez = fz - Z;
-                        const f2 r2 = ex * ex + ey * ey + ez * ez;
-                        bool h0, h1;
-                        if (UH) { h0 = r2.x < hi2f; h1 = r2.y < hi2f; }
-                        else {
-                            const f2 W = *reinterpret_cast<const f2 *>(&tw[idx]);
-                            h0 = (r2.x < hi2f) | (r2.x < W.x);
-                            h1 = (r2.y < hi2f) | (r2.y < W.y);
-                        }
-                        h0 &= (k0 + 2 * p) < lenc;
-                        h1 &= (k0 + 2 * p + 1) < lenc;
-                        mm |= (h0 ? (1u << (2 * p)) : 0u) | (h1 ? (2u << (2 * p)) : 0u);
-                    }
-                    if (k0 < 64) m0 |= (unsigned long long)mm << k0;
-                    else m1 |= mm << (k0 - 64);
-                }
-                // rare long ranges: set the remaining candidates' bits unconditionally is not
-                // possible (mask is 96 bits) -> exact tail from the LDS records
-                if (__any(len > AMAXLEN)) {
-                    for (int k = AMAXLEN; k < len; k++) {
-                        const double *rj = lrec + (size_t)(s0 + k) * NR;
-                        const double4 pj = *reinterpret_cast<const double4 *>(rj);
-                        double hj2 = hi2;
-                        if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
-                        const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-                        if ((r2 < hi2) || (r2 < hj2)) {
-                            double sj[Fam::NA];
-#pragma unroll
-                            for (int q = 0; q < Fam::NA; q++) sj[q] = rj[4 + q];
-                            Fam::template pair<KK, UH>(D, pi, pj, r2, sj, sd.flags, a);
-                        }
-                    }
-                }
-            };
-            auto one_hit = [&](const double *lrec, int idx) {
-                const double *rj = lrec + (size_t)idx * NR;
-                const double4 pj = *reinterpret_cast<const double4 *>(rj);
-                double hj2 = hi2;
-                if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
-                const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-                if (((r2 < hi2) || (r2 < hj2)) && a.ablate != 1) {
-                    double sj[Fam::NA];
-#pragma unroll
-                    for (int q = 0; q < Fam::NA; q++) sj[q] = rj[4 + q];
-                    Fam::template pair<KK, UH>(D, pi, pj, r2, sj, sd.flags, a);
-                }
-            };
-            // row groups: centre alone, then the four opposite pairs
-            for (int gidx = 0; gidx < 5; gidx++) {
-                static const int GDY[5] = {0, -1, 0, -1, -1}, GDZ[5] = {0, 0, -1, -1, 1};
-                const int dyA = GDY[gidx], dzA = GDZ[gidx];
-                const int yyA = cyR + dyA, zzA = czR + dzA, yyB = cyR - dyA, zzB = czR - dzA;
-                const bool okA = yyA >= 0 && yyA < ncy && zzA >= 0 && zzA < ncz;
-                const bool okB = gidx > 0 && yyB >= 0 && yyB < ncy && zzB >= 0 && zzB < ncz;
-                const uint32_t rowA = okA ? (uint32_t)(ncx * (yyA + ncy * zzA)) : 0u;
-                const uint32_t rowB = okB ? (uint32_t)(ncx * (yyB + ncy * zzB)) : 0u;
-                uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-                if (okA) { a0 = sd.cell_start[rowA + xa]; a1 = sd.cell_start[rowA + xb + 1]; }
-                if (okB) { b0 = sd.cell_start[rowB + xa]; b1 = sd.cell_start[rowB + xb + 1]; }
-                const uint32_t npa = (a1 - a0 + PCAP - 1) / PCAP, npb = (b1 - b0 + PCAP - 1) / PCAP;
-                const uint32_t npc = max(npa, npb);
-                for (uint32_t pc = 0; pc < npc; pc++) {
-                    unsigned long long mA0 = 0, mB0 = 0;
-                    uint32_t mA1 = 0, mB1 = 0;
-                    int sA = 0, sB = 0;
-                    if (pc < npa) {
-                        const uint32_t tb = a0 + pc * PCAP;
-                        stage_and_test(lrecA, rowA, tb, (int)min((uint32_t)PCAP, a1 - tb), mA0, mA1, sA);
-                    }
-                    if (pc < npb) {
-                        const uint32_t tb = b0 + pc * PCAP;
-                        stage_and_test(lrecB, rowB, tb, (int)min((uint32_t)PCAP, b1 - tb), mB0, mB1, sB);
-                    }
-                    if (a.ablate == 2) continue;
-                    // ---- phase 2: both rows' hits in one loop, records from LDS
-                    for (;;) {
-                        const bool hasA = (mA0 | mA1) != 0, hasB = (mB0 | mB1) != 0;
-                        if (!__any(hasA || hasB)) break;
-                        if (hasA) {
-                            int bit;
-                            if (mA0) { bit = __builtin_ctzll(mA0); mA0 &= mA0 - 1; }
-                            else { bit = 64 + __builtin_ctz(mA1); mA1 &= mA1 - 1; }
-                            one_hit(lrecA, sA + bit);
-                        } else if (hasB) {
-                            int bit;
-                            if (mB0) { bit = __builtin_ctzll(mB0); mB0 &= mB0 - 1; }
-                            else { bit = 64 + __builtin_ctz(mB1); mB1 &= mB1 - 1; }
-                            one_hit(lrecB, sB + bit);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (active) Fam::finish(D, a, o);
-}
-
-template <class Fam> static size_t rows2_lds_bytes()
-{
-    return (size_t)2 * PCAP * Fam::NR * 8 + (size_t)4 * (PCAP + 8) * 4 + 72 * 4 + 64;
-}
-
 template <class Fam> static size_t wg_lds_bytes() { return (size_t)TCAP * Fam::NR * 8 + (size_t)(TCAP + 8) * 16 + 64; }
 
 // ---------------------------------------------------------------------------
@@ -1642,30 +1269,7 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
 template <class Fam> static void launch_pair(sph_ctx *c, int kk, const PairArgs<Fam> &a)
 {
     if (a.nd == 0) return;
-    const bool tiled = c->pair_variant != 0;
     const bool uh = c->uniform_h && c->use_uniform_h;
-    if (c->pair_variant == 4) {
-        dim3 g2(div_up(a.nd, 256)), b2(256);
-        size_t lds = rows2_lds_bytes<Fam>();
-#define LAUNCH4(K)                                                                                  \
-        if (uh) {                                                                                   \
-            (void)hipFuncSetAttribute((const void *)k_pair_rows2<Fam, K, true>,                     \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-            hipLaunchKernelGGL((k_pair_rows2<Fam, K, true>), g2, b2, lds, c->stream, a);            \
-        } else {                                                                                    \
-            (void)hipFuncSetAttribute((const void *)k_pair_rows2<Fam, K, false>,                    \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-            hipLaunchKernelGGL((k_pair_rows2<Fam, K, false>), g2, b2, lds, c->stream, a);           \
-        }
-        switch (kk) {
-        case 1: LAUNCH4(1); break;
-        case 2: LAUNCH4(2); break;
-        case 3: LAUNCH4(3); break;
-        case 4: LAUNCH4(4); break;
-        }
-#undef LAUNCH4
-        return;
-    }
     if (c->pair_variant == 3) {
         dim3 g2(div_up(a.nd, 256)), b2(256);
 #define LAUNCH3(K)                                                                           \
@@ -1695,13 +1299,9 @@ template <class Fam> static void launch_pair(sph_ctx *c, int kk, const PairArgs<
 #undef LAUNCH2
         return;
     }
-    dim3 gt(div_up(a.nd, 64)), bt(64), gd(div_up(a.nd, 256)), bd(256);
+    dim3 gd(div_up(a.nd, 256)), bd(256);
 #define LAUNCH(K)                                                                                \
-    if (tiled && uh && c->wpe == 4) hipLaunchKernelGGL((k_pair_tiled<Fam, K, true, 4>), gt, bt, 0, c->stream, a);   \
-    else if (tiled && uh && c->wpe == 3) hipLaunchKernelGGL((k_pair_tiled<Fam, K, true, 3>), gt, bt, 0, c->stream, a);   \
-    else if (tiled && uh) hipLaunchKernelGGL((k_pair_tiled<Fam, K, true, 2>), gt, bt, 0, c->stream, a);   \
-    else if (tiled) hipLaunchKernelGGL((k_pair_tiled<Fam, K, false, 2>), gt, bt, 0, c->stream, a);   \
-    else if (uh) hipLaunchKernelGGL((k_pair_direct<Fam, K, true>), gd, bd, 0, c->stream, a);      \
+    if (uh) hipLaunchKernelGGL((k_pair_direct<Fam, K, true>), gd, bd, 0, c->stream, a);      \
     else hipLaunchKernelGGL((k_pair_direct<Fam, K, false>), gd, bd, 0, c->stream, a)
     switch (kk) {
     case 1: LAUNCH(1); break;

@@ -91,7 +91,6 @@ struct sph_ctx {
     long pair_variant = 3;
     long ablate = 0;
     long use_uniform_h = 1;
-    long wpe = 2;
     long block_sorted_outputs = 0;
 
     // timers

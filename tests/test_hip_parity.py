@@ -32,7 +32,7 @@ def make_eval(arrays, eqs, kernel, dim, variant=3, sync='auto'):
     return a_eval, nnps, ctx
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4])
+@pytest.mark.parametrize('variant', [0, 2, 3])
 @pytest.mark.parametrize('case', CASES)
 def test_golden_parity(case, variant):
     g = load_golden(case + '.npz')
@@ -104,7 +104,7 @@ def _copy_arrays(arrays):
     return out
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4])
+@pytest.mark.parametrize('variant', [0, 2, 3])
 def test_dam_break_27k_vs_oracle(oracle, variant):
     """BASELINE config 1: dam_break_3d, dx=0.04 (9360+15152+160 particles)."""
     from pysph_amd.examples import dam_break_3d as db
@@ -159,9 +159,8 @@ def cube_equations(dx, hdx=1.3):
     return s.get_equations()
 
 
-@pytest.mark.parametrize('variant,varh', [(0, 0.0), (1, 0.0), (1, 0.2),
-                                          (2, 0.0), (2, 0.2), (3, 0.0), (3, 0.2),
-                                          (4, 0.0), (4, 0.2)])
+@pytest.mark.parametrize('variant,varh', [(0, 0.0), (2, 0.0), (2, 0.2),
+                                          (3, 0.0), (3, 0.2)])
 def test_cube_100k_vs_oracle(oracle, variant, varh):
     from pysph_amd import kernels as K
     pa, dx = make_cube(46, varh=varh)
@@ -194,16 +193,16 @@ def test_full_size_1m_properties():
     eqs = cube_equations(dx)
     kernel = K.WendlandQuintic(dim=3)
     res = {}
-    for variant in (0, 1, 2, 3):
+    for variant in (0, 2, 3):
         q = _copy_arrays([pa])
         a_eval, nnps, ctx = make_eval(q, eqs, kernel, 3, variant)
         a_eval.compute(0.0, 1e-5)
         res[variant] = q[0]
         ctx.close()
     for prop in WC_OUT:
-        a, b, c, d = (res[v].properties[prop] for v in (0, 1, 2, 3))
+        a, c, d = (res[v].properties[prop] for v in (0, 2, 3))
         assert np.all(np.isfinite(d))
-        for other in (a, b, c):
+        for other in (a, c):
             assert rel_err(other, d) < 1e-12, prop
 
 
@@ -306,7 +305,7 @@ def test_edge_cases_empty_single_and_2d(oracle):
     ref = _copy_arrays([pa])
     eqs = [Group(equations=[SummationDensity(dest='fluid', sources=['fluid'])])]
     kernel = K.WendlandQuintic(dim=2)
-    for variant in (0, 1, 2, 3, 4):
+    for variant in (0, 2, 3):
         q = _copy_arrays([pa])
         a_eval, nnps, ctx = make_eval(q, eqs, kernel, 2, variant)
         a_eval.compute(0.0, 0.1)
