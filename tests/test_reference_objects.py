@@ -1,0 +1,106 @@
+"""Drop-in check on the CPU: the backend consumes the REFERENCE's own objects.
+
+Runs only where /root/reference exists (build container).  The reference's
+``WCSPHScheme`` / ``TVFScheme`` / kernel classes are imported under the stub
+``compyle`` (oracle/_stubs) and their equation groups are marshalled by the
+same code path ``HipAccelerationEval`` uses (``_CGroup``): the resulting C-ABI
+structs must equal those marshalled from this package's specification classes.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+REF = '/root/reference'
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF),
+                                reason='reference tree not present')
+
+
+def _ref_imports():
+    for p in (REF, os.path.join(REPO, 'oracle', '_stubs')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _marshal(groups, arrays):
+    from pysph_amd.acceleration_eval import _CGroup
+    ids = dict((pa.name, i) for i, pa in enumerate(arrays))
+    amap = dict((pa.name, pa) for pa in arrays)
+    out = []
+    for g in groups:
+        cg = _CGroup(g, ids, amap)
+        cg.refresh_range()
+        eqs = []
+        for i in range(cg.cg.neq):
+            e = cg.ceqs[i]
+            eqs.append((e.kind, e.dest, e.nsrc, list(e.src)[:e.nsrc],
+                        [e.par[k] for k in range(16)]))
+        out.append((cg.cg.real, cg.cg.start_idx, cg.cg.stop_idx, eqs))
+    return out
+
+
+def test_reference_wcsph_scheme_marshals_identically():
+    _ref_imports()
+    from pysph.sph.scheme import WCSPHScheme as RefScheme
+    from pysph.base.kernels import WendlandQuintic as RefKernel
+    from pysph_amd.scheme import WCSPHScheme
+    from pysph_amd.kernels import WendlandQuintic, kernel_id
+    from pysph_amd.examples import dam_break_3d as db
+    arrays = db.create_particles(0.2)
+    kw = dict(dim=3, rho0=db.ro, c0=db.c0, h0=0.26, hdx=1.3, gz=-9.81,
+              alpha=db.alpha, beta=db.beta, gamma=db.gamma, hg_correction=True,
+              tensile_correction=False)
+    ref = RefScheme(['fluid'], ['boundary', 'obstacle'], **kw).get_equations()
+    mine = WCSPHScheme(['fluid'], ['boundary', 'obstacle'], **kw).get_equations()
+    assert _marshal(ref, arrays) == _marshal(mine, arrays)
+    rk, mk = RefKernel(dim=3), WendlandQuintic(dim=3)
+    assert kernel_id(rk) == kernel_id(mk)
+    assert (rk.fac, rk.radius_scale, rk.get_deltap(), rk.dim) == \
+        (mk.fac, mk.radius_scale, mk.get_deltap(), mk.dim)
+
+
+def test_reference_tvf_scheme_marshals_identically():
+    _ref_imports()
+    from pysph.sph.scheme import TVFScheme as RefScheme
+    from pysph_amd.scheme import TVFScheme
+    from pysph_amd.particle_array import get_particle_array_tvf_fluid
+    pa = get_particle_array_tvf_fluid(name='fluid', x=np.zeros(4))
+    kw = dict(dim=3, rho0=1.0, c0=10.0, nu=0.01, p0=100.0, pb=100.0, h0=0.1,
+              gx=0.1, alpha=0.2)
+    ref = RefScheme(['fluid'], [], **kw).get_equations()
+    mine = TVFScheme(['fluid'], [], **kw).get_equations()
+    assert _marshal(ref, [pa]) == _marshal(mine, [pa])
+
+
+def test_reference_accelerationeval_is_accepted():
+    """A real pysph AccelerationEval (equation_groups, kernel, particle_arrays)
+    is what HipAccelerationEval reads; its MegaGroup order equals ours."""
+    _ref_imports()
+    from pysph.sph.acceleration_eval import AccelerationEval as RefAE
+    from pysph.sph.scheme import WCSPHScheme as RefScheme
+    from pysph.base.kernels import WendlandQuintic as RefKernel
+    from pysph_amd.acceleration_eval import AccelerationEval
+    from pysph_amd.scheme import WCSPHScheme
+    from pysph_amd.kernels import WendlandQuintic
+    from pysph_amd.examples import dam_break_3d as db
+    arrays = db.create_particles(0.2)
+    kw = dict(dim=3, rho0=db.ro, c0=db.c0, h0=0.26, hdx=1.3, gz=-9.81,
+              alpha=db.alpha, beta=db.beta, gamma=db.gamma, hg_correction=True)
+    ref = RefAE(arrays, RefScheme(['fluid'], ['boundary', 'obstacle'], **kw)
+                .get_equations(), RefKernel(dim=3))
+    mine = AccelerationEval(arrays, WCSPHScheme(['fluid'], ['boundary', 'obstacle'],
+                                                **kw).get_equations(),
+                            WendlandQuintic(dim=3))
+    for rg, mg in zip(ref.mega_groups, mine.mega_groups):
+        assert list(rg.data.keys()) == list(mg.data.keys())
+        for dest in rg.data:
+            r_no, r_src, r_all = rg.data[dest]
+            m_no, m_src, m_all = mg.data[dest]
+            assert [e.name for e in r_no.equations] == [e.name for e in m_no]
+            assert list(r_src.keys()) == list(m_src.keys())
+            assert [e.name for e in r_all.equations] == [e.name for e in m_all]
+    assert _marshal(ref.equation_groups, arrays) == \
+        _marshal(mine.equation_groups, arrays)
