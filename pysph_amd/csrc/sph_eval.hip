@@ -204,6 +204,7 @@ struct PackArgs {
     double *aux;
     double *rec;                  // non-null: interleaved records [x y z h aux... pad], nr doubles each
     int nr;
+    int split_wcsph;              // 1: record layout [x y z cs | u v w m | rho tmpj | h p] (aggregated kernel)
     float4 *fpos;                 // non-null: fp32 {x-xmin, y-ymin, z-zmin, radius_scale*h} for the prefilter tiles
     double gmin[3];
     double radius_scale;
@@ -233,6 +234,12 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
     if (a.rec) {
         // 32-B stores: every store covers whole sectors of the record
         double4 *r = reinterpret_cast<double4 *>(a.rec + (a.off + i) * (size_t)a.nr);
+        if (a.split_wcsph) {
+            r[0] = make_double4(ph.x, ph.y, ph.z, v[6]);
+            r[1] = make_double4(v[0], v[1], v[2], v[3]);
+            r[2] = make_double4(v[4], v[5], ph.w, v[7]);
+            return;
+        }
         r[0] = ph;
         const int n4 = (a.nr - 4) / 4;
 #pragma unroll
@@ -347,6 +354,15 @@ template <int KK> __device__ __forceinline__ double pair_gradfac(const PairGeom 
     return g.rij > 1e-12 ? t : 0.0;
 }
 
+// Record access for the aggregated kernel.  Default layout: [x y z h | aux...].
+template <class Fam, bool UH>
+__device__ __forceinline__ void load_record(const double *__restrict__ rj, uint32_t fl, double4 &pj, double (&s)[Fam::NA])
+{
+    pj = *reinterpret_cast<const double4 *>(rj);
+#pragma unroll
+    for (int k = 0; k < Fam::NA; k++) s[k] = rj[4 + k];
+}
+
 // ---- WCSPH: Continuity + Momentum + XSPH (wc/basic.py, basic_equations.py) --
 struct FamWCSPH {
     static constexpr int NA = 8; // u v w m rho tmpj(=p/rho^2) cs p
@@ -439,6 +455,26 @@ struct FamWCSPH {
         }
     }
 };
+
+// WCSPH records of the aggregated kernel use the layout
+//   [x y z cs | u v w m | rho tmpj | h p]
+// so that the common case (uniform h, no tensile correction) gathers 80 B =
+// five 16-B pieces per pair and never touches the last piece.
+template <bool UH>
+__device__ __forceinline__ void load_record_wcsph(const double *__restrict__ rj, uint32_t fl, double4 &pj, double (&s)[8])
+{
+    const double4 a = *reinterpret_cast<const double4 *>(rj);
+    const double4 b = *reinterpret_cast<const double4 *>(rj + 4);
+    const double2 c = *reinterpret_cast<const double2 *>(rj + 8);
+    pj.x = a.x; pj.y = a.y; pj.z = a.z; pj.w = 0.0;
+    s[0] = b.x; s[1] = b.y; s[2] = b.z; s[3] = b.w; s[4] = c.x; s[5] = c.y; s[6] = a.w; s[7] = 0.0;
+    if (!UH || (fl & F_TENSILE)) {
+        const double2 d = *reinterpret_cast<const double2 *>(rj + 10);
+        pj.w = d.x; s[7] = d.y;
+    }
+}
+template <> __device__ __forceinline__ void load_record<FamWCSPH, true>(const double *__restrict__ rj, uint32_t fl, double4 &pj, double (&s)[8]) { load_record_wcsph<true>(rj, fl, pj, s); }
+template <> __device__ __forceinline__ void load_record<FamWCSPH, false>(const double *__restrict__ rj, uint32_t fl, double4 &pj, double (&s)[8]) { load_record_wcsph<false>(rj, fl, pj, s); }
 
 // ---- density summations (basic_equations.py:19-29, transport_velocity.py:24-58)
 struct FamDensity {
@@ -913,10 +949,14 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256, 4) void 
     const uint32_t ic = valid ? i : a.nd - 1;
     const uint32_t o = a.d_perm[ic];
     const bool active = valid && o >= a.d_start && o < a.d_stop;
-    const double *drec = a.rec + (size_t)(a.d_off + ic) * NR;
-    const double4 pi = *reinterpret_cast<const double4 *>(drec);
+    double4 pi;
     typename Fam::Dest D;
-    Fam::load(D, drec + 4);
+    {
+        double sd_[Fam::NA];
+        // a destination needs its own h and p: ask for the full record
+        load_record<Fam, false>(a.rec + (size_t)(a.d_off + ic) * NR, 0xffffffffu, pi, sd_);
+        Fam::load(D, sd_);
+    }
     const uint32_t key = a.d_keys[ic];
     const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
     const int cx = key % ncx;
@@ -931,11 +971,9 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256, 4) void 
 
     // exact criterion + pair arithmetic for one candidate record
     auto do_pair = [&](uint32_t jg, uint32_t flags) {
-        const double *rj = a.rec + (size_t)jg * NR;
-        const double4 pj = *reinterpret_cast<const double4 *>(rj);
+        double4 pj;
         double sj[Fam::NA];
-#pragma unroll
-        for (int k = 0; k < Fam::NA; k++) sj[k] = rj[4 + k];
+        load_record<Fam, UH>(a.rec + (size_t)jg * NR, flags, pj, sj);
         double hj2 = hi2;
         if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
         const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
@@ -1262,6 +1300,7 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
     pa.radius_scale = c->radius_scale;
     if (c->pair_variant >= 2) pa.rec = c->posh.as<double>();
     if (c->pair_variant >= 3) pa.fpos = c->fposb.as<float4>();
+    pa.split_wcsph = (c->pair_variant == 3 && fam == FAM_WCSPH) ? 1 : 0;
     hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, pa);
     return SPH_OK;
 }
