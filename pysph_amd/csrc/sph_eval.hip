@@ -35,7 +35,9 @@
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double r2_exact(double dx, double dy, double dz)
 {
-    return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+#pragma clang fp contract(off)
+    const double a = dx * dx, b = dy * dy, c = dz * dz;
+    return (a + b) + c;
 }
 
 // ---------------------------------------------------------------------------
@@ -934,8 +936,11 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256, 4) void k_pair_agg(PairArgs<Fam> a)
 {
     constexpr int NR = Fam::NR;
-    __shared__ __attribute__((aligned(16))) float tx[ACAP + 8], ty[ACAP + 8], tz[ACAP + 8];
-    __shared__ __attribute__((aligned(16))) float tw[UH ? 8 : ACAP + 8];
+    // fp32 tile: x | y | z | (w) planes of TS floats each; reads past a plane's
+    // valid part land in the next plane / the mask area and are masked out
+    constexpr int TS = ACAP + 8;
+    __shared__ __attribute__((aligned(16))) float tile[(UH ? 3 : 4) * TS];
+    float *const tx = tile, *const ty = tile + TS, *const tz = tile + 2 * TS, *const tw = tile + (UH ? 0 : 3 * TS);
     __shared__ uint32_t csl[72];
     __shared__ unsigned long long mlo[AQ][256];
     __shared__ uint32_t mhi[AQ][256];
@@ -1073,25 +1078,26 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256, 4) void 
                         uint32_t m1 = 0;
                         for (int k0 = 0; __any(k0 < lenc); k0 += 8) {
                             unsigned mm = 0;
+                            const float *tb0 = tile + (s0 + k0); // one address, constant offsets below
 #pragma unroll
                             for (int p = 0; p < 4; p++) {
-                                const int idx = min(s0 + k0 + 2 * p, tn + 6); // stays inside the padded tile
-                                const f2 X = *reinterpret_cast<const f2 *>(&tx[idx]);
-                                const f2 Y = *reinterpret_cast<const f2 *>(&ty[idx]);
-                                const f2 Z = *reinterpret_cast<const f2 *>(&tz[idx]);
+                                const f2 X = *reinterpret_cast<const f2 *>(tb0 + 2 * p);
+                                const f2 Y = *reinterpret_cast<const f2 *>(tb0 + TS + 2 * p);
+                                const f2 Z = *reinterpret_cast<const f2 *>(tb0 + 2 * TS + 2 * p);
                                 const f2 ex = fx - X, ey = fy - Y, ez = fz - Z;
                                 const f2 r2 = ex * ex + ey * ey + ez * ez;
                                 bool h0, h1;
                                 if (UH) { h0 = r2.x < hi2f; h1 = r2.y < hi2f; }
                                 else {
-                                    const f2 W = *reinterpret_cast<const f2 *>(&tw[idx]);
+                                    const f2 W = *reinterpret_cast<const f2 *>(tb0 + 3 * TS + 2 * p);
                                     h0 = (r2.x < hi2f) | (r2.x < W.x);
                                     h1 = (r2.y < hi2f) | (r2.y < W.y);
                                 }
-                                h0 &= (k0 + 2 * p) < lenc;
-                                h1 &= (k0 + 2 * p + 1) < lenc;
                                 mm |= (h0 ? (1u << (2 * p)) : 0u) | (h1 ? (2u << (2 * p)) : 0u);
                             }
+                            // candidates beyond this lane's range (its own tail / other lanes' longer ranges)
+                            const int rem = lenc - k0;
+                            mm = rem >= 8 ? mm : (rem > 0 ? (mm & ((1u << rem) - 1u)) : 0u);
                             if (k0 < 64) m0 |= (unsigned long long)mm << k0;
                             else m1 |= mm << (k0 - 64);
                         }
