@@ -237,9 +237,12 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
         // 32-B stores: every store covers whole sectors of the record
         double4 *r = reinterpret_cast<double4 *>(a.rec + (a.off + i) * (size_t)a.nr);
         if (a.split_wcsph) {
-            r[0] = make_double4(ph.x, ph.y, ph.z, v[6]);
-            r[1] = make_double4(v[0], v[1], v[2], v[3]);
-            r[2] = make_double4(v[4], v[5], ph.w, v[7]);
+            // 16-B stores: compact records (nr == 10) are only 16-B aligned
+            double2 *r2 = reinterpret_cast<double2 *>(r);
+            r2[0] = make_double2(ph.x, ph.y); r2[1] = make_double2(ph.z, v[6]);
+            r2[2] = make_double2(v[0], v[1]); r2[3] = make_double2(v[2], v[3]);
+            r2[4] = make_double2(v[4], v[5]);
+            if (a.nr > 10) r2[5] = make_double2(ph.w, v[7]);
             return;
         }
         r[0] = ph;
@@ -271,6 +274,7 @@ template <class Fam> struct PairArgs {
     const double4 *posh;
     const double *aux;
     const double *rec; // variant 2: interleaved records, Fam::NR doubles each
+    int nrec;          // variant 3: doubles per record (Fam::NR, or 10 for compact WCSPH records)
     const float4 *fpos; // variant 3: fp32 grid-relative positions + radius_scale*h (prefilter only)
     double dom_extent;  // largest grid extent: bounds the fp32 rounding of fpos
     uint32_t d_off, nd;
@@ -465,11 +469,10 @@ struct FamWCSPH {
 template <bool UH>
 __device__ __forceinline__ void load_record_wcsph(const double *__restrict__ rj, uint32_t fl, double4 &pj, double (&s)[8])
 {
-    const double4 a = *reinterpret_cast<const double4 *>(rj);
-    const double4 b = *reinterpret_cast<const double4 *>(rj + 4);
-    const double2 c = *reinterpret_cast<const double2 *>(rj + 8);
-    pj.x = a.x; pj.y = a.y; pj.z = a.z; pj.w = 0.0;
-    s[0] = b.x; s[1] = b.y; s[2] = b.z; s[3] = b.w; s[4] = c.x; s[5] = c.y; s[6] = a.w; s[7] = 0.0;
+    const double2 *r2 = reinterpret_cast<const double2 *>(rj);
+    const double2 a0 = r2[0], a1 = r2[1], b0 = r2[2], b1 = r2[3], c = r2[4];
+    pj.x = a0.x; pj.y = a0.y; pj.z = a1.x; pj.w = 0.0;
+    s[0] = b0.x; s[1] = b0.y; s[2] = b1.x; s[3] = b1.y; s[4] = c.x; s[5] = c.y; s[6] = a1.y; s[7] = 0.0;
     if (!UH || (fl & F_TENSILE)) {
         const double2 d = *reinterpret_cast<const double2 *>(rj + 10);
         pj.w = d.x; s[7] = d.y;
@@ -935,7 +938,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256, 4) void k_pair_agg(PairArgs<Fam> a)
 {
-    constexpr int NR = Fam::NR;
+    const int NR = a.nrec;
     // fp32 tile: x | y | z | (w) planes of TS floats each; reads past a plane's
     // valid part land in the next plane / the mask area and are masked out
     constexpr int TS = ACAP + 8;
@@ -958,8 +961,10 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256, 4) void 
     typename Fam::Dest D;
     {
         double sd_[Fam::NA];
-        // a destination needs its own h and p: ask for the full record
-        load_record<Fam, false>(a.rec + (size_t)(a.d_off + ic) * NR, 0xffffffffu, pi, sd_);
+        // the destination's own h / p come with the same rules as a source's
+        // (uniform h: the constant; p only for the tensile correction)
+        load_record<Fam, UH>(a.rec + (size_t)(a.d_off + ic) * NR, a.dflags, pi, sd_);
+        if (UH) pi.w = a.hu;
         Fam::load(D, sd_);
     }
     const uint32_t key = a.d_keys[ic];
@@ -1363,6 +1368,7 @@ static void fill_common(sph_ctx *c, PairArgs<Fam> &a, const sph_kernel *K, doubl
     a.posh = c->posh.as<double4>();
     a.aux = c->aux.as<double>();
     a.rec = c->posh.as<double>();
+    a.nrec = c->cur_nrec;
     a.fpos = c->fposb.as<float4>();
     a.dom_extent = fmax(fmax(c->xmax[0] - c->xmin[0], c->xmax[1] - c->xmin[1]), c->xmax[2] - c->xmin[2]);
     for (int k = 0; k < 3; k++) { a.nc[k] = c->nc[k]; a.xmin[k] = c->xmin[k]; }
@@ -1481,6 +1487,9 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         else for (int j = 0; j < nsrcs; j++) if (srcs[j] == dst) d_off = off_of[j];
         if (total >= (1ull << 32)) { sph_set_error("too many particles for 32-bit packed indices"); return SPH_ERR_ARG; }
         PackPlan pl = pack_plan(fam);
+        // compact 80-B WCSPH records when neither h nor p of a neighbour is read
+        if (c->pair_variant == 3 && fam == FAM_WCSPH && c->uniform_h && c->use_uniform_h && !(dflags & F_TENSILE)) pl.nr = 10;
+        c->cur_nrec = pl.nr;
         SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * (c->pair_variant >= 2 ? pl.nr : 4)));
         SPH_TRY(c->aux.reserve((total + 64) * sizeof(double) * pl.na));
         if (c->pair_variant >= 3) SPH_TRY(c->fposb.reserve((total + 64) * sizeof(float4)));

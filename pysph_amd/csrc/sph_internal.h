@@ -91,6 +91,7 @@ struct sph_ctx {
     long pair_variant = 3;
     long ablate = 0;
     long use_uniform_h = 1;
+    int cur_nrec = 0;       // doubles per packed record of the pair launch being set up
     long block_sorted_outputs = 0;
 
     // timers
