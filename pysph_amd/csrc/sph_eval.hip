@@ -1079,33 +1079,43 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256, 4) void 
                             len = hi - s0;
                         }
                         const int lenc = min(len, AMAXLEN);
-                        unsigned long long m0 = 0;
-                        uint32_t m1 = 0;
-                        for (int k0 = 0; __any(k0 < lenc); k0 += 8) {
-                            unsigned mm = 0;
-                            const float *tb0 = tile + (s0 + k0); // one address, constant offsets below
+                        // One sign bit per candidate: d = |x_i - x_j|^2 - thr^2 in packed fp32 FMAs,
+                        // shifted into a 32-bit word with v_alignbit (1 VALU per candidate).
+                        uint32_t wd[3] = {0u, 0u, 0u};
 #pragma unroll
-                            for (int p = 0; p < 4; p++) {
-                                const f2 X = *reinterpret_cast<const f2 *>(tb0 + 2 * p);
-                                const f2 Y = *reinterpret_cast<const f2 *>(tb0 + TS + 2 * p);
-                                const f2 Z = *reinterpret_cast<const f2 *>(tb0 + 2 * TS + 2 * p);
-                                const f2 ex = fx - X, ey = fy - Y, ez = fz - Z;
-                                const f2 r2 = ex * ex + ey * ey + ez * ez;
-                                bool h0, h1;
-                                if (UH) { h0 = r2.x < hi2f; h1 = r2.y < hi2f; }
-                                else {
-                                    const f2 W = *reinterpret_cast<const f2 *>(tb0 + 3 * TS + 2 * p);
-                                    h0 = (r2.x < hi2f) | (r2.x < W.x);
-                                    h1 = (r2.y < hi2f) | (r2.y < W.y);
+                        for (int gw = 0; gw < 3; gw++) {
+                            if (!__any(32 * gw < lenc)) break; // wave-uniform
+                            uint32_t mm = 0;
+                            int g8 = 0;
+                            for (; g8 < 4 && __any(32 * gw + 8 * g8 < lenc); g8++) {
+                                const float *tb0 = tile + (s0 + 32 * gw + 8 * g8); // one address, constant offsets below
+#pragma unroll
+                                for (int p = 0; p < 4; p++) {
+                                    const f2 X = *reinterpret_cast<const f2 *>(tb0 + 2 * p);
+                                    const f2 Y = *reinterpret_cast<const f2 *>(tb0 + TS + 2 * p);
+                                    const f2 Z = *reinterpret_cast<const f2 *>(tb0 + 2 * TS + 2 * p);
+                                    const f2 ex = fx - X, ey = fy - Y, ez = fz - Z;
+                                    f2 nthr = {-hi2f, -hi2f};
+                                    if (!UH) {
+                                        const f2 W = *reinterpret_cast<const f2 *>(tb0 + 3 * TS + 2 * p);
+                                        nthr.x = -fmaxf(hi2f, W.x); // r2 < hi^2 or r2 < hj^2
+                                        nthr.y = -fmaxf(hi2f, W.y);
+                                    }
+                                    f2 d = __builtin_elementwise_fma(ex, ex, nthr);
+                                    d = __builtin_elementwise_fma(ey, ey, d);
+                                    d = __builtin_elementwise_fma(ez, ez, d);
+                                    mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.x), 31);
+                                    mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.y), 31);
                                 }
-                                mm |= (h0 ? (1u << (2 * p)) : 0u) | (h1 ? (2u << (2 * p)) : 0u);
                             }
+                            if (g8 < 4) mm <<= 8 * (4 - g8);
+                            mm = __builtin_bitreverse32(mm); // bit b <-> candidate 32*gw + b
                             // candidates beyond this lane's range (its own tail / other lanes' longer ranges)
-                            const int rem = lenc - k0;
-                            mm = rem >= 8 ? mm : (rem > 0 ? (mm & ((1u << rem) - 1u)) : 0u);
-                            if (k0 < 64) m0 |= (unsigned long long)mm << k0;
-                            else m1 |= mm << (k0 - 64);
+                            const int rem = lenc - 32 * gw;
+                            wd[gw] = rem >= 32 ? mm : (rem > 0 ? (mm & ((1u << rem) - 1u)) : 0u);
                         }
+                        const unsigned long long m0 = (unsigned long long)wd[0] | ((unsigned long long)wd[1] << 32);
+                        const uint32_t m1 = wd[2];
                         mlo[nq][t] = m0;
                         mhi[nq][t] = m1;
                         mofs[nq][t] = (unsigned short)s0;
