@@ -308,9 +308,13 @@ __device__ __forceinline__ double fast_rcp(double d)
     x = fma(x, e, x);
     return x;
 }
-// s = sqrt(a), rs = 1/sqrt(a); a == 0 -> s = rs = 0
+// s = sqrt(a), rs = 1/sqrt(a).  a is clamped to 1e-300 so that coincident
+// particles (a == 0: the self pair) give finite s ~ 1e-150, rs ~ 1e150; every
+// use of rs multiplies it with a factor that is exactly 0 for such pairs
+// (XIJ, or h*VIJ.XIJ), and the gradient has the reference's own r > 1e-12 guard.
 __device__ __forceinline__ void fast_sqrt_rsqrt(double a, double &s, double &rs)
 {
+    a = fmax(a, 1e-300);
     double y = __builtin_amdgcn_rsq(a);
     double g = a * y, h = 0.5 * y;
     double r = fma(-h, g, 0.5);
@@ -319,9 +323,8 @@ __device__ __forceinline__ void fast_sqrt_rsqrt(double a, double &s, double &rs)
     r = fma(-h, g, 0.5);
     g = fma(g, r, g);
     h = fma(h, r, h);
-    bool ok = a > 1e-290;
-    s = ok ? g : 0.0;
-    rs = ok ? h + h : 0.0;
+    s = g;
+    rs = h + h;
 }
 
 // per-pair geometry shared by all families
@@ -348,15 +351,15 @@ __device__ __forceinline__ void pair_geom(PairGeom &g, const double4 &pi, const 
     }
     g.q = g.rij * g.h1;
 }
-template <int KK> __device__ __forceinline__ double pair_w(const PairGeom &g) { return SphKernel<KK>::w(g.q) * g.fac; }
+template <int KK, bool UH> __device__ __forceinline__ double pair_w(const PairGeom &g) { return SphKernel<KK>::template w<UH>(g.q) * g.fac; }
 // GRADIENT(XIJ, RIJ, HIJ, DWIJ) (kernels.py:126-137) returns tmp*xij with
 // tmp = dwdq*h1/rij; here tmp only.  dw(q)/rij = dwq(q)*h1 when the kernel has
 // a closed form for dw/q.
-template <int KK> __device__ __forceinline__ double pair_gradfac(const PairGeom &g)
+template <int KK, bool UH> __device__ __forceinline__ double pair_gradfac(const PairGeom &g)
 {
     double t;
-    if (SphKernel<KK>::HAS_DWQ) t = SphKernel<KK>::dwq(g.q) * (g.fac * g.h1 * g.h1);
-    else t = SphKernel<KK>::dw(g.q) * (g.fac * g.h1) * g.rinv;
+    if (SphKernel<KK>::HAS_DWQ) t = SphKernel<KK>::template dwq<UH>(g.q) * (g.fac * g.h1 * g.h1);
+    else t = SphKernel<KK>::template dw<UH>(g.q) * (g.fac * g.h1) * g.rinv;
     return g.rij > 1e-12 ? t : 0.0;
 }
 
@@ -397,7 +400,7 @@ struct FamWCSPH {
     {
         PairGeom g;
         pair_geom<KK, UH>(g, pi, pj, r2, a);
-        const double tg = pair_gradfac<KK>(g);
+        const double tg = pair_gradfac<KK, UH>(g);
         const double vij0 = D.u - s[0], vij1 = D.v - s[1], vij2 = D.w - s[2]; // VIJ equation.py:214-223
         const double vdotx = vij0 * g.xij[0] + vij1 * g.xij[1] + vij2 * g.xij[2];
         const double mj = s[3];
@@ -406,7 +409,7 @@ struct FamWCSPH {
             const double rhoij = 0.5 * (D.rho + s[4]); // RHOIJ equation.py:196
             double rhoij1;                              // RHOIJ1 :199
             double wij = 0.0;
-            if (fl & (F_XSPH | F_TENSILE)) wij = pair_w<KK>(g);
+            if (fl & (F_XSPH | F_TENSILE)) wij = pair_w<KK, UH>(g);
             if (fl & F_MOM) { // wc/basic.py:204-259
                 const double re = r2 + g.eps;
                 const double tt = fast_rcp(re * rhoij);
@@ -494,7 +497,7 @@ struct FamDensity {
     {
         PairGeom g;
         pair_geom<KK, UH>(g, pi, pj, r2, a);
-        double wij = pair_w<KK>(g);
+        double wij = pair_w<KK, UH>(g);
         if (fl & F_SD) D.rho += s[0] * wij;
         if (fl & F_TVFSD) { D.V += wij; D.rho += D.m * wij; }
     }
@@ -529,7 +532,7 @@ struct FamTVF {
     {
         PairGeom g;
         pair_geom<KK, UH>(g, pi, pj, r2, a);
-        double tg = pair_gradfac<KK>(g);
+        double tg = pair_gradfac<KK, UH>(g);
         double dw0 = tg * g.xij[0], dw1 = tg * g.xij[1], dw2 = tg * g.xij[2];
         double rhoj = s[6], Vj2 = s[10];
         double vsum = D.Vi2 + Vj2;
@@ -603,7 +606,7 @@ struct FamVGrad {
     {
         PairGeom g;
         pair_geom<KK, UH>(g, pi, pj, r2, a);
-        const double tg = pair_gradfac<KK>(g);
+        const double tg = pair_gradfac<KK, UH>(g);
         const double dw[3] = {tg * g.xij[0], tg * g.xij[1], tg * g.xij[2]};
         const double tmp = s[3] * fast_rcp(s[4]); // m/rho
         const double nv[3] = {-(D.u - s[0]), -(D.v - s[1]), -(D.w - s[2])};
@@ -647,14 +650,14 @@ struct FamElastic {
     {
         PairGeom g;
         pair_geom<KK, UH>(g, pi, pj, r2, a);
-        const double tg = pair_gradfac<KK>(g);
+        const double tg = pair_gradfac<KK, UH>(g);
         const double dw0 = tg * g.xij[0], dw1 = tg * g.xij[1], dw2 = tg * g.xij[2];
         const double vij0 = D.u - s[0], vij1 = D.v - s[1], vij2 = D.w - s[2];
         const double vdotx = vij0 * g.xij[0] + vij1 * g.xij[1] + vij2 * g.xij[2];
         const double mj = s[3];
         if (fl & F_ECONT) D.arho = fma(mj * tg, vdotx, D.arho);
         double wij = 0.0;
-        if (fl & (F_ESTRESS | F_EXSPH)) wij = pair_w<KK>(g);
+        if (fl & (F_ESTRESS | F_EXSPH)) wij = pair_w<KK, UH>(g);
         if (fl & F_ESTRESS) { // solid_mech/basic.py:267-387
             double fab = 0.0;
             if (a.p.wdeltap > 0.) {
@@ -938,7 +941,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256, 4) void k_pair_agg(PairArgs<Fam> a)
 {
-    const int NR = a.nrec;
+    const uint32_t NR = (uint32_t)a.nrec;
     // fp32 tile: x | y | z | (w) planes of TS floats each; reads past a plane's
     // valid part land in the next plane / the mask area and are masked out
     constexpr int TS = ACAP + 8;
@@ -983,7 +986,7 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256, 4) void 
     auto do_pair = [&](uint32_t jg, uint32_t flags) {
         double4 pj;
         double sj[Fam::NA];
-        load_record<Fam, UH>(a.rec + (size_t)jg * NR, flags, pj, sj);
+        load_record<Fam, UH>(a.rec + (unsigned long long)jg * NR, flags, pj, sj);
         double hj2 = hi2;
         if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
         const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);

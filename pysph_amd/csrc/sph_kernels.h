@@ -6,6 +6,8 @@
 // reference's; what changes is that h1 = 1/h, q and the normalisation
 // fac = sigma * h1^dim are computed ONCE per pair and shared by W, dW/dq and
 // the gradient (the reference recomputes them in every method).
+// INSUP = true: the caller guarantees q < radius_scale (uniform-h pairs that
+// passed the neighbour criterion), so the support test is dropped.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -23,71 +25,71 @@ template <class R> __device__ __forceinline__ R kernel_norm(R sigma, R h1, int d
 
 template <> struct SphKernel<1> { // CubicSpline
     static constexpr bool HAS_DWQ = false;
-    template <class R> static __device__ __forceinline__ R dwq(R) { return R(0); }
-    template <class R> static __device__ __forceinline__ R w(R q)
+    template <bool INSUP = false, class R> static __device__ __forceinline__ R dwq(R) { return R(0); }
+    template <bool INSUP = false, class R> static __device__ __forceinline__ R w(R q)
     {
         R t2 = R(2) - q;
         R a = R(0.25) * t2 * t2 * t2;
         R b = R(1) - R(1.5) * q * q * (R(1) - R(0.5) * q);
-        return q > R(2) ? R(0) : (q > R(1) ? a : b);
+        return (!INSUP && q > R(2)) ? R(0) : (q > R(1) ? a : b);
     }
-    template <class R> static __device__ __forceinline__ R dw(R q)
+    template <bool INSUP = false, class R> static __device__ __forceinline__ R dw(R q)
     {
         R t2 = R(2) - q;
         R a = R(-0.75) * t2 * t2;
         R b = R(-3) * q * (R(1) - R(0.75) * q);
-        return q > R(2) ? R(0) : (q > R(1) ? a : b);
+        return (!INSUP && q > R(2)) ? R(0) : (q > R(1) ? a : b);
     }
 };
 
 template <> struct SphKernel<2> { // WendlandQuintic
     static constexpr bool HAS_DWQ = true; // dw/q = -5 (1 - q/2)^3: no division by r needed
-    template <class R> static __device__ __forceinline__ R dwq(R q)
+    template <bool INSUP = false, class R> static __device__ __forceinline__ R dwq(R q)
     {
         R t = R(1) - R(0.5) * q;
-        return q < R(2) ? R(-5) * t * t * t : R(0);
+        return (INSUP || q < R(2)) ? R(-5) * t * t * t : R(0);
     }
-    template <class R> static __device__ __forceinline__ R w(R q)
+    template <bool INSUP = false, class R> static __device__ __forceinline__ R w(R q)
     {
         R t = R(1) - R(0.5) * q;
         R v = t * t * t * t * (R(2) * q + R(1));
-        return q < R(2) ? v : R(0);
+        return (INSUP || q < R(2)) ? v : R(0);
     }
-    template <class R> static __device__ __forceinline__ R dw(R q)
+    template <bool INSUP = false, class R> static __device__ __forceinline__ R dw(R q)
     {
         R t = R(1) - R(0.5) * q;
         R v = R(-5) * q * t * t * t;
-        return q < R(2) ? v : R(0);
+        return (INSUP || q < R(2)) ? v : R(0);
     }
 };
 
 template <> struct SphKernel<3> { // QuinticSpline
     static constexpr bool HAS_DWQ = false;
-    template <class R> static __device__ __forceinline__ R dwq(R) { return R(0); }
-    template <class R> static __device__ __forceinline__ R w(R q)
+    template <bool INSUP = false, class R> static __device__ __forceinline__ R dwq(R) { return R(0); }
+    template <bool INSUP = false, class R> static __device__ __forceinline__ R w(R q)
     {
         R t3 = R(3) - q, t2 = R(2) - q, t1 = R(1) - q;
         R v = t3 * t3 * t3 * t3 * t3;
         if (q <= R(2)) v -= R(6) * t2 * t2 * t2 * t2 * t2;
         if (q <= R(1)) v += R(15) * t1 * t1 * t1 * t1 * t1;
-        return q > R(3) ? R(0) : v;
+        return (!INSUP && q > R(3)) ? R(0) : v;
     }
-    template <class R> static __device__ __forceinline__ R dw(R q)
+    template <bool INSUP = false, class R> static __device__ __forceinline__ R dw(R q)
     {
         R t3 = R(3) - q, t2 = R(2) - q, t1 = R(1) - q;
         R v = R(-5) * t3 * t3 * t3 * t3;
         if (q <= R(2)) v += R(30) * t2 * t2 * t2 * t2;
         if (q <= R(1)) v -= R(75) * t1 * t1 * t1 * t1;
-        return q > R(3) ? R(0) : v;
+        return (!INSUP && q > R(3)) ? R(0) : v;
     }
 };
 
 template <> struct SphKernel<4> { // Gaussian
     static constexpr bool HAS_DWQ = true; // dw/q = -2 exp(-q^2)
-    template <class R> static __device__ __forceinline__ R dwq(R q) { return q < R(3) ? R(-2) * exp(-q * q) : R(0); }
-    template <class R> static __device__ __forceinline__ R w(R q) { return q < R(3) ? exp(-q * q) : R(0); }
-    template <class R> static __device__ __forceinline__ R dw(R q)
+    template <bool INSUP = false, class R> static __device__ __forceinline__ R dwq(R q) { return (INSUP || q < R(3)) ? R(-2) * exp(-q * q) : R(0); }
+    template <bool INSUP = false, class R> static __device__ __forceinline__ R w(R q) { return (INSUP || q < R(3)) ? exp(-q * q) : R(0); }
+    template <bool INSUP = false, class R> static __device__ __forceinline__ R dw(R q)
     {
-        return q < R(3) ? R(-2) * q * exp(-q * q) : R(0);
+        return (INSUP || q < R(3)) ? R(-2) * q * exp(-q * q) : R(0);
     }
 };
