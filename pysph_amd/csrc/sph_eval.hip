@@ -933,7 +933,7 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256) void k_p
 //   processing), gathering the fp64 record of each hit, applying the
 //   reference's exact criterion and the fused pair arithmetic.
 // ---------------------------------------------------------------------------
-#define ACAP 352   // candidates per LDS position tile
+#define ACAP 480   // candidates per LDS position tile
 #define AQ 9       // mask slots per thread (one source's 3x3 rows)
 #define AMAXLEN 96 // hit bits kept per row and lane; longer ranges take the slow tail
 
