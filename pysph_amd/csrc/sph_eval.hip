@@ -935,11 +935,12 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256) void k_p
 // ---------------------------------------------------------------------------
 #define ACAP 480   // candidates per LDS position tile
 #define AQ 9       // mask slots per thread (one source's 3x3 rows)
+#define ABS 256     // threads (= destinations) per workgroup of the aggregated kernel
 #define AMAXLEN 96 // hit bits kept per row and lane; longer ranges take the slow tail
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256, 4) void k_pair_agg(PairArgs<Fam> a)
+template <class Fam, int KK, bool UH> __global__ __launch_bounds__(ABS, 1024 / ABS) void k_pair_agg(PairArgs<Fam> a)
 {
     const uint32_t NR = (uint32_t)a.nrec;
     // fp32 tile: x | y | z | (w) planes of TS floats each; reads past a plane's
@@ -948,14 +949,14 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256, 4) void 
     __shared__ __attribute__((aligned(16))) float tile[(UH ? 3 : 4) * TS];
     float *const tx = tile, *const ty = tile + TS, *const tz = tile + 2 * TS, *const tw = tile + (UH ? 0 : 3 * TS);
     __shared__ uint32_t csl[72];
-    __shared__ unsigned long long mlo[AQ][256];
-    __shared__ uint32_t mhi[AQ][256];
-    __shared__ unsigned short mofs[AQ][256];
+    __shared__ unsigned long long mlo[AQ][ABS];
+    __shared__ uint32_t mhi[AQ][ABS];
+    __shared__ unsigned short mofs[AQ][ABS];
     __shared__ uint32_t qbase[AQ];
-    __shared__ int wx[10];
+    __shared__ int wx[2 * (ABS / 64) + 2];
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * 256 + t;
+    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * ABS + t;
     const bool valid = i < a.nd;
     const uint32_t ic = valid ? i : a.nd - 1;
     const uint32_t o = a.d_perm[ic];
@@ -977,10 +978,10 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256, 4) void 
     const double hi_r = a.radius_scale * pi.w;
     const double hi2 = UH ? a.hr2u : hi_r * hi_r;
 
-    if (t == 0) wx[8] = row;
-    if (t == 255) wx[9] = row;
+    if (t == 0) wx[2 * (ABS / 64)] = row;
+    if (t == ABS - 1) wx[2 * (ABS / 64) + 1] = row;
     __syncthreads();
-    const int row_first = wx[8], row_last = wx[9];
+    const int row_first = wx[2 * (ABS / 64)], row_last = wx[2 * (ABS / 64) + 1];
 
     // exact criterion + pair arithmetic for one candidate record
     auto do_pair = [&](uint32_t jg, uint32_t flags) {
@@ -1004,8 +1005,9 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256, 4) void 
         __syncthreads();
         if (lane == 0) { wx[2 * wv] = cxa_w; wx[2 * wv + 1] = cxb_w; }
         __syncthreads();
-        const int cxa = min(min(wx[0], wx[2]), min(wx[4], wx[6]));
-        const int cxb = max(max(wx[1], wx[3]), max(wx[5], wx[7]));
+        int cxa = wx[0], cxb = wx[1];
+#pragma unroll
+        for (int w2 = 1; w2 < ABS / 64; w2++) { cxa = min(cxa, wx[2 * w2]); cxb = max(cxb, wx[2 * w2 + 1]); }
         if (cxb < 0) continue;
         const int cyR = R % ncy, czR = R / ncy;
         const int xa = max(cxa - 1, 0), xb = min(cxb + 1, ncx - 1);
@@ -1058,8 +1060,8 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256, 4) void 
                     for (uint32_t tb = j0; tb < j1; tb += ACAP) {
                         const int tn = (int)min((uint32_t)ACAP, j1 - tb);
                         __syncthreads(); // previous tile's readers are done
-                        for (int q = t; q < ncs && q < 72; q += 256) csl[q] = sd.cell_start[rowb + xa + q];
-                        for (int k = t; k < tn + 8; k += 256) {
+                        for (int q = t; q < ncs && q < 72; q += ABS) csl[q] = sd.cell_start[rowb + xa + q];
+                        for (int k = t; k < tn + 8; k += ABS) {
                             float vx = 3.0e18f, vy = 3.0e18f, vz = 3.0e18f, vw = 0.f;
                             if (k < tn) {
                                 const float4 fj = a.fpos[sd.off + tb + k];
@@ -1334,7 +1336,7 @@ template <class Fam> static void launch_pair(sph_ctx *c, int kk, const PairArgs<
     if (a.nd == 0) return;
     const bool uh = c->uniform_h && c->use_uniform_h;
     if (c->pair_variant == 3) {
-        dim3 g2(div_up(a.nd, 256)), b2(256);
+        dim3 g2(div_up(a.nd, ABS)), b2(ABS);
 #define LAUNCH3(K)                                                                           \
         if (uh) hipLaunchKernelGGL((k_pair_agg<Fam, K, true>), g2, b2, 0, c->stream, a);     \
         else hipLaunchKernelGGL((k_pair_agg<Fam, K, false>), g2, b2, 0, c->stream, a)
