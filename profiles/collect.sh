@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 cd /tmp
 python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o runc -- $BENCH > "$OUT/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o runc -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/stats.log" 2>&1
 for SET in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" \

@@ -202,6 +202,7 @@ struct PackArgs {
     const double *src[MAX_AUX];   // nullptr -> 0.0
     int derived;                  // 1: aux[5] = p/(rho*rho) (p = aux[7], rho = aux[4]); 2: aux[10] = 1/V^2 (V = aux[8]);
                                   // 3: aux[6..11] = (s_ij - p delta_ij)/rho^2 (p = aux[18], rho = aux[4])
+                                  // 4: aux[3] = m/rho (m = aux[3], rho = aux[4]; aux[4] itself is not stored)
     double4 *posh;
     double *aux;
     double *rec;                  // non-null: interleaved records [x y z h aux... pad], nr doubles each
@@ -221,9 +222,10 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
     ph.x = a.x[o]; ph.y = a.y[o]; ph.z = a.z[o]; ph.w = a.h[o];
     double v[MAX_AUX];
 #pragma unroll
-    for (int k = 0; k < MAX_AUX; k++) v[k] = ((k < a.na || (a.derived == 3 && k == 18)) && a.src[k]) ? a.src[k][o] : 0.0;
+    for (int k = 0; k < MAX_AUX; k++) v[k] = ((k < a.na || (a.derived == 3 && k == 18) || (a.derived == 4 && k == 4)) && a.src[k]) ? a.src[k][o] : 0.0;
     if (a.derived == 1) v[5] = v[4] != 0.0 ? v[7] * (1.0 / (v[4] * v[4])) : 0.0; // tmpj = p*rhoj21, wc/basic.py:211,234
     if (a.derived == 2) { double Vj = 1. / v[8]; v[10] = Vj * Vj; } // Vj2, transport_velocity.py:303-306
+    if (a.derived == 4) v[3] = v[3] / v[4]; // m/rho, basic_equations.py:103,139 (VelocityGradient tmp)
     if (a.derived == 3) { // (sigma_ij)/rho^2 with sigma = s - p I: solid_mech/basic.py:281-283,333-339,367-378
         const double r21 = 1. / (v[4] * v[4]), pr = v[18];
         v[6] = (v[6] - pr) * r21; v[7] *= r21; v[8] *= r21;
@@ -374,6 +376,7 @@ __device__ __forceinline__ void load_record(const double *__restrict__ rj, uint3
 
 // ---- WCSPH: Continuity + Momentum + XSPH (wc/basic.py, basic_equations.py) --
 struct FamWCSPH {
+    static constexpr int MINB = 4; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
     static constexpr int NA = 8; // u v w m rho tmpj(=p/rho^2) cs p
     static constexpr int NR = 12; // x y z h + NA (128-B padded records measured slower: larger L2 footprint)
     struct Params {
@@ -486,6 +489,7 @@ template <> __device__ __forceinline__ void load_record<FamWCSPH, false>(const d
 
 // ---- density summations (basic_equations.py:19-29, transport_velocity.py:24-58)
 struct FamDensity {
+    static constexpr int MINB = 4; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
     static constexpr int NA = 1; // m
     static constexpr int NR = 6;  // x y z h m pad
     struct Params { double *rho, *V; };
@@ -510,6 +514,7 @@ struct FamDensity {
 
 // ---- TVF momentum terms (transport_velocity.py:219-545) -------------------
 struct FamTVF {
+    static constexpr int MINB = 3; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
     static constexpr int NA = 12; // u v w uhat vhat what rho p V m Vj2 pad
     static constexpr int NR = 16; // x y z h + NA
     struct Params {
@@ -591,8 +596,9 @@ struct FamTVF {
 
 // ---- velocity gradient (basic_equations.py:63-148) -------------------------
 struct FamVGrad {
-    static constexpr int NA = 6; // u v w m rho pad
-    static constexpr int NR = 10;
+    static constexpr int MINB = 3; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
+    static constexpr int NA = 4; // u v w m/rho
+    static constexpr int NR = 8;
     struct Params { double *v[9]; };
     struct Dest { double u, v, w; double g[9]; };
     static __device__ __forceinline__ void load(Dest &D, const double *a)
@@ -608,7 +614,7 @@ struct FamVGrad {
         pair_geom<KK, UH>(g, pi, pj, r2, a);
         const double tg = pair_gradfac<KK, UH>(g);
         const double dw[3] = {tg * g.xij[0], tg * g.xij[1], tg * g.xij[2]};
-        const double tmp = s[3] * fast_rcp(s[4]); // m/rho
+        const double tmp = s[3]; // m/rho (divided once per particle by k_pack)
         const double nv[3] = {-(D.u - s[0]), -(D.v - s[1]), -(D.w - s[2])};
         const int n = (fl & F_VG3) ? 3 : 2;
 #pragma unroll
@@ -620,7 +626,11 @@ struct FamVGrad {
     template <class A> static __device__ __forceinline__ void finish(Dest &D, const A &a, uint32_t o)
     {
         const int n = (a.dflags & F_VG3) ? 3 : 2;
-        for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) a.p.v[3 * i + j][o] = D.g[3 * i + j];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                if (i < n && j < n) a.p.v[3 * i + j][o] = D.g[3 * i + j];
     }
 };
 
@@ -628,6 +638,7 @@ struct FamVGrad {
 //      MonaghanArtificialViscosity + XSPH  (solid_mech/basic.py:245-387,
 //      basic_equations.py:177-300) -------------------------------------------
 struct FamElastic {
+    static constexpr int MINB = 2; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
     static constexpr int NA = 18; // u v w m rho cs | t00 t01 t02 t11 t12 t22 (= sigma/rho^2) | r00 r01 r02 r11 r12 r22
     static constexpr int NR = 22;
     struct Params {
@@ -940,7 +951,7 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256) void k_p
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-template <class Fam, int KK, bool UH> __global__ __launch_bounds__(ABS, 1024 / ABS) void k_pair_agg(PairArgs<Fam> a)
+template <class Fam, int KK, bool UH> __global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_agg(PairArgs<Fam> a)
 {
     const uint32_t NR = (uint32_t)a.nrec;
     // fp32 tile: x | y | z | (w) planes of TS floats each; reads past a plane's
@@ -1253,9 +1264,10 @@ static PackPlan pack_plan(int fam)
         p.props[0] = SPH_M;
     } else if (fam == FAM_VGRAD) {
         p.nr = FamVGrad::NR;
-        p.na = 6;
-        int pr[6] = {SPH_U, SPH_V, SPH_W, SPH_M, SPH_RHO, -1};
-        for (int k = 0; k < 6; k++) p.props[k] = pr[k];
+        p.na = 4;
+        int pr[5] = {SPH_U, SPH_V, SPH_W, SPH_M, SPH_RHO};
+        for (int k = 0; k < 5; k++) p.props[k] = pr[k];
+        p.derived = 4;
     } else if (fam == FAM_ELASTIC) {
         p.nr = FamElastic::NR;
         p.na = 18;
@@ -1311,7 +1323,7 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
     pa.na = pl.na;
     for (int k = 0; k < MAX_AUX; k++) {
         pa.src[k] = nullptr;
-        if ((k < pl.na || (pl.derived == 3 && k == 18)) && pl.props[k] >= 0) {
+        if ((k < pl.na || (pl.derived == 3 && k == 18) || (pl.derived == 4 && k == 4)) && pl.props[k] >= 0) {
             pa.src[k] = A.prop[pl.props[k]];
             if (!pa.src[k] && slot_required(fam, flags, pl.props[k])) return need_prop(c, id, pl.props[k], "pair loop");
         }
