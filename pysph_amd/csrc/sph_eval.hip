@@ -247,6 +247,10 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
             if (a.nr > 10) r2[5] = make_double2(ph.w, v[7]);
             return;
         }
+        if (a.nr == 4) { // compact density records [x y z m] (uniform h)
+            r[0] = make_double4(ph.x, ph.y, ph.z, v[0]);
+            return;
+        }
         r[0] = ph;
         const int n4 = (a.nr - 4) / 4;
 #pragma unroll
@@ -512,6 +516,16 @@ struct FamDensity {
     }
 };
 
+// Density records of the aggregated kernel under uniform h: [x y z m] (32 B, two
+// 16-B pieces per pair); otherwise the generic [x y z h | m pad].
+template <> __device__ __forceinline__ void load_record<FamDensity, true>(const double *__restrict__ rj, uint32_t fl, double4 &pj, double (&s)[1])
+{
+    const double2 *r2 = reinterpret_cast<const double2 *>(rj);
+    const double2 a0 = r2[0], a1 = r2[1];
+    pj.x = a0.x; pj.y = a0.y; pj.z = a1.x; pj.w = 0.0;
+    s[0] = a1.y;
+}
+
 // ---- TVF momentum terms (transport_velocity.py:219-545) -------------------
 struct FamTVF {
     static constexpr int MINB = 3; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
@@ -596,7 +610,7 @@ struct FamTVF {
 
 // ---- velocity gradient (basic_equations.py:63-148) -------------------------
 struct FamVGrad {
-    static constexpr int MINB = 3; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
+    static constexpr int MINB = 4; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
     static constexpr int NA = 4; // u v w m/rho
     static constexpr int NR = 8;
     struct Params { double *v[9]; };
@@ -1516,6 +1530,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         PackPlan pl = pack_plan(fam);
         // compact 80-B WCSPH records when neither h nor p of a neighbour is read
         if (c->pair_variant == 3 && fam == FAM_WCSPH && c->uniform_h && c->use_uniform_h && !(dflags & F_TENSILE)) pl.nr = 10;
+        if (c->pair_variant == 3 && fam == FAM_DENSITY && c->uniform_h && c->use_uniform_h) pl.nr = 4;
         c->cur_nrec = pl.nr;
         SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * (c->pair_variant >= 2 ? pl.nr : 4)));
         SPH_TRY(c->aux.reserve((total + 64) * sizeof(double) * pl.na));
