@@ -222,6 +222,15 @@ int sph_halo_pack(sph_ctx *ctx, int array_id, int side, int nprops, const int *p
 int sph_halo_append(sph_ctx *ctx, int array_id, int nprops, const int *props, const void *src_device,
                     size_t count);
 
+/* Remove the particles of the last sph_halo_select (both sides) from the
+ * array -- particles that migrated to a neighbouring slab, after their
+ * properties were packed with sph_halo_pack (ParallelManager's exported
+ * particles, pysph/parallel/parallel_manager.pyx:1085-1157).  Stable
+ * compaction of every device property; requires n == n_real (ghosts dropped).
+ * Afterwards n = n_real = *n_left.  Received particles are appended with
+ * sph_halo_append and made real with sph_array_resize(n, n).                 */
+int sph_halo_remove_selected(sph_ctx *ctx, int array_id, size_t *n_left);
+
 /* Box-wrap the first n_real particles along `axis` into [vmin, vmax]:
  * v < vmin -> v + translate; v > vmax -> v - translate
  * (CPUDomainManager._box_wrap_periodic, pysph/base/nnps_base.pyx:699-748).   */

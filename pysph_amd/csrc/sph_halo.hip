@@ -67,6 +67,7 @@ extern "C" int sph_halo_select(sph_ctx *c, int id, int axis, int mode, double p0
     size_t n = upto ? (upto < A.n ? upto : A.n) : A.n_real;
     counts[0] = counts[1] = 0;
     H.count[0] = H.count[1] = 0;
+    H.nsel = n;
     if (n == 0) return SPH_OK;
     const double *coord = A.prop[SPH_X + axis];
     if (!coord) { sph_set_error("sph_halo_select: no device coordinates"); return SPH_ERR_MISSING_PROP; }
@@ -135,6 +136,71 @@ extern "C" int sph_halo_append(sph_ctx *c, int id, int nprops, const int *props,
     for (int k = 0; k < nprops; k++)
         HIP_TRY(hipMemcpyAsync(A.prop[props[k]] + n0, (const double *)src + (size_t)k * count, count * sizeof(double),
                                hipMemcpyDeviceToDevice, c->stream));
+    c->nnps_valid = false;
+    return SPH_OK;
+}
+
+__global__ __launch_bounds__(256) void k_keep_flags(const uint32_t *__restrict__ flo, const uint32_t *__restrict__ fhi,
+                                                    size_t nsel, size_t n, uint32_t *__restrict__ keep)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keep[i] = (i < nsel && (flo[i] | fhi[i])) ? 0u : 1u;
+}
+
+__global__ __launch_bounds__(256) void k_compact_f64(const double *__restrict__ src, const uint32_t *__restrict__ list,
+                                                     size_t count, double *__restrict__ dst)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    dst[i] = src[list[i]];
+}
+
+// Particles that left this rank's slab (ParallelManager's "exported" particles,
+// pysph/parallel/parallel_manager.pyx:1085-1157 remove_particles after the
+// lb_exchange_data send): stable compaction of every device property.
+extern "C" int sph_halo_remove_selected(sph_ctx *c, int id, size_t *n_left)
+{
+    if (!c || id < 0 || id >= SPH_MAX_ARRAYS) { sph_set_error("sph_halo_remove_selected: bad arguments"); return SPH_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    DevArray &A = c->arr[id];
+    HaloState &H = c->halo[id];
+    if (A.n != A.n_real) { sph_set_error("sph_halo_remove_selected: drop ghost particles first (n=%zu, n_real=%zu)", A.n, A.n_real); return SPH_ERR_STATE; }
+    if (H.nsel > A.n) { sph_set_error("sph_halo_remove_selected: selection is stale"); return SPH_ERR_STATE; }
+    const size_t n = A.n, gone = H.count[0] + H.count[1];
+    if (n_left) *n_left = n - gone;
+    if (gone == 0 || n == 0) return SPH_OK;
+    const size_t keepn = n - gone;
+    // keep flags -> positions -> list of kept indices (ascending: order is preserved)
+    DevBuf keep, pos, list;
+    SPH_TRY(keep.reserve((n + 1) * 4));
+    SPH_TRY(pos.reserve((n + 1) * 4));
+    SPH_TRY(list.reserve((keepn + 1) * 4));
+    hipLaunchKernelGGL(k_keep_flags, dim3(div_up(n, 256)), dim3(256), 0, c->stream, H.flag[0].as<uint32_t>(),
+                       H.flag[1].as<uint32_t>(), H.nsel, n, keep.as<uint32_t>());
+    size_t tmpb = 0;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpb, keep.as<uint32_t>(), pos.as<uint32_t>(), (int)n, c->stream));
+    SPH_TRY(c->cub_tmp.reserve(tmpb));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.ptr, tmpb, keep.as<uint32_t>(), pos.as<uint32_t>(), (int)n, c->stream));
+    if (keepn)
+        hipLaunchKernelGGL(k_halo_scatter, dim3(div_up(n, 256)), dim3(256), 0, c->stream, keep.as<uint32_t>(),
+                           pos.as<uint32_t>(), n, list.as<uint32_t>());
+    double *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&tmp, A.cap * sizeof(double)));
+    for (int p = 0; p < SPH_PROP_COUNT; p++) {
+        if (!A.prop[p]) continue;
+        if (keepn)
+            hipLaunchKernelGGL(k_compact_f64, dim3(div_up(keepn, 256)), dim3(256), 0, c->stream, A.prop[p],
+                               list.as<uint32_t>(), keepn, tmp);
+        double *old = A.prop[p];
+        A.prop[p] = tmp;
+        tmp = old;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(tmp));
+    keep.release(); pos.release(); list.release();
+    A.n = A.n_real = keepn;
+    H.count[0] = H.count[1] = 0;
     c->nnps_valid = false;
     return SPH_OK;
 }

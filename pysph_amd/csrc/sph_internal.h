@@ -54,6 +54,7 @@ struct DevArray {
 struct HaloState {
     DevBuf flag[2], pos[2], list[2];
     size_t count[2] = {0, 0};
+    size_t nsel = 0; // particles the flags of the last sph_halo_select cover
 };
 
 enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_STAGE, T_COUNT };

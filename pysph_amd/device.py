@@ -80,6 +80,7 @@ SIGNATURES = {
                                 C.POINTER(C.c_int), C.c_int, C.c_double, _P]),
     'sph_halo_append': (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int),
                                   _P, C.c_size_t]),
+    'sph_halo_remove_selected': (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
     'sph_reduce_max': (C.c_int, [_P, C.c_int, C.c_int, _PD]),
     'sph_reduce_min': (C.c_int, [_P, C.c_int, C.c_int, _PD]),
     'sph_integrate_stage': (C.c_int, [_P, C.c_int, C.c_int, C.c_int,
@@ -263,6 +264,37 @@ class HipDeviceHelper(object):
             _check(self.lib.sph_array_pull(
                 self.ctx._h, self.array_id, pid, arr.ctypes.data_as(_PD), 0,
                 min(arr.size, self.get_number_of_particles())))
+
+    def pull_into(self, prop, out):
+        """device -> a caller-provided fp64 buffer (first out.size values)."""
+        if out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise SphError('pull_into(%s): buffer must be contiguous fp64' % prop)
+        _check(self.lib.sph_array_pull(
+            self.ctx._h, self.array_id, prop_id(prop), out.ctypes.data_as(_PD),
+            0, min(out.size, self.get_number_of_particles())))
+        return out
+
+    def sync_host(self, ghosts=False):
+        """Make the host array mirror a device-managed array (after halo
+        exchange / migration the device owns the particle count): resize the
+        host array, pull every mirrored property.  ghosts=False keeps only the
+        real particles on the host (what dump_output wants)."""
+        pa = self._pa
+        nreal = self.get_number_of_particles(True)
+        n = self.get_number_of_particles() if ghosts else nreal
+        pa.resize(n)
+        pa.set_num_real_particles(nreal)
+        ids = (C.c_int * 256)()
+        cnt = C.c_int(0)
+        _check(self.lib.sph_array_props(self.ctx._h, self.array_id, ids,
+                                        C.byref(cnt)))
+        on_device = set(int(ids[k]) for k in range(cnt.value))
+        for p in pa.properties:
+            pid = prop_id(p)
+            if pid in on_device and get_npy(pa, p).dtype == np.float64:
+                arr = get_npy(pa, p)
+                _check(self.lib.sph_array_pull(self.ctx._h, self.array_id, pid,
+                                               arr.ctypes.data_as(_PD), 0, n))
 
     def max(self, prop):
         out = C.c_double()

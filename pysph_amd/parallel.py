@@ -63,8 +63,8 @@ class DeviceHaloOps(object):
                                             0, lo_cut, hi_cut, 0.0, 0, counts))
         return int(counts[0]), int(counts[1])
 
-    def new_buffer(self, count):
-        return self.torch.empty(max(count * self.nprops, 1),
+    def new_buffer(self, count, nprops=None):
+        return self.torch.empty(max(count * (nprops or self.nprops), 1),
                                 dtype=self.torch.float64, device=self.device)
 
     def int_tensor(self, values):
@@ -83,9 +83,52 @@ class DeviceHaloOps(object):
             self.ctx._h, self.id, self.nprops, self.props,
             C.c_void_p(buf.data_ptr()), count))
 
+    # -- migration of owned particles (every device property travels) -------
+    def all_props(self):
+        """ids of the properties with device storage, ascending: identical
+        on every rank because every rank runs the same equations"""
+        out = (C.c_int * 256)()
+        n = C.c_int(0)
+        dev._check(self.lib.sph_array_props(self.ctx._h, self.id, out,
+                                            C.byref(n)))
+        return [int(out[k]) for k in range(n.value)]
+
+    def pack_all(self, side, count, shift):
+        ids = self.all_props()
+        buf = self.new_buffer(count, len(ids))
+        dev._check(self.lib.sph_halo_pack(
+            self.ctx._h, self.id, side, len(ids), (C.c_int * len(ids))(*ids),
+            self.axis, float(shift), C.c_void_p(buf.data_ptr())))
+        return buf, len(ids)
+
+    def remove_selected(self):
+        left = C.c_size_t(0)
+        dev._check(self.lib.sph_halo_remove_selected(self.ctx._h, self.id,
+                                                     C.byref(left)))
+        return int(left.value)
+
+    def append_real(self, buf, count):
+        ids = self.all_props()
+        dev._check(self.lib.sph_halo_append(
+            self.ctx._h, self.id, len(ids), (C.c_int * len(ids))(*ids),
+            C.c_void_p(buf.data_ptr()), count))
+        n = self.gpu.get_number_of_particles()
+        dev._check(self.lib.sph_array_resize(self.ctx._h, self.id, n, n))
+
+    def coords(self):
+        """host copy of the real particles' coordinate along the slab axis
+        (re-balancing only; every k steps)"""
+        import numpy as np
+        n = self.n_real()
+        out = np.empty(n)
+        if n:
+            self.gpu.pull_into('xyz'[self.axis], out)
+        return out
+
 
 class SlabHalo(object):
-    """Ghost exchange for one particle array of a slab-decomposed domain.
+    """Ghost exchange + migration for one particle array of a
+    slab-decomposed domain.
 
     rank r owns coordinate range [lo, hi) along `axis`; its neighbours are
     r-1 and r+1 (wrapping with a coordinate shift of -+`period` when
@@ -105,6 +148,7 @@ class SlabHalo(object):
         self.period = float(period)
         self.ops = ops or DeviceHaloOps(pa, ctx, props, axis)
         self.last_counts = (0, 0, 0, 0)   # sent lo/hi, received lo/hi
+        self.last_migrated = (0, 0, 0, 0)
 
     def neighbours(self):
         """[(side, peer rank, coordinate shift applied to what we SEND)]"""
@@ -120,24 +164,18 @@ class SlabHalo(object):
             out.append((1, 0, -self.period))
         return out
 
-    def exchange(self):
+    def _swap(self, nbrs, send_cnt, out_buf, nprops):
+        """counts handshake (one tiny all_gather) + one batch of point-to-point
+        send/recv with the <=2 neighbours; returns ({side: recv buffer},
+        {side: recv count})"""
         ops, dist = self.ops, self.dist
-        ops.drop_ghosts()
-        n_lo, n_hi = ops.select(self.lo + self.width, self.hi - self.width)
-        nbrs = self.neighbours()
-        if not nbrs:
-            return
-        # 1. counts handshake: one tiny all_gather of (n_lo, n_hi) per rank
-        send_cnt = {0: n_lo, 1: n_hi}
-        mine = ops.int_tensor([n_lo, n_hi])
+        mine = ops.int_tensor([send_cnt[0], send_cnt[1]])
         allc = ops.int_tensor([0] * (2 * self.world))
         dist.all_gather_into_tensor(allc, mine)
         allc = [int(v) for v in allc.cpu()]
         # what peer sends to me: its hi list if it is my lo neighbour, else lo
         recv_cnt = {s: allc[2 * peer + (1 - s)] for s, peer, _ in nbrs}
-        # 2. payloads: one flat [nprops][count] buffer per neighbour
-        out_buf = {s: ops.pack(s, send_cnt[s], shift) for s, _, shift in nbrs}
-        in_buf = {s: ops.new_buffer(recv_cnt[s]) for s, _, _ in nbrs}
+        in_buf = {s: ops.new_buffer(recv_cnt[s], nprops) for s, _, _ in nbrs}
         reqs = []
         for s, peer, _ in nbrs:
             if send_cnt[s]:
@@ -147,11 +185,150 @@ class SlabHalo(object):
         if reqs:
             for w in dist.batch_isend_irecv(reqs):
                 w.wait()
-        # 3. ghosts go behind the real particles (lo side first: deterministic)
+        return in_buf, recv_cnt
+
+    def exchange(self):
+        """refresh the ghosts (ParallelManager.update, :512-530)"""
+        ops = self.ops
+        ops.drop_ghosts()
+        n_lo, n_hi = ops.select(self.lo + self.width, self.hi - self.width)
+        nbrs = self.neighbours()
+        if not nbrs:
+            return
+        send_cnt = {0: n_lo, 1: n_hi}
+        # payloads: one flat [nprops][count] buffer per neighbour
+        out_buf = {s: ops.pack(s, send_cnt[s], shift) for s, _, shift in nbrs}
+        for s in (0, 1):             # nothing goes out through an open face
+            if s not in out_buf:
+                send_cnt[s] = 0
+        in_buf, recv_cnt = self._swap(nbrs, send_cnt, out_buf, ops.nprops)
+        # ghosts go behind the real particles (lo side first: deterministic)
         for s, _, _ in nbrs:
             if recv_cnt[s]:
                 ops.append(in_buf[s], recv_cnt[s])
-        self.last_counts = (n_lo, n_hi, recv_cnt.get(0, 0), recv_cnt.get(1, 0))
+        self.last_counts = (send_cnt[0], send_cnt[1], recv_cnt.get(0, 0),
+                            recv_cnt.get(1, 0))
+
+    def migrate(self):
+        """hand the REAL particles that left [lo, hi) to the neighbouring
+        slab, with every property (parallel_manager.pyx:1085-1157: exported
+        particles are sent, removed locally and arrive as Local particles).
+        A particle moves at most one slab per call; returns the number that
+        left this rank."""
+        ops = self.ops
+        ops.drop_ghosts()
+        nbrs = self.neighbours()
+        if not nbrs:
+            return 0
+        sides = [s for s, _, _ in nbrs]
+        inf = float('inf')
+        # an open (non-periodic) outer face keeps its particles
+        n_lo, n_hi = ops.select(self.lo if 0 in sides else -inf,
+                                self.hi if 1 in sides else inf)
+        send_cnt = {0: n_lo, 1: n_hi}
+        out_buf, nprops = {}, None
+        for s, _, shift in nbrs:
+            out_buf[s], nprops = ops.pack_all(s, send_cnt[s], shift)
+        ops.remove_selected()
+        in_buf, recv_cnt = self._swap(nbrs, send_cnt, out_buf, nprops)
+        for s, _, _ in nbrs:
+            if recv_cnt[s]:
+                ops.append_real(in_buf[s], recv_cnt[s])
+        self.last_migrated = (n_lo, n_hi, recv_cnt.get(0, 0),
+                              recv_cnt.get(1, 0))
+        return n_lo + n_hi
+
+
+class SlabDecomposition(object):
+    """All particle arrays of one rank: what ``ParallelManager.update()``
+    (parallel_manager.pyx:512-530) does before an acceleration evaluation --
+    migrate owned particles that crossed a slab face, then refresh the ghosts
+    -- plus ``rebalance()`` (the reference's Zoltan load balance,
+    parallel_manager.pyx:577-640, reduced to moving the slab faces)."""
+
+    def __init__(self, arrays, ctx, rank, world, axis, width, lo, hi,
+                 props=WCSPH_HALO_PROPS, periodic=False, period=0.0,
+                 ops_factory=None, dist=None):
+        if dist is None:
+            import torch.distributed as dist
+        self.dist = dist
+        self.rank, self.world, self.axis = rank, world, axis
+        self.halos = []
+        for pa in arrays:
+            p = props[pa.name] if isinstance(props, dict) else props
+            ops = ops_factory(pa, axis, p) if ops_factory else None
+            self.halos.append(SlabHalo(pa, ctx, rank, world, axis, width, lo,
+                                       hi, props=p, periodic=periodic,
+                                       period=period, ops=ops, dist=dist))
+
+    @property
+    def lo(self):
+        return self.halos[0].lo
+
+    @property
+    def hi(self):
+        return self.halos[0].hi
+
+    def migrate(self):
+        return sum(h.migrate() for h in self.halos)
+
+    def exchange(self):
+        for h in self.halos:
+            h.exchange()
+
+    def update(self):
+        self.migrate()
+        self.exchange()
+
+    def rebalance(self, nbins=4096, weights=None):
+        """Move the slab faces so that every rank owns about the same number
+        of real particles (optionally weighted per array, e.g. fluid particles
+        cost more than boundary ones): global histogram of the slab-axis
+        coordinate (all_reduce SUM), faces at its quantiles, then migrate until
+        every particle is home (a particle moves one slab per round)."""
+        import numpy as np
+        dist = self.dist
+        ops0 = self.halos[0].ops
+        coords = [h.ops.coords() for h in self.halos]
+        lmin = min([c.min() for c in coords if c.size] or [float('inf')])
+        lmax = max([c.max() for c in coords if c.size] or [-float('inf')])
+        gmin = -allreduce_scalars([-lmin], 'max', dist=dist,
+                                  device=getattr(ops0, 'device', None))[0]
+        gmax = allreduce_scalars([lmax], 'max', dist=dist,
+                                 device=getattr(ops0, 'device', None))[0]
+        span = max(gmax - gmin, 1e-300)
+        hist = np.zeros(nbins)
+        for k, c in enumerate(coords):
+            w = 1.0 if weights is None else float(weights[k])
+            if c.size:
+                b = np.minimum(((c - gmin) / span * nbins).astype(np.int64),
+                               nbins - 1)
+                hist += w * np.bincount(b, minlength=nbins)
+        import torch
+        t = torch.tensor(hist, dtype=torch.float64,
+                         device=getattr(ops0, 'device', None))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        cum = np.concatenate([[0.0], np.cumsum(t.cpu().numpy())])
+        edges = gmin + span * np.arange(nbins + 1) / nbins
+        targets = cum[-1] * np.arange(1, self.world) / self.world
+        cuts = np.interp(targets, cum, edges)
+        faces = np.concatenate([[-np.inf if not self.halos[0].periodic else gmin],
+                                cuts, [np.inf if not self.halos[0].periodic else gmax]])
+        for h in self.halos:
+            # the outer faces keep their meaning (open, or the periodic box)
+            if 0 < self.rank:
+                h.lo = float(faces[self.rank])
+            if self.rank < self.world - 1:
+                h.hi = float(faces[self.rank + 1])
+        rounds = 0
+        while True:
+            moved = self.migrate()
+            total = allreduce_scalars([float(moved)], 'max', dist=dist,
+                                      device=getattr(ops0, 'device', None))[0]
+            rounds += 1
+            if total == 0 or rounds > self.world:
+                break
+        return faces, rounds
 
 
 def allreduce_scalars(values, op, dist=None, device=None):

@@ -54,3 +54,89 @@ def rel_err(a, b, scale=None):
     if scale is None:
         scale = max(np.max(np.abs(b)), 1e-300) if b.size else 1.0
     return float(np.max(np.abs(a - b)) / scale) if b.size else 0.0
+
+
+class ThreadDist(object):
+    """In-process stand-in for ``torch.distributed`` used by the -m gpu tests:
+    `world` threads play the ranks of one node on ONE GPU (RCCL cannot put two
+    ranks on one device).  Tensors are handed over by reference and copied on
+    the receiver's stream after a device synchronize -- the ordering RCCL's
+    stream semantics give.  ``view(rank)`` returns the per-rank object to pass
+    as ``dist=``."""
+
+    def __init__(self, world):
+        import queue
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.q = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+
+    def view(self, rank):
+        return _ThreadDistRank(self, rank)
+
+
+class _Done(object):
+    def wait(self):
+        return True
+
+
+class _ThreadDistRank(object):
+    class ReduceOp(object):
+        MIN, MAX, SUM = 'min', 'max', 'sum'
+
+    class P2POp(object):
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    isend, irecv = 'isend', 'irecv'
+
+    def __init__(self, hub, rank):
+        self.hub, self.rank = hub, rank
+
+    def _sync(self):
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def all_gather_into_tensor(self, out, inp):
+        import torch
+        hub = self.hub
+        self._sync()
+        hub.slots[self.rank] = inp.clone()
+        self._sync()
+        hub.barrier.wait()
+        out.copy_(torch.cat([s.reshape(-1) for s in hub.slots]))
+        self._sync()
+        hub.barrier.wait()
+
+    def all_reduce(self, t, op=None):
+        import torch
+        hub = self.hub
+        self._sync()
+        hub.slots[self.rank] = t.clone()
+        self._sync()
+        hub.barrier.wait()
+        st = torch.stack(hub.slots)
+        r = {'min': st.min(0).values, 'max': st.max(0).values, 'sum': st.sum(0)}[op]
+        self._sync()
+        hub.barrier.wait()
+        t.copy_(r)
+        self._sync()
+        hub.barrier.wait()
+
+    def batch_isend_irecv(self, reqs):
+        hub = self.hub
+        self._sync()
+        for r in reqs:
+            if r.op == 'isend':
+                hub.q[(self.rank, r.peer)].put(r.tensor)
+        for r in reqs:
+            if r.op == 'irecv':
+                src = hub.q[(r.peer, self.rank)].get(timeout=120)
+                r.tensor.copy_(src[:r.tensor.numel()])
+        self._sync()
+        return [_Done()]
+
+    def barrier(self):
+        self.hub.barrier.wait()

@@ -418,6 +418,180 @@ def test_halo_device_ops_two_slabs_one_gpu(oracle):
             assert e < TOL, (prop, e)
 
 
+def test_slab_decomposition_migrate_rebalance_one_gpu(oracle):
+    """SlabDecomposition end to end with the DEVICE primitives
+    (sph_halo_select/pack/remove_selected/append) on one GPU: two threads play
+    two slab ranks (tests/helpers.ThreadDist stands in for torch.distributed).
+    Ownership starts wrong and lopsided; after update() every particle is in
+    its slab, after rebalance() the counts are even, and the evaluation of each
+    slab's real particles equals the single-domain oracle matched by global id
+    (carried in the spare fp64 property e0).  Mirrors
+    pysph/parallel/tests/example_test_case.py:143-166."""
+    import threading
+    import torch
+    from helpers import ThreadDist
+    from pysph_amd import device as dev
+    from pysph_amd import kernels as K
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.nnps import HipNNPS
+    from pysph_amd.parallel import SlabDecomposition
+    from pysph_amd.particle_array import ParticleArray
+    full, dx = make_cube(24)
+    n = full.get_number_of_particles()
+    kernel = K.WendlandQuintic(dim=3)
+    eqs = cube_equations(dx)
+    width = kernel.radius_scale * 1.3 * dx
+    hub = ThreadDist(2)
+    results, errors = {}, []
+
+    def rank_main(rank):
+        try:
+            ts = torch.cuda.Stream()
+            with torch.cuda.stream(ts):
+                x = full.x
+                own = np.nonzero(x < 0.3)[0] if rank == 0 else np.nonzero(x >= 0.3)[0]
+                props = {k: v[own].copy() for k, v in full.properties.items()}
+                props['e0'] = own.astype(np.float64)
+                pa = ParticleArray(name='fluid', **props)
+                ctx = dev.HipContext(0, ts.cuda_stream)
+                dev.attach(pa, ctx).push()
+                lo, hi = (0.0, 0.5) if rank == 0 else (0.5, 1.0)
+                dec = SlabDecomposition([pa], ctx, rank, 2, axis=0, width=width,
+                                        lo=lo, hi=hi, dist=hub.view(rank))
+                dec.update()
+                gpu = pa.gpu
+                xs = np.empty(gpu.get_number_of_particles(True))
+                gpu.pull_into('x', xs)
+                assert (xs < 0.5).all() if rank == 0 else (xs >= 0.5).all()
+                assert gpu.get_number_of_particles() > xs.size        # ghosts
+                faces, rounds = dec.rebalance(nbins=1024)
+                dec.exchange()
+                nreal = gpu.get_number_of_particles(True)
+                assert abs(nreal - n // 2) <= 0.02 * n, nreal
+                a_eval = AccelerationEval([pa], eqs, kernel)
+                SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+                nnps = HipNNPS(3, [pa], radius_scale=2.0, ctx=ctx, sync=False)
+                a_eval.set_nnps(nnps)
+                a_eval.compute(0.0, 1e-5)
+                gpu.sync_host()
+                results[rank] = {k: pa.properties[k].copy() for k in WC_OUT + ['e0']}
+        except Exception as e:      # surface in the main thread
+            import traceback
+            errors.append(traceback.format_exc())
+            try:
+                hub.barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors[0]
+    onn = oracle.OracleNNPS(3, [full], 2.0)
+    onn.update()
+    oev = oracle.OracleEval([full], eqs, kernel, nthreads=4)
+    oev.set_nnps(onn)
+    oev.compute(0.0, 1e-5)
+    gids = []
+    for r in range(2):
+        gid = results[r]['e0'].astype(np.int64)
+        gids.append(gid)
+        for prop in WC_OUT:
+            e = rel_err(results[r][prop], full.properties[prop][gid])
+            assert e < TOL, (r, prop, e)
+    assert (np.sort(np.concatenate(gids)) == np.arange(n)).all()
+
+
+def test_dam_break_two_slabs_three_arrays_one_gpu(oracle):
+    """BASELINE config 4 in miniature: the dam-break tank (fluid + boundary +
+    obstacle) cut into two x-slabs at the particle-count median, one thread per
+    slab rank on one GPU.  Every array gets its own ghosts
+    (SlabDecomposition); the slab that has no obstacle particles holds an EMPTY
+    obstacle array.  real=False EOS groups recompute p, cs on the ghosts;
+    results of all real particles equal the single-domain oracle by global id."""
+    import threading
+    import torch
+    from helpers import ThreadDist
+    from pysph_amd import device as dev
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.examples import dam_break_3d as db
+    from pysph_amd.nnps import HipNNPS
+    from pysph_amd.parallel import SlabDecomposition, slab_bounds
+    dx = 0.06
+    full = db.create_particles(dx)
+    _perturb(full, 7, db.c0, db.ro, dx)
+    for a in full:
+        a.add_property('e0', data=np.arange(a.get_number_of_particles(), dtype=np.float64))
+    ref = _copy_arrays(full)
+    eqs = db.create_scheme(dx).get_equations()
+    kernel = db.create_kernel()
+    cuts = slab_bounds(np.concatenate([a.x for a in full]), 2)
+    width = kernel.radius_scale * db.hdx * dx
+    hub = ThreadDist(2)
+    results, errors = {}, []
+
+    def rank_main(rank):
+        try:
+            ts = torch.cuda.Stream()
+            with torch.cuda.stream(ts):
+                lo = -1e30 if rank == 0 else float(cuts[1])
+                hi = float(cuts[1]) if rank == 0 else 1e30
+                arrays = [a.extract_particles(np.nonzero((a.x >= lo) & (a.x < hi))[0], name=a.name)
+                          for a in full]
+                ctx = dev.HipContext(0, ts.cuda_stream)
+                for a in arrays:
+                    dev.attach(a, ctx).push()
+                dec = SlabDecomposition(arrays, ctx, rank, 2, axis=0, width=width, lo=lo, hi=hi,
+                                        dist=hub.view(rank))
+                dec.update()
+                a_eval = AccelerationEval(arrays, eqs, kernel)
+                SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+                nnps = HipNNPS(3, arrays, radius_scale=kernel.radius_scale, ctx=ctx, sync=False)
+                a_eval.set_nnps(nnps)
+                a_eval.compute(0.0, 1e-5)
+                out = {}
+                for a in arrays:
+                    a.gpu.sync_host()
+                    out[a.name] = {k: a.properties[k].copy() for k in WC_OUT + ['e0']}
+                results[rank] = out
+        except Exception:
+            import traceback
+            errors.append(traceback.format_exc())
+            try:
+                hub.barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors[0]
+    onn = oracle.OracleNNPS(3, ref, radius_scale=kernel.radius_scale)
+    onn.update()
+    oev = oracle.OracleEval(ref, eqs, kernel, nthreads=8)
+    oev.set_nnps(onn)
+    oev.compute(0.0, 1e-5)
+    sizes = [len(results[r]['obstacle']['e0']) for r in range(2)]
+    assert min(sizes) == 0 and max(sizes) > 0          # one slab has no obstacle
+    for pr in ref:
+        seen = 0
+        for r in range(2):
+            d = results[r][pr.name]
+            gid = d['e0'].astype(np.int64)
+            seen += gid.size
+            if gid.size == 0:
+                continue
+            for prop in WC_OUT:
+                e = rel_err(d[prop], pr.properties[prop][gid],
+                            scale=max(np.abs(pr.properties[prop]).max(), 1e-300))
+                assert e < TOL, (r, pr.name, prop, e)
+        assert seen == pr.get_number_of_particles()
+
+
 def test_device_reorder_keeps_results(oracle):
     """NNPS.spatially_order_particles on device-resident state
     (nnps_base.pyx:1615-1629; solver.py:296-302): properties are permuted by

@@ -48,8 +48,8 @@ class NumpyHaloOps(object):
         self._sel = {0: np.nonzero(c < lo_cut)[0], 1: np.nonzero(c >= hi_cut)[0]}
         return len(self._sel[0]), len(self._sel[1])
 
-    def new_buffer(self, count):
-        return torch.empty(max(count * self.nprops, 1), dtype=torch.float64)
+    def new_buffer(self, count, nprops=None):
+        return torch.empty(max(count * (nprops or self.nprops), 1), dtype=torch.float64)
 
     def int_tensor(self, values):
         return torch.tensor(values, dtype=torch.int64)
@@ -74,6 +74,43 @@ class NumpyHaloOps(object):
         for k, p in enumerate(PROPS):
             self.pa.properties[p][n0:] = arr[k * count:(k + 1) * count]
         self.pa.properties['tag'][n0:] = 1  # Remote
+
+    # -- migration ---------------------------------------------------------
+    def all_props(self):
+        return sorted(k for k, v in self.pa.properties.items()
+                      if v.dtype == np.float64)
+
+    def pack_all(self, side, count, shift):
+        names = self.all_props()
+        buf = self.new_buffer(count, len(names))
+        idx = self._sel[side]
+        out = buf.numpy()
+        for k, p in enumerate(names):
+            v = self.pa.properties[p][idx]
+            if p == self.axis:
+                v = v + shift
+            out[k * count:(k + 1) * count] = v
+        return buf, len(names)
+
+    def remove_selected(self):
+        gone = np.concatenate([self._sel[0], self._sel[1]])
+        keep = np.setdiff1d(np.arange(self.pa.get_number_of_particles()), gone)
+        for k in list(self.pa.properties):
+            self.pa.properties[k] = self.pa.properties[k][keep].copy()
+        self.pa.num_real_particles = keep.size
+        return keep.size
+
+    def append_real(self, buf, count):
+        names = self.all_props()
+        n0 = self.pa.get_number_of_particles()
+        self.pa.resize(n0 + count)
+        self.pa.set_num_real_particles(n0 + count)
+        arr = buf.numpy()
+        for k, p in enumerate(names):
+            self.pa.properties[p][n0:] = arr[k * count:(k + 1) * count]
+
+    def coords(self):
+        return self.pa.properties[self.axis][:self.n_real()].copy()
 
 
 def _worker(rank, world, port, periodic, out):
@@ -123,6 +160,82 @@ def _worker(rank, world, port, periodic, out):
         np.save((out % rank) + '.max.npy', np.array(mx))
     finally:
         dist.destroy_process_group()
+
+
+def _worker_migrate(rank, world, port, out):
+    """ownership starts WRONG (cut at x = 0.3 while the slabs are [.,0.5) and
+    [0.5,.)) and lopsided; SlabDecomposition.update() must migrate, then
+    rebalance() must even out the counts; results equal the single domain."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from test_hip_parity import make_cube, cube_equations
+        from pysph_amd import kernels as K
+        from pysph_amd.parallel import SlabDecomposition
+        from pysph_amd.particle_array import ParticleArray
+        from oracle import oracle as orc
+        full, dx = make_cube(14)
+        n = full.get_number_of_particles()
+        x = full.x
+        own = np.nonzero(x < 0.3)[0] if rank == 0 else np.nonzero(x >= 0.3)[0]
+        props = {k: v[own].copy() for k, v in full.properties.items()}
+        props['e0'] = own.astype(np.float64)        # global id rides along
+        pa = ParticleArray(name='fluid', **props)
+        kernel = K.WendlandQuintic(dim=3)
+        width = kernel.radius_scale * 1.3 * dx
+        lo, hi = (0.0, 0.5) if rank == 0 else (0.5, 1.0)
+        dec = SlabDecomposition([pa], None, rank, world, axis=0, width=width,
+                                lo=lo, hi=hi,
+                                ops_factory=lambda a, ax, p: NumpyHaloOps(a, ax),
+                                dist=dist)
+        dec.update()
+        nreal = pa.get_number_of_particles(True)
+        xr = pa.x[:nreal]
+        assert (xr < 0.5).all() if rank == 0 else (xr >= 0.5).all()
+        moved = dec.halos[0].last_migrated
+        assert (moved[3] > 0) if rank == 0 else (moved[0] > 0)
+        # lopsided on purpose -> rebalance moves the face to the median
+        dec.halos[0].lo, dec.halos[0].hi = (0.0, 0.8) if rank == 0 else (0.8, 1.0)
+        dec.update()
+        n_before = pa.get_number_of_particles(True)
+        faces, rounds = dec.rebalance(nbins=512)
+        dec.exchange()
+        nreal = pa.get_number_of_particles(True)
+        assert abs(nreal - n // 2) <= 0.02 * n, (n_before, nreal)
+        nn = orc.OracleNNPS(3, [pa], 2.0)
+        nn.update()
+        ev = orc.OracleEval([pa], cube_equations(dx), kernel)
+        ev.set_nnps(nn)
+        ev.compute(0.0, 1e-5)
+        np.savez(out % rank, gid=pa.e0[:nreal].astype(np.int64), face=faces[1],
+                 **{k: pa.properties[k][:nreal] for k in
+                    ('arho', 'au', 'av', 'aw', 'ax', 'ay', 'az')})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_migration_and_rebalance(tmp_path, oracle):
+    from test_hip_parity import make_cube, cube_equations
+    from helpers import rel_err
+    from pysph_amd import kernels as K
+    out = str(tmp_path / 'mig%d.npz')
+    mp.spawn(_worker_migrate, args=(2, _free_port(), out), nprocs=2, join=True)
+    full, dx = make_cube(14)
+    kernel = K.WendlandQuintic(dim=3)
+    nn = oracle.OracleNNPS(3, [full], 2.0)
+    nn.update()
+    ev = oracle.OracleEval([full], cube_equations(dx), kernel)
+    ev.set_nnps(nn)
+    ev.compute(0.0, 1e-5)
+    gids = []
+    for r in range(2):
+        d = np.load(out % r)
+        gids.append(d['gid'])
+        for k in ('arho', 'au', 'av', 'aw', 'ax', 'ay', 'az'):
+            assert rel_err(d[k], full.properties[k][d['gid']]) < 1e-13, (r, k)
+    allg = np.sort(np.concatenate(gids))
+    assert (allg == np.arange(full.get_number_of_particles())).all()   # nobody lost or duplicated
 
 
 def _free_port():
