@@ -32,6 +32,8 @@ sys.path.insert(0, REPO)
 
 ALGO_BYTES_PAIR = 160.0      # pair-loop kernel, fp64, per particle-update
 ALGO_BYTES_UPDATE = 184.0    # whole compute() (EOS + pair pass)
+FLOP_PER_PAIR = 130.0            # fused WCSPH fluid<-fluid group, reference operation count
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X fp64 vector (non-MFMA) peak
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -295,6 +297,12 @@ def main():
         elapsed = float(tt.item())
 
     timers = {k: ctx.timer_get(k) for k in ('nnps', 'pack', 'eos', 'pair')}
+    # true neighbour pairs of one evaluation (outside the timed region): the
+    # flop-side reading of the pair loop that SURVEY 8(d) asks for next to the
+    # HBM one
+    pairs = None
+    if args.workload == 'cube' and rank == 0:
+        pairs = nnps.count_neighbors(0, 0)
     pair_ms, pair_launches = timers['pair']
     n_total = n_local * world          # real particles only (ghosts are extra work)
     if scaling == 'strong':
@@ -346,6 +354,13 @@ def main():
                 'avg_kernel_ms': pair_avg_s * 1e3,
             },
             'kernel_ms_per_step': {k: v[0] / args.steps for k, v in timers.items()},
+            'fp64_valu': None if not pairs else {
+                'pairs_per_launch': pairs,
+                'flop_per_pair': FLOP_PER_PAIR,
+                'achieved': pairs * FLOP_PER_PAIR / pair_step_s / 1e12,
+                'peak': FP64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': pairs * FLOP_PER_PAIR / pair_step_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                'Gpairs_per_s': pairs / pair_step_s / 1e9},
             'algorithmic_GBs_whole_update': ALGO_BYTES_UPDATE * value / 1e9,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -113,6 +113,18 @@ class HipNNPS(object):
             C.byref(total)))
         return start, nbrs[:total.value]
 
+    def count_neighbors(self, src_index, dst_index):
+        """total number of (destination, source) neighbour pairs -- pass 1 of
+        the CSR query only (nd+1 counters come back, no lists)."""
+        nd = self.helpers[dst_index].get_number_of_particles()
+        start = np.zeros(nd + 1, dtype=np.uint32)
+        total = C.c_size_t()
+        s, d = self.helpers[src_index].array_id, self.helpers[dst_index].array_id
+        dev._check(self.lib.sph_nnps_get_csr(self.ctx._h, s, d,
+                                             start.ctypes.data_as(dev._PU), None,
+                                             C.byref(total)))
+        return int(total.value)
+
     def get_nearest_particles(self, src_index, dst_index, d_idx, nbrs=None):
         """Neighbours of destination particle `d_idx` (ascending ids; the
         reference returns cell-traversal order unless sort_gids)."""
