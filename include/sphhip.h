@@ -49,7 +49,11 @@ enum sph_prop {
     SPH_AS00, SPH_AS01, SPH_AS02, SPH_AS11, SPH_AS12, SPH_AS22,
     SPH_R00, SPH_R01, SPH_R02, SPH_R11, SPH_R12, SPH_R22,
     SPH_S000, SPH_S010, SPH_S020, SPH_S110, SPH_S120, SPH_S220,
-    SPH_PROP_COUNT
+    /* user properties: slots named at run time with sph_prop_register (the
+     * reference's ParticleArray.add_property for equation-specific arrays,
+     * e.g. uf, ug, wij of the TVF wall equations)                           */
+    SPH_USER0,
+    SPH_PROP_COUNT = SPH_USER0 + 48
 };
 
 /* pysph/base/kernels.py class -> id */
@@ -190,6 +194,75 @@ int sph_nnps_reorder_array(sph_ctx *ctx, int array_id);
 /* ---------------------------------------------------------------------- */
 int sph_eval_group(sph_ctx *ctx, const sph_kernel *kernel, const sph_group *group,
                    double t, double dt);
+
+/* ---------------------------------------------------------------------- */
+/* user properties and generated equation families                          */
+/* replaces, for equations that are not hand-written in this library, the   */
+/* transpile-and-compile step of the reference (pysph/sph/equation.py       */
+/* :748-892 get_loop_code..., acceleration_eval_cython_helper.py:147-181):   */
+/* the host language translates the Equation bodies into a family struct    */
+/* for the pair-loop skeleton (pysph_amd/csrc/sph_pair.h), builds it with    */
+/* hipcc into its own shared object and hands the library the module's      */
+/* launch function.                                                          */
+/* ---------------------------------------------------------------------- */
+/* Id of the property called `name`: a built-in one, an already registered
+ * user slot, or a new user slot (process-wide table; <0: table full).       */
+int sph_prop_register(const char *name);
+
+#define SPH_GEN_MAX_PROPS 32
+#define SPH_GEN_MAX_SPROPS 20
+#define SPH_GEN_MAX_PAR 64
+
+/* What the library hands to a generated module's launch function: plain
+ * device pointers and scalars (the contents of PairArgs<Fam> in sph_pair.h). */
+typedef struct sph_gen_args {
+    void *stream;                 /* hipStream_t */
+    int kernel_kind, uniform_h;
+    int nsrc;                     /* 0: equations without sources only    */
+    const uint32_t *src_cell_start[SPH_MAX_ARRAYS];
+    uint32_t src_off[SPH_MAX_ARRAYS], src_flags[SPH_MAX_ARRAYS];
+    const double *rec;            /* packed records [x y z h | sprops...]  */
+    int nrec;                     /* doubles per record                    */
+    const void *fpos;             /* float4 prefilter positions            */
+    double dom_extent;
+    uint32_t d_off, nd;
+    const uint32_t *d_keys, *d_perm;
+    uint32_t d_start, d_stop, dflags;
+    int nc[3];
+    double xmin[3], cell_size, radius_scale;
+    double sigma, deltap;
+    int dim;
+    double t, dt;
+    double hu, h1u, facu, epsu, hr2u;
+    int n_din, n_dout, npar;
+    const double *din[SPH_GEN_MAX_PROPS];   /* destination props read      */
+    double *dout[SPH_GEN_MAX_PROPS];        /* destination props read-modify-written */
+    double par[SPH_GEN_MAX_PAR];
+} sph_gen_args;
+
+typedef int (*sph_gen_launch_fn)(const sph_gen_args *);
+
+/* One destination of one group, all of its equations generated.  Equation k
+ * of the family acts for source j iff bit k of src_flags[j] is set.          */
+typedef struct sph_gen_family {
+    sph_gen_launch_fn launch;
+    int dest;
+    int nsrc;
+    int src[SPH_MAX_ARRAYS];
+    uint32_t src_flags[SPH_MAX_ARRAYS];
+    int n_sprops, sprops[SPH_GEN_MAX_SPROPS]; /* source props in record order (after x y z h) */
+    int n_din, din[SPH_GEN_MAX_PROPS];
+    int n_dout, dout[SPH_GEN_MAX_PROPS];
+    int npar;
+    double par[SPH_GEN_MAX_PAR];
+    int real;                    /* Group(real=...)                          */
+    long start_idx, stop_idx;    /* Group(start_idx, stop_idx); <0: None     */
+} sph_gen_family;
+
+/* initialize -> no-source loops -> per-source pair loops -> post_loop of one
+ * generated family (the loop nest of acceleration_eval_cython.mako:10-154).  */
+int sph_eval_generated(sph_ctx *ctx, const sph_kernel *kernel, const sph_gen_family *family,
+                       double t, double dt);
 /* max over the first n_real particles of a property (dt_cfl, dt_force:
  * pysph/sph/integrator.py:161-200).                                        */
 int sph_reduce_max(sph_ctx *ctx, int array_id, int prop, double *out);

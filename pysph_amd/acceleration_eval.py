@@ -48,7 +48,13 @@ def check_equation_array_properties(equation, particle_arrays):
     """acceleration_eval.py:32-73: RuntimeError when a destination/source array
     or one of the properties the equation touches is missing."""
     arrays = dict((pa.name, pa) for pa in particle_arrays)
-    kind, vals, dprops, sprops = resolve_equation(equation)
+    try:
+        kind, vals, dprops, sprops = resolve_equation(equation)
+    except NotImplementedError:
+        from .codegen import has_python_body, method_properties
+        if not has_python_body(equation):
+            raise
+        dprops, sprops = method_properties(equation)
     if equation.dest not in arrays:
         raise RuntimeError("ERROR: Equation %s has invalid dest: '%s'" %
                            (equation.name, equation.dest))
@@ -149,15 +155,24 @@ def make_acceleration_evals(particle_arrays, equations, kernel, mode='serial',
             for g in groups]
 
 
-class _CGroup(object):
-    """One leaf group marshalled for ``sph_eval_group``."""
+def is_builtin(eq):
+    """hand-written kernel available (matched by class name, as
+    ``resolve_equation`` does)?"""
+    try:
+        resolve_equation(eq)
+        return True
+    except NotImplementedError:
+        return False
 
-    def __init__(self, group, array_ids, arrays):
+
+class _BuiltinUnit(object):
+    """Equations of one destination with hand-written kernels, marshalled for
+    ``sph_eval_group``."""
+
+    def __init__(self, group, eqs, array_ids, arrays, owner):
         self.group = group
-        eqs = group.equations
+        self.eqs = eqs
         self.ceqs = (dev.SphEquation * max(len(eqs), 1))()
-        self.inputs = defaultdict(set)    # array name -> props read
-        self.outputs = defaultdict(set)   # array name -> props written
         self._const_params = []
         for i, eq in enumerate(eqs):
             kind, vals, dprops, sprops = resolve_equation(eq)
@@ -173,20 +188,127 @@ class _CGroup(object):
                     self._const_params.append((i, k, eq.dest, v[1:]))
                 else:
                     ce.par[k] = v
-            self.inputs[eq.dest].update(dprops)
-            self.outputs[eq.dest].update(dprops)
+            owner.inputs[eq.dest].update(dprops)
+            owner.outputs[eq.dest].update(dprops)
             for s in srcs:
-                self.inputs[s].update(sprops)
+                owner.inputs[s].update(sprops)
         self.cg = dev.SphGroup()
         self.cg.real = 1 if group.real else 0
         self.cg.neq = len(eqs)
         self.cg.eqs = self.ceqs
         self._arrays = arrays
 
-    def refresh_range(self):
+    def refresh(self, start, stop):
         from .particle_array import get_npy as _get
         for i, k, dest, cname in self._const_params:
             self.ceqs[i].par[k] = float(_get(self._arrays[dest], cname)[0])
+        self.cg.start_idx, self.cg.stop_idx = start, stop
+
+    def run(self, ev, t, dt):
+        dev._check(ev.lib.sph_eval_group(
+            ev.ctx._h, C.byref(ev.ckernel), C.byref(self.cg), t, dt))
+
+
+class _GeneratedUnit(object):
+    """Equations of one destination WITHOUT hand-written kernels: translated
+    and compiled by ``pysph_amd.codegen`` and run through
+    ``sph_eval_generated``."""
+
+    def __init__(self, group, dest, eqs, array_ids, arrays, kernel_kind, owner,
+                 skip_initialize=()):
+        from .codegen import GeneratedFamily
+        self.group = group
+        self.eqs = eqs
+        self.fam = GeneratedFamily(dest, eqs, arrays, kernel_kind,
+                                   name='%s_%s' % (group.name, dest),
+                                   skip_initialize=skip_initialize)
+        f = self.fam
+        lib = f.load()
+        self.cf = dev.SphGenFamily()
+        self.cf.launch = C.cast(lib.sphgen_launch, C.c_void_p).value
+        self.cf.dest = array_ids[dest]
+        self.cf.nsrc = len(f.sources)
+        for j, sname in enumerate(f.sources):
+            self.cf.src[j] = array_ids[sname]
+            self.cf.src_flags[j] = f.src_flags[sname]
+        self.cf.n_sprops = len(f.sprops)
+        for k, p in enumerate(f.sprops):
+            self.cf.sprops[k] = dev.prop_register(p)
+        self.cf.n_din = len(f.din)
+        for k, p in enumerate(f.din):
+            self.cf.din[k] = dev.prop_register(p)
+        self.cf.n_dout = len(f.dout)
+        for k, p in enumerate(f.dout):
+            self.cf.dout[k] = dev.prop_register(p)
+        self.cf.npar = len(f.params)
+        self.cf.real = 1 if group.real else 0
+        owner.inputs[dest].update(f.dprops)
+        owner.outputs[dest].update(f.dout)
+        for sname in f.sources:
+            owner.inputs[sname].update(list(f.sprops) + ['x', 'y', 'z', 'h'])
+
+    def refresh(self, start, stop):
+        for k, v in enumerate(self.fam.param_values()):
+            self.cf.par[k] = v
+        self.cf.start_idx, self.cf.stop_idx = start, stop
+
+    def run(self, ev, t, dt):
+        dev._check(ev.lib.sph_eval_generated(
+            ev.ctx._h, C.addressof(ev.ckernel), C.addressof(self.cf), t, dt))
+
+
+class _CGroup(object):
+    """One leaf group: per destination (first-appearance order,
+    acceleration_eval.py:126-131) a unit with hand-written kernels and/or a
+    generated unit.
+
+    When a destination mixes both kinds, the hand-written unit runs first and
+    the generated one continues from the values in memory (``d_au[d_idx] += ..``
+    keeps its meaning; the sums only associate differently).  That is exact
+    with respect to the reference's initialize -> loops -> post_loop order as
+    long as the generated equations have no ``initialize`` (it would reset what
+    the first pass accumulated) -- which is checked."""
+
+    def __init__(self, group, array_ids, arrays, kernel_kind=None):
+        self.group = group
+        self.inputs = defaultdict(set)    # array name -> props read
+        self.outputs = defaultdict(set)   # array name -> props written
+        self.units = []
+        self._arrays = arrays
+        dests = []
+        for eq in group.equations:
+            if eq.dest not in dests:
+                dests.append(eq.dest)
+        for dest in dests:
+            eqs = [eq for eq in group.equations if eq.dest == dest]
+            builtin = [eq for eq in eqs if is_builtin(eq)]
+            custom = [eq for eq in eqs if not is_builtin(eq)]
+            if builtin:
+                self.units.append(_BuiltinUnit(group, builtin, array_ids, arrays, self))
+            if custom:
+                from .codegen import has_python_body, initialize_only_resets
+                skip = []
+                reset_by_builtin = set()
+                for eq in builtin:
+                    reset_by_builtin.update(resolve_equation(eq)[2])
+                for eq in custom:
+                    if not has_python_body(eq):
+                        resolve_equation(eq)     # raises the "no kernel" error
+                    if builtin and callable(getattr(type(eq), 'initialize', None)):
+                        # the hand-written pass has already run: an initialize
+                        # that only repeats its resets is dropped, anything
+                        # else cannot be ordered correctly
+                        if not initialize_only_resets(eq, reset_by_builtin):
+                            raise NotImplementedError(
+                                'destination %r mixes hand-written equations with '
+                                'the generated %s, whose initialize() would run '
+                                'after the hand-written pass; put it in its own '
+                                'group' % (dest, type(eq).__name__))
+                        skip.append(eq)
+                self.units.append(_GeneratedUnit(group, dest, custom, array_ids,
+                                                 arrays, kernel_kind, self, skip))
+
+    def refresh_range(self):
         g = self.group
         dest = self._arrays[g.equations[0].dest] if g.equations else None
 
@@ -197,8 +319,13 @@ class _CGroup(object):
                 from .particle_array import get_npy
                 return int(get_npy(dest, v)[0])
             return int(v)
-        self.cg.start_idx = resolve(g.start_idx, 0)
-        self.cg.stop_idx = resolve(g.stop_idx, -1)
+        start, stop = resolve(g.start_idx, 0), resolve(g.stop_idx, -1)
+        for u in self.units:
+            u.refresh(start, stop)
+
+    def run(self, ev, t, dt):
+        for u in self.units:
+            u.run(ev, t, dt)
 
 
 class HipAccelerationEval(object):
@@ -245,7 +372,7 @@ class HipAccelerationEval(object):
     def _plan_group(self, g, ids):
         if g.has_subgroups:
             return (g, [self._plan_group(sg, ids) for sg in g.equations])
-        return (g, _CGroup(g, ids, self.arrays))
+        return (g, _CGroup(g, ids, self.arrays, self.ckernel.kind))
 
     def _leaves(self, plan):
         for g, item in plan:
@@ -339,8 +466,7 @@ class HipAccelerationEval(object):
                 if hasattr(eq, 'py_initialize'):
                     eq.py_initialize(self.arrays[eq.dest], t, dt)
             item.refresh_range()
-            dev._check(self.lib.sph_eval_group(
-                self.ctx._h, C.byref(self.ckernel), C.byref(item.cg), t, dt))
+            item.run(self, t, dt)
             for eq in g.equations:
                 if hasattr(eq, 'reduce'):
                     eq.reduce(self.arrays[eq.dest], t, dt)

@@ -1,0 +1,725 @@
+"""Equation bodies -> HIP: the generated-family path of the HIP backend.
+
+The reference turns every ``Equation``'s Python methods into C through
+``compyle`` (pysph/sph/equation.py:748-892 ``get_*_code``,
+acceleration_eval_cython_helper.py:147-305) and drops them into the loop nest
+of acceleration_eval_cython.mako:10-154.  The hand-written families of
+``libsphhip`` cover the benchmark equation sets; for every other equation this
+module does the analogous step for gfx950:
+
+* the ``initialize / loop / post_loop`` methods of all equations acting on one
+  destination in one group are parsed (``ast``) and re-emitted as the
+  ``load / pair / finish`` members of a *family struct* for the pair-loop
+  skeleton ``csrc/sph_pair.h`` (the same aggregated two-phase kernel the
+  hand-written families use -- cell-ordered records, fp32 prefilter, exact
+  fp64 criterion, register accumulators, one write per output);
+* the struct is compiled by ``hipcc --offload-arch=gfx950`` into a shared
+  object of its own under ``pysph_amd/_gen/`` (cached by source hash) that
+  exports ``sphgen_launch``;
+* ``HipAccelerationEval`` hands that function pointer and the property / source
+  lists to ``sph_eval_generated`` (include/sphhip.h).
+
+Supported Python subset (what the reference's equations use): float
+arithmetic, comparisons, ``and/or/not``, conditional expressions, ``if/elif/
+else``, ``for i in range(..)``, local scalars, ``declare('matrix(n)')`` local
+arrays, augmented assignment, bare ``return``, the libm calls compyle maps
+(``sqrt pow exp log sin cos tan tanh fabs abs max min floor ceil atan2``),
+``M_PI``/``pi``, ``self.<scalar attribute>`` (copied by value when the family is
+built, like equation.py:885-892 does), ``d_<prop>[d_idx]``,
+``s_<prop>[s_idx]``, ``d_<constant>[k]`` and the precomputed symbols ``XIJ
+VIJ R2IJ RIJ HIJ RHOIJ RHOIJ1 EPS WIJ DWIJ WI WJ DWI DWJ t dt``
+(equation.py:188-297).  Anything else raises ``CodegenError`` -- the equation
+then has to be hand-written or simplified; there is no silent fallback.
+"""
+import ast
+import ctypes as C
+import hashlib
+import inspect
+import os
+import subprocess
+import textwrap
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
+GEN_DIR = os.path.join(_HERE, '_gen')
+
+VEC_SYMBOLS = ('XIJ', 'VIJ', 'DWIJ', 'DWI', 'DWJ')
+SCALAR_SYMBOLS = ('R2IJ', 'RIJ', 'HIJ', 'RHOIJ', 'RHOIJ1', 'EPS', 'WIJ', 'WI',
+                  'WJ', 't', 'dt')
+MATH_1 = {'sqrt': 'sqrt', 'exp': 'exp', 'log': 'log', 'sin': 'sin',
+          'cos': 'cos', 'tan': 'tan', 'tanh': 'tanh', 'fabs': 'fabs',
+          'abs': 'fabs', 'floor': 'floor', 'ceil': 'ceil', 'log10': 'log10',
+          'asin': 'asin', 'acos': 'acos', 'atan': 'atan', 'sinh': 'sinh',
+          'cosh': 'cosh', 'erf': 'erf'}
+MATH_2 = {'pow': 'pow', 'atan2': 'atan2', 'fmod': 'fmod'}
+CONSTANTS = {'M_PI': 'M_PI', 'pi': 'M_PI', 'M_1_PI': 'M_1_PI',
+             'M_2_SQRTPI': 'M_2_SQRTPI', 'M_PI_2': 'M_PI_2', 'INFINITY': 'INFINITY'}
+METHODS = ('initialize', 'loop', 'post_loop')
+UNSUPPORTED_METHODS = ('loop_all', 'initialize_pair')
+
+
+class CodegenError(Exception):
+    pass
+
+
+def has_python_body(eq):
+    """True when the object carries translatable method bodies (a reference
+    equation, or a user's own ``Equation`` subclass)."""
+    return any(callable(getattr(type(eq), m, None)) for m in METHODS)
+
+
+def method_properties(eq):
+    """(destination properties, source properties) named in the argument
+    lists of the equation's methods -- what the reference's
+    check_equation_array_properties inspects (acceleration_eval.py:32-73)."""
+    d, s = set(), set()
+    for m in METHODS:
+        fn = getattr(type(eq), m, None)
+        if fn is None:
+            continue
+        for a in inspect.getfullargspec(fn).args:
+            if a.startswith('d_') and a != 'd_idx':
+                d.add(a[2:])
+            elif a.startswith('s_') and a != 's_idx':
+                s.add(a[2:])
+    return sorted(d), sorted(s)
+
+
+def initialize_only_resets(eq, props):
+    """True when ``eq.initialize`` does nothing but assign literals to
+    ``d_<p>[d_idx]`` with every p in `props` -- i.e. it only repeats resets that
+    another equation on the same destination performs anyway."""
+    fdef = _method_ast(eq, 'initialize')
+    if fdef is None:
+        return True
+    for st in fdef.body:
+        if isinstance(st, ast.Expr) and isinstance(st.value, ast.Constant):
+            continue
+        if not (isinstance(st, ast.Assign) and len(st.targets) == 1
+                and isinstance(st.value, ast.Constant)
+                and isinstance(st.targets[0], ast.Subscript)
+                and isinstance(st.targets[0].value, ast.Name)
+                and st.targets[0].value.id.startswith('d_')
+                and st.targets[0].value.id[2:] in props):
+            return False
+    return True
+
+
+def _method_ast(eq, name):
+    fn = getattr(type(eq), name, None)
+    if fn is None:
+        return None
+    try:
+        src = textwrap.dedent(inspect.getsource(fn))
+    except (OSError, TypeError) as e:
+        raise CodegenError('%s.%s: source not available (%s)' %
+                           (type(eq).__name__, name, e))
+    tree = ast.parse(src)
+    return tree.body[0]
+
+
+class _Body(object):
+    """Translation of one method of one equation."""
+
+    def __init__(self, fam, eq, eq_index, kind, fdef):
+        self.fam = fam
+        self.eq = eq
+        self.k = eq_index
+        self.kind = kind            # 'initialize' | 'loop' | 'post_loop'
+        self.pair = kind == 'loop' and not fam.is_no_source(eq)
+        self.fdef = fdef
+        self.locals = {}            # name -> ('double', None) | ('array', n)
+        self.loop_vars = set()
+        self.where = '%s.%s' % (type(eq).__name__, kind)
+        self.lines = []
+        self._emit_block(fdef.body, 1)
+
+    # -- helpers -----------------------------------------------------------
+    def err(self, node, msg):
+        raise CodegenError('%s line %d: %s' % (self.where,
+                                               getattr(node, 'lineno', 0), msg))
+
+    def _self_param(self, node, attr):
+        if not hasattr(self.eq, attr):
+            self.err(node, 'self.%s is not set on the equation object' % attr)
+        val = getattr(self.eq, attr)
+        if isinstance(val, bool):
+            val = 1.0 if val else 0.0
+        if not isinstance(val, (int, float)):
+            try:
+                val = float(val)
+            except Exception:
+                self.err(node, 'self.%s is not a scalar (%r)' % (attr, type(val)))
+        return self.fam.param(('self', self.k, attr), float(val))
+
+    # -- expressions -------------------------------------------------------
+    def expr(self, n):
+        if isinstance(n, ast.Constant):
+            if isinstance(n.value, bool):
+                return '1.0' if n.value else '0.0'
+            if isinstance(n.value, (int, float)):
+                return repr(float(n.value))
+            self.err(n, 'constant %r' % (n.value,))
+        if isinstance(n, ast.Name):
+            return self.name(n)
+        if isinstance(n, ast.Attribute):
+            if isinstance(n.value, ast.Name) and n.value.id == 'self':
+                return self._self_param(n, n.attr)
+            if isinstance(n.value, ast.Name) and n.value.id in ('math', 'np', 'numpy', 'M'):
+                if n.attr in CONSTANTS:
+                    return CONSTANTS[n.attr]
+            self.err(n, 'attribute access %s' % ast.dump(n))
+        if isinstance(n, ast.Subscript):
+            return self.subscript(n, store=False)
+        if isinstance(n, ast.BinOp):
+            a, b = self.expr(n.left), self.expr(n.right)
+            if isinstance(n.op, ast.Add):
+                return '(%s + %s)' % (a, b)
+            if isinstance(n.op, ast.Sub):
+                return '(%s - %s)' % (a, b)
+            if isinstance(n.op, ast.Mult):
+                return '(%s * %s)' % (a, b)
+            if isinstance(n.op, ast.Div):
+                return '(%s / %s)' % (a, b)
+            if isinstance(n.op, ast.Mod):
+                return 'fmod(%s, %s)' % (a, b)
+            if isinstance(n.op, ast.Pow):
+                if isinstance(n.right, ast.Constant) and n.right.value == 2:
+                    return '(%s * %s)' % (a, a)
+                return 'pow(%s, %s)' % (a, b)
+            self.err(n, 'operator %s' % type(n.op).__name__)
+        if isinstance(n, ast.UnaryOp):
+            v = self.expr(n.operand)
+            if isinstance(n.op, ast.USub):
+                return '(-%s)' % v
+            if isinstance(n.op, ast.UAdd):
+                return v
+            if isinstance(n.op, ast.Not):
+                return '(!(%s))' % v
+            self.err(n, 'unary operator')
+        if isinstance(n, ast.BoolOp):
+            op = ' && ' if isinstance(n.op, ast.And) else ' || '
+            return '(' + op.join('(%s)' % self.expr(v) for v in n.values) + ')'
+        if isinstance(n, ast.Compare):
+            ops = {ast.Lt: '<', ast.Gt: '>', ast.LtE: '<=', ast.GtE: '>=',
+                   ast.Eq: '==', ast.NotEq: '!='}
+            parts, left = [], n.left
+            for op, right in zip(n.ops, n.comparators):
+                if type(op) not in ops:
+                    self.err(n, 'comparison %s' % type(op).__name__)
+                parts.append('(%s %s %s)' % (self.expr(left), ops[type(op)],
+                                             self.expr(right)))
+                left = right
+            return '(' + ' && '.join(parts) + ')'
+        if isinstance(n, ast.IfExp):
+            return '((%s) ? (%s) : (%s))' % (self.expr(n.test), self.expr(n.body),
+                                             self.expr(n.orelse))
+        if isinstance(n, ast.Call):
+            return self.call(n)
+        self.err(n, 'expression %s' % type(n).__name__)
+
+    def call(self, n):
+        f = n.func
+        fname = f.id if isinstance(f, ast.Name) else (
+            f.attr if isinstance(f, ast.Attribute) and isinstance(f.value, ast.Name)
+            and f.value.id in ('math', 'np', 'numpy', 'M') else None)
+        if fname is None or n.keywords:
+            self.err(n, 'call %s' % ast.dump(f))
+        args = [self.expr(a) for a in n.args]
+        if fname in MATH_1 and len(args) == 1:
+            return '%s(%s)' % (MATH_1[fname], args[0])
+        if fname in MATH_2 and len(args) == 2:
+            return '%s(%s, %s)' % (MATH_2[fname], args[0], args[1])
+        if fname in ('max', 'min') and len(args) >= 2:
+            fn = 'fmax' if fname == 'max' else 'fmin'
+            out = args[0]
+            for a in args[1:]:
+                out = '%s(%s, %s)' % (fn, out, a)
+            return out
+        if fname in ('float', 'double') and len(args) == 1:
+            return '((double)(%s))' % args[0]
+        self.err(n, 'call to %s()' % fname)
+
+    def name(self, n):
+        v = n.id
+        if v in self.loop_vars:
+            return v
+        if v in self.locals:
+            return v
+        if v in CONSTANTS:
+            return CONSTANTS[v]
+        if v in ('True', 'False'):
+            return '1.0' if v == 'True' else '0.0'
+        if v in SCALAR_SYMBOLS:
+            if v not in ('t', 'dt') and not self.pair:
+                self.err(n, 'pair symbol %s outside a pair loop' % v)
+            self.fam.use_symbol(v)
+            return v
+        if v in VEC_SYMBOLS:
+            self.err(n, 'vector symbol %s must be subscripted' % v)
+        if v in ('d_idx', 's_idx'):
+            self.err(n, '%s may only index a property array' % v)
+        self.err(n, 'unknown name %r (locals must be assigned before use)' % v)
+
+    def index(self, n):
+        """integer index expression (loop variables, literals, + - *)"""
+        if isinstance(n, ast.Constant) and isinstance(n.value, int):
+            return str(n.value)
+        if isinstance(n, ast.Name) and n.id in self.loop_vars:
+            return n.id
+        if isinstance(n, ast.BinOp) and isinstance(n.op, (ast.Add, ast.Sub, ast.Mult)):
+            op = {ast.Add: '+', ast.Sub: '-', ast.Mult: '*'}[type(n.op)]
+            return '(%s %s %s)' % (self.index(n.left), op, self.index(n.right))
+        self.err(n, 'array index must be an integer literal or a loop variable')
+
+    def subscript(self, n, store):
+        if not isinstance(n.value, ast.Name):
+            self.err(n, 'subscript of %s' % type(n.value).__name__)
+        base = n.value.id
+        sl = n.slice
+        if isinstance(sl, ast.Index):      # py<3.9
+            sl = sl.value
+        if base.startswith('d_'):
+            prop = base[2:]
+            if isinstance(sl, ast.Name) and sl.id == 'd_idx':
+                return self.fam.dest_prop(prop, store)
+            if self.fam.is_dest_constant(prop):
+                if store:
+                    self.err(n, 'constants are read-only here')
+                if not (isinstance(sl, ast.Constant) and isinstance(sl.value, int)):
+                    self.err(n, 'constant %s needs a literal index' % base)
+                return self.fam.param(('const', prop, sl.value), None)
+            self.err(n, '%s must be indexed with d_idx' % base)
+        if base.startswith('s_'):
+            prop = base[2:]
+            if store:
+                self.err(n, 'source arrays are read-only (gather formulation)')
+            if not self.pair:
+                self.err(n, '%s outside a pair loop' % base)
+            if isinstance(sl, ast.Name) and sl.id == 's_idx':
+                return self.fam.src_prop(prop)
+            self.err(n, '%s must be indexed with s_idx' % base)
+        if base in VEC_SYMBOLS:
+            if store:
+                self.err(n, 'precomputed symbols are read-only')
+            if not self.pair:
+                self.err(n, 'pair symbol %s outside a pair loop' % base)
+            self.fam.use_symbol(base)
+            return '%s[%s]' % (base, self.index(sl))
+        if base in self.locals and self.locals[base][0] == 'array':
+            return '%s[%s]' % (base, self.index(sl))
+        self.err(n, 'subscript of unknown array %r' % base)
+
+    # -- statements --------------------------------------------------------
+    def _emit(self, ind, text):
+        self.lines.append('    ' * ind + text)
+
+    def _emit_block(self, body, ind):
+        for st in body:
+            self._emit_stmt(st, ind)
+
+    def _declare_call(self, value):
+        """x = declare('matrix(3)') / declare('double')"""
+        if isinstance(value, ast.Call) and isinstance(value.func, ast.Name) \
+                and value.func.id == 'declare' and value.args \
+                and isinstance(value.args[0], ast.Constant):
+            spec = str(value.args[0].value).replace(' ', '')
+            if spec.startswith('matrix(') and spec.endswith(')'):
+                dims = spec[7:-1].strip('()').split(',')
+                n = 1
+                for d in dims:
+                    if d:
+                        n *= int(d)
+                return ('array', n)
+            if spec in ('double', 'float', 'int', 'long'):
+                return ('double', None)
+        return None
+
+    def _emit_stmt(self, st, ind):
+        if isinstance(st, ast.Expr):
+            if isinstance(st.value, ast.Constant):      # docstring
+                return
+            self.err(st, 'expression statement')
+        if isinstance(st, ast.Pass):
+            return
+        if isinstance(st, ast.Return):
+            if st.value is not None:
+                self.err(st, 'return with a value')
+            self._emit(ind, 'return;')
+            return
+        if isinstance(st, ast.Assign):
+            if len(st.targets) != 1:
+                self.err(st, 'chained assignment')
+            tgt = st.targets[0]
+            if isinstance(tgt, ast.Tuple):
+                if not isinstance(st.value, ast.Tuple) or len(tgt.elts) != len(st.value.elts):
+                    self.err(st, 'tuple assignment')
+                decl = [self._declare_call(v) for v in st.value.elts]
+                if all(d is not None for d in decl):
+                    for t_, d in zip(tgt.elts, decl):
+                        self._declare(t_, d, st)
+                    return
+                vals = [self.expr(v) for v in st.value.elts]
+                tmp = ['_t%d_%d' % (st.lineno, i) for i in range(len(vals))]
+                for tn, v in zip(tmp, vals):
+                    self._emit(ind, 'const double %s = %s;' % (tn, v))
+                for t_, tn in zip(tgt.elts, tmp):
+                    self._emit(ind, '%s = %s;' % (self._target(t_, st), tn))
+                return
+            d = self._declare_call(st.value)
+            if d is not None:
+                self._declare(tgt, d, st)
+                return
+            rhs = self.expr(st.value)
+            self._emit(ind, '%s = %s;' % (self._target(tgt, st), rhs))
+            return
+        if isinstance(st, ast.AugAssign):
+            ops = {ast.Add: '+=', ast.Sub: '-=', ast.Mult: '*=', ast.Div: '/='}
+            if type(st.op) not in ops:
+                self.err(st, 'augmented operator')
+            rhs = self.expr(st.value)
+            self._emit(ind, '%s %s %s;' % (self._target(st.target, st, aug=True),
+                                           ops[type(st.op)], rhs))
+            return
+        if isinstance(st, ast.If):
+            self._emit(ind, 'if (%s) {' % self.expr(st.test))
+            self._emit_block(st.body, ind + 1)
+            if st.orelse:
+                self._emit(ind, '} else {')
+                self._emit_block(st.orelse, ind + 1)
+            self._emit(ind, '}')
+            return
+        if isinstance(st, ast.For):
+            it = st.iter
+            if not (isinstance(st.target, ast.Name) and isinstance(it, ast.Call)
+                    and isinstance(it.func, ast.Name) and it.func.id == 'range'
+                    and 1 <= len(it.args) <= 2) or st.orelse:
+                self.err(st, 'only "for i in range(a[, b])" loops')
+            var = st.target.id
+            lo, hi = ('0', self.index(it.args[0])) if len(it.args) == 1 else \
+                (self.index(it.args[0]), self.index(it.args[1]))
+            fresh = var not in self.loop_vars
+            self.loop_vars.add(var)
+            self._emit(ind, 'for (int %s = %s; %s < %s; %s++) {' % (var, lo, var, hi, var))
+            self._emit_block(st.body, ind + 1)
+            self._emit(ind, '}')
+            if fresh:
+                self.loop_vars.discard(var)
+            return
+        self.err(st, 'statement %s' % type(st).__name__)
+
+    def _declare(self, tgt, d, st):
+        if not isinstance(tgt, ast.Name):
+            self.err(st, 'declare() target')
+        self.locals[tgt.id] = d
+
+    def _target(self, tgt, st, aug=False):
+        if isinstance(tgt, ast.Name):
+            if tgt.id in self.loop_vars or tgt.id in SCALAR_SYMBOLS or tgt.id in VEC_SYMBOLS:
+                self.err(st, 'assignment to %s' % tgt.id)
+            if tgt.id not in self.locals:
+                if aug:
+                    self.err(st, '%s used before assignment' % tgt.id)
+                self.locals[tgt.id] = ('double', None)
+            return tgt.id
+        if isinstance(tgt, ast.Subscript):
+            return self.subscript(tgt, store=True)
+        self.err(st, 'assignment target %s' % type(tgt).__name__)
+
+    def code(self, ind):
+        """the body wrapped in an immediately invoked lambda: locals are
+        hoisted to its top, a bare ``return`` leaves just this equation"""
+        pad = '    ' * ind
+        out = [pad + '[&]() {  // %s' % self.where]
+        for name, (kind, n) in sorted(self.locals.items()):
+            if kind == 'array':
+                out.append(pad + '    double %s[%d] = {};' % (name, n))
+            else:
+                out.append(pad + '    double %s = 0.0;' % name)
+        for ln in self.lines:
+            out.append(pad + ln)
+        out.append(pad + '}();')
+        return '\n'.join(out)
+
+
+class GeneratedFamily(object):
+    """All equations of one group acting on one destination, generated."""
+
+    def __init__(self, dest, equations, arrays, kernel_kind, name=None,
+                 skip_initialize=()):
+        if len(equations) > 32:
+            raise CodegenError('more than 32 equations on one destination')
+        self.dest = dest
+        self.equations = list(equations)
+        self.arrays = arrays
+        self.kernel_kind = int(kernel_kind)
+        self.name = name or 'gen'
+        self.dprops = []        # dest props, order of first use
+        self.dwritten = set()
+        self.sprops = []        # source props packed into the records
+        self.symbols = set()
+        self.params = []        # [(key, value)]
+        self.sources = []       # first-appearance order (acceleration_eval.py:136-151)
+        self.src_flags = {}
+        for k, eq in enumerate(self.equations):
+            for m in UNSUPPORTED_METHODS:
+                if callable(getattr(type(eq), m, None)):
+                    raise CodegenError('%s.%s is not supported by the generated path'
+                                       % (type(eq).__name__, m))
+            for s in (eq.sources or []):
+                if s not in self.sources:
+                    self.sources.append(s)
+                    self.src_flags[s] = 0
+                self.src_flags[s] |= 1 << k
+        self.bodies = {m: [] for m in METHODS}
+        self.nosrc_loops = []
+        for k, eq in enumerate(self.equations):
+            for m in METHODS:
+                fdef = _method_ast(eq, m)
+                if fdef is None or (m == 'initialize' and eq in skip_initialize):
+                    continue
+                b = _Body(self, eq, k, m, fdef)
+                if m == 'loop' and self.is_no_source(eq):
+                    self.nosrc_loops.append(b)
+                else:
+                    self.bodies[m].append(b)
+        if 'VIJ' in self.symbols:
+            for p in 'uvw':
+                self.dest_prop(p, False)
+                self.src_prop(p)
+        if self.symbols & {'RHOIJ', 'RHOIJ1'}:
+            self.dest_prop('rho', False)
+            self.src_prop('rho')
+        if len(self.sprops) > 20:
+            raise CodegenError('more than 20 source properties in one family')
+        if len(self.dprops) > 32:
+            raise CodegenError('more than 32 destination properties in one family')
+        if len(self.params) > 64:
+            raise CodegenError('more than 64 scalar parameters in one family')
+        self.source = self._emit_source()
+        self.hash = hashlib.sha1(self.source.encode()).hexdigest()[:16]
+        self.lib = None
+
+    # -- bookkeeping used by the bodies -------------------------------------
+    @staticmethod
+    def is_no_source(eq):
+        return not eq.sources
+
+    def is_dest_constant(self, name):
+        pa = self.arrays.get(self.dest)
+        return pa is not None and name in getattr(pa, 'constants', {})
+
+    def dest_prop(self, prop, store):
+        if prop not in self.dprops:
+            self.dprops.append(prop)
+        if store:
+            self.dwritten.add(prop)
+        return 'D.d_%s' % prop
+
+    def src_prop(self, prop):
+        if prop in ('x', 'y', 'z', 'h'):
+            return {'x': 'pj.x', 'y': 'pj.y', 'z': 'pj.z', 'h': 's_h'}[prop]
+        if prop not in self.sprops:
+            self.sprops.append(prop)
+        return 's_%s' % prop
+
+    def use_symbol(self, s):
+        self.symbols.add(s)
+
+    def param(self, key, value):
+        for i, (k, _) in enumerate(self.params):
+            if k == key:
+                return 'PAR[%d]' % i
+        self.params.append((key, value))
+        return 'PAR[%d]' % (len(self.params) - 1)
+
+    def param_values(self):
+        """current values: self.* are frozen at build time (equation.py:885-892),
+        array constants are read at every compute (they may be updated)."""
+        from .particle_array import get_npy
+        out = []
+        for key, val in self.params:
+            if key[0] == 'const':
+                out.append(float(get_npy(self.arrays[self.dest], key[1])[key[2]]))
+            else:
+                out.append(val)
+        return out
+
+    # -- emission -----------------------------------------------------------
+    def _emit_source(self):
+        din = [p for p in self.dprops if p not in self.dwritten]
+        dout = [p for p in self.dprops if p in self.dwritten]
+        self.din, self.dout = din, dout
+        na = max(2, (len(self.sprops) + 1) & ~1)
+        S = self.symbols
+        L = []
+        A = L.append
+        A('// generated by pysph_amd/codegen.py -- do not edit')
+        A('// destination: %s; equations: %s' % (
+            self.dest, ', '.join(type(e).__name__ for e in self.equations)))
+        A('#include "sph_pair.h"')
+        A('#include <cstring>')
+        A('')
+        A('struct FamGen {')
+        A('    static constexpr int MINB = 3;')
+        A('    static constexpr int NA = %d;' % na)
+        A('    static constexpr int NR = 4 + NA;')
+        A('    struct Params {')
+        A('        const double *din[%d];' % max(len(din), 1))
+        A('        double *dout[%d];' % max(len(dout), 1))
+        A('        double par[%d];' % max(len(self.params), 1))
+        A('    };')
+        A('    struct Dest {')
+        for p in self.dprops:
+            A('        double d_%s;' % p)
+        if not self.dprops:
+            A('        double unused_;')
+        A('    };')
+        # ---- load = memory -> registers, initialize, no-source loops
+        A('    template <class A> static __device__ __forceinline__ void load(Dest &D, const double *, const A &a, uint32_t o)')
+        A('    {')
+        A('        const double *PAR = a.p.par; (void)PAR;')
+        A('        const double t = a.t, dt = a.dt; (void)t; (void)dt;')
+        for i, p in enumerate(din):
+            A('        D.d_%s = a.p.din[%d][o];' % (p, i))
+        for i, p in enumerate(dout):
+            A('        D.d_%s = a.p.dout[%d][o];' % (p, i))
+        for b in self.bodies['initialize']:
+            A(b.code(2))
+        for b in self.nosrc_loops:
+            A(b.code(2))
+        A('    }')
+        # ---- pair
+        A('    template <int KK, bool UH, class A>')
+        A('    static __device__ __forceinline__ void pair(Dest &D, const double4 &pi, const double4 &pj, double r2,')
+        A('                                                const double (&s)[NA], uint32_t fl, const A &a)')
+        A('    {')
+        A('        const double *PAR = a.p.par; (void)PAR;')
+        A('        const double t = a.t, dt = a.dt; (void)t; (void)dt;')
+        A('        PairGeom g;')
+        A('        pair_geom<KK, UH>(g, pi, pj, r2, a);')
+        A('        const double XIJ[3] = {g.xij[0], g.xij[1], g.xij[2]}; (void)XIJ;')
+        A('        const double R2IJ = r2, RIJ = g.rij, HIJ = g.hij, EPS = g.eps; (void)R2IJ; (void)RIJ; (void)HIJ; (void)EPS;')
+        A('        const double s_h = UH ? a.hu : pj.w; (void)s_h;')
+        for i, p in enumerate(self.sprops):
+            A('        const double s_%s = s[%d];' % (p, i))
+        if 'VIJ' in S:
+            A('        const double VIJ[3] = {D.d_u - s_u, D.d_v - s_v, D.d_w - s_w};')
+        if S & {'RHOIJ', 'RHOIJ1'}:
+            A('        const double RHOIJ = 0.5 * (D.d_rho + s_rho); (void)RHOIJ;')
+            A('        const double RHOIJ1 = 1.0 / RHOIJ; (void)RHOIJ1;')
+        if 'WIJ' in S:
+            A('        const double WIJ = pair_w<KK, UH>(g);')
+        if 'DWIJ' in S:
+            A('        const double tg_ = pair_gradfac<KK, UH>(g);')
+            A('        const double DWIJ[3] = {tg_ * XIJ[0], tg_ * XIJ[1], tg_ * XIJ[2]};')
+        if S & {'WI', 'DWI', 'WJ', 'DWJ'}:
+            # kernels evaluated with h_d / h_s (equation.py:262-297)
+            A('        PairGeom gi = g, gj = g;')
+            A('        if (!UH) {')
+            A('            gi.hij = pi.w; gi.h1 = 1.0 / pi.w; gi.fac = kernel_norm(a.k.sigma, gi.h1, a.k.dim); gi.q = g.rij * gi.h1;')
+            A('            gj.hij = pj.w; gj.h1 = 1.0 / pj.w; gj.fac = kernel_norm(a.k.sigma, gj.h1, a.k.dim); gj.q = g.rij * gj.h1;')
+            A('        }')
+            if 'WI' in S:
+                A('        const double WI = pair_w<KK, false>(gi);')
+            if 'WJ' in S:
+                A('        const double WJ = pair_w<KK, false>(gj);')
+            if 'DWI' in S:
+                A('        const double tgi_ = pair_gradfac<KK, false>(gi);')
+                A('        const double DWI[3] = {tgi_ * XIJ[0], tgi_ * XIJ[1], tgi_ * XIJ[2]};')
+            if 'DWJ' in S:
+                A('        const double tgj_ = pair_gradfac<KK, false>(gj);')
+                A('        const double DWJ[3] = {tgj_ * XIJ[0], tgj_ * XIJ[1], tgj_ * XIJ[2]};')
+        for b in self.bodies['loop']:
+            A('        if (fl & %du) {' % (1 << b.k))
+            A(b.code(3))
+            A('        }')
+        A('    }')
+        # ---- finish = post_loop + stores
+        A('    template <class A> static __device__ __forceinline__ void finish(Dest &D, const A &a, uint32_t o)')
+        A('    {')
+        A('        const double *PAR = a.p.par; (void)PAR;')
+        A('        const double t = a.t, dt = a.dt; (void)t; (void)dt;')
+        for b in self.bodies['post_loop']:
+            A(b.code(2))
+        for i, p in enumerate(dout):
+            A('        a.p.dout[%d][o] = D.d_%s;' % (i, p))
+        A('    }')
+        A('};')
+        A('')
+        A('__global__ __launch_bounds__(256) void k_gen_nosrc(PairArgs<FamGen> a)')
+        A('{')
+        A('    const size_t i = (size_t)a.d_start + (size_t)blockIdx.x * 256 + threadIdx.x;')
+        A('    if (i >= a.d_stop) return;')
+        A('    FamGen::Dest D;')
+        A('    FamGen::load(D, nullptr, a, (uint32_t)i);')
+        A('    FamGen::finish(D, a, (uint32_t)i);')
+        A('}')
+        A('')
+        A('extern "C" int sphgen_kernel_kind(void) { return %d; }' % self.kernel_kind)
+        A('')
+        A('extern "C" int sphgen_launch(const sph_gen_args *g)')
+        A('{')
+        A('    if (g->kernel_kind != %d) return -1000;' % self.kernel_kind)
+        A('    if (g->n_din != %d || g->n_dout != %d || g->npar != %d) return -1001;' % (
+            len(din), len(dout), len(self.params)))
+        A('    PairArgs<FamGen> a;')
+        A('    memset(&a, 0, sizeof a);')
+        A('    a.nsrc = g->nsrc;')
+        A('    for (int j = 0; j < g->nsrc; j++) a.src[j] = {g->src_cell_start[j], g->src_off[j], g->src_flags[j]};')
+        A('    a.rec = g->rec; a.nrec = g->nrec; a.fpos = (const float4 *)g->fpos; a.dom_extent = g->dom_extent;')
+        A('    a.d_off = g->d_off; a.nd = g->nd; a.d_keys = g->d_keys; a.d_perm = g->d_perm;')
+        A('    a.d_start = g->d_start; a.d_stop = g->d_stop; a.dflags = g->dflags;')
+        A('    for (int k = 0; k < 3; k++) { a.nc[k] = g->nc[k]; a.xmin[k] = g->xmin[k]; }')
+        A('    a.cell_size = g->cell_size; a.radius_scale = g->radius_scale;')
+        A('    a.k.sigma = g->sigma; a.k.deltap = g->deltap; a.k.dim = g->dim;')
+        A('    a.t = g->t; a.dt = g->dt;')
+        A('    a.hu = g->hu; a.h1u = g->h1u; a.facu = g->facu; a.epsu = g->epsu; a.hr2u = g->hr2u;')
+        A('    for (int k = 0; k < g->n_din; k++) a.p.din[k] = g->din[k];')
+        A('    for (int k = 0; k < g->n_dout; k++) a.p.dout[k] = g->dout[k];')
+        A('    for (int k = 0; k < g->npar; k++) a.p.par[k] = g->par[k];')
+        A('    hipStream_t st = (hipStream_t)g->stream;')
+        A('    if (g->nsrc == 0) {')
+        A('        const size_t n = (size_t)g->d_stop - g->d_start;')
+        A('        hipLaunchKernelGGL(k_gen_nosrc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);')
+        A('    } else {')
+        A('        if (g->nrec != FamGen::NR) return -1002;')
+        A('        dim3 grid((a.nd + ABS - 1) / ABS), block(ABS);')
+        A('        if (g->uniform_h) hipLaunchKernelGGL((k_pair_agg<FamGen, %d, true>), grid, block, 0, st, a);' % self.kernel_kind)
+        A('        else hipLaunchKernelGGL((k_pair_agg<FamGen, %d, false>), grid, block, 0, st, a);' % self.kernel_kind)
+        A('    }')
+        A('    return (int)hipGetLastError();')
+        A('}')
+        return '\n'.join(L) + '\n'
+
+    # -- build / load ---------------------------------------------------------
+    def so_path(self):
+        return os.path.join(GEN_DIR, 'fam_%s_%s.so' % (self.name, self.hash))
+
+    def build(self, force=False):
+        """hipcc the family into its own shared object (cached by hash)."""
+        os.makedirs(GEN_DIR, exist_ok=True)
+        so = self.so_path()
+        if os.path.exists(so) and not force:
+            return so
+        src = so[:-3] + '.hip'
+        with open(src, 'w') as f:
+            f.write(self.source)
+        hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+        cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC',
+               '-shared', '-I', CSRC, '-I', INCLUDE, src, '-o', so + '.tmp']
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           universal_newlines=True)
+        if r.returncode != 0:
+            raise CodegenError('hipcc failed for %s:\n%s\n--- source: %s' %
+                               (self.name, r.stdout[-4000:], src))
+        os.replace(so + '.tmp', so)
+        return so
+
+    def load(self):
+        if self.lib is None:
+            self.lib = C.CDLL(self.build())
+            self.lib.sphgen_launch.restype = C.c_int
+            self.lib.sphgen_launch.argtypes = [C.c_void_p]
+        return self.lib

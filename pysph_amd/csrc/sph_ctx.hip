@@ -52,7 +52,7 @@ ScopedTimer::~ScopedTimer()
     c->timers[key].pending.emplace_back(a, b);
 }
 
-static const char *PROP_NAMES[SPH_PROP_COUNT] = {
+static const char *PROP_NAMES[SPH_USER0] = {
     "x", "y", "z", "u", "v", "w", "h", "m", "rho", "p", "cs",
     "arho", "au", "av", "aw", "ax", "ay", "az", "dt_cfl", "dt_force",
     "V", "uhat", "vhat", "what", "auhat", "avhat", "awhat",
@@ -69,11 +69,29 @@ extern "C" {
 const char *sph_last_error(void) { return g_err; }
 const char *sph_version(void) { return "sphhip 0.1 (gfx950)"; }
 
+// user property names (process-wide: ids must agree between contexts/ranks
+// that register the same names in the same order)
+static char g_user_names[SPH_PROP_COUNT - SPH_USER0][48];
+static int g_n_user = 0;
+
 int sph_prop_id(const char *name)
 {
-    for (int i = 0; i < SPH_PROP_COUNT; i++)
+    if (!name) return -1;
+    for (int i = 0; i < SPH_USER0; i++)
         if (strcmp(name, PROP_NAMES[i]) == 0) return i;
+    for (int i = 0; i < g_n_user; i++)
+        if (strcmp(name, g_user_names[i]) == 0) return SPH_USER0 + i;
     return -1;
+}
+
+int sph_prop_register(const char *name)
+{
+    int id = sph_prop_id(name);
+    if (id >= 0) return id;
+    if (!name || !name[0] || strlen(name) >= sizeof g_user_names[0]) { sph_set_error("sph_prop_register: bad name"); return SPH_ERR_ARG; }
+    if (g_n_user >= SPH_PROP_COUNT - SPH_USER0) { sph_set_error("sph_prop_register: all %d user property slots are taken", SPH_PROP_COUNT - SPH_USER0); return SPH_ERR_ARG; }
+    strcpy(g_user_names[g_n_user], name);
+    return SPH_USER0 + g_n_user++;
 }
 
 int sph_ctx_create(int device, void *stream, sph_ctx **out)

@@ -25,20 +25,10 @@
 //     the fp32 test in front of it is a conservative superset filter.
 #include "sph_internal.h"
 #include "sph_kernels.h"
+#include "sph_pair.h"
 
 #include <cfloat>
 #include <cmath>
-
-// ---------------------------------------------------------------------------
-// exact (non-contracted) squared distance: must round like the reference's
-// norm2 (nnps_base.pxd:36-37) so that neighbour SETS are identical.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ double r2_exact(double dx, double dy, double dz)
-{
-#pragma clang fp contract(off)
-    const double a = dx * dx, b = dy * dy, c = dz * dz;
-    return (a + b) + c;
-}
 
 // ---------------------------------------------------------------------------
 // equations without sources (elementwise)
@@ -186,12 +176,6 @@ enum { F_CONT = 1, F_MOM = 2, F_XSPH = 4, F_TENSILE = 8,               // WCSPH
        F_SD = 1, F_TVFSD = 2,                                           // density
        F_TP = 1, F_TVISC = 2, F_TAV = 4, F_TAS = 8 };                   // TVF force
 
-struct KernelConst {
-    double sigma;  // kernel.fac
-    double deltap; // kernel.get_deltap()
-    int dim;
-};
-
 #define MAX_AUX 20
 struct PackArgs {
     const uint32_t *perm;
@@ -207,7 +191,8 @@ struct PackArgs {
     double *aux;
     double *rec;                  // non-null: interleaved records [x y z h aux... pad], nr doubles each
     int nr;
-    int split_wcsph;              // 1: record layout [x y z cs | u v w m | rho tmpj | h p] (aggregated kernel)
+    int layout;                   // 0: [x y z h | aux...]; 1: WCSPH [x y z cs | u v w m | rho tmpj | h p]; 2: density [x y z m]
+                                  // (1, 2: aggregated kernel only)
     float4 *fpos;                 // non-null: fp32 {x-xmin, y-ymin, z-zmin, radius_scale*h} for the prefilter tiles
     double gmin[3];
     double radius_scale;
@@ -238,7 +223,7 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
     if (a.rec) {
         // 32-B stores: every store covers whole sectors of the record
         double4 *r = reinterpret_cast<double4 *>(a.rec + (a.off + i) * (size_t)a.nr);
-        if (a.split_wcsph) {
+        if (a.layout == 1) {
             // 16-B stores: compact records (nr == 10) are only 16-B aligned
             double2 *r2 = reinterpret_cast<double2 *>(r);
             r2[0] = make_double2(ph.x, ph.y); r2[1] = make_double2(ph.z, v[6]);
@@ -247,7 +232,7 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
             if (a.nr > 10) r2[5] = make_double2(ph.w, v[7]);
             return;
         }
-        if (a.nr == 4) { // compact density records [x y z m] (uniform h)
+        if (a.layout == 2) { // compact density records [x y z m] (uniform h)
             r[0] = make_double4(ph.x, ph.y, ph.z, v[0]);
             return;
         }
@@ -268,117 +253,6 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
     }
 }
 
-struct SrcDesc {
-    const uint32_t *cell_start;
-    uint32_t off;    // offset of this source's segment in the packed buffers
-    uint32_t flags;  // equations acting for this (dest, source) pair
-};
-
-template <class Fam> struct PairArgs {
-    int nsrc;
-    SrcDesc src[SPH_MAX_ARRAYS];
-    const double4 *posh;
-    const double *aux;
-    const double *rec; // variant 2: interleaved records, Fam::NR doubles each
-    int nrec;          // variant 3: doubles per record (Fam::NR, or 10 for compact WCSPH records)
-    const float4 *fpos; // variant 3: fp32 grid-relative positions + radius_scale*h (prefilter only)
-    double dom_extent;  // largest grid extent: bounds the fp32 rounding of fpos
-    uint32_t d_off, nd;
-    const uint32_t *d_keys, *d_perm;
-    uint32_t d_start, d_stop;
-    int nc[3];
-    double xmin[3];
-    double cell_size;
-    double radius_scale;
-    KernelConst k;
-    uint32_t dflags; // union of the source flags
-    int ablate;      // profiling only: 1 = skip pair arithmetic, 2 = skip phase 2
-    double t;
-    // constants of the uniform-h specialisation (hmin == hmax over all arrays)
-    double hu, h1u, facu, epsu, hr2u;
-    typename Fam::Params p;
-};
-
-// ---------------------------------------------------------------------------
-// fast fp64 reciprocal / square root: hardware estimate + two Newton steps
-// (error ~1 ulp; no div_scale/div_fixup range handling -- operands here are
-// densities, distances and smoothing lengths, far from the fp64 range limits).
-// The 1e-10 parity budget (BASELINE.json) absorbs the ~1e-16 differences.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ double fast_rcp(double d)
-{
-    double x = __builtin_amdgcn_rcp(d);
-    double e = fma(-d, x, 1.0);
-    x = fma(x, e, x);
-    e = fma(-d, x, 1.0);
-    x = fma(x, e, x);
-    return x;
-}
-// s = sqrt(a), rs = 1/sqrt(a).  a is clamped to 1e-300 so that coincident
-// particles (a == 0: the self pair) give finite s ~ 1e-150, rs ~ 1e150; every
-// use of rs multiplies it with a factor that is exactly 0 for such pairs
-// (XIJ, or h*VIJ.XIJ), and the gradient has the reference's own r > 1e-12 guard.
-__device__ __forceinline__ void fast_sqrt_rsqrt(double a, double &s, double &rs)
-{
-    a = fmax(a, 1e-300);
-    double y = __builtin_amdgcn_rsq(a);
-    double g = a * y, h = 0.5 * y;
-    double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    s = g;
-    rs = h + h;
-}
-
-// per-pair geometry shared by all families
-struct PairGeom {
-    double xij[3];
-    double r2, rij, rinv, hij, h1, q, fac, eps;
-};
-
-// UH: every particle has the same h -> HIJ, 1/HIJ, the kernel normalisation
-// and EPS are launch constants.
-template <int KK, bool UH, class A>
-__device__ __forceinline__ void pair_geom(PairGeom &g, const double4 &pi, const double4 &pj, double r2, const A &a)
-{
-    g.xij[0] = pi.x - pj.x; g.xij[1] = pi.y - pj.y; g.xij[2] = pi.z - pj.z; // XIJ equation.py:205-212
-    g.r2 = r2;                                                               // R2IJ :226-233
-    fast_sqrt_rsqrt(r2, g.rij, g.rinv);                                      // RIJ  :235
-    if (UH) {
-        g.hij = a.hu; g.h1 = a.h1u; g.fac = a.facu; g.eps = a.epsu;
-    } else {
-        g.hij = 0.5 * (pi.w + pj.w);                                         // HIJ  :192
-        g.h1 = fast_rcp(g.hij);
-        g.fac = kernel_norm(a.k.sigma, g.h1, a.k.dim);
-        g.eps = 0.01 * g.hij * g.hij;                                        // EPS  :194
-    }
-    g.q = g.rij * g.h1;
-}
-template <int KK, bool UH> __device__ __forceinline__ double pair_w(const PairGeom &g) { return SphKernel<KK>::template w<UH>(g.q) * g.fac; }
-// GRADIENT(XIJ, RIJ, HIJ, DWIJ) (kernels.py:126-137) returns tmp*xij with
-// tmp = dwdq*h1/rij; here tmp only.  dw(q)/rij = dwq(q)*h1 when the kernel has
-// a closed form for dw/q.
-template <int KK, bool UH> __device__ __forceinline__ double pair_gradfac(const PairGeom &g)
-{
-    double t;
-    if (SphKernel<KK>::HAS_DWQ) t = SphKernel<KK>::template dwq<UH>(g.q) * (g.fac * g.h1 * g.h1);
-    else t = SphKernel<KK>::template dw<UH>(g.q) * (g.fac * g.h1) * g.rinv;
-    return g.rij > 1e-12 ? t : 0.0;
-}
-
-// Record access for the aggregated kernel.  Default layout: [x y z h | aux...].
-template <class Fam, bool UH>
-__device__ __forceinline__ void load_record(const double *__restrict__ rj, uint32_t fl, double4 &pj, double (&s)[Fam::NA])
-{
-    pj = *reinterpret_cast<const double4 *>(rj);
-#pragma unroll
-    for (int k = 0; k < Fam::NA; k++) s[k] = rj[4 + k];
-}
-
-// ---- WCSPH: Continuity + Momentum + XSPH (wc/basic.py, basic_equations.py) --
 struct FamWCSPH {
     static constexpr int MINB = 4; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
     static constexpr int NA = 8; // u v w m rho tmpj(=p/rho^2) cs p
@@ -391,7 +265,7 @@ struct FamWCSPH {
         double u, v, w, rho, p, cs, tmpi;
         double arho, au, av, aw, ax, ay, az, dt_cfl;
     };
-    static __device__ __forceinline__ void load(Dest &D, const double *a)
+    template <class A> static __device__ __forceinline__ void load(Dest &D, const double *a, const A &, uint32_t)
     {
         D.u = a[0]; D.v = a[1]; D.w = a[2]; D.rho = a[4]; D.tmpi = a[5]; D.cs = a[6]; D.p = a[7];
         D.arho = D.au = D.av = D.aw = D.ax = D.ay = D.az = D.dt_cfl = 0.0;
@@ -498,7 +372,7 @@ struct FamDensity {
     static constexpr int NR = 6;  // x y z h m pad
     struct Params { double *rho, *V; };
     struct Dest { double m, rho, V; };
-    static __device__ __forceinline__ void load(Dest &D, const double *a) { D.m = a[0]; D.rho = 0.0; D.V = 0.0; }
+    template <class A> static __device__ __forceinline__ void load(Dest &D, const double *a, const A &, uint32_t) { D.m = a[0]; D.rho = 0.0; D.V = 0.0; }
     template <int KK, bool UH, class A>
     static __device__ __forceinline__ void pair(Dest &D, const double4 &pi, const double4 &pj, double r2,
                                                 const double (&s)[NA], uint32_t fl, const A &a)
@@ -539,7 +413,7 @@ struct FamTVF {
         double u, v, w, uh, vh, wh, rho, p, Vi2, mi1;
         double au, av, aw, auh, avh, awh;
     };
-    static __device__ __forceinline__ void load(Dest &D, const double *a)
+    template <class A> static __device__ __forceinline__ void load(Dest &D, const double *a, const A &, uint32_t)
     {
         D.u = a[0]; D.v = a[1]; D.w = a[2]; D.uh = a[3]; D.vh = a[4]; D.wh = a[5];
         D.rho = a[6]; D.p = a[7]; D.Vi2 = a[10]; D.mi1 = 1.0 / a[9];
@@ -615,7 +489,7 @@ struct FamVGrad {
     static constexpr int NR = 8;
     struct Params { double *v[9]; };
     struct Dest { double u, v, w; double g[9]; };
-    static __device__ __forceinline__ void load(Dest &D, const double *a)
+    template <class A> static __device__ __forceinline__ void load(Dest &D, const double *a, const A &, uint32_t)
     {
         D.u = a[0]; D.v = a[1]; D.w = a[2];
         for (int k = 0; k < 9; k++) D.g[k] = 0.0;
@@ -663,7 +537,7 @@ struct FamElastic {
         double u, v, w, rho, cs, t[6], r[6];
         double arho, au, av, aw, ax, ay, az;
     };
-    static __device__ __forceinline__ void load(Dest &D, const double *a)
+    template <class A> static __device__ __forceinline__ void load(Dest &D, const double *a, const A &, uint32_t)
     {
         D.u = a[0]; D.v = a[1]; D.w = a[2]; D.rho = a[4]; D.cs = a[5];
         for (int k = 0; k < 6; k++) { D.t[k] = a[6 + k]; D.r[k] = a[12 + k]; }
@@ -731,20 +605,6 @@ struct FamElastic {
 };
 
 // ---------------------------------------------------------------------------
-// XCD-aware block remap (MI355X: 8 XCDs, block b runs on XCD b % 8, each XCD
-// has a private 4 MiB L2).  Consecutive tiles of the cell-ordered destination
-// array share their 3x3 neighbour rows, so give every XCD one CONTIGUOUS chunk
-// of tiles: the rows a workgroup gathers from are then already in its XCD's L2.
-// Placement only affects speed, never results.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nb)
-{
-    const uint32_t xcd = b & 7u, idx = b >> 3;
-    const uint32_t base = nb >> 3, rem = nb & 7u;
-    return xcd * base + min(xcd, rem) + idx;
-}
-
-// ---------------------------------------------------------------------------
 // variant 0: per-lane walk over the 3x3 rows of cells (x-contiguous ranges)
 // ---------------------------------------------------------------------------
 template <class Fam> __device__ __forceinline__ void load_aux(double (&s)[Fam::NA], const double *__restrict__ p)
@@ -761,7 +621,7 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256) void k_p
     if (o < a.d_start || o >= a.d_stop) return;
     double4 pi = a.posh[a.d_off + i];
     typename Fam::Dest D;
-    Fam::load(D, a.aux + (size_t)(a.d_off + i) * Fam::NA);
+    Fam::load(D, a.aux + (size_t)(a.d_off + i) * Fam::NA, a, o);
     uint32_t key = a.d_keys[i];
     int cx = key % a.nc[0];
     int t = key / a.nc[0];
@@ -827,7 +687,7 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256) void k_p
     const double *drec = a.rec + (size_t)(a.d_off + ic) * NR;
     const double4 pi = *reinterpret_cast<const double4 *>(drec);
     typename Fam::Dest D;
-    Fam::load(D, drec + 4);
+    Fam::load(D, drec + 4, a, o);
     const uint32_t key = a.d_keys[ic];
     const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
     const int cx = key % ncx;
@@ -940,229 +800,6 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256) void k_p
                         __syncthreads(); // tile is overwritten next
                     }
                 }
-        }
-    }
-    if (active) Fam::finish(D, a, o);
-}
-
-// ---------------------------------------------------------------------------
-// variant 3 (default): aggregated two-phase kernel.
-//   workgroup = 256 consecutive cell-ordered destinations (4 wave64).
-//   For every neighbouring row of cells the workgroup stages only the fp32
-//   positions of the row's candidate range (SoA, ~4 KB) plus the cell_start
-//   slice into LDS.  Phase 1: each LANE tests just the candidates of ITS OWN
-//   3 cells (two per packed-fp32 instruction) and stores a <=96-bit hit mask
-//   per row in its private LDS column.  After all 3x3 rows of a source are
-//   done, phase 2 lets every lane walk the hit bits of ALL rows back to back
-//   (simulated lane utilisation 0.94 instead of 0.44 for row-by-row
-//   processing), gathering the fp64 record of each hit, applying the
-//   reference's exact criterion and the fused pair arithmetic.
-// ---------------------------------------------------------------------------
-#define ACAP 480   // candidates per LDS position tile
-#define AQ 9       // mask slots per thread (one source's 3x3 rows)
-#define ABS 256     // threads (= destinations) per workgroup of the aggregated kernel
-#define AMAXLEN 96 // hit bits kept per row and lane; longer ranges take the slow tail
-
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-template <class Fam, int KK, bool UH> __global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_agg(PairArgs<Fam> a)
-{
-    const uint32_t NR = (uint32_t)a.nrec;
-    // fp32 tile: x | y | z | (w) planes of TS floats each; reads past a plane's
-    // valid part land in the next plane / the mask area and are masked out
-    constexpr int TS = ACAP + 8;
-    __shared__ __attribute__((aligned(16))) float tile[(UH ? 3 : 4) * TS];
-    float *const tx = tile, *const ty = tile + TS, *const tz = tile + 2 * TS, *const tw = tile + (UH ? 0 : 3 * TS);
-    __shared__ uint32_t csl[72];
-    __shared__ unsigned long long mlo[AQ][ABS];
-    __shared__ uint32_t mhi[AQ][ABS];
-    __shared__ unsigned short mofs[AQ][ABS];
-    __shared__ uint32_t qbase[AQ];
-    __shared__ int wx[2 * (ABS / 64) + 2];
-
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * ABS + t;
-    const bool valid = i < a.nd;
-    const uint32_t ic = valid ? i : a.nd - 1;
-    const uint32_t o = a.d_perm[ic];
-    const bool active = valid && o >= a.d_start && o < a.d_stop;
-    double4 pi;
-    typename Fam::Dest D;
-    {
-        double sd_[Fam::NA];
-        // the destination's own h / p come with the same rules as a source's
-        // (uniform h: the constant; p only for the tensile correction)
-        load_record<Fam, UH>(a.rec + (size_t)(a.d_off + ic) * NR, a.dflags, pi, sd_);
-        if (UH) pi.w = a.hu;
-        Fam::load(D, sd_);
-    }
-    const uint32_t key = a.d_keys[ic];
-    const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
-    const int cx = key % ncx;
-    const int row = key / ncx;
-    const double hi_r = a.radius_scale * pi.w;
-    const double hi2 = UH ? a.hr2u : hi_r * hi_r;
-
-    if (t == 0) wx[2 * (ABS / 64)] = row;
-    if (t == ABS - 1) wx[2 * (ABS / 64) + 1] = row;
-    __syncthreads();
-    const int row_first = wx[2 * (ABS / 64)], row_last = wx[2 * (ABS / 64) + 1];
-
-    // exact criterion + pair arithmetic for one candidate record
-    auto do_pair = [&](uint32_t jg, uint32_t flags) {
-        double4 pj;
-        double sj[Fam::NA];
-        load_record<Fam, UH>(a.rec + (unsigned long long)jg * NR, flags, pj, sj);
-        double hj2 = hi2;
-        if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
-        const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-        if (((r2 < hi2) || (r2 < hj2)) && a.ablate != 1) Fam::template pair<KK, UH>(D, pi, pj, r2, sj, flags, a);
-    };
-
-    for (int R = row_first; R <= row_last; R++) {
-        const bool inseg = active && row == R;
-        const unsigned long long segm = __ballot(inseg);
-        int cxa_w = 0x7fffffff, cxb_w = -1;
-        if (segm) {
-            cxa_w = __builtin_amdgcn_readlane(cx, __builtin_ctzll(segm));
-            cxb_w = __builtin_amdgcn_readlane(cx, 63 - __builtin_clzll(segm));
-        }
-        __syncthreads();
-        if (lane == 0) { wx[2 * wv] = cxa_w; wx[2 * wv + 1] = cxb_w; }
-        __syncthreads();
-        int cxa = wx[0], cxb = wx[1];
-#pragma unroll
-        for (int w2 = 1; w2 < ABS / 64; w2++) { cxa = min(cxa, wx[2 * w2]); cxb = max(cxb, wx[2 * w2 + 1]); }
-        if (cxb < 0) continue;
-        const int cyR = R % ncy, czR = R / ncy;
-        const int xa = max(cxa - 1, 0), xb = min(cxb + 1, ncx - 1);
-        const int ncs = xb - xa + 2; // cell_start entries needed: cells xa..xb and the end
-        // fp32 coordinates: grid-relative positions (fpos, rounded once from
-        // fp64) minus this row segment's origin; every value carries at most
-        // 2^-24 * dom_extent of rounding, covered by `slack`
-        const float oxf = (float)(a.cell_size * xa);
-        const float oyf = (float)(a.cell_size * (cyR - 1));
-        const float ozf = (float)(a.cell_size * (czR - 1));
-        const double L = fmax(a.cell_size * (double)max(xb - xa + 2, 4), a.dom_extent);
-        const float slack = (float)(L * 1.5e-6);
-        const float4 fpi = a.fpos[a.d_off + ic];
-        const float fxs = fpi.x - oxf, fys = fpi.y - oyf, fzs = fpi.z - ozf;
-        const f2 fx = {fxs, fxs}, fy = {fys, fys}, fz = {fzs, fzs};
-        const float hif = (float)hi_r * 1.000001f + slack;
-        const float hi2f = hif * hif;
-        const int mycl = max(cx - 1, xa) - xa, mych = min(cx + 1, xb) + 1 - xa;
-
-        for (int s = 0; s < a.nsrc; s++) {
-            const SrcDesc sd = a.src[s];
-            int nq = 0;
-            // ---- phase 2 over the slots filled so far (per wavefront, no barrier needed:
-            // every thread only touches its own mask column)
-            auto phase2 = [&]() {
-                if (a.ablate != 2 && nq > 0) {
-                    int q = 0;
-                    unsigned long long m0 = mlo[0][t];
-                    uint32_t m1 = mhi[0][t];
-                    for (;;) {
-                        while (m0 == 0 && m1 == 0 && q + 1 < nq) { ++q; m0 = mlo[q][t]; m1 = mhi[q][t]; }
-                        const bool has = (m0 != 0) || (m1 != 0);
-                        if (!__any(has)) break;
-                        if (has) {
-                            int bit;
-                            if (m0) { bit = __builtin_ctzll(m0); m0 &= m0 - 1; }
-                            else { bit = 64 + __builtin_ctz(m1); m1 &= m1 - 1; }
-                            do_pair(qbase[q] + mofs[q][t] + bit, sd.flags);
-                        }
-                    }
-                }
-                nq = 0;
-            };
-            for (int dz = -1; dz <= 1; dz++)
-                for (int dy = -1; dy <= 1; dy++) {
-                    const int yy = cyR + dy, zz = czR + dz;
-                    if (yy < 0 || yy >= ncy || zz < 0 || zz >= ncz) continue;
-                    const uint32_t rowb = (uint32_t)(ncx * (yy + ncy * zz));
-                    const uint32_t j0 = sd.cell_start[rowb + xa], j1 = sd.cell_start[rowb + xb + 1];
-                    for (uint32_t tb = j0; tb < j1; tb += ACAP) {
-                        const int tn = (int)min((uint32_t)ACAP, j1 - tb);
-                        __syncthreads(); // previous tile's readers are done
-                        for (int q = t; q < ncs && q < 72; q += ABS) csl[q] = sd.cell_start[rowb + xa + q];
-                        for (int k = t; k < tn + 8; k += ABS) {
-                            float vx = 3.0e18f, vy = 3.0e18f, vz = 3.0e18f, vw = 0.f;
-                            if (k < tn) {
-                                const float4 fj = a.fpos[sd.off + tb + k];
-                                vx = fj.x - oxf; vy = fj.y - oyf; vz = fj.z - ozf;
-                                const float hjf = fj.w * 1.000001f + slack;
-                                vw = hjf * hjf;
-                            }
-                            tx[k] = vx; ty[k] = vy; tz[k] = vz;
-                            if (!UH) tw[k] = vw;
-                        }
-                        __syncthreads();
-                        // ---- my own candidate range inside this tile (3 cells), even-aligned start
-                        int s0 = 0, len = 0;
-                        if (inseg) {
-                            int lo, hi;
-                            if (ncs <= 72) { lo = (int)(csl[mycl] - tb); hi = (int)(csl[mych] - tb); }
-                            else { lo = (int)(sd.cell_start[rowb + xa + mycl] - tb); hi = (int)(sd.cell_start[rowb + xa + mych] - tb); }
-                            lo = max(lo, 0); hi = min(hi, tn);
-                            s0 = lo & ~1;
-                            len = hi - s0;
-                        }
-                        const int lenc = min(len, AMAXLEN);
-                        // One sign bit per candidate: d = |x_i - x_j|^2 - thr^2 in packed fp32 FMAs,
-                        // shifted into a 32-bit word with v_alignbit (1 VALU per candidate).
-                        uint32_t wd[3] = {0u, 0u, 0u};
-#pragma unroll
-                        for (int gw = 0; gw < 3; gw++) {
-                            if (!__any(32 * gw < lenc)) break; // wave-uniform
-                            uint32_t mm = 0;
-                            int g8 = 0;
-                            for (; g8 < 4 && __any(32 * gw + 8 * g8 < lenc); g8++) {
-                                const float *tb0 = tile + (s0 + 32 * gw + 8 * g8); // one address, constant offsets below
-#pragma unroll
-                                for (int p = 0; p < 4; p++) {
-                                    const f2 X = *reinterpret_cast<const f2 *>(tb0 + 2 * p);
-                                    const f2 Y = *reinterpret_cast<const f2 *>(tb0 + TS + 2 * p);
-                                    const f2 Z = *reinterpret_cast<const f2 *>(tb0 + 2 * TS + 2 * p);
-                                    const f2 ex = fx - X, ey = fy - Y, ez = fz - Z;
-                                    f2 nthr = {-hi2f, -hi2f};
-                                    if (!UH) {
-                                        const f2 W = *reinterpret_cast<const f2 *>(tb0 + 3 * TS + 2 * p);
-                                        nthr.x = -fmaxf(hi2f, W.x); // r2 < hi^2 or r2 < hj^2
-                                        nthr.y = -fmaxf(hi2f, W.y);
-                                    }
-                                    f2 d = __builtin_elementwise_fma(ex, ex, nthr);
-                                    d = __builtin_elementwise_fma(ey, ey, d);
-                                    d = __builtin_elementwise_fma(ez, ez, d);
-                                    mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.x), 31);
-                                    mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.y), 31);
-                                }
-                            }
-                            if (g8 < 4) mm <<= 8 * (4 - g8);
-                            mm = __builtin_bitreverse32(mm); // bit b <-> candidate 32*gw + b
-                            // candidates beyond this lane's range (its own tail / other lanes' longer ranges)
-                            const int rem = lenc - 32 * gw;
-                            wd[gw] = rem >= 32 ? mm : (rem > 0 ? (mm & ((1u << rem) - 1u)) : 0u);
-                        }
-                        const unsigned long long m0 = (unsigned long long)wd[0] | ((unsigned long long)wd[1] << 32);
-                        const uint32_t m1 = wd[2];
-                        mlo[nq][t] = m0;
-                        mhi[nq][t] = m1;
-                        mofs[nq][t] = (unsigned short)s0;
-                        if (t == 0) qbase[nq] = sd.off + tb;
-                        // ---- rare: a lane's 3-cell range is longer than AMAXLEN -> exact tail, in place
-                        if (__any(len > AMAXLEN)) {
-                            for (int k = AMAXLEN; k < len; k++) do_pair(sd.off + tb + s0 + k, sd.flags);
-                        }
-                        nq++;
-                        if (nq == AQ) {
-                            __syncthreads(); // qbase visible
-                            phase2();
-                        }
-                    }
-                }
-            __syncthreads(); // qbase visible
-            phase2();
         }
     }
     if (active) Fam::finish(D, a, o);
@@ -1352,7 +989,7 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
     pa.radius_scale = c->radius_scale;
     if (c->pair_variant >= 2) pa.rec = c->posh.as<double>();
     if (c->pair_variant >= 3) pa.fpos = c->fposb.as<float4>();
-    pa.split_wcsph = (c->pair_variant == 3 && fam == FAM_WCSPH) ? 1 : 0;
+    pa.layout = (c->pair_variant == 3 && fam == FAM_WCSPH) ? 1 : (c->pair_variant == 3 && fam == FAM_DENSITY && pl.nr == 4) ? 2 : 0;
     hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, pa);
     return SPH_OK;
 }
@@ -1419,6 +1056,7 @@ static void fill_common(sph_ctx *c, PairArgs<Fam> &a, const sph_kernel *K, doubl
     a.k.deltap = K->deltap;
     a.k.dim = K->dim;
     a.t = t;
+    a.dt = c->cur_dt;
     a.ablate = (int)c->ablate;
     // uniform-h constants, computed as the general path would per pair
     a.hu = 0.5 * (c->h_uniform + c->h_uniform);
@@ -1438,7 +1076,7 @@ static int ensure_out(sph_ctx *c, int id, std::initializer_list<int> props)
 
 extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *g, double t, double dt)
 {
-    (void)dt;
+    c->cur_dt = dt;
     if (!c || !K || !g) { sph_set_error("sph_eval_group: NULL argument"); return SPH_ERR_ARG; }
     if (g->neq > SPH_MAX_EQS) { sph_set_error("sph_eval_group: too many equations"); return SPH_ERR_ARG; }
     if (K->kind < 1 || K->kind > 4) { sph_set_error("sph_eval_group: unknown kernel kind %d", K->kind); return SPH_ERR_UNSUPPORTED; }
@@ -1537,7 +1175,8 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         if (c->pair_variant >= 3) SPH_TRY(c->fposb.reserve((total + 64) * sizeof(float4)));
         {
             ScopedTimer tm(c, T_PACK);
-            for (int j = 0; j < nsrcs; j++) SPH_TRY(pack_array(c, srcs[j], off_of[j], pl, fam, dflags));
+            // a source must hold what ITS equations read; the destination's own record what all of them read
+            for (int j = 0; j < nsrcs; j++) SPH_TRY(pack_array(c, srcs[j], off_of[j], pl, fam, srcs[j] == dst ? dflags : sflags[j]));
             if (!dest_is_src) SPH_TRY(pack_array(c, dst, d_off, pl, fam, dflags));
         }
 
@@ -1644,6 +1283,142 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         }
     }
     HIP_TRY(hipGetLastError());
+    return SPH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// generated equation families (pysph_amd/codegen.py): pack the sources'
+// records with the properties the generated bodies read, then call the
+// module's launch function with plain pointers.
+// ---------------------------------------------------------------------------
+static int pack_generic(sph_ctx *c, int id, size_t off, int nprops, const int *props, int nr)
+{
+    DevArray &A = c->arr[id];
+    if (A.n == 0) return SPH_OK;
+    PackArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.perm = A.perm.as<uint32_t>();
+    pa.n = A.n;
+    pa.off = off;
+    pa.x = A.prop[SPH_X]; pa.y = A.prop[SPH_Y]; pa.z = A.prop[SPH_Z]; pa.h = A.prop[SPH_H];
+    pa.na = nprops;
+    for (int k = 0; k < nprops; k++) {
+        pa.src[k] = A.prop[props[k]];
+        if (!pa.src[k]) return need_prop(c, id, props[k], "generated pair loop");
+    }
+    pa.posh = c->posh.as<double4>();
+    pa.aux = c->aux.as<double>();
+    pa.rec = c->posh.as<double>();
+    pa.nr = nr;
+    pa.fpos = c->fposb.as<float4>();
+    for (int k = 0; k < 3; k++) pa.gmin[k] = c->xmin[k];
+    pa.radius_scale = c->radius_scale;
+    hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, pa);
+    return SPH_OK;
+}
+
+extern "C" int sph_eval_generated(sph_ctx *c, const sph_kernel *K, const sph_gen_family *f, double t, double dt)
+{
+    if (!c || !K || !f || !f->launch) { sph_set_error("sph_eval_generated: NULL argument"); return SPH_ERR_ARG; }
+    if (K->kind < 1 || K->kind > 4) { sph_set_error("sph_eval_generated: unknown kernel kind %d", K->kind); return SPH_ERR_UNSUPPORTED; }
+    if (f->dest < 0 || f->dest >= SPH_MAX_ARRAYS || !c->arr[f->dest].used) { sph_set_error("sph_eval_generated: bad dest array %d", f->dest); return SPH_ERR_ARG; }
+    if (f->nsrc < 0 || f->nsrc > SPH_MAX_ARRAYS || f->n_sprops < 0 || f->n_sprops > SPH_GEN_MAX_SPROPS || f->n_sprops > MAX_AUX ||
+        f->n_din < 0 || f->n_din > SPH_GEN_MAX_PROPS || f->n_dout < 0 || f->n_dout > SPH_GEN_MAX_PROPS || f->npar < 0 ||
+        f->npar > SPH_GEN_MAX_PAR) {
+        sph_set_error("sph_eval_generated: family descriptor out of range");
+        return SPH_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    const int dst = f->dest;
+    DevArray &D = c->arr[dst];
+    size_t start = f->start_idx > 0 ? (size_t)f->start_idx : 0;
+    size_t stop = f->stop_idx >= 0 ? (size_t)f->stop_idx : (f->real ? D.n_real : D.n);
+    if (stop > D.n) stop = D.n;
+
+    sph_gen_args g;
+    memset(&g, 0, sizeof g);
+    g.stream = (void *)c->stream;
+    g.kernel_kind = K->kind;
+    g.uniform_h = (c->uniform_h && c->use_uniform_h) ? 1 : 0;
+    g.nsrc = f->nsrc;
+    g.t = t; g.dt = dt;
+    g.n_din = f->n_din; g.n_dout = f->n_dout; g.npar = f->npar;
+    for (int k = 0; k < f->npar; k++) g.par[k] = f->par[k];
+    for (int k = 0; k < f->n_dout; k++) {
+        int p = f->dout[k];
+        if (p < 0 || p >= SPH_PROP_COUNT) { sph_set_error("sph_eval_generated: bad output property %d", p); return SPH_ERR_ARG; }
+        SPH_TRY(sph_array_ensure_prop(c, dst, p));
+        g.dout[k] = D.prop[p];
+    }
+    for (int k = 0; k < f->n_din; k++) {
+        int p = f->din[k];
+        if (p < 0 || p >= SPH_PROP_COUNT) { sph_set_error("sph_eval_generated: bad input property %d", p); return SPH_ERR_ARG; }
+        if (!D.prop[p]) return need_prop(c, dst, p, "generated equation (destination)");
+        g.din[k] = D.prop[p];
+    }
+    g.d_start = (uint32_t)start; g.d_stop = (uint32_t)stop;
+    g.nd = (uint32_t)D.n;
+    g.sigma = K->fac; g.deltap = K->deltap; g.dim = K->dim;
+    if (D.n == 0 || stop <= start) return SPH_OK;
+
+    if (f->nsrc > 0) {
+        if (!c->nnps_valid) { sph_set_error("sph_eval_generated: neighbour grid is stale; call sph_nnps_update"); return SPH_ERR_STATE; }
+        if (D.nnps_slot < 0) { sph_set_error("destination array %d is not part of the neighbour grid", dst); return SPH_ERR_STATE; }
+        size_t total = 0, off_of[SPH_MAX_ARRAYS];
+        bool dest_is_src = false;
+        for (int j = 0; j < f->nsrc; j++) {
+            int s = f->src[j];
+            if (s < 0 || s >= SPH_MAX_ARRAYS || !c->arr[s].used) { sph_set_error("bad source array %d", s); return SPH_ERR_ARG; }
+            if (c->arr[s].nnps_slot < 0) { sph_set_error("source array %d is not part of the neighbour grid", s); return SPH_ERR_STATE; }
+            for (int i = 0; i < j; i++) if (f->src[i] == s) { sph_set_error("source array %d listed twice", s); return SPH_ERR_ARG; }
+            off_of[j] = total; total += c->arr[s].n; dest_is_src |= s == dst;
+        }
+        size_t d_off = total;
+        if (!dest_is_src) total += D.n;
+        else for (int j = 0; j < f->nsrc; j++) if (f->src[j] == dst) d_off = off_of[j];
+        if (total >= (1ull << 32)) { sph_set_error("too many particles for 32-bit packed indices"); return SPH_ERR_ARG; }
+        const int na = f->n_sprops;
+        const int nr = 4 + ((na + 1) & ~1); // whole 16-byte pieces
+        SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * nr));
+        SPH_TRY(c->aux.reserve(64));
+        SPH_TRY(c->fposb.reserve((total + 64) * sizeof(float4)));
+        {
+            ScopedTimer tm(c, T_PACK);
+            for (int j = 0; j < f->nsrc; j++) SPH_TRY(pack_generic(c, f->src[j], off_of[j], na, f->sprops, nr));
+            if (!dest_is_src) {
+                // the destination only needs its position record; properties it lacks are not read
+                int have[SPH_GEN_MAX_SPROPS], nh = 0;
+                for (int k = 0; k < na; k++) if (D.prop[f->sprops[k]]) have[nh++] = f->sprops[k];
+                SPH_TRY(pack_generic(c, dst, d_off, nh == na ? na : 0, f->sprops, nr));
+            }
+        }
+        g.rec = c->posh.as<double>();
+        g.nrec = nr;
+        g.fpos = c->fposb.as<float4>();
+        g.dom_extent = fmax(fmax(c->xmax[0] - c->xmin[0], c->xmax[1] - c->xmin[1]), c->xmax[2] - c->xmin[2]);
+        for (int k = 0; k < 3; k++) { g.nc[k] = c->nc[k]; g.xmin[k] = c->xmin[k]; }
+        g.cell_size = c->cell_size;
+        g.radius_scale = c->radius_scale;
+        g.hu = 0.5 * (c->h_uniform + c->h_uniform);
+        g.h1u = 1.0 / g.hu;
+        g.facu = K->fac * g.h1u;
+        if (K->dim > 1) g.facu *= g.h1u;
+        if (K->dim > 2) g.facu *= g.h1u;
+        g.epsu = 0.01 * g.hu * g.hu;
+        g.hr2u = (c->radius_scale * c->h_uniform) * (c->radius_scale * c->h_uniform);
+        for (int j = 0; j < f->nsrc; j++) {
+            g.src_cell_start[j] = c->arr[f->src[j]].cell_start.as<uint32_t>();
+            g.src_off[j] = (uint32_t)off_of[j];
+            g.src_flags[j] = f->src_flags[j];
+            g.dflags |= f->src_flags[j];
+        }
+        g.d_off = (uint32_t)d_off;
+        g.d_keys = D.keys_sorted.as<uint32_t>();
+        g.d_perm = D.perm.as<uint32_t>();
+    }
+    ScopedTimer tm(c, f->nsrc > 0 ? T_PAIR : T_EOS);
+    int rc = f->launch(&g);
+    if (rc != 0) { sph_set_error("generated family launch failed (code %d)", rc); return SPH_ERR_HIP; }
     return SPH_OK;
 }
 

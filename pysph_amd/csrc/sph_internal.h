@@ -92,6 +92,7 @@ struct sph_ctx {
     long pair_variant = 3;
     long ablate = 0;
     long use_uniform_h = 1;
+    double cur_dt = 0.0;    // dt of the sph_eval_group call being set up
     int cur_nrec = 0;       // doubles per packed record of the pair launch being set up
     long block_sorted_outputs = 0;
 

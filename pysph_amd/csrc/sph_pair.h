@@ -1,0 +1,390 @@
+// sph_pair.h -- the pair-loop skeleton shared by the hand-written equation
+// families (sph_eval.hip) and by generated ones (pysph_amd/codegen.py):
+// launch arguments, per-pair geometry and kernel helpers, record access and the
+// aggregated two-phase pair kernel k_pair_agg<Fam, KK, UH>.
+//
+// A family `Fam` supplies
+//   MINB                 workgroups per CU to compile for (VGPR budget)
+//   NA, NR               aux doubles per record, record length (>= 4 + NA)
+//   Params               launch constants / output pointers
+//   Dest                 per-destination registers (inputs + accumulators)
+//   load(D, s, a, o)     initialize: from the destination's own record `s`
+//                        (and, for generated families, memory at original index o)
+//   pair<KK,UH>(D, pi, pj, r2, s, flags, a)   one neighbour pair
+//   finish(D, a, o)      post_loop + the single write per output
+// and may specialise load_record<Fam, UH> for a custom record layout.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "sphhip.h"
+#include "sph_kernels.h"
+
+// ---------------------------------------------------------------------------
+// exact (non-contracted) squared distance: must round like the reference's
+// norm2 (nnps_base.pxd:36-37) so that neighbour SETS are identical.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double r2_exact(double dx, double dy, double dz)
+{
+#pragma clang fp contract(off)
+    const double a = dx * dx, b = dy * dy, c = dz * dz;
+    return (a + b) + c;
+}
+
+
+struct KernelConst {
+    double sigma;  // kernel.fac
+    double deltap; // kernel.get_deltap()
+    int dim;
+};
+
+
+struct SrcDesc {
+    const uint32_t *cell_start;
+    uint32_t off;    // offset of this source's segment in the packed buffers
+    uint32_t flags;  // equations acting for this (dest, source) pair
+};
+
+template <class Fam> struct PairArgs {
+    int nsrc;
+    SrcDesc src[SPH_MAX_ARRAYS];
+    const double4 *posh;
+    const double *aux;
+    const double *rec; // variant 2: interleaved records, Fam::NR doubles each
+    int nrec;          // variant 3: doubles per record (Fam::NR, or 10 for compact WCSPH records)
+    const float4 *fpos; // variant 3: fp32 grid-relative positions + radius_scale*h (prefilter only)
+    double dom_extent;  // largest grid extent: bounds the fp32 rounding of fpos
+    uint32_t d_off, nd;
+    const uint32_t *d_keys, *d_perm;
+    uint32_t d_start, d_stop;
+    int nc[3];
+    double xmin[3];
+    double cell_size;
+    double radius_scale;
+    KernelConst k;
+    uint32_t dflags; // union of the source flags
+    int ablate;      // profiling only: 1 = skip pair arithmetic, 2 = skip phase 2
+    double t, dt;
+    // constants of the uniform-h specialisation (hmin == hmax over all arrays)
+    double hu, h1u, facu, epsu, hr2u;
+    typename Fam::Params p;
+};
+
+// ---------------------------------------------------------------------------
+// fast fp64 reciprocal / square root: hardware estimate + two Newton steps
+// (error ~1 ulp; no div_scale/div_fixup range handling -- operands here are
+// densities, distances and smoothing lengths, far from the fp64 range limits).
+// The 1e-10 parity budget (BASELINE.json) absorbs the ~1e-16 differences.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double fast_rcp(double d)
+{
+    double x = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    return x;
+}
+// s = sqrt(a), rs = 1/sqrt(a).  a is clamped to 1e-300 so that coincident
+// particles (a == 0: the self pair) give finite s ~ 1e-150, rs ~ 1e150; every
+// use of rs multiplies it with a factor that is exactly 0 for such pairs
+// (XIJ, or h*VIJ.XIJ), and the gradient has the reference's own r > 1e-12 guard.
+__device__ __forceinline__ void fast_sqrt_rsqrt(double a, double &s, double &rs)
+{
+    a = fmax(a, 1e-300);
+    double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    s = g;
+    rs = h + h;
+}
+
+// per-pair geometry shared by all families
+struct PairGeom {
+    double xij[3];
+    double r2, rij, rinv, hij, h1, q, fac, eps;
+};
+
+// UH: every particle has the same h -> HIJ, 1/HIJ, the kernel normalisation
+// and EPS are launch constants.
+template <int KK, bool UH, class A>
+__device__ __forceinline__ void pair_geom(PairGeom &g, const double4 &pi, const double4 &pj, double r2, const A &a)
+{
+    g.xij[0] = pi.x - pj.x; g.xij[1] = pi.y - pj.y; g.xij[2] = pi.z - pj.z; // XIJ equation.py:205-212
+    g.r2 = r2;                                                               // R2IJ :226-233
+    fast_sqrt_rsqrt(r2, g.rij, g.rinv);                                      // RIJ  :235
+    if (UH) {
+        g.hij = a.hu; g.h1 = a.h1u; g.fac = a.facu; g.eps = a.epsu;
+    } else {
+        g.hij = 0.5 * (pi.w + pj.w);                                         // HIJ  :192
+        g.h1 = fast_rcp(g.hij);
+        g.fac = kernel_norm(a.k.sigma, g.h1, a.k.dim);
+        g.eps = 0.01 * g.hij * g.hij;                                        // EPS  :194
+    }
+    g.q = g.rij * g.h1;
+}
+template <int KK, bool UH> __device__ __forceinline__ double pair_w(const PairGeom &g) { return SphKernel<KK>::template w<UH>(g.q) * g.fac; }
+// GRADIENT(XIJ, RIJ, HIJ, DWIJ) (kernels.py:126-137) returns tmp*xij with
+// tmp = dwdq*h1/rij; here tmp only.  dw(q)/rij = dwq(q)*h1 when the kernel has
+// a closed form for dw/q.
+template <int KK, bool UH> __device__ __forceinline__ double pair_gradfac(const PairGeom &g)
+{
+    double t;
+    if (SphKernel<KK>::HAS_DWQ) t = SphKernel<KK>::template dwq<UH>(g.q) * (g.fac * g.h1 * g.h1);
+    else t = SphKernel<KK>::template dw<UH>(g.q) * (g.fac * g.h1) * g.rinv;
+    return g.rij > 1e-12 ? t : 0.0;
+}
+
+// Record access for the aggregated kernel.  Default layout: [x y z h | aux...].
+template <class Fam, bool UH>
+__device__ __forceinline__ void load_record(const double *__restrict__ rj, uint32_t fl, double4 &pj, double (&s)[Fam::NA])
+{
+    pj = *reinterpret_cast<const double4 *>(rj);
+#pragma unroll
+    for (int k = 0; k < Fam::NA; k++) s[k] = rj[4 + k];
+}
+
+// ---- WCSPH: Continuity + Momentum + XSPH (wc/basic.py, basic_equations.py) --
+// ---------------------------------------------------------------------------
+// XCD-aware block remap (MI355X: 8 XCDs, block b runs on XCD b % 8, each XCD
+// has a private 4 MiB L2).  Consecutive tiles of the cell-ordered destination
+// array share their 3x3 neighbour rows, so give every XCD one CONTIGUOUS chunk
+// of tiles: the rows a workgroup gathers from are then already in its XCD's L2.
+// Placement only affects speed, never results.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nb)
+{
+    const uint32_t xcd = b & 7u, idx = b >> 3;
+    const uint32_t base = nb >> 3, rem = nb & 7u;
+    return xcd * base + min(xcd, rem) + idx;
+}
+
+// ---------------------------------------------------------------------------
+// variant 3 (default): aggregated two-phase kernel.
+//   workgroup = 256 consecutive cell-ordered destinations (4 wave64).
+//   For every neighbouring row of cells the workgroup stages only the fp32
+//   positions of the row's candidate range (SoA, ~4 KB) plus the cell_start
+//   slice into LDS.  Phase 1: each LANE tests just the candidates of ITS OWN
+//   3 cells (two per packed-fp32 instruction) and stores a <=96-bit hit mask
+//   per row in its private LDS column.  After all 3x3 rows of a source are
+//   done, phase 2 lets every lane walk the hit bits of ALL rows back to back
+//   (simulated lane utilisation 0.94 instead of 0.44 for row-by-row
+//   processing), gathering the fp64 record of each hit, applying the
+//   reference's exact criterion and the fused pair arithmetic.
+// ---------------------------------------------------------------------------
+#define ACAP 480   // candidates per LDS position tile
+#define AQ 9       // mask slots per thread (one source's 3x3 rows)
+#define ABS 256     // threads (= destinations) per workgroup of the aggregated kernel
+#define AMAXLEN 96 // hit bits kept per row and lane; longer ranges take the slow tail
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <class Fam, int KK, bool UH> __global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_agg(PairArgs<Fam> a)
+{
+    const uint32_t NR = (uint32_t)a.nrec;
+    // fp32 tile: x | y | z | (w) planes of TS floats each; reads past a plane's
+    // valid part land in the next plane / the mask area and are masked out
+    constexpr int TS = ACAP + 8;
+    __shared__ __attribute__((aligned(16))) float tile[(UH ? 3 : 4) * TS];
+    float *const tx = tile, *const ty = tile + TS, *const tz = tile + 2 * TS, *const tw = tile + (UH ? 0 : 3 * TS);
+    __shared__ uint32_t csl[72];
+    __shared__ unsigned long long mlo[AQ][ABS];
+    __shared__ uint32_t mhi[AQ][ABS];
+    __shared__ unsigned short mofs[AQ][ABS];
+    __shared__ uint32_t qbase[AQ];
+    __shared__ int wx[2 * (ABS / 64) + 2];
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * ABS + t;
+    const bool valid = i < a.nd;
+    const uint32_t ic = valid ? i : a.nd - 1;
+    const uint32_t o = a.d_perm[ic];
+    const bool active = valid && o >= a.d_start && o < a.d_stop;
+    double4 pi;
+    typename Fam::Dest D;
+    {
+        double sd_[Fam::NA];
+        // the destination's own h / p come with the same rules as a source's
+        // (uniform h: the constant; p only for the tensile correction)
+        load_record<Fam, UH>(a.rec + (size_t)(a.d_off + ic) * NR, a.dflags, pi, sd_);
+        if (UH) pi.w = a.hu;
+        Fam::load(D, sd_, a, o);
+    }
+    const uint32_t key = a.d_keys[ic];
+    const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
+    const int cx = key % ncx;
+    const int row = key / ncx;
+    const double hi_r = a.radius_scale * pi.w;
+    const double hi2 = UH ? a.hr2u : hi_r * hi_r;
+
+    if (t == 0) wx[2 * (ABS / 64)] = row;
+    if (t == ABS - 1) wx[2 * (ABS / 64) + 1] = row;
+    __syncthreads();
+    const int row_first = wx[2 * (ABS / 64)], row_last = wx[2 * (ABS / 64) + 1];
+
+    // exact criterion + pair arithmetic for one candidate record
+    auto do_pair = [&](uint32_t jg, uint32_t flags) {
+        double4 pj;
+        double sj[Fam::NA];
+        load_record<Fam, UH>(a.rec + (unsigned long long)jg * NR, flags, pj, sj);
+        double hj2 = hi2;
+        if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
+        const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+        if (((r2 < hi2) || (r2 < hj2)) && a.ablate != 1) Fam::template pair<KK, UH>(D, pi, pj, r2, sj, flags, a);
+    };
+
+    for (int R = row_first; R <= row_last; R++) {
+        const bool inseg = active && row == R;
+        const unsigned long long segm = __ballot(inseg);
+        int cxa_w = 0x7fffffff, cxb_w = -1;
+        if (segm) {
+            cxa_w = __builtin_amdgcn_readlane(cx, __builtin_ctzll(segm));
+            cxb_w = __builtin_amdgcn_readlane(cx, 63 - __builtin_clzll(segm));
+        }
+        __syncthreads();
+        if (lane == 0) { wx[2 * wv] = cxa_w; wx[2 * wv + 1] = cxb_w; }
+        __syncthreads();
+        int cxa = wx[0], cxb = wx[1];
+#pragma unroll
+        for (int w2 = 1; w2 < ABS / 64; w2++) { cxa = min(cxa, wx[2 * w2]); cxb = max(cxb, wx[2 * w2 + 1]); }
+        if (cxb < 0) continue;
+        const int cyR = R % ncy, czR = R / ncy;
+        const int xa = max(cxa - 1, 0), xb = min(cxb + 1, ncx - 1);
+        const int ncs = xb - xa + 2; // cell_start entries needed: cells xa..xb and the end
+        // fp32 coordinates: grid-relative positions (fpos, rounded once from
+        // fp64) minus this row segment's origin; every value carries at most
+        // 2^-24 * dom_extent of rounding, covered by `slack`
+        const float oxf = (float)(a.cell_size * xa);
+        const float oyf = (float)(a.cell_size * (cyR - 1));
+        const float ozf = (float)(a.cell_size * (czR - 1));
+        const double L = fmax(a.cell_size * (double)max(xb - xa + 2, 4), a.dom_extent);
+        const float slack = (float)(L * 1.5e-6);
+        const float4 fpi = a.fpos[a.d_off + ic];
+        const float fxs = fpi.x - oxf, fys = fpi.y - oyf, fzs = fpi.z - ozf;
+        const f2 fx = {fxs, fxs}, fy = {fys, fys}, fz = {fzs, fzs};
+        const float hif = (float)hi_r * 1.000001f + slack;
+        const float hi2f = hif * hif;
+        const int mycl = max(cx - 1, xa) - xa, mych = min(cx + 1, xb) + 1 - xa;
+
+        for (int s = 0; s < a.nsrc; s++) {
+            const SrcDesc sd = a.src[s];
+            int nq = 0;
+            // ---- phase 2 over the slots filled so far (per wavefront, no barrier needed:
+            // every thread only touches its own mask column)
+            auto phase2 = [&]() {
+                if (a.ablate != 2 && nq > 0) {
+                    int q = 0;
+                    unsigned long long m0 = mlo[0][t];
+                    uint32_t m1 = mhi[0][t];
+                    for (;;) {
+                        while (m0 == 0 && m1 == 0 && q + 1 < nq) { ++q; m0 = mlo[q][t]; m1 = mhi[q][t]; }
+                        const bool has = (m0 != 0) || (m1 != 0);
+                        if (!__any(has)) break;
+                        if (has) {
+                            int bit;
+                            if (m0) { bit = __builtin_ctzll(m0); m0 &= m0 - 1; }
+                            else { bit = 64 + __builtin_ctz(m1); m1 &= m1 - 1; }
+                            do_pair(qbase[q] + mofs[q][t] + bit, sd.flags);
+                        }
+                    }
+                }
+                nq = 0;
+            };
+            for (int dz = -1; dz <= 1; dz++)
+                for (int dy = -1; dy <= 1; dy++) {
+                    const int yy = cyR + dy, zz = czR + dz;
+                    if (yy < 0 || yy >= ncy || zz < 0 || zz >= ncz) continue;
+                    const uint32_t rowb = (uint32_t)(ncx * (yy + ncy * zz));
+                    const uint32_t j0 = sd.cell_start[rowb + xa], j1 = sd.cell_start[rowb + xb + 1];
+                    for (uint32_t tb = j0; tb < j1; tb += ACAP) {
+                        const int tn = (int)min((uint32_t)ACAP, j1 - tb);
+                        __syncthreads(); // previous tile's readers are done
+                        for (int q = t; q < ncs && q < 72; q += ABS) csl[q] = sd.cell_start[rowb + xa + q];
+                        for (int k = t; k < tn + 8; k += ABS) {
+                            float vx = 3.0e18f, vy = 3.0e18f, vz = 3.0e18f, vw = 0.f;
+                            if (k < tn) {
+                                const float4 fj = a.fpos[sd.off + tb + k];
+                                vx = fj.x - oxf; vy = fj.y - oyf; vz = fj.z - ozf;
+                                const float hjf = fj.w * 1.000001f + slack;
+                                vw = hjf * hjf;
+                            }
+                            tx[k] = vx; ty[k] = vy; tz[k] = vz;
+                            if (!UH) tw[k] = vw;
+                        }
+                        __syncthreads();
+                        // ---- my own candidate range inside this tile (3 cells), even-aligned start
+                        int s0 = 0, len = 0;
+                        if (inseg) {
+                            int lo, hi;
+                            if (ncs <= 72) { lo = (int)(csl[mycl] - tb); hi = (int)(csl[mych] - tb); }
+                            else { lo = (int)(sd.cell_start[rowb + xa + mycl] - tb); hi = (int)(sd.cell_start[rowb + xa + mych] - tb); }
+                            lo = max(lo, 0); hi = min(hi, tn);
+                            s0 = lo & ~1;
+                            len = hi - s0;
+                        }
+                        const int lenc = min(len, AMAXLEN);
+                        // One sign bit per candidate: d = |x_i - x_j|^2 - thr^2 in packed fp32 FMAs,
+                        // shifted into a 32-bit word with v_alignbit (1 VALU per candidate).
+                        uint32_t wd[3] = {0u, 0u, 0u};
+#pragma unroll
+                        for (int gw = 0; gw < 3; gw++) {
+                            if (!__any(32 * gw < lenc)) break; // wave-uniform
+                            uint32_t mm = 0;
+                            int g8 = 0;
+                            for (; g8 < 4 && __any(32 * gw + 8 * g8 < lenc); g8++) {
+                                const float *tb0 = tile + (s0 + 32 * gw + 8 * g8); // one address, constant offsets below
+#pragma unroll
+                                for (int p = 0; p < 4; p++) {
+                                    const f2 X = *reinterpret_cast<const f2 *>(tb0 + 2 * p);
+                                    const f2 Y = *reinterpret_cast<const f2 *>(tb0 + TS + 2 * p);
+                                    const f2 Z = *reinterpret_cast<const f2 *>(tb0 + 2 * TS + 2 * p);
+                                    const f2 ex = fx - X, ey = fy - Y, ez = fz - Z;
+                                    f2 nthr = {-hi2f, -hi2f};
+                                    if (!UH) {
+                                        const f2 W = *reinterpret_cast<const f2 *>(tb0 + 3 * TS + 2 * p);
+                                        nthr.x = -fmaxf(hi2f, W.x); // r2 < hi^2 or r2 < hj^2
+                                        nthr.y = -fmaxf(hi2f, W.y);
+                                    }
+                                    f2 d = __builtin_elementwise_fma(ex, ex, nthr);
+                                    d = __builtin_elementwise_fma(ey, ey, d);
+                                    d = __builtin_elementwise_fma(ez, ez, d);
+                                    mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.x), 31);
+                                    mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.y), 31);
+                                }
+                            }
+                            if (g8 < 4) mm <<= 8 * (4 - g8);
+                            mm = __builtin_bitreverse32(mm); // bit b <-> candidate 32*gw + b
+                            // candidates beyond this lane's range (its own tail / other lanes' longer ranges)
+                            const int rem = lenc - 32 * gw;
+                            wd[gw] = rem >= 32 ? mm : (rem > 0 ? (mm & ((1u << rem) - 1u)) : 0u);
+                        }
+                        const unsigned long long m0 = (unsigned long long)wd[0] | ((unsigned long long)wd[1] << 32);
+                        const uint32_t m1 = wd[2];
+                        mlo[nq][t] = m0;
+                        mhi[nq][t] = m1;
+                        mofs[nq][t] = (unsigned short)s0;
+                        if (t == 0) qbase[nq] = sd.off + tb;
+                        // ---- rare: a lane's 3-cell range is longer than AMAXLEN -> exact tail, in place
+                        if (__any(len > AMAXLEN)) {
+                            for (int k = AMAXLEN; k < len; k++) do_pair(sd.off + tb + s0 + k, sd.flags);
+                        }
+                        nq++;
+                        if (nq == AQ) {
+                            __syncthreads(); // qbase visible
+                            phase2();
+                        }
+                    }
+                }
+            __syncthreads(); // qbase visible
+            phase2();
+        }
+    }
+    if (active) Fam::finish(D, a, o);
+}
+

@@ -81,6 +81,8 @@ SIGNATURES = {
     'sph_halo_append': (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int),
                                   _P, C.c_size_t]),
     'sph_halo_remove_selected': (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
+    'sph_prop_register': (C.c_int, [C.c_char_p]),
+    'sph_eval_generated': (C.c_int, [_P, _P, _P, C.c_double, C.c_double]),
     'sph_reduce_max': (C.c_int, [_P, C.c_int, C.c_int, _PD]),
     'sph_reduce_min': (C.c_int, [_P, C.c_int, C.c_int, _PD]),
     'sph_integrate_stage': (C.c_int, [_P, C.c_int, C.c_int, C.c_int,
@@ -127,6 +129,32 @@ def _check(rc):
 def prop_id(name):
     pid = load_library().sph_prop_id(name.encode())
     return pid
+
+
+def prop_register(name):
+    """id of a property, giving it a user slot if it is not built in
+    (equation-specific arrays of generated families)."""
+    pid = load_library().sph_prop_register(name.encode())
+    if pid < 0:
+        raise SphError('sph_prop_register(%s): %s' % (
+            name, load_library().sph_last_error().decode()))
+    return pid
+
+
+GEN_MAX_PROPS, GEN_MAX_SPROPS, GEN_MAX_PAR = 32, 20, 64
+
+
+class SphGenFamily(C.Structure):
+    """``sph_gen_family`` of include/sphhip.h."""
+    _fields_ = [('launch', C.c_void_p), ('dest', C.c_int), ('nsrc', C.c_int),
+                ('src', C.c_int * MAX_ARRAYS),
+                ('src_flags', C.c_uint32 * MAX_ARRAYS),
+                ('n_sprops', C.c_int), ('sprops', C.c_int * GEN_MAX_SPROPS),
+                ('n_din', C.c_int), ('din', C.c_int * GEN_MAX_PROPS),
+                ('n_dout', C.c_int), ('dout', C.c_int * GEN_MAX_PROPS),
+                ('npar', C.c_int), ('par', C.c_double * GEN_MAX_PAR),
+                ('real', C.c_int), ('start_idx', C.c_long),
+                ('stop_idx', C.c_long)]
 
 
 class HipContext(object):

@@ -251,6 +251,19 @@ TVF_FLUID_PROPS = ['uhat', 'vhat', 'what', 'auhat', 'avhat', 'awhat', 'vmag2',
                    'V', 'arho', 'x0', 'y0', 'z0', 'u0', 'v0', 'w0', 'cs']
 
 
+TVF_SOLID_PROPS = ['u0', 'v0', 'w0', 'V', 'wij', 'ax', 'ay', 'az', 'uf', 'vf',
+                   'wf', 'ug', 'vg', 'wg']
+
+
+def get_particle_array_tvf_solid(constants=None, **props):
+    """utils.py ``get_particle_array_tvf_solid`` (:329-360)."""
+    pa = get_particle_array(constants=constants,
+                            additional_props=TVF_SOLID_PROPS, **props)
+    pa.set_output_arrays(['x', 'y', 'z', 'u', 'v', 'w', 'rho', 'p', 'h', 'm',
+                          'V', 'pid', 'gid', 'tag'])
+    return pa
+
+
 def get_particle_array_tvf_fluid(constants=None, **props):
     """utils.py ``get_particle_array_tvf_fluid``."""
     pa = get_particle_array(constants=constants,

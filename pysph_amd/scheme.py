@@ -84,12 +84,8 @@ class WCSPHScheme(object):
 class TVFScheme(object):
     def __init__(self, fluids, solids, dim, rho0, c0, nu, p0, pb, h0,
                  gx=0.0, gy=0.0, gz=0.0, alpha=0.0, tdamp=0.0):
-        if solids:
-            raise NotImplementedError(
-                'HIP backend: TVF solid-wall equations (SetWallVelocity, '
-                'SolidWallPressureBC, SolidWallNoSlipBC) not implemented')
         self.fluids = list(fluids)
-        self.solids = []
+        self.solids = list(solids or [])
         self.dim = dim
         self.rho0, self.c0, self.nu, self.p0, self.pb, self.h0 = \
             rho0, c0, nu, p0, pb, h0
@@ -98,29 +94,48 @@ class TVFScheme(object):
         self.tdamp = 0.0  # sic: scheme.py:545 ignores the argument
 
     def get_equations(self):
+        """scheme.py:616-687.  The wall equations (``solids`` given) have no
+        hand-written kernel: they run through the generated-family path."""
+        from .wall_equations import (SetWallVelocity, SolidWallNoSlipBC,
+                                     SolidWallPressureBC)
+        everyone = self.fluids + self.solids
         groups = [
             Group(real=False, equations=[
-                TVFSummationDensity(dest=f, sources=self.fluids)
+                TVFSummationDensity(dest=f, sources=everyone)
                 for f in self.fluids]),
-            Group(real=False, equations=[
-                StateEquation(dest=f, sources=None, p0=self.p0,
-                              rho0=self.rho0, b=1.0) for f in self.fluids]),
         ]
+        g2 = [StateEquation(dest=f, sources=None, p0=self.p0, rho0=self.rho0,
+                            b=1.0) for f in self.fluids]
+        g2 += [SetWallVelocity(dest=s, sources=self.fluids) for s in self.solids]
+        groups.append(Group(real=False, equations=g2))
+        if self.solids:
+            groups.append(Group(real=False, equations=[
+                SolidWallPressureBC(dest=s, sources=self.fluids, b=1.0,
+                                    rho0=self.rho0, p0=self.p0, gx=self.gx,
+                                    gy=self.gy, gz=self.gz)
+                for s in self.solids]))
         force = []
         for f in self.fluids:
             force.append(MomentumEquationPressureGradient(
-                dest=f, sources=self.fluids, pb=self.pb, gx=self.gx,
+                dest=f, sources=everyone, pb=self.pb, gx=self.gx,
                 gy=self.gy, gz=self.gz, tdamp=self.tdamp))
             if self.alpha > 0.0:
                 force.append(MomentumEquationArtificialViscosity(
-                    dest=f, sources=self.fluids, c0=self.c0, alpha=self.alpha))
+                    dest=f, sources=everyone, c0=self.c0, alpha=self.alpha))
             if self.nu > 0.0:
                 force.append(MomentumEquationViscosity(
                     dest=f, sources=self.fluids, nu=self.nu))
+                if self.solids:
+                    force.append(SolidWallNoSlipBC(
+                        dest=f, sources=self.solids, nu=self.nu))
             force.append(MomentumEquationArtificialStress(
                 dest=f, sources=self.fluids))
         groups.append(Group(equations=force))
         return groups
 
     def setup_properties(self, particles, clean=True):
-        _ensure_props(particles, TVF_FLUID_PROPS)
+        from .particle_array import TVF_SOLID_PROPS
+        _ensure_props([p for p in particles if p.name in self.fluids],
+                      TVF_FLUID_PROPS)
+        _ensure_props([p for p in particles if p.name in self.solids],
+                      TVF_SOLID_PROPS)

@@ -200,6 +200,57 @@ def case_tvf_cube():
              QuinticSpline(dim=3), 3, t=0.01, meta=dict(dx=dx))
 
 
+def case_tvf_wall():
+    """Fluid block between two wall slabs, the reference TVFScheme WITH solids:
+    SetWallVelocity, SolidWallPressureBC and SolidWallNoSlipBC of
+    transport_velocity.py act next to the momentum equations (the wall
+    equations have no hand-written HIP kernel: this pins the generated-family
+    path against the reference's own classes)."""
+    rng = np.random.default_rng(23)
+    nx, ny, nz, nw = 7, 6, 6, 3
+    dx = 1.0 / nx
+    gx_ = (np.arange(nx) + 0.5) * dx
+    gy_ = (np.arange(ny) + 0.5) * dx
+    gz_ = (np.arange(nz) + 0.5) * dx
+    x, y, z = [a.ravel() for a in np.meshgrid(gx_, gy_, gz_, indexing='ij')]
+    n = x.size
+    rho0, c0 = 1.0, 10.0
+    fluid = dict(
+        x=x + 0.1 * dx * rng.uniform(-1, 1, n),
+        y=y + 0.1 * dx * rng.uniform(-1, 1, n),
+        z=z + 0.1 * dx * rng.uniform(-1, 1, n),
+        u=rng.uniform(-1, 1, n), v=rng.uniform(-1, 1, n),
+        w=rng.uniform(-1, 1, n),
+        uhat=rng.uniform(-1, 1, n), vhat=rng.uniform(-1, 1, n),
+        what=rng.uniform(-1, 1, n),
+        h=dx * np.ones(n), m=rho0 * dx ** 3 * np.ones(n),
+        rho=rho0 * (1 + 0.05 * rng.uniform(-1, 1, n)))
+    for k in ['p', 'V', 'au', 'av', 'aw', 'auhat', 'avhat', 'awhat']:
+        fluid[k] = rng.uniform(0.5, 1, n)
+    # walls: nw layers below y=0 and above y=ny*dx (two layers further than
+    # the kernel support stay untouched by the fluid: wij = 0 branch)
+    gyw = np.concatenate([-(np.arange(nw) + 0.5) * dx,
+                          ny * dx + (np.arange(nw) + 0.5) * dx])
+    xw, yw, zw = [a.ravel() for a in np.meshgrid(gx_, gyw, gz_, indexing='ij')]
+    m_ = xw.size
+    wall = dict(
+        x=xw.copy(), y=yw.copy(), z=zw.copy(),
+        u=0.3 * np.ones(m_) * (yw > 0), v=np.zeros(m_), w=0.1 * np.ones(m_) * (yw < 0),
+        h=dx * np.ones(m_), m=rho0 * dx ** 3 * np.ones(m_),
+        rho=rho0 * np.ones(m_), p=rng.uniform(0.5, 1, m_),
+        V=np.ones(m_) / dx ** 3,
+        au=0.05 * rng.uniform(-1, 1, m_), av=0.05 * rng.uniform(-1, 1, m_),
+        aw=0.05 * rng.uniform(-1, 1, m_))
+    for k in ['wij', 'uf', 'vf', 'wf', 'ug', 'vg', 'wg']:
+        wall[k] = rng.uniform(0.5, 1, m_)
+    s = TVFScheme(['fluid'], ['wall'], dim=3, rho0=rho0, c0=c0, nu=0.01,
+                  p0=c0 * c0 * rho0, pb=c0 * c0 * rho0, h0=dx, gy=-0.5,
+                  alpha=0.2)
+    run_case('tvf_wall.npz', [('fluid', fluid, n), ('wall', wall, m_)],
+             s.get_equations(), QuinticSpline(dim=3), 3, t=0.01,
+             meta=dict(dx=dx))
+
+
 def case_kernels():
     """Kernel known answers from the reference's kernel classes (the same
     functions pysph/base/tests/test_kernel.py integrates)."""

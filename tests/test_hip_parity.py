@@ -57,6 +57,33 @@ def test_golden_parity(case, variant):
     print('golden %s variant %d: max rel err %.3e' % (case, variant, worst))
 
 
+def test_generated_wall_equations_match_reference():
+    """TVF with solid walls: SetWallVelocity, SolidWallPressureBC and
+    SolidWallNoSlipBC have no hand-written kernel -- their Python bodies
+    (pysph_amd/wall_equations.py) are translated by pysph_amd.codegen, compiled
+    for gfx950 and run through sph_eval_generated, next to the hand-written TVF
+    momentum kernels on the same destination.  Golden = the reference's own
+    TVFScheme(fluids, solids) classes executed by oracle/ref_driver.py."""
+    g = load_golden('tvf_wall.npz')
+    arrays = arrays_from_golden(g, 'in')
+    eqs, kernel, dim, outs = golden_case('tvf_wall', g)
+    a_eval, nnps, ctx = make_eval(arrays, eqs, kernel, dim, 3)
+    a_eval.compute(float(g['t']), float(g['dt']))
+    worst, checked = 0.0, 0
+    for pa in arrays:
+        for prop in outs:
+            key = 'out/%s/%s' % (pa.name, prop)
+            if key in g.files and prop in pa.properties:
+                e = rel_err(pa.properties[prop], g[key])
+                worst = max(worst, e)
+                checked += 1
+                assert e < TOL, (pa.name, prop, e)
+    wall = [pa for pa in arrays if pa.name == 'wall'][0]
+    assert (wall.wij == 0).any() and (wall.wij > 0).any()   # both branches of post_loop
+    assert checked >= 18
+    print('tvf_wall (generated families): max rel err %.3e' % worst)
+
+
 @pytest.mark.parametrize('case', ['sd_1d_line', 'wcsph_cube_varh',
                                   'wcsph_dam_dx0.1'])
 def test_neighbour_sets_match_reference(case):

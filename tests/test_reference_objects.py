@@ -34,11 +34,13 @@ def _marshal(groups, arrays):
         cg = _CGroup(g, ids, amap)
         cg.refresh_range()
         eqs = []
-        for i in range(cg.cg.neq):
-            e = cg.ceqs[i]
-            eqs.append((e.kind, e.dest, e.nsrc, list(e.src)[:e.nsrc],
-                        [e.par[k] for k in range(16)]))
-        out.append((cg.cg.real, cg.cg.start_idx, cg.cg.stop_idx, eqs))
+        for u in cg.units:          # one unit per destination, in order
+            for i in range(u.cg.neq):
+                e = u.ceqs[i]
+                eqs.append((e.kind, e.dest, e.nsrc, list(e.src)[:e.nsrc],
+                            [e.par[k] for k in range(16)]))
+        u0 = cg.units[0]
+        out.append((u0.cg.real, u0.cg.start_idx, u0.cg.stop_idx, eqs))
     return out
 
 
