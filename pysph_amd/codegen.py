@@ -27,7 +27,7 @@ arrays, augmented assignment, bare ``return``, the libm calls compyle maps
 ``M_PI``/``pi``, ``self.<scalar attribute>`` (copied by value when the family is
 built, like equation.py:885-892 does), ``d_<prop>[d_idx]``,
 ``s_<prop>[s_idx]``, ``d_<constant>[k]`` and the precomputed symbols ``XIJ
-VIJ R2IJ RIJ HIJ RHOIJ RHOIJ1 EPS WIJ DWIJ WI WJ DWI DWJ t dt``
+VIJ R2IJ RIJ HIJ RHOIJ RHOIJ1 EPS WIJ DWIJ WI WJ DWI DWJ WDP t dt``
 (equation.py:188-297).  Anything else raises ``CodegenError`` -- the equation
 then has to be hand-written or simplified; there is no silent fallback.
 """
@@ -46,7 +46,7 @@ GEN_DIR = os.path.join(_HERE, '_gen')
 
 VEC_SYMBOLS = ('XIJ', 'VIJ', 'DWIJ', 'DWI', 'DWJ')
 SCALAR_SYMBOLS = ('R2IJ', 'RIJ', 'HIJ', 'RHOIJ', 'RHOIJ1', 'EPS', 'WIJ', 'WI',
-                  'WJ', 't', 'dt')
+                  'WJ', 'WDP', 't', 'dt')
 MATH_1 = {'sqrt': 'sqrt', 'exp': 'exp', 'log': 'log', 'sin': 'sin',
           'cos': 'cos', 'tan': 'tan', 'tanh': 'tanh', 'fabs': 'fabs',
           'abs': 'fabs', 'floor': 'floor', 'ceil': 'ceil', 'log10': 'log10',
@@ -352,6 +352,10 @@ class _Body(object):
             if len(st.targets) != 1:
                 self.err(st, 'chained assignment')
             tgt = st.targets[0]
+            if isinstance(tgt, ast.Tuple) and self._declare_call(st.value) is not None:
+                for t_ in tgt.elts:       # i, j = declare('int', 2)
+                    self._declare(t_, ('double', None), st)
+                return
             if isinstance(tgt, ast.Tuple):
                 if not isinstance(st.value, ast.Tuple) or len(tgt.elts) != len(st.value.elts):
                     self.err(st, 'tuple assignment')
@@ -611,6 +615,8 @@ class GeneratedFamily(object):
             A('        const double RHOIJ1 = 1.0 / RHOIJ; (void)RHOIJ1;')
         if 'WIJ' in S:
             A('        const double WIJ = pair_w<KK, UH>(g);')
+        if 'WDP' in S:   # KERNEL(XIJ, DELTAP*HIJ, HIJ), equation.py:243-246
+            A('        const double WDP = SphKernel<KK>::template w<false>((a.k.deltap * g.hij) * g.h1) * g.fac;')
         if 'DWIJ' in S:
             A('        const double tg_ = pair_gradfac<KK, UH>(g);')
             A('        const double DWIJ[3] = {tg_ * XIJ[0], tg_ * XIJ[1], tg_ * XIJ[2]};')

@@ -84,6 +84,73 @@ def test_generated_wall_equations_match_reference():
     print('tvf_wall (generated families): max rel err %.3e' % worst)
 
 
+def _custom_setup(varh, seed=5):
+    from pysph_amd.equations import Group
+    from pysph_amd.particle_array import get_particle_array
+    from custom_equations import KitchenSink, PowerLawState, WallPush
+    rng = np.random.default_rng(seed)
+    n1 = 9
+    dx = 1.0 / n1
+    g = (np.arange(n1) + 0.5) * dx
+    x, y, z = [a.ravel() for a in np.meshgrid(g, g, g, indexing='ij')]
+    wall = y < 2.5 * dx
+    arrays = []
+    for name, msk in (('fluid', ~wall), ('solid', wall)):
+        n = int(msk.sum())
+        pa = get_particle_array(
+            name=name, constants=dict(coef=np.array([1.25, -0.5])),
+            x=x[msk] + 0.1 * dx * rng.uniform(-1, 1, n),
+            y=y[msk] + 0.1 * dx * rng.uniform(-1, 1, n),
+            z=z[msk] + 0.1 * dx * rng.uniform(-1, 1, n),
+            u=rng.uniform(-1, 1, n), v=rng.uniform(-1, 1, n), w=rng.uniform(-1, 1, n),
+            h=1.3 * dx * (1 + varh * rng.uniform(-1, 1, n)),
+            m=dx ** 3 * np.ones(n), rho=1 + 0.1 * rng.uniform(-1, 1, n),
+            additional_props=['q', 'gx', 'gy', 'gz', 'e'])
+        for k in ('q', 'gx', 'gy', 'gz', 'e', 'p'):
+            pa.properties[k][:] = rng.uniform(1, 2, n)     # junk the equations must overwrite
+        arrays.append(pa)
+    eqs = [
+        Group(real=False, equations=[PowerLawState('fluid', None, k=1.5, n=1.4),
+                                     PowerLawState('solid', None, k=0.5, n=2.0)]),
+        Group(equations=[
+            KitchenSink('fluid', ['fluid', 'solid'], a=0.3, b=0.05, flag=True),
+            WallPush('fluid', ['solid'], c=0.7),
+            KitchenSink('solid', ['fluid'], a=0.1, b=2.0, flag=False)]),
+    ]
+    return arrays, eqs
+
+
+@pytest.mark.parametrize('varh', [0.0, 0.15])
+@pytest.mark.parametrize('kname', ['CubicSpline', 'Gaussian'])
+def test_generated_custom_equations_vs_python(oracle, varh, kname):
+    """Arbitrary user equations (tests/custom_equations.py) through the
+    generated-family path vs the same Python bodies executed by
+    oracle/py_eval.py: no-source equations with an array constant, two
+    equations with different source lists on one destination, WI/WJ/DWI/DWJ
+    with per-particle h (and the uniform-h specialisation), local arrays,
+    loops, early return, elif chains."""
+    from oracle.py_eval import PyEval
+    from pysph_amd import kernels as K
+    arrays, eqs = _custom_setup(varh)
+    ref = _copy_arrays(arrays)
+    for r, a in zip(ref, arrays):
+        r.constants = dict((k, v.copy()) for k, v in a.constants.items())
+    kernel = getattr(K, kname)(dim=3)
+    t, dt = 0.25, 1e-3
+    a_eval, nnps, ctx = make_eval(arrays, eqs, kernel, 3)
+    a_eval.compute(t, dt)
+    onn = oracle.OracleNNPS(3, ref, radius_scale=kernel.radius_scale)
+    onn.update()
+    PyEval(ref, eqs, kernel, onn).compute(t, dt)
+    worst = 0.0
+    for pa, pr in zip(arrays, ref):
+        for prop in ('p', 'e', 'q', 'gx', 'gy', 'gz'):
+            e = rel_err(pa.properties[prop], pr.properties[prop])
+            worst = max(worst, e)
+            assert e < TOL, (pa.name, prop, e)
+    print('custom equations %s varh=%g: max rel err %.3e' % (kname, varh, worst))
+
+
 @pytest.mark.parametrize('case', ['sd_1d_line', 'wcsph_cube_varh',
                                   'wcsph_dam_dx0.1'])
 def test_neighbour_sets_match_reference(case):
