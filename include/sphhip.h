@@ -289,6 +289,11 @@ int sph_halo_select(sph_ctx *ctx, int array_id, int axis, int mode, double p0, d
  * `axis` coordinate (periodic wrap, nnps_base.pyx:841-856).                */
 int sph_halo_pack(sph_ctx *ctx, int array_id, int side, int nprops, const int *props, int axis,
                   double shift, void *dst_device);
+/* As sph_halo_pack for a reflecting boundary: the `axis` coordinate becomes
+ * x + 2*(plane - x), the `axis` velocity component (u, v or w) changes sign
+ * (CPUDomainManager._create_ghosts_mirror, pysph/base/nnps_base.pyx:506-697). */
+int sph_halo_pack_mirror(sph_ctx *ctx, int array_id, int side, int nprops, const int *props, int axis,
+                         double plane, void *dst_device);
 /* Append `count` ghost particles (tag Remote: sources only) behind the
  * current ones from a device buffer laid out [nprops][count].  n grows,
  * n_real is unchanged.  Drop them again with sph_array_resize(n_real).      */

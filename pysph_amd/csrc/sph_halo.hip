@@ -125,6 +125,45 @@ extern "C" int sph_halo_pack(sph_ctx *c, int id, int side, int nprops, const int
     return SPH_OK;
 }
 
+__global__ __launch_bounds__(256) void k_halo_gather_mirror(const double *__restrict__ src, const uint32_t *__restrict__ list,
+                                                            size_t count, int what, double plane, double *__restrict__ dst)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const double v = src[list[i]];
+    // what 1: the mirrored coordinate, x + 2*(plane - x) as nnps_base.pyx:568-575,598-611 computes it
+    //      2: the normal velocity component, sign flipped (_mul_to_array(.., -1))
+    dst[i] = what == 1 ? v + 2.0 * (plane - v) : (what == 2 ? -v : v);
+}
+
+// Mirror images of the particles selected for `side` (CPUDomainManager.
+// _create_ghosts_mirror, pysph/base/nnps_base.pyx:506-697): coordinate
+// reflected about `plane`, normal velocity negated, everything else copied.
+extern "C" int sph_halo_pack_mirror(sph_ctx *c, int id, int side, int nprops, const int *props, int axis, double plane,
+                                    void *dst)
+{
+    if (!c || id < 0 || id >= SPH_MAX_ARRAYS || side < 0 || side > 1 || nprops < 1 || axis < 0 || axis > 2) {
+        sph_set_error("sph_halo_pack_mirror: bad arguments");
+        return SPH_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    DevArray &A = c->arr[id];
+    HaloState &H = c->halo[id];
+    size_t cnt = H.count[side];
+    if (cnt == 0) return SPH_OK;
+    for (int k = 0; k < nprops; k++) {
+        int p = props[k];
+        if (p < 0 || p >= SPH_PROP_COUNT || !A.prop[p]) {
+            sph_set_error("sph_halo_pack_mirror: array %d has no device property %d", id, p);
+            return SPH_ERR_MISSING_PROP;
+        }
+        const int what = p == SPH_X + axis ? 1 : (p == SPH_U + axis ? 2 : 0);
+        hipLaunchKernelGGL(k_halo_gather_mirror, dim3(div_up(cnt, 256)), dim3(256), 0, c->stream, A.prop[p],
+                           H.list[side].as<uint32_t>(), cnt, what, plane, (double *)dst + (size_t)k * cnt);
+    }
+    return SPH_OK;
+}
+
 extern "C" int sph_halo_append(sph_ctx *c, int id, int nprops, const int *props, const void *src, size_t count)
 {
     if (!c || id < 0 || id >= SPH_MAX_ARRAYS || nprops < 1) { sph_set_error("sph_halo_append: bad arguments"); return SPH_ERR_ARG; }

@@ -20,8 +20,11 @@ Two implementations with the same interface:
   ``sph_halo_select(mode=1)`` / ``sph_halo_pack`` / ``sph_halo_append`` -- the
   ghost copy is the multi-GPU halo copy with a coordinate shift.
 
-Mirror (reflecting) boundaries are not implemented (not used by the
-BASELINE configs) and raise.
+Mirror (reflecting) boundaries (``mirror_in_x/y/z``,
+``_create_ghosts_mirror`` :506-697) use the same machinery: every particle
+(images of earlier axes included -- the corner reflections) within
+``n_layers * cell_size`` of a mirror plane gets an image with the coordinate
+``x + 2*(plane - x)`` and the normal velocity component negated.
 """
 import ctypes as C
 
@@ -36,8 +39,8 @@ class _DomainBase(object):
                  zmax=0., periodic_in_x=False, periodic_in_y=False,
                  periodic_in_z=False, n_layers=2.0, props=None,
                  mirror_in_x=False, mirror_in_y=False, mirror_in_z=False):
-        if mirror_in_x or mirror_in_y or mirror_in_z:
-            raise NotImplementedError('mirror boundaries are not implemented')
+        self.mirror = [bool(mirror_in_x), bool(mirror_in_y), bool(mirror_in_z)]
+        self.is_mirror = any(self.mirror)
         for lo, hi in ((xmin, xmax), (ymin, ymax), (zmin, zmax)):
             if hi < lo:
                 raise ValueError('Invalid domain limits')   # _check_limits
@@ -80,7 +83,7 @@ class DomainManager(_DomainBase):
         return 1.0 if cs < 1e-6 else cs
 
     def update(self):
-        if not self.is_periodic:
+        if not (self.is_periodic or self.is_mirror):
             return
         for pa in self.particles:
             if pa.get_number_of_particles() != pa.get_number_of_particles(True):
@@ -111,6 +114,24 @@ class DomainManager(_DomainBase):
                     g.properties[name] += shift
                     pa.append_parray(g, tag=ParticleTAGS.Ghost)
                     pa.set_num_real_particles(nreal)
+            # reflecting planes, after the periodic images (nnps_base.pyx:471-480)
+            for ax, (name, vel) in enumerate(zip('xyz', 'uvw')):
+                if not self.mirror[ax]:
+                    continue
+                lo, hi = self.lims[ax]
+                v = pa.properties[name]
+                low = np.nonzero((v - lo) <= width)[0]
+                high = np.nonzero((hi - v) <= width)[0]
+                for idx, plane in ((low, lo), (high, hi)):
+                    if idx.size == 0:
+                        continue
+                    g = pa.extract_particles(idx)
+                    c = g.properties[name]
+                    c += 2.0 * (plane - c)
+                    if vel in g.properties:
+                        g.properties[vel] *= -1.0
+                    pa.append_parray(g, tag=ParticleTAGS.Ghost)
+                    pa.set_num_real_particles(nreal)
 
 
 class HipDomainManager(_DomainBase):
@@ -136,7 +157,7 @@ class HipDomainManager(_DomainBase):
         return out[7]
 
     def update(self):
-        if not self.is_periodic:
+        if not (self.is_periodic or self.is_mirror):
             return
         lib, ctx = self.lib, self.ctx._h
         for h in self.helpers:
@@ -175,6 +196,29 @@ class HipDomainManager(_DomainBase):
                     if cnt:
                         dev._check(lib.sph_halo_pack(
                             ctx, aid, side, nprops, pr, ax, shift,
+                            C.c_void_p(buf.data_ptr())))
+                    bufs.append((buf, cnt))
+                for buf, cnt in bufs:
+                    if cnt:
+                        dev._check(lib.sph_halo_append(
+                            ctx, aid, nprops, pr, C.c_void_p(buf.data_ptr()),
+                            cnt))
+            for ax in range(3):
+                if not self.mirror[ax]:
+                    continue
+                lo, hi = self.lims[ax]
+                counts = (C.c_size_t * 2)()
+                n_all = h.get_number_of_particles()
+                dev._check(lib.sph_halo_select(ctx, aid, ax, 1, lo, hi, width,
+                                               n_all, counts))
+                bufs = []
+                for side, plane in ((0, lo), (1, hi)):
+                    cnt = int(counts[side])
+                    buf = torch.empty(max(cnt * nprops, 1), dtype=torch.float64,
+                                      device=device)
+                    if cnt:
+                        dev._check(lib.sph_halo_pack_mirror(
+                            ctx, aid, side, nprops, pr, ax, plane,
                             C.c_void_p(buf.data_ptr())))
                     bufs.append((buf, cnt))
                 for buf, cnt in bufs:

@@ -169,3 +169,100 @@ def test_device_domain_manager_matches_host(oracle):
     for prop in ('rho', 'V', 'p', 'au', 'av', 'aw', 'auhat', 'avhat', 'awhat'):
         e = rel_err(pa.properties[prop][:nreal], ref[0].properties[prop][:nreal])
         assert e < 1e-10, (prop, e)
+
+
+def test_host_mirror_ghosts_lattice_density(oracle):
+    """Reflecting planes (nnps_base.pyx:506-697): a lattice whose first layer
+    sits half a spacing from the plane continues seamlessly across it, so the
+    summation density of a closed mirrored box equals that of the periodic
+    one for every particle; images carry the flipped normal velocity; corner
+    images (x and y reflected) exist."""
+    from pysph_amd import kernels as K
+    from pysph_amd.domain import DomainManager
+    from pysph_amd.equations import Group, TVFSummationDensity
+    pa, dx = lattice(12, dim=2, hdx=1.2)
+    pa.u[:] = 1.0 + pa.y
+    pa.v[:] = -0.5
+    kernel = K.QuinticSpline(dim=2)
+    dom = DomainManager(xmin=0, xmax=1, ymin=0, ymax=1, mirror_in_x=True,
+                        mirror_in_y=True)
+    dom.set_particles([pa], kernel.radius_scale)
+    dom.update()
+    n, nreal = pa.get_number_of_particles(), pa.get_number_of_particles(True)
+    assert nreal == 144 and n > nreal and np.all(pa.tag[nreal:] == 2)
+    dom.update()
+    assert pa.get_number_of_particles() == n                  # idempotent
+    gx, gy, gu, gv = pa.x[nreal:], pa.y[nreal:], pa.u[nreal:], pa.v[nreal:]
+    assert gx.min() < 0 and gx.max() > 1 and gy.min() < 0 and gy.max() > 1
+    corner = (gx < 0) & (gy < 0)
+    assert corner.any()
+    # every image is the reflection of a real particle: fold back and match
+    fx = np.where(gx < 0, -gx, np.where(gx > 1, 2 - gx, gx))
+    fy = np.where(gy < 0, -gy, np.where(gy > 1, 2 - gy, gy))
+    real = set(zip(np.round(pa.x[:nreal] / dx - 0.5).astype(int),
+                   np.round(pa.y[:nreal] / dx - 0.5).astype(int)))
+    assert all((int(round(a / dx - 0.5)), int(round(b / dx - 0.5))) in real
+               for a, b in zip(fx, fy))
+    xflip = (gx < 0) | (gx > 1)
+    yflip = (gy < 0) | (gy > 1)
+    assert np.allclose(np.where(xflip, -gu, gu), 1.0 + fy, atol=1e-14)
+    assert np.allclose(np.where(yflip, -gv, gv), -0.5, atol=1e-14)
+    eqs = [Group(equations=[TVFSummationDensity(dest='fluid', sources=['fluid'])])]
+    nn = oracle.OracleNNPS(2, [pa], kernel.radius_scale)
+    nn.update()
+    ev = oracle.OracleEval([pa], eqs, kernel)
+    ev.set_nnps(nn)
+    ev.compute(0.0, 0.1)
+    V = pa.V[:nreal]
+    assert np.max(np.abs(V - V[0])) < 1e-11 * V[0]
+    assert np.max(np.abs(1.0 / V - dx ** 2)) < 1e-4 * dx ** 2
+
+
+@pytest.mark.gpu
+def test_device_mirror_matches_host(oracle):
+    """HipDomainManager with reflecting planes (sph_halo_pack_mirror) builds
+    the same image set as the host DomainManager (periodic in z on top) and
+    the WCSPH evaluation of the real particles agrees with the oracle."""
+    from pysph_amd import kernels as K
+    from pysph_amd import device as dev
+    from pysph_amd.domain import DomainManager, HipDomainManager
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.nnps import HipNNPS
+    from test_hip_parity import _copy_arrays, make_cube, cube_equations
+    pa, dx = make_cube(12)
+    kernel = K.WendlandQuintic(dim=3)
+    eqs = cube_equations(dx)
+    kw = dict(xmin=0, xmax=1, ymin=0, ymax=1, zmin=0, zmax=1, mirror_in_x=True,
+              mirror_in_y=True, periodic_in_z=True, n_layers=1.0)
+    ref = _copy_arrays([pa])
+    dref = DomainManager(**kw)
+    dref.set_particles(ref, kernel.radius_scale)
+    dref.update()
+    onn = oracle.OracleNNPS(3, ref, kernel.radius_scale)
+    onn.update()
+    oev = oracle.OracleEval(ref, eqs, kernel, nthreads=4)
+    oev.set_nnps(onn)
+    oev.compute(0.0, 1e-5)
+    ctx = dev.HipContext(0)
+    nreal = pa.get_number_of_particles()
+    dev.attach(pa, ctx).push()
+    a_eval = AccelerationEval([pa], eqs, kernel)
+    SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+    nnps = HipNNPS(3, [pa], radius_scale=kernel.radius_scale, ctx=ctx,
+                   domain=HipDomainManager(ctx=ctx, **kw), sync=False)
+    a_eval.set_nnps(nnps)
+    n_dev = pa.gpu.get_number_of_particles()
+    assert n_dev == ref[0].get_number_of_particles() and n_dev > nreal
+    # same image SET (positions + flipped velocities), order aside
+    got = np.empty((5, n_dev))
+    for k, p in enumerate(('x', 'y', 'z', 'u', 'v')):
+        pa.gpu.pull_into(p, got[k])
+    want = np.array([ref[0].properties[p] for p in ('x', 'y', 'z', 'u', 'v')])
+    key = lambda a: a[:, np.lexsort(a[::-1])]
+    assert np.array_equal(key(got[:, nreal:]), key(want[:, nreal:]))
+    a_eval.compute(0.0, 1e-5)
+    outs = ('arho', 'au', 'av', 'aw', 'ax', 'ay', 'az')
+    pa.gpu.pull(*outs)
+    for prop in outs:
+        e = rel_err(pa.properties[prop][:nreal], ref[0].properties[prop][:nreal])
+        assert e < 1e-10, (prop, e)
