@@ -113,6 +113,16 @@ def load_library(path=None):
                 'HIP extension %s is missing: run `python -c "import '
                 '__graft_entry__ as g; g.build()"` (or make -C pysph_amd/csrc)'
                 % path)
+        # One HIP/HSA runtime per process: PyTorch-ROCm bundles its own
+        # libamdhip64/libhsa-runtime64, and whichever runtime initialises
+        # first owns the device (measured: creating a context from this
+        # library before `import torch` leaves torch without GPUs).  torch is
+        # this package's plumbing for streams, device buffers and RCCL, so let
+        # it load its runtime first; libsphhip then binds to the same one.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if not exported

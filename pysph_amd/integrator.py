@@ -122,6 +122,9 @@ class Integrator(object):
         for pa in self.acceleration_evals[0].particle_arrays:
             if pa.get_number_of_particles(True):
                 hmin = min(hmin, pa.gpu.min('h'))
+        pm = self.parallel_manager
+        if pm is not None and hasattr(pm, 'reduce_min'):
+            hmin = pm.reduce_min([hmin])[0]        # parallel_manager.pyx:463
         self.h_minimum = hmin
 
     def _get_dt_adapt_factors(self):
@@ -131,6 +134,9 @@ class Integrator(object):
                 if name in pa.properties and dev.prop_id(name) >= 0 and \
                         pa.get_number_of_particles(True):
                     factors[i] = max(factors[i], pa.gpu.max(name))
+        pm = self.parallel_manager
+        if pm is not None and hasattr(pm, 'reduce_max'):
+            factors = pm.reduce_max(factors)
         return factors
 
     def compute_time_step(self, dt, cfl):

@@ -331,6 +331,37 @@ class SlabDecomposition(object):
         return faces, rounds
 
 
+class HipParallelManager(object):
+    """The object ``Integrator.set_parallel_manager`` expects
+    (integrator.py:274-286 calls ``pm.update()`` before every ``nnps.update()``;
+    solver.py:476-480 and parallel_manager.pyx:463 reduce the adaptive
+    time-step inputs over all ranks): a ``SlabDecomposition`` plus the scalar
+    all-reduces, with an optional re-balance every ``rebalance_every`` updates
+    (the reference's ``lb_freq``)."""
+
+    def __init__(self, decomposition, rebalance_every=0, weights=None):
+        self.dec = decomposition
+        self.dist = decomposition.dist
+        self.rebalance_every = int(rebalance_every)
+        self.weights = weights
+        self.count = 0
+        self._device = getattr(decomposition.halos[0].ops, 'device', None)
+
+    def update(self):
+        self.count += 1
+        if self.rebalance_every and self.count % self.rebalance_every == 0:
+            self.dec.rebalance(weights=self.weights)
+            self.dec.exchange()
+        else:
+            self.dec.update()
+
+    def reduce_max(self, values):
+        return allreduce_scalars(values, 'max', dist=self.dist, device=self._device)
+
+    def reduce_min(self, values):
+        return allreduce_scalars(values, 'min', dist=self.dist, device=self._device)
+
+
 def allreduce_scalars(values, op, dist=None, device=None):
     """MIN/MAX of a few doubles over all ranks (dt, dt_cfl, dt_force, bounds,
     hmax): parallel_manager.pyx:463 ``update_time_steps`` and :937-945

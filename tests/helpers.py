@@ -73,6 +73,14 @@ class ThreadDist(object):
     def __init__(self, world):
         import queue
         import threading
+        try:                      # initialise torch's HIP state once, in the
+            import torch          # creating thread (lazy init from several
+            if torch.cuda.is_available():      # threads at once races)
+                torch.cuda.init()
+                torch.zeros(1, device='cuda')      # forces context creation
+                torch.cuda.synchronize()
+        except ImportError:
+            pass
         self.world = world
         self.barrier = threading.Barrier(world)
         self.slots = [None] * world

@@ -135,3 +135,109 @@ def test_epec_steps_device_resident_vs_oracle(oracle):
     want = 0.3 * min(hmin / r.dt_cfl.max(),
                      np.sqrt(hmin / np.sqrt(r.dt_force.max())))
     assert abs(got - want) < 1e-9 * want
+
+
+@pytest.mark.gpu
+def test_epec_steps_two_slab_ranks_match_single_domain():
+    """SURVEY.md 8(e) parity check: the same EPEC run on one context and on
+    two slab ranks (two threads on one GPU, tests/helpers.ThreadDist standing in
+    for torch.distributed) -- migration across the slab face, ghost refresh
+    before every evaluation, re-balancing, all-reduced adaptive time step --
+    ends in the same particle state, matched by global id."""
+    import threading
+    import torch
+    from helpers import ThreadDist
+    from pysph_amd import device as dev
+    from pysph_amd import kernels as K
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.integrator import EPECIntegrator, WCSPHStep, setup_integrator
+    from pysph_amd.nnps import HipNNPS
+    from pysph_amd.parallel import HipParallelManager, SlabDecomposition
+    from pysph_amd.particle_array import ParticleArray
+    from test_hip_parity import make_cube, cube_equations
+    full, dx = make_cube(16)
+    n = full.get_number_of_particles()
+    full.u[:] += 6.0               # drift in +x: particles cross the slab face
+    full.add_property('e0', data=np.arange(n, dtype=np.float64))
+    eqs = cube_equations(dx)
+    kernel = K.WendlandQuintic(dim=3)
+    dt = 0.25 * 1.3 * dx / 32.85
+    nsteps = 6
+    PROPS = ('x', 'y', 'z', 'u', 'v', 'w', 'rho', 'au', 'av', 'aw', 'arho')
+
+    def run(pa, ctx, pm_factory=None):
+        dev.attach(pa, ctx).push()
+        a_eval = AccelerationEval([pa], eqs, kernel)
+        SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+        nnps = HipNNPS(3, [pa], radius_scale=2.0, ctx=ctx, sync=False)
+        a_eval.set_nnps(nnps)
+        integ = EPECIntegrator(fluid=WCSPHStep())
+        setup_integrator(integ, a_eval, nnps)
+        pm = None
+        if pm_factory:
+            pm = pm_factory(pa, ctx)
+            integ.set_parallel_manager(pm)
+        t = 0.0
+        for _ in range(nsteps):
+            integ.step(t, dt)
+            t += dt
+        dtn = integ.compute_time_step(dt, 0.3)
+        pa.gpu.managed = True
+        pa.gpu.sync_host()
+        return dict((k, pa.properties[k].copy()) for k in PROPS + ('e0',)), dtn, pm
+
+    # single domain
+    single = ParticleArray(name='fluid', **{k: v.copy() for k, v in full.properties.items()})
+    ref, dt_ref, _ = run(single, dev.HipContext(0))
+
+    hub = ThreadDist(2)
+    results, errors = {}, []
+
+    def rank_main(rank):
+        try:
+            ts = torch.cuda.Stream()
+            with torch.cuda.stream(ts):
+                x = full.x
+                own = np.nonzero(x < 0.5)[0] if rank == 0 else np.nonzero(x >= 0.5)[0]
+                pa = ParticleArray(name='fluid', **{k: v[own].copy() for k, v in full.properties.items()})
+                ctx = dev.HipContext(0, ts.cuda_stream)
+                lo, hi = (0.0, 0.5) if rank == 0 else (0.5, 1.0)
+
+                def pmf(pa_, ctx_):
+                    dec = SlabDecomposition([pa_], ctx_, rank, 2, axis=0,
+                                            width=2.0 * 1.3 * dx * 1.05, lo=lo, hi=hi,
+                                            dist=hub.view(rank))
+                    return HipParallelManager(dec, rebalance_every=5)
+                out, dtn, pm = run(pa, ctx, pmf)
+                results[rank] = (out, dtn, pm.dec.halos[0].last_migrated, pm.count)
+        except Exception:
+            import traceback
+            errors.append(traceback.format_exc())
+            try:
+                hub.barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t_ in threads:
+        t_.start()
+    for t_ in threads:
+        t_.join(600)
+    assert not errors, errors[0]
+    order = np.argsort(ref['e0'])
+    gids = []
+    moved = 0
+    for r in range(2):
+        out, dtn, mig, count = results[r]
+        gid = out['e0'].astype(np.int64)
+        gids.append(gid)
+        moved += sum(mig)
+        assert count == 2 * nsteps                 # pm.update() before every evaluation
+        assert abs(dtn - dt_ref) < 1e-9 * dt_ref   # all-reduced dt inputs
+        for k in PROPS:
+            e = rel_err(out[k], ref[k][order][gid])
+            assert e < 1e-9, (r, k, e)
+    assert (np.sort(np.concatenate(gids)) == np.arange(n)).all()
+    # the drift really moved particles over the face at some point
+    start_left = int((full.x < 0.5).sum())
+    assert len(gids[0]) != start_left or moved > 0
