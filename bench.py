@@ -110,7 +110,7 @@ def cpu_baseline(n1=100, target_seconds=15.0):
                       'schedule(dynamic,64), %d threads)' % (n1, n, reps, cores)}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
@@ -127,8 +127,11 @@ def main():
                     help='skip Solver.reorder_particles() before timing')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-n1', type=int, default=100)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def main():
+    args = parse_args()
     import torch
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -142,6 +145,19 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world,
                                 device_id=torch.device('cuda', local_rank))
+    out = run(args, rank, local_rank, world, dist)
+    if out is not None:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run(args, rank, local_rank, world, dist):
+    """One rank of the benchmark; `dist` is torch.distributed (RCCL) or, in the
+    one-GPU test of the N>1 code path, an in-process stand-in with the same
+    calls (tests/helpers.ThreadDist).  Returns the JSON dict on rank 0."""
+    import torch
 
     from pysph_amd import device as dev
     from pysph_amd import kernels as K
@@ -248,12 +264,12 @@ def main():
         from pysph_amd.parallel import SlabDecomposition
         halo = SlabDecomposition(arrays, ctx, rank, world, axis=0,
                                  width=kernel.radius_scale * 1.3 * dx,
-                                 lo=slab_lo, hi=slab_hi)
+                                 lo=slab_lo, hi=slab_hi, dist=dist)
     elif world > 1:
         from pysph_amd.parallel import SlabHalo
         halo = SlabHalo(pa, ctx, rank, world, axis=0,
                         width=kernel.radius_scale * 1.3 * dx,
-                        lo=float(rank), hi=float(rank + 1))
+                        lo=float(rank), hi=float(rank + 1), dist=dist)
     a_eval = AccelerationEval(arrays, eqs, kernel)
     SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
     nnps = HipNNPS(3, arrays, radius_scale=kernel.radius_scale, ctx=ctx,
@@ -365,10 +381,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.cpu_n1)
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        return out
+    return None
 
 
 if __name__ == '__main__':
