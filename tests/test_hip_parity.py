@@ -414,6 +414,45 @@ def test_edge_cases_empty_single_and_2d(oracle):
         assert np.array_equal(start, ostart)
 
 
+@pytest.mark.parametrize('varh', [0.0, 0.1])
+def test_dense_cells_coincident_particles(oracle, varh):
+    """Stress the rarely taken paths of the aggregated kernel: > 96 candidates
+    in a lane's 3-cell range (exact in-place tail), rows longer than one
+    480-candidate tile (several tiles per row, mask slots flushed mid-source),
+    and distinct particles at IDENTICAL positions (r = 0: the reference's
+    r > 1e-12 gradient guard, linked-list neighbours include them)."""
+    from pysph_amd import kernels as K
+    from pysph_amd.particle_array import get_particle_array_wcsph
+    rng = np.random.default_rng(17)
+    n = 9000
+    x, y, z = rng.uniform(0, 1, n), rng.uniform(0, 1, n), rng.uniform(0, 0.5, n)
+    x[-60:], y[-60:], z[-60:] = x[:60], y[:60], z[:60]         # exact duplicates
+    h0 = 0.11
+    pa = get_particle_array_wcsph(
+        name='fluid', x=x, y=y, z=z, h=h0 * (1 + varh * rng.uniform(-1, 1, n)),
+        m=np.ones(n) / n, rho=1000.0 * (1 + 0.02 * rng.uniform(-1, 1, n)),
+        u=rng.uniform(-1, 1, n), v=rng.uniform(-1, 1, n), w=rng.uniform(-1, 1, n))
+    eqs = cube_equations(h0 / 1.3)
+    kernel = K.WendlandQuintic(dim=3)
+    ref = _copy_arrays([pa])
+    onn = oracle.OracleNNPS(3, ref, 2.0)
+    onn.update()
+    oev = oracle.OracleEval(ref, eqs, kernel, nthreads=8)
+    oev.set_nnps(onn)
+    oev.compute(0.0, 1e-5)
+    ostart, _ = onn.get_csr(0, 0)
+    assert np.diff(ostart.astype(np.int64)).max() > 300       # really dense
+    for variant in (0, 3):
+        q = _copy_arrays([pa])
+        a_eval, nnps, ctx = make_eval(q, eqs, kernel, 3, variant)
+        a_eval.compute(0.0, 1e-5)
+        start, idx = nnps.get_csr(0, 0)
+        assert np.array_equal(start, ostart)
+        for prop in WC_OUT:
+            e = rel_err(q[0].properties[prop], ref[0].properties[prop])
+            assert e < TOL, (variant, prop, e)
+
+
 def test_error_behaviour():
     """Same failures as the reference: RuntimeError for missing properties
     (acceleration_eval.py:32-73) and for >2^28 cells
