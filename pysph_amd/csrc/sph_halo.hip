@@ -45,12 +45,31 @@ __global__ __launch_bounds__(256) void k_halo_scatter(const uint32_t *__restrict
     if (flag[i]) list[pos[i]] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(256) void k_halo_gather(const double *__restrict__ src, const uint32_t *__restrict__ list,
-                                                     size_t count, double shift, double *__restrict__ dst)
+// Every property of one pack/append call in ONE launch (blockIdx.y = property):
+// a periodic domain update is ~200 property gathers, launch-bound otherwise.
+struct PropList {
+    double *p[SPH_PROP_COUNT];
+    int what[SPH_PROP_COUNT]; // 0 copy, 1 add `val`, 2 mirror about `val`, 3 negate
+};
+
+__global__ __launch_bounds__(256) void k_halo_gather_multi(PropList L, const uint32_t *__restrict__ list, size_t count,
+                                                           double val, double *__restrict__ dst)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    dst[i] = src[list[i]] + shift;
+    const int k = blockIdx.y, what = L.what[k];
+    const double v = L.p[k][list[i]];
+    // mirror: x + 2*(plane - x) as nnps_base.pyx:568-575,598-611 computes it
+    dst[(size_t)k * count + i] = what == 1 ? v + val : (what == 2 ? v + 2.0 * (val - v) : (what == 3 ? -v : v));
+}
+
+__global__ __launch_bounds__(256) void k_halo_append_multi(PropList L, const double *__restrict__ src, size_t n0,
+                                                           size_t count)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int k = blockIdx.y;
+    L.p[k][n0 + i] = src[(size_t)k * count + i];
 }
 
 
@@ -103,7 +122,7 @@ extern "C" int sph_halo_select(sph_ctx *c, int id, int axis, int mode, double p0
 extern "C" int sph_halo_pack(sph_ctx *c, int id, int side, int nprops, const int *props, int axis, double shift,
                              void *dst)
 {
-    if (!c || id < 0 || id >= SPH_MAX_ARRAYS || side < 0 || side > 1 || nprops < 1) {
+    if (!c || id < 0 || id >= SPH_MAX_ARRAYS || side < 0 || side > 1 || nprops < 1 || nprops > SPH_PROP_COUNT) {
         sph_set_error("sph_halo_pack: bad arguments");
         return SPH_ERR_ARG;
     }
@@ -112,28 +131,19 @@ extern "C" int sph_halo_pack(sph_ctx *c, int id, int side, int nprops, const int
     HaloState &H = c->halo[id];
     size_t cnt = H.count[side];
     if (cnt == 0) return SPH_OK;
+    PropList L;
     for (int k = 0; k < nprops; k++) {
         int p = props[k];
         if (p < 0 || p >= SPH_PROP_COUNT || !A.prop[p]) {
             sph_set_error("sph_halo_pack: array %d has no device property %d", id, p);
             return SPH_ERR_MISSING_PROP;
         }
-        hipLaunchKernelGGL(k_halo_gather, dim3(div_up(cnt, 256)), dim3(256), 0, c->stream, A.prop[p],
-                           H.list[side].as<uint32_t>(), cnt, (p == SPH_X + axis) ? shift : 0.0,
-                           (double *)dst + (size_t)k * cnt);
+        L.p[k] = A.prop[p];
+        L.what[k] = (p == SPH_X + axis) ? 1 : 0;
     }
+    hipLaunchKernelGGL(k_halo_gather_multi, dim3(div_up(cnt, 256), nprops), dim3(256), 0, c->stream, L,
+                       H.list[side].as<uint32_t>(), cnt, shift, (double *)dst);
     return SPH_OK;
-}
-
-__global__ __launch_bounds__(256) void k_halo_gather_mirror(const double *__restrict__ src, const uint32_t *__restrict__ list,
-                                                            size_t count, int what, double plane, double *__restrict__ dst)
-{
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const double v = src[list[i]];
-    // what 1: the mirrored coordinate, x + 2*(plane - x) as nnps_base.pyx:568-575,598-611 computes it
-    //      2: the normal velocity component, sign flipped (_mul_to_array(.., -1))
-    dst[i] = what == 1 ? v + 2.0 * (plane - v) : (what == 2 ? -v : v);
 }
 
 // Mirror images of the particles selected for `side` (CPUDomainManager.
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(256) void k_halo_gather_mirror(const double *__rest
 extern "C" int sph_halo_pack_mirror(sph_ctx *c, int id, int side, int nprops, const int *props, int axis, double plane,
                                     void *dst)
 {
-    if (!c || id < 0 || id >= SPH_MAX_ARRAYS || side < 0 || side > 1 || nprops < 1 || axis < 0 || axis > 2) {
+    if (!c || id < 0 || id >= SPH_MAX_ARRAYS || side < 0 || side > 1 || nprops < 1 || nprops > SPH_PROP_COUNT || axis < 0 || axis > 2) {
         sph_set_error("sph_halo_pack_mirror: bad arguments");
         return SPH_ERR_ARG;
     }
@@ -151,16 +161,19 @@ extern "C" int sph_halo_pack_mirror(sph_ctx *c, int id, int side, int nprops, co
     HaloState &H = c->halo[id];
     size_t cnt = H.count[side];
     if (cnt == 0) return SPH_OK;
+    PropList L;
     for (int k = 0; k < nprops; k++) {
         int p = props[k];
         if (p < 0 || p >= SPH_PROP_COUNT || !A.prop[p]) {
             sph_set_error("sph_halo_pack_mirror: array %d has no device property %d", id, p);
             return SPH_ERR_MISSING_PROP;
         }
-        const int what = p == SPH_X + axis ? 1 : (p == SPH_U + axis ? 2 : 0);
-        hipLaunchKernelGGL(k_halo_gather_mirror, dim3(div_up(cnt, 256)), dim3(256), 0, c->stream, A.prop[p],
-                           H.list[side].as<uint32_t>(), cnt, what, plane, (double *)dst + (size_t)k * cnt);
+        L.p[k] = A.prop[p];
+        // the mirrored coordinate; the normal velocity component flips sign (_mul_to_array(.., -1))
+        L.what[k] = p == SPH_X + axis ? 2 : (p == SPH_U + axis ? 3 : 0);
     }
+    hipLaunchKernelGGL(k_halo_gather_multi, dim3(div_up(cnt, 256), nprops), dim3(256), 0, c->stream, L,
+                       H.list[side].as<uint32_t>(), cnt, plane, (double *)dst);
     return SPH_OK;
 }
 
@@ -172,9 +185,11 @@ extern "C" int sph_halo_append(sph_ctx *c, int id, int nprops, const int *props,
     size_t n0 = A.n;
     for (int k = 0; k < nprops; k++) SPH_TRY(sph_array_ensure_prop(c, id, props[k]));
     SPH_TRY(sph_array_resize(c, id, n0 + count, A.n_real));
-    for (int k = 0; k < nprops; k++)
-        HIP_TRY(hipMemcpyAsync(A.prop[props[k]] + n0, (const double *)src + (size_t)k * count, count * sizeof(double),
-                               hipMemcpyDeviceToDevice, c->stream));
+    if (nprops > SPH_PROP_COUNT) { sph_set_error("sph_halo_append: too many properties"); return SPH_ERR_ARG; }
+    PropList L;
+    for (int k = 0; k < nprops; k++) { L.p[k] = A.prop[props[k]]; L.what[k] = 0; }
+    hipLaunchKernelGGL(k_halo_append_multi, dim3(div_up(count, 256), nprops), dim3(256), 0, c->stream, L,
+                       (const double *)src, n0, count);
     c->nnps_valid = false;
     return SPH_OK;
 }
