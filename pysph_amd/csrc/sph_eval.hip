@@ -191,7 +191,8 @@ struct PackArgs {
     double *aux;
     double *rec;                  // non-null: interleaved records [x y z h aux... pad], nr doubles each
     int nr;
-    int layout;                   // 0: [x y z h | aux...]; 1: WCSPH [x y z cs | u v w m | rho tmpj | h p]; 2: density [x y z m]
+    int layout;                   // 0: [x y z h | aux...]; 1: WCSPH [x y z cs | u v w m | rho tmpj | h p]; 2: density [x y z m];
+                                  // 3: TVF [x y z rho | u v w p | Vj2 m uhat vhat | what -]
                                   // (1, 2: aggregated kernel only)
     float4 *fpos;                 // non-null: fp32 {x-xmin, y-ymin, z-zmin, radius_scale*h} for the prefilter tiles
     double gmin[3];
@@ -230,6 +231,14 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
             r2[2] = make_double2(v[0], v[1]); r2[3] = make_double2(v[2], v[3]);
             r2[4] = make_double2(v[4], v[5]);
             if (a.nr > 10) r2[5] = make_double2(ph.w, v[7]);
+            return;
+        }
+        if (a.layout == 3) { // TVF under uniform h: [x y z rho | u v w p | Vj2 m uhat vhat | what -]
+            double2 *r2 = reinterpret_cast<double2 *>(r);
+            r2[0] = make_double2(ph.x, ph.y); r2[1] = make_double2(ph.z, v[6]);
+            r2[2] = make_double2(v[0], v[1]); r2[3] = make_double2(v[2], v[7]);
+            r2[4] = make_double2(v[10], v[9]); r2[5] = make_double2(v[3], v[4]);
+            r2[6] = make_double2(v[5], 0.0);
             return;
         }
         if (a.layout == 2) { // compact density records [x y z m] (uniform h)
@@ -456,18 +465,16 @@ struct FamTVF {
             D.au += tmp * vij0; D.av += tmp * vij1; D.aw += tmp * vij2;
         }
         if (fl & F_TAS) { // :473-545
-            double ui = D.u, vi = D.v, wi = D.w, uj = s[0], vj = s[1], wj = s[2];
-            double du_i = D.uh - ui, dv_i = D.vh - vi, dw_i = D.wh - wi;
-            double du_j = s[3] - uj, dv_j = s[4] - vj, dw_j = s[5] - wj;
-            double ri = D.rho, rj = rhoj;
-            double Ax = 0.5 * ((ri * ui * du_i + rj * uj * du_j) * dw0 + (ri * ui * dv_i + rj * uj * dv_j) * dw1 +
-                               (ri * ui * dw_i + rj * uj * dw_j) * dw2);
-            double Ay = 0.5 * ((ri * vi * du_i + rj * vj * du_j) * dw0 + (ri * vi * dv_i + rj * vj * dv_j) * dw1 +
-                               (ri * vi * dw_i + rj * vj * dw_j) * dw2);
-            double Az = 0.5 * ((ri * wi * du_i + rj * wj * du_j) * dw0 + (ri * wi * dv_i + rj * wj * dv_j) * dw1 +
-                               (ri * wi * dw_i + rj * wj * dw_j) * dw2);
-            double tmp = D.mi1 * vsum;
-            D.au += tmp * Ax; D.av += tmp * Ay; D.aw += tmp * Az;
+            // A = rho v (x) (vhat - v);  0.5 (A_i + A_j) . DWIJ, with the dot
+            // products (vhat - v) . DWIJ taken first (same terms as the
+            // reference's 18 products, associated per particle)
+            const double ddi = (D.uh - D.u) * dw0 + (D.vh - D.v) * dw1 + (D.wh - D.w) * dw2;
+            const double ddj = (s[3] - s[0]) * dw0 + (s[4] - s[1]) * dw1 + (s[5] - s[2]) * dw2;
+            const double ci = D.rho * ddi, cj = rhoj * ddj;
+            const double tmp = 0.5 * D.mi1 * vsum;
+            D.au += tmp * (ci * D.u + cj * s[0]);
+            D.av += tmp * (ci * D.v + cj * s[1]);
+            D.aw += tmp * (ci * D.w + cj * s[2]);
         }
     }
     template <class A> static __device__ __forceinline__ void finish(Dest &D, const A &a, uint32_t o)
@@ -481,6 +488,21 @@ struct FamTVF {
         if (a.dflags & F_TP) { a.p.auhat[o] = D.auh; a.p.avhat[o] = D.avh; a.p.awhat[o] = D.awh; }
     }
 };
+
+// TVF records of the aggregated kernel under uniform h (see k_pack layout 3):
+// five 16-B pieces per pair, two more only when the artificial-stress term acts.
+template <> __device__ __forceinline__ void load_record<FamTVF, true>(const double *__restrict__ rj, uint32_t fl, double4 &pj, double (&s)[12])
+{
+    const double2 *r2 = reinterpret_cast<const double2 *>(rj);
+    const double2 a0 = r2[0], a1 = r2[1], b0 = r2[2], b1 = r2[3], c0 = r2[4];
+    pj.x = a0.x; pj.y = a0.y; pj.z = a1.x; pj.w = 0.0;
+    s[0] = b0.x; s[1] = b0.y; s[2] = b1.x; s[6] = a1.y; s[7] = b1.y; s[8] = 0.0; s[9] = c0.y; s[10] = c0.x; s[11] = 0.0;
+    s[3] = s[4] = s[5] = 0.0;
+    if (fl & F_TAS) {
+        const double2 d0 = r2[5], d1 = r2[6];
+        s[3] = d0.x; s[4] = d0.y; s[5] = d1.x;
+    }
+}
 
 // ---- velocity gradient (basic_equations.py:63-148) -------------------------
 struct FamVGrad {
@@ -989,7 +1011,8 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
     pa.radius_scale = c->radius_scale;
     if (c->pair_variant >= 2) pa.rec = c->posh.as<double>();
     if (c->pair_variant >= 3) pa.fpos = c->fposb.as<float4>();
-    pa.layout = (c->pair_variant == 3 && fam == FAM_WCSPH) ? 1 : (c->pair_variant == 3 && fam == FAM_DENSITY && pl.nr == 4) ? 2 : 0;
+    pa.layout = (c->pair_variant == 3 && fam == FAM_WCSPH) ? 1 : (c->pair_variant == 3 && fam == FAM_DENSITY && pl.nr == 4) ? 2
+              : (c->pair_variant == 3 && fam == FAM_TVF && pl.nr == 14) ? 3 : 0;
     hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, pa);
     return SPH_OK;
 }
@@ -1169,6 +1192,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         // compact 80-B WCSPH records when neither h nor p of a neighbour is read
         if (c->pair_variant == 3 && fam == FAM_WCSPH && c->uniform_h && c->use_uniform_h && !(dflags & F_TENSILE)) pl.nr = 10;
         if (c->pair_variant == 3 && fam == FAM_DENSITY && c->uniform_h && c->use_uniform_h) pl.nr = 4;
+        if (c->pair_variant == 3 && fam == FAM_TVF && c->uniform_h && c->use_uniform_h) pl.nr = 14;
         c->cur_nrec = pl.nr;
         SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * (c->pair_variant >= 2 ? pl.nr : 4)));
         SPH_TRY(c->aux.reserve((total + 64) * sizeof(double) * pl.na));
