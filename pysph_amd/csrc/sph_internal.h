@@ -48,6 +48,7 @@ struct DevArray {
     DevBuf keys, keys_sorted, idx, perm; // uint32 each; perm: sorted position -> original index
     DevBuf cell_start;                   // uint32[n_cells + 1]
     int nnps_slot = -1;                  // position in the last sph_nnps_update list
+    size_t perm_n = 0;                   // particles `perm` was built for (0: none / already applied)
 };
 
 // ghost selection lists of one array (sph_halo.hip)

@@ -272,6 +272,7 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
         c->ids[a] = ids[a];
         DevArray &A = c->arr[ids[a]];
         A.nnps_slot = a;
+        A.perm_n = A.n;
         size_t n = A.n;
         SPH_TRY(A.keys.reserve((n + 1) * 4));
         SPH_TRY(A.keys_sorted.reserve((n + 1) * 4));
@@ -429,7 +430,14 @@ __global__ __launch_bounds__(256) void k_gather_f64(const double *__restrict__ s
 extern "C" int sph_nnps_reorder_array(sph_ctx *c, int id)
 {
     if (!c || id < 0 || id >= SPH_MAX_ARRAYS) { sph_set_error("sph_nnps_reorder_array: bad arguments"); return SPH_ERR_ARG; }
-    if (!c->nnps_valid || c->arr[id].nnps_slot < 0) { sph_set_error("sph_nnps_reorder_array: array not binned"); return SPH_ERR_STATE; }
+    // the cell order of the LAST sph_nnps_update is applied (as the reference's
+    // spatially_order_particles uses the cell lists of its last update); several
+    // arrays can be reordered back to back, each at most once per update
+    if (c->arr[id].nnps_slot < 0 || c->arr[id].perm_n != c->arr[id].n) {
+        if (c->arr[id].n == 0) return SPH_OK;
+        sph_set_error("sph_nnps_reorder_array: array not binned (call sph_nnps_update first; one reorder per update)");
+        return SPH_ERR_STATE;
+    }
     HIP_TRY(hipSetDevice(c->device));
     DevArray &A = c->arr[id];
     if (A.n == 0) return SPH_OK;
@@ -452,6 +460,7 @@ extern "C" int sph_nnps_reorder_array(sph_ctx *c, int id)
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipFree(tmp));
+    A.perm_n = 0;
     c->nnps_valid = false;
     return SPH_OK;
 }

@@ -91,3 +91,72 @@ def create_particles(dx=0.02, hdx=hdx):
     geom = DamBreak3DGeometry(dx=dx, nboundary_layers=nboundary_layers,
                               hdx=hdx, rho0=ro)
     return geom.create_particles()
+
+
+def run(dx=0.04, n_steps=20, tf=None, cfl=0.3, reorder_freq=50, ctx=None,
+        adaptive=True, log=None):
+    """The time loop of ``Solver.solve`` (pysph/solver/solver.py:430-520) for
+    this problem with everything device-resident: EPEC integrator with
+    ``WCSPHStep`` for the fluid (boundary and obstacle have no stepper, as in
+    ``WCSPHScheme.configure_solver`` scheme.py:360-386), adaptive time step
+    from the device reductions (integrator.py:161-200), particles re-ordered
+    into cell order every ``reorder_freq`` steps (solver.py:296-302).  One push
+    before the loop, one pull after.  Returns (arrays, stats)."""
+    import time
+
+    from .. import device as dev
+    from ..acceleration_eval import AccelerationEval, SPHCompiler
+    from ..integrator import EPECIntegrator, WCSPHStep, setup_integrator
+    from ..nnps import HipNNPS
+    ctx = ctx or dev.HipContext(0)
+    arrays = create_particles(dx)
+    kernel = create_kernel()
+    eqs = create_scheme(dx).get_equations()
+    for a in arrays:
+        dev.attach(a, ctx).push()
+    a_eval = AccelerationEval(arrays, eqs, kernel)
+    SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+    nnps = HipNNPS(dim, arrays, radius_scale=kernel.radius_scale, ctx=ctx,
+                   sync=False)
+    a_eval.set_nnps(nnps)
+    integ = EPECIntegrator(fluid=WCSPHStep())
+    setup_integrator(integ, a_eval, nnps)
+    dt = 0.125 * hdx * dx / (1.1 * c0)        # dam_break_3d.py:33 (dt = 0.125 h0/(1.1 c0))
+    t, step, t0 = 0.0, 0, time.perf_counter()
+    dts = []
+    while step < n_steps and (tf is None or t < tf):
+        if reorder_freq and step % reorder_freq == 0:
+            for i in range(len(arrays)):
+                nnps.spatially_order_particles(i)
+            nnps.update()
+        integ.step(t, dt)
+        t += dt
+        step += 1
+        dts.append(dt)
+        if adaptive:
+            new = integ.compute_time_step(dt, cfl)
+            if new is not None:
+                dt = new
+        if log and step % log == 0:
+            print('step %d  t = %.5f  dt = %.3e' % (step, t, dt))
+    ctx.synchronize()
+    wall = time.perf_counter() - t0
+    for a in arrays:
+        a.gpu.pull()
+    n = sum(a.get_number_of_particles() for a in arrays)
+    stats = dict(steps=step, t=t, wall_s=wall, steps_per_s=step / wall,
+                 particles=n, particle_steps_per_s=n * step / wall, dts=dts)
+    return arrays, stats
+
+
+if __name__ == '__main__':
+    import argparse
+    ap = argparse.ArgumentParser(description='3-D dam break on one MI355X')
+    ap.add_argument('--dx', type=float, default=0.02)
+    ap.add_argument('--steps', type=int, default=200)
+    args = ap.parse_args()
+    _, st = run(dx=args.dx, n_steps=args.steps, log=50)
+    print('%d particles, %d steps to t = %.4f s in %.2f s wall: %.1f steps/s, '
+          '%.3g particle-steps/s' % (st['particles'], st['steps'], st['t'],
+                                     st['wall_s'], st['steps_per_s'],
+                                     st['particle_steps_per_s']))
