@@ -66,20 +66,23 @@ __global__ __launch_bounds__(256) void k_minmax(const double *__restrict__ x, co
     }
 }
 
-__global__ __launch_bounds__(64) void k_minmax_final(const double *__restrict__ part, int nblocks, double *__restrict__ out)
+__global__ __launch_bounds__(512) void k_minmax_final(const double *__restrict__ part, int nblocks, double *__restrict__ out)
 {
-    int k = threadIdx.x & 7;
+    // 64 groups of 8 lanes stride over the partials (the single-wavefront
+    // version spent 35-70 us on a chain of dependent loads)
+    __shared__ double s[64][8];
+    const int k = threadIdx.x & 7, g = threadIdx.x >> 3;
     double v = (k < 4) ? DBL_MAX : -DBL_MAX;
-    for (int b = threadIdx.x >> 3; b < nblocks; b += 8) {
+    for (int b = g; b < nblocks; b += 64) {
         double w = part[(size_t)b * 8 + k];
         v = (k < 4) ? fmin(v, w) : fmax(v, w);
     }
-    // combine the 8 lane-groups (lanes k, k+8, ..., k+56)
-    for (int o = 8; o < 64; o <<= 1) {
-        double w = __shfl_xor(v, o, 64);
-        v = (k < 4) ? fmin(v, w) : fmax(v, w);
+    s[g][k] = v;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        for (int q = 1; q < 64; q++) v = (k < 4) ? fmin(v, s[q][k]) : fmax(v, s[q][k]);
+        out[k] = v;
     }
-    if (threadIdx.x < 8) out[k] = v;
 }
 
 int nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *out8)
@@ -105,7 +108,7 @@ int nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *out8)
         for (int k = 0; k < 4; k++) { out8[k] = DBL_MAX; out8[4 + k] = -DBL_MAX; }
         return SPH_OK;
     }
-    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(64), 0, c->stream, c->red_part.as<double>(), nb_total,
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(512), 0, c->stream, c->red_part.as<double>(), nb_total,
                        c->red_out.as<double>());
     HIP_TRY(hipMemcpyAsync(c->pinned, c->red_out.ptr, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
