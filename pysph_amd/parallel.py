@@ -156,11 +156,11 @@ class SlabHalo(object):
         r, w = self.rank, self.world
         if r > 0:
             out.append((0, r - 1, 0.0))
-        elif self.periodic and w > 1:
+        elif self.periodic:          # w == 1: the slab is its own neighbour
             out.append((0, w - 1, +self.period))
         if r < w - 1:
             out.append((1, r + 1, 0.0))
-        elif self.periodic and w > 1:
+        elif self.periodic:
             out.append((1, 0, -self.period))
         return out
 
@@ -176,10 +176,15 @@ class SlabHalo(object):
         # what peer sends to me: its hi list if it is my lo neighbour, else lo
         recv_cnt = {s: allc[2 * peer + (1 - s)] for s, peer, _ in nbrs}
         in_buf = {s: ops.new_buffer(recv_cnt[s], nprops) for s, _, _ in nbrs}
+        # Between one pair of ranks messages match in posting order.  With a
+        # periodic axis and <= 2 ranks both faces talk to the SAME peer, whose
+        # side-0 buffer expects my side-1 list: post the sends hi-face first,
+        # the receives lo-face first.
         reqs = []
-        for s, peer, _ in nbrs:
+        for s, peer, _ in sorted(nbrs, key=lambda nb: -nb[0]):
             if send_cnt[s]:
                 reqs.append(dist.P2POp(dist.isend, out_buf[s], peer))
+        for s, peer, _ in sorted(nbrs, key=lambda nb: nb[0]):
             if recv_cnt[s]:
                 reqs.append(dist.P2POp(dist.irecv, in_buf[s], peer))
         if reqs:

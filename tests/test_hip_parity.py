@@ -6,6 +6,8 @@ Bar (BASELINE.json north_star): fp64 results within 1e-10 relative of the
 reference.  `rel_err` scales by max|field| (mixed abs/rel), see helpers.py.
 Neighbour SETS must be identical (integer work: bit-exact).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -723,6 +725,72 @@ def test_dam_break_two_slabs_three_arrays_one_gpu(oracle):
                             scale=max(np.abs(pr.properties[prop]).max(), 1e-300))
                 assert e < TOL, (r, pr.name, prop, e)
         assert seen == pr.get_number_of_particles()
+
+
+def test_rccl_transport_self_periodic_slab(oracle):
+    """The REAL transport on one GPU: torch.distributed with the nccl backend
+    (= RCCL) and world_size 1.  A slab that is periodic along its own axis is
+    its own neighbour on both faces, so SlabHalo.exchange() runs its whole
+    RCCL path -- all_gather_into_tensor for the counts, batch_isend_irecv for
+    both payloads (two messages to the SAME peer: the posting-order case) --
+    on the context's stream; all_reduce for the scalars.  Reference: the same
+    periodic images from the host DomainManager, evaluated by the oracle."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from pysph_amd import device as dev
+    from pysph_amd import kernels as K
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.domain import DomainManager
+    from pysph_amd.nnps import HipNNPS
+    from pysph_amd.parallel import SlabHalo, allreduce_scalars
+    pa, dx = make_cube(20)
+    nreal = pa.get_number_of_particles()
+    kernel = K.WendlandQuintic(dim=3)
+    eqs = cube_equations(dx)
+    ref = _copy_arrays([pa])
+    dom = DomainManager(xmin=0.0, xmax=1.0, periodic_in_x=True, n_layers=1.0)
+    dom.set_particles(ref, kernel.radius_scale)
+    dom.update()
+    onn = oracle.OracleNNPS(3, ref, 2.0)
+    onn.update()
+    oev = oracle.OracleEval(ref, eqs, kernel, nthreads=4)
+    oev.set_nnps(onn)
+    oev.compute(0.0, 1e-5)
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('nccl', rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    try:
+        ts = torch.cuda.Stream()
+        with torch.cuda.stream(ts):
+            ctx = dev.HipContext(0, ts.cuda_stream)
+            dev.attach(pa, ctx).push()
+            halo = SlabHalo(pa, ctx, 0, 1, axis=0, width=kernel.radius_scale * 1.3 * dx,
+                            lo=0.0, hi=1.0, periodic=True, period=1.0, dist=dist)
+            halo.exchange()
+            halo.exchange()                      # ghosts are dropped and rebuilt
+            sent_lo, sent_hi, got_lo, got_hi = halo.last_counts
+            assert sent_lo > 0 and sent_hi > 0 and (got_lo, got_hi) == (sent_hi, sent_lo)
+            assert pa.gpu.get_number_of_particles() == ref[0].get_number_of_particles()
+            a_eval = AccelerationEval([pa], eqs, kernel)
+            SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+            nnps = HipNNPS(3, [pa], radius_scale=2.0, ctx=ctx, sync=False)
+            a_eval.set_nnps(nnps)
+            a_eval.compute(0.0, 1e-5)
+            mx = allreduce_scalars([pa.gpu.max('dt_cfl')], 'max', dist=dist,
+                                   device=torch.device('cuda', 0))[0]
+            pa.gpu.pull(*WC_OUT)
+    finally:
+        dist.destroy_process_group()
+    assert mx == ref[0].dt_cfl[:nreal].max()
+    for prop in WC_OUT:
+        e = rel_err(pa.properties[prop][:nreal], ref[0].properties[prop][:nreal])
+        assert e < TOL, (prop, e)
 
 
 def test_device_reorder_keeps_results(oracle):

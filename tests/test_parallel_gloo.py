@@ -247,7 +247,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize('periodic', [False])
+@pytest.mark.parametrize('periodic', [False, True])
 def test_two_rank_halo_matches_single_domain(tmp_path, oracle, periodic):
     from test_hip_parity import make_cube, cube_equations
     from helpers import rel_err
@@ -255,7 +255,16 @@ def test_two_rank_halo_matches_single_domain(tmp_path, oracle, periodic):
     out = str(tmp_path / 'rank%d.npz')
     mp.spawn(_worker, args=(2, _free_port(), periodic, out), nprocs=2, join=True)
     full, dx = make_cube(14)
+    nfull = full.get_number_of_particles()
     kernel = K.WendlandQuintic(dim=3)
+    if periodic:
+        # single-domain reference: periodic images in x (both faces talk to the
+        # SAME peer with two ranks: the message-order case of SlabHalo._swap)
+        from pysph_amd.domain import DomainManager
+        dom = DomainManager(xmin=0.0, xmax=1.0, periodic_in_x=True, n_layers=1.0)
+        dom.set_particles([full], kernel.radius_scale)
+        dom.update()
+        assert full.get_number_of_particles() > nfull
     nn = oracle.OracleNNPS(3, [full], 2.0)
     nn.update()
     ev = oracle.OracleEval([full], cube_equations(dx), kernel)
@@ -272,8 +281,8 @@ def test_two_rank_halo_matches_single_domain(tmp_path, oracle, periodic):
                   'dt_cfl', 'dt_force'):
             assert rel_err(d[k], full.properties[k][gid]) < 1e-13, (r, k)
         gmax = float(np.load((out % r) + '.max.npy')[0])
-    assert seen == full.get_number_of_particles()
-    assert gmax == full.dt_cfl.max()      # all_reduce(MAX) of the dt input
+    assert seen == nfull
+    assert gmax == full.dt_cfl[:nfull].max()      # all_reduce(MAX) of the dt input
 
 
 def test_slab_bounds_equal_counts():
