@@ -562,11 +562,14 @@ class GeneratedFamily(object):
         A('// generated by pysph_amd/codegen.py -- do not edit')
         A('// destination: %s; equations: %s' % (
             self.dest, ', '.join(type(e).__name__ for e in self.equations)))
+        A('#ifndef SPHGEN_MINB')
+        A('#define SPHGEN_MINB 3')
+        A('#endif')
         A('#include "sph_pair.h"')
         A('#include <cstring>')
         A('')
         A('struct FamGen {')
-        A('    static constexpr int MINB = 3;')
+        A('    static constexpr int MINB = SPHGEN_MINB;   // workgroups per CU, chosen at build time')
         A('    static constexpr int NA = %d;' % na)
         A('    static constexpr int NR = 4 + NA;')
         A('    struct Params {')
@@ -713,13 +716,32 @@ class GeneratedFamily(object):
         with open(src, 'w') as f:
             f.write(self.source)
         hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-        cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC',
-               '-shared', '-I', CSRC, '-I', INCLUDE, src, '-o', so + '.tmp']
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                           universal_newlines=True)
-        if r.returncode != 0:
-            raise CodegenError('hipcc failed for %s:\n%s\n--- source: %s' %
-                               (self.name, r.stdout[-4000:], src))
+        # occupancy: 4 workgroups/CU (128 VGPRs) when the pair kernel fits
+        # without scratch, else 3 (168), else 2 (256) -- what the hand-written
+        # families fix by hand (Fam::MINB), read here from the compiler's
+        # resource-usage remarks
+        log = ''
+        for minb in (4, 3, 2):
+            cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC',
+                   '-shared', '-DSPHGEN_MINB=%d' % minb,
+                   '-Rpass-analysis=kernel-resource-usage', '-I', CSRC, '-I',
+                   INCLUDE, src, '-o', so + '.tmp']
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               universal_newlines=True)
+            log = r.stdout
+            if r.returncode != 0:
+                errs = [ln for ln in log.splitlines() if 'remark:' not in ln]
+                raise CodegenError('hipcc failed for %s:\n%s\n--- source: %s' %
+                                   (self.name, '\n'.join(errs)[-4000:], src))
+            scratch, in_pair = 0, False
+            for ln in log.splitlines():
+                if 'Function Name:' in ln:
+                    in_pair = 'k_pair_agg' in ln
+                elif in_pair and 'ScratchSize' in ln:
+                    scratch = max(scratch, int(ln.split(':')[-1].split('[')[0]))
+            self.minb, self.scratch = minb, scratch
+            if scratch == 0 or minb == 2:
+                break
         os.replace(so + '.tmp', so)
         return so
 

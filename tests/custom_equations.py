@@ -77,3 +77,97 @@ class WallPush(Equation):
 
     def loop(self, d_idx, s_idx, d_gy, s_p, d_rho, WIJ, RIJ, HIJ):
         d_gy[d_idx] += self.c * s_p[s_idx] / d_rho[d_idx] * WIJ * (RIJ / HIJ) ** 2
+
+
+# ---------------------------------------------------------------------------
+# The WCSPH rate equations as Python bodies (semantics of
+# pysph/sph/basic_equations.py:177-192, :285-300 and pysph/sph/wc/basic.py:198-271):
+# the SAME physics the hand-written FamWCSPH kernel implements, here pushed
+# through the translator -- generated vs hand-written on identical input.
+# ---------------------------------------------------------------------------
+class PyContinuity(Equation):
+    def initialize(self, d_idx, d_arho):
+        d_arho[d_idx] = 0.0
+
+    def loop(self, d_idx, d_arho, s_idx, s_m, DWIJ, VIJ):
+        vijdotdwij = DWIJ[0] * VIJ[0] + DWIJ[1] * VIJ[1] + DWIJ[2] * VIJ[2]
+        d_arho[d_idx] += s_m[s_idx] * vijdotdwij
+
+
+class PyMomentum(Equation):
+    def __init__(self, dest, sources, c0, alpha=1.0, beta=1.0, gx=0.0, gy=0.0,
+                 gz=0.0, tensile_correction=False):
+        self.c0, self.alpha, self.beta = c0, alpha, beta
+        self.gx, self.gy, self.gz = gx, gy, gz
+        self.tensile_correction = tensile_correction
+        super(PyMomentum, self).__init__(dest, sources)
+
+    def initialize(self, d_idx, d_au, d_av, d_aw, d_dt_cfl):
+        d_au[d_idx] = 0.0
+        d_av[d_idx] = 0.0
+        d_aw[d_idx] = 0.0
+        d_dt_cfl[d_idx] = 0.0
+
+    def loop(self, d_idx, s_idx, d_rho, d_cs, d_p, d_au, d_av, d_aw, s_m, s_rho,
+             s_cs, s_p, VIJ, XIJ, HIJ, R2IJ, RHOIJ1, EPS, DWIJ, WIJ, WDP, d_dt_cfl):
+        rhoi21 = 1.0 / (d_rho[d_idx] * d_rho[d_idx])
+        rhoj21 = 1.0 / (s_rho[s_idx] * s_rho[s_idx])
+        vijdotxij = VIJ[0] * XIJ[0] + VIJ[1] * XIJ[1] + VIJ[2] * XIJ[2]
+        piij = 0.0
+        if vijdotxij < 0:
+            cij = 0.5 * (d_cs[d_idx] + s_cs[s_idx])
+            muij = (HIJ * vijdotxij) / (R2IJ + EPS)
+            piij = -self.alpha * cij * muij + self.beta * muij * muij
+            piij = piij * RHOIJ1
+        if R2IJ > 1e-12:
+            _dt_cfl = abs(HIJ * vijdotxij / R2IJ) + self.c0
+            d_dt_cfl[d_idx] = max(_dt_cfl, d_dt_cfl[d_idx])
+        tmpi = d_p[d_idx] * rhoi21
+        tmpj = s_p[s_idx] * rhoj21
+        fij = WIJ / WDP
+        Ri = 0.0
+        Rj = 0.0
+        if self.tensile_correction:
+            fij = fij * fij
+            fij = fij * fij
+            if d_p[d_idx] > 0:
+                Ri = 0.01 * tmpi
+            else:
+                Ri = 0.2 * abs(tmpi)
+            if s_p[s_idx] > 0:
+                Rj = 0.01 * tmpj
+            else:
+                Rj = 0.2 * abs(tmpj)
+        tmp = (tmpi + tmpj) + (Ri + Rj) * fij
+        d_au[d_idx] += -s_m[s_idx] * (tmp + piij) * DWIJ[0]
+        d_av[d_idx] += -s_m[s_idx] * (tmp + piij) * DWIJ[1]
+        d_aw[d_idx] += -s_m[s_idx] * (tmp + piij) * DWIJ[2]
+
+    def post_loop(self, d_idx, d_au, d_av, d_aw, d_dt_force):
+        d_au[d_idx] += self.gx
+        d_av[d_idx] += self.gy
+        d_aw[d_idx] += self.gz
+        d_dt_force[d_idx] = d_au[d_idx] * d_au[d_idx] + d_av[d_idx] * d_av[d_idx] + \
+            d_aw[d_idx] * d_aw[d_idx]
+
+
+class PyXSPH(Equation):
+    def __init__(self, dest, sources, eps=0.5):
+        self.eps = eps
+        super(PyXSPH, self).__init__(dest, sources)
+
+    def initialize(self, d_idx, d_ax, d_ay, d_az):
+        d_ax[d_idx] = 0.0
+        d_ay[d_idx] = 0.0
+        d_az[d_idx] = 0.0
+
+    def loop(self, s_idx, d_idx, s_m, d_ax, d_ay, d_az, WIJ, RHOIJ1, VIJ):
+        tmp = -self.eps * s_m[s_idx] * WIJ * RHOIJ1
+        d_ax[d_idx] += tmp * VIJ[0]
+        d_ay[d_idx] += tmp * VIJ[1]
+        d_az[d_idx] += tmp * VIJ[2]
+
+    def post_loop(self, d_idx, d_ax, d_ay, d_az, d_u, d_v, d_w):
+        d_ax[d_idx] += d_u[d_idx]
+        d_ay[d_idx] += d_v[d_idx]
+        d_az[d_idx] += d_w[d_idx]

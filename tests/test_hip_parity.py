@@ -153,6 +153,68 @@ def test_generated_custom_equations_vs_python(oracle, varh, kname):
     print('custom equations %s varh=%g: max rel err %.3e' % (kname, varh, worst))
 
 
+@pytest.mark.parametrize('tensile', [False, True])
+def test_generated_wcsph_matches_handwritten_and_oracle(oracle, tensile):
+    """Continuity + Momentum (+tensile correction) + XSPH written as Python
+    bodies (tests/custom_equations.py) and pushed through the translator, vs
+    the hand-written FamWCSPH kernel and the C oracle on the same 110 k-particle
+    cube: the generated family sits on the same skeleton, so it must agree
+    with both to rounding -- and its run time is printed next to the
+    hand-written one."""
+    import time
+    from custom_equations import PyContinuity, PyMomentum, PyXSPH
+    from pysph_amd.equations import Group, TaitEOS
+    pa, dx = make_cube(48)
+    kernel = K_Wendland()
+    c0 = 32.85
+    hand = cube_equations(dx) if not tensile else None
+    from pysph_amd.equations import (ContinuityEquation, MomentumEquation,
+                                     XSPHCorrection)
+    kw = dict(c0=c0, alpha=0.25, beta=0.1, gz=-9.81, tensile_correction=tensile)
+    eos = Group(real=False, equations=[TaitEOS(dest='fluid', sources=None, rho0=1000.0,
+                                                c0=c0, gamma=7.0)])
+    hand = [eos, Group(equations=[
+        ContinuityEquation(dest='fluid', sources=['fluid']),
+        MomentumEquation(dest='fluid', sources=['fluid'], **kw),
+        XSPHCorrection(dest='fluid', sources=['fluid'], eps=0.5)])]
+    gen = [eos, Group(equations=[
+        PyContinuity(dest='fluid', sources=['fluid']),
+        PyMomentum(dest='fluid', sources=['fluid'], **kw),
+        PyXSPH(dest='fluid', sources=['fluid'], eps=0.5)])]
+    out = {}
+    for tag, eqs in (('hand', hand), ('gen', gen)):
+        q = _copy_arrays([pa])
+        a_eval, nnps, ctx = make_eval(q, eqs, kernel, 3, 3, sync='manual')
+        q[0].gpu.push()
+        nnps.update()
+        a_eval.compute(0.0, 1e-5)            # warm-up (and the build of the family)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            a_eval.compute(0.0, 1e-5)
+        ctx.synchronize()
+        out[tag + '_ms'] = (time.perf_counter() - t0) / 5 * 1e3
+        q[0].gpu.pull()
+        out[tag] = q[0]
+    ref = _copy_arrays([pa])
+    onn = oracle.OracleNNPS(3, ref, 2.0)
+    onn.update()
+    oev = oracle.OracleEval(ref, hand, kernel, nthreads=8)
+    oev.set_nnps(onn)
+    oev.compute(0.0, 1e-5)
+    for prop in WC_OUT:
+        e1 = rel_err(out['gen'].properties[prop], out['hand'].properties[prop])
+        e2 = rel_err(out['gen'].properties[prop], ref[0].properties[prop])
+        assert e1 < TOL and e2 < TOL, (prop, e1, e2)
+    print('WCSPH 110k, tensile=%s: hand-written %.3f ms, generated %.3f ms per compute'
+          % (tensile, out['hand_ms'], out['gen_ms']))
+
+
+def K_Wendland():
+    from pysph_amd import kernels as K
+    return K.WendlandQuintic(dim=3)
+
+
 @pytest.mark.parametrize('case', ['sd_1d_line', 'wcsph_cube_varh',
                                   'wcsph_dam_dx0.1'])
 def test_neighbour_sets_match_reference(case):
