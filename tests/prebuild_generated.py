@@ -1,0 +1,51 @@
+"""Build (hipcc, gfx950) every generated family the -m gpu tests use, without
+a GPU: called by __graft_entry__.build() so that the shared objects under
+pysph_amd/_gen/ travel with the snapshot and the GPU run does not compile."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def main():
+    from pysph_amd import kernels as K
+    from pysph_amd.acceleration_eval import AccelerationEval, _CGroup
+    from conftest import load_golden, arrays_from_golden
+    from helpers import golden_case
+    import test_hip_parity as T
+    from custom_equations import PyContinuity, PyMomentum, PyXSPH
+    from pysph_amd.equations import Group
+    n = 0
+
+    def plan(arrays, eqs, kernel):
+        count = 0
+        a = AccelerationEval(arrays, eqs, kernel)
+        ids = dict((pa.name, i) for i, pa in enumerate(arrays))
+        amap = dict((pa.name, pa) for pa in arrays)
+        for g in a.equation_groups:
+            cg = _CGroup(g, ids, amap, K.kernel_id(kernel))
+            count += sum(hasattr(u, 'fam') for u in cg.units)
+        return count
+
+    g = load_golden('tvf_wall.npz')
+    eqs, kernel, dim, outs = golden_case('tvf_wall', g)
+    n += plan(arrays_from_golden(g, 'in'), eqs, kernel)
+    for kname in ('CubicSpline', 'Gaussian'):
+        arrays, eqs = T._custom_setup(0.0)
+        n += plan(arrays, eqs, getattr(K, kname)(dim=3))
+    pa, dx = T.make_cube(6)
+    for tensile in (False, True):
+        kw = dict(c0=32.85, alpha=0.25, beta=0.1, gz=-9.81, tensile_correction=tensile)
+        eqs = [Group(equations=[PyContinuity(dest='fluid', sources=['fluid']),
+                                PyMomentum(dest='fluid', sources=['fluid'], **kw),
+                                PyXSPH(dest='fluid', sources=['fluid'], eps=0.5)])]
+        n += plan([pa], eqs, K.WendlandQuintic(dim=3))
+    return n
+
+
+if __name__ == '__main__':
+    print('generated families built:', main())
