@@ -704,7 +704,7 @@ class GeneratedFamily(object):
 
     # -- build / load ---------------------------------------------------------
     def so_path(self):
-        return os.path.join(GEN_DIR, 'fam_%s_%s.so' % (self.name, self.hash))
+        return os.path.join(GEN_DIR, 'fam_%s.so' % self.hash)   # content-addressed
 
     def build(self, force=False):
         """hipcc the family into its own shared object (cached by hash)."""
