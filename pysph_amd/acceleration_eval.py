@@ -407,7 +407,8 @@ class HipAccelerationEval(object):
         for name, props in self.inputs.items():
             pa = self.arrays[name]
             have = [p for p in sorted(props)
-                    if p in pa.properties and dev.prop_id(p) >= 0
+                    if ((p in pa.properties and dev.prop_id(p) >= 0)
+                        or self.helpers[name]._component(p) is not None)
                     and p not in skip]
             self.helpers[name].push(*have)
 
@@ -415,7 +416,8 @@ class HipAccelerationEval(object):
         for name, props in self.outputs.items():
             pa = self.arrays[name]
             out = [p for p in sorted(props)
-                   if p in pa.properties and dev.prop_id(p) >= 0 and p not in ('x', 'y', 'z', 'h', 'm',
+                   if ((p in pa.properties and dev.prop_id(p) >= 0)
+                       or self.helpers[name]._component(p) is not None) and p not in ('x', 'y', 'z', 'h', 'm',
                                                     'u', 'v', 'w', 'uhat',
                                                     'vhat', 'what')]
             self.helpers[name].pull(*out)

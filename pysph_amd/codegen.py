@@ -26,7 +26,8 @@ arrays, augmented assignment, bare ``return``, the libm calls compyle maps
 (``sqrt pow exp log sin cos tan tanh fabs abs max min floor ceil atan2``),
 ``M_PI``/``pi``, ``self.<scalar attribute>`` (copied by value when the family is
 built, like equation.py:885-892 does), ``d_<prop>[d_idx]``,
-``s_<prop>[s_idx]``, ``d_<constant>[k]`` and the precomputed symbols ``XIJ
+``s_<prop>[s_idx]``, components of strided properties ``d_<prop>[d_idx*S + k]``,
+``d_<constant>[k]`` and the precomputed symbols ``XIJ
 VIJ R2IJ RIJ HIJ RHOIJ RHOIJ1 EPS WIJ DWIJ WI WJ DWI DWJ WDP t dt``
 (equation.py:188-297).  Anything else raises ``CodegenError`` -- the equation
 then has to be hand-written or simplified; there is no silent fallback.
@@ -273,6 +274,28 @@ class _Body(object):
             return '(%s %s %s)' % (self.index(n.left), op, self.index(n.right))
         self.err(n, 'array index must be an integer literal or a loop variable')
 
+    def _strided(self, sl, idx_name):
+        """``<idx>*S + K`` / ``S*<idx> + K`` with literal S, K -> (S, K): one
+        component of a multi-component property (ParticleArray stride,
+        particle_array.pyx add_property(stride=...)); None otherwise."""
+        k = 0
+        if isinstance(sl, ast.BinOp) and isinstance(sl.op, ast.Add):
+            if isinstance(sl.right, ast.Constant) and isinstance(sl.right.value, int):
+                k, sl = sl.right.value, sl.left
+            elif isinstance(sl.left, ast.Constant) and isinstance(sl.left.value, int):
+                k, sl = sl.left.value, sl.right
+            else:
+                return None
+        if isinstance(sl, ast.BinOp) and isinstance(sl.op, ast.Mult):
+            a, b = sl.left, sl.right
+            if isinstance(b, ast.Name):
+                a, b = b, a
+            if isinstance(a, ast.Name) and a.id == idx_name and \
+                    isinstance(b, ast.Constant) and isinstance(b.value, int) and b.value > 1 \
+                    and 0 <= k < b.value:
+                return b.value, k
+        return None
+
     def subscript(self, n, store):
         if not isinstance(n.value, ast.Name):
             self.err(n, 'subscript of %s' % type(n.value).__name__)
@@ -284,6 +307,10 @@ class _Body(object):
             prop = base[2:]
             if isinstance(sl, ast.Name) and sl.id == 'd_idx':
                 return self.fam.dest_prop(prop, store)
+            sk = self._strided(sl, 'd_idx')
+            if sk is not None:
+                self.fam.note_stride(prop, sk[0], self, n)
+                return self.fam.dest_prop('%s__%d' % (prop, sk[1]), store)
             if self.fam.is_dest_constant(prop):
                 if store:
                     self.err(n, 'constants are read-only here')
@@ -299,6 +326,10 @@ class _Body(object):
                 self.err(n, '%s outside a pair loop' % base)
             if isinstance(sl, ast.Name) and sl.id == 's_idx':
                 return self.fam.src_prop(prop)
+            sk = self._strided(sl, 's_idx')
+            if sk is not None:
+                self.fam.note_stride(prop, sk[0], self, n)
+                return self.fam.src_prop('%s__%d' % (prop, sk[1]))
             self.err(n, '%s must be indexed with s_idx' % base)
         if base in VEC_SYMBOLS:
             if store:
@@ -463,6 +494,7 @@ class GeneratedFamily(object):
         self.dwritten = set()
         self.sprops = []        # source props packed into the records
         self.symbols = set()
+        self.strides = {}       # multi-component properties: name -> stride
         self.params = []        # [(key, value)]
         self.sources = []       # first-appearance order (acceleration_eval.py:136-151)
         self.src_flags = {}
@@ -530,6 +562,12 @@ class GeneratedFamily(object):
 
     def use_symbol(self, s):
         self.symbols.add(s)
+
+    def note_stride(self, prop, stride, body, node):
+        """component k of a stride-S property travels as the scalar device
+        property ``<prop>__k`` (split / re-interleaved by HipDeviceHelper)"""
+        if self.strides.setdefault(prop, stride) != stride:
+            body.err(node, 'property %s used with two strides' % prop)
 
     def param(self, key, value):
         for i, (k, _) in enumerate(self.params):

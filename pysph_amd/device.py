@@ -273,6 +273,17 @@ class HipDeviceHelper(object):
         if n != self._n or nreal != self.get_number_of_particles(True):
             self.resize(n)
 
+    def _component(self, name):
+        """``base__k`` -> (host array of the stride-S property `base`, S, k) for
+        the components generated families use; None for scalar properties."""
+        base, sep, k = name.rpartition('__')
+        pa = self._pa
+        if sep and k.isdigit() and base in pa.properties:
+            stride = getattr(pa, 'stride', {}).get(base, 1)
+            if stride > 1 and int(k) < stride:
+                return get_npy(pa, base), stride, int(k)
+        return None
+
     def push(self, *props):
         """host -> device.  No args: every fp64 property the device knows."""
         pa = self._pa
@@ -280,6 +291,14 @@ class HipDeviceHelper(object):
         if not props:
             props = [p for p in pa.properties if prop_id(p) >= 0]
         for p in props:
+            comp = self._component(p)
+            if comp is not None:      # one component of a strided property
+                host, stride, k = comp
+                col = np.ascontiguousarray(host[k::stride], dtype=np.float64)
+                _check(self.lib.sph_array_push(
+                    self.ctx._h, self.array_id, prop_register(p),
+                    col.ctypes.data_as(_PD), 0, col.size))
+                continue
             pid = prop_id(p)
             if pid < 0:
                 raise SphError('property %r has no device mirror' % p)
@@ -294,6 +313,16 @@ class HipDeviceHelper(object):
         if not props:
             props = [p for p in pa.properties if prop_id(p) >= 0]
         for p in props:
+            comp = self._component(p)
+            if comp is not None:
+                host, stride, k = comp
+                n = min(host.size // stride, self.get_number_of_particles())
+                col = np.empty(n)
+                _check(self.lib.sph_array_pull(
+                    self.ctx._h, self.array_id, prop_register(p),
+                    col.ctypes.data_as(_PD), 0, n))
+                host[k:n * stride:stride] = col
+                continue
             pid = prop_id(p)
             if pid < 0:
                 raise SphError('property %r has no device mirror' % p)

@@ -171,3 +171,41 @@ class PyXSPH(Equation):
         d_ax[d_idx] += d_u[d_idx]
         d_ay[d_idx] += d_v[d_idx]
         d_az[d_idx] += d_w[d_idx]
+
+
+# ---------------------------------------------------------------------------
+# multi-component (strided) properties: d_g3[d_idx*3 + k], s_g3[s_idx*3 + k]
+# (the access pattern of the reference's delta-SPH equations,
+# pysph/sph/wc/basic.py:355-414)
+# ---------------------------------------------------------------------------
+class StridedGradient(Equation):
+    def initialize(self, d_idx, d_g3):
+        d_g3[d_idx * 3 + 0] = 0.0
+        d_g3[d_idx * 3 + 1] = 0.0
+        d_g3[3 * d_idx + 2] = 0.0
+
+    def loop(self, d_idx, s_idx, d_g3, d_rho, s_rho, s_m, DWIJ):
+        Vj = s_m[s_idx] / s_rho[s_idx]
+        d_g3[d_idx * 3 + 0] += (s_rho[s_idx] - d_rho[d_idx]) * DWIJ[0] * Vj
+        d_g3[d_idx * 3 + 1] += (s_rho[s_idx] - d_rho[d_idx]) * DWIJ[1] * Vj
+        d_g3[d_idx * 3 + 2] += (s_rho[s_idx] - d_rho[d_idx]) * DWIJ[2] * Vj
+
+
+class StridedDiffusion(Equation):
+    def __init__(self, dest, sources, delta=0.1, c0=10.0):
+        self.delta = delta
+        self.c0 = c0
+        super(StridedDiffusion, self).__init__(dest, sources)
+
+    def initialize(self, d_idx, d_arho):
+        d_arho[d_idx] = 0.0
+
+    def loop(self, d_idx, d_arho, s_idx, s_m, d_rho, s_rho, DWIJ, XIJ, R2IJ, HIJ,
+             EPS, d_g3, s_g3):
+        Vj = s_m[s_idx] / s_rho[s_idx]
+        fac = -2.0 * (s_rho[s_idx] - d_rho[d_idx]) / (R2IJ + EPS)
+        psix = fac * XIJ[0] - d_g3[d_idx * 3 + 0] - s_g3[s_idx * 3 + 0]
+        psiy = fac * XIJ[1] - d_g3[d_idx * 3 + 1] - s_g3[s_idx * 3 + 1]
+        psiz = fac * XIJ[2] - d_g3[d_idx * 3 + 2] - s_g3[s_idx * 3 + 2]
+        d_arho[d_idx] += self.delta * HIJ * self.c0 * \
+            (psix * DWIJ[0] + psiy * DWIJ[1] + psiz * DWIJ[2]) * Vj

@@ -44,6 +44,13 @@ def main():
                                 PyMomentum(dest='fluid', sources=['fluid'], **kw),
                                 PyXSPH(dest='fluid', sources=['fluid'], eps=0.5)])]
         n += plan([pa], eqs, K.WendlandQuintic(dim=3))
+    from custom_equations import StridedDiffusion, StridedGradient
+    from pysph_amd.particle_array import get_particle_array_wcsph
+    pb = get_particle_array_wcsph(name='fluid', x=np.zeros(2))
+    pb.add_property('g3', stride=3)
+    n += plan([pb], [Group(equations=[StridedGradient('fluid', ['fluid'])], real=False),
+                     Group(equations=[StridedDiffusion('fluid', ['fluid'])])],
+              K.CubicSpline(dim=3))
     return n
 
 
