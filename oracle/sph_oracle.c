@@ -1005,6 +1005,7 @@ static int do_group(orc_nnps *nn, const orc_kernel *K, const orc_group *g, doubl
         const orc_array *D = nn->arr[dst];
         long start = g->start_idx;
         long np_dest = g->stop_idx >= 0 ? g->stop_idx : (g->real ? D->n_real : D->n);
+        if (np_dest > D->n) np_dest = D->n; /* a stop_idx beyond a destination is out of bounds in the reference */
 
         /* sources in first-appearance order over this destination's equations */
         int srcs[ORC_MAX_ARRAYS], nsrcs = 0;

@@ -559,6 +559,92 @@ def test_dense_cells_coincident_particles(oracle, varh):
             assert e < TOL, (variant, prop, e)
 
 
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('SPH_FUZZ_SEEDS', '12')))))
+def test_randomised_configurations_vs_oracle(oracle, seed):
+    """Differential test over randomly drawn problem shapes: dimension,
+    particle count, clustered vs uniform positions, constant or strongly
+    varying h, one or two arrays (the second may be empty or tiny), kernel,
+    Group(real, start_idx, stop_idx), pair-kernel variant.  Neighbour lists
+    must be identical to the oracle's, fields within tolerance."""
+    from pysph_amd import kernels as K
+    from pysph_amd.equations import (ContinuityEquation, Group, MomentumEquation,
+                                     SummationDensity, TaitEOS, XSPHCorrection)
+    from pysph_amd.particle_array import get_particle_array_wcsph
+    rng = np.random.default_rng(1000 + seed)
+    dim = int(rng.choice([1, 2, 3], p=[0.15, 0.35, 0.5]))
+    n = int(rng.choice([1, 7, 300, 2500, 9000]))
+    if dim == 1:
+        n = min(n, 2500)
+    kname = str(rng.choice(['CubicSpline', 'WendlandQuintic', 'QuinticSpline', 'Gaussian']))
+    if kname == 'WendlandQuintic' and dim == 1:
+        kname = 'CubicSpline'
+    kernel = getattr(K, kname)(dim=dim)
+    varh = float(rng.choice([0.0, 0.0, 0.3]))
+    clustered = bool(rng.integers(0, 2))
+    spacing = (1.0 / max(n, 2)) ** (1.0 / dim)
+
+    def coords(m):
+        c = rng.uniform(0, 1, (m, 3))
+        if clustered:
+            c = c ** 2.5                      # dense corner, ragged cells
+        c[:, dim:] = 0.0
+        return c
+    arrays = []
+    sizes = [n, int(rng.choice([0, 1, max(n // 5, 1)]))]
+    for name, m in zip(('fluid', 'solid'), sizes):
+        c = coords(m)
+        h = 1.3 * spacing * (1 + varh * rng.uniform(-1, 1, m))
+        pa = get_particle_array_wcsph(
+            name=name, x=c[:, 0], y=c[:, 1], z=c[:, 2], h=h, m=spacing ** dim * np.ones(m),
+            rho=1000.0 * (1 + 0.02 * rng.uniform(-1, 1, m)), u=rng.uniform(-1, 1, m),
+            v=rng.uniform(-1, 1, m), w=rng.uniform(-1, 1, m))
+        arrays.append(pa)
+    real = bool(rng.integers(0, 2))
+    start = int(rng.integers(0, max(n // 3, 1)))
+    stop = None if rng.integers(0, 2) else int(rng.integers(start, n + 1))
+    c0 = 10.0
+    eqs = [
+        Group(real=False, equations=[TaitEOS(dest=a.name, sources=None, rho0=1000.0, c0=c0, gamma=7.0)
+                                     for a in arrays]),
+        Group(real=real, start_idx=start, stop_idx=stop, equations=[
+            ContinuityEquation(dest='fluid', sources=['fluid', 'solid']),
+            MomentumEquation(dest='fluid', sources=['fluid', 'solid'], c0=c0, alpha=0.3, beta=0.1,
+                             gy=-1.0, tensile_correction=bool(rng.integers(0, 2))),
+            XSPHCorrection(dest='fluid', sources=['fluid'], eps=0.4)]),
+        # start/stop of a group apply to every destination in it: the solid
+        # destination gets its own groups
+        Group(equations=[ContinuityEquation(dest='solid', sources=['fluid'])]),
+        Group(equations=[SummationDensity(dest='solid', sources=['fluid', 'solid'])]),
+    ]
+    # fields the groups do not touch keep their input values: give them some
+    for a in arrays:
+        for k in ('arho', 'au', 'av', 'aw', 'ax', 'ay', 'az'):
+            a.properties[k][:] = rng.uniform(-1, 1, a.get_number_of_particles())
+    ref = _copy_arrays(arrays)
+    onn = oracle.OracleNNPS(dim, ref, radius_scale=kernel.radius_scale)
+    onn.update()
+    oev = oracle.OracleEval(ref, eqs, kernel, nthreads=4)
+    oev.set_nnps(onn)
+    oev.compute(0.1, 1e-4)
+    variant = int(rng.choice([0, 2, 3, 3]))
+    q = _copy_arrays(arrays)
+    a_eval, nnps, ctx = make_eval(q, eqs, kernel, dim, variant)
+    a_eval.compute(0.1, 1e-4)
+    for si in range(2):
+        for di in range(2):
+            if q[di].get_number_of_particles() == 0:
+                continue
+            s1, i1 = nnps.get_csr(si, di)
+            s2, i2 = onn.get_csr(si, di)
+            assert np.array_equal(s1, s2), (seed, si, di)
+            assert np.array_equal(i1, np.concatenate(
+                [np.sort(i2[s2[k]:s2[k + 1]]) for k in range(len(s2) - 1)] or [i2[:0]]))
+    for pa, pr in zip(q, ref):
+        for prop in WC_OUT:
+            e = rel_err(pa.properties[prop], pr.properties[prop])
+            assert e < TOL, (seed, dim, n, kname, varh, clustered, variant, pa.name, prop, e)
+
+
 def test_error_behaviour():
     """Same failures as the reference: RuntimeError for missing properties
     (acceleration_eval.py:32-73) and for >2^28 cells
