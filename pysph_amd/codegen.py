@@ -64,6 +64,21 @@ class CodegenError(Exception):
     pass
 
 
+_SKELETON = None
+
+
+def _skeleton_digest():
+    global _SKELETON
+    if _SKELETON is None:
+        h = hashlib.sha1()
+        for path in (os.path.join(CSRC, 'sph_pair.h'), os.path.join(CSRC, 'sph_kernels.h'),
+                     os.path.join(INCLUDE, 'sphhip.h')):
+            with open(path, 'rb') as f:
+                h.update(f.read())
+        _SKELETON = h.hexdigest()
+    return _SKELETON
+
+
 def has_python_body(eq):
     """True when the object carries translatable method bodies (a reference
     equation, or a user's own ``Equation`` subclass)."""
@@ -534,7 +549,9 @@ class GeneratedFamily(object):
         if len(self.params) > 64:
             raise CodegenError('more than 64 scalar parameters in one family')
         self.source = self._emit_source()
-        self.hash = hashlib.sha1(self.source.encode()).hexdigest()[:16]
+        # content address: the generated struct AND the skeleton it is compiled
+        # against (a changed sph_pair.h must not pick up a stale binary)
+        self.hash = hashlib.sha1((self.source + _skeleton_digest()).encode()).hexdigest()[:16]
         self.lib = None
 
     # -- bookkeeping used by the bodies -------------------------------------

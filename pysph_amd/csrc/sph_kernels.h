@@ -84,12 +84,16 @@ template <> struct SphKernel<3> { // QuinticSpline
     }
 };
 
+// The Gaussian is CUT OFF at q = 3 where it is still 1.2e-4 of its peak, so the
+// support test is kept even when the caller guarantees the neighbour criterion:
+// a pair at r = 3h to within rounding must give exactly 0 like the reference
+// (the polynomial kernels vanish at their support radius, there INSUP is safe).
 template <> struct SphKernel<4> { // Gaussian
     static constexpr bool HAS_DWQ = true; // dw/q = -2 exp(-q^2)
-    template <bool INSUP = false, class R> static __device__ __forceinline__ R dwq(R q) { return (INSUP || q < R(3)) ? R(-2) * exp(-q * q) : R(0); }
-    template <bool INSUP = false, class R> static __device__ __forceinline__ R w(R q) { return (INSUP || q < R(3)) ? exp(-q * q) : R(0); }
+    template <bool INSUP = false, class R> static __device__ __forceinline__ R dwq(R q) { return (q < R(3)) ? R(-2) * exp(-q * q) : R(0); }
+    template <bool INSUP = false, class R> static __device__ __forceinline__ R w(R q) { return (q < R(3)) ? exp(-q * q) : R(0); }
     template <bool INSUP = false, class R> static __device__ __forceinline__ R dw(R q)
     {
-        return (INSUP || q < R(3)) ? R(-2) * q * exp(-q * q) : R(0);
+        return (q < R(3)) ? R(-2) * q * exp(-q * q) : R(0);
     }
 };

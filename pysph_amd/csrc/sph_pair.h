@@ -118,12 +118,24 @@ __device__ __forceinline__ void pair_geom(PairGeom &g, const double4 &pi, const 
 {
     g.xij[0] = pi.x - pj.x; g.xij[1] = pi.y - pj.y; g.xij[2] = pi.z - pj.z; // XIJ equation.py:205-212
     g.r2 = r2;                                                               // R2IJ :226-233
-    fast_sqrt_rsqrt(r2, g.rij, g.rinv);                                      // RIJ  :235
+    // The Gaussian is cut off at q = 3 where it is still 1.2e-4 of its peak: a
+    // pair at r = 3h to within an ulp (exact lattices produce them) is in or out
+    // depending on the last bit of q, so q must be the reference's own
+    // q = sqrt(r2) * (1/h) with correctly rounded sqrt and division.  The
+    // polynomial kernels vanish at their support radius; the ~1 ulp fast paths
+    // are invisible there.
+    constexpr bool EXACT_Q = (KK == 4);
+    if (EXACT_Q) {
+        g.rij = sqrt(r2);
+        g.rinv = g.rij > 0.0 ? 1.0 / g.rij : 0.0;
+    } else {
+        fast_sqrt_rsqrt(r2, g.rij, g.rinv);                                  // RIJ  :235
+    }
     if (UH) {
         g.hij = a.hu; g.h1 = a.h1u; g.fac = a.facu; g.eps = a.epsu;
     } else {
         g.hij = 0.5 * (pi.w + pj.w);                                         // HIJ  :192
-        g.h1 = fast_rcp(g.hij);
+        g.h1 = EXACT_Q ? 1.0 / g.hij : fast_rcp(g.hij);
         g.fac = kernel_norm(a.k.sigma, g.h1, a.k.dim);
         g.eps = 0.01 * g.hij * g.hij;                                        // EPS  :194
     }

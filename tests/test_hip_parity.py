@@ -645,6 +645,76 @@ def test_randomised_configurations_vs_oracle(oracle, seed):
             assert e < TOL, (seed, dim, n, kname, varh, clustered, variant, pa.name, prop, e)
 
 
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('SPH_FUZZ_SEEDS', '8')))))
+def test_randomised_tvf_and_elastic_vs_oracle(oracle, seed):
+    """The same differential idea for the other two hand-written equation sets:
+    TVF (QuinticSpline / Gaussian, optional artificial viscosity) and the
+    elastic-solid set (CubicSpline / WendlandQuintic, 2-D or 3-D), random
+    sizes, jitter, constant or varying h, random input fields."""
+    from pysph_amd import kernels as K
+    from pysph_amd.particle_array import get_particle_array_tvf_fluid
+    from pysph_amd.scheme import TVFScheme
+    from pysph_amd.solid_mech import ElasticSolidsScheme, get_particle_array_elastic_dynamics
+    from helpers import TVF_OUT, EL_OUT
+    rng = np.random.default_rng(5000 + seed)
+    which = 'tvf' if seed % 2 == 0 else 'elastic'
+    dim = int(rng.choice([2, 3]))
+    n1 = int(rng.choice([5, 9, 14])) if dim == 3 else int(rng.choice([8, 30, 60]))
+    dx = 1.0 / n1
+    g = (np.arange(n1) + 0.5) * dx
+    if dim == 3:
+        x, y, z = [a.ravel() for a in np.meshgrid(g, g, g, indexing='ij')]
+    else:
+        x, y = [a.ravel() for a in np.meshgrid(g, g, indexing='ij')]
+        z = np.zeros_like(x)
+    n = x.size
+    jit = float(rng.choice([0.0, 0.15]))
+    x = x + jit * dx * rng.uniform(-1, 1, n)
+    y = y + jit * dx * rng.uniform(-1, 1, n)
+    if dim == 3:
+        z = z + jit * dx * rng.uniform(-1, 1, n)
+    varh = float(rng.choice([0.0, 0.2]))
+    if which == 'tvf':
+        kernel = getattr(K, str(rng.choice(['QuinticSpline', 'Gaussian'])))(dim=dim)
+        pa = get_particle_array_tvf_fluid(
+            name='fluid', x=x, y=y, z=z, h=dx * (1 + varh * rng.uniform(-1, 1, n)),
+            m=dx ** dim * np.ones(n), rho=1 + 0.05 * rng.uniform(-1, 1, n),
+            u=rng.uniform(-1, 1, n), v=rng.uniform(-1, 1, n), w=rng.uniform(-1, 1, n),
+            uhat=rng.uniform(-1, 1, n), vhat=rng.uniform(-1, 1, n), what=rng.uniform(-1, 1, n))
+        eqs = TVFScheme(['fluid'], [], dim=dim, rho0=1.0, c0=10.0, nu=float(rng.choice([0.0, 0.02])),
+                        p0=100.0, pb=100.0, h0=dx, gx=0.3, alpha=float(rng.choice([0.0, 0.2]))
+                        ).get_equations()
+        outs = TVF_OUT
+    else:
+        kernel = getattr(K, str(rng.choice(['CubicSpline', 'WendlandQuintic'])))(dim=dim)
+        h0 = 1.3 * dx
+        pa = get_particle_array_elastic_dynamics(
+            name='solid', x=x, y=y, z=z, h=h0 * (1 + varh * rng.uniform(-1, 1, n)),
+            m=1.2 * dx ** dim * np.ones(n), rho=1.2 * (1 + 0.02 * rng.uniform(-1, 1, n)),
+            u=0.1 * rng.uniform(-1, 1, n), v=0.1 * rng.uniform(-1, 1, n),
+            w=0.1 * rng.uniform(-1, 1, n) * (dim == 3),
+            constants=dict(E=1e7, nu=0.3975, rho_ref=1.2, n=4,
+                           wdeltap=float(kernel.kernel(rij=dx, h=h0))))
+        for k in ('s00', 's01', 's02', 's11', 's12', 's22'):
+            pa.properties[k][:] = 1e3 * rng.uniform(-1, 1, n)
+        eqs = ElasticSolidsScheme(['solid'], [], dim=dim).get_equations()
+        outs = EL_OUT
+    ref = _copy_arrays([pa])
+    ref[0].constants = dict((k, v.copy()) for k, v in pa.constants.items())
+    onn = oracle.OracleNNPS(dim, ref, radius_scale=kernel.radius_scale)
+    onn.update()
+    oev = oracle.OracleEval(ref, eqs, kernel, nthreads=4)
+    oev.set_nnps(onn)
+    oev.compute(0.0, 1e-5)
+    variant = int(rng.choice([0, 2, 3, 3]))
+    a_eval, nnps, ctx = make_eval([pa], eqs, kernel, dim, variant)
+    a_eval.compute(0.0, 1e-5)
+    for prop in outs:
+        if prop in pa.properties:
+            e = rel_err(pa.properties[prop], ref[0].properties[prop])
+            assert e < TOL, (seed, which, dim, n1, type(kernel).__name__, varh, variant, prop, e)
+
+
 def test_error_behaviour():
     """Same failures as the reference: RuntimeError for missing properties
     (acceleration_eval.py:32-73) and for >2^28 cells
