@@ -1053,6 +1053,105 @@ def test_rccl_transport_self_periodic_slab(oracle):
         assert e < TOL, (prop, e)
 
 
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('SPH_FUZZ_SEEDS', '6')))))
+def test_randomised_slab_decomposition_vs_single_domain(oracle, seed):
+    """Random multi-rank layouts on one GPU (threads + ThreadDist): 2-4 slab
+    ranks, uneven random cuts (a slab may start empty), optionally periodic
+    along the slab axis, ownership scrambled so that migration has to move
+    particles (possibly over several slabs), then ghosts; every rank's real
+    particles must reproduce the single-domain oracle by global id."""
+    import threading
+    import torch
+    from helpers import ThreadDist
+    from pysph_amd import device as dev
+    from pysph_amd import kernels as K
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.domain import DomainManager
+    from pysph_amd.nnps import HipNNPS
+    from pysph_amd.parallel import SlabDecomposition
+    from pysph_amd.particle_array import ParticleArray
+    rng = np.random.default_rng(9000 + seed)
+    world = int(rng.choice([2, 3, 4]))
+    periodic = bool(rng.integers(0, 2))
+    n1 = int(rng.choice([18, 22]))
+    full, dx = make_cube(n1, seed=int(rng.integers(1, 1000)))
+    n = full.get_number_of_particles()
+    full.add_property('e0', data=np.arange(n, dtype=np.float64))
+    kernel = K.WendlandQuintic(dim=3)
+    eqs = cube_equations(dx)
+    width = kernel.radius_scale * 1.3 * dx
+    # random faces in (0,1), at least one ghost width apart when periodic
+    while True:
+        cuts = np.sort(rng.uniform(0.05, 0.95, world - 1))
+        faces = np.concatenate([[0.0], cuts, [1.0]])
+        if np.diff(faces).min() > 1.1 * width:      # feasible: world * 1.1 * width < 1
+            break
+    # scrambled initial ownership: each particle starts on a random rank
+    start_rank = rng.integers(0, world, n)
+    ref = _copy_arrays([full])
+    if periodic:
+        dom = DomainManager(xmin=0.0, xmax=1.0, periodic_in_x=True, n_layers=1.0)
+        dom.set_particles(ref, kernel.radius_scale)
+        dom.update()
+    onn = oracle.OracleNNPS(3, ref, 2.0)
+    onn.update()
+    oev = oracle.OracleEval(ref, eqs, kernel, nthreads=4)
+    oev.set_nnps(onn)
+    oev.compute(0.0, 1e-5)
+    hub = ThreadDist(world)
+    results, errors = {}, []
+
+    def rank_main(rank):
+        try:
+            ts = torch.cuda.Stream()
+            with torch.cuda.stream(ts):
+                own = np.nonzero(start_rank == rank)[0]
+                pa = ParticleArray(name='fluid', **{k: v[own].copy() for k, v in full.properties.items()})
+                ctx = dev.HipContext(0, ts.cuda_stream)
+                dev.attach(pa, ctx).push()
+                dec = SlabDecomposition([pa], ctx, rank, world, axis=0, width=width,
+                                        lo=float(faces[rank]), hi=float(faces[rank + 1]),
+                                        periodic=periodic, period=1.0, dist=hub.view(rank))
+                for _ in range(world):          # a particle moves one slab per call
+                    dec.migrate()
+                dec.exchange()
+                a_eval = AccelerationEval([pa], eqs, kernel)
+                SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+                nnps = HipNNPS(3, [pa], radius_scale=2.0, ctx=ctx, sync=False)
+                a_eval.set_nnps(nnps)
+                a_eval.compute(0.0, 1e-5)
+                pa.gpu.sync_host()
+                results[rank] = dict((k, pa.properties[k].copy()) for k in WC_OUT + ['e0', 'x'])
+        except Exception:
+            import traceback
+            errors.append(traceback.format_exc())
+            try:
+                hub.barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errors, errors[0]
+    gids = []
+    for r in range(world):
+        d = results[r]
+        gid = d['e0'].astype(np.int64)
+        gids.append(gid)
+        if gid.size == 0:
+            continue
+        assert (d['x'] >= faces[r] - (1e30 if r == 0 and not periodic else 0)).all()
+        assert (d['x'] < faces[r + 1] + (1e30 if r == world - 1 and not periodic else 0)).all()
+        for prop in WC_OUT:
+            e = rel_err(d[prop], ref[0].properties[prop][gid],
+                        scale=max(np.abs(ref[0].properties[prop][:n]).max(), 1e-300))
+            assert e < TOL, (seed, world, periodic, r, prop, e)
+    assert (np.sort(np.concatenate(gids)) == np.arange(n)).all()
+
+
 def test_device_reorder_keeps_results(oracle):
     """NNPS.spatially_order_particles on device-resident state
     (nnps_base.pyx:1615-1629; solver.py:296-302): properties are permuted by

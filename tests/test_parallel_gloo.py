@@ -97,6 +97,7 @@ class NumpyHaloOps(object):
         keep = np.setdiff1d(np.arange(self.pa.get_number_of_particles()), gone)
         for k in list(self.pa.properties):
             self.pa.properties[k] = self.pa.properties[k][keep].copy()
+        self.pa._n = keep.size
         self.pa.num_real_particles = keep.size
         return keep.size
 
