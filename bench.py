@@ -140,17 +140,29 @@ def main():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # SPH_BENCH_FORCE_DIST=1: bring RCCL up even for one rank (checks the
+    # process-group plumbing and the stdout ordering on a 1-GPU box)
+    if world > 1 or os.environ.get('SPH_BENCH_FORCE_DIST') == '1':
         import torch.distributed as dist
+        os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world,
                                 device_id=torch.device('cuda', local_rank))
     out = run(args, rank, local_rank, world, dist)
-    if out is not None:
-        print(json.dumps(out))
+    # The JSON line must be the LAST thing on stdout: RCCL's version banner
+    # (NCCL_DEBUG=VERSION on the GPU boxes) sits in the C stdio buffer of every
+    # rank until the process exits -- push it out before the final barrier,
+    # tear the process group down, then print.
+    import ctypes
+    libc = ctypes.CDLL(None)
+    libc.fflush(None)
+    sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+        libc.fflush(None)
+    if out is not None:
+        print(json.dumps(out), flush=True)
 
 
 def run(args, rank, local_rank, world, dist):
