@@ -227,6 +227,7 @@ typedef struct sph_gen_args {
     double dom_extent;
     uint32_t d_off, nd;
     const uint32_t *d_keys, *d_perm;
+    const uint32_t *d_tile_order; /* traversal order of the 256-particle destination tiles, or NULL */
     uint32_t d_start, d_stop, dflags;
     int nc[3];
     double xmin[3], cell_size, radius_scale;

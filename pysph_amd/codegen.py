@@ -734,6 +734,7 @@ class GeneratedFamily(object):
         A('    for (int j = 0; j < g->nsrc; j++) a.src[j] = {g->src_cell_start[j], g->src_off[j], g->src_flags[j]};')
         A('    a.rec = g->rec; a.nrec = g->nrec; a.fpos = (const float4 *)g->fpos; a.dom_extent = g->dom_extent;')
         A('    a.d_off = g->d_off; a.nd = g->nd; a.d_keys = g->d_keys; a.d_perm = g->d_perm;')
+        A('    a.d_tile_order = g->d_tile_order;')
         A('    a.d_start = g->d_start; a.d_stop = g->d_stop; a.dflags = g->dflags;')
         A('    for (int k = 0; k < 3; k++) { a.nc[k] = g->nc[k]; a.xmin[k] = g->xmin[k]; }')
         A('    a.cell_size = g->cell_size; a.radius_scale = g->radius_scale;')

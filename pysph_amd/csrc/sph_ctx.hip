@@ -125,6 +125,7 @@ int sph_ctx_destroy(sph_ctx *c)
     for (auto &A : c->arr) {
         for (auto &p : A.prop) if (p) (void)hipFree(p);
         A.keys.release(); A.keys_sorted.release(); A.idx.release(); A.perm.release();
+        A.tile_key.release(); A.tile_id.release(); A.tile_order.release();
         A.cell_start.release();
     }
     for (auto &H : c->halo)
@@ -247,6 +248,10 @@ int sph_set_option(sph_ctx *c, const char *key, long value)
         return SPH_OK;
     }
     if (strcmp(key, "uniform_h") == 0) { c->use_uniform_h = value; return SPH_OK; }
+    if (strcmp(key, "tile_block_rows") == 0) {
+        if (value < 0 || value > 4096) { sph_set_error("tile_block_rows out of range"); return SPH_ERR_ARG; }
+        c->tile_block_rows = value; c->nnps_valid = false; return SPH_OK;
+    }
     if (strcmp(key, "ablate") == 0) { c->ablate = value; return SPH_OK; }
     if (strcmp(key, "invalidate_nnps") == 0) { c->nnps_valid = false; return SPH_OK; }
     sph_set_error("sph_set_option: unknown key '%s'", key);

@@ -1227,6 +1227,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j]};
             a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
             a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
+            a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
             a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
             launch_pair<FamWCSPH>(c, K->kind, a);
         } else if (fam == FAM_DENSITY) {
@@ -1241,6 +1242,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j]};
             a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
             a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
+            a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
             a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
             launch_pair<FamDensity>(c, K->kind, a);
         } else if (fam == FAM_VGRAD) {
@@ -1257,6 +1259,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j]};
             a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
             a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
+            a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
             a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
             launch_pair<FamVGrad>(c, K->kind, a);
         } else if (fam == FAM_ELASTIC) {
@@ -1281,6 +1284,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j]};
             a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
             a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
+            a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
             a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
             launch_pair<FamElastic>(c, K->kind, a);
         } else {
@@ -1302,6 +1306,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j]};
             a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
             a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
+            a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
             a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
             launch_pair<FamTVF>(c, K->kind, a);
         }
@@ -1439,6 +1444,7 @@ extern "C" int sph_eval_generated(sph_ctx *c, const sph_kernel *K, const sph_gen
         g.d_off = (uint32_t)d_off;
         g.d_keys = D.keys_sorted.as<uint32_t>();
         g.d_perm = D.perm.as<uint32_t>();
+        g.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
     }
     ScopedTimer tm(c, f->nsrc > 0 ? T_PAIR : T_EOS);
     int rc = f->launch(&g);

@@ -47,6 +47,8 @@ struct DevArray {
     // neighbour-search state (valid after sph_nnps_update)
     DevBuf keys, keys_sorted, idx, perm; // uint32 each; perm: sorted position -> original index
     DevBuf cell_start;                   // uint32[n_cells + 1]
+    DevBuf tile_key, tile_id, tile_order; // traversal order of the 256-particle destination tiles (aggregated kernel)
+    size_t n_tiles = 0;
     int nnps_slot = -1;                  // position in the last sph_nnps_update list
     size_t perm_n = 0;                   // particles `perm` was built for (0: none / already applied)
 };
@@ -93,6 +95,7 @@ struct sph_ctx {
     long pair_variant = 3;
     long ablate = 0;
     long use_uniform_h = 1;
+    long tile_block_rows = 8; // destination tiles are traversed in blocks of this many cell rows (y) through all z planes; 0: memory order
     double cur_dt = 0.0;    // dt of the sph_eval_group call being set up
     int cur_nrec = 0;       // doubles per packed record of the pair launch being set up
     long block_sorted_outputs = 0;

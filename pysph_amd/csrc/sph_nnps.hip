@@ -142,6 +142,28 @@ __global__ __launch_bounds__(256) void k_cell_keys(const double *__restrict__ x,
     idx[i] = (uint32_t)i;
 }
 
+// Traversal order of the destination tiles (runs of SPH_TILE cell-sorted
+// particles) of the aggregated pair kernel.  Memory order is x fastest, then y,
+// then z: a tile's z-neighbour rows are a whole plane of tiles away, more than
+// the 4 MiB L2 of an XCD holds, so every row used to be fetched from HBM once
+// per plane that needs it.  Traversing blocks of `by` rows through ALL planes
+// (key = ((cy / by) * ncz + cz) * by + cy % by, ties in memory order) brings
+// the reuse distance of a row down to a few hundred KB.  Results do not depend
+// on the order.
+#define SPH_TILE 256
+__global__ __launch_bounds__(256) void k_tile_keys(const uint32_t *__restrict__ skeys, size_t n, uint32_t n_tiles, int ncx,
+                                                   int ncy, int ncz, int by, uint32_t *__restrict__ key,
+                                                   uint32_t *__restrict__ id)
+{
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const uint32_t k = skeys[(size_t)t * SPH_TILE];
+    const uint32_t row = k / (uint32_t)ncx;
+    const uint32_t cy = row % (uint32_t)ncy, cz = row / (uint32_t)ncy;
+    key[t] = ((cy / (uint32_t)by) * (uint32_t)ncz + cz) * (uint32_t)by + cy % (uint32_t)by;
+    id[t] = t;
+}
+
 // cell_start[c] = first sorted position whose key >= c, for c in [0, n_cells]:
 // one thread per cell, lower_bound over the sorted keys (no atomics, no scan,
 // cost independent of how sparsely an array occupies the grid).
@@ -299,6 +321,24 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
                                                    A.perm.as<uint32_t>(), (int)n, 0, end_bit, c->stream));
         hipLaunchKernelGGL(k_cell_start, dim3(div_up((size_t)n_cells_alloc + 1, 256)), dim3(256), 0, c->stream,
                            A.keys_sorted.as<uint32_t>(), n, (uint32_t)n_cells_alloc, A.cell_start.as<uint32_t>());
+        // tile traversal order (only worth it when there is more than one z plane of tiles)
+        A.n_tiles = 0;
+        if (c->tile_block_rows > 0 && c->nc[2] > 1 && n > 64 * SPH_TILE) {
+            const uint32_t nt = (uint32_t)div_up(n, SPH_TILE);
+            SPH_TRY(A.tile_key.reserve((size_t)nt * 4 * 2));
+            SPH_TRY(A.tile_id.reserve((size_t)nt * 4));
+            SPH_TRY(A.tile_order.reserve((size_t)nt * 4));
+            uint32_t *tk = A.tile_key.as<uint32_t>(), *tk2 = tk + nt;
+            hipLaunchKernelGGL(k_tile_keys, dim3(div_up(nt, 256)), dim3(256), 0, c->stream, A.keys_sorted.as<uint32_t>(), n, nt,
+                               c->nc[0], c->nc[1], c->nc[2], (int)c->tile_block_rows, tk, A.tile_id.as<uint32_t>());
+            size_t tb2 = 0;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, tk, tk2, A.tile_id.as<uint32_t>(),
+                                                       A.tile_order.as<uint32_t>(), (int)nt, 0, 32, c->stream));
+            SPH_TRY(c->cub_tmp.reserve(tb2));
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.ptr, tb2, tk, tk2, A.tile_id.as<uint32_t>(),
+                                                       A.tile_order.as<uint32_t>(), (int)nt, 0, 32, c->stream));
+            A.n_tiles = nt;
+        }
     }
     HIP_TRY(hipGetLastError());
     c->nnps_valid = true;

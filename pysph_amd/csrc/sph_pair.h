@@ -57,6 +57,7 @@ template <class Fam> struct PairArgs {
     double dom_extent;  // largest grid extent: bounds the fp32 rounding of fpos
     uint32_t d_off, nd;
     const uint32_t *d_keys, *d_perm;
+    const uint32_t *d_tile_order; // traversal order of the destination tiles (null: memory order)
     uint32_t d_start, d_stop;
     int nc[3];
     double xmin[3];
@@ -213,7 +214,9 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(ABS, Fam::MIN
     __shared__ int wx[2 * (ABS / 64) + 2];
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * ABS + t;
+    uint32_t dtile = xcd_tile(blockIdx.x, gridDim.x);
+    if (a.d_tile_order) dtile = a.d_tile_order[dtile];
+    const uint32_t i = dtile * ABS + t;
     const bool valid = i < a.nd;
     const uint32_t ic = valid ? i : a.nd - 1;
     const uint32_t o = a.d_perm[ic];
