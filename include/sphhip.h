@@ -235,6 +235,18 @@ typedef struct sph_gen_args {
     int dim;
     double t, dt;
     double hu, h1u, facu, epsu, hr2u;
+    /* mode 0: no-source kernel (nsrc == 0) or fused pair kernel;
+     * mode 1: initialize + no-source loops only, results stored (run before the
+     *         records are packed when a later loop reads a property as s_<prop>
+     *         that initialize writes -- the reference finishes initialize for
+     *         all particles first, acceleration_eval_cython.mako:36-58);
+     * mode 2: loop_all equations: one thread per destination walks its
+     *         neighbour list (NBRS, N_NBRS; mako :62-80).                      */
+    int mode;
+    int skip_init;                /* mode 0/2: initialize already done by a mode-1 launch */
+    const uint32_t *csr_start[SPH_MAX_ARRAYS]; /* mode 2: per source, start[nd+1] */
+    const uint32_t *csr_nbrs[SPH_MAX_ARRAYS];  /*         and neighbour indices   */
+    const double *sraw[SPH_MAX_ARRAYS][SPH_GEN_MAX_SPROPS]; /* mode 2: source props, original order */
     int n_din, n_dout, npar;
     const double *din[SPH_GEN_MAX_PROPS];   /* destination props read      */
     double *dout[SPH_GEN_MAX_PROPS];        /* destination props read-modify-written */
@@ -258,6 +270,8 @@ typedef struct sph_gen_family {
     double par[SPH_GEN_MAX_PAR];
     int real;                    /* Group(real=...)                          */
     long start_idx, stop_idx;    /* Group(start_idx, stop_idx); <0: None     */
+    int split_init;              /* 1: run a mode-1 launch before packing    */
+    int loop_all;                /* 1: the family's source equations are loop_all (mode 2) */
 } sph_gen_family;
 
 /* initialize -> no-source loops -> per-source pair loops -> post_loop of one

@@ -96,11 +96,29 @@ class PyEval(object):
             for sname in sources:
                 src = self.arrays[self.names.index(sname)]
                 seqs = [e for e in eqs if e.sources and sname in e.sources]
-                self._pairs(dst, src, seqs, ns, start, stop)
+                # loop_all first, then the pair loop (mako :62-110)
+                if any(getattr(type(e), 'loop_all', None) for e in seqs):
+                    self._all_nbrs(dst, src, seqs, ns, start, stop)
+                if any(getattr(type(e), 'loop', None) for e in seqs):
+                    self._pairs(dst, src, seqs, ns, start, stop)
             for i in range(start, stop):
                 ns['d_idx'] = i
                 for e in eqs:
                     self._call(e, 'post_loop', ns)
+
+    def _all_nbrs(self, dst, src, eqs, ns, start, stop):
+        si, di = self.names.index(src.name), self.names.index(dst.name)
+        cs, nb = self.nnps.get_csr(si, di)
+        pns = dict(ns)
+        for k in list(src.properties) + list(src.constants):
+            pns['s_' + k] = self._arr(src, k)
+        pns['SPH_KERNEL'] = self.kernel
+        for i in range(start, stop):
+            pns['d_idx'] = i
+            lst = [int(j) for j in nb[cs[i]:cs[i + 1]]]
+            pns['NBRS'], pns['N_NBRS'] = lst, len(lst)
+            for e in eqs:
+                self._call(e, 'loop_all', pns)
 
     def _pairs(self, dst, src, eqs, ns, start, stop):
         K = self.kernel
@@ -144,6 +162,11 @@ class PyEval(object):
 def declare(spec, *a):
     """stand-in for compyle.api.declare inside equation bodies run as Python"""
     spec = spec.replace(' ', '')
+    if a and isinstance(a[0], int):         # declare('int', 2) -> two values
+        return tuple(0 for _ in range(a[0])) if spec in ('int', 'long') else \
+            tuple(0.0 for _ in range(a[0]))
+    if spec in ('int', 'long'):
+        return 0
     if spec.startswith('matrix('):
         n = 1
         for d in spec[7:-1].strip('()').split(','):

@@ -242,6 +242,8 @@ class _GeneratedUnit(object):
             self.cf.dout[k] = dev.prop_register(p)
         self.cf.npar = len(f.params)
         self.cf.real = 1 if group.real else 0
+        self.cf.split_init = 1 if f.split_init else 0
+        self.cf.loop_all = 1 if f.loop_all else 0
         owner.inputs[dest].update(f.dprops)
         owner.outputs[dest].update(f.dout)
         for sname in f.sources:

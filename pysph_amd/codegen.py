@@ -56,8 +56,8 @@ MATH_1 = {'sqrt': 'sqrt', 'exp': 'exp', 'log': 'log', 'sin': 'sin',
 MATH_2 = {'pow': 'pow', 'atan2': 'atan2', 'fmod': 'fmod'}
 CONSTANTS = {'M_PI': 'M_PI', 'pi': 'M_PI', 'M_1_PI': 'M_1_PI',
              'M_2_SQRTPI': 'M_2_SQRTPI', 'M_PI_2': 'M_PI_2', 'INFINITY': 'INFINITY'}
-METHODS = ('initialize', 'loop', 'post_loop')
-UNSUPPORTED_METHODS = ('loop_all', 'initialize_pair')
+METHODS = ('initialize', 'loop', 'loop_all', 'post_loop')
+UNSUPPORTED_METHODS = ('initialize_pair',)
 
 
 class CodegenError(Exception):
@@ -144,12 +144,16 @@ class _Body(object):
         self.k = eq_index
         self.kind = kind            # 'initialize' | 'loop' | 'post_loop'
         self.pair = kind == 'loop' and not fam.is_no_source(eq)
+        self.all_nbrs = kind == 'loop_all'
         self.fdef = fdef
-        self.locals = {}            # name -> ('double', None) | ('array', n)
+        self.locals = {}            # name -> ('double', None) | ('array', n) | ('int', None)
         self.loop_vars = set()
         self.where = '%s.%s' % (type(eq).__name__, kind)
         self.lines = []
+        fam._writes = set()
         self._emit_block(fdef.body, 1)
+        self.writes = fam._writes
+        fam._writes = None
 
     # -- helpers -----------------------------------------------------------
     def err(self, node, msg):
@@ -237,6 +241,18 @@ class _Body(object):
 
     def call(self, n):
         f = n.func
+        if isinstance(f, ast.Attribute) and isinstance(f.value, ast.Name) and f.value.id == 'SPH_KERNEL':
+            if not self.all_nbrs:
+                self.err(n, 'SPH_KERNEL is only available in loop_all')
+            args = [a.id if (isinstance(a, ast.Name) and self.locals.get(a.id, ('',))[0] == 'array')
+                    else self.expr(a) for a in n.args]
+            if f.attr == 'kernel' and len(args) == 3:       # kernel(xij, rij, h)
+                return 'gen_kernel_w<KK>(%s, %s, a)' % (args[1], args[2])
+            if f.attr == 'dwdq' and len(args) == 2:
+                return 'gen_kernel_dwdq<KK>(%s, %s, a)' % (args[0], args[1])
+            if f.attr == 'get_deltap' and not args:
+                return 'a.k.deltap'
+            self.err(n, 'SPH_KERNEL.%s' % f.attr)
         fname = f.id if isinstance(f, ast.Name) else (
             f.attr if isinstance(f, ast.Attribute) and isinstance(f.value, ast.Name)
             and f.value.id in ('math', 'np', 'numpy', 'M') else None)
@@ -263,6 +279,8 @@ class _Body(object):
             return v
         if v in self.locals:
             return v
+        if v == 'N_NBRS' and self.all_nbrs:
+            return 'N_NBRS'
         if v in CONSTANTS:
             return CONSTANTS[v]
         if v in ('True', 'False'):
@@ -282,8 +300,17 @@ class _Body(object):
         """integer index expression (loop variables, literals, + - *)"""
         if isinstance(n, ast.Constant) and isinstance(n.value, int):
             return str(n.value)
-        if isinstance(n, ast.Name) and n.id in self.loop_vars:
+        if isinstance(n, ast.Name) and (n.id in self.loop_vars or
+                                        self.locals.get(n.id, ('', 0))[0] == 'int'):
             return n.id
+        if isinstance(n, ast.Name) and n.id == 'N_NBRS' and self.all_nbrs:
+            return 'N_NBRS'
+        if isinstance(n, ast.Subscript) and isinstance(n.value, ast.Name) and n.value.id == 'NBRS' \
+                and self.all_nbrs:
+            return self.subscript(n, store=False)           # s_m[NBRS[i]]
+        if isinstance(n, ast.Attribute) and isinstance(n.value, ast.Name) and n.value.id == 'self' \
+                and isinstance(getattr(self.eq, n.attr, None), int):
+            return str(int(getattr(self.eq, n.attr)))       # frozen at build time
         if isinstance(n, ast.BinOp) and isinstance(n.op, (ast.Add, ast.Sub, ast.Mult)):
             op = {ast.Add: '+', ast.Sub: '-', ast.Mult: '*'}[type(n.op)]
             return '(%s %s %s)' % (self.index(n.left), op, self.index(n.right))
@@ -311,6 +338,25 @@ class _Body(object):
                 return b.value, k
         return None
 
+    def _strided_any(self, sl):
+        """``<int index>*S + K`` with literal S, K -> (S, index text, K)"""
+        k = 0
+        if isinstance(sl, ast.BinOp) and isinstance(sl.op, ast.Add):
+            if isinstance(sl.right, ast.Constant) and isinstance(sl.right.value, int):
+                k, sl = sl.right.value, sl.left
+            elif isinstance(sl.left, ast.Constant) and isinstance(sl.left.value, int):
+                k, sl = sl.left.value, sl.right
+            else:
+                return None
+        if isinstance(sl, ast.BinOp) and isinstance(sl.op, ast.Mult):
+            a, b = sl.left, sl.right
+            if isinstance(a, ast.Constant):
+                a, b = b, a
+            if isinstance(b, ast.Constant) and isinstance(b.value, int) and b.value > 1 \
+                    and 0 <= k < b.value and isinstance(a, ast.Name):
+                return b.value, self.index(a), k
+        return None
+
     def subscript(self, n, store):
         if not isinstance(n.value, ast.Name):
             self.err(n, 'subscript of %s' % type(n.value).__name__)
@@ -333,6 +379,18 @@ class _Body(object):
                     self.err(n, 'constant %s needs a literal index' % base)
                 return self.fam.param(('const', prop, sl.value), None)
             self.err(n, '%s must be indexed with d_idx' % base)
+        if base == 'NBRS' and self.all_nbrs:
+            if store:
+                self.err(n, 'NBRS is read-only')
+            return '((int)NBRS[%s])' % self.index(sl)
+        if base.startswith('s_') and self.all_nbrs:
+            if store:
+                self.err(n, 'source arrays are read-only (gather formulation)')
+            sk = self._strided_any(sl)
+            if sk is not None:
+                self.fam.note_stride(base[2:], sk[0], self, n)
+                return 'S_%s[%s]' % (self.fam.raw_src_prop('%s__%d' % (base[2:], sk[2])), sk[1])
+            return 'S_%s[%s]' % (self.fam.raw_src_prop(base[2:]), self.index(sl))
         if base.startswith('s_'):
             prop = base[2:]
             if store:
@@ -378,13 +436,25 @@ class _Body(object):
                     if d:
                         n *= int(d)
                 return ('array', n)
-            if spec in ('double', 'float', 'int', 'long'):
+            if spec in ('int', 'long', 'unsigned int', 'unsignedint'):
+                return ('int', None)
+            if spec in ('double', 'float'):
                 return ('double', None)
         return None
 
     def _emit_stmt(self, st, ind):
         if isinstance(st, ast.Expr):
             if isinstance(st.value, ast.Constant):      # docstring
+                return
+            v = st.value
+            if isinstance(v, ast.Call) and isinstance(v.func, ast.Attribute) and \
+                    isinstance(v.func.value, ast.Name) and v.func.value.id == 'SPH_KERNEL' and \
+                    v.func.attr == 'gradient' and len(v.args) == 4 and self.all_nbrs and \
+                    all(isinstance(v.args[k], ast.Name) and self.locals.get(v.args[k].id, ('',))[0] == 'array'
+                        for k in (0, 3)):
+                # gradient(xij, rij, h, grad): kernels.py:126-137
+                self._emit(ind, 'gen_kernel_gradient<KK>(%s, %s, %s, %s, a);' % (
+                    v.args[0].id, self.expr(v.args[1]), self.expr(v.args[2]), v.args[3].id))
                 return
             self.err(st, 'expression statement')
         if isinstance(st, ast.Pass):
@@ -400,7 +470,7 @@ class _Body(object):
             tgt = st.targets[0]
             if isinstance(tgt, ast.Tuple) and self._declare_call(st.value) is not None:
                 for t_ in tgt.elts:       # i, j = declare('int', 2)
-                    self._declare(t_, ('double', None), st)
+                    self._declare(t_, self._declare_call(st.value), st)
                 return
             if isinstance(tgt, ast.Tuple):
                 if not isinstance(st.value, ast.Tuple) or len(tgt.elts) != len(st.value.elts):
@@ -420,6 +490,14 @@ class _Body(object):
             d = self._declare_call(st.value)
             if d is not None:
                 self._declare(tgt, d, st)
+                return
+            if isinstance(tgt, ast.Name) and self.locals.get(tgt.id, ('',))[0] == 'int':
+                if isinstance(st.value, ast.Subscript) and isinstance(st.value.value, ast.Name) \
+                        and st.value.value.id == 'NBRS':
+                    rhs = self.subscript(st.value, store=False)
+                else:
+                    rhs = self.index(st.value)
+                self._emit(ind, '%s = %s;' % (tgt.id, rhs))
                 return
             rhs = self.expr(st.value)
             self._emit(ind, '%s = %s;' % (self._target(tgt, st), rhs))
@@ -485,6 +563,8 @@ class _Body(object):
         for name, (kind, n) in sorted(self.locals.items()):
             if kind == 'array':
                 out.append(pad + '    double %s[%d] = {};' % (name, n))
+            elif kind == 'int':
+                out.append(pad + '    int %s = 0; (void)%s;' % (name, name))
             else:
                 out.append(pad + '    double %s = 0.0;' % name)
         for ln in self.lines:
@@ -535,6 +615,19 @@ class GeneratedFamily(object):
                     self.nosrc_loops.append(b)
                 else:
                     self.bodies[m].append(b)
+        # loop_all families: one thread per destination walks its neighbour list
+        self.loop_all = bool(self.bodies['loop_all'])
+        if self.loop_all and self.bodies['loop']:
+            raise CodegenError('destination %r mixes loop and loop_all equations; put '
+                               'them in separate groups' % dest)
+        # initialize()/no-source loops of ALL particles must be finished before a
+        # loop reads what they wrote as a SOURCE property (mako :36-58): then
+        # they run as a launch of their own, before the records are packed
+        early = set()
+        for b in self.bodies['initialize'] + self.nosrc_loops:
+            early |= b.writes
+        self.split_init = bool(self.sources) and dest in self.sources and \
+            bool(early & set(self.sprops))
         if 'VIJ' in self.symbols:
             for p in 'uvw':
                 self.dest_prop(p, False)
@@ -568,6 +661,8 @@ class GeneratedFamily(object):
             self.dprops.append(prop)
         if store:
             self.dwritten.add(prop)
+            if getattr(self, '_writes', None) is not None:
+                self._writes.add(prop)
         return 'D.d_%s' % prop
 
     def src_prop(self, prop):
@@ -579,6 +674,13 @@ class GeneratedFamily(object):
 
     def use_symbol(self, s):
         self.symbols.add(s)
+
+    def raw_src_prop(self, prop):
+        """loop_all: source properties are read from the arrays themselves
+        (original order), x y z h included"""
+        if prop not in self.sprops:
+            self.sprops.append(prop)
+        return prop
 
     def note_stride(self, prop, stride, body, node):
         """component k of a stride-S property travels as the scalar device
@@ -623,6 +725,26 @@ class GeneratedFamily(object):
         A('#include "sph_pair.h"')
         A('#include <cstring>')
         A('')
+        A('// kernel functions by (r, h) for loop_all bodies: SPH_KERNEL.kernel / gradient / dwdq')
+        A('template <int KK, class A> __device__ __forceinline__ double gen_kernel_w(double rij, double h, const A &a)')
+        A('{')
+        A('    const double h1 = 1.0 / h;')
+        A('    return kernel_norm(a.k.sigma, h1, a.k.dim) * SphKernel<KK>::template w<false>(rij * h1);')
+        A('}')
+        A('template <int KK, class A> __device__ __forceinline__ double gen_kernel_dwdq(double rij, double h, const A &a)')
+        A('{')
+        A('    const double h1 = 1.0 / h;')
+        A('    return kernel_norm(a.k.sigma, h1, a.k.dim) * SphKernel<KK>::template dw<false>(rij * h1);')
+        A('}')
+        A('template <int KK, class A>')
+        A('__device__ __forceinline__ void gen_kernel_gradient(const double *xij, double rij, double h, double *grad, const A &a)')
+        A('{')
+        A('    const double h1 = 1.0 / h;')
+        A('    const double wdash = kernel_norm(a.k.sigma, h1, a.k.dim) * SphKernel<KK>::template dw<false>(rij * h1);')
+        A('    const double tmp = rij > 1e-12 ? wdash * h1 / rij : 0.0;     // kernels.py:126-137')
+        A('    grad[0] = tmp * xij[0]; grad[1] = tmp * xij[1]; grad[2] = tmp * xij[2];')
+        A('}')
+        A('')
         A('struct FamGen {')
         A('    static constexpr int MINB = SPHGEN_MINB;   // workgroups per CU, chosen at build time')
         A('    static constexpr int NA = %d;' % na)
@@ -631,6 +753,8 @@ class GeneratedFamily(object):
         A('        const double *din[%d];' % max(len(din), 1))
         A('        double *dout[%d];' % max(len(dout), 1))
         A('        double par[%d];' % max(len(self.params), 1))
+        A('        const uint32_t *csr_start[SPH_MAX_ARRAYS], *csr_nbrs[SPH_MAX_ARRAYS];   // loop_all')
+        A('        const double *sraw[SPH_MAX_ARRAYS][%d];' % max(len(self.sprops), 1))
         A('    };')
         A('    struct Dest {')
         for p in self.dprops:
@@ -647,10 +771,12 @@ class GeneratedFamily(object):
             A('        D.d_%s = a.p.din[%d][o];' % (p, i))
         for i, p in enumerate(dout):
             A('        D.d_%s = a.p.dout[%d][o];' % (p, i))
+        A('        if (!a.skip_init) {')
         for b in self.bodies['initialize']:
-            A(b.code(2))
+            A(b.code(3))
         for b in self.nosrc_loops:
-            A(b.code(2))
+            A(b.code(3))
+        A('        }')
         A('    }')
         # ---- pair
         A('    template <int KK, bool UH, class A>')
@@ -665,7 +791,8 @@ class GeneratedFamily(object):
         A('        const double R2IJ = r2, RIJ = g.rij, HIJ = g.hij, EPS = g.eps; (void)R2IJ; (void)RIJ; (void)HIJ; (void)EPS;')
         A('        const double s_h = UH ? a.hu : pj.w; (void)s_h;')
         for i, p in enumerate(self.sprops):
-            A('        const double s_%s = s[%d];' % (p, i))
+            if p not in ('x', 'y', 'z', 'h'):
+                A('        const double s_%s = s[%d];' % (p, i))
         if 'VIJ' in S:
             A('        const double VIJ[3] = {D.d_u - s_u, D.d_v - s_v, D.d_w - s_w};')
         if S & {'RHOIJ', 'RHOIJ1'}:
@@ -707,8 +834,29 @@ class GeneratedFamily(object):
         A('        const double t = a.t, dt = a.dt; (void)t; (void)dt;')
         for b in self.bodies['post_loop']:
             A(b.code(2))
+        A('        store(D, a, o);')
+        A('    }')
+        A('    template <class A> static __device__ __forceinline__ void store(Dest &D, const A &a, uint32_t o)')
+        A('    {')
         for i, p in enumerate(dout):
             A('        a.p.dout[%d][o] = D.d_%s;' % (i, p))
+        A('    }')
+        # ---- loop_all bodies of one source
+        A('    template <int KK, class A>')
+        A('    static __device__ __forceinline__ void all_nbrs(Dest &D, const A &a, int j, uint32_t d_idx)')
+        A('    {')
+        A('        const double *PAR = a.p.par; (void)PAR;')
+        A('        const double t = a.t, dt = a.dt; (void)t; (void)dt;')
+        A('        const uint32_t fl = a.src[j].flags; (void)fl;')
+        A('        const uint32_t *NBRS = a.p.csr_nbrs[j] + a.p.csr_start[j][d_idx]; (void)NBRS;')
+        A('        const int N_NBRS = (int)(a.p.csr_start[j][d_idx + 1] - a.p.csr_start[j][d_idx]); (void)N_NBRS;')
+        if self.loop_all:
+            for i, p in enumerate(self.sprops):
+                A('        const double *S_%s = a.p.sraw[j][%d]; (void)S_%s;' % (p, i, p))
+        for b in self.bodies['loop_all']:
+            A('        if (fl & %du) {' % (1 << b.k))
+            A(b.code(3))
+            A('        }')
         A('    }')
         A('};')
         A('')
@@ -718,6 +866,27 @@ class GeneratedFamily(object):
         A('    if (i >= a.d_stop) return;')
         A('    FamGen::Dest D;')
         A('    FamGen::load(D, nullptr, a, (uint32_t)i);')
+        A('    FamGen::finish(D, a, (uint32_t)i);')
+        A('}')
+        A('')
+        A('// initialize + no-source loops only (mode 1): results go to memory')
+        A('__global__ __launch_bounds__(256) void k_gen_init(PairArgs<FamGen> a)')
+        A('{')
+        A('    const size_t i = (size_t)a.d_start + (size_t)blockIdx.x * 256 + threadIdx.x;')
+        A('    if (i >= a.d_stop) return;')
+        A('    FamGen::Dest D;')
+        A('    FamGen::load(D, nullptr, a, (uint32_t)i);')
+        A('    FamGen::store(D, a, (uint32_t)i);')
+        A('}')
+        A('')
+        A('// loop_all equations (mode 2): one thread per destination, neighbour lists in CSR form')
+        A('__global__ __launch_bounds__(256) void k_gen_loop_all(PairArgs<FamGen> a)')
+        A('{')
+        A('    const size_t i = (size_t)a.d_start + (size_t)blockIdx.x * 256 + threadIdx.x;')
+        A('    if (i >= a.d_stop) return;')
+        A('    FamGen::Dest D;')
+        A('    FamGen::load(D, nullptr, a, (uint32_t)i);')
+        A('    for (int j = 0; j < a.nsrc; j++) FamGen::all_nbrs<%d>(D, a, j, (uint32_t)i);' % self.kernel_kind)
         A('    FamGen::finish(D, a, (uint32_t)i);')
         A('}')
         A('')
@@ -744,8 +913,19 @@ class GeneratedFamily(object):
         A('    for (int k = 0; k < g->n_din; k++) a.p.din[k] = g->din[k];')
         A('    for (int k = 0; k < g->n_dout; k++) a.p.dout[k] = g->dout[k];')
         A('    for (int k = 0; k < g->npar; k++) a.p.par[k] = g->par[k];')
+        A('    a.skip_init = g->skip_init;')
+        A('    for (int j = 0; j < SPH_MAX_ARRAYS; j++) {')
+        A('        a.p.csr_start[j] = g->csr_start[j]; a.p.csr_nbrs[j] = g->csr_nbrs[j];')
+        A('        for (int k = 0; k < %d; k++) a.p.sraw[j][k] = g->sraw[j][k];' % max(len(self.sprops), 1))
+        A('    }')
         A('    hipStream_t st = (hipStream_t)g->stream;')
-        A('    if (g->nsrc == 0) {')
+        A('    const size_t nrange = (size_t)g->d_stop - g->d_start;')
+        A('    const dim3 lin((unsigned)((nrange + 255) / 256));')
+        A('    if (g->mode == 1) {')
+        A('        hipLaunchKernelGGL(k_gen_init, lin, dim3(256), 0, st, a);')
+        A('    } else if (g->mode == 2) {')
+        A('        hipLaunchKernelGGL(k_gen_loop_all, lin, dim3(256), 0, st, a);')
+        A('    } else if (g->nsrc == 0) {')
         A('        const size_t n = (size_t)g->d_stop - g->d_start;')
         A('        hipLaunchKernelGGL(k_gen_nosrc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);')
         A('    } else {')

@@ -133,6 +133,8 @@ int sph_ctx_destroy(sph_ctx *c)
     for (DevBuf *b : {&c->cub_tmp, &c->red_part, &c->red_out, &c->posh, &c->aux, &c->fposb, &c->dkeys, &c->dperm,
                       &c->tmp_u32a, &c->tmp_u32b})
         b->release();
+    for (auto &b : c->csr_start) b.release();
+    for (auto &b : c->csr_nbrs) b.release();
     for (auto &t : c->timers)
         for (auto &pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->pinned) (void)hipHostFree(c->pinned);

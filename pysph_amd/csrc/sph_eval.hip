@@ -1390,6 +1390,41 @@ extern "C" int sph_eval_generated(sph_ctx *c, const sph_kernel *K, const sph_gen
     g.sigma = K->fac; g.deltap = K->deltap; g.dim = K->dim;
     if (D.n == 0 || stop <= start) return SPH_OK;
 
+    if (f->split_init) { // initialize for ALL particles before anything reads it as a source
+        sph_gen_args gi = g;
+        gi.mode = 1;
+        gi.nsrc = 0;
+        ScopedTimer tm(c, T_EOS);
+        int rc = f->launch(&gi);
+        if (rc != 0) { sph_set_error("generated family initialize launch failed (code %d)", rc); return SPH_ERR_HIP; }
+        g.skip_init = 1;
+    }
+
+    if (f->nsrc > 0 && f->loop_all) {
+        if (!c->nnps_valid) { sph_set_error("sph_eval_generated: neighbour grid is stale; call sph_nnps_update"); return SPH_ERR_STATE; }
+        for (int j = 0; j < f->nsrc; j++) {
+            int s = f->src[j];
+            if (s < 0 || s >= SPH_MAX_ARRAYS || !c->arr[s].used) { sph_set_error("bad source array %d", s); return SPH_ERR_ARG; }
+            size_t total = 0;
+            SPH_TRY(nnps_build_csr_device(c, s, dst, c->csr_start[j], c->csr_nbrs[j], &total));
+            g.csr_start[j] = c->csr_start[j].as<uint32_t>();
+            g.csr_nbrs[j] = c->csr_nbrs[j].as<uint32_t>();
+            g.src_flags[j] = f->src_flags[j];
+            g.dflags |= f->src_flags[j];
+            for (int k = 0; k < f->n_sprops; k++) {
+                const double *p = c->arr[s].prop[f->sprops[k]];
+                if (!p && c->arr[s].n) return need_prop(c, s, f->sprops[k], "generated loop_all");
+                g.sraw[j][k] = p;
+            }
+        }
+        g.mode = 2;
+        g.radius_scale = c->radius_scale;
+        ScopedTimer tm(c, T_PAIR);
+        int rc = f->launch(&g);
+        if (rc != 0) { sph_set_error("generated loop_all launch failed (code %d)", rc); return SPH_ERR_HIP; }
+        return SPH_OK;
+    }
+
     if (f->nsrc > 0) {
         if (!c->nnps_valid) { sph_set_error("sph_eval_generated: neighbour grid is stale; call sph_nnps_update"); return SPH_ERR_STATE; }
         if (D.nnps_slot < 0) { sph_set_error("destination array %d is not part of the neighbour grid", dst); return SPH_ERR_STATE; }

@@ -97,6 +97,7 @@ struct sph_ctx {
     long use_uniform_h = 1;
     long tile_block_rows = 8; // destination tiles are traversed in blocks of this many cell rows (y) through all z planes; 0: memory order
     double cur_dt = 0.0;    // dt of the sph_eval_group call being set up
+    DevBuf csr_start[SPH_MAX_ARRAYS], csr_nbrs[SPH_MAX_ARRAYS]; // neighbour lists of generated loop_all families
     int cur_nrec = 0;       // doubles per packed record of the pair launch being set up
     long block_sorted_outputs = 0;
 
@@ -115,6 +116,7 @@ struct ScopedTimer {
 
 // nnps.hip
 int nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *out8);
+int nnps_build_csr_device(sph_ctx *c, int src, int dst, DevBuf &start, DevBuf &nbrs, size_t *total);
 
 // eval.hip helpers
 static inline unsigned div_up(size_t a, unsigned b) { return (unsigned)((a + b - 1) / b); }

@@ -382,6 +382,7 @@ __global__ __launch_bounds__(256) void k_csr(const double *__restrict__ dx, cons
                                              GridDesc g, double radius_scale, uint32_t *__restrict__ start,
                                              uint32_t *__restrict__ nbrs)
 {
+#pragma clang fp contract(off) // r2 must round like the reference's norm2 (nnps_base.pxd:36-37)
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nd) return;
     double x = dx[i], y = dy[i], z = dz[i];
@@ -457,6 +458,45 @@ extern "C" int sph_nnps_get_csr(sph_ctx *c, int src, int dst, uint32_t *start, u
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < nd; i++) std::sort(nbrs + start[i], nbrs + start[i + 1]);
     if (total) *total = tot;
+    return SPH_OK;
+}
+
+// Device-resident CSR neighbour lists (original particle indices, cell-traversal
+// order) for generated loop_all equations: counts -> exclusive scan -> fill.
+int nnps_build_csr_device(sph_ctx *c, int src, int dst, DevBuf &start, DevBuf &nbrs, size_t *total)
+{
+    if (!c->nnps_valid) { sph_set_error("neighbour lists: call sph_nnps_update first"); return SPH_ERR_STATE; }
+    if (c->arr[src].nnps_slot < 0 || c->arr[dst].nnps_slot < 0) {
+        sph_set_error("neighbour lists: arrays %d/%d are not part of the current grid", src, dst);
+        return SPH_ERR_ARG;
+    }
+    DevArray &S = c->arr[src], &D = c->arr[dst];
+    const size_t nd = D.n;
+    GridDesc g;
+    for (int k = 0; k < 3; k++) { g.xmin[k] = c->xmin[k]; g.nc[k] = c->nc[k]; }
+    g.cell_size = c->cell_size;
+    SPH_TRY(start.reserve((nd + 2) * 4));
+    SPH_TRY(c->tmp_u32a.reserve((nd + 2) * 4));
+    *total = 0;
+    if (nd == 0) return SPH_OK;
+    uint32_t *cnt = c->tmp_u32a.as<uint32_t>();
+    HIP_TRY(hipMemsetAsync(cnt + nd, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_csr<false>, dim3(div_up(nd, 256)), dim3(256), 0, c->stream, D.prop[SPH_X], D.prop[SPH_Y],
+                       D.prop[SPH_Z], D.prop[SPH_H], nd, S.prop[SPH_X], S.prop[SPH_Y], S.prop[SPH_Z], S.prop[SPH_H],
+                       S.perm.as<uint32_t>(), S.cell_start.as<uint32_t>(), g, c->radius_scale, cnt, (uint32_t *)nullptr);
+    size_t tb = 0;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, start.as<uint32_t>(), (int)(nd + 1), c->stream));
+    SPH_TRY(c->cub_tmp.reserve(tb));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.ptr, tb, cnt, start.as<uint32_t>(), (int)(nd + 1), c->stream));
+    uint32_t *pin = (uint32_t *)c->pinned;
+    HIP_TRY(hipMemcpyAsync(pin, start.as<uint32_t>() + nd, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *total = pin[0];
+    SPH_TRY(nbrs.reserve(((size_t)pin[0] + 1) * 4));
+    hipLaunchKernelGGL(k_csr<true>, dim3(div_up(nd, 256)), dim3(256), 0, c->stream, D.prop[SPH_X], D.prop[SPH_Y],
+                       D.prop[SPH_Z], D.prop[SPH_H], nd, S.prop[SPH_X], S.prop[SPH_Y], S.prop[SPH_Z], S.prop[SPH_H],
+                       S.perm.as<uint32_t>(), S.cell_start.as<uint32_t>(), g, c->radius_scale, start.as<uint32_t>(),
+                       nbrs.as<uint32_t>());
     return SPH_OK;
 }
 

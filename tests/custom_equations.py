@@ -209,3 +209,66 @@ class StridedDiffusion(Equation):
         psiz = fac * XIJ[2] - d_g3[d_idx * 3 + 2] - s_g3[s_idx * 3 + 2]
         d_arho[d_idx] += self.delta * HIJ * self.c0 * \
             (psix * DWIJ[0] + psiy * DWIJ[1] + psiz * DWIJ[2]) * Vj
+
+
+# ---------------------------------------------------------------------------
+# loop_all: the equation walks the neighbour list itself (NBRS, N_NBRS) and calls
+# the kernel object -- semantics of ShepardFilter,
+# pysph/sph/wc/density_correction.py:24-46 (zeroth-order density
+# re-initialisation).  initialize() copies rho -> rhotmp for ALL particles
+# before any neighbour sum reads s_rhotmp.
+# ---------------------------------------------------------------------------
+class ShepardFilter(Equation):
+    def initialize(self, d_idx, d_rho, d_rhotmp):
+        d_rhotmp[d_idx] = d_rho[d_idx]
+
+    def loop_all(self, d_idx, d_rho, d_x, d_y, d_z, s_m, s_rhotmp, s_x, s_y,
+                 s_z, d_h, s_h, SPH_KERNEL, NBRS, N_NBRS):
+        i, s_idx = declare('int', 2)
+        xij = declare('matrix(3)')
+        tmp_w = 0.0
+        x = d_x[d_idx]
+        y = d_y[d_idx]
+        z = d_z[d_idx]
+        d_rho[d_idx] = 0.0
+        for i in range(N_NBRS):
+            s_idx = NBRS[i]
+            xij[0] = x - s_x[s_idx]
+            xij[1] = y - s_y[s_idx]
+            xij[2] = z - s_z[s_idx]
+            rij = sqrt(xij[0] * xij[0] + xij[1] * xij[1] + xij[2] * xij[2])
+            hij = (d_h[d_idx] + s_h[s_idx]) * 0.5
+            wij = SPH_KERNEL.kernel(xij, rij, hij)
+            tmp_w += wij * s_m[s_idx] / s_rhotmp[s_idx]
+            d_rho[d_idx] += wij * s_m[s_idx]
+        d_rho[d_idx] /= tmp_w
+
+
+class GradientAllNbrs(Equation):
+    """made up: SPH_KERNEL.gradient + dwdq inside loop_all, two sources"""
+
+    def __init__(self, dest, sources, scale=0.5):
+        self.scale = scale
+        super(GradientAllNbrs, self).__init__(dest, sources)
+
+    def initialize(self, d_idx, d_gx, d_gy, d_gz):
+        d_gx[d_idx] = 0.0
+        d_gy[d_idx] = 0.0
+        d_gz[d_idx] = 0.0
+
+    def loop_all(self, d_idx, d_gx, d_gy, d_gz, d_x, d_y, d_z, d_h, s_x, s_y, s_z, s_m,
+                 s_rho, SPH_KERNEL, NBRS, N_NBRS):
+        k, j = declare('int', 2)
+        xij = declare('matrix(3)')
+        grad = declare('matrix(3)')
+        for k in range(N_NBRS):
+            j = NBRS[k]
+            xij[0] = d_x[d_idx] - s_x[j]
+            xij[1] = d_y[d_idx] - s_y[j]
+            xij[2] = d_z[d_idx] - s_z[j]
+            rij = sqrt(xij[0] * xij[0] + xij[1] * xij[1] + xij[2] * xij[2])
+            SPH_KERNEL.gradient(xij, rij, d_h[d_idx], grad)
+            vol = self.scale * s_m[j] / s_rho[j]
+            d_gx[d_idx] += vol * grad[0]
+            d_gy[d_idx] += vol * grad[1]
+            d_gz[d_idx] += vol * (grad[2] + 1e-3 * SPH_KERNEL.dwdq(rij, d_h[d_idx]))

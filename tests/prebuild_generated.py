@@ -51,6 +51,18 @@ def main():
     n += plan([pb], [Group(equations=[StridedGradient('fluid', ['fluid'])], real=False),
                      Group(equations=[StridedDiffusion('fluid', ['fluid'])])],
               K.CubicSpline(dim=3))
+    from custom_equations import GradientAllNbrs, ShepardFilter
+    arrs = []
+    for name in ('fluid', 'solid'):
+        pc = get_particle_array_wcsph(name=name, x=np.zeros(2))
+        for extra in ('rhotmp', 'gx', 'gy', 'gz'):
+            pc.add_property(extra)
+        arrs.append(pc)
+    for kname in ('CubicSpline', 'WendlandQuintic'):
+        n += plan(arrs, [Group(equations=[ShepardFilter('fluid', ['fluid'])]),
+                         Group(equations=[GradientAllNbrs('fluid', ['fluid', 'solid'], scale=0.5),
+                                          GradientAllNbrs('solid', ['fluid'], scale=2.0)], real=False)],
+                  getattr(K, kname)(dim=3))
     return n
 
 

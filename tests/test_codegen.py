@@ -119,15 +119,25 @@ def test_loop_all_and_missing_kernel_are_errors():
     from pysph_amd.equations import Equation, Group
 
     class NeedsLists(Equation):
-        def loop_all(self, d_idx, d_au, NBRS, N_NBRS):
-            pass
+        def loop_all(self, d_idx, d_au, s_m, NBRS, N_NBRS):
+            i = declare('int')
+            for i in range(N_NBRS):
+                d_au[d_idx] += s_m[NBRS[i]]
+
+    class PairToo(Equation):
+        def loop(self, d_idx, d_au, WIJ):
+            d_au[d_idx] += WIJ
 
     class NoBody(Equation):
         pass
 
     arrays = _arrays()
-    with pytest.raises(CodegenError):
-        GeneratedFamily('fluid', [NeedsLists('fluid', ['fluid'])], arrays, 2, 'la')
+    fam = GeneratedFamily('fluid', [NeedsLists('fluid', ['fluid'])], arrays, 2, 'la')
+    assert fam.loop_all and not fam.split_init and fam.sprops == ['m']
+    assert 'S_m[((int)NBRS[i])]' in fam.source
+    with pytest.raises(CodegenError):     # loop and loop_all on one destination in one group
+        GeneratedFamily('fluid', [NeedsLists('fluid', ['fluid']), PairToo('fluid', ['fluid'])],
+                        arrays, 2, 'mix')
     ids = {'fluid': 0, 'wall': 1}
     with pytest.raises(NotImplementedError):      # neither hand-written nor translatable
         _CGroup(Group([NoBody('fluid', ['fluid'])]), ids, arrays, 2)
@@ -183,6 +193,18 @@ def test_reference_classes_translate_like_the_restatements():
         ('VolumeSummation', dict(dest='fluid', sources=['fluid', 'wall'])),
         ('VolumeFromMassDensity', dict(dest='fluid', sources=None)),
     ]
+    # a loop_all equation: ShepardFilter (density_correction.py:24-46) vs the
+    # restatement the GPU test runs; initialize() must be split off
+    import pysph.sph.wc.density_correction as dcorr
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import custom_equations as ce
+    from pysph_amd.particle_array import get_particle_array_wcsph
+    pf = get_particle_array_wcsph(name='fluid', x=np.zeros(2))
+    pf.add_property('rhotmp')
+    a = GeneratedFamily('fluid', [dcorr.ShepardFilter('fluid', ['fluid'])], {'fluid': pf}, 2, 'r')
+    b = GeneratedFamily('fluid', [ce.ShepardFilter('fluid', ['fluid'])], {'fluid': pf}, 2, 'm')
+    assert _body_lines(a.source) == _body_lines(b.source)
+    assert a.loop_all and a.split_init
     for name, kw in cases:
         a = GeneratedFamily(kw['dest'], [getattr(tv, name)(**kw)], arrays, 3, 'r')
         b = GeneratedFamily(kw['dest'], [getattr(mine, name)(**kw)], arrays, 3, 'm')

@@ -257,6 +257,55 @@ def test_generated_strided_properties_vs_python(oracle):
     assert np.abs(ref.g3).max() > 0 and np.abs(ref.arho).max() > 0
 
 
+@pytest.mark.parametrize('kname', ['CubicSpline', 'WendlandQuintic'])
+def test_generated_loop_all_vs_python(oracle, kname):
+    """loop_all equations (the neighbour list NBRS / N_NBRS and the kernel
+    object SPH_KERNEL handed to the equation, mako :62-80): a device CSR list per
+    source, one thread per destination.  ShepardFilter's initialize() writes
+    rhotmp, which its loop_all reads as a SOURCE property: the generated family
+    runs initialize for all particles first (split launch), as the reference does.
+    Checked against the same bodies executed as Python."""
+    from oracle.py_eval import PyEval
+    from custom_equations import GradientAllNbrs, ShepardFilter
+    from pysph_amd import kernels as K
+    from pysph_amd.equations import Group
+    from pysph_amd.particle_array import get_particle_array_wcsph
+
+    def build():
+        rng = np.random.default_rng(21)
+        out = []
+        for name, n1, off in (('fluid', 11, 0.0), ('solid', 6, 0.02)):
+            dx = 1.0 / n1
+            g = (np.arange(n1) + 0.5) * dx
+            x, y, z = [a.ravel() for a in np.meshgrid(g, g, g, indexing='ij')]
+            n = x.size
+            pa = get_particle_array_wcsph(
+                name=name, x=x + off + 0.1 * dx * rng.uniform(-1, 1, n),
+                y=y + 0.1 * dx * rng.uniform(-1, 1, n), z=z + 0.1 * dx * rng.uniform(-1, 1, n),
+                h=1.2 / 11 * (1 + 0.1 * rng.uniform(-1, 1, n)), m=dx ** 3 * np.ones(n),
+                rho=1 + 0.2 * rng.uniform(-1, 1, n))
+            for extra in ('rhotmp', 'gx', 'gy', 'gz'):
+                pa.add_property(extra)
+            pa.rhotmp[:] = -5.0
+            out.append(pa)
+        return out
+    eqs = [Group(equations=[ShepardFilter('fluid', ['fluid'])]),
+           Group(equations=[GradientAllNbrs('fluid', ['fluid', 'solid'], scale=0.5),
+                            GradientAllNbrs('solid', ['fluid'], scale=2.0)], real=False)]
+    kernel = getattr(K, kname)(dim=3)
+    arrays, ref = build(), build()
+    a_eval, nnps, ctx = make_eval(arrays, eqs, kernel, 3)
+    a_eval.compute(0.0, 1e-4)
+    onn = oracle.OracleNNPS(3, ref, radius_scale=2.0)
+    onn.update()
+    PyEval(ref, eqs, kernel, onn).compute(0.0, 1e-4)
+    for pa, pr in zip(arrays, ref):
+        for prop in ('rho', 'rhotmp', 'gx', 'gy', 'gz'):
+            e = rel_err(pa.properties[prop], pr.properties[prop])
+            assert e < TOL, (pa.name, prop, e)
+    assert abs(ref[0].rho - 1).max() < 0.5 and (ref[0].rhotmp != -5.0).all()
+
+
 @pytest.mark.parametrize('case', ['sd_1d_line', 'wcsph_cube_varh',
                                   'wcsph_dam_dx0.1'])
 def test_neighbour_sets_match_reference(case):
