@@ -272,3 +272,15 @@ class GradientAllNbrs(Equation):
             d_gx[d_idx] += vol * grad[0]
             d_gy[d_idx] += vol * grad[1]
             d_gz[d_idx] += vol * (grad[2] + 1e-3 * SPH_KERNEL.dwdq(rij, d_h[d_idx]))
+
+
+class SmoothCopy(Equation):
+    """initialize() saves q in qtmp and clears q; loop() reads the SAVED value of
+    the neighbours (s_qtmp): needs initialize finished for all particles first."""
+
+    def initialize(self, d_idx, d_q, d_qtmp):
+        d_qtmp[d_idx] = d_q[d_idx]
+        d_q[d_idx] = 0.0
+
+    def loop(self, d_idx, s_idx, d_q, s_qtmp, s_m, s_rho, WIJ):
+        d_q[d_idx] += s_qtmp[s_idx] * s_m[s_idx] / s_rho[s_idx] * WIJ

@@ -51,7 +51,11 @@ def main():
     n += plan([pb], [Group(equations=[StridedGradient('fluid', ['fluid'])], real=False),
                      Group(equations=[StridedDiffusion('fluid', ['fluid'])])],
               K.CubicSpline(dim=3))
-    from custom_equations import GradientAllNbrs, ShepardFilter
+    from custom_equations import GradientAllNbrs, ShepardFilter, SmoothCopy
+    pq = get_particle_array_wcsph(name='fluid', x=np.zeros(2))
+    pq.add_property('q')
+    pq.add_property('qtmp')
+    n += plan([pq], [Group(equations=[SmoothCopy('fluid', ['fluid'])])], K.CubicSpline(dim=3))
     arrs = []
     for name in ('fluid', 'solid'):
         pc = get_particle_array_wcsph(name=name, x=np.zeros(2))

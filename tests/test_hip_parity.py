@@ -257,6 +257,45 @@ def test_generated_strided_properties_vs_python(oracle):
     assert np.abs(ref.g3).max() > 0 and np.abs(ref.arho).max() > 0
 
 
+def test_generated_split_initialize_in_pair_mode(oracle):
+    """initialize() writes qtmp, loop() reads s_qtmp: the packed source records
+    must hold the values AFTER initialize ran for every particle (the reference
+    finishes initialize first, mako :36-47), so the family launches initialize
+    on its own before packing."""
+    from oracle.py_eval import PyEval
+    from custom_equations import SmoothCopy
+    from pysph_amd import kernels as K
+    from pysph_amd.acceleration_eval import _CGroup
+    from pysph_amd.equations import Group
+    from pysph_amd.particle_array import get_particle_array_wcsph
+
+    def build():
+        rng = np.random.default_rng(4)
+        n1 = 10
+        dx = 1.0 / n1
+        g = (np.arange(n1) + 0.5) * dx
+        x, y, z = [a.ravel() for a in np.meshgrid(g, g, g, indexing='ij')]
+        n = x.size
+        pa = get_particle_array_wcsph(name='fluid', x=x, y=y, z=z, h=1.3 * dx * np.ones(n),
+                                      m=dx ** 3 * np.ones(n), rho=np.ones(n))
+        pa.add_property('q')
+        pa.add_property('qtmp')
+        pa.q[:] = rng.uniform(0, 1, n)
+        pa.qtmp[:] = 99.0
+        return pa
+    eqs = [Group(equations=[SmoothCopy('fluid', ['fluid'])])]
+    kernel = K.CubicSpline(dim=3)
+    pa, ref = build(), build()
+    a_eval, nnps, ctx = make_eval([pa], eqs, kernel, 3)
+    assert a_eval.c_acceleration_eval.plan[0][1].units[0].fam.split_init
+    a_eval.compute(0.0, 1e-4)
+    onn = oracle.OracleNNPS(3, [ref], radius_scale=2.0)
+    onn.update()
+    PyEval([ref], eqs, kernel, onn).compute(0.0, 1e-4)
+    assert rel_err(pa.qtmp, ref.qtmp) == 0.0
+    assert rel_err(pa.q, ref.q) < TOL
+
+
 @pytest.mark.parametrize('kname', ['CubicSpline', 'WendlandQuintic'])
 def test_generated_loop_all_vs_python(oracle, kname):
     """loop_all equations (the neighbour list NBRS / N_NBRS and the kernel
