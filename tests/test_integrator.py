@@ -263,3 +263,27 @@ def test_dam_break_time_loop_runs_and_stays_physical():
     # boundary particles have no stepper: the same set of positions as at t = 0
     assert np.array_equal(np.sort(wall.x), np.sort(ref[1].x))
     assert sorted(fluid.properties) == sorted(ref[0].properties)
+
+
+@pytest.mark.gpu
+def test_rings_collision_time_loop():
+    """BASELINE config 5's problem (colliding elastic rings, rings.py) through
+    the elastic equation set + SolidMechStep, device-resident PEC steps: the
+    rings approach, linear momentum stays zero by symmetry, the stress state
+    builds up only after contact, nothing blows up."""
+    from pysph_amd.examples import rings
+    dx = 0.001
+    ref = rings.create_particles(dx)[0]
+    arrays, st = rings.run(dx=dx, n_steps=150, dt=2e-8, reorder_freq=50)
+    pa = arrays[0]
+    assert st['steps'] == 150 and pa.get_number_of_particles() == ref.get_number_of_particles()
+    for k in ('x', 'y', 'u', 'v', 'rho', 's00', 's01', 's11', 'p'):
+        assert np.isfinite(pa.properties[k]).all(), k
+    left, right = pa.x < np.median(pa.x), pa.x >= np.median(pa.x)
+    gap0 = ref.x[ref.x >= np.median(ref.x)].min() - ref.x[ref.x < np.median(ref.x)].max()
+    gap1 = pa.x[right].min() - pa.x[left].max()
+    assert gap1 < gap0                                             # approaching
+    mom = (pa.m * pa.u).sum() / (pa.m * np.abs(pa.u)).sum()
+    assert abs(mom) < 1e-9                                         # mirror-symmetric set-up
+    assert abs(pa.rho - 1.0).max() < 0.2
+    assert abs((pa.m * pa.v).sum()) < 1e-9 * (pa.m * np.abs(pa.u)).sum()
