@@ -860,6 +860,21 @@ class GeneratedFamily(object):
         A('    }')
         A('};')
         A('')
+        ns = len(self.sprops)
+        nrc = (3 + ns + 1) & ~1
+        A('// records under uniform h: [x y z | source props...] (%d doubles)' % nrc)
+        A('template <> __device__ __forceinline__ void load_record<FamGen, true>(const double *__restrict__ rj, uint32_t,')
+        A('                                                                      double4 &pj, double (&s)[FamGen::NA])')
+        A('{')
+        A('    const double2 *r2 = reinterpret_cast<const double2 *>(rj);')
+        A('    double w[%d];' % nrc)
+        A('#pragma unroll')
+        A('    for (int q = 0; q < %d; q++) { const double2 t = r2[q]; w[2 * q] = t.x; w[2 * q + 1] = t.y; }' % (nrc // 2))
+        A('    pj.x = w[0]; pj.y = w[1]; pj.z = w[2]; pj.w = 0.0;')
+        A('#pragma unroll')
+        A('    for (int k = 0; k < FamGen::NA; k++) s[k] = k < %d ? w[3 + (k < %d ? k : 0)] : 0.0;' % (ns, max(ns, 1)))
+        A('}')
+        A('')
         A('__global__ __launch_bounds__(256) void k_gen_nosrc(PairArgs<FamGen> a)')
         A('{')
         A('    const size_t i = (size_t)a.d_start + (size_t)blockIdx.x * 256 + threadIdx.x;')
@@ -929,7 +944,7 @@ class GeneratedFamily(object):
         A('        const size_t n = (size_t)g->d_stop - g->d_start;')
         A('        hipLaunchKernelGGL(k_gen_nosrc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);')
         A('    } else {')
-        A('        if (g->nrec != FamGen::NR) return -1002;')
+        A('        if (g->nrec != (g->uniform_h ? %d : FamGen::NR)) return -1002;' % nrc)
         A('        dim3 grid((a.nd + ABS - 1) / ABS), block(ABS);')
         A('        if (g->uniform_h) hipLaunchKernelGGL((k_pair_agg<FamGen, %d, true>), grid, block, 0, st, a);' % self.kernel_kind)
         A('        else hipLaunchKernelGGL((k_pair_agg<FamGen, %d, false>), grid, block, 0, st, a);' % self.kernel_kind)

@@ -192,7 +192,8 @@ struct PackArgs {
     double *rec;                  // non-null: interleaved records [x y z h aux... pad], nr doubles each
     int nr;
     int layout;                   // 0: [x y z h | aux...]; 1: WCSPH [x y z cs | u v w m | rho tmpj | h p]; 2: density [x y z m];
-                                  // 3: TVF [x y z rho | u v w p | Vj2 m uhat vhat | what -]
+                                  // 3: TVF [x y z rho | u v w p | Vj2 m uhat vhat | what -];
+                                  // 4: generated, uniform h [x y z | aux...]
                                   // (1, 2: aggregated kernel only)
     float4 *fpos;                 // non-null: fp32 {x-xmin, y-ymin, z-zmin, radius_scale*h} for the prefilter tiles
     double gmin[3];
@@ -231,6 +232,17 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
             r2[2] = make_double2(v[0], v[1]); r2[3] = make_double2(v[2], v[3]);
             r2[4] = make_double2(v[4], v[5]);
             if (a.nr > 10) r2[5] = make_double2(ph.w, v[7]);
+            return;
+        }
+        if (a.layout == 4) { // generated families under uniform h: [x y z | aux...] (h is a launch constant)
+            double2 *r2 = reinterpret_cast<double2 *>(r);
+            double w[3 + MAX_AUX + 1];
+            w[0] = ph.x; w[1] = ph.y; w[2] = ph.z;
+#pragma unroll
+            for (int k = 0; k < MAX_AUX + 1; k++) w[3 + k] = k < a.na ? v[k < MAX_AUX ? k : 0] : 0.0;
+#pragma unroll
+            for (int q = 0; q < (3 + MAX_AUX + 1) / 2; q++)
+                if (2 * q < a.nr) r2[q] = make_double2(w[2 * q], w[2 * q + 1]);
             return;
         }
         if (a.layout == 3) { // TVF under uniform h: [x y z rho | u v w p | Vj2 m uhat vhat | what -]
@@ -1320,7 +1332,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
 // records with the properties the generated bodies read, then call the
 // module's launch function with plain pointers.
 // ---------------------------------------------------------------------------
-static int pack_generic(sph_ctx *c, int id, size_t off, int nprops, const int *props, int nr)
+static int pack_generic(sph_ctx *c, int id, size_t off, int nprops, const int *props, int nr, int layout)
 {
     DevArray &A = c->arr[id];
     if (A.n == 0) return SPH_OK;
@@ -1339,6 +1351,7 @@ static int pack_generic(sph_ctx *c, int id, size_t off, int nprops, const int *p
     pa.aux = c->aux.as<double>();
     pa.rec = c->posh.as<double>();
     pa.nr = nr;
+    pa.layout = layout;
     pa.fpos = c->fposb.as<float4>();
     for (int k = 0; k < 3; k++) pa.gmin[k] = c->xmin[k];
     pa.radius_scale = c->radius_scale;
@@ -1442,18 +1455,21 @@ extern "C" int sph_eval_generated(sph_ctx *c, const sph_kernel *K, const sph_gen
         else for (int j = 0; j < f->nsrc; j++) if (f->src[j] == dst) d_off = off_of[j];
         if (total >= (1ull << 32)) { sph_set_error("too many particles for 32-bit packed indices"); return SPH_ERR_ARG; }
         const int na = f->n_sprops;
-        const int nr = 4 + ((na + 1) & ~1); // whole 16-byte pieces
+        // whole 16-byte pieces; under uniform h the records drop h: [x y z | aux...]
+        const bool compact = g.uniform_h != 0;
+        const int nr = compact ? ((3 + na + 1) & ~1) : 4 + ((na + 1) & ~1);
+        const int layout = compact ? 4 : 0;
         SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * nr));
         SPH_TRY(c->aux.reserve(64));
         SPH_TRY(c->fposb.reserve((total + 64) * sizeof(float4)));
         {
             ScopedTimer tm(c, T_PACK);
-            for (int j = 0; j < f->nsrc; j++) SPH_TRY(pack_generic(c, f->src[j], off_of[j], na, f->sprops, nr));
+            for (int j = 0; j < f->nsrc; j++) SPH_TRY(pack_generic(c, f->src[j], off_of[j], na, f->sprops, nr, layout));
             if (!dest_is_src) {
                 // the destination only needs its position record; properties it lacks are not read
                 int have[SPH_GEN_MAX_SPROPS], nh = 0;
                 for (int k = 0; k < na; k++) if (D.prop[f->sprops[k]]) have[nh++] = f->sprops[k];
-                SPH_TRY(pack_generic(c, dst, d_off, nh == na ? na : 0, f->sprops, nr));
+                SPH_TRY(pack_generic(c, dst, d_off, nh == na ? na : 0, f->sprops, nr, layout));
             }
         }
         g.rec = c->posh.as<double>();
