@@ -244,6 +244,7 @@ typedef struct sph_gen_args {
      *         neighbour list (NBRS, N_NBRS; mako :62-80).                      */
     int mode;
     int skip_init;                /* mode 0/2: initialize already done by a mode-1 launch */
+    int rec_f32;                  /* records are floats [x-x0 y-y0 z-z0 h | sprops...] (option record_f32) */
     const uint32_t *csr_start[SPH_MAX_ARRAYS]; /* mode 2: per source, start[nd+1] */
     const uint32_t *csr_nbrs[SPH_MAX_ARRAYS];  /*         and neighbour indices   */
     const double *sraw[SPH_MAX_ARRAYS][SPH_GEN_MAX_SPROPS]; /* mode 2: source props, original order */

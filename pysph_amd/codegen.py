@@ -944,9 +944,11 @@ class GeneratedFamily(object):
         A('        const size_t n = (size_t)g->d_stop - g->d_start;')
         A('        hipLaunchKernelGGL(k_gen_nosrc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);')
         A('    } else {')
-        A('        if (g->nrec != (g->uniform_h ? %d : FamGen::NR)) return -1002;' % nrc)
+        A('        if (g->nrec != (g->rec_f32 ? ((4 + FamGen::NA + 3) & ~3) : g->uniform_h ? %d : FamGen::NR)) return -1002;' % nrc)
         A('        dim3 grid((a.nd + ABS - 1) / ABS), block(ABS);')
-        A('        if (g->uniform_h) hipLaunchKernelGGL((k_pair_agg<FamGen, %d, true>), grid, block, 0, st, a);' % self.kernel_kind)
+        A('        if (g->rec_f32 && g->uniform_h) hipLaunchKernelGGL((k_pair_agg<FamGen, %d, true, true>), grid, block, 0, st, a);' % self.kernel_kind)
+        A('        else if (g->rec_f32) hipLaunchKernelGGL((k_pair_agg<FamGen, %d, false, true>), grid, block, 0, st, a);' % self.kernel_kind)
+        A('        else if (g->uniform_h) hipLaunchKernelGGL((k_pair_agg<FamGen, %d, true>), grid, block, 0, st, a);' % self.kernel_kind)
         A('        else hipLaunchKernelGGL((k_pair_agg<FamGen, %d, false>), grid, block, 0, st, a);' % self.kernel_kind)
         A('    }')
         A('    return (int)hipGetLastError();')

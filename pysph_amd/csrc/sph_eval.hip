@@ -193,7 +193,7 @@ struct PackArgs {
     int nr;
     int layout;                   // 0: [x y z h | aux...]; 1: WCSPH [x y z cs | u v w m | rho tmpj | h p]; 2: density [x y z m];
                                   // 3: TVF [x y z rho | u v w p | Vj2 m uhat vhat | what -];
-                                  // 4: generated, uniform h [x y z | aux...]
+                                  // 4: generated, uniform h [x y z | aux...]; 5: fp32 records (floats, any family)
                                   // (1, 2: aggregated kernel only)
     float4 *fpos;                 // non-null: fp32 {x-xmin, y-ymin, z-zmin, radius_scale*h} for the prefilter tiles
     double gmin[3];
@@ -232,6 +232,18 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
             r2[2] = make_double2(v[0], v[1]); r2[3] = make_double2(v[2], v[3]);
             r2[4] = make_double2(v[4], v[5]);
             if (a.nr > 10) r2[5] = make_double2(ph.w, v[7]);
+            return;
+        }
+        if (a.layout == 5) { // fp32 records [x-x0 y-y0 z-z0 h | aux...] (option record_f32), a.nr floats
+            float4 *r4 = reinterpret_cast<float4 *>(reinterpret_cast<float *>(a.rec) + (a.off + i) * (size_t)a.nr);
+            float w[4 + MAX_AUX];
+            w[0] = (float)(ph.x - a.gmin[0]); w[1] = (float)(ph.y - a.gmin[1]); w[2] = (float)(ph.z - a.gmin[2]);
+            w[3] = (float)ph.w;
+#pragma unroll
+            for (int k = 0; k < MAX_AUX; k++) w[4 + k] = k < a.na ? (float)v[k] : 0.f;
+#pragma unroll
+            for (int q = 0; q < (4 + MAX_AUX) / 4; q++)
+                if (4 * q < a.nr) r4[q] = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
             return;
         }
         if (a.layout == 4) { // generated families under uniform h: [x y z | aux...] (h is a launch constant)
@@ -1025,6 +1037,7 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
     if (c->pair_variant >= 3) pa.fpos = c->fposb.as<float4>();
     pa.layout = (c->pair_variant == 3 && fam == FAM_WCSPH) ? 1 : (c->pair_variant == 3 && fam == FAM_DENSITY && pl.nr == 4) ? 2
               : (c->pair_variant == 3 && fam == FAM_TVF && pl.nr == 14) ? 3 : 0;
+    if (c->pair_variant == 3 && c->record_f32) pa.layout = 5;
     hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, pa);
     return SPH_OK;
 }
@@ -1035,8 +1048,11 @@ template <class Fam> static void launch_pair(sph_ctx *c, int kk, const PairArgs<
     const bool uh = c->uniform_h && c->use_uniform_h;
     if (c->pair_variant == 3) {
         dim3 g2(div_up(a.nd, ABS)), b2(ABS);
-#define LAUNCH3(K)                                                                           \
-        if (uh) hipLaunchKernelGGL((k_pair_agg<Fam, K, true>), g2, b2, 0, c->stream, a);     \
+#define LAUNCH3(K)                                                                                      \
+        if (c->record_f32) {                                                                            \
+            if (uh) hipLaunchKernelGGL((k_pair_agg<Fam, K, true, true>), g2, b2, 0, c->stream, a);      \
+            else hipLaunchKernelGGL((k_pair_agg<Fam, K, false, true>), g2, b2, 0, c->stream, a);        \
+        } else if (uh) hipLaunchKernelGGL((k_pair_agg<Fam, K, true>), g2, b2, 0, c->stream, a);         \
         else hipLaunchKernelGGL((k_pair_agg<Fam, K, false>), g2, b2, 0, c->stream, a)
         switch (kk) {
         case 1: LAUNCH3(1); break;
@@ -1205,6 +1221,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         if (c->pair_variant == 3 && fam == FAM_WCSPH && c->uniform_h && c->use_uniform_h && !(dflags & F_TENSILE)) pl.nr = 10;
         if (c->pair_variant == 3 && fam == FAM_DENSITY && c->uniform_h && c->use_uniform_h) pl.nr = 4;
         if (c->pair_variant == 3 && fam == FAM_TVF && c->uniform_h && c->use_uniform_h) pl.nr = 14;
+        if (c->pair_variant == 3 && c->record_f32) pl.nr = (4 + pl.na + 3) & ~3; // floats
         c->cur_nrec = pl.nr;
         SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * (c->pair_variant >= 2 ? pl.nr : 4)));
         SPH_TRY(c->aux.reserve((total + 64) * sizeof(double) * pl.na));
@@ -1457,8 +1474,11 @@ extern "C" int sph_eval_generated(sph_ctx *c, const sph_kernel *K, const sph_gen
         const int na = f->n_sprops;
         // whole 16-byte pieces; under uniform h the records drop h: [x y z | aux...]
         const bool compact = g.uniform_h != 0;
-        const int nr = compact ? ((3 + na + 1) & ~1) : 4 + ((na + 1) & ~1);
-        const int layout = compact ? 4 : 0;
+        const int na_fam = ((na + 1) & ~1) < 2 ? 2 : ((na + 1) & ~1); // FamGen::NA
+        const int nr = c->record_f32 ? ((4 + na_fam + 3) & ~3) /* floats */
+                     : compact ? ((3 + na + 1) & ~1) : 4 + ((na + 1) & ~1);
+        const int layout = c->record_f32 ? 5 : (compact ? 4 : 0);
+        g.rec_f32 = c->record_f32 ? 1 : 0;
         SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * nr));
         SPH_TRY(c->aux.reserve(64));
         SPH_TRY(c->fposb.reserve((total + 64) * sizeof(float4)));

@@ -52,7 +52,7 @@ template <class Fam> struct PairArgs {
     const double4 *posh;
     const double *aux;
     const double *rec; // variant 2: interleaved records, Fam::NR doubles each
-    int nrec;          // variant 3: doubles per record (Fam::NR, or 10 for compact WCSPH records)
+    int nrec;          // variant 3: doubles per record (Fam::NR, or a compact layout's), floats with record_f32
     const float4 *fpos; // variant 3: fp32 grid-relative positions + radius_scale*h (prefilter only)
     double dom_extent;  // largest grid extent: bounds the fp32 rounding of fpos
     uint32_t d_off, nd;
@@ -164,6 +164,24 @@ __device__ __forceinline__ void load_record(const double *__restrict__ rj, uint3
     for (int k = 0; k < Fam::NA; k++) s[k] = rj[4 + k];
 }
 
+// fp32 RECORDS (option record_f32): [x-x0 y-y0 z-z0 h | aux...] as floats, 16-byte
+// pieces of four; positions are relative to the grid origin so that their
+// rounding is relative to the domain extent.  The values are widened to double
+// on load -- arithmetic and accumulation stay fp64, the inputs carry fp32
+// precision, and a pair costs about half the gather pieces.
+template <class Fam>
+__device__ __forceinline__ void load_record_f32(const float *__restrict__ rj, double4 &pj, double (&s)[Fam::NA])
+{
+    constexpr int NF = (4 + Fam::NA + 3) & ~3;
+    float f[NF];
+    const float4 *r4 = reinterpret_cast<const float4 *>(rj);
+#pragma unroll
+    for (int q = 0; q < NF / 4; q++) { const float4 t = r4[q]; f[4 * q] = t.x; f[4 * q + 1] = t.y; f[4 * q + 2] = t.z; f[4 * q + 3] = t.w; }
+    pj.x = f[0]; pj.y = f[1]; pj.z = f[2]; pj.w = f[3];
+#pragma unroll
+    for (int k = 0; k < Fam::NA; k++) s[k] = f[4 + k];
+}
+
 // ---- WCSPH: Continuity + Momentum + XSPH (wc/basic.py, basic_equations.py) --
 // ---------------------------------------------------------------------------
 // XCD-aware block remap (MI355X: 8 XCDs, block b runs on XCD b % 8, each XCD
@@ -199,7 +217,8 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nb)
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-template <class Fam, int KK, bool UH> __global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_agg(PairArgs<Fam> a)
+template <class Fam, int KK, bool UH, bool F32 = false>
+__global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_agg(PairArgs<Fam> a)
 {
     const uint32_t NR = (uint32_t)a.nrec;
     // fp32 tile: x | y | z | (w) planes of TS floats each; reads past a plane's
@@ -228,7 +247,8 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(ABS, Fam::MIN
         double sd_[Fam::NA];
         // the destination's own h / p come with the same rules as a source's
         // (uniform h: the constant; p only for the tensile correction)
-        load_record<Fam, UH>(a.rec + (size_t)(a.d_off + ic) * NR, a.dflags, pi, sd_);
+        if (F32) load_record_f32<Fam>(reinterpret_cast<const float *>(a.rec) + (size_t)(a.d_off + ic) * NR, pi, sd_);
+        else load_record<Fam, UH>(a.rec + (size_t)(a.d_off + ic) * NR, a.dflags, pi, sd_);
         if (UH) pi.w = a.hu;
         Fam::load(D, sd_, a, o);
     }
@@ -248,7 +268,8 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(ABS, Fam::MIN
     auto do_pair = [&](uint32_t jg, uint32_t flags) {
         double4 pj;
         double sj[Fam::NA];
-        load_record<Fam, UH>(a.rec + (unsigned long long)jg * NR, flags, pj, sj);
+        if (F32) load_record_f32<Fam>(reinterpret_cast<const float *>(a.rec) + (unsigned long long)jg * NR, pj, sj);
+        else load_record<Fam, UH>(a.rec + (unsigned long long)jg * NR, flags, pj, sj);
         double hj2 = hi2;
         if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
         const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
@@ -306,7 +327,8 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(ABS, Fam::MIN
                             int bit;
                             if (m0) { bit = __builtin_ctzll(m0); m0 &= m0 - 1; }
                             else { bit = 64 + __builtin_ctz(m1); m1 &= m1 - 1; }
-                            do_pair(qbase[q] + mofs[q][t] + bit, sd.flags);
+                            // ablate 3 (profiling): every gather hits the destination's own record (L1-resident)
+                            do_pair(a.ablate == 3 ? a.d_off + ic : qbase[q] + mofs[q][t] + bit, sd.flags);
                         }
                     }
                 }

@@ -803,6 +803,33 @@ def test_randomised_tvf_and_elastic_vs_oracle(oracle, seed):
             assert e < TOL, (seed, which, dim, n1, type(kernel).__name__, varh, variant, prop, e)
 
 
+@pytest.mark.parametrize('case', ['wcsph_cube_varh', 'tvf_cube', 'wcsph_dam_dx0.1', 'elastic_3d',
+                                  'elastic_2d', 'tvf_wall'])
+def test_record_f32_mode_vs_golden(case):
+    """Option record_f32: the packed records (positions relative to the grid
+    origin, h and every gathered property) are stored as floats -- about half the
+    gather pieces per pair -- while the pair arithmetic and the accumulation stay
+    fp64.  Results carry fp32 input precision: compared with the fp64 golden
+    vectors at an fp32 tolerance (fp32 parity is against the
+    fp64 oracle), for every hand-written family and a generated one."""
+    g = load_golden(case + '.npz')
+    arrays = arrays_from_golden(g, 'in')
+    eqs, kernel, dim, outs = golden_case(case, g)
+    a_eval, nnps, ctx = make_eval(arrays, eqs, kernel, dim, 3)
+    ctx.set_option('record_f32', 1)
+    a_eval.compute(float(g['t']), float(g['dt']))
+    worst = 0.0
+    for pa in arrays:
+        for prop in outs:
+            key = 'out/%s/%s' % (pa.name, prop)
+            if key in g.files and prop in pa.properties:
+                e = rel_err(pa.properties[prop], g[key])
+                worst = max(worst, e)
+                assert e < 2e-5, (case, pa.name, prop, e)
+    assert worst > 1e-12          # really a different precision, not the fp64 path
+    print('record_f32 %s: max rel err %.3e' % (case, worst))
+
+
 def test_error_behaviour():
     """Same failures as the reference: RuntimeError for missing properties
     (acceleration_eval.py:32-73) and for >2^28 cells
