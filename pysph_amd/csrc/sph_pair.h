@@ -319,8 +319,16 @@ __global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_agg(PairArg
                     int q = 0;
                     unsigned long long m0 = mlo[0][t];
                     uint32_t m1 = mhi[0][t];
+                    // candidate index of bit 0 of the current slot: read from LDS only
+                    // when the slot changes, not on the dependent chain of every hit
+                    uint32_t jb = qbase[0] + mofs[0][t];
                     for (;;) {
-                        while (m0 == 0 && m1 == 0 && q + 1 < nq) { ++q; m0 = mlo[q][t]; m1 = mhi[q][t]; }
+                        while (m0 == 0 && m1 == 0 && q + 1 < nq) {
+                            ++q;
+                            m0 = mlo[q][t];
+                            m1 = mhi[q][t];
+                            jb = qbase[q] + mofs[q][t];
+                        }
                         const bool has = (m0 != 0) || (m1 != 0);
                         if (!__any(has)) break;
                         if (has) {
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_agg(PairArg
                             if (m0) { bit = __builtin_ctzll(m0); m0 &= m0 - 1; }
                             else { bit = 64 + __builtin_ctz(m1); m1 &= m1 - 1; }
                             // ablate 3 (profiling): every gather hits the destination's own record (L1-resident)
-                            do_pair(a.ablate == 3 ? a.d_off + ic : qbase[q] + mofs[q][t] + bit, sd.flags);
+                            do_pair(a.ablate == 3 ? a.d_off + ic : jb + bit, sd.flags);
                         }
                     }
                 }
