@@ -512,9 +512,9 @@ class SPHCompiler(object):
                  sync='auto'):
         if not isinstance(acceleration_evals, (list, tuple)):
             acceleration_evals = [acceleration_evals]
-        if integrator is not None:
-            raise NotImplementedError('HIP integrator stage kernels: next round')
         self.acceleration_evals = list(acceleration_evals)
+        self.integrator = integrator
+        self.ctx = ctx
         self.helpers = [AccelerationEvalHipHelper(a, ctx, sync)
                         for a in self.acceleration_evals]
 
@@ -522,3 +522,12 @@ class SPHCompiler(object):
         for h in self.helpers:
             h.compile(h.get_code())
             h.setup_compiled_module(None)
+        if self.integrator is not None:
+            # sph_compiler.py:27-59: the integrator gets its compiled object too
+            # (stage sweeps = sph_integrate_stage); the caller hands it the NNPS
+            # afterwards with integrator.set_nnps(nnps), as Solver.setup does
+            from .integrator import HipIntegrator
+            integ = self.integrator
+            integ.set_acceleration_evals(self.acceleration_evals)
+            integ.set_compiled_object(HipIntegrator(
+                integ, self.acceleration_evals[0].c_acceleration_eval, self.ctx))

@@ -1008,7 +1008,7 @@ static bool slot_required(int fam, uint32_t flags, int prop)
     return false;
 }
 
-static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fam, uint32_t flags)
+static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fam, uint32_t flags, bool dest_only = false)
 {
     DevArray &A = c->arr[id];
     if (A.n == 0) return SPH_OK;
@@ -1022,7 +1022,12 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
         pa.src[k] = nullptr;
         if ((k < pl.na || (pl.derived == 3 && k == 18) || (pl.derived == 4 && k == 4)) && pl.props[k] >= 0) {
             pa.src[k] = A.prop[pl.props[k]];
-            if (!pa.src[k] && slot_required(fam, flags, pl.props[k])) return need_prop(c, id, pl.props[k], "pair loop");
+            // a destination that is not among the sources is only read through Fam::load:
+            // it does not need a mass unless the equation uses the destination's own
+            // (transport_velocity.SummationDensity: rho_i = m_i sum W)
+            const bool mass_free = dest_only && pl.props[k] == SPH_M &&
+                                   (fam == FAM_WCSPH || (fam == FAM_DENSITY && !(flags & F_TVFSD)));
+            if (!pa.src[k] && !mass_free && slot_required(fam, flags, pl.props[k])) return need_prop(c, id, pl.props[k], "pair loop");
         }
     }
     pa.derived = pl.derived;
@@ -1230,7 +1235,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             ScopedTimer tm(c, T_PACK);
             // a source must hold what ITS equations read; the destination's own record what all of them read
             for (int j = 0; j < nsrcs; j++) SPH_TRY(pack_array(c, srcs[j], off_of[j], pl, fam, srcs[j] == dst ? dflags : sflags[j]));
-            if (!dest_is_src) SPH_TRY(pack_array(c, dst, d_off, pl, fam, dflags));
+            if (!dest_is_src) SPH_TRY(pack_array(c, dst, d_off, pl, fam, dflags, true));
         }
 
         // 4. fused pair kernel

@@ -180,11 +180,27 @@ class HipContext(object):
         self.device = device
         self._ids = {}
 
-    def array_id(self, name):
+    def array_id(self, name, owner=None):
+        """Device slot of the particle array called `name`.  A context mirrors
+        ONE set of arrays: a second, different array object with the same name
+        would silently share (and resize) the first one's device storage, so
+        that is refused -- use a context of its own (HipContext()) for it."""
         if name not in self._ids:
             if len(self._ids) >= MAX_ARRAYS:
                 raise SphError('at most %d particle arrays' % MAX_ARRAYS)
             self._ids[name] = len(self._ids)
+        if owner is not None:
+            import weakref
+            owners = self.__dict__.setdefault('_owners', {})
+            prev = owners.get(name)
+            prev = prev() if prev is not None else None
+            if prev is not None and prev is not owner:
+                raise SphError('two different particle arrays named %r in one HipContext; '
+                               'create a separate HipContext for the second set' % name)
+            try:
+                owners[name] = weakref.ref(owner)
+            except TypeError:
+                pass
         return self._ids[name]
 
     def synchronize(self):
@@ -245,7 +261,7 @@ class HipDeviceHelper(object):
         self._pa = pa
         self.ctx = ctx or get_context()
         self.lib = self.ctx.lib
-        self.array_id = self.ctx.array_id(pa.name)
+        self.array_id = self.ctx.array_id(pa.name, pa)
         self._n = -1
         # True when the device holds extra (ghost) particles the host array
         # does not have: sizes are then managed by the halo exchange

@@ -1300,3 +1300,37 @@ def test_device_reorder_keeps_results(oracle):
     assert np.array_equal(pa.x, ref[0].x[order])
     for prop in WC_OUT:
         assert rel_err(pa.properties[prop], ref[0].properties[prop][order]) < TOL, prop
+
+
+def test_sph_evaluator_known_answers():
+    """The reference's own known answers for SPHEvaluator
+    (pysph/tools/tests/test_sph_evaluator.py:21-73): summation density of ten
+    unit masses on [0, 1] seen from x = 0.5 is 9.0 (2 places), from x = 0 with a
+    periodic domain 9.0, from x = 0 without it 7.0 (1 place); default Gaussian
+    kernel, host arrays authoritative."""
+    from pysph_amd.domain import DomainManager
+    from pysph_amd.equations import SummationDensity
+    from pysph_amd.particle_array import get_particle_array
+    from pysph_amd.tools import SPHEvaluator
+    x = np.linspace(0, 1, 10)
+    dx = x[1] - x[0]
+    src = get_particle_array(name='src', x=x, m=np.ones_like(x), h=np.ones_like(x) * dx)
+    eqs = [SummationDensity(dest='dest', sources=['src'])]
+    dest = get_particle_array(name='dest', x=[0.5], h=src.h[:1])
+    ev = SPHEvaluator(arrays=[dest, src], equations=eqs, dim=1)
+    ev.evaluate()
+    assert abs(dest.rho[0] - 9.0) < 0.5e-2
+    # with a periodic domain
+    dest2 = get_particle_array(name='dest', x=[0.0], h=src.h[:1])
+    src2 = get_particle_array(name='src', x=x, m=np.ones_like(x), h=np.ones_like(x) * dx)
+    dm = DomainManager(xmin=-dx / 2, xmax=1.0 + dx / 2, periodic_in_x=True)
+    ev2 = SPHEvaluator(arrays=[dest2, src2], equations=eqs, dim=1, domain_manager=dm)
+    ev2.evaluate()
+    assert abs(dest2.rho[0] - 9.0) < 0.5e-2
+    # new particle arrays: the destination moved to the end of the line
+    rho0 = dest.rho[0]
+    dest.x[0] = 0.0
+    ev.update_particle_arrays([dest, src])
+    ev.evaluate()
+    assert dest.rho[0] != rho0
+    assert abs(dest.rho[0] - 7.0) < 0.5e-1
