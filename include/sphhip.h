@@ -244,6 +244,7 @@ typedef struct sph_gen_args {
      *         neighbour list (NBRS, N_NBRS; mako :62-80).                      */
     int mode;
     int skip_init;                /* mode 0/2: initialize already done by a mode-1 launch */
+    int skip_post;                /* mode 2 followed by a pair launch of the same family: no post_loop yet */
     int rec_f32;                  /* records are floats [x-x0 y-y0 z-z0 h | sprops...] (option record_f32) */
     const uint32_t *csr_start[SPH_MAX_ARRAYS]; /* mode 2: per source, start[nd+1] */
     const uint32_t *csr_nbrs[SPH_MAX_ARRAYS];  /*         and neighbour indices   */
@@ -272,7 +273,8 @@ typedef struct sph_gen_family {
     int real;                    /* Group(real=...)                          */
     long start_idx, stop_idx;    /* Group(start_idx, stop_idx); <0: None     */
     int split_init;              /* 1: run a mode-1 launch before packing    */
-    int loop_all;                /* 1: the family's source equations are loop_all (mode 2) */
+    int loop_all;                /* 1: the family has loop_all equations (mode 2 launch)   */
+    int also_pair;               /* 1: ... and pair loops as well: mode 2 (no post_loop), then the pair launch */
 } sph_gen_family;
 
 /* initialize -> no-source loops -> per-source pair loops -> post_loop of one

@@ -244,8 +244,9 @@ class _GeneratedUnit(object):
         self.cf.real = 1 if group.real else 0
         self.cf.split_init = 1 if f.split_init else 0
         self.cf.loop_all = 1 if f.loop_all else 0
+        self.cf.also_pair = 1 if f.also_pair else 0
         owner.inputs[dest].update(f.dprops)
-        owner.outputs[dest].update(f.dout)
+        owner.outputs_exact[dest].update(f.dout)    # exactly what the bodies write
         for sname in f.sources:
             owner.inputs[sname].update(list(f.sprops) + ['x', 'y', 'z', 'h'])
 
@@ -274,7 +275,8 @@ class _CGroup(object):
     def __init__(self, group, array_ids, arrays, kernel_kind=None):
         self.group = group
         self.inputs = defaultdict(set)    # array name -> props read
-        self.outputs = defaultdict(set)   # array name -> props written
+        self.outputs = defaultdict(set)   # array name -> props written (hand-written kernels: a superset)
+        self.outputs_exact = defaultdict(set)  # generated families: exactly the written properties
         self.units = []
         self._arrays = arrays
         dests = []
@@ -365,11 +367,14 @@ class HipAccelerationEval(object):
         self.plan = [self._plan_group(g, ids) for g in groups]
         self.inputs = defaultdict(set)
         self.outputs = defaultdict(set)
+        self.outputs_exact = defaultdict(set)
         for cg in self._leaves(self.plan):
             for n, p in cg.inputs.items():
                 self.inputs[n].update(p)
             for n, p in cg.outputs.items():
                 self.outputs[n].update(p)
+            for n, p in cg.outputs_exact.items():
+                self.outputs_exact[n].update(p)
 
     def _plan_group(self, g, ids):
         if g.has_subgroups:
@@ -415,13 +420,16 @@ class HipAccelerationEval(object):
             self.helpers[name].push(*have)
 
     def pull_outputs(self):
-        for name, props in self.outputs.items():
+        # the hand-written kernels' tables list every property an equation
+        # touches on its destination, inputs included: those never change
+        never_written = ('x', 'y', 'z', 'h', 'm', 'u', 'v', 'w', 'uhat', 'vhat', 'what')
+        for name in set(self.outputs) | set(self.outputs_exact):
             pa = self.arrays[name]
+            props = set(p for p in self.outputs.get(name, ()) if p not in never_written)
+            props |= set(self.outputs_exact.get(name, ()))
             out = [p for p in sorted(props)
-                   if ((p in pa.properties and dev.prop_id(p) >= 0)
-                       or self.helpers[name]._component(p) is not None) and p not in ('x', 'y', 'z', 'h', 'm',
-                                                    'u', 'v', 'w', 'uhat',
-                                                    'vhat', 'what')]
+                   if (p in pa.properties and dev.prop_id(p) >= 0)
+                   or self.helpers[name]._component(p) is not None]
             self.helpers[name].pull(*out)
 
     # -- group execution (acceleration_eval_cython.mako:291-363) -------------
@@ -456,9 +464,21 @@ class HipAccelerationEval(object):
             for eq in g.equations:
                 yield eq
 
+    def _host_hook(self, fn, *args):
+        """Run a host-side callback (Group.pre/post, Equation.py_initialize,
+        Equation.reduce).  With sync='auto' the host arrays are authoritative:
+        bring them up to date first and push whatever the callback changed
+        (the reference's own GPU tests do the same pull/push by hand inside
+        their callbacks, test_acceleration_eval.py:178-191)."""
+        if self.sync == 'auto':
+            self.pull_outputs()
+        fn(*args)
+        if self.sync == 'auto':
+            self.push_inputs()
+
     def _run_once(self, g, item, t, dt):
         if g.pre:
-            g.pre()
+            self._host_hook(g.pre)
         if isinstance(item, list):
             for sub in item:
                 sg = sub[0]
@@ -468,17 +488,17 @@ class HipAccelerationEval(object):
         else:
             for eq in g.equations:
                 if hasattr(eq, 'py_initialize'):
-                    eq.py_initialize(self.arrays[eq.dest], t, dt)
+                    self._host_hook(eq.py_initialize, self.arrays[eq.dest], t, dt)
             item.refresh_range()
             item.run(self, t, dt)
             for eq in g.equations:
                 if hasattr(eq, 'reduce'):
-                    eq.reduce(self.arrays[eq.dest], t, dt)
+                    self._host_hook(eq.reduce, self.arrays[eq.dest], t, dt)
         if g.update_nnps:
             self.nnps.update_domain()
             self.nnps.update()
         if g.post:
-            g.post()
+            self._host_hook(g.post)
 
 
 class AccelerationEvalHipHelper(object):

@@ -617,17 +617,18 @@ class GeneratedFamily(object):
                     self.bodies[m].append(b)
         # loop_all families: one thread per destination walks its neighbour list
         self.loop_all = bool(self.bodies['loop_all'])
-        if self.loop_all and self.bodies['loop']:
-            raise CodegenError('destination %r mixes loop and loop_all equations; put '
-                               'them in separate groups' % dest)
+        # loop_all AND loop on one destination (mako :62-110 runs loop_all, then
+        # the pair loop, per source): initialize gets its own launch, then the
+        # loop_all launch (no post_loop), then the pair launch (with post_loop)
+        self.also_pair = self.loop_all and bool(self.bodies['loop'])
         # initialize()/no-source loops of ALL particles must be finished before a
         # loop reads what they wrote as a SOURCE property (mako :36-58): then
         # they run as a launch of their own, before the records are packed
         early = set()
         for b in self.bodies['initialize'] + self.nosrc_loops:
             early |= b.writes
-        self.split_init = bool(self.sources) and dest in self.sources and \
-            bool(early & set(self.sprops))
+        self.split_init = self.also_pair or (bool(self.sources) and dest in self.sources and
+                                             bool(early & set(self.sprops)))
         if 'VIJ' in self.symbols:
             for p in 'uvw':
                 self.dest_prop(p, False)
@@ -902,7 +903,8 @@ class GeneratedFamily(object):
         A('    FamGen::Dest D;')
         A('    FamGen::load(D, nullptr, a, (uint32_t)i);')
         A('    for (int j = 0; j < a.nsrc; j++) FamGen::all_nbrs<%d>(D, a, j, (uint32_t)i);' % self.kernel_kind)
-        A('    FamGen::finish(D, a, (uint32_t)i);')
+        A('    if (a.skip_post) FamGen::store(D, a, (uint32_t)i);')
+        A('    else FamGen::finish(D, a, (uint32_t)i);')
         A('}')
         A('')
         A('extern "C" int sphgen_kernel_kind(void) { return %d; }' % self.kernel_kind)
@@ -929,6 +931,7 @@ class GeneratedFamily(object):
         A('    for (int k = 0; k < g->n_dout; k++) a.p.dout[k] = g->dout[k];')
         A('    for (int k = 0; k < g->npar; k++) a.p.par[k] = g->par[k];')
         A('    a.skip_init = g->skip_init;')
+        A('    a.skip_post = g->skip_post;')
         A('    for (int j = 0; j < SPH_MAX_ARRAYS; j++) {')
         A('        a.p.csr_start[j] = g->csr_start[j]; a.p.csr_nbrs[j] = g->csr_nbrs[j];')
         A('        for (int k = 0; k < %d; k++) a.p.sraw[j][k] = g->sraw[j][k];' % max(len(self.sprops), 1))

@@ -1454,10 +1454,19 @@ extern "C" int sph_eval_generated(sph_ctx *c, const sph_kernel *K, const sph_gen
         }
         g.mode = 2;
         g.radius_scale = c->radius_scale;
-        ScopedTimer tm(c, T_PAIR);
-        int rc = f->launch(&g);
-        if (rc != 0) { sph_set_error("generated loop_all launch failed (code %d)", rc); return SPH_ERR_HIP; }
-        return SPH_OK;
+        g.skip_post = f->also_pair ? 1 : 0;
+        {
+            ScopedTimer tm(c, T_PAIR);
+            int rc = f->launch(&g);
+            if (rc != 0) { sph_set_error("generated loop_all launch failed (code %d)", rc); return SPH_ERR_HIP; }
+        }
+        if (!f->also_pair) return SPH_OK;
+        // the same family's pair loops follow (mako :62-110: loop_all, then loop, per source);
+        // initialize has run (split launch), post_loop runs at the end of the pair launch
+        g.mode = 0;
+        g.skip_post = 0;
+        g.skip_init = 1;
+        g.dflags = 0;
     }
 
     if (f->nsrc > 0) {

@@ -67,6 +67,7 @@ template <class Fam> struct PairArgs {
     uint32_t dflags; // union of the source flags
     int ablate;      // profiling only: 1 = skip pair arithmetic, 2 = skip phase 2
     int skip_init;   // generated families: initialize() already ran in a launch of its own
+    int skip_post;   // generated loop_all launch followed by a pair launch: post_loop runs there
     double t, dt;
     // constants of the uniform-h specialisation (hmin == hmax over all arrays)
     double hu, h1u, facu, epsu, hr2u;

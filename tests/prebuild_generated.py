@@ -67,6 +67,17 @@ def main():
                          Group(equations=[GradientAllNbrs('fluid', ['fluid', 'solid'], scale=0.5),
                                           GradientAllNbrs('solid', ['fluid'], scale=2.0)], real=False)],
                   getattr(K, kname)(dim=3))
+    import test_reference_scenarios as RS
+    from pysph_amd.particle_array import get_particle_array
+    ps = get_particle_array(name='fluid', x=np.zeros(3))
+    ps.add_constant('total_mass', 0.0)
+    ps.add_constant('reduce_calls', 0)
+    for cls, src in ((RS.SimpleEquation, ['fluid']), (RS.SimpleReduction, ['fluid']), (RS.PyInit, None),
+                     (RS.LoopAllEquation, ['fluid']), (RS.DumbEquation, ['fluid']),
+                     (RS.EqWithTime, ['fluid']), (RS.SillyEquation, ['fluid'])):
+        n += plan([ps], [Group(equations=[cls('fluid', src)])], K.CubicSpline(dim=1))
+    n += plan([ps], [Group(equations=[RS.SimpleEquation('fluid', ['fluid']),
+                                      RS.SimpleEquation('fluid', ['fluid'])])], K.CubicSpline(dim=1))
     return n
 
 

@@ -1,0 +1,279 @@
+"""The reference's own AccelerationEval test scenarios
+(pysph/sph/tests/test_acceleration_eval.py) on the HIP backend, with the same
+user-defined test equations (restated below from :137-241) going through the
+generated-family path and the SAME expected values the reference asserts
+(line numbers cited per test).  Set-up = TestAccelerationEval1D.setUp (:295-316):
+ten particles on [0, 1], h = 1.05 dx, unit mass, CubicSpline(dim=1)."""
+import numpy as np
+import pytest
+
+from pysph_amd.equations import Equation, Group, SummationDensity
+
+pytestmark = pytest.mark.gpu
+
+
+def declare(spec, *a):          # the bodies below are translated, never run as Python
+    return None
+
+
+class SimpleEquation(Equation):                     # :137-159
+    def __init__(self, dest, sources):
+        super(SimpleEquation, self).__init__(dest, sources)
+        self.count = 0
+
+    def initialize(self, d_idx, d_u, d_au):
+        d_u[d_idx] = 0.0
+        d_au[d_idx] = 0.0
+
+    def loop(self, d_idx, d_au, s_idx, s_m):
+        d_au[d_idx] += s_m[s_idx]
+
+    def post_loop(self, d_idx, d_u, d_au):
+        d_u[d_idx] = d_au[d_idx]
+
+    def converged(self):
+        self.count += 1
+        result = self.count - 1
+        if result > 0:
+            self.count = 0
+        return result
+
+
+class SimpleReduction(Equation):                    # :174-181
+    def initialize(self, d_idx, d_au):
+        d_au[d_idx] = 0.0
+
+    def reduce(self, dst, t, dt):
+        dst.total_mass[0] = np.sum(dst.m)
+
+
+class PyInit(Equation):                             # :184-194
+    def py_initialize(self, dst, t, dt):
+        self.called_with = t, dt
+        dst.au[:] = 1.0
+
+    def initialize(self, d_idx, d_au):
+        d_au[d_idx] += 1.0
+
+
+class LoopAllEquation(Equation):                    # :197-218
+    def initialize(self, d_idx, d_rho):
+        d_rho[d_idx] = 0.0
+
+    def loop(self, d_idx, d_rho, s_m, s_idx, WIJ):
+        d_rho[d_idx] += s_m[s_idx] * WIJ
+
+    def loop_all(self, d_idx, d_x, d_rho, s_m, s_x, s_h, SPH_KERNEL, NBRS, N_NBRS):
+        i = declare('int')
+        s_idx = declare('long')
+        xij = declare('matrix((3,))')
+        rij = 0.0
+        sum = 0.0
+        xij[1] = 0.0
+        xij[2] = 0.0
+        for i in range(N_NBRS):
+            s_idx = NBRS[i]
+            xij[0] = d_x[d_idx] - s_x[s_idx]
+            rij = abs(xij[0])
+            sum += s_m[s_idx] * SPH_KERNEL.kernel(xij, rij, s_h[s_idx])
+        d_rho[d_idx] += sum
+
+
+class DumbEquation(Equation):                       # :221-232
+    def initialize(self, d_idx, d_au):
+        d_au[d_idx] += 1
+
+    def loop(self, d_idx, d_au):
+        d_au[d_idx] += 1
+
+    def post_loop(self, d_idx, d_au):
+        d_au[d_idx] += 1
+
+    def reduce(self, dst, t, dt):
+        dst.reduce_calls[0] = dst.reduce_calls[0] + 1
+
+
+class EqWithTime(Equation):                         # :668-673
+    def initialize(self, d_idx, d_au, t, dt):
+        d_au[d_idx] = t + dt
+
+    def loop(self, d_idx, d_au, s_idx, s_m, t, dt):
+        d_au[d_idx] += t + dt
+
+
+EXPECT = np.asarray([3., 4., 5., 5., 5., 5., 5., 5., 4., 3.])
+
+
+@pytest.fixture
+def pa():
+    from pysph_amd.particle_array import get_particle_array
+    n = 10
+    dx = 1.0 / (n - 1)
+    x = np.linspace(0, 1, n)
+    return get_particle_array(name='fluid', x=x, h=np.ones_like(x) * dx * 1.05,
+                              m=np.ones_like(x))
+
+
+def make_eval(pa, equations):
+    """_make_accel_eval (:305-316)"""
+    from pysph_amd import device as dev
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.kernels import CubicSpline
+    from pysph_amd.nnps import HipNNPS
+    kernel = CubicSpline(dim=1)
+    ctx = dev.HipContext(0)
+    a_eval = AccelerationEval(particle_arrays=[pa], equations=equations, kernel=kernel)
+    SPHCompiler(a_eval, integrator=None, ctx=ctx).compile()
+    nnps = HipNNPS(dim=1, particles=[pa], ctx=ctx)
+    nnps.update()
+    a_eval.set_nnps(nnps)
+    return a_eval
+
+
+def test_should_not_iterate_normal_group(pa):       # :331-342
+    a_eval = make_eval(pa, [SimpleEquation(dest='fluid', sources=['fluid'])])
+    a_eval.compute(0.1, 0.1)
+    assert list(pa.u) == list(EXPECT)
+
+
+def test_should_iterate_iterated_group(pa):         # :357-374
+    eqs = [Group(equations=[SimpleEquation(dest='fluid', sources=['fluid']),
+                            SimpleEquation(dest='fluid', sources=['fluid'])], iterate=True)]
+    a_eval = make_eval(pa, eqs)
+    a_eval.compute(0.1, 0.1)
+    assert list(pa.u) == list(EXPECT * 2)
+
+
+def test_should_iterate_nested_groups(pa):          # :376-396
+    eqs = [Group(equations=[Group(equations=[SimpleEquation(dest='fluid', sources=['fluid'])]),
+                            Group(equations=[SimpleEquation(dest='fluid', sources=['fluid'])])],
+                 iterate=True)]
+    a_eval = make_eval(pa, eqs)
+    a_eval.compute(0.1, 0.1)
+    assert list(pa.u) == list(EXPECT)
+
+
+def test_should_run_reduce(pa):                     # :398-410
+    pa.add_constant('total_mass', 0.0)
+    a_eval = make_eval(pa, [SimpleReduction(dest='fluid', sources=['fluid'])])
+    a_eval.compute(0.1, 0.1)
+    assert abs(pa.total_mass[0] - np.sum(pa.m)) < 1e-14
+
+
+def test_should_call_py_initialize(pa):             # :431-447
+    eq = PyInit(dest='fluid', sources=None)
+    a_eval = make_eval(pa, [eq])
+    a_eval.compute(1.0, 0.1)
+    np.testing.assert_array_almost_equal(pa.au, np.ones_like(pa.x) * 2.0)
+    assert eq.called_with == (1.0, 0.1)
+
+
+def test_should_support_loop_all_and_loop(pa):      # :462-479
+    a_eval = make_eval(pa, [SummationDensity(dest='fluid', sources=['fluid'])])
+    a_eval.compute(0.1, 0.1)
+    ref_rho = pa.rho.copy()
+    pa.rho[:] = 0.0
+    a_eval = make_eval(pa, [LoopAllEquation(dest='fluid', sources=['fluid'])])
+    a_eval.compute(0.1, 0.1)
+    # 2*ref_rho: both the loop and the loop_all are called
+    assert np.allclose(pa.rho, 2.0 * ref_rho, rtol=1e-13, atol=0)
+
+
+def test_should_call_pre_post_functions_in_group(pa):   # :506-531
+    def pre():
+        pa.m += 1.0
+
+    def post():
+        pa.u += 1.0
+    eqs = [Group(equations=[SimpleEquation(dest='fluid', sources=['fluid'])], pre=pre, post=post)]
+    a_eval = make_eval(pa, eqs)
+    a_eval.compute(0.1, 0.1)
+    assert list(pa.u) == [7., 9., 11., 11., 11., 11., 11., 11., 9., 7.]
+
+
+def test_should_honor_start_stop_idx_in_group(pa):  # :562-585
+    pa.u[:] = 1.0
+    pa.au[:] = 1.0
+    eqs = [Group(equations=[SimpleEquation(dest='fluid', sources=['fluid'])], start_idx=1, stop_idx=2)]
+    a_eval = make_eval(pa, eqs)
+    a_eval.compute(0.1, 0.1)
+    expect = np.ones_like(pa.u)
+    expect[1] = 4.0
+    assert list(pa.u) == list(expect) and list(pa.au) == list(expect)
+
+
+def test_should_honor_start_stop_idx_as_str_in_group(pa):   # :587-613
+    pa.add_constant('start', 1)
+    pa.add_constant('stop', 3)
+    pa.u[:] = 1.0
+    pa.au[:] = 1.0
+    eqs = [Group(equations=[SimpleEquation(dest='fluid', sources=['fluid'])],
+                 start_idx='start', stop_idx='stop')]
+    a_eval = make_eval(pa, eqs)
+    a_eval.compute(0.1, 0.1)
+    expect = np.ones_like(pa.u)
+    expect[1] = 4.0
+    expect[2] = 5.0
+    assert list(pa.u) == list(expect) and list(pa.au) == list(expect)
+
+
+def test_group_honors_condition(pa):                # :615-666
+    pa.add_constant('reduce_calls', 0)
+    pa.au[:] = 0.0
+    call_data = []
+
+    def cond(t, dt):
+        call_data.append((t, dt))
+        return False
+    eqs = [Group(equations=[DumbEquation(dest='fluid', sources=['fluid'])], condition=cond),
+           Group(equations=[Group(equations=[DumbEquation(dest='fluid', sources=['fluid'])],
+                                  condition=cond)]),
+           Group(equations=[DumbEquation(dest='fluid', sources=['fluid'])])]
+    a_eval = make_eval(pa, eqs)
+    a_eval.compute(0.0, 0.1)
+    expect = np.ones_like(pa.au) * 7
+    expect[0] = expect[-1] = 5
+    expect[1] = expect[-2] = 6
+    assert len(call_data) == 2 and call_data[0] == (0.0, 0.1) and call_data[1] == (0.0, 0.1)
+    assert list(pa.au) == list(expect)
+
+
+def test_equation_with_time(pa):                    # :766-779
+    a_eval = make_eval(pa, [EqWithTime(dest='fluid', sources=['fluid'])])
+    a_eval.compute(0.2, 0.1)
+    expect = np.asarray([4., 5., 6., 6., 6., 6., 6., 6., 5., 4.]) * 0.3
+    assert np.allclose(expect, pa.au)
+
+
+class SillyEquation(Equation):                      # :828-834
+    def loop(self, d_idx, d_au, s_idx, s_m):
+        d_au[d_idx] += s_m[s_idx]
+
+    def converged(self):
+        return 0
+
+
+def test_should_stop_iteration_with_max_iteration(pa):  # :825-854
+    eqs = [Group(equations=[Group(equations=[SillyEquation(dest='fluid', sources=['fluid'])]),
+                            Group(equations=[SillyEquation(dest='fluid', sources=['fluid'])])],
+                 iterate=True, max_iterations=2)]
+    a_eval = make_eval(pa, eqs)
+    a_eval.compute(0.1, 0.1)
+    # no initialize(): au keeps accumulating from memory, 2 groups x 2 iterations
+    assert list(pa.au) == list(EXPECT * 4.0)
+
+
+def test_update_nnps_group_flag(pa):                # :781-823, :1255-1318
+    """Group(update_nnps=True): the neighbour structure is rebuilt after the
+    group; here the first group moves nothing, the results must be unchanged and
+    the rebuild must have happened exactly once per such group."""
+    calls = []
+    eqs = [Group(equations=[SummationDensity(dest='fluid', sources=['fluid'])], update_nnps=True),
+           Group(equations=[EqWithTime(dest='fluid', sources=['fluid'])])]
+    a_eval = make_eval(pa, eqs)
+    nnps = a_eval.c_acceleration_eval.nnps
+    orig = nnps.update
+    nnps.update = lambda: (calls.append(1), orig())[1]
+    a_eval.compute(0.2, 0.1)
+    assert len(calls) == 1
+    assert np.allclose(pa.au, np.asarray([4., 5., 6., 6., 6., 6., 6., 6., 5., 4.]) * 0.3)
