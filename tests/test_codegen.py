@@ -113,7 +113,7 @@ def test_unsupported_constructs_fail_loudly(body, msg, tmp_path):
         sys.path.remove(str(tmp_path))
 
 
-def test_loop_all_and_missing_kernel_are_errors():
+def test_loop_all_families_and_missing_kernel():
     from pysph_amd.acceleration_eval import _CGroup
     from pysph_amd.codegen import CodegenError, GeneratedFamily
     from pysph_amd.equations import Equation, Group
@@ -135,9 +135,11 @@ def test_loop_all_and_missing_kernel_are_errors():
     fam = GeneratedFamily('fluid', [NeedsLists('fluid', ['fluid'])], arrays, 2, 'la')
     assert fam.loop_all and not fam.split_init and fam.sprops == ['m']
     assert 'S_m[((int)NBRS[i])]' in fam.source
-    with pytest.raises(CodegenError):     # loop and loop_all on one destination in one group
-        GeneratedFamily('fluid', [NeedsLists('fluid', ['fluid']), PairToo('fluid', ['fluid'])],
-                        arrays, 2, 'mix')
+    # loop and loop_all on one destination: loop_all launch, then the pair launch,
+    # initialize split off (mako :62-110 runs loop_all, then loop, per source)
+    mix = GeneratedFamily('fluid', [NeedsLists('fluid', ['fluid']), PairToo('fluid', ['fluid'])],
+                          arrays, 2, 'mix')
+    assert mix.loop_all and mix.also_pair and mix.split_init
     ids = {'fluid': 0, 'wall': 1}
     with pytest.raises(NotImplementedError):      # neither hand-written nor translatable
         _CGroup(Group([NoBody('fluid', ['fluid'])]), ids, arrays, 2)
