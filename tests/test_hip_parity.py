@@ -1334,3 +1334,22 @@ def test_sph_evaluator_known_answers():
     ev.evaluate()
     assert dest.rho[0] != rho0
     assert abs(dest.rho[0] - 7.0) < 0.5e-1
+
+
+def test_degenerate_h_gives_unit_cell_size(oracle):
+    """The reference's ten-particle fixture with h = 0 (test_nnps.py:26-115):
+    cell size falls back to 1.0, the grid scalars equal the oracle's, nobody
+    has neighbours (r2 < (k*0)^2 never holds)."""
+    from pysph_amd import device as dev
+    from pysph_amd.nnps import HipNNPS
+    from test_oracle_golden import _ten_particles
+    pa = _ten_particles()
+    ref = _ten_particles()
+    nnps = HipNNPS(3, [pa], radius_scale=1.0, ctx=dev.HipContext(0))
+    onn = oracle.OracleNNPS(3, [ref], radius_scale=1.0)
+    onn.update()
+    assert nnps.cell_size == 1.0 == onn.cell_size
+    assert np.array_equal(nnps.xmin, onn.xmin) and np.array_equal(nnps.xmax, onn.xmax)
+    assert np.array_equal(nnps.ncells_per_dim, onn.ncells_per_dim)
+    start, idx = nnps.get_csr(0, 0)
+    assert start[-1] == 0 and idx.size == 0

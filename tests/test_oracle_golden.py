@@ -112,3 +112,25 @@ def test_wendland_w0_analytic():
     from pysph_amd import kernels as K
     k = K.WendlandQuintic(dim=3)
     assert abs(float(k.kernel(rij=0.0, h=1.0)) - 21.0 / (16 * np.pi)) < 1e-15
+
+
+def _ten_particles():
+    """test_nnps.py:26-77 (SimpleNNPSTestCase): ten particles, degenerate h = 0."""
+    from pysph_amd.particle_array import get_particle_array
+    x = np.array([-1.5, 0.33, 1.25, 0.05, -0.5, -0.75, -1.25, 0.5, 0.5, 0.5])
+    y = np.array([0.25, -0.25, -1.25, 1.25, 0.5, 0.75, 0.5, 1.5, -0.5, 1.75])
+    z = np.array([0.5, 0.25, 1.25, -0.5, -1.25, -1.25, 0.5, -0.5, 0.5, -0.75])
+    return get_particle_array(name='a', x=x, y=y, z=z, h=np.zeros_like(x))
+
+
+def test_degenerate_h_gives_unit_cell_size(oracle):
+    """test_nnps.py:106-115 test_cell_size: h = 0 everywhere -> cell_size 1.0
+    (DomainManager._compute_cell_size_for_binning, nnps_base.pyx:971-977); with
+    unit cells and radius_scale 1 nobody has a neighbour but itself... and with
+    h = 0 not even that (r2 < 0 is false)."""
+    pa = _ten_particles()
+    nn = oracle.OracleNNPS(3, [pa], radius_scale=1.0)
+    nn.update()
+    assert nn.cell_size == 1.0
+    start, nbrs = nn.get_csr(0, 0)
+    assert start[-1] == 0
