@@ -34,6 +34,7 @@ then has to be hand-written or simplified; there is no silent fallback.
 """
 import ast
 import ctypes as C
+from collections import OrderedDict
 import hashlib
 import inspect
 import os
@@ -256,7 +257,31 @@ class _Body(object):
         fname = f.id if isinstance(f, ast.Name) else (
             f.attr if isinstance(f, ast.Attribute) and isinstance(f.value, ast.Name)
             and f.value.id in ('math', 'np', 'numpy', 'M') else None)
-        if fname is None or n.keywords:
+        if fname is None:
+            self.err(n, 'call %s' % ast.dump(f))
+        helper = None
+        if isinstance(f, ast.Name) and fname not in MATH_1 and fname not in MATH_2 \
+                and fname not in ('max', 'min', 'float', 'double'):
+            helper = self.fam.helper(self, n, fname)
+        if helper is not None:
+            # plain Python helper functions (Equation._get_helpers_,
+            # equation.py:860-872): scalar double arguments, one double result
+            vals = [self.expr(a) for a in n.args]
+            names = helper.argnames
+            if len(vals) > len(names):
+                self.err(n, '%s(): too many arguments' % fname)
+            slots = vals + [None] * (len(names) - len(vals))
+            for kw in n.keywords:
+                if kw.arg not in names or slots[names.index(kw.arg)] is not None:
+                    self.err(n, '%s(): keyword %s' % (fname, kw.arg))
+                slots[names.index(kw.arg)] = self.expr(kw.value)
+            for i, v in enumerate(slots):
+                if v is None:
+                    if helper.defaults[i] is None:
+                        self.err(n, '%s(): argument %s missing' % (fname, names[i]))
+                    slots[i] = helper.defaults[i]
+            return '%s(%s)' % (helper.cname, ', '.join(slots))
+        if n.keywords:
             self.err(n, 'call %s' % ast.dump(f))
         args = [self.expr(a) for a in n.args]
         if fname in MATH_1 and len(args) == 1:
@@ -460,6 +485,10 @@ class _Body(object):
         if isinstance(st, ast.Pass):
             return
         if isinstance(st, ast.Return):
+            if self.kind == 'helper':
+                self._emit(ind, 'return %s;' % (self.expr(st.value) if st.value is not None
+                                                else '0.0'))
+                return
             if st.value is not None:
                 self.err(st, 'return with a value')
             self._emit(ind, 'return;')
@@ -573,6 +602,57 @@ class _Body(object):
         return '\n'.join(out)
 
 
+class _HelperBody(_Body):
+    """A module-level Python function called from an equation/stepper body,
+    emitted as a ``__device__`` function of doubles."""
+
+    def __init__(self, fam, fn, name):
+        self.fam = fam
+        self.eq = None
+        self.k = -1
+        self.kind = 'helper'
+        self.pair = self.all_nbrs = False
+        try:
+            src = textwrap.dedent(inspect.getsource(fn))
+        except (OSError, TypeError) as e:
+            raise CodegenError('helper %s: source not available (%s)' % (name, e))
+        self.fdef = fdef = ast.parse(src).body[0]
+        self.fn = fn
+        self.where = 'helper %s' % name
+        self.cname = 'gen_helper_%s' % name
+        a = fdef.args
+        if a.vararg or a.kwarg or a.kwonlyargs:
+            raise CodegenError('helper %s: only plain scalar arguments' % name)
+        self.argnames = [x.arg for x in a.args]
+        self.defaults = [None] * (len(a.args) - len(a.defaults))
+        for d in a.defaults:
+            if not (isinstance(d, ast.Constant) and isinstance(d.value, (int, float))):
+                raise CodegenError('helper %s: default values must be numbers' % name)
+            self.defaults.append(repr(float(d.value)))
+        self.locals = dict((n_, ('arg', None)) for n_ in self.argnames)
+        self.loop_vars = set()
+        self.lines = []
+        self._emit_block(fdef.body, 1)
+        self.writes = set()
+
+    def _self_param(self, node, attr):
+        self.err(node, 'self is not available in a helper function')
+
+    def definition(self):
+        out = ['__device__ __forceinline__ double %s(%s)' % (
+            self.cname, ', '.join('double ' + n for n in self.argnames)), '{']
+        for name, (kind, n) in sorted(self.locals.items()):
+            if kind == 'array':
+                out.append('    double %s[%d] = {};' % (name, n))
+            elif kind == 'int':
+                out.append('    int %s = 0; (void)%s;' % (name, name))
+            elif kind != 'arg':
+                out.append('    double %s = 0.0;' % name)
+        out += self.lines
+        out += ['    return 0.0;', '}']
+        return '\n'.join(out)
+
+
 class GeneratedFamily(object):
     """All equations of one group acting on one destination, generated."""
 
@@ -603,6 +683,7 @@ class GeneratedFamily(object):
                     self.sources.append(s)
                     self.src_flags[s] = 0
                 self.src_flags[s] |= 1 << k
+        self.helpers = OrderedDict()    # name -> _HelperBody, in dependency order
         self.bodies = {m: [] for m in METHODS}
         self.nosrc_loops = []
         for k, eq in enumerate(self.equations):
@@ -676,6 +757,41 @@ class GeneratedFamily(object):
     def use_symbol(self, s):
         self.symbols.add(s)
 
+    def helper(self, body, node, fname):
+        """the Python function `fname` as seen from the calling body: listed by
+        the equation's/stepper's ``_get_helpers_()`` or a plain function in the
+        globals of the calling method"""
+        if fname in self.helpers:
+            return self.helpers[fname]
+        fn = None
+        owner = body.eq if body.eq is not None else None
+        cands = []
+        if owner is not None:
+            get = getattr(owner, '_get_helpers_', None)
+            if callable(get):
+                cands += list(get() or [])
+            for m in METHODS:
+                meth = getattr(type(owner), m, None)
+                if meth is not None and hasattr(meth, '__globals__'):
+                    g = meth.__globals__.get(fname)
+                    if g is not None:
+                        cands.append(g)
+        else:
+            g = body.fn.__globals__.get(fname)
+            if g is not None:
+                cands.append(g)
+        for c in cands:
+            if inspect.isfunction(c) and c.__name__ == fname:
+                fn = c
+                break
+        if fn is None:
+            return None
+        saved = getattr(self, '_writes', None)
+        h = _HelperBody(self, fn, fname)       # may pull in further helpers first
+        self._writes = saved
+        self.helpers[fname] = h
+        return h
+
     def raw_src_prop(self, prop):
         """loop_all: source properties are read from the arrays themselves
         (original order), x y z h included"""
@@ -746,6 +862,9 @@ class GeneratedFamily(object):
         A('    grad[0] = tmp * xij[0]; grad[1] = tmp * xij[1]; grad[2] = tmp * xij[2];')
         A('}')
         A('')
+        for h in self.helpers.values():
+            L.extend(h.definition().split('\n'))
+            A('')
         A('struct FamGen {')
         A('    static constexpr int MINB = SPHGEN_MINB;   // workgroups per CU, chosen at build time')
         A('    static constexpr int NA = %d;' % na)

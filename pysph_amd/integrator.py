@@ -51,12 +51,49 @@ _STEP_KINDS = {'WCSPHStep': STEP_WCSPH, 'TransportVelocityStep': STEP_TVF}
 
 
 def stepper_kind(step):
-    name = type(step).__name__
-    if name not in _STEP_KINDS:
-        raise NotImplementedError(
-            'HIP backend: stepper %s has no stage kernel (have %s)' %
-            (name, sorted(_STEP_KINDS)))
-    return _STEP_KINDS[name]
+    """C-ABI id of a hand-written stage kernel, or None: the stepper's own
+    ``initialize / stage1 / stage2 ...`` bodies are then translated like
+    no-source equations (pysph_amd/codegen.py) -- the reference compiles
+    user-defined steppers the same way it compiles equations
+    (integrator_cython_helper.py:24-120)."""
+    return _STEP_KINDS.get(type(step).__name__)
+
+
+STAGE_NAMES = ('initialize', 'stage1', 'stage2', 'stage3', 'stage4', 'stage5')
+
+
+class LeapFrogStep(IntegratorStep):
+    """integrator_step.py:708-730 (runs as a generated stepper)."""
+
+    def stage1(self, d_idx, d_x, d_y, d_z, d_u, d_v, d_w, d_ax, d_ay, d_az, dt):
+        d_x[d_idx] += 0.5 * dt * (d_u[d_idx] + d_ax[d_idx])
+        d_y[d_idx] += 0.5 * dt * (d_v[d_idx] + d_ay[d_idx])
+        d_z[d_idx] += 0.5 * dt * (d_w[d_idx] + d_az[d_idx])
+
+    def stage2(self, d_idx, d_x, d_y, d_z, d_u, d_au, d_v, d_av, d_w, d_aw, d_ax, d_ay,
+               d_az, d_rho, d_arho, d_e, d_ae, dt):
+        d_u[d_idx] += dt * d_au[d_idx]
+        d_v[d_idx] += dt * d_av[d_idx]
+        d_w[d_idx] += dt * d_aw[d_idx]
+        d_rho[d_idx] += dt * d_arho[d_idx]
+        d_e[d_idx] += dt * d_ae[d_idx]
+        d_x[d_idx] += 0.5 * dt * (d_u[d_idx] + d_ax[d_idx])
+        d_y[d_idx] += 0.5 * dt * (d_v[d_idx] + d_ay[d_idx])
+        d_z[d_idx] += 0.5 * dt * (d_w[d_idx] + d_az[d_idx])
+
+
+class EulerStep(IntegratorStep):
+    """integrator_step.py:22-35 (runs as a generated stepper)."""
+
+    def stage1(self, d_idx, d_u, d_v, d_w, d_au, d_av, d_aw, d_x, d_y, d_z, d_rho,
+               d_arho, dt):
+        d_u[d_idx] += dt * d_au[d_idx]
+        d_v[d_idx] += dt * d_av[d_idx]
+        d_w[d_idx] += dt * d_aw[d_idx]
+        d_x[d_idx] += dt * d_u[d_idx]
+        d_y[d_idx] += dt * d_v[d_idx]
+        d_z[d_idx] += dt * d_w[d_idx]
+        d_rho[d_idx] += dt * d_arho[d_idx]
 
 
 class Integrator(object):
@@ -117,11 +154,45 @@ class Integrator(object):
     def update_domain(self):
         self.nnps.update_domain()
 
+    def _reduce(self, pa, name, op):
+        """max/min of one property: on the device when the state is
+        device-resident (sync='manual') and the property is one the device
+        owns (h, or anything an equation writes); from the host array
+        otherwise (sync='auto', or a property only the user sets)."""
+        ev = getattr(self.acceleration_evals[0], 'c_acceleration_eval', None)
+        manual = getattr(ev, 'sync', 'auto') == 'manual'
+        written = set()
+        if ev is not None:
+            written = set(ev.outputs.get(pa.name, ())) | set(ev.outputs_exact.get(pa.name, ()))
+        if manual and pa.gpu is not None and dev.prop_id(name) >= 0 and \
+                (name == 'h' or name in written):
+            return pa.gpu.max(name) if op == 'max' else pa.gpu.min(name)
+        import numpy as np
+        from .particle_array import get_npy
+        arr = get_npy(pa, name)
+        return float(np.max(arr) if op == 'max' else np.min(arr))
+
+    def _get_explicit_dt_adapt(self):
+        """integrator.py:83-117: a user-specified ``dt_adapt`` property is the
+        allowed time step."""
+        arrays = [pa for pa in self.acceleration_evals[0].particle_arrays
+                  if 'dt_adapt' in pa.properties]
+        if not arrays:
+            return None
+        dt_min = float('inf')
+        for pa in arrays:
+            if pa.get_number_of_particles() > 0:
+                dt_min = min(dt_min, self._reduce(pa, 'dt_adapt', 'min'))
+        pm = self.parallel_manager
+        if pm is not None and hasattr(pm, 'reduce_min'):
+            dt_min = pm.reduce_min([dt_min])[0]
+        return dt_min if dt_min > 0.0 else None
+
     def compute_h_minimum(self):
         hmin = 1.0
         for pa in self.acceleration_evals[0].particle_arrays:
             if pa.get_number_of_particles(True):
-                hmin = min(hmin, pa.gpu.min('h'))
+                hmin = min(hmin, self._reduce(pa, 'h', 'min'))
         pm = self.parallel_manager
         if pm is not None and hasattr(pm, 'reduce_min'):
             hmin = pm.reduce_min([hmin])[0]        # parallel_manager.pyx:463
@@ -131,9 +202,8 @@ class Integrator(object):
         factors = [-1.0, -1.0, -1.0]
         for pa in self.acceleration_evals[0].particle_arrays:
             for i, name in enumerate(('dt_cfl', 'dt_force', 'dt_visc')):
-                if name in pa.properties and dev.prop_id(name) >= 0 and \
-                        pa.get_number_of_particles(True):
-                    factors[i] = max(factors[i], pa.gpu.max(name))
+                if name in pa.properties and pa.get_number_of_particles(True):
+                    factors[i] = max(factors[i], self._reduce(pa, name, 'max'))
         pm = self.parallel_manager
         if pm is not None and hasattr(pm, 'reduce_max'):
             factors = pm.reduce_max(factors)
@@ -141,6 +211,9 @@ class Integrator(object):
 
     def compute_time_step(self, dt, cfl):
         """integrator.py:161-200."""
+        dt_adapt = self._get_explicit_dt_adapt()
+        if dt_adapt is not None:
+            return dt_adapt
         cfl_f, force_f, visc_f = self._get_dt_adapt_factors()
         if not self.fixed_h or self.h_minimum is None:
             self.compute_h_minimum()
@@ -174,6 +247,121 @@ class PECIntegrator(Integrator):
     """integrator.py:300-358."""
 
 
+class LeapFrogIntegrator(PECIntegrator):
+    """integrator.py:464-477."""
+
+    def one_timestep(self, t, dt):
+        self.stage1()
+        self.update_domain()
+        self.do_post_stage(0.5 * dt, 1)
+        self.compute_accelerations()
+        self.stage2()
+        self.update_domain()
+        self.do_post_stage(dt, 2)
+
+
+class EulerIntegrator(Integrator):
+    """integrator.py:426-437."""
+
+    def one_timestep(self, t, dt):
+        self.compute_accelerations()
+        self.stage1()
+        self.update_domain()
+        self.do_post_stage(dt, 1)
+
+
+class PEFRLStep(IntegratorStep):
+    """Position-extended Forest-Ruth-like scheme of Omelyan, Mryglod & Folk,
+    Comput. Phys. Commun. 146 (2002) 188 (integrator_step.py:738-830): five
+    position sub-steps with weights (xi, chi, 1-2(xi+chi), chi, xi) and four
+    velocity sub-steps with weights ((1-2 lam)/2, lam, lam, (1-2 lam)/2).
+    Runs as a generated stepper."""
+
+    def stage1(self, d_idx, d_x, d_y, d_z, d_u, d_v, d_w, d_ax, d_ay, d_az, dt):
+        cx = 0.1786178958448091 * dt
+        d_x[d_idx] += cx * (d_u[d_idx] + d_ax[d_idx])
+        d_y[d_idx] += cx * (d_v[d_idx] + d_ay[d_idx])
+        d_z[d_idx] += cx * (d_w[d_idx] + d_az[d_idx])
+
+    def stage2(self, d_idx, d_x, d_y, d_z, d_u, d_au, d_v, d_av, d_w, d_aw, d_ax, d_ay,
+               d_az, d_rho, d_arho, d_e, d_ae, dt):
+        cv = 0.5 * (1.0 - 2.0 * (-0.2123418310626054)) * dt
+        cx = -0.06626458266981849 * dt
+        d_u[d_idx] += cv * d_au[d_idx]
+        d_v[d_idx] += cv * d_av[d_idx]
+        d_w[d_idx] += cv * d_aw[d_idx]
+        d_rho[d_idx] += cv * d_arho[d_idx]
+        d_e[d_idx] += cv * d_ae[d_idx]
+        d_x[d_idx] += cx * (d_u[d_idx] + d_ax[d_idx])
+        d_y[d_idx] += cx * (d_v[d_idx] + d_ay[d_idx])
+        d_z[d_idx] += cx * (d_w[d_idx] + d_az[d_idx])
+
+    def stage3(self, d_idx, d_x, d_y, d_z, d_u, d_au, d_v, d_av, d_w, d_aw, d_ax, d_ay,
+               d_az, d_rho, d_arho, d_e, d_ae, dt):
+        cv = -0.2123418310626054 * dt
+        cx = (1.0 - 2.0 * (0.1786178958448091 + (-0.06626458266981849))) * dt
+        d_u[d_idx] += cv * d_au[d_idx]
+        d_v[d_idx] += cv * d_av[d_idx]
+        d_w[d_idx] += cv * d_aw[d_idx]
+        d_rho[d_idx] += cv * d_arho[d_idx]
+        d_e[d_idx] += cv * d_ae[d_idx]
+        d_x[d_idx] += cx * (d_u[d_idx] + d_ax[d_idx])
+        d_y[d_idx] += cx * (d_v[d_idx] + d_ay[d_idx])
+        d_z[d_idx] += cx * (d_w[d_idx] + d_az[d_idx])
+
+    def stage4(self, d_idx, d_x, d_y, d_z, d_u, d_au, d_v, d_av, d_w, d_aw, d_ax, d_ay,
+               d_az, d_rho, d_arho, d_e, d_ae, dt):
+        cv = -0.2123418310626054 * dt
+        cx = -0.06626458266981849 * dt
+        d_u[d_idx] += cv * d_au[d_idx]
+        d_v[d_idx] += cv * d_av[d_idx]
+        d_w[d_idx] += cv * d_aw[d_idx]
+        d_rho[d_idx] += cv * d_arho[d_idx]
+        d_e[d_idx] += cv * d_ae[d_idx]
+        d_x[d_idx] += cx * (d_u[d_idx] + d_ax[d_idx])
+        d_y[d_idx] += cx * (d_v[d_idx] + d_ay[d_idx])
+        d_z[d_idx] += cx * (d_w[d_idx] + d_az[d_idx])
+
+    def stage5(self, d_idx, d_x, d_y, d_z, d_u, d_au, d_v, d_av, d_w, d_aw, d_ax, d_ay,
+               d_az, d_rho, d_arho, d_e, d_ae, dt):
+        cv = 0.5 * (1.0 - 2.0 * (-0.2123418310626054)) * dt
+        cx = 0.1786178958448091 * dt
+        d_u[d_idx] += cv * d_au[d_idx]
+        d_v[d_idx] += cv * d_av[d_idx]
+        d_w[d_idx] += cv * d_aw[d_idx]
+        d_rho[d_idx] += cv * d_arho[d_idx]
+        d_e[d_idx] += cv * d_ae[d_idx]
+        d_x[d_idx] += cx * (d_u[d_idx] + d_ax[d_idx])
+        d_y[d_idx] += cx * (d_v[d_idx] + d_ay[d_idx])
+        d_z[d_idx] += cx * (d_w[d_idx] + d_az[d_idx])
+
+
+class PEFRLIntegrator(Integrator):
+    """integrator.py:481-517: the stage times are the cumulative position
+    weights xi, xi+chi, 1-(xi+chi), 1-xi, 1."""
+
+    def one_timestep(self, t, dt):
+        self.stage1()
+        self.update_domain()
+        self.do_post_stage(0.1786178958448091 * dt, 1)
+        self.compute_accelerations()
+        self.stage2()
+        self.update_domain()
+        self.do_post_stage(0.1123533131749906 * dt, 2)
+        self.compute_accelerations()
+        self.stage3()
+        self.update_domain()
+        self.do_post_stage(0.8876466868250094 * dt, 3)
+        self.compute_accelerations()
+        self.stage4()
+        self.update_domain()
+        self.do_post_stage(0.8213821041551909 * dt, 4)
+        self.compute_accelerations()
+        self.stage5()
+        self.update_domain()
+        self.do_post_stage(dt, 5)
+
+
 class EPECIntegrator(Integrator):
     """integrator.py:367-420."""
 
@@ -189,6 +377,77 @@ class EPECIntegrator(Integrator):
         self.do_post_stage(dt, 2)
 
 
+def method_properties_of(fn):
+    """d_* array names in a stage method's signature"""
+    import inspect
+    return [a[2:] for a in inspect.signature(fn).parameters
+            if a.startswith('d_') and a != 'd_idx']
+
+
+def stage_family(stepper, method, pa, kernel_kind):
+    """One stage method of a user-defined stepper as a generated no-source
+    family: the body is per-particle code on d_* arrays, t and dt -- exactly a
+    no-source ``Equation.loop``."""
+    from .codegen import GeneratedFamily
+    from .equations import Equation
+    fn = getattr(type(stepper), method)
+    body = {'loop': fn}
+    if callable(getattr(type(stepper), '_get_helpers_', None)):
+        body['_get_helpers_'] = getattr(type(stepper), '_get_helpers_')
+    adapter_cls = type('%s_%s' % (type(stepper).__name__, method), (Equation,), body)
+    eq = adapter_cls(pa.name, None)
+    for k, v in stepper.__dict__.items():       # scalar parameters of the stepper
+        if not hasattr(eq, k):
+            setattr(eq, k, v)
+    missing = [p for p in method_properties_of(fn) if p not in pa.properties
+               and p not in getattr(pa, 'constants', {})]
+    if missing:
+        # sph_compiler.py / integrator_cython_helper.py:122-150 check_array_properties
+        raise RuntimeError('stepper %s.%s needs %s, which array %r lacks' % (
+            type(stepper).__name__, method, sorted(missing), pa.name))
+    return GeneratedFamily(pa.name, [eq], {pa.name: pa}, kernel_kind, name='step')
+
+
+def generated_stages(stepper, pa, array_id, kernel_kind):
+    """{stage name: _GeneratedStage} for every stage method the stepper defines"""
+    out = {}
+    for m in STAGE_NAMES:
+        if callable(getattr(type(stepper), m, None)):
+            out[m] = _GeneratedStage(stepper, m, pa, array_id, kernel_kind)
+    return out
+
+
+class _GeneratedStage(object):
+    """A built stage family and its ``sph_gen_family`` descriptor."""
+
+    def __init__(self, stepper, method, pa, array_id, kernel_kind):
+        import ctypes as C
+        self.fam = stage_family(stepper, method, pa, kernel_kind)
+        lib = self.fam.load()
+        cf = dev.SphGenFamily()
+        cf.launch = C.cast(lib.sphgen_launch, C.c_void_p).value
+        cf.dest = array_id
+        cf.nsrc = 0
+        cf.n_din = len(self.fam.din)
+        for k, p in enumerate(self.fam.din):
+            cf.din[k] = dev.prop_register(p)
+        cf.n_dout = len(self.fam.dout)
+        for k, p in enumerate(self.fam.dout):
+            cf.dout[k] = dev.prop_register(p)
+        cf.npar = len(self.fam.params)
+        cf.real = 1                                   # steppers act on real particles only
+        cf.start_idx, cf.stop_idx = 0, -1
+        self.cf = cf
+
+    def run(self, integ, t, dt):
+        import ctypes as C
+        for k, v in enumerate(self.fam.param_values()):
+            self.cf.par[k] = v
+        ev = integ.acceleration_eval
+        dev._check(integ.lib.sph_eval_generated(ev.ctx._h, C.addressof(ev.ckernel),
+                                                C.addressof(self.cf), t, dt))
+
+
 class HipIntegrator(object):
     """The ``c_integrator`` object (integrator_cython.mako:24-113)."""
 
@@ -202,8 +461,14 @@ class HipIntegrator(object):
         self._stages = []
         for name in sorted(integrator.steppers):
             helper = acceleration_eval_obj.helpers[name]
-            self._stages.append((helper.array_id,
-                                 stepper_kind(integrator.steppers[name])))
+            stepper = integrator.steppers[name]
+            pa = acceleration_eval_obj.arrays[name]
+            kind = stepper_kind(stepper)
+            gen = {}
+            if kind is None:
+                gen = generated_stages(stepper, pa, helper.array_id,
+                                       acceleration_eval_obj.ckernel.kind)
+            self._stages.append((helper, stepper, pa, kind, gen))
 
     def set_nnps(self, nnps):
         pass
@@ -226,9 +491,31 @@ class HipIntegrator(object):
             self._post_stage_callback(self.t, self.dt, stage)
 
     def _sweep(self, stage):
-        for aid, kind in self._stages:
-            dev._check(self.lib.sph_integrate_stage(self.ctx._h, aid, kind,
-                                                    stage, self.dt))
+        """One stage over every stepped array: the optional host hook
+        ``py_<stage>(dest, t, dt)`` first, then the per-particle stage
+        (integrator_cython.mako:87-113).  With the acceleration eval in
+        sync='auto' the host arrays are authoritative: they are pushed before
+        and pulled after the sweep (and around the hook)."""
+        name = STAGE_NAMES[stage]
+        auto = getattr(self.acceleration_eval, 'sync', 'manual') == 'auto'
+        for helper, stepper, pa, kind, gen in self._stages:
+            hook = getattr(stepper, 'py_' + name, None)
+            if hook is not None:
+                hook(pa, self.t, self.dt)
+            if kind is not None:
+                if auto:
+                    helper.push()
+                dev._check(self.lib.sph_integrate_stage(self.ctx._h, helper.array_id, kind,
+                                                        stage, self.dt))
+                if auto:
+                    helper.pull()
+            elif name in gen:
+                st = gen[name]
+                if auto:
+                    helper.push(*[p for p in st.fam.dprops if p in pa.properties])
+                st.run(self, self.t, self.dt)
+                if auto:
+                    helper.pull(*[p for p in st.fam.dout if p in pa.properties])
 
     def initialize(self):
         self._sweep(0)
@@ -238,6 +525,15 @@ class HipIntegrator(object):
 
     def stage2(self):
         self._sweep(2)
+
+    def stage3(self):
+        self._sweep(3)
+
+    def stage4(self):
+        self._sweep(4)
+
+    def stage5(self):
+        self._sweep(5)
 
     def step(self, t, dt):
         self.orig_t = self.t = t

@@ -1,0 +1,313 @@
+"""The scenarios of the reference's integrator tests
+(pysph/sph/tests/test_integrator.py) on the HIP backend: user-defined steppers
+translated to device code, ``py_stage*`` host hooks, helper functions, the
+leap-frog / PEFRL / Euler integrators on a harmonic oscillator and the
+adaptive-time-step rules."""
+import numpy as np
+import pytest
+
+from pysph_amd.equations import Equation
+from pysph_amd.integrator import (EulerIntegrator, IntegratorStep, LeapFrogIntegrator,
+                                  LeapFrogStep, PECIntegrator, PEFRLIntegrator, PEFRLStep)
+
+
+class SHM(Equation):
+    """simple harmonic oscillator (test_integrator.py:22-27)"""
+
+    def initialize(self, d_idx, d_x, d_au):
+        d_au[d_idx] = -d_x[d_idx]
+
+
+class EulerXStep(IntegratorStep):
+    def stage1(self, d_idx, d_x, d_u, dt):
+        d_x[d_idx] += dt * d_u[d_idx]
+
+
+class S1Step(IntegratorStep):
+    def py_stage1(self, dest, t, dt):
+        self.called_with1 = t, dt
+        dest.u[:] = 1.0
+
+    def stage1(self, d_idx, d_u, d_au, dt):
+        d_u[d_idx] += d_au[d_idx] * dt * 0.5
+
+    def stage2(self, d_idx, d_x, d_u, d_au, dt):
+        d_u[d_idx] += 0.5 * dt * d_au[d_idx]
+        d_x[d_idx] += dt * d_u[d_idx]
+
+
+class S12Step(IntegratorStep):
+    """explicit push/pull in the hooks, as the reference's GPU variant does"""
+
+    def py_stage1(self, dest, t, dt):
+        self.called_with1 = t, dt
+        dest.u[:] = 1.0
+        if dest.gpu:
+            dest.gpu.push('u')
+
+    def stage1(self, d_idx, d_u, d_au, dt):
+        d_u[d_idx] += d_au[d_idx] * dt * 0.5
+
+    def py_stage2(self, dest, t, dt):
+        self.called_with2 = t, dt
+        if dest.gpu:
+            dest.gpu.pull('u')
+        dest.u += 0.5
+        if dest.gpu:
+            dest.gpu.push('u')
+
+    def stage2(self, d_idx, d_x, d_u, d_au, dt):
+        d_u[d_idx] += 0.5 * dt * d_au[d_idx]
+        d_x[d_idx] += dt * d_u[d_idx]
+
+
+class OnlyPyStep(IntegratorStep):
+    def py_stage1(self, dest, t, dt):
+        self.called_with1 = t, dt
+        dest.x[:] = 0.0
+        dest.u[:] = 1.0
+
+    def py_stage2(self, dest, t, dt):
+        self.called_with2 = t, dt
+        dest.u += 0.5
+        dest.x += 0.5
+
+
+def twice(dt=0.0):
+    return dt * 2.0
+
+
+def scaled(a, fac=1.0):
+    tmp = twice(a)
+    if fac > 1.5:
+        return tmp * fac
+    return tmp
+
+
+class StepWithHelper(IntegratorStep):
+    def _get_helpers_(self):
+        return [twice]
+
+    def stage1(self, d_idx, d_u, d_au, dt):
+        d_u[d_idx] += d_au[d_idx] * twice(dt)
+
+
+class StepWithNestedHelper(IntegratorStep):
+    def stage1(self, d_idx, d_u, d_au, dt):
+        d_u[d_idx] += d_au[d_idx] * scaled(dt, fac=2.0)
+
+
+def make_pa(n=1):
+    from pysph_amd.particle_array import get_particle_array
+    x = np.asarray([1.0] + [0.0] * (n - 1))
+    pa = get_particle_array(name='fluid', x=x, u=np.zeros(n), h=np.ones(n), m=np.ones(n))
+    for prop in ('ax', 'ay', 'az', 'ae', 'arho', 'e'):
+        pa.add_property(prop)
+    return pa
+
+
+def setup(pa, integrator, sync='auto', extra=()):
+    from pysph_amd import device as dev
+    from pysph_amd import kernels as K
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.nnps import HipNNPS
+    kernel = K.CubicSpline(dim=1)
+    arrays = [pa] + list(extra)
+    a_eval = AccelerationEval(arrays, [SHM(dest='fluid', sources=None)], kernel)
+    ctx = dev.HipContext(0)
+    SPHCompiler(a_eval, integrator=integrator, ctx=ctx, sync=sync).compile()
+    if sync == 'manual':            # device-resident state: the caller moves the data
+        for a in arrays:
+            a.gpu.push()
+    nnps = HipNNPS(kernel.dim, arrays, radius_scale=kernel.radius_scale, ctx=ctx,
+                   sync=(sync == 'auto'))
+    a_eval.set_nnps(nnps)
+    integrator.set_nnps(nnps)
+    return ctx
+
+
+def integrate(integrator, dt, tf, callback):
+    t = 0.0
+    while t < tf:
+        integrator.step(t, dt)
+        callback(t + dt)
+        t += dt
+
+
+ALL_STEPPERS = (LeapFrogStep, PEFRLStep, EulerXStep, S1Step, S12Step, OnlyPyStep,
+                StepWithHelper, StepWithNestedHelper)
+
+
+def prebuild():
+    """every stage family of this file, built without a GPU (called by
+    tests/prebuild_generated.py)"""
+    from pysph_amd import kernels as K
+    from pysph_amd.integrator import generated_stages
+    n = 0
+    pa = make_pa()
+    for cls in ALL_STEPPERS:
+        n += len(generated_stages(cls(), pa, 0, K.kernel_id(K.CubicSpline(dim=1))))
+    return n
+
+
+# ---------------------------------------------------------------------------
+# CPU: translation only
+# ---------------------------------------------------------------------------
+def test_stepper_stage_translates_with_helpers():
+    from pysph_amd.integrator import stage_family
+    fam = stage_family(StepWithNestedHelper(), 'stage1', make_pa(), 1)
+    src = fam.source
+    # helpers are emitted before use, callee first; keyword and default
+    # arguments are resolved at the call site
+    assert src.index('gen_helper_twice(double dt)') < src.index('gen_helper_scaled(double a, double fac)')
+    assert 'gen_helper_scaled(dt, 2.0)' in src
+    assert fam.dout == ['u'] and fam.din == ['au']
+
+
+def test_missing_stepper_arrays_are_detected():
+    """test_integrator.py:31-72: RuntimeError naming what the array lacks"""
+    from pysph_amd.integrator import stage_family
+    from pysph_amd.particle_array import get_particle_array
+    pa = get_particle_array(name='fluid', x=np.ones(1), h=np.ones(1), m=np.ones(1))
+    with pytest.raises(RuntimeError) as e:
+        stage_family(LeapFrogStep(), 'stage1', pa, 1)
+    assert 'ax' in str(e.value)
+
+
+# ---------------------------------------------------------------------------
+# GPU
+# ---------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('sync', ['auto', 'manual'])
+def test_leapfrog_conserves_energy_and_is_second_order(sync):
+    """test_integrator.py:262-282, :362-398"""
+    pa = make_pa()
+    integrator = LeapFrogIntegrator(fluid=LeapFrogStep())
+    setup(pa, integrator, sync)
+    tf = np.pi
+    errs = []
+    for dt in (0.02 * tf, 0.01 * tf):
+        pa.x[0], pa.u[0] = 1.0, 0.0
+        if sync == 'manual':
+            pa.gpu.push()
+        energy = []
+
+        def callback(t):
+            if sync == 'manual':
+                pa.gpu.pull('x', 'u')
+            energy.append(0.5 * (pa.x[0] ** 2 + pa.u[0] ** 2))
+
+        callback(0.0)
+        integrate(integrator, dt, tf, callback)
+        errs.append(np.max(np.abs(np.asarray(energy) - 0.5)))
+    assert errs[0] < 5e-4
+    assert errs[1] < errs[0]
+    assert abs(errs[0] / errs[1] - 4.0) < 5e-3
+
+
+@pytest.mark.gpu
+def test_pefrl_is_fourth_order():
+    """test_integrator.py:419-472"""
+    pa = make_pa()
+    integrator = PEFRLIntegrator(fluid=PEFRLStep())
+    setup(pa, integrator)
+    tf = np.pi
+    errs = []
+    for dt in (0.1 * tf, 0.05 * tf):
+        pa.x[0], pa.u[0] = 1.0, 0.0
+        energy = [0.5]
+        integrate(integrator, dt, tf,
+                  lambda t: energy.append(0.5 * (pa.x[0] ** 2 + pa.u[0] ** 2)))
+        errs.append(np.max(np.abs(np.asarray(energy) - 0.5)))
+    assert errs[0] < 5e-5
+    assert errs[0] / errs[1] > 16.0
+
+
+@pytest.mark.gpu
+def test_integrator_calls_py_stage1():
+    """test_integrator.py:284-309"""
+    pa = make_pa()
+    stepper = S1Step()
+    integrator = LeapFrogIntegrator(fluid=stepper)
+    setup(pa, integrator)
+    calls = []
+    integrate(integrator, 1.0, 1.0, calls.append)
+    assert len(calls) == 1
+    assert stepper.called_with1 == (0.0, 1.0)
+    np.testing.assert_array_almost_equal(pa.x, [1.5])
+    np.testing.assert_array_almost_equal(pa.u, [0.5])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('sync', ['auto', 'manual'])
+def test_integrator_calls_py_stage1_stage2(sync):
+    """test_integrator.py:311-338 (manual sync: the hooks' own push/pull is
+    what moves the data, as with the reference's GPU backend)"""
+    pa = make_pa()
+    stepper = S12Step()
+    integrator = LeapFrogIntegrator(fluid=stepper)
+    setup(pa, integrator, sync)
+    if sync == 'manual':
+        pa.gpu.push()
+    integrate(integrator, 1.0, 1.0, lambda t: None)
+    if sync == 'manual':
+        pa.gpu.pull('x', 'u')
+    assert stepper.called_with1 == (0.0, 1.0)
+    assert stepper.called_with2 == (0.5, 1.0)
+    np.testing.assert_array_almost_equal(pa.x, [2.0])
+    np.testing.assert_array_almost_equal(pa.u, [1.0])
+
+
+@pytest.mark.gpu
+def test_integrator_calls_only_py_when_no_stage():
+    """test_integrator.py:340-360"""
+    pa = make_pa()
+    stepper = OnlyPyStep()
+    integrator = LeapFrogIntegrator(fluid=stepper)
+    setup(pa, integrator)
+    integrate(integrator, 1.0, 1.0, lambda t: None)
+    assert stepper.called_with1 == (0.0, 1.0)
+    assert stepper.called_with2 == (0.5, 1.0)
+    np.testing.assert_array_almost_equal(pa.x, [0.5])
+    np.testing.assert_array_almost_equal(pa.u, [1.5])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cls,fac', [(StepWithHelper, 2.0), (StepWithNestedHelper, 4.0)])
+def test_helper_can_be_used_with_stepper(cls, fac):
+    """test_integrator.py:400-417"""
+    pa = make_pa()
+    integrator = EulerIntegrator(fluid=cls())
+    setup(pa, integrator)
+    integrate(integrator, 0.5, 1.0, lambda t: None)
+    assert pa.u[0] == -fac * pa.x[0]
+
+
+@pytest.mark.gpu
+def test_compiling_detects_missing_arrays():
+    from pysph_amd.particle_array import get_particle_array, get_particle_array_wcsph
+    fluid = get_particle_array_wcsph(name='fluid', x=np.ones(1), h=np.ones(1), m=np.ones(1))
+    solid = get_particle_array(name='solid', x=np.ones(1), h=np.ones(1), m=np.ones(1))
+    integrator = PECIntegrator(fluid=LeapFrogStep(), solid=LeapFrogStep())
+    with pytest.raises(RuntimeError):
+        setup(fluid, integrator, extra=[solid])
+
+
+@pytest.mark.gpu
+def test_compute_time_step_rules():
+    """test_integrator.py:111-205: None without constraints, dt_adapt wins
+    over dt_cfl, invalid dt_adapt is ignored, cfl*h/dt_cfl otherwise"""
+    def run(**props):
+        pa = make_pa(2)
+        for k, v in props.items():
+            pa.add_property(k)
+            pa.properties[k][:] = v
+        integrator = EulerIntegrator(fluid=EulerXStep())
+        setup(pa, integrator)
+        return integrator.compute_time_step(0.1, 0.5)
+
+    assert run() is None
+    assert run(dt_adapt=[0.1, 0.2]) == 0.1
+    assert run(dt_adapt=[0.0, -2.0]) is None
+    assert run(dt_adapt=[0.1, 0.2], dt_cfl=[1.0, 1.0]) == 0.1
+    assert run(dt_cfl=[1.0, 2.0]) == 0.5 * 1.0 / 2.0
