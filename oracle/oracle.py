@@ -113,6 +113,12 @@ def lib():
             f.restype = C.c_long
             f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long,
                           C.POINTER(C.c_uint), C.c_long]
+        L.orc_flatten.restype = C.c_long
+        L.orc_flatten.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.orc_unflatten.restype = None
+        L.orc_unflatten.argtypes = [C.c_long, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
+        L.orc_valid_cell_index.restype = C.c_long
+        L.orc_valid_cell_index.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_long]
         L.orc_nnps_csr.restype = C.c_long
         L.orc_nnps_csr.argtypes = [C.c_void_p, C.c_int, C.c_int,
                                    C.POINTER(C.c_uint), C.POINTER(C.c_uint),
@@ -322,3 +328,24 @@ def eigen3(a):
     P = C.POINTER(C.c_double)
     lib().orc_eigen3(A.ctypes.data_as(P), V.ctypes.data_as(P), d.ctypes.data_as(P))
     return d, V.reshape(3, 3)
+
+
+def flatten(cid, ncells_per_dim):
+    """nnps_base.pyx:55-59 ``py_flatten``."""
+    nc = (C.c_int * 3)(*[int(v) for v in ncells_per_dim])
+    return int(lib().orc_flatten(int(cid[0]), int(cid[1]), int(cid[2]), nc))
+
+
+def unflatten(cell_index, ncells_per_dim, dim):
+    """nnps_base.pyx:97-101 ``py_unflatten``."""
+    nc = (C.c_int * 3)(*[int(v) for v in ncells_per_dim])
+    out = (C.c_int * 3)()
+    lib().orc_unflatten(int(cell_index), nc, int(dim), out)
+    return tuple(out)
+
+
+def get_valid_cell_index(cid, ncells_per_dim, n_cells):
+    """nnps_base.pyx:61-65 ``py_get_valid_cell_index``."""
+    nc = (C.c_int * 3)(*[int(v) for v in ncells_per_dim])
+    return int(lib().orc_valid_cell_index(int(cid[0]), int(cid[1]), int(cid[2]), nc,
+                                          int(n_cells)))

@@ -193,6 +193,37 @@ static inline long valid_cell_index(int cx, int cy, int cz, const int *nc, long 
     return cell_index;
 }
 
+/* exported for the tests that mirror test_nnps.py:1394-1467 */
+long orc_flatten(int cx, int cy, int cz, const int *nc)
+{
+    /* nnps_base.pxd:83-96 flatten_raw: row-major in x, then y, then z; `dim` unused */
+    return (long)(cx + (long)nc[0] * cy + (long)nc[0] * (long)nc[1] * cz);
+}
+
+void orc_unflatten(long cell_index, const int *nc, int dim, int *out3)
+{
+    /* nnps_base.pyx:70-95: integer division (cdivision), dim-aware */
+    int ncx = nc[0], ncy = nc[1];
+    int ix = 0, iy = 0, iz = 0;
+    if (dim > 1) {
+        if (dim > 2) {
+            int plane = ncx * ncy;
+            iz = (int)(cell_index / plane);
+            cell_index -= (long)iz * plane;
+        }
+        iy = (int)(cell_index / ncx);
+        ix = (int)(cell_index - (long)iy * ncx);
+    } else {
+        ix = (int)cell_index;
+    }
+    out3[0] = ix; out3[1] = iy; out3[2] = iz;
+}
+
+long orc_valid_cell_index(int cx, int cy, int cz, const int *nc, long n_cells)
+{
+    return valid_cell_index(cx, cy, cz, nc, n_cells);
+}
+
 int orc_nnps_update(orc_nnps *n)
 {
     /* DomainManager._compute_cell_size_for_binning  nnps_base.pyx:942-978 */

@@ -78,6 +78,9 @@ def main():
         n += plan([ps], [Group(equations=[cls('fluid', src)])], K.CubicSpline(dim=1))
     n += plan([ps], [Group(equations=[RS.SimpleEquation('fluid', ['fluid']),
                                       RS.SimpleEquation('fluid', ['fluid'])])], K.CubicSpline(dim=1))
+    import test_kernel_moments as KM
+    for kname, dim in sorted(KM.PLACES):
+        n += plan(list(KM.moment_arrays(2)), KM.moment_equations(), getattr(K, kname)(dim=dim))
     import test_reference_integrators as RI
     n += RI.prebuild()
     n += plan([RI.make_pa()], [RI.SHM(dest='fluid', sources=None)], K.CubicSpline(dim=1))

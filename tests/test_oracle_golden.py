@@ -134,3 +134,37 @@ def test_degenerate_h_gives_unit_cell_size(oracle):
     assert nn.cell_size == 1.0
     start, nbrs = nn.get_csr(0, 0)
     assert start[-1] == 0
+
+
+def test_flatten_unflatten_tables(oracle):
+    """test_nnps.py:1394-1428: a 4x5 grid (2-D) and a 4x5x2 grid (3-D); every
+    valid cell index survives flatten -> unflatten."""
+    nc = [4, 5, 0]
+    for i in range(4):
+        for j in range(5):
+            f = oracle.flatten((i, j, 0), nc)
+            assert f == i + 4 * j
+            assert oracle.unflatten(f, nc, 2) == (i, j, 0)
+    nc = [4, 5, 2]
+    seen = set()
+    for i in range(4):
+        for j in range(5):
+            for k in range(2):
+                f = oracle.flatten((i, j, k), nc)
+                seen.add(f)
+                assert oracle.unflatten(f, nc, 3) == (i, j, k)
+    assert seen == set(range(40))
+
+
+def test_1d_get_valid_cell_index(oracle):
+    """test_nnps.py:1431-1464: ten cells along x; off-axis shifts and
+    out-of-range x are invalid (-1)."""
+    n_cells, nc = 10, [10, 1, 1]
+    cx = 1
+    for i in (-1, 0, 1):
+        assert oracle.get_valid_cell_index((cx + i, 0, 0), nc, n_cells) != -1
+    for j in (-1, 1):
+        for k in (-1, 1):
+            assert oracle.get_valid_cell_index((cx, j, k), nc, n_cells) == -1
+    for i in (-2, -1, n_cells, n_cells + 1):
+        assert oracle.get_valid_cell_index((i, 0, 0), nc, n_cells) == -1
