@@ -275,6 +275,8 @@ typedef struct sph_gen_family {
     int split_init;              /* 1: run a mode-1 launch before packing    */
     int loop_all;                /* 1: the family has loop_all equations (mode 2 launch)   */
     int also_pair;               /* 1: ... and pair loops as well: mode 2 (no post_loop), then the pair launch */
+    int init_pair;               /* initialize_pair equations: 1 = mode-3 launch per source, then the loops;
+                                  * 2 = nothing else follows (the last mode-3 launch runs post_loop)      */
 } sph_gen_family;
 
 /* initialize -> no-source loops -> per-source pair loops -> post_loop of one

@@ -96,6 +96,14 @@ class PyEval(object):
             for sname in sources:
                 src = self.arrays[self.names.index(sname)]
                 seqs = [e for e in eqs if e.sources and sname in e.sources]
+                if any(getattr(type(e), 'initialize_pair', None) for e in seqs):
+                    pns = dict(ns)
+                    for k in list(src.properties) + list(src.constants):
+                        pns['s_' + k] = self._arr(src, k)
+                    for i in range(start, stop):
+                        pns['d_idx'] = i
+                        for e in seqs:
+                            self._call(e, 'initialize_pair', pns)
                 # loop_all first, then the pair loop (mako :62-110)
                 if any(getattr(type(e), 'loop_all', None) for e in seqs):
                     self._all_nbrs(dst, src, seqs, ns, start, stop)

@@ -245,6 +245,7 @@ class _GeneratedUnit(object):
         self.cf.split_init = 1 if f.split_init else 0
         self.cf.loop_all = 1 if f.loop_all else 0
         self.cf.also_pair = 1 if f.also_pair else 0
+        self.cf.init_pair = int(f.init_pair)
         owner.inputs[dest].update(f.dprops)
         owner.outputs_exact[dest].update(f.dout)    # exactly what the bodies write
         for sname in f.sources:

@@ -57,8 +57,8 @@ MATH_1 = {'sqrt': 'sqrt', 'exp': 'exp', 'log': 'log', 'sin': 'sin',
 MATH_2 = {'pow': 'pow', 'atan2': 'atan2', 'fmod': 'fmod'}
 CONSTANTS = {'M_PI': 'M_PI', 'pi': 'M_PI', 'M_1_PI': 'M_1_PI',
              'M_2_SQRTPI': 'M_2_SQRTPI', 'M_PI_2': 'M_PI_2', 'INFINITY': 'INFINITY'}
-METHODS = ('initialize', 'loop', 'loop_all', 'post_loop')
-UNSUPPORTED_METHODS = ('initialize_pair',)
+METHODS = ('initialize', 'initialize_pair', 'loop', 'loop_all', 'post_loop')
+UNSUPPORTED_METHODS = ()
 
 
 class CodegenError(Exception):
@@ -146,6 +146,8 @@ class _Body(object):
         self.kind = kind            # 'initialize' | 'loop' | 'post_loop'
         self.pair = kind == 'loop' and not fam.is_no_source(eq)
         self.all_nbrs = kind == 'loop_all'
+        # whole source arrays are visible (any index), not one packed neighbour
+        self.raw_src = kind in ('loop_all', 'initialize_pair')
         self.fdef = fdef
         self.locals = {}            # name -> ('double', None) | ('array', n) | ('int', None)
         self.loop_vars = set()
@@ -330,6 +332,8 @@ class _Body(object):
             return n.id
         if isinstance(n, ast.Name) and n.id == 'N_NBRS' and self.all_nbrs:
             return 'N_NBRS'
+        if isinstance(n, ast.Name) and n.id == 'd_idx' and self.raw_src:
+            return '((int)d_idx)'
         if isinstance(n, ast.Subscript) and isinstance(n.value, ast.Name) and n.value.id == 'NBRS' \
                 and self.all_nbrs:
             return self.subscript(n, store=False)           # s_m[NBRS[i]]
@@ -408,7 +412,7 @@ class _Body(object):
             if store:
                 self.err(n, 'NBRS is read-only')
             return '((int)NBRS[%s])' % self.index(sl)
-        if base.startswith('s_') and self.all_nbrs:
+        if base.startswith('s_') and self.raw_src:
             if store:
                 self.err(n, 'source arrays are read-only (gather formulation)')
             sk = self._strided_any(sl)
@@ -611,7 +615,7 @@ class _HelperBody(_Body):
         self.eq = None
         self.k = -1
         self.kind = 'helper'
-        self.pair = self.all_nbrs = False
+        self.pair = self.all_nbrs = self.raw_src = False
         try:
             src = textwrap.dedent(inspect.getsource(fn))
         except (OSError, TypeError) as e:
@@ -702,14 +706,20 @@ class GeneratedFamily(object):
         # the pair loop, per source): initialize gets its own launch, then the
         # loop_all launch (no post_loop), then the pair launch (with post_loop)
         self.also_pair = self.loop_all and bool(self.bodies['loop'])
+        # initialize_pair (mako :62-75): per source, before its loops, one sweep
+        # over the destinations with the source ARRAYS in view.  1: loops
+        # follow; 2: nothing else walks neighbours (post_loop ends the sweep)
+        self.init_pair = 0
+        if self.bodies['initialize_pair']:
+            self.init_pair = 1 if (self.loop_all or self.bodies['loop']) else 2
         # initialize()/no-source loops of ALL particles must be finished before a
         # loop reads what they wrote as a SOURCE property (mako :36-58): then
         # they run as a launch of their own, before the records are packed
         early = set()
         for b in self.bodies['initialize'] + self.nosrc_loops:
             early |= b.writes
-        self.split_init = self.also_pair or (bool(self.sources) and dest in self.sources and
-                                             bool(early & set(self.sprops)))
+        self.split_init = self.also_pair or bool(self.init_pair) or (
+            bool(self.sources) and dest in self.sources and bool(early & set(self.sprops)))
         if 'VIJ' in self.symbols:
             for p in 'uvw':
                 self.dest_prop(p, False)
@@ -952,8 +962,11 @@ class GeneratedFamily(object):
         A('    {')
         A('        const double *PAR = a.p.par; (void)PAR;')
         A('        const double t = a.t, dt = a.dt; (void)t; (void)dt;')
-        for b in self.bodies['post_loop']:
-            A(b.code(2))
+        if self.bodies['post_loop']:
+            A('        if (!a.skip_post) {   // an intermediate launch of a sequenced family: stores only')
+            for b in self.bodies['post_loop']:
+                A(b.code(3))
+            A('        }')
         A('        store(D, a, o);')
         A('    }')
         A('    template <class A> static __device__ __forceinline__ void store(Dest &D, const A &a, uint32_t o)')
@@ -974,6 +987,21 @@ class GeneratedFamily(object):
             for i, p in enumerate(self.sprops):
                 A('        const double *S_%s = a.p.sraw[j][%d]; (void)S_%s;' % (p, i, p))
         for b in self.bodies['loop_all']:
+            A('        if (fl & %du) {' % (1 << b.k))
+            A(b.code(3))
+            A('        }')
+        A('    }')
+        # ---- initialize_pair bodies of one source
+        A('    template <class A>')
+        A('    static __device__ __forceinline__ void init_pair(Dest &D, const A &a, int j, uint32_t d_idx)')
+        A('    {')
+        A('        const double *PAR = a.p.par; (void)PAR;')
+        A('        const double t = a.t, dt = a.dt; (void)t; (void)dt;')
+        A('        const uint32_t fl = a.src[j].flags; (void)fl;')
+        if self.init_pair:
+            for i, p in enumerate(self.sprops):
+                A('        const double *S_%s = a.p.sraw[j][%d]; (void)S_%s;' % (p, i, p))
+        for b in self.bodies['initialize_pair']:
             A('        if (fl & %du) {' % (1 << b.k))
             A(b.code(3))
             A('        }')
@@ -1022,8 +1050,18 @@ class GeneratedFamily(object):
         A('    FamGen::Dest D;')
         A('    FamGen::load(D, nullptr, a, (uint32_t)i);')
         A('    for (int j = 0; j < a.nsrc; j++) FamGen::all_nbrs<%d>(D, a, j, (uint32_t)i);' % self.kernel_kind)
-        A('    if (a.skip_post) FamGen::store(D, a, (uint32_t)i);')
-        A('    else FamGen::finish(D, a, (uint32_t)i);')
+        A('    FamGen::finish(D, a, (uint32_t)i);')
+        A('}')
+        A('')
+        A('// initialize_pair equations (mode 3): the sources whose flags are set, in order')
+        A('__global__ __launch_bounds__(256) void k_gen_init_pair(PairArgs<FamGen> a)')
+        A('{')
+        A('    const size_t i = (size_t)a.d_start + (size_t)blockIdx.x * 256 + threadIdx.x;')
+        A('    if (i >= a.d_stop) return;')
+        A('    FamGen::Dest D;')
+        A('    FamGen::load(D, nullptr, a, (uint32_t)i);')
+        A('    for (int j = 0; j < a.nsrc; j++) if (a.src[j].flags) FamGen::init_pair(D, a, j, (uint32_t)i);')
+        A('    FamGen::finish(D, a, (uint32_t)i);')
         A('}')
         A('')
         A('extern "C" int sphgen_kernel_kind(void) { return %d; }' % self.kernel_kind)
@@ -1062,6 +1100,8 @@ class GeneratedFamily(object):
         A('        hipLaunchKernelGGL(k_gen_init, lin, dim3(256), 0, st, a);')
         A('    } else if (g->mode == 2) {')
         A('        hipLaunchKernelGGL(k_gen_loop_all, lin, dim3(256), 0, st, a);')
+        A('    } else if (g->mode == 3) {')
+        A('        hipLaunchKernelGGL(k_gen_init_pair, lin, dim3(256), 0, st, a);')
         A('    } else if (g->nsrc == 0) {')
         A('        const size_t n = (size_t)g->d_stop - g->d_start;')
         A('        hipLaunchKernelGGL(k_gen_nosrc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);')

@@ -1435,106 +1435,142 @@ extern "C" int sph_eval_generated(sph_ctx *c, const sph_kernel *K, const sph_gen
         g.skip_init = 1;
     }
 
-    if (f->nsrc > 0 && f->loop_all) {
-        if (!c->nnps_valid) { sph_set_error("sph_eval_generated: neighbour grid is stale; call sph_nnps_update"); return SPH_ERR_STATE; }
-        for (int j = 0; j < f->nsrc; j++) {
-            int s = f->src[j];
-            if (s < 0 || s >= SPH_MAX_ARRAYS || !c->arr[s].used) { sph_set_error("bad source array %d", s); return SPH_ERR_ARG; }
-            size_t total = 0;
-            SPH_TRY(nnps_build_csr_device(c, s, dst, c->csr_start[j], c->csr_nbrs[j], &total));
-            g.csr_start[j] = c->csr_start[j].as<uint32_t>();
-            g.csr_nbrs[j] = c->csr_nbrs[j].as<uint32_t>();
-            g.src_flags[j] = f->src_flags[j];
-            g.dflags |= f->src_flags[j];
-            for (int k = 0; k < f->n_sprops; k++) {
-                const double *p = c->arr[s].prop[f->sprops[k]];
-                if (!p && c->arr[s].n) return need_prop(c, s, f->sprops[k], "generated loop_all");
-                g.sraw[j][k] = p;
+    // The per-source part of the loop nest.  `only` < 0: every source in one fused pass (the
+    // normal case); otherwise just source `only` (families with initialize_pair and several
+    // sources, which the reference sequences source by source: mako :62-110).
+    auto loops = [&](int only, bool last) -> int {
+        int idx[SPH_MAX_ARRAYS], ns = 0;
+        for (int j = 0; j < f->nsrc; j++) if (only < 0 || only == j) idx[ns++] = j;
+        sph_gen_args q = g;
+        q.nsrc = ns;
+        q.dflags = 0;
+        if (ns > 0 && f->loop_all) {
+            if (!c->nnps_valid) { sph_set_error("sph_eval_generated: neighbour grid is stale; call sph_nnps_update"); return SPH_ERR_STATE; }
+            for (int jj = 0; jj < ns; jj++) {
+                const int j = idx[jj], s = f->src[j];
+                size_t total = 0;
+                SPH_TRY(nnps_build_csr_device(c, s, dst, c->csr_start[jj], c->csr_nbrs[jj], &total));
+                q.csr_start[jj] = c->csr_start[jj].as<uint32_t>();
+                q.csr_nbrs[jj] = c->csr_nbrs[jj].as<uint32_t>();
+                q.src_flags[jj] = f->src_flags[j];
+                q.dflags |= f->src_flags[j];
+                for (int k = 0; k < f->n_sprops; k++) {
+                    const double *p = c->arr[s].prop[f->sprops[k]];
+                    if (!p && c->arr[s].n) return need_prop(c, s, f->sprops[k], "generated loop_all");
+                    q.sraw[jj][k] = p;
+                }
             }
+            q.mode = 2;
+            q.radius_scale = c->radius_scale;
+            q.skip_post = (f->also_pair || !last) ? 1 : 0;
+            {
+                ScopedTimer tm(c, T_PAIR);
+                int rc = f->launch(&q);
+                if (rc != 0) { sph_set_error("generated loop_all launch failed (code %d)", rc); return SPH_ERR_HIP; }
+            }
+            if (!f->also_pair) return SPH_OK;
+            // the same family's pair loops follow (mako :62-110: loop_all, then loop, per source);
+            // initialize has run (split launch), post_loop runs at the end of the pair launch
+            q.mode = 0;
+            q.skip_init = 1;
+            q.dflags = 0;
         }
-        g.mode = 2;
-        g.radius_scale = c->radius_scale;
-        g.skip_post = f->also_pair ? 1 : 0;
-        {
-            ScopedTimer tm(c, T_PAIR);
-            int rc = f->launch(&g);
-            if (rc != 0) { sph_set_error("generated loop_all launch failed (code %d)", rc); return SPH_ERR_HIP; }
-        }
-        if (!f->also_pair) return SPH_OK;
-        // the same family's pair loops follow (mako :62-110: loop_all, then loop, per source);
-        // initialize has run (split launch), post_loop runs at the end of the pair launch
-        g.mode = 0;
-        g.skip_post = 0;
-        g.skip_init = 1;
-        g.dflags = 0;
-    }
+        q.skip_post = last ? 0 : 1;
 
-    if (f->nsrc > 0) {
-        if (!c->nnps_valid) { sph_set_error("sph_eval_generated: neighbour grid is stale; call sph_nnps_update"); return SPH_ERR_STATE; }
-        if (D.nnps_slot < 0) { sph_set_error("destination array %d is not part of the neighbour grid", dst); return SPH_ERR_STATE; }
-        size_t total = 0, off_of[SPH_MAX_ARRAYS];
-        bool dest_is_src = false;
-        for (int j = 0; j < f->nsrc; j++) {
-            int s = f->src[j];
-            if (s < 0 || s >= SPH_MAX_ARRAYS || !c->arr[s].used) { sph_set_error("bad source array %d", s); return SPH_ERR_ARG; }
-            if (c->arr[s].nnps_slot < 0) { sph_set_error("source array %d is not part of the neighbour grid", s); return SPH_ERR_STATE; }
-            for (int i = 0; i < j; i++) if (f->src[i] == s) { sph_set_error("source array %d listed twice", s); return SPH_ERR_ARG; }
-            off_of[j] = total; total += c->arr[s].n; dest_is_src |= s == dst;
-        }
-        size_t d_off = total;
-        if (!dest_is_src) total += D.n;
-        else for (int j = 0; j < f->nsrc; j++) if (f->src[j] == dst) d_off = off_of[j];
-        if (total >= (1ull << 32)) { sph_set_error("too many particles for 32-bit packed indices"); return SPH_ERR_ARG; }
-        const int na = f->n_sprops;
-        // whole 16-byte pieces; under uniform h the records drop h: [x y z | aux...]
-        const bool compact = g.uniform_h != 0;
-        const int na_fam = ((na + 1) & ~1) < 2 ? 2 : ((na + 1) & ~1); // FamGen::NA
-        const int nr = c->record_f32 ? ((4 + na_fam + 3) & ~3) /* floats */
-                     : compact ? ((3 + na + 1) & ~1) : 4 + ((na + 1) & ~1);
-        const int layout = c->record_f32 ? 5 : (compact ? 4 : 0);
-        g.rec_f32 = c->record_f32 ? 1 : 0;
-        SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * nr));
-        SPH_TRY(c->aux.reserve(64));
-        SPH_TRY(c->fposb.reserve((total + 64) * sizeof(float4)));
-        {
-            ScopedTimer tm(c, T_PACK);
-            for (int j = 0; j < f->nsrc; j++) SPH_TRY(pack_generic(c, f->src[j], off_of[j], na, f->sprops, nr, layout));
-            if (!dest_is_src) {
-                // the destination only needs its position record; properties it lacks are not read
-                int have[SPH_GEN_MAX_SPROPS], nh = 0;
-                for (int k = 0; k < na; k++) if (D.prop[f->sprops[k]]) have[nh++] = f->sprops[k];
-                SPH_TRY(pack_generic(c, dst, d_off, nh == na ? na : 0, f->sprops, nr, layout));
+        if (ns > 0) {
+            if (!c->nnps_valid) { sph_set_error("sph_eval_generated: neighbour grid is stale; call sph_nnps_update"); return SPH_ERR_STATE; }
+            if (D.nnps_slot < 0) { sph_set_error("destination array %d is not part of the neighbour grid", dst); return SPH_ERR_STATE; }
+            size_t total = 0, off_of[SPH_MAX_ARRAYS];
+            bool dest_is_src = false;
+            for (int jj = 0; jj < ns; jj++) {
+                const int s = f->src[idx[jj]];
+                if (c->arr[s].nnps_slot < 0) { sph_set_error("source array %d is not part of the neighbour grid", s); return SPH_ERR_STATE; }
+                off_of[jj] = total; total += c->arr[s].n; dest_is_src |= s == dst;
             }
+            size_t d_off = total;
+            if (!dest_is_src) total += D.n;
+            else for (int jj = 0; jj < ns; jj++) if (f->src[idx[jj]] == dst) d_off = off_of[jj];
+            if (total >= (1ull << 32)) { sph_set_error("too many particles for 32-bit packed indices"); return SPH_ERR_ARG; }
+            const int na = f->n_sprops;
+            // whole 16-byte pieces; under uniform h the records drop h: [x y z | aux...]
+            const bool compact = q.uniform_h != 0;
+            const int na_fam = ((na + 1) & ~1) < 2 ? 2 : ((na + 1) & ~1); // FamGen::NA
+            const int nr = c->record_f32 ? ((4 + na_fam + 3) & ~3) /* floats */
+                         : compact ? ((3 + na + 1) & ~1) : 4 + ((na + 1) & ~1);
+            const int layout = c->record_f32 ? 5 : (compact ? 4 : 0);
+            q.rec_f32 = c->record_f32 ? 1 : 0;
+            SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * nr));
+            SPH_TRY(c->aux.reserve(64));
+            SPH_TRY(c->fposb.reserve((total + 64) * sizeof(float4)));
+            {
+                ScopedTimer tm(c, T_PACK);
+                for (int jj = 0; jj < ns; jj++) SPH_TRY(pack_generic(c, f->src[idx[jj]], off_of[jj], na, f->sprops, nr, layout));
+                if (!dest_is_src) {
+                    // the destination only needs its position record; properties it lacks are not read
+                    int have[SPH_GEN_MAX_SPROPS], nh = 0;
+                    for (int k = 0; k < na; k++) if (D.prop[f->sprops[k]]) have[nh++] = f->sprops[k];
+                    SPH_TRY(pack_generic(c, dst, d_off, nh == na ? na : 0, f->sprops, nr, layout));
+                }
+            }
+            q.rec = c->posh.as<double>();
+            q.nrec = nr;
+            q.fpos = c->fposb.as<float4>();
+            q.dom_extent = fmax(fmax(c->xmax[0] - c->xmin[0], c->xmax[1] - c->xmin[1]), c->xmax[2] - c->xmin[2]);
+            for (int k = 0; k < 3; k++) { q.nc[k] = c->nc[k]; q.xmin[k] = c->xmin[k]; }
+            q.cell_size = c->cell_size;
+            q.radius_scale = c->radius_scale;
+            q.hu = 0.5 * (c->h_uniform + c->h_uniform);
+            q.h1u = 1.0 / q.hu;
+            q.facu = K->fac * q.h1u;
+            if (K->dim > 1) q.facu *= q.h1u;
+            if (K->dim > 2) q.facu *= q.h1u;
+            q.epsu = 0.01 * q.hu * q.hu;
+            q.hr2u = (c->radius_scale * c->h_uniform) * (c->radius_scale * c->h_uniform);
+            for (int jj = 0; jj < ns; jj++) {
+                const int j = idx[jj];
+                q.src_cell_start[jj] = c->arr[f->src[j]].cell_start.as<uint32_t>();
+                q.src_off[jj] = (uint32_t)off_of[jj];
+                q.src_flags[jj] = f->src_flags[j];
+                q.dflags |= f->src_flags[j];
+            }
+            q.d_off = (uint32_t)d_off;
+            q.d_keys = D.keys_sorted.as<uint32_t>();
+            q.d_perm = D.perm.as<uint32_t>();
+            q.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
         }
-        g.rec = c->posh.as<double>();
-        g.nrec = nr;
-        g.fpos = c->fposb.as<float4>();
-        g.dom_extent = fmax(fmax(c->xmax[0] - c->xmin[0], c->xmax[1] - c->xmin[1]), c->xmax[2] - c->xmin[2]);
-        for (int k = 0; k < 3; k++) { g.nc[k] = c->nc[k]; g.xmin[k] = c->xmin[k]; }
-        g.cell_size = c->cell_size;
-        g.radius_scale = c->radius_scale;
-        g.hu = 0.5 * (c->h_uniform + c->h_uniform);
-        g.h1u = 1.0 / g.hu;
-        g.facu = K->fac * g.h1u;
-        if (K->dim > 1) g.facu *= g.h1u;
-        if (K->dim > 2) g.facu *= g.h1u;
-        g.epsu = 0.01 * g.hu * g.hu;
-        g.hr2u = (c->radius_scale * c->h_uniform) * (c->radius_scale * c->h_uniform);
-        for (int j = 0; j < f->nsrc; j++) {
-            g.src_cell_start[j] = c->arr[f->src[j]].cell_start.as<uint32_t>();
-            g.src_off[j] = (uint32_t)off_of[j];
-            g.src_flags[j] = f->src_flags[j];
-            g.dflags |= f->src_flags[j];
-        }
-        g.d_off = (uint32_t)d_off;
-        g.d_keys = D.keys_sorted.as<uint32_t>();
-        g.d_perm = D.perm.as<uint32_t>();
-        g.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
+        ScopedTimer tm(c, ns > 0 ? T_PAIR : T_EOS);
+        int rc = f->launch(&q);
+        if (rc != 0) { sph_set_error("generated family launch failed (code %d)", rc); return SPH_ERR_HIP; }
+        return SPH_OK;
+    };
+
+    for (int j = 0; j < f->nsrc; j++) {
+        const int s = f->src[j];
+        if (s < 0 || s >= SPH_MAX_ARRAYS || !c->arr[s].used) { sph_set_error("bad source array %d", s); return SPH_ERR_ARG; }
+        for (int i = 0; i < j; i++) if (f->src[i] == s) { sph_set_error("source array %d listed twice", s); return SPH_ERR_ARG; }
     }
-    ScopedTimer tm(c, f->nsrc > 0 ? T_PAIR : T_EOS);
-    int rc = f->launch(&g);
-    if (rc != 0) { sph_set_error("generated family launch failed (code %d)", rc); return SPH_ERR_HIP; }
-    return SPH_OK;
+    if (f->nsrc > 0 && f->init_pair) {
+        // initialize_pair (mako :62-75): per source, before that source's loops, one sweep over
+        // the destinations with the source's ARRAYS in view (mode 3; initialize ran as a split launch)
+        g.skip_init = 1;
+        for (int j = 0; j < f->nsrc; j++) {
+            sph_gen_args gp = g;
+            gp.mode = 3;
+            gp.nsrc = 1;
+            gp.src_flags[0] = f->src_flags[j];
+            for (int k = 0; k < f->n_sprops; k++) gp.sraw[0][k] = c->arr[f->src[j]].prop[f->sprops[k]];
+            const bool last = j == f->nsrc - 1;
+            gp.skip_post = (f->init_pair == 2 && last) ? 0 : 1;
+            {
+                ScopedTimer tm(c, T_EOS);
+                int rc = f->launch(&gp);
+                if (rc != 0) { sph_set_error("generated initialize_pair launch failed (code %d)", rc); return SPH_ERR_HIP; }
+            }
+            if (f->init_pair == 1) SPH_TRY(loops(j, last));
+        }
+        return SPH_OK;
+    }
+    return loops(-1, true);
 }
 
 // ---------------------------------------------------------------------------

@@ -167,7 +167,8 @@ class SphGenFamily(C.Structure):
                 ('npar', C.c_int), ('par', C.c_double * GEN_MAX_PAR),
                 ('real', C.c_int), ('start_idx', C.c_long),
                 ('stop_idx', C.c_long), ('split_init', C.c_int),
-                ('loop_all', C.c_int), ('also_pair', C.c_int)]
+                ('loop_all', C.c_int), ('also_pair', C.c_int),
+                ('init_pair', C.c_int)]
 
 
 class HipContext(object):

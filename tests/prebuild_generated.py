@@ -78,6 +78,8 @@ def main():
         n += plan([ps], [Group(equations=[cls('fluid', src)])], K.CubicSpline(dim=1))
     n += plan([ps], [Group(equations=[RS.SimpleEquation('fluid', ['fluid']),
                                       RS.SimpleEquation('fluid', ['fluid'])])], K.CubicSpline(dim=1))
+    n += plan([ps], [Group(equations=[RS.InitializePair('fluid', ['fluid'])])], K.CubicSpline(dim=1))
+    n += plan(RS.ghost_copy_arrays(), RS.ghost_copy_equations(), K.CubicSpline(dim=1))
     import test_kernel_moments as KM
     for kname, dim in sorted(KM.PLACES):
         n += plan(list(KM.moment_arrays(2)), KM.moment_equations(), getattr(K, kname)(dim=dim))

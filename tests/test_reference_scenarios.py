@@ -277,3 +277,78 @@ def test_update_nnps_group_flag(pa):                # :781-823, :1255-1318
     a_eval.compute(0.2, 0.1)
     assert len(calls) == 1
     assert np.allclose(pa.au, np.asarray([4., 5., 6., 6., 6., 6., 6., 6., 5., 4.]) * 0.3)
+
+
+class InitializePair(Equation):                     # :235-239
+    def initialize_pair(self, d_idx, d_u, s_u):
+        # only meaningful when source and destination have equally many particles
+        d_u[d_idx] = s_u[d_idx] * 1.5
+
+
+class GhostCopyThenSum(Equation):
+    """the bc/interpolate.py Copy*FromGhost pattern (:126-133, :253-260)
+    followed by a pair loop on the same destination: u is mirrored from the
+    array standing behind this one, then summed over the neighbours."""
+
+    def initialize(self, d_idx, d_au):
+        d_au[d_idx] = 0.0
+
+    def initialize_pair(self, d_idx, d_u, s_u, d_v, s_v):
+        d_u[d_idx] = -1.0 * s_u[d_idx]
+        d_v[d_idx] += s_v[d_idx]
+
+    def loop(self, d_idx, s_idx, d_au, d_u, s_m, WIJ):
+        d_au[d_idx] += d_u[d_idx] * s_m[s_idx] * WIJ
+
+    def post_loop(self, d_idx, d_au, d_v):
+        d_au[d_idx] += d_v[d_idx]
+
+
+def test_should_call_initialize_pair(pa):           # :412-429, :939-956
+    pa.u[:] = 1.0
+    a_eval = make_eval(pa, [InitializePair(dest='fluid', sources=['fluid'])])
+    a_eval.compute(0.0, 0.1)
+    np.testing.assert_array_almost_equal(pa.u, np.ones_like(pa.x) * 1.5)
+
+
+def ghost_copy_arrays():
+    from pysph_amd.particle_array import get_particle_array
+    n = 10
+    x = np.linspace(0, 1, n)
+    h = np.ones_like(x) * 1.05 / (n - 1)
+    rng = np.random.default_rng(5)
+    arrays = []
+    for name, shift in (('fluid', 0.0), ('ghost', 0.03), ('mirror', -0.02)):
+        arrays.append(get_particle_array(name=name, x=x + shift, h=h, m=np.ones_like(x),
+                                         u=rng.uniform(-1, 1, n), v=rng.uniform(-1, 1, n),
+                                         rho=np.ones_like(x)))
+    return arrays
+
+
+def ghost_copy_equations():
+    return [Group(equations=[GhostCopyThenSum(dest='fluid', sources=['ghost', 'mirror'])])]
+
+
+def test_initialize_pair_two_sources_then_loop_vs_python_evaluator():
+    from oracle import oracle as orc
+    from oracle.py_eval import PyEval
+    from pysph_amd import device as dev
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.kernels import CubicSpline
+    from pysph_amd.nnps import HipNNPS
+    kernel = CubicSpline(dim=1)
+    arrays, ref = ghost_copy_arrays(), ghost_copy_arrays()
+    ctx = dev.HipContext(0)
+    a_eval = AccelerationEval(arrays, ghost_copy_equations(), kernel)
+    SPHCompiler(a_eval, ctx=ctx).compile()
+    nnps = HipNNPS(dim=1, particles=arrays, ctx=ctx)
+    a_eval.set_nnps(nnps)
+    a_eval.compute(0.0, 0.1)
+    onn = orc.OracleNNPS(1, ref, radius_scale=kernel.radius_scale)
+    onn.update()
+    PyEval(ref, ghost_copy_equations(), kernel, onn).compute(0.0, 0.1)
+    for prop in ('u', 'v', 'au'):
+        assert np.allclose(arrays[0].properties[prop], ref[0].properties[prop],
+                           rtol=1e-13, atol=1e-15), prop
+    # v accumulated BOTH sources' values, u holds the last source's mirror image
+    assert np.allclose(arrays[0].u, -ref[2].u)
