@@ -71,6 +71,18 @@ class DeviceHaloOps(object):
         return self.torch.tensor(values, dtype=self.torch.int64,
                                  device=self.device)
 
+    # -- ordering between this context's HIP stream and the transport -------
+    # The pack/append kernels run on the context's own stream; RCCL orders its
+    # work after (and `work.wait()` orders it before) torch's CURRENT stream
+    # only, which knows nothing about that stream.  Two host-side syncs per
+    # exchange (a few tens of microseconds against a multi-millisecond step).
+    def before_comm(self):
+        self.ctx.synchronize()          # payloads are complete before they are sent
+
+    def after_comm(self):
+        # the receives are complete before the append kernels read them
+        self.torch.cuda.current_stream(self.device).synchronize()
+
     def pack(self, side, count, shift):
         buf = self.new_buffer(count)
         dev._check(self.lib.sph_halo_pack(
@@ -169,6 +181,9 @@ class SlabHalo(object):
         send/recv with the <=2 neighbours; returns ({side: recv buffer},
         {side: recv count})"""
         ops, dist = self.ops, self.dist
+        sync = getattr(ops, 'before_comm', None)
+        if sync is not None:
+            sync()
         mine = ops.int_tensor([send_cnt[0], send_cnt[1]])
         allc = ops.int_tensor([0] * (2 * self.world))
         dist.all_gather_into_tensor(allc, mine)
@@ -190,6 +205,9 @@ class SlabHalo(object):
         if reqs:
             for w in dist.batch_isend_irecv(reqs):
                 w.wait()
+        sync = getattr(ops, 'after_comm', None)
+        if sync is not None:
+            sync()
         return in_buf, recv_cnt
 
     def exchange(self):
