@@ -53,7 +53,7 @@ enum sph_prop {
      * reference's ParticleArray.add_property for equation-specific arrays,
      * e.g. uf, ug, wij of the TVF wall equations)                           */
     SPH_USER0,
-    SPH_PROP_COUNT = SPH_USER0 + 48
+    SPH_PROP_COUNT = SPH_USER0 + 96
 };
 
 /* pysph/base/kernels.py class -> id */
@@ -209,7 +209,7 @@ int sph_eval_group(sph_ctx *ctx, const sph_kernel *kernel, const sph_group *grou
  * user slot, or a new user slot (process-wide table; <0: table full).       */
 int sph_prop_register(const char *name);
 
-#define SPH_GEN_MAX_PROPS 32
+#define SPH_GEN_MAX_PROPS 48
 #define SPH_GEN_MAX_SPROPS 20
 #define SPH_GEN_MAX_PAR 64
 

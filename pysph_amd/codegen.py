@@ -151,6 +151,8 @@ class _Body(object):
         self.fdef = fdef
         self.locals = {}            # name -> ('double', None) | ('array', n) | ('int', None)
         self.loop_vars = set()
+        self.unrolled = {}          # loop variables of statically unrolled loops -> value
+        self.affine_ints = {}       # int locals with a known value a*d_idx + b*s_idx + c
         self.where = '%s.%s' % (type(eq).__name__, kind)
         self.lines = []
         fam._writes = set()
@@ -175,6 +177,113 @@ class _Body(object):
             except Exception:
                 self.err(node, 'self.%s is not a scalar (%r)' % (attr, type(val)))
         return self.fam.param(('self', self.k, attr), float(val))
+
+    # -- integer index algebra ----------------------------------------------
+    def _assign_counts(self):
+        if not hasattr(self, '_acount'):
+            cnt = {}
+            for node in ast.walk(self.fdef):
+                tgts = []
+                if isinstance(node, ast.Assign):
+                    vals = node.value.elts if isinstance(node.value, ast.Tuple) else [node.value]
+                    if all(self._declare_call(v) is not None for v in vals):
+                        continue                    # x = declare(...) is a declaration
+                    tgts = node.targets
+                elif isinstance(node, (ast.AugAssign, ast.For)):
+                    tgts = [node.target]
+                for t_ in tgts:
+                    for e in (t_.elts if isinstance(t_, ast.Tuple) else [t_]):
+                        if isinstance(e, ast.Name):
+                            cnt[e.id] = cnt.get(e.id, 0) + 1
+            self._acount = cnt
+        return self._acount
+
+    def _affine(self, n):
+        """integer expression as ({symbol: coefficient}, constant) or None.
+        Symbols: d_idx, s_idx (pair loops) and run-time int names."""
+        if isinstance(n, ast.Constant) and isinstance(n.value, int) and not isinstance(n.value, bool):
+            return {}, n.value
+        if isinstance(n, ast.Name):
+            if n.id in self.unrolled:
+                return {}, self.unrolled[n.id]
+            if n.id in self.affine_ints:
+                syms, c = self.affine_ints[n.id]
+                return dict(syms), c
+            if n.id == 'd_idx' or (n.id == 's_idx' and self.pair):
+                return {n.id: 1}, 0
+            if n.id in self.loop_vars or self.locals.get(n.id, ('',))[0] == 'int':
+                return {n.id: 1}, 0
+            return None
+        if isinstance(n, ast.Attribute) and isinstance(n.value, ast.Name) and n.value.id == 'self' \
+                and self.eq is not None and isinstance(getattr(self.eq, n.attr, None), int) \
+                and not isinstance(getattr(self.eq, n.attr), bool):
+            return {}, int(getattr(self.eq, n.attr))
+        if isinstance(n, ast.UnaryOp) and isinstance(n.op, ast.USub):
+            a = self._affine(n.operand)
+            return None if a is None else (dict((k, -v) for k, v in a[0].items()), -a[1])
+        if isinstance(n, ast.BinOp) and isinstance(n.op, (ast.Add, ast.Sub, ast.Mult)):
+            a, b = self._affine(n.left), self._affine(n.right)
+            if a is None or b is None:
+                return None
+            if isinstance(n.op, ast.Mult):
+                if a[0] and b[0]:
+                    return None
+                if a[0]:
+                    a, b = b, a
+                return dict((k, v * a[1]) for k, v in b[0].items() if v * a[1]), a[1] * b[1]
+            sg = 1 if isinstance(n.op, ast.Add) else -1
+            syms = dict(a[0])
+            for k, v in b[0].items():
+                syms[k] = syms.get(k, 0) + sg * v
+            return dict((k, v) for k, v in syms.items() if v), a[1] + sg * b[1]
+        return None
+
+    def _const_int(self, n):
+        a = self._affine(n)
+        return a[1] if a is not None and not a[0] else None
+
+    def _component(self, sl, idx_name):
+        """``S*<idx_name> + K`` (any arrangement that reduces to it, K from
+        literals / unrolled loop variables / known ints) -> (S, K); S = 1,
+        K = 0 is the plain scalar access"""
+        a = self._affine(sl)
+        if a is None or set(a[0]) != {idx_name}:
+            return None
+        S, K = a[0][idx_name], a[1]
+        if S >= 1 and 0 <= K < S:
+            return S, K
+        return None
+
+    def _mentions_in_property_index(self, body, var):
+        for st in body:
+            for node in ast.walk(st):
+                if isinstance(node, ast.Subscript) and isinstance(node.value, ast.Name) and \
+                        (node.value.id.startswith('d_') or node.value.id.startswith('s_')) and \
+                        node.value.id not in self.locals:
+                    sl = node.slice
+                    names = set(x.id for x in ast.walk(sl) if isinstance(x, ast.Name))
+                    if var in names:
+                        return True
+                    # through an int local that was computed from the loop variable
+                    for nm in names:
+                        if nm in self._depends_on(var):
+                            return True
+        return False
+
+    def _depends_on(self, var):
+        """int locals assigned (anywhere in the method) from expressions that
+        mention `var`"""
+        out, changed = set(), True
+        while changed:
+            changed = False
+            for node in ast.walk(self.fdef):
+                if isinstance(node, ast.Assign) and len(node.targets) == 1 and \
+                        isinstance(node.targets[0], ast.Name) and node.targets[0].id not in out:
+                    names = set(x.id for x in ast.walk(node.value) if isinstance(x, ast.Name))
+                    if var in names or names & out:
+                        out.add(node.targets[0].id)
+                        changed = True
+        return out
 
     # -- expressions -------------------------------------------------------
     def expr(self, n):
@@ -245,9 +354,10 @@ class _Body(object):
     def call(self, n):
         f = n.func
         if isinstance(f, ast.Attribute) and isinstance(f.value, ast.Name) and f.value.id == 'SPH_KERNEL':
-            if not self.all_nbrs:
-                self.err(n, 'SPH_KERNEL is only available in loop_all')
-            args = [a.id if (isinstance(a, ast.Name) and self.locals.get(a.id, ('',))[0] == 'array')
+            if not (self.all_nbrs or self.pair):
+                self.err(n, 'SPH_KERNEL is only available in loop and loop_all')
+            args = [a.id if (isinstance(a, ast.Name) and (
+                        self.locals.get(a.id, ('',))[0] in ('array', 'arrayarg') or a.id in VEC_SYMBOLS))
                     else self.expr(a) for a in n.args]
             if f.attr == 'kernel' and len(args) == 3:       # kernel(xij, rij, h)
                 return 'gen_kernel_w<KK>(%s, %s, a)' % (args[1], args[2])
@@ -267,16 +377,34 @@ class _Body(object):
             helper = self.fam.helper(self, n, fname)
         if helper is not None:
             # plain Python helper functions (Equation._get_helpers_,
-            # equation.py:860-872): scalar double arguments, one double result
-            vals = [self.expr(a) for a in n.args]
+            # equation.py:860-872).  Argument types follow the defaults, as in
+            # the reference's translator: a list is a double array, an int an
+            # int, anything else a double; the result is a double.
             names = helper.argnames
-            if len(vals) > len(names):
+            if len(n.args) > len(names):
                 self.err(n, '%s(): too many arguments' % fname)
-            slots = vals + [None] * (len(names) - len(vals))
+
+            def passed(i, node):
+                kind = helper.argtypes[i]
+                if kind == 'array':
+                    if isinstance(node, ast.Name) and \
+                            self.locals.get(node.id, ('',))[0] in ('array', 'arrayarg'):
+                        return node.id
+                    if isinstance(node, ast.Name) and node.id in VEC_SYMBOLS and self.pair:
+                        self.fam.use_symbol(node.id)
+                        self.fam.sym_written.add(node.id)    # the callee may write it
+                        return node.id
+                    self.err(n, '%s(): argument %s must be a local matrix' % (fname, names[i]))
+                if kind == 'int':
+                    return self.index(node)
+                return self.expr(node)
+
+            slots = [passed(i, a) for i, a in enumerate(n.args)]
+            slots += [None] * (len(names) - len(slots))
             for kw in n.keywords:
                 if kw.arg not in names or slots[names.index(kw.arg)] is not None:
                     self.err(n, '%s(): keyword %s' % (fname, kw.arg))
-                slots[names.index(kw.arg)] = self.expr(kw.value)
+                slots[names.index(kw.arg)] = passed(names.index(kw.arg), kw.value)
             for i, v in enumerate(slots):
                 if v is None:
                     if helper.defaults[i] is None:
@@ -302,6 +430,8 @@ class _Body(object):
 
     def name(self, n):
         v = n.id
+        if v in self.unrolled:
+            return repr(float(self.unrolled[v]))
         if v in self.loop_vars:
             return v
         if v in self.locals:
@@ -327,6 +457,10 @@ class _Body(object):
         """integer index expression (loop variables, literals, + - *)"""
         if isinstance(n, ast.Constant) and isinstance(n.value, int):
             return str(n.value)
+        if isinstance(n, ast.Name) and n.id in self.unrolled:
+            return str(self.unrolled[n.id])
+        if isinstance(n, ast.Name) and n.id in self.affine_ints and not self.affine_ints[n.id][0]:
+            return str(self.affine_ints[n.id][1])
         if isinstance(n, ast.Name) and (n.id in self.loop_vars or
                                         self.locals.get(n.id, ('', 0))[0] == 'int'):
             return n.id
@@ -397,7 +531,9 @@ class _Body(object):
             prop = base[2:]
             if isinstance(sl, ast.Name) and sl.id == 'd_idx':
                 return self.fam.dest_prop(prop, store)
-            sk = self._strided(sl, 'd_idx')
+            sk = self._strided(sl, 'd_idx') or self._component(sl, 'd_idx')
+            if sk is not None and sk[0] == 1:
+                return self.fam.dest_prop(prop, store)
             if sk is not None:
                 self.fam.note_stride(prop, sk[0], self, n)
                 return self.fam.dest_prop('%s__%d' % (prop, sk[1]), store)
@@ -416,6 +552,12 @@ class _Body(object):
             if store:
                 self.err(n, 'source arrays are read-only (gather formulation)')
             sk = self._strided_any(sl)
+            if sk is None:
+                a = self._affine(sl)
+                if a is not None and len(a[0]) == 1:
+                    (nm, S), = a[0].items()
+                    if S > 1 and 0 <= a[1] < S:
+                        sk = (S, '((int)d_idx)' if nm == 'd_idx' else nm, a[1])
             if sk is not None:
                 self.fam.note_stride(base[2:], sk[0], self, n)
                 return 'S_%s[%s]' % (self.fam.raw_src_prop('%s__%d' % (base[2:], sk[2])), sk[1])
@@ -428,19 +570,25 @@ class _Body(object):
                 self.err(n, '%s outside a pair loop' % base)
             if isinstance(sl, ast.Name) and sl.id == 's_idx':
                 return self.fam.src_prop(prop)
-            sk = self._strided(sl, 's_idx')
+            sk = self._strided(sl, 's_idx') or self._component(sl, 's_idx')
+            if sk is not None and sk[0] == 1:
+                return self.fam.src_prop(prop)
             if sk is not None:
                 self.fam.note_stride(prop, sk[0], self, n)
                 return self.fam.src_prop('%s__%d' % (prop, sk[1]))
             self.err(n, '%s must be indexed with s_idx' % base)
         if base in VEC_SYMBOLS:
-            if store:
-                self.err(n, 'precomputed symbols are read-only')
+            if store and self.pair:
+                # e.g. GradientCorrection (kernel_correction.py:95-125) rewrites
+                # DWIJ for the equations after it in the group
+                self.fam.sym_written.add(base)
+            elif store:
+                self.err(n, 'precomputed symbols are read-only here')
             if not self.pair:
                 self.err(n, 'pair symbol %s outside a pair loop' % base)
             self.fam.use_symbol(base)
             return '%s[%s]' % (base, self.index(sl))
-        if base in self.locals and self.locals[base][0] == 'array':
+        if base in self.locals and self.locals[base][0] in ('array', 'arrayarg'):
             return '%s[%s]' % (base, self.index(sl))
         self.err(n, 'subscript of unknown array %r' % base)
 
@@ -478,12 +626,17 @@ class _Body(object):
             v = st.value
             if isinstance(v, ast.Call) and isinstance(v.func, ast.Attribute) and \
                     isinstance(v.func.value, ast.Name) and v.func.value.id == 'SPH_KERNEL' and \
-                    v.func.attr == 'gradient' and len(v.args) == 4 and self.all_nbrs and \
-                    all(isinstance(v.args[k], ast.Name) and self.locals.get(v.args[k].id, ('',))[0] == 'array'
-                        for k in (0, 3)):
+                    v.func.attr == 'gradient' and len(v.args) == 4 and (self.all_nbrs or self.pair) and \
+                    all(isinstance(v.args[k], ast.Name) and (
+                        self.locals.get(v.args[k].id, ('',))[0] in ('array', 'arrayarg')
+                        or (k == 0 and v.args[k].id in VEC_SYMBOLS)) for k in (0, 3)):
                 # gradient(xij, rij, h, grad): kernels.py:126-137
                 self._emit(ind, 'gen_kernel_gradient<KK>(%s, %s, %s, %s, a);' % (
                     v.args[0].id, self.expr(v.args[1]), self.expr(v.args[2]), v.args[3].id))
+                return
+            if isinstance(v, ast.Call) and isinstance(v.func, ast.Name) and \
+                    self.fam.helper(self, v, v.func.id) is not None:
+                self._emit(ind, '(void)%s;' % self.call(v))      # result ignored
                 return
             self.err(st, 'expression statement')
         if isinstance(st, ast.Pass):
@@ -525,6 +678,17 @@ class _Body(object):
                 self._declare(tgt, d, st)
                 return
             if isinstance(tgt, ast.Name) and self.locals.get(tgt.id, ('',))[0] == 'int':
+                self.affine_ints.pop(tgt.id, None)
+                aff = self._affine(st.value)
+                if aff is not None and not (set(aff[0]) - {'d_idx', 's_idx'}) and \
+                        (self._assign_counts().get(tgt.id, 0) == 1 or self.unrolled):
+                    # i16 = 16*d_idx / n = self.dim: a value known at translation
+                    # time (single assignment, or inside an unrolled loop)
+                    self.affine_ints[tgt.id] = aff
+                    if aff[0]:
+                        return                      # only ever used inside indices
+                    self._emit(ind, '%s = %d;' % (tgt.id, aff[1]))
+                    return
                 if isinstance(st.value, ast.Subscript) and isinstance(st.value.value, ast.Name) \
                         and st.value.value.id == 'NBRS':
                     rhs = self.subscript(st.value, store=False)
@@ -558,6 +722,25 @@ class _Body(object):
                     and 1 <= len(it.args) <= 2) or st.orelse:
                 self.err(st, 'only "for i in range(a[, b])" loops')
             var = st.target.id
+            clo = 0 if len(it.args) == 1 else self._const_int(it.args[0])
+            chi = self._const_int(it.args[-1])
+            if clo is not None and chi is not None and chi - clo <= 64 and \
+                    self._mentions_in_property_index(st.body, var):
+                # components of strided properties live in separate registers:
+                # a loop over them is unrolled at translation time
+                saved = self.unrolled.get(var)
+                for val in range(clo, chi):
+                    self.unrolled[var] = val
+                    self._emit(ind, '{   // %s = %d' % (var, val))
+                    self._emit_block(st.body, ind + 1)
+                    self._emit(ind, '}')
+                if saved is None:
+                    self.unrolled.pop(var, None)
+                else:
+                    self.unrolled[var] = saved
+                for nm in self._depends_on(var):
+                    self.affine_ints.pop(nm, None)
+                return
             lo, hi = ('0', self.index(it.args[0])) if len(it.args) == 1 else \
                 (self.index(it.args[0]), self.index(it.args[1]))
             fresh = var not in self.loop_vars
@@ -628,13 +811,28 @@ class _HelperBody(_Body):
         if a.vararg or a.kwarg or a.kwonlyargs:
             raise CodegenError('helper %s: only plain scalar arguments' % name)
         self.argnames = [x.arg for x in a.args]
-        self.defaults = [None] * (len(a.args) - len(a.defaults))
+        nd = len(a.args) - len(a.defaults)
+        self.defaults = [None] * nd
+        self.argtypes = ['double'] * nd
         for d in a.defaults:
-            if not (isinstance(d, ast.Constant) and isinstance(d.value, (int, float))):
-                raise CodegenError('helper %s: default values must be numbers' % name)
-            self.defaults.append(repr(float(d.value)))
-        self.locals = dict((n_, ('arg', None)) for n_ in self.argnames)
+            if isinstance(d, ast.List):                     # m=[1., 0.]  -> double *
+                self.defaults.append(None)
+                self.argtypes.append('array')
+            elif isinstance(d, ast.Constant) and isinstance(d.value, bool):
+                raise CodegenError('helper %s: boolean defaults' % name)
+            elif isinstance(d, ast.Constant) and isinstance(d.value, int):
+                self.defaults.append(str(d.value))
+                self.argtypes.append('int')
+            elif isinstance(d, ast.Constant) and isinstance(d.value, float):
+                self.defaults.append(repr(d.value))
+                self.argtypes.append('double')
+            else:
+                raise CodegenError('helper %s: default values must be numbers or lists' % name)
+        kinds = {'double': 'arg', 'int': 'int', 'array': 'arrayarg'}
+        self.locals = dict((n_, (kinds[t_], None)) for n_, t_ in zip(self.argnames, self.argtypes))
         self.loop_vars = set()
+        self.unrolled = {}
+        self.affine_ints = {}
         self.lines = []
         self._emit_block(fdef.body, 1)
         self.writes = set()
@@ -643,14 +841,17 @@ class _HelperBody(_Body):
         self.err(node, 'self is not available in a helper function')
 
     def definition(self):
+        ctype = {'double': 'double ', 'int': 'int ', 'array': 'double *'}
         out = ['__device__ __forceinline__ double %s(%s)' % (
-            self.cname, ', '.join('double ' + n for n in self.argnames)), '{']
+            self.cname, ', '.join(ctype[t] + n for n, t in zip(self.argnames, self.argtypes))), '{']
         for name, (kind, n) in sorted(self.locals.items()):
+            if name in self.argnames:
+                continue
             if kind == 'array':
                 out.append('    double %s[%d] = {};' % (name, n))
             elif kind == 'int':
                 out.append('    int %s = 0; (void)%s;' % (name, name))
-            elif kind != 'arg':
+            else:
                 out.append('    double %s = 0.0;' % name)
         out += self.lines
         out += ['    return 0.0;', '}']
@@ -688,6 +889,7 @@ class GeneratedFamily(object):
                     self.src_flags[s] = 0
                 self.src_flags[s] |= 1 << k
         self.helpers = OrderedDict()    # name -> _HelperBody, in dependency order
+        self.sym_written = set()        # pair symbols some equation assigns to
         self.bodies = {m: [] for m in METHODS}
         self.nosrc_loops = []
         for k, eq in enumerate(self.equations):
@@ -729,8 +931,8 @@ class GeneratedFamily(object):
             self.src_prop('rho')
         if len(self.sprops) > 20:
             raise CodegenError('more than 20 source properties in one family')
-        if len(self.dprops) > 32:
-            raise CodegenError('more than 32 destination properties in one family')
+        if len(self.dprops) > 48:
+            raise CodegenError('more than 48 destination properties in one family')
         if len(self.params) > 64:
             raise CodegenError('more than 64 scalar parameters in one family')
         self.source = self._emit_source()
@@ -1115,7 +1317,11 @@ class GeneratedFamily(object):
         A('    }')
         A('    return (int)hipGetLastError();')
         A('}')
-        return '\n'.join(L) + '\n'
+        src = '\n'.join(L) + '\n'
+        for sym in sorted(self.sym_written):     # symbols an equation assigns to lose their const
+            src = src.replace('const double %s[3] =' % sym, 'double %s[3] =' % sym)
+            src = src.replace('const double %s =' % sym, 'double %s =' % sym)
+        return src
 
     # -- build / load ---------------------------------------------------------
     def so_path(self):

@@ -153,7 +153,7 @@ def prop_register(name):
     return pid
 
 
-GEN_MAX_PROPS, GEN_MAX_SPROPS, GEN_MAX_PAR = 32, 20, 64
+GEN_MAX_PROPS, GEN_MAX_SPROPS, GEN_MAX_PAR = 48, 20, 64
 
 
 class SphGenFamily(C.Structure):

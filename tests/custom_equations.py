@@ -284,3 +284,193 @@ class SmoothCopy(Equation):
 
     def loop(self, d_idx, s_idx, d_q, s_qtmp, s_m, s_rho, WIJ):
         d_q[d_idx] += s_qtmp[s_idx] * s_m[s_idx] / s_rho[s_idx] * WIJ
+
+
+# ---------------------------------------------------------------------------
+# helper functions with array / int arguments (types follow the defaults, as in
+# the reference's translator: list -> double*, int -> int, float -> double)
+# ---------------------------------------------------------------------------
+def stack_columns(A=[0.0, 0.0], b=[0.0, 0.0], n=3, nb=1, lda=3, out=[0.0, 0.0]):
+    """[A | b] of the leading n x n block of a row-major lda x lda matrix and
+    nb right-hand sides, row-major n x (n + nb) in `out`."""
+    i, j, w = declare('int', 3)
+    w = n + nb
+    for i in range(n):
+        for j in range(n):
+            out[w * i + j] = A[lda * i + j]
+        for j in range(nb):
+            out[w * i + n + j] = b[nb * i + j]
+
+
+def eliminate(m=[1.0, 0.0], n=3, nb=1, x=[0.0, 0.0]):
+    """Gauss-Jordan with row pivoting on the augmented n x (n + nb) matrix m;
+    the solution goes to x (n x nb).  Returns 1.0 for a singular matrix."""
+    i, j, k, w, piv = declare('int', 5)
+    w = n + nb
+    for k in range(n):
+        piv = k
+        for i in range(k + 1, n):
+            if fabs(m[w * i + k]) > fabs(m[w * piv + k]):
+                piv = i
+        if fabs(m[w * piv + k]) < 1e-14:
+            return 1.0
+        if piv != k:
+            for j in range(w):
+                tmp = m[w * k + j]
+                m[w * k + j] = m[w * piv + j]
+                m[w * piv + j] = tmp
+        d = 1.0 / m[w * k + k]
+        for j in range(w):
+            m[w * k + j] = m[w * k + j] * d
+        for i in range(n):
+            if i != k:
+                f = m[w * i + k]
+                for j in range(w):
+                    m[w * i + j] -= f * m[w * k + j]
+    for i in range(n):
+        for j in range(nb):
+            x[nb * i + j] = m[w * i + n + j]
+    return 0.0
+
+
+class CorrectionMatrix(Equation):
+    """Bonet-Lok gradient-correction matrix (the pattern of
+    kernel_correction.py:40-78): a stride-9 property zeroed in a loop, filled
+    from loop_all with SPH_KERNEL.gradient and a doubly nested component loop."""
+
+    def __init__(self, dest, sources, dim=3):
+        self.dim = dim
+        super(CorrectionMatrix, self).__init__(dest, sources)
+
+    def initialize(self, d_idx, d_lmat):
+        i = declare('int')
+        for i in range(9):
+            d_lmat[9 * d_idx + i] = 0.0
+
+    def loop_all(self, d_idx, d_lmat, d_x, d_y, d_z, d_h, s_x, s_y, s_z, s_h, s_m, s_rho,
+                 SPH_KERNEL, NBRS, N_NBRS):
+        i, j, k, s_idx, n = declare('int', 5)
+        xij = declare('matrix(3)')
+        dw = declare('matrix(3)')
+        n = self.dim
+        for k in range(N_NBRS):
+            s_idx = NBRS[k]
+            xij[0] = d_x[d_idx] - s_x[s_idx]
+            xij[1] = d_y[d_idx] - s_y[s_idx]
+            xij[2] = d_z[d_idx] - s_z[s_idx]
+            r = sqrt(xij[0] * xij[0] + xij[1] * xij[1] + xij[2] * xij[2])
+            SPH_KERNEL.gradient(xij, r, 0.5 * (d_h[d_idx] + s_h[s_idx]), dw)
+            vol = s_m[s_idx] / s_rho[s_idx]
+            if r > 1e-12:
+                for i in range(n):
+                    for j in range(n):
+                        d_lmat[9 * d_idx + 3 * i + j] -= vol * dw[i] * xij[j]
+
+
+class CorrectGradient(Equation):
+    """kernel_correction.py:95-125 pattern: solve L x = DWIJ per pair with a
+    helper taking local matrices and REPLACE DWIJ for the equations after this
+    one in the group."""
+
+    def __init__(self, dest, sources, dim=3, tol=0.5):
+        self.dim = dim
+        self.tol = tol
+        super(CorrectGradient, self).__init__(dest, sources)
+
+    def _get_helpers_(self):
+        return [eliminate]
+
+    def loop(self, d_idx, d_lmat, DWIJ, HIJ):
+        i, j, n, w = declare('int', 4)
+        n = self.dim
+        w = n + 1
+        aug = declare('matrix(12)')
+        res = declare('matrix(3)')
+        for i in range(n):
+            for j in range(n):
+                aug[w * i + j] = d_lmat[9 * d_idx + 3 * i + j]
+            aug[w * i + n] = DWIJ[i]
+        bad = eliminate(aug, n, 1, res)
+        before = 0.0
+        after = 0.0
+        for i in range(n):
+            before += fabs(DWIJ[i])
+            after += fabs(res[i])
+        if bad < 0.5 and fabs(after - before) < self.tol * (before + 1e-4 * HIJ):
+            for i in range(n):
+                DWIJ[i] = res[i]
+
+
+class GradientOfLinearField(Equation):
+    """consumer of the (corrected) DWIJ: gradient of f = 2x - 3y + z + 1, which
+    the corrected kernel gradient reproduces to rounding"""
+
+    def initialize(self, d_idx, d_gx, d_gy, d_gz):
+        d_gx[d_idx] = 0.0
+        d_gy[d_idx] = 0.0
+        d_gz[d_idx] = 0.0
+
+    def loop(self, d_idx, s_idx, d_gx, d_gy, d_gz, s_m, s_rho, XIJ, DWIJ):
+        fji = -(2.0 * XIJ[0] - 3.0 * XIJ[1] + XIJ[2])
+        vol = s_m[s_idx] / s_rho[s_idx]
+        d_gx[d_idx] += vol * fji * DWIJ[0]
+        d_gy[d_idx] += vol * fji * DWIJ[1]
+        d_gz[d_idx] += vol * fji * DWIJ[2]
+
+
+class MomentMatrix(Equation):
+    """bc/interpolate.py:340-380 pattern: 4x4 moment matrix per destination in
+    a stride-16 property, addressed through an int local holding 16*d_idx."""
+
+    def initialize(self, d_idx, d_amat, d_bvec):
+        i, j = declare('int', 2)
+        for i in range(4):
+            d_bvec[4 * d_idx + i] = 0.0
+            for j in range(4):
+                d_amat[16 * d_idx + j + 4 * i] = 0.0
+
+    def loop(self, d_idx, s_idx, d_amat, d_bvec, s_m, s_rho, s_p, XIJ, WIJ):
+        vol = s_m[s_idx] / s_rho[s_idx]
+        i16, i4, i, j = declare('int', 4)
+        i16 = 16 * d_idx
+        i4 = 4 * d_idx
+        basis = declare('matrix(4)')
+        basis[0] = 1.0
+        basis[1] = -XIJ[0]
+        basis[2] = -XIJ[1]
+        basis[3] = -XIJ[2]
+        for i in range(4):
+            d_bvec[i4 + i] += s_p[s_idx] * basis[i] * WIJ * vol
+            for j in range(4):
+                d_amat[i16 + 4 * i + j] += basis[i] * basis[j] * WIJ * vol
+
+
+class SolveMoments(Equation):
+    """bc/interpolate.py:292-313 pattern: post_loop gathers the strided
+    properties into local matrices, calls two helpers, scatters the result."""
+
+    def __init__(self, dest, sources, dim=3):
+        self.dim = dim
+        super(SolveMoments, self).__init__(dest, sources)
+
+    def _get_helpers_(self):
+        return [stack_columns, eliminate]
+
+    def post_loop(self, d_idx, d_amat, d_bvec, d_pfit):
+        a = declare('matrix(16)')
+        aug = declare('matrix(20)')
+        b = declare('matrix(4)')
+        res = declare('matrix(4)')
+        i, n, i16, i4 = declare('int', 4)
+        i16 = 16 * d_idx
+        i4 = 4 * d_idx
+        for i in range(16):
+            a[i] = d_amat[i16 + i]
+        for i in range(4):
+            b[i] = d_bvec[i4 + i]
+            res[i] = 0.0
+        n = self.dim + 1
+        stack_columns(a, b, n, 1, 4, aug)
+        eliminate(aug, n, 1, res)
+        for i in range(4):
+            d_pfit[i4 + i] = res[i]

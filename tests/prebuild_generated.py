@@ -80,6 +80,7 @@ def main():
                                       RS.SimpleEquation('fluid', ['fluid'])])], K.CubicSpline(dim=1))
     n += plan([ps], [Group(equations=[RS.InitializePair('fluid', ['fluid'])])], K.CubicSpline(dim=1))
     n += plan(RS.ghost_copy_arrays(), RS.ghost_copy_equations(), K.CubicSpline(dim=1))
+    n += plan([T._correction_case()], T._correction_equations(), K.CubicSpline(dim=3))
     import test_kernel_moments as KM
     for kname, dim in sorted(KM.PLACES):
         n += plan(list(KM.moment_arrays(2)), KM.moment_equations(), getattr(K, kname)(dim=dim))

@@ -220,3 +220,77 @@ def test_reference_classes_translate_like_the_restatements():
     assert {'WDP', 'WIJ', 'DWIJ', 'VIJ', 'RHOIJ1'} <= fam.symbols
     assert fam.src_flags == {'fluid': 7, 'wall': 3}
     fam.build()
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference tree only exists in the build container')
+def test_reference_equation_census():
+    """Every Equation subclass of the reference's pysph.sph modules that can be
+    imported here (through the compyle stub) is pushed through the translator:
+    initialize / initialize_pair / loop / loop_all / post_loop bodies, strided
+    properties, helper functions, SPH_KERNEL calls.  Known exception:
+    MLSFirstOrder3D, whose loop_all calls augmented_matrix with five arguments
+    (density_correction.py:189; the 2-D twin passes six) -- rejected here as it
+    would be by a C compiler."""
+    import importlib
+    import inspect
+    import pkgutil
+    for p in (REF, os.path.join(REPO, 'oracle', '_stubs')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import pysph.sph
+    from pysph.sph.equation import Equation as RefEquation
+    from pysph_amd.codegen import METHODS, CodegenError, GeneratedFamily
+
+    class AnyArray(object):
+        name = 'fluid'
+        constants = {}
+        stride = {}
+
+        class _Props(dict):
+            def __contains__(self, k):
+                return True
+
+            def __getitem__(self, k):
+                return np.zeros(2)
+        properties = _Props()
+
+    mods = []
+    for m in pkgutil.walk_packages(pysph.sph.__path__, 'pysph.sph.'):
+        if '.tests' in m.name:
+            continue
+        try:
+            mods.append(importlib.import_module(m.name))
+        except Exception:
+            pass                      # needs cyarray / mako / the Cython particle array
+    ok, bad, seen = [], {}, set()
+    for mod in mods:
+        for name, cls in inspect.getmembers(mod, inspect.isclass):
+            if not issubclass(cls, RefEquation) or cls in seen or cls.__module__ != mod.__name__:
+                continue
+            seen.add(cls)
+            if not any(callable(getattr(cls, m, None)) for m in METHODS):
+                continue
+            kw = {}
+            for pn, pp in list(inspect.signature(cls.__init__).parameters.items())[1:]:
+                if pn == 'dest':
+                    kw[pn] = 'fluid'
+                elif pn == 'sources':
+                    kw[pn] = ['fluid']
+                elif pp.default is inspect._empty:
+                    kw[pn] = 2 if pn == 'dim' else 1.0
+            try:
+                eq = cls(**kw)
+            except Exception:
+                continue              # constructor wants specific values
+            try:
+                GeneratedFamily('fluid', [eq], {'fluid': AnyArray()}, 2, 'census')
+                ok.append(name)
+            except CodegenError as e:
+                bad[name] = str(e)
+    assert set(bad) <= {'MLSFirstOrder3D'}, bad
+    assert len(ok) >= 65, len(ok)
+    for name in ('GradientCorrectionPreStep', 'GradientCorrection', 'MixedGradientCorrection',
+                 'UpdateMomentMatrix', 'EvaluateP', 'CopyPFromGhost', 'MLSFirstOrder2D',
+                 'ComputeNormals', 'SetWallVelocityNew', 'MomentumEquationDeltaSPH',
+                 'SolidWallNoSlipBC', 'ShepardFilter'):
+        assert name in ok, name

@@ -1353,3 +1353,69 @@ def test_degenerate_h_gives_unit_cell_size(oracle):
     assert np.array_equal(nnps.ncells_per_dim, onn.ncells_per_dim)
     start, idx = nnps.get_csr(0, 0)
     assert start[-1] == 0 and idx.size == 0
+
+
+def _correction_case():
+    """jittered 9^3 cube carrying the linear field p = 2x - 3y + z + 1"""
+    from pysph_amd.particle_array import get_particle_array_wcsph
+    rng = np.random.default_rng(21)
+    n1 = 9
+    dx = 1.0 / n1
+    g = (np.arange(n1) + 0.5) * dx
+    x, y, z = [a.ravel() for a in np.meshgrid(g, g, g, indexing='ij')]
+    n = x.size
+    x = x + 0.15 * dx * rng.uniform(-1, 1, n)
+    y = y + 0.15 * dx * rng.uniform(-1, 1, n)
+    z = z + 0.15 * dx * rng.uniform(-1, 1, n)
+    pa = get_particle_array_wcsph(name='fluid', x=x, y=y, z=z, h=1.3 * dx * np.ones(n),
+                                  m=dx ** 3 * np.ones(n), rho=np.ones(n),
+                                  p=2 * x - 3 * y + z + 1)
+    for name, stride in (('lmat', 9), ('amat', 16), ('bvec', 4), ('pfit', 4)):
+        pa.add_property(name, stride=stride)
+        pa.properties[name][:] = rng.uniform(-1, 1, stride * n)     # junk to be overwritten
+    for name in ('gx', 'gy', 'gz'):
+        pa.add_property(name)
+    return pa
+
+
+def _correction_equations():
+    from custom_equations import (CorrectGradient, CorrectionMatrix, GradientOfLinearField,
+                                  MomentMatrix, SolveMoments)
+    from pysph_amd.equations import Group
+    return [Group(equations=[CorrectionMatrix('fluid', ['fluid'], dim=3)]),
+            Group(equations=[CorrectGradient('fluid', ['fluid'], dim=3, tol=50.0),
+                             GradientOfLinearField('fluid', ['fluid'])]),
+            Group(equations=[MomentMatrix('fluid', ['fluid']),
+                             SolveMoments('fluid', ['fluid'], dim=3)])]
+
+
+def test_generated_matrix_helpers_unrolled_components_and_symbol_rewrite(oracle):
+    """The constructs of the reference's kernel-correction and interpolation
+    equations (kernel_correction.py:40-125, bc/interpolate.py:263-380): strided
+    properties addressed through loops and int locals (unrolled at translation
+    time), helper functions with matrix / int arguments, SPH_KERNEL.gradient in
+    loop_all, and an equation that REWRITES DWIJ for the ones after it.
+    Oracle: the same Python bodies run by oracle/py_eval.py; plus the analytic
+    property that both corrections reproduce a linear field exactly."""
+    from oracle.py_eval import PyEval
+    from pysph_amd import kernels as K
+    kernel = K.CubicSpline(dim=3)
+    eqs = _correction_equations()
+    pa, ref = _correction_case(), _correction_case()
+    a_eval, nnps, ctx = make_eval([pa], eqs, kernel, 3)
+    a_eval.compute(0.0, 1e-4)
+    onn = oracle.OracleNNPS(3, [ref], radius_scale=2.0)
+    onn.update()
+    PyEval([ref], eqs, kernel, onn).compute(0.0, 1e-4)
+    assert rel_err(pa.lmat, ref.lmat) < TOL
+    assert rel_err(pa.amat, ref.amat) < TOL and rel_err(pa.bvec, ref.bvec) < TOL
+    # the linear solves amplify last-bit differences (fma contraction) by the
+    # condition number of the local matrices
+    for prop in ('gx', 'gy', 'gz', 'pfit'):
+        assert rel_err(pa.properties[prop], ref.properties[prop]) < 1e-8, prop
+    # analytic: corrected gradient of the linear field, and its MLS fit
+    assert np.abs(pa.gx - 2.0).max() < 1e-9 and np.abs(pa.gy + 3.0).max() < 1e-9
+    assert np.abs(pa.gz - 1.0).max() < 1e-9
+    fit = pa.pfit.reshape(-1, 4)
+    assert np.abs(fit[:, 0] - pa.p).max() < 1e-9
+    assert np.abs(fit[:, 1:] - np.array([2.0, -3.0, 1.0])).max() < 1e-8
