@@ -65,6 +65,24 @@ class CodegenError(Exception):
     pass
 
 
+# identifiers a Python local may not keep in the generated C++: keywords and the
+# names the emitted skeleton itself uses around the bodies
+_RESERVED = set("""alignas alignof and and_eq asm auto bitand bitor bool break case catch char
+    class compl const constexpr const_cast continue decltype default delete do double
+    dynamic_cast else enum explicit export extern false float for friend goto if inline int
+    long mutable namespace new noexcept not not_eq nullptr operator or or_eq private
+    protected public register reinterpret_cast return short signed sizeof static
+    static_assert static_cast struct switch template this thread_local throw true try
+    typedef typeid typename union unsigned using virtual void volatile wchar_t while xor
+    xor_eq restrict a D g s sj pi pj fl o PAR KK UH A NBRS N_NBRS r2 hi2 hj2 gi gj
+    tg_ tgi_ tgj_ uint32_t size_t""".split())
+
+
+def _cn(name):
+    """C++ spelling of a Python local / loop variable / helper argument"""
+    return name + '_' if name in _RESERVED else name
+
+
 _SKELETON = None
 
 
@@ -356,7 +374,7 @@ class _Body(object):
         if isinstance(f, ast.Attribute) and isinstance(f.value, ast.Name) and f.value.id == 'SPH_KERNEL':
             if not (self.all_nbrs or self.pair):
                 self.err(n, 'SPH_KERNEL is only available in loop and loop_all')
-            args = [a.id if (isinstance(a, ast.Name) and (
+            args = [_cn(a.id) if (isinstance(a, ast.Name) and (
                         self.locals.get(a.id, ('',))[0] in ('array', 'arrayarg') or a.id in VEC_SYMBOLS))
                     else self.expr(a) for a in n.args]
             if f.attr == 'kernel' and len(args) == 3:       # kernel(xij, rij, h)
@@ -389,7 +407,7 @@ class _Body(object):
                 if kind == 'array':
                     if isinstance(node, ast.Name) and \
                             self.locals.get(node.id, ('',))[0] in ('array', 'arrayarg'):
-                        return node.id
+                        return _cn(node.id)
                     if isinstance(node, ast.Name) and node.id in VEC_SYMBOLS and self.pair:
                         self.fam.use_symbol(node.id)
                         self.fam.sym_written.add(node.id)    # the callee may write it
@@ -433,9 +451,9 @@ class _Body(object):
         if v in self.unrolled:
             return repr(float(self.unrolled[v]))
         if v in self.loop_vars:
-            return v
+            return _cn(v)
         if v in self.locals:
-            return v
+            return _cn(v)
         if v == 'N_NBRS' and self.all_nbrs:
             return 'N_NBRS'
         if v in CONSTANTS:
@@ -449,6 +467,8 @@ class _Body(object):
             return v
         if v in VEC_SYMBOLS:
             self.err(n, 'vector symbol %s must be subscripted' % v)
+        if v == 'd_idx' and self.raw_src:
+            return '((double)d_idx)'            # compared with NBRS[k] in loop_all bodies
         if v in ('d_idx', 's_idx'):
             self.err(n, '%s may only index a property array' % v)
         self.err(n, 'unknown name %r (locals must be assigned before use)' % v)
@@ -463,7 +483,7 @@ class _Body(object):
             return str(self.affine_ints[n.id][1])
         if isinstance(n, ast.Name) and (n.id in self.loop_vars or
                                         self.locals.get(n.id, ('', 0))[0] == 'int'):
-            return n.id
+            return _cn(n.id)
         if isinstance(n, ast.Name) and n.id == 'N_NBRS' and self.all_nbrs:
             return 'N_NBRS'
         if isinstance(n, ast.Name) and n.id == 'd_idx' and self.raw_src:
@@ -557,7 +577,7 @@ class _Body(object):
                 if a is not None and len(a[0]) == 1:
                     (nm, S), = a[0].items()
                     if S > 1 and 0 <= a[1] < S:
-                        sk = (S, '((int)d_idx)' if nm == 'd_idx' else nm, a[1])
+                        sk = (S, '((int)d_idx)' if nm == 'd_idx' else _cn(nm), a[1])
             if sk is not None:
                 self.fam.note_stride(base[2:], sk[0], self, n)
                 return 'S_%s[%s]' % (self.fam.raw_src_prop('%s__%d' % (base[2:], sk[2])), sk[1])
@@ -587,9 +607,9 @@ class _Body(object):
             if not self.pair:
                 self.err(n, 'pair symbol %s outside a pair loop' % base)
             self.fam.use_symbol(base)
-            return '%s[%s]' % (base, self.index(sl))
+            return '%s[%s]' % (_cn(base), self.index(sl))
         if base in self.locals and self.locals[base][0] in ('array', 'arrayarg'):
-            return '%s[%s]' % (base, self.index(sl))
+            return '%s[%s]' % (_cn(base), self.index(sl))
         self.err(n, 'subscript of unknown array %r' % base)
 
     # -- statements --------------------------------------------------------
@@ -632,7 +652,7 @@ class _Body(object):
                         or (k == 0 and v.args[k].id in VEC_SYMBOLS)) for k in (0, 3)):
                 # gradient(xij, rij, h, grad): kernels.py:126-137
                 self._emit(ind, 'gen_kernel_gradient<KK>(%s, %s, %s, %s, a);' % (
-                    v.args[0].id, self.expr(v.args[1]), self.expr(v.args[2]), v.args[3].id))
+                    _cn(v.args[0].id), self.expr(v.args[1]), self.expr(v.args[2]), _cn(v.args[3].id)))
                 return
             if isinstance(v, ast.Call) and isinstance(v.func, ast.Name) and \
                     self.fam.helper(self, v, v.func.id) is not None:
@@ -640,6 +660,11 @@ class _Body(object):
                 return
             self.err(st, 'expression statement')
         if isinstance(st, ast.Pass):
+            return
+        if isinstance(st, (ast.Continue, ast.Break)):
+            if not getattr(self, '_runtime_loops', 0):
+                self.err(st, '%s outside a run-time loop' % type(st).__name__.lower())
+            self._emit(ind, 'continue;' if isinstance(st, ast.Continue) else 'break;')
             return
         if isinstance(st, ast.Return):
             if self.kind == 'helper':
@@ -687,14 +712,14 @@ class _Body(object):
                     self.affine_ints[tgt.id] = aff
                     if aff[0]:
                         return                      # only ever used inside indices
-                    self._emit(ind, '%s = %d;' % (tgt.id, aff[1]))
+                    self._emit(ind, '%s = %d;' % (_cn(tgt.id), aff[1]))
                     return
                 if isinstance(st.value, ast.Subscript) and isinstance(st.value.value, ast.Name) \
                         and st.value.value.id == 'NBRS':
                     rhs = self.subscript(st.value, store=False)
                 else:
                     rhs = self.index(st.value)
-                self._emit(ind, '%s = %s;' % (tgt.id, rhs))
+                self._emit(ind, '%s = %s;' % (_cn(tgt.id), rhs))
                 return
             rhs = self.expr(st.value)
             self._emit(ind, '%s = %s;' % (self._target(tgt, st), rhs))
@@ -729,11 +754,13 @@ class _Body(object):
                 # components of strided properties live in separate registers:
                 # a loop over them is unrolled at translation time
                 saved = self.unrolled.get(var)
+                outer_loops, self._runtime_loops = getattr(self, '_runtime_loops', 0), 0
                 for val in range(clo, chi):
                     self.unrolled[var] = val
                     self._emit(ind, '{   // %s = %d' % (var, val))
                     self._emit_block(st.body, ind + 1)
                     self._emit(ind, '}')
+                self._runtime_loops = outer_loops
                 if saved is None:
                     self.unrolled.pop(var, None)
                 else:
@@ -745,8 +772,11 @@ class _Body(object):
                 (self.index(it.args[0]), self.index(it.args[1]))
             fresh = var not in self.loop_vars
             self.loop_vars.add(var)
-            self._emit(ind, 'for (int %s = %s; %s < %s; %s++) {' % (var, lo, var, hi, var))
+            cv = _cn(var)
+            self._emit(ind, 'for (int %s = %s; %s < %s; %s++) {' % (cv, lo, cv, hi, cv))
+            self._runtime_loops = getattr(self, '_runtime_loops', 0) + 1
             self._emit_block(st.body, ind + 1)
+            self._runtime_loops -= 1
             self._emit(ind, '}')
             if fresh:
                 self.loop_vars.discard(var)
@@ -760,13 +790,18 @@ class _Body(object):
 
     def _target(self, tgt, st, aug=False):
         if isinstance(tgt, ast.Name):
+            if tgt.id in SCALAR_SYMBOLS and tgt.id not in ('t', 'dt') and self.pair:
+                # e.g. CRKSPHSymmetric (crksph.py) rescales WI / WJ in place
+                self.fam.use_symbol(tgt.id)
+                self.fam.sym_written.add(tgt.id)
+                return tgt.id
             if tgt.id in self.loop_vars or tgt.id in SCALAR_SYMBOLS or tgt.id in VEC_SYMBOLS:
                 self.err(st, 'assignment to %s' % tgt.id)
             if tgt.id not in self.locals:
                 if aug:
                     self.err(st, '%s used before assignment' % tgt.id)
                 self.locals[tgt.id] = ('double', None)
-            return tgt.id
+            return _cn(tgt.id)
         if isinstance(tgt, ast.Subscript):
             return self.subscript(tgt, store=True)
         self.err(st, 'assignment target %s' % type(tgt).__name__)
@@ -778,11 +813,11 @@ class _Body(object):
         out = [pad + '[&]() {  // %s' % self.where]
         for name, (kind, n) in sorted(self.locals.items()):
             if kind == 'array':
-                out.append(pad + '    double %s[%d] = {};' % (name, n))
+                out.append(pad + '    double %s[%d] = {};' % (_cn(name), n))
             elif kind == 'int':
-                out.append(pad + '    int %s = 0; (void)%s;' % (name, name))
+                out.append(pad + '    int %s = 0; (void)%s;' % (_cn(name), _cn(name)))
             else:
-                out.append(pad + '    double %s = 0.0;' % name)
+                out.append(pad + '    double %s = 0.0;' % _cn(name))
         for ln in self.lines:
             out.append(pad + ln)
         out.append(pad + '}();')
@@ -843,16 +878,16 @@ class _HelperBody(_Body):
     def definition(self):
         ctype = {'double': 'double ', 'int': 'int ', 'array': 'double *'}
         out = ['__device__ __forceinline__ double %s(%s)' % (
-            self.cname, ', '.join(ctype[t] + n for n, t in zip(self.argnames, self.argtypes))), '{']
+            self.cname, ', '.join(ctype[t] + _cn(n) for n, t in zip(self.argnames, self.argtypes))), '{']
         for name, (kind, n) in sorted(self.locals.items()):
             if name in self.argnames:
                 continue
             if kind == 'array':
-                out.append('    double %s[%d] = {};' % (name, n))
+                out.append('    double %s[%d] = {};' % (_cn(name), n))
             elif kind == 'int':
-                out.append('    int %s = 0; (void)%s;' % (name, name))
+                out.append('    int %s = 0; (void)%s;' % (_cn(name), _cn(name)))
             else:
-                out.append('    double %s = 0.0;' % name)
+                out.append('    double %s = 0.0;' % _cn(name))
         out += self.lines
         out += ['    return 0.0;', '}']
         return '\n'.join(out)

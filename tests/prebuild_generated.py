@@ -86,6 +86,7 @@ def main():
         n += plan(list(KM.moment_arrays(2)), KM.moment_equations(), getattr(K, kname)(dim=dim))
     import test_reference_integrators as RI
     n += RI.prebuild()
+    n += RI.prebuild_golden_steppers()
     n += plan([RI.make_pa()], [RI.SHM(dest='fluid', sources=None)], K.CubicSpline(dim=1))
     return n
 

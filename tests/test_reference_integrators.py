@@ -159,7 +159,7 @@ def test_stepper_stage_translates_with_helpers():
     src = fam.source
     # helpers are emitted before use, callee first; keyword and default
     # arguments are resolved at the call site
-    assert src.index('gen_helper_twice(double dt)') < src.index('gen_helper_scaled(double a, double fac)')
+    assert src.index('gen_helper_twice(double dt)') < src.index('gen_helper_scaled(double a_, double fac)')
     assert 'gen_helper_scaled(dt, 2.0)' in src
     assert fam.dout == ['u'] and fam.din == ['au']
 
@@ -311,3 +311,108 @@ def test_compute_time_step_rules():
     assert run(dt_adapt=[0.0, -2.0]) is None
     assert run(dt_adapt=[0.1, 0.2], dt_cfl=[1.0, 1.0]) == 0.1
     assert run(dt_cfl=[1.0, 2.0]) == 0.5 * 1.0 / 2.0
+
+
+class PyWCSPHStep(IntegratorStep):
+    """the WCSPH two-stage stepper as Python bodies (semantics of
+    integrator_step.py:38-93; cf. oracle/steppers.py): save the state, then
+    q = q0 + f*dt*aq with f = 1/2 and 1"""
+
+    def initialize(self, d_idx, d_x0, d_y0, d_z0, d_x, d_y, d_z, d_u0, d_v0, d_w0, d_u, d_v,
+                   d_w, d_rho0, d_rho):
+        d_x0[d_idx] = d_x[d_idx]
+        d_y0[d_idx] = d_y[d_idx]
+        d_z0[d_idx] = d_z[d_idx]
+        d_u0[d_idx] = d_u[d_idx]
+        d_v0[d_idx] = d_v[d_idx]
+        d_w0[d_idx] = d_w[d_idx]
+        d_rho0[d_idx] = d_rho[d_idx]
+
+    def stage1(self, d_idx, d_x0, d_y0, d_z0, d_x, d_y, d_z, d_u0, d_v0, d_w0, d_u, d_v, d_w,
+               d_rho0, d_rho, d_au, d_av, d_aw, d_ax, d_ay, d_az, d_arho, dt):
+        dtb2 = 0.5 * dt
+        d_u[d_idx] = d_u0[d_idx] + dtb2 * d_au[d_idx]
+        d_v[d_idx] = d_v0[d_idx] + dtb2 * d_av[d_idx]
+        d_w[d_idx] = d_w0[d_idx] + dtb2 * d_aw[d_idx]
+        d_x[d_idx] = d_x0[d_idx] + dtb2 * d_ax[d_idx]
+        d_y[d_idx] = d_y0[d_idx] + dtb2 * d_ay[d_idx]
+        d_z[d_idx] = d_z0[d_idx] + dtb2 * d_az[d_idx]
+        d_rho[d_idx] = d_rho0[d_idx] + dtb2 * d_arho[d_idx]
+
+    def stage2(self, d_idx, d_x0, d_y0, d_z0, d_x, d_y, d_z, d_u0, d_v0, d_w0, d_u, d_v, d_w,
+               d_rho0, d_rho, d_au, d_av, d_aw, d_ax, d_ay, d_az, d_arho, dt):
+        d_u[d_idx] = d_u0[d_idx] + dt * d_au[d_idx]
+        d_v[d_idx] = d_v0[d_idx] + dt * d_av[d_idx]
+        d_w[d_idx] = d_w0[d_idx] + dt * d_aw[d_idx]
+        d_x[d_idx] = d_x0[d_idx] + dt * d_ax[d_idx]
+        d_y[d_idx] = d_y0[d_idx] + dt * d_ay[d_idx]
+        d_z[d_idx] = d_z0[d_idx] + dt * d_az[d_idx]
+        d_rho[d_idx] = d_rho0[d_idx] + dt * d_arho[d_idx]
+
+
+class PyTVFStep(IntegratorStep):
+    """the transport-velocity kick-drift-kick stepper as Python bodies
+    (semantics of integrator_step.py:257-299)"""
+
+    def stage1(self, d_idx, d_u, d_v, d_w, d_au, d_av, d_aw, d_uhat, d_vhat, d_what, d_auhat,
+               d_avhat, d_awhat, d_x, d_y, d_z, dt):
+        dtb2 = 0.5 * dt
+        d_u[d_idx] += dtb2 * d_au[d_idx]
+        d_v[d_idx] += dtb2 * d_av[d_idx]
+        d_w[d_idx] += dtb2 * d_aw[d_idx]
+        d_uhat[d_idx] = d_u[d_idx] + dtb2 * d_auhat[d_idx]
+        d_vhat[d_idx] = d_v[d_idx] + dtb2 * d_avhat[d_idx]
+        d_what[d_idx] = d_w[d_idx] + dtb2 * d_awhat[d_idx]
+        d_x[d_idx] += dt * d_uhat[d_idx]
+        d_y[d_idx] += dt * d_vhat[d_idx]
+        d_z[d_idx] += dt * d_what[d_idx]
+
+    def stage2(self, d_idx, d_u, d_v, d_w, d_au, d_av, d_aw, d_vmag2, dt):
+        dtb2 = 0.5 * dt
+        d_u[d_idx] += dtb2 * d_au[d_idx]
+        d_v[d_idx] += dtb2 * d_av[d_idx]
+        d_w[d_idx] += dtb2 * d_aw[d_idx]
+        d_vmag2[d_idx] = (d_u[d_idx] * d_u[d_idx] + d_v[d_idx] * d_v[d_idx] +
+                          d_w[d_idx] * d_w[d_idx])
+
+
+def golden_stepper_array():
+    from conftest import load_golden
+    from test_integrator import STEP_PROPS, _pa_from
+    g = load_golden('steppers.npz')
+    return g, _pa_from(g), STEP_PROPS
+
+
+def prebuild_golden_steppers():
+    from pysph_amd.integrator import generated_stages
+    g, pa, _ = golden_stepper_array()
+    return sum(len(generated_stages(cls(), pa, 0, 1)) for cls in (PyWCSPHStep, PyTVFStep))
+
+
+@pytest.mark.gpu
+def test_generated_steppers_match_reference_golden_vectors():
+    """Python-bodied steppers through the generated path vs the outputs of the
+    reference's own WCSPHStep / TransportVelocityStep methods
+    (tests/golden/steppers.npz), stage by stage; fma contraction may move the
+    last bit."""
+    import ctypes as C
+    from pysph_amd import device as dev
+    from pysph_amd.integrator import generated_stages
+    g, _, props = golden_stepper_array()
+    dt = float(g['dt'])
+    kern = dev.SphKernel(1, 3, 1.0, 2.0, 0.5)
+    for cls, tag, names in ((PyWCSPHStep, 'wcsph', ['initialize', 'stage1', 'stage2']),
+                            (PyTVFStep, 'tvf', ['stage1', 'stage2'])):
+        _, pa, _ = golden_stepper_array()
+        ctx = dev.HipContext(0)
+        gpu = dev.attach(pa, ctx)
+        gpu.push()
+        stages = generated_stages(cls(), pa, gpu.array_id, 1)
+        for name in names:
+            st = stages[name]
+            dev._check(ctx.lib.sph_eval_generated(ctx._h, C.addressof(kern), C.addressof(st.cf),
+                                                  0.0, dt))
+            gpu.pull()
+            for k in props:
+                ref = g['%s/%s/%s' % (tag, name, k)]
+                assert np.allclose(pa.properties[k], ref, rtol=1e-15, atol=1e-16), (tag, name, k)
