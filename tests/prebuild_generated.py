@@ -81,12 +81,16 @@ def main():
     n += plan([ps], [Group(equations=[RS.InitializePair('fluid', ['fluid'])])], K.CubicSpline(dim=1))
     n += plan(RS.ghost_copy_arrays(), RS.ghost_copy_equations(), K.CubicSpline(dim=1))
     n += plan([T._correction_case()], T._correction_equations(), K.CubicSpline(dim=3))
+    import test_kernel_corrections as KC
+    for dim in (2, 3):
+        n += plan([KC.corner_particles(dim)], KC.correction_equations(dim), K.CubicSpline(dim=dim))
     import test_kernel_moments as KM
     for kname, dim in sorted(KM.PLACES):
         n += plan(list(KM.moment_arrays(2)), KM.moment_equations(), getattr(K, kname)(dim=dim))
     import test_reference_integrators as RI
     n += RI.prebuild()
     n += RI.prebuild_golden_steppers()
+    n += RI.prebuild_multi_stage()
     n += plan([RI.make_pa()], [RI.SHM(dest='fluid', sources=None)], K.CubicSpline(dim=1))
     return n
 

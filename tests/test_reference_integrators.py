@@ -416,3 +416,89 @@ def test_generated_steppers_match_reference_golden_vectors():
             for k in props:
                 ref = g['%s/%s/%s' % (tag, name, k)]
                 assert np.allclose(pa.properties[k], ref, rtol=1e-15, atol=1e-16), (tag, name, k)
+
+
+# ---------------------------------------------------------------------------
+# sph/tests/test_multi_group_integrator.py: one acceleration evaluator per stage
+# ---------------------------------------------------------------------------
+class Eq1(Equation):
+    def initialize(self, d_idx, d_au):
+        d_au[d_idx] = 1.0
+
+
+class Eq2(Equation):
+    def initialize(self, d_idx, d_au):
+        d_au[d_idx] += 1.0
+
+
+class TwoKickStep(IntegratorStep):
+    def stage1(self, d_idx, d_u, d_au, dt):
+        d_u[d_idx] += d_au[d_idx] * dt
+
+    def stage2(self, d_idx, d_u, d_au, dt):
+        d_u[d_idx] += d_au[d_idx] * dt
+
+
+def multi_stage_array():
+    from pysph_amd.particle_array import get_particle_array
+    n = 10
+    x = np.linspace(0, 1, n)
+    return get_particle_array(name='fluid', x=x, h=np.ones_like(x) * 1.05 / (n - 1),
+                              m=np.ones_like(x), au=0.0, u=0.0)
+
+
+def multi_stage_equations():
+    from pysph_amd.equations import MultiStageEquations
+    return MultiStageEquations([[Eq1(dest='fluid', sources=['fluid'])],
+                                [Eq2(dest='fluid', sources=['fluid'])]])
+
+
+def prebuild_multi_stage():
+    from pysph_amd import kernels as K
+    from pysph_amd.acceleration_eval import _CGroup, make_acceleration_evals
+    from pysph_amd.integrator import generated_stages
+    pa = multi_stage_array()
+    n = len(generated_stages(TwoKickStep(), pa, 0, 1))
+    for a in make_acceleration_evals([pa], multi_stage_equations(), K.CubicSpline(dim=1)):
+        for g in a.equation_groups:
+            n += len(_CGroup(g, {'fluid': 0}, {'fluid': pa}, 1).units)
+    return n
+
+
+@pytest.mark.gpu
+def test_different_accels_per_stage():
+    """test_multi_group_integrator.py:52-98: MultiStageEquations ->
+    make_acceleration_evals -> SPHCompiler with a user integrator calling
+    compute_accelerations(index, update_nnps=False)"""
+    from pysph_amd import device as dev
+    from pysph_amd import kernels as K
+    from pysph_amd.acceleration_eval import SPHCompiler, make_acceleration_evals
+    from pysph_amd.integrator import Integrator
+    from pysph_amd.nnps import HipNNPS
+
+    class TwoEvalIntegrator(Integrator):
+        def one_timestep(self, t, dt):
+            self.compute_accelerations(0, update_nnps=False)
+            self.stage1()
+            self.do_post_stage(dt, 1)
+            self.compute_accelerations(1, update_nnps=False)
+            self.stage2()
+            self.update_domain()
+            self.do_post_stage(dt, 2)
+
+    pa = multi_stage_array()
+    kernel = K.CubicSpline(dim=1)
+    a_evals = make_acceleration_evals([pa], multi_stage_equations(), kernel)
+    assert len(a_evals) == 2
+    integrator = TwoEvalIntegrator(fluid=TwoKickStep())
+    ctx = dev.HipContext(0)
+    SPHCompiler(a_evals, integrator=integrator, ctx=ctx).compile()
+    nnps = HipNNPS(kernel.dim, [pa], radius_scale=kernel.radius_scale, ctx=ctx)
+    nnps.update()
+    for ae in a_evals:
+        ae.set_nnps(nnps)
+    integrator.set_nnps(nnps)
+    integrator.step(0.0, 0.1)
+    one = np.ones_like(pa.x)
+    np.testing.assert_array_almost_equal(pa.au, 2.0 * one)
+    np.testing.assert_array_almost_equal(pa.u, 0.3 * one)
