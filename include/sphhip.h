@@ -140,6 +140,11 @@ int sph_prop_id(const char *name); /* -1 if unknown */
  * min(old, new).                                                           */
 int sph_array_resize(sph_ctx *ctx, int array_id, size_t n, size_t n_real);
 int sph_array_size(sph_ctx *ctx, int array_id, size_t *n, size_t *n_real);
+/* New particle i takes every device property of old particle indices[i]
+ * (host array of n_new indices < n); afterwards n = n_new, of which the first
+ * n_real_new are real.  DeviceHelper.align / remove_particles /
+ * align_particles (pysph/base/device_helper.py:241-345, :480-560).          */
+int sph_array_permute(sph_ctx *ctx, int array_id, const uint32_t *indices, size_t n_new, size_t n_real_new);
 /* Make sure property `prop` has device storage (zero-filled when created). */
 int sph_array_ensure_prop(sph_ctx *ctx, int array_id, int prop);
 /* host -> device / device -> host of n doubles starting at particle `offset`. */

@@ -510,6 +510,42 @@ __global__ __launch_bounds__(256) void k_gather_f64(const double *__restrict__ s
     if (i < n) dst[i] = src[perm[i]];
 }
 
+// DeviceHelper.align(indices) (pysph/base/device_helper.py:241-288): new particle i
+// takes every property of old particle indices[i]; n becomes n_new (<= old n drops
+// particles: remove_particles / remove_tagged_particles are "keep list" gathers).
+extern "C" int sph_array_permute(sph_ctx *c, int id, const uint32_t *indices, size_t n_new, size_t n_real_new)
+{
+    if (!c || id < 0 || id >= SPH_MAX_ARRAYS || (n_new && !indices) || n_real_new > n_new) {
+        sph_set_error("sph_array_permute: bad arguments");
+        return SPH_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    DevArray &A = c->arr[id];
+    if (n_new > A.n) { sph_set_error("sph_array_permute: %zu indices for %zu particles", n_new, A.n); return SPH_ERR_ARG; }
+    for (size_t i = 0; i < n_new; i++)
+        if (indices[i] >= A.n) { sph_set_error("sph_array_permute: index %u out of range (n=%zu)", indices[i], A.n); return SPH_ERR_ARG; }
+    if (n_new) {
+        SPH_TRY(c->aux.reserve(n_new * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpyAsync(c->aux.ptr, indices, n_new * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        double *tmp = nullptr;
+        HIP_TRY(hipMalloc((void **)&tmp, A.cap * sizeof(double)));
+        HIP_TRY(hipMemsetAsync(tmp, 0, A.cap * sizeof(double), c->stream));
+        for (int p = 0; p < SPH_PROP_COUNT; p++) {
+            if (!A.prop[p]) continue;
+            hipLaunchKernelGGL(k_gather_f64, dim3(div_up(n_new, 256)), dim3(256), 0, c->stream, A.prop[p],
+                               c->aux.as<uint32_t>(), n_new, tmp);
+            double *old = A.prop[p];
+            A.prop[p] = tmp;
+            tmp = old;
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(tmp));
+    }
+    A.perm_n = 0;
+    c->nnps_valid = false;
+    return sph_array_resize(c, id, n_new, n_real_new);
+}
+
 extern "C" int sph_nnps_reorder_array(sph_ctx *c, int id)
 {
     if (!c || id < 0 || id >= SPH_MAX_ARRAYS) { sph_set_error("sph_nnps_reorder_array: bad arguments"); return SPH_ERR_ARG; }

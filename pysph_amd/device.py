@@ -54,6 +54,8 @@ SIGNATURES = {
     'sph_array_size': (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t),
                                  C.POINTER(C.c_size_t)]),
     'sph_array_ensure_prop': (C.c_int, [_P, C.c_int, C.c_int]),
+    'sph_array_permute': (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint32), C.c_size_t,
+                                    C.c_size_t]),
     'sph_array_push': (C.c_int, [_P, C.c_int, C.c_int, _PD, C.c_size_t,
                                  C.c_size_t]),
     'sph_array_pull': (C.c_int, [_P, C.c_int, C.c_int, _PD, C.c_size_t,
@@ -254,9 +256,90 @@ def _as_f64(arr, name):
     return np.ascontiguousarray(arr)
 
 
+class DeviceProperty(object):
+    """``pa.gpu.x``: what the reference's DeviceHelper exposes as a compyle
+    Array (device_helper.py:96-128) -- ``get()`` / ``set()`` move the whole
+    property, ``[a:b].get()`` a range of particles.  Integer properties (tag,
+    pid, gid) are host-resident metadata of the device state and are served
+    from the host array."""
+
+    def __init__(self, helper, name, lo=0, hi=None):
+        self._h, self.name, self._lo, self._hi = helper, name, lo, hi
+
+    def _host(self):
+        return get_npy(self._h._pa, self.name)
+
+    def _stride(self):
+        return getattr(self._h._pa, 'stride', {}).get(self.name, 1)
+
+    @property
+    def dtype(self):
+        return self._host().dtype
+
+    @property
+    def data(self):
+        return self._h.device_ptr(self.name)
+
+    def __len__(self):
+        return self._h.get_number_of_particles() * self._stride()
+
+    def __getitem__(self, sl):
+        if not isinstance(sl, slice) or sl.step not in (None, 1):
+            raise IndexError('DeviceProperty: contiguous slices only')
+        lo, hi, _ = sl.indices(len(self))
+        return DeviceProperty(self._h, self.name, lo, hi)
+
+    def get(self):
+        h, host = self._h, self._host()
+        if host.dtype != np.float64 or (self._stride() == 1 and prop_id(self.name) < 0):
+            return host[self._lo:self._hi].copy()
+        stride, n = self._stride(), h.get_number_of_particles()
+        out = np.empty(n * stride)
+        if stride == 1:
+            h.pull_into(self.name, out)
+        else:
+            for k in range(stride):
+                col = np.empty(n)
+                _check(h.lib.sph_array_pull(h.ctx._h, h.array_id,
+                                            prop_register('%s__%d' % (self.name, k)),
+                                            col.ctypes.data_as(_PD), 0, n))
+                out[k::stride] = col
+        return out[self._lo:self._hi]
+
+    def __setitem__(self, key, value):
+        """``gpu.rho[0] = 1.0`` / ``gpu.tag[:] = 1``: read-modify-write of the
+        whole property (a convenience, not a fast path)"""
+        host = self._host()
+        if host.dtype != np.float64:
+            host[key] = value
+            return
+        cur = DeviceProperty(self._h, self.name).get()
+        cur[key] = value
+        DeviceProperty(self._h, self.name).set(cur)
+
+    def set(self, values):
+        h, host = self._h, self._host()
+        values = np.asarray(values)
+        if self._lo != 0 or self._hi is not None:
+            raise SphError('DeviceProperty.set: whole properties only')
+        if values.size != host.size:
+            raise SphError('%s.set: %d values for %d slots' % (self.name, values.size, host.size))
+        host[:] = values
+        if host.dtype == np.float64:
+            stride = self._stride()
+            h.push(*([self.name] if stride == 1 else
+                     ['%s__%d' % (self.name, k) for k in range(stride)]))
+
+
 class HipDeviceHelper(object):
-    """``pa.gpu`` for the HIP backend (DeviceHelper API subset:
-    device_helper.py:130 resize, :200 pull, :219 push, :170 max)."""
+    """``pa.gpu`` for the HIP backend: the DeviceHelper surface of
+    pysph/base/device_helper.py -- push/pull/resize/max/min (:130-239),
+    property access ``gpu.x.get()``, and the structural operations align,
+    align_particles, remove_particles, remove_tagged_particles, add_particles,
+    extend, append_parray, extract_particles, empty_clone (:241-672).  The
+    structural operations restructure the device arrays (``sph_array_permute``)
+    AND the host arrays, so the two stay the same shape; integer properties
+    (tag, pid, gid) live on the host."""
 
     def __init__(self, pa, ctx=None):
         self._pa = pa
@@ -277,6 +360,14 @@ class HipDeviceHelper(object):
 
     def resize(self, n=None):
         pa = self._pa
+        if n is not None and n != pa.get_number_of_particles() and not self.managed \
+                and hasattr(pa, 'resize'):
+            # an explicit device resize (device_helper.py:130-150) keeps the host
+            # array -- which holds the integer properties -- the same shape
+            grow = n > pa.get_number_of_particles()
+            nr0 = pa.get_number_of_particles(True)
+            pa.resize(n)
+            pa.set_num_real_particles(n if grow and nr0 == self._n else min(nr0, n))
         n = pa.get_number_of_particles() if n is None else n
         nreal = min(pa.get_number_of_particles(True), n)
         _check(self.lib.sph_array_resize(self.ctx._h, self.array_id, n, nreal))
@@ -309,6 +400,8 @@ class HipDeviceHelper(object):
         if not props:
             props = [p for p in pa.properties if prop_id(p) >= 0]
         for p in props:
+            if p in pa.properties and get_npy(pa, p).dtype != np.float64 and prop_id(p) < 0:
+                continue              # tag / pid / gid: host-resident metadata
             comp = self._component(p)
             if comp is not None:      # one component of a strided property
                 host, stride, k = comp
@@ -318,6 +411,8 @@ class HipDeviceHelper(object):
                     col.ctypes.data_as(_PD), 0, col.size))
                 continue
             pid = prop_id(p)
+            if pid < 0 and p in pa.properties:
+                pid = prop_register(p)          # a user property, pushed by name
             if pid < 0:
                 raise SphError('property %r has no device mirror' % p)
             arr = _as_f64(get_npy(pa, p), p)
@@ -331,6 +426,8 @@ class HipDeviceHelper(object):
         if not props:
             props = [p for p in pa.properties if prop_id(p) >= 0]
         for p in props:
+            if p in pa.properties and get_npy(pa, p).dtype != np.float64 and prop_id(p) < 0:
+                continue              # tag / pid / gid: host-resident metadata
             comp = self._component(p)
             if comp is not None:
                 host, stride, k = comp
@@ -400,6 +497,166 @@ class HipDeviceHelper(object):
         _check(self.lib.sph_array_device_ptr(self.ctx._h, self.array_id,
                                              prop_id(prop), C.byref(ptr)))
         return ptr.value
+
+    # -- DeviceHelper surface: properties as attributes ------------------------
+    def __getattr__(self, name):
+        if name.startswith('_'):
+            raise AttributeError(name)
+        pa = self.__dict__.get('_pa')
+        if pa is not None and name in pa.properties:
+            return DeviceProperty(self, name)
+        raise AttributeError('HipDeviceHelper has no attribute or property %r' % name)
+
+    @property
+    def properties(self):
+        return list(self._pa.properties)
+
+    # -- structural operations ---------------------------------------------------
+    def _host_take(self, idx):
+        """host arrays <- rows idx (all properties, stride-aware)"""
+        pa = self._pa
+        for key, arr in list(pa.properties.items()):
+            st = getattr(pa, 'stride', {}).get(key, 1)
+            pa.properties[key] = (arr[idx] if st == 1 else
+                                  arr.reshape(-1, st)[idx].ravel()).copy()
+        pa._n = int(len(idx))
+
+    def align(self, indices):
+        """new particle i = old particle indices[i] (device_helper.py:241-288);
+        fewer indices than particles drops the rest"""
+        idx = np.ascontiguousarray(np.asarray(indices).ravel(), dtype=np.uint32)
+        pa = self._pa
+        tag = get_npy(pa, 'tag')[idx]
+        nreal = int(np.count_nonzero(tag == 0))
+        if nreal and not np.all(tag[:nreal] == 0):
+            nreal = min(self.get_number_of_particles(True), idx.size)   # caller aligns later
+        _check(self.lib.sph_array_permute(
+            self.ctx._h, self.array_id, idx.ctypes.data_as(C.POINTER(C.c_uint32)),
+            idx.size, nreal))
+        self._host_take(idx.astype(np.int64))
+        pa.set_num_real_particles(nreal)
+        self._n = idx.size
+
+    def align_particles(self):
+        """real (Local) particles first, stable (device_helper.py:290-345)"""
+        tag = get_npy(self._pa, 'tag')
+        order = np.argsort(tag != 0, kind='stable')
+        self.align(order)
+        nreal = int(np.count_nonzero(get_npy(self._pa, 'tag') == 0))
+        self._pa.set_num_real_particles(nreal)
+        _check(self.lib.sph_array_resize(self.ctx._h, self.array_id, order.size, nreal))
+
+    def remove_particles(self, indices, align=True):
+        """device_helper.py:480-525"""
+        n = self.get_number_of_particles()
+        keep = np.ones(n, dtype=bool)
+        keep[np.asarray(indices, dtype=np.int64)] = False
+        self.align(np.nonzero(keep)[0])
+        if align:
+            self.align_particles()
+
+    def remove_tagged_particles(self, tag, align=True):
+        """device_helper.py:527-560"""
+        self.remove_particles(np.nonzero(get_npy(self._pa, 'tag') == tag)[0], align)
+
+    def extend(self, num_particles):
+        """num_particles new (Local, zero-valued) particles at the end
+        (device_helper.py:596-610)"""
+        if num_particles <= 0:
+            return
+        pa = self._pa
+        n0 = self.get_number_of_particles()
+        pa.resize(n0 + num_particles)
+        get_npy(pa, 'tag')[n0:] = 0
+        _check(self.lib.sph_array_resize(self.ctx._h, self.array_id, n0 + num_particles,
+                                         self.get_number_of_particles(True)))
+        self._n = n0 + num_particles
+
+    def add_particles(self, align=True, **particle_props):
+        """device_helper.py:562-594: append particles with the given property
+        values (others default), then align"""
+        if not particle_props:
+            return
+        pa = self._pa
+        count = max(np.asarray(v).size // getattr(pa, 'stride', {}).get(k, 1)
+                    for k, v in particle_props.items())
+        n0 = self.get_number_of_particles()
+        self.extend(count)
+        for key, val in particle_props.items():
+            st = getattr(pa, 'stride', {}).get(key, 1)
+            get_npy(pa, key)[n0 * st:] = np.asarray(val).ravel()
+        self._push_range(n0, n0 + count)
+        if align:
+            self.align_particles()
+
+    def _push_range(self, lo, hi):
+        pa = self._pa
+        for key, arr in pa.properties.items():
+            if arr.dtype != np.float64:
+                continue
+            st = getattr(pa, 'stride', {}).get(key, 1)
+            for k in range(st):
+                name = key if st == 1 else '%s__%d' % (key, k)
+                pid = prop_id(name)
+                if pid < 0:
+                    continue
+                dptr = _P()
+                _check(self.lib.sph_array_device_ptr(self.ctx._h, self.array_id, pid,
+                                                     C.byref(dptr)))
+                col = np.ascontiguousarray(arr[lo * st + k:hi * st:st] if st > 1 else arr[lo:hi])
+                _check(self.lib.sph_array_push(self.ctx._h, self.array_id, pid,
+                                               col.ctypes.data_as(_PD), lo, hi - lo))
+
+    def append_parray(self, parray, align=True, update_constants=False):
+        """device_helper.py:612-640"""
+        n1 = parray.get_number_of_particles()
+        if n1 == 0:
+            return
+        pa = self._pa
+        n0 = self.get_number_of_particles()
+        self.extend(n1)
+        for key in pa.properties:
+            if key in parray.properties:
+                st = getattr(pa, 'stride', {}).get(key, 1)
+                get_npy(pa, key)[n0 * st:] = get_npy(parray, key)
+        self._push_range(n0, n0 + n1)
+        if align:
+            self.align_particles()
+
+    def empty_clone(self, props=None):
+        """a particle array with the same properties and no particles
+        (device_helper.py:642-658)"""
+        from .particle_array import ParticleArray
+        pa = self._pa
+        out = ParticleArray(name=pa.name)
+        for key, arr in pa.properties.items():
+            if props is None or key in props or key in ('tag', 'pid', 'gid'):
+                st = getattr(pa, 'stride', {}).get(key, 1)
+                out.properties[key] = np.empty(0, dtype=arr.dtype)
+                if st != 1:
+                    out.stride[key] = st
+        for key, val in pa.constants.items():
+            out.constants[key] = val.copy()
+        return out
+
+    def extract_particles(self, indices, dest_array=None, align=True, props=None):
+        """the DEVICE values of the chosen particles as a (host) particle array
+        (device_helper.py:660-672)"""
+        idx = np.asarray(indices, dtype=np.int64).ravel()
+        pa = self._pa
+        out = dest_array if dest_array is not None else self.empty_clone(props)
+        n0 = out.get_number_of_particles()
+        out.resize(n0 + idx.size)
+        for key in out.properties:
+            if key not in pa.properties:
+                continue
+            st = getattr(pa, 'stride', {}).get(key, 1)
+            vals = DeviceProperty(self, key).get()
+            vals = vals[idx] if st == 1 else vals.reshape(-1, st)[idx].ravel()
+            out.properties[key][n0 * st:] = vals
+        if align:
+            out.align_particles()
+        return out
 
 
 _HELPERS = {}
