@@ -18,6 +18,8 @@ import numpy as np
 
 from . import device as dev
 
+from .particle_array import get_npy
+
 _XYZH = ('x', 'y', 'z', 'h')
 
 
@@ -134,6 +136,12 @@ class HipNNPS(object):
             self._csr_key = key
         start, idx = self._csr
         out = idx[start[d_idx]:start[d_idx + 1]].copy()
+        if self.sort_gids and out.size:
+            # nnps_base.pyx:1577-1611 _sort_neighbors: by gid when the source
+            # has valid gids, by index otherwise (gids[0] == UINT_MAX)
+            gid = np.asarray(get_npy(self.particles[src_index], 'gid'))
+            if gid.size and gid[0] != np.iinfo(np.uint32).max:
+                out = out[np.argsort(gid[out], kind='stable')]
         if nbrs is not None and hasattr(nbrs, 'set_data'):
             nbrs.set_data(out)
         return out
