@@ -63,6 +63,19 @@ class _DomainBase(object):
     ymax = property(lambda self: self.lims[1][1])
     zmin = property(lambda self: self.lims[2][0])
     zmax = property(lambda self: self.lims[2][1])
+    periodic_in_x = property(lambda self: self.periodic[0])
+    periodic_in_y = property(lambda self: self.periodic[1])
+    periodic_in_z = property(lambda self: self.periodic[2])
+    mirror_in_x = property(lambda self: self.mirror[0])
+    mirror_in_y = property(lambda self: self.mirror[1])
+    mirror_in_z = property(lambda self: self.mirror[2])
+
+    @property
+    def manager(self):
+        """the reference's DomainManager is a facade over a CPU/GPU manager
+        (``domain.manager.periodic_in_x``, nnps_base.pyx:227-290); here the
+        object is its own manager"""
+        return self
 
     def set_particles(self, particles, radius_scale):
         self.particles = list(particles)

@@ -266,3 +266,126 @@ def test_device_mirror_matches_host(oracle):
     for prop in outs:
         e = rel_err(pa.properties[prop][:nreal], ref[0].properties[prop][:nreal])
         assert e < 1e-10, (prop, e)
+
+
+# ---------------------------------------------------------------------------
+# pysph/base/tests/test_periodic_nnps.py: fluid between two plates, periodic
+# along the channel (two particle arrays share the periodic images)
+# ---------------------------------------------------------------------------
+def periodic_channel_2d(n=100):
+    """test_periodic_nnps.py:30-77"""
+    from pysph_amd.particle_array import get_particle_array
+    L, hdx = 1.0, 1.5
+    dx = L / n
+    _x = np.arange(dx / 2, L, dx)
+    xx, yy = np.meshgrid(_x, _x)
+    x, y = xx.ravel(), yy.ravel()
+    fluid = get_particle_array(name='fluid', x=x, y=y, h=np.ones_like(x) * hdx * dx,
+                               m=np.ones_like(x) * dx * dx, V=np.zeros_like(x))
+    xt, yt = [a.ravel() for a in np.meshgrid(_x, np.arange(L + dx / 2, L + dx / 2 + 10 * dx, dx))]
+    xb, yb = [a.ravel() for a in np.meshgrid(_x, np.arange(-dx / 2, -dx / 2 - 10 * dx, -dx))]
+    x, y = np.concatenate((xt, xb)), np.concatenate((yt, yb))
+    channel = get_particle_array(name='channel', x=x, y=y, h=np.ones_like(x) * hdx * dx,
+                                 m=np.ones_like(x) * dx * dx, V=np.zeros_like(x))
+    return [fluid, channel], dx * dx
+
+
+def channel_density_equations():
+    from pysph_amd.equations import Group, TVFSummationDensity
+    return [Group(equations=[TVFSummationDensity(dest='fluid', sources=['fluid', 'channel'])])]
+
+
+def check_channel(fluid, vol, nreal):
+    """test_periodic_nnps.py:143-147: number density and density by summation,
+    to six places, for EVERY fluid particle (also those next to the periodic
+    faces and next to the plates)"""
+    V, rho, m = fluid.V[:nreal], fluid.rho[:nreal], fluid.m[:nreal]
+    assert np.max(np.abs(1.0 / V - vol)) < 0.5e-6
+    assert np.max(np.abs(rho - m / (1.0 / V))) < 0.5e-6
+
+
+def test_host_periodic_channel_two_arrays(oracle):
+    from pysph_amd import kernels as K
+    from pysph_amd.domain import DomainManager
+    arrays, vol = periodic_channel_2d(40)
+    kernel = K.Gaussian(dim=2)
+    dom = DomainManager(xmin=0, xmax=1.0, periodic_in_x=True)
+    assert dom.is_periodic and dom.periodic_in_x and not dom.periodic_in_y and not dom.periodic_in_z
+    dom.set_particles(arrays, kernel.radius_scale)
+    dom.update()
+    nreal = arrays[0].get_number_of_particles(True)
+    assert all(a.get_number_of_particles() > a.get_number_of_particles(True) for a in arrays)
+    nn = oracle.OracleNNPS(2, arrays, kernel.radius_scale)
+    nn.update()
+    ev = oracle.OracleEval(arrays, channel_density_equations(), kernel, nthreads=8)
+    ev.set_nnps(nn)
+    ev.compute(0.0, 0.1)
+    check_channel(arrays[0], vol, nreal)
+
+
+@pytest.mark.gpu
+def test_device_periodic_channel_two_arrays():
+    """the reference's full-size case (n = 100: 10 000 fluid + 2 000 plate
+    particles) with device-resident periodic images of BOTH arrays"""
+    from pysph_amd import device as dev
+    from pysph_amd import kernels as K
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.domain import HipDomainManager
+    from pysph_amd.nnps import HipNNPS
+    arrays, vol = periodic_channel_2d(100)
+    kernel = K.Gaussian(dim=2)
+    ctx = dev.HipContext(0)
+    for a in arrays:
+        dev.attach(a, ctx).push()
+    a_eval = AccelerationEval(arrays, channel_density_equations(), kernel)
+    SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+    dom = HipDomainManager(ctx=ctx, xmin=0, xmax=1.0, periodic_in_x=True)
+    nnps = HipNNPS(2, arrays, radius_scale=kernel.radius_scale, ctx=ctx, domain=dom, sync=False)
+    assert dom.is_periodic and dom.periodic_in_x and not dom.periodic_in_y
+    a_eval.set_nnps(nnps)
+    a_eval.compute(0.0, 0.1)
+    fluid = arrays[0]
+    nreal = fluid.gpu.get_number_of_particles(True)
+    assert nreal == 10000 and fluid.gpu.get_number_of_particles() > nreal
+    fluid.gpu.pull('V', 'rho')
+    check_channel(fluid, vol, nreal)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('axes', ['xyz', 'z', 'xy'])
+def test_device_periodic_3d_flag_combinations(axes):
+    """test_periodic_nnps.py:227-310: the flag combinations; for each, a
+    lattice filling the periodic directions has the lattice number density on
+    every particle away from the open faces"""
+    from pysph_amd import device as dev
+    from pysph_amd import kernels as K
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.domain import HipDomainManager
+    from pysph_amd.equations import Group, TVFSummationDensity
+    from pysph_amd.nnps import HipNNPS
+    pa, dx = lattice(12, dim=3, hdx=1.5)
+    for p in ('x', 'y', 'z'):
+        pa.properties[p] -= 0.5                     # box [-1/2, 1/2]^3 as in the reference
+    kernel = K.Gaussian(dim=3)
+    kw = {}
+    for ax in axes:
+        kw.update({ax + 'min': -0.5, ax + 'max': 0.5, 'periodic_in_' + ax: True})
+    ctx = dev.HipContext(0)
+    dev.attach(pa, ctx).push()
+    a_eval = AccelerationEval([pa], [Group(equations=[TVFSummationDensity('fluid', ['fluid'])])],
+                              kernel)
+    SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+    dom = HipDomainManager(ctx=ctx, **kw)
+    nnps = HipNNPS(3, [pa], radius_scale=kernel.radius_scale, ctx=ctx, domain=dom, sync=False)
+    assert (dom.periodic_in_x, dom.periodic_in_y, dom.periodic_in_z) == \
+        ('x' in axes, 'y' in axes, 'z' in axes)
+    a_eval.set_nnps(nnps)
+    a_eval.compute(0.0, 0.1)
+    nreal = pa.gpu.get_number_of_particles(True)
+    pa.gpu.pull('V')
+    inner = np.ones(nreal, dtype=bool)
+    for ax in 'xyz':
+        if ax not in axes:                          # open direction: stay 3h from the faces
+            inner &= np.abs(pa.properties[ax][:nreal]) < 0.5 - 3.2 * 1.5 * dx
+    assert inner.any()
+    assert np.max(np.abs(1.0 / pa.V[:nreal][inner] - dx ** 3)) < 0.5e-6
