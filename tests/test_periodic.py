@@ -389,3 +389,118 @@ def test_device_periodic_3d_flag_combinations(axes):
             inner &= np.abs(pa.properties[ax][:nreal]) < 0.5 - 3.2 * 1.5 * dx
     assert inner.any()
     assert np.max(np.abs(1.0 / pa.V[:nreal][inner] - dx ** 3)) < 0.5e-6
+
+
+# ---------------------------------------------------------------------------
+# pysph/base/tests/test_domain_manager.py: periodic box, every property of a
+# ghost is the property of its original; box wrapping of particles that left
+# ---------------------------------------------------------------------------
+def periodic_box(dim, n=10):
+    """test_domain_manager.py:30-57, :249-293; p = mod(x) + mod(y) + mod(z)"""
+    from pysph_amd.particle_array import get_particle_array
+    L, hdx = 1.0, 1.5
+    dx = L / n
+    _x = np.arange(dx / 2, L, dx)
+    if dim == 2:
+        x, y = [a.ravel() for a in np.meshgrid(_x, _x)]
+        z = np.zeros_like(x)
+    else:
+        x, y, z = [a.ravel() for a in np.meshgrid(_x, _x, _x)]
+    p = np.mod(x, L) + np.mod(y, L) + np.mod(z, L)
+    pa = get_particle_array(name='fluid', x=x, y=y, z=z, h=np.ones_like(x) * hdx * dx,
+                            m=np.ones_like(x) * dx ** dim, V=np.zeros_like(x), p=p)
+    kw = dict(xmin=0, xmax=L, ymin=0, ymax=L, periodic_in_x=True, periodic_in_y=True)
+    if dim == 3:
+        kw.update(zmin=0, zmax=L, periodic_in_z=True)
+    return pa, dx ** dim, kw
+
+
+@pytest.mark.parametrize('dim', [2, 3])
+def test_host_ghosts_carry_every_property_and_box_wrapping(oracle, dim):
+    from pysph_amd import kernels as K
+    from pysph_amd.domain import DomainManager
+    from pysph_amd.equations import Group, TVFSummationDensity
+    pa, vol, kw = periodic_box(dim, 10 if dim == 2 else 8)
+    kernel = K.Gaussian(dim=dim)
+    orig_n = pa.get_number_of_particles()
+    dom = DomainManager(**kw)
+    dom.set_particles([pa], kernel.radius_scale)
+    dom.update()
+    # test_periodicity (:216-237): images beyond every periodic face, with the
+    # pressure of the particle they are an image of
+    assert pa.get_number_of_particles() > orig_n
+    for ax in 'xyz'[:dim]:
+        v = pa.properties[ax]
+        assert v.min() < 0.0 and v.max() > 1.0
+    expect = np.mod(pa.x, 1.0) + np.mod(pa.y, 1.0) + np.mod(pa.z, 1.0)
+    assert np.allclose(pa.p, expect, atol=1e-14)
+    # test_box_wrapping (:209-214): move everything by 0.35, update, density unchanged
+    n = pa.get_number_of_particles(True)
+    pa.x[:n] += 0.35
+    pa.y[:n] += 0.35
+    dom.update()
+    n = pa.get_number_of_particles(True)
+    assert n == orig_n and pa.x[:n].max() <= 1.0 and pa.x[:n].min() >= 0.0
+    nn = oracle.OracleNNPS(dim, [pa], kernel.radius_scale)
+    nn.update()
+    ev = oracle.OracleEval([pa], [Group(equations=[TVFSummationDensity('fluid', ['fluid'])])],
+                           kernel, nthreads=4)
+    ev.set_nnps(nn)
+    ev.compute(0.0, 0.1)
+    V, rho = pa.V[:n], pa.rho[:n]
+    assert np.max(np.abs(1.0 / V - vol)) < 0.5e-5                 # :115 (5 places)
+    assert np.max(np.abs(rho - pa.m[:n] * V)) < 0.5e-14           # :116 (14 places)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dim', [2, 3])
+def test_device_ghosts_carry_every_property_and_box_wrapping(dim):
+    from pysph_amd import device as dev
+    from pysph_amd import kernels as K
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.domain import HipDomainManager
+    from pysph_amd.equations import Group, TVFSummationDensity
+    from pysph_amd.nnps import HipNNPS
+    pa, vol, kw = periodic_box(dim, 10 if dim == 2 else 8)
+    kernel = K.Gaussian(dim=dim)
+    orig_n = pa.get_number_of_particles()
+    ctx = dev.HipContext(0)
+    dev.attach(pa, ctx).push()
+    a_eval = AccelerationEval([pa], [Group(equations=[TVFSummationDensity('fluid', ['fluid'])])],
+                              kernel)
+    SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+    dom = HipDomainManager(ctx=ctx, **kw)
+    nnps = HipNNPS(dim, [pa], radius_scale=kernel.radius_scale, ctx=ctx, domain=dom, sync=False)
+    a_eval.set_nnps(nnps)
+    n_all = pa.gpu.get_number_of_particles()
+    assert n_all > orig_n and pa.gpu.get_number_of_particles(True) == orig_n
+    x, y, z, p = [getattr(pa.gpu, k).get() for k in ('x', 'y', 'z', 'p')]
+    for v in (x, y, z)[:dim]:
+        assert v.min() < 0.0 and v.max() > 1.0
+    assert np.allclose(p, np.mod(x, 1.0) + np.mod(y, 1.0) + np.mod(z, 1.0), atol=1e-14)
+    # everything moves by 0.35: wrapped back into the box, density as before
+    shifted = pa.gpu.x.get()
+    shifted[:orig_n] += 0.35
+    _push_all(pa, 'x', shifted)
+    shifted = pa.gpu.y.get()
+    shifted[:orig_n] += 0.35
+    _push_all(pa, 'y', shifted)
+    nnps.update_domain()
+    nnps.update()
+    a_eval.compute(0.0, 0.1)
+    x = pa.gpu.x.get()[:orig_n]
+    assert x.max() <= 1.0 and x.min() >= 0.0
+    V = pa.gpu.V.get()[:orig_n]
+    rho = pa.gpu.rho.get()[:orig_n]
+    assert np.max(np.abs(1.0 / V - vol)) < 0.5e-5
+    assert np.max(np.abs(rho - pa.m[:orig_n] * V)) < 0.5e-14
+
+
+def _push_all(pa, prop, values):
+    """overwrite a device property including its ghost tail"""
+    import ctypes as C
+    from pysph_amd import device as dev
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    dev._check(pa.gpu.lib.sph_array_push(pa.gpu.ctx._h, pa.gpu.array_id, dev.prop_id(prop),
+                                         values.ctypes.data_as(C.POINTER(C.c_double)), 0,
+                                         values.size))
