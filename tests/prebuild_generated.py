@@ -37,6 +37,9 @@ def main():
     for kname in ('CubicSpline', 'Gaussian'):
         arrays, eqs = T._custom_setup(0.0)
         n += plan(arrays, eqs, getattr(K, kname)(dim=3))
+    for kname in ('CubicSpline', 'WendlandQuintic', 'QuinticSpline', 'Gaussian'):
+        arrays, eqs, dim, _ = T._random_generated_case(7)
+        n += plan(arrays, eqs, getattr(K, kname)(dim=3))
     pa, dx = T.make_cube(6)
     for tensile in (False, True):
         kw = dict(c0=32.85, alpha=0.25, beta=0.1, gz=-9.81, tensile_correction=tensile)

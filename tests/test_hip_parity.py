@@ -1419,3 +1419,74 @@ def test_generated_matrix_helpers_unrolled_components_and_symbol_rewrite(oracle)
     fit = pa.pfit.reshape(-1, 4)
     assert np.abs(fit[:, 0] - pa.p).max() < 1e-9
     assert np.abs(fit[:, 1:] - np.array([2.0, -3.0, 1.0])).max() < 1e-8
+
+
+def _random_generated_case(seed):
+    """problem shape drawn from the seed; the equations are the made-up ones of
+    tests/custom_equations.py (every translator construct)"""
+    from custom_equations import KitchenSink, PowerLawState, WallPush
+    from pysph_amd.equations import Group
+    from pysph_amd.particle_array import get_particle_array
+    rng = np.random.default_rng(5000 + seed)
+    dim = int(rng.choice([1, 2, 3], p=[0.2, 0.4, 0.4]))
+    n = int(rng.choice([1, 5, 60, 250]))
+    kname = str(rng.choice(['CubicSpline', 'WendlandQuintic', 'QuinticSpline', 'Gaussian']))
+    if kname == 'WendlandQuintic' and dim == 1:
+        kname = 'QuinticSpline'
+    varh = float(rng.choice([0.0, 0.0, 0.2]))
+    clustered = bool(rng.integers(2))
+    spacing = 1.0 / max(n, 2) ** (1.0 / dim)
+    arrays = []
+    for name, m in (('fluid', n), ('solid', int(rng.choice([0, 1, max(n // 4, 1)])))):
+        c = rng.uniform(0, 1, (m, 3))
+        if clustered:
+            c = c ** 2.0
+        c[:, dim:] = 0.0
+        pa = get_particle_array(
+            name=name, constants=dict(coef=np.array([1.25, -0.5])),
+            x=c[:, 0], y=c[:, 1], z=c[:, 2],
+            u=rng.uniform(-1, 1, m), v=rng.uniform(-1, 1, m), w=rng.uniform(-1, 1, m),
+            h=1.2 * spacing * (1 + varh * rng.uniform(-1, 1, m)),
+            m=spacing ** dim * np.ones(m), rho=1 + 0.1 * rng.uniform(-1, 1, m),
+            additional_props=['q', 'gx', 'gy', 'gz', 'e'])
+        for k in ('q', 'gx', 'gy', 'gz', 'e', 'p'):
+            pa.properties[k][:] = rng.uniform(1, 2, m)
+        arrays.append(pa)
+    real = bool(rng.integers(2))
+    start = int(rng.integers(0, max(n // 3, 1)))
+    stop = None if rng.integers(2) else int(rng.integers(start, n + 1))
+    eqs = [
+        Group(real=False, equations=[PowerLawState('fluid', None, k=1.5, n=1.4),
+                                     PowerLawState('solid', None, k=0.5, n=2.0)]),
+        Group(real=real, start_idx=start, stop_idx=stop, equations=[
+            KitchenSink('fluid', ['fluid', 'solid'], a=0.3, b=0.05, flag=bool(rng.integers(2))),
+            WallPush('fluid', ['solid'], c=0.7)]),
+        Group(equations=[KitchenSink('solid', ['fluid'], a=0.1, b=2.0, flag=False)]),
+    ]
+    return arrays, eqs, dim, kname
+
+
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('SPH_FUZZ_SEEDS', '12')))))
+def test_randomised_generated_families_vs_python(oracle, seed):
+    """the generated-family path under randomly drawn dimension / kernel /
+    particle distribution / per-particle h / empty and one-particle arrays /
+    Group(real, start_idx, stop_idx), against the same Python bodies run by
+    oracle/py_eval.py"""
+    from oracle.py_eval import PyEval
+    from pysph_amd import kernels as K
+    arrays, eqs, dim, kname = _random_generated_case(seed)
+    ref = _copy_arrays(arrays)
+    for r, a in zip(ref, arrays):
+        r.constants = dict((k, v.copy()) for k, v in a.constants.items())
+    kernel = getattr(K, kname)(dim=dim)
+    a_eval, nnps, ctx = make_eval(arrays, eqs, kernel, dim)
+    a_eval.compute(0.25, 1e-3)
+    onn = oracle.OracleNNPS(dim, ref, radius_scale=kernel.radius_scale)
+    onn.update()
+    PyEval(ref, eqs, kernel, onn).compute(0.25, 1e-3)
+    for pa, pr in zip(arrays, ref):
+        for prop in ('p', 'e', 'q', 'gx', 'gy', 'gz'):
+            got, want = pa.properties[prop], pr.properties[prop]
+            if got.size:
+                scale = max(np.abs(want).max(), 1e-300)
+                assert np.abs(got - want).max() <= TOL * scale, (seed, dim, kname, pa.name, prop)
