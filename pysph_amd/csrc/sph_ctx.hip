@@ -251,7 +251,6 @@ int sph_set_option(sph_ctx *c, const char *key, long value)
     }
     if (strcmp(key, "uniform_h") == 0) { c->use_uniform_h = value; return SPH_OK; }
     if (strcmp(key, "record_f32") == 0) { c->record_f32 = value ? 1 : 0; return SPH_OK; }
-    if (strcmp(key, "lds_records") == 0) { c->lds_records = value ? 1 : 0; return SPH_OK; }
     if (strcmp(key, "tile_block_rows") == 0) {
         if (value < 0 || value > 4096) { sph_set_error("tile_block_rows out of range"); return SPH_ERR_ARG; }
         c->tile_block_rows = value; c->nnps_valid = false; return SPH_OK;

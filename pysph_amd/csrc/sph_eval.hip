@@ -1051,20 +1051,6 @@ template <class Fam> static void launch_pair(sph_ctx *c, int kk, const PairArgs<
 {
     if (a.nd == 0) return;
     const bool uh = c->uniform_h && c->use_uniform_h;
-    if (c->pair_variant == 3 && c->lds_records && !c->record_f32) {
-        dim3 g2(div_up(a.nd, ABS)), b2(ABS);
-#define LAUNCH5(K)                                                                                      \
-        if (uh) hipLaunchKernelGGL((k_pair_lds<Fam, K, true>), g2, b2, 0, c->stream, a);                \
-        else hipLaunchKernelGGL((k_pair_lds<Fam, K, false>), g2, b2, 0, c->stream, a)
-        switch (kk) {
-        case 1: LAUNCH5(1); break;
-        case 2: LAUNCH5(2); break;
-        case 3: LAUNCH5(3); break;
-        case 4: LAUNCH5(4); break;
-        }
-#undef LAUNCH5
-        return;
-    }
     if (c->pair_variant == 3) {
         dim3 g2(div_up(a.nd, ABS)), b2(ABS);
 #define LAUNCH3(K)                                                                                      \

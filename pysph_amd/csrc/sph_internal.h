@@ -95,7 +95,6 @@ struct sph_ctx {
     long pair_variant = 3;
     long ablate = 0;
     long use_uniform_h = 1;
-    long lds_records = 0;   // experimental variant 5: candidate records staged in LDS
     long record_f32 = 0;    // packed records in fp32 (inputs rounded, arithmetic fp64): aggregated kernel only
     long tile_block_rows = 8; // destination tiles are traversed in blocks of this many cell rows (y) through all z planes; 0: memory order
     double cur_dt = 0.0;    // dt of the sph_eval_group call being set up

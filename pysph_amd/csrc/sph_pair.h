@@ -435,239 +435,3 @@ __global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_agg(PairArg
     if (active) Fam::finish(D, a, o);
 }
 
-
-// ---------------------------------------------------------------------------
-// variant 5 (experimental, option "lds_records"): like variant 3, but the
-// candidate RECORDS of the three rows of one dz plane are staged in LDS with
-// coalesced loads and phase 2 reads each hit's record with ds_read instead of a
-// per-lane gather from L2.  Hits are aggregated over the three rows of a plane
-// (not nine).  62 KB of records per workgroup -> 2 workgroups per CU, 256 VGPRs.
-// Rows that do not fit one tile / one record buffer take the gather path.
-// ---------------------------------------------------------------------------
-#define LROWB 16640 // bytes of one staged row of records (208 records of 80 B)
-#define LQ 4        // mask slots per flush (3 rows + one overflow tile)
-
-template <class Fam, int KK, bool UH>
-__global__ __launch_bounds__(ABS, 2) void k_pair_lds(PairArgs<Fam> a)
-{
-    const uint32_t NR = (uint32_t)a.nrec;
-    constexpr int TS = ACAP + 8;
-    __shared__ __attribute__((aligned(16))) float tile[(UH ? 3 : 4) * TS];
-    float *const tx = tile, *const ty = tile + TS, *const tz = tile + 2 * TS, *const tw = tile + (UH ? 0 : 3 * TS);
-    __shared__ uint32_t csl[72];
-    __shared__ unsigned long long mlo[LQ][ABS];
-    __shared__ uint32_t mhi[LQ][ABS];
-    __shared__ unsigned short mofs[LQ][ABS];
-    __shared__ uint32_t qbase[LQ];
-    __shared__ int qbuf[LQ]; // record buffer of the slot, or -1: gather from memory
-    __shared__ int wx[2 * (ABS / 64) + 2];
-    __shared__ __attribute__((aligned(16))) double recs[3][LROWB / 8];
-
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    uint32_t dtile = xcd_tile(blockIdx.x, gridDim.x);
-    if (a.d_tile_order) dtile = a.d_tile_order[dtile];
-    const uint32_t i = dtile * ABS + t;
-    const bool valid = i < a.nd;
-    const uint32_t ic = valid ? i : a.nd - 1;
-    const uint32_t o = a.d_perm[ic];
-    const bool active = valid && o >= a.d_start && o < a.d_stop;
-    double4 pi;
-    typename Fam::Dest D;
-    {
-        double sd_[Fam::NA];
-        load_record<Fam, UH>(a.rec + (size_t)(a.d_off + ic) * NR, a.dflags, pi, sd_);
-        if (UH) pi.w = a.hu;
-        Fam::load(D, sd_, a, o);
-    }
-    const uint32_t key = a.d_keys[ic];
-    const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
-    const int cx = key % ncx;
-    const int row = key / ncx;
-    const double hi_r = a.radius_scale * pi.w;
-    const double hi2 = UH ? a.hr2u : hi_r * hi_r;
-    const int lcap = (int)(LROWB / (NR * 8)); // records per staged row
-
-    if (t == 0) wx[2 * (ABS / 64)] = row;
-    if (t == ABS - 1) wx[2 * (ABS / 64) + 1] = row;
-    __syncthreads();
-    const int row_first = wx[2 * (ABS / 64)], row_last = wx[2 * (ABS / 64) + 1];
-
-    auto pair_of = [&](const double4 &pj, const double (&sj)[Fam::NA], uint32_t flags) {
-        double hj2 = hi2;
-        if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
-        const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-        if (((r2 < hi2) || (r2 < hj2)) && a.ablate != 1) Fam::template pair<KK, UH>(D, pi, pj, r2, sj, flags, a);
-    };
-    auto do_pair = [&](uint32_t jg, uint32_t flags) { // record gathered from memory
-        double4 pj;
-        double sj[Fam::NA];
-        load_record<Fam, UH>(a.rec + (unsigned long long)jg * NR, flags, pj, sj);
-        pair_of(pj, sj, flags);
-    };
-
-    for (int R = row_first; R <= row_last; R++) {
-        const bool inseg = active && row == R;
-        const unsigned long long segm = __ballot(inseg);
-        int cxa_w = 0x7fffffff, cxb_w = -1;
-        if (segm) {
-            cxa_w = __builtin_amdgcn_readlane(cx, __builtin_ctzll(segm));
-            cxb_w = __builtin_amdgcn_readlane(cx, 63 - __builtin_clzll(segm));
-        }
-        __syncthreads();
-        if (lane == 0) { wx[2 * wv] = cxa_w; wx[2 * wv + 1] = cxb_w; }
-        __syncthreads();
-        int cxa = wx[0], cxb = wx[1];
-#pragma unroll
-        for (int w2 = 1; w2 < ABS / 64; w2++) { cxa = min(cxa, wx[2 * w2]); cxb = max(cxb, wx[2 * w2 + 1]); }
-        if (cxb < 0) continue;
-        const int cyR = R % ncy, czR = R / ncy;
-        const int xa = max(cxa - 1, 0), xb = min(cxb + 1, ncx - 1);
-        const int ncs = xb - xa + 2;
-        const float oxf = (float)(a.cell_size * xa);
-        const float oyf = (float)(a.cell_size * (cyR - 1));
-        const float ozf = (float)(a.cell_size * (czR - 1));
-        const double L = fmax(a.cell_size * (double)max(xb - xa + 2, 4), a.dom_extent);
-        const float slack = (float)(L * 1.5e-6);
-        const float4 fpi = a.fpos[a.d_off + ic];
-        const float fxs = fpi.x - oxf, fys = fpi.y - oyf, fzs = fpi.z - ozf;
-        const f2 fx = {fxs, fxs}, fy = {fys, fys}, fz = {fzs, fzs};
-        const float hif = (float)hi_r * 1.000001f + slack;
-        const float hi2f = hif * hif;
-        const int mycl = max(cx - 1, xa) - xa, mych = min(cx + 1, xb) + 1 - xa;
-
-        for (int s = 0; s < a.nsrc; s++) {
-            const SrcDesc sd = a.src[s];
-            int nq = 0, nbuf = 0;
-            auto phase2 = [&]() {
-                if (a.ablate != 2 && nq > 0) {
-                    // aggregated over the slots of this plane: every lane pops its own hit bits
-                    // back to back, slot after slot (no wave-wide synchronisation per row)
-                    int q = 0;
-                    unsigned long long m0 = mlo[0][t];
-                    uint32_t m1 = mhi[0][t];
-                    uint32_t lofs = mofs[0][t];
-                    int buf = qbuf[0];
-                    uint32_t jb = qbase[0] + lofs;
-                    for (;;) {
-                        while (m0 == 0 && m1 == 0 && q + 1 < nq) {
-                            ++q;
-                            m0 = mlo[q][t];
-                            m1 = mhi[q][t];
-                            lofs = mofs[q][t];
-                            buf = qbuf[q];
-                            jb = qbase[q] + lofs;
-                        }
-                        const bool has = (m0 != 0) || (m1 != 0);
-                        if (!__any(has)) break;
-                        if (has) {
-                            int bit;
-                            if (m0) { bit = __builtin_ctzll(m0); m0 &= m0 - 1; }
-                            else { bit = 64 + __builtin_ctz(m1); m1 &= m1 - 1; }
-                            if (buf >= 0) {
-                                double4 pj;
-                                double sj[Fam::NA];
-                                load_record<Fam, UH>(&recs[0][0] + (size_t)buf * (LROWB / 8) + (lofs + bit) * NR, sd.flags, pj, sj);
-                                pair_of(pj, sj, sd.flags);
-                            } else {
-                                do_pair(jb + bit, sd.flags);
-                            }
-                        }
-                    }
-                }
-                nq = 0;
-                nbuf = 0;
-            };
-            for (int dz = -1; dz <= 1; dz++) {
-                for (int dy = -1; dy <= 1; dy++) {
-                    const int yy = cyR + dy, zz = czR + dz;
-                    if (yy < 0 || yy >= ncy || zz < 0 || zz >= ncz) continue;
-                    const uint32_t rowb = (uint32_t)(ncx * (yy + ncy * zz));
-                    const uint32_t j0 = sd.cell_start[rowb + xa], j1 = sd.cell_start[rowb + xb + 1];
-                    for (uint32_t tb = j0; tb < j1; tb += ACAP) {
-                        const int tn = (int)min((uint32_t)ACAP, j1 - tb);
-                        if (nq == LQ) {
-                            __syncthreads(); // qbase / qbuf / staged records visible
-                            phase2();
-                        }
-                        __syncthreads(); // previous tile's and record buffers' readers are done
-                        const bool stage = tb == j0 && tn <= lcap && nbuf < 3; // whole row in one buffer
-                        if (stage) {
-                            // coalesced copy of the row's records: 16-byte pieces, consecutive lanes
-                            const double2 *src = reinterpret_cast<const double2 *>(a.rec + (unsigned long long)(sd.off + tb) * NR);
-                            double2 *dst = reinterpret_cast<double2 *>(recs[nbuf]);
-                            const int np = tn * (int)NR / 2;
-                            for (int k = t; k < np; k += ABS) dst[k] = src[k];
-                        }
-                        for (int q = t; q < ncs && q < 72; q += ABS) csl[q] = sd.cell_start[rowb + xa + q];
-                        for (int k = t; k < tn + 8; k += ABS) {
-                            float vx = 3.0e18f, vy = 3.0e18f, vz = 3.0e18f, vw = 0.f;
-                            if (k < tn) {
-                                const float4 fj = a.fpos[sd.off + tb + k];
-                                vx = fj.x - oxf; vy = fj.y - oyf; vz = fj.z - ozf;
-                                const float hjf = fj.w * 1.000001f + slack;
-                                vw = hjf * hjf;
-                            }
-                            tx[k] = vx; ty[k] = vy; tz[k] = vz;
-                            if (!UH) tw[k] = vw;
-                        }
-                        __syncthreads();
-                        int s0 = 0, len = 0;
-                        if (inseg) {
-                            int lo, hi;
-                            if (ncs <= 72) { lo = (int)(csl[mycl] - tb); hi = (int)(csl[mych] - tb); }
-                            else { lo = (int)(sd.cell_start[rowb + xa + mycl] - tb); hi = (int)(sd.cell_start[rowb + xa + mych] - tb); }
-                            lo = max(lo, 0); hi = min(hi, tn);
-                            s0 = lo & ~1;
-                            len = hi - s0;
-                        }
-                        const int lenc = min(len, AMAXLEN);
-                        uint32_t wd[3] = {0u, 0u, 0u};
-#pragma unroll
-                        for (int gw = 0; gw < 3; gw++) {
-                            if (!__any(32 * gw < lenc)) break;
-                            uint32_t mm = 0;
-                            int g8 = 0;
-                            for (; g8 < 4 && __any(32 * gw + 8 * g8 < lenc); g8++) {
-                                const float *tb0 = tile + (s0 + 32 * gw + 8 * g8);
-#pragma unroll
-                                for (int p = 0; p < 4; p++) {
-                                    const f2 X = *reinterpret_cast<const f2 *>(tb0 + 2 * p);
-                                    const f2 Y = *reinterpret_cast<const f2 *>(tb0 + TS + 2 * p);
-                                    const f2 Z = *reinterpret_cast<const f2 *>(tb0 + 2 * TS + 2 * p);
-                                    const f2 ex = fx - X, ey = fy - Y, ez = fz - Z;
-                                    f2 nthr = {-hi2f, -hi2f};
-                                    if (!UH) {
-                                        const f2 W = *reinterpret_cast<const f2 *>(tb0 + 3 * TS + 2 * p);
-                                        nthr.x = -fmaxf(hi2f, W.x);
-                                        nthr.y = -fmaxf(hi2f, W.y);
-                                    }
-                                    f2 d = __builtin_elementwise_fma(ex, ex, nthr);
-                                    d = __builtin_elementwise_fma(ey, ey, d);
-                                    d = __builtin_elementwise_fma(ez, ez, d);
-                                    mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.x), 31);
-                                    mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.y), 31);
-                                }
-                            }
-                            if (g8 < 4) mm <<= 8 * (4 - g8);
-                            mm = __builtin_bitreverse32(mm);
-                            const int rem = lenc - 32 * gw;
-                            wd[gw] = rem >= 32 ? mm : (rem > 0 ? (mm & ((1u << rem) - 1u)) : 0u);
-                        }
-                        mlo[nq][t] = (unsigned long long)wd[0] | ((unsigned long long)wd[1] << 32);
-                        mhi[nq][t] = wd[2];
-                        mofs[nq][t] = (unsigned short)s0;
-                        if (t == 0) { qbase[nq] = sd.off + tb; qbuf[nq] = stage ? nbuf : -1; }
-                        if (__any(len > AMAXLEN)) {
-                            for (int k = AMAXLEN; k < len; k++) do_pair(sd.off + tb + s0 + k, sd.flags);
-                        }
-                        nq++;
-                        if (stage) nbuf++;
-                    }
-                }
-                __syncthreads(); // qbase / qbuf / staged records visible
-                phase2();        // one dz plane at a time: its three rows are in LDS
-            }
-        }
-    }
-    if (active) Fam::finish(D, a, o);
-}
