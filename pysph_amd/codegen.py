@@ -563,6 +563,12 @@ class _Body(object):
                 if not (isinstance(sl, ast.Constant) and isinstance(sl.value, int)):
                     self.err(n, 'constant %s needs a literal index' % base)
                 return self.fam.param(('const', prop, sl.value), None)
+            if not store and not self.pair and isinstance(sl, ast.Name) and \
+                    self.locals.get(sl.id, ('',))[0] == 'int':
+                # d_rho[idx] with a run-time index: another particle of the SAME array, read
+                # from memory as it is when the launch reads it (the ghost-update equations,
+                # e.g. iisph.py:250-261, copy from the particle a ghost is an image of)
+                return '%s[%s]' % (self.fam.raw_dest_prop(prop), _cn(sl.id))
             self.err(n, '%s must be indexed with d_idx' % base)
         if base == 'NBRS' and self.all_nbrs:
             if store:
@@ -718,7 +724,11 @@ class _Body(object):
                         and st.value.value.id == 'NBRS':
                     rhs = self.subscript(st.value, store=False)
                 else:
-                    rhs = self.index(st.value)
+                    try:
+                        rhs = self.index(st.value)
+                    except CodegenError:
+                        # idx = d_orig_idx[d_idx]: an index held in a (double) property
+                        rhs = '(int)(%s)' % self.expr(st.value)
                 self._emit(ind, '%s = %s;' % (_cn(tgt.id), rhs))
                 return
             rhs = self.expr(st.value)
@@ -925,6 +935,7 @@ class GeneratedFamily(object):
                 self.src_flags[s] |= 1 << k
         self.helpers = OrderedDict()    # name -> _HelperBody, in dependency order
         self.sym_written = set()        # pair symbols some equation assigns to
+        self.raw_dest = set()           # destination properties also read at a run-time index
         self.bodies = {m: [] for m in METHODS}
         self.nosrc_loops = []
         for k, eq in enumerate(self.equations):
@@ -1003,6 +1014,13 @@ class GeneratedFamily(object):
 
     def use_symbol(self, s):
         self.symbols.add(s)
+
+    def raw_dest_prop(self, prop):
+        """placeholder for the memory pointer of a destination property (resolved
+        to din[]/dout[] once every body is translated)"""
+        self.dest_prop(prop, False)
+        self.raw_dest.add(prop)
+        return '@RAWD_%s@' % prop
 
     def helper(self, body, node, fname):
         """the Python function `fname` as seen from the calling body: listed by
@@ -1353,6 +1371,9 @@ class GeneratedFamily(object):
         A('    return (int)hipGetLastError();')
         A('}')
         src = '\n'.join(L) + '\n'
+        for prop in sorted(self.raw_dest):
+            ptr = 'a.p.dout[%d]' % dout.index(prop) if prop in dout else 'a.p.din[%d]' % din.index(prop)
+            src = src.replace('@RAWD_%s@' % prop, ptr)
         for sym in sorted(self.sym_written):     # symbols an equation assigns to lose their const
             src = src.replace('const double %s[3] =' % sym, 'double %s[3] =' % sym)
             src = src.replace('const double %s =' % sym, 'double %s =' % sym)

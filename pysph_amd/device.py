@@ -250,6 +250,10 @@ def get_context(device=0, stream=None):
 
 
 def _as_f64(arr, name):
+    if arr.dtype.kind in 'iu':
+        # an integer property an equation reads (orig_idx, ...): the device copy
+        # holds the same values as doubles (exact below 2^53)
+        return np.ascontiguousarray(arr, dtype=np.float64)
     if arr.dtype != np.float64:
         raise SphError('property %s: the HIP backend mirrors fp64 arrays '
                        '(got %s)' % (name, arr.dtype))
@@ -442,6 +446,12 @@ class HipDeviceHelper(object):
             if pid < 0:
                 raise SphError('property %r has no device mirror' % p)
             arr = get_npy(pa, p)
+            if arr.dtype.kind in 'iu':
+                tmp = np.empty(min(arr.size, self.get_number_of_particles()))
+                _check(self.lib.sph_array_pull(self.ctx._h, self.array_id, pid,
+                                               tmp.ctypes.data_as(_PD), 0, tmp.size))
+                arr[:tmp.size] = tmp.astype(arr.dtype)
+                continue
             if arr.dtype != np.float64 or not arr.flags.c_contiguous:
                 raise SphError('pull(%s): host array must be contiguous fp64'
                                % p)

@@ -474,3 +474,18 @@ class SolveMoments(Equation):
         eliminate(aug, n, 1, res)
         for i in range(4):
             d_pfit[i4 + i] = res[i]
+
+
+class CopyFromOriginal(Equation):
+    """the ghost-update pattern (iisph.py:243-261, gas_dynamics UpdateGhostProps):
+    particles flagged as images copy properties from the particle they are an
+    image of -- a read of the destination array at a run-time index held in an
+    integer property"""
+
+    def initialize(self, d_idx, d_image, d_orig_idx, d_rho, d_p, d_q):
+        idx = declare('int')
+        if d_image[d_idx] > 0.5:
+            idx = d_orig_idx[d_idx]
+            d_rho[d_idx] = d_rho[idx]
+            d_p[d_idx] = 2.0 * d_p[idx]
+            d_q[d_idx] = d_rho[idx] + d_p[idx]

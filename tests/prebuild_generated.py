@@ -40,6 +40,7 @@ def main():
     for kname in ('CubicSpline', 'WendlandQuintic', 'QuinticSpline', 'Gaussian'):
         arrays, eqs, dim, _ = T._random_generated_case(7)
         n += plan(arrays, eqs, getattr(K, kname)(dim=3))
+    n += plan([T._image_case()], T._image_equations(), K.CubicSpline(dim=1))
     pa, dx = T.make_cube(6)
     for tensile in (False, True):
         kw = dict(c0=32.85, alpha=0.25, beta=0.1, gz=-9.81, tensile_correction=tensile)

@@ -1490,3 +1490,42 @@ def test_randomised_generated_families_vs_python(oracle, seed):
             if got.size:
                 scale = max(np.abs(want).max(), 1e-300)
                 assert np.abs(got - want).max() <= TOL * scale, (seed, dim, kname, pa.name, prop)
+
+
+def _image_case():
+    from pysph_amd.particle_array import get_particle_array
+    rng = np.random.default_rng(2)
+    n = 500
+    pa = get_particle_array(name='fluid', x=rng.uniform(0, 1, n), h=0.05 * np.ones(n),
+                            rho=rng.uniform(1, 2, n), p=rng.uniform(1, 2, n))
+    pa.add_property('q')
+    pa.add_property('image')
+    pa.add_property('orig_idx', type='int')
+    pa.image[300:] = 1.0                              # the last 200 are images ...
+    pa.orig_idx[:] = np.arange(n)
+    pa.orig_idx[300:] = rng.integers(0, 300, 200)     # ... of particles among the first 300
+    return pa
+
+
+def _image_equations():
+    from custom_equations import CopyFromOriginal
+    from pysph_amd.equations import Group
+    return [Group(equations=[CopyFromOriginal('fluid', None)], real=False)]
+
+
+def test_generated_read_of_destination_at_runtime_index(oracle):
+    """d_rho[idx] with idx read from an INTEGER property: the image particles
+    end up with the values of their originals (which the launch does not write)"""
+    from oracle.py_eval import PyEval
+    from pysph_amd import kernels as K
+    kernel = K.CubicSpline(dim=1)
+    pa, ref = _image_case(), _image_case()
+    a_eval, nnps, ctx = make_eval([pa], _image_equations(), kernel, 1)
+    a_eval.compute(0.0, 0.1)
+    onn = oracle.OracleNNPS(1, [ref], radius_scale=2.0)
+    onn.update()
+    PyEval([ref], _image_equations(), kernel, onn).compute(0.0, 0.1)
+    for prop in ('rho', 'p', 'q'):
+        assert np.array_equal(pa.properties[prop], ref.properties[prop]), prop
+    assert np.array_equal(pa.rho[300:], pa.rho[pa.orig_idx[300:]])
+    assert pa.orig_idx.dtype.kind == 'i' and np.array_equal(pa.orig_idx, ref.orig_idx)
