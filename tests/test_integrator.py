@@ -88,9 +88,12 @@ def test_stage_kernels_match_reference_golden():
 
 
 @pytest.mark.gpu
-def test_epec_steps_device_resident_vs_oracle(oracle):
-    """Three EPEC steps of the WCSPH cube with everything device-resident
-    (one push, one pull) against the CPU oracle loop; also the adaptive
+@pytest.mark.parametrize('sync', ['manual', 'auto'])
+def test_epec_steps_device_resident_vs_oracle(oracle, sync):
+    """Three EPEC steps of the WCSPH cube against the CPU oracle loop, with
+    everything device-resident (sync='manual': one push, one pull) and with the
+    host arrays authoritative (sync='auto': the Cython backend's behaviour --
+    every evaluation and every stage moves its data); also the adaptive
     time-step reductions (integrator.py:161-200)."""
     from oracle import steppers as S
     from pysph_amd import device as dev
@@ -107,8 +110,8 @@ def test_epec_steps_device_resident_vs_oracle(oracle):
     ctx = dev.HipContext(0)
     dev.attach(pa, ctx).push()
     a_eval = AccelerationEval([pa], eqs, kernel)
-    SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
-    nnps = HipNNPS(3, [pa], radius_scale=2.0, ctx=ctx, sync=False)
+    SPHCompiler(a_eval, ctx=ctx, sync=sync).compile()
+    nnps = HipNNPS(3, [pa], radius_scale=2.0, ctx=ctx, sync=(sync == 'auto'))
     a_eval.set_nnps(nnps)
     integ = EPECIntegrator(fluid=WCSPHStep())
     setup_integrator(integ, a_eval, nnps)
@@ -124,7 +127,8 @@ def test_epec_steps_device_resident_vs_oracle(oracle):
         t += dt
     assert len(calls) == 6 and calls[0][1] == 1 and calls[1][1] == 2
     assert abs(calls[0][0] - 0.5 * dt) < 1e-18
-    pa.gpu.pull()
+    if sync == 'manual':
+        pa.gpu.pull()
     for prop in ('x', 'y', 'z', 'u', 'v', 'w', 'rho', 'au', 'av', 'aw', 'arho'):
         e = rel_err(pa.properties[prop], ref[0].properties[prop])
         assert e < 1e-10, (prop, e)
