@@ -217,6 +217,7 @@ int sph_prop_register(const char *name);
 #define SPH_GEN_MAX_PROPS 48
 #define SPH_GEN_MAX_SPROPS 20
 #define SPH_GEN_MAX_PAR 64
+#define SPH_GEN_MAX_STATE 16
 
 /* What the library hands to a generated module's launch function: plain
  * device pointers and scalars (the contents of PairArgs<Fam> in sph_pair.h). */
@@ -258,6 +259,7 @@ typedef struct sph_gen_args {
     const double *din[SPH_GEN_MAX_PROPS];   /* destination props read      */
     double *dout[SPH_GEN_MAX_PROPS];        /* destination props read-modify-written */
     double par[SPH_GEN_MAX_PAR];
+    double *state;                /* device copy of sph_gen_family.state (equation attributes the bodies write) */
 } sph_gen_args;
 
 typedef int (*sph_gen_launch_fn)(const sph_gen_args *);
@@ -282,11 +284,13 @@ typedef struct sph_gen_family {
     int also_pair;               /* 1: ... and pair loops as well: mode 2 (no post_loop), then the pair launch */
     int init_pair;               /* initialize_pair equations: 1 = mode-3 launch per source, then the loops;
                                   * 2 = nothing else follows (the last mode-3 launch runs post_loop)      */
+    int nstate;                  /* equation attributes the device code assigns (self.x = ...): in/out    */
+    double state[SPH_GEN_MAX_STATE];
 } sph_gen_family;
 
 /* initialize -> no-source loops -> per-source pair loops -> post_loop of one
  * generated family (the loop nest of acceleration_eval_cython.mako:10-154).  */
-int sph_eval_generated(sph_ctx *ctx, const sph_kernel *kernel, const sph_gen_family *family,
+int sph_eval_generated(sph_ctx *ctx, const sph_kernel *kernel, sph_gen_family *family,
                        double t, double dt);
 /* max over the first n_real particles of a property (dt_cfl, dt_force:
  * pysph/sph/integrator.py:161-200).                                        */

@@ -155,10 +155,13 @@ class PyEval(object):
                 if has(dst, 'rho') and has(src, 'rho'):
                     rhoij = 0.5 * (float(dst.rho[i]) + float(src.rho[j]))
                     pns['RHOIJ'] = rhoij
-                    pns['RHOIJ1'] = 1.0 / rhoij
+                    pns['RHOIJ1'] = 1.0 / rhoij if rhoij else float('inf')   # C: 1/0 = inf, no trap
                 pns['WIJ'] = K.kernel(xij, rij, hij)
                 pns['WI'] = K.kernel(xij, rij, float(dh[i]))
                 pns['WJ'] = K.kernel(xij, rij, float(sh[j]))
+                pns['GHI'] = float(K.gradient_h(xij, rij, float(dh[i])))
+                pns['GHJ'] = float(K.gradient_h(xij, rij, float(sh[j])))
+                pns['GHIJ'] = float(K.gradient_h(xij, rij, hij))
                 for nm, hh in (('DWIJ', hij), ('DWI', float(dh[i])), ('DWJ', float(sh[j]))):
                     gr = [0.0, 0.0, 0.0]
                     K.gradient(xij, rij, hh, gr)

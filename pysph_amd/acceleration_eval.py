@@ -246,6 +246,7 @@ class _GeneratedUnit(object):
         self.cf.loop_all = 1 if f.loop_all else 0
         self.cf.also_pair = 1 if f.also_pair else 0
         self.cf.init_pair = int(f.init_pair)
+        self.cf.nstate = len(f.state)
         owner.inputs[dest].update(f.dprops)
         owner.outputs_exact[dest].update(f.dout)    # exactly what the bodies write
         for sname in f.sources:
@@ -257,8 +258,13 @@ class _GeneratedUnit(object):
         self.cf.start_idx, self.cf.stop_idx = start, stop
 
     def run(self, ev, t, dt):
+        f = self.fam
+        for k, v in enumerate(f.state_values()):
+            self.cf.state[k] = v
         dev._check(ev.lib.sph_eval_generated(
             ev.ctx._h, C.addressof(ev.ckernel), C.addressof(self.cf), t, dt))
+        if f.state:
+            f.store_state([self.cf.state[k] for k in range(len(f.state))])
 
 
 class _CGroup(object):

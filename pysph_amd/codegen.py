@@ -48,7 +48,7 @@ GEN_DIR = os.path.join(_HERE, '_gen')
 
 VEC_SYMBOLS = ('XIJ', 'VIJ', 'DWIJ', 'DWI', 'DWJ')
 SCALAR_SYMBOLS = ('R2IJ', 'RIJ', 'HIJ', 'RHOIJ', 'RHOIJ1', 'EPS', 'WIJ', 'WI',
-                  'WJ', 'WDP', 't', 'dt')
+                  'WJ', 'WDP', 'GHI', 'GHJ', 'GHIJ', 't', 'dt')
 MATH_1 = {'sqrt': 'sqrt', 'exp': 'exp', 'log': 'log', 'sin': 'sin',
           'cos': 'cos', 'tan': 'tan', 'tanh': 'tanh', 'fabs': 'fabs',
           'abs': 'fabs', 'floor': 'floor', 'ceil': 'ceil', 'log10': 'log10',
@@ -814,6 +814,13 @@ class _Body(object):
             return _cn(tgt.id)
         if isinstance(tgt, ast.Subscript):
             return self.subscript(tgt, store=True)
+        if isinstance(tgt, ast.Attribute) and isinstance(tgt.value, ast.Name) and tgt.value.id == 'self' \
+                and self.eq is not None and not aug:
+            # self.equation_has_converged = -1 (gas_dynamics/basic.py:121-160, swe/basic.py):
+            # a flag the host reads back (converged()); every lane stores the same constant
+            if not isinstance(getattr(self.eq, tgt.attr, None), (int, float)):
+                self.err(st, 'self.%s is not a scalar attribute of the equation' % tgt.attr)
+            return self.fam.state_slot(self.k, tgt.attr, self.kind)
         self.err(st, 'assignment target %s' % type(tgt).__name__)
 
     def code(self, ind):
@@ -936,6 +943,8 @@ class GeneratedFamily(object):
         self.helpers = OrderedDict()    # name -> _HelperBody, in dependency order
         self.sym_written = set()        # pair symbols some equation assigns to
         self.raw_dest = set()           # destination properties also read at a run-time index
+        self.state = []                 # [(equation index, attribute)] assigned by device code
+        self.state_in_init = False
         self.bodies = {m: [] for m in METHODS}
         self.nosrc_loops = []
         for k, eq in enumerate(self.equations):
@@ -966,7 +975,7 @@ class GeneratedFamily(object):
         early = set()
         for b in self.bodies['initialize'] + self.nosrc_loops:
             early |= b.writes
-        self.split_init = self.also_pair or bool(self.init_pair) or (
+        self.split_init = self.also_pair or bool(self.init_pair) or self.state_in_init or (
             bool(self.sources) and dest in self.sources and bool(early & set(self.sprops)))
         if 'VIJ' in self.symbols:
             for p in 'uvw':
@@ -1014,6 +1023,26 @@ class GeneratedFamily(object):
 
     def use_symbol(self, s):
         self.symbols.add(s)
+
+    def state_slot(self, k, attr, kind):
+        key = (k, attr)
+        if key not in self.state:
+            if len(self.state) >= 16:
+                raise CodegenError('more than 16 equation attributes assigned by device code')
+            self.state.append(key)
+        if kind == 'initialize':
+            self.state_in_init = True
+        return 'a.p.state[%d]' % self.state.index(key)
+
+    def state_values(self):
+        return [float(getattr(self.equations[k], attr)) for k, attr in self.state]
+
+    def store_state(self, values):
+        """what the device code left in the attributes goes back to the equation
+        objects (type of the current value kept)"""
+        for (k, attr), v in zip(self.state, values):
+            cur = getattr(self.equations[k], attr)
+            setattr(self.equations[k], attr, type(cur)(v) if isinstance(cur, (int, bool)) else float(v))
 
     def raw_dest_prop(self, prop):
         """placeholder for the memory pointer of a destination property (resolved
@@ -1139,6 +1168,7 @@ class GeneratedFamily(object):
         A('        double *dout[%d];' % max(len(dout), 1))
         A('        double par[%d];' % max(len(self.params), 1))
         A('        const uint32_t *csr_start[SPH_MAX_ARRAYS], *csr_nbrs[SPH_MAX_ARRAYS];   // loop_all')
+        A('        double *state;   // equation attributes assigned by the bodies')
         A('        const double *sraw[SPH_MAX_ARRAYS][%d];' % max(len(self.sprops), 1))
         A('    };')
         A('    struct Dest {')
@@ -1190,7 +1220,9 @@ class GeneratedFamily(object):
         if 'DWIJ' in S:
             A('        const double tg_ = pair_gradfac<KK, UH>(g);')
             A('        const double DWIJ[3] = {tg_ * XIJ[0], tg_ * XIJ[1], tg_ * XIJ[2]};')
-        if S & {'WI', 'DWI', 'WJ', 'DWJ'}:
+        if 'GHIJ' in S:     # dW/dh at HIJ (equation.py:285-295 GRADH)
+            A('        const double GHIJ = pair_gradh<KK, UH>(g, a.k.dim);')
+        if S & {'WI', 'DWI', 'WJ', 'DWJ', 'GHI', 'GHJ'}:
             # kernels evaluated with h_d / h_s (equation.py:262-297)
             A('        PairGeom gi = g, gj = g;')
             A('        if (!UH) {')
@@ -1201,6 +1233,10 @@ class GeneratedFamily(object):
                 A('        const double WI = pair_w<KK, false>(gi);')
             if 'WJ' in S:
                 A('        const double WJ = pair_w<KK, false>(gj);')
+            if 'GHI' in S:
+                A('        const double GHI = pair_gradh<KK, false>(gi, a.k.dim);')
+            if 'GHJ' in S:
+                A('        const double GHJ = pair_gradh<KK, false>(gj, a.k.dim);')
             if 'DWI' in S:
                 A('        const double tgi_ = pair_gradfac<KK, false>(gi);')
                 A('        const double DWI[3] = {tgi_ * XIJ[0], tgi_ * XIJ[1], tgi_ * XIJ[2]};')
@@ -1343,6 +1379,7 @@ class GeneratedFamily(object):
         A('    for (int k = 0; k < g->n_dout; k++) a.p.dout[k] = g->dout[k];')
         A('    for (int k = 0; k < g->npar; k++) a.p.par[k] = g->par[k];')
         A('    a.skip_init = g->skip_init;')
+        A('    a.p.state = g->state;')
         A('    a.skip_post = g->skip_post;')
         A('    for (int j = 0; j < SPH_MAX_ARRAYS; j++) {')
         A('        a.p.csr_start[j] = g->csr_start[j]; a.p.csr_nbrs[j] = g->csr_nbrs[j];')

@@ -1381,7 +1381,32 @@ static int pack_generic(sph_ctx *c, int id, size_t off, int nprops, const int *p
     return SPH_OK;
 }
 
-extern "C" int sph_eval_generated(sph_ctx *c, const sph_kernel *K, const sph_gen_family *f, double t, double dt)
+// the loop nest of one generated family; sph_eval_generated wraps it with the
+// round trip of the equation attributes the device code assigns
+static int eval_generated_launches(sph_ctx *c, const sph_kernel *K, const sph_gen_family *f, double t, double dt, double *d_state);
+
+extern "C" int sph_eval_generated(sph_ctx *c, const sph_kernel *K, sph_gen_family *f, double t, double dt)
+{
+    if (!c || !K || !f || !f->launch) { sph_set_error("sph_eval_generated: NULL argument"); return SPH_ERR_ARG; }
+    if (f->nstate < 0 || f->nstate > SPH_GEN_MAX_STATE) { sph_set_error("sph_eval_generated: nstate out of range"); return SPH_ERR_ARG; }
+    double *d_state = nullptr;
+    if (f->nstate > 0) {
+        // self.<attr> = ... in an equation body (e.g. the convergence flag of an iterated group,
+        // gas_dynamics/basic.py:121-160): values go in before the launches and come back after
+        HIP_TRY(hipSetDevice(c->device));
+        SPH_TRY(c->gen_state.reserve(SPH_GEN_MAX_STATE * sizeof(double)));
+        d_state = c->gen_state.as<double>();
+        HIP_TRY(hipMemcpyAsync(d_state, f->state, f->nstate * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    int rc = eval_generated_launches(c, K, f, t, dt, d_state);
+    if (rc == SPH_OK && f->nstate > 0) {
+        HIP_TRY(hipMemcpyAsync(f->state, d_state, f->nstate * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return rc;
+}
+
+static int eval_generated_launches(sph_ctx *c, const sph_kernel *K, const sph_gen_family *f, double t, double dt, double *d_state)
 {
     if (!c || !K || !f || !f->launch) { sph_set_error("sph_eval_generated: NULL argument"); return SPH_ERR_ARG; }
     if (K->kind < 1 || K->kind > 4) { sph_set_error("sph_eval_generated: unknown kernel kind %d", K->kind); return SPH_ERR_UNSUPPORTED; }
@@ -1406,6 +1431,7 @@ extern "C" int sph_eval_generated(sph_ctx *c, const sph_kernel *K, const sph_gen
     g.uniform_h = (c->uniform_h && c->use_uniform_h) ? 1 : 0;
     g.nsrc = f->nsrc;
     g.t = t; g.dt = dt;
+    g.state = d_state;
     g.n_din = f->n_din; g.n_dout = f->n_dout; g.npar = f->npar;
     for (int k = 0; k < f->npar; k++) g.par[k] = f->par[k];
     for (int k = 0; k < f->n_dout; k++) {

@@ -145,6 +145,11 @@ __device__ __forceinline__ void pair_geom(PairGeom &g, const double4 &pi, const 
     g.q = g.rij * g.h1;
 }
 template <int KK, bool UH> __device__ __forceinline__ double pair_w(const PairGeom &g) { return SphKernel<KK>::template w<UH>(g.q) * g.fac; }
+// GRADH(XIJ, RIJ, h) = dW/dh (kernels.py gradient_h, e.g. :138-163): -fac*h1*(dw*q + w*dim)
+template <int KK, bool UH> __device__ __forceinline__ double pair_gradh(const PairGeom &g, int dim)
+{
+    return -g.fac * g.h1 * (SphKernel<KK>::template dw<UH>(g.q) * g.q + SphKernel<KK>::template w<UH>(g.q) * dim);
+}
 // GRADIENT(XIJ, RIJ, HIJ, DWIJ) (kernels.py:126-137) returns tmp*xij with
 // tmp = dwdq*h1/rij; here tmp only.  dw(q)/rij = dwq(q)*h1 when the kernel has
 // a closed form for dw/q.

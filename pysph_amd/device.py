@@ -170,7 +170,8 @@ class SphGenFamily(C.Structure):
                 ('real', C.c_int), ('start_idx', C.c_long),
                 ('stop_idx', C.c_long), ('split_init', C.c_int),
                 ('loop_all', C.c_int), ('also_pair', C.c_int),
-                ('init_pair', C.c_int)]
+                ('init_pair', C.c_int), ('nstate', C.c_int),
+                ('state', C.c_double * 16)]
 
 
 class HipContext(object):

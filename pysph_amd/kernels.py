@@ -49,6 +49,11 @@ class _Kernel(object):
         r = np.asarray(rij, dtype=float)
         return np.where(r > 1e-12, self._dw(r / h), 0.0) * self._norm(h)
 
+    def gradient_h(self, xij=(0., 0., 0.), rij=1.0, h=1.0):
+        """dW/dh (kernels.py gradient_h, e.g. :138-163): -fac h1 (dw q + w dim)"""
+        q = np.asarray(rij, dtype=float) / h
+        return -self._norm(h) / h * (self._dw(q) * q + self._w(q) * self.dim)
+
     def gradient(self, xij=(0., 0., 0.), rij=1.0, h=1.0, grad=None):
         r = np.asarray(rij, dtype=float)
         safe = np.where(r > 1e-12, r, 1.0)

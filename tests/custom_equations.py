@@ -489,3 +489,19 @@ class CopyFromOriginal(Equation):
             d_rho[d_idx] = d_rho[idx]
             d_p[d_idx] = 2.0 * d_p[idx]
             d_q[d_idx] = d_rho[idx] + d_p[idx]
+
+
+class DensityWithGradH(Equation):
+    """the adaptive-h summation pattern of gas_dynamics/basic.py:123-160: density
+    with the kernel at h_i, and the dW/dh sums that correct for a varying h
+    (symbols GHI, GHJ, GHIJ)"""
+
+    def initialize(self, d_idx, d_rho, d_dwdh, d_q):
+        d_rho[d_idx] = 0.0
+        d_dwdh[d_idx] = 0.0
+        d_q[d_idx] = 0.0
+
+    def loop(self, d_idx, s_idx, d_rho, d_dwdh, d_q, s_m, WI, GHI, GHJ, GHIJ):
+        d_rho[d_idx] += s_m[s_idx] * WI
+        d_dwdh[d_idx] += s_m[s_idx] * GHI
+        d_q[d_idx] += s_m[s_idx] * (GHJ - 0.5 * GHIJ)

@@ -41,6 +41,9 @@ def main():
         arrays, eqs, dim, _ = T._random_generated_case(7)
         n += plan(arrays, eqs, getattr(K, kname)(dim=3))
     n += plan([T._image_case()], T._image_equations(), K.CubicSpline(dim=1))
+    for kname in ('CubicSpline', 'WendlandQuintic', 'QuinticSpline', 'Gaussian'):
+        gp, geqs, gk = T._gradh_case(kname)
+        n += plan([gp], geqs, gk)
     pa, dx = T.make_cube(6)
     for tensile in (False, True):
         kw = dict(c0=32.85, alpha=0.25, beta=0.1, gz=-9.81, tensile_correction=tensile)
@@ -83,6 +86,7 @@ def main():
     n += plan([ps], [Group(equations=[RS.SimpleEquation('fluid', ['fluid']),
                                       RS.SimpleEquation('fluid', ['fluid'])])], K.CubicSpline(dim=1))
     n += plan([ps], [Group(equations=[RS.InitializePair('fluid', ['fluid'])])], K.CubicSpline(dim=1))
+    n += plan([RS.newton_array()], RS.newton_equations(RS.NewtonSqrt('fluid', None)), K.CubicSpline(dim=1))
     n += plan(RS.ghost_copy_arrays(), RS.ghost_copy_equations(), K.CubicSpline(dim=1))
     n += plan([T._correction_case()], T._correction_equations(), K.CubicSpline(dim=3))
     import test_kernel_corrections as KC

@@ -1529,3 +1529,40 @@ def test_generated_read_of_destination_at_runtime_index(oracle):
         assert np.array_equal(pa.properties[prop], ref.properties[prop]), prop
     assert np.array_equal(pa.rho[300:], pa.rho[pa.orig_idx[300:]])
     assert pa.orig_idx.dtype.kind == 'i' and np.array_equal(pa.orig_idx, ref.orig_idx)
+
+
+def _gradh_case(kname):
+    from custom_equations import DensityWithGradH
+    from pysph_amd import kernels as K
+    from pysph_amd.equations import Group
+    from pysph_amd.particle_array import get_particle_array
+    rng = np.random.default_rng(8)
+    n1 = 9
+    dx = 1.0 / n1
+    g = (np.arange(n1) + 0.5) * dx
+    x, y, z = [a.ravel() for a in np.meshgrid(g, g, g, indexing='ij')]
+    n = x.size
+    pa = get_particle_array(name='fluid', x=x + 0.1 * dx * rng.uniform(-1, 1, n),
+                            y=y + 0.1 * dx * rng.uniform(-1, 1, n), z=z + 0.1 * dx * rng.uniform(-1, 1, n),
+                            h=1.2 * dx * (1 + 0.2 * rng.uniform(-1, 1, n)), m=dx ** 3 * np.ones(n))
+    pa.add_property('dwdh')
+    pa.add_property('q')
+    eqs = [Group(equations=[DensityWithGradH('fluid', ['fluid'])])]
+    return pa, eqs, getattr(K, kname)(dim=3)
+
+
+@pytest.mark.parametrize('kname', ['CubicSpline', 'WendlandQuintic', 'QuinticSpline', 'Gaussian'])
+def test_generated_gradh_symbols_vs_python(oracle, kname):
+    """GHI / GHJ / GHIJ = dW/dh (equation.py:285-295, kernels.py gradient_h) with
+    per-particle h, all four kernels"""
+    from oracle.py_eval import PyEval
+    pa, eqs, kernel = _gradh_case(kname)
+    ref, _, _ = _gradh_case(kname)
+    a_eval, nnps, ctx = make_eval([pa], eqs, kernel, 3)
+    a_eval.compute(0.0, 0.1)
+    onn = oracle.OracleNNPS(3, [ref], radius_scale=kernel.radius_scale)
+    onn.update()
+    PyEval([ref], eqs, kernel, onn).compute(0.0, 0.1)
+    for prop in ('rho', 'dwdh', 'q'):
+        assert rel_err(pa.properties[prop], ref.properties[prop]) < TOL, (kname, prop)
+    assert np.abs(ref.dwdh).max() > 0

@@ -352,3 +352,68 @@ def test_initialize_pair_two_sources_then_loop_vs_python_evaluator():
                            rtol=1e-13, atol=1e-15), prop
     # v accumulated BOTH sources' values, u holds the last source's mirror image
     assert np.allclose(arrays[0].u, -ref[2].u)
+
+
+class NewtonSqrt(Equation):
+    """per-particle Newton iteration y <- (y + x/y)/2 in an iterated group whose
+    convergence flag is written by the DEVICE code, the way the reference's
+    adaptive-h SummationDensity (gas_dynamics/basic.py:108-160) and the SWE
+    density iteration (swe/basic.py:891-960) do: initialize sets the attribute to
+    1, post_loop sets it to -1 if any particle has not converged, converged()
+    returns it"""
+
+    def __init__(self, dest, sources, tol=1e-13):
+        self.tol = tol
+        self.equation_has_converged = 1
+        self.sweeps = 0
+        super(NewtonSqrt, self).__init__(dest, sources)
+
+    def initialize(self, d_idx, d_ynew):
+        d_ynew[d_idx] = 0.0
+        self.equation_has_converged = 1
+
+    def loop(self, d_idx, d_ynew, d_yv, d_xv):
+        d_ynew[d_idx] = 0.5 * (d_yv[d_idx] + d_xv[d_idx] / d_yv[d_idx])
+
+    def post_loop(self, d_idx, d_ynew, d_yv):
+        if abs(d_ynew[d_idx] - d_yv[d_idx]) > self.tol * d_ynew[d_idx]:
+            self.equation_has_converged = -1
+        d_yv[d_idx] = d_ynew[d_idx]
+
+    def converged(self):
+        self.sweeps += 1
+        return self.equation_has_converged
+
+
+def newton_array():
+    from pysph_amd.particle_array import get_particle_array
+    n = 1000
+    x = np.linspace(0, 1, n)
+    pa = get_particle_array(name='fluid', x=x, h=np.ones(n) * 1.05 / (n - 1), m=np.ones(n))
+    for p in ('xv', 'yv', 'ynew'):
+        pa.add_property(p)
+    pa.xv[:] = np.linspace(0.5, 400.0, n)
+    pa.yv[:] = 1.0
+    return pa
+
+
+def newton_equations(eq):
+    return [Group(equations=[eq], iterate=True, min_iterations=1, max_iterations=40)]
+
+
+def test_iterated_group_with_device_written_convergence_flag():
+    fluid = newton_array()
+    eq = NewtonSqrt(dest='fluid', sources=None)
+    a_eval = make_eval(fluid, newton_equations(eq))
+    a_eval.compute(0.0, 0.1)
+    assert np.allclose(fluid.yv, np.sqrt(fluid.xv), rtol=1e-12, atol=0)
+    # sqrt(400) from 1.0 needs about a dozen Newton sweeps; the group stopped on
+    # the flag the device wrote, not on max_iterations
+    assert 8 <= eq.sweeps < 20, eq.sweeps
+    assert eq.equation_has_converged == 1 and isinstance(eq.equation_has_converged, int)
+    # a tolerance nobody can meet: the flag stays -1 and max_iterations ends the loop
+    fluid.yv[:] = 1.0
+    eq2 = NewtonSqrt(dest='fluid', sources=None, tol=-1.0)
+    a_eval = make_eval(fluid, newton_equations(eq2))
+    a_eval.compute(0.0, 0.1)
+    assert eq2.sweeps == 40 and eq2.equation_has_converged == -1
