@@ -113,8 +113,8 @@ def cpu_baseline(n1=100, target_seconds=15.0):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--n1', type=int, default=159, help='lattice side per GPU')
     ap.add_argument('--workload', default='cube',
                     choices=['cube', 'dam_break', 'taylor_green', 'elastic'],
