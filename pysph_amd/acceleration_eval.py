@@ -104,7 +104,14 @@ class MegaGroup(object):
             else:
                 for s in eq.sources:
                     sources.setdefault(s, []).append(eq)
-        return dests
+        # dest -> (eqs_with_no_source: Group, {source: Group}, all_eqs: Group), the user's
+        # equation order kept in each (acceleration_eval.py:126-162)
+        out = OrderedDict()
+        for dest, (no_src, sources, all_eqs) in dests.items():
+            out[dest] = (self.Group(equations=no_src),
+                         OrderedDict((s_, self.Group(equations=e_)) for s_, e_ in sources.items()),
+                         self.Group(equations=all_eqs))
+        return out
 
 
 class AccelerationEval(object):

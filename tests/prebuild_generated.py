@@ -89,6 +89,10 @@ def main():
     n += plan([RS.newton_array()], RS.newton_equations(RS.NewtonSqrt('fluid', None)), K.CubicSpline(dim=1))
     n += plan(RS.ghost_copy_arrays(), RS.ghost_copy_equations(), K.CubicSpline(dim=1))
     n += plan([T._correction_case()], T._correction_equations(), K.CubicSpline(dim=3))
+    for cls in (RS.HelperEquation, RS.MixedTypeEquation):
+        n += plan([ps], [Group(equations=[cls('fluid', ['fluid'])])], K.CubicSpline(dim=1))
+    n += plan([ps], [Group(equations=[RS.HelperEquation('fluid', ['fluid']),
+                                      RS.HelperEquation('fluid', ['fluid'])])], K.CubicSpline(dim=1))
     import test_kernel_corrections as KC
     for dim in (2, 3):
         n += plan([KC.corner_particles(dim)], KC.correction_equations(dim), K.CubicSpline(dim=dim))

@@ -417,3 +417,74 @@ def test_iterated_group_with_device_written_convergence_flag():
     a_eval = make_eval(fluid, newton_equations(eq2))
     a_eval.compute(0.0, 0.1)
     assert eq2.sweeps == 40 and eq2.equation_has_converged == -1
+
+
+def times_one_and_a_half(x=1.0):
+    return x * 1.5
+
+
+class HelperEquation(Equation):                     # :898-922 (SillyEquation2)
+    def initialize(self, d_idx, d_au, d_m):
+        d_au[d_idx] += times_one_and_a_half(d_m[d_idx])
+
+    def _get_helpers_(self):
+        return [times_one_and_a_half]
+
+
+class MixedTypeEquation(Equation):                  # :162-171: integer properties in device code
+    def initialize(self, d_idx, d_u, d_au, d_pid, d_tag):
+        d_u[d_idx] = 0.0 + d_pid[d_idx]
+        d_au[d_idx] = 0.0 + d_tag[d_idx]
+
+    def loop(self, d_idx, d_au, s_idx, s_m, s_pid, s_tag):
+        d_au[d_idx] += s_m[s_idx] + s_pid[s_idx] + s_tag[s_idx]
+
+    def post_loop(self, d_idx, d_u, d_au, d_pid):
+        d_u[d_idx] = d_au[d_idx] + d_pid[d_idx]
+
+
+def test_should_handle_helper_functions(pa):        # :898-922, two equations sharing one helper
+    a_eval = make_eval(pa, [HelperEquation(dest='fluid', sources=['fluid']),
+                            HelperEquation(dest='fluid', sources=['fluid'])])
+    a_eval.compute(0.1, 0.1)
+    assert list(pa.au) == [3.0] * 10
+
+
+def test_should_work_with_non_double_arrays(pa):    # :449-460
+    a_eval = make_eval(pa, [MixedTypeEquation(dest='fluid', sources=['fluid'])])
+    a_eval.compute(0.1, 0.1)
+    assert list(pa.u) == list(EXPECT)
+    # and with non-trivial integer values
+    pa.pid[:] = 2
+    a_eval.compute(0.1, 0.1)
+    assert list(pa.u) == list(3.0 * EXPECT + 2.0)
+    assert pa.pid.dtype.kind == 'i' and list(pa.pid) == [2] * 10
+
+
+def test_should_call_pre_post_in_mother_group(pa):  # :533-560
+    def pre():
+        pa.m += 1.0
+
+    def post():
+        pa.u += 1.0
+
+    eqs = [Group(equations=[Group(equations=[SimpleEquation(dest='fluid', sources=['fluid'])])],
+                 pre=pre, post=post)]
+    a_eval = make_eval(pa, eqs)
+    a_eval.compute(0.1, 0.1)
+    assert list(pa.u) == [7., 9., 11., 11., 11., 11., 11., 11., 9., 7.]
+
+
+def test_should_work_with_cached_nnps(pa):          # :344-355
+    from pysph_amd import device as dev
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.kernels import CubicSpline
+    from pysph_amd.nnps import HipNNPS
+    kernel = CubicSpline(dim=1)
+    ctx = dev.HipContext(0)
+    a_eval = AccelerationEval([pa], [SimpleEquation(dest='fluid', sources=['fluid'])], kernel)
+    SPHCompiler(a_eval, ctx=ctx).compile()
+    nnps = HipNNPS(dim=1, particles=[pa], ctx=ctx, cache=True)
+    a_eval.set_nnps(nnps)
+    a_eval.compute(0.1, 0.1)
+    assert list(pa.u) == list(EXPECT)
