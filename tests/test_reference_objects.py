@@ -101,8 +101,11 @@ def test_reference_accelerationeval_is_accepted():
         for dest in rg.data:
             r_no, r_src, r_all = rg.data[dest]
             m_no, m_src, m_all = mg.data[dest]
-            assert [e.name for e in r_no.equations] == [e.name for e in m_no]
+            assert [e.name for e in r_no.equations] == [e.name for e in m_no.equations]
             assert list(r_src.keys()) == list(m_src.keys())
-            assert [e.name for e in r_all.equations] == [e.name for e in m_all]
+            for src in r_src:
+                assert [e.name for e in r_src[src].equations] == \
+                    [e.name for e in m_src[src].equations]
+            assert [e.name for e in r_all.equations] == [e.name for e in m_all.equations]
     assert _marshal(ref.equation_groups, arrays) == \
         _marshal(mine.equation_groups, arrays)
