@@ -488,3 +488,10 @@ def test_should_work_with_cached_nnps(pa):          # :344-355
     a_eval.set_nnps(nnps)
     a_eval.compute(0.1, 0.1)
     assert list(pa.u) == list(EXPECT)
+
+
+def test_precomputed_symbols_summation_density(pa):  # :727-741
+    a_eval = make_eval(pa, [SummationDensity(dest='fluid', sources=['fluid'])])
+    a_eval.compute(0.1, 0.1)
+    expect = np.asarray([7.357, 9.0, 9., 9., 9., 9., 9., 9., 9., 7.357])
+    assert np.allclose(expect, pa.rho, atol=1e-2)
