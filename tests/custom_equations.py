@@ -505,3 +505,33 @@ class DensityWithGradH(Equation):
         d_rho[d_idx] += s_m[s_idx] * WI
         d_dwdh[d_idx] += s_m[s_idx] * GHI
         d_q[d_idx] += s_m[s_idx] * (GHJ - 0.5 * GHIJ)
+
+
+class SolveSystems(Equation):
+    """one n x n linear system per particle (n = self.n <= 4), matrix and
+    right-hand side in strided properties: the reference's wc/linalg.py helpers'
+    use case (sph/tests/test_linalg.py) on the device"""
+
+    def __init__(self, dest, sources, n=4):
+        self.n = n
+        super(SolveSystems, self).__init__(dest, sources)
+
+    def _get_helpers_(self):
+        return [stack_columns, eliminate]
+
+    def loop(self, d_idx, d_amat, d_bvec, d_pfit, d_q):
+        a = declare('matrix(16)')
+        b = declare('matrix(4)')
+        aug = declare('matrix(20)')
+        x = declare('matrix(4)')
+        i, n = declare('int', 2)
+        n = self.n
+        for i in range(16):
+            a[i] = d_amat[16 * d_idx + i]
+        for i in range(4):
+            b[i] = d_bvec[4 * d_idx + i]
+            x[i] = 0.0
+        stack_columns(a, b, n, 1, 4, aug)
+        d_q[d_idx] = eliminate(aug, n, 1, x)
+        for i in range(4):
+            d_pfit[4 * d_idx + i] = x[i]

@@ -44,6 +44,9 @@ def main():
     for kname in ('CubicSpline', 'WendlandQuintic', 'QuinticSpline', 'Gaussian'):
         gp, geqs, gk = T._gradh_case(kname)
         n += plan([gp], geqs, gk)
+    for nsys in (2, 3, 4):
+        sp, seqs = T._systems_case(nsys)
+        n += plan([sp], seqs, K.CubicSpline(dim=1))
     pa, dx = T.make_cube(6)
     for tensile in (False, True):
         kw = dict(c0=32.85, alpha=0.25, beta=0.1, gz=-9.81, tensile_correction=tensile)

@@ -1566,3 +1566,43 @@ def test_generated_gradh_symbols_vs_python(oracle, kname):
     for prop in ('rho', 'dwdh', 'q'):
         assert rel_err(pa.properties[prop], ref.properties[prop]) < TOL, (kname, prop)
     assert np.abs(ref.dwdh).max() > 0
+
+
+def _systems_case(n):
+    from custom_equations import SolveSystems
+    from pysph_amd.equations import Group
+    from pysph_amd.particle_array import get_particle_array
+    rng = np.random.default_rng(31 + n)
+    m = 600
+    pa = get_particle_array(name='fluid', x=np.linspace(0, 1, m), h=0.01 * np.ones(m))
+    for name, stride in (('amat', 16), ('bvec', 4), ('pfit', 4)):
+        pa.add_property(name, stride=stride)
+    pa.add_property('q')
+    A = rng.uniform(-1, 1, (m, 4, 4))
+    A[::3, 0, 0] = 0.0                     # a zero pivot: needs row exchange
+    A[5] = 0.0                             # one singular system
+    pa.amat[:] = A.ravel()
+    pa.bvec[:] = rng.uniform(-1, 1, 4 * m)
+    return pa, [Group(equations=[SolveSystems('fluid', None, n=n)])]
+
+
+@pytest.mark.parametrize('n', [2, 3, 4])
+def test_generated_linear_solver_helpers_vs_numpy(n):
+    """sph/tests/test_linalg.py on the device: 600 systems per launch, the
+    leading n x n block of a 4 x 4 matrix (augmented_matrix 'lower dimension'
+    cases), zero pivots needing row exchange, one singular matrix"""
+    from pysph_amd import kernels as K
+    pa, eqs = _systems_case(n)
+    a_eval, nnps, ctx = make_eval([pa], eqs, K.CubicSpline(dim=1), 1)
+    a_eval.compute(0.0, 0.1)
+    A = pa.amat.reshape(-1, 4, 4)[:, :n, :n]
+    b = pa.bvec.reshape(-1, 4)[:, :n]
+    x = pa.pfit.reshape(-1, 4)
+    assert pa.q[5] == 1.0 and np.all(np.delete(pa.q, 5) == 0.0)      # singular flag
+    ok = np.ones(pa.q.size, dtype=bool)
+    ok[5] = False
+    want = np.linalg.solve(A[ok], b[ok][..., None])[..., 0]
+    cond = np.linalg.cond(A[ok])
+    err = np.abs(x[ok][:, :n] - want).max(axis=1) / np.abs(want).max(axis=1)
+    assert np.all(err < 1e-12 * np.maximum(cond, 10.0))
+    assert np.all(x[ok][:, n:] == 0.0)
