@@ -910,6 +910,28 @@ class _HelperBody(_Body):
         return '\n'.join(out)
 
 
+# Ahead-of-time builds (tests/prebuild_generated.py, __graft_entry__.build()): while
+# DEFERRED is a list, families that are not in the cache are only collected; then
+# build_deferred() compiles them side by side.
+DEFERRED = None
+
+
+class _DeferredModule(object):
+    sphgen_launch = C.CFUNCTYPE(C.c_int, C.c_void_p)(lambda args: -1)
+
+
+def build_deferred(jobs=None):
+    """compile the collected families with `jobs` hipcc processes at a time"""
+    global DEFERRED
+    from concurrent.futures import ThreadPoolExecutor
+    pending, DEFERRED = DEFERRED or [], None
+    unique = list(dict((f.hash, f) for f in pending).values())
+    if unique:
+        with ThreadPoolExecutor(max_workers=jobs or min(16, os.cpu_count() or 4)) as pool:
+            list(pool.map(lambda f: f.build(), unique))
+    return len(unique)
+
+
 class GeneratedFamily(object):
     """All equations of one group acting on one destination, generated."""
 
@@ -1426,6 +1448,9 @@ class GeneratedFamily(object):
         so = self.so_path()
         if os.path.exists(so) and not force:
             return so
+        if DEFERRED is not None and not force:
+            DEFERRED.append(self)       # built later, in parallel (build_deferred)
+            return so
         src = so[:-3] + '.hip'
         with open(src, 'w') as f:
             f.write(self.source)
@@ -1461,7 +1486,10 @@ class GeneratedFamily(object):
 
     def load(self):
         if self.lib is None:
-            self.lib = C.CDLL(self.build())
+            so = self.build()
+            if DEFERRED is not None and not os.path.exists(so):
+                return _DeferredModule()      # collection pass: nothing is launched
+            self.lib = C.CDLL(so)
             self.lib.sphgen_launch.restype = C.c_int
             self.lib.sphgen_launch.argtypes = [C.c_void_p]
         return self.lib

@@ -111,4 +111,10 @@ def main():
 
 
 if __name__ == '__main__':
+    # pass 1 collects what is missing from the cache, build_deferred() compiles it in
+    # parallel, pass 2 walks everything again with the real modules (loads every one)
+    from pysph_amd import codegen
+    codegen.DEFERRED = []
+    main()
+    print('compiled in parallel:', codegen.build_deferred())
     print('generated families built:', main())
