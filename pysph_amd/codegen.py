@@ -469,6 +469,8 @@ class _Body(object):
             self.err(n, 'vector symbol %s must be subscripted' % v)
         if v == 'd_idx' and self.raw_src:
             return '((double)d_idx)'            # compared with NBRS[k] in loop_all bodies
+        if v == 'd_idx' and not self.pair and self.kind in ('initialize', 'loop', 'post_loop'):
+            return '((double)o)'                # load()/finish(): o is the particle's own index
         if v in ('d_idx', 's_idx'):
             self.err(n, '%s may only index a property array' % v)
         self.err(n, 'unknown name %r (locals must be assigned before use)' % v)
