@@ -1606,3 +1606,88 @@ def test_generated_linear_solver_helpers_vs_numpy(n):
     err = np.abs(x[ok][:, :n] - want).max(axis=1) / np.abs(want).max(axis=1)
     assert np.all(err < 1e-12 * np.maximum(cond, 10.0))
     assert np.all(x[ok][:, n:] == 0.0)
+
+
+def test_tvf_two_slabs_two_halo_layers_one_gpu(oracle):
+    """The TVF set across two slab ranks: its first group is a
+    real=False summation density, i.e. V and rho of the GHOSTS are recomputed
+    locally, which needs the neighbours of the ghosts -- a halo two support
+    radii wide (the reason the reference defaults to two ghost layers).  The
+    inner ghost layer then carries correct V, rho, p for the force group; results
+    of all real particles equal the single-domain oracle by global id."""
+    import threading
+    import torch
+    from helpers import ThreadDist
+    from test_periodic import lattice
+    from pysph_amd import device as dev
+    from pysph_amd import kernels as K
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.nnps import HipNNPS
+    from pysph_amd.parallel import TVF_HALO_PROPS, SlabHalo
+    from pysph_amd.scheme import TVFScheme
+    full, dx = lattice(14, dim=3, hdx=1.0, jitter=0.08)
+    rng = np.random.default_rng(12)
+    n = full.get_number_of_particles()
+    for k in 'uvw':
+        full.properties[k][:] = rng.uniform(-1, 1, n)
+        full.properties[k + 'hat'][:] = full.properties[k] + 0.1 * rng.uniform(-1, 1, n)
+    full.add_property('e0', data=np.arange(n, dtype=np.float64))
+    kernel = K.QuinticSpline(dim=3)
+    eqs = TVFScheme(['fluid'], [], dim=3, rho0=1.0, c0=10.0, nu=0.01, p0=100.0, pb=100.0,
+                    h0=dx).get_equations()
+    ref = _copy_arrays([full])
+    cut = 0.5
+    width = 2.0 * kernel.radius_scale * dx * 1.02          # two support radii
+    outs = ['rho', 'V', 'p', 'au', 'av', 'aw', 'auhat', 'avhat', 'awhat']
+    hub = ThreadDist(2)
+    results, errors = {}, []
+
+    def rank_main(rank):
+        try:
+            ts = torch.cuda.Stream()
+            with torch.cuda.stream(ts):
+                lo, hi = (-1e30, cut) if rank == 0 else (cut, 1e30)
+                pa = full.extract_particles(np.nonzero((full.x >= lo) & (full.x < hi))[0], name='fluid')
+                ctx = dev.HipContext(0, ts.cuda_stream)
+                dev.attach(pa, ctx).push()
+                halo = SlabHalo(pa, ctx, rank, 2, axis=0, width=width, lo=lo, hi=hi,
+                                props=TVF_HALO_PROPS, dist=hub.view(rank))
+                halo.exchange()
+                a_eval = AccelerationEval([pa], eqs, kernel)
+                SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+                nnps = HipNNPS(3, [pa], radius_scale=kernel.radius_scale, ctx=ctx, sync=False)
+                a_eval.set_nnps(nnps)
+                a_eval.compute(0.0, 1e-4)
+                nreal = pa.gpu.get_number_of_particles(True)
+                assert pa.gpu.get_number_of_particles() > nreal
+                pa.gpu.sync_host()
+                results[rank] = {k: pa.properties[k][:nreal].copy() for k in outs + ['e0']}
+        except Exception:
+            import traceback
+            errors.append(traceback.format_exc())
+            try:
+                hub.barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors[0]
+    onn = oracle.OracleNNPS(3, ref, radius_scale=kernel.radius_scale)
+    onn.update()
+    oev = oracle.OracleEval(ref, eqs, kernel, nthreads=8)
+    oev.set_nnps(onn)
+    oev.compute(0.0, 1e-4)
+    seen = 0
+    for r in range(2):
+        d = results[r]
+        gid = d['e0'].astype(np.int64)
+        seen += gid.size
+        for prop in outs:
+            want = ref[0].properties[prop]
+            e = rel_err(d[prop], want[gid], scale=max(np.abs(want).max(), 1e-300))
+            assert e < TOL, (r, prop, e)
+    assert seen == n
