@@ -375,7 +375,7 @@ def run(args, rank, local_rank, world, dist):
             },
             'roofline': {
                 'bound': 'hbm', 'kernel': 'k_pair_%s<FamWCSPH,WendlandQuintic>' %
-                {0: 'direct', 2: 'wg', 3: 'agg'}[args.variant],
+                {0: 'direct', 2: 'wg', 3: 'agg', 6: 'lean'}[args.variant],
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                 'algorithmic_bytes_per_particle': algo_pair,

@@ -3,6 +3,7 @@
 // Replaces the reference's DeviceHelper (pysph/base/device_helper.py:47-672:
 // push/pull/resize of `pa.gpu`) with an explicit host<->HIP buffer table:
 // the Python host keeps owning the numpy buffers and decides when to move data.
+#include <cstdlib>
 #include "sph_internal.h"
 
 static thread_local char g_err[1024] = "";
@@ -113,6 +114,8 @@ int sph_ctx_create(int device, void *stream, sph_ctx **out)
         c->own_stream = true;
     }
     HIP_TRY(hipHostMalloc((void **)&c->pinned, 64 * sizeof(double), hipHostMallocDefault));
+    // development aid: SPH_PAIR_VARIANT overrides the default pair-kernel schedule
+    if (const char *pv = getenv("SPH_PAIR_VARIANT")) c->pair_variant = atol(pv);
     *out = c;
     return SPH_OK;
 }
@@ -245,7 +248,7 @@ int sph_array_device_ptr(sph_ctx *c, int id, int prop, void **dptr)
 int sph_set_option(sph_ctx *c, const char *key, long value)
 {
     if (strcmp(key, "pair_variant") == 0) {
-        if (value != 0 && value != 2 && value != 3) { sph_set_error("pair_variant must be 0 (direct), 2 (row tiles) or 3 (aggregated)"); return SPH_ERR_ARG; }
+        if (value != 0 && value != 2 && value != 3 && value != 6) { sph_set_error("pair_variant must be 0 (direct), 2 (row tiles), 3 (aggregated) or 6 (aggregated, lean phase 2)"); return SPH_ERR_ARG; }
         c->pair_variant = value;
         return SPH_OK;
     }
@@ -256,6 +259,7 @@ int sph_set_option(sph_ctx *c, const char *key, long value)
         c->tile_block_rows = value; c->nnps_valid = false; return SPH_OK;
     }
     if (strcmp(key, "ablate") == 0) { c->ablate = value; return SPH_OK; }
+    if (strcmp(key, "const_flags") == 0) { c->const_flags = value; return SPH_OK; }
     if (strcmp(key, "invalidate_nnps") == 0) { c->nnps_valid = false; return SPH_OK; }
     sph_set_error("sph_set_option: unknown key '%s'", key);
     return SPH_ERR_ARG;

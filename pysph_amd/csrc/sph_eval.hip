@@ -287,6 +287,7 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
 }
 
 struct FamWCSPH {
+    static constexpr uint32_t CF0 = F_CONT | F_MOM | F_XSPH; // flag set compiled as a constant (variant 6)
     static constexpr int MINB = 4; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
     static constexpr int NA = 8; // u v w m rho tmpj(=p/rho^2) cs p
     static constexpr int NR = 12; // x y z h + NA (128-B padded records measured slower: larger L2 footprint)
@@ -308,16 +309,21 @@ struct FamWCSPH {
     //   DWIJ.VIJ = tg*(XIJ.VIJ),   f*DWIJ = (f*tg)*XIJ,
     //   1/(R2IJ+EPS) and 1/RHOIJ from one reciprocal of their product,
     //   1/R2IJ = rinv^2.
+    // PRED: the lean kernel calls pair() for every lane of every iteration and
+    // passes the neighbour criterion as `pass`; a pair that fails contributes
+    // exactly zero because every term carries the factor m_j (set to 0) -- no
+    // branch around the accumulators, which then stay in their registers.
+    static constexpr bool PRED = true;
     template <int KK, bool UH, class A>
     static __device__ __forceinline__ void pair(Dest &D, const double4 &pi, const double4 &pj, double r2,
-                                                const double (&s)[NA], uint32_t fl, const A &a)
+                                                const double (&s)[NA], uint32_t fl, const A &a, bool pass = true)
     {
         PairGeom g;
         pair_geom<KK, UH>(g, pi, pj, r2, a);
         const double tg = pair_gradfac<KK, UH>(g);
         const double vij0 = D.u - s[0], vij1 = D.v - s[1], vij2 = D.w - s[2]; // VIJ equation.py:214-223
         const double vdotx = vij0 * g.xij[0] + vij1 * g.xij[1] + vij2 * g.xij[2];
-        const double mj = s[3];
+        const double mj = pass ? s[3] : 0.0;
         if (fl & F_CONT) D.arho = fma(mj * tg, vdotx, D.arho); // basic_equations.py:187-192
         if (fl & (F_MOM | F_XSPH)) {
             const double rhoij = 0.5 * (D.rho + s[4]); // RHOIJ equation.py:196
@@ -335,7 +341,7 @@ struct FamWCSPH {
                 double piij = (a.p.beta * muij - a.p.alpha * cij) * muij * rhoij1;
                 piij = vdotx < 0 ? piij : 0.0;
                 const double dtc = fabs(hv * (g.rinv * g.rinv)) + a.p.c0;
-                D.dt_cfl = r2 > 1e-12 ? fmax(dtc, D.dt_cfl) : D.dt_cfl;
+                D.dt_cfl = (r2 > 1e-12 && pass) ? fmax(dtc, D.dt_cfl) : D.dt_cfl;
                 const double tmpj = s[5];
                 double tmp = D.tmpi + tmpj;
                 if (fl & F_TENSILE) {
@@ -388,6 +394,10 @@ __device__ __forceinline__ void load_record_wcsph(const double *__restrict__ rj,
 {
     const double2 *r2 = reinterpret_cast<const double2 *>(rj);
     const double2 a0 = r2[0], a1 = r2[1], b0 = r2[2], b1 = r2[3], c = r2[4];
+    // keep the five 16-B pieces together, ahead of the exact criterion: without
+    // this use the optimiser sinks the non-position pieces into the pair branch
+    // (as misaligned loads), i.e. two memory latencies per hit
+    asm volatile("" ::"v"(a0.x), "v"(a0.y), "v"(a1.x), "v"(a1.y), "v"(b0.x), "v"(b0.y), "v"(b1.x), "v"(b1.y), "v"(c.x), "v"(c.y));
     pj.x = a0.x; pj.y = a0.y; pj.z = a1.x; pj.w = 0.0;
     s[0] = b0.x; s[1] = b0.y; s[2] = b1.x; s[3] = b1.y; s[4] = c.x; s[5] = c.y; s[6] = a1.y; s[7] = 0.0;
     if (!UH || (fl & F_TENSILE)) {
@@ -400,6 +410,8 @@ template <> __device__ __forceinline__ void load_record<FamWCSPH, false>(const d
 
 // ---- density summations (basic_equations.py:19-29, transport_velocity.py:24-58)
 struct FamDensity {
+    static constexpr bool PRED = false;
+    static constexpr uint32_t CF0 = F_TVFSD; // flag set compiled as a constant (variant 6)
     static constexpr int MINB = 4; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
     static constexpr int NA = 1; // m
     static constexpr int NR = 6;  // x y z h m pad
@@ -435,6 +447,8 @@ template <> __device__ __forceinline__ void load_record<FamDensity, true>(const 
 
 // ---- TVF momentum terms (transport_velocity.py:219-545) -------------------
 struct FamTVF {
+    static constexpr bool PRED = false;
+    static constexpr uint32_t CF0 = F_TP | F_TVISC | F_TAS; // flag set compiled as a constant (variant 6)
     static constexpr int MINB = 3; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
     static constexpr int NA = 12; // u v w uhat vhat what rho p V m Vj2 pad
     static constexpr int NR = 16; // x y z h + NA
@@ -530,6 +544,8 @@ template <> __device__ __forceinline__ void load_record<FamTVF, true>(const doub
 
 // ---- velocity gradient (basic_equations.py:63-148) -------------------------
 struct FamVGrad {
+    static constexpr bool PRED = false;
+    static constexpr uint32_t CF0 = F_VG3; // flag set compiled as a constant (variant 6)
     static constexpr int MINB = 4; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
     static constexpr int NA = 4; // u v w m/rho
     static constexpr int NR = 8;
@@ -572,6 +588,8 @@ struct FamVGrad {
 //      MonaghanArtificialViscosity + XSPH  (solid_mech/basic.py:245-387,
 //      basic_equations.py:177-300) -------------------------------------------
 struct FamElastic {
+    static constexpr bool PRED = false;
+    static constexpr uint32_t CF0 = F_ECONT | F_ESTRESS | F_EAV | F_EXSPH; // flag set compiled as a constant (variant 6)
     static constexpr int MINB = 2; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
     static constexpr int NA = 18; // u v w m rho cs | t00 t01 t02 t11 t12 t22 (= sigma/rho^2) | r00 r01 r02 r11 r12 r22
     static constexpr int NR = 22;
@@ -1040,9 +1058,9 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
     pa.radius_scale = c->radius_scale;
     if (c->pair_variant >= 2) pa.rec = c->posh.as<double>();
     if (c->pair_variant >= 3) pa.fpos = c->fposb.as<float4>();
-    pa.layout = (c->pair_variant == 3 && fam == FAM_WCSPH) ? 1 : (c->pair_variant == 3 && fam == FAM_DENSITY && pl.nr == 4) ? 2
-              : (c->pair_variant == 3 && fam == FAM_TVF && pl.nr == 14) ? 3 : 0;
-    if (c->pair_variant == 3 && c->record_f32) pa.layout = 5;
+    pa.layout = (c->pair_variant >= 3 && fam == FAM_WCSPH) ? 1 : (c->pair_variant >= 3 && fam == FAM_DENSITY && pl.nr == 4) ? 2
+              : (c->pair_variant >= 3 && fam == FAM_TVF && pl.nr == 14) ? 3 : 0;
+    if (c->pair_variant >= 3 && c->record_f32) pa.layout = 5;
     hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, pa);
     return SPH_OK;
 }
@@ -1051,6 +1069,29 @@ template <class Fam> static void launch_pair(sph_ctx *c, int kk, const PairArgs<
 {
     if (a.nd == 0) return;
     const bool uh = c->uniform_h && c->use_uniform_h;
+    if (c->pair_variant == 6) {
+        dim3 g2(div_up(a.nd, ABS)), b2(ABS);
+        // equation flags as a compile-time constant when every source carries the same set
+        uint32_t cf = a.src[0].flags;
+        for (int j = 1; j < a.nsrc; j++) if (a.src[j].flags != cf) cf = 0;
+        if (c->const_flags == 0) cf = 0;
+#define LAUNCH6F(K, UHV, CFV) hipLaunchKernelGGL((k_pair_lean<Fam, K, UHV, false, CFV>), g2, b2, 0, c->stream, a)
+#define LAUNCH6(K)                                                                                      \
+        if (c->record_f32) {                                                                            \
+            if (uh) hipLaunchKernelGGL((k_pair_lean<Fam, K, true, true>), g2, b2, 0, c->stream, a);     \
+            else hipLaunchKernelGGL((k_pair_lean<Fam, K, false, true>), g2, b2, 0, c->stream, a);       \
+        } else if (uh) { if (cf == Fam::CF0) LAUNCH6F(K, true, Fam::CF0); else LAUNCH6F(K, true, 0); }  \
+        else { if (cf == Fam::CF0) LAUNCH6F(K, false, Fam::CF0); else LAUNCH6F(K, false, 0); }
+        switch (kk) {
+        case 1: LAUNCH6(1); break;
+        case 2: LAUNCH6(2); break;
+        case 3: LAUNCH6(3); break;
+        case 4: LAUNCH6(4); break;
+        }
+#undef LAUNCH6
+#undef LAUNCH6F
+        return;
+    }
     if (c->pair_variant == 3) {
         dim3 g2(div_up(a.nd, ABS)), b2(ABS);
 #define LAUNCH3(K)                                                                                      \
@@ -1223,10 +1264,10 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         if (total >= (1ull << 32)) { sph_set_error("too many particles for 32-bit packed indices"); return SPH_ERR_ARG; }
         PackPlan pl = pack_plan(fam);
         // compact 80-B WCSPH records when neither h nor p of a neighbour is read
-        if (c->pair_variant == 3 && fam == FAM_WCSPH && c->uniform_h && c->use_uniform_h && !(dflags & F_TENSILE)) pl.nr = 10;
-        if (c->pair_variant == 3 && fam == FAM_DENSITY && c->uniform_h && c->use_uniform_h) pl.nr = 4;
-        if (c->pair_variant == 3 && fam == FAM_TVF && c->uniform_h && c->use_uniform_h) pl.nr = 14;
-        if (c->pair_variant == 3 && c->record_f32) pl.nr = (4 + pl.na + 3) & ~3; // floats
+        if (c->pair_variant >= 3 && fam == FAM_WCSPH && c->uniform_h && c->use_uniform_h && !(dflags & F_TENSILE)) pl.nr = 10;
+        if (c->pair_variant >= 3 && fam == FAM_DENSITY && c->uniform_h && c->use_uniform_h) pl.nr = 4;
+        if (c->pair_variant >= 3 && fam == FAM_TVF && c->uniform_h && c->use_uniform_h) pl.nr = 14;
+        if (c->pair_variant >= 3 && c->record_f32) pl.nr = (4 + pl.na + 3) & ~3; // floats
         c->cur_nrec = pl.nr;
         SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * (c->pair_variant >= 2 ? pl.nr : 4)));
         SPH_TRY(c->aux.reserve((total + 64) * sizeof(double) * pl.na));

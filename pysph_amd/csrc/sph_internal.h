@@ -94,6 +94,7 @@ struct sph_ctx {
     // options
     long pair_variant = 3;
     long ablate = 0;
+    long const_flags = 1;   // variant 6: compile-time equation flags when all sources agree (0: always run-time flags)
     long use_uniform_h = 1;
     long record_f32 = 0;    // packed records in fp32 (inputs rounded, arithmetic fp64): aggregated kernel only
     long tile_block_rows = 8; // destination tiles are traversed in blocks of this many cell rows (y) through all z planes; 0: memory order

@@ -75,18 +75,26 @@ template <class Fam> struct PairArgs {
 };
 
 // ---------------------------------------------------------------------------
-// fast fp64 reciprocal / square root: hardware estimate + two Newton steps
-// (error ~1 ulp; no div_scale/div_fixup range handling -- operands here are
-// densities, distances and smoothing lengths, far from the fp64 range limits).
-// The 1e-10 parity budget (BASELINE.json) absorbs the ~1e-16 differences.
+// fast fp64 reciprocal / square root: hardware estimate (v_rcp_f64 / v_rsq_f64,
+// ~2^-26 relative) + SPH_NEWTON_STEPS Newton steps: one step leaves ~1e-14
+// relative (measured: tools/microbench/rcp_accuracy.hip), two ~1 ulp.  No
+// div_scale/div_fixup range handling -- operands here are densities, distances
+// and smoothing lengths, far from the fp64 range limits.  The 1e-10 parity
+// budget (BASELINE.json) is four orders of magnitude above the one-step error;
+// neighbour SETS do not depend on it (exact r2 comparison).
 // ---------------------------------------------------------------------------
+#ifndef SPH_NEWTON_STEPS
+#define SPH_NEWTON_STEPS 1
+#endif
 __device__ __forceinline__ double fast_rcp(double d)
 {
     double x = __builtin_amdgcn_rcp(d);
     double e = fma(-d, x, 1.0);
     x = fma(x, e, x);
-    e = fma(-d, x, 1.0);
-    x = fma(x, e, x);
+    if (SPH_NEWTON_STEPS > 1) {
+        e = fma(-d, x, 1.0);
+        x = fma(x, e, x);
+    }
     return x;
 }
 // s = sqrt(a), rs = 1/sqrt(a).  a is clamped to 1e-300 so that coincident
@@ -101,9 +109,11 @@ __device__ __forceinline__ void fast_sqrt_rsqrt(double a, double &s, double &rs)
     double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
     h = fma(h, r, h);
-    r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
+    if (SPH_NEWTON_STEPS > 1) {
+        r = fma(-h, g, 0.5);
+        g = fma(g, r, g);
+        h = fma(h, r, h);
+    }
     s = g;
     rs = h + h;
 }
@@ -237,6 +247,7 @@ __global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_agg(PairArg
     __shared__ uint32_t mhi[AQ][ABS];
     __shared__ unsigned short mofs[AQ][ABS];
     __shared__ uint32_t qbase[AQ];
+    __shared__ int qown[AQ]; // profiling (ablate 4/5): slot holds the destinations' own row of cells
     __shared__ int wx[2 * (ABS / 64) + 2];
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -328,12 +339,14 @@ __global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_agg(PairArg
                     // candidate index of bit 0 of the current slot: read from LDS only
                     // when the slot changes, not on the dependent chain of every hit
                     uint32_t jb = qbase[0] + mofs[0][t];
+                    int own = qown[0];
                     for (;;) {
                         while (m0 == 0 && m1 == 0 && q + 1 < nq) {
                             ++q;
                             m0 = mlo[q][t];
                             m1 = mhi[q][t];
                             jb = qbase[q] + mofs[q][t];
+                            own = qown[q];
                         }
                         const bool has = (m0 != 0) || (m1 != 0);
                         if (!__any(has)) break;
@@ -342,7 +355,9 @@ __global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_agg(PairArg
                             if (m0) { bit = __builtin_ctzll(m0); m0 &= m0 - 1; }
                             else { bit = 64 + __builtin_ctz(m1); m1 &= m1 - 1; }
                             // ablate 3 (profiling): every gather hits the destination's own record (L1-resident)
-                            do_pair(a.ablate == 3 ? a.d_off + ic : jb + bit, sd.flags);
+                            // ablate 4: own-row hits skipped; 5: own-row hits gather the destination's own record
+                            if (!(a.ablate == 4 && own))
+                                do_pair((a.ablate == 3 || (a.ablate == 5 && own)) ? a.d_off + ic : jb + bit, sd.flags);
                         }
                     }
                 }
@@ -421,7 +436,7 @@ __global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_agg(PairArg
                         mlo[nq][t] = m0;
                         mhi[nq][t] = m1;
                         mofs[nq][t] = (unsigned short)s0;
-                        if (t == 0) qbase[nq] = sd.off + tb;
+                        if (t == 0) { qbase[nq] = sd.off + tb; qown[nq] = (dz == 0 && dy == 0); }
                         // ---- rare: a lane's 3-cell range is longer than AMAXLEN -> exact tail, in place
                         if (__any(len > AMAXLEN)) {
                             for (int k = AMAXLEN; k < len; k++) do_pair(sd.off + tb + s0 + k, sd.flags);
@@ -440,3 +455,221 @@ __global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_agg(PairArg
     if (active) Fam::finish(D, a, o);
 }
 
+
+// ---------------------------------------------------------------------------
+// variant 6: the aggregated kernel with a lean phase 2.
+//   Phase 1 is that of variant 3.  A lane keeps its hit bits as a private list
+//   of NON-EMPTY slots {64-bit mask, absolute index of bit 0} (a row whose range
+//   is longer than 64 candidates makes two slots), so phase 2 is one loop per
+//   lane -- pop the lowest bit, step to the next slot when the mask runs empty,
+//   gather, exact criterion, pair -- with no shared slot bookkeeping, no barrier
+//   between the phases and (CF != 0) the equation flags known at compile time.
+// ---------------------------------------------------------------------------
+#define LQ_UH 11  // slots per lane, uniform h (3 tile planes): 39 976 B of LDS per workgroup -> 4 per CU
+#define LQ_VH 10  // variable h (4 tile planes)
+
+template <class Fam, int KK, bool UH, bool F32 = false, uint32_t CF = 0>
+__global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_lean(PairArgs<Fam> a)
+{
+    const uint32_t NR = (uint32_t)a.nrec;
+    constexpr int TS = ACAP + 8;
+    constexpr int LQ = UH ? LQ_UH : LQ_VH;
+    __shared__ __attribute__((aligned(16))) float tile[(UH ? 3 : 4) * TS];
+    float *const tx = tile, *const ty = tile + TS, *const tz = tile + 2 * TS, *const tw = tile + (UH ? 0 : 3 * TS);
+    __shared__ uint32_t csl[72];
+    __shared__ unsigned long long smask[LQ][ABS];
+    __shared__ uint32_t sjb[LQ][ABS];
+    __shared__ int wx[2 * (ABS / 64) + 2];
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    uint32_t dtile = xcd_tile(blockIdx.x, gridDim.x);
+    if (a.d_tile_order) dtile = a.d_tile_order[dtile];
+    const uint32_t i = dtile * ABS + t;
+    const bool valid = i < a.nd;
+    const uint32_t ic = valid ? i : a.nd - 1;
+    const uint32_t o = a.d_perm[ic];
+    const bool active = valid && o >= a.d_start && o < a.d_stop;
+    double4 pi;
+    typename Fam::Dest D;
+    {
+        double sd_[Fam::NA];
+        if (F32) load_record_f32<Fam>(reinterpret_cast<const float *>(a.rec) + (size_t)(a.d_off + ic) * NR, pi, sd_);
+        else load_record<Fam, UH>(a.rec + (size_t)(a.d_off + ic) * NR, a.dflags, pi, sd_);
+        if (UH) pi.w = a.hu;
+        Fam::load(D, sd_, a, o);
+    }
+    const uint32_t key = a.d_keys[ic];
+    const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
+    const int cx = key % ncx;
+    const int row = key / ncx;
+    const double hi_r = a.radius_scale * pi.w;
+    const double hi2 = UH ? a.hr2u : hi_r * hi_r;
+
+    if (t == 0) wx[2 * (ABS / 64)] = row;
+    if (t == ABS - 1) wx[2 * (ABS / 64) + 1] = row;
+    __syncthreads();
+    const int row_first = wx[2 * (ABS / 64)], row_last = wx[2 * (ABS / 64) + 1];
+
+    // exact criterion + pair arithmetic for one candidate record
+    auto do_pair = [&](uint32_t jg, uint32_t flags) {
+        double4 pj;
+        double sj[Fam::NA];
+        if (F32) load_record_f32<Fam>(reinterpret_cast<const float *>(a.rec) + (unsigned long long)jg * NR, pj, sj);
+        else load_record<Fam, UH>(a.rec + (unsigned long long)jg * NR, flags, pj, sj);
+        double hj2 = hi2;
+        if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
+        const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+        if (((r2 < hi2) || (r2 < hj2)) && a.ablate != 1) Fam::template pair<KK, UH>(D, pi, pj, r2, sj, flags, a);
+    };
+    // the same for every lane of the wavefront, `has` = this lane holds a candidate:
+    // families with PRED take the criterion as a factor instead of a branch
+    auto do_pair_all = [&](uint32_t jg, uint32_t flags, bool has) {
+        if constexpr (!Fam::PRED) {
+            if (has) do_pair(jg, flags);
+        } else {
+            double4 pj;
+            double sj[Fam::NA];
+            if (F32) load_record_f32<Fam>(reinterpret_cast<const float *>(a.rec) + (unsigned long long)jg * NR, pj, sj);
+            else load_record<Fam, UH>(a.rec + (unsigned long long)jg * NR, flags, pj, sj);
+            double hj2 = hi2;
+            if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
+            const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+            const bool pass = has && ((r2 < hi2) || (r2 < hj2)) && a.ablate != 1;
+            Fam::template pair<KK, UH>(D, pi, pj, r2, sj, flags, a, pass);
+        }
+    };
+
+    int cq = 0; // slots this lane holds
+    // phase 2 over this lane's slots (wave-collective only through the loop condition)
+    auto phase2 = [&](uint32_t flags) {
+        unsigned long long m = 0;
+        uint32_t jb = 0;
+        int q = 0;
+        if (cq > 0 && a.ablate != 2) { m = smask[0][t]; jb = sjb[0][t]; }
+        const uint32_t self = a.d_off + ic; // lanes without a candidate gather their own record (in L1) and contribute nothing
+        if (__any(m != 0)) {
+            do {
+                const bool has = m != 0;
+                const uint32_t j = has ? jb + (uint32_t)__builtin_ctzll(m) : self;
+                m &= m - 1;
+                if (m == 0 && q + 1 < cq) { ++q; m = smask[q][t]; jb = sjb[q][t]; }
+                do_pair_all(a.ablate == 3 ? self : j, flags, has);
+            } while (__any(m != 0));
+        }
+        cq = 0;
+    };
+
+    for (int R = row_first; R <= row_last; R++) {
+        const bool inseg = active && row == R;
+        const unsigned long long segm = __ballot(inseg);
+        int cxa_w = 0x7fffffff, cxb_w = -1;
+        if (segm) {
+            cxa_w = __builtin_amdgcn_readlane(cx, __builtin_ctzll(segm));
+            cxb_w = __builtin_amdgcn_readlane(cx, 63 - __builtin_clzll(segm));
+        }
+        __syncthreads();
+        if (lane == 0) { wx[2 * wv] = cxa_w; wx[2 * wv + 1] = cxb_w; }
+        __syncthreads();
+        int cxa = wx[0], cxb = wx[1];
+#pragma unroll
+        for (int w2 = 1; w2 < ABS / 64; w2++) { cxa = min(cxa, wx[2 * w2]); cxb = max(cxb, wx[2 * w2 + 1]); }
+        if (cxb < 0) continue;
+        const int cyR = R % ncy, czR = R / ncy;
+        const int xa = max(cxa - 1, 0), xb = min(cxb + 1, ncx - 1);
+        const int ncs = xb - xa + 2;
+        const float oxf = (float)(a.cell_size * xa);
+        const float oyf = (float)(a.cell_size * (cyR - 1));
+        const float ozf = (float)(a.cell_size * (czR - 1));
+        const double L = fmax(a.cell_size * (double)max(xb - xa + 2, 4), a.dom_extent);
+        const float slack = (float)(L * 1.5e-6);
+        const float4 fpi = a.fpos[a.d_off + ic];
+        const float fxs = fpi.x - oxf, fys = fpi.y - oyf, fzs = fpi.z - ozf;
+        const f2 fx = {fxs, fxs}, fy = {fys, fys}, fz = {fzs, fzs};
+        const float hif = (float)hi_r * 1.000001f + slack;
+        const float hi2f = hif * hif;
+        const int mycl = max(cx - 1, xa) - xa, mych = min(cx + 1, xb) + 1 - xa;
+
+        for (int s = 0; s < a.nsrc; s++) {
+            const SrcDesc sd = a.src[s];
+            const uint32_t fl = CF ? CF : sd.flags;
+            for (int dz = -1; dz <= 1; dz++)
+                for (int dy = -1; dy <= 1; dy++) {
+                    const int yy = cyR + dy, zz = czR + dz;
+                    if (yy < 0 || yy >= ncy || zz < 0 || zz >= ncz) continue;
+                    const uint32_t rowb = (uint32_t)(ncx * (yy + ncy * zz));
+                    const uint32_t j0 = sd.cell_start[rowb + xa], j1 = sd.cell_start[rowb + xb + 1];
+                    for (uint32_t tb = j0; tb < j1; tb += ACAP) {
+                        const int tn = (int)min((uint32_t)ACAP, j1 - tb);
+                        // room for this tile's (at most two) slots
+                        if (__any(cq > LQ - 2)) phase2(fl);
+                        __syncthreads(); // previous tile's readers are done
+                        for (int q = t; q < ncs && q < 72; q += ABS) csl[q] = sd.cell_start[rowb + xa + q];
+                        for (int k = t; k < tn + 8; k += ABS) {
+                            float vx = 3.0e18f, vy = 3.0e18f, vz = 3.0e18f, vw = 0.f;
+                            if (k < tn) {
+                                const float4 fj = a.fpos[sd.off + tb + k];
+                                vx = fj.x - oxf; vy = fj.y - oyf; vz = fj.z - ozf;
+                                const float hjf = fj.w * 1.000001f + slack;
+                                vw = hjf * hjf;
+                            }
+                            tx[k] = vx; ty[k] = vy; tz[k] = vz;
+                            if (!UH) tw[k] = vw;
+                        }
+                        __syncthreads();
+                        int s0 = 0, len = 0;
+                        if (inseg) {
+                            int lo, hi;
+                            if (ncs <= 72) { lo = (int)(csl[mycl] - tb); hi = (int)(csl[mych] - tb); }
+                            else { lo = (int)(sd.cell_start[rowb + xa + mycl] - tb); hi = (int)(sd.cell_start[rowb + xa + mych] - tb); }
+                            lo = max(lo, 0); hi = min(hi, tn);
+                            s0 = lo & ~1;
+                            len = hi - s0;
+                        }
+                        const int lenc = min(len, AMAXLEN);
+                        uint32_t wd[3] = {0u, 0u, 0u};
+#pragma unroll
+                        for (int gw = 0; gw < 3; gw++) {
+                            if (!__any(32 * gw < lenc)) break; // wave-uniform
+                            uint32_t mm = 0;
+                            int g8 = 0;
+                            for (; g8 < 4 && __any(32 * gw + 8 * g8 < lenc); g8++) {
+                                const float *tb0 = tile + (s0 + 32 * gw + 8 * g8);
+#pragma unroll
+                                for (int p = 0; p < 4; p++) {
+                                    const f2 X = *reinterpret_cast<const f2 *>(tb0 + 2 * p);
+                                    const f2 Y = *reinterpret_cast<const f2 *>(tb0 + TS + 2 * p);
+                                    const f2 Z = *reinterpret_cast<const f2 *>(tb0 + 2 * TS + 2 * p);
+                                    const f2 ex = fx - X, ey = fy - Y, ez = fz - Z;
+                                    f2 nthr = {-hi2f, -hi2f};
+                                    if (!UH) {
+                                        const f2 W = *reinterpret_cast<const f2 *>(tb0 + 3 * TS + 2 * p);
+                                        nthr.x = -fmaxf(hi2f, W.x);
+                                        nthr.y = -fmaxf(hi2f, W.y);
+                                    }
+                                    f2 d = __builtin_elementwise_fma(ex, ex, nthr);
+                                    d = __builtin_elementwise_fma(ey, ey, d);
+                                    d = __builtin_elementwise_fma(ez, ez, d);
+                                    mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.x), 31);
+                                    mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.y), 31);
+                                }
+                            }
+                            if (g8 < 4) mm <<= 8 * (4 - g8);
+                            mm = __builtin_bitreverse32(mm);
+                            const int rem = lenc - 32 * gw;
+                            wd[gw] = rem >= 32 ? mm : (rem > 0 ? (mm & ((1u << rem) - 1u)) : 0u);
+                        }
+                        const unsigned long long m0 = (unsigned long long)wd[0] | ((unsigned long long)wd[1] << 32);
+                        const uint32_t jb0 = sd.off + tb + (uint32_t)s0;
+                        if (m0) { smask[cq][t] = m0; sjb[cq][t] = jb0; cq++; }
+                        if (wd[2]) { smask[cq][t] = wd[2]; sjb[cq][t] = jb0 + 64u; cq++; }
+                        // rare: a lane's 3-cell range is longer than AMAXLEN -> exact tail, in place
+                        if (__any(len > AMAXLEN)) {
+                            for (int k = AMAXLEN; k < len; k++) do_pair(sd.off + tb + s0 + k, fl);
+                        }
+                    }
+                }
+            phase2(fl);
+        }
+    }
+    if (active) Fam::finish(D, a, o);
+}
