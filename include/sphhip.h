@@ -214,6 +214,10 @@ int sph_eval_group(sph_ctx *ctx, const sph_kernel *kernel, const sph_group *grou
  * user slot, or a new user slot (process-wide table; <0: table full).       */
 int sph_prop_register(const char *name);
 
+/* x sub-bins per cell in the device sort key (sph_nnps.hip k_cell_keys): particles of a
+ * cell are ordered along x, fine_start has one entry per sub-bin. */
+#define SPH_NSUB 8
+
 #define SPH_GEN_MAX_PROPS 48
 #define SPH_GEN_MAX_SPROPS 20
 #define SPH_GEN_MAX_PAR 64
@@ -226,13 +230,14 @@ typedef struct sph_gen_args {
     int kernel_kind, uniform_h;
     int nsrc;                     /* 0: equations without sources only    */
     const uint32_t *src_cell_start[SPH_MAX_ARRAYS];
+    const uint32_t *src_fine_start[SPH_MAX_ARRAYS]; /* per x sub-bin of a cell (sph_nnps.hip)     */
     uint32_t src_off[SPH_MAX_ARRAYS], src_flags[SPH_MAX_ARRAYS];
     const double *rec;            /* packed records [x y z h | sprops...]  */
     int nrec;                     /* doubles per record                    */
     const void *fpos;             /* float4 prefilter positions            */
     double dom_extent;
     uint32_t d_off, nd;
-    const uint32_t *d_keys, *d_perm;
+    const uint32_t *d_keys, *d_fkeys, *d_perm; /* cell ids, fine (sub-bin) keys, sorted -> original */
     const uint32_t *d_tile_order; /* traversal order of the 256-particle destination tiles, or NULL */
     uint32_t d_start, d_stop, dflags;
     int nc[3];

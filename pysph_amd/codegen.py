@@ -1185,6 +1185,8 @@ class GeneratedFamily(object):
             A('')
         A('struct FamGen {')
         A('    static constexpr int MINB = SPHGEN_MINB;   // workgroups per CU, chosen at build time')
+        A('    static constexpr bool PRED = false;        // the neighbour criterion stays a branch around pair()')
+        A('    static constexpr uint32_t CF0 = 0;         // equation flags are run-time values')
         A('    static constexpr int NA = %d;' % na)
         A('    static constexpr int NR = 4 + NA;')
         A('    struct Params {')
@@ -1389,9 +1391,9 @@ class GeneratedFamily(object):
         A('    PairArgs<FamGen> a;')
         A('    memset(&a, 0, sizeof a);')
         A('    a.nsrc = g->nsrc;')
-        A('    for (int j = 0; j < g->nsrc; j++) a.src[j] = {g->src_cell_start[j], g->src_off[j], g->src_flags[j]};')
+        A('    for (int j = 0; j < g->nsrc; j++) a.src[j] = {g->src_cell_start[j], g->src_off[j], g->src_flags[j], g->src_fine_start[j]};')
         A('    a.rec = g->rec; a.nrec = g->nrec; a.fpos = (const float4 *)g->fpos; a.dom_extent = g->dom_extent;')
-        A('    a.d_off = g->d_off; a.nd = g->nd; a.d_keys = g->d_keys; a.d_perm = g->d_perm;')
+        A('    a.d_off = g->d_off; a.nd = g->nd; a.d_keys = g->d_keys; a.d_fkeys = g->d_fkeys; a.d_perm = g->d_perm;')
         A('    a.d_tile_order = g->d_tile_order;')
         A('    a.d_start = g->d_start; a.d_stop = g->d_stop; a.dflags = g->dflags;')
         A('    for (int k = 0; k < 3; k++) { a.nc[k] = g->nc[k]; a.xmin[k] = g->xmin[k]; }')
@@ -1423,11 +1425,11 @@ class GeneratedFamily(object):
         A('        hipLaunchKernelGGL(k_gen_nosrc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);')
         A('    } else {')
         A('        if (g->nrec != (g->rec_f32 ? ((4 + FamGen::NA + 3) & ~3) : g->uniform_h ? %d : FamGen::NR)) return -1002;' % nrc)
-        A('        dim3 grid((a.nd + ABS - 1) / ABS), block(ABS);')
-        A('        if (g->rec_f32 && g->uniform_h) hipLaunchKernelGGL((k_pair_agg<FamGen, %d, true, true>), grid, block, 0, st, a);' % self.kernel_kind)
-        A('        else if (g->rec_f32) hipLaunchKernelGGL((k_pair_agg<FamGen, %d, false, true>), grid, block, 0, st, a);' % self.kernel_kind)
-        A('        else if (g->uniform_h) hipLaunchKernelGGL((k_pair_agg<FamGen, %d, true>), grid, block, 0, st, a);' % self.kernel_kind)
-        A('        else hipLaunchKernelGGL((k_pair_agg<FamGen, %d, false>), grid, block, 0, st, a);' % self.kernel_kind)
+        A('        dim3 grid(4 * ((a.nd + 255) / 256)), block(64);')
+        A('        if (g->rec_f32 && g->uniform_h) hipLaunchKernelGGL((k_pair_wave<FamGen, %d, true, true>), grid, block, 0, st, a);' % self.kernel_kind)
+        A('        else if (g->rec_f32) hipLaunchKernelGGL((k_pair_wave<FamGen, %d, false, true>), grid, block, 0, st, a);' % self.kernel_kind)
+        A('        else if (g->uniform_h) hipLaunchKernelGGL((k_pair_wave<FamGen, %d, true>), grid, block, 0, st, a);' % self.kernel_kind)
+        A('        else hipLaunchKernelGGL((k_pair_wave<FamGen, %d, false>), grid, block, 0, st, a);' % self.kernel_kind)
         A('    }')
         A('    return (int)hipGetLastError();')
         A('}')
@@ -1477,7 +1479,7 @@ class GeneratedFamily(object):
             scratch, in_pair = 0, False
             for ln in log.splitlines():
                 if 'Function Name:' in ln:
-                    in_pair = 'k_pair_agg' in ln
+                    in_pair = 'k_pair_wave' in ln
                 elif in_pair and 'ScratchSize' in ln:
                     scratch = max(scratch, int(ln.split(':')[-1].split('[')[0]))
             self.minb, self.scratch = minb, scratch

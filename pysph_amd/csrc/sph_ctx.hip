@@ -129,7 +129,7 @@ int sph_ctx_destroy(sph_ctx *c)
         for (auto &p : A.prop) if (p) (void)hipFree(p);
         A.keys.release(); A.keys_sorted.release(); A.idx.release(); A.perm.release();
         A.tile_key.release(); A.tile_id.release(); A.tile_order.release();
-        A.cell_start.release();
+        A.cell_start.release(); A.fkeys_sorted.release(); A.fine_start.release();
     }
     for (auto &H : c->halo)
         for (int s = 0; s < 2; s++) { H.flag[s].release(); H.pos[s].release(); H.list[s].release(); }

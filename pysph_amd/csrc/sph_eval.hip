@@ -394,10 +394,6 @@ __device__ __forceinline__ void load_record_wcsph(const double *__restrict__ rj,
 {
     const double2 *r2 = reinterpret_cast<const double2 *>(rj);
     const double2 a0 = r2[0], a1 = r2[1], b0 = r2[2], b1 = r2[3], c = r2[4];
-    // keep the five 16-B pieces together, ahead of the exact criterion: without
-    // this use the optimiser sinks the non-position pieces into the pair branch
-    // (as misaligned loads), i.e. two memory latencies per hit
-    asm volatile("" ::"v"(a0.x), "v"(a0.y), "v"(a1.x), "v"(a1.y), "v"(b0.x), "v"(b0.y), "v"(b1.x), "v"(b1.y), "v"(c.x), "v"(c.y));
     pj.x = a0.x; pj.y = a0.y; pj.z = a1.x; pj.w = 0.0;
     s[0] = b0.x; s[1] = b0.y; s[2] = b1.x; s[3] = b1.y; s[4] = c.x; s[5] = c.y; s[6] = a1.y; s[7] = 0.0;
     if (!UH || (fl & F_TENSILE)) {
@@ -410,7 +406,7 @@ template <> __device__ __forceinline__ void load_record<FamWCSPH, false>(const d
 
 // ---- density summations (basic_equations.py:19-29, transport_velocity.py:24-58)
 struct FamDensity {
-    static constexpr bool PRED = false;
+    static constexpr bool PRED = true; // see FamWCSPH
     static constexpr uint32_t CF0 = F_TVFSD; // flag set compiled as a constant (variant 6)
     static constexpr int MINB = 4; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
     static constexpr int NA = 1; // m
@@ -420,11 +416,12 @@ struct FamDensity {
     template <class A> static __device__ __forceinline__ void load(Dest &D, const double *a, const A &, uint32_t) { D.m = a[0]; D.rho = 0.0; D.V = 0.0; }
     template <int KK, bool UH, class A>
     static __device__ __forceinline__ void pair(Dest &D, const double4 &pi, const double4 &pj, double r2,
-                                                const double (&s)[NA], uint32_t fl, const A &a)
+                                                const double (&s)[NA], uint32_t fl, const A &a, bool pass = true)
     {
         PairGeom g;
         pair_geom<KK, UH>(g, pi, pj, r2, a);
         double wij = pair_w<KK, UH>(g);
+        wij = pass ? wij : 0.0; // PRED: a pair outside the criterion adds exactly zero
         if (fl & F_SD) D.rho += s[0] * wij;
         if (fl & F_TVFSD) { D.V += wij; D.rho += D.m * wij; }
     }
@@ -447,7 +444,7 @@ template <> __device__ __forceinline__ void load_record<FamDensity, true>(const 
 
 // ---- TVF momentum terms (transport_velocity.py:219-545) -------------------
 struct FamTVF {
-    static constexpr bool PRED = false;
+    static constexpr bool PRED = true; // see FamWCSPH
     static constexpr uint32_t CF0 = F_TP | F_TVISC | F_TAS; // flag set compiled as a constant (variant 6)
     static constexpr int MINB = 3; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
     static constexpr int NA = 12; // u v w uhat vhat what rho p V m Vj2 pad
@@ -468,11 +465,12 @@ struct FamTVF {
     }
     template <int KK, bool UH, class A>
     static __device__ __forceinline__ void pair(Dest &D, const double4 &pi, const double4 &pj, double r2,
-                                                const double (&s)[NA], uint32_t fl, const A &a)
+                                                const double (&s)[NA], uint32_t fl, const A &a, bool pass = true)
     {
         PairGeom g;
         pair_geom<KK, UH>(g, pi, pj, r2, a);
         double tg = pair_gradfac<KK, UH>(g);
+        tg = pass ? tg : 0.0; // PRED: every term carries DWIJ
         double dw0 = tg * g.xij[0], dw1 = tg * g.xij[1], dw2 = tg * g.xij[2];
         double rhoj = s[6], Vj2 = s[10];
         double vsum = D.Vi2 + Vj2;
@@ -544,7 +542,7 @@ template <> __device__ __forceinline__ void load_record<FamTVF, true>(const doub
 
 // ---- velocity gradient (basic_equations.py:63-148) -------------------------
 struct FamVGrad {
-    static constexpr bool PRED = false;
+    static constexpr bool PRED = true; // see FamWCSPH
     static constexpr uint32_t CF0 = F_VG3; // flag set compiled as a constant (variant 6)
     static constexpr int MINB = 4; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
     static constexpr int NA = 4; // u v w m/rho
@@ -558,11 +556,12 @@ struct FamVGrad {
     }
     template <int KK, bool UH, class A>
     static __device__ __forceinline__ void pair(Dest &D, const double4 &pi, const double4 &pj, double r2,
-                                                const double (&s)[NA], uint32_t fl, const A &a)
+                                                const double (&s)[NA], uint32_t fl, const A &a, bool pass = true)
     {
         PairGeom g;
         pair_geom<KK, UH>(g, pi, pj, r2, a);
-        const double tg = pair_gradfac<KK, UH>(g);
+        double tg = pair_gradfac<KK, UH>(g);
+        tg = pass ? tg : 0.0; // PRED
         const double dw[3] = {tg * g.xij[0], tg * g.xij[1], tg * g.xij[2]};
         const double tmp = s[3]; // m/rho (divided once per particle by k_pack)
         const double nv[3] = {-(D.u - s[0]), -(D.v - s[1]), -(D.w - s[2])};
@@ -588,7 +587,7 @@ struct FamVGrad {
 //      MonaghanArtificialViscosity + XSPH  (solid_mech/basic.py:245-387,
 //      basic_equations.py:177-300) -------------------------------------------
 struct FamElastic {
-    static constexpr bool PRED = false;
+    static constexpr bool PRED = true; // see FamWCSPH
     static constexpr uint32_t CF0 = F_ECONT | F_ESTRESS | F_EAV | F_EXSPH; // flag set compiled as a constant (variant 6)
     static constexpr int MINB = 2; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
     static constexpr int NA = 18; // u v w m rho cs | t00 t01 t02 t11 t12 t22 (= sigma/rho^2) | r00 r01 r02 r11 r12 r22
@@ -609,11 +608,12 @@ struct FamElastic {
     }
     template <int KK, bool UH, class A>
     static __device__ __forceinline__ void pair(Dest &D, const double4 &pi, const double4 &pj, double r2,
-                                                const double (&s)[NA], uint32_t fl, const A &a)
+                                                const double (&s)[NA], uint32_t fl, const A &a, bool pass = true)
     {
         PairGeom g;
         pair_geom<KK, UH>(g, pi, pj, r2, a);
-        const double tg = pair_gradfac<KK, UH>(g);
+        double tg = pair_gradfac<KK, UH>(g);
+        tg = pass ? tg : 0.0; // PRED: terms carry DWIJ, the XSPH one WIJ
         const double dw0 = tg * g.xij[0], dw1 = tg * g.xij[1], dw2 = tg * g.xij[2];
         const double vij0 = D.u - s[0], vij1 = D.v - s[1], vij2 = D.w - s[2];
         const double vdotx = vij0 * g.xij[0] + vij1 * g.xij[1] + vij2 * g.xij[2];
@@ -621,6 +621,7 @@ struct FamElastic {
         if (fl & F_ECONT) D.arho = fma(mj * tg, vdotx, D.arho);
         double wij = 0.0;
         if (fl & (F_ESTRESS | F_EXSPH)) wij = pair_w<KK, UH>(g);
+        wij = pass ? wij : 0.0;
         if (fl & F_ESTRESS) { // solid_mech/basic.py:267-387
             double fab = 0.0;
             if (a.p.wdeltap > 0.) {
@@ -1070,16 +1071,16 @@ template <class Fam> static void launch_pair(sph_ctx *c, int kk, const PairArgs<
     if (a.nd == 0) return;
     const bool uh = c->uniform_h && c->use_uniform_h;
     if (c->pair_variant == 6) {
-        dim3 g2(div_up(a.nd, ABS)), b2(ABS);
+        dim3 g2(4 * div_up(a.nd, 256)), b2(64);
         // equation flags as a compile-time constant when every source carries the same set
         uint32_t cf = a.src[0].flags;
         for (int j = 1; j < a.nsrc; j++) if (a.src[j].flags != cf) cf = 0;
         if (c->const_flags == 0) cf = 0;
-#define LAUNCH6F(K, UHV, CFV) hipLaunchKernelGGL((k_pair_lean<Fam, K, UHV, false, CFV>), g2, b2, 0, c->stream, a)
+#define LAUNCH6F(K, UHV, CFV) hipLaunchKernelGGL((k_pair_wave<Fam, K, UHV, false, CFV>), g2, b2, 0, c->stream, a)
 #define LAUNCH6(K)                                                                                      \
         if (c->record_f32) {                                                                            \
-            if (uh) hipLaunchKernelGGL((k_pair_lean<Fam, K, true, true>), g2, b2, 0, c->stream, a);     \
-            else hipLaunchKernelGGL((k_pair_lean<Fam, K, false, true>), g2, b2, 0, c->stream, a);       \
+            if (uh) hipLaunchKernelGGL((k_pair_wave<Fam, K, true, true>), g2, b2, 0, c->stream, a);     \
+            else hipLaunchKernelGGL((k_pair_wave<Fam, K, false, true>), g2, b2, 0, c->stream, a);       \
         } else if (uh) { if (cf == Fam::CF0) LAUNCH6F(K, true, Fam::CF0); else LAUNCH6F(K, true, 0); }  \
         else { if (cf == Fam::CF0) LAUNCH6F(K, false, Fam::CF0); else LAUNCH6F(K, false, 0); }
         switch (kk) {
@@ -1299,9 +1300,9 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
                 a.p.ax = D.prop[SPH_AX]; a.p.ay = D.prop[SPH_AY]; a.p.az = D.prop[SPH_AZ];
             }
             a.nsrc = nsrcs;
-            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j]};
+            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j], c->arr[srcs[j]].fine_start.as<uint32_t>()};
             a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
-            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
+            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
             a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
             a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
             launch_pair<FamWCSPH>(c, K->kind, a);
@@ -1314,9 +1315,9 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             if (dflags & F_TVFSD) { SPH_TRY(ensure_out(c, dst, {SPH_VOL})); a.p.V = D.prop[SPH_VOL]; }
             if ((dflags & F_SD) && (dflags & F_TVFSD)) { sph_set_error("both SummationDensity flavours on one destination"); return SPH_ERR_UNSUPPORTED; }
             a.nsrc = nsrcs;
-            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j]};
+            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j], c->arr[srcs[j]].fine_start.as<uint32_t>()};
             a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
-            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
+            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
             a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
             a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
             launch_pair<FamDensity>(c, K->kind, a);
@@ -1331,9 +1332,9 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
                 if (used) { SPH_TRY(sph_array_ensure_prop(c, dst, vp[k])); a.p.v[k] = D.prop[vp[k]]; }
             }
             a.nsrc = nsrcs;
-            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j]};
+            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j], c->arr[srcs[j]].fine_start.as<uint32_t>()};
             a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
-            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
+            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
             a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
             a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
             launch_pair<FamVGrad>(c, K->kind, a);
@@ -1356,9 +1357,9 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
                 a.p.ax = D.prop[SPH_AX]; a.p.ay = D.prop[SPH_AY]; a.p.az = D.prop[SPH_AZ];
             }
             a.nsrc = nsrcs;
-            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j]};
+            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j], c->arr[srcs[j]].fine_start.as<uint32_t>()};
             a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
-            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
+            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
             a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
             a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
             launch_pair<FamElastic>(c, K->kind, a);
@@ -1378,9 +1379,9 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
                 a.p.auhat = D.prop[SPH_AUHAT]; a.p.avhat = D.prop[SPH_AVHAT]; a.p.awhat = D.prop[SPH_AWHAT];
             }
             a.nsrc = nsrcs;
-            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j]};
+            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j], c->arr[srcs[j]].fine_start.as<uint32_t>()};
             a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
-            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
+            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
             a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
             a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
             launch_pair<FamTVF>(c, K->kind, a);
@@ -1596,12 +1597,14 @@ static int eval_generated_launches(sph_ctx *c, const sph_kernel *K, const sph_ge
             for (int jj = 0; jj < ns; jj++) {
                 const int j = idx[jj];
                 q.src_cell_start[jj] = c->arr[f->src[j]].cell_start.as<uint32_t>();
+                q.src_fine_start[jj] = c->arr[f->src[j]].fine_start.as<uint32_t>();
                 q.src_off[jj] = (uint32_t)off_of[jj];
                 q.src_flags[jj] = f->src_flags[j];
                 q.dflags |= f->src_flags[j];
             }
             q.d_off = (uint32_t)d_off;
             q.d_keys = D.keys_sorted.as<uint32_t>();
+            q.d_fkeys = D.fkeys_sorted.as<uint32_t>();
             q.d_perm = D.perm.as<uint32_t>();
             q.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
         }

@@ -47,6 +47,7 @@ struct DevArray {
     // neighbour-search state (valid after sph_nnps_update)
     DevBuf keys, keys_sorted, idx, perm; // uint32 each; perm: sorted position -> original index
     DevBuf cell_start;                   // uint32[n_cells + 1]
+    DevBuf fkeys_sorted, fine_start;     // sorted fine keys (cell * SPH_NSUB + x sub-bin); uint32[n_cells * SPH_NSUB + 1]
     DevBuf tile_key, tile_id, tile_order; // traversal order of the 256-particle destination tiles (aggregated kernel)
     size_t n_tiles = 0;
     int nnps_slot = -1;                  // position in the last sph_nnps_update list
@@ -92,7 +93,7 @@ struct sph_ctx {
     double *pinned = nullptr; // small pinned host buffer (64 doubles)
 
     // options
-    long pair_variant = 3;
+    long pair_variant = 6;
     long ablate = 0;
     long const_flags = 1;   // variant 6: compile-time equation flags when all sources agree (0: always run-time flags)
     long use_uniform_h = 1;

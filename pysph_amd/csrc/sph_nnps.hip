@@ -126,20 +126,46 @@ struct GridDesc {
 };
 
 // nnps_base.pxd:39-57 real_to_int = <int>floor(real_val/step), flatten_raw :83-96
+// The sort key is FINER than the reference's cell id: key = cell * SPH_NSUB +
+// sub, sub = the particle's x position inside its cell in SPH_NSUB sub-bins.
+// Cells stay the reference's (cell id = key / SPH_NSUB, cell_start per cell);
+// the sub-bins only order the particles of a cell along x, so that a pair
+// kernel can cut a destination's candidate range in a row of cells from three
+// whole cells to its x window (fine_start per sub-bin).  Costs no extra radix
+// pass (18 + 3 bits at 4 M particles).
 __global__ __launch_bounds__(256) void k_cell_keys(const double *__restrict__ x, const double *__restrict__ y,
                                                    const double *__restrict__ z, size_t n, GridDesc g,
                                                    uint32_t *__restrict__ keys, uint32_t *__restrict__ idx)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int cx = (int)floor((x[i] - g.xmin[0]) / g.cell_size);
+    const double ux = (x[i] - g.xmin[0]) / g.cell_size;
+    int cx = (int)floor(ux);
     int cy = (int)floor((y[i] - g.xmin[1]) / g.cell_size);
     int cz = (int)floor((z[i] - g.xmin[2]) / g.cell_size);
-    cx = min(max(cx, 0), g.nc[0] - 1);
+    int sub = (int)floor((ux - (double)cx) * SPH_NSUB);
+    if (cx < 0) { cx = 0; sub = 0; }
+    if (cx > g.nc[0] - 1) { cx = g.nc[0] - 1; sub = SPH_NSUB - 1; }
+    sub = min(max(sub, 0), SPH_NSUB - 1);
     cy = min(max(cy, 0), g.nc[1] - 1);
     cz = min(max(cz, 0), g.nc[2] - 1);
-    keys[i] = (uint32_t)(cx + g.nc[0] * (cy + g.nc[1] * cz));
+    keys[i] = (uint32_t)(cx + g.nc[0] * (cy + g.nc[1] * cz)) * SPH_NSUB + (uint32_t)sub;
     idx[i] = (uint32_t)i;
+}
+
+// fine (sub-bin) keys of the sorted order -> cell ids
+__global__ __launch_bounds__(256) void k_coarse_keys(const uint32_t *__restrict__ fkeys, size_t n, uint32_t *__restrict__ keys)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = fkeys[i] / SPH_NSUB;
+}
+
+// cell_start[c] = fine_start[c * SPH_NSUB]
+__global__ __launch_bounds__(256) void k_coarse_start(const uint32_t *__restrict__ fine_start, uint32_t n_cells,
+                                                      uint32_t *__restrict__ cell_start)
+{
+    size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c <= n_cells) cell_start[c] = fine_start[c * SPH_NSUB];
 }
 
 // Traversal order of the destination tiles (runs of SPH_TILE cell-sorted
@@ -164,21 +190,32 @@ __global__ __launch_bounds__(256) void k_tile_keys(const uint32_t *__restrict__ 
     id[t] = t;
 }
 
-// cell_start[c] = first sorted position whose key >= c, for c in [0, n_cells]:
-// one thread per cell, lower_bound over the sorted keys (no atomics, no scan,
-// cost independent of how sparsely an array occupies the grid).
-__global__ __launch_bounds__(256) void k_cell_start(const uint32_t *__restrict__ skeys, size_t n, uint32_t n_cells,
-                                                    uint32_t *__restrict__ cell_start)
+// start[k] = first sorted position whose key >= k, for k in [0, ntab]: thread i
+// owns the boundary between sorted positions i-1 and i and fills the table
+// entries in (key[i-1], key[i]] with i.  Short gaps are written by the owning
+// lane, long ones (empty rows / planes of a sparsely occupied grid) by the whole
+// wavefront -- O(n + ntab) stores, no atomics, no scan, no per-entry search.
+__global__ __launch_bounds__(256) void k_cell_start(const uint32_t *__restrict__ skeys, size_t n, uint32_t ntab,
+                                                    uint32_t *__restrict__ start)
 {
-    size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > n_cells) return;
-    size_t lo = 0, hi = n;
-    while (lo < hi) {
-        size_t mid = (lo + hi) >> 1;
-        if (skeys[mid] < (uint32_t)c) lo = mid + 1;
-        else hi = mid;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    long first = 0, last = -1; // entries first..last get the value i
+    if (i <= n) {
+        first = i > 0 ? (long)skeys[i - 1] + 1 : 0;
+        last = i < n ? (long)skeys[i] : (long)ntab;
     }
-    cell_start[c] = (uint32_t)lo;
+    const bool big = last - first >= 64;
+    if (!big)
+        for (long k = first; k <= last; k++) start[k] = (uint32_t)i;
+    unsigned long long m = __ballot(big);
+    while (m) {
+        const int src = __builtin_ctzll(m);
+        m &= m - 1;
+        const long f = __shfl(first, src, 64), l = __shfl(last, src, 64);
+        const uint32_t v = (uint32_t)__shfl((unsigned long long)i, src, 64);
+        for (long k = f + lane; k <= l; k += 64) start[k] = v;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_fill_u32(uint32_t *p, size_t n, uint32_t v)
@@ -291,7 +328,8 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
     GridDesc g;
     for (int k = 0; k < 3; k++) { g.xmin[k] = c->xmin[k]; g.nc[k] = c->nc[k]; }
     g.cell_size = cell_size;
-    int end_bit = bits_for(n_cells_alloc);
+    const size_t n_fine = (size_t)n_cells_alloc * SPH_NSUB;
+    int end_bit = bits_for((long)n_fine);
 
     for (int a = 0; a < narrays; a++) {
         c->ids[a] = ids[a];
@@ -304,23 +342,31 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
         SPH_TRY(A.idx.reserve((n + 1) * 4));
         SPH_TRY(A.perm.reserve((n + 1) * 4));
         SPH_TRY(A.cell_start.reserve(((size_t)n_cells_alloc + 1) * 4));
+        SPH_TRY(A.fkeys_sorted.reserve((n + 1) * 4));
+        SPH_TRY(A.fine_start.reserve((n_fine + 1) * 4));
         if (n == 0) {
             hipLaunchKernelGGL(k_fill_u32, dim3(div_up(n_cells_alloc + 1, 256)), dim3(256), 0, c->stream,
                                A.cell_start.as<uint32_t>(), (size_t)n_cells_alloc + 1, 0u);
+            hipLaunchKernelGGL(k_fill_u32, dim3(div_up(n_fine + 1, 256)), dim3(256), 0, c->stream,
+                               A.fine_start.as<uint32_t>(), n_fine + 1, 0u);
             continue;
         }
         hipLaunchKernelGGL(k_cell_keys, dim3(div_up(n, 256)), dim3(256), 0, c->stream, A.prop[SPH_X], A.prop[SPH_Y],
                            A.prop[SPH_Z], n, g, A.keys.as<uint32_t>(), A.idx.as<uint32_t>());
         size_t tmp_bytes = 0;
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, A.keys.as<uint32_t>(), A.keys_sorted.as<uint32_t>(),
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, A.keys.as<uint32_t>(), A.fkeys_sorted.as<uint32_t>(),
                                                    A.idx.as<uint32_t>(), A.perm.as<uint32_t>(), (int)n, 0, end_bit,
                                                    c->stream));
         SPH_TRY(c->cub_tmp.reserve(tmp_bytes));
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.ptr, tmp_bytes, A.keys.as<uint32_t>(),
-                                                   A.keys_sorted.as<uint32_t>(), A.idx.as<uint32_t>(),
+                                                   A.fkeys_sorted.as<uint32_t>(), A.idx.as<uint32_t>(),
                                                    A.perm.as<uint32_t>(), (int)n, 0, end_bit, c->stream));
-        hipLaunchKernelGGL(k_cell_start, dim3(div_up((size_t)n_cells_alloc + 1, 256)), dim3(256), 0, c->stream,
-                           A.keys_sorted.as<uint32_t>(), n, (uint32_t)n_cells_alloc, A.cell_start.as<uint32_t>());
+        hipLaunchKernelGGL(k_coarse_keys, dim3(div_up(n, 256)), dim3(256), 0, c->stream, A.fkeys_sorted.as<uint32_t>(), n,
+                           A.keys_sorted.as<uint32_t>());
+        hipLaunchKernelGGL(k_cell_start, dim3(div_up(n + 1, 256)), dim3(256), 0, c->stream,
+                           A.fkeys_sorted.as<uint32_t>(), n, (uint32_t)n_fine, A.fine_start.as<uint32_t>());
+        hipLaunchKernelGGL(k_coarse_start, dim3(div_up((size_t)n_cells_alloc + 1, 256)), dim3(256), 0, c->stream,
+                           A.fine_start.as<uint32_t>(), (uint32_t)n_cells_alloc, A.cell_start.as<uint32_t>());
         // tile traversal order (only worth it when there is more than one z plane of tiles)
         A.n_tiles = 0;
         if (c->tile_block_rows > 0 && c->nc[2] > 1 && n > 64 * SPH_TILE) {

@@ -44,6 +44,7 @@ struct SrcDesc {
     const uint32_t *cell_start;
     uint32_t off;    // offset of this source's segment in the packed buffers
     uint32_t flags;  // equations acting for this (dest, source) pair
+    const uint32_t *fine_start; // first sorted position per x sub-bin (SPH_NSUB per cell)
 };
 
 template <class Fam> struct PairArgs {
@@ -56,7 +57,7 @@ template <class Fam> struct PairArgs {
     const float4 *fpos; // variant 3: fp32 grid-relative positions + radius_scale*h (prefilter only)
     double dom_extent;  // largest grid extent: bounds the fp32 rounding of fpos
     uint32_t d_off, nd;
-    const uint32_t *d_keys, *d_perm;
+    const uint32_t *d_keys, *d_fkeys, *d_perm; // cell ids / fine keys of the sorted destinations, sorted -> original index
     const uint32_t *d_tile_order; // traversal order of the destination tiles (null: memory order)
     uint32_t d_start, d_stop;
     int nc[3];
@@ -196,6 +197,19 @@ __device__ __forceinline__ void load_record_f32(const float *__restrict__ rj, do
     pj.x = f[0]; pj.y = f[1]; pj.z = f[2]; pj.w = f[3];
 #pragma unroll
     for (int k = 0; k < Fam::NA; k++) s[k] = f[4 + k];
+}
+
+// Branching kernels (`if (criterion) pair(...)`) call this between the gather
+// and the criterion: the use keeps all pieces of the record in ONE batch of
+// loads ahead of the branch.  Without it the optimiser sinks the non-position
+// pieces into the branch (as misaligned loads): two memory latencies per hit.
+template <int NA>
+__device__ __forceinline__ void pin_record(const double4 &pj, const double (&s)[NA])
+{
+    asm volatile("" ::"v"(pj.x), "v"(pj.y), "v"(pj.z));
+#pragma unroll
+    for (int k = 0; k < NA; k++)
+        if (!__builtin_constant_p(s[k])) asm volatile("" ::"v"(s[k]));
 }
 
 // ---- WCSPH: Continuity + Momentum + XSPH (wc/basic.py, basic_equations.py) --
@@ -457,34 +471,49 @@ __global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_agg(PairArg
 
 
 // ---------------------------------------------------------------------------
-// variant 6: the aggregated kernel with a lean phase 2.
-//   Phase 1 is that of variant 3.  A lane keeps its hit bits as a private list
-//   of NON-EMPTY slots {64-bit mask, absolute index of bit 0} (a row whose range
-//   is longer than 64 candidates makes two slots), so phase 2 is one loop per
-//   lane -- pop the lowest bit, step to the next slot when the mask runs empty,
-//   gather, exact criterion, pair -- with no shared slot bookkeeping, no barrier
-//   between the phases and (CF != 0) the equation flags known at compile time.
+// variant 6 (default): one WAVEFRONT per 64 consecutive cell-ordered
+// destinations, no workgroup barriers.
+//   Phase 1 (per row of cells, per source): the wavefront stages the fp32
+//   positions of ITS candidate range of the row (x sub-bins [first lane - XWIN,
+//   last lane + XWIN], ~100 candidates) and the row's fine_start slice in its own
+//   LDS tile; every lane tests the candidates of its own x window (its sub-bin
+//   +- XWIN instead of three whole cells), two per packed-fp32 instruction, one
+//   sign bit each, and appends its NON-EMPTY 64-bit hit masks to a private slot
+//   list {mask, absolute index of bit 0}.
+//   Phase 2 (once per source): one loop per lane -- pop the lowest bit, step to
+//   the next slot when the mask runs empty, gather the fp64 record, exact
+//   criterion, pair -- wave-collective only through the loop condition.  Lanes
+//   that have run out of hits gather their own record (in L1) and contribute
+//   nothing; families with PRED take the criterion as a factor, so the loop body
+//   is branch-free and the accumulators stay in their registers.  With CF != 0
+//   the equation flags are a compile-time constant.
+//   Measured on the 4 M cube against the 256-thread workgroup version of the
+//   same schedule (barriers around every shared row tile): see DESIGN.md.
 // ---------------------------------------------------------------------------
-#define LQ_UH 11  // slots per lane, uniform h (3 tile planes): 39 976 B of LDS per workgroup -> 4 per CU
-#define LQ_VH 10  // variable h (4 tile planes)
+#define WLQ 11      // slots per lane
+#define WCAP 120    // candidates per LDS tile piece
+#define WCSL 96     // fine_start entries of one row segment kept in LDS (16-bit, relative to the segment start)
+#define XWIN (SPH_NSUB + 1) // a lane's candidate window: its own x sub-bin +- XWIN (one bin of slack for the
+                            // rounding of the sub-bin index: |x_j - x_i| < cell_size spans at most SPH_NSUB bins exactly)
 
 template <class Fam, int KK, bool UH, bool F32 = false, uint32_t CF = 0>
-__global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_lean(PairArgs<Fam> a)
+__global__ __launch_bounds__(64, Fam::MINB) void k_pair_wave(PairArgs<Fam> a)
 {
     const uint32_t NR = (uint32_t)a.nrec;
-    constexpr int TS = ACAP + 8;
-    constexpr int LQ = UH ? LQ_UH : LQ_VH;
+    constexpr int TS = WCAP + 8;
     __shared__ __attribute__((aligned(16))) float tile[(UH ? 3 : 4) * TS];
     float *const tx = tile, *const ty = tile + TS, *const tz = tile + 2 * TS, *const tw = tile + (UH ? 0 : 3 * TS);
-    __shared__ uint32_t csl[72];
-    __shared__ unsigned long long smask[LQ][ABS];
-    __shared__ uint32_t sjb[LQ][ABS];
-    __shared__ int wx[2 * (ABS / 64) + 2];
+    __shared__ unsigned short csl[WCSL];
+    __shared__ unsigned long long smask[WLQ][64];
+    __shared__ uint32_t sjb[WLQ][64];
 
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    uint32_t dtile = xcd_tile(blockIdx.x, gridDim.x);
+    const int t = threadIdx.x; // = lane
+    // 64-destination wave tiles inside the 256-destination tiles of the traversal order
+    const uint32_t wt = xcd_tile(blockIdx.x, gridDim.x);
+    uint32_t dtile = wt >> 2;
     if (a.d_tile_order) dtile = a.d_tile_order[dtile];
-    const uint32_t i = dtile * ABS + t;
+    const uint32_t i = dtile * 256u + (wt & 3u) * 64u + t;
+    if (dtile * 256u + (wt & 3u) * 64u >= a.nd) return; // whole wavefront past the end
     const bool valid = i < a.nd;
     const uint32_t ic = valid ? i : a.nd - 1;
     const uint32_t o = a.d_perm[ic];
@@ -493,101 +522,94 @@ __global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_lean(PairAr
     typename Fam::Dest D;
     {
         double sd_[Fam::NA];
+        // the destination's own h / p come with the same rules as a source's
+        // (uniform h: the constant; p only for the tensile correction)
         if (F32) load_record_f32<Fam>(reinterpret_cast<const float *>(a.rec) + (size_t)(a.d_off + ic) * NR, pi, sd_);
         else load_record<Fam, UH>(a.rec + (size_t)(a.d_off + ic) * NR, a.dflags, pi, sd_);
         if (UH) pi.w = a.hu;
         Fam::load(D, sd_, a, o);
     }
-    const uint32_t key = a.d_keys[ic];
+    const uint32_t fkey = a.d_fkeys[ic];
+    const uint32_t key = fkey / SPH_NSUB;
     const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
-    const int cx = key % ncx;
     const int row = key / ncx;
+    const int cx = (int)(key % ncx) * SPH_NSUB + (int)(fkey % SPH_NSUB); // x sub-bin along the row
+    const int nfx = ncx * SPH_NSUB;
     const double hi_r = a.radius_scale * pi.w;
     const double hi2 = UH ? a.hr2u : hi_r * hi_r;
+    const int row_first = __builtin_amdgcn_readfirstlane(row), row_last = __builtin_amdgcn_readlane(row, 63);
 
-    if (t == 0) wx[2 * (ABS / 64)] = row;
-    if (t == ABS - 1) wx[2 * (ABS / 64) + 1] = row;
-    __syncthreads();
-    const int row_first = wx[2 * (ABS / 64)], row_last = wx[2 * (ABS / 64) + 1];
-
-    // exact criterion + pair arithmetic for one candidate record
+    // exact criterion + pair arithmetic for one candidate record (branching form)
     auto do_pair = [&](uint32_t jg, uint32_t flags) {
         double4 pj;
         double sj[Fam::NA];
         if (F32) load_record_f32<Fam>(reinterpret_cast<const float *>(a.rec) + (unsigned long long)jg * NR, pj, sj);
         else load_record<Fam, UH>(a.rec + (unsigned long long)jg * NR, flags, pj, sj);
+        pin_record<Fam::NA>(pj, sj);
         double hj2 = hi2;
         if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
         const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
         if (((r2 < hi2) || (r2 < hj2)) && a.ablate != 1) Fam::template pair<KK, UH>(D, pi, pj, r2, sj, flags, a);
     };
-    // the same for every lane of the wavefront, `has` = this lane holds a candidate:
-    // families with PRED take the criterion as a factor instead of a branch
-    auto do_pair_all = [&](uint32_t jg, uint32_t flags, bool has) {
-        if constexpr (!Fam::PRED) {
-            if (has) do_pair(jg, flags);
-        } else {
-            double4 pj;
-            double sj[Fam::NA];
-            if (F32) load_record_f32<Fam>(reinterpret_cast<const float *>(a.rec) + (unsigned long long)jg * NR, pj, sj);
-            else load_record<Fam, UH>(a.rec + (unsigned long long)jg * NR, flags, pj, sj);
-            double hj2 = hi2;
-            if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
-            const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-            const bool pass = has && ((r2 < hi2) || (r2 < hj2)) && a.ablate != 1;
-            Fam::template pair<KK, UH>(D, pi, pj, r2, sj, flags, a, pass);
-        }
-    };
 
     int cq = 0; // slots this lane holds
-    // phase 2 over this lane's slots (wave-collective only through the loop condition)
     auto phase2 = [&](uint32_t flags) {
         unsigned long long m = 0;
         uint32_t jb = 0;
         int q = 0;
         if (cq > 0 && a.ablate != 2) { m = smask[0][t]; jb = sjb[0][t]; }
-        const uint32_t self = a.d_off + ic; // lanes without a candidate gather their own record (in L1) and contribute nothing
+        const uint32_t self = a.d_off + ic;
         if (__any(m != 0)) {
             do {
                 const bool has = m != 0;
-                const uint32_t j = has ? jb + (uint32_t)__builtin_ctzll(m) : self;
+                uint32_t j = has ? jb + (uint32_t)__builtin_ctzll(m) : self;
                 m &= m - 1;
                 if (m == 0 && q + 1 < cq) { ++q; m = smask[q][t]; jb = sjb[q][t]; }
-                do_pair_all(a.ablate == 3 ? self : j, flags, has);
+                if (a.ablate == 3) j = self;
+                if constexpr (Fam::PRED) {
+                    double4 pj;
+                    double sj[Fam::NA];
+                    if (F32) load_record_f32<Fam>(reinterpret_cast<const float *>(a.rec) + (unsigned long long)j * NR, pj, sj);
+                    else load_record<Fam, UH>(a.rec + (unsigned long long)j * NR, flags, pj, sj);
+                    double hj2 = hi2;
+                    if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
+                    const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+                    const bool pass = has && ((r2 < hi2) || (r2 < hj2)) && a.ablate != 1;
+                    Fam::template pair<KK, UH>(D, pi, pj, r2, sj, flags, a, pass);
+                } else {
+                    if (has) do_pair(j, flags);
+                }
             } while (__any(m != 0));
         }
         cq = 0;
     };
 
     for (int R = row_first; R <= row_last; R++) {
+        if (a.ablate == 6) break; // profiling: prologue + finish only
         const bool inseg = active && row == R;
         const unsigned long long segm = __ballot(inseg);
-        int cxa_w = 0x7fffffff, cxb_w = -1;
-        if (segm) {
-            cxa_w = __builtin_amdgcn_readlane(cx, __builtin_ctzll(segm));
-            cxb_w = __builtin_amdgcn_readlane(cx, 63 - __builtin_clzll(segm));
-        }
-        __syncthreads();
-        if (lane == 0) { wx[2 * wv] = cxa_w; wx[2 * wv + 1] = cxb_w; }
-        __syncthreads();
-        int cxa = wx[0], cxb = wx[1];
-#pragma unroll
-        for (int w2 = 1; w2 < ABS / 64; w2++) { cxa = min(cxa, wx[2 * w2]); cxb = max(cxb, wx[2 * w2 + 1]); }
-        if (cxb < 0) continue;
+        if (!segm) continue;
+        const int cxa = __builtin_amdgcn_readlane(cx, __builtin_ctzll(segm));
+        const int cxb = __builtin_amdgcn_readlane(cx, 63 - __builtin_clzll(segm));
         const int cyR = R % ncy, czR = R / ncy;
-        const int xa = max(cxa - 1, 0), xb = min(cxb + 1, ncx - 1);
-        const int ncs = xb - xa + 2;
-        const float oxf = (float)(a.cell_size * xa);
+        // x sub-bins this segment's destinations can reach, and mine
+        const int xa = max(cxa - XWIN, 0), xb = min(cxb + XWIN, nfx - 1);
+        const int ncs = xb - xa + 2; // fine_start entries needed: bins xa..xb and the end
+        const double binw = a.cell_size * (1.0 / SPH_NSUB);
+        // fp32 coordinates: grid-relative positions (fpos, rounded once from
+        // fp64) minus this row segment's origin; every value carries at most
+        // 2^-24 * dom_extent of rounding, covered by `slack`
+        const float oxf = (float)(binw * xa);
         const float oyf = (float)(a.cell_size * (cyR - 1));
         const float ozf = (float)(a.cell_size * (czR - 1));
-        const double L = fmax(a.cell_size * (double)max(xb - xa + 2, 4), a.dom_extent);
+        const double L = fmax(a.cell_size * (double)max((xb - xa) / SPH_NSUB + 2, 4), a.dom_extent);
         const float slack = (float)(L * 1.5e-6);
         const float4 fpi = a.fpos[a.d_off + ic];
         const float fxs = fpi.x - oxf, fys = fpi.y - oyf, fzs = fpi.z - ozf;
         const f2 fx = {fxs, fxs}, fy = {fys, fys}, fz = {fzs, fzs};
         const float hif = (float)hi_r * 1.000001f + slack;
         const float hi2f = hif * hif;
-        const int mycl = max(cx - 1, xa) - xa, mych = min(cx + 1, xb) + 1 - xa;
+        const int mycl = max(cx - XWIN, xa) - xa, mych = min(cx + XWIN, xb) + 1 - xa;
 
         for (int s = 0; s < a.nsrc; s++) {
             const SrcDesc sd = a.src[s];
@@ -596,15 +618,16 @@ __global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_lean(PairAr
                 for (int dy = -1; dy <= 1; dy++) {
                     const int yy = cyR + dy, zz = czR + dz;
                     if (yy < 0 || yy >= ncy || zz < 0 || zz >= ncz) continue;
-                    const uint32_t rowb = (uint32_t)(ncx * (yy + ncy * zz));
-                    const uint32_t j0 = sd.cell_start[rowb + xa], j1 = sd.cell_start[rowb + xb + 1];
-                    for (uint32_t tb = j0; tb < j1; tb += ACAP) {
-                        const int tn = (int)min((uint32_t)ACAP, j1 - tb);
+                    const uint32_t rowb = (uint32_t)(ncx * (yy + ncy * zz)) * SPH_NSUB; // fine index of the row's first sub-bin
+                    const uint32_t j0 = sd.fine_start[rowb + xa], j1 = sd.fine_start[rowb + xb + 1];
+                    const bool csl_ok = ncs <= WCSL && j1 - j0 < 65536u;
+                    for (uint32_t tb = j0; tb < j1; tb += WCAP) {
+                        const int tn = (int)min((uint32_t)WCAP, j1 - tb);
                         // room for this tile's (at most two) slots
-                        if (__any(cq > LQ - 2)) phase2(fl);
-                        __syncthreads(); // previous tile's readers are done
-                        for (int q = t; q < ncs && q < 72; q += ABS) csl[q] = sd.cell_start[rowb + xa + q];
-                        for (int k = t; k < tn + 8; k += ABS) {
+                        if (__any(cq > WLQ - 2)) phase2(fl);
+                        if (csl_ok && tb == j0)
+                            for (int q = t; q < ncs; q += 64) csl[q] = (unsigned short)(sd.fine_start[rowb + xa + q] - j0);
+                        for (int k = t; k < tn + 8; k += 64) {
                             float vx = 3.0e18f, vy = 3.0e18f, vz = 3.0e18f, vw = 0.f;
                             if (k < tn) {
                                 const float4 fj = a.fpos[sd.off + tb + k];
@@ -615,17 +638,21 @@ __global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_lean(PairAr
                             tx[k] = vx; ty[k] = vy; tz[k] = vz;
                             if (!UH) tw[k] = vw;
                         }
-                        __syncthreads();
+                        // the tile is private to this wavefront: its LDS accesses execute in
+                        // program order, the fence only keeps the compiler from reordering them
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         int s0 = 0, len = 0;
                         if (inseg) {
                             int lo, hi;
-                            if (ncs <= 72) { lo = (int)(csl[mycl] - tb); hi = (int)(csl[mych] - tb); }
-                            else { lo = (int)(sd.cell_start[rowb + xa + mycl] - tb); hi = (int)(sd.cell_start[rowb + xa + mych] - tb); }
+                            if (csl_ok) { lo = (int)(j0 + csl[mycl] - tb); hi = (int)(j0 + csl[mych] - tb); }
+                            else { lo = (int)(sd.fine_start[rowb + xa + mycl] - tb); hi = (int)(sd.fine_start[rowb + xa + mych] - tb); }
                             lo = max(lo, 0); hi = min(hi, tn);
                             s0 = lo & ~1;
                             len = hi - s0;
                         }
-                        const int lenc = min(len, AMAXLEN);
+                        const int lenc = a.ablate == 7 ? 0 : min(len, AMAXLEN); // 7 (profiling): staging only
+                        // One sign bit per candidate: d = |x_i - x_j|^2 - thr^2 in packed fp32 FMAs,
+                        // shifted into a 32-bit word with v_alignbit (1 VALU per candidate).
                         uint32_t wd[3] = {0u, 0u, 0u};
 #pragma unroll
                         for (int gw = 0; gw < 3; gw++) {
@@ -633,7 +660,7 @@ __global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_lean(PairAr
                             uint32_t mm = 0;
                             int g8 = 0;
                             for (; g8 < 4 && __any(32 * gw + 8 * g8 < lenc); g8++) {
-                                const float *tb0 = tile + (s0 + 32 * gw + 8 * g8);
+                                const float *tb0 = tile + (s0 + 32 * gw + 8 * g8); // one address, constant offsets below
 #pragma unroll
                                 for (int p = 0; p < 4; p++) {
                                     const f2 X = *reinterpret_cast<const f2 *>(tb0 + 2 * p);
@@ -643,7 +670,7 @@ __global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_lean(PairAr
                                     f2 nthr = {-hi2f, -hi2f};
                                     if (!UH) {
                                         const f2 W = *reinterpret_cast<const f2 *>(tb0 + 3 * TS + 2 * p);
-                                        nthr.x = -fmaxf(hi2f, W.x);
+                                        nthr.x = -fmaxf(hi2f, W.x); // r2 < hi^2 or r2 < hj^2
                                         nthr.y = -fmaxf(hi2f, W.y);
                                     }
                                     f2 d = __builtin_elementwise_fma(ex, ex, nthr);
@@ -654,15 +681,17 @@ __global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_lean(PairAr
                                 }
                             }
                             if (g8 < 4) mm <<= 8 * (4 - g8);
-                            mm = __builtin_bitreverse32(mm);
+                            mm = __builtin_bitreverse32(mm); // bit b <-> candidate 32*gw + b
+                            // candidates beyond this lane's range (its own tail / other lanes' longer ranges)
                             const int rem = lenc - 32 * gw;
                             wd[gw] = rem >= 32 ? mm : (rem > 0 ? (mm & ((1u << rem) - 1u)) : 0u);
                         }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // tile reads before the next tile's writes
                         const unsigned long long m0 = (unsigned long long)wd[0] | ((unsigned long long)wd[1] << 32);
                         const uint32_t jb0 = sd.off + tb + (uint32_t)s0;
                         if (m0) { smask[cq][t] = m0; sjb[cq][t] = jb0; cq++; }
                         if (wd[2]) { smask[cq][t] = wd[2]; sjb[cq][t] = jb0 + 64u; cq++; }
-                        // rare: a lane's 3-cell range is longer than AMAXLEN -> exact tail, in place
+                        // rare: a lane's range is longer than AMAXLEN -> exact tail, in place
                         if (__any(len > AMAXLEN)) {
                             for (int k = AMAXLEN; k < len; k++) do_pair(sd.off + tb + s0 + k, fl);
                         }
