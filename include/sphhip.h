@@ -175,8 +175,11 @@ int sph_nnps_minmax(sph_ctx *ctx, int narrays, const int *array_ids, double *out
  * (nnps_base.pyx:1290-1323) / GPUNeighborCache (gpu_nnps_base.pyx:54-117).
  * Pass 1 (nbrs==NULL): fills start[0..nd] (exclusive scan of the counts) and
  * *total.  Pass 2: fills nbrs[total]; each list is sorted ascending.  Host
- * buffers.                                                                 */
-int sph_nnps_get_csr(sph_ctx *ctx, int src, int dst, uint32_t *start, uint32_t *nbrs, size_t *total);
+ * buffers; start_len must equal nd + 1 with nd the DEVICE particle count of
+ * dst (sph_array_info: ghosts included), nbrs_len >= total -- a mismatch is
+ * SPH_ERR_ARG, never an overrun.                                            */
+int sph_nnps_get_csr(sph_ctx *ctx, int src, int dst, uint32_t *start, size_t start_len, uint32_t *nbrs,
+                     size_t nbrs_len, size_t *total);
 /* Permutation of array `array_id` into cell order (sorted -> original
  * index), n entries: get_spatially_ordered_indices
  * (linked_list_nnps.pyx:198-209).                                          */
@@ -347,9 +350,10 @@ int sph_halo_remove_selected(sph_ctx *ctx, int array_id, size_t *n_left);
  * v < vmin -> v + translate; v > vmax -> v - translate
  * (CPUDomainManager._box_wrap_periodic, pysph/base/nnps_base.pyx:699-748).   */
 int sph_domain_box_wrap(sph_ctx *ctx, int array_id, int axis, double vmin, double vmax, double translate);
-/* Ids of the properties that currently have device storage (out: up to
- * SPH_PROP_COUNT ints, *n receives the count).                              */
-int sph_array_props(sph_ctx *ctx, int array_id, int *out, int *n);
+/* Ids of the properties that currently have device storage: out[cap], *n
+ * receives the count (at most SPH_PROP_COUNT); SPH_ERR_ARG if cap is too
+ * small.                                                                    */
+int sph_array_props(sph_ctx *ctx, int array_id, int *out, int cap, int *n);
 
 /* ---------------------------------------------------------------------- */
 /* integrator stage sweeps (the caller either side of the hot path)         */

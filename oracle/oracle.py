@@ -212,6 +212,14 @@ class OracleNNPS(object):
             out.ctypes.data_as(C.POINTER(C.c_uint)), cap)
         return out[:n].copy()
 
+    def count_csr(self, src_index, dst_index, nthreads=1):
+        """start[nd+1] only (exclusive scan of the neighbour counts)"""
+        nd = self.particles[dst_index].get_number_of_particles()
+        start = np.zeros(nd + 1, dtype=np.uint32)
+        self._L.orc_nnps_csr(self._h, src_index, dst_index,
+                             start.ctypes.data_as(C.POINTER(C.c_uint)), None, nthreads)
+        return start
+
     def get_csr(self, src_index, dst_index, nthreads=1):
         nd = self.particles[dst_index].get_number_of_particles()
         start = np.zeros(nd + 1, dtype=np.uint32)

@@ -272,11 +272,15 @@ extern "C" int sph_domain_box_wrap(sph_ctx *c, int id, int axis, double vmin, do
     return SPH_OK;
 }
 
-extern "C" int sph_array_props(sph_ctx *c, int id, int *out, int *n)
+extern "C" int sph_array_props(sph_ctx *c, int id, int *out, int cap, int *n)
 {
     if (!c || id < 0 || id >= SPH_MAX_ARRAYS || !out || !n) { sph_set_error("sph_array_props: bad arguments"); return SPH_ERR_ARG; }
     int k = 0;
-    for (int p = 0; p < SPH_PROP_COUNT; p++) if (c->arr[id].prop[p]) out[k++] = p;
+    for (int p = 0; p < SPH_PROP_COUNT; p++)
+        if (c->arr[id].prop[p]) {
+            if (k >= cap) { sph_set_error("sph_array_props: buffer of %d ints is too small (SPH_PROP_COUNT = %d)", cap, SPH_PROP_COUNT); return SPH_ERR_ARG; }
+            out[k++] = p;
+        }
     *n = k;
     return SPH_OK;
 }

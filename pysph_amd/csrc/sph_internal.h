@@ -89,7 +89,7 @@ struct sph_ctx {
     double h_uniform = 0;
 
     // scratch
-    DevBuf cub_tmp, red_part, red_out, posh, aux, fposb, dkeys, dperm, tmp_u32a, tmp_u32b, gen_state;
+    DevBuf cub_tmp, red_part, red_out, posh, aux, fposb, dkeys, dperm, tmp_u32a, tmp_u32b, gen_state, gapq;
     double *pinned = nullptr; // small pinned host buffer (64 doubles)
 
     // options

@@ -193,10 +193,15 @@ __global__ __launch_bounds__(256) void k_tile_keys(const uint32_t *__restrict__ 
 // start[k] = first sorted position whose key >= k, for k in [0, ntab]: thread i
 // owns the boundary between sorted positions i-1 and i and fills the table
 // entries in (key[i-1], key[i]] with i.  Short gaps are written by the owning
-// lane, long ones (empty rows / planes of a sparsely occupied grid) by the whole
-// wavefront -- O(n + ntab) stores, no atomics, no scan, no per-entry search.
+// lane, medium ones by its wavefront, and the long ones (empty rows / planes of
+// a sparsely occupied grid: the obstacle of the dam break occupies 0.1 % of the
+// tank's cells) are queued for k_fill_gaps, which spreads each of them over the
+// whole grid -- O(n + ntab) stores, no atomics on the table, no per-entry search.
+#define GAP_WAVE 64      // gaps of at least this many entries: wave-cooperative
+#define GAP_GRID 8192    // ... and of at least this many: queued for k_fill_gaps
+#define GAP_QUEUE 4096   // queue capacity (a full queue falls back to the wave-cooperative fill)
 __global__ __launch_bounds__(256) void k_cell_start(const uint32_t *__restrict__ skeys, size_t n, uint32_t ntab,
-                                                    uint32_t *__restrict__ start)
+                                                    uint32_t *__restrict__ start, uint32_t *__restrict__ gapq)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -205,9 +210,16 @@ __global__ __launch_bounds__(256) void k_cell_start(const uint32_t *__restrict__
         first = i > 0 ? (long)skeys[i - 1] + 1 : 0;
         last = i < n ? (long)skeys[i] : (long)ntab;
     }
-    const bool big = last - first >= 64;
+    bool big = last - first >= GAP_WAVE;
     if (!big)
         for (long k = first; k <= last; k++) start[k] = (uint32_t)i;
+    if (big && last - first >= GAP_GRID) {
+        const uint32_t slot = atomicAdd(&gapq[0], 1u);
+        if (slot < GAP_QUEUE) {
+            gapq[4 + 3 * slot] = (uint32_t)first; gapq[5 + 3 * slot] = (uint32_t)last; gapq[6 + 3 * slot] = (uint32_t)i;
+            big = false;
+        }
+    }
     unsigned long long m = __ballot(big);
     while (m) {
         const int src = __builtin_ctzll(m);
@@ -215,6 +227,16 @@ __global__ __launch_bounds__(256) void k_cell_start(const uint32_t *__restrict__
         const long f = __shfl(first, src, 64), l = __shfl(last, src, 64);
         const uint32_t v = (uint32_t)__shfl((unsigned long long)i, src, 64);
         for (long k = f + lane; k <= l; k += 64) start[k] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill_gaps(const uint32_t *__restrict__ gapq, uint32_t *__restrict__ start)
+{
+    const uint32_t ng = min(gapq[0], (uint32_t)GAP_QUEUE);
+    for (uint32_t g = 0; g < ng; g++) {
+        const size_t f = gapq[4 + 3 * g], l = gapq[5 + 3 * g];
+        const uint32_t v = gapq[6 + 3 * g];
+        for (size_t k = f + (size_t)blockIdx.x * blockDim.x + threadIdx.x; k <= l; k += (size_t)gridDim.x * blockDim.x) start[k] = v;
     }
 }
 
@@ -363,8 +385,13 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
                                                    A.perm.as<uint32_t>(), (int)n, 0, end_bit, c->stream));
         hipLaunchKernelGGL(k_coarse_keys, dim3(div_up(n, 256)), dim3(256), 0, c->stream, A.fkeys_sorted.as<uint32_t>(), n,
                            A.keys_sorted.as<uint32_t>());
+        SPH_TRY(c->gapq.reserve((4 + 3 * GAP_QUEUE) * 4));
+        HIP_TRY(hipMemsetAsync(c->gapq.ptr, 0, 16, c->stream));
         hipLaunchKernelGGL(k_cell_start, dim3(div_up(n + 1, 256)), dim3(256), 0, c->stream,
-                           A.fkeys_sorted.as<uint32_t>(), n, (uint32_t)n_fine, A.fine_start.as<uint32_t>());
+                           A.fkeys_sorted.as<uint32_t>(), n, (uint32_t)n_fine, A.fine_start.as<uint32_t>(),
+                           c->gapq.as<uint32_t>());
+        hipLaunchKernelGGL(k_fill_gaps, dim3(512), dim3(256), 0, c->stream, c->gapq.as<uint32_t>(),
+                           A.fine_start.as<uint32_t>());
         hipLaunchKernelGGL(k_coarse_start, dim3(div_up((size_t)n_cells_alloc + 1, 256)), dim3(256), 0, c->stream,
                            A.fine_start.as<uint32_t>(), (uint32_t)n_cells_alloc, A.cell_start.as<uint32_t>());
         // tile traversal order (only worth it when there is more than one z plane of tiles)
@@ -462,9 +489,11 @@ __global__ __launch_bounds__(256) void k_csr(const double *__restrict__ dx, cons
     if (!FILL) start[i] = count;
 }
 
-extern "C" int sph_nnps_get_csr(sph_ctx *c, int src, int dst, uint32_t *start, uint32_t *nbrs, size_t *total)
+extern "C" int sph_nnps_get_csr(sph_ctx *c, int src, int dst, uint32_t *start, size_t start_len, uint32_t *nbrs,
+                                size_t nbrs_len, size_t *total)
 {
     if (!c->nnps_valid) { sph_set_error("sph_nnps_get_csr: call sph_nnps_update first"); return SPH_ERR_STATE; }
+    if (!start || !total) { sph_set_error("sph_nnps_get_csr: NULL start/total"); return SPH_ERR_ARG; }
     if (src < 0 || src >= SPH_MAX_ARRAYS || dst < 0 || dst >= SPH_MAX_ARRAYS || c->arr[src].nnps_slot < 0 ||
         c->arr[dst].nnps_slot < 0) {
         sph_set_error("sph_nnps_get_csr: arrays %d/%d are not part of the current grid", src, dst);
@@ -473,6 +502,13 @@ extern "C" int sph_nnps_get_csr(sph_ctx *c, int src, int dst, uint32_t *start, u
     HIP_TRY(hipSetDevice(c->device));
     DevArray &S = c->arr[src], &D = c->arr[dst];
     size_t nd = D.n;
+    // the caller sized `start` from ITS idea of the particle count; the device
+    // array may hold ghosts the host never saw
+    if (start_len != nd + 1) {
+        sph_set_error("sph_nnps_get_csr: start has %zu entries, destination %d holds %zu particles on the device (needs %zu)",
+                      start_len, dst, nd, nd + 1);
+        return SPH_ERR_ARG;
+    }
     GridDesc g;
     for (int k = 0; k < 3; k++) { g.xmin[k] = c->xmin[k]; g.nc[k] = c->nc[k]; }
     g.cell_size = c->cell_size;
@@ -493,6 +529,7 @@ extern "C" int sph_nnps_get_csr(sph_ctx *c, int src, int dst, uint32_t *start, u
         return SPH_OK;
     }
     size_t tot = start[nd];
+    if (nbrs_len < tot) { sph_set_error("sph_nnps_get_csr: nbrs has %zu entries, %zu needed", nbrs_len, tot); return SPH_ERR_ARG; }
     SPH_TRY(c->tmp_u32b.reserve((tot + 1) * 4));
     HIP_TRY(hipMemcpyAsync(d_start, start, (nd + 1) * 4, hipMemcpyHostToDevice, c->stream));
     if (nd)

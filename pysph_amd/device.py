@@ -65,8 +65,8 @@ SIGNATURES = {
                                   C.c_double, C.c_double, _PD]),
     'sph_nnps_info': (C.c_int, [_P, _PD, C.POINTER(C.c_long)]),
     'sph_nnps_minmax': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), _PD]),
-    'sph_nnps_get_csr': (C.c_int, [_P, C.c_int, C.c_int, _PU, _PU,
-                                   C.POINTER(C.c_size_t)]),
+    'sph_nnps_get_csr': (C.c_int, [_P, C.c_int, C.c_int, _PU, C.c_size_t, _PU,
+                                   C.c_size_t, C.POINTER(C.c_size_t)]),
     'sph_nnps_get_order': (C.c_int, [_P, C.c_int, _PU]),
     'sph_nnps_reorder_array': (C.c_int, [_P, C.c_int]),
     'sph_eval_group': (C.c_int, [_P, C.POINTER(SphKernel),
@@ -76,7 +76,7 @@ SIGNATURES = {
                                   C.POINTER(C.c_size_t)]),
     'sph_domain_box_wrap': (C.c_int, [_P, C.c_int, C.c_int, C.c_double,
                                       C.c_double, C.c_double]),
-    'sph_array_props': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int),
+    'sph_array_props': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.c_int,
                                   C.POINTER(C.c_int)]),
     'sph_halo_pack': (C.c_int, [_P, C.c_int, C.c_int, C.c_int,
                                 C.POINTER(C.c_int), C.c_int, C.c_double, _P]),
@@ -469,6 +469,15 @@ class HipDeviceHelper(object):
             0, min(out.size, self.get_number_of_particles())))
         return out
 
+    def device_props(self):
+        """ids of the properties that have device storage, ascending"""
+        cap = 512                       # > SPH_PROP_COUNT; the library checks it
+        ids = (C.c_int * cap)()
+        cnt = C.c_int(0)
+        _check(self.lib.sph_array_props(self.ctx._h, self.array_id, ids, cap,
+                                        C.byref(cnt)))
+        return [int(ids[k]) for k in range(cnt.value)]
+
     def sync_host(self, ghosts=False):
         """Make the host array mirror a device-managed array (after halo
         exchange / migration the device owns the particle count): resize the
@@ -479,17 +488,22 @@ class HipDeviceHelper(object):
         n = self.get_number_of_particles() if ghosts else nreal
         pa.resize(n)
         pa.set_num_real_particles(nreal)
-        ids = (C.c_int * 256)()
-        cnt = C.c_int(0)
-        _check(self.lib.sph_array_props(self.ctx._h, self.array_id, ids,
-                                        C.byref(cnt)))
-        on_device = set(int(ids[k]) for k in range(cnt.value))
+        on_device = set(self.device_props())
         for p in pa.properties:
             pid = prop_id(p)
-            if pid in on_device and get_npy(pa, p).dtype == np.float64:
-                arr = get_npy(pa, p)
+            if pid not in on_device:
+                continue
+            arr = get_npy(pa, p)
+            if arr.dtype == np.float64:
                 _check(self.lib.sph_array_pull(self.ctx._h, self.array_id, pid,
                                                arr.ctypes.data_as(_PD), 0, n))
+            elif arr.dtype.kind in 'iu':
+                # integer metadata mirrored as doubles (gid of a slab-decomposed
+                # array: it migrates with its particle)
+                tmp = np.empty(n)
+                _check(self.lib.sph_array_pull(self.ctx._h, self.array_id, pid,
+                                               tmp.ctypes.data_as(_PD), 0, n))
+                arr[:n] = tmp.astype(arr.dtype)
 
     def max(self, prop):
         out = C.c_double()

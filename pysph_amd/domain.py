@@ -151,7 +151,15 @@ class HipDomainManager(_DomainBase):
     """Device-resident periodic ghosts (sync='manual')."""
 
     def __init__(self, *args, **kw):
+        """slab: a SlabHalo / SlabDecomposition of the SAME arrays (multi-GPU).
+        Its axis is then the slab transport's business -- remote ghosts, the
+        periodic wrap 0 <-> P-1 with its coordinate shift
+        (nnps_base.pyx:841-856 done between ranks) -- and this manager makes the
+        images of the remaining axes AFTER that exchange, so that the corner
+        images of remote ghosts exist (the reference gets the same effect from
+        processing the axes one after the other, nnps_base.pyx:751-940)."""
         ctx = kw.pop('ctx', None)
+        self.slab = kw.pop('slab', None)
         _DomainBase.__init__(self, *args, **kw)
         self.ctx = ctx or dev.get_context()
         self.lib = self.ctx.lib
@@ -160,6 +168,14 @@ class HipDomainManager(_DomainBase):
         _DomainBase.set_particles(self, particles, radius_scale)
         self.helpers = [dev.attach(pa, self.ctx) for pa in self.particles]
         for h in self.helpers:
+            owner = getattr(h, 'ghost_owner', None)
+            if owner == 'slab' and self.slab is None:
+                # both keep their ghosts behind n_real and drop ALL of them on
+                # update: uncoordinated, each would delete the other's
+                raise RuntimeError(
+                    "array '%s' has a slab halo; pass it as HipDomainManager(slab=...) so "
+                    "that the two ghost layers are built in one ordered update" % h._pa.name)
+            h.ghost_owner = 'domain+slab' if self.slab is not None else 'domain'
             h.managed = True
 
     def _hmax(self):
@@ -170,9 +186,10 @@ class HipDomainManager(_DomainBase):
         return out[7]
 
     def update(self):
-        if not (self.is_periodic or self.is_mirror):
+        if not (self.is_periodic or self.is_mirror or self.slab is not None):
             return
         lib, ctx = self.lib, self.ctx._h
+        slab_axis = self.slab.axis if self.slab is not None else -1
         for h in self.helpers:
             nreal = h.get_number_of_particles(True)
             dev._check(lib.sph_array_resize(ctx, h.array_id, nreal, nreal))
@@ -182,18 +199,20 @@ class HipDomainManager(_DomainBase):
         import torch
         device = torch.device('cuda', self.ctx.device)
         for h in self.helpers:
-            aid = h.array_id
-            pr = (C.c_int * 64)()
-            npr = C.c_int()
-            dev._check(lib.sph_array_props(ctx, aid, pr, C.byref(npr)))
-            nprops = npr.value
             for ax in range(3):
-                if self.periodic[ax]:
+                if self.periodic[ax] and ax != slab_axis:
                     lo, hi = self.lims[ax]
-                    dev._check(lib.sph_domain_box_wrap(ctx, aid, ax, lo, hi,
+                    dev._check(lib.sph_domain_box_wrap(ctx, h.array_id, ax, lo, hi,
                                                        self.translate[ax]))
+        if self.slab is not None:
+            self.slab.exchange(drop=False)     # remote ghosts along the slab axis first
+        for h in self.helpers:
+            aid = h.array_id
+            props = h.device_props()
+            nprops = len(props)
+            pr = (C.c_int * max(nprops, 1))(*props)
             for ax in range(3):
-                if not self.periodic[ax]:
+                if not self.periodic[ax] or ax == slab_axis:
                     continue
                 lo, hi = self.lims[ax]
                 counts = (C.c_size_t * 2)()

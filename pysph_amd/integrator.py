@@ -62,40 +62,6 @@ def stepper_kind(step):
 STAGE_NAMES = ('initialize', 'stage1', 'stage2', 'stage3', 'stage4', 'stage5')
 
 
-class LeapFrogStep(IntegratorStep):
-    """integrator_step.py:708-730 (runs as a generated stepper)."""
-
-    def stage1(self, d_idx, d_x, d_y, d_z, d_u, d_v, d_w, d_ax, d_ay, d_az, dt):
-        d_x[d_idx] += 0.5 * dt * (d_u[d_idx] + d_ax[d_idx])
-        d_y[d_idx] += 0.5 * dt * (d_v[d_idx] + d_ay[d_idx])
-        d_z[d_idx] += 0.5 * dt * (d_w[d_idx] + d_az[d_idx])
-
-    def stage2(self, d_idx, d_x, d_y, d_z, d_u, d_au, d_v, d_av, d_w, d_aw, d_ax, d_ay,
-               d_az, d_rho, d_arho, d_e, d_ae, dt):
-        d_u[d_idx] += dt * d_au[d_idx]
-        d_v[d_idx] += dt * d_av[d_idx]
-        d_w[d_idx] += dt * d_aw[d_idx]
-        d_rho[d_idx] += dt * d_arho[d_idx]
-        d_e[d_idx] += dt * d_ae[d_idx]
-        d_x[d_idx] += 0.5 * dt * (d_u[d_idx] + d_ax[d_idx])
-        d_y[d_idx] += 0.5 * dt * (d_v[d_idx] + d_ay[d_idx])
-        d_z[d_idx] += 0.5 * dt * (d_w[d_idx] + d_az[d_idx])
-
-
-class EulerStep(IntegratorStep):
-    """integrator_step.py:22-35 (runs as a generated stepper)."""
-
-    def stage1(self, d_idx, d_u, d_v, d_w, d_au, d_av, d_aw, d_x, d_y, d_z, d_rho,
-               d_arho, dt):
-        d_u[d_idx] += dt * d_au[d_idx]
-        d_v[d_idx] += dt * d_av[d_idx]
-        d_w[d_idx] += dt * d_aw[d_idx]
-        d_x[d_idx] += dt * d_u[d_idx]
-        d_y[d_idx] += dt * d_v[d_idx]
-        d_z[d_idx] += dt * d_w[d_idx]
-        d_rho[d_idx] += dt * d_arho[d_idx]
-
-
 class Integrator(object):
     """pysph/sph/integrator.py:20-360 (default one_timestep == PEC)."""
 
@@ -231,150 +197,39 @@ class Integrator(object):
         return cfl * dt_min
 
     # -- user-overridable ----------------------------------------------------
+    # The order of operations of one time step is the user-visible protocol of
+    # the reference (its generated integrator inlines the SOURCE of
+    # one_timestep, integrator_cython_helper.py:177-181); subclasses may
+    # override one_timestep with any sequence of the calls below.  The two
+    # built-in sequences are data:
+    #   'init'            -> self.initialize()
+    #   'accel'           -> self.compute_accelerations()
+    #   ('stage', k, f)   -> self.stage<k>(); self.update_domain();
+    #                        self.do_post_stage(f * dt, k)
+    SEQUENCE = ('init', ('stage', 1, 0.5), 'accel', ('stage', 2, 1.0))  # PEC: pysph/sph/integrator.py:227-246
+
     def one_timestep(self, t, dt):
-        """integrator.py:227-246 (predict-evaluate-correct)."""
-        self.initialize()
-        self.stage1()
-        self.update_domain()
-        self.do_post_stage(0.5 * dt, 1)
-        self.compute_accelerations()
-        self.stage2()
-        self.update_domain()
-        self.do_post_stage(dt, 2)
+        for op in self.SEQUENCE:
+            if op == 'init':
+                self.initialize()
+            elif op == 'accel':
+                self.compute_accelerations()
+            else:
+                _, k, f = op
+                getattr(self, 'stage%d' % k)()
+                self.update_domain()
+                self.do_post_stage(f * dt, k)
 
 
 class PECIntegrator(Integrator):
-    """integrator.py:300-358."""
-
-
-class LeapFrogIntegrator(PECIntegrator):
-    """integrator.py:464-477."""
-
-    def one_timestep(self, t, dt):
-        self.stage1()
-        self.update_domain()
-        self.do_post_stage(0.5 * dt, 1)
-        self.compute_accelerations()
-        self.stage2()
-        self.update_domain()
-        self.do_post_stage(dt, 2)
-
-
-class EulerIntegrator(Integrator):
-    """integrator.py:426-437."""
-
-    def one_timestep(self, t, dt):
-        self.compute_accelerations()
-        self.stage1()
-        self.update_domain()
-        self.do_post_stage(dt, 1)
-
-
-class PEFRLStep(IntegratorStep):
-    """Position-extended Forest-Ruth-like scheme of Omelyan, Mryglod & Folk,
-    Comput. Phys. Commun. 146 (2002) 188 (integrator_step.py:738-830): five
-    position sub-steps with weights (xi, chi, 1-2(xi+chi), chi, xi) and four
-    velocity sub-steps with weights ((1-2 lam)/2, lam, lam, (1-2 lam)/2).
-    Runs as a generated stepper."""
-
-    def stage1(self, d_idx, d_x, d_y, d_z, d_u, d_v, d_w, d_ax, d_ay, d_az, dt):
-        cx = 0.1786178958448091 * dt
-        d_x[d_idx] += cx * (d_u[d_idx] + d_ax[d_idx])
-        d_y[d_idx] += cx * (d_v[d_idx] + d_ay[d_idx])
-        d_z[d_idx] += cx * (d_w[d_idx] + d_az[d_idx])
-
-    def stage2(self, d_idx, d_x, d_y, d_z, d_u, d_au, d_v, d_av, d_w, d_aw, d_ax, d_ay,
-               d_az, d_rho, d_arho, d_e, d_ae, dt):
-        cv = 0.5 * (1.0 - 2.0 * (-0.2123418310626054)) * dt
-        cx = -0.06626458266981849 * dt
-        d_u[d_idx] += cv * d_au[d_idx]
-        d_v[d_idx] += cv * d_av[d_idx]
-        d_w[d_idx] += cv * d_aw[d_idx]
-        d_rho[d_idx] += cv * d_arho[d_idx]
-        d_e[d_idx] += cv * d_ae[d_idx]
-        d_x[d_idx] += cx * (d_u[d_idx] + d_ax[d_idx])
-        d_y[d_idx] += cx * (d_v[d_idx] + d_ay[d_idx])
-        d_z[d_idx] += cx * (d_w[d_idx] + d_az[d_idx])
-
-    def stage3(self, d_idx, d_x, d_y, d_z, d_u, d_au, d_v, d_av, d_w, d_aw, d_ax, d_ay,
-               d_az, d_rho, d_arho, d_e, d_ae, dt):
-        cv = -0.2123418310626054 * dt
-        cx = (1.0 - 2.0 * (0.1786178958448091 + (-0.06626458266981849))) * dt
-        d_u[d_idx] += cv * d_au[d_idx]
-        d_v[d_idx] += cv * d_av[d_idx]
-        d_w[d_idx] += cv * d_aw[d_idx]
-        d_rho[d_idx] += cv * d_arho[d_idx]
-        d_e[d_idx] += cv * d_ae[d_idx]
-        d_x[d_idx] += cx * (d_u[d_idx] + d_ax[d_idx])
-        d_y[d_idx] += cx * (d_v[d_idx] + d_ay[d_idx])
-        d_z[d_idx] += cx * (d_w[d_idx] + d_az[d_idx])
-
-    def stage4(self, d_idx, d_x, d_y, d_z, d_u, d_au, d_v, d_av, d_w, d_aw, d_ax, d_ay,
-               d_az, d_rho, d_arho, d_e, d_ae, dt):
-        cv = -0.2123418310626054 * dt
-        cx = -0.06626458266981849 * dt
-        d_u[d_idx] += cv * d_au[d_idx]
-        d_v[d_idx] += cv * d_av[d_idx]
-        d_w[d_idx] += cv * d_aw[d_idx]
-        d_rho[d_idx] += cv * d_arho[d_idx]
-        d_e[d_idx] += cv * d_ae[d_idx]
-        d_x[d_idx] += cx * (d_u[d_idx] + d_ax[d_idx])
-        d_y[d_idx] += cx * (d_v[d_idx] + d_ay[d_idx])
-        d_z[d_idx] += cx * (d_w[d_idx] + d_az[d_idx])
-
-    def stage5(self, d_idx, d_x, d_y, d_z, d_u, d_au, d_v, d_av, d_w, d_aw, d_ax, d_ay,
-               d_az, d_rho, d_arho, d_e, d_ae, dt):
-        cv = 0.5 * (1.0 - 2.0 * (-0.2123418310626054)) * dt
-        cx = 0.1786178958448091 * dt
-        d_u[d_idx] += cv * d_au[d_idx]
-        d_v[d_idx] += cv * d_av[d_idx]
-        d_w[d_idx] += cv * d_aw[d_idx]
-        d_rho[d_idx] += cv * d_arho[d_idx]
-        d_e[d_idx] += cv * d_ae[d_idx]
-        d_x[d_idx] += cx * (d_u[d_idx] + d_ax[d_idx])
-        d_y[d_idx] += cx * (d_v[d_idx] + d_ay[d_idx])
-        d_z[d_idx] += cx * (d_w[d_idx] + d_az[d_idx])
-
-
-class PEFRLIntegrator(Integrator):
-    """integrator.py:481-517: the stage times are the cumulative position
-    weights xi, xi+chi, 1-(xi+chi), 1-xi, 1."""
-
-    def one_timestep(self, t, dt):
-        self.stage1()
-        self.update_domain()
-        self.do_post_stage(0.1786178958448091 * dt, 1)
-        self.compute_accelerations()
-        self.stage2()
-        self.update_domain()
-        self.do_post_stage(0.1123533131749906 * dt, 2)
-        self.compute_accelerations()
-        self.stage3()
-        self.update_domain()
-        self.do_post_stage(0.8876466868250094 * dt, 3)
-        self.compute_accelerations()
-        self.stage4()
-        self.update_domain()
-        self.do_post_stage(0.8213821041551909 * dt, 4)
-        self.compute_accelerations()
-        self.stage5()
-        self.update_domain()
-        self.do_post_stage(dt, 5)
+    """Predict-evaluate-correct: pysph/sph/integrator.py:300-358."""
 
 
 class EPECIntegrator(Integrator):
-    """integrator.py:367-420."""
-
-    def one_timestep(self, t, dt):
-        self.initialize()
-        self.compute_accelerations()
-        self.stage1()
-        self.update_domain()
-        self.do_post_stage(0.5 * dt, 1)
-        self.compute_accelerations()
-        self.stage2()
-        self.update_domain()
-        self.do_post_stage(dt, 2)
+    """Evaluate-predict-evaluate-correct (two acceleration evaluations per
+    step, the integrator of the dam-break / Taylor-Green examples):
+    pysph/sph/integrator.py:367-420."""
+    SEQUENCE = ('init', 'accel', ('stage', 1, 0.5), 'accel', ('stage', 2, 1.0))
 
 
 def method_properties_of(fn):
@@ -539,6 +394,7 @@ class HipIntegrator(object):
         self.orig_t = self.t = t
         self.dt = dt
         # the reference inlines the *source* of one_timestep into this class
+        self.SEQUENCE = type(self.integrator).SEQUENCE
         type(self.integrator).one_timestep(self, t, dt)
 
 

@@ -75,6 +75,7 @@ class HipNNPS(object):
             self._csr_key = None
 
     def update(self):
+        self._csr_key = None    # cached neighbour lists describe the previous particle state
         if self.sync:
             for h in self.helpers:
                 h.push(*_XYZH)
@@ -101,19 +102,34 @@ class HipNNPS(object):
         self.n_cells = int(i4[3])
 
     def get_csr(self, src_index, dst_index):
-        """(start[nd+1], nbrs) with each list sorted ascending."""
-        nd = self.particles[dst_index].get_number_of_particles()
+        """(start[nd+1], nbrs) with each list sorted ascending.  nd is the
+        DEVICE particle count of the destination (it holds the ghosts of a
+        device domain manager / slab halo that the host array never sees); the
+        library checks the buffer length it is given against it."""
+        nd = self.helpers[dst_index].get_number_of_particles()
         start = np.zeros(nd + 1, dtype=np.uint32)
         total = C.c_size_t()
         s, d = self.helpers[src_index].array_id, self.helpers[dst_index].array_id
         sp = start.ctypes.data_as(dev._PU)
-        dev._check(self.lib.sph_nnps_get_csr(self.ctx._h, s, d, sp, None,
-                                             C.byref(total)))
+        dev._check(self.lib.sph_nnps_get_csr(self.ctx._h, s, d, sp, nd + 1, None,
+                                             0, C.byref(total)))
         nbrs = np.empty(max(total.value, 1), dtype=np.uint32)
         dev._check(self.lib.sph_nnps_get_csr(
-            self.ctx._h, s, d, sp, nbrs.ctypes.data_as(dev._PU),
-            C.byref(total)))
+            self.ctx._h, s, d, sp, nd + 1, nbrs.ctypes.data_as(dev._PU),
+            nbrs.size, C.byref(total)))
         return start, nbrs[:total.value]
+
+    def get_csr_start(self, src_index, dst_index):
+        """start[nd+1] only: the exclusive scan of every destination's
+        neighbour count (pass 1 of the CSR query; no lists are materialised)."""
+        nd = self.helpers[dst_index].get_number_of_particles()
+        start = np.zeros(nd + 1, dtype=np.uint32)
+        total = C.c_size_t()
+        s, d = self.helpers[src_index].array_id, self.helpers[dst_index].array_id
+        dev._check(self.lib.sph_nnps_get_csr(self.ctx._h, s, d,
+                                             start.ctypes.data_as(dev._PU), nd + 1,
+                                             None, 0, C.byref(total)))
+        return start
 
     def count_neighbors(self, src_index, dst_index):
         """total number of (destination, source) neighbour pairs -- pass 1 of
@@ -123,8 +139,8 @@ class HipNNPS(object):
         total = C.c_size_t()
         s, d = self.helpers[src_index].array_id, self.helpers[dst_index].array_id
         dev._check(self.lib.sph_nnps_get_csr(self.ctx._h, s, d,
-                                             start.ctypes.data_as(dev._PU), None,
-                                             C.byref(total)))
+                                             start.ctypes.data_as(dev._PU), nd + 1,
+                                             None, 0, C.byref(total)))
         return int(total.value)
 
     def get_nearest_particles(self, src_index, dst_index, d_idx, nbrs=None):

@@ -43,8 +43,28 @@ class DeviceHaloOps(object):
         self.ctx = ctx
         self.lib = ctx.lib
         self.gpu = dev.attach(pa, ctx)
+        # Both this halo and HipDomainManager keep their ghosts as the rows
+        # behind n_real and drop ALL of them on update (the reference removes
+        # only Remote- resp. Ghost-tagged rows, parallel_manager.pyx:512-530,
+        # nnps_base.pyx:485-520): on one array each would delete the other's.
+        # The periodic wrap ALONG the slab axis is this halo's own job
+        # (periodic=True); other periodic / mirror axes are not supported
+        # together with slabs.
+        if getattr(self.gpu, 'ghost_owner', None) not in (None, 'slab', 'domain+slab'):
+            raise RuntimeError(
+                "array '%s' already has device ghosts managed by %s; a slab halo "
+                "on the same array would delete them" % (pa.name, self.gpu.ghost_owner))
+        if getattr(self.gpu, 'ghost_owner', None) is None:
+            self.gpu.ghost_owner = 'slab'
         self.gpu.managed = True
         self.id = self.gpu.array_id
+        # gid identifies a particle across ranks (1-vs-N parity checks, output):
+        # mirror it on the device (as a double, exact below 2^53) so that
+        # migration carries it along with the fp64 properties; tag and pid are
+        # re-derived on the host (rows >= n_real are Remote, pid = rank)
+        if 'gid' in getattr(pa, 'properties', {}):
+            dev.prop_register('gid')
+            self.gpu.push('gid')
         self.axis = axis
         self.nprops = len(props)
         self.props = (C.c_int * self.nprops)(*[dev.prop_id(p) for p in props])
@@ -99,11 +119,7 @@ class DeviceHaloOps(object):
     def all_props(self):
         """ids of the properties with device storage, ascending: identical
         on every rank because every rank runs the same equations"""
-        out = (C.c_int * 256)()
-        n = C.c_int(0)
-        dev._check(self.lib.sph_array_props(self.ctx._h, self.id, out,
-                                            C.byref(n)))
-        return [int(out[k]) for k in range(n.value)]
+        return self.gpu.device_props()
 
     def pack_all(self, side, count, shift):
         ids = self.all_props()
@@ -210,10 +226,13 @@ class SlabHalo(object):
             sync()
         return in_buf, recv_cnt
 
-    def exchange(self):
-        """refresh the ghosts (ParallelManager.update, :512-530)"""
+    def exchange(self, drop=True):
+        """refresh the ghosts (ParallelManager.update, :512-530).  drop=False:
+        the caller (HipDomainManager with slab=...) has already removed every
+        ghost row and will add the periodic images of the other axes after."""
         ops = self.ops
-        ops.drop_ghosts()
+        if drop:
+            ops.drop_ghosts()
         n_lo, n_hi = ops.select(self.lo + self.width, self.hi - self.width)
         nbrs = self.neighbours()
         if not nbrs:
@@ -295,9 +314,9 @@ class SlabDecomposition(object):
     def migrate(self):
         return sum(h.migrate() for h in self.halos)
 
-    def exchange(self):
+    def exchange(self, drop=True):
         for h in self.halos:
-            h.exchange()
+            h.exchange(drop=drop)
 
     def update(self):
         self.migrate()

@@ -83,7 +83,14 @@ class WCSPHScheme(object):
 
 class TVFScheme(object):
     def __init__(self, fluids, solids, dim, rho0, c0, nu, p0, pb, h0,
-                 gx=0.0, gy=0.0, gz=0.0, alpha=0.0, tdamp=0.0):
+                 gx=0.0, gy=0.0, gz=0.0, alpha=0.0, tdamp=0.0,
+                 wall_equations=None):
+        """wall_equations: module (or object) providing ``SetWallVelocity``,
+        ``SolidWallPressureBC`` and ``SolidWallNoSlipBC`` as Equation classes
+        with Python bodies; default: the reference's own
+        ``pysph.sph.wc.transport_velocity`` (they have no hand-written kernel
+        and run through pysph_amd.codegen).  Only needed when `solids` is given."""
+        self.wall_equations = wall_equations
         self.fluids = list(fluids)
         self.solids = list(solids or [])
         self.dim = dim
@@ -96,8 +103,22 @@ class TVFScheme(object):
     def get_equations(self):
         """scheme.py:616-687.  The wall equations (``solids`` given) have no
         hand-written kernel: they run through the generated-family path."""
-        from .wall_equations import (SetWallVelocity, SolidWallNoSlipBC,
-                                     SolidWallPressureBC)
+        SetWallVelocity = SolidWallNoSlipBC = SolidWallPressureBC = None
+        if self.solids:
+            we = self.wall_equations
+            if we is None:
+                try:
+                    from pysph.sph.wc import transport_velocity as we
+                except ImportError as e:
+                    raise ImportError(
+                        'TVFScheme(solids=%r) needs the solid-wall equation classes '
+                        '(SetWallVelocity, SolidWallPressureBC, SolidWallNoSlipBC): '
+                        'pysph.sph.wc.transport_velocity is not importable (%s); pass '
+                        'wall_equations=<module with these Equation classes>' %
+                        (self.solids, e))
+            SetWallVelocity = we.SetWallVelocity
+            SolidWallNoSlipBC = we.SolidWallNoSlipBC
+            SolidWallPressureBC = we.SolidWallPressureBC
         everyone = self.fluids + self.solids
         groups = [
             Group(real=False, equations=[

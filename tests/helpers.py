@@ -39,8 +39,10 @@ def golden_case(name, g):
         return s.get_equations(), K.QuinticSpline(dim=3), 3, TVF_OUT
     if name == 'tvf_wall':
         dx = float(g['meta/dx'])
+        import wall_equations_fixture
         s = TVFScheme(['fluid'], ['wall'], dim=3, rho0=1.0, c0=10.0, nu=0.01,
-                      p0=100.0, pb=100.0, h0=dx, gy=-0.5, alpha=0.2)
+                      p0=100.0, pb=100.0, h0=dx, gy=-0.5, alpha=0.2,
+                      wall_equations=wall_equations_fixture)
         return s.get_equations(), K.QuinticSpline(dim=3), 3, TVF_OUT + [
             'wij', 'uf', 'vf', 'wf', 'ug', 'vg', 'wg']
     if name in ('elastic_2d', 'elastic_3d'):

@@ -1,0 +1,85 @@
+"""Parity against the CPU oracle AT THE BASELINE SIZES (BASELINE.json configs):
+the 159^3 = 4.02 M headline cube (spatially ordered and not, uniform and +-15 %
+variable h, both parameter sets), the C2 dam break (dx 0.0087: 1.05 M fluid +
+0.26 M boundary + 16 k obstacle, three arrays) and the 4 M periodic
+Taylor-Green TVF case.  Every output field is compared (max|a-b| / max|b| <
+1e-10, BASELINE.json north_star) and, for the non-periodic cases, the neighbour
+COUNT of every destination exactly -- index arithmetic (32-bit offsets, tile
+order, slot overflow, long rows) only shows up at size.
+
+Same code path as ``bench.py``'s own post-run check (``parity_check``): the
+oracle (oracle/sph_oracle.c, OpenMP) needs 3-6 s per case on the GPU box's
+host cores."""
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(argv):
+    import torch
+    import bench
+    from pysph_amd import device as dev
+    args = bench.parse_args(argv + ['--no-cpu-baseline', '--no-extras'])
+    stream = torch.cuda.current_stream()
+    ctx = dev.HipContext(0, stream.cuda_stream)
+    bench.apply_options(args, ctx)
+    w = bench.build_workload(args, 0, 1)
+    nnps, a_eval, halo, domain, step, ordered = bench.setup(args, w, 0, 1, None, ctx)
+    for a in w.arrays:
+        a.gpu.pull()
+    host_in = bench.copy_arrays(w.arrays)
+    step()
+    step()          # the second evaluation runs on buffers the first one sized
+    res = bench.parity_check(w, host_in, nnps, domain)
+    n = sum(a.get_number_of_particles() for a in w.arrays)
+    del nnps, a_eval, step
+    ctx.close()
+    torch.cuda.empty_cache()
+    return res, n, ordered
+
+
+@pytest.mark.parametrize('extra', [
+    [],
+    ['--no-reorder'],
+    ['--vary-h', '0.15'],
+    ['--vary-h', '0.15', '--no-reorder'],
+    ['--params', 'cube'],
+], ids=['sorted-uniform-h', 'unsorted-uniform-h', 'sorted-variable-h', 'unsorted-variable-h',
+        'cube.py-parameters'])
+def test_cube_4m_vs_oracle(extra):
+    res, n, ordered = _case(['--n1', '159'] + extra)
+    assert n == 159 ** 3
+    assert ordered == ('--no-reorder' not in extra)
+    assert res['parity_neighbour_count_mismatches'] == 0, res
+    assert res['parity_max_rel'] < 1e-10, res
+
+
+def test_dam_break_c2_vs_oracle():
+    """BASELINE config 2: three arrays, fluid <- {fluid, boundary, obstacle},
+    solids <- fluid, sparse boundary shells (long empty rows in the cell tables)."""
+    res, n, _ = _case(['--workload', 'dam_break', '--dx', '0.0087'])
+    assert n > 1.3e6
+    assert res['parity_neighbour_count_mismatches'] == 0, res
+    assert res['parity_max_rel'] < 1e-10, res
+
+
+def test_taylor_green_4m_periodic_vs_oracle():
+    """BASELINE config 3: 159^3 periodic TVF; the oracle runs on the ghosts of
+    the host DomainManager, the device on those of HipDomainManager."""
+    res, n, _ = _case(['--workload', 'taylor_green', '--n1', '159'])
+    assert n == 159 ** 3
+    assert res['parity_max_rel'] < 1e-10, res
+
+
+def test_elastic_2m_vs_oracle():
+    """BASELINE config 5's equation set at 126^3 = 2.0 M (fp64 arithmetic)."""
+    res, n, _ = _case(['--workload', 'elastic', '--n1', '126'])
+    assert n == 126 ** 3
+    assert res['parity_neighbour_count_mismatches'] == 0, res
+    assert res['parity_max_rel'] < 1e-10, res

@@ -34,7 +34,7 @@ def _body_lines(src):
 
 def test_wall_equations_translate_build_and_export():
     from pysph_amd.codegen import GeneratedFamily
-    from pysph_amd.wall_equations import (SetWallVelocity, SolidWallNoSlipBC,
+    from wall_equations_fixture import (SetWallVelocity, SolidWallNoSlipBC,
                                           SolidWallPressureBC)
     arrays = _arrays()
     fam = GeneratedFamily('wall', [SetWallVelocity('wall', ['fluid'])], arrays, 3, 'cg_swv')
@@ -152,7 +152,7 @@ def test_mixed_destination_rules():
     from pysph_amd.acceleration_eval import _CGroup
     from pysph_amd.equations import (Equation, Group,
                                      MomentumEquationPressureGradient)
-    from pysph_amd.wall_equations import SolidWallNoSlipBC
+    from wall_equations_fixture import SolidWallNoSlipBC
 
     class Scales(Equation):
         def initialize(self, d_idx, d_au):
@@ -174,7 +174,7 @@ def test_mixed_destination_rules():
 @pytest.mark.skipif(not os.path.isdir(REF), reason='reference tree only exists in the build container')
 def test_reference_classes_translate_like_the_restatements():
     """The reference's own wall-equation classes go through the same translator
-    and give the SAME generated code as pysph_amd/wall_equations.py (comments
+    and give the SAME generated code as tests/wall_equations_fixture.py (comments
     aside): the in-repo bodies are the reference's semantics, statement by
     statement.  A few other reference equations are translated and compiled to
     show the drop-in for real pysph objects (WDP, RHOIJ1, VIJ ...)."""
@@ -184,7 +184,7 @@ def test_reference_classes_translate_like_the_restatements():
     import pysph.sph.wc.transport_velocity as tv
     import pysph.sph.wc.basic as wb
     import pysph.sph.basic_equations as be
-    from pysph_amd import wall_equations as mine
+    import wall_equations_fixture as mine
     from pysph_amd.codegen import GeneratedFamily
     arrays = _arrays()
     cases = [
@@ -276,3 +276,28 @@ def test_locals_named_like_cpp_keywords_or_skeleton_variables():
     assert 'double D_[3] = {};' in src and 'for (int o_ = 0; o_ < 2; o_++)' in src
     assert 'D.d_au += (D_[0] * s_m);' in src
     fam.build()
+
+
+def test_tvf_scheme_wall_equations_come_from_the_reference_or_the_caller(monkeypatch):
+    """The product carries no copy of the reference's wall-equation bodies:
+    TVFScheme(fluids, solids) takes them from pysph when importable, from the
+    `wall_equations` argument otherwise, and says so when neither is there."""
+    import builtins
+    import wall_equations_fixture
+    from pysph_amd.scheme import TVFScheme
+    kw = dict(dim=3, rho0=1.0, c0=10.0, nu=0.01, p0=100.0, pb=100.0, h0=0.1)
+    groups = TVFScheme(['fluid'], ['wall'], wall_equations=wall_equations_fixture, **kw).get_equations()
+    names = [type(e).__name__ for g in groups for e in g.equations]
+    assert {'SetWallVelocity', 'SolidWallPressureBC', 'SolidWallNoSlipBC'} <= set(names)
+    assert not os.path.exists(os.path.join(REPO, 'pysph_amd', 'wall_equations.py'))
+    real_import = builtins.__import__
+
+    def no_pysph(name, *a, **k):
+        if name == 'pysph' or name.startswith('pysph.'):
+            raise ImportError('No module named pysph (test)')
+        return real_import(name, *a, **k)
+    monkeypatch.setattr(builtins, '__import__', no_pysph)
+    with pytest.raises(ImportError, match='wall_equations='):
+        TVFScheme(['fluid'], ['wall'], **kw).get_equations()
+    # no solids: nothing is needed
+    assert len(TVFScheme(['fluid'], [], **kw).get_equations()) == 3

@@ -62,7 +62,7 @@ def test_golden_parity(case, variant):
 def test_generated_wall_equations_match_reference():
     """TVF with solid walls: SetWallVelocity, SolidWallPressureBC and
     SolidWallNoSlipBC have no hand-written kernel -- their Python bodies
-    (pysph_amd/wall_equations.py) are translated by pysph_amd.codegen, compiled
+    (tests/wall_equations_fixture.py) are translated by pysph_amd.codegen, compiled
     for gfx950 and run through sph_eval_generated, next to the hand-written TVF
     momentum kernels on the same destination.  Golden = the reference's own
     TVFScheme(fluids, solids) classes executed by oracle/ref_driver.py."""

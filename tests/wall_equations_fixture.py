@@ -1,6 +1,13 @@
-"""Solid-wall equations of the transport-velocity scheme (Adami et al. 2012),
-carried as *Python bodies* and run through the generated-family path
-(``pysph_amd.codegen``) -- no hand-written kernel exists for them.
+"""TEST FIXTURE (not product code): the solid-wall equations of the
+transport-velocity scheme (Adami et al. 2012) as *Python bodies*, for the
+generated-family path (``pysph_amd.codegen``) on a box without the reference.
+
+The product consumes the reference's own classes
+(``pysph.sph.wc.transport_velocity``) when ``pysph`` is importable
+(``pysph_amd.scheme.TVFScheme``); the GPU box has no reference, so the tests
+hand this restatement to ``TVFScheme(..., wall_equations=<this module>)``.
+tests/test_codegen.py checks (where the reference is present) that both
+translate to the same generated code.
 
 Same class names, constructor arguments and array names as
 pysph/sph/wc/transport_velocity.py (``SetWallVelocity`` :84-134,
@@ -12,7 +19,7 @@ floating-point operations matters for parity) but are written for the
 translator's subset: plain float arithmetic on ``d_*[d_idx]`` / ``s_*[s_idx]``
 and the precomputed pair symbols.
 """
-from .equations import Equation
+from pysph_amd.equations import Equation
 
 
 class SetWallVelocity(Equation):
