@@ -775,6 +775,7 @@ def multi_rank_parity(args, rank, local_rank, world, dist, tstream):
             for ai in range(len(w1.arrays)):
                 for p in parts[1:]:
                     w1.arrays[ai].append_parray(p.arrays[ai])
+                w1.arrays[ai].set_num_real_particles(w1.arrays[ai].get_number_of_particles())
         nn1, ev1, _, dom1, step1, _ = setup(a2, w1, 0, 1, None, ctx1)
         step1()
         for ai, pa in enumerate(w1.arrays):

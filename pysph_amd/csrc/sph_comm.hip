@@ -1,0 +1,233 @@
+// sph_comm.hip -- ghost-halo transport on RCCL for hosts WITHOUT torch.distributed.
+//
+// The Python host reaches RCCL through torch.distributed (pysph_amd/parallel.py);
+// a C / C++ / Fortran host binding this library cannot.  These entry points give
+// it the same exchange (SURVEY.md 8b "sph_comm_init_all / sph_halo_exchange /
+// sph_allreduce_*"): ParallelManager.update's ghost refresh
+// (pysph/parallel/parallel_manager.pyx:512-530, remote_exchange_data :159-210)
+// and the dt / bounds reductions (:463, :937-945) as
+//   select (device) -> counts to the two neighbours -> pack (device)
+//   -> ncclGroupStart; ncclSend/ncclRecv x <= 2; ncclGroupEnd -> append (device)
+// all on the context's stream, point-to-point over xGMI.  Built as its own
+// shared object (libsphcomm.so, links librccl) so that libsphhip.so has no RCCL
+// dependency and a process that already holds torch's bundled RCCL never sees
+// two copies through one library.
+#include "sph_internal.h"
+
+#include <rccl/rccl.h>
+
+#define NCCL_TRY(expr)                                                                   \
+    do {                                                                                 \
+        ncclResult_t _r = (expr);                                                        \
+        if (_r != ncclSuccess) {                                                         \
+            sph_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, ncclGetErrorString(_r)); \
+            return SPH_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+struct SphComm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    DevBuf send[2], recv[2], cnt; // payloads per face, 4 counters (send lo/hi, recv lo/hi)
+    unsigned long long *h_cnt = nullptr; // pinned
+};
+
+static SphComm *comm_of(sph_ctx *c) { return static_cast<SphComm *>(c->comm); }
+
+extern "C" {
+
+int sph_comm_unique_id(void *id128)
+{
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    if (!id128) { sph_set_error("sph_comm_unique_id: NULL"); return SPH_ERR_ARG; }
+    NCCL_TRY(ncclGetUniqueId(static_cast<ncclUniqueId *>(id128)));
+    return SPH_OK;
+}
+
+static int comm_attach(sph_ctx *c, ncclComm_t comm, int rank, int world)
+{
+    SphComm *m = new SphComm();
+    m->comm = comm; m->rank = rank; m->world = world;
+    HIP_TRY(hipHostMalloc((void **)&m->h_cnt, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+    c->comm = m;
+    return SPH_OK;
+}
+
+int sph_comm_init_rank(sph_ctx *c, int rank, int world, const void *id128)
+{
+    if (!c || !id128 || world < 1 || rank < 0 || rank >= world) { sph_set_error("sph_comm_init_rank: bad arguments"); return SPH_ERR_ARG; }
+    if (c->comm) { sph_set_error("sph_comm_init_rank: context already has a communicator"); return SPH_ERR_STATE; }
+    HIP_TRY(hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclComm_t comm;
+    NCCL_TRY(ncclCommInitRank(&comm, world, id, rank));
+    return comm_attach(c, comm, rank, world);
+}
+
+int sph_comm_init_all(int ndev, sph_ctx **ctxs)
+{
+    if (ndev < 1 || ndev > 64 || !ctxs) { sph_set_error("sph_comm_init_all: bad arguments"); return SPH_ERR_ARG; }
+    std::vector<int> devs(ndev);
+    for (int i = 0; i < ndev; i++) {
+        if (!ctxs[i] || ctxs[i]->comm) { sph_set_error("sph_comm_init_all: context %d missing or already initialised", i); return SPH_ERR_ARG; }
+        devs[i] = ctxs[i]->device;
+    }
+    std::vector<ncclComm_t> comms(ndev);
+    NCCL_TRY(ncclCommInitAll(comms.data(), ndev, devs.data()));
+    for (int i = 0; i < ndev; i++) SPH_TRY(comm_attach(ctxs[i], comms[i], i, ndev));
+    return SPH_OK;
+}
+
+int sph_comm_destroy(sph_ctx *c)
+{
+    if (!c || !c->comm) return SPH_OK;
+    SphComm *m = comm_of(c);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (m->comm) (void)ncclCommDestroy(m->comm);
+    for (DevBuf *b : {&m->send[0], &m->send[1], &m->recv[0], &m->recv[1], &m->cnt}) b->release();
+    if (m->h_cnt) (void)hipHostFree(m->h_cnt);
+    delete m;
+    c->comm = nullptr;
+    return SPH_OK;
+}
+
+// neighbours of `rank` in a 1-D slab decomposition: side 0 = lower face
+static int peer_of(const SphComm *m, int side, int periodic, double period, double *shift)
+{
+    *shift = 0.0;
+    if (side == 0) {
+        if (m->rank > 0) return m->rank - 1;
+        if (periodic) { *shift = +period; return m->world - 1; }
+    } else {
+        if (m->rank < m->world - 1) return m->rank + 1;
+        if (periodic) { *shift = -period; return 0; }
+    }
+    return -1;
+}
+
+// Ghost refresh of `n` contexts in one call: n == 1 in the one-process-per-GPU
+// model; n == ndev when one process drives all GPUs (sph_comm_init_all), where
+// the sends and receives of all devices must sit in one NCCL group.
+int sph_halo_exchange_all(int n, sph_ctx **ctxs, int array_id, int axis, const double *lo, const double *hi,
+                          double width, int periodic, double period, int nprops, const int *props, int drop,
+                          size_t *counts4)
+{
+    if (n < 1 || !ctxs || !lo || !hi || !props || nprops < 1 || nprops > SPH_PROP_COUNT || axis < 0 || axis > 2) {
+        sph_set_error("sph_halo_exchange: bad arguments");
+        return SPH_ERR_ARG;
+    }
+    struct Face { int peer; double shift; size_t ns, nr; };
+    std::vector<Face> F(2 * n);
+    // 1. selection on every device, send counts to the host
+    for (int i = 0; i < n; i++) {
+        sph_ctx *c = ctxs[i];
+        SphComm *m = c ? comm_of(c) : nullptr;
+        if (!m) { sph_set_error("sph_halo_exchange: context %d has no communicator (sph_comm_init_rank / _all)", i); return SPH_ERR_STATE; }
+        HIP_TRY(hipSetDevice(c->device));
+        size_t nn, nreal;
+        SPH_TRY(sph_array_size(c, array_id, &nn, &nreal));
+        if (drop) SPH_TRY(sph_array_resize(c, array_id, nreal, nreal)); // ghosts of the previous step
+        size_t cnt[2];
+        SPH_TRY(sph_halo_select(c, array_id, axis, 0, lo[i] + width, hi[i] - width, 0.0, 0, cnt));
+        for (int s = 0; s < 2; s++) {
+            Face &f = F[2 * i + s];
+            f.peer = peer_of(m, s, periodic, period, &f.shift);
+            f.ns = f.peer >= 0 ? cnt[s] : 0;
+            f.nr = 0;
+        }
+    }
+    // 2. counts handshake: my lo face talks to the peer's hi face and vice versa
+    NCCL_TRY(ncclGroupStart());
+    for (int i = 0; i < n; i++) {
+        sph_ctx *c = ctxs[i];
+        SphComm *m = comm_of(c);
+        HIP_TRY(hipSetDevice(c->device));
+        SPH_TRY(m->cnt.reserve(8 * sizeof(unsigned long long)));
+        for (int s = 0; s < 2; s++) m->h_cnt[s] = F[2 * i + s].ns;
+        HIP_TRY(hipMemcpyAsync(m->cnt.ptr, m->h_cnt, 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+        unsigned long long *d = m->cnt.as<unsigned long long>();
+        // between one pair of ranks messages match in posting order: with a periodic
+        // axis and <= 2 ranks both faces talk to the SAME peer -- send hi first, receive lo first
+        for (int s = 1; s >= 0; s--)
+            if (F[2 * i + s].peer >= 0) NCCL_TRY(ncclSend(d + s, 1, ncclUint64, F[2 * i + s].peer, m->comm, c->stream));
+        for (int s = 0; s < 2; s++)
+            if (F[2 * i + s].peer >= 0) NCCL_TRY(ncclRecv(d + 2 + s, 1, ncclUint64, F[2 * i + s].peer, m->comm, c->stream));
+    }
+    NCCL_TRY(ncclGroupEnd());
+    for (int i = 0; i < n; i++) {
+        sph_ctx *c = ctxs[i];
+        SphComm *m = comm_of(c);
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipMemcpyAsync(m->h_cnt + 2, m->cnt.as<unsigned long long>() + 2, 2 * sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int s = 0; s < 2; s++) F[2 * i + s].nr = F[2 * i + s].peer >= 0 ? (size_t)m->h_cnt[2 + s] : 0;
+    }
+    // 3. pack, 4. one group of point-to-point transfers
+    for (int i = 0; i < n; i++) {
+        sph_ctx *c = ctxs[i];
+        SphComm *m = comm_of(c);
+        HIP_TRY(hipSetDevice(c->device));
+        for (int s = 0; s < 2; s++) {
+            Face &f = F[2 * i + s];
+            SPH_TRY(m->send[s].reserve((f.ns * nprops + 1) * sizeof(double)));
+            SPH_TRY(m->recv[s].reserve((f.nr * nprops + 1) * sizeof(double)));
+            if (f.ns) SPH_TRY(sph_halo_pack(c, array_id, s, nprops, props, axis, f.shift, m->send[s].ptr));
+        }
+    }
+    NCCL_TRY(ncclGroupStart());
+    for (int i = 0; i < n; i++) {
+        sph_ctx *c = ctxs[i];
+        SphComm *m = comm_of(c);
+        HIP_TRY(hipSetDevice(c->device));
+        for (int s = 1; s >= 0; s--) {
+            Face &f = F[2 * i + s];
+            if (f.ns) NCCL_TRY(ncclSend(m->send[s].ptr, f.ns * nprops, ncclDouble, f.peer, m->comm, c->stream));
+        }
+        for (int s = 0; s < 2; s++) {
+            Face &f = F[2 * i + s];
+            if (f.nr) NCCL_TRY(ncclRecv(m->recv[s].ptr, f.nr * nprops, ncclDouble, f.peer, m->comm, c->stream));
+        }
+    }
+    NCCL_TRY(ncclGroupEnd());
+    // 5. ghosts go behind the real particles (lo side first: deterministic)
+    for (int i = 0; i < n; i++) {
+        sph_ctx *c = ctxs[i];
+        SphComm *m = comm_of(c);
+        HIP_TRY(hipSetDevice(c->device));
+        for (int s = 0; s < 2; s++) {
+            Face &f = F[2 * i + s];
+            if (f.nr) SPH_TRY(sph_halo_append(c, array_id, nprops, props, m->recv[s].ptr, f.nr));
+        }
+        if (counts4) {
+            counts4[4 * i + 0] = F[2 * i].ns; counts4[4 * i + 1] = F[2 * i + 1].ns;
+            counts4[4 * i + 2] = F[2 * i].nr; counts4[4 * i + 3] = F[2 * i + 1].nr;
+        }
+    }
+    return SPH_OK;
+}
+
+int sph_halo_exchange(sph_ctx *c, int array_id, int axis, double lo, double hi, double width, int periodic, double period,
+                      int nprops, const int *props, int drop, size_t *counts4)
+{
+    return sph_halo_exchange_all(1, &c, array_id, axis, &lo, &hi, width, periodic, period, nprops, props, drop, counts4);
+}
+
+// MIN / MAX / SUM of a few doubles over all ranks (dt, dt_cfl, dt_force, bounds, hmax)
+int sph_allreduce(sph_ctx *c, double *vals, int nvals, int op)
+{
+    SphComm *m = c ? comm_of(c) : nullptr;
+    if (!m || !vals || nvals < 1 || nvals > 64 || op < 0 || op > 2) { sph_set_error("sph_allreduce: bad arguments / no communicator"); return SPH_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    SPH_TRY(m->send[0].reserve(64 * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(m->send[0].ptr, vals, nvals * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const ncclRedOp_t ops[3] = {ncclMin, ncclMax, ncclSum};
+    NCCL_TRY(ncclAllReduce(m->send[0].ptr, m->send[0].ptr, nvals, ncclDouble, ops[op], m->comm, c->stream));
+    HIP_TRY(hipMemcpyAsync(vals, m->send[0].ptr, nvals * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+} // extern "C"

@@ -104,6 +104,8 @@ struct sph_ctx {
     int cur_nrec = 0;       // doubles per packed record of the pair launch being set up
     long block_sorted_outputs = 0;
 
+    void *comm = nullptr;   // SphComm of libsphcomm.so (sph_comm.hip), or nullptr
+
     // timers
     bool timers_on = false;
     Timer timers[T_COUNT];

@@ -63,3 +63,106 @@ def test_bench_dam_break_strong_scaling_path_two_ranks():
     from pysph_amd.examples import dam_break_3d as db
     total = sum(a.get_number_of_particles() for a in db.create_particles(0.05))
     assert abs(out['value'] * out['ms_per_step'] * 1e-3 - total) < 1e-6 * total
+
+
+def _run_two_ranks_collect(argv, fields):
+    """two thread-ranks run one step of the workload; returns {gid: row} of the
+    requested fields over both ranks, and the same from ONE domain"""
+    import numpy as np
+    import torch
+    import bench
+    from helpers import ThreadDist
+    from pysph_amd import device as dev
+    hub = ThreadDist(2)
+    rows, errors = {}, []
+
+    def rank_main(rank):
+        try:
+            args = bench.parse_args(argv + ['--gpus', '2'])
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                ctx = dev.HipContext(0, stream.cuda_stream)
+                bench.apply_options(args, ctx)
+                w = bench.build_workload(args, rank, 2)
+                nnps, a_eval, halo, domain, step, _ = bench.setup(args, w, rank, 2, hub.view(rank), ctx)
+                step()
+                pa = w.arrays[0]
+                pa.gpu.sync_host()
+                n = pa.get_number_of_particles(True)
+                rows[rank] = (np.asarray(pa.gid[:n]).copy(),
+                              np.stack([np.asarray(pa.get(f))[:n] for f in fields], 1))
+                del nnps, a_eval, step
+                ctx.close()
+        except BaseException:
+            import traceback
+            errors.append(traceback.format_exc())
+            try:
+                hub.barrier.abort()
+            except Exception:
+                pass
+
+    ths = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(600)
+    assert not errors, errors[0]
+    gid = np.concatenate([rows[0][0], rows[1][0]])
+    val = np.concatenate([rows[0][1], rows[1][1]], 0)
+    # one domain: both cubes in one array
+    args = bench.parse_args(argv + ['--gpus', '2'])
+    parts = [bench.build_workload(args, r, 2) for r in range(2)]
+    w1 = parts[0]
+    w1.arrays[0].append_parray(parts[1].arrays[0])
+    w1.arrays[0].set_num_real_particles(w1.arrays[0].get_number_of_particles())
+    ctx = dev.HipContext(0, torch.cuda.current_stream().cuda_stream)
+    bench.apply_options(args, ctx)
+    nnps, a_eval, halo, domain, step, _ = bench.setup(args, w1, 0, 1, None, ctx)
+    step()
+    pa = w1.arrays[0]
+    pa.gpu.sync_host()
+    n = pa.get_number_of_particles(True)
+    gid1 = np.asarray(pa.gid[:n])
+    val1 = np.stack([np.asarray(pa.get(f))[:n] for f in fields], 1)
+    ctx.close()
+    return gid, val, gid1, val1
+
+
+@pytest.mark.gpu
+def test_taylor_green_two_slabs_periodic_matches_one_domain():
+    """Slab decomposition along x (periodic: slab 0 <-> slab 1 wrap with the
+    coordinate shift, nnps_base.pyx:841-856) COMBINED with the device domain
+    manager's periodic images in y and z: the remote ghosts are exchanged
+    first, their y/z images made after (HipDomainManager(slab=...)).  Every real
+    particle matches the single-domain evaluation, gid by gid -- the reference's
+    own recipe for its parallel runs (parallel/tests/example_test_case.py:143-166)."""
+    import numpy as np
+    fields = ['rho', 'V', 'au', 'av', 'aw', 'auhat', 'avhat', 'awhat']
+    gid, val, gid1, val1 = _run_two_ranks_collect(
+        ['--workload', 'taylor_green', '--n1', '20', '--steps', '1', '--warmup', '0'], fields)
+    assert gid.size == gid1.size == 2 * 20 ** 3
+    a = val[np.argsort(gid)]
+    b = val1[np.argsort(gid1)]
+    scale_acc = np.max(np.abs(b[:, 2:]))
+    assert np.max(np.abs(a[:, :2] - b[:, :2])) / np.max(np.abs(b[:, :2])) < 1e-12
+    assert np.max(np.abs(a[:, 2:] - b[:, 2:])) / scale_acc < 1e-10
+
+
+@pytest.mark.gpu
+def test_cube_two_slabs_matches_one_domain_by_gid():
+    import numpy as np
+    fields = ['arho', 'au', 'av', 'aw', 'ax', 'ay', 'az']
+    gid, val, gid1, val1 = _run_two_ranks_collect(
+        ['--n1', '24', '--steps', '1', '--warmup', '0'], fields)
+    a = val[np.argsort(gid)]
+    b = val1[np.argsort(gid1)]
+    for k in range(len(fields)):
+        assert np.max(np.abs(a[:, k] - b[:, k])) / np.max(np.abs(b[:, k])) < 1e-10, fields[k]
+
+
+@pytest.mark.gpu
+def test_bench_taylor_green_path_two_ranks():
+    out = _run_two_ranks(['--gpus', '2', '--workload', 'taylor_green', '--n1', '20', '--steps', '2',
+                          '--warmup', '1', '--no-cpu-baseline'])
+    assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'slab2'
+    assert out['config']['particles_per_gpu'] == 20 ** 3
