@@ -17,16 +17,25 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """A checkout that was never built (the shared objects are not in the git
-    history) builds the HIP library once, with the same Makefile
-    __graft_entry__.build() uses.  No fallback is involved: without hipcc the
-    product keeps failing loudly in device.load_library()."""
+    """The shared objects are not in the git history: a checkout that was never
+    built, OR whose libraries were built from other sources than the ones in
+    the tree now (pysph_amd/csrc/srchash.py: sha256 of csrc/ + include/ stored by
+    the Makefile in libsphhip.stamp), is (re)built once with the Makefile
+    __graft_entry__.build() uses.  No fallback is involved: without hipcc a
+    stale or missing library is an error, not a skipped check."""
     import shutil
     import subprocess
+    sys.path.insert(0, os.path.join(REPO, 'pysph_amd', 'csrc'))
+    import srchash
     lib = os.path.join(REPO, 'pysph_amd', 'libsphhip.so')
     hipcc = shutil.which('hipcc') or ('/opt/rocm/bin/hipcc' if os.path.exists('/opt/rocm/bin/hipcc') else None)
-    if not os.path.exists(lib) and hipcc:
-        subprocess.check_call(['make', '-C', os.path.join(REPO, 'pysph_amd', 'csrc'), '-j8'])
+    if os.path.exists(lib) and srchash.is_current():
+        return
+    if not hipcc:
+        raise RuntimeError('pysph_amd/libsphhip.so is missing or was built from different sources '
+                           '(libsphhip.stamp != srchash) and there is no hipcc to rebuild it')
+    subprocess.check_call(['make', '-C', os.path.join(REPO, 'pysph_amd', 'csrc'), '-j8'])
+    assert srchash.is_current()
 
 
 def load_golden(name):
