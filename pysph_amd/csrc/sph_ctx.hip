@@ -248,12 +248,13 @@ int sph_array_device_ptr(sph_ctx *c, int id, int prop, void **dptr)
 int sph_set_option(sph_ctx *c, const char *key, long value)
 {
     if (strcmp(key, "pair_variant") == 0) {
-        if (value != 0 && value != 2 && value != 3 && value != 6) { sph_set_error("pair_variant must be 0 (direct), 2 (row tiles), 3 (aggregated) or 6 (aggregated, lean phase 2)"); return SPH_ERR_ARG; }
+        if (value != 0 && value != 6) { sph_set_error("pair_variant must be 0 (direct per-lane walk) or 6 (wavefront tiles, the default)"); return SPH_ERR_ARG; }
         c->pair_variant = value;
         return SPH_OK;
     }
     if (strcmp(key, "uniform_h") == 0) { c->use_uniform_h = value; return SPH_OK; }
     if (strcmp(key, "record_f32") == 0) { c->record_f32 = value ? 1 : 0; return SPH_OK; }
+    if (strcmp(key, "arith_f32") == 0) { c->arith_f32 = value ? 1 : 0; return SPH_OK; }
     if (strcmp(key, "tile_block_rows") == 0) {
         if (value < 0 || value > 4096) { sph_set_error("tile_block_rows out of range"); return SPH_ERR_ARG; }
         c->tile_block_rows = value; c->nnps_valid = false; return SPH_OK;

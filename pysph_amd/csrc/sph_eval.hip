@@ -286,23 +286,24 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
     }
 }
 
-struct FamWCSPH {
+template <class T> struct FamWCSPH_T {
+    typedef T Real; // arithmetic type of the pair loop
     static constexpr uint32_t CF0 = F_CONT | F_MOM | F_XSPH; // flag set compiled as a constant (variant 6)
     static constexpr int MINB = 4; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
     static constexpr int NA = 8; // u v w m rho tmpj(=p/rho^2) cs p
     static constexpr int NR = 12; // x y z h + NA (128-B padded records measured slower: larger L2 footprint)
     struct Params {
-        double c0, alpha, beta, gx, gy, gz, eps;
+        T c0, alpha, beta, gx, gy, gz, eps;
         double *arho, *au, *av, *aw, *ax, *ay, *az, *dt_cfl, *dt_force;
     };
     struct Dest {
-        double u, v, w, rho, p, cs, tmpi;
-        double arho, au, av, aw, ax, ay, az, dt_cfl;
+        T u, v, w, rho, p, cs, tmpi;
+        T arho, au, av, aw, ax, ay, az, dt_cfl;
     };
-    template <class A> static __device__ __forceinline__ void load(Dest &D, const double *a, const A &, uint32_t)
+    template <class A> static __device__ __forceinline__ void load(Dest &D, const T *a, const A &, uint32_t)
     {
         D.u = a[0]; D.v = a[1]; D.w = a[2]; D.rho = a[4]; D.tmpi = a[5]; D.cs = a[6]; D.p = a[7];
-        D.arho = D.au = D.av = D.aw = D.ax = D.ay = D.az = D.dt_cfl = 0.0;
+        D.arho = D.au = D.av = D.aw = D.ax = D.ay = D.az = D.dt_cfl = T(0.0);
     }
     // The algebra below is the reference's (cited per term) regrouped so that a
     // pair costs one rsqrt and one reciprocal:  DWIJ = tg*XIJ  =>
@@ -315,47 +316,47 @@ struct FamWCSPH {
     // branch around the accumulators, which then stay in their registers.
     static constexpr bool PRED = true;
     template <int KK, bool UH, class A>
-    static __device__ __forceinline__ void pair(Dest &D, const double4 &pi, const double4 &pj, double r2,
-                                                const double (&s)[NA], uint32_t fl, const A &a, bool pass = true)
+    static __device__ __forceinline__ void pair(Dest &D, const real4<T> &pi, const real4<T> &pj, T r2,
+                                                const T (&s)[NA], uint32_t fl, const A &a, bool pass = true)
     {
-        PairGeom g;
+        PairGeomT<T> g;
         pair_geom<KK, UH>(g, pi, pj, r2, a);
-        const double tg = pair_gradfac<KK, UH>(g);
-        const double vij0 = D.u - s[0], vij1 = D.v - s[1], vij2 = D.w - s[2]; // VIJ equation.py:214-223
-        const double vdotx = vij0 * g.xij[0] + vij1 * g.xij[1] + vij2 * g.xij[2];
-        const double mj = pass ? s[3] : 0.0;
+        const T tg = pair_gradfac<KK, UH>(g);
+        const T vij0 = D.u - s[0], vij1 = D.v - s[1], vij2 = D.w - s[2]; // VIJ equation.py:214-223
+        const T vdotx = vij0 * g.xij[0] + vij1 * g.xij[1] + vij2 * g.xij[2];
+        const T mj = pass ? s[3] : T(0.0);
         if (fl & F_CONT) D.arho = fma(mj * tg, vdotx, D.arho); // basic_equations.py:187-192
         if (fl & (F_MOM | F_XSPH)) {
-            const double rhoij = 0.5 * (D.rho + s[4]); // RHOIJ equation.py:196
-            double rhoij1;                              // RHOIJ1 :199
-            double wij = 0.0;
+            const T rhoij = T(0.5) * (D.rho + s[4]); // RHOIJ equation.py:196
+            T rhoij1;                              // RHOIJ1 :199
+            T wij = T(0.0);
             if (fl & (F_XSPH | F_TENSILE)) wij = pair_w<KK, UH>(g);
             if (fl & F_MOM) { // wc/basic.py:204-259
-                const double re = r2 + g.eps;
-                const double tt = fast_rcp(re * rhoij);
-                const double inv_re = rhoij * tt;
+                const T re = r2 + g.eps;
+                const T tt = fast_rcp(re * rhoij);
+                const T inv_re = rhoij * tt;
                 rhoij1 = re * tt;
-                const double hv = g.hij * vdotx;
-                const double muij = hv * inv_re;
-                const double cij = 0.5 * (D.cs + s[6]);
-                double piij = (a.p.beta * muij - a.p.alpha * cij) * muij * rhoij1;
-                piij = vdotx < 0 ? piij : 0.0;
-                const double dtc = fabs(hv * (g.rinv * g.rinv)) + a.p.c0;
-                D.dt_cfl = (r2 > 1e-12 && pass) ? fmax(dtc, D.dt_cfl) : D.dt_cfl;
-                const double tmpj = s[5];
-                double tmp = D.tmpi + tmpj;
+                const T hv = g.hij * vdotx;
+                const T muij = hv * inv_re;
+                const T cij = T(0.5) * (D.cs + s[6]);
+                T piij = (a.p.beta * muij - a.p.alpha * cij) * muij * rhoij1;
+                piij = vdotx < 0 ? piij : T(0.0);
+                const T dtc = fabs(hv * (g.rinv * g.rinv)) + a.p.c0;
+                D.dt_cfl = (r2 > T(1e-12) && pass) ? fmax(dtc, D.dt_cfl) : D.dt_cfl;
+                const T tmpj = s[5];
+                T tmp = D.tmpi + tmpj;
                 if (fl & F_TENSILE) {
                     // WDP = KERNEL(XIJ, DELTAP*HIJ, HIJ)  equation.py:243-246
-                    const double qd = (a.k.deltap * g.hij) * g.h1;
-                    const double wdp = SphKernel<KK>::w(qd) * g.fac;
-                    double fij = wij * fast_rcp(wdp);
+                    const T qd = (a.k.deltap * g.hij) * g.h1;
+                    const T wdp = SphKernel<KK>::w(qd) * g.fac;
+                    T fij = wij * fast_rcp(wdp);
                     fij = fij * fij;
                     fij = fij * fij;
-                    const double Ri = D.p > 0 ? 0.01 * D.tmpi : 0.2 * fabs(D.tmpi);
-                    const double Rj = s[7] > 0 ? 0.01 * tmpj : 0.2 * fabs(tmpj);
+                    const T Ri = D.p > 0 ? T(0.01) * D.tmpi : T(0.2) * fabs(D.tmpi);
+                    const T Rj = s[7] > 0 ? T(0.01) * tmpj : T(0.2) * fabs(tmpj);
                     tmp = (D.tmpi + tmpj) + (Ri + Rj) * fij;
                 }
-                const double ft = -mj * (tmp + piij) * tg;
+                const T ft = -mj * (tmp + piij) * tg;
                 D.au = fma(ft, g.xij[0], D.au);
                 D.av = fma(ft, g.xij[1], D.av);
                 D.aw = fma(ft, g.xij[2], D.aw);
@@ -363,7 +364,7 @@ struct FamWCSPH {
                 rhoij1 = fast_rcp(rhoij);
             }
             if (fl & F_XSPH) { // basic_equations.py:290-295
-                const double tmp = -a.p.eps * mj * wij * rhoij1;
+                const T tmp = -a.p.eps * mj * wij * rhoij1;
                 D.ax = fma(tmp, vij0, D.ax);
                 D.ay = fma(tmp, vij1, D.ay);
                 D.az = fma(tmp, vij2, D.az);
@@ -374,7 +375,7 @@ struct FamWCSPH {
     {
         if (a.dflags & F_CONT) a.p.arho[o] = D.arho;
         if (a.dflags & F_MOM) { // post_loop wc/basic.py:261-271
-            double au = D.au + a.p.gx, av = D.av + a.p.gy, aw = D.aw + a.p.gz;
+            T au = D.au + a.p.gx, av = D.av + a.p.gy, aw = D.aw + a.p.gz;
             a.p.au[o] = au; a.p.av[o] = av; a.p.aw[o] = aw;
             a.p.dt_cfl[o] = D.dt_cfl;
             a.p.dt_force[o] = au * au + av * av + aw * aw;
@@ -384,6 +385,7 @@ struct FamWCSPH {
         }
     }
 };
+typedef FamWCSPH_T<double> FamWCSPH;
 
 // WCSPH records of the aggregated kernel use the layout
 //   [x y z cs | u v w m | rho tmpj | h p]
@@ -405,23 +407,24 @@ template <> __device__ __forceinline__ void load_record<FamWCSPH, true>(const do
 template <> __device__ __forceinline__ void load_record<FamWCSPH, false>(const double *__restrict__ rj, uint32_t fl, double4 &pj, double (&s)[8]) { load_record_wcsph<false>(rj, fl, pj, s); }
 
 // ---- density summations (basic_equations.py:19-29, transport_velocity.py:24-58)
-struct FamDensity {
+template <class T> struct FamDensity_T {
+    typedef T Real; // arithmetic type of the pair loop
     static constexpr bool PRED = true; // see FamWCSPH
     static constexpr uint32_t CF0 = F_TVFSD; // flag set compiled as a constant (variant 6)
     static constexpr int MINB = 4; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
     static constexpr int NA = 1; // m
     static constexpr int NR = 6;  // x y z h m pad
     struct Params { double *rho, *V; };
-    struct Dest { double m, rho, V; };
-    template <class A> static __device__ __forceinline__ void load(Dest &D, const double *a, const A &, uint32_t) { D.m = a[0]; D.rho = 0.0; D.V = 0.0; }
+    struct Dest { T m, rho, V; };
+    template <class A> static __device__ __forceinline__ void load(Dest &D, const T *a, const A &, uint32_t) { D.m = a[0]; D.rho = T(0.0); D.V = T(0.0); }
     template <int KK, bool UH, class A>
-    static __device__ __forceinline__ void pair(Dest &D, const double4 &pi, const double4 &pj, double r2,
-                                                const double (&s)[NA], uint32_t fl, const A &a, bool pass = true)
+    static __device__ __forceinline__ void pair(Dest &D, const real4<T> &pi, const real4<T> &pj, T r2,
+                                                const T (&s)[NA], uint32_t fl, const A &a, bool pass = true)
     {
-        PairGeom g;
+        PairGeomT<T> g;
         pair_geom<KK, UH>(g, pi, pj, r2, a);
-        double wij = pair_w<KK, UH>(g);
-        wij = pass ? wij : 0.0; // PRED: a pair outside the criterion adds exactly zero
+        T wij = pair_w<KK, UH>(g);
+        wij = pass ? wij : T(0.0); // PRED: a pair outside the criterion adds exactly zero
         if (fl & F_SD) D.rho += s[0] * wij;
         if (fl & F_TVFSD) { D.V += wij; D.rho += D.m * wij; }
     }
@@ -431,6 +434,7 @@ struct FamDensity {
         if (a.dflags & F_TVFSD) a.p.V[o] = D.V;
     }
 };
+typedef FamDensity_T<double> FamDensity;
 
 // Density records of the aggregated kernel under uniform h: [x y z m] (32 B, two
 // 16-B pieces per pair); otherwise the generic [x y z h | m pad].
@@ -443,71 +447,72 @@ template <> __device__ __forceinline__ void load_record<FamDensity, true>(const 
 }
 
 // ---- TVF momentum terms (transport_velocity.py:219-545) -------------------
-struct FamTVF {
+template <class T> struct FamTVF_T {
+    typedef T Real; // arithmetic type of the pair loop
     static constexpr bool PRED = true; // see FamWCSPH
     static constexpr uint32_t CF0 = F_TP | F_TVISC | F_TAS; // flag set compiled as a constant (variant 6)
     static constexpr int MINB = 3; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
     static constexpr int NA = 12; // u v w uhat vhat what rho p V m Vj2 pad
     static constexpr int NR = 16; // x y z h + NA
     struct Params {
-        double pb, gx, gy, gz, tdamp, nu, c0, alpha;
+        T pb, gx, gy, gz, tdamp, nu, c0, alpha;
         double *au, *av, *aw, *auhat, *avhat, *awhat;
     };
     struct Dest {
-        double u, v, w, uh, vh, wh, rho, p, Vi2, mi1;
-        double au, av, aw, auh, avh, awh;
+        T u, v, w, uh, vh, wh, rho, p, Vi2, mi1;
+        T au, av, aw, auh, avh, awh;
     };
-    template <class A> static __device__ __forceinline__ void load(Dest &D, const double *a, const A &, uint32_t)
+    template <class A> static __device__ __forceinline__ void load(Dest &D, const T *a, const A &, uint32_t)
     {
         D.u = a[0]; D.v = a[1]; D.w = a[2]; D.uh = a[3]; D.vh = a[4]; D.wh = a[5];
-        D.rho = a[6]; D.p = a[7]; D.Vi2 = a[10]; D.mi1 = 1.0 / a[9];
-        D.au = D.av = D.aw = D.auh = D.avh = D.awh = 0.0;
+        D.rho = a[6]; D.p = a[7]; D.Vi2 = a[10]; D.mi1 = T(1.0) / a[9];
+        D.au = D.av = D.aw = D.auh = D.avh = D.awh = T(0.0);
     }
     template <int KK, bool UH, class A>
-    static __device__ __forceinline__ void pair(Dest &D, const double4 &pi, const double4 &pj, double r2,
-                                                const double (&s)[NA], uint32_t fl, const A &a, bool pass = true)
+    static __device__ __forceinline__ void pair(Dest &D, const real4<T> &pi, const real4<T> &pj, T r2,
+                                                const T (&s)[NA], uint32_t fl, const A &a, bool pass = true)
     {
-        PairGeom g;
+        PairGeomT<T> g;
         pair_geom<KK, UH>(g, pi, pj, r2, a);
-        double tg = pair_gradfac<KK, UH>(g);
-        tg = pass ? tg : 0.0; // PRED: every term carries DWIJ
-        double dw0 = tg * g.xij[0], dw1 = tg * g.xij[1], dw2 = tg * g.xij[2];
-        double rhoj = s[6], Vj2 = s[10];
-        double vsum = D.Vi2 + Vj2;
-        double vij0 = D.u - s[0], vij1 = D.v - s[1], vij2 = D.w - s[2];
+        T tg = pair_gradfac<KK, UH>(g);
+        tg = pass ? tg : T(0.0); // PRED: every term carries DWIJ
+        T dw0 = tg * g.xij[0], dw1 = tg * g.xij[1], dw2 = tg * g.xij[2];
+        T rhoj = s[6], Vj2 = s[10];
+        T vsum = D.Vi2 + Vj2;
+        T vij0 = D.u - s[0], vij1 = D.v - s[1], vij2 = D.w - s[2];
         if (fl & F_TP) { // :290-320
-            double pij = rhoj * D.p + D.rho * s[7];
+            T pij = rhoj * D.p + D.rho * s[7];
             pij *= fast_rcp(rhoj + D.rho);
-            double tmp = -pij * D.mi1 * vsum;
+            T tmp = -pij * D.mi1 * vsum;
             D.au += tmp * dw0; D.av += tmp * dw1; D.aw += tmp * dw2;
             tmp = -a.p.pb * D.mi1 * vsum;
             D.auh += tmp * dw0; D.avh += tmp * dw1; D.awh += tmp * dw2;
         }
         if (fl & F_TAV) { // :420-436
-            double vijdotrij = vij0 * g.xij[0] + vij1 * g.xij[1] + vij2 * g.xij[2];
-            double piij = 0.0;
+            T vijdotrij = vij0 * g.xij[0] + vij1 * g.xij[1] + vij2 * g.xij[2];
+            T piij = T(0.0);
             if (vijdotrij < 0) {
-                double muij = (g.hij * vijdotrij) * fast_rcp(r2 + g.eps);
+                T muij = (g.hij * vijdotrij) * fast_rcp(r2 + g.eps);
                 piij = -a.p.alpha * a.p.c0 * muij;
-                piij = s[9] * piij * fast_rcp(0.5 * (D.rho + rhoj));
+                piij = s[9] * piij * fast_rcp(T(0.5) * (D.rho + rhoj));
             }
             D.au += -piij * dw0; D.av += -piij * dw1; D.aw += -piij * dw2;
         }
         if (fl & F_TVISC) { // :363-384
-            double etai = a.p.nu * D.rho, etaj = a.p.nu * rhoj;
-            double etaij = 2 * (etai * etaj) * fast_rcp(etai + etaj);
-            double Fij = dw0 * g.xij[0] + dw1 * g.xij[1] + dw2 * g.xij[2];
-            double tmp = D.mi1 * vsum * etaij * Fij * fast_rcp(r2 + g.eps);
+            T etai = a.p.nu * D.rho, etaj = a.p.nu * rhoj;
+            T etaij = 2 * (etai * etaj) * fast_rcp(etai + etaj);
+            T Fij = dw0 * g.xij[0] + dw1 * g.xij[1] + dw2 * g.xij[2];
+            T tmp = D.mi1 * vsum * etaij * Fij * fast_rcp(r2 + g.eps);
             D.au += tmp * vij0; D.av += tmp * vij1; D.aw += tmp * vij2;
         }
         if (fl & F_TAS) { // :473-545
             // A = rho v (x) (vhat - v);  0.5 (A_i + A_j) . DWIJ, with the dot
             // products (vhat - v) . DWIJ taken first (same terms as the
             // reference's 18 products, associated per particle)
-            const double ddi = (D.uh - D.u) * dw0 + (D.vh - D.v) * dw1 + (D.wh - D.w) * dw2;
-            const double ddj = (s[3] - s[0]) * dw0 + (s[4] - s[1]) * dw1 + (s[5] - s[2]) * dw2;
-            const double ci = D.rho * ddi, cj = rhoj * ddj;
-            const double tmp = 0.5 * D.mi1 * vsum;
+            const T ddi = (D.uh - D.u) * dw0 + (D.vh - D.v) * dw1 + (D.wh - D.w) * dw2;
+            const T ddj = (s[3] - s[0]) * dw0 + (s[4] - s[1]) * dw1 + (s[5] - s[2]) * dw2;
+            const T ci = D.rho * ddi, cj = rhoj * ddj;
+            const T tmp = T(0.5) * D.mi1 * vsum;
             D.au += tmp * (ci * D.u + cj * s[0]);
             D.av += tmp * (ci * D.v + cj * s[1]);
             D.aw += tmp * (ci * D.w + cj * s[2]);
@@ -515,15 +520,16 @@ struct FamTVF {
     }
     template <class A> static __device__ __forceinline__ void finish(Dest &D, const A &a, uint32_t o)
     {
-        double damp = 1.0; // post_loop :322-325
-        if (a.t < a.p.tdamp) damp = 0.5 * (sin((-0.5 + a.t / a.p.tdamp) * M_PI) + 1.0);
-        double gx = (a.dflags & F_TP) ? a.p.gx * damp : 0.0;
-        double gy = (a.dflags & F_TP) ? a.p.gy * damp : 0.0;
-        double gz = (a.dflags & F_TP) ? a.p.gz * damp : 0.0;
+        T damp = T(1.0); // post_loop :322-325
+        if (a.t < a.p.tdamp) damp = T(0.5) * (sin((-T(0.5) + a.t / a.p.tdamp) * M_PI) + T(1.0));
+        T gx = (a.dflags & F_TP) ? a.p.gx * damp : T(0.0);
+        T gy = (a.dflags & F_TP) ? a.p.gy * damp : T(0.0);
+        T gz = (a.dflags & F_TP) ? a.p.gz * damp : T(0.0);
         a.p.au[o] = D.au + gx; a.p.av[o] = D.av + gy; a.p.aw[o] = D.aw + gz;
         if (a.dflags & F_TP) { a.p.auhat[o] = D.auh; a.p.avhat[o] = D.avh; a.p.awhat[o] = D.awh; }
     }
 };
+typedef FamTVF_T<double> FamTVF;
 
 // TVF records of the aggregated kernel under uniform h (see k_pack layout 3):
 // five 16-B pieces per pair, two more only when the artificial-stress term acts.
@@ -541,30 +547,31 @@ template <> __device__ __forceinline__ void load_record<FamTVF, true>(const doub
 }
 
 // ---- velocity gradient (basic_equations.py:63-148) -------------------------
-struct FamVGrad {
+template <class T> struct FamVGrad_T {
+    typedef T Real; // arithmetic type of the pair loop
     static constexpr bool PRED = true; // see FamWCSPH
     static constexpr uint32_t CF0 = F_VG3; // flag set compiled as a constant (variant 6)
     static constexpr int MINB = 4; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
     static constexpr int NA = 4; // u v w m/rho
     static constexpr int NR = 8;
     struct Params { double *v[9]; };
-    struct Dest { double u, v, w; double g[9]; };
-    template <class A> static __device__ __forceinline__ void load(Dest &D, const double *a, const A &, uint32_t)
+    struct Dest { T u, v, w; T g[9]; };
+    template <class A> static __device__ __forceinline__ void load(Dest &D, const T *a, const A &, uint32_t)
     {
         D.u = a[0]; D.v = a[1]; D.w = a[2];
-        for (int k = 0; k < 9; k++) D.g[k] = 0.0;
+        for (int k = 0; k < 9; k++) D.g[k] = T(0.0);
     }
     template <int KK, bool UH, class A>
-    static __device__ __forceinline__ void pair(Dest &D, const double4 &pi, const double4 &pj, double r2,
-                                                const double (&s)[NA], uint32_t fl, const A &a, bool pass = true)
+    static __device__ __forceinline__ void pair(Dest &D, const real4<T> &pi, const real4<T> &pj, T r2,
+                                                const T (&s)[NA], uint32_t fl, const A &a, bool pass = true)
     {
-        PairGeom g;
+        PairGeomT<T> g;
         pair_geom<KK, UH>(g, pi, pj, r2, a);
-        double tg = pair_gradfac<KK, UH>(g);
-        tg = pass ? tg : 0.0; // PRED
-        const double dw[3] = {tg * g.xij[0], tg * g.xij[1], tg * g.xij[2]};
-        const double tmp = s[3]; // m/rho (divided once per particle by k_pack)
-        const double nv[3] = {-(D.u - s[0]), -(D.v - s[1]), -(D.w - s[2])};
+        T tg = pair_gradfac<KK, UH>(g);
+        tg = pass ? tg : T(0.0); // PRED
+        const T dw[3] = {tg * g.xij[0], tg * g.xij[1], tg * g.xij[2]};
+        const T tmp = s[3]; // m/rho (divided once per particle by k_pack)
+        const T nv[3] = {-(D.u - s[0]), -(D.v - s[1]), -(D.w - s[2])};
         const int n = (fl & F_VG3) ? 3 : 2;
 #pragma unroll
         for (int i = 0; i < 3; i++)
@@ -582,81 +589,83 @@ struct FamVGrad {
                 if (i < n && j < n) a.p.v[3 * i + j][o] = D.g[3 * i + j];
     }
 };
+typedef FamVGrad_T<double> FamVGrad;
 
 // ---- elastic rates: Continuity + MomentumEquationWithStress +
 //      MonaghanArtificialViscosity + XSPH  (solid_mech/basic.py:245-387,
 //      basic_equations.py:177-300) -------------------------------------------
-struct FamElastic {
+template <class T> struct FamElastic_T {
+    typedef T Real; // arithmetic type of the pair loop
     static constexpr bool PRED = true; // see FamWCSPH
     static constexpr uint32_t CF0 = F_ECONT | F_ESTRESS | F_EAV | F_EXSPH; // flag set compiled as a constant (variant 6)
     static constexpr int MINB = 2; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
     static constexpr int NA = 18; // u v w m rho cs | t00 t01 t02 t11 t12 t22 (= sigma/rho^2) | r00 r01 r02 r11 r12 r22
     static constexpr int NR = 22;
     struct Params {
-        double wdeltap, n, alpha, beta, eps;
+        T wdeltap, n, alpha, beta, eps;
         double *arho, *au, *av, *aw, *ax, *ay, *az;
     };
     struct Dest {
-        double u, v, w, rho, cs, t[6], r[6];
-        double arho, au, av, aw, ax, ay, az;
+        T u, v, w, rho, cs, t[6], r[6];
+        T arho, au, av, aw, ax, ay, az;
     };
-    template <class A> static __device__ __forceinline__ void load(Dest &D, const double *a, const A &, uint32_t)
+    template <class A> static __device__ __forceinline__ void load(Dest &D, const T *a, const A &, uint32_t)
     {
         D.u = a[0]; D.v = a[1]; D.w = a[2]; D.rho = a[4]; D.cs = a[5];
         for (int k = 0; k < 6; k++) { D.t[k] = a[6 + k]; D.r[k] = a[12 + k]; }
-        D.arho = D.au = D.av = D.aw = D.ax = D.ay = D.az = 0.0;
+        D.arho = D.au = D.av = D.aw = D.ax = D.ay = D.az = T(0.0);
     }
     template <int KK, bool UH, class A>
-    static __device__ __forceinline__ void pair(Dest &D, const double4 &pi, const double4 &pj, double r2,
-                                                const double (&s)[NA], uint32_t fl, const A &a, bool pass = true)
+    static __device__ __forceinline__ void pair(Dest &D, const real4<T> &pi, const real4<T> &pj, T r2,
+                                                const T (&s)[NA], uint32_t fl, const A &a, bool pass = true)
     {
-        PairGeom g;
+        PairGeomT<T> g;
         pair_geom<KK, UH>(g, pi, pj, r2, a);
-        double tg = pair_gradfac<KK, UH>(g);
-        tg = pass ? tg : 0.0; // PRED: terms carry DWIJ, the XSPH one WIJ
-        const double dw0 = tg * g.xij[0], dw1 = tg * g.xij[1], dw2 = tg * g.xij[2];
-        const double vij0 = D.u - s[0], vij1 = D.v - s[1], vij2 = D.w - s[2];
-        const double vdotx = vij0 * g.xij[0] + vij1 * g.xij[1] + vij2 * g.xij[2];
-        const double mj = s[3];
+        T tg = pair_gradfac<KK, UH>(g);
+        tg = pass ? tg : T(0.0); // PRED: terms carry DWIJ, the XSPH one WIJ
+        const T dw0 = tg * g.xij[0], dw1 = tg * g.xij[1], dw2 = tg * g.xij[2];
+        const T vij0 = D.u - s[0], vij1 = D.v - s[1], vij2 = D.w - s[2];
+        const T vdotx = vij0 * g.xij[0] + vij1 * g.xij[1] + vij2 * g.xij[2];
+        const T mj = s[3];
         if (fl & F_ECONT) D.arho = fma(mj * tg, vdotx, D.arho);
-        double wij = 0.0;
+        T wij = T(0.0);
         if (fl & (F_ESTRESS | F_EXSPH)) wij = pair_w<KK, UH>(g);
-        wij = pass ? wij : 0.0;
+        wij = pass ? wij : T(0.0);
         if (fl & F_ESTRESS) { // solid_mech/basic.py:267-387
-            double fab = 0.0;
-            if (a.p.wdeltap > 0.) {
-                const double f = wij * fast_rcp(a.p.wdeltap);
-                if (a.p.n == 4.0) { const double f2 = f * f; fab = f2 * f2; }
-                else if (a.p.n == 2.0) fab = f * f;
-                else if (a.p.n == 1.0) fab = f;
+            T fab = T(0.0);
+            if (a.p.wdeltap > T(0.)) {
+                const T f = wij * fast_rcp(a.p.wdeltap);
+                if (a.p.n == T(4.0)) { const T f2 = f * f; fab = f2 * f2; }
+                else if (a.p.n == T(2.0)) fab = f * f;
+                else if (a.p.n == T(1.0)) fab = f;
                 else fab = pow(f, a.p.n);
             }
-            const double a00 = D.t[0] + s[6] + fab * (D.r[0] + s[12]);
-            const double a01 = D.t[1] + s[7] + fab * (D.r[1] + s[13]);
-            const double a02 = D.t[2] + s[8] + fab * (D.r[2] + s[14]);
-            const double a11 = D.t[3] + s[9] + fab * (D.r[3] + s[15]);
-            const double a12 = D.t[4] + s[10] + fab * (D.r[4] + s[16]);
-            const double a22 = D.t[5] + s[11] + fab * (D.r[5] + s[17]);
+            const T a00 = D.t[0] + s[6] + fab * (D.r[0] + s[12]);
+            const T a01 = D.t[1] + s[7] + fab * (D.r[1] + s[13]);
+            const T a02 = D.t[2] + s[8] + fab * (D.r[2] + s[14]);
+            const T a11 = D.t[3] + s[9] + fab * (D.r[3] + s[15]);
+            const T a12 = D.t[4] + s[10] + fab * (D.r[4] + s[16]);
+            const T a22 = D.t[5] + s[11] + fab * (D.r[5] + s[17]);
             D.au += mj * (a00 * dw0 + a01 * dw1 + a02 * dw2);
             D.av += mj * (a01 * dw0 + a11 * dw1 + a12 * dw2);
             D.aw += mj * (a02 * dw0 + a12 * dw1 + a22 * dw2);
         }
         if (fl & (F_EAV | F_EXSPH)) {
-            const double rhoij = 0.5 * (D.rho + s[4]);
-            double rhoij1;
+            const T rhoij = T(0.5) * (D.rho + s[4]);
+            T rhoij1;
             if (fl & F_EAV) { // basic_equations.py:236-257
-                const double re = r2 + g.eps;
-                const double tt = fast_rcp(re * rhoij);
+                const T re = r2 + g.eps;
+                const T tt = fast_rcp(re * rhoij);
                 rhoij1 = re * tt;
-                const double muij = (g.hij * vdotx) * (rhoij * tt);
-                const double cij = 0.5 * (D.cs + s[5]);
-                double piij = (a.p.beta * muij - a.p.alpha * cij) * muij * rhoij1;
-                piij = vdotx < 0 ? piij : 0.0;
-                const double f = -mj * piij;
+                const T muij = (g.hij * vdotx) * (rhoij * tt);
+                const T cij = T(0.5) * (D.cs + s[5]);
+                T piij = (a.p.beta * muij - a.p.alpha * cij) * muij * rhoij1;
+                piij = vdotx < 0 ? piij : T(0.0);
+                const T f = -mj * piij;
                 D.au = fma(f, dw0, D.au); D.av = fma(f, dw1, D.av); D.aw = fma(f, dw2, D.aw);
             } else rhoij1 = fast_rcp(rhoij);
             if (fl & F_EXSPH) { // basic_equations.py:290-295
-                const double tmp = -a.p.eps * mj * wij * rhoij1;
+                const T tmp = -a.p.eps * mj * wij * rhoij1;
                 D.ax = fma(tmp, vij0, D.ax); D.ay = fma(tmp, vij1, D.ay); D.az = fma(tmp, vij2, D.az);
             }
         }
@@ -668,6 +677,7 @@ struct FamElastic {
         if (a.dflags & F_EXSPH) { a.p.ax[o] = D.ax + D.u; a.p.ay[o] = D.ay + D.v; a.p.az[o] = D.az + D.w; }
     }
 };
+typedef FamElastic_T<double> FamElastic;
 
 // ---------------------------------------------------------------------------
 // variant 0: per-lane walk over the 3x3 rows of cells (x-contiguous ranges)
@@ -717,160 +727,6 @@ template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256) void k_p
     }
     Fam::finish(D, a, o);
 }
-
-// ---------------------------------------------------------------------------
-// variant 2: one workgroup = 256 consecutive (cell-ordered)
-// destinations = 4 wavefronts.  For each of the 3x3 neighbouring rows of cells
-// the whole x-range of candidate records the workgroup needs (~290 records of
-// 96 B for WCSPH) is staged ONCE into LDS with coalesced 16-B loads; each
-// wavefront then
-//   phase 1: tests its own sub-range of the tile against its 64 destinations
-//            in fp32 (conservative slack), LDS broadcast reads, one hit bit per
-//            candidate per lane kept in two 64-bit registers;
-//   phase 2: every lane walks its own hit bits and reads the full fp64 record
-//            from LDS (no global gather), applies the reference's exact fp64
-//            criterion and runs the fused pair arithmetic.
-// HBM/L2 traffic per destination drops to ~1 KB (vs ~7 KB of per-pair gathers).
-// ---------------------------------------------------------------------------
-#define TCAP 320  // records per LDS tile
-#define SUBW 128  // candidates per phase-1/phase-2 round of one wavefront
-
-template <class Fam, int KK, bool UH> __global__ __launch_bounds__(256) void k_pair_wg(PairArgs<Fam> a)
-{
-    constexpr int NR = Fam::NR;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *lrec = reinterpret_cast<double *>(smem);                       // TCAP * NR doubles
-    float4 *ftile = reinterpret_cast<float4 *>(smem + (size_t)TCAP * NR * 8); // TCAP
-    int *wx = reinterpret_cast<int *>(smem + (size_t)TCAP * NR * 8 + (size_t)(TCAP + 8) * 16); // [4][2] + [2]
-
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * 256 + t;
-    const bool valid = i < a.nd;
-    const uint32_t ic = valid ? i : a.nd - 1;
-    const uint32_t o = a.d_perm[ic];
-    const bool active = valid && o >= a.d_start && o < a.d_stop;
-    const double *drec = a.rec + (size_t)(a.d_off + ic) * NR;
-    const double4 pi = *reinterpret_cast<const double4 *>(drec);
-    typename Fam::Dest D;
-    Fam::load(D, drec + 4, a, o);
-    const uint32_t key = a.d_keys[ic];
-    const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
-    const int cx = key % ncx;
-    const int row = key / ncx;
-    const double hi_r = a.radius_scale * pi.w;
-    const double hi2 = UH ? a.hr2u : hi_r * hi_r;
-
-    if (t == 0) wx[8] = row;
-    if (t == 255) wx[9] = row;
-    __syncthreads();
-    const int row_first = wx[8], row_last = wx[9];
-
-    for (int R = row_first; R <= row_last; R++) {
-        const bool inseg = active && row == R;
-        const unsigned long long segm = __ballot(inseg);
-        int cxa_w = 0x7fffffff, cxb_w = -1;
-        if (segm) {
-            cxa_w = __builtin_amdgcn_readlane(cx, __builtin_ctzll(segm));
-            cxb_w = __builtin_amdgcn_readlane(cx, 63 - __builtin_clzll(segm));
-        }
-        __syncthreads(); // previous iteration's readers of wx are done
-        if (lane == 0) { wx[2 * wv] = cxa_w; wx[2 * wv + 1] = cxb_w; }
-        __syncthreads();
-        const int cxa = min(min(wx[0], wx[2]), min(wx[4], wx[6]));
-        const int cxb = max(max(wx[1], wx[3]), max(wx[5], wx[7]));
-        if (cxb < 0) continue; // nothing to do in this row (uniform over the workgroup)
-        const int cyR = R % ncy, czR = R / ncy;
-        const int xa = max(cxa - 1, 0), xb = min(cxb + 1, ncx - 1);
-        const int wxa = max(cxa_w - 1, 0), wxb = min(cxb_w + 1, ncx - 1);
-        // fp32 coordinates are relative to this row segment's origin
-        const double ox = a.xmin[0] + a.cell_size * xa;
-        const double oy = a.xmin[1] + a.cell_size * (cyR - 1);
-        const double oz = a.xmin[2] + a.cell_size * (czR - 1);
-        const double L = a.cell_size * (double)max(xb - xa + 2, 4);
-        const float slack = (float)(L * 1.5e-6);
-        const float fx = (float)(pi.x - ox), fy = (float)(pi.y - oy), fz = (float)(pi.z - oz);
-        const float hif = (float)hi_r * 1.000001f + slack;
-        const float hi2f = hif * hif;
-
-        for (int s = 0; s < a.nsrc; s++) {
-            const SrcDesc sd = a.src[s];
-            for (int dz = -1; dz <= 1; dz++)
-                for (int dy = -1; dy <= 1; dy++) {
-                    const int yy = cyR + dy, zz = czR + dz;
-                    if (yy < 0 || yy >= ncy || zz < 0 || zz >= ncz) continue;
-                    const uint32_t rowb = (uint32_t)(ncx * (yy + ncy * zz));
-                    const uint32_t j0 = sd.cell_start[rowb + xa], j1 = sd.cell_start[rowb + xb + 1];
-                    uint32_t wj0 = 0, wj1 = 0;
-                    if (segm) { wj0 = sd.cell_start[rowb + wxa]; wj1 = sd.cell_start[rowb + wxb + 1]; }
-                    for (uint32_t tb = j0; tb < j1; tb += TCAP) {
-                        const int tn = (int)min((uint32_t)TCAP, j1 - tb);
-                        // ---- stage tn records: coalesced 16-B pieces, global -> LDS
-                        {
-                            const double2 *g = reinterpret_cast<const double2 *>(a.rec + (size_t)(sd.off + tb) * NR);
-                            double2 *l = reinterpret_cast<double2 *>(lrec);
-                            const int np = tn * (NR / 2);
-                            for (int q = t; q < np; q += 256) l[q] = g[q];
-                        }
-                        __syncthreads();
-                        // ---- fp32 prefilter tile
-                        for (int r = t; r < tn; r += 256) {
-                            const double4 pj = *reinterpret_cast<const double4 *>(lrec + (size_t)r * NR);
-                            const float hjf = (float)(a.radius_scale * pj.w) * 1.000001f + slack;
-                            ftile[r] = make_float4((float)(pj.x - ox), (float)(pj.y - oy), (float)(pj.z - oz), hjf * hjf);
-                        }
-                        __syncthreads();
-                        // ---- this wavefront's sub-range of the tile
-                        const int k_lo = (int)(max(wj0, tb) - tb);
-                        const int k_hi = (int)min((long)wj1 - (long)tb, (long)tn);
-                        for (int kb = k_lo; kb < k_hi; kb += SUBW) {
-                            const int kn = min(SUBW, k_hi - kb);
-                            unsigned long long m0 = 0, m1 = 0;
-                            if (inseg) {
-                                for (int k0 = 0; k0 < kn; k0 += 8) {
-                                    unsigned mm = 0;
-#pragma unroll
-                                    for (int k = 0; k < 8; k++) {
-                                        // reads past kn stay inside the LDS tile allocation (TCAP + 8 slots)
-                                        const float4 tk = ftile[kb + k0 + k];
-                                        const float ex = fx - tk.x, ey = fy - tk.y, ez = fz - tk.z;
-                                        const float r2 = ex * ex + ey * ey + ez * ez;
-                                        bool hit = UH ? (r2 < hi2f) : ((r2 < hi2f) | (r2 < tk.w));
-                                        hit &= (k0 + k) < kn;
-                                        mm |= hit ? (1u << k) : 0u;
-                                    }
-                                    if (k0 < 64) m0 |= (unsigned long long)mm << k0;
-                                    else m1 |= (unsigned long long)mm << (k0 - 64);
-                                }
-                            }
-                            if (a.ablate == 2) continue;
-                            while (__any((m0 | m1) != 0)) {
-                                if ((m0 | m1) != 0) {
-                                    int kbit;
-                                    if (m0) { kbit = __builtin_ctzll(m0); m0 &= m0 - 1; }
-                                    else { kbit = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
-                                    const double *rj = lrec + (size_t)(kb + kbit) * NR;
-                                    const double4 pj = *reinterpret_cast<const double4 *>(rj);
-                                    double hj2 = hi2;
-                                    if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
-                                    const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-                                    if (((r2 < hi2) || (r2 < hj2)) && a.ablate != 1) {
-                                        double sj[Fam::NA];
-#pragma unroll
-                                        for (int k = 0; k < Fam::NA; k++) sj[k] = rj[4 + k];
-                                        Fam::template pair<KK, UH>(D, pi, pj, r2, sj, sd.flags, a);
-                                    }
-                                }
-                            }
-                        }
-                        __syncthreads(); // tile is overwritten next
-                    }
-                }
-        }
-    }
-    if (active) Fam::finish(D, a, o);
-}
-
-template <class Fam> static size_t wg_lds_bytes() { return (size_t)TCAP * Fam::NR * 8 + (size_t)(TCAP + 8) * 16 + 64; }
 
 // ---------------------------------------------------------------------------
 // host driver
@@ -1061,28 +917,29 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
     if (c->pair_variant >= 3) pa.fpos = c->fposb.as<float4>();
     pa.layout = (c->pair_variant >= 3 && fam == FAM_WCSPH) ? 1 : (c->pair_variant >= 3 && fam == FAM_DENSITY && pl.nr == 4) ? 2
               : (c->pair_variant >= 3 && fam == FAM_TVF && pl.nr == 14) ? 3 : 0;
-    if (c->pair_variant >= 3 && c->record_f32) pa.layout = 5;
+    if (c->pair_variant >= 3 && (c->record_f32 || c->arith_f32)) pa.layout = 5;
     hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, pa);
     return SPH_OK;
 }
 
-template <class Fam> static void launch_pair(sph_ctx *c, int kk, const PairArgs<Fam> &a)
+template <class Fam> static int launch_pair(sph_ctx *c, int kk, const PairArgs<Fam> &a)
 {
-    if (a.nd == 0) return;
+    if (a.nd == 0) return SPH_OK;
     const bool uh = c->uniform_h && c->use_uniform_h;
+    constexpr bool FP32 = sizeof(typename Fam::Real) == 4;
     if (c->pair_variant == 6) {
         dim3 g2(4 * div_up(a.nd, 256)), b2(64);
         // equation flags as a compile-time constant when every source carries the same set
         uint32_t cf = a.src[0].flags;
         for (int j = 1; j < a.nsrc; j++) if (a.src[j].flags != cf) cf = 0;
         if (c->const_flags == 0) cf = 0;
-#define LAUNCH6F(K, UHV, CFV) hipLaunchKernelGGL((k_pair_wave<Fam, K, UHV, false, CFV>), g2, b2, 0, c->stream, a)
-#define LAUNCH6(K)                                                                                      \
-        if (c->record_f32) {                                                                            \
-            if (uh) hipLaunchKernelGGL((k_pair_wave<Fam, K, true, true>), g2, b2, 0, c->stream, a);     \
-            else hipLaunchKernelGGL((k_pair_wave<Fam, K, false, true>), g2, b2, 0, c->stream, a);       \
-        } else if (uh) { if (cf == Fam::CF0) LAUNCH6F(K, true, Fam::CF0); else LAUNCH6F(K, true, 0); }  \
-        else { if (cf == Fam::CF0) LAUNCH6F(K, false, Fam::CF0); else LAUNCH6F(K, false, 0); }
+#define LAUNCH6F(K, UHV, F32V, CFV) hipLaunchKernelGGL((k_pair_wave<Fam, K, UHV, F32V, CFV>), g2, b2, 0, c->stream, a)
+#define LAUNCH6U(K, F32V)                                                                                 \
+        if (uh) { if (cf == Fam::CF0) LAUNCH6F(K, true, F32V, Fam::CF0); else LAUNCH6F(K, true, F32V, 0); }  \
+        else { if (cf == Fam::CF0) LAUNCH6F(K, false, F32V, Fam::CF0); else LAUNCH6F(K, false, F32V, 0); }
+#define LAUNCH6(K)                                                       \
+        if constexpr (FP32) { LAUNCH6U(K, true) }                        \
+        else { if (c->record_f32) { LAUNCH6U(K, true) } else { LAUNCH6U(K, false) } }
         switch (kk) {
         case 1: LAUNCH6(1); break;
         case 2: LAUNCH6(2); break;
@@ -1090,52 +947,27 @@ template <class Fam> static void launch_pair(sph_ctx *c, int kk, const PairArgs<
         case 4: LAUNCH6(4); break;
         }
 #undef LAUNCH6
+#undef LAUNCH6U
 #undef LAUNCH6F
-        return;
+        return SPH_OK;
     }
-    if (c->pair_variant == 3) {
-        dim3 g2(div_up(a.nd, ABS)), b2(ABS);
-#define LAUNCH3(K)                                                                                      \
-        if (c->record_f32) {                                                                            \
-            if (uh) hipLaunchKernelGGL((k_pair_agg<Fam, K, true, true>), g2, b2, 0, c->stream, a);      \
-            else hipLaunchKernelGGL((k_pair_agg<Fam, K, false, true>), g2, b2, 0, c->stream, a);        \
-        } else if (uh) hipLaunchKernelGGL((k_pair_agg<Fam, K, true>), g2, b2, 0, c->stream, a);         \
-        else hipLaunchKernelGGL((k_pair_agg<Fam, K, false>), g2, b2, 0, c->stream, a)
-        switch (kk) {
-        case 1: LAUNCH3(1); break;
-        case 2: LAUNCH3(2); break;
-        case 3: LAUNCH3(3); break;
-        case 4: LAUNCH3(4); break;
-        }
-#undef LAUNCH3
-        return;
-    }
-    if (c->pair_variant == 2) {
-        dim3 g2(div_up(a.nd, 256)), b2(256);
-        size_t lds = wg_lds_bytes<Fam>();
-#define LAUNCH2(K)                                                                               \
-        if (uh) hipLaunchKernelGGL((k_pair_wg<Fam, K, true>), g2, b2, lds, c->stream, a);        \
-        else hipLaunchKernelGGL((k_pair_wg<Fam, K, false>), g2, b2, lds, c->stream, a)
-        switch (kk) {
-        case 1: LAUNCH2(1); break;
-        case 2: LAUNCH2(2); break;
-        case 3: LAUNCH2(3); break;
-        case 4: LAUNCH2(4); break;
-        }
-#undef LAUNCH2
-        return;
-    }
-    dim3 gd(div_up(a.nd, 256)), bd(256);
+    if constexpr (FP32) {
+        sph_set_error("fp32 arithmetic (arith_f32) needs pair_variant 6");
+        return SPH_ERR_UNSUPPORTED;
+    } else {
+        dim3 gd(div_up(a.nd, 256)), bd(256);
 #define LAUNCH(K)                                                                                \
-    if (uh) hipLaunchKernelGGL((k_pair_direct<Fam, K, true>), gd, bd, 0, c->stream, a);      \
-    else hipLaunchKernelGGL((k_pair_direct<Fam, K, false>), gd, bd, 0, c->stream, a)
-    switch (kk) {
-    case 1: LAUNCH(1); break;
-    case 2: LAUNCH(2); break;
-    case 3: LAUNCH(3); break;
-    case 4: LAUNCH(4); break;
-    }
+        if (uh) hipLaunchKernelGGL((k_pair_direct<Fam, K, true>), gd, bd, 0, c->stream, a);      \
+        else hipLaunchKernelGGL((k_pair_direct<Fam, K, false>), gd, bd, 0, c->stream, a)
+        switch (kk) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        case 3: LAUNCH(3); break;
+        case 4: LAUNCH(4); break;
+        }
 #undef LAUNCH
+        return SPH_OK;
+    }
 }
 
 template <class Fam>
@@ -1268,7 +1100,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         if (c->pair_variant >= 3 && fam == FAM_WCSPH && c->uniform_h && c->use_uniform_h && !(dflags & F_TENSILE)) pl.nr = 10;
         if (c->pair_variant >= 3 && fam == FAM_DENSITY && c->uniform_h && c->use_uniform_h) pl.nr = 4;
         if (c->pair_variant >= 3 && fam == FAM_TVF && c->uniform_h && c->use_uniform_h) pl.nr = 14;
-        if (c->pair_variant >= 3 && c->record_f32) pl.nr = (4 + pl.na + 3) & ~3; // floats
+        if (c->pair_variant >= 3 && (c->record_f32 || c->arith_f32)) pl.nr = (4 + pl.na + 3) & ~3; // floats
         c->cur_nrec = pl.nr;
         SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * (c->pair_variant >= 2 ? pl.nr : 4)));
         SPH_TRY(c->aux.reserve((total + 64) * sizeof(double) * pl.na));
@@ -1280,12 +1112,23 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             if (!dest_is_src) SPH_TRY(pack_array(c, dst, d_off, pl, fam, dflags, true));
         }
 
-        // 4. fused pair kernel
+        // 4. fused pair kernel, in the arithmetic type of the context (fp64, or fp32 with option arith_f32)
         ScopedTimer tm(c, T_PAIR);
-        if (fam == FAM_WCSPH) {
-            PairArgs<FamWCSPH> a;
-            memset(&a, 0, sizeof a);
+        // the part of the launch arguments every family shares
+        auto common = [&](auto &a) {
             fill_common(c, a, K, t);
+            a.nsrc = nsrcs;
+            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j], c->arr[srcs[j]].fine_start.as<uint32_t>()};
+            a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
+            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
+            a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
+            a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
+        };
+        auto run_wcsph = [&](auto tag) -> int {
+            typedef decltype(tag) F;
+            PairArgs<F> a;
+            memset(&a, 0, sizeof a);
+            common(a);
             const sph_equation *me = eq_of[SPH_EQ_MOMENTUM], *xe = eq_of[SPH_EQ_XSPH];
             if (me) { a.p.c0 = me->par[0]; a.p.alpha = me->par[1]; a.p.beta = me->par[2]; a.p.gx = me->par[3]; a.p.gy = me->par[4]; a.p.gz = me->par[5]; }
             if (xe) a.p.eps = xe->par[0];
@@ -1299,49 +1142,37 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
                 SPH_TRY(ensure_out(c, dst, {SPH_AX, SPH_AY, SPH_AZ}));
                 a.p.ax = D.prop[SPH_AX]; a.p.ay = D.prop[SPH_AY]; a.p.az = D.prop[SPH_AZ];
             }
-            a.nsrc = nsrcs;
-            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j], c->arr[srcs[j]].fine_start.as<uint32_t>()};
-            a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
-            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
-            a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
-            a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
-            launch_pair<FamWCSPH>(c, K->kind, a);
-        } else if (fam == FAM_DENSITY) {
-            PairArgs<FamDensity> a;
+            return launch_pair<F>(c, K->kind, a);
+        };
+        auto run_density = [&](auto tag) -> int {
+            typedef decltype(tag) F;
+            PairArgs<F> a;
             memset(&a, 0, sizeof a);
-            fill_common(c, a, K, t);
+            common(a);
             SPH_TRY(ensure_out(c, dst, {SPH_RHO}));
             a.p.rho = D.prop[SPH_RHO];
             if (dflags & F_TVFSD) { SPH_TRY(ensure_out(c, dst, {SPH_VOL})); a.p.V = D.prop[SPH_VOL]; }
             if ((dflags & F_SD) && (dflags & F_TVFSD)) { sph_set_error("both SummationDensity flavours on one destination"); return SPH_ERR_UNSUPPORTED; }
-            a.nsrc = nsrcs;
-            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j], c->arr[srcs[j]].fine_start.as<uint32_t>()};
-            a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
-            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
-            a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
-            a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
-            launch_pair<FamDensity>(c, K->kind, a);
-        } else if (fam == FAM_VGRAD) {
-            PairArgs<FamVGrad> a;
+            return launch_pair<F>(c, K->kind, a);
+        };
+        auto run_vgrad = [&](auto tag) -> int {
+            typedef decltype(tag) F;
+            PairArgs<F> a;
             memset(&a, 0, sizeof a);
-            fill_common(c, a, K, t);
+            common(a);
             static const int vp[9] = {SPH_V00, SPH_V01, SPH_V02, SPH_V10, SPH_V11, SPH_V12, SPH_V20, SPH_V21, SPH_V22};
             if ((dflags & F_VG2) && (dflags & F_VG3)) { sph_set_error("both VelocityGradient2D and 3D on one destination"); return SPH_ERR_UNSUPPORTED; }
             for (int k = 0; k < 9; k++) {
                 const bool used = (dflags & F_VG3) || (k == 0 || k == 1 || k == 3 || k == 4);
                 if (used) { SPH_TRY(sph_array_ensure_prop(c, dst, vp[k])); a.p.v[k] = D.prop[vp[k]]; }
             }
-            a.nsrc = nsrcs;
-            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j], c->arr[srcs[j]].fine_start.as<uint32_t>()};
-            a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
-            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
-            a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
-            a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
-            launch_pair<FamVGrad>(c, K->kind, a);
-        } else if (fam == FAM_ELASTIC) {
-            PairArgs<FamElastic> a;
+            return launch_pair<F>(c, K->kind, a);
+        };
+        auto run_elastic = [&](auto tag) -> int {
+            typedef decltype(tag) F;
+            PairArgs<F> a;
             memset(&a, 0, sizeof a);
-            fill_common(c, a, K, t);
+            common(a);
             const sph_equation *se = eq_of[SPH_EQ_MOMENTUM_WITH_STRESS], *ae = eq_of[SPH_EQ_MONAGHAN_ART_VISCOSITY],
                                *xe = eq_of[SPH_EQ_XSPH];
             if (se) { a.p.wdeltap = se->par[0]; a.p.n = se->par[1]; }
@@ -1356,17 +1187,13 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
                 SPH_TRY(ensure_out(c, dst, {SPH_AX, SPH_AY, SPH_AZ}));
                 a.p.ax = D.prop[SPH_AX]; a.p.ay = D.prop[SPH_AY]; a.p.az = D.prop[SPH_AZ];
             }
-            a.nsrc = nsrcs;
-            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j], c->arr[srcs[j]].fine_start.as<uint32_t>()};
-            a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
-            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
-            a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
-            a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
-            launch_pair<FamElastic>(c, K->kind, a);
-        } else {
-            PairArgs<FamTVF> a;
+            return launch_pair<F>(c, K->kind, a);
+        };
+        auto run_tvf = [&](auto tag) -> int {
+            typedef decltype(tag) F;
+            PairArgs<F> a;
             memset(&a, 0, sizeof a);
-            fill_common(c, a, K, t);
+            common(a);
             const sph_equation *pe = eq_of[SPH_EQ_TVF_MOM_PRESSURE], *ve = eq_of[SPH_EQ_TVF_MOM_VISCOSITY],
                                *ae = eq_of[SPH_EQ_TVF_MOM_ART_VISCOSITY];
             if (pe) { a.p.pb = pe->par[0]; a.p.gx = pe->par[1]; a.p.gy = pe->par[2]; a.p.gz = pe->par[3]; a.p.tdamp = pe->par[4]; }
@@ -1378,14 +1205,14 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
                 SPH_TRY(ensure_out(c, dst, {SPH_AUHAT, SPH_AVHAT, SPH_AWHAT}));
                 a.p.auhat = D.prop[SPH_AUHAT]; a.p.avhat = D.prop[SPH_AVHAT]; a.p.awhat = D.prop[SPH_AWHAT];
             }
-            a.nsrc = nsrcs;
-            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j], c->arr[srcs[j]].fine_start.as<uint32_t>()};
-            a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
-            a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
-            a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
-            a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
-            launch_pair<FamTVF>(c, K->kind, a);
-        }
+            return launch_pair<F>(c, K->kind, a);
+        };
+        const bool f32 = c->arith_f32 != 0;
+        if (fam == FAM_WCSPH) SPH_TRY(f32 ? run_wcsph(FamWCSPH_T<float>()) : run_wcsph(FamWCSPH()));
+        else if (fam == FAM_DENSITY) SPH_TRY(f32 ? run_density(FamDensity_T<float>()) : run_density(FamDensity()));
+        else if (fam == FAM_VGRAD) SPH_TRY(f32 ? run_vgrad(FamVGrad_T<float>()) : run_vgrad(FamVGrad()));
+        else if (fam == FAM_ELASTIC) SPH_TRY(f32 ? run_elastic(FamElastic_T<float>()) : run_elastic(FamElastic()));
+        else SPH_TRY(f32 ? run_tvf(FamTVF_T<float>()) : run_tvf(FamTVF()));
     }
     HIP_TRY(hipGetLastError());
     return SPH_OK;

@@ -97,6 +97,7 @@ struct sph_ctx {
     long ablate = 0;
     long const_flags = 1;   // variant 6: compile-time equation flags when all sources agree (0: always run-time flags)
     long use_uniform_h = 1;
+    long arith_f32 = 0;     // hand-written families compute in fp32 (fp32 records, fp32 accumulators; BASELINE config 5)
     long record_f32 = 0;    // packed records in fp32 (inputs rounded, arithmetic fp64): aggregated kernel only
     long tile_block_rows = 8; // destination tiles are traversed in blocks of this many cell rows (y) through all z planes; 0: memory order
     double cur_dt = 0.0;    // dt of the sph_eval_group call being set up

@@ -1,10 +1,13 @@
 // sph_pair.h -- the pair-loop skeleton shared by the hand-written equation
 // families (sph_eval.hip) and by generated ones (pysph_amd/codegen.py):
 // launch arguments, per-pair geometry and kernel helpers, record access and the
-// aggregated two-phase pair kernel k_pair_agg<Fam, KK, UH>.
+// two-phase pair kernel k_pair_wave<Fam, KK, UH, F32, CF>.
 //
 // A family `Fam` supplies
-//   MINB                 workgroups per CU to compile for (VGPR budget)
+//   Real                 double or float: the type the pair arithmetic runs in
+//                        (float: BASELINE config 5 / the reference's GPU default,
+//                        acceleration_eval_gpu_helper.py:281-283,437-441)
+//   MINB                 wavefronts per SIMD to compile for (VGPR budget)
 //   NA, NR               aux doubles per record, record length (>= 4 + NA)
 //   Params               launch constants / output pointers
 //   Dest                 per-destination registers (inputs + accumulators)
@@ -25,12 +28,18 @@
 // exact (non-contracted) squared distance: must round like the reference's
 // norm2 (nnps_base.pxd:36-37) so that neighbour SETS are identical.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double r2_exact(double dx, double dy, double dz)
+template <class T> __device__ __forceinline__ T r2_exact(T dx, T dy, T dz)
 {
 #pragma clang fp contract(off)
-    const double a = dx * dx, b = dy * dy, c = dz * dz;
+    const T a = dx * dx, b = dy * dy, c = dz * dz;
     return (a + b) + c;
 }
+
+// 4-vector of the arithmetic type
+template <class T> struct Real4Of;
+template <> struct Real4Of<double> { typedef double4 type; };
+template <> struct Real4Of<float> { typedef float4 type; };
+template <class T> using real4 = typename Real4Of<T>::type;
 
 
 struct KernelConst {
@@ -118,17 +127,26 @@ __device__ __forceinline__ void fast_sqrt_rsqrt(double a, double &s, double &rs)
     s = g;
     rs = h + h;
 }
+// fp32: v_rcp_f32 / v_rsq_f32 are 1-ulp instructions, no refinement needed
+__device__ __forceinline__ float fast_rcp(float d) { return __builtin_amdgcn_rcpf(d); }
+__device__ __forceinline__ void fast_sqrt_rsqrt(float a, float &s, float &rs)
+{
+    a = fmaxf(a, 1e-35f);
+    rs = __builtin_amdgcn_rsqf(a);
+    s = a * rs;
+}
 
 // per-pair geometry shared by all families
-struct PairGeom {
-    double xij[3];
-    double r2, rij, rinv, hij, h1, q, fac, eps;
+template <class T> struct PairGeomT {
+    T xij[3];
+    T r2, rij, rinv, hij, h1, q, fac, eps;
 };
+typedef PairGeomT<double> PairGeom;
 
 // UH: every particle has the same h -> HIJ, 1/HIJ, the kernel normalisation
 // and EPS are launch constants.
-template <int KK, bool UH, class A>
-__device__ __forceinline__ void pair_geom(PairGeom &g, const double4 &pi, const double4 &pj, double r2, const A &a)
+template <int KK, bool UH, class T, class A>
+__device__ __forceinline__ void pair_geom(PairGeomT<T> &g, const real4<T> &pi, const real4<T> &pj, T r2, const A &a)
 {
     g.xij[0] = pi.x - pj.x; g.xij[1] = pi.y - pj.y; g.xij[2] = pi.z - pj.z; // XIJ equation.py:205-212
     g.r2 = r2;                                                               // R2IJ :226-233
@@ -141,38 +159,38 @@ __device__ __forceinline__ void pair_geom(PairGeom &g, const double4 &pi, const 
     constexpr bool EXACT_Q = (KK == 4);
     if (EXACT_Q) {
         g.rij = sqrt(r2);
-        g.rinv = g.rij > 0.0 ? 1.0 / g.rij : 0.0;
+        g.rinv = g.rij > T(0) ? T(1) / g.rij : T(0);
     } else {
         fast_sqrt_rsqrt(r2, g.rij, g.rinv);                                  // RIJ  :235
     }
     if (UH) {
-        g.hij = a.hu; g.h1 = a.h1u; g.fac = a.facu; g.eps = a.epsu;
+        g.hij = (T)a.hu; g.h1 = (T)a.h1u; g.fac = (T)a.facu; g.eps = (T)a.epsu;
     } else {
-        g.hij = 0.5 * (pi.w + pj.w);                                         // HIJ  :192
-        g.h1 = EXACT_Q ? 1.0 / g.hij : fast_rcp(g.hij);
-        g.fac = kernel_norm(a.k.sigma, g.h1, a.k.dim);
-        g.eps = 0.01 * g.hij * g.hij;                                        // EPS  :194
+        g.hij = T(0.5) * (pi.w + pj.w);                                      // HIJ  :192
+        g.h1 = EXACT_Q ? T(1) / g.hij : fast_rcp(g.hij);
+        g.fac = kernel_norm((T)a.k.sigma, g.h1, a.k.dim);
+        g.eps = T(0.01) * g.hij * g.hij;                                     // EPS  :194
     }
     g.q = g.rij * g.h1;
 }
-template <int KK, bool UH> __device__ __forceinline__ double pair_w(const PairGeom &g) { return SphKernel<KK>::template w<UH>(g.q) * g.fac; }
+template <int KK, bool UH, class T> __device__ __forceinline__ T pair_w(const PairGeomT<T> &g) { return SphKernel<KK>::template w<UH>(g.q) * g.fac; }
 // GRADH(XIJ, RIJ, h) = dW/dh (kernels.py gradient_h, e.g. :138-163): -fac*h1*(dw*q + w*dim)
-template <int KK, bool UH> __device__ __forceinline__ double pair_gradh(const PairGeom &g, int dim)
+template <int KK, bool UH, class T> __device__ __forceinline__ T pair_gradh(const PairGeomT<T> &g, int dim)
 {
-    return -g.fac * g.h1 * (SphKernel<KK>::template dw<UH>(g.q) * g.q + SphKernel<KK>::template w<UH>(g.q) * dim);
+    return -g.fac * g.h1 * (SphKernel<KK>::template dw<UH>(g.q) * g.q + SphKernel<KK>::template w<UH>(g.q) * (T)dim);
 }
 // GRADIENT(XIJ, RIJ, HIJ, DWIJ) (kernels.py:126-137) returns tmp*xij with
 // tmp = dwdq*h1/rij; here tmp only.  dw(q)/rij = dwq(q)*h1 when the kernel has
 // a closed form for dw/q.
-template <int KK, bool UH> __device__ __forceinline__ double pair_gradfac(const PairGeom &g)
+template <int KK, bool UH, class T> __device__ __forceinline__ T pair_gradfac(const PairGeomT<T> &g)
 {
-    double t;
+    T t;
     if (SphKernel<KK>::HAS_DWQ) t = SphKernel<KK>::template dwq<UH>(g.q) * (g.fac * g.h1 * g.h1);
     else t = SphKernel<KK>::template dw<UH>(g.q) * (g.fac * g.h1) * g.rinv;
-    return g.rij > 1e-12 ? t : 0.0;
+    return g.rij > T(1e-12) ? t : T(0);
 }
 
-// Record access for the aggregated kernel.  Default layout: [x y z h | aux...].
+// Record access of the pair kernel.  Default layout: [x y z h | aux...].
 template <class Fam, bool UH>
 __device__ __forceinline__ void load_record(const double *__restrict__ rj, uint32_t fl, double4 &pj, double (&s)[Fam::NA])
 {
@@ -181,13 +199,13 @@ __device__ __forceinline__ void load_record(const double *__restrict__ rj, uint3
     for (int k = 0; k < Fam::NA; k++) s[k] = rj[4 + k];
 }
 
-// fp32 RECORDS (option record_f32): [x-x0 y-y0 z-z0 h | aux...] as floats, 16-byte
-// pieces of four; positions are relative to the grid origin so that their
-// rounding is relative to the domain extent.  The values are widened to double
-// on load -- arithmetic and accumulation stay fp64, the inputs carry fp32
-// precision, and a pair costs about half the gather pieces.
-template <class Fam>
-__device__ __forceinline__ void load_record_f32(const float *__restrict__ rj, double4 &pj, double (&s)[Fam::NA])
+// fp32 RECORDS: [x-x0 y-y0 z-z0 h | aux...] as floats, 16-byte pieces of four;
+// positions are relative to the grid origin so that their rounding is relative
+// to the domain extent.  Read by the fp32 families (Real = float) as they are,
+// and by fp64 families under option record_f32 (values widened on load:
+// arithmetic and accumulation fp64, inputs of fp32 precision).
+template <class Fam, class T>
+__device__ __forceinline__ void load_record_f32(const float *__restrict__ rj, real4<T> &pj, T (&s)[Fam::NA])
 {
     constexpr int NF = (4 + Fam::NA + 3) & ~3;
     float f[NF];
@@ -203,8 +221,8 @@ __device__ __forceinline__ void load_record_f32(const float *__restrict__ rj, do
 // and the criterion: the use keeps all pieces of the record in ONE batch of
 // loads ahead of the branch.  Without it the optimiser sinks the non-position
 // pieces into the branch (as misaligned loads): two memory latencies per hit.
-template <int NA>
-__device__ __forceinline__ void pin_record(const double4 &pj, const double (&s)[NA])
+template <int NA, class T>
+__device__ __forceinline__ void pin_record(const real4<T> &pj, const T (&s)[NA])
 {
     asm volatile("" ::"v"(pj.x), "v"(pj.y), "v"(pj.z));
 #pragma unroll
@@ -227,248 +245,9 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nb)
     return xcd * base + min(xcd, rem) + idx;
 }
 
-// ---------------------------------------------------------------------------
-// variant 3 (default): aggregated two-phase kernel.
-//   workgroup = 256 consecutive cell-ordered destinations (4 wave64).
-//   For every neighbouring row of cells the workgroup stages only the fp32
-//   positions of the row's candidate range (SoA, ~4 KB) plus the cell_start
-//   slice into LDS.  Phase 1: each LANE tests just the candidates of ITS OWN
-//   3 cells (two per packed-fp32 instruction) and stores a <=96-bit hit mask
-//   per row in its private LDS column.  After all 3x3 rows of a source are
-//   done, phase 2 lets every lane walk the hit bits of ALL rows back to back
-//   (simulated lane utilisation 0.94 instead of 0.44 for row-by-row
-//   processing), gathering the fp64 record of each hit, applying the
-//   reference's exact criterion and the fused pair arithmetic.
-// ---------------------------------------------------------------------------
-#define ACAP 480   // candidates per LDS position tile
-#define AQ 9       // mask slots per thread (one source's 3x3 rows)
-#define ABS 256     // threads (= destinations) per workgroup of the aggregated kernel
 #define AMAXLEN 96 // hit bits kept per row and lane; longer ranges take the slow tail
 
 typedef float f2 __attribute__((ext_vector_type(2)));
-
-template <class Fam, int KK, bool UH, bool F32 = false>
-__global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_agg(PairArgs<Fam> a)
-{
-    const uint32_t NR = (uint32_t)a.nrec;
-    // fp32 tile: x | y | z | (w) planes of TS floats each; reads past a plane's
-    // valid part land in the next plane / the mask area and are masked out
-    constexpr int TS = ACAP + 8;
-    __shared__ __attribute__((aligned(16))) float tile[(UH ? 3 : 4) * TS];
-    float *const tx = tile, *const ty = tile + TS, *const tz = tile + 2 * TS, *const tw = tile + (UH ? 0 : 3 * TS);
-    __shared__ uint32_t csl[72];
-    __shared__ unsigned long long mlo[AQ][ABS];
-    __shared__ uint32_t mhi[AQ][ABS];
-    __shared__ unsigned short mofs[AQ][ABS];
-    __shared__ uint32_t qbase[AQ];
-    __shared__ int qown[AQ]; // profiling (ablate 4/5): slot holds the destinations' own row of cells
-    __shared__ int wx[2 * (ABS / 64) + 2];
-
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    uint32_t dtile = xcd_tile(blockIdx.x, gridDim.x);
-    if (a.d_tile_order) dtile = a.d_tile_order[dtile];
-    const uint32_t i = dtile * ABS + t;
-    const bool valid = i < a.nd;
-    const uint32_t ic = valid ? i : a.nd - 1;
-    const uint32_t o = a.d_perm[ic];
-    const bool active = valid && o >= a.d_start && o < a.d_stop;
-    double4 pi;
-    typename Fam::Dest D;
-    {
-        double sd_[Fam::NA];
-        // the destination's own h / p come with the same rules as a source's
-        // (uniform h: the constant; p only for the tensile correction)
-        if (F32) load_record_f32<Fam>(reinterpret_cast<const float *>(a.rec) + (size_t)(a.d_off + ic) * NR, pi, sd_);
-        else load_record<Fam, UH>(a.rec + (size_t)(a.d_off + ic) * NR, a.dflags, pi, sd_);
-        if (UH) pi.w = a.hu;
-        Fam::load(D, sd_, a, o);
-    }
-    const uint32_t key = a.d_keys[ic];
-    const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
-    const int cx = key % ncx;
-    const int row = key / ncx;
-    const double hi_r = a.radius_scale * pi.w;
-    const double hi2 = UH ? a.hr2u : hi_r * hi_r;
-
-    if (t == 0) wx[2 * (ABS / 64)] = row;
-    if (t == ABS - 1) wx[2 * (ABS / 64) + 1] = row;
-    __syncthreads();
-    const int row_first = wx[2 * (ABS / 64)], row_last = wx[2 * (ABS / 64) + 1];
-
-    // exact criterion + pair arithmetic for one candidate record
-    auto do_pair = [&](uint32_t jg, uint32_t flags) {
-        double4 pj;
-        double sj[Fam::NA];
-        if (F32) load_record_f32<Fam>(reinterpret_cast<const float *>(a.rec) + (unsigned long long)jg * NR, pj, sj);
-        else load_record<Fam, UH>(a.rec + (unsigned long long)jg * NR, flags, pj, sj);
-        double hj2 = hi2;
-        if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
-        const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-        if (((r2 < hi2) || (r2 < hj2)) && a.ablate != 1) Fam::template pair<KK, UH>(D, pi, pj, r2, sj, flags, a);
-    };
-
-    for (int R = row_first; R <= row_last; R++) {
-        const bool inseg = active && row == R;
-        const unsigned long long segm = __ballot(inseg);
-        int cxa_w = 0x7fffffff, cxb_w = -1;
-        if (segm) {
-            cxa_w = __builtin_amdgcn_readlane(cx, __builtin_ctzll(segm));
-            cxb_w = __builtin_amdgcn_readlane(cx, 63 - __builtin_clzll(segm));
-        }
-        __syncthreads();
-        if (lane == 0) { wx[2 * wv] = cxa_w; wx[2 * wv + 1] = cxb_w; }
-        __syncthreads();
-        int cxa = wx[0], cxb = wx[1];
-#pragma unroll
-        for (int w2 = 1; w2 < ABS / 64; w2++) { cxa = min(cxa, wx[2 * w2]); cxb = max(cxb, wx[2 * w2 + 1]); }
-        if (cxb < 0) continue;
-        const int cyR = R % ncy, czR = R / ncy;
-        const int xa = max(cxa - 1, 0), xb = min(cxb + 1, ncx - 1);
-        const int ncs = xb - xa + 2; // cell_start entries needed: cells xa..xb and the end
-        // fp32 coordinates: grid-relative positions (fpos, rounded once from
-        // fp64) minus this row segment's origin; every value carries at most
-        // 2^-24 * dom_extent of rounding, covered by `slack`
-        const float oxf = (float)(a.cell_size * xa);
-        const float oyf = (float)(a.cell_size * (cyR - 1));
-        const float ozf = (float)(a.cell_size * (czR - 1));
-        const double L = fmax(a.cell_size * (double)max(xb - xa + 2, 4), a.dom_extent);
-        const float slack = (float)(L * 1.5e-6);
-        const float4 fpi = a.fpos[a.d_off + ic];
-        const float fxs = fpi.x - oxf, fys = fpi.y - oyf, fzs = fpi.z - ozf;
-        const f2 fx = {fxs, fxs}, fy = {fys, fys}, fz = {fzs, fzs};
-        const float hif = (float)hi_r * 1.000001f + slack;
-        const float hi2f = hif * hif;
-        const int mycl = max(cx - 1, xa) - xa, mych = min(cx + 1, xb) + 1 - xa;
-
-        for (int s = 0; s < a.nsrc; s++) {
-            const SrcDesc sd = a.src[s];
-            int nq = 0;
-            // ---- phase 2 over the slots filled so far (per wavefront, no barrier needed:
-            // every thread only touches its own mask column)
-            auto phase2 = [&]() {
-                if (a.ablate != 2 && nq > 0) {
-                    int q = 0;
-                    unsigned long long m0 = mlo[0][t];
-                    uint32_t m1 = mhi[0][t];
-                    // candidate index of bit 0 of the current slot: read from LDS only
-                    // when the slot changes, not on the dependent chain of every hit
-                    uint32_t jb = qbase[0] + mofs[0][t];
-                    int own = qown[0];
-                    for (;;) {
-                        while (m0 == 0 && m1 == 0 && q + 1 < nq) {
-                            ++q;
-                            m0 = mlo[q][t];
-                            m1 = mhi[q][t];
-                            jb = qbase[q] + mofs[q][t];
-                            own = qown[q];
-                        }
-                        const bool has = (m0 != 0) || (m1 != 0);
-                        if (!__any(has)) break;
-                        if (has) {
-                            int bit;
-                            if (m0) { bit = __builtin_ctzll(m0); m0 &= m0 - 1; }
-                            else { bit = 64 + __builtin_ctz(m1); m1 &= m1 - 1; }
-                            // ablate 3 (profiling): every gather hits the destination's own record (L1-resident)
-                            // ablate 4: own-row hits skipped; 5: own-row hits gather the destination's own record
-                            if (!(a.ablate == 4 && own))
-                                do_pair((a.ablate == 3 || (a.ablate == 5 && own)) ? a.d_off + ic : jb + bit, sd.flags);
-                        }
-                    }
-                }
-                nq = 0;
-            };
-            for (int dz = -1; dz <= 1; dz++)
-                for (int dy = -1; dy <= 1; dy++) {
-                    const int yy = cyR + dy, zz = czR + dz;
-                    if (yy < 0 || yy >= ncy || zz < 0 || zz >= ncz) continue;
-                    const uint32_t rowb = (uint32_t)(ncx * (yy + ncy * zz));
-                    const uint32_t j0 = sd.cell_start[rowb + xa], j1 = sd.cell_start[rowb + xb + 1];
-                    for (uint32_t tb = j0; tb < j1; tb += ACAP) {
-                        const int tn = (int)min((uint32_t)ACAP, j1 - tb);
-                        __syncthreads(); // previous tile's readers are done
-                        for (int q = t; q < ncs && q < 72; q += ABS) csl[q] = sd.cell_start[rowb + xa + q];
-                        for (int k = t; k < tn + 8; k += ABS) {
-                            float vx = 3.0e18f, vy = 3.0e18f, vz = 3.0e18f, vw = 0.f;
-                            if (k < tn) {
-                                const float4 fj = a.fpos[sd.off + tb + k];
-                                vx = fj.x - oxf; vy = fj.y - oyf; vz = fj.z - ozf;
-                                const float hjf = fj.w * 1.000001f + slack;
-                                vw = hjf * hjf;
-                            }
-                            tx[k] = vx; ty[k] = vy; tz[k] = vz;
-                            if (!UH) tw[k] = vw;
-                        }
-                        __syncthreads();
-                        // ---- my own candidate range inside this tile (3 cells), even-aligned start
-                        int s0 = 0, len = 0;
-                        if (inseg) {
-                            int lo, hi;
-                            if (ncs <= 72) { lo = (int)(csl[mycl] - tb); hi = (int)(csl[mych] - tb); }
-                            else { lo = (int)(sd.cell_start[rowb + xa + mycl] - tb); hi = (int)(sd.cell_start[rowb + xa + mych] - tb); }
-                            lo = max(lo, 0); hi = min(hi, tn);
-                            s0 = lo & ~1;
-                            len = hi - s0;
-                        }
-                        const int lenc = min(len, AMAXLEN);
-                        // One sign bit per candidate: d = |x_i - x_j|^2 - thr^2 in packed fp32 FMAs,
-                        // shifted into a 32-bit word with v_alignbit (1 VALU per candidate).
-                        uint32_t wd[3] = {0u, 0u, 0u};
-#pragma unroll
-                        for (int gw = 0; gw < 3; gw++) {
-                            if (!__any(32 * gw < lenc)) break; // wave-uniform
-                            uint32_t mm = 0;
-                            int g8 = 0;
-                            for (; g8 < 4 && __any(32 * gw + 8 * g8 < lenc); g8++) {
-                                const float *tb0 = tile + (s0 + 32 * gw + 8 * g8); // one address, constant offsets below
-#pragma unroll
-                                for (int p = 0; p < 4; p++) {
-                                    const f2 X = *reinterpret_cast<const f2 *>(tb0 + 2 * p);
-                                    const f2 Y = *reinterpret_cast<const f2 *>(tb0 + TS + 2 * p);
-                                    const f2 Z = *reinterpret_cast<const f2 *>(tb0 + 2 * TS + 2 * p);
-                                    const f2 ex = fx - X, ey = fy - Y, ez = fz - Z;
-                                    f2 nthr = {-hi2f, -hi2f};
-                                    if (!UH) {
-                                        const f2 W = *reinterpret_cast<const f2 *>(tb0 + 3 * TS + 2 * p);
-                                        nthr.x = -fmaxf(hi2f, W.x); // r2 < hi^2 or r2 < hj^2
-                                        nthr.y = -fmaxf(hi2f, W.y);
-                                    }
-                                    f2 d = __builtin_elementwise_fma(ex, ex, nthr);
-                                    d = __builtin_elementwise_fma(ey, ey, d);
-                                    d = __builtin_elementwise_fma(ez, ez, d);
-                                    mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.x), 31);
-                                    mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.y), 31);
-                                }
-                            }
-                            if (g8 < 4) mm <<= 8 * (4 - g8);
-                            mm = __builtin_bitreverse32(mm); // bit b <-> candidate 32*gw + b
-                            // candidates beyond this lane's range (its own tail / other lanes' longer ranges)
-                            const int rem = lenc - 32 * gw;
-                            wd[gw] = rem >= 32 ? mm : (rem > 0 ? (mm & ((1u << rem) - 1u)) : 0u);
-                        }
-                        const unsigned long long m0 = (unsigned long long)wd[0] | ((unsigned long long)wd[1] << 32);
-                        const uint32_t m1 = wd[2];
-                        mlo[nq][t] = m0;
-                        mhi[nq][t] = m1;
-                        mofs[nq][t] = (unsigned short)s0;
-                        if (t == 0) { qbase[nq] = sd.off + tb; qown[nq] = (dz == 0 && dy == 0); }
-                        // ---- rare: a lane's 3-cell range is longer than AMAXLEN -> exact tail, in place
-                        if (__any(len > AMAXLEN)) {
-                            for (int k = AMAXLEN; k < len; k++) do_pair(sd.off + tb + s0 + k, sd.flags);
-                        }
-                        nq++;
-                        if (nq == AQ) {
-                            __syncthreads(); // qbase visible
-                            phase2();
-                        }
-                    }
-                }
-            __syncthreads(); // qbase visible
-            phase2();
-        }
-    }
-    if (active) Fam::finish(D, a, o);
-}
-
 
 // ---------------------------------------------------------------------------
 // variant 6 (default): one WAVEFRONT per 64 consecutive cell-ordered
@@ -499,6 +278,8 @@ __global__ __launch_bounds__(ABS, Fam::MINB * 256 / ABS) void k_pair_agg(PairArg
 template <class Fam, int KK, bool UH, bool F32 = false, uint32_t CF = 0>
 __global__ __launch_bounds__(64, Fam::MINB) void k_pair_wave(PairArgs<Fam> a)
 {
+    typedef typename Fam::Real T; // arithmetic type of the pair loop
+    static_assert(F32 || sizeof(T) == 8, "fp32 arithmetic reads fp32 records");
     const uint32_t NR = (uint32_t)a.nrec;
     constexpr int TS = WCAP + 8;
     __shared__ __attribute__((aligned(16))) float tile[(UH ? 3 : 4) * TS];
@@ -518,15 +299,19 @@ __global__ __launch_bounds__(64, Fam::MINB) void k_pair_wave(PairArgs<Fam> a)
     const uint32_t ic = valid ? i : a.nd - 1;
     const uint32_t o = a.d_perm[ic];
     const bool active = valid && o >= a.d_start && o < a.d_stop;
-    double4 pi;
+    real4<T> pi;
     typename Fam::Dest D;
+    // one record: fp32 records for Real = float (and for record_f32), else fp64
+    auto fetch = [&](uint32_t jg, uint32_t flags, real4<T> &pj, T (&sj)[Fam::NA]) {
+        if constexpr (F32) load_record_f32<Fam, T>(reinterpret_cast<const float *>(a.rec) + (unsigned long long)jg * NR, pj, sj);
+        else load_record<Fam, UH>(a.rec + (unsigned long long)jg * NR, flags, pj, sj);
+    };
     {
-        double sd_[Fam::NA];
+        T sd_[Fam::NA];
         // the destination's own h / p come with the same rules as a source's
         // (uniform h: the constant; p only for the tensile correction)
-        if (F32) load_record_f32<Fam>(reinterpret_cast<const float *>(a.rec) + (size_t)(a.d_off + ic) * NR, pi, sd_);
-        else load_record<Fam, UH>(a.rec + (size_t)(a.d_off + ic) * NR, a.dflags, pi, sd_);
-        if (UH) pi.w = a.hu;
+        fetch(a.d_off + ic, a.dflags, pi, sd_);
+        if (UH) pi.w = (T)a.hu;
         Fam::load(D, sd_, a, o);
     }
     const uint32_t fkey = a.d_fkeys[ic];
@@ -535,20 +320,19 @@ __global__ __launch_bounds__(64, Fam::MINB) void k_pair_wave(PairArgs<Fam> a)
     const int row = key / ncx;
     const int cx = (int)(key % ncx) * SPH_NSUB + (int)(fkey % SPH_NSUB); // x sub-bin along the row
     const int nfx = ncx * SPH_NSUB;
-    const double hi_r = a.radius_scale * pi.w;
-    const double hi2 = UH ? a.hr2u : hi_r * hi_r;
+    const T hi_r = (T)a.radius_scale * pi.w;
+    const T hi2 = UH ? (T)a.hr2u : hi_r * hi_r;
     const int row_first = __builtin_amdgcn_readfirstlane(row), row_last = __builtin_amdgcn_readlane(row, 63);
 
     // exact criterion + pair arithmetic for one candidate record (branching form)
     auto do_pair = [&](uint32_t jg, uint32_t flags) {
-        double4 pj;
-        double sj[Fam::NA];
-        if (F32) load_record_f32<Fam>(reinterpret_cast<const float *>(a.rec) + (unsigned long long)jg * NR, pj, sj);
-        else load_record<Fam, UH>(a.rec + (unsigned long long)jg * NR, flags, pj, sj);
-        pin_record<Fam::NA>(pj, sj);
-        double hj2 = hi2;
-        if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
-        const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+        real4<T> pj;
+        T sj[Fam::NA];
+        fetch(jg, flags, pj, sj);
+        pin_record<Fam::NA, T>(pj, sj);
+        T hj2 = hi2;
+        if (!UH) { hj2 = (T)a.radius_scale * pj.w; hj2 *= hj2; }
+        const T r2 = r2_exact<T>(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
         if (((r2 < hi2) || (r2 < hj2)) && a.ablate != 1) Fam::template pair<KK, UH>(D, pi, pj, r2, sj, flags, a);
     };
 
@@ -567,13 +351,12 @@ __global__ __launch_bounds__(64, Fam::MINB) void k_pair_wave(PairArgs<Fam> a)
                 if (m == 0 && q + 1 < cq) { ++q; m = smask[q][t]; jb = sjb[q][t]; }
                 if (a.ablate == 3) j = self;
                 if constexpr (Fam::PRED) {
-                    double4 pj;
-                    double sj[Fam::NA];
-                    if (F32) load_record_f32<Fam>(reinterpret_cast<const float *>(a.rec) + (unsigned long long)j * NR, pj, sj);
-                    else load_record<Fam, UH>(a.rec + (unsigned long long)j * NR, flags, pj, sj);
-                    double hj2 = hi2;
-                    if (!UH) { hj2 = a.radius_scale * pj.w; hj2 *= hj2; }
-                    const double r2 = r2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+                    real4<T> pj;
+                    T sj[Fam::NA];
+                    fetch(j, flags, pj, sj);
+                    T hj2 = hi2;
+                    if (!UH) { hj2 = (T)a.radius_scale * pj.w; hj2 *= hj2; }
+                    const T r2 = r2_exact<T>(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
                     const bool pass = has && ((r2 < hi2) || (r2 < hj2)) && a.ablate != 1;
                     Fam::template pair<KK, UH>(D, pi, pj, r2, sj, flags, a, pass);
                 } else {

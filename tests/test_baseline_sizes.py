@@ -83,3 +83,17 @@ def test_elastic_2m_vs_oracle():
     assert n == 126 ** 3
     assert res['parity_neighbour_count_mismatches'] == 0, res
     assert res['parity_max_rel'] < 1e-10, res
+
+
+def test_elastic_2m_fp32_vs_oracle():
+    """BASELINE config 5 as named: the elastic equation set, 126^3 = 2.0 M
+    particles, fp32 arithmetic -- against the fp64 oracle at the fp32 tolerance
+    (see tests/test_hip_parity.py::test_fp32_arithmetic_vs_golden)."""
+    res, n, _ = _case(['--workload', 'elastic', '--n1', '126', '--dtype', 'f32'])
+    assert n == 126 ** 3
+    assert 1e-9 < res['parity_max_rel'] < 5e-5, res
+
+
+def test_cube_4m_fp32_vs_oracle():
+    res, n, _ = _case(['--n1', '159', '--dtype', 'f32'])
+    assert 1e-9 < res['parity_max_rel'] < 5e-5, res
