@@ -218,6 +218,12 @@ def build_workload(args, rank, world):
         # p = p0 (rho / rho0 - 1) is left out: on the lattice rho = rho0 to 1e-15,
         # p is pure cancellation noise with no scale of its own; rho and V carry it
         w.fields = ('rho', 'V', 'au', 'av', 'aw', 'auhat', 'avhat', 'awhat')
+        if args.dtype == 'f32':
+            # the background-pressure sum (auhat) is ~113 terms of magnitude 3e4
+            # that cancel to zero on the lattice: fp32 (as in the reference's own
+            # fp32 GPU backends) leaves rounding noise of order 0.1 there -- a
+            # property of the formulation in fp32, not comparable at any tolerance
+            w.fields = ('rho', 'V', 'au', 'av', 'aw')
     else:
         from pysph_amd.solid_mech import ElasticSolidsScheme
         if world > 1:
@@ -509,12 +515,17 @@ def setup(args, w, rank, world, dist, ctx):
                    sync=False, domain=domain)
     a_eval.set_nnps(nnps)
     ordered = False
-    if not args.no_reorder and domain is None and halo is None:
+    if not args.no_reorder:
         # what the reference's Solver does for its GPU backends before the first
         # step and every 50 steps (solver.py:296-302, application.py:1157-1161):
-        # put the particles in cell order so gathers/scatters coalesce
+        # put the particles in cell order so gathers/scatters coalesce (ghosts
+        # are dropped for it and rebuilt by the first step)
         for i in range(len(w.arrays)):
             nnps.spatially_order_particles(i)
+            if domain is not None:
+                nnps.update_domain()
+            elif halo is not None:
+                halo.exchange()
             nnps.update()
         ordered = True
 

@@ -1,34 +1,50 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for one round on the GPU box (run from the repo
-# root through gpurun):   bash profiles/collect.sh r01
-# Pass 1: kernel trace + stats.  Passes 2..n: one PMC counter set per run
-# (--pmc with --kernel-trace only, as the pool requires).  Raw output goes to
-# gpurun_out/<tag>/; profiles/summarize.py condenses it into profiles/.
+# root through gpurun):   bash profiles/collect.sh r02 [bench args...]
+#   gpurun_out/<tag>/<workload>/stats/...  kernel trace + stats of `python bench.py <args>`
+#   gpurun_out/<tag>/<workload>/pmc_<set>  one PMC counter set per run (--pmc with
+#                                          --kernel-trace only, as the pool requires)
+# profiles/summarize.py condenses the raw CSVs into profiles/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}; shift || true
 ROOT=$(pwd)
-OUT=$ROOT/gpurun_out/$TAG
-mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 cd /tmp
-python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o runc -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/stats.log" 2>&1
-for SET in "FETCH_SIZE" "WRITE_SIZE" \
-           "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU" \
-           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" \
-           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
-           "GRBM_GUI_ACTIVE TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum" \
-           "TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum" \
-           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCC_REQ_sum"; do
-    NAME=$(echo $SET | cut -d' ' -f1)
-    timeout 600 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/pmc_$NAME" -o runc -- $BENCH > "$OUT/pmc_$NAME.log" 2>&1
-    echo "$NAME rc=$?" >> "$OUT/passes.log"
-done
-find "$OUT" -name "*_agent_info.csv" -delete
-# counter CSVs of every kernel of every launch are large; keep the pair/pack/nnps kernels only
-for f in $(find "$OUT" -name "*_counter_collection.csv"); do
-    (head -1 "$f"; grep -E "k_pair|k_pack|k_nosrc|k_cell_keys|k_cell_start" "$f") > "$f.tmp" && mv "$f.tmp" "$f"
-done
-find "$OUT" -name "*_kernel_trace.csv" -path "*pmc_*" -delete
-du -sh "$OUT"
+run_one() {   # name, pmc (0/1), bench args...
+    local NAME=$1 PMC=$2; shift 2
+    local OUT=$ROOT/gpurun_out/$TAG/$NAME
+    mkdir -p "$OUT"
+    local BENCH="python $ROOT/bench.py --no-cpu-baseline --no-check --no-extras $*"
+    $BENCH --steps 10 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o runc -- $BENCH --steps 10 --warmup 3 > "$OUT/stats.log" 2>&1
+    if [ "$PMC" = 1 ]; then
+        for SET in "FETCH_SIZE" "WRITE_SIZE" \
+                   "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU" \
+                   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" \
+                   "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
+                   "GRBM_GUI_ACTIVE TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum" \
+                   "TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum" \
+                   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCC_REQ_sum"; do
+            local N=$(echo $SET | cut -d' ' -f1)
+            timeout 600 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/pmc_$N" -o runc -- $BENCH --steps 3 --warmup 1 > "$OUT/pmc_$N.log" 2>&1
+            echo "$N rc=$?" >> "$OUT/passes.log"
+        done
+    fi
+    find "$OUT" -name "*_agent_info.csv" -delete
+    # counter CSVs of every kernel of every launch are large; keep the hot kernels only
+    for f in $(find "$OUT" -name "*_counter_collection.csv"); do
+        (head -1 "$f"; grep -E "k_pair|k_pack|k_nosrc|k_cell_keys|k_cell_start" "$f") > "$f.tmp" && mv "$f.tmp" "$f"
+    done
+    find "$OUT" -name "*_kernel_trace.csv" -path "*pmc_*" -delete
+}
+if [ $# -gt 0 ]; then
+    run_one custom 1 "$@"
+else
+    run_one cube 1
+    run_one cube_f32 0 --dtype f32
+    run_one taylor_green 0 --workload taylor_green
+    run_one elastic 0 --workload elastic --n1 126
+    run_one elastic_f32 0 --workload elastic --n1 126 --dtype f32
+    run_one dam_break 0 --workload dam_break
+fi
+du -sh "$ROOT/gpurun_out/$TAG"

@@ -176,8 +176,18 @@ class HipNNPS(object):
         device-resident properties are permuted in place.  As in the reference
         (solver.py:296-302) the caller must ``update()`` afterwards."""
         if not self.sync:
-            dev._check(self.lib.sph_nnps_reorder_array(
-                self.ctx._h, self.helpers[pa_index].array_id))
+            h = self.helpers[pa_index]
+            if h.get_number_of_particles() != h.get_number_of_particles(True):
+                # device ghosts (periodic images, remote halo) are transient and
+                # must stay behind the real particles: drop them, bin the real
+                # particles alone, permute; the caller's update_domain() /
+                # halo exchange rebuilds the ghosts in the new order
+                for g in self.helpers:
+                    nreal = g.get_number_of_particles(True)
+                    dev._check(self.lib.sph_array_resize(self.ctx._h, g.array_id,
+                                                         nreal, nreal))
+                self.update()
+            dev._check(self.lib.sph_nnps_reorder_array(self.ctx._h, h.array_id))
             self._csr_key = None
             return
         pa = self.particles[pa_index]
