@@ -1,38 +1,62 @@
 #!/usr/bin/env python
 """Condense gpurun_out/<tag>/ (written by profiles/collect.sh) into the tracked
-summaries:  profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc_summary.json and
-profiles/pmc_traffic.json (the number bench.py quotes as roofline.traffic).
+summaries:
 
-    python profiles/summarize.py r01
+    profiles/<tag>_<workload>_kernel_stats.csv   rocprofv3 --kernel-trace --stats (top kernels)
+    profiles/<tag>_pmc_summary.json              per-launch means of every PMC pass (cube workload),
+                                                 FETCH/WRITE calibration, derived HBM traffic
+    profiles/<tag>_bench_lines.json              the bench line of every profiled workload (same box)
+    profiles/pmc_traffic.json                    the number bench.py quotes as roofline.traffic
+
+    python profiles/summarize.py r02
 """
 import csv
 import glob
 import json
 import os
-import shutil
 import sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 here = os.path.dirname(os.path.abspath(__file__))
 raw = os.path.join(os.path.dirname(here), 'gpurun_out', tag)
 
-KERNELS = ('k_pair_agg', 'k_pack', 'k_nosrc', 'k_cell_keys', 'k_cell_start')
+KERNELS = ('k_pair_wave', 'k_pack', 'k_nosrc', 'k_cell_keys', 'k_cell_start')
 
 
 def short(name):
     for k in KERNELS:
         if k in name:
+            if k == 'k_pair_wave':
+                fam = name.split('<')[1].split(',')[0].replace('_T', '')
+                return 'k_pair_wave<%s>' % fam
             return k
     return None
 
 
-stats = glob.glob(os.path.join(raw, 'stats', '**', '*_kernel_stats.csv'), recursive=True)
-if stats:
-    shutil.copy(stats[0], os.path.join(here, '%s_kernel_stats.csv' % tag))
+lines = {}
+for wdir in sorted(glob.glob(os.path.join(raw, '*'))):
+    w = os.path.basename(wdir)
+    if not os.path.isdir(wdir):
+        continue
+    stats = glob.glob(os.path.join(wdir, 'stats', '**', '*_kernel_stats.csv'), recursive=True)
+    if stats:
+        rows = list(csv.DictReader(open(stats[0])))
+        with open(os.path.join(here, '%s_%s_kernel_stats.csv' % (tag, w)), 'w') as f:
+            wr = csv.writer(f)
+            wr.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'MinNs', 'MaxNs', 'Percentage'])
+            for r in rows[:14]:
+                wr.writerow([r['Name'][:160], r['Calls'], r['TotalDurationNs'], r['AverageNs'],
+                             r['MinNs'], r['MaxNs'], r['Percentage']])
+    try:
+        lines[w] = json.loads(open(os.path.join(wdir, 'bench.json')).read().strip().splitlines()[-1])
+    except Exception:
+        pass
+json.dump(lines, open(os.path.join(here, '%s_bench_lines.json' % tag), 'w'), indent=1)
 
+cube = os.path.join(raw, 'cube')
 per = defaultdict(lambda: defaultdict(list))
-for f in glob.glob(os.path.join(raw, 'pmc_*', '**', '*_counter_collection.csv'), recursive=True):
+for f in glob.glob(os.path.join(cube, 'pmc_*', '**', '*_counter_collection.csv'), recursive=True):
     acc = defaultdict(float)          # (dispatch, kernel, counter) -> value
     for r in csv.DictReader(open(f)):
         k = short(r['Kernel_Name'])
@@ -42,41 +66,60 @@ for f in glob.glob(os.path.join(raw, 'pmc_*', '**', '*_counter_collection.csv'),
         per[k][c].append(v)
 mean = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in per.items()}
 
-bench = json.loads(open(os.path.join(raw, 'bench.json')).read().strip().splitlines()[-1])
-n = bench['config']['particles_per_gpu']
+bench = lines.get('cube', {})
+n = bench.get('config', {}).get('particles_per_gpu', 0)
 out = {
     'command': 'bash profiles/collect.sh %s  (rocprofv3 --pmc <one set> --kernel-trace '
-               '--output-format csv -- python bench.py --steps 3 --warmup 1 '
-               '--no-cpu-baseline; one pass per counter set)' % tag,
+               '--output-format csv -- python bench.py --no-cpu-baseline --no-check --no-extras '
+               '--steps 3 --warmup 1; one pass per counter set)' % tag,
     'particles': n,
     'bench_line_same_box': bench,
     'per_launch_mean': mean,
 }
 cal = {}
 KiB = 1024.0
-if 'k_nosrc' in mean and 'FETCH_SIZE' in mean['k_nosrc']:
+if n and 'k_nosrc' in mean and 'FETCH_SIZE' in mean['k_nosrc']:
     cal['k_nosrc_fetch_B_per_particle (reads 8)'] = mean['k_nosrc']['FETCH_SIZE'] * KiB / n
     cal['k_nosrc_write_B_per_particle (writes 16)'] = mean['k_nosrc']['WRITE_SIZE'] * KiB / n
-if 'k_cell_keys' in mean and 'FETCH_SIZE' in mean['k_cell_keys']:
+if n and 'k_cell_keys' in mean and 'FETCH_SIZE' in mean['k_cell_keys']:
     cal['k_cell_keys_fetch_B_per_particle (reads 24)'] = mean['k_cell_keys']['FETCH_SIZE'] * KiB / n
     cal['k_cell_keys_write_B_per_particle (writes 8)'] = mean['k_cell_keys']['WRITE_SIZE'] * KiB / n
 out['calibration'] = cal
-pa = mean.get('k_pair_agg', {})
-if 'FETCH_SIZE' in pa and 'WRITE_SIZE' in pa:
-    fetch = pa['FETCH_SIZE'] * KiB * 2.0      # gfx950: FETCH_SIZE reports 1/2 (guide + calibration above)
-    write = pa['WRITE_SIZE'] * KiB
-    out['k_pair_agg_traffic'] = {
-        'fetch_bytes_corrected': fetch, 'write_bytes': write,
-        'bytes_per_launch': fetch + write,
-        'bytes_per_particle': (fetch + write) / n,
-        'algorithmic_bytes_per_particle': 160.0,
-    }
-    if 'TCC_HIT_sum' in pa:
-        out['k_pair_agg_traffic']['l2_hit_rate'] = pa['TCC_HIT_sum'] / (pa['TCC_HIT_sum'] + pa['TCC_MISS_sum'])
-    json.dump({'config': {'n1': round(n ** (1 / 3.0)), 'variant': bench['config']['pair_variant'],
-                          'spatially_ordered': bench['config']['spatially_ordered']},
+pk = [k for k in mean if k.startswith('k_pair_wave')]
+if n and pk and 'FETCH_SIZE' in mean[pk[0]]:
+    m = mean[pk[0]]
+    # gfx950: FETCH_SIZE reports half of wide coalesced reads (MI355X_MICROARCH.md, HBM
+    # section; reproduced by the calibration kernels above), WRITE_SIZE is exact
+    fetch = m['FETCH_SIZE'] * KiB * 2.0
+    write = m['WRITE_SIZE'] * KiB
+    tr = {'kernel': pk[0], 'fetch_bytes_corrected': fetch, 'write_bytes': write,
+          'bytes_per_launch': fetch + write, 'bytes_per_particle': (fetch + write) / n,
+          'algorithmic_bytes_per_particle': 160.0}
+    if 'TCC_HIT_sum' in m:
+        tr['l2_hit_rate'] = m['TCC_HIT_sum'] / (m['TCC_HIT_sum'] + m['TCC_MISS_sum'])
+    if 'GRBM_GUI_ACTIVE' in m:
+        cyc = m['GRBM_GUI_ACTIVE'] / 8.0          # summed over the 8 XCDs
+        tr['kernel_cycles_per_xcd'] = cyc
+        if 'SQ_ACTIVE_INST_VALU' in m:
+            tr['valu_busy'] = m['SQ_ACTIVE_INST_VALU'] * 4.0 / (cyc * 1024.0)
+        if 'TA_BUSY_avr' in m:
+            tr['ta_busy'] = m['TA_BUSY_avr'] / cyc
+        if 'TCP_TOTAL_CACHE_ACCESSES_sum' in m:
+            tr['tcp_accesses_per_cu_cycle'] = m['TCP_TOTAL_CACHE_ACCESSES_sum'] / 256.0 / cyc
+        if 'TCP_READ_TAGCONFLICT_STALL_CYCLES_sum' in m:
+            tr['tcp_tagconflict_stall_frac'] = m['TCP_READ_TAGCONFLICT_STALL_CYCLES_sum'] / 256.0 / cyc
+    if 'SQ_INSTS_VALU' in m and 'SQ_WAVES' in m:
+        tr['valu_insts_per_wave'] = m['SQ_INSTS_VALU'] / m['SQ_WAVES']
+        tr['vmem_rd_per_wave'] = m['SQ_INSTS_VMEM_RD'] / m['SQ_WAVES']
+    out['pair_kernel'] = tr
+    json.dump({'config': {'n1': 159, 'variant': bench['config']['pair_variant'],
+                          'spatially_ordered': bench['config']['spatially_ordered'],
+                          'workload': 'cube', 'dtype': bench.get('dtype', 'f64')},
                'bytes_per_launch': fetch + write,
-               'source': 'profiles/%s_pmc_summary.json' % tag},
+               'source': 'profiles/%s_pmc_summary.json: FETCH_SIZE x 2 + WRITE_SIZE of separate '
+                         'rocprofv3 --pmc passes of this command on another box, not measured in '
+                         'this run' % tag},
               open(os.path.join(here, 'pmc_traffic.json'), 'w'), indent=1)
 json.dump(out, open(os.path.join(here, '%s_pmc_summary.json' % tag), 'w'), indent=1)
-print(json.dumps({k: v for k, v in out.items() if k != 'per_launch_mean'}, indent=1)[:3000])
+print(json.dumps(out.get('pair_kernel', {}), indent=1))
+print(json.dumps(cal, indent=1))

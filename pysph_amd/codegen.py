@@ -1426,7 +1426,7 @@ class GeneratedFamily(object):
         A('        hipLaunchKernelGGL(k_gen_nosrc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);')
         A('    } else {')
         A('        if (g->nrec != (g->rec_f32 ? ((4 + FamGen::NA + 3) & ~3) : g->uniform_h ? %d : FamGen::NR)) return -1002;' % nrc)
-        A('        dim3 grid(4 * ((a.nd + 255) / 256)), block(64);')
+        A('        dim3 grid(4 * ((a.nd + 255) / 256) / WPB), block(64 * WPB);')
         A('        if (g->rec_f32 && g->uniform_h) hipLaunchKernelGGL((k_pair_wave<FamGen, %d, true, true>), grid, block, 0, st, a);' % self.kernel_kind)
         A('        else if (g->rec_f32) hipLaunchKernelGGL((k_pair_wave<FamGen, %d, false, true>), grid, block, 0, st, a);' % self.kernel_kind)
         A('        else if (g->uniform_h) hipLaunchKernelGGL((k_pair_wave<FamGen, %d, true>), grid, block, 0, st, a);' % self.kernel_kind)

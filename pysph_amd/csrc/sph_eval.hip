@@ -928,7 +928,7 @@ template <class Fam> static int launch_pair(sph_ctx *c, int kk, const PairArgs<F
     const bool uh = c->uniform_h && c->use_uniform_h;
     constexpr bool FP32 = sizeof(typename Fam::Real) == 4;
     if (c->pair_variant == 6) {
-        dim3 g2(4 * div_up(a.nd, 256)), b2(64);
+        dim3 g2(4 * div_up(a.nd, 256) / WPB), b2(64 * WPB);
         // equation flags as a compile-time constant when every source carries the same set
         uint32_t cf = a.src[0].flags;
         for (int j = 1; j < a.nsrc; j++) if (a.src[j].flags != cf) cf = 0;

@@ -275,22 +275,34 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define XWIN (SPH_NSUB + 1) // a lane's candidate window: its own x sub-bin +- XWIN (one bin of slack for the
                             // rounding of the sub-bin index: |x_j - x_i| < cell_size spans at most SPH_NSUB bins exactly)
 
+#ifndef WPB
+#define WPB 1       // wavefronts per workgroup.  There are no barriers, so any value works; 4 (x-adjacent tiles on one
+                    // CU, sharing gathered lines in its L1) measured 1 % faster on the uniform-h cube but loses a
+                    // workgroup of occupancy to LDS granularity with variable h (4 x 10.7 KB > 40 KB)
+#endif
+
 template <class Fam, int KK, bool UH, bool F32 = false, uint32_t CF = 0>
-__global__ __launch_bounds__(64, Fam::MINB) void k_pair_wave(PairArgs<Fam> a)
+__global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam> a)
 {
     typedef typename Fam::Real T; // arithmetic type of the pair loop
     static_assert(F32 || sizeof(T) == 8, "fp32 arithmetic reads fp32 records");
     const uint32_t NR = (uint32_t)a.nrec;
     constexpr int TS = WCAP + 8;
-    __shared__ __attribute__((aligned(16))) float tile[(UH ? 3 : 4) * TS];
+    // every wavefront of the workgroup has its own LDS areas
+    __shared__ __attribute__((aligned(16))) float tile_[WPB][(UH ? 3 : 4) * TS];
+    __shared__ unsigned short csl_[WPB][WCSL];
+    __shared__ unsigned long long smask_[WPB][WLQ][64];
+    __shared__ uint32_t sjb_[WPB][WLQ][64];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float *const tile = tile_[wv];
     float *const tx = tile, *const ty = tile + TS, *const tz = tile + 2 * TS, *const tw = tile + (UH ? 0 : 3 * TS);
-    __shared__ unsigned short csl[WCSL];
-    __shared__ unsigned long long smask[WLQ][64];
-    __shared__ uint32_t sjb[WLQ][64];
+    unsigned short *const csl = csl_[wv];
+    unsigned long long (*const smask)[64] = smask_[wv];
+    uint32_t (*const sjb)[64] = sjb_[wv];
 
-    const int t = threadIdx.x; // = lane
+    const int t = threadIdx.x & 63; // lane
     // 64-destination wave tiles inside the 256-destination tiles of the traversal order
-    const uint32_t wt = xcd_tile(blockIdx.x, gridDim.x);
+    const uint32_t wt = xcd_tile(blockIdx.x, gridDim.x) * WPB + (uint32_t)wv;
     uint32_t dtile = wt >> 2;
     if (a.d_tile_order) dtile = a.d_tile_order[dtile];
     const uint32_t i = dtile * 256u + (wt & 3u) * 64u + t;
@@ -367,6 +379,12 @@ __global__ __launch_bounds__(64, Fam::MINB) void k_pair_wave(PairArgs<Fam> a)
         cq = 0;
     };
 
+    // Sources outermost: a wavefront whose 64 destinations straddle a row
+    // boundary does phase 1 once per row segment (only that segment's lanes
+    // build masks) but ONE phase 2 per source for all its lanes together.
+    for (int s = 0; s < a.nsrc; s++) {
+    const SrcDesc sd = a.src[s];
+    const uint32_t fl = CF ? CF : sd.flags;
     for (int R = row_first; R <= row_last; R++) {
         if (a.ablate == 6) break; // profiling: prologue + finish only
         const bool inseg = active && row == R;
@@ -394,9 +412,7 @@ __global__ __launch_bounds__(64, Fam::MINB) void k_pair_wave(PairArgs<Fam> a)
         const float hi2f = hif * hif;
         const int mycl = max(cx - XWIN, xa) - xa, mych = min(cx + XWIN, xb) + 1 - xa;
 
-        for (int s = 0; s < a.nsrc; s++) {
-            const SrcDesc sd = a.src[s];
-            const uint32_t fl = CF ? CF : sd.flags;
+        {
             for (int dz = -1; dz <= 1; dz++)
                 for (int dy = -1; dy <= 1; dy++) {
                     const int yy = cyR + dy, zz = czR + dz;
@@ -480,8 +496,9 @@ __global__ __launch_bounds__(64, Fam::MINB) void k_pair_wave(PairArgs<Fam> a)
                         }
                     }
                 }
-            phase2(fl);
         }
+    }
+    phase2(fl);
     }
     if (active) Fam::finish(D, a, o);
 }

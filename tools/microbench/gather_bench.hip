@@ -10,6 +10,7 @@
 //        1: quad cooperative: 4 lanes load the 4 pieces of ONE record (4 instr serve 4 records), rest per lane
 //        2: as 0 through raw buffer loads with cache-policy bits AUX (1 sc0, 2 nt, 16 sc1)
 //        4: records in LDS, random per-lane ds_read_b128
+//        6/7/8: as 0, but the 4 lanes of a quad / 8 / 16 adjacent lanes gather the SAME record
 // PATTERN 0: record index uniformly random in the wave's window of W records
 //         1: sliding front: lane + 4*step + rnd(36), a new "row" every 10 steps
 //            (neighbouring lanes touch neighbouring records, like the pair kernel)
@@ -52,7 +53,10 @@ __global__ __launch_bounds__(256, 4) void k_gather(Args a)
             const uint32_t row = (uint32_t)it / 10u;
             j = (wbase + row * 1531u + lane + 4u * ((uint32_t)it % 10u) + (uint32_t)(((uint64_t)lcg(s) * 36u) >> 24)) % a.ntab;
         }
-        if (MODE == 0) {
+        if (MODE == 6) j = __shfl(j, lane & ~3, 64);
+        if (MODE == 7) j = __shfl(j, lane & ~7, 64);
+        if (MODE == 8) j = __shfl(j, lane & ~15, 64);
+        if (MODE == 0 || MODE >= 6) {
 #pragma unroll
             for (int q = 0; q < NP; q++) acc += a.rec[idx(j, q)];
         } else if (MODE == 2) {
@@ -117,6 +121,10 @@ int main()
             if (pat == 1 && W != 1024u) continue;
             printf("---- pattern %d window %u\n", pat, W);
             run<0, 5, 0, 0>("aos80", 5, nt, W, pat);
+            run<6, 5, 0, 0>("aos80 quad-same", 5, nt, W, pat);
+            run<7, 5, 0, 0>("aos80 oct-same", 5, nt, W, pat);
+            run<8, 5, 0, 0>("aos80 16-same", 5, nt, W, pat);
+            run<6, 3, 0, 0>("aos48 quad-same", 3, nt, W, pat);
             run<0, 5, 0, 0>("aos128", 8, nt, W, pat);
             run<0, 4, 0, 0>("aos64", 4, nt, W, pat);
             run<0, 3, 0, 0>("aos48", 3, nt, W, pat);
