@@ -133,7 +133,7 @@ int sph_ctx_destroy(sph_ctx *c)
     }
     for (auto &H : c->halo)
         for (int s = 0; s < 2; s++) { H.flag[s].release(); H.pos[s].release(); H.list[s].release(); }
-    for (DevBuf *b : {&c->gapq, &c->cub_tmp, &c->red_part, &c->red_out, &c->posh, &c->aux, &c->fposb, &c->dkeys, &c->dperm,
+    for (DevBuf *b : {&c->dbgc, &c->gapq, &c->cub_tmp, &c->red_part, &c->red_out, &c->posh, &c->aux, &c->fposb, &c->dkeys, &c->dperm,
                       &c->tmp_u32a, &c->tmp_u32b, &c->gen_state})
         b->release();
     for (auto &b : c->csr_start) b.release();
@@ -260,6 +260,17 @@ int sph_set_option(sph_ctx *c, const char *key, long value)
         c->tile_block_rows = value; c->nnps_valid = false; return SPH_OK;
     }
     if (strcmp(key, "ablate") == 0) { c->ablate = value; return SPH_OK; }
+    if (strcmp(key, "count_iters") == 0) {
+        c->count_iters = value;
+        if (value) { SPH_TRY(c->dbgc.reserve(64)); HIP_TRY(hipMemset(c->dbgc.ptr, 0, 64)); }
+        return SPH_OK;
+    }
+    if (strcmp(key, "dump_counters") == 0) {
+        unsigned long long h[4] = {};
+        if (c->dbgc.ptr) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipMemcpy(h, c->dbgc.ptr, 32, hipMemcpyDeviceToHost)); }
+        fprintf(stderr, "pair kernel counters: phase-2 iterations %llu, phase-2 calls %llu, wavefronts %llu, row tiles %llu\n", h[0], h[1], h[2], h[3]);
+        return SPH_OK;
+    }
     if (strcmp(key, "const_flags") == 0) { c->const_flags = value; return SPH_OK; }
     if (strcmp(key, "invalidate_nnps") == 0) { c->nnps_valid = false; return SPH_OK; }
     sph_set_error("sph_set_option: unknown key '%s'", key);

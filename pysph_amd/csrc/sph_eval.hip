@@ -988,6 +988,7 @@ static void fill_common(sph_ctx *c, PairArgs<Fam> &a, const sph_kernel *K, doubl
     a.t = t;
     a.dt = c->cur_dt;
     a.ablate = (int)c->ablate;
+    a.dbg = c->count_iters ? c->dbgc.as<unsigned long long>() : nullptr;
     // uniform-h constants, computed as the general path would per pair
     a.hu = 0.5 * (c->h_uniform + c->h_uniform);
     a.h1u = 1.0 / a.hu;

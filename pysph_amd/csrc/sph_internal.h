@@ -95,6 +95,8 @@ struct sph_ctx {
     // options
     long pair_variant = 6;
     long ablate = 0;
+    long count_iters = 0;   // profiling: the pair kernel counts its phase-2 iterations (option count_iters; dump_counters prints them)
+    DevBuf dbgc;
     long const_flags = 1;   // variant 6: compile-time equation flags when all sources agree (0: always run-time flags)
     long use_uniform_h = 1;
     long arith_f32 = 0;     // hand-written families compute in fp32 (fp32 records, fp32 accumulators; BASELINE config 5)

@@ -75,6 +75,7 @@ template <class Fam> struct PairArgs {
     double radius_scale;
     KernelConst k;
     uint32_t dflags; // union of the source flags
+    unsigned long long *dbg; // profiling only (option count_iters): [0] phase-2 iterations, [1] phase-2 calls, [2] wavefronts, [3] row tiles
     int ablate;      // profiling only: 1 = skip pair arithmetic, 2 = skip phase 2
     int skip_init;   // generated families: initialize() already ran in a launch of its own
     int skip_post;   // generated loop_all launch followed by a pair launch: post_loop runs there
@@ -269,8 +270,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 //   Measured on the 4 M cube against the 256-thread workgroup version of the
 //   same schedule (barriers around every shared row tile): see DESIGN.md.
 // ---------------------------------------------------------------------------
-#define WLQ 11      // slots per lane
-#define WCAP 120    // candidates per LDS tile piece
+#define WLQ 10      // slots per lane (9 rows of cells + one spare; a lane out of slots flushes its wavefront's phase 2 early)
+#define WCAP_UH 184 // candidates per LDS tile piece (a wavefront's row range is ~105 for WCSPH, ~125 for TVF);
+#define WCAP_VH 136 // variable h keeps a fourth plane (the candidates' own radii): same 2304 B
 #define WCSL 96     // fine_start entries of one row segment kept in LDS (16-bit, relative to the segment start)
 #define XWIN (SPH_NSUB + 1) // a lane's candidate window: its own x sub-bin +- XWIN (one bin of slack for the
                             // rounding of the sub-bin index: |x_j - x_i| < cell_size spans at most SPH_NSUB bins exactly)
@@ -287,6 +289,7 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     typedef typename Fam::Real T; // arithmetic type of the pair loop
     static_assert(F32 || sizeof(T) == 8, "fp32 arithmetic reads fp32 records");
     const uint32_t NR = (uint32_t)a.nrec;
+    constexpr int WCAP = UH ? WCAP_UH : WCAP_VH;
     constexpr int TS = WCAP + 8;
     // every wavefront of the workgroup has its own LDS areas
     __shared__ __attribute__((aligned(16))) float tile_[WPB][(UH ? 3 : 4) * TS];
@@ -335,6 +338,7 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     const T hi_r = (T)a.radius_scale * pi.w;
     const T hi2 = UH ? (T)a.hr2u : hi_r * hi_r;
     const int row_first = __builtin_amdgcn_readfirstlane(row), row_last = __builtin_amdgcn_readlane(row, 63);
+    if (a.dbg && t == 0) atomicAdd(a.dbg + 2, 1ull);
 
     // exact criterion + pair arithmetic for one candidate record (branching form)
     auto do_pair = [&](uint32_t jg, uint32_t flags) {
@@ -356,7 +360,9 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
         if (cq > 0 && a.ablate != 2) { m = smask[0][t]; jb = sjb[0][t]; }
         const uint32_t self = a.d_off + ic;
         if (__any(m != 0)) {
+            if (a.dbg && t == 0) atomicAdd(a.dbg + 1, 1ull);
             do {
+                if (a.dbg && t == 0) atomicAdd(a.dbg, 1ull);
                 const bool has = m != 0;
                 uint32_t j = has ? jb + (uint32_t)__builtin_ctzll(m) : self;
                 m &= m - 1;
@@ -422,8 +428,7 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
                     const bool csl_ok = ncs <= WCSL && j1 - j0 < 65536u;
                     for (uint32_t tb = j0; tb < j1; tb += WCAP) {
                         const int tn = (int)min((uint32_t)WCAP, j1 - tb);
-                        // room for this tile's (at most two) slots
-                        if (__any(cq > WLQ - 2)) phase2(fl);
+                        if (a.dbg && t == 0) atomicAdd(a.dbg + 3, 1ull);
                         if (csl_ok && tb == j0)
                             for (int q = t; q < ncs; q += 64) csl[q] = (unsigned short)(sd.fine_start[rowb + xa + q] - j0);
                         for (int k = t; k < tn + 8; k += 64) {
@@ -488,6 +493,8 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // tile reads before the next tile's writes
                         const unsigned long long m0 = (unsigned long long)wd[0] | ((unsigned long long)wd[1] << 32);
                         const uint32_t jb0 = sd.off + tb + (uint32_t)s0;
+                        // a lane without room for this tile's slots: the wavefront works its lists off first (rare)
+                        if (__any(cq + (m0 != 0) + (wd[2] != 0) > WLQ)) phase2(fl);
                         if (m0) { smask[cq][t] = m0; sjb[cq][t] = jb0; cq++; }
                         if (wd[2]) { smask[cq][t] = wd[2]; sjb[cq][t] = jb0 + 64u; cq++; }
                         // rare: a lane's range is longer than AMAXLEN -> exact tail, in place
