@@ -181,6 +181,7 @@ class HipContext(object):
         self.lib = load_library()
         self._h = _P()
         _check(self.lib.sph_ctx_create(device, stream, C.byref(self._h)))
+        self.stream = stream        # the caller's HIP stream handle, or None: the library made its own
         self.device = device
         self._ids = {}
 

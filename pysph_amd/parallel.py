@@ -92,16 +92,24 @@ class DeviceHaloOps(object):
                                  device=self.device)
 
     # -- ordering between this context's HIP stream and the transport -------
-    # The pack/append kernels run on the context's own stream; RCCL orders its
-    # work after (and `work.wait()` orders it before) torch's CURRENT stream
-    # only, which knows nothing about that stream.  Two host-side syncs per
-    # exchange (a few tens of microseconds against a multi-millisecond step).
+    # RCCL orders its work after (and `work.wait()` orders it before) torch's
+    # CURRENT stream.  When the context runs on that very stream (bench.py and
+    # the integrator pipeline create it that way) the pack kernels, the
+    # transfers and the append kernels are ordered by the stream itself and no
+    # host synchronisation is needed; a context with a stream of its own needs
+    # two host-side syncs per exchange.
+    def _shares_torch_stream(self):
+        cur = self.torch.cuda.current_stream(self.device).cuda_stream
+        return self.ctx.stream is not None and int(self.ctx.stream) == int(cur)
+
     def before_comm(self):
-        self.ctx.synchronize()          # payloads are complete before they are sent
+        if not self._shares_torch_stream():
+            self.ctx.synchronize()      # payloads are complete before they are sent
 
     def after_comm(self):
-        # the receives are complete before the append kernels read them
-        self.torch.cuda.current_stream(self.device).synchronize()
+        if not self._shares_torch_stream():
+            # the receives are complete before the append kernels read them
+            self.torch.cuda.current_stream(self.device).synchronize()
 
     def pack(self, side, count, shift):
         buf = self.new_buffer(count)
@@ -315,8 +323,66 @@ class SlabDecomposition(object):
         return sum(h.migrate() for h in self.halos)
 
     def exchange(self, drop=True):
-        for h in self.halos:
-            h.exchange(drop=drop)
+        """Ghost refresh of ALL arrays with one counts handshake and one batch of
+        point-to-point transfers (a dam break has three arrays: one all_gather
+        and one batch_isend_irecv instead of three of each)."""
+        hs = self.halos
+        if len(hs) == 1:
+            return hs[0].exchange(drop=drop)
+        h0 = hs[0]
+        nbrs = h0.neighbours()
+        dist, ops0 = self.dist, h0.ops
+        na = len(hs)
+        send = []
+        for h in hs:
+            if drop:
+                h.ops.drop_ghosts()
+            n_lo, n_hi = h.ops.select(h.lo + h.width, h.hi - h.width)
+            send.append({0: n_lo, 1: n_hi})
+        if not nbrs:
+            return
+        sides = [s for s, _, _ in nbrs]
+        for c in send:                  # nothing goes out through an open face
+            for s in (0, 1):
+                if s not in sides:
+                    c[s] = 0
+        out = [{s: h.ops.pack(s, c[s], shift) for s, _, shift in nbrs} for h, c in zip(hs, send)]
+        for h in hs:
+            sync = getattr(h.ops, 'before_comm', None)
+            if sync is not None:
+                sync()
+        mine = ops0.int_tensor([c[s] for c in send for s in (0, 1)])
+        allc = ops0.int_tensor([0] * (2 * na * self.world))
+        dist.all_gather_into_tensor(allc, mine)
+        allc = [int(v) for v in allc.cpu()]
+        # what peer sends to me: its hi list if it is my lo neighbour, else lo
+        recv = [{s: allc[2 * na * peer + 2 * a + (1 - s)] for s, peer, _ in nbrs} for a in range(na)]
+        inb = [{s: h.ops.new_buffer(recv[a][s], h.ops.nprops) for s, _, _ in nbrs}
+               for a, h in enumerate(hs)]
+        # between one pair of ranks messages match in posting order: sends hi-face
+        # first, receives lo-face first (periodic axis with <= 2 ranks: both faces
+        # talk to the same peer), arrays in the same order on both sides
+        reqs = []
+        for s, peer, _ in sorted(nbrs, key=lambda nb: -nb[0]):
+            for a in range(na):
+                if send[a][s]:
+                    reqs.append(dist.P2POp(dist.isend, out[a][s], peer))
+        for s, peer, _ in sorted(nbrs, key=lambda nb: nb[0]):
+            for a in range(na):
+                if recv[a][s]:
+                    reqs.append(dist.P2POp(dist.irecv, inb[a][s], peer))
+        if reqs:
+            for w in dist.batch_isend_irecv(reqs):
+                w.wait()
+        for h in hs:
+            sync = getattr(h.ops, 'after_comm', None)
+            if sync is not None:
+                sync()
+        for a, h in enumerate(hs):
+            for s, _, _ in nbrs:
+                if recv[a][s]:
+                    h.ops.append(inb[a][s], recv[a][s])
+            h.last_counts = (send[a][0], send[a][1], recv[a].get(0, 0), recv[a].get(1, 0))
 
     def update(self):
         self.migrate()

@@ -318,3 +318,51 @@ def test_neighbour_topology():
                     assert nb[0][2] == float(world)
                 if rank == world - 1:
                     assert nb[1][2] == -float(world)
+
+
+def _worker_fused(rank, world, port, periodic, out):
+    """SlabDecomposition.exchange() with TWO arrays: one counts handshake and one
+    batch of transfers for both; each array must receive exactly the ghosts the
+    per-array exchange gives it (same order: lo face first, ascending index)."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from test_hip_parity import make_cube
+        from pysph_amd.parallel import SlabDecomposition, SlabHalo
+        from pysph_amd.particle_array import ParticleArray
+        full, dx = make_cube(12)
+        x = full.x
+        lo, hi = (0.0, 0.5) if rank == 0 else (0.5, 1.0)
+        own = np.nonzero((x >= lo) & (x < hi))[0]
+        odd, even = own[own % 2 == 1], own[own % 2 == 0]
+
+        def make(idx, name):
+            return ParticleArray(name=name, **{k: v[idx].copy() for k, v in full.properties.items()})
+        width = 2.6 * dx
+        a, b = make(odd, 'a'), make(even, 'b')
+        a2, b2 = make(odd, 'a'), make(even, 'b')
+        dec = SlabDecomposition([a, b], None, rank, world, axis=0, width=width, lo=lo, hi=hi,
+                                periodic=periodic, period=1.0,
+                                ops_factory=lambda pa, ax, p: NumpyHaloOps(pa, ax), dist=dist)
+        dec.exchange()
+        dec.exchange()           # idempotent
+        for pa, ref in ((a, a2), (b, b2)):
+            h = SlabHalo(ref, None, rank, world, axis=0, width=width, lo=lo, hi=hi,
+                         periodic=periodic, period=1.0, ops=NumpyHaloOps(ref, 0), dist=dist)
+            h.exchange()
+            assert pa.get_number_of_particles() == ref.get_number_of_particles() > ref.get_number_of_particles(True)
+            for k in PROPS:
+                assert np.array_equal(pa.properties[k], ref.properties[k]), (pa.name, k)
+        np.save(out % rank, np.array([a.get_number_of_particles(), b.get_number_of_particles()]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('periodic', [False, True])
+def test_fused_two_array_exchange_equals_per_array(tmp_path, periodic):
+    port = 29600 + (os.getpid() % 200) + (7 if periodic else 0)
+    out = str(tmp_path / 'f%d.npy')
+    mp.spawn(_worker_fused, args=(2, port, periodic, out), nprocs=2, join=True)
+    n0, n1 = np.load(out % 0), np.load(out % 1)
+    assert n0.min() > 0 and n1.min() > 0
