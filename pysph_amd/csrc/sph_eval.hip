@@ -6,21 +6,24 @@
 // post_loop), with the destination/source regrouping of MegaGroup
 // (pysph/sph/acceleration_eval.py:94-162) done here on the host.
 //
-// Design (gfx950, fp64, no MFMA -- an irregular gather, not a contraction):
+// Design (gfx950, no MFMA -- an irregular gather, not a contraction):
 //   * every array taking part in a (dest, sources) block is gathered into
 //     cell order as packed records {x,y,z,h | equation-family aux} (+ a compact
 //     fp32 position array for the prefilter) -> all pair-loop reads are
-//     contiguous runs (a row of cells along x is one run);
+//     contiguous runs (a row of cells along x is one run, sorted along x to 1/8
+//     of a cell);
 //   * one fused kernel per destination does initialize + ALL sources + post_loop
 //     with the sums held in registers and ONE write per output, no atomics;
-//   * three schedules of the same arithmetic, selectable for cross-checking:
-//       variant 3 (default) k_pair_agg : aggregated two-phase kernel,
-//       variant 2           k_pair_wg  : row-by-row LDS record tiles,
-//       variant 0           k_pair_direct : plain per-lane 27-cell walk;
-//     (two further schedules were measured and dropped: 64-candidate LDS
-//     tiles per wavefront with per-pair gathers, and LDS-resident opposite
-//     row pairs -- see DESIGN.md section 4);
-//   * the exact fp64 criterion of the reference (r2 < (k h_i)^2 or r2 < (k h_j)^2,
+//   * two schedules of the same arithmetic:
+//       variant 6 (default) k_pair_wave   : one wavefront per 64 destinations,
+//                                           fp32 prefilter tiles in LDS, per-lane
+//                                           hit-mask slot lists (sph_pair.h),
+//       variant 0           k_pair_direct : plain per-lane 27-cell walk, the
+//                                           independent cross-check;
+//     (schedules measured and dropped: DESIGN.md section 4);
+//   * every family is a template on the arithmetic type: double (default) or
+//     float (option arith_f32);
+//   * the exact criterion of the reference (r2 < (k h_i)^2 or r2 < (k h_j)^2,
 //     linked_list_nnps.pyx:176-184) decides neighbourhood in every schedule;
 //     the fp32 test in front of it is a conservative superset filter.
 #include "sph_internal.h"
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
 template <class T> struct FamWCSPH_T {
     typedef T Real; // arithmetic type of the pair loop
     static constexpr uint32_t CF0 = F_CONT | F_MOM | F_XSPH; // flag set compiled as a constant (variant 6)
-    static constexpr int MINB = 4; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
+    static constexpr int MINB = 4; // wavefronts per SIMD the pair kernel is compiled for (VGPR budget)
     static constexpr int NA = 8; // u v w m rho tmpj(=p/rho^2) cs p
     static constexpr int NR = 12; // x y z h + NA (128-B padded records measured slower: larger L2 footprint)
     struct Params {
@@ -411,7 +414,7 @@ template <class T> struct FamDensity_T {
     typedef T Real; // arithmetic type of the pair loop
     static constexpr bool PRED = true; // see FamWCSPH
     static constexpr uint32_t CF0 = F_TVFSD; // flag set compiled as a constant (variant 6)
-    static constexpr int MINB = 4; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
+    static constexpr int MINB = 4; // wavefronts per SIMD the pair kernel is compiled for (VGPR budget)
     static constexpr int NA = 1; // m
     static constexpr int NR = 6;  // x y z h m pad
     struct Params { double *rho, *V; };
@@ -451,7 +454,7 @@ template <class T> struct FamTVF_T {
     typedef T Real; // arithmetic type of the pair loop
     static constexpr bool PRED = true; // see FamWCSPH
     static constexpr uint32_t CF0 = F_TP | F_TVISC | F_TAS; // flag set compiled as a constant (variant 6)
-    static constexpr int MINB = 3; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
+    static constexpr int MINB = 3; // wavefronts per SIMD the pair kernel is compiled for (VGPR budget)
     static constexpr int NA = 12; // u v w uhat vhat what rho p V m Vj2 pad
     static constexpr int NR = 16; // x y z h + NA
     struct Params {
@@ -551,7 +554,7 @@ template <class T> struct FamVGrad_T {
     typedef T Real; // arithmetic type of the pair loop
     static constexpr bool PRED = true; // see FamWCSPH
     static constexpr uint32_t CF0 = F_VG3; // flag set compiled as a constant (variant 6)
-    static constexpr int MINB = 4; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
+    static constexpr int MINB = 4; // wavefronts per SIMD the pair kernel is compiled for (VGPR budget)
     static constexpr int NA = 4; // u v w m/rho
     static constexpr int NR = 8;
     struct Params { double *v[9]; };
@@ -598,7 +601,7 @@ template <class T> struct FamElastic_T {
     typedef T Real; // arithmetic type of the pair loop
     static constexpr bool PRED = true; // see FamWCSPH
     static constexpr uint32_t CF0 = F_ECONT | F_ESTRESS | F_EAV | F_EXSPH; // flag set compiled as a constant (variant 6)
-    static constexpr int MINB = 2; // workgroups per CU the aggregated kernel is compiled for (VGPR budget)
+    static constexpr int MINB = 2; // wavefronts per SIMD the pair kernel is compiled for (VGPR budget)
     static constexpr int NA = 18; // u v w m rho cs | t00 t01 t02 t11 t12 t22 (= sigma/rho^2) | r00 r01 r02 r11 r12 r22
     static constexpr int NR = 22;
     struct Params {
