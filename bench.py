@@ -337,6 +337,8 @@ def parity_check(w, host_in, nnps, domain, tol=PARITY_TOL):
                 err = float(np.max(np.abs(a)))
             else:
                 err = float(np.max(np.abs(a - b)) / scale)
+            if not (np.all(np.isfinite(a)) and np.isfinite(err)):
+                err = 1e300             # a NaN never compares greater: make it the worst case
             if err > worst:
                 worst, worst_field = err, '%s.%s' % (pa.name, f)
     out = {'parity_max_rel': worst, 'parity_worst_field': worst_field,
@@ -404,6 +406,9 @@ def parse_args(argv=None):
     ap.add_argument('--no-check', action='store_true', help='skip the oracle parity check')
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary configurations')
     ap.add_argument('--cpu-n1', type=int, default=100)
+    ap.add_argument('--self-slab', action='store_true', dest='self_slab',
+                    help='taylor_green on ONE GPU through the N>1 code path: the periodic x axis '
+                         'is a slab whose two faces are exchanged with this rank itself over RCCL')
     return ap.parse_args(argv)
 
 
@@ -457,7 +462,7 @@ def main():
     dist = None
     # SPH_BENCH_FORCE_DIST=1: bring RCCL up even for one rank (checks the
     # process-group plumbing and the stdout ordering on a 1-GPU box)
-    if world > 1 or os.environ.get('SPH_BENCH_FORCE_DIST') == '1':
+    if world > 1 or args.self_slab or os.environ.get('SPH_BENCH_FORCE_DIST') == '1':
         import torch.distributed as dist
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -500,7 +505,7 @@ def setup(args, w, rank, world, dist, ctx):
     for a in w.arrays:
         dev.attach(a, ctx).push()       # everything resident in HBM
     halo = None
-    if world > 1:
+    if world > 1 or (args.self_slab and w.slab is not None and w.slab[2]):
         from pysph_amd.parallel import (SlabDecomposition, TVF_HALO_PROPS,
                                         WCSPH_HALO_PROPS)
         lo, hi, periodic, period = w.slab
@@ -654,7 +659,7 @@ def run(args, rank, local_rank, world, dist):
             'workload': w.name,
             'particles_per_gpu': n_local, 'pair_variant': args.variant,
             'spatially_ordered': ordered,
-            'parallelism': 'slab%d' % world if world > 1 else 'single',
+            'parallelism': 'slab%d' % world if world > 1 else ('slab1-self-exchange' if halo is not None else 'single'),
             'rccl_ranks': world if dist is not None else 0,
         },
         'roofline': {

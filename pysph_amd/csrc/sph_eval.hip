@@ -260,12 +260,12 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
                 if (2 * q < a.nr) r2[q] = make_double2(w[2 * q], w[2 * q + 1]);
             return;
         }
-        if (a.layout == 3) { // TVF under uniform h: [x y z rho | u v w p | Vj2 m uhat vhat | what -]
+        if (a.layout == 3) { // TVF under uniform h: [x y | z rho | u v | w p | Vj2 what | uhat vhat] (+ [m -] with artificial viscosity)
             double2 *r2 = reinterpret_cast<double2 *>(r);
             r2[0] = make_double2(ph.x, ph.y); r2[1] = make_double2(ph.z, v[6]);
             r2[2] = make_double2(v[0], v[1]); r2[3] = make_double2(v[2], v[7]);
-            r2[4] = make_double2(v[10], v[9]); r2[5] = make_double2(v[3], v[4]);
-            r2[6] = make_double2(v[5], 0.0);
+            r2[4] = make_double2(v[10], v[5]); r2[5] = make_double2(v[3], v[4]);
+            if (a.nr > 12) r2[6] = make_double2(v[9], 0.0);
             return;
         }
         if (a.layout == 2) { // compact density records [x y z m] (uniform h)
@@ -459,16 +459,17 @@ template <class T> struct FamTVF_T {
     static constexpr int NR = 16; // x y z h + NA
     struct Params {
         T pb, gx, gy, gz, tdamp, nu, c0, alpha;
+        const double *m; // the destination's own mass (a neighbour's travels in the records only with F_TAV)
         double *au, *av, *aw, *auhat, *avhat, *awhat;
     };
     struct Dest {
         T u, v, w, uh, vh, wh, rho, p, Vi2, mi1;
         T au, av, aw, auh, avh, awh;
     };
-    template <class A> static __device__ __forceinline__ void load(Dest &D, const T *a, const A &, uint32_t)
+    template <class A> static __device__ __forceinline__ void load(Dest &D, const T *a, const A &A_, uint32_t o)
     {
         D.u = a[0]; D.v = a[1]; D.w = a[2]; D.uh = a[3]; D.vh = a[4]; D.wh = a[5];
-        D.rho = a[6]; D.p = a[7]; D.Vi2 = a[10]; D.mi1 = T(1.0) / a[9];
+        D.rho = a[6]; D.p = a[7]; D.Vi2 = a[10]; D.mi1 = T(1.0) / T(A_.p.m[o]);
         D.au = D.av = D.aw = D.auh = D.avh = D.awh = T(0.0);
     }
     template <int KK, bool UH, class A>
@@ -535,18 +536,20 @@ template <class T> struct FamTVF_T {
 typedef FamTVF_T<double> FamTVF;
 
 // TVF records of the aggregated kernel under uniform h (see k_pack layout 3):
-// five 16-B pieces per pair, two more only when the artificial-stress term acts.
+// five 16-B pieces per pair, a sixth when the artificial-stress term acts, a
+// seventh (the neighbour's mass) only for the artificial viscosity.
 template <> __device__ __forceinline__ void load_record<FamTVF, true>(const double *__restrict__ rj, uint32_t fl, double4 &pj, double (&s)[12])
 {
     const double2 *r2 = reinterpret_cast<const double2 *>(rj);
     const double2 a0 = r2[0], a1 = r2[1], b0 = r2[2], b1 = r2[3], c0 = r2[4];
     pj.x = a0.x; pj.y = a0.y; pj.z = a1.x; pj.w = 0.0;
-    s[0] = b0.x; s[1] = b0.y; s[2] = b1.x; s[6] = a1.y; s[7] = b1.y; s[8] = 0.0; s[9] = c0.y; s[10] = c0.x; s[11] = 0.0;
-    s[3] = s[4] = s[5] = 0.0;
+    s[0] = b0.x; s[1] = b0.y; s[2] = b1.x; s[6] = a1.y; s[7] = b1.y; s[8] = 0.0; s[9] = 0.0; s[10] = c0.x; s[11] = 0.0;
+    s[3] = s[4] = 0.0; s[5] = c0.y;
     if (fl & F_TAS) {
-        const double2 d0 = r2[5], d1 = r2[6];
-        s[3] = d0.x; s[4] = d0.y; s[5] = d1.x;
+        const double2 d0 = r2[5];
+        s[3] = d0.x; s[4] = d0.y;
     }
+    if (fl & F_TAV) s[9] = r2[6].x;
 }
 
 // ---- velocity gradient (basic_equations.py:63-148) -------------------------
@@ -919,7 +922,7 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
     if (c->pair_variant >= 2) pa.rec = c->posh.as<double>();
     if (c->pair_variant >= 3) pa.fpos = c->fposb.as<float4>();
     pa.layout = (c->pair_variant >= 3 && fam == FAM_WCSPH) ? 1 : (c->pair_variant >= 3 && fam == FAM_DENSITY && pl.nr == 4) ? 2
-              : (c->pair_variant >= 3 && fam == FAM_TVF && pl.nr == 14) ? 3 : 0;
+              : (c->pair_variant >= 3 && fam == FAM_TVF && (pl.nr == 14 || pl.nr == 12)) ? 3 : 0;
     if (c->pair_variant >= 3 && (c->record_f32 || c->arith_f32)) pa.layout = 5;
     hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, pa);
     return SPH_OK;
@@ -1103,7 +1106,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         // compact 80-B WCSPH records when neither h nor p of a neighbour is read
         if (c->pair_variant >= 3 && fam == FAM_WCSPH && c->uniform_h && c->use_uniform_h && !(dflags & F_TENSILE)) pl.nr = 10;
         if (c->pair_variant >= 3 && fam == FAM_DENSITY && c->uniform_h && c->use_uniform_h) pl.nr = 4;
-        if (c->pair_variant >= 3 && fam == FAM_TVF && c->uniform_h && c->use_uniform_h) pl.nr = 14;
+        if (c->pair_variant >= 3 && fam == FAM_TVF && c->uniform_h && c->use_uniform_h) pl.nr = (dflags & F_TAV) ? 14 : 12;
         if (c->pair_variant >= 3 && (c->record_f32 || c->arith_f32)) pl.nr = (4 + pl.na + 3) & ~3; // floats
         c->cur_nrec = pl.nr;
         SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * (c->pair_variant >= 2 ? pl.nr : 4)));
@@ -1205,6 +1208,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             if (ae) { a.p.c0 = ae->par[0]; a.p.alpha = ae->par[1]; }
             SPH_TRY(ensure_out(c, dst, {SPH_AU, SPH_AV, SPH_AW}));
             a.p.au = D.prop[SPH_AU]; a.p.av = D.prop[SPH_AV]; a.p.aw = D.prop[SPH_AW];
+            a.p.m = D.prop[SPH_M];
             if (dflags & F_TP) {
                 SPH_TRY(ensure_out(c, dst, {SPH_AUHAT, SPH_AVHAT, SPH_AWHAT}));
                 a.p.auhat = D.prop[SPH_AUHAT]; a.p.avhat = D.prop[SPH_AVHAT]; a.p.awhat = D.prop[SPH_AWHAT];

@@ -6,6 +6,7 @@
 //
 // LAYOUT 0: AoS, `strideP` 16-B pieces per record, NP pieces read
 //        1: SoA of pieces: piece q of record j at rec[q*ntab + j]
+//        2/3: AoSoA: blocks of 8 / 16 records, piece q of record j at rec[(j/B)*B*NP + q*B + j%B]
 // MODE   0: every lane loads its own record's pieces (global_load_dwordx4)
 //        1: quad cooperative: 4 lanes load the 4 pieces of ONE record (4 instr serve 4 records), rest per lane
 //        2: as 0 through raw buffer loads with cache-policy bits AUX (1 sc0, 2 nt, 16 sc1)
@@ -45,7 +46,12 @@ __global__ __launch_bounds__(256, 4) void k_gather(Args a)
     const uint32_t wbase = (uint32_t)(((uint64_t)(blockIdx.x * 4 + wv) * 977u) % (a.ntab - a.W));
     f4 acc = {0, 0, 0, 0};
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.rec, 0, 0x7fffffff, 0x00020000);
-    auto idx = [&](uint32_t j, int q) -> size_t { return LAYOUT == 0 ? (size_t)j * a.strideP + q : (size_t)q * a.ntab + j; };
+    auto idx = [&](uint32_t j, int q) -> size_t {
+        if (LAYOUT == 0) return (size_t)j * a.strideP + q;
+        if (LAYOUT == 1) return (size_t)q * a.ntab + j;
+        constexpr uint32_t B = LAYOUT == 2 ? 8u : 16u;
+        return (size_t)(j / B) * (B * NP) + q * B + (j % B);
+    };
     for (int it = 0; it < a.iters; it++) {
         uint32_t j;
         if (a.pattern == 0) j = wbase + (uint32_t)(((uint64_t)lcg(s) * a.W) >> 24);
@@ -109,7 +115,7 @@ static void run(const char *name, int strideP, uint32_t ntab, uint32_t W, int pa
 
 int main()
 {
-    const size_t bytes = 64u << 20;
+    const size_t bytes = 512u << 20;
     std::vector<float> h(bytes / 4);
     for (size_t i = 0; i < h.size(); i++) h[i] = (float)(i % 97) * 0.01f;
     CK(hipMalloc(&d_rec, bytes));
@@ -141,6 +147,15 @@ int main()
             run<2, 5, 0, 16>("buf aos128 sc1", 8, nt, W, pat);
             run<2, 5, 1, 16>("buf soa5 sc1", 5, nt, W, pat);
         }
+    }
+    printf("---- table-size sweep, pattern 1\n");
+    for (uint32_t nt : {24576u, 400000u, 4000000u}) {
+        run<0, 5, 0, 0>("aos80", 5, nt, 1024, 1);
+        run<0, 5, 1, 0>("soa5", 5, nt, 1024, 1);
+        run<0, 5, 2, 0>("aosoa8", 5, nt, 1024, 1);
+        run<0, 5, 3, 0>("aosoa16", 5, nt, 1024, 1);
+        run<0, 3, 0, 0>("aos48", 3, nt, 1024, 1);
+        run<0, 3, 2, 0>("aosoa8 x3", 3, nt, 1024, 1);
     }
     printf("---- LDS-resident records, random ds_read_b128\n");
     run<4, 5, 0, 0>("lds128", 5, 24576, 400, 0, 400 * 80);
