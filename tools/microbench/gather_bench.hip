@@ -11,6 +11,8 @@
 //        1: quad cooperative: 4 lanes load the 4 pieces of ONE record (4 instr serve 4 records), rest per lane
 //        2: as 0 through raw buffer loads with cache-policy bits AUX (1 sc0, 2 nt, 16 sc1)
 //        4: records in LDS, random per-lane ds_read_b128
+//        9: quad cooperative through LDS: 4 x global_load_lds_dwordx4 (the 4 lanes of a quad fetch the 4 first
+//           pieces of ONE record into LDS, lane-linear), 4 x ds_read_b128 transposed, remaining pieces per lane
 //        6/7/8: as 0, but the 4 lanes of a quad / 8 / 16 adjacent lanes gather the SAME record
 // PATTERN 0: record index uniformly random in the wave's window of W records
 //         1: sliding front: lane + 4*step + rnd(36), a new "row" every 10 steps
@@ -21,6 +23,7 @@
 #include <cstdlib>
 #include <vector>
 #include <cstdint>
+#include <cmath>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
@@ -35,6 +38,7 @@ struct Args {
     uint32_t ntab, W;
     int iters, pattern;
     float *out;
+    int verify;
 };
 
 template <int MODE, int NP, int LAYOUT, int AUX>
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256, 4) void k_gather(Args a)
         if (MODE == 6) j = __shfl(j, lane & ~3, 64);
         if (MODE == 7) j = __shfl(j, lane & ~7, 64);
         if (MODE == 8) j = __shfl(j, lane & ~15, 64);
-        if (MODE == 0 || MODE >= 6) {
+        if (MODE == 0 || (MODE >= 6 && MODE <= 8)) {
 #pragma unroll
             for (int q = 0; q < NP; q++) acc += a.rec[idx(j, q)];
         } else if (MODE == 2) {
@@ -79,6 +83,72 @@ __global__ __launch_bounds__(256, 4) void k_gather(Args a)
             }
 #pragma unroll
             for (int q = 4; q < NP; q++) acc += a.rec[(size_t)j * a.strideP + q];
+        } else if (MODE == 9) {
+            // region i (1 KiB + 16 B skew) <- instruction i: lane l holds piece (l & 3) of the record of lane (l & ~3) | i
+            char *wbase_lds = smem + wv * (4 * 1040);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t jk = __shfl(j, (lane & ~3) | k, 64);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.rec + (size_t)jk * a.strideP + (lane & 3)),
+                                                 (__attribute__((address_space(3))) void *)(wbase_lds + k * 1040), 16, 0, 0);
+            }
+#pragma unroll
+            for (int q = 4; q < NP; q++) acc += a.rec[(size_t)j * a.strideP + q];
+            __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
+            const f4 *mine = reinterpret_cast<const f4 *>(wbase_lds + (lane & 3) * 1040) + (lane & ~3);
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc += mine[q];
+            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the reads are done before the next DMA overwrites
+        } else if (MODE == 10) {
+            // as 9, staged through registers: 4 cooperative global loads, ds_write_b128 lane-linear, ds_read_b128 transposed
+            char *wbase_lds = smem + wv * (4 * 1040);
+            f4 r[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t jk = __shfl(j, (lane & ~3) | k, 64);
+                r[k] = a.rec[(size_t)jk * a.strideP + (lane & 3)];
+            }
+#pragma unroll
+            for (int q = 4; q < NP; q++) acc += a.rec[(size_t)j * a.strideP + q];
+#pragma unroll
+            for (int k = 0; k < 4; k++) reinterpret_cast<f4 *>(wbase_lds + k * 1040)[lane] = r[k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const f4 *mine = reinterpret_cast<const f4 *>(wbase_lds + (lane & 3) * 1040) + (lane & ~3);
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc += mine[q];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else if (MODE == 11) {
+            // as 10 with the record SPLIT: pieces 0..3 in a 64-B-aligned array (stride 64 B), the rest in a second array
+            char *wbase_lds = smem + wv * (4 * 1040);
+            const f4 *rec2 = a.rec + (size_t)a.ntab * 4;
+            f4 r[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t jk = __shfl(j, (lane & ~3) | k, 64);
+                r[k] = a.rec[(size_t)jk * 4 + (lane & 3)];
+            }
+#pragma unroll
+            for (int q = 4; q < NP; q++) acc += rec2[(size_t)j * (NP - 4) + (q - 4)];
+#pragma unroll
+            for (int k = 0; k < 4; k++) reinterpret_cast<f4 *>(wbase_lds + k * 1040)[lane] = r[k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const f4 *mine = reinterpret_cast<const f4 *>(wbase_lds + (lane & 3) * 1040) + (lane & ~3);
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc += mine[q];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else if (MODE == 12) {
+            // per-lane gathers from the same split layout (no cooperation)
+            const f4 *rec2 = a.rec + (size_t)a.ntab * 4;
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc += a.rec[(size_t)j * 4 + q];
+#pragma unroll
+            for (int q = 4; q < NP; q++) acc += rec2[(size_t)j * (NP - 4) + (q - 4)];
         } else if (MODE == 4) {
             const uint32_t jl = (uint32_t)(((uint64_t)lcg(s) * a.W) >> 24);
             const f4 *p = reinterpret_cast<const f4 *>(smem) + (size_t)jl * a.strideP;
@@ -86,7 +156,7 @@ __global__ __launch_bounds__(256, 4) void k_gather(Args a)
             for (int q = 0; q < NP; q++) acc += p[q];
         }
     }
-    if (acc.x + acc.y + acc.z + acc.w == 123.456f) a.out[blockIdx.x * 256 + t] = acc.x;
+    if (a.verify || acc.x + acc.y + acc.z + acc.w == 123.456f) a.out[blockIdx.x * 256 + t] = acc.x + acc.y + acc.z + acc.w;
 }
 
 static f4 *d_rec; static float *d_out;
@@ -98,7 +168,7 @@ static void run(const char *name, int strideP, uint32_t ntab, uint32_t W, int pa
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     if (lds) CK(hipFuncSetAttribute((const void *)k_gather<MODE, NP, LAYOUT, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    Args a{d_rec, strideP, ntab, W, 50, pattern, d_out};
+    Args a{d_rec, strideP, ntab, W, 50, pattern, d_out, 0};
     hipLaunchKernelGGL((k_gather<MODE, NP, LAYOUT, AUX>), dim3(blocks), dim3(256), lds, 0, a);
     CK(hipDeviceSynchronize());
     a.iters = iters;
@@ -111,6 +181,17 @@ static void run(const char *name, int strideP, uint32_t ntab, uint32_t W, int pa
     const double cu_ns = ms * 1e6 * 256.0 / wave_iters;
     printf("%-14s NP=%d stride=%3dB tab=%5.0fKB W=%6u pat=%d: %7.3f ms  %6.1f cyc/wave-iter  %5.2f cyc/lane-hit  (%5.1f cyc per piece-instr)\n",
            name, NP, strideP * 16, (double)ntab * strideP * 16 / 1024.0, W, pattern, ms, cu_ns * 2.4, cu_ns * 2.4 / 64, cu_ns * 2.4 / NP);
+}
+
+template <int MODE, int NP>
+static std::vector<float> sums(int strideP, uint32_t ntab, size_t lds)
+{
+    if (lds) CK(hipFuncSetAttribute((const void *)k_gather<MODE, NP, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    Args a{d_rec, strideP, ntab, 1024, 7, 1, d_out, 1};
+    hipLaunchKernelGGL((k_gather<MODE, NP, 0, 0>), dim3(64), dim3(256), lds, 0, a);
+    std::vector<float> h(64 * 256);
+    CK(hipMemcpy(h.data(), d_out, h.size() * 4, hipMemcpyDeviceToHost));
+    return h;
 }
 
 int main()
@@ -147,6 +228,34 @@ int main()
             run<2, 5, 0, 16>("buf aos128 sc1", 8, nt, W, pat);
             run<2, 5, 1, 16>("buf soa5 sc1", 5, nt, W, pat);
         }
+    }
+    {
+        auto r0 = sums<0, 5>(5, 24576, 0), r9 = sums<9, 5>(5, 24576, 4 * 4 * 1040);
+        size_t bad = 0;
+        for (size_t i = 0; i < r0.size(); i++) bad += fabsf(r0[i] - r9[i]) > 1e-3f * fabsf(r0[i]);
+        printf("quadlds vs per-lane gather: %zu of %zu lane sums differ\n", bad, r0.size());
+        auto r10 = sums<10, 5>(5, 24576, 4 * 4 * 1040);
+        bad = 0;
+        for (size_t i = 0; i < r0.size(); i++) bad += fabsf(r0[i] - r10[i]) > 1e-3f * fabsf(r0[i]);
+        printf("quadreg vs per-lane gather: %zu of %zu lane sums differ\n", bad, r0.size());
+    }
+    printf("---- quad cooperative through LDS-DMA\n");
+    for (uint32_t nt : {24576u, 4000000u}) {
+        run<0, 5, 0, 0>("aos80", 5, nt, 1024, 1);
+        run<9, 5, 0, 0>("quadlds 80", 5, nt, 1024, 1, 4 * 4 * 1040);
+        run<10, 5, 0, 0>("quadreg 80", 5, nt, 1024, 1, 4 * 4 * 1040);
+        run<10, 7, 0, 0>("quadreg 112", 7, nt, 1024, 1, 4 * 4 * 1040);
+        run<1, 4, 0, 0>("quad64 (no transpose)", 4, nt, 1024, 1);
+        run<11, 4, 0, 0>("quadreg 64", 4, nt, 1024, 1, 4 * 4 * 1040);
+        run<0, 4, 0, 0>("aos64", 4, nt, 1024, 1);
+        run<0, 1, 0, 0>("aos16", 1, nt, 1024, 1);
+        run<11, 5, 0, 0>("quadreg 64+16", 5, nt, 1024, 1, 4 * 4 * 1040);
+        run<12, 5, 0, 0>("split 64+16", 5, nt, 1024, 1);
+        run<11, 7, 0, 0>("quadreg 64+48", 7, nt, 1024, 1, 4 * 4 * 1040);
+        run<12, 7, 0, 0>("split 64+48", 7, nt, 1024, 1);
+        run<9, 4, 0, 0>("quadlds 64", 4, nt, 1024, 1, 4 * 4 * 1040);
+        run<9, 7, 0, 0>("quadlds 112", 7, nt, 1024, 1, 4 * 4 * 1040);
+        run<0, 7, 0, 0>("aos112", 7, nt, 1024, 1);
     }
     printf("---- table-size sweep, pattern 1\n");
     for (uint32_t nt : {24576u, 400000u, 4000000u}) {
