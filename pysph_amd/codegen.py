@@ -1186,7 +1186,6 @@ class GeneratedFamily(object):
         A('struct FamGen {')
         A('    static constexpr int MINB = SPHGEN_MINB;   // workgroups per CU, chosen at build time')
         A('    typedef double Real;                       // generated bodies compute in fp64')
-        A('    static constexpr bool AOSOA = false;')
         A('    static constexpr bool PRED = false;        // the neighbour criterion stays a branch around pair()')
         A('    static constexpr uint32_t CF0 = 0;         // equation flags are run-time values')
         A('    static constexpr int NA = %d;' % na)

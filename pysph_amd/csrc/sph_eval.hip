@@ -231,16 +231,6 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
         if (a.layout == 1) {
             // 16-B stores: compact records (nr == 10) are only 16-B aligned
             double2 *r2 = reinterpret_cast<double2 *>(r);
-#if SPH_AOSOA
-            if (a.nr == 10) {
-                const size_t jr = a.off + i;
-                r2 = reinterpret_cast<double2 *>(a.rec) + ((jr >> 4) * 80u + (jr & 15u));
-                r2[0] = make_double2(ph.x, ph.y); r2[16] = make_double2(ph.z, v[6]);
-                r2[32] = make_double2(v[0], v[1]); r2[48] = make_double2(v[2], v[3]);
-                r2[64] = make_double2(v[4], v[5]);
-                return;
-            }
-#endif
             r2[0] = make_double2(ph.x, ph.y); r2[1] = make_double2(ph.z, v[6]);
             r2[2] = make_double2(v[0], v[1]); r2[3] = make_double2(v[2], v[3]);
             r2[4] = make_double2(v[4], v[5]);
@@ -301,14 +291,6 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
 
 template <class T> struct FamWCSPH_T {
     typedef T Real; // arithmetic type of the pair loop
-    static constexpr bool AOSOA = sizeof(T) == 8;
-    // the five pieces of a compact record (load_record_wcsph, uniform h, no tensile correction)
-    static __device__ __forceinline__ void decode5(const double2 &p0, const double2 &p1, const double2 &p2, const double2 &p3,
-                                                   const double2 &p4, double4 &pj, double (&s)[8])
-    {
-        pj.x = p0.x; pj.y = p0.y; pj.z = p1.x; pj.w = 0.0;
-        s[0] = p2.x; s[1] = p2.y; s[2] = p3.x; s[3] = p3.y; s[4] = p4.x; s[5] = p4.y; s[6] = p1.y; s[7] = 0.0;
-    }
     static constexpr uint32_t CF0 = F_CONT | F_MOM | F_XSPH; // flag set compiled as a constant (variant 6)
     static constexpr int MINB = 4; // wavefronts per SIMD the pair kernel is compiled for (VGPR budget)
     static constexpr int NA = 8; // u v w m rho tmpj(=p/rho^2) cs p
@@ -430,7 +412,6 @@ template <> __device__ __forceinline__ void load_record<FamWCSPH, false>(const d
 // ---- density summations (basic_equations.py:19-29, transport_velocity.py:24-58)
 template <class T> struct FamDensity_T {
     typedef T Real; // arithmetic type of the pair loop
-    static constexpr bool AOSOA = false;
     static constexpr bool PRED = true; // see FamWCSPH
     static constexpr uint32_t CF0 = F_TVFSD; // flag set compiled as a constant (variant 6)
     static constexpr int MINB = 4; // wavefronts per SIMD the pair kernel is compiled for (VGPR budget)
@@ -471,7 +452,6 @@ template <> __device__ __forceinline__ void load_record<FamDensity, true>(const 
 // ---- TVF momentum terms (transport_velocity.py:219-545) -------------------
 template <class T> struct FamTVF_T {
     typedef T Real; // arithmetic type of the pair loop
-    static constexpr bool AOSOA = false;
     static constexpr bool PRED = true; // see FamWCSPH
     static constexpr uint32_t CF0 = F_TP | F_TVISC | F_TAS; // flag set compiled as a constant (variant 6)
     static constexpr int MINB = 3; // wavefronts per SIMD the pair kernel is compiled for (VGPR budget)
@@ -575,7 +555,6 @@ template <> __device__ __forceinline__ void load_record<FamTVF, true>(const doub
 // ---- velocity gradient (basic_equations.py:63-148) -------------------------
 template <class T> struct FamVGrad_T {
     typedef T Real; // arithmetic type of the pair loop
-    static constexpr bool AOSOA = false;
     static constexpr bool PRED = true; // see FamWCSPH
     static constexpr uint32_t CF0 = F_VG3; // flag set compiled as a constant (variant 6)
     static constexpr int MINB = 4; // wavefronts per SIMD the pair kernel is compiled for (VGPR budget)
@@ -623,7 +602,6 @@ typedef FamVGrad_T<double> FamVGrad;
 //      basic_equations.py:177-300) -------------------------------------------
 template <class T> struct FamElastic_T {
     typedef T Real; // arithmetic type of the pair loop
-    static constexpr bool AOSOA = false;
     static constexpr bool PRED = true; // see FamWCSPH
     static constexpr uint32_t CF0 = F_ECONT | F_ESTRESS | F_EAV | F_EXSPH; // flag set compiled as a constant (variant 6)
     static constexpr int MINB = 2; // wavefronts per SIMD the pair kernel is compiled for (VGPR budget)

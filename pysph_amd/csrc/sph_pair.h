@@ -270,9 +270,6 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 //   Measured on the 4 M cube against the 256-thread workgroup version of the
 //   same schedule (barriers around every shared row tile): see DESIGN.md.
 // ---------------------------------------------------------------------------
-#ifndef SPH_AOSOA
-#define SPH_AOSOA 0 // experiment: compact WCSPH records in blocks of 16 (piece q of record j at ((j/16)*80 + q*16 + j%16) * 16 B)
-#endif
 #define WLQ 10      // slots per lane (9 rows of cells + one spare; a lane out of slots flushes its wavefront's phase 2 early)
 #define WCAP_UH 184 // candidates per LDS tile piece (a wavefront's row range is ~105 for WCSPH, ~125 for TVF);
 #define WCAP_VH 136 // variable h keeps a fourth plane (the candidates' own radii): same 2304 B
@@ -322,13 +319,7 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     // one record: fp32 records for Real = float (and for record_f32), else fp64
     auto fetch = [&](uint32_t jg, uint32_t flags, real4<T> &pj, T (&sj)[Fam::NA]) {
         if constexpr (F32) load_record_f32<Fam, T>(reinterpret_cast<const float *>(a.rec) + (unsigned long long)jg * NR, pj, sj);
-        else if constexpr (SPH_AOSOA && Fam::AOSOA && UH) {
-            if (NR == 10) {
-                const double2 *b = reinterpret_cast<const double2 *>(a.rec) + ((unsigned long long)(jg >> 4) * 80u + (jg & 15u));
-                const double2 p0 = b[0], p1 = b[16], p2 = b[32], p3 = b[48], p4 = b[64];
-                Fam::decode5(p0, p1, p2, p3, p4, pj, sj);
-            } else load_record<Fam, UH>(a.rec + (unsigned long long)jg * NR, flags, pj, sj);
-        } else load_record<Fam, UH>(a.rec + (unsigned long long)jg * NR, flags, pj, sj);
+        else load_record<Fam, UH>(a.rec + (unsigned long long)jg * NR, flags, pj, sj);
     };
     {
         T sd_[Fam::NA];
