@@ -1460,6 +1460,14 @@ class GeneratedFamily(object):
         with open(src, 'w') as f:
             f.write(self.source)
         hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+        import shutil
+        if not (os.path.isfile(hipcc) or shutil.which(hipcc)):
+            # a box without the compiler only runs what was prebuilt into the
+            # cache (tests/prebuild_generated.py, __graft_entry__.build())
+            raise CodegenError(
+                "equation family '%s' is not in the prebuilt cache (%s) and there is no "
+                "hipcc at '%s' to compile it: build it where ROCm is installed (the cache "
+                "directory travels with the package) or set HIPCC" % (self.name, so, hipcc))
         # occupancy: 4 workgroups/CU (128 VGPRs) when the pair kernel fits
         # without scratch, else 3 (168), else 2 (256) -- what the hand-written
         # families fix by hand (Fam::MINB), read here from the compiler's

@@ -301,3 +301,19 @@ def test_tvf_scheme_wall_equations_come_from_the_reference_or_the_caller(monkeyp
         TVFScheme(['fluid'], ['wall'], **kw).get_equations()
     # no solids: nothing is needed
     assert len(TVFScheme(['fluid'], [], **kw).get_equations()) == 3
+
+
+def test_cache_miss_without_hipcc_says_so(monkeypatch, tmp_path):
+    """A box without ROCm's compiler runs prebuilt families only: a family that is
+    not in the cache must name the missing .so and the compiler path, not die in
+    subprocess with FileNotFoundError."""
+    import pysph_amd.codegen as cg
+    from wall_equations_fixture import SetWallVelocity
+    monkeypatch.setattr(cg, 'GEN_DIR', str(tmp_path))        # empty cache
+    monkeypatch.setattr(cg, 'DEFERRED', None)
+    monkeypatch.setenv('HIPCC', str(tmp_path / 'no-such-hipcc'))
+    fam = cg.GeneratedFamily('wall', [SetWallVelocity('wall', ['fluid'])], _arrays(), 3, 'cg_nohipcc')
+    with pytest.raises(cg.CodegenError) as e:
+        fam.build()
+    msg = str(e.value)
+    assert 'not in the prebuilt cache' in msg and 'no-such-hipcc' in msg and 'fam_' in msg
