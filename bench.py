@@ -46,6 +46,7 @@ ALGO_BYTES_UPDATE = 184.0    # whole compute() (EOS + pair pass)
 FLOP_PER_PAIR = 130.0            # fused WCSPH fluid<-fluid group, reference operation count
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X fp64 vector (non-MFMA) peak
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+L2_PEAK_TBS = 34.5           # MI355X_MICROARCH.md, L2 section: aggregate L2 bandwidth of the 8 XCDs
 PARITY_TOL = 1e-10           # BASELINE.json north_star
 
 
@@ -622,7 +623,7 @@ def run(args, rank, local_rank, world, dist):
     # HBM bytes per launch of the dominant kernel come from a separate
     # rocprofv3 --pmc run of this same command (profiles/); only quoted when
     # the configuration matches the profiled one, else null
-    traffic, traffic_source = None, None
+    traffic, traffic_source, l1_fill = None, None, None
     try:
         pt = json.load(open(os.path.join(REPO, 'profiles', 'pmc_traffic.json')))
         c = pt['config']
@@ -631,6 +632,7 @@ def run(args, rank, local_rank, world, dist):
                 (args.n1, args.variant, ordered, args.workload, args.dtype) \
                 and world == 1 and args.params == 'db' and not args.vary_h:
             traffic = pt['bytes_per_launch']
+            l1_fill = pt.get('l1_fill_bytes_per_launch')
             traffic_source = pt.get('source', 'profiles/pmc_traffic.json: separate rocprofv3 --pmc '
                                               'passes of this command, not measured in this run')
     except Exception:
@@ -672,6 +674,12 @@ def run(args, rank, local_rank, world, dist):
             'algorithmic_bytes_per_particle': algo_pair,
             'avg_kernel_ms': pair_avg_s * 1e3,
             'pair_kernel_ms_per_step': pair_step_s * 1e3,
+            # what the kernel is actually bound by: the per-lane record
+            # gathers re-fetch their 128-B lines from the L2 into the CUs' 32-KB L1s
+            'l2_to_l1': None if not l1_fill or pair_avg_s <= 0 else {
+                'bytes_per_launch': l1_fill, 'achieved': l1_fill / pair_avg_s / 1e12,
+                'peak': L2_PEAK_TBS, 'unit': 'TB/s', 'frac': l1_fill / pair_avg_s / 1e12 / L2_PEAK_TBS,
+                'source': 'TCP_TCC_READ_REQ x 128 B of the profiled run (profiles/), this run\'s kernel time'},
         },
         'kernel_ms_per_step': {k: v[0] / args.steps for k, v in timers.items()},
         'fp64_valu': None if not pairs else {

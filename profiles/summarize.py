@@ -108,6 +108,16 @@ if n and pk and 'FETCH_SIZE' in mean[pk[0]]:
             tr['tcp_accesses_per_cu_cycle'] = m['TCP_TOTAL_CACHE_ACCESSES_sum'] / 256.0 / cyc
         if 'TCP_READ_TAGCONFLICT_STALL_CYCLES_sum' in m:
             tr['tcp_tagconflict_stall_frac'] = m['TCP_READ_TAGCONFLICT_STALL_CYCLES_sum'] / 256.0 / cyc
+    if 'TCP_TCC_READ_REQ_sum' in m:
+        # 128-B line requests of the CUs' L1s to the L2 (calibration: k_nosrc reads 8 B per
+        # particle coalesced and counts 8/128 requests per particle, k_cell_keys 24/128)
+        tr['l1_fill_bytes_per_launch'] = m['TCP_TCC_READ_REQ_sum'] * 128.0
+        tr['l1_fill_bytes_per_particle'] = m['TCP_TCC_READ_REQ_sum'] * 128.0 / n
+        if 'GRBM_GUI_ACTIVE' in m:
+            tr['l1_fill_bytes_per_cu_cycle'] = m['TCP_TCC_READ_REQ_sum'] * 128.0 / 256.0 / (m['GRBM_GUI_ACTIVE'] / 8.0)
+    for kk in ('k_nosrc', 'k_cell_keys'):
+        if n and kk in mean and 'TCP_TCC_READ_REQ_sum' in mean[kk]:
+            cal['%s_l1_line_requests_per_particle (x128 B)' % kk] = mean[kk]['TCP_TCC_READ_REQ_sum'] / n
     if 'SQ_INSTS_VALU' in m and 'SQ_WAVES' in m:
         tr['valu_insts_per_wave'] = m['SQ_INSTS_VALU'] / m['SQ_WAVES']
         tr['vmem_rd_per_wave'] = m['SQ_INSTS_VMEM_RD'] / m['SQ_WAVES']
@@ -116,6 +126,7 @@ if n and pk and 'FETCH_SIZE' in mean[pk[0]]:
                           'spatially_ordered': bench['config']['spatially_ordered'],
                           'workload': 'cube', 'dtype': bench.get('dtype', 'f64')},
                'bytes_per_launch': fetch + write,
+               'l1_fill_bytes_per_launch': tr.get('l1_fill_bytes_per_launch'),
                'source': 'profiles/%s_pmc_summary.json: FETCH_SIZE x 2 + WRITE_SIZE of separate '
                          'rocprofv3 --pmc passes of this command on another box, not measured in '
                          'this run' % tag},

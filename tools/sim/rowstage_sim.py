@@ -68,3 +68,43 @@ for name, v in res.items():
     ldsc = lds * 55 + 700
     print('%-30s LDS it %5.1f (lane use %.2f) + gather it %5.1f = %5.1f | rows %.1f | per-CU cycles/wave: VALU %5.0f TA %5.0f LDS %5.0f' % (
         name, lds, v[:, 2].mean(), gat, lds + gat, v[:, 3].mean(), valu, ta, ldsc))
+
+# ---- symmetric row groups: a lane short of hits in row (dy=+1) has more in (dy=-1)
+print('\nphase 2 per GROUP of rows (all of a group staged together), no deferral:')
+def groups_of(kind):
+    if kind == 'rows':
+        return [[(dy, dz)] for dz in (-1, 0, 1) for dy in (-1, 0, 1)]
+    if kind == 'centre | dy pair | dz pair | corners':
+        return [[(0, 0)], [(-1, 0), (1, 0)], [(0, -1), (0, 1)], [(-1, -1), (1, -1), (-1, 1), (1, 1)]]
+    if kind == 'dz planes':
+        return [[(dy, dz) for dy in (-1, 0, 1)] for dz in (-1, 0, 1)]
+    if kind == 'centre+dy pair | rest':
+        return [[(0, 0), (-1, 0), (1, 0)], [(0, -1), (0, 1), (-1, -1), (1, -1), (-1, 1), (1, 1)]]
+    if kind == 'centre | faces | corners':
+        return [[(0, 0)], [(-1, 0), (1, 0), (0, -1), (0, 1)], [(-1, -1), (1, -1), (-1, 1), (1, 1)]]
+    if kind == 'all':
+        return [[(dy, dz) for dy in (-1, 0, 1) for dz in (-1, 0, 1)]]
+out = {}
+for w in np.nonzero(inner)[0][::7]:
+    ii, jj = i[bounds[w]:bounds[w + 1]], j[bounds[w]:bounds[w + 1]]
+    lane = pos[ii] - w * 64
+    # a wavefront that straddles a row end is skipped here (two row segments)
+    if np.unique(row[ii]).size != 1:
+        continue
+    dy = c[jj, 1] - c[ii, 1]
+    dz = c[jj, 2] - c[ii, 2]
+    for kind in ('rows', 'centre | dy pair | dz pair | corners', 'dz planes', 'centre+dy pair | rest',
+                 'centre | faces | corners', 'all'):
+        tot, recs = 0, []
+        for grp in groups_of(kind):
+            sel = np.zeros(ii.size, bool)
+            for (a, b) in grp:
+                sel |= (dy == a) & (dz == b)
+            h = np.bincount(lane[sel], minlength=64)
+            tot += h.max()
+            recs.append(np.unique(jj[sel]).size)
+        out.setdefault(kind, []).append((tot, max(recs), sum(recs)))
+for kind, v in out.items():
+    v = np.array(v, float)
+    print('%-40s iterations %6.1f   largest staged group %5.0f records (%.1f KB)   staged per wave %.0f' % (
+        kind, v[:, 0].mean(), v[:, 1].mean(), v[:, 1].mean() * 80 / 1024, v[:, 2].mean()))
