@@ -939,7 +939,7 @@ template <class Fam> static int launch_pair(sph_ctx *c, int kk, const PairArgs<F
         uint32_t cf = a.src[0].flags;
         for (int j = 1; j < a.nsrc; j++) if (a.src[j].flags != cf) cf = 0;
         if (c->const_flags == 0) cf = 0;
-#define LAUNCH6F(K, UHV, F32V, CFV) hipLaunchKernelGGL((k_pair_wave<Fam, K, UHV, F32V, CFV>), g2, b2, 0, c->stream, a)
+#define LAUNCH6F(K, UHV, F32V, CFV) hipLaunchKernelGGL((k_pair_wave<Fam, K, UHV, F32V, CFV>), g2, b2, (size_t)c->lds_pad, c->stream, a)
 #define LAUNCH6U(K, F32V)                                                                                 \
         if (uh) { if (cf == Fam::CF0) LAUNCH6F(K, true, F32V, Fam::CF0); else LAUNCH6F(K, true, F32V, 0); }  \
         else { if (cf == Fam::CF0) LAUNCH6F(K, false, F32V, Fam::CF0); else LAUNCH6F(K, false, F32V, 0); }
