@@ -158,6 +158,11 @@ def build_workload(args, rank, world):
                       ', h +-%g %%' % (100 * args.vary_h) if args.vary_h else ''))
         w.halo_width = w.kernel.radius_scale * hdx * dx * (1.0 + args.vary_h)
         w.slab = (float(rank), float(rank + 1), False, 0.0)
+        if args.self_slab and world == 1:
+            # timing of the halo path only: the cube made periodic in x through the
+            # slab transport (a different problem than the oracle's: no parity check)
+            w.slab = (0.0, 1.0, True, 1.0)
+            args.no_check = True
         w.fields = ('arho', 'au', 'av', 'aw', 'ax', 'ay', 'az', 'p', 'cs')
     elif args.workload == 'dam_break':
         from pysph_amd.examples import dam_break_3d as db
@@ -823,6 +828,8 @@ def multi_rank_parity(args, rank, local_rank, world, dist, tstream):
                 a = g[oN, 1 + k]
                 scale = np.max(np.abs(b))
                 err = float(np.max(np.abs(a - b)) / scale) if scale > 0 else float(np.max(np.abs(a)))
+                if not np.isfinite(err):
+                    err = 1e300         # a NaN never compares greater
                 worst[0] = max(float(worst[0]), err)
         del nn1, ev1, step1, dom1
         ctx1.close()
