@@ -25,6 +25,7 @@ under gloo in tests/ with a numpy test double; the product ops
 host fallback inside the package.
 """
 import ctypes as C
+import os
 
 from . import device as dev
 
@@ -111,8 +112,10 @@ class DeviceHaloOps(object):
             # the receives are complete before the append kernels read them
             self.torch.cuda.current_stream(self.device).synchronize()
 
-    def pack(self, side, count, shift):
-        buf = self.new_buffer(count)
+    def pack(self, side, count, shift, out=None):
+        """[nprops][count] payload of the rows selected for `side`; `out`: a larger
+        buffer to fill from its start (the fixed-capacity messages)"""
+        buf = out if out is not None else self.new_buffer(count)
         dev._check(self.lib.sph_halo_pack(
             self.ctx._h, self.id, side, self.nprops, self.props, self.axis,
             float(shift), C.c_void_p(buf.data_ptr())))
@@ -185,6 +188,13 @@ class SlabHalo(object):
         self.ops = ops or DeviceHaloOps(pa, ctx, props, axis)
         self.last_counts = (0, 0, 0, 0)   # sent lo/hi, received lo/hi
         self.last_migrated = (0, 0, 0, 0)
+        # ghost exchange protocol (exchange_halos): 'capacity' = fixed-size
+        # messages with the row count in their last element, sized from the
+        # count both ends saw in the previous exchange; 'handshake' = counts
+        # all_gather before exactly-sized messages (always used the first time)
+        self.protocol = os.environ.get('SPH_HALO_PROTOCOL', 'capacity')
+        self.cap_send, self.cap_recv = {}, {}
+        self.handshakes = 0               # exchanges that needed the counts round
 
     def neighbours(self):
         """[(side, peer rank, coordinate shift applied to what we SEND)]"""
@@ -238,26 +248,7 @@ class SlabHalo(object):
         """refresh the ghosts (ParallelManager.update, :512-530).  drop=False:
         the caller (HipDomainManager with slab=...) has already removed every
         ghost row and will add the periodic images of the other axes after."""
-        ops = self.ops
-        if drop:
-            ops.drop_ghosts()
-        n_lo, n_hi = ops.select(self.lo + self.width, self.hi - self.width)
-        nbrs = self.neighbours()
-        if not nbrs:
-            return
-        send_cnt = {0: n_lo, 1: n_hi}
-        # payloads: one flat [nprops][count] buffer per neighbour
-        out_buf = {s: ops.pack(s, send_cnt[s], shift) for s, _, shift in nbrs}
-        for s in (0, 1):             # nothing goes out through an open face
-            if s not in out_buf:
-                send_cnt[s] = 0
-        in_buf, recv_cnt = self._swap(nbrs, send_cnt, out_buf, ops.nprops)
-        # ghosts go behind the real particles (lo side first: deterministic)
-        for s, _, _ in nbrs:
-            if recv_cnt[s]:
-                ops.append(in_buf[s], recv_cnt[s])
-        self.last_counts = (send_cnt[0], send_cnt[1], recv_cnt.get(0, 0),
-                            recv_cnt.get(1, 0))
+        exchange_halos([self], drop=drop)
 
     def migrate(self):
         """hand the REAL particles that left [lo, hi) to the neighbouring
@@ -287,6 +278,142 @@ class SlabHalo(object):
         self.last_migrated = (n_lo, n_hi, recv_cnt.get(0, 0),
                               recv_cnt.get(1, 0))
         return n_lo + n_hi
+
+
+def _capacity(count):
+    """rows a fixed-size ghost message is sized for, from the count both ends of
+    the face saw last: a quarter of headroom + 4096 rows, in units of 1024"""
+    return ((count + count // 4 + 4096 + 1023) // 1024) * 1024
+
+
+def _next_capacity(cap, count):
+    """the SAME rule on both ends of a face (sender: the count it sent;
+    receiver: the count in the header), so the two stay in step without talking"""
+    if cap is None or count > cap or count + count // 8 + 1024 > cap or 4 * count + 16384 < cap:
+        return _capacity(count)
+    return cap
+
+
+def exchange_halos(hs, drop=True):
+    """Ghost refresh of the arrays `hs` (SlabHalo objects of ONE rank, same slab).
+
+    'capacity' protocol (default): every face carries ONE fixed-size message per
+    array -- [nprops][count] rows packed at its start, the row count in its last
+    element -- whose size both ends derived from the previous exchange's count;
+    one batch_isend_irecv, then ONE small device->host copy of the headers (the
+    host needs the counts to resize the arrays).  A face that outgrew its
+    capacity sends a negative header and the pair repeats that face with the
+    exact size.  The very first exchange (no capacities yet) and
+    SPH_HALO_PROTOCOL=handshake use a counts all_gather before exactly-sized
+    messages.  Between one pair of ranks messages match in posting order: sends
+    hi-face first, receives lo-face first (periodic axis with <= 2 ranks: both
+    faces talk to the same peer), arrays in the same order on both sides."""
+    h0 = hs[0]
+    dist, ops0, world, na = h0.dist, h0.ops, h0.world, len(hs)
+    send = []
+    for h in hs:
+        if drop:
+            h.ops.drop_ghosts()
+        n_lo, n_hi = h.ops.select(h.lo + h.width, h.hi - h.width)
+        send.append({0: n_lo, 1: n_hi})
+    nbrs = h0.neighbours()
+    if not nbrs:
+        return
+    sides = [s for s, _, _ in nbrs]
+    for c in send:                  # nothing goes out through an open face
+        for s in (0, 1):
+            if s not in sides:
+                c[s] = 0
+    send_order = sorted(nbrs, key=lambda nb: -nb[0])
+    recv_order = sorted(nbrs, key=lambda nb: nb[0])
+
+    def comm_sync(which):
+        for h in hs:
+            f = getattr(h.ops, which, None)
+            if f is not None:
+                f()
+
+    def run(reqs):
+        if reqs:
+            for w in dist.batch_isend_irecv(reqs):
+                w.wait()
+
+    fixed = h0.protocol == 'capacity' and all(
+        h.cap_send.get(s) is not None and h.cap_recv.get(s) is not None for h in hs for s in sides)
+    if not fixed:
+        out = [{s: h.ops.pack(s, c[s], shift) for s, _, shift in nbrs} for h, c in zip(hs, send)]
+        comm_sync('before_comm')
+        mine = ops0.int_tensor([c[s] for c in send for s in (0, 1)])
+        allc = ops0.int_tensor([0] * (2 * na * world))
+        dist.all_gather_into_tensor(allc, mine)
+        allc = [int(v) for v in allc.cpu()]
+        # what peer sends to me: its hi list if it is my lo neighbour, else lo
+        recv = [{s: allc[2 * na * peer + 2 * a + (1 - s)] for s, peer, _ in nbrs} for a in range(na)]
+        inb = [{s: h.ops.new_buffer(recv[a][s], h.ops.nprops) for s, _, _ in nbrs}
+               for a, h in enumerate(hs)]
+        reqs = []
+        for s, peer, _ in send_order:
+            for a in range(na):
+                if send[a][s]:
+                    reqs.append(dist.P2POp(dist.isend, out[a][s], peer))
+        for s, peer, _ in recv_order:
+            for a in range(na):
+                if recv[a][s]:
+                    reqs.append(dist.P2POp(dist.irecv, inb[a][s], peer))
+        run(reqs)
+        comm_sync('after_comm')
+        for h in hs:
+            h.handshakes += 1
+    else:
+        import torch
+        out, inb = [], []
+        for a, h in enumerate(hs):
+            npr, oa, ia = h.ops.nprops, {}, {}
+            for s, _, shift in nbrs:
+                cap, cnt = h.cap_send[s], send[a][s]
+                big = h.ops.new_buffer(cap * npr + 1, 1)
+                if cnt <= cap:
+                    try:
+                        h.ops.pack(s, cnt, shift, out=big)
+                    except TypeError:       # a primitive set without out=: pack, then copy
+                        big[:cnt * npr] = h.ops.pack(s, cnt, shift)[:cnt * npr]
+                big[-1] = float(cnt if cnt <= cap else -cnt)
+                oa[s] = big
+                ia[s] = h.ops.new_buffer(h.cap_recv[s] * npr + 1, 1)
+            out.append(oa)
+            inb.append(ia)
+        comm_sync('before_comm')
+        reqs = [dist.P2POp(dist.isend, out[a][s], peer) for s, peer, _ in send_order for a in range(na)]
+        reqs += [dist.P2POp(dist.irecv, inb[a][s], peer) for s, peer, _ in recv_order for a in range(na)]
+        run(reqs)
+        # the one readback of the exchange: the row counts the peers packed
+        hdr = torch.stack([inb[a][s][-1] for a in range(na) for s in sides]).cpu().tolist()
+        hdr = {(a, s): int(v) for (a, s), v in zip([(a, s) for a in range(na) for s in sides], hdr)}
+        recv = [{s: abs(hdr[(a, s)]) for s in sides} for a in range(na)]
+        # faces that outgrew their capacity: the pair repeats them, exactly sized
+        over_send = [(a, s) for a in range(na) for s in sides if send[a][s] > hs[a].cap_send[s]]
+        over_recv = [(a, s) for a in range(na) for s in sides if hdr[(a, s)] < 0]
+        if over_send or over_recv:
+            shift_of = {s: shift for s, _, shift in nbrs}
+            for a, s in over_send:
+                out[a][s] = hs[a].ops.pack(s, send[a][s], shift_of[s])
+            for a, s in over_recv:
+                inb[a][s] = hs[a].ops.new_buffer(recv[a][s], hs[a].ops.nprops)
+            comm_sync('before_comm')
+            reqs = [dist.P2POp(dist.isend, out[a][s], peer) for s, peer, _ in send_order
+                    for a in range(na) if (a, s) in over_send]
+            reqs += [dist.P2POp(dist.irecv, inb[a][s], peer) for s, peer, _ in recv_order
+                     for a in range(na) if (a, s) in over_recv]
+            run(reqs)
+        comm_sync('after_comm')
+    # ghosts go behind the real particles (lo side first: deterministic)
+    for a, h in enumerate(hs):
+        for s, _, _ in nbrs:
+            if recv[a][s]:
+                h.ops.append(inb[a][s], recv[a][s])
+            h.cap_send[s] = _next_capacity(h.cap_send.get(s), send[a][s])
+            h.cap_recv[s] = _next_capacity(h.cap_recv.get(s), recv[a][s])
+        h.last_counts = (send[a][0], send[a][1], recv[a].get(0, 0), recv[a].get(1, 0))
 
 
 class SlabDecomposition(object):
@@ -323,66 +450,9 @@ class SlabDecomposition(object):
         return sum(h.migrate() for h in self.halos)
 
     def exchange(self, drop=True):
-        """Ghost refresh of ALL arrays with one counts handshake and one batch of
-        point-to-point transfers (a dam break has three arrays: one all_gather
-        and one batch_isend_irecv instead of three of each)."""
-        hs = self.halos
-        if len(hs) == 1:
-            return hs[0].exchange(drop=drop)
-        h0 = hs[0]
-        nbrs = h0.neighbours()
-        dist, ops0 = self.dist, h0.ops
-        na = len(hs)
-        send = []
-        for h in hs:
-            if drop:
-                h.ops.drop_ghosts()
-            n_lo, n_hi = h.ops.select(h.lo + h.width, h.hi - h.width)
-            send.append({0: n_lo, 1: n_hi})
-        if not nbrs:
-            return
-        sides = [s for s, _, _ in nbrs]
-        for c in send:                  # nothing goes out through an open face
-            for s in (0, 1):
-                if s not in sides:
-                    c[s] = 0
-        out = [{s: h.ops.pack(s, c[s], shift) for s, _, shift in nbrs} for h, c in zip(hs, send)]
-        for h in hs:
-            sync = getattr(h.ops, 'before_comm', None)
-            if sync is not None:
-                sync()
-        mine = ops0.int_tensor([c[s] for c in send for s in (0, 1)])
-        allc = ops0.int_tensor([0] * (2 * na * self.world))
-        dist.all_gather_into_tensor(allc, mine)
-        allc = [int(v) for v in allc.cpu()]
-        # what peer sends to me: its hi list if it is my lo neighbour, else lo
-        recv = [{s: allc[2 * na * peer + 2 * a + (1 - s)] for s, peer, _ in nbrs} for a in range(na)]
-        inb = [{s: h.ops.new_buffer(recv[a][s], h.ops.nprops) for s, _, _ in nbrs}
-               for a, h in enumerate(hs)]
-        # between one pair of ranks messages match in posting order: sends hi-face
-        # first, receives lo-face first (periodic axis with <= 2 ranks: both faces
-        # talk to the same peer), arrays in the same order on both sides
-        reqs = []
-        for s, peer, _ in sorted(nbrs, key=lambda nb: -nb[0]):
-            for a in range(na):
-                if send[a][s]:
-                    reqs.append(dist.P2POp(dist.isend, out[a][s], peer))
-        for s, peer, _ in sorted(nbrs, key=lambda nb: nb[0]):
-            for a in range(na):
-                if recv[a][s]:
-                    reqs.append(dist.P2POp(dist.irecv, inb[a][s], peer))
-        if reqs:
-            for w in dist.batch_isend_irecv(reqs):
-                w.wait()
-        for h in hs:
-            sync = getattr(h.ops, 'after_comm', None)
-            if sync is not None:
-                sync()
-        for a, h in enumerate(hs):
-            for s, _, _ in nbrs:
-                if recv[a][s]:
-                    h.ops.append(inb[a][s], recv[a][s])
-            h.last_counts = (send[a][0], send[a][1], recv[a].get(0, 0), recv[a].get(1, 0))
+        """Ghost refresh of ALL arrays with one batch of point-to-point transfers
+        (a dam break has three arrays): see exchange_halos."""
+        exchange_halos(self.halos, drop=drop)
 
     def update(self):
         self.migrate()

@@ -366,3 +366,68 @@ def test_fused_two_array_exchange_equals_per_array(tmp_path, periodic):
     mp.spawn(_worker_fused, args=(2, port, periodic, out), nprocs=2, join=True)
     n0, n1 = np.load(out % 0), np.load(out % 1)
     assert n0.min() > 0 and n1.min() > 0
+
+
+def _worker_protocols(rank, world, port, periodic, out):
+    """the fixed-capacity ghost messages against the counts handshake: same ghost
+    rows after every exchange while the slab faces (and so the counts) move;
+    tiny capacities force the repeat-with-exact-size path on every face"""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import pysph_amd.parallel as par
+        from test_hip_parity import make_cube
+        from pysph_amd.particle_array import ParticleArray
+        full, dx = make_cube(12)
+        x = full.x
+        own = np.nonzero(x < 0.5)[0] if rank == 0 else np.nonzero(x >= 0.5)[0]
+        lo, hi = (0.0, 0.5) if rank == 0 else (0.5, 1.0)
+
+        def build(protocol):
+            pa = ParticleArray(name='fluid', **{k: v[own].copy() for k, v in full.properties.items()})
+            h = par.SlabHalo(pa, None, rank, world, axis=0, width=0.1, lo=lo, hi=hi,
+                             periodic=periodic, period=1.0, ops=NumpyHaloOps(pa, 0), dist=dist)
+            h.protocol = protocol
+            return pa, h
+        pa_h, hh = build('handshake')
+        pa_c, hc = build('capacity')
+        pa_o, ho = build('capacity')
+        log = []
+        for step, width in enumerate((0.1, 0.1, 0.22, 0.05, 0.3, 0.3)):
+            for h in (hh, hc, ho):
+                h.width = width
+            hh.exchange()
+            hc.exchange()
+            if step:                 # capacities of 8 rows: every face overflows
+                ho.cap_send = {s: 8 for s in ho.cap_send}
+                ho.cap_recv = {s: 8 for s in ho.cap_recv}
+            ho.exchange()
+            n = pa_h.get_number_of_particles()
+            assert pa_c.get_number_of_particles() == n == pa_o.get_number_of_particles()
+            for k in PROPS:
+                assert np.array_equal(pa_h.properties[k][:n], pa_c.properties[k][:n]), (step, k)
+                assert np.array_equal(pa_h.properties[k][:n], pa_o.properties[k][:n]), (step, k)
+            assert hh.last_counts == hc.last_counts == ho.last_counts
+            log.append(hc.last_counts)
+        # the handshake ran once (first exchange) under 'capacity', every time under 'handshake'
+        assert hc.handshakes == 1 and hh.handshakes == 6 and ho.handshakes == 1
+        # capacities follow the counts on both ends without a word being exchanged
+        for s, c in hc.cap_send.items():
+            assert c >= hc.last_counts[s] and c % 1024 == 0
+        np.save(out % rank, np.array(log))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('periodic', [False, True])
+def test_capacity_protocol_equals_handshake(tmp_path, periodic):
+    out = str(tmp_path / 'proto_%d.npy')
+    mp.spawn(_worker_protocols, args=(2, _free_port(), periodic, out), nprocs=2, join=True)
+    a, b = np.load(out % 0), np.load(out % 1)
+    assert a.shape == (6, 4) and a[:, :2].sum() > 0
+    if periodic:
+        # what rank 0 sent through its lo face arrived at rank 1's hi face, and so on
+        assert np.array_equal(a[:, 0], b[:, 3]) and np.array_equal(a[:, 1], b[:, 2])
+    else:
+        assert np.array_equal(a[:, 1], b[:, 2]) and np.array_equal(b[:, 0], a[:, 3])
