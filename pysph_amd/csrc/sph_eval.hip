@@ -199,9 +199,40 @@ struct PackArgs {
                                   // 4: generated, uniform h [x y z | aux...]; 5: fp32 records (floats, any family)
                                   // (1, 2: aggregated kernel only)
     float4 *fpos;                 // non-null: fp32 {x-xmin, y-ymin, z-zmin, radius_scale*h} for the prefilter tiles
+    int lds_np;                   // 16-B pieces per record when the launch carries 256 * lds_np * 16 B of LDS, else 0
     double gmin[3];
     double radius_scale;
 };
+
+#define PACK_MAXP ((4 + MAX_AUX) / 2) // 16-B pieces of the widest record
+
+// Store one record of `np` 16-B pieces per lane.  The 64 records of a wavefront are contiguous in
+// the packed buffer: a whole block transposes them through (dynamic) LDS so that each store
+// instruction writes 1 KiB of whole lines instead of 64 pieces a record apart (k_pack 0.29 -> 0.22 ms
+// on the 4 M cube); the ragged last block, and launches without LDS, store per lane.
+__device__ __forceinline__ void emit_pieces(const PackArgs &a, size_t i, const double2 (&pc)[PACK_MAXP], int np)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 pack_lds[];
+    double2 *const base = reinterpret_cast<double2 *>(a.rec);
+    if (a.lds_np == np && ((size_t)blockIdx.x + 1) * 256 <= a.n) {
+        const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+        double2 *const sw = pack_lds + (size_t)w * 64 * np;
+#pragma unroll
+        for (int q = 0; q < PACK_MAXP; q++)
+            if (q < np) sw[l * np + q] = pc[q];
+        // private to the wavefront: program order is execution order, the fence is for the compiler
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        double2 *const ow = base + (a.off + (size_t)blockIdx.x * 256 + (size_t)w * 64) * np;
+#pragma unroll
+        for (int q = 0; q < PACK_MAXP; q++)
+            if (q < np) ow[q * 64 + l] = sw[q * 64 + l];
+    } else {
+        double2 *const r2 = base + (a.off + i) * np;
+#pragma unroll
+        for (int q = 0; q < PACK_MAXP; q++)
+            if (q < np) r2[q] = pc[q];
+    }
+}
 
 __global__ __launch_bounds__(256) void k_pack(PackArgs a)
 {
@@ -226,19 +257,18 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
         a.fpos[a.off + i] = make_float4((float)(ph.x - a.gmin[0]), (float)(ph.y - a.gmin[1]), (float)(ph.z - a.gmin[2]),
                                         (float)(a.radius_scale * ph.w));
     if (a.rec) {
-        // 32-B stores: every store covers whole sectors of the record
-        double4 *r = reinterpret_cast<double4 *>(a.rec + (a.off + i) * (size_t)a.nr);
-        if (a.layout == 1) {
-            // 16-B stores: compact records (nr == 10) are only 16-B aligned
-            double2 *r2 = reinterpret_cast<double2 *>(r);
-            r2[0] = make_double2(ph.x, ph.y); r2[1] = make_double2(ph.z, v[6]);
-            r2[2] = make_double2(v[0], v[1]); r2[3] = make_double2(v[2], v[3]);
-            r2[4] = make_double2(v[4], v[5]);
-            if (a.nr > 10) r2[5] = make_double2(ph.w, v[7]);
-            return;
-        }
-        if (a.layout == 5) { // fp32 records [x-x0 y-y0 z-z0 h | aux...] (option record_f32), a.nr floats
-            float4 *r4 = reinterpret_cast<float4 *>(reinterpret_cast<float *>(a.rec) + (a.off + i) * (size_t)a.nr);
+        // the record as 16-B pieces, then ONE way out (emit_pieces): the records of a wavefront
+        // are contiguous, so they leave transposed through LDS as whole lines
+        double2 pc[PACK_MAXP];
+#pragma unroll
+        for (int q = 0; q < PACK_MAXP; q++) pc[q] = make_double2(0.0, 0.0);
+        int np;
+        if (a.layout == 1) { // WCSPH [x y | z cs | u v | w m | rho tmpj] (+ [h p]: variable h / tensile correction)
+            pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, v[6]);
+            pc[2] = make_double2(v[0], v[1]); pc[3] = make_double2(v[2], v[3]);
+            pc[4] = make_double2(v[4], v[5]); pc[5] = make_double2(ph.w, v[7]);
+            np = a.nr > 10 ? 6 : 5;
+        } else if (a.layout == 5) { // fp32 records [x-x0 y-y0 z-z0 h | aux...] (option record_f32), a.nr floats
             float w[4 + MAX_AUX];
             w[0] = (float)(ph.x - a.gmin[0]); w[1] = (float)(ph.y - a.gmin[1]); w[2] = (float)(ph.z - a.gmin[2]);
             w[3] = (float)ph.w;
@@ -246,41 +276,32 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
             for (int k = 0; k < MAX_AUX; k++) w[4 + k] = k < a.na ? (float)v[k] : 0.f;
 #pragma unroll
             for (int q = 0; q < (4 + MAX_AUX) / 4; q++)
-                if (4 * q < a.nr) r4[q] = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
-            return;
-        }
-        if (a.layout == 4) { // generated families under uniform h: [x y z | aux...] (h is a launch constant)
-            double2 *r2 = reinterpret_cast<double2 *>(r);
+                pc[q] = __builtin_bit_cast(double2, make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]));
+            np = a.nr / 4;
+        } else if (a.layout == 4) { // generated families under uniform h: [x y z | aux...] (h is a launch constant)
             double w[3 + MAX_AUX + 1];
             w[0] = ph.x; w[1] = ph.y; w[2] = ph.z;
 #pragma unroll
             for (int k = 0; k < MAX_AUX + 1; k++) w[3 + k] = k < a.na ? v[k < MAX_AUX ? k : 0] : 0.0;
 #pragma unroll
-            for (int q = 0; q < (3 + MAX_AUX + 1) / 2; q++)
-                if (2 * q < a.nr) r2[q] = make_double2(w[2 * q], w[2 * q + 1]);
-            return;
-        }
-        if (a.layout == 3) { // TVF under uniform h: [x y | z rho | u v | w p | Vj2 what | uhat vhat] (+ [m -] with artificial viscosity)
-            double2 *r2 = reinterpret_cast<double2 *>(r);
-            r2[0] = make_double2(ph.x, ph.y); r2[1] = make_double2(ph.z, v[6]);
-            r2[2] = make_double2(v[0], v[1]); r2[3] = make_double2(v[2], v[7]);
-            r2[4] = make_double2(v[10], v[5]); r2[5] = make_double2(v[3], v[4]);
-            if (a.nr > 12) r2[6] = make_double2(v[9], 0.0);
-            return;
-        }
-        if (a.layout == 2) { // compact density records [x y z m] (uniform h)
-            r[0] = make_double4(ph.x, ph.y, ph.z, v[0]);
-            return;
-        }
-        r[0] = ph;
-        const int n4 = (a.nr - 4) / 4;
+            for (int q = 0; q < (3 + MAX_AUX + 1) / 2; q++) pc[q] = make_double2(w[2 * q], w[2 * q + 1]);
+            np = (a.nr + 1) / 2;
+        } else if (a.layout == 3) { // TVF under uniform h: [x y | z rho | u v | w p | Vj2 what | uhat vhat] (+ [m -] with artificial viscosity)
+            pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, v[6]);
+            pc[2] = make_double2(v[0], v[1]); pc[3] = make_double2(v[2], v[7]);
+            pc[4] = make_double2(v[10], v[5]); pc[5] = make_double2(v[3], v[4]);
+            pc[6] = make_double2(v[9], 0.0);
+            np = a.nr > 12 ? 7 : 6;
+        } else if (a.layout == 2) { // compact density records [x y z m] (uniform h)
+            pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, v[0]);
+            np = 2;
+        } else { // [x y z h | aux...]
+            pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, ph.w);
 #pragma unroll
-        for (int q = 0; q < MAX_AUX / 4; q++)
-            if (q < n4) r[1 + q] = make_double4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-        if ((a.nr - 4) & 3) { // 16-B tail (density family: 6 doubles)
-            double2 *t2 = reinterpret_cast<double2 *>(a.rec + (a.off + i) * (size_t)a.nr + 4 + 4 * n4);
-            *t2 = make_double2(v[4 * n4], v[4 * n4 + 1]);
+            for (int q = 0; q < MAX_AUX / 2; q++) pc[2 + q] = make_double2(v[2 * q], v[2 * q + 1]);
+            np = a.nr / 2;
         }
+        emit_pieces(a, i, pc, np);
     } else {
         a.posh[a.off + i] = ph;
         double *dst = a.aux + (a.off + i) * (size_t)a.na;
@@ -889,6 +910,16 @@ static bool slot_required(int fam, uint32_t flags, int prop)
     return false;
 }
 
+// 16-B pieces of one packed record, as k_pack counts them; 0: records that are not a whole number of
+// pieces (no LDS transposition, per-lane stores)
+static int pack_pieces(const PackArgs &pa)
+{
+    if (!pa.rec) return 0;
+    if (pa.layout == 5) return (pa.nr % 4) ? 0 : pa.nr / 4;
+    if (pa.nr % 2) return 0;
+    return pa.nr / 2;
+}
+
 static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fam, uint32_t flags, bool dest_only = false)
 {
     DevArray &A = c->arr[id];
@@ -924,7 +955,8 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
     pa.layout = (c->pair_variant >= 3 && fam == FAM_WCSPH) ? 1 : (c->pair_variant >= 3 && fam == FAM_DENSITY && pl.nr == 4) ? 2
               : (c->pair_variant >= 3 && fam == FAM_TVF && (pl.nr == 14 || pl.nr == 12)) ? 3 : 0;
     if (c->pair_variant >= 3 && (c->record_f32 || c->arith_f32)) pa.layout = 5;
-    hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, pa);
+    pa.lds_np = pack_pieces(pa);
+    hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), (size_t)pa.lds_np * 256 * 16, c->stream, pa);
     return SPH_OK;
 }
 
@@ -1254,7 +1286,8 @@ static int pack_generic(sph_ctx *c, int id, size_t off, int nprops, const int *p
     pa.fpos = c->fposb.as<float4>();
     for (int k = 0; k < 3; k++) pa.gmin[k] = c->xmin[k];
     pa.radius_scale = c->radius_scale;
-    hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, pa);
+    pa.lds_np = pack_pieces(pa);
+    hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), (size_t)pa.lds_np * 256 * 16, c->stream, pa);
     return SPH_OK;
 }
 
