@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
             pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, v[6]);
             pc[2] = make_double2(v[0], v[1]); pc[3] = make_double2(v[2], v[3]);
             pc[4] = make_double2(v[4], v[5]); pc[5] = make_double2(ph.w, v[7]);
-            np = a.nr > 10 ? 6 : 5;
+            np = a.nr / 2;
         } else if (a.layout == 5) { // fp32 records [x-x0 y-y0 z-z0 h | aux...] (option record_f32), a.nr floats
             float w[4 + MAX_AUX];
             w[0] = (float)(ph.x - a.gmin[0]); w[1] = (float)(ph.y - a.gmin[1]); w[2] = (float)(ph.z - a.gmin[2]);
@@ -1136,7 +1136,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         if (total >= (1ull << 32)) { sph_set_error("too many particles for 32-bit packed indices"); return SPH_ERR_ARG; }
         PackPlan pl = pack_plan(fam);
         // compact 80-B WCSPH records when neither h nor p of a neighbour is read
-        if (c->pair_variant >= 3 && fam == FAM_WCSPH && c->uniform_h && c->use_uniform_h && !(dflags & F_TENSILE)) pl.nr = 10;
+        if (c->pair_variant >= 3 && fam == FAM_WCSPH && c->uniform_h && c->use_uniform_h && !(dflags & F_TENSILE)) pl.nr = c->wcsph_nr ? (int)c->wcsph_nr : 10;
         if (c->pair_variant >= 3 && fam == FAM_DENSITY && c->uniform_h && c->use_uniform_h) pl.nr = 4;
         if (c->pair_variant >= 3 && fam == FAM_TVF && c->uniform_h && c->use_uniform_h) pl.nr = (dflags & F_TAV) ? 14 : 12;
         if (c->pair_variant >= 3 && (c->record_f32 || c->arith_f32)) pl.nr = (4 + pl.na + 3) & ~3; // floats

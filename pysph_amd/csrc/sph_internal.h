@@ -104,6 +104,7 @@ struct sph_ctx {
     long tile_block_rows = 8; // destination tiles are traversed in blocks of this many cell rows (y) through all z planes; 0: memory order
     double cur_dt = 0.0;    // dt of the sph_eval_group call being set up
     DevBuf csr_start[SPH_MAX_ARRAYS], csr_nbrs[SPH_MAX_ARRAYS]; // neighbour lists of generated loop_all families
+    long wcsph_nr = 0;      // experiment: doubles per compact WCSPH record (10; 12/16 pad the stride)
     long lds_pad = 0;       // profiling: extra dynamic LDS per pair-kernel workgroup (limits wavefronts per CU)
     int cur_nrec = 0;       // doubles per packed record of the pair launch being set up
     long block_sorted_outputs = 0;
