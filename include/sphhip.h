@@ -372,9 +372,22 @@ int sph_integrate_stage(sph_ctx *ctx, int array_id, int stepper, int stage, doub
  * pysph/sph/integrator.py:150-160).                                        */
 int sph_reduce_min(sph_ctx *ctx, int array_id, int prop, double *out);
 
-/* options: "pair_variant" 3 = aggregated two-phase kernel (default),
- * 2 = row-by-row LDS record tiles, 0 = per-lane cell walk (cross-checks);
- * "uniform_h" 0/1 = allow the hmin==hmax specialisation; "ablate" (profiling). */
+/* options (key, value):
+ *   "pair_variant"   6 = one wavefront per 64 destinations, two-phase pair
+ *                    kernel k_pair_wave (default); 0 = per-lane cell walk
+ *                    k_pair_direct (cross-checks)
+ *   "uniform_h"      0/1: allow the hmin == hmax specialisation (default 1)
+ *   "arith_f32"      0/1: pair loops in fp32 arithmetic on fp32 records (the
+ *                    reference's GPU backends without --use-double,
+ *                    acceleration_eval_gpu_helper.py:281-283); default 0
+ *   "record_f32"     0/1: fp32 records, fp64 arithmetic; default 0
+ *   "const_flags"    0/1: equation-flag set compiled as a constant when it is
+ *                    the family's usual one (default 1)
+ *   "tile_block_rows" rows of 256-destination tiles per traversal block (XCD-aware
+ *                    tile order); "invalidate_nnps": the next evaluation needs a
+ *                    fresh sph_nnps_update
+ *   profiling only:  "ablate", "count_iters", "dump_counters", "lds_pad",
+ *                    "wcsph_nr"                        */
 int sph_set_option(sph_ctx *ctx, const char *key, long value);
 
 /* ---------------------------------------------------------------------- */
