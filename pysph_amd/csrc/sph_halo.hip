@@ -10,20 +10,23 @@
 
 #include <hipcub/hipcub.hpp>
 
+// one 64-bit flag per particle: bit 0 = selected for the low side, bit 32 = for the high side,
+// so that ONE exclusive scan yields both lists' positions (low word / high word)
 __global__ __launch_bounds__(256) void k_halo_flags(const double *__restrict__ coord, size_t n, int mode, double p0,
-                                                    double p1, double p2, uint32_t *__restrict__ flo,
-                                                    uint32_t *__restrict__ fhi)
+                                                    double p1, double p2, unsigned long long *__restrict__ fl)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double v = coord[i];
+    bool lo, hi;
     if (mode == 0) {
-        flo[i] = v < p0 ? 1u : 0u;
-        fhi[i] = v >= p1 ? 1u : 0u;
+        lo = v < p0;
+        hi = v >= p1;
     } else { // nnps_base.pyx:805-817
-        flo[i] = (v - p0) <= p2 ? 1u : 0u;
-        fhi[i] = (p1 - v) <= p2 ? 1u : 0u;
+        lo = (v - p0) <= p2;
+        hi = (p1 - v) <= p2;
     }
+    fl[i] = (lo ? 1ull : 0ull) | (hi ? 1ull << 32 : 0ull);
 }
 
 __global__ __launch_bounds__(256) void k_box_wrap(double *__restrict__ coord, size_t n, double vmin, double vmax,
@@ -37,7 +40,18 @@ __global__ __launch_bounds__(256) void k_box_wrap(double *__restrict__ coord, si
     coord[i] = v;
 }
 
-__global__ __launch_bounds__(256) void k_halo_scatter(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos,
+__global__ __launch_bounds__(256) void k_halo_scatter(const unsigned long long *__restrict__ flag,
+                                                      const unsigned long long *__restrict__ pos, size_t n,
+                                                      uint32_t *__restrict__ list_lo, uint32_t *__restrict__ list_hi)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long f = flag[i], p = pos[i];
+    if (f & 1ull) list_lo[(uint32_t)p] = (uint32_t)i;
+    if (f >> 32) list_hi[(uint32_t)(p >> 32)] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_list_scatter(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos,
                                                       size_t n, uint32_t *__restrict__ list)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -90,32 +104,28 @@ extern "C" int sph_halo_select(sph_ctx *c, int id, int axis, int mode, double p0
     if (n == 0) return SPH_OK;
     const double *coord = A.prop[SPH_X + axis];
     if (!coord) { sph_set_error("sph_halo_select: no device coordinates"); return SPH_ERR_MISSING_PROP; }
-    for (int s = 0; s < 2; s++) {
-        SPH_TRY(H.flag[s].reserve((n + 1) * 4));
-        SPH_TRY(H.pos[s].reserve((n + 1) * 4));
-    }
-    hipLaunchKernelGGL(k_halo_flags, dim3(div_up(n, 256)), dim3(256), 0, c->stream, coord, n, mode, p0, p1, p2,
-                       H.flag[0].as<uint32_t>(), H.flag[1].as<uint32_t>());
-    uint32_t *pin = (uint32_t *)c->pinned;
-    for (int s = 0; s < 2; s++) {
-        size_t tmp = 0;
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, H.flag[s].as<uint32_t>(), H.pos[s].as<uint32_t>(),
-                                                 (int)n, c->stream));
-        SPH_TRY(c->cub_tmp.reserve(tmp));
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.ptr, tmp, H.flag[s].as<uint32_t>(),
-                                                 H.pos[s].as<uint32_t>(), (int)n, c->stream));
-        HIP_TRY(hipMemcpyAsync(pin + 2 * s, H.pos[s].as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(pin + 2 * s + 1, H.flag[s].as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
-    }
+    SPH_TRY(H.flag[0].reserve((n + 1) * 8));
+    SPH_TRY(H.pos[0].reserve((n + 1) * 8));
+    unsigned long long *fl = H.flag[0].as<unsigned long long>(), *ps = H.pos[0].as<unsigned long long>();
+    hipLaunchKernelGGL(k_halo_flags, dim3(div_up(n, 256)), dim3(256), 0, c->stream, coord, n, mode, p0, p1, p2, fl);
+    size_t tmp = 0;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, fl, ps, (int)n, c->stream));
+    SPH_TRY(c->cub_tmp.reserve(tmp));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.ptr, tmp, fl, ps, (int)n, c->stream));
+    unsigned long long *pin = (unsigned long long *)c->pinned;
+    HIP_TRY(hipMemcpyAsync(pin, ps + (n - 1), 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(pin + 1, fl + (n - 1), 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    const unsigned long long tot = pin[0] + pin[1]; // no carry between the words: each count < 2^32
+    H.count[0] = (size_t)(tot & 0xffffffffull);
+    H.count[1] = (size_t)(tot >> 32);
     for (int s = 0; s < 2; s++) {
-        H.count[s] = (size_t)pin[2 * s] + pin[2 * s + 1];
         counts[s] = H.count[s];
         SPH_TRY(H.list[s].reserve((H.count[s] + 1) * 4));
-        if (H.count[s])
-            hipLaunchKernelGGL(k_halo_scatter, dim3(div_up(n, 256)), dim3(256), 0, c->stream, H.flag[s].as<uint32_t>(),
-                               H.pos[s].as<uint32_t>(), n, H.list[s].as<uint32_t>());
     }
+    if (H.count[0] + H.count[1])
+        hipLaunchKernelGGL(k_halo_scatter, dim3(div_up(n, 256)), dim3(256), 0, c->stream, fl, ps, n,
+                           H.list[0].as<uint32_t>(), H.list[1].as<uint32_t>());
     return SPH_OK;
 }
 
@@ -194,12 +204,12 @@ extern "C" int sph_halo_append(sph_ctx *c, int id, int nprops, const int *props,
     return SPH_OK;
 }
 
-__global__ __launch_bounds__(256) void k_keep_flags(const uint32_t *__restrict__ flo, const uint32_t *__restrict__ fhi,
-                                                    size_t nsel, size_t n, uint32_t *__restrict__ keep)
+__global__ __launch_bounds__(256) void k_keep_flags(const unsigned long long *__restrict__ fl, size_t nsel, size_t n,
+                                                    uint32_t *__restrict__ keep)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    keep[i] = (i < nsel && (flo[i] | fhi[i])) ? 0u : 1u;
+    keep[i] = (i < nsel && fl[i]) ? 0u : 1u;
 }
 
 __global__ __launch_bounds__(256) void k_compact_f64(const double *__restrict__ src, const uint32_t *__restrict__ list,
@@ -230,14 +240,14 @@ extern "C" int sph_halo_remove_selected(sph_ctx *c, int id, size_t *n_left)
     SPH_TRY(keep.reserve((n + 1) * 4));
     SPH_TRY(pos.reserve((n + 1) * 4));
     SPH_TRY(list.reserve((keepn + 1) * 4));
-    hipLaunchKernelGGL(k_keep_flags, dim3(div_up(n, 256)), dim3(256), 0, c->stream, H.flag[0].as<uint32_t>(),
-                       H.flag[1].as<uint32_t>(), H.nsel, n, keep.as<uint32_t>());
+    hipLaunchKernelGGL(k_keep_flags, dim3(div_up(n, 256)), dim3(256), 0, c->stream,
+                       H.flag[0].as<unsigned long long>(), H.nsel, n, keep.as<uint32_t>());
     size_t tmpb = 0;
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpb, keep.as<uint32_t>(), pos.as<uint32_t>(), (int)n, c->stream));
     SPH_TRY(c->cub_tmp.reserve(tmpb));
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.ptr, tmpb, keep.as<uint32_t>(), pos.as<uint32_t>(), (int)n, c->stream));
     if (keepn)
-        hipLaunchKernelGGL(k_halo_scatter, dim3(div_up(n, 256)), dim3(256), 0, c->stream, keep.as<uint32_t>(),
+        hipLaunchKernelGGL(k_list_scatter, dim3(div_up(n, 256)), dim3(256), 0, c->stream, keep.as<uint32_t>(),
                            pos.as<uint32_t>(), n, list.as<uint32_t>());
     double *tmp = nullptr;
     HIP_TRY(hipMalloc((void **)&tmp, A.cap * sizeof(double)));
