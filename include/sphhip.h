@@ -386,6 +386,10 @@ int sph_reduce_min(sph_ctx *ctx, int array_id, int prop, double *out);
  *   "tile_block_rows" rows of 256-destination tiles per traversal block (XCD-aware
  *                    tile order); "invalidate_nnps": the next evaluation needs a
  *                    fresh sph_nnps_update
+ *   "pack_group"     1 ... 0 around the sph_eval_group calls (one per destination)
+ *                    of ONE group: WCSPH source records are packed once per
+ *                    group instead of once per destination that reads them.
+ *                    Nothing else may modify the arrays in between.
  *   profiling only:  "ablate", "count_iters", "dump_counters", "lds_pad",
  *                    "wcsph_nr"                        */
 int sph_set_option(sph_ctx *ctx, const char *key, long value);

@@ -342,8 +342,18 @@ class _CGroup(object):
             u.refresh(start, stop)
 
     def run(self, ev, t, dt):
-        for u in self.units:
-            u.run(ev, t, dt)
+        # several destinations with hand-written kernels only: the library packs
+        # every source array once for the whole group (option pack_group)
+        # instead of once per destination that reads it
+        shared = len(self.units) > 1 and all(isinstance(u, _BuiltinUnit) for u in self.units)
+        if shared:
+            ev.ctx.set_option('pack_group', 1)
+        try:
+            for u in self.units:
+                u.run(ev, t, dt)
+        finally:
+            if shared:
+                ev.ctx.set_option('pack_group', 0)
 
 
 class HipAccelerationEval(object):

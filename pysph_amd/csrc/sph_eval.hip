@@ -920,7 +920,10 @@ static int pack_pieces(const PackArgs &pa)
     return pa.nr / 2;
 }
 
-static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fam, uint32_t flags, bool dest_only = false)
+// `launch` false: validate only (the records of this array are already in the packed buffer, see
+// the pack cache in sph_eval_group)
+static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fam, uint32_t flags, bool dest_only = false,
+                      bool launch = true)
 {
     DevArray &A = c->arr[id];
     if (A.n == 0) return SPH_OK;
@@ -956,7 +959,7 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
               : (c->pair_variant >= 3 && fam == FAM_TVF && (pl.nr == 14 || pl.nr == 12)) ? 3 : 0;
     if (c->pair_variant >= 3 && (c->record_f32 || c->arith_f32)) pa.layout = 5;
     pa.lds_np = pack_pieces(pa);
-    hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), (size_t)pa.lds_np * 256 * 16, c->stream, pa);
+    if (launch) hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), (size_t)pa.lds_np * 256 * 16, c->stream, pa);
     return SPH_OK;
 }
 
@@ -1050,6 +1053,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
     if (g->neq > SPH_MAX_EQS) { sph_set_error("sph_eval_group: too many equations"); return SPH_ERR_ARG; }
     if (K->kind < 1 || K->kind > 4) { sph_set_error("sph_eval_group: unknown kernel kind %d", K->kind); return SPH_ERR_UNSUPPORTED; }
     HIP_TRY(hipSetDevice(c->device));
+    if (!c->pack_group) c->pack_epoch++; // packed records are reused between the destinations of ONE group only (option pack_group)
 
     // destinations in first-appearance order (acceleration_eval.py:126-131)
     int dests[SPH_MAX_ARRAYS], ndest = 0;
@@ -1074,6 +1078,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             if (e.dest != dst || e.nsrc != 0) continue;
             if (!is_nosrc_kind(e.kind)) { sph_set_error("equation kind %d needs sources", e.kind); return SPH_ERR_UNSUPPORTED; }
             SPH_TRY(run_nosrc(c, e, start, stop));
+            c->pack_cache[dst].epoch = 0; // its properties changed: records packed for an earlier destination are stale
         }
 
         // 2. sources in first-appearance order with their equation flags (acceleration_eval.py:136-151)
@@ -1133,6 +1138,19 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         size_t d_off = total;
         if (!dest_is_src) total += D.n;
         else for (int j = 0; j < nsrcs; j++) if (srcs[j] == dst) d_off = off_of[j];
+        // WCSPH groups with several destinations (a dam break: fluid, boundary, obstacle) read the
+        // SAME source records, and nothing the family writes (accelerations) is part of a record:
+        // one buffer slot per neighbour-grid array, each array packed once per group instead of
+        // once per destination that reads it (dam break C2: 7 -> 3 k_pack launches per evaluation).
+        // The host brackets the per-destination calls of one group with option pack_group 1 / 0.
+        const bool share = fam == FAM_WCSPH && c->pair_variant >= 3 && (ndest > 1 || c->pack_group);
+        if (share) {
+            size_t goff[SPH_MAX_ARRAYS] = {};
+            total = 0;
+            for (int a = 0; a < c->narrays; a++) { goff[c->ids[a]] = total; total += c->arr[c->ids[a]].n; }
+            for (int j = 0; j < nsrcs; j++) off_of[j] = goff[srcs[j]];
+            d_off = goff[dst];
+        }
         if (total >= (1ull << 32)) { sph_set_error("too many particles for 32-bit packed indices"); return SPH_ERR_ARG; }
         PackPlan pl = pack_plan(fam);
         // compact 80-B WCSPH records when neither h nor p of a neighbour is read
@@ -1141,14 +1159,25 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         if (c->pair_variant >= 3 && fam == FAM_TVF && c->uniform_h && c->use_uniform_h) pl.nr = (dflags & F_TAV) ? 14 : 12;
         if (c->pair_variant >= 3 && (c->record_f32 || c->arith_f32)) pl.nr = (4 + pl.na + 3) & ~3; // floats
         c->cur_nrec = pl.nr;
+        const void *rec_was = c->posh.ptr, *fpos_was = c->fposb.ptr;
         SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * (c->pair_variant >= 2 ? pl.nr : 4)));
         SPH_TRY(c->aux.reserve((total + 64) * sizeof(double) * pl.na));
         if (c->pair_variant >= 3) SPH_TRY(c->fposb.reserve((total + 64) * sizeof(float4)));
+        if (c->posh.ptr != rec_was || c->fposb.ptr != fpos_was) // the buffers moved: nothing packed earlier is there
+            for (auto &pc : c->pack_cache) pc.epoch = 0;
         {
             ScopedTimer tm(c, T_PACK);
             // a source must hold what ITS equations read; the destination's own record what all of them read
-            for (int j = 0; j < nsrcs; j++) SPH_TRY(pack_array(c, srcs[j], off_of[j], pl, fam, srcs[j] == dst ? dflags : sflags[j]));
-            if (!dest_is_src) SPH_TRY(pack_array(c, dst, d_off, pl, fam, dflags, true));
+            const int sig = pl.nr * 4 + (c->record_f32 ? 1 : 0) + (c->arith_f32 ? 2 : 0);
+            auto pack_once = [&](int id, size_t off, uint32_t fl, bool dest_only) -> int {
+                PackCache &pc = c->pack_cache[id];
+                const bool hit = share && pc.epoch == c->pack_epoch && pc.fam == fam && pc.sig == sig;
+                SPH_TRY(pack_array(c, id, off, pl, fam, fl, dest_only, !hit)); // a hit still validates
+                pc.epoch = share ? c->pack_epoch : 0; pc.fam = fam; pc.sig = sig;
+                return SPH_OK;
+            };
+            for (int j = 0; j < nsrcs; j++) SPH_TRY(pack_once(srcs[j], off_of[j], srcs[j] == dst ? dflags : sflags[j], false));
+            if (!dest_is_src) SPH_TRY(pack_once(dst, d_off, dflags, true));
         }
 
         // 4. fused pair kernel, in the arithmetic type of the context (fp64, or fp32 with option arith_f32)

@@ -69,6 +69,12 @@ struct Timer {
     long count = 0;
 };
 
+// records of one array in the packed buffer of the current sph_eval_group call
+struct PackCache {
+    unsigned long long epoch = 0;
+    int fam = -1, sig = 0;
+};
+
 struct sph_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -104,6 +110,9 @@ struct sph_ctx {
     long tile_block_rows = 8; // destination tiles are traversed in blocks of this many cell rows (y) through all z planes; 0: memory order
     double cur_dt = 0.0;    // dt of the sph_eval_group call being set up
     DevBuf csr_start[SPH_MAX_ARRAYS], csr_nbrs[SPH_MAX_ARRAYS]; // neighbour lists of generated loop_all families
+    unsigned long long pack_epoch = 0;
+    long pack_group = 0;    // 1 between the per-destination sph_eval_group calls of one host group (records shared)
+    PackCache pack_cache[SPH_MAX_ARRAYS];
     long wcsph_nr = 0;      // experiment: doubles per compact WCSPH record (10; 12/16 pad the stride)
     long lds_pad = 0;       // profiling: extra dynamic LDS per pair-kernel workgroup (limits wavefronts per CU)
     int cur_nrec = 0;       // doubles per packed record of the pair launch being set up
