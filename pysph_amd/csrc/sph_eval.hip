@@ -89,9 +89,17 @@ __global__ __launch_bounds__(256) void k_nosrc(EosArgs a)
     case SPH_EQ_TAIT_EOS: { // wc/basic.py:60-65
         double rho0 = a.par[0], c0 = a.par[1], gamma = a.par[2], p0 = a.par[3];
         double ratio = a.rho[i] * (1.0 / rho0);
-        double tmp = pow(ratio, gamma);
+        double tmp, csr;
+        if (gamma == 7.0) { // the usual water exponent: ratio^7 and ratio^3 by multiplication (two pow() calls made this kernel compute-bound)
+            const double r2 = ratio * ratio;
+            csr = r2 * ratio;
+            tmp = (r2 * r2) * csr;
+        } else {
+            tmp = pow(ratio, gamma);
+            csr = pow(ratio, 0.5 * (gamma - 1.0));
+        }
         a.p[i] = p0 + (rho0 * c0 * c0 / gamma) * (tmp - 1.0);
-        a.cs[i] = c0 * pow(ratio, 0.5 * (gamma - 1.0));
+        a.cs[i] = c0 * csr;
         break;
     }
     case SPH_EQ_TAIT_EOS_HG: { // wc/basic.py:118-126
