@@ -431,3 +431,27 @@ def test_capacity_protocol_equals_handshake(tmp_path, periodic):
         assert np.array_equal(a[:, 0], b[:, 3]) and np.array_equal(a[:, 1], b[:, 2])
     else:
         assert np.array_equal(a[:, 1], b[:, 2]) and np.array_equal(b[:, 0], a[:, 3])
+
+
+def test_capacity_rule_is_symmetric_and_stable():
+    """both ends of a face apply _next_capacity to the SAME (capacity, count) pair:
+    it must be a pure function, grow before the count reaches the capacity, not
+    oscillate on a steady count and shrink after a large drop"""
+    from pysph_amd.parallel import _capacity, _next_capacity
+    for count in (0, 1, 4095, 4096, 75843, 10 ** 6, 3 * 10 ** 7):
+        cap = _capacity(count)
+        assert cap % 1024 == 0 and cap >= count + count // 4 + 4096
+        assert _next_capacity(None, count) == cap
+        assert _next_capacity(cap, count) == cap                 # steady state: no change
+        assert _next_capacity(cap, count + count // 16) == cap   # small growth fits the headroom
+        assert _next_capacity(cap, cap + 1) == _capacity(cap + 1)            # overflow -> resized
+    big = _capacity(10 ** 6)
+    assert _next_capacity(big, 1000) == _capacity(1000)          # a large drop shrinks the messages
+    # a slowly growing count is re-sized BEFORE it overflows
+    cap, resized, overflowed = _capacity(50000), 0, 0
+    for count in range(50000, 200000, 500):
+        overflowed += count > cap
+        new = _next_capacity(cap, count)
+        resized += new != cap
+        cap = new
+    assert overflowed == 0 and 0 < resized < 12
