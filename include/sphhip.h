@@ -334,6 +334,14 @@ int sph_halo_pack_mirror(sph_ctx *ctx, int array_id, int side, int nprops, const
 /* Append `count` ghost particles (tag Remote: sources only) behind the
  * current ones from a device buffer laid out [nprops][count].  n grows,
  * n_real is unchanged.  Drop them again with sph_array_resize(n_real).      */
+/* Local images in ONE step (periodic / mirror ghosts of a single-rank domain,
+ * CPUDomainManager._create_ghosts_periodic / _mirror, nnps_base.pyx:506-940):
+ * the particles selected for `side` are appended behind the array as ghosts,
+ * mode 0: `axis` coordinate + val (periodic shift); mode 1: reflected about
+ * the plane `val`, normal velocity negated.  Equivalent to sph_halo_pack(_mirror)
+ * into a buffer followed by sph_halo_append of that buffer.  *count = images made. */
+int sph_halo_image(sph_ctx *ctx, int array_id, int side, int nprops, const int *props, int axis, int mode,
+                   double val, size_t *count);
 int sph_halo_append(sph_ctx *ctx, int array_id, int nprops, const int *props, const void *src_device,
                     size_t count);
 

@@ -204,6 +204,56 @@ extern "C" int sph_halo_append(sph_ctx *c, int id, int nprops, const int *props,
     return SPH_OK;
 }
 
+__global__ __launch_bounds__(256) void k_halo_image_multi(PropList L, const uint32_t *__restrict__ list, size_t count,
+                                                          double val, size_t n0)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int k = blockIdx.y, what = L.what[k];
+    const double v = L.p[k][list[i]];
+    // same arithmetic as k_halo_gather_multi (the image position must be bit-identical to the packed one)
+    L.p[k][n0 + i] = what == 1 ? v + val : (what == 2 ? v + 2.0 * (val - v) : (what == 3 ? -v : v));
+}
+
+extern "C" int sph_halo_image(sph_ctx *c, int id, int side, int nprops, const int *props, int axis, int mode, double val,
+                              size_t *count)
+{
+    if (!c || id < 0 || id >= SPH_MAX_ARRAYS || side < 0 || side > 1 || nprops < 1 || nprops > SPH_PROP_COUNT ||
+        axis < 0 || axis > 2 || mode < 0 || mode > 1) {
+        sph_set_error("sph_halo_image: bad arguments");
+        return SPH_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HaloState &H = c->halo[id];
+    const size_t cnt = H.count[side];
+    if (count) *count = cnt;
+    if (cnt == 0) return SPH_OK;
+    {
+        DevArray &A0 = c->arr[id];
+        if (H.nsel > A0.n) { sph_set_error("sph_halo_image: selection is stale"); return SPH_ERR_STATE; }
+        for (int k = 0; k < nprops; k++) {
+            int p = props[k];
+            if (p < 0 || p >= SPH_PROP_COUNT || !A0.prop[p]) {
+                sph_set_error("sph_halo_image: array %d has no device property %d", id, p);
+                return SPH_ERR_MISSING_PROP;
+            }
+        }
+    }
+    const size_t n0 = c->arr[id].n;
+    SPH_TRY(sph_array_resize(c, id, n0 + cnt, c->arr[id].n_real)); // may move the property buffers
+    DevArray &A = c->arr[id];
+    PropList L;
+    for (int k = 0; k < nprops; k++) {
+        const int p = props[k];
+        L.p[k] = A.prop[p];
+        L.what[k] = mode == 0 ? (p == SPH_X + axis ? 1 : 0) : (p == SPH_X + axis ? 2 : (p == SPH_U + axis ? 3 : 0));
+    }
+    hipLaunchKernelGGL(k_halo_image_multi, dim3(div_up(cnt, 256), nprops), dim3(256), 0, c->stream, L,
+                       H.list[side].as<uint32_t>(), cnt, val, n0);
+    c->nnps_valid = false;
+    return SPH_OK;
+}
+
 __global__ __launch_bounds__(256) void k_keep_flags(const unsigned long long *__restrict__ fl, size_t nsel, size_t n,
                                                     uint32_t *__restrict__ keep)
 {

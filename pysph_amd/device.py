@@ -82,6 +82,8 @@ SIGNATURES = {
                                 C.POINTER(C.c_int), C.c_int, C.c_double, _P]),
     'sph_halo_pack_mirror': (C.c_int, [_P, C.c_int, C.c_int, C.c_int,
                                        C.POINTER(C.c_int), C.c_int, C.c_double, _P]),
+    'sph_halo_image': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int,
+                                 C.c_double, C.POINTER(C.c_size_t)]),
     'sph_halo_append': (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int),
                                   _P, C.c_size_t]),
     'sph_halo_remove_selected': (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),

@@ -17,8 +17,9 @@ Two implementations with the same interface:
   reference does it (``Integrator.update_domain`` -> ``nnps.update_domain()``);
 * ``HipDomainManager``  device-resident state (``sync='manual'``): the same
   steps run as HIP kernels through ``sph_domain_box_wrap`` /
-  ``sph_halo_select(mode=1)`` / ``sph_halo_pack`` / ``sph_halo_append`` -- the
-  ghost copy is the multi-GPU halo copy with a coordinate shift.
+  ``sph_halo_select(mode=1)`` / ``sph_halo_image`` -- the ghost copy is the
+  multi-GPU halo copy (``sph_halo_pack`` + ``sph_halo_append``) with a
+  coordinate shift, done in place.
 
 Mirror (reflecting) boundaries (``mirror_in_x/y/z``,
 ``_create_ghosts_mirror`` :506-697) use the same machinery: every particle
@@ -196,8 +197,6 @@ class HipDomainManager(_DomainBase):
         cs = self.radius_scale * self._hmax()
         self.cell_size = 1.0 if cs < 1e-6 else cs
         width = self.n_layers * self.cell_size
-        import torch
-        device = torch.device('cuda', self.ctx.device)
         for h in self.helpers:
             for ax in range(3):
                 if self.periodic[ax] and ax != slab_axis:
@@ -219,22 +218,13 @@ class HipDomainManager(_DomainBase):
                 n_all = h.get_number_of_particles()
                 dev._check(lib.sph_halo_select(ctx, aid, ax, 1, lo, hi, width,
                                                n_all, counts))
-                bufs = []
+                # both sides were selected among the n_all particles present
+                # before either side's images exist (nnps_base.pyx:805-856)
                 for side, shift in ((0, self.translate[ax]),
                                     (1, -self.translate[ax])):
-                    cnt = int(counts[side])
-                    buf = torch.empty(max(cnt * nprops, 1), dtype=torch.float64,
-                                      device=device)
-                    if cnt:
-                        dev._check(lib.sph_halo_pack(
-                            ctx, aid, side, nprops, pr, ax, shift,
-                            C.c_void_p(buf.data_ptr())))
-                    bufs.append((buf, cnt))
-                for buf, cnt in bufs:
-                    if cnt:
-                        dev._check(lib.sph_halo_append(
-                            ctx, aid, nprops, pr, C.c_void_p(buf.data_ptr()),
-                            cnt))
+                    if counts[side]:
+                        dev._check(lib.sph_halo_image(ctx, aid, side, nprops, pr, ax,
+                                                      0, shift, None))
             for ax in range(3):
                 if not self.mirror[ax]:
                     continue
@@ -243,18 +233,7 @@ class HipDomainManager(_DomainBase):
                 n_all = h.get_number_of_particles()
                 dev._check(lib.sph_halo_select(ctx, aid, ax, 1, lo, hi, width,
                                                n_all, counts))
-                bufs = []
                 for side, plane in ((0, lo), (1, hi)):
-                    cnt = int(counts[side])
-                    buf = torch.empty(max(cnt * nprops, 1), dtype=torch.float64,
-                                      device=device)
-                    if cnt:
-                        dev._check(lib.sph_halo_pack_mirror(
-                            ctx, aid, side, nprops, pr, ax, plane,
-                            C.c_void_p(buf.data_ptr())))
-                    bufs.append((buf, cnt))
-                for buf, cnt in bufs:
-                    if cnt:
-                        dev._check(lib.sph_halo_append(
-                            ctx, aid, nprops, pr, C.c_void_p(buf.data_ptr()),
-                            cnt))
+                    if counts[side]:
+                        dev._check(lib.sph_halo_image(ctx, aid, side, nprops, pr, ax,
+                                                      1, plane, None))
