@@ -113,7 +113,7 @@ struct sph_ctx {
     unsigned long long pack_epoch = 0;
     long pack_group = 0;    // 1 between the per-destination sph_eval_group calls of one host group (records shared)
     PackCache pack_cache[SPH_MAX_ARRAYS];
-    long wcsph_nr = 0;      // experiment: doubles per compact WCSPH record (10; 12/16 pad the stride)
+    long wcsph_nr = 0;      // profiling: doubles per compact WCSPH record (default 10; 12/14/16 pad the stride)
     long lds_pad = 0;       // profiling: extra dynamic LDS per pair-kernel workgroup (limits wavefronts per CU)
     int cur_nrec = 0;       // doubles per packed record of the pair launch being set up
     long block_sorted_outputs = 0;
