@@ -301,6 +301,21 @@ def cpu_baseline(n1=100, target_seconds=15.0):
                       'schedule(dynamic,64), %d threads)' % (n1, n, reps, cores)}
 
 
+def field_error(a, b, scale_fields):
+    """max|a-b| / max|b|, the components of one vector (`scale_fields`) sharing
+    their scale -- a component that vanishes by symmetry, the y force of a
+    lattice, has no scale of its own; absolute when the scale is zero.  A NaN or
+    Inf anywhere in `a` is the worst possible error (a NaN never compares
+    greater, so it must not reach the comparison)."""
+    scale = max([float(np.max(np.abs(g))) for g in scale_fields if g.size] + [0.0])
+    if a.size == 0:
+        return 0.0
+    if not np.all(np.isfinite(a)):
+        return 1e300
+    err = float(np.max(np.abs(a))) if scale == 0.0 else float(np.max(np.abs(a - b)) / scale)
+    return err if np.isfinite(err) else 1e300
+
+
 def parity_check(w, host_in, nnps, domain, tol=PARITY_TOL):
     """Device results of the state the timed loop ran on vs the CPU oracle on
     the SAME inputs (tests/ and this leg are the only users of oracle/): every
@@ -332,19 +347,8 @@ def parity_check(w, host_in, nnps, domain, tol=PARITY_TOL):
         for f in w.fields:
             if f not in pa.properties or f not in pr.properties:
                 continue
-            a = np.asarray(pa.get(f))[:nreal]
-            b = np.asarray(pr.get(f))[:nreal]
-            # max|a-b| / max|b|, the components of one vector sharing their
-            # scale (a component that vanishes by symmetry -- the y force of a
-            # lattice -- has no scale of its own)
-            scale = max([float(np.max(np.abs(np.asarray(pr.get(g))[:nreal])))
-                         for g in _scale_group(f) if g in pr.properties] + [0.0])
-            if scale == 0.0:
-                err = float(np.max(np.abs(a)))
-            else:
-                err = float(np.max(np.abs(a - b)) / scale)
-            if not (np.all(np.isfinite(a)) and np.isfinite(err)):
-                err = 1e300             # a NaN never compares greater: make it the worst case
+            err = field_error(np.asarray(pa.get(f))[:nreal], np.asarray(pr.get(f))[:nreal],
+                              [np.asarray(pr.get(g))[:nreal] for g in _scale_group(f) if g in pr.properties])
             if err > worst:
                 worst, worst_field = err, '%s.%s' % (pa.name, f)
     out = {'parity_max_rel': worst, 'parity_worst_field': worst_field,

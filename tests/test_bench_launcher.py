@@ -44,3 +44,23 @@ def test_launch_command_shape():
     assert cmd[cmd.index('--nproc-per-node') + 1] == '8'
     assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
     assert cmd[-4:] == ['--gpus', '8', '--steps', '3'] and cmd[-5].endswith('bench.py')
+
+
+def test_field_error_treats_nan_as_failure():
+    """the bench's own parity check: a NaN in the device result must not pass as
+    'no error found' (np.max of NaN never compares greater than the running max)"""
+    import numpy as np
+    import bench
+    b = np.array([1.0, -2.0, 0.5])
+    assert bench.field_error(b.copy(), b, [b]) == 0.0
+    a = b.copy(); a[1] += 2e-9
+    assert abs(bench.field_error(a, b, [b]) - 1e-9) < 1e-12
+    a[0] = np.nan
+    assert bench.field_error(a, b, [b]) == 1e300
+    a[0] = np.inf
+    assert bench.field_error(a, b, [b]) == 1e300
+    # a component that vanishes by symmetry borrows the scale of its vector
+    z = np.zeros(3)
+    assert bench.field_error(z + 1e-12, z, [z, b]) == 1e-12 / 2.0
+    assert bench.field_error(z + 1e-12, z, [z]) == 1e-12       # no scale at all: absolute
+    assert bench.field_error(np.zeros(0), np.zeros(0), []) == 0.0
