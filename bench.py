@@ -48,6 +48,8 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X fp64 vector (non-MFMA) peak
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 L2_PEAK_TBS = 34.5           # MI355X_MICROARCH.md, L2 section: aggregate L2 bandwidth of the 8 XCDs
 PARITY_TOL = 1e-10           # BASELINE.json north_star
+PAIR_FAMILIES = ('pair_wcsph', 'pair_density', 'pair_tvf', 'pair_vgrad', 'pair_elastic')
+ELEMENTWISE_FLOOR = 1e-6     # element-wise parity: |b_i| floored at this fraction of the field's scale
 
 
 # ---------------------------------------------------------------------------
@@ -111,6 +113,49 @@ def make_taylor_green(n1, x_offset=0.0):
     return pa, dx
 
 
+def make_rings3d(dx, spacing=0.041, seed=7):
+    """S-rings3d of SURVEY.md 8(d) (BASELINE config 5): the colliding rings of
+    pysph/examples/solid_mech/rings.py:20-80 taken to 3-D -- two hollow spheres
+    (inner radius 0.03, outer 0.04) on a lattice, centres 2 x `spacing` apart
+    along x, ONE particle array, CubicSpline hdx 1.5, E 1e7, nu 0.3975, rho0 1,
+    approaching each other with u = +-0.059 cs.  dx = 5.372e-4 gives 2.0 M
+    particles.  The reference starts from the stress-free state, where every
+    rate but the velocity-gradient one vanishes inside a body; a seeded
+    perturbation (rho +-1 %, velocities +-0.01 cs on top of the approach
+    speed, deviatoric stresses +-1e-3 E) makes every term of the equation set
+    act, tension included (the artificial-stress eigen-decomposition)."""
+    from pysph_amd import kernels as K
+    from pysph_amd.solid_mech import get_particle_array_elastic_dynamics
+    E, nu, rho0, hdx = 1e7, 0.3975, 1.0, 1.5     # rings.py:21-28
+    ri, ro = 0.03, 0.04                           # rings.py:31-32
+    g = np.arange(-ro, ro, dx)                    # numpy.mgrid[-ro:ro:dx], rings.py:42
+    x, y, z = [a.ravel() for a in np.meshgrid(g, g, g, indexing='ij')]
+    d = x * x + y * y + z * z
+    keep = np.flatnonzero((ri * ri <= d) & (d < ro * ro))
+    x, y, z = x[keep], y[keep], z[keep]
+    side = np.concatenate([np.ones(x.size), -np.ones(x.size)])   # +1: left body, moving right
+    x = np.concatenate([x - spacing, x + spacing])
+    y = np.concatenate([y, y])
+    z = np.concatenate([z, z])
+    n = x.size
+    kernel = K.CubicSpline(dim=3)
+    h0 = hdx * dx
+    rng = np.random.default_rng(seed)
+    pa = get_particle_array_elastic_dynamics(
+        name='solid', x=x + spacing, y=y, z=z, h=h0 * np.ones(n),
+        m=rho0 * dx ** 3 * np.ones(n), rho=rho0 * (1 + 0.01 * rng.uniform(-1, 1, n)),
+        constants=dict(E=E, nu=nu, rho_ref=rho0, n=4,
+                       wdeltap=float(kernel.kernel(rij=dx, h=h0))))
+    cs = float(pa.cs[0])
+    pa.u[:] = cs * 0.059 * side + 0.01 * cs * rng.uniform(-1, 1, n)   # rings.py:76-77
+    pa.v[:] = 0.01 * cs * rng.uniform(-1, 1, n)
+    pa.w[:] = 0.01 * cs * rng.uniform(-1, 1, n)
+    for c in ('s00', 's01', 's02', 's11', 's12', 's22'):
+        pa.get(c)[:] = 1e-3 * E * rng.uniform(-1, 1, n)
+    pa.gid[:] = np.arange(n, dtype=pa.gid.dtype)
+    return pa, kernel
+
+
 def make_elastic(n1):
     from pysph_amd import kernels as K
     from pysph_amd.solid_mech import get_particle_array_elastic_dynamics
@@ -134,7 +179,8 @@ class Workload(object):
     """particle arrays + equations + kernel (+ periodic domain) of one rank"""
     domain_kw = None      # HipDomainManager arguments (periodic workloads)
     scaling = 'weak'
-    algo_pair = ALGO_BYTES_PAIR
+    algo_pair = ALGO_BYTES_PAIR   # algorithmic bytes of the pair passes of one evaluation, per real particle of arrays[0]
+    algo_solid = 0.0              # ... per particle of the other arrays (dam break: boundary, obstacle)
     fields = ()           # output properties the parity checks compare
     slab = None           # (lo, hi, periodic, period) of this rank's slab
     halo_width = 0.0
@@ -200,6 +246,8 @@ def build_workload(args, rank, world):
             dx, ', '.join('%s %d' % (a.name, a.get_number_of_particles())
                           for a in arrays)))
         w.halo_width = w.kernel.radius_scale * 1.3 * dx
+        # solids <- fluid continuity: x,y,z,h,u,v,w read (56 B), arho written (8 B): SURVEY 8(d)
+        w.algo_solid = 64.0
         w.slab = (lo, hi, False, 0.0)
         w.fields = ('arho', 'au', 'av', 'aw', 'ax', 'ay', 'az', 'p', 'cs')
     elif args.workload == 'taylor_green':
@@ -213,7 +261,8 @@ def build_workload(args, rank, world):
         # unit cube per rank, periodic box [0, world] x [0,1] x [0,1]
         w.domain_kw = dict(xmin=0, xmax=float(world), ymin=0, ymax=1, zmin=0, zmax=1,
                            periodic_in_x=True, periodic_in_y=True, periodic_in_z=True)
-        w.algo_pair = 160.0   # force pass: 112 R + 48 W (SURVEY 8d TVF pass 2)
+        # density pass 40 R + 16 W, force pass 112 R + 48 W (TVF passes 1 and 2)
+        w.algo_pair = 216.0
         w.name = ('Taylor-Green 3D TVF (taylor_green.py parameters), periodic unit '
                   'cube %d^3 = %d particles per GPU, QuinticSpline hdx 1.0' % (
                       n1, pa.get_number_of_particles()))
@@ -233,6 +282,26 @@ def build_workload(args, rank, world):
             # property of the formulation in fp32, not of this kernel; only the
             # density sum is comparable.
             w.fields = ('rho', 'V')
+    elif args.workload == 'elastic':
+        from pysph_amd.solid_mech import ElasticSolidsScheme
+        if world > 1:
+            raise SystemExit('elastic workload: single GPU only (DESIGN.md section 6)')
+        spacing = args.rings_spacing if args.rings_spacing > 0 else 0.041
+        pa, kernel = make_rings3d(args.rings_dx, spacing=spacing)
+        w.arrays = [pa]
+        w.kernel = kernel
+        w.eqs = ElasticSolidsScheme(['solid'], [], dim=3).get_equations()
+        # velocity-gradient pass: x,y,z,h,u,v,w,m,rho read (72 B), v00..v22 written (72 B);
+        # rates pass: x,y,z,h,u,v,w,m,rho,cs,p,s_ij,r_ij read (184 B), arho,au..aw,ax..az written (56 B)
+        w.algo_pair = 144.0 + 240.0
+        w.name = ('S-rings3d: two hollow spheres (ri 0.03, ro 0.04, centres %g apart), '
+                  'Gray 2001 elastic set, rings.py material and approach speed, '
+                  'CubicSpline hdx 1.5, dx %g: %d particles' % (
+                      2 * spacing, args.rings_dx, pa.get_number_of_particles()))
+        w.fields = ('arho', 'au', 'av', 'aw', 'ax', 'ay', 'az', 'p',
+                    'as00', 'as01', 'as02', 'as11', 'as12', 'as22',
+                    'v00', 'v01', 'v02', 'v10', 'v11', 'v12', 'v20', 'v21', 'v22',
+                    'r00', 'r01', 'r02', 'r11', 'r12', 'r22')
     else:
         from pysph_amd.solid_mech import ElasticSolidsScheme
         if world > 1:
@@ -244,7 +313,7 @@ def build_workload(args, rank, world):
         w.arrays = [pa]
         w.kernel = kernel
         w.eqs = ElasticSolidsScheme(['solid'], [], dim=3).get_equations()
-        w.algo_pair = 8.0 * (22 + 7)
+        w.algo_pair = 144.0 + 240.0
         w.name = ('Elastic solid block (Gray 2001 equation set, rings.py material), '
                   '%d^3 = %d particles, CubicSpline hdx 1.3' % (n1, pa.get_number_of_particles()))
         w.fields = ('arho', 'au', 'av', 'aw', 'ax', 'ay', 'az', 'p',
@@ -301,27 +370,41 @@ def cpu_baseline(n1=100, target_seconds=15.0):
                       'schedule(dynamic,64), %d threads)' % (n1, n, reps, cores)}
 
 
-def field_error(a, b, scale_fields):
+def field_error(a, b, scale_fields, elementwise=False):
     """max|a-b| / max|b|, the components of one vector (`scale_fields`) sharing
     their scale -- a component that vanishes by symmetry, the y force of a
     lattice, has no scale of its own; absolute when the scale is zero.  A NaN or
     Inf anywhere in `a` is the worst possible error (a NaN never compares
-    greater, so it must not reach the comparison)."""
+    greater, so it must not reach the comparison).
+
+    `elementwise`: also the stricter element-wise figure
+    max_i |a_i - b_i| / max(|b_i|, 1e-6 max|b|) -- every particle judged against
+    its OWN value, floored at a millionth of the field's scale (a sum that
+    cancels to nothing has no relative accuracy in any summation order);
+    returns the pair (norm-wise, element-wise)."""
     scale = max([float(np.max(np.abs(g))) for g in scale_fields if g.size] + [0.0])
     if a.size == 0:
-        return 0.0
+        return (0.0, 0.0) if elementwise else 0.0
     if not np.all(np.isfinite(a)):
-        return 1e300
-    err = float(np.max(np.abs(a))) if scale == 0.0 else float(np.max(np.abs(a - b)) / scale)
-    return err if np.isfinite(err) else 1e300
+        return (1e300, 1e300) if elementwise else 1e300
+    d = np.abs(a - b)
+    err = float(np.max(np.abs(a))) if scale == 0.0 else float(np.max(d) / scale)
+    err = err if np.isfinite(err) else 1e300
+    if not elementwise:
+        return err
+    if scale == 0.0:
+        return err, err
+    ew = float(np.max(d / np.maximum(np.abs(b), ELEMENTWISE_FLOOR * scale)))
+    return err, (ew if np.isfinite(ew) else 1e300)
 
 
 def parity_check(w, host_in, nnps, domain, tol=PARITY_TOL):
     """Device results of the state the timed loop ran on vs the CPU oracle on
     the SAME inputs (tests/ and this leg are the only users of oracle/): every
-    output field, max|a-b| / max|b| per field, plus the neighbour COUNT of every
-    destination (exact).  `host_in`: pristine host copies of the inputs in the
-    device's particle order."""
+    output field, norm-wise (max|a-b| / max|b| per field) AND element-wise
+    (`field_error`), plus the neighbour COUNT of every real destination (exact;
+    periodic workloads: ghosts count as sources on both sides).  `host_in`:
+    pristine host copies of the inputs in the device's particle order."""
     from oracle import oracle as orc
     ref = host_in
     nt = _host_threads()
@@ -339,6 +422,7 @@ def parity_check(w, host_in, nnps, domain, tol=PARITY_TOL):
     oev.compute(0.0, 1e-5)
     t_oracle = time.perf_counter() - t0
     worst, worst_field = 0.0, None
+    worst_ew, worst_ew_field = 0.0, None
     for pa, pr in zip(w.arrays, ref):
         nreal = pr.get_number_of_particles(True)
         if nreal == 0:
@@ -347,33 +431,48 @@ def parity_check(w, host_in, nnps, domain, tol=PARITY_TOL):
         for f in w.fields:
             if f not in pa.properties or f not in pr.properties:
                 continue
-            err = field_error(np.asarray(pa.get(f))[:nreal], np.asarray(pr.get(f))[:nreal],
-                              [np.asarray(pr.get(g))[:nreal] for g in _scale_group(f) if g in pr.properties])
+            err, ew = field_error(
+                np.asarray(pa.get(f))[:nreal], np.asarray(pr.get(f))[:nreal],
+                [np.asarray(pr.get(g))[:nreal] for g in _scale_group(f) if g in pr.properties],
+                elementwise=True)
             if err > worst:
                 worst, worst_field = err, '%s.%s' % (pa.name, f)
+            if ew > worst_ew:
+                worst_ew, worst_ew_field = ew, '%s.%s' % (pa.name, f)
     out = {'parity_max_rel': worst, 'parity_worst_field': worst_field,
+           'parity_elementwise_max_rel': worst_ew,
+           'parity_elementwise_worst_field': worst_ew_field,
+           'parity_elementwise_floor': ELEMENTWISE_FLOOR,
            'parity_tolerance': tol, 'parity_ok': bool(worst < tol),
            'parity_oracle_seconds': t_oracle, 'parity_oracle_threads': nt}
-    if domain is None:
-        # neighbour counts of every destination, exact (the oracle's criterion
-        # is the reference's, linked_list_nnps.pyx:176-184)
-        mism = 0
-        for di in range(len(w.arrays)):
-            for si in range(len(w.arrays)):
-                if w.arrays[di].get_number_of_particles() == 0 or \
-                        w.arrays[si].get_number_of_particles() == 0:
-                    continue
-                start = nnps.get_csr_start(si, di)
-                ostart = onn.count_csr(si, di, nthreads=nt)
-                n = min(start.size, ostart.size)
-                mism += int(np.count_nonzero(start[:n] != ostart[:n])) + abs(start.size - ostart.size)
-        out['parity_neighbour_count_mismatches'] = mism
-        out['parity_ok'] = bool(out['parity_ok'] and mism == 0)
+    # neighbour counts of every REAL destination, exact (the oracle's criterion
+    # is the reference's, linked_list_nnps.pyx:176-184); sources are all
+    # particles of the source array -- with a periodic domain that includes the
+    # ghost images, whose ORDER differs between the host and the device domain
+    # managers while their set does not (tests/test_ghost_sets.py)
+    mism = 0
+    for di in range(len(w.arrays)):
+        nreal = ref[di].get_number_of_particles(True)
+        for si in range(len(w.arrays)):
+            if w.arrays[di].get_number_of_particles() == 0 or \
+                    w.arrays[si].get_number_of_particles() == 0:
+                continue
+            start = np.asarray(nnps.get_csr_start(si, di))
+            ostart = np.asarray(onn.count_csr(si, di, nthreads=nt))
+            if start.size <= nreal or ostart.size <= nreal:
+                mism += nreal
+                continue
+            mism += int(np.count_nonzero(np.diff(start[:nreal + 1].astype(np.int64)) !=
+                                         np.diff(ostart[:nreal + 1].astype(np.int64))))
+    out['parity_neighbour_count_mismatches'] = mism
+    out['parity_ok'] = bool(out['parity_ok'] and mism == 0)
     return out
 
 
 _VECTORS = (('au', 'av', 'aw', 'auhat', 'avhat', 'awhat'), ('ax', 'ay', 'az'),
-            ('as00', 'as01', 'as02', 'as11', 'as12', 'as22'))
+            ('as00', 'as01', 'as02', 'as11', 'as12', 'as22'),
+            ('v00', 'v01', 'v02', 'v10', 'v11', 'v12', 'v20', 'v21', 'v22'),
+            ('r00', 'r01', 'r02', 'r11', 'r12', 'r22'))
 
 
 def _scale_group(f):
@@ -397,8 +496,14 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--n1', type=int, default=159, help='lattice side per GPU')
     ap.add_argument('--workload', default='cube',
-                    choices=['cube', 'dam_break', 'taylor_green', 'elastic'],
-                    help='cube = S-cube WCSPH (headline); others: BASELINE configs 2/3/5')
+                    choices=['cube', 'dam_break', 'taylor_green', 'elastic', 'elastic_block'],
+                    help='cube = S-cube WCSPH (headline); dam_break / taylor_green / elastic (= S-rings3d): '
+                         'BASELINE configs 2/3/5; elastic_block: a solid block, hdx 1.3 (round-2 stand-in)')
+    ap.add_argument('--rings-dx', type=float, default=5.372e-4, dest='rings_dx',
+                    help='elastic workload: lattice spacing (5.372e-4: 2.0 M particles)')
+    ap.add_argument('--rings-spacing', type=float, default=0.0, dest='rings_spacing',
+                    help='elastic workload: half the distance of the centres (default 0.041, rings.py:34; '
+                         '0.04 + dx puts the bodies in contact)')
     ap.add_argument('--params', default='db', choices=['db', 'cube'],
                     help='cube workload: dam_break_3d.py or cube.py parameter set')
     ap.add_argument('--hdx', type=float, default=0.0)
@@ -569,7 +674,7 @@ def timed(steps, warmup, step, barrier, ctx):
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.timer_enable(False)
-    timers = {k: ctx.timer_get(k) for k in ('nnps', 'pack', 'eos', 'pair')}
+    timers = {k: ctx.timer_get(k) for k in ('nnps', 'pack', 'eos', 'pair') + PAIR_FAMILIES}
     return elapsed, timers
 
 
@@ -652,14 +757,16 @@ def run(args, rank, local_rank, world, dist):
     pair_step_s = pair_ms / args.steps * 1e-3
     bytes_scale = 0.5 if args.dtype == 'f32' else 1.0
     algo_pair = w.algo_pair * bytes_scale
-    achieved = algo_pair * n_local / pair_step_s / 1e9 if pair_step_s > 0 else 0.0
+    n_first = w.arrays[0].get_number_of_particles(True)
+    algo_bytes = algo_pair * n_first + w.algo_solid * bytes_scale * (n_local - n_first)
+    achieved = algo_bytes / pair_step_s / 1e9 if pair_step_s > 0 else 0.0
     fam = {'cube': 'FamWCSPH', 'dam_break': 'FamWCSPH', 'taylor_green': 'FamDensity+FamTVF',
-           'elastic': 'FamVGrad+FamElastic'}[args.workload]
+           'elastic': 'FamVGrad+FamElastic', 'elastic_block': 'FamVGrad+FamElastic'}[args.workload]
     valu_peak = FP64_VECTOR_PEAK_TFLOPS * (2.0 if args.dtype == 'f32' else 1.0)
     out = {
         'metric': 'particle-updates/sec (nnps.update + AccelerationEval.compute), '
                   '%s 3D, %s' % ({'cube': 'WCSPH', 'dam_break': 'WCSPH', 'taylor_green': 'TVF',
-                                  'elastic': 'elastic'}[args.workload],
+                                  'elastic': 'elastic', 'elastic_block': 'elastic'}[args.workload],
                                  'fp64' if args.dtype == 'f64' else 'fp32'),
         'value': value, 'unit': 'particle-updates/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup,
@@ -690,7 +797,8 @@ def run(args, rank, local_rank, world, dist):
                 'peak': L2_PEAK_TBS, 'unit': 'TB/s', 'frac': l1_fill / pair_avg_s / 1e12 / L2_PEAK_TBS,
                 'source': 'TCP_TCC_READ_REQ x 128 B of the profiled run (profiles/), this run\'s kernel time'},
         },
-        'kernel_ms_per_step': {k: v[0] / args.steps for k, v in timers.items()},
+        'kernel_ms_per_step': {k: v[0] / args.steps for k, v in timers.items() if k not in PAIR_FAMILIES},
+        'pair_ms_per_family': family_ms(timers, args.steps),
         'fp64_valu': None if not pairs else {
             'pairs_per_launch': pairs,
             'flop_per_pair': FLOP_PER_PAIR,
@@ -719,22 +827,39 @@ def run(args, rank, local_rank, world, dist):
     return out
 
 
+def family_ms(timers, steps):
+    """pair-kernel ms per step of every equation family that ran"""
+    return {k[5:]: v[0] / steps for k, v in timers.items()
+            if k in PAIR_FAMILIES and v[1] > 0}
+
+
 def secondary_runs(args, local_rank, tstream):
-    """The configurations BASELINE.md section 4 quotes next to the headline, measured in
-    the same invocation (fewer steps each): other sizes, particles NOT
-    spatially ordered, variable h, the reference's "cube" parameterisation."""
+    """The other BASELINE configurations AS SPECIFIED, each
+    measured in this same invocation and checked against the oracle on the
+    state it ran on -- C2 dam break (dx 0.0087, 1 M fluid), the dam break at
+    dx 0.0055 (4.06 M fluid: the size BASELINE's `metric` names), C3
+    Taylor-Green 159^3 periodic TVF, C5 S-rings3d 2 M in fp32 (as named) and
+    fp64 --, then the timing-only variants of the headline cube BASELINE.md
+    section 4 quotes (other sizes, unsorted, variable h, cube.py parameters).
+    Every checked entry carries ms_per_step, the pair-kernel ms per equation
+    family, its own algorithmic-bytes roofline fraction and parity_max_rel."""
     import copy
     import torch
     from pysph_amd import device as dev
     res = {}
     cases = [
-        ('100^3', dict(n1=100)),
-        ('252^3', dict(n1=252)),
-        ('159^3 unsorted', dict(no_reorder=True)),
-        ('159^3 h +-15%', dict(vary_h=0.15)),
-        ('159^3 cube.py parameters (CubicSpline, hdx 1.5, alpha 0.5, c0 10)', dict(params='cube')),
+        ('C2 dam break dx 0.0087', dict(workload='dam_break', dx=0.0087), True),
+        ('dam break dx 0.0055 (4 M fluid)', dict(workload='dam_break', dx=0.0055), True),
+        ('C3 Taylor-Green 159^3 TVF', dict(workload='taylor_green', n1=159), True),
+        ('C5 S-rings3d 2 M fp32', dict(workload='elastic', dtype='f32'), True),
+        ('C5 S-rings3d 2 M fp64', dict(workload='elastic'), True),
+        ('100^3', dict(n1=100), False),
+        ('252^3', dict(n1=252), False),
+        ('159^3 unsorted', dict(no_reorder=True), False),
+        ('159^3 h +-15%', dict(vary_h=0.15), False),
+        ('159^3 cube.py parameters (CubicSpline, hdx 1.5, alpha 0.5, c0 10)', dict(params='cube'), False),
     ]
-    for name, kw in cases:
+    for name, kw, check in cases:
         a2 = copy.copy(args)
         steps, warmup = max(3, args.steps // 4), 2
         for k, v in kw.items():
@@ -744,13 +869,38 @@ def secondary_runs(args, local_rank, tstream):
         try:
             w = build_workload(a2, 0, 1)
             nnps, a_eval, halo, domain, step, ordered = setup(a2, w, 0, 1, None, ctx)
+            host_in = None
+            if check:
+                for a in w.arrays:
+                    a.gpu.pull()
+                host_in = copy_arrays(w.arrays)
             elapsed, timers = timed(steps, warmup, step, torch.cuda.synchronize, ctx)
-            n = sum(a.get_number_of_particles() for a in w.arrays)
-            res[name] = {'particles': n, 'ms_per_step': elapsed / steps * 1e3,
-                         'particle_updates_per_s': n * steps / elapsed,
-                         'pair_ms_per_step': timers['pair'][0] / steps,
-                         'steps': steps}
-            del nnps, a_eval, step, w
+            n = sum(a.get_number_of_particles(True) for a in w.arrays)
+            n_fluid = w.arrays[0].get_number_of_particles(True)
+            pair_step_s = timers['pair'][0] / steps * 1e-3
+            scale = 0.5 if a2.dtype == 'f32' else 1.0
+            algo = w.algo_pair * scale
+            algo_bytes = algo * n_fluid + w.algo_solid * scale * (n - n_fluid)
+            achieved = algo_bytes / pair_step_s / 1e9 if pair_step_s > 0 else 0.0
+            r = {'workload': w.name, 'dtype': a2.dtype, 'particles': n,
+                 'ms_per_step': elapsed / steps * 1e3,
+                 'particle_updates_per_s': n * steps / elapsed,
+                 'pair_ms_per_step': timers['pair'][0] / steps,
+                 'pair_ms_per_family': family_ms(timers, steps),
+                 'kernel_ms_per_step': {k: timers[k][0] / steps for k in ('nnps', 'pack', 'eos', 'pair')},
+                 'roofline': {'algorithmic_bytes_per_particle': algo,
+                              'algorithmic_bytes_per_evaluation': algo_bytes,
+                              'achieved_GBs': achieved, 'frac': achieved / HBM_PEAK_GBS},
+                 'steps': steps}
+            if check:
+                tol = PARITY_TOL if a2.dtype == 'f64' else 5e-5
+                pc = parity_check(w, host_in, nnps, domain, tol)
+                for k in ('parity_max_rel', 'parity_worst_field', 'parity_elementwise_max_rel',
+                          'parity_elementwise_worst_field', 'parity_tolerance',
+                          'parity_neighbour_count_mismatches', 'parity_ok'):
+                    r[k] = pc[k]
+            res[name] = r
+            del nnps, a_eval, step, w, host_in
         except Exception as e:         # a secondary number must not lose the headline
             res[name] = {'error': '%s: %s' % (type(e).__name__, e)}
         finally:
@@ -839,7 +989,7 @@ def multi_rank_parity(args, rank, local_rank, world, dist, tstream):
         ctx1.close()
     dist.all_reduce(worst, op=dist.ReduceOp.MAX)
     val = float(worst.item())
-    if val > 1e-9:
+    if val > PARITY_TOL:
         raise SystemExit('1-vs-%d-rank parity check failed: max relative difference %g' % (world, val))
     return val
 

@@ -409,7 +409,9 @@ int sph_set_option(sph_ctx *ctx, const char *key, long value);
 /* ---------------------------------------------------------------------- */
 int sph_timer_enable(sph_ctx *ctx, int on);
 int sph_timer_reset(sph_ctx *ctx);
-/* keys: "nnps", "pack", "eos", "pair", "stage"; out: total ms and launches */
+/* keys: "nnps", "pack", "eos", "pair", "stage"; the pair launches once more per
+ * equation family: "pair_wcsph", "pair_density", "pair_tvf", "pair_vgrad",
+ * "pair_elastic"; out: total ms and launches */
 int sph_timer_get(sph_ctx *ctx, const char *key, double *ms, long *count);
 
 #ifdef __cplusplus

@@ -306,7 +306,8 @@ int sph_timer_reset(sph_ctx *c)
 
 int sph_timer_get(sph_ctx *c, const char *key, double *ms, long *count)
 {
-    static const char *names[T_COUNT] = {"nnps", "pack", "eos", "pair", "stage"};
+    static const char *names[T_COUNT] = {"nnps", "pack", "eos", "pair", "stage",
+                                         "pair_none", "pair_wcsph", "pair_density", "pair_tvf", "pair_vgrad", "pair_elastic"};
     SPH_TRY(timer_drain(c));
     for (int i = 0; i < T_COUNT; i++)
         if (strcmp(key, names[i]) == 0) {

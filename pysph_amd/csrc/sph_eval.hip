@@ -1177,6 +1177,15 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             ScopedTimer tm(c, T_PACK);
             // a source must hold what ITS equations read; the destination's own record what all of them read
             const int sig = pl.nr * 4 + (c->record_f32 ? 1 : 0) + (c->arith_f32 ? 2 : 0);
+            // The shared slots live in the same buffers every other unit packs into from offset 0:
+            // a unit that does not share (another family, a single-destination call), or one whose
+            // record layout differs from what the cache holds, overwrites them -- nothing cached survives.
+            bool keep = share;
+            if (share)
+                for (auto &pc : c->pack_cache)
+                    if (pc.epoch == c->pack_epoch && (pc.fam != fam || pc.sig != sig)) keep = false;
+            if (!keep)
+                for (auto &pc : c->pack_cache) pc.epoch = 0;
             auto pack_once = [&](int id, size_t off, uint32_t fl, bool dest_only) -> int {
                 PackCache &pc = c->pack_cache[id];
                 const bool hit = share && pc.epoch == c->pack_epoch && pc.fam == fam && pc.sig == sig;
@@ -1190,6 +1199,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
 
         // 4. fused pair kernel, in the arithmetic type of the context (fp64, or fp32 with option arith_f32)
         ScopedTimer tm(c, T_PAIR);
+        ScopedTimer tmf(c, T_PAIR_FAM + fam);
         // the part of the launch arguments every family shares
         auto common = [&](auto &a) {
             fill_common(c, a, K, t);
@@ -1473,6 +1483,7 @@ static int eval_generated_launches(sph_ctx *c, const sph_kernel *K, const sph_ge
             const int layout = c->record_f32 ? 5 : (compact ? 4 : 0);
             q.rec_f32 = c->record_f32 ? 1 : 0;
             SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * nr));
+            for (auto &pc : c->pack_cache) pc.epoch = 0; // the generated family's records overwrite the shared WCSPH slots
             SPH_TRY(c->aux.reserve(64));
             SPH_TRY(c->fposb.reserve((total + 64) * sizeof(float4)));
             {

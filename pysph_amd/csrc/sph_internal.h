@@ -61,7 +61,8 @@ struct HaloState {
     size_t nsel = 0; // particles the flags of the last sph_halo_select cover
 };
 
-enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_STAGE, T_COUNT };
+// T_PAIR: every pair launch; T_PAIR_FAM + family (sph_eval.hip enum Family): the same launches per equation family
+enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_STAGE, T_PAIR_FAM, T_COUNT = T_PAIR_FAM + 6 };
 
 struct Timer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;

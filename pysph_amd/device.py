@@ -182,8 +182,14 @@ class HipContext(object):
     def __init__(self, device=0, stream=None):
         self.lib = load_library()
         self._h = _P()
+        if isinstance(stream, C.c_void_p):
+            stream = stream.value
+        stream = int(stream) if stream else None
         _check(self.lib.sph_ctx_create(device, stream, C.byref(self._h)))
-        self.stream = stream        # the caller's HIP stream handle, or None: the library made its own
+        # the caller's HIP stream handle, or None: the library made its own.  A
+        # null handle (torch's legacy default stream reports 0) is NOT a shared
+        # stream: sph_ctx_create then creates a non-blocking stream of its own
+        self.stream = stream
         self.device = device
         self._ids = {}
 
@@ -503,10 +509,17 @@ class HipDeviceHelper(object):
             elif arr.dtype.kind in 'iu':
                 # integer metadata mirrored as doubles (gid of a slab-decomposed
                 # array: it migrates with its particle)
-                tmp = np.empty(n)
-                _check(self.lib.sph_array_pull(self.ctx._h, self.array_id, pid,
-                                               tmp.ctypes.data_as(_PD), 0, n))
-                arr[:n] = tmp.astype(arr.dtype)
+                # The ghost exchange does not carry it (sph_halo_append writes the
+                # listed fp64 properties only): rows >= nreal are uninitialised on
+                # the device and get the reference's "no gid" sentinel
+                # (UINT_MAX, particle_array.pyx) instead of a cast of garbage
+                tmp = np.empty(nreal)
+                if nreal:
+                    _check(self.lib.sph_array_pull(self.ctx._h, self.array_id, pid,
+                                                   tmp.ctypes.data_as(_PD), 0, nreal))
+                arr[:nreal] = tmp.astype(arr.dtype)
+                if n > nreal:
+                    arr[nreal:n] = np.iinfo(arr.dtype).max
 
     def max(self, prop):
         out = C.c_double()

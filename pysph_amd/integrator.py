@@ -409,3 +409,156 @@ def setup_integrator(integrator, a_evals, nnps, ctx=None):
     integrator.set_compiled_object(obj)
     integrator.set_nnps(nnps)
     return obj
+
+
+# ---------------------------------------------------------------------------
+# The reference's other explicit integrators and their steppers
+# (pysph/sph/integrator.py:426-517, pysph/sph/integrator_step.py:22-35,
+# 708-830).  The integrators are SEQUENCE data like PEC / EPEC above; the
+# steppers have no hand-written stage kernel: their stage methods below are
+# per-particle bodies that run as generated stage families (`stage_family`),
+# written as "kick" (velocities, density, energy by the rates) and "drift"
+# (positions by velocity + XSPH correction) with the weights of each scheme.
+# ---------------------------------------------------------------------------
+class EulerIntegrator(Integrator):
+    """Forward Euler: evaluate, then one full step (integrator.py:426-437)."""
+    SEQUENCE = ('accel', ('stage', 1, 1.0))
+
+
+class LeapFrogIntegrator(Integrator):
+    """Drift-kick-drift leap-frog: half drift, evaluate at t + dt/2, kick and
+    second half drift (integrator.py:464-477)."""
+    SEQUENCE = (('stage', 1, 0.5), 'accel', ('stage', 2, 1.0))
+
+
+class EulerStep(IntegratorStep):
+    """Forward-Euler stepper (integrator_step.py:22-35): kick, then drift with
+    the NEW velocity, then the density."""
+
+    def stage1(self, d_idx, d_x, d_y, d_z, d_u, d_v, d_w, d_au, d_av, d_aw,
+               d_rho, d_arho, dt):
+        un = d_u[d_idx] + dt * d_au[d_idx]
+        vn = d_v[d_idx] + dt * d_av[d_idx]
+        wn = d_w[d_idx] + dt * d_aw[d_idx]
+        d_u[d_idx] = un
+        d_v[d_idx] = vn
+        d_w[d_idx] = wn
+        d_x[d_idx] += dt * un
+        d_y[d_idx] += dt * vn
+        d_z[d_idx] += dt * wn
+        d_rho[d_idx] += dt * d_arho[d_idx]
+
+
+class LeapFrogStep(IntegratorStep):
+    """Stepper of `LeapFrogIntegrator` (integrator_step.py:708-730): positions
+    move with u + ax (XSPH-corrected velocity), half a step either side of the
+    kick."""
+
+    def stage1(self, d_idx, d_x, d_y, d_z, d_u, d_v, d_w, d_ax, d_ay, d_az, dt):
+        hdt = 0.5 * dt
+        d_x[d_idx] += hdt * (d_u[d_idx] + d_ax[d_idx])
+        d_y[d_idx] += hdt * (d_v[d_idx] + d_ay[d_idx])
+        d_z[d_idx] += hdt * (d_w[d_idx] + d_az[d_idx])
+
+    def stage2(self, d_idx, d_x, d_y, d_z, d_u, d_v, d_w, d_au, d_av, d_aw,
+               d_ax, d_ay, d_az, d_rho, d_arho, d_e, d_ae, dt):
+        hdt = 0.5 * dt
+        # kick
+        d_u[d_idx] += dt * d_au[d_idx]
+        d_v[d_idx] += dt * d_av[d_idx]
+        d_w[d_idx] += dt * d_aw[d_idx]
+        d_rho[d_idx] += dt * d_arho[d_idx]
+        d_e[d_idx] += dt * d_ae[d_idx]
+        # second half drift with the kicked velocity
+        d_x[d_idx] += hdt * (d_u[d_idx] + d_ax[d_idx])
+        d_y[d_idx] += hdt * (d_v[d_idx] + d_ay[d_idx])
+        d_z[d_idx] += hdt * (d_w[d_idx] + d_az[d_idx])
+
+
+# Omelyan, Mryglod & Folk, Comput. Phys. Commun. 146 (2002) 188, eq. (20)
+PEFRL_XI = 0.1786178958448091
+PEFRL_LAMBDA = -0.2123418310626054
+PEFRL_CHI = -0.06626458266981849
+
+
+class PEFRLIntegrator(Integrator):
+    """Position-extended Forest-Ruth-like, 4th order, four evaluations per step
+    (integrator.py:481-517).  The post-stage times are the cumulative drift
+    weights xi, xi + chi, 1 - (xi + chi), 1 - xi, 1."""
+    SEQUENCE = (('stage', 1, PEFRL_XI), 'accel',
+                ('stage', 2, PEFRL_XI + PEFRL_CHI), 'accel',
+                ('stage', 3, 1.0 - (PEFRL_XI + PEFRL_CHI)), 'accel',
+                ('stage', 4, 1.0 - PEFRL_XI), 'accel',
+                ('stage', 5, 1.0))
+
+
+class PEFRLStep(IntegratorStep):
+    """Stepper of `PEFRLIntegrator` (integrator_step.py:738-830): drifts with
+    weights (xi, chi, 1 - 2 (chi + xi), chi, xi), kicks in between with weights
+    ((1 - 2 lambda) / 2, lambda, lambda, (1 - 2 lambda) / 2).  The weights are
+    scalar attributes, frozen into the generated stage kernels at build time."""
+
+    def __init__(self):
+        self.xi = PEFRL_XI
+        self.lam = PEFRL_LAMBDA
+        self.chi = PEFRL_CHI
+        self.kick_outer = 0.5 * (1.0 - 2.0 * PEFRL_LAMBDA)
+        self.drift_mid = 1.0 - 2.0 * (PEFRL_CHI + PEFRL_XI)
+
+    def stage1(self, d_idx, d_x, d_y, d_z, d_u, d_v, d_w, d_ax, d_ay, d_az, dt):
+        wx = self.xi * dt
+        d_x[d_idx] += wx * (d_u[d_idx] + d_ax[d_idx])
+        d_y[d_idx] += wx * (d_v[d_idx] + d_ay[d_idx])
+        d_z[d_idx] += wx * (d_w[d_idx] + d_az[d_idx])
+
+    def stage2(self, d_idx, d_x, d_y, d_z, d_u, d_v, d_w, d_au, d_av, d_aw,
+               d_ax, d_ay, d_az, d_rho, d_arho, d_e, d_ae, dt):
+        wv = self.kick_outer * dt
+        wx = self.chi * dt
+        d_u[d_idx] += wv * d_au[d_idx]
+        d_v[d_idx] += wv * d_av[d_idx]
+        d_w[d_idx] += wv * d_aw[d_idx]
+        d_rho[d_idx] += wv * d_arho[d_idx]
+        d_e[d_idx] += wv * d_ae[d_idx]
+        d_x[d_idx] += wx * (d_u[d_idx] + d_ax[d_idx])
+        d_y[d_idx] += wx * (d_v[d_idx] + d_ay[d_idx])
+        d_z[d_idx] += wx * (d_w[d_idx] + d_az[d_idx])
+
+    def stage3(self, d_idx, d_x, d_y, d_z, d_u, d_v, d_w, d_au, d_av, d_aw,
+               d_ax, d_ay, d_az, d_rho, d_arho, d_e, d_ae, dt):
+        wv = self.lam * dt
+        wx = self.drift_mid * dt
+        d_u[d_idx] += wv * d_au[d_idx]
+        d_v[d_idx] += wv * d_av[d_idx]
+        d_w[d_idx] += wv * d_aw[d_idx]
+        d_rho[d_idx] += wv * d_arho[d_idx]
+        d_e[d_idx] += wv * d_ae[d_idx]
+        d_x[d_idx] += wx * (d_u[d_idx] + d_ax[d_idx])
+        d_y[d_idx] += wx * (d_v[d_idx] + d_ay[d_idx])
+        d_z[d_idx] += wx * (d_w[d_idx] + d_az[d_idx])
+
+    def stage4(self, d_idx, d_x, d_y, d_z, d_u, d_v, d_w, d_au, d_av, d_aw,
+               d_ax, d_ay, d_az, d_rho, d_arho, d_e, d_ae, dt):
+        wv = self.lam * dt
+        wx = self.chi * dt
+        d_u[d_idx] += wv * d_au[d_idx]
+        d_v[d_idx] += wv * d_av[d_idx]
+        d_w[d_idx] += wv * d_aw[d_idx]
+        d_rho[d_idx] += wv * d_arho[d_idx]
+        d_e[d_idx] += wv * d_ae[d_idx]
+        d_x[d_idx] += wx * (d_u[d_idx] + d_ax[d_idx])
+        d_y[d_idx] += wx * (d_v[d_idx] + d_ay[d_idx])
+        d_z[d_idx] += wx * (d_w[d_idx] + d_az[d_idx])
+
+    def stage5(self, d_idx, d_x, d_y, d_z, d_u, d_v, d_w, d_au, d_av, d_aw,
+               d_ax, d_ay, d_az, d_rho, d_arho, d_e, d_ae, dt):
+        wv = self.kick_outer * dt
+        wx = self.xi * dt
+        d_u[d_idx] += wv * d_au[d_idx]
+        d_v[d_idx] += wv * d_av[d_idx]
+        d_w[d_idx] += wv * d_aw[d_idx]
+        d_rho[d_idx] += wv * d_arho[d_idx]
+        d_e[d_idx] += wv * d_ae[d_idx]
+        d_x[d_idx] += wx * (d_u[d_idx] + d_ax[d_idx])
+        d_y[d_idx] += wx * (d_v[d_idx] + d_ay[d_idx])
+        d_z[d_idx] += wx * (d_w[d_idx] + d_az[d_idx])

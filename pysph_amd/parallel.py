@@ -100,8 +100,14 @@ class DeviceHaloOps(object):
     # host synchronisation is needed; a context with a stream of its own needs
     # two host-side syncs per exchange.
     def _shares_torch_stream(self):
+        mine = self.ctx.stream
+        mine = getattr(mine, 'value', mine)         # a ctypes.c_void_p handle
+        if not mine:
+            # no caller-supplied stream (None, or the null handle of torch's
+            # default stream): the library runs on a stream of its own
+            return False
         cur = self.torch.cuda.current_stream(self.device).cuda_stream
-        return self.ctx.stream is not None and int(self.ctx.stream) == int(cur)
+        return int(mine) == int(cur)
 
     def before_comm(self):
         if not self._shares_torch_stream():

@@ -87,9 +87,10 @@ class TVFScheme(object):
                  wall_equations=None):
         """wall_equations: module (or object) providing ``SetWallVelocity``,
         ``SolidWallPressureBC`` and ``SolidWallNoSlipBC`` as Equation classes
-        with Python bodies; default: the reference's own
-        ``pysph.sph.wc.transport_velocity`` (they have no hand-written kernel
-        and run through pysph_amd.codegen).  Only needed when `solids` is given."""
+        with Python bodies (they have no hand-written kernel and run through
+        pysph_amd.codegen); default: ``pysph_amd.wall_bc``.  The reference's
+        own ``pysph.sph.wc.transport_velocity`` works as well.  Only used when
+        `solids` is given."""
         self.wall_equations = wall_equations
         self.fluids = list(fluids)
         self.solids = list(solids or [])
@@ -107,15 +108,7 @@ class TVFScheme(object):
         if self.solids:
             we = self.wall_equations
             if we is None:
-                try:
-                    from pysph.sph.wc import transport_velocity as we
-                except ImportError as e:
-                    raise ImportError(
-                        'TVFScheme(solids=%r) needs the solid-wall equation classes '
-                        '(SetWallVelocity, SolidWallPressureBC, SolidWallNoSlipBC): '
-                        'pysph.sph.wc.transport_velocity is not importable (%s); pass '
-                        'wall_equations=<module with these Equation classes>' %
-                        (self.solids, e))
+                from . import wall_bc as we
             SetWallVelocity = we.SetWallVelocity
             SolidWallNoSlipBC = we.SolidWallNoSlipBC
             SolidWallPressureBC = we.SolidWallPressureBC

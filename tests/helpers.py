@@ -15,7 +15,7 @@ EL_OUT = ['p', 'v00', 'v01', 'v02', 'v10', 'v11', 'v12', 'v20', 'v21', 'v22',
 TVF_OUT = ['rho', 'V', 'p', 'au', 'av', 'aw', 'auhat', 'avhat', 'awhat']
 
 
-def golden_case(name, g):
+def golden_case(name, g, wall_equations=None):
     """(equations, kernel, dim, output props) matching make_golden.py."""
     if name == 'wcsph_dam_dx0.1':
         dx = float(g['meta/dx'])
@@ -39,10 +39,12 @@ def golden_case(name, g):
         return s.get_equations(), K.QuinticSpline(dim=3), 3, TVF_OUT
     if name == 'tvf_wall':
         dx = float(g['meta/dx'])
-        import wall_equations_fixture
+        # wall equations: the product's own (pysph_amd/wall_bc.py), or -- for the
+        # cross-check against the statement-by-statement restatement of the
+        # reference's bodies -- tests/wall_equations_fixture.py
         s = TVFScheme(['fluid'], ['wall'], dim=3, rho0=1.0, c0=10.0, nu=0.01,
                       p0=100.0, pb=100.0, h0=dx, gy=-0.5, alpha=0.2,
-                      wall_equations=wall_equations_fixture)
+                      wall_equations=wall_equations)
         return s.get_equations(), K.QuinticSpline(dim=3), 3, TVF_OUT + [
             'wij', 'uf', 'vf', 'wf', 'ug', 'vg', 'wg']
     if name in ('elastic_2d', 'elastic_3d'):

@@ -34,6 +34,9 @@ def main():
     g = load_golden('tvf_wall.npz')
     eqs, kernel, dim, outs = golden_case('tvf_wall', g)
     n += plan(arrays_from_golden(g, 'in'), eqs, kernel)
+    import wall_equations_fixture
+    eqs, kernel, dim, outs = golden_case('tvf_wall', g, wall_equations=wall_equations_fixture)
+    n += plan(arrays_from_golden(g, 'in'), eqs, kernel)
     for kname in ('CubicSpline', 'Gaussian'):
         arrays, eqs = T._custom_setup(0.0)
         n += plan(arrays, eqs, getattr(K, kname)(dim=3))

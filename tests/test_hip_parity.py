@@ -59,16 +59,22 @@ def test_golden_parity(case, variant):
     print('golden %s variant %d: max rel err %.3e' % (case, variant, worst))
 
 
-def test_generated_wall_equations_match_reference():
+@pytest.mark.parametrize('which', ['product', 'restatement'])
+def test_generated_wall_equations_match_reference(which):
     """TVF with solid walls: SetWallVelocity, SolidWallPressureBC and
     SolidWallNoSlipBC have no hand-written kernel -- their Python bodies
-    (tests/wall_equations_fixture.py) are translated by pysph_amd.codegen, compiled
-    for gfx950 and run through sph_eval_generated, next to the hand-written TVF
-    momentum kernels on the same destination.  Golden = the reference's own
-    TVFScheme(fluids, solids) classes executed by oracle/ref_driver.py."""
+    (the product's pysph_amd/wall_bc.py, and the statement-by-statement
+    restatement of the reference's in tests/wall_equations_fixture.py) are
+    translated by pysph_amd.codegen, compiled for gfx950 and run through
+    sph_eval_generated, next to the hand-written TVF momentum kernels on the same
+    destination.  Golden = the reference's own TVFScheme(fluids, solids) classes
+    executed by oracle/ref_driver.py."""
     g = load_golden('tvf_wall.npz')
     arrays = arrays_from_golden(g, 'in')
-    eqs, kernel, dim, outs = golden_case('tvf_wall', g)
+    we = None
+    if which == 'restatement':
+        import wall_equations_fixture as we
+    eqs, kernel, dim, outs = golden_case('tvf_wall', g, wall_equations=we)
     a_eval, nnps, ctx = make_eval(arrays, eqs, kernel, dim, 6)
     a_eval.compute(float(g['t']), float(g['dt']))
     worst, checked = 0.0, 0

@@ -455,3 +455,29 @@ def test_capacity_rule_is_symmetric_and_stable():
         resized += new != cap
         cap = new
     assert overflowed == 0 and 0 < resized < 12
+
+
+def test_null_stream_handle_is_not_a_shared_stream():
+    """HipContext(dev, torch.cuda.current_stream().cuda_stream) on torch's
+    default stream passes the NULL handle; the library then creates a stream of
+    its own, so the halo's pack / append kernels and the transport do NOT share a
+    stream and the two host synchronisations must stay (a skipped one lets RCCL
+    send a payload the pack kernel has not finished)."""
+    import ctypes
+    import types
+    from pysph_amd.parallel import DeviceHaloOps
+
+    def fake(handle, current):
+        ops = types.SimpleNamespace()
+        ops.ctx = types.SimpleNamespace(stream=handle)
+        ops.device = None
+        ops.torch = types.SimpleNamespace(cuda=types.SimpleNamespace(
+            current_stream=lambda d: types.SimpleNamespace(cuda_stream=current)))
+        return ops
+    shares = DeviceHaloOps._shares_torch_stream
+    assert not shares(fake(None, 0))
+    assert not shares(fake(0, 0))                       # null handle: library-owned stream
+    assert not shares(fake(ctypes.c_void_p(0), 0))
+    assert shares(fake(0x7f00, 0x7f00))
+    assert shares(fake(ctypes.c_void_p(0x7f00), 0x7f00))
+    assert not shares(fake(0x7f00, 0x7f10))

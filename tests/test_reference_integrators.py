@@ -7,9 +7,8 @@ import numpy as np
 import pytest
 
 from pysph_amd.equations import Equation
-from pysph_amd.integrator import IntegratorStep, PECIntegrator
-from extra_integrators_fixture import (EulerIntegrator, LeapFrogIntegrator, LeapFrogStep,
-                                       PEFRLIntegrator, PEFRLStep)
+from pysph_amd.integrator import (EulerIntegrator, IntegratorStep, LeapFrogIntegrator,
+                                  LeapFrogStep, PECIntegrator, PEFRLIntegrator, PEFRLStep)
 
 
 class SHM(Equation):
