@@ -115,6 +115,24 @@ typedef struct {
     long stop_idx;             /* < 0: None -> dst.size(real) */
     int neq;
     const sph_equation *eqs;
+    /* Optional promises of the caller about this group inside ONE evaluation
+     * (all zero: none).  They only select faster schedules; results are the
+     * same.  The Python host derives them from the structure of the group list
+     * (pysph_amd/acceleration_eval.py: annotate_plan).
+     * src_eos = 1: p and cs of every array this group's pair loops read are the
+     *   Tait EOS of its rho with eos_par = {rho0, c0, gamma, p0}, as an
+     *   SPH_EQ_TAIT_EOS[_HG] equation over ALL its particles left them (the
+     *   group before this one) -- the pair kernel may recompute them from rho
+     *   instead of gathering them (64-byte records).
+     * nl_mode: reuse of the neighbour lists between the pair passes of one
+     *   evaluation (the reference's NeighborCache, nnps_base.pyx:1144-1257):
+     *   1 = a later group of this evaluation loops over the same (destination,
+     *   single source): keep this pass's per-lane hit lists; 2 = start from the
+     *   lists kept by such a pass (ignored unless they were kept for the same
+     *   arrays since the last sph_nnps_update).                               */
+    int src_eos;
+    double eos_par[4];
+    int nl_mode;
 } sph_group;
 
 /* ---------------------------------------------------------------------- */
@@ -398,6 +416,9 @@ int sph_reduce_min(sph_ctx *ctx, int array_id, int prop, double *out);
  *                    of ONE group: WCSPH source records are packed once per
  *                    group instead of once per destination that reads them.
  *                    Nothing else may modify the arrays in between.
+ *   "eos_fuse"       0: ignore sph_group.src_eos (default 1)
+ *   "nl_reuse"       0: ignore sph_group.nl_mode (default 1)
+ *   "norm_masks"     0: hit masks are not shifted down to a lane's first hit (default 1)
  *   profiling only:  "ablate", "count_iters", "dump_counters", "lds_pad",
  *                    "wcsph_nr"                        */
 int sph_set_option(sph_ctx *ctx, const char *key, long value);
@@ -411,7 +432,10 @@ int sph_timer_enable(sph_ctx *ctx, int on);
 int sph_timer_reset(sph_ctx *ctx);
 /* keys: "nnps", "pack", "eos", "pair", "stage"; the pair launches once more per
  * equation family: "pair_wcsph", "pair_density", "pair_tvf", "pair_vgrad",
- * "pair_elastic"; out: total ms and launches */
+ * "pair_elastic"; out: total ms and launches.  Launch counters (ms = 0, counted
+ * whether or not timing is enabled): "n_eos_fused" (pair launches on the 64-byte
+ * EOS-fused records), "n_nl_keep" / "n_nl_reuse" (launches that kept / started
+ * from kept neighbour lists). */
 int sph_timer_get(sph_ctx *ctx, const char *key, double *ms, long *count);
 
 #ifdef __cplusplus

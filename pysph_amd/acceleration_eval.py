@@ -205,6 +205,23 @@ class _BuiltinUnit(object):
         self.cg.eqs = self.ceqs
         self._arrays = arrays
 
+    @property
+    def has_pair(self):
+        return any(self.ceqs[k].nsrc > 0 for k in range(len(self.eqs)))
+
+    def single_pair_key(self):
+        """(dest id, source id) when every pair equation of this unit loops over
+        the same single source, else None"""
+        keys = set()
+        for k in range(len(self.eqs)):
+            ce = self.ceqs[k]
+            if ce.nsrc == 0:
+                continue
+            if ce.nsrc != 1:
+                return None
+            keys.add((ce.dest, ce.src[0]))
+        return keys.pop() if len(keys) == 1 else None
+
     def refresh(self, start, stop):
         from .particle_array import get_npy as _get
         for i, k, dest, cname in self._const_params:
@@ -356,6 +373,107 @@ class _CGroup(object):
                 ev.ctx.set_option('pack_group', 0)
 
 
+_TAIT_KINDS = (1, 2)            # SPH_EQ_TAIT_EOS, SPH_EQ_TAIT_EOS_HG
+_WCSPH_PAIR_KINDS = (3, 4, 5)   # SPH_EQ_CONTINUITY, SPH_EQ_MOMENTUM, SPH_EQ_XSPH
+
+
+def _plain_leaf(g, cg):
+    """a leaf group whose execution is exactly one pass over its units: no
+    host callbacks, no iteration, no condition, no neighbour update after it"""
+    if g.has_subgroups or g.iterate or g.condition is not None or g.pre or g.post \
+            or g.update_nnps:
+        return False
+    for eq in g.equations:
+        if hasattr(eq, 'py_initialize') or hasattr(eq, 'reduce'):
+            return False
+    return all(isinstance(u, _BuiltinUnit) for u in cg.units)
+
+
+def _ranged(g):
+    """Group(start_idx=..., stop_idx=...) restricts the destinations"""
+    return g.start_idx not in (None, 0) or g.stop_idx is not None
+
+
+def annotate_plan(plan):
+    """What the STRUCTURE of the group list allows the library to assume inside
+    one evaluation (sph_group.src_eos / nl_mode, include/sphhip.h).  Only
+    sequences of plain leaf groups with hand-written kernels are considered;
+    everything else keeps the general path.
+
+    * EOS fusion: a WCSPH pair group (Continuity / Momentum / XSPH) directly
+      preceded by a group that is nothing but TaitEOS / TaitEOSHGCorrection over
+      ALL particles (real=False, no index range) of every array the pair group
+      touches, all with the same rho0, c0, gamma and p0: p and cs of those
+      arrays are then functions of rho when the pair group runs.
+    * neighbour-list reuse: two pair units of the same evaluation over the same
+      (destination, single source) with no neighbour update in between -- TVF's
+      density and force passes, the elastic set's velocity-gradient and rate
+      passes: the first keeps its per-lane hit lists, the second starts from
+      them (the reference's NeighborCache, nnps_base.pyx:1144-1257)."""
+    if any(isinstance(item, list) for _, item in plan):
+        return
+    leaves = [(g, cg) for g, cg in plan]
+    plain = [_plain_leaf(g, cg) for g, cg in leaves]
+    for g, cg in leaves:
+        for u in cg.units:
+            if isinstance(u, _BuiltinUnit):
+                u.cg.src_eos = 0
+                u.cg.nl_mode = 0
+    # -- EOS fusion ---------------------------------------------------------
+    for i in range(1, len(leaves)):
+        if not (plain[i] and plain[i - 1]):
+            continue
+        g0, cg0 = leaves[i - 1]
+        g1, cg1 = leaves[i]
+        if g0.real or _ranged(g0):
+            continue
+        eos = {}
+        ok = True
+        for u in cg0.units:
+            for k in range(len(u.eqs)):
+                ce = u.ceqs[k]
+                if ce.kind not in _TAIT_KINDS or u._const_params:
+                    ok = False
+                    break
+                par = (ce.par[0], ce.par[1], ce.par[2], ce.par[3] if ce.kind == 1 else 0.0)
+                if eos.setdefault(ce.dest, par) != par:
+                    ok = False
+        if not ok or not eos or len(set(eos.values())) != 1:
+            continue
+        par = list(eos.values())[0]
+        for u in cg1.units:
+            used = set()
+            pair = True
+            for k in range(len(u.eqs)):
+                ce = u.ceqs[k]
+                if ce.kind not in _WCSPH_PAIR_KINDS or ce.nsrc == 0:
+                    pair = False
+                used.add(ce.dest)
+                used.update(ce.src[j] for j in range(ce.nsrc))
+            if pair and used and used <= set(eos):
+                u.cg.src_eos = 1
+                for k in range(4):
+                    u.cg.eos_par[k] = par[k]
+    # -- neighbour-list reuse ---------------------------------------------
+    keeper = None                    # (key, unit, group) of the pass whose lists would be the kept ones
+    for (g, cg), ok in zip(leaves, plain):
+        if not ok:
+            keeper = None
+            continue
+        for u in cg.units:
+            if not u.has_pair:
+                continue             # equations without sources leave positions and h alone
+            key = u.single_pair_key()
+            if key is None or _ranged(g):
+                keeper = None
+                continue
+            if keeper is not None and keeper[0] == key and (not keeper[2].real or g.real):
+                keeper[1].cg.nl_mode = 1     # its destination range covers this pass's
+                u.cg.nl_mode = 2
+            else:
+                keeper = (key, u, g)
+
+
 class HipAccelerationEval(object):
     """The compiled object behind ``AccelerationEval.set_compiled_object``.
 
@@ -389,6 +507,7 @@ class HipAccelerationEval(object):
         if groups is None:
             groups = group_equations(self.a_eval.equations)
         self.plan = [self._plan_group(g, ids) for g in groups]
+        annotate_plan(self.plan)
         self.inputs = defaultdict(set)
         self.outputs = defaultdict(set)
         self.outputs_exact = defaultdict(set)

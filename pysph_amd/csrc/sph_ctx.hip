@@ -134,7 +134,7 @@ int sph_ctx_destroy(sph_ctx *c)
     for (auto &H : c->halo)
         for (int s = 0; s < 2; s++) { H.flag[s].release(); H.pos[s].release(); H.list[s].release(); }
     for (DevBuf *b : {&c->dbgc, &c->gapq, &c->cub_tmp, &c->red_part, &c->red_out, &c->posh, &c->aux, &c->fposb, &c->dkeys, &c->dperm,
-                      &c->tmp_u32a, &c->tmp_u32b, &c->gen_state})
+                      &c->tmp_u32a, &c->tmp_u32b, &c->gen_state, &c->nlbuf})
         b->release();
     for (auto &b : c->csr_start) b.release();
     for (auto &b : c->csr_nbrs) b.release();
@@ -276,6 +276,9 @@ int sph_set_option(sph_ctx *c, const char *key, long value)
     }
     if (strcmp(key, "const_flags") == 0) { c->const_flags = value; return SPH_OK; }
     if (strcmp(key, "invalidate_nnps") == 0) { c->nnps_valid = false; return SPH_OK; }
+    if (strcmp(key, "eos_fuse") == 0) { c->eos_fuse = value; return SPH_OK; }
+    if (strcmp(key, "nl_reuse") == 0) { c->nl_reuse = value; c->nl.valid = false; return SPH_OK; }
+    if (strcmp(key, "norm_masks") == 0) { c->norm_masks = value; return SPH_OK; }
     sph_set_error("sph_set_option: unknown key '%s'", key);
     return SPH_ERR_ARG;
 }
@@ -307,7 +310,8 @@ int sph_timer_reset(sph_ctx *c)
 int sph_timer_get(sph_ctx *c, const char *key, double *ms, long *count)
 {
     static const char *names[T_COUNT] = {"nnps", "pack", "eos", "pair", "stage",
-                                         "pair_none", "pair_wcsph", "pair_density", "pair_tvf", "pair_vgrad", "pair_elastic"};
+                                         "pair_none", "pair_wcsph", "pair_density", "pair_tvf", "pair_vgrad", "pair_elastic",
+                                         "n_eos_fused", "n_nl_keep", "n_nl_reuse"};
     SPH_TRY(timer_drain(c));
     for (int i = 0; i < T_COUNT; i++)
         if (strcmp(key, names[i]) == 0) {

@@ -205,6 +205,8 @@ struct PackArgs {
     int layout;                   // 0: [x y z h | aux...]; 1: WCSPH [x y z cs | u v w m | rho tmpj | h p]; 2: density [x y z m];
                                   // 3: TVF [x y z rho | u v w p | Vj2 m uhat vhat | what -];
                                   // 4: generated, uniform h [x y z | aux...]; 5: fp32 records (floats, any family)
+                                  // 6: WCSPH, p and cs recomputed by the pair kernel [x y | z u | v w | rho m] (64 B);
+                                  // 7: the same in fp32 [x-x0 y-y0 z-z0 u | v w rho m] (32 B)
                                   // (1, 2: aggregated kernel only)
     float4 *fpos;                 // non-null: fp32 {x-xmin, y-ymin, z-zmin, radius_scale*h} for the prefilter tiles
     int lds_np;                   // 16-B pieces per record when the launch carries 256 * lds_np * 16 B of LDS, else 0
@@ -271,7 +273,16 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
 #pragma unroll
         for (int q = 0; q < PACK_MAXP; q++) pc[q] = make_double2(0.0, 0.0);
         int np;
-        if (a.layout == 1) { // WCSPH [x y | z cs | u v | w m | rho tmpj] (+ [h p]: variable h / tensile correction)
+        if (a.layout == 6) { // WCSPH with the EOS fused into the pair kernel: one 64-B half line per record
+            pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, v[0]);
+            pc[2] = make_double2(v[1], v[2]); pc[3] = make_double2(v[4], v[3]);
+            np = 4;
+        } else if (a.layout == 7) {
+            pc[0] = __builtin_bit_cast(double2, make_float4((float)(ph.x - a.gmin[0]), (float)(ph.y - a.gmin[1]),
+                                                            (float)(ph.z - a.gmin[2]), (float)v[0]));
+            pc[1] = __builtin_bit_cast(double2, make_float4((float)v[1], (float)v[2], (float)v[4], (float)v[3]));
+            np = 2;
+        } else if (a.layout == 1) { // WCSPH [x y | z cs | u v | w m | rho tmpj] (+ [h p]: variable h / tensile correction)
             pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, v[6]);
             pc[2] = make_double2(v[0], v[1]); pc[3] = make_double2(v[2], v[3]);
             pc[4] = make_double2(v[4], v[5]); pc[5] = make_double2(ph.w, v[7]);
@@ -418,6 +429,39 @@ template <class T> struct FamWCSPH_T {
     }
 };
 typedef FamWCSPH_T<double> FamWCSPH;
+
+// The same equations on 64-byte records [x y | z u | v w | rho m] (fp32: 32 bytes): when the group before
+// this one was the Tait EOS over every array read here (sph_group.src_eos), p and cs are functions of rho
+// and are recomputed per gathered record -- four 16-B pieces in ONE 64-B half line instead of five pieces
+// that straddle a 128-B line half of the time.  ~14 more VALU operations per pair, hidden under the gathers.
+// Arithmetic as k_nosrc's (TaitEOS, gamma = 7) and k_pack's p / rho^2.
+template <class T> struct FamWCSPHE_T : FamWCSPH_T<T> {
+    static constexpr bool EOSF = true;
+    static constexpr int NR = 8;
+    template <class A> static __device__ __forceinline__ void load_fused(const A &a, uint32_t jg, real4<T> &pj, T (&s)[8])
+    {
+        T rho;
+        if constexpr (sizeof(T) == 8) {
+            const double2 *r = reinterpret_cast<const double2 *>(a.rec) + (unsigned long long)jg * 4;
+            const double2 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
+            pj.x = q0.x; pj.y = q0.y; pj.z = q1.x; pj.w = 0.0;
+            s[0] = q1.y; s[1] = q2.x; s[2] = q2.y; s[3] = q3.y; rho = q3.x;
+        } else {
+            const float4 *r = reinterpret_cast<const float4 *>(a.rec) + (unsigned long long)jg * 2;
+            const float4 q0 = r[0], q1 = r[1];
+            pj.x = q0.x; pj.y = q0.y; pj.z = q0.z; pj.w = 0.f;
+            s[0] = q0.w; s[1] = q1.x; s[2] = q1.y; s[3] = q1.w; rho = q1.z;
+        }
+        const T ratio = rho * (T)a.e_rho01;
+        const T r2 = ratio * ratio, r3 = r2 * ratio;
+        const T r7 = (r2 * r2) * r3;
+        const T p = (T)a.e_p0 + (T)a.e_B * (r7 - T(1.0));
+        s[4] = rho;
+        s[5] = rho != T(0.0) ? p * fast_rcp(rho * rho) : T(0.0);
+        s[6] = (T)a.e_c0 * r3;
+        s[7] = p;
+    }
+};
 
 // WCSPH records of the aggregated kernel use the layout
 //   [x y z cs | u v w m | rho tmpj | h p]
@@ -923,6 +967,8 @@ static bool slot_required(int fam, uint32_t flags, int prop)
 static int pack_pieces(const PackArgs &pa)
 {
     if (!pa.rec) return 0;
+    if (pa.layout == 6) return 4;
+    if (pa.layout == 7) return 2;
     if (pa.layout == 5) return (pa.nr % 4) ? 0 : pa.nr / 4;
     if (pa.nr % 2) return 0;
     return pa.nr / 2;
@@ -966,6 +1012,7 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
     pa.layout = (c->pair_variant >= 3 && fam == FAM_WCSPH) ? 1 : (c->pair_variant >= 3 && fam == FAM_DENSITY && pl.nr == 4) ? 2
               : (c->pair_variant >= 3 && fam == FAM_TVF && (pl.nr == 14 || pl.nr == 12)) ? 3 : 0;
     if (c->pair_variant >= 3 && (c->record_f32 || c->arith_f32)) pa.layout = 5;
+    if (c->cur_eosf) pa.layout = c->arith_f32 ? 7 : 6;
     pa.lds_np = pack_pieces(pa);
     if (launch) hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), (size_t)pa.lds_np * 256 * 16, c->stream, pa);
     return SPH_OK;
@@ -1019,6 +1066,28 @@ template <class Fam> static int launch_pair(sph_ctx *c, int kk, const PairArgs<F
     }
 }
 
+// the EOS-fused WCSPH family: uniform h, variant 6 only (sph_eval_group checks)
+template <class Fam> static int launch_pair_fused(sph_ctx *c, int kk, const PairArgs<Fam> &a)
+{
+    if (a.nd == 0) return SPH_OK;
+    constexpr bool FP32 = sizeof(typename Fam::Real) == 4;
+    dim3 g2(4 * div_up(a.nd, 256) / WPB), b2(64 * WPB);
+    uint32_t cf = a.src[0].flags;
+    for (int j = 1; j < a.nsrc; j++) if (a.src[j].flags != cf) cf = 0;
+    if (c->const_flags == 0) cf = 0;
+#define LAUNCHE(K)                                                                                                              \
+    if (cf == Fam::CF0) hipLaunchKernelGGL((k_pair_wave<Fam, K, true, FP32, Fam::CF0>), g2, b2, (size_t)c->lds_pad, c->stream, a); \
+    else hipLaunchKernelGGL((k_pair_wave<Fam, K, true, FP32, 0>), g2, b2, (size_t)c->lds_pad, c->stream, a)
+    switch (kk) {
+    case 1: LAUNCHE(1); break;
+    case 2: LAUNCHE(2); break;
+    case 3: LAUNCHE(3); break;
+    case 4: LAUNCHE(4); break;
+    }
+#undef LAUNCHE
+    return SPH_OK;
+}
+
 template <class Fam>
 static void fill_common(sph_ctx *c, PairArgs<Fam> &a, const sph_kernel *K, double t)
 {
@@ -1046,6 +1115,7 @@ static void fill_common(sph_ctx *c, PairArgs<Fam> &a, const sph_kernel *K, doubl
     if (K->dim > 2) a.facu *= a.h1u;
     a.epsu = 0.01 * a.hu * a.hu;
     a.hr2u = (c->radius_scale * c->h_uniform) * (c->radius_scale * c->h_uniform);
+    a.norm_masks = (int)c->norm_masks;
 }
 
 static int ensure_out(sph_ctx *c, int id, std::initializer_list<int> props)
@@ -1166,6 +1236,14 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         if (c->pair_variant >= 3 && fam == FAM_DENSITY && c->uniform_h && c->use_uniform_h) pl.nr = 4;
         if (c->pair_variant >= 3 && fam == FAM_TVF && c->uniform_h && c->use_uniform_h) pl.nr = (dflags & F_TAV) ? 14 : 12;
         if (c->pair_variant >= 3 && (c->record_f32 || c->arith_f32)) pl.nr = (4 + pl.na + 3) & ~3; // floats
+        // The caller promised (sph_group.src_eos) that p, cs of every array read here are the Tait EOS of its
+        // rho: with gamma = 7 (powers by multiplication), uniform h and no tensile correction the pair kernel
+        // recomputes them and the records shrink to 64 bytes (32 in fp32).
+        const bool eosf = g->src_eos == 1 && c->eos_fuse && fam == FAM_WCSPH && c->pair_variant == 6 && c->uniform_h &&
+                          c->use_uniform_h && !(dflags & F_TENSILE) && (dflags & F_MOM) && g->eos_par[2] == 7.0 &&
+                          g->eos_par[0] > 0.0 && !c->record_f32 && !c->wcsph_nr;
+        if (eosf) pl.nr = 8; // doubles, or floats with arith_f32
+        c->cur_eosf = eosf;
         c->cur_nrec = pl.nr;
         const void *rec_was = c->posh.ptr, *fpos_was = c->fposb.ptr;
         SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * (c->pair_variant >= 2 ? pl.nr : 4)));
@@ -1176,7 +1254,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         {
             ScopedTimer tm(c, T_PACK);
             // a source must hold what ITS equations read; the destination's own record what all of them read
-            const int sig = pl.nr * 4 + (c->record_f32 ? 1 : 0) + (c->arith_f32 ? 2 : 0);
+            const int sig = pl.nr * 8 + (c->record_f32 ? 1 : 0) + (c->arith_f32 ? 2 : 0) + (eosf ? 4 : 0);
             // The shared slots live in the same buffers every other unit packs into from offset 0:
             // a unit that does not share (another family, a single-destination call), or one whose
             // record layout differs from what the cache holds, overwrites them -- nothing cached survives.
@@ -1197,9 +1275,31 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             if (!dest_is_src) SPH_TRY(pack_once(dst, d_off, dflags, true));
         }
 
+        // Neighbour-list reuse between the pair passes of one evaluation (sph_group.nl_mode): one source,
+        // the wave-tile kernel, same grid.  A pass that keeps its lists (1) records what they belong to; a pass
+        // that wants them (2) gets them only if that record matches -- otherwise it runs its own phase 1.
+        int nl_mode = 0;
+        if (c->nl_reuse && c->pair_variant == 6 && nsrcs == 1 && g->nl_mode && !c->ablate) {
+            const size_t n_wt = (size_t)4 * div_up(D.n, 256);
+            if (g->nl_mode == 1) {
+                SPH_TRY(c->nlbuf.reserve(n_wt * NLW * sizeof(uint32_t)));
+                c->nl.valid = true; c->nl.epoch = c->nnps_epoch; c->nl.dst = dst; c->nl.src = srcs[0];
+                c->nl.start = start; c->nl.stop = stop; c->nl.nd = D.n;
+                nl_mode = 1;
+            } else if (g->nl_mode == 2 && c->nl.valid && c->nl.epoch == c->nnps_epoch && c->nl.dst == dst && c->nl.src == srcs[0] &&
+                       c->nl.nd == D.n && c->nl.start <= start && c->nl.stop >= stop && c->nlbuf.bytes >= n_wt * NLW * sizeof(uint32_t)) {
+                nl_mode = 2;
+            }
+        } else if (g->nl_mode != 2) {
+            c->nl.valid = c->nl.valid && !(g->nl_mode == 1); // a keeping pass that could not keep: nothing to reuse
+        }
+
         // 4. fused pair kernel, in the arithmetic type of the context (fp64, or fp32 with option arith_f32)
         ScopedTimer tm(c, T_PAIR);
         ScopedTimer tmf(c, T_PAIR_FAM + fam);
+        if (eosf) c->timers[T_N_EOSF].count++;
+        if (nl_mode == 1) c->timers[T_N_NLKEEP].count++;
+        if (nl_mode == 2) c->timers[T_N_NLREUSE].count++;
         // the part of the launch arguments every family shares
         auto common = [&](auto &a) {
             fill_common(c, a, K, t);
@@ -1209,6 +1309,13 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
             a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
             a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
+            a.nl = nullptr; a.nl_mode = nl_mode;
+            if (nl_mode) a.nl = c->nlbuf.as<uint32_t>();
+            if (eosf) {
+                a.e_rho01 = 1.0 / g->eos_par[0]; a.e_c0 = g->eos_par[1];
+                a.e_B = g->eos_par[0] * g->eos_par[1] * g->eos_par[1] / g->eos_par[2];
+                a.e_p0 = g->eos_par[3];
+            }
         };
         auto run_wcsph = [&](auto tag) -> int {
             typedef decltype(tag) F;
@@ -1228,7 +1335,8 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
                 SPH_TRY(ensure_out(c, dst, {SPH_AX, SPH_AY, SPH_AZ}));
                 a.p.ax = D.prop[SPH_AX]; a.p.ay = D.prop[SPH_AY]; a.p.az = D.prop[SPH_AZ];
             }
-            return launch_pair<F>(c, K->kind, a);
+            if constexpr (fam_eosf<F>::value) return launch_pair_fused<F>(c, K->kind, a);
+            else return launch_pair<F>(c, K->kind, a);
         };
         auto run_density = [&](auto tag) -> int {
             typedef decltype(tag) F;
@@ -1295,7 +1403,8 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             return launch_pair<F>(c, K->kind, a);
         };
         const bool f32 = c->arith_f32 != 0;
-        if (fam == FAM_WCSPH) SPH_TRY(f32 ? run_wcsph(FamWCSPH_T<float>()) : run_wcsph(FamWCSPH()));
+        if (fam == FAM_WCSPH && eosf) SPH_TRY(f32 ? run_wcsph(FamWCSPHE_T<float>()) : run_wcsph(FamWCSPHE_T<double>()));
+        else if (fam == FAM_WCSPH) SPH_TRY(f32 ? run_wcsph(FamWCSPH_T<float>()) : run_wcsph(FamWCSPH()));
         else if (fam == FAM_DENSITY) SPH_TRY(f32 ? run_density(FamDensity_T<float>()) : run_density(FamDensity()));
         else if (fam == FAM_VGRAD) SPH_TRY(f32 ? run_vgrad(FamVGrad_T<float>()) : run_vgrad(FamVGrad()));
         else if (fam == FAM_ELASTIC) SPH_TRY(f32 ? run_elastic(FamElastic_T<float>()) : run_elastic(FamElastic()));
@@ -1375,6 +1484,7 @@ static int eval_generated_launches(sph_ctx *c, const sph_kernel *K, const sph_ge
         return SPH_ERR_ARG;
     }
     HIP_TRY(hipSetDevice(c->device));
+    c->nl.valid = false; // a generated body may write positions or h: kept neighbour lists are not trusted across it
     const int dst = f->dest;
     DevArray &D = c->arr[dst];
     size_t start = f->start_idx > 0 ? (size_t)f->start_idx : 0;

@@ -62,7 +62,8 @@ struct HaloState {
 };
 
 // T_PAIR: every pair launch; T_PAIR_FAM + family (sph_eval.hip enum Family): the same launches per equation family
-enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_STAGE, T_PAIR_FAM, T_COUNT = T_PAIR_FAM + 6 };
+// T_N_*: launch counters only (no time): pair launches on EOS-fused records, launches that kept / reused neighbour lists
+enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_STAGE, T_PAIR_FAM, T_N_EOSF = T_PAIR_FAM + 6, T_N_NLKEEP, T_N_NLREUSE, T_COUNT };
 
 struct Timer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -117,7 +118,15 @@ struct sph_ctx {
     long wcsph_nr = 0;      // profiling: doubles per compact WCSPH record (default 10; 12/14/16 pad the stride)
     long lds_pad = 0;       // profiling: extra dynamic LDS per pair-kernel workgroup (limits wavefronts per CU)
     int cur_nrec = 0;       // doubles per packed record of the pair launch being set up
+    bool cur_eosf = false;  // the pair launch being set up reads the 64-byte WCSPH records (EOS recomputed per record)
     long block_sorted_outputs = 0;
+    long eos_fuse = 1;      // honour sph_group.src_eos (64-byte WCSPH records, p and cs recomputed from rho)
+    long nl_reuse = 1;      // honour sph_group.nl_mode (neighbour lists kept between the pair passes of one evaluation)
+    long norm_masks = 1;    // shift a row's hit bits down to the lane's first hit
+    // neighbour lists kept by the last nl_mode-1 pair pass
+    DevBuf nlbuf;
+    struct { bool valid = false; unsigned long long epoch = 0; int dst = -1, src = -1; size_t start = 0, stop = 0, nd = 0; } nl;
+    unsigned long long nnps_epoch = 0; // bumped by every sph_nnps_update
 
     void *comm = nullptr;   // SphComm of libsphcomm.so (sph_comm.hip), or nullptr
 

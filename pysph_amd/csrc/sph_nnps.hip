@@ -464,6 +464,7 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
     }
     HIP_TRY(hipGetLastError());
     c->nnps_valid = true;
+    c->nnps_epoch++;
     return SPH_OK;
 }
 

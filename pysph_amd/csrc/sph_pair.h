@@ -82,8 +82,21 @@ template <class Fam> struct PairArgs {
     double t, dt;
     // constants of the uniform-h specialisation (hmin == hmax over all arrays)
     double hu, h1u, facu, epsu, hr2u;
+    // neighbour-list reuse between the pair passes of one evaluation (the reference's NeighborCache,
+    // nnps_base.pyx:1144-1257): nl_mode 1 = this pass keeps every lane's hit-mask slot list, 2 = this pass
+    // starts from the lists a previous pass kept (one source only).  Per wave tile NLW words:
+    // [slots held][per slot: mask lo, mask hi, index of bit 0 relative to the source's segment] x 64 lanes.
+    uint32_t *nl;
+    int nl_mode;
+    int norm_masks;  // 1: a row's 96 hit bits are shifted down to the lane's first hit before they become slots
+    // Tait EOS of the records' density (families with EOSF: p and cs are not gathered but recomputed)
+    double e_rho01, e_c0, e_B, e_p0;
     typename Fam::Params p;
 };
+
+// does the family recompute p, cs from rho (64-byte WCSPH records)?
+template <class F, class = void> struct fam_eosf { static constexpr bool value = false; };
+template <class F> struct fam_eosf<F, decltype((void)F::EOSF)> { static constexpr bool value = F::EOSF; };
 
 // ---------------------------------------------------------------------------
 // fast fp64 reciprocal / square root: hardware estimate (v_rcp_f64 / v_rsq_f64,
@@ -246,6 +259,14 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nb)
     return xcd * base + min(xcd, rem) + idx;
 }
 
+// wave-uniform maximum of a per-lane int
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
 #define AMAXLEN 96 // hit bits kept per row and lane; longer ranges take the slow tail
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -274,6 +295,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define WCAP_UH 184 // candidates per LDS tile piece (a wavefront's row range is ~105 for WCSPH, ~125 for TVF);
 #define WCAP_VH 136 // variable h keeps a fourth plane (the candidates' own radii): same 2304 B
 #define WCSL 96     // fine_start entries of one row segment kept in LDS (16-bit, relative to the segment start)
+#define NLW (64 * (1 + 3 * WLQ)) // 32-bit words one wave tile keeps for the neighbour-list reuse
+#define NL_NONE 0xFFFFFFFFu     // stored slot count of a wave tile whose lists are not reusable (flushed early / long rows)
 #define XWIN (SPH_NSUB + 1) // a lane's candidate window: its own x sub-bin +- XWIN (one bin of slack for the
                             // rounding of the sub-bin index: |x_j - x_i| < cell_size spans at most SPH_NSUB bins exactly)
 
@@ -318,7 +341,8 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     typename Fam::Dest D;
     // one record: fp32 records for Real = float (and for record_f32), else fp64
     auto fetch = [&](uint32_t jg, uint32_t flags, real4<T> &pj, T (&sj)[Fam::NA]) {
-        if constexpr (F32) load_record_f32<Fam, T>(reinterpret_cast<const float *>(a.rec) + (unsigned long long)jg * NR, pj, sj);
+        if constexpr (fam_eosf<Fam>::value) Fam::load_fused(a, jg, pj, sj);
+        else if constexpr (F32) load_record_f32<Fam, T>(reinterpret_cast<const float *>(a.rec) + (unsigned long long)jg * NR, pj, sj);
         else load_record<Fam, UH>(a.rec + (unsigned long long)jg * NR, flags, pj, sj);
     };
     {
@@ -385,6 +409,25 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
         cq = 0;
     };
 
+    // neighbour-list reuse (one source): this wave tile's block of the list buffer
+    uint32_t *const nlw = a.nl_mode ? a.nl + (size_t)wt * NLW : nullptr;
+    bool reuse = false, unsaved = false; // wave-uniform
+    if (a.nl_mode == 2) {
+        const uint32_t nq = nlw[t];
+        reuse = !__any(nq == NL_NONE);
+        if (reuse) {
+            const uint32_t off0 = a.src[0].off;
+            const int nqmax = wave_max_i32((int)nq);
+            for (int q = 0; q < nqmax; q++) {
+                const uint32_t *w = nlw + 64 * (1 + 3 * q) + t;
+                smask[q][t] = (unsigned long long)w[0] | ((unsigned long long)w[64] << 32);
+                sjb[q][t] = w[128] + off0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            cq = active ? (int)nq : 0; // a lane outside this pass's destination range holds no work
+        }
+    }
+
     // Sources outermost: a wavefront whose 64 destinations straddle a row
     // boundary does phase 1 once per row segment (only that segment's lanes
     // build masks) but ONE phase 2 per source for all its lanes together.
@@ -392,6 +435,7 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     const SrcDesc sd = a.src[s];
     const uint32_t fl = CF ? CF : sd.flags;
     for (int R = row_first; R <= row_last; R++) {
+        if (reuse) break; // the lists are in LDS already
         if (a.ablate == 6) break; // profiling: prologue + finish only
         const bool inseg = active && row == R;
         const unsigned long long segm = __ballot(inseg);
@@ -491,18 +535,47 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
                             wd[gw] = rem >= 32 ? mm : (rem > 0 ? (mm & ((1u << rem) - 1u)) : 0u);
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // tile reads before the next tile's writes
-                        const unsigned long long m0 = (unsigned long long)wd[0] | ((unsigned long long)wd[1] << 32);
-                        const uint32_t jb0 = sd.off + tb + (uint32_t)s0;
+                        unsigned long long m0 = (unsigned long long)wd[0] | ((unsigned long long)wd[1] << 32);
+                        uint32_t m2 = wd[2];
+                        uint32_t jb0 = sd.off + tb + (uint32_t)s0;
+                        // Hits beyond bit 63 would cost a second slot although a lane's hits in one row
+                        // span less than 64 candidates: shift the 96 bits down to the lane's first hit
+                        // (wide windows only: QuinticSpline / radius_scale 3, where slots run out otherwise)
+                        if (a.norm_masks && __any(m2 != 0)) {
+                            const int sh = m0 ? __builtin_ctzll(m0) : (m2 ? 64 + __builtin_ctz(m2) : 0);
+                            if (sh >= 64) { m0 = (unsigned long long)(m2 >> (sh - 64)); m2 = 0; }
+                            else if (sh > 0) {
+                                m0 = (m0 >> sh) | ((unsigned long long)m2 << (64 - sh));
+                                m2 = sh >= 32 ? 0u : (m2 >> sh);
+                            }
+                            jb0 += (uint32_t)sh;
+                        }
                         // a lane without room for this tile's slots: the wavefront works its lists off first (rare)
-                        if (__any(cq + (m0 != 0) + (wd[2] != 0) > WLQ)) phase2(fl);
+                        if (__any(cq + (m0 != 0) + (m2 != 0) > WLQ)) { phase2(fl); unsaved = true; }
                         if (m0) { smask[cq][t] = m0; sjb[cq][t] = jb0; cq++; }
-                        if (wd[2]) { smask[cq][t] = wd[2]; sjb[cq][t] = jb0 + 64u; cq++; }
+                        if (m2) { smask[cq][t] = m2; sjb[cq][t] = jb0 + 64u; cq++; }
                         // rare: a lane's range is longer than AMAXLEN -> exact tail, in place
                         if (__any(len > AMAXLEN)) {
+                            unsaved = true;
                             for (int k = AMAXLEN; k < len; k++) do_pair(sd.off + tb + s0 + k, fl);
                         }
                     }
                 }
+        }
+    }
+    if (a.nl_mode == 1 && s == 0) {
+        // keep the lists for the next pass of this evaluation over the same (destination, source)
+        if (unsaved) nlw[t] = NL_NONE;
+        else {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            nlw[t] = (uint32_t)cq;
+            const int nqmax = wave_max_i32(cq);
+            for (int q = 0; q < nqmax; q++) {
+                uint32_t *w = nlw + 64 * (1 + 3 * q) + t;
+                const unsigned long long m = q < cq ? smask[q][t] : 0ull;
+                w[0] = (uint32_t)m; w[64] = (uint32_t)(m >> 32);
+                w[128] = q < cq ? sjb[q][t] - sd.off : 0u;
+            }
         }
     }
     phase2(fl);

@@ -36,7 +36,11 @@ class SphEquation(C.Structure):
 class SphGroup(C.Structure):
     _fields_ = [('real', C.c_int), ('start_idx', C.c_long),
                 ('stop_idx', C.c_long), ('neq', C.c_int),
-                ('eqs', C.POINTER(SphEquation))]
+                ('eqs', C.POINTER(SphEquation)),
+                # optional promises about this group inside one evaluation
+                # (include/sphhip.h; set by acceleration_eval.annotate_plan)
+                ('src_eos', C.c_int), ('eos_par', C.c_double * 4),
+                ('nl_mode', C.c_int)]
 
 
 # every symbol include/sphhip.h declares, with its ctypes signature

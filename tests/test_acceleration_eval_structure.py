@@ -114,3 +114,81 @@ def test_mega_group_copies_props_of_group():                        # :272-291
     for prop in ('real update_nnps iterate max_iterations condition min_iterations pre post '
                  'start_idx stop_idx name').split():
         assert getattr(mg, prop) == getattr(g, prop)
+
+
+# ---------------------------------------------------------------------------
+# what the structure of a group list lets the library assume inside one
+# evaluation (sph_group.src_eos / nl_mode): derived on the host, no device needed
+# ---------------------------------------------------------------------------
+def _plan(arrays, groups, kernel_kind=2):
+    from pysph_amd.acceleration_eval import _CGroup, annotate_plan
+    ids = dict((pa.name, i) for i, pa in enumerate(arrays))
+    amap = dict((pa.name, pa) for pa in arrays)
+    plan = [(g, _CGroup(g, ids, amap, kernel_kind)) for g in groups]
+    annotate_plan(plan)
+    return plan
+
+
+def _modes(plan):
+    return [[(u.cg.src_eos, u.cg.nl_mode) for u in cg.units] for _, cg in plan]
+
+
+def test_dam_break_groups_promise_the_tait_eos_to_the_pair_group():
+    from pysph_amd.examples import dam_break_3d as db
+    arrays = db.create_particles(0.2)
+    plan = _plan(arrays, db.create_scheme(0.2).get_equations())
+    m = _modes(plan)
+    assert all(e == 0 for grp in m[:-1] for e, _ in grp)          # the EOS group itself: nothing
+    assert [e for e, _ in m[-1]] == [1] * len(m[-1])              # fluid, boundary, obstacle destinations
+    u = plan[-1][1].units[0]
+    assert list(u.cg.eos_par) == [db.ro, db.c0, db.gamma, 0.0]
+    assert all(n == 0 for grp in m for _, n in grp)               # three sources: no list reuse
+
+
+def test_eos_promise_needs_every_array_and_all_particles():
+    from pysph_amd.equations import (ContinuityEquation, Group, MomentumEquation, TaitEOS)
+    from pysph_amd.particle_array import get_particle_array_wcsph
+    a = get_particle_array_wcsph(name='a', x=np.zeros(2))
+    b = get_particle_array_wcsph(name='b', x=np.zeros(2))
+    pair = Group(equations=[ContinuityEquation('a', ['a', 'b']),
+                            MomentumEquation('a', ['a', 'b'], c0=10.0)])
+    eos_a = TaitEOS('a', None, rho0=1000., c0=10., gamma=7.)
+    eos_b = TaitEOS('b', None, rho0=1000., c0=10., gamma=7.)
+    full = _plan([a, b], [Group(equations=[eos_a, eos_b], real=False), pair])
+    assert _modes(full)[-1][0][0] == 1
+    # b has no EOS / the EOS skips the ghosts / another c0 / a neighbour update in
+    # between / a group in between: no promise
+    between = Group(equations=[ContinuityEquation('b', ['a'])])
+    for groups in ([Group(equations=[eos_a], real=False), pair],
+                   [Group(equations=[eos_a, eos_b], real=True), pair],
+                   [Group(equations=[eos_a, TaitEOS('b', None, rho0=1000., c0=11., gamma=7.)],
+                          real=False), pair],
+                   [Group(equations=[eos_a, eos_b], real=False, update_nnps=True), pair],
+                   [Group(equations=[eos_a, eos_b], real=False), between, pair]):
+        assert _modes(_plan([a, b], groups))[-1][0][0] == 0, groups
+
+
+def test_tvf_and_elastic_second_passes_reuse_the_first_pass_lists():
+    from pysph_amd import kernels as K
+    from pysph_amd.particle_array import get_particle_array_tvf_fluid
+    from pysph_amd.scheme import TVFScheme
+    from pysph_amd.solid_mech import (ElasticSolidsScheme,
+                                      get_particle_array_elastic_dynamics)
+    f = get_particle_array_tvf_fluid(name='fluid', x=np.zeros(2))
+    groups = TVFScheme(['fluid'], [], dim=3, rho0=1.0, c0=10.0, nu=0.01, p0=100.0,
+                       pb=100.0, h0=0.1).get_equations()
+    m = _modes(_plan([f], groups, kernel_kind=3))
+    assert [n for grp in m for _, n in grp] == [1, 0, 2]          # density keeps, state equation, force reuses
+    s = get_particle_array_elastic_dynamics(name='solid', x=np.zeros(2))
+    m = _modes(_plan([s], ElasticSolidsScheme(['solid'], [], dim=3).get_equations(), kernel_kind=1))
+    assert [n for grp in m for _, n in grp] == [1, 2]             # velocity gradient keeps, rates reuse
+    # a real=True first pass does not cover the ghosts a real=False second pass loops over
+    from pysph_amd.equations import Group, SummationDensity
+    w = get_particle_array(name='w')
+    g1 = Group(equations=[SummationDensity('w', ['w'])], real=True)
+    g2 = Group(equations=[SummationDensity('w', ['w'])], real=False)
+    assert [n for grp in _modes(_plan([w], [g1, g2])) for _, n in grp] == [0, 0]
+    assert [n for grp in _modes(_plan([w], [g2, g1])) for _, n in grp] == [1, 2]
+    # a neighbour update between the passes: nothing is kept
+    g2u = Group(equations=[SummationDensity('w', ['w'])], real=False, update_nnps=True)
+    assert [n for grp in _modes(_plan([w], [g2u, g1])) for _, n in grp] == [0, 0]

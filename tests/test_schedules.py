@@ -1,0 +1,126 @@
+"""The schedule options of round 3 change speed, never results:
+
+* ``eos_fuse``  -- WCSPH pair kernel on 64-byte records with p, cs recomputed
+  from rho (taken when the group list promises the Tait EOS, sph_group.src_eos);
+* ``nl_reuse``  -- the second pair pass of an evaluation (TVF force, elastic
+  rates) starts from the hit lists the first pass kept (sph_group.nl_mode);
+* ``norm_masks`` -- a row's hit bits shifted down to the lane's first hit.
+
+Each is compared ON against OFF (to rounding where the arithmetic is regrouped,
+bit for bit where only the schedule differs) and against the oracle, and the
+launch counters prove the path under test really ran."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(argv, opts, steps=2):
+    """one bench workload through the C-ABI with the given library options;
+    returns ({field: array}, counters, neighbour counts)"""
+    import torch
+    import bench
+    from pysph_amd import device as dev
+    args = bench.parse_args(argv + ['--no-cpu-baseline', '--no-extras'])
+    ctx = dev.HipContext(0, torch.cuda.current_stream().cuda_stream)
+    bench.apply_options(args, ctx)
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    w = bench.build_workload(args, 0, 1)
+    nnps, a_eval, halo, domain, step, ordered = bench.setup(args, w, 0, 1, None, ctx)
+    for a in w.arrays:
+        a.gpu.pull()
+    host_in = bench.copy_arrays(w.arrays)
+    for _ in range(steps):
+        step()
+    out = {}
+    for pa in w.arrays:
+        nreal = pa.get_number_of_particles(True)
+        pa.gpu.pull(*[f for f in w.fields if f in pa.properties])
+        for f in w.fields:
+            if f in pa.properties:
+                out[pa.name + '.' + f] = np.array(pa.get(f)[:nreal])
+    cnt = {k: ctx.timer_get(k)[1] for k in ('n_eos_fused', 'n_nl_keep', 'n_nl_reuse')}
+    res = bench.parity_check(w, host_in, nnps, domain,
+                             bench.PARITY_TOL if args.dtype == 'f64' else 5e-5)
+    del nnps, a_eval, step
+    ctx.close()
+    torch.cuda.empty_cache()
+    return out, cnt, res
+
+
+def _max_rel(a, b):
+    worst = 0.0
+    for k in a:
+        s = np.max(np.abs(b[k]))
+        if s > 0:
+            worst = max(worst, float(np.max(np.abs(a[k] - b[k])) / s))
+    return worst
+
+
+@pytest.mark.parametrize('argv', [['--n1', '64'], ['--n1', '64', '--no-reorder'],
+                                  ['--workload', 'dam_break', '--dx', '0.03']],
+                         ids=['cube', 'cube-unsorted', 'dam-break'])
+def test_eos_fused_records_match_gathered_records(argv):
+    on, c_on, r_on = _run(argv, {})
+    off, c_off, r_off = _run(argv, {'eos_fuse': 0})
+    assert c_on['n_eos_fused'] > 0 and c_off['n_eos_fused'] == 0
+    assert r_on['parity_ok'] and r_off['parity_ok'], (r_on, r_off)
+    assert _max_rel(on, off) < 1e-13
+
+
+def test_eos_fused_records_fp32():
+    on, c_on, r_on = _run(['--n1', '64', '--dtype', 'f32'], {})
+    off, c_off, r_off = _run(['--n1', '64', '--dtype', 'f32'], {'eos_fuse': 0})
+    assert c_on['n_eos_fused'] > 0 and c_off['n_eos_fused'] == 0
+    assert r_on['parity_max_rel'] < 5e-5 and r_off['parity_max_rel'] < 5e-5
+    assert r_on['parity_neighbour_count_mismatches'] == 0
+
+
+def test_eos_not_fused_when_h_varies_or_tensile():
+    """the promise is there, the conditions of the 64-byte layout are not"""
+    out, cnt, res = _run(['--n1', '48', '--vary-h', '0.1'], {})
+    assert cnt['n_eos_fused'] == 0 and res['parity_ok']
+
+
+@pytest.mark.parametrize('argv', [['--workload', 'taylor_green', '--n1', '48'],
+                                  ['--workload', 'elastic', '--rings-dx', '1.6e-3'],
+                                  ['--workload', 'elastic', '--rings-dx', '1.6e-3', '--rings-spacing', '0.0416'],
+                                  ['--workload', 'elastic_block', '--n1', '40'],
+                                  ['--workload', 'elastic', '--rings-dx', '1.6e-3', '--dtype', 'f32']],
+                         ids=['taylor-green', 'rings', 'rings-in-contact', 'block', 'rings-fp32'])
+def test_second_pass_on_kept_lists_is_bit_identical(argv):
+    """only the schedule changes: same pairs, same order within a lane's list"""
+    on, c_on, r_on = _run(argv, {})
+    off, c_off, r_off = _run(argv, {'nl_reuse': 0})
+    assert c_on['n_nl_keep'] > 0 and c_on['n_nl_reuse'] == c_on['n_nl_keep']
+    assert c_off['n_nl_keep'] == 0 and c_off['n_nl_reuse'] == 0
+    assert r_on['parity_ok'] or '--dtype' in argv, r_on
+    for k in on:
+        assert np.array_equal(on[k], off[k]), k
+
+
+def test_kept_lists_are_dropped_by_a_neighbour_update():
+    """the lists belong to ONE sph_nnps_update: the next evaluation's first
+    pass keeps new ones, a second pass never starts from the previous step's"""
+    on, cnt, res = _run(['--workload', 'taylor_green', '--n1', '40'], {}, steps=3)
+    assert cnt['n_nl_keep'] == 3 and cnt['n_nl_reuse'] == 3 and res['parity_ok']
+
+
+@pytest.mark.parametrize('argv', [['--workload', 'taylor_green', '--n1', '48'],
+                                  ['--params', 'cube', '--n1', '64'],
+                                  ['--workload', 'elastic', '--rings-dx', '1.6e-3']],
+                         ids=['taylor-green', 'cube.py', 'rings'])
+def test_normalised_masks_are_bit_identical(argv):
+    on, _, r_on = _run(argv, {})
+    off, _, r_off = _run(argv, {'norm_masks': 0})
+    assert r_on['parity_ok'] and r_off['parity_ok']
+    assert r_on['parity_neighbour_count_mismatches'] == 0
+    for k in on:
+        assert np.array_equal(on[k], off[k]), k
