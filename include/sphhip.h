@@ -417,7 +417,7 @@ int sph_reduce_min(sph_ctx *ctx, int array_id, int prop, double *out);
  *                    group instead of once per destination that reads them.
  *                    Nothing else may modify the arrays in between.
  *   "eos_fuse"       0: ignore sph_group.src_eos (default 1)
- *   "nl_reuse"       0: ignore sph_group.nl_mode (default 1)
+ *   "nl_reuse"       1: honour sph_group.nl_mode (default 0: measured slower)
  *   "norm_masks"     0: hit masks are not shifted down to a lane's first hit (default 1)
  *   profiling only:  "ablate", "count_iters", "dump_counters", "lds_pad",
  *                    "wcsph_nr"                        */

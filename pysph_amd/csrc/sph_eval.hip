@@ -32,6 +32,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <type_traits>
 
 // ---------------------------------------------------------------------------
 // equations without sources (elementwise)
@@ -438,19 +439,30 @@ typedef FamWCSPH_T<double> FamWCSPH;
 template <class T> struct FamWCSPHE_T : FamWCSPH_T<T> {
     static constexpr bool EOSF = true;
     static constexpr int NR = 8;
-    template <class A> static __device__ __forceinline__ void load_fused(const A &a, uint32_t jg, real4<T> &pj, T (&s)[8])
+    // one gathered record as it arrives (four / two 16-B pieces), and its decoding: kept apart so that the
+    // pipelined phase 2 can hold undecoded records in flight
+    struct Raw {
+        typename std::conditional<sizeof(T) == 8, double2, float4>::type q[sizeof(T) == 8 ? 4 : 2];
+    };
+    template <class A> static __device__ __forceinline__ void load_raw(const A &a, uint32_t jg, Raw &r)
+    {
+        if constexpr (sizeof(T) == 8) {
+            const double2 *p = reinterpret_cast<const double2 *>(a.rec) + (unsigned long long)jg * 4;
+            r.q[0] = p[0]; r.q[1] = p[1]; r.q[2] = p[2]; r.q[3] = p[3];
+        } else {
+            const float4 *p = reinterpret_cast<const float4 *>(a.rec) + (unsigned long long)jg * 2;
+            r.q[0] = p[0]; r.q[1] = p[1];
+        }
+    }
+    template <class A> static __device__ __forceinline__ void decode(const A &a, const Raw &r, real4<T> &pj, T (&s)[8])
     {
         T rho;
         if constexpr (sizeof(T) == 8) {
-            const double2 *r = reinterpret_cast<const double2 *>(a.rec) + (unsigned long long)jg * 4;
-            const double2 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
-            pj.x = q0.x; pj.y = q0.y; pj.z = q1.x; pj.w = 0.0;
-            s[0] = q1.y; s[1] = q2.x; s[2] = q2.y; s[3] = q3.y; rho = q3.x;
+            pj.x = r.q[0].x; pj.y = r.q[0].y; pj.z = r.q[1].x; pj.w = 0.0;
+            s[0] = r.q[1].y; s[1] = r.q[2].x; s[2] = r.q[2].y; s[3] = r.q[3].y; rho = r.q[3].x;
         } else {
-            const float4 *r = reinterpret_cast<const float4 *>(a.rec) + (unsigned long long)jg * 2;
-            const float4 q0 = r[0], q1 = r[1];
-            pj.x = q0.x; pj.y = q0.y; pj.z = q0.z; pj.w = 0.f;
-            s[0] = q0.w; s[1] = q1.x; s[2] = q1.y; s[3] = q1.w; rho = q1.z;
+            pj.x = r.q[0].x; pj.y = r.q[0].y; pj.z = r.q[0].z; pj.w = 0.f;
+            s[0] = r.q[0].w; s[1] = r.q[1].x; s[2] = r.q[1].y; s[3] = r.q[1].w; rho = r.q[1].z;
         }
         const T ratio = rho * (T)a.e_rho01;
         const T r2 = ratio * ratio, r3 = r2 * ratio;
@@ -460,6 +472,12 @@ template <class T> struct FamWCSPHE_T : FamWCSPH_T<T> {
         s[5] = rho != T(0.0) ? p * fast_rcp(rho * rho) : T(0.0);
         s[6] = (T)a.e_c0 * r3;
         s[7] = p;
+    }
+    template <class A> static __device__ __forceinline__ void load_fused(const A &a, uint32_t jg, real4<T> &pj, T (&s)[8])
+    {
+        Raw r;
+        load_raw(a, jg, r);
+        decode(a, r, pj, s);
     }
 };
 
@@ -1012,7 +1030,12 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
     pa.layout = (c->pair_variant >= 3 && fam == FAM_WCSPH) ? 1 : (c->pair_variant >= 3 && fam == FAM_DENSITY && pl.nr == 4) ? 2
               : (c->pair_variant >= 3 && fam == FAM_TVF && (pl.nr == 14 || pl.nr == 12)) ? 3 : 0;
     if (c->pair_variant >= 3 && (c->record_f32 || c->arith_f32)) pa.layout = 5;
-    if (c->cur_eosf) pa.layout = c->arith_f32 ? 7 : 6;
+    if (c->cur_eosf) {
+        // p, cs (and p / rho^2) are recomputed by the pair kernel: not read here
+        pa.layout = c->arith_f32 ? 7 : 6;
+        pa.src[5] = pa.src[6] = pa.src[7] = nullptr;
+        pa.derived = 0;
+    }
     pa.lds_np = pack_pieces(pa);
     if (launch) hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), (size_t)pa.lds_np * 256 * 16, c->stream, pa);
     return SPH_OK;
@@ -1076,7 +1099,10 @@ template <class Fam> static int launch_pair_fused(sph_ctx *c, int kk, const Pair
     for (int j = 1; j < a.nsrc; j++) if (a.src[j].flags != cf) cf = 0;
     if (c->const_flags == 0) cf = 0;
 #define LAUNCHE(K)                                                                                                              \
-    if (cf == Fam::CF0) hipLaunchKernelGGL((k_pair_wave<Fam, K, true, FP32, Fam::CF0>), g2, b2, (size_t)c->lds_pad, c->stream, a); \
+    if (cf == Fam::CF0 && c->pipe_depth == 2) hipLaunchKernelGGL((k_pair_wave<Fam, K, true, FP32, Fam::CF0, 2>), g2, b2, (size_t)c->lds_pad, c->stream, a); \
+    else if (cf == Fam::CF0 && c->pipe_depth == 3) hipLaunchKernelGGL((k_pair_wave<Fam, K, true, FP32, Fam::CF0, 3>), g2, b2, (size_t)c->lds_pad, c->stream, a); \
+    else if (cf == Fam::CF0 && c->pipe_depth == 4) hipLaunchKernelGGL((k_pair_wave<Fam, K, true, FP32, Fam::CF0, 4>), g2, b2, (size_t)c->lds_pad, c->stream, a); \
+    else if (cf == Fam::CF0) hipLaunchKernelGGL((k_pair_wave<Fam, K, true, FP32, Fam::CF0>), g2, b2, (size_t)c->lds_pad, c->stream, a); \
     else hipLaunchKernelGGL((k_pair_wave<Fam, K, true, FP32, 0>), g2, b2, (size_t)c->lds_pad, c->stream, a)
     switch (kk) {
     case 1: LAUNCHE(1); break;

@@ -50,6 +50,8 @@ struct DevArray {
     DevBuf fkeys_sorted, fine_start;     // sorted fine keys (cell * SPH_NSUB + x sub-bin); uint32[n_cells * SPH_NSUB + 1]
     DevBuf tile_key, tile_id, tile_order; // traversal order of the 256-particle destination tiles (aggregated kernel)
     size_t n_tiles = 0;
+    int tile_grid[4] = {0, 0, 0, 0};     // grid (ncx, ncy, ncz, block rows) the tile order was built for
+    int tile_age = 0;                    // updates since the tile order was built
     int nnps_slot = -1;                  // position in the last sph_nnps_update list
     size_t perm_n = 0;                   // particles `perm` was built for (0: none / already applied)
 };
@@ -121,8 +123,10 @@ struct sph_ctx {
     bool cur_eosf = false;  // the pair launch being set up reads the 64-byte WCSPH records (EOS recomputed per record)
     long block_sorted_outputs = 0;
     long eos_fuse = 1;      // honour sph_group.src_eos (64-byte WCSPH records, p and cs recomputed from rho)
-    long nl_reuse = 1;      // honour sph_group.nl_mode (neighbour lists kept between the pair passes of one evaluation)
+    long nl_reuse = 0;      // honour sph_group.nl_mode (neighbour lists kept between the pair passes of one evaluation): built,
+                            // bit-identical, and measured SLOWER on MI355X (phase 1 overlaps other wavefronts' gathers)
     long norm_masks = 1;    // shift a row's hit bits down to the lane's first hit
+    long pipe_depth = 0;    // EOS-fused WCSPH kernel: gathered records in flight per lane (0: none; 2-4: one wavefront per SIMD)
     // neighbour lists kept by the last nl_mode-1 pair pass
     DevBuf nlbuf;
     struct { bool valid = false; unsigned long long epoch = 0; int dst = -1, src = -1; size_t start = 0, stop = 0, nd = 0; } nl;

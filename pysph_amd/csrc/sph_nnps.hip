@@ -175,11 +175,13 @@ __global__ __launch_bounds__(256) void k_split_segment(const uint32_t *__restric
 }
 
 // cell_start[c] = fine_start[c * SPH_NSUB]
+// Runs after k_fill_gaps: also empties the gap queue for its next user (the queue is empty between uses).
 __global__ __launch_bounds__(256) void k_coarse_start(const uint32_t *__restrict__ fine_start, uint32_t n_cells,
-                                                      uint32_t *__restrict__ cell_start)
+                                                      uint32_t *__restrict__ cell_start, uint32_t *__restrict__ gapq)
 {
     size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c <= n_cells) cell_start[c] = fine_start[c * SPH_NSUB];
+    if (c == 0) gapq[0] = 0u;
 }
 
 // Traversal order of the destination tiles (runs of SPH_TILE cell-sorted
@@ -214,8 +216,10 @@ __global__ __launch_bounds__(256) void k_tile_keys(const uint32_t *__restrict__ 
 #define GAP_WAVE 64      // gaps of at least this many entries: wave-cooperative
 #define GAP_GRID 8192    // ... and of at least this many: queued for k_fill_gaps
 #define GAP_QUEUE 4096   // queue capacity (a full queue falls back to the wave-cooperative fill)
+// `coarse` (optional): the cell ids of the sorted order, coarse[i] = skeys[i] / SPH_NSUB, written on the way.
 __global__ __launch_bounds__(256) void k_cell_start(const uint32_t *__restrict__ skeys, size_t n, uint32_t ntab,
-                                                    uint32_t *__restrict__ start, uint32_t *__restrict__ gapq)
+                                                    uint32_t *__restrict__ start, uint32_t *__restrict__ gapq,
+                                                    uint32_t *__restrict__ coarse)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -223,6 +227,7 @@ __global__ __launch_bounds__(256) void k_cell_start(const uint32_t *__restrict__
     if (i <= n) {
         first = i > 0 ? (long)skeys[i - 1] + 1 : 0;
         last = i < n ? (long)skeys[i] : (long)ntab;
+        if (coarse && i < n) coarse[i] = (uint32_t)last / SPH_NSUB;
     }
     bool big = last - first >= GAP_WAVE;
     if (!big)
@@ -431,21 +436,34 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.ptr, tmp_bytes, A.keys.as<uint32_t>(),
                                                    A.fkeys_sorted.as<uint32_t>(), A.idx.as<uint32_t>(),
                                                    A.perm.as<uint32_t>(), (int)n, 0, end_bit, c->stream));
-        hipLaunchKernelGGL(k_coarse_keys, dim3(div_up(n, 256)), dim3(256), 0, c->stream, A.fkeys_sorted.as<uint32_t>(), n,
-                           A.keys_sorted.as<uint32_t>());
         }
-        SPH_TRY(c->gapq.reserve((4 + 3 * GAP_QUEUE) * 4));
-        HIP_TRY(hipMemsetAsync(c->gapq.ptr, 0, 16, c->stream));
+        if (!c->gapq.ptr) { // first use: the queue starts empty; afterwards k_coarse_start leaves it empty
+            SPH_TRY(c->gapq.reserve((4 + 3 * GAP_QUEUE) * 4));
+            HIP_TRY(hipMemsetAsync(c->gapq.ptr, 0, 16, c->stream));
+        }
+        // the single-array path gets its cell ids (keys_sorted) from this kernel; the concatenated one has them already
         hipLaunchKernelGGL(k_cell_start, dim3(div_up(n + 1, 256)), dim3(256), 0, c->stream,
                            A.fkeys_sorted.as<uint32_t>(), n, (uint32_t)n_fine, A.fine_start.as<uint32_t>(),
-                           c->gapq.as<uint32_t>());
+                           c->gapq.as<uint32_t>(), cat ? (uint32_t *)nullptr : A.keys_sorted.as<uint32_t>());
         hipLaunchKernelGGL(k_fill_gaps, dim3(512), dim3(256), 0, c->stream, c->gapq.as<uint32_t>(),
                            A.fine_start.as<uint32_t>());
         hipLaunchKernelGGL(k_coarse_start, dim3(div_up((size_t)n_cells_alloc + 1, 256)), dim3(256), 0, c->stream,
-                           A.fine_start.as<uint32_t>(), (uint32_t)n_cells_alloc, A.cell_start.as<uint32_t>());
+                           A.fine_start.as<uint32_t>(), (uint32_t)n_cells_alloc, A.cell_start.as<uint32_t>(),
+                           c->gapq.as<uint32_t>());
         // tile traversal order (only worth it when there is more than one z plane of tiles)
+        // The order is a permutation of the tile ids that only steers locality: any permutation of the same nt
+        // tiles gives the same results.  Particles move a fraction of a cell per step, so the order of the last
+        // build stays good: rebuilt when the tile count or the grid changed and every 16th update.
+        const bool want_tiles = c->tile_block_rows > 0 && c->nc[2] > 1 && n > 64 * SPH_TILE;
+        const uint32_t nt_now = (uint32_t)div_up(n, SPH_TILE);
+        if (want_tiles && A.n_tiles == nt_now && A.tile_grid[0] == c->nc[0] && A.tile_grid[1] == c->nc[1] &&
+            A.tile_grid[2] == c->nc[2] && A.tile_grid[3] == (int)c->tile_block_rows && ++A.tile_age < 16) {
+            continue;
+        }
         A.n_tiles = 0;
-        if (c->tile_block_rows > 0 && c->nc[2] > 1 && n > 64 * SPH_TILE) {
+        if (want_tiles) {
+            A.tile_age = 0;
+            A.tile_grid[0] = c->nc[0]; A.tile_grid[1] = c->nc[1]; A.tile_grid[2] = c->nc[2]; A.tile_grid[3] = (int)c->tile_block_rows;
             const uint32_t nt = (uint32_t)div_up(n, SPH_TILE);
             SPH_TRY(A.tile_key.reserve((size_t)nt * 4 * 2));
             SPH_TRY(A.tile_id.reserve((size_t)nt * 4));

@@ -4,6 +4,7 @@
   from rho (taken when the group list promises the Tait EOS, sph_group.src_eos);
 * ``nl_reuse``  -- the second pair pass of an evaluation (TVF force, elastic
   rates) starts from the hit lists the first pass kept (sph_group.nl_mode);
+  off by default: measured 2-6 % slower (DESIGN.md section 4);
 * ``norm_masks`` -- a row's hit bits shifted down to the lane's first hit.
 
 Each is compared ON against OFF (to rounding where the arithmetic is regrouped,
@@ -97,8 +98,8 @@ def test_eos_not_fused_when_h_varies_or_tensile():
                          ids=['taylor-green', 'rings', 'rings-in-contact', 'block', 'rings-fp32'])
 def test_second_pass_on_kept_lists_is_bit_identical(argv):
     """only the schedule changes: same pairs, same order within a lane's list"""
-    on, c_on, r_on = _run(argv, {})
-    off, c_off, r_off = _run(argv, {'nl_reuse': 0})
+    on, c_on, r_on = _run(argv, {'nl_reuse': 1})
+    off, c_off, r_off = _run(argv, {})
     assert c_on['n_nl_keep'] > 0 and c_on['n_nl_reuse'] == c_on['n_nl_keep']
     assert c_off['n_nl_keep'] == 0 and c_off['n_nl_reuse'] == 0
     assert r_on['parity_ok'] or '--dtype' in argv, r_on
@@ -109,7 +110,7 @@ def test_second_pass_on_kept_lists_is_bit_identical(argv):
 def test_kept_lists_are_dropped_by_a_neighbour_update():
     """the lists belong to ONE sph_nnps_update: the next evaluation's first
     pass keeps new ones, a second pass never starts from the previous step's"""
-    on, cnt, res = _run(['--workload', 'taylor_green', '--n1', '40'], {}, steps=3)
+    on, cnt, res = _run(['--workload', 'taylor_green', '--n1', '40'], {'nl_reuse': 1}, steps=3)
     assert cnt['n_nl_keep'] == 3 and cnt['n_nl_reuse'] == 3 and res['parity_ok']
 
 
@@ -124,3 +125,18 @@ def test_normalised_masks_are_bit_identical(argv):
     assert r_on['parity_neighbour_count_mismatches'] == 0
     for k in on:
         assert np.array_equal(on[k], off[k]), k
+
+
+@pytest.mark.parametrize('depth', [2, 3, 4])
+@pytest.mark.parametrize('argv', [['--n1', '64'], ['--n1', '64', '--dtype', 'f32'],
+                                  ['--workload', 'dam_break', '--dx', '0.03']],
+                         ids=['cube', 'cube-fp32', 'dam-break'])
+def test_pipelined_phase2_is_bit_identical(argv, depth):
+    """option pipe_depth: the EOS-fused kernel with `depth` gathered records in
+    flight per lane (one wavefront per SIMD) -- same pairs in the same order"""
+    base, c0, r0 = _run(argv, {})
+    pipe, c1, r1 = _run(argv, {'pipe_depth': depth, 'lds_pad': 24576})
+    assert c0['n_eos_fused'] > 0 and c1['n_eos_fused'] > 0
+    assert r1['parity_neighbour_count_mismatches'] == 0
+    for k in base:
+        assert np.array_equal(base[k], pipe[k]), k

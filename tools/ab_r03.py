@@ -12,24 +12,20 @@ BASE = [sys.executable, os.path.join(REPO, 'bench.py'), '--no-cpu-baseline', '--
 
 CASES = [
     ('cube f64', []),
-    ('cube f64 eos_fuse=0', ['--opt', 'eos_fuse=0']),
     ('cube f32', ['--dtype', 'f32']),
-    ('cube f32 eos_fuse=0', ['--dtype', 'f32', '--opt', 'eos_fuse=0']),
     ('dam 0.0087', ['--workload', 'dam_break']),
-    ('dam 0.0087 eos_fuse=0', ['--workload', 'dam_break', '--opt', 'eos_fuse=0']),
+    ('dam 0.0055', ['--workload', 'dam_break', '--dx', '0.0055']),
     ('tg', ['--workload', 'taylor_green']),
-    ('tg nl_reuse=0', ['--workload', 'taylor_green', '--opt', 'nl_reuse=0']),
-    ('tg norm_masks=0', ['--workload', 'taylor_green', '--opt', 'norm_masks=0']),
-    ('tg nl_reuse=0 norm_masks=0', ['--workload', 'taylor_green', '--opt', 'nl_reuse=0', '--opt', 'norm_masks=0']),
     ('rings f64', ['--workload', 'elastic']),
-    ('rings f64 nl_reuse=0', ['--workload', 'elastic', '--opt', 'nl_reuse=0']),
-    ('rings f64 nl_reuse=0 norm_masks=0', ['--workload', 'elastic', '--opt', 'nl_reuse=0', '--opt', 'norm_masks=0']),
     ('rings f32', ['--workload', 'elastic', '--dtype', 'f32']),
-    ('rings f32 nl_reuse=0', ['--workload', 'elastic', '--dtype', 'f32', '--opt', 'nl_reuse=0']),
-    ('block f64', ['--workload', 'elastic_block', '--n1', '126']),
-    ('cube.py params', ['--params', 'cube']),
-    ('cube.py params norm_masks=0', ['--params', 'cube', '--opt', 'norm_masks=0']),
 ]
+for dt in ('f64', 'f32'):
+    for pd in (0, 2, 3, 4):
+        for pad in (0, 16384, 24576, 45056):
+            if pd == 0 and pad == 0:
+                continue
+            CASES.append(('pipe %s depth=%d lds_pad=%d' % (dt, pd, pad),
+                          ['--dtype', dt, '--opt', 'pipe_depth=%d' % pd, '--opt', 'lds_pad=%d' % pad]))
 
 
 def main():
