@@ -279,10 +279,6 @@ int sph_set_option(sph_ctx *c, const char *key, long value)
     if (strcmp(key, "eos_fuse") == 0) { c->eos_fuse = value; return SPH_OK; }
     if (strcmp(key, "nl_reuse") == 0) { c->nl_reuse = value; c->nl.valid = false; return SPH_OK; }
     if (strcmp(key, "norm_masks") == 0) { c->norm_masks = value; return SPH_OK; }
-    if (strcmp(key, "pipe_depth") == 0) {
-        if (value != 0 && (value < 2 || value > 4)) { sph_set_error("pipe_depth must be 0, 2, 3 or 4"); return SPH_ERR_ARG; }
-        c->pipe_depth = value; return SPH_OK;
-    }
     sph_set_error("sph_set_option: unknown key '%s'", key);
     return SPH_ERR_ARG;
 }

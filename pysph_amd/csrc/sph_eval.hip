@@ -439,8 +439,7 @@ typedef FamWCSPH_T<double> FamWCSPH;
 template <class T> struct FamWCSPHE_T : FamWCSPH_T<T> {
     static constexpr bool EOSF = true;
     static constexpr int NR = 8;
-    // one gathered record as it arrives (four / two 16-B pieces), and its decoding: kept apart so that the
-    // pipelined phase 2 can hold undecoded records in flight
+    // one gathered record as it arrives (four / two 16-B pieces), and its decoding
     struct Raw {
         typename std::conditional<sizeof(T) == 8, double2, float4>::type q[sizeof(T) == 8 ? 4 : 2];
     };
@@ -1099,10 +1098,7 @@ template <class Fam> static int launch_pair_fused(sph_ctx *c, int kk, const Pair
     for (int j = 1; j < a.nsrc; j++) if (a.src[j].flags != cf) cf = 0;
     if (c->const_flags == 0) cf = 0;
 #define LAUNCHE(K)                                                                                                              \
-    if (cf == Fam::CF0 && c->pipe_depth == 2) hipLaunchKernelGGL((k_pair_wave<Fam, K, true, FP32, Fam::CF0, 2>), g2, b2, (size_t)c->lds_pad, c->stream, a); \
-    else if (cf == Fam::CF0 && c->pipe_depth == 3) hipLaunchKernelGGL((k_pair_wave<Fam, K, true, FP32, Fam::CF0, 3>), g2, b2, (size_t)c->lds_pad, c->stream, a); \
-    else if (cf == Fam::CF0 && c->pipe_depth == 4) hipLaunchKernelGGL((k_pair_wave<Fam, K, true, FP32, Fam::CF0, 4>), g2, b2, (size_t)c->lds_pad, c->stream, a); \
-    else if (cf == Fam::CF0) hipLaunchKernelGGL((k_pair_wave<Fam, K, true, FP32, Fam::CF0>), g2, b2, (size_t)c->lds_pad, c->stream, a); \
+    if (cf == Fam::CF0) hipLaunchKernelGGL((k_pair_wave<Fam, K, true, FP32, Fam::CF0>), g2, b2, (size_t)c->lds_pad, c->stream, a); \
     else hipLaunchKernelGGL((k_pair_wave<Fam, K, true, FP32, 0>), g2, b2, (size_t)c->lds_pad, c->stream, a)
     switch (kk) {
     case 1: LAUNCHE(1); break;

@@ -306,14 +306,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
                     // workgroup of occupancy to LDS granularity with variable h (4 x 10.7 KB > 40 KB)
 #endif
 
-// PD > 0 (families with load_raw / decode, i.e. the EOS-fused WCSPH records): phase 2 keeps PD gathered
-// records in flight per lane -- the record of hit k + PD is requested before hit k is worked on -- and the
-// kernel is compiled for ONE wavefront per SIMD (512 VGPRs): with few wavefronts per CU their row windows
-// fit the 32-KB L1 and a line is filled once per sweep instead of once per iteration, while the software
-// pipeline, not other wavefronts, covers the L2 latency (option pipe_depth, with lds_pad limiting the
-// wavefronts per CU; measured in DESIGN.md section 4).
-template <class Fam, int KK, bool UH, bool F32 = false, uint32_t CF = 0, int PD = 0>
-__global__ __launch_bounds__(64 * WPB, PD ? 1 : Fam::MINB) void k_pair_wave(PairArgs<Fam> a)
+template <class Fam, int KK, bool UH, bool F32 = false, uint32_t CF = 0>
+__global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam> a)
 {
     typedef typename Fam::Real T; // arithmetic type of the pair loop
     static_assert(F32 || sizeof(T) == 8, "fp32 arithmetic reads fp32 records");
@@ -413,49 +407,6 @@ __global__ __launch_bounds__(64 * WPB, PD ? 1 : Fam::MINB) void k_pair_wave(Pair
             } while (__any(m != 0));
         }
         cq = 0;
-    };
-
-    // phase 2 with PD records in flight per lane (see the template comment)
-    auto phase2p = [&](uint32_t flags) {
-        if constexpr (PD > 0) {
-            unsigned long long m = 0;
-            uint32_t jb = 0;
-            int q = 0;
-            if (cq > 0) { m = smask[0][t]; jb = sjb[0][t]; }
-            const uint32_t self = a.d_off + ic;
-            if (__any(m != 0)) {
-                typename Fam::Raw raw[PD];
-                bool has[PD];
-                auto advance = [&](int d) {
-                    has[d] = m != 0;
-                    const uint32_t j = has[d] ? jb + (uint32_t)__builtin_ctzll(m) : self;
-                    m &= m - 1;
-                    if (m == 0 && q + 1 < cq) { ++q; m = smask[q][t]; jb = sjb[q][t]; }
-                    Fam::load_raw(a, j, raw[d]);
-                };
-#pragma unroll
-                for (int d = 0; d < PD; d++) advance(d);
-                bool more = true;
-                while (more) {
-#pragma unroll
-                    for (int d = 0; d < PD; d++) {
-                        if (!__any(has[d])) { more = false; break; } // lists are consumed in order: nothing follows
-                        real4<T> pj;
-                        T sj[Fam::NA];
-                        Fam::decode(a, raw[d], pj, sj);
-                        const T r2 = r2_exact<T>(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-                        const bool pass = has[d] && (r2 < hi2);
-                        Fam::template pair<KK, UH>(D, pi, pj, r2, sj, flags, a, pass);
-                        advance(d);
-                    }
-                }
-            }
-            cq = 0;
-        }
-    };
-    auto run_phase2 = [&](uint32_t flags) {
-        if constexpr (PD > 0) phase2p(flags);
-        else phase2(flags);
     };
 
     // neighbour-list reuse (one source): this wave tile's block of the list buffer
@@ -600,7 +551,7 @@ __global__ __launch_bounds__(64 * WPB, PD ? 1 : Fam::MINB) void k_pair_wave(Pair
                             jb0 += (uint32_t)sh;
                         }
                         // a lane without room for this tile's slots: the wavefront works its lists off first (rare)
-                        if (__any(cq + (m0 != 0) + (m2 != 0) > WLQ)) { run_phase2(fl); unsaved = true; }
+                        if (__any(cq + (m0 != 0) + (m2 != 0) > WLQ)) { phase2(fl); unsaved = true; }
                         if (m0) { smask[cq][t] = m0; sjb[cq][t] = jb0; cq++; }
                         if (m2) { smask[cq][t] = m2; sjb[cq][t] = jb0 + 64u; cq++; }
                         // rare: a lane's range is longer than AMAXLEN -> exact tail, in place
@@ -627,7 +578,7 @@ __global__ __launch_bounds__(64 * WPB, PD ? 1 : Fam::MINB) void k_pair_wave(Pair
             }
         }
     }
-    run_phase2(fl);
+    phase2(fl);
     }
     if (active) Fam::finish(D, a, o);
 }

@@ -126,17 +126,3 @@ def test_normalised_masks_are_bit_identical(argv):
     for k in on:
         assert np.array_equal(on[k], off[k]), k
 
-
-@pytest.mark.parametrize('depth', [2, 3, 4])
-@pytest.mark.parametrize('argv', [['--n1', '64'], ['--n1', '64', '--dtype', 'f32'],
-                                  ['--workload', 'dam_break', '--dx', '0.03']],
-                         ids=['cube', 'cube-fp32', 'dam-break'])
-def test_pipelined_phase2_is_bit_identical(argv, depth):
-    """option pipe_depth: the EOS-fused kernel with `depth` gathered records in
-    flight per lane (one wavefront per SIMD) -- same pairs in the same order"""
-    base, c0, r0 = _run(argv, {})
-    pipe, c1, r1 = _run(argv, {'pipe_depth': depth, 'lds_pad': 24576})
-    assert c0['n_eos_fused'] > 0 and c1['n_eos_fused'] > 0
-    assert r1['parity_neighbour_count_mismatches'] == 0
-    for k in base:
-        assert np.array_equal(base[k], pipe[k]), k
