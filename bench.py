@@ -172,6 +172,7 @@ def make_elastic(n1):
         u=1e-2 * rng.uniform(-1, 1, x.size),
         constants=dict(E=E, nu=nu, rho_ref=rho0, n=4,
                        wdeltap=float(kernel.kernel(rij=dx, h=h0))))
+    pa.gid[:] = np.arange(x.size, dtype=pa.gid.dtype)
     return pa, dx, kernel
 
 
@@ -184,6 +185,21 @@ class Workload(object):
     fields = ()           # output properties the parity checks compare
     slab = None           # (lo, hi, periodic, period) of this rank's slab
     halo_width = 0.0
+
+
+def cut_slab(w, pa, rank, world, halo_width):
+    """N > 1, ONE problem (strong scaling): this rank's slab of `pa` along x,
+    cut at the quantiles of x (equal particle counts)"""
+    if world == 1:
+        return pa
+    from pysph_amd.parallel import slab_bounds
+    cuts = slab_bounds(pa.x, world)
+    lo = -1e30 if rank == 0 else float(cuts[rank])
+    hi = 1e30 if rank == world - 1 else float(cuts[rank + 1])
+    w.scaling = 'strong'
+    w.slab = (lo, hi, False, 0.0)
+    w.halo_width = halo_width
+    return pa.extract_particles(np.nonzero((pa.x >= lo) & (pa.x < hi))[0], name=pa.name)
 
 
 def build_workload(args, rank, world):
@@ -284,13 +300,13 @@ def build_workload(args, rank, world):
             w.fields = ('rho', 'V')
     elif args.workload == 'elastic':
         from pysph_amd.solid_mech import ElasticSolidsScheme
-        if world > 1:
-            raise SystemExit('elastic workload: single GPU only (DESIGN.md section 6)')
         spacing = args.rings_spacing if args.rings_spacing > 0 else 0.041
         pa, kernel = make_rings3d(args.rings_dx, spacing=spacing)
+        pa = cut_slab(w, pa, rank, world, kernel.radius_scale * 1.5 * args.rings_dx)
         w.arrays = [pa]
         w.kernel = kernel
-        w.eqs = ElasticSolidsScheme(['solid'], [], dim=3).get_equations()
+        w.eqs = ElasticSolidsScheme(['solid'], [], dim=3,
+                                    ghost_recompute=world > 1).get_equations()
         # velocity-gradient pass: x,y,z,h,u,v,w,m,rho read (72 B), v00..v22 written (72 B);
         # rates pass: x,y,z,h,u,v,w,m,rho,cs,p,s_ij,r_ij read (184 B), arho,au..aw,ax..az written (56 B)
         w.algo_pair = 144.0 + 240.0
@@ -304,15 +320,12 @@ def build_workload(args, rank, world):
                     'r00', 'r01', 'r02', 'r11', 'r12', 'r22')
     else:
         from pysph_amd.solid_mech import ElasticSolidsScheme
-        if world > 1:
-            # its first group (real=True) computes p and the artificial stress
-            # r_ij that the second group reads from ghosts: needs the reference's
-            # mid-evaluation update_remote_particle_properties, not built
-            raise SystemExit('elastic workload: single GPU only (DESIGN.md section 6)')
         pa, dx, kernel = make_elastic(n1)
+        pa = cut_slab(w, pa, rank, world, kernel.radius_scale * 1.3 * dx)
         w.arrays = [pa]
         w.kernel = kernel
-        w.eqs = ElasticSolidsScheme(['solid'], [], dim=3).get_equations()
+        w.eqs = ElasticSolidsScheme(['solid'], [], dim=3,
+                                    ghost_recompute=world > 1).get_equations()
         w.algo_pair = 144.0 + 240.0
         w.name = ('Elastic solid block (Gray 2001 equation set, rings.py material), '
                   '%d^3 = %d particles, CubicSpline hdx 1.3' % (n1, pa.get_number_of_particles()))
@@ -521,6 +534,11 @@ def parse_args(argv=None):
     ap.add_argument('--no-check', action='store_true', help='skip the oracle parity check')
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary configurations')
     ap.add_argument('--cpu-n1', type=int, default=100)
+    ap.add_argument('--fixed-bounds', action='store_true', dest='fixed_bounds',
+                    help='hand nnps.update() the grid bounds and the (constant) h range instead of '
+                         'reducing them every update: LinkedListNNPS(fixed_h=True) plus bounds a '
+                         'stepping host knows from its own reductions; removes the min/max pass and '
+                         'its device->host round trip from the step (reported in config)')
     ap.add_argument('--self-slab', action='store_true', dest='self_slab',
                     help='taylor_green on ONE GPU through the N>1 code path: the periodic x axis '
                          'is a slab whose two faces are exchanged with this rank itself over RCCL')
@@ -621,10 +639,11 @@ def setup(args, w, rank, world, dist, ctx):
         dev.attach(a, ctx).push()       # everything resident in HBM
     halo = None
     if world > 1 or (args.self_slab and w.slab is not None and w.slab[2]):
-        from pysph_amd.parallel import (SlabDecomposition, TVF_HALO_PROPS,
-                                        WCSPH_HALO_PROPS)
+        from pysph_amd.parallel import (ELASTIC_HALO_PROPS, SlabDecomposition,
+                                        TVF_HALO_PROPS, WCSPH_HALO_PROPS)
         lo, hi, periodic, period = w.slab
-        props = TVF_HALO_PROPS if args.workload == 'taylor_green' else WCSPH_HALO_PROPS
+        props = {'taylor_green': TVF_HALO_PROPS, 'elastic': ELASTIC_HALO_PROPS,
+                 'elastic_block': ELASTIC_HALO_PROPS}.get(args.workload, WCSPH_HALO_PROPS)
         halo = SlabDecomposition(w.arrays, ctx, rank, world, axis=0,
                                  width=w.halo_width, lo=lo, hi=hi, props=props,
                                  periodic=periodic, period=period, dist=dist)
@@ -635,7 +654,7 @@ def setup(args, w, rank, world, dist, ctx):
     a_eval = AccelerationEval(w.arrays, w.eqs, w.kernel)
     SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
     nnps = HipNNPS(3, w.arrays, radius_scale=w.kernel.radius_scale, ctx=ctx,
-                   sync=False, domain=domain)
+                   sync=False, domain=domain, fixed_h=bool(args.fixed_bounds))
     a_eval.set_nnps(nnps)
     ordered = False
     if not args.no_reorder:
@@ -651,6 +670,17 @@ def setup(args, w, rank, world, dist, ctx):
                 halo.exchange()
             nnps.update()
         ordered = True
+
+    if args.fixed_bounds:
+        # the particles of this benchmark do not move: the box of one full update
+        # (ghosts included), padded by a cell, holds every later one
+        if domain is not None:
+            nnps.update_domain()
+        elif halo is not None:
+            halo.exchange()
+        nnps.update()
+        pad = nnps.cell_size
+        nnps.bounds = tuple(nnps.xmin - pad) + tuple(nnps.xmax + pad)
 
     def step():
         if domain is not None:
@@ -779,6 +809,7 @@ def run(args, rank, local_rank, world, dist):
             'spatially_ordered': ordered,
             'parallelism': 'slab%d' % world if world > 1 else ('slab1-self-exchange' if halo is not None else 'single'),
             'rccl_ranks': world if dist is not None else 0,
+            'fixed_bounds': bool(args.fixed_bounds),
         },
         'roofline': {
             'bound': 'hbm', 'kernel': 'k_pair_%s<%s,%s>' % (
@@ -918,9 +949,11 @@ def multi_rank_parity(args, rank, local_rank, world, dist, tstream):
     import torch
     from pysph_amd import device as dev
     a2 = copy.copy(args)
+    one_problem = args.workload in ('dam_break', 'elastic', 'elastic_block')   # cut into slabs (strong scaling)
     if args.workload != 'dam_break':
         a2.n1 = 24
     a2.dx = max(args.dx, 0.05)
+    a2.rings_dx = max(args.rings_dx, 2e-3)
     a2.no_reorder = True
     ctx = dev.HipContext(local_rank, tstream.cuda_stream)
     apply_options(a2, ctx)
@@ -953,7 +986,7 @@ def multi_rank_parity(args, rank, local_rank, world, dist, tstream):
         # the whole domain on this GPU alone
         ctx1 = dev.HipContext(local_rank, tstream.cuda_stream)
         apply_options(a2, ctx1)
-        if args.workload == 'dam_break':
+        if one_problem:
             w1 = build_workload(a2, 0, 1)
         else:
             parts = [build_workload(a2, r, world) for r in range(world)]

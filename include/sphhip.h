@@ -184,6 +184,12 @@ int sph_array_device_ptr(sph_ctx *ctx, int array_id, int prop, void **dptr);
  * when non-NULL (multi-GPU runs share the global grid).                    */
 int sph_nnps_update(sph_ctx *ctx, int dim, int narrays, const int *array_ids,
                     double radius_scale, double cell_size, const double *bounds);
+/* The caller knows the range of h (Integrator.set_fixed_h / LinkedListNNPS(fixed_h=True),
+ * pysph/sph/integrator.py:62-81, linked_list_nnps.pyx:54: smoothing lengths that
+ * never change): sph_nnps_update then skips the h reduction, and with `bounds`
+ * given as well the whole min/max pass and its device->host round trip.
+ * hmax < 0 forgets the range.                                                */
+int sph_nnps_set_h_range(sph_ctx *ctx, double hmin, double hmax);
 /* d8: cell_size hmin xmin[3] xmax[3];  i4: ncx ncy ncz n_cells             */
 int sph_nnps_info(sph_ctx *ctx, double *d8, long *i4);
 /* min/max of x,y,z,h over the listed arrays, no padding (out: 8 doubles
@@ -362,6 +368,25 @@ int sph_halo_image(sph_ctx *ctx, int array_id, int side, int nprops, const int *
                    double val, size_t *count);
 int sph_halo_append(sph_ctx *ctx, int array_id, int nprops, const int *props, const void *src_device,
                     size_t count);
+/* Selection AND packing of both slab faces (mode 0 of sph_halo_select: lo:
+ * v < lo_cut, hi: v >= hi_cut) without a host round trip -- the ghost refresh of
+ * ParallelManager.update (pysph/parallel/parallel_manager.pyx:512-530,
+ * remote_exchange_data :159-210) as ONE device pass per array: the rows go
+ * straight into two fixed-capacity device messages dst2[side], laid out
+ * [nprops][cap2[side]] doubles followed by ONE header double = the row count,
+ * NEGATED when it exceeds the capacity (the payload is then incomplete: repeat
+ * that face through sph_halo_select / sph_halo_pack with the exact size).
+ * shift2[side] is added to the `axis` coordinate (periodic wrap).  dst2[side]
+ * may be NULL (open face).  At most 32 properties.  The host learns the counts
+ * from the headers (the receiver's copy tells it how many rows to append with
+ * sph_halo_append_strided).                                                  */
+int sph_halo_select_pack(sph_ctx *ctx, int array_id, int axis, double lo_cut, double hi_cut, size_t upto,
+                         int nprops, const int *props, const double *shift2, const size_t *cap2,
+                         void *const *dst2);
+/* sph_halo_append from a message whose rows are `stride` doubles apart
+ * (property k of row i at src[k * stride + i], stride >= count).            */
+int sph_halo_append_strided(sph_ctx *ctx, int array_id, int nprops, const int *props, const void *src_device,
+                            size_t count, size_t stride);
 
 /* Remove the particles of the last sph_halo_select (both sides) from the
  * array -- particles that migrated to a neighbouring slab, after their

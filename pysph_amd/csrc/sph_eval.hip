@@ -199,6 +199,7 @@ struct PackArgs {
     int derived;                  // 1: aux[5] = p/(rho*rho) (p = aux[7], rho = aux[4]); 2: aux[10] = 1/V^2 (V = aux[8]);
                                   // 3: aux[6..11] = (s_ij - p delta_ij)/rho^2 (p = aux[18], rho = aux[4])
                                   // 4: aux[3] = m/rho (m = aux[3], rho = aux[4]; aux[4] itself is not stored)
+                                  // 5: aux[0] = the particle's original index (neighbour lists)
     double4 *posh;
     double *aux;
     double *rec;                  // non-null: interleaved records [x y z h aux... pad], nr doubles each
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
     if (a.derived == 1) v[5] = v[4] != 0.0 ? v[7] * (1.0 / (v[4] * v[4])) : 0.0; // tmpj = p*rhoj21, wc/basic.py:211,234
     if (a.derived == 2) { double Vj = 1. / v[8]; v[10] = Vj * Vj; } // Vj2, transport_velocity.py:303-306
     if (a.derived == 4) v[3] = v[3] / v[4]; // m/rho, basic_equations.py:103,139 (VelocityGradient tmp)
+    if (a.derived == 5) v[0] = (double)o;
     if (a.derived == 3) { // (sigma_ij)/rho^2 with sigma = s - p I: solid_mech/basic.py:281-283,333-339,367-378
         const double r21 = 1. / (v[4] * v[4]), pr = v[18];
         v[6] = (v[6] - pr) * r21; v[7] *= r21; v[8] *= r21;
@@ -532,6 +534,47 @@ typedef FamDensity_T<double> FamDensity;
 // Density records of the aggregated kernel under uniform h: [x y z m] (32 B, two
 // 16-B pieces per pair); otherwise the generic [x y z h | m pad].
 template <> __device__ __forceinline__ void load_record<FamDensity, true>(const double *__restrict__ rj, uint32_t fl, double4 &pj, double (&s)[1])
+{
+    const double2 *r2 = reinterpret_cast<const double2 *>(rj);
+    const double2 a0 = r2[0], a1 = r2[1];
+    pj.x = a0.x; pj.y = a0.y; pj.z = a1.x; pj.w = 0.0;
+    s[0] = a1.y;
+}
+
+// ---- neighbour lists (LinkedListNNPS.find_nearest_neighbors, linked_list_nnps.pyx:92-196; the reference's
+//      NeighborCache, nnps_base.pyx:1144-1257) on the pair-kernel skeleton: the "equation" counts the pairs
+//      that pass the exact criterion and, in the fill pass, writes the neighbour's ORIGINAL index (it travels
+//      in the record as a double) behind the destination's list start.  Same candidate tiles, fp32 prefilter
+//      and exact test as every other family, so the lists are the pair loops' own neighbour sets.
+struct FamNbr {
+    typedef double Real;
+    static constexpr bool PRED = true;
+    static constexpr uint32_t CF0 = 1;
+    static constexpr int MINB = 4;
+    static constexpr int NA = 1; // original index of the particle
+    static constexpr int NR = 6; // x y z h idx pad  (uniform h: [x y z idx])
+    struct Params { uint32_t *count; const uint32_t *start; uint32_t *nbrs; };
+    struct Dest { uint32_t n, base; };
+    template <class A> static __device__ __forceinline__ void load(Dest &D, const double *, const A &a, uint32_t o)
+    {
+        D.n = 0;
+        D.base = a.p.start ? a.p.start[o] : 0u;
+    }
+    template <int KK, bool UH, class A>
+    static __device__ __forceinline__ void pair(Dest &D, const double4 &, const double4 &, double, const double (&s)[NA], uint32_t,
+                                                const A &a, bool pass = true)
+    {
+        if (pass) {
+            if (a.p.nbrs) a.p.nbrs[D.base + D.n] = (uint32_t)s[0];
+            D.n++;
+        }
+    }
+    template <class A> static __device__ __forceinline__ void finish(Dest &D, const A &a, uint32_t o)
+    {
+        if (a.p.count) a.p.count[o] = D.n;
+    }
+};
+template <> __device__ __forceinline__ void load_record<FamNbr, true>(const double *__restrict__ rj, uint32_t, double4 &pj, double (&s)[1])
 {
     const double2 *r2 = reinterpret_cast<const double2 *>(rj);
     const double2 a0 = r2[0], a1 = r2[1];
@@ -879,7 +922,7 @@ static int run_nosrc(sph_ctx *c, const sph_equation &e, size_t start, size_t sto
     return SPH_OK;
 }
 
-enum Family { FAM_NONE, FAM_WCSPH, FAM_DENSITY, FAM_TVF, FAM_VGRAD, FAM_ELASTIC };
+enum Family { FAM_NONE, FAM_WCSPH, FAM_DENSITY, FAM_TVF, FAM_VGRAD, FAM_ELASTIC, FAM_NBR };
 
 static int eq_family(int kind, uint32_t *flag, bool elastic)
 {
@@ -930,6 +973,10 @@ static PackPlan pack_plan(int fam)
         p.nr = FamDensity::NR;
         p.na = 1;
         p.props[0] = SPH_M;
+    } else if (fam == FAM_NBR) {
+        p.nr = FamNbr::NR;
+        p.na = 1;
+        p.derived = 5; // aux[0] = the particle's original index
     } else if (fam == FAM_VGRAD) {
         p.nr = FamVGrad::NR;
         p.na = 4;
@@ -963,6 +1010,7 @@ static bool slot_required(int fam, uint32_t flags, int prop)
         return false;
     }
     if (fam == FAM_DENSITY) return prop == SPH_M;
+    if (fam == FAM_NBR) return false;
     if (fam == FAM_VGRAD) return true;
     if (fam == FAM_ELASTIC) {
         if (prop == SPH_U || prop == SPH_V || prop == SPH_W || prop == SPH_M) return true;
@@ -1026,7 +1074,7 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
     pa.radius_scale = c->radius_scale;
     if (c->pair_variant >= 2) pa.rec = c->posh.as<double>();
     if (c->pair_variant >= 3) pa.fpos = c->fposb.as<float4>();
-    pa.layout = (c->pair_variant >= 3 && fam == FAM_WCSPH) ? 1 : (c->pair_variant >= 3 && fam == FAM_DENSITY && pl.nr == 4) ? 2
+    pa.layout = (c->pair_variant >= 3 && fam == FAM_WCSPH) ? 1 : (c->pair_variant >= 3 && (fam == FAM_DENSITY || fam == FAM_NBR) && pl.nr == 4) ? 2
               : (c->pair_variant >= 3 && fam == FAM_TVF && (pl.nr == 14 || pl.nr == 12)) ? 3 : 0;
     if (c->pair_variant >= 3 && (c->record_f32 || c->arith_f32)) pa.layout = 5;
     if (c->cur_eosf) {
@@ -1143,6 +1191,50 @@ static void fill_common(sph_ctx *c, PairArgs<Fam> &a, const sph_kernel *K, doubl
 static int ensure_out(sph_ctx *c, int id, std::initializer_list<int> props)
 {
     for (int p : props) SPH_TRY(sph_array_ensure_prop(c, id, p));
+    return SPH_OK;
+}
+
+// Neighbour lists of `dst` among `src` through the wave-tile pair kernel (nnps_build_csr_device /
+// sph_nnps_get_csr): count pass (count[nd] filled, start == nullptr) or fill pass (start[nd], nbrs filled).
+int nnps_csr_pair_kernel(sph_ctx *c, int src, int dst, uint32_t *count, const uint32_t *start, uint32_t *nbrs)
+{
+    DevArray &S = c->arr[src], &D = c->arr[dst];
+    if (D.n == 0) return SPH_OK;
+    const bool uh = c->uniform_h && c->use_uniform_h;
+    const bool dest_is_src = src == dst;
+    const size_t total = S.n + (dest_is_src ? 0 : D.n);
+    if (total >= (1ull << 32)) { sph_set_error("too many particles for 32-bit packed indices"); return SPH_ERR_ARG; }
+    PackPlan pl = pack_plan(FAM_NBR);
+    if (uh) pl.nr = 4;
+    const bool was_f32 = c->record_f32 != 0, was_a32 = c->arith_f32 != 0; // lists are exact: fp64 records always
+    c->record_f32 = 0; c->arith_f32 = 0;
+    c->cur_eosf = false;
+    c->cur_nrec = pl.nr;
+    int rc = c->posh.reserve((total + 64) * sizeof(double) * pl.nr);
+    if (rc == SPH_OK) rc = c->aux.reserve(64);
+    if (rc == SPH_OK) rc = c->fposb.reserve((total + 64) * sizeof(float4));
+    for (auto &pc : c->pack_cache) pc.epoch = 0;
+    if (rc == SPH_OK) rc = pack_array(c, src, 0, pl, FAM_NBR, 1u, false);
+    if (rc == SPH_OK && !dest_is_src) rc = pack_array(c, dst, S.n, pl, FAM_NBR, 1u, true);
+    c->record_f32 = was_f32; c->arith_f32 = was_a32;
+    if (rc != SPH_OK) return rc;
+    sph_kernel K;
+    K.kind = 1; K.dim = c->dim; K.fac = 1.0; K.radius_scale = c->radius_scale; K.deltap = 0.0;
+    PairArgs<FamNbr> a;
+    memset(&a, 0, sizeof a);
+    fill_common(c, a, &K, 0.0);
+    a.ablate = 0; a.dbg = nullptr;
+    a.nsrc = 1;
+    a.src[0] = {S.cell_start.as<uint32_t>(), 0u, 1u, S.fine_start.as<uint32_t>()};
+    a.d_off = dest_is_src ? 0u : (uint32_t)S.n;
+    a.nd = (uint32_t)D.n;
+    a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
+    a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
+    a.d_start = 0; a.d_stop = (uint32_t)D.n; a.dflags = 1u;
+    a.p.count = count; a.p.start = start; a.p.nbrs = nbrs;
+    dim3 g2(4 * div_up(a.nd, 256) / WPB), b2(64 * WPB);
+    if (uh) hipLaunchKernelGGL((k_pair_wave<FamNbr, 1, true, false, 1>), g2, b2, 0, c->stream, a);
+    else hipLaunchKernelGGL((k_pair_wave<FamNbr, 1, false, false, 1>), g2, b2, 0, c->stream, a);
     return SPH_OK;
 }
 

@@ -78,12 +78,12 @@ __global__ __launch_bounds__(256) void k_halo_gather_multi(PropList L, const uin
 }
 
 __global__ __launch_bounds__(256) void k_halo_append_multi(PropList L, const double *__restrict__ src, size_t n0,
-                                                           size_t count)
+                                                           size_t count, size_t stride)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const int k = blockIdx.y;
-    L.p[k][n0 + i] = src[(size_t)k * count + i];
+    L.p[k][n0 + i] = src[(size_t)k * stride + i];
 }
 
 
@@ -126,6 +126,87 @@ extern "C" int sph_halo_select(sph_ctx *c, int id, int axis, int mode, double p0
     if (H.count[0] + H.count[1])
         hipLaunchKernelGGL(k_halo_scatter, dim3(div_up(n, 256)), dim3(256), 0, c->stream, fl, ps, n,
                            H.list[0].as<uint32_t>(), H.list[1].as<uint32_t>());
+    return SPH_OK;
+}
+
+// Selection and packing of both faces WITHOUT the host: thread i owns particle i, its list positions come
+// from the scan, its rows go straight into the two fixed-capacity messages [nprops][cap] (+ one header
+// double behind them: the row count, negated when it exceeds the capacity -- the payload is then incomplete
+// and the pair repeats that face with the exact size).  The thread of the last particle writes the headers.
+struct DirectPack {
+    const double *p[32];
+    int nprops, axis_k; // index of the slab-axis coordinate among the packed properties, or -1
+    double shift[2];
+    size_t cap[2];
+    double *dst[2];
+};
+
+__global__ __launch_bounds__(256) void k_halo_pack_direct(DirectPack a, const unsigned long long *__restrict__ flag,
+                                                          const unsigned long long *__restrict__ pos, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long f = flag[i], p = pos[i];
+    const size_t pl[2] = {(size_t)(p & 0xffffffffull), (size_t)(p >> 32)};
+    const bool on[2] = {(f & 1ull) != 0, (f >> 32) != 0};
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        if (on[s] && a.dst[s] && pl[s] < a.cap[s])
+            for (int k = 0; k < a.nprops; k++) {
+                double v = a.p[k][i];
+                if (k == a.axis_k) v += a.shift[s];
+                a.dst[s][(size_t)k * a.cap[s] + pl[s]] = v;
+            }
+        if (i == n - 1 && a.dst[s]) {
+            const size_t cnt = pl[s] + (on[s] ? 1 : 0);
+            a.dst[s][(size_t)a.nprops * a.cap[s]] = cnt <= a.cap[s] ? (double)cnt : -(double)cnt;
+        }
+    }
+}
+
+extern "C" int sph_halo_select_pack(sph_ctx *c, int id, int axis, double lo_cut, double hi_cut, size_t upto, int nprops,
+                                    const int *props, const double *shift2, const size_t *cap2, void *const *dst2)
+{
+    if (!c || id < 0 || id >= SPH_MAX_ARRAYS || axis < 0 || axis > 2 || nprops < 1 || nprops > 32 || !props || !shift2 ||
+        !cap2 || !dst2) {
+        sph_set_error("sph_halo_select_pack: bad arguments (at most 32 properties)");
+        return SPH_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    DevArray &A = c->arr[id];
+    HaloState &H = c->halo[id];
+    const size_t n = upto ? (upto < A.n ? upto : A.n) : A.n_real;
+    H.count[0] = H.count[1] = 0; // the host does not learn the counts: no list-based call may follow
+    H.nsel = 0;
+    DirectPack a;
+    a.nprops = nprops;
+    a.axis_k = -1;
+    for (int k = 0; k < nprops; k++) {
+        const int p = props[k];
+        if (p < 0 || p >= SPH_PROP_COUNT || !A.prop[p]) {
+            sph_set_error("sph_halo_select_pack: array %d has no device property %d", id, p);
+            return SPH_ERR_MISSING_PROP;
+        }
+        a.p[k] = A.prop[p];
+        if (p == SPH_X + axis) a.axis_k = k;
+    }
+    for (int s = 0; s < 2; s++) { a.shift[s] = shift2[s]; a.cap[s] = cap2[s]; a.dst[s] = (double *)dst2[s]; }
+    if (n == 0) { // empty array: empty messages
+        for (int s = 0; s < 2; s++)
+            if (a.dst[s]) HIP_TRY(hipMemsetAsync(a.dst[s] + (size_t)nprops * a.cap[s], 0, sizeof(double), c->stream));
+        return SPH_OK;
+    }
+    const double *coord = A.prop[SPH_X + axis];
+    if (!coord) { sph_set_error("sph_halo_select_pack: no device coordinates"); return SPH_ERR_MISSING_PROP; }
+    SPH_TRY(H.flag[0].reserve((n + 1) * 8));
+    SPH_TRY(H.pos[0].reserve((n + 1) * 8));
+    unsigned long long *fl = H.flag[0].as<unsigned long long>(), *ps = H.pos[0].as<unsigned long long>();
+    hipLaunchKernelGGL(k_halo_flags, dim3(div_up(n, 256)), dim3(256), 0, c->stream, coord, n, 0, lo_cut, hi_cut, 0.0, fl);
+    size_t tmp = 0;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, fl, ps, (int)n, c->stream));
+    SPH_TRY(c->cub_tmp.reserve(tmp));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.ptr, tmp, fl, ps, (int)n, c->stream));
+    hipLaunchKernelGGL(k_halo_pack_direct, dim3(div_up(n, 256)), dim3(256), 0, c->stream, a, fl, ps, n);
     return SPH_OK;
 }
 
@@ -189,7 +270,14 @@ extern "C" int sph_halo_pack_mirror(sph_ctx *c, int id, int side, int nprops, co
 
 extern "C" int sph_halo_append(sph_ctx *c, int id, int nprops, const int *props, const void *src, size_t count)
 {
-    if (!c || id < 0 || id >= SPH_MAX_ARRAYS || nprops < 1) { sph_set_error("sph_halo_append: bad arguments"); return SPH_ERR_ARG; }
+    return sph_halo_append_strided(c, id, nprops, props, src, count, count);
+}
+
+// rows of a fixed-capacity message: property k of row i at src[k * stride + i]
+extern "C" int sph_halo_append_strided(sph_ctx *c, int id, int nprops, const int *props, const void *src, size_t count,
+                                       size_t stride)
+{
+    if (!c || id < 0 || id >= SPH_MAX_ARRAYS || nprops < 1 || stride < count) { sph_set_error("sph_halo_append: bad arguments"); return SPH_ERR_ARG; }
     if (count == 0) return SPH_OK;
     DevArray &A = c->arr[id];
     size_t n0 = A.n;
@@ -199,7 +287,7 @@ extern "C" int sph_halo_append(sph_ctx *c, int id, int nprops, const int *props,
     PropList L;
     for (int k = 0; k < nprops; k++) { L.p[k] = A.prop[props[k]]; L.what[k] = 0; }
     hipLaunchKernelGGL(k_halo_append_multi, dim3(div_up(count, 256), nprops), dim3(256), 0, c->stream, L,
-                       (const double *)src, n0, count);
+                       (const double *)src, n0, count, stride);
     c->nnps_valid = false;
     return SPH_OK;
 }

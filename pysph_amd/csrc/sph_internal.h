@@ -130,6 +130,7 @@ struct sph_ctx {
     DevBuf nlbuf;
     struct { bool valid = false; unsigned long long epoch = 0; int dst = -1, src = -1; size_t start = 0, stop = 0, nd = 0; } nl;
     unsigned long long nnps_epoch = 0; // bumped by every sph_nnps_update
+    double h_known[2] = {0.0, -1.0};   // sph_nnps_set_h_range: hmin, hmax (hmax < 0: unknown)
 
     void *comm = nullptr;   // SphComm of libsphcomm.so (sph_comm.hip), or nullptr
 
@@ -149,6 +150,8 @@ struct ScopedTimer {
 // nnps.hip
 int nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *out8);
 int nnps_build_csr_device(sph_ctx *c, int src, int dst, DevBuf &start, DevBuf &nbrs, size_t *total);
+// eval.hip: the same lists through the wave-tile pair kernel (count pass: start == nullptr; fill pass: start, nbrs)
+int nnps_csr_pair_kernel(sph_ctx *c, int src, int dst, uint32_t *count, const uint32_t *start, uint32_t *nbrs);
 
 // eval.hip helpers
 static inline unsigned div_up(size_t a, unsigned b) { return (unsigned)((a + b - 1) / b); }

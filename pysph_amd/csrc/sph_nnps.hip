@@ -296,7 +296,19 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
         }
     }
     double mm[8];
-    SPH_TRY(nnps_minmax(c, narrays, ids, mm));
+    if (bounds && c->h_known[1] >= 0.0) {
+        // the grid is given and the h range known (sph_nnps_set_h_range): no reduction, no round trip
+        for (int k = 0; k < 3; k++) { mm[k] = bounds[k]; mm[4 + k] = bounds[3 + k]; }
+        mm[3] = c->h_known[0]; mm[7] = c->h_known[1];
+        for (int a = 0; a < narrays; a++) {
+            DevArray &A = c->arr[ids[a]];
+            for (int p : {SPH_X, SPH_Y, SPH_Z, SPH_H})
+                if (A.n && !A.prop[p]) { sph_set_error("nnps: array %d has no device copy of x/y/z/h", ids[a]); return SPH_ERR_MISSING_PROP; }
+        }
+    } else {
+        SPH_TRY(nnps_minmax(c, narrays, ids, mm));
+        if (c->h_known[1] >= 0.0) { mm[3] = c->h_known[0]; mm[7] = c->h_known[1]; }
+    }
 
     // DomainManager._compute_cell_size_for_binning (nnps_base.pyx:942-978)
     double hmax = -1.0, hmin = DBL_MAX;
@@ -486,6 +498,13 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
     return SPH_OK;
 }
 
+extern "C" int sph_nnps_set_h_range(sph_ctx *c, double hmin, double hmax)
+{
+    if (!c || (hmax >= 0.0 && hmin > hmax)) { sph_set_error("sph_nnps_set_h_range: bad arguments"); return SPH_ERR_ARG; }
+    c->h_known[0] = hmin; c->h_known[1] = hmax;
+    return SPH_OK;
+}
+
 extern "C" int sph_nnps_info(sph_ctx *c, double *d8, long *i4)
 {
     if (!c->nnps_valid) { sph_set_error("sph_nnps_info: call sph_nnps_update first"); return SPH_ERR_STATE; }
@@ -582,8 +601,12 @@ extern "C" int sph_nnps_get_csr(sph_ctx *c, int src, int dst, uint32_t *start, s
     g.cell_size = c->cell_size;
     SPH_TRY(c->tmp_u32a.reserve((nd + 1) * 4));
     uint32_t *d_start = c->tmp_u32a.as<uint32_t>();
+    // variant 6 (default): the lists come from the wave-tile pair kernel itself (nnps_csr_pair_kernel);
+    // variant 0 keeps the plain per-particle 27-cell walk as the independent cross-check
+    const bool wave = c->pair_variant == 6;
     if (!nbrs) {
-        if (nd)
+        if (nd && wave) SPH_TRY(nnps_csr_pair_kernel(c, src, dst, d_start, nullptr, nullptr));
+        else if (nd)
             hipLaunchKernelGGL(k_csr<false>, dim3(div_up(nd, 256)), dim3(256), 0, c->stream, D.prop[SPH_X], D.prop[SPH_Y],
                                D.prop[SPH_Z], D.prop[SPH_H], nd, S.prop[SPH_X], S.prop[SPH_Y], S.prop[SPH_Z],
                                S.prop[SPH_H], S.perm.as<uint32_t>(), S.cell_start.as<uint32_t>(), g, c->radius_scale,
@@ -600,7 +623,8 @@ extern "C" int sph_nnps_get_csr(sph_ctx *c, int src, int dst, uint32_t *start, s
     if (nbrs_len < tot) { sph_set_error("sph_nnps_get_csr: nbrs has %zu entries, %zu needed", nbrs_len, tot); return SPH_ERR_ARG; }
     SPH_TRY(c->tmp_u32b.reserve((tot + 1) * 4));
     HIP_TRY(hipMemcpyAsync(d_start, start, (nd + 1) * 4, hipMemcpyHostToDevice, c->stream));
-    if (nd)
+    if (nd && wave) SPH_TRY(nnps_csr_pair_kernel(c, src, dst, nullptr, d_start, c->tmp_u32b.as<uint32_t>()));
+    else if (nd)
         hipLaunchKernelGGL(k_csr<true>, dim3(div_up(nd, 256)), dim3(256), 0, c->stream, D.prop[SPH_X], D.prop[SPH_Y],
                            D.prop[SPH_Z], D.prop[SPH_H], nd, S.prop[SPH_X], S.prop[SPH_Y], S.prop[SPH_Z], S.prop[SPH_H],
                            S.perm.as<uint32_t>(), S.cell_start.as<uint32_t>(), g, c->radius_scale, d_start,
@@ -632,6 +656,9 @@ int nnps_build_csr_device(sph_ctx *c, int src, int dst, DevBuf &start, DevBuf &n
     if (nd == 0) return SPH_OK;
     uint32_t *cnt = c->tmp_u32a.as<uint32_t>();
     HIP_TRY(hipMemsetAsync(cnt + nd, 0, 4, c->stream));
+    const bool wave = c->pair_variant == 6;
+    if (wave) SPH_TRY(nnps_csr_pair_kernel(c, src, dst, cnt, nullptr, nullptr));
+    else
     hipLaunchKernelGGL(k_csr<false>, dim3(div_up(nd, 256)), dim3(256), 0, c->stream, D.prop[SPH_X], D.prop[SPH_Y],
                        D.prop[SPH_Z], D.prop[SPH_H], nd, S.prop[SPH_X], S.prop[SPH_Y], S.prop[SPH_Z], S.prop[SPH_H],
                        S.perm.as<uint32_t>(), S.cell_start.as<uint32_t>(), g, c->radius_scale, cnt, (uint32_t *)nullptr);
@@ -644,6 +671,7 @@ int nnps_build_csr_device(sph_ctx *c, int src, int dst, DevBuf &start, DevBuf &n
     HIP_TRY(hipStreamSynchronize(c->stream));
     *total = pin[0];
     SPH_TRY(nbrs.reserve(((size_t)pin[0] + 1) * 4));
+    if (wave) return nnps_csr_pair_kernel(c, src, dst, nullptr, start.as<uint32_t>(), nbrs.as<uint32_t>());
     hipLaunchKernelGGL(k_csr<true>, dim3(div_up(nd, 256)), dim3(256), 0, c->stream, D.prop[SPH_X], D.prop[SPH_Y],
                        D.prop[SPH_Z], D.prop[SPH_H], nd, S.prop[SPH_X], S.prop[SPH_Y], S.prop[SPH_Z], S.prop[SPH_H],
                        S.perm.as<uint32_t>(), S.cell_start.as<uint32_t>(), g, c->radius_scale, start.as<uint32_t>(),

@@ -51,6 +51,7 @@ class HipNNPS(object):
         self.ncells_per_dim = np.ones(3, dtype=np.int32)
         self.n_cells = 0
         self.bounds = None       # optional fixed global bounds (multi-GPU)
+        self._h_fixed = False
         self.cell_size_override = -1.0
         if self.domain is not None:
             self.domain.set_particles(self.particles, self.radius_scale)
@@ -96,6 +97,16 @@ class HipNNPS(object):
         i4 = (C.c_long * 4)()
         dev._check(self.lib.sph_nnps_info(self.ctx._h, d8, i4))
         self.cell_size, self.hmin = d8[0], d8[1]
+        if self.fixed_h and not self._h_fixed:
+            # fixed_h (linked_list_nnps.pyx:54): the smoothing lengths never
+            # change, so the range found by this first update stays: later updates
+            # skip the h reduction (and, with `bounds`, the whole min/max pass and
+            # its device->host round trip)
+            mm = (C.c_double * 8)()
+            dev._check(self.lib.sph_nnps_minmax(self.ctx._h, self.narrays, ids, mm))
+            if mm[7] >= mm[3]:
+                dev._check(self.lib.sph_nnps_set_h_range(self.ctx._h, mm[3], mm[7]))
+                self._h_fixed = True
         self.xmin = np.array(d8[2:5])
         self.xmax = np.array(d8[5:8])
         self.ncells_per_dim = np.array(i4[0:3], dtype=np.int32)

@@ -32,6 +32,9 @@ from . import device as dev
 # what a WCSPH ghost needs (72 B/particle); p, cs are recomputed
 WCSPH_HALO_PROPS = ('x', 'y', 'z', 'u', 'v', 'w', 'rho', 'h', 'm')
 TVF_HALO_PROPS = WCSPH_HALO_PROPS + ('uhat', 'vhat', 'what')
+# elastic solids: cs and the deviatoric stress travel; p and the artificial stress
+# r_ij are recomputed on the ghosts (ElasticSolidsScheme(ghost_recompute=True))
+ELASTIC_HALO_PROPS = WCSPH_HALO_PROPS + ('cs', 's00', 's01', 's02', 's11', 's12', 's22')
 
 
 class DeviceHaloOps(object):
@@ -127,10 +130,24 @@ class DeviceHaloOps(object):
             float(shift), C.c_void_p(buf.data_ptr())))
         return buf
 
-    def append(self, buf, count):
-        dev._check(self.lib.sph_halo_append(
+    def append(self, buf, count, stride=None):
+        """`stride`: rows of a fixed-capacity message (property k of row i at
+        buf[k * stride + i])"""
+        dev._check(self.lib.sph_halo_append_strided(
             self.ctx._h, self.id, self.nprops, self.props,
-            C.c_void_p(buf.data_ptr()), count))
+            C.c_void_p(buf.data_ptr()), count, count if stride is None else stride))
+
+    def select_pack(self, lo_cut, hi_cut, shifts, caps, bufs):
+        """Both faces selected AND packed on the device, no host round trip:
+        bufs[side] (or None) is a message of caps[side] * nprops + 1 doubles,
+        rows laid out [nprops][cap], the row count (negative: more than cap) in
+        its last element (sph_halo_select_pack)."""
+        sh = (C.c_double * 2)(float(shifts[0]), float(shifts[1]))
+        cp = (C.c_size_t * 2)(int(caps[0]), int(caps[1]))
+        ds = (C.c_void_p * 2)(*[b.data_ptr() if b is not None else None for b in bufs])
+        dev._check(self.lib.sph_halo_select_pack(
+            self.ctx._h, self.id, self.axis, float(lo_cut), float(hi_cut), 0,
+            self.nprops, self.props, sh, cp, ds))
 
     # -- migration of owned particles (every device property travels) -------
     def all_props(self):
@@ -316,20 +333,25 @@ def exchange_halos(hs, drop=True):
     faces talk to the same peer), arrays in the same order on both sides."""
     h0 = hs[0]
     dist, ops0, world, na = h0.dist, h0.ops, h0.world, len(hs)
-    send = []
     for h in hs:
         if drop:
             h.ops.drop_ghosts()
-        n_lo, n_hi = h.ops.select(h.lo + h.width, h.hi - h.width)
-        send.append({0: n_lo, 1: n_hi})
     nbrs = h0.neighbours()
     if not nbrs:
         return
     sides = [s for s, _, _ in nbrs]
-    for c in send:                  # nothing goes out through an open face
-        for s in (0, 1):
-            if s not in sides:
-                c[s] = 0
+    fixed = h0.protocol == 'capacity' and all(
+        h.cap_send.get(s) is not None and h.cap_recv.get(s) is not None for h in hs for s in sides)
+    # with fixed-capacity messages and device-side packing the host never sees
+    # the selection: the counts come back with the headers
+    device_pack = fixed and all(hasattr(h.ops, 'select_pack') for h in hs)
+    send = [{0: 0, 1: 0} for _ in hs]
+    if not device_pack:
+        for c, h in zip(send, hs):
+            c[0], c[1] = h.ops.select(h.lo + h.width, h.hi - h.width)
+            for s in (0, 1):        # nothing goes out through an open face
+                if s not in sides:
+                    c[s] = 0
     send_order = sorted(nbrs, key=lambda nb: -nb[0])
     recv_order = sorted(nbrs, key=lambda nb: nb[0])
 
@@ -344,8 +366,6 @@ def exchange_halos(hs, drop=True):
             for w in dist.batch_isend_irecv(reqs):
                 w.wait()
 
-    fixed = h0.protocol == 'capacity' and all(
-        h.cap_send.get(s) is not None and h.cap_recv.get(s) is not None for h in hs for s in sides)
     if not fixed:
         out = [{s: h.ops.pack(s, c[s], shift) for s, _, shift in nbrs} for h, c in zip(hs, send)]
         comm_sync('before_comm')
@@ -372,39 +392,58 @@ def exchange_halos(hs, drop=True):
             h.handshakes += 1
     else:
         import torch
+        shift_of = {s: shift for s, _, shift in nbrs}
         out, inb = [], []
         for a, h in enumerate(hs):
             npr, oa, ia = h.ops.nprops, {}, {}
-            for s, _, shift in nbrs:
-                cap, cnt = h.cap_send[s], send[a][s]
-                big = h.ops.new_buffer(cap * npr + 1, 1)
-                if cnt <= cap:
-                    try:
-                        h.ops.pack(s, cnt, shift, out=big)
-                    except TypeError:       # a primitive set without out=: pack, then copy
-                        big[:cnt * npr] = h.ops.pack(s, cnt, shift)[:cnt * npr]
-                big[-1] = float(cnt if cnt <= cap else -cnt)
-                oa[s] = big
+            for s in sides:
+                oa[s] = h.ops.new_buffer(h.cap_send[s] * npr + 1, 1)
                 ia[s] = h.ops.new_buffer(h.cap_recv[s] * npr + 1, 1)
+            if device_pack:
+                # selection and packing of both faces in one device pass, the row
+                # counts stay on the device (headers of the messages)
+                h.ops.select_pack(h.lo + h.width, h.hi - h.width,
+                                  [shift_of.get(0, 0.0), shift_of.get(1, 0.0)],
+                                  [h.cap_send.get(0, 0), h.cap_send.get(1, 0)],
+                                  [oa.get(0), oa.get(1)])
+            else:
+                for s in sides:
+                    cap, cnt = h.cap_send[s], send[a][s]
+                    if cnt <= cap:
+                        packed = h.ops.pack(s, cnt, shift_of[s])
+                        # rows [nprops][cap]: property k of row i at k * cap + i
+                        oa[s][:cap * npr].view(npr, cap)[:, :cnt] = packed[:cnt * npr].view(npr, cnt)
+                    oa[s][-1] = float(cnt if cnt <= cap else -cnt)
             out.append(oa)
             inb.append(ia)
         comm_sync('before_comm')
         reqs = [dist.P2POp(dist.isend, out[a][s], peer) for s, peer, _ in send_order for a in range(na)]
         reqs += [dist.P2POp(dist.irecv, inb[a][s], peer) for s, peer, _ in recv_order for a in range(na)]
         run(reqs)
-        # the one readback of the exchange: the row counts the peers packed
-        hdr = torch.stack([inb[a][s][-1] for a in range(na) for s in sides]).cpu().tolist()
-        hdr = {(a, s): int(v) for (a, s), v in zip([(a, s) for a in range(na) for s in sides], hdr)}
+        # the ONE readback of the exchange: the row counts this rank packed and
+        # the ones its peers packed (the host sizes the arrays with them)
+        keys = [(a, s) for a in range(na) for s in sides]
+        hdr = torch.stack([out[a][s][-1] for a, s in keys] +
+                          [inb[a][s][-1] for a, s in keys]).cpu().tolist()
+        sent = {k: int(v) for k, v in zip(keys, hdr[:len(keys)])}
+        hdr = {k: int(v) for k, v in zip(keys, hdr[len(keys):])}
+        for a, s in keys:
+            send[a][s] = abs(sent[(a, s)])
         recv = [{s: abs(hdr[(a, s)]) for s in sides} for a in range(na)]
+        stride = [{s: hs[a].cap_recv[s] for s in sides} for a in range(na)]
         # faces that outgrew their capacity: the pair repeats them, exactly sized
-        over_send = [(a, s) for a in range(na) for s in sides if send[a][s] > hs[a].cap_send[s]]
-        over_recv = [(a, s) for a in range(na) for s in sides if hdr[(a, s)] < 0]
+        over_send = [k for k in keys if sent[k] < 0]
+        over_recv = [k for k in keys if hdr[k] < 0]
         if over_send or over_recv:
-            shift_of = {s: shift for s, _, shift in nbrs}
+            if over_send and device_pack:
+                for a in sorted(set(a for a, _ in over_send)):
+                    h = hs[a]               # the index lists of the faces, this time
+                    h.ops.select(h.lo + h.width, h.hi - h.width)
             for a, s in over_send:
                 out[a][s] = hs[a].ops.pack(s, send[a][s], shift_of[s])
             for a, s in over_recv:
                 inb[a][s] = hs[a].ops.new_buffer(recv[a][s], hs[a].ops.nprops)
+                stride[a][s] = recv[a][s]
             comm_sync('before_comm')
             reqs = [dist.P2POp(dist.isend, out[a][s], peer) for s, peer, _ in send_order
                     for a in range(na) if (a, s) in over_send]
@@ -416,7 +455,10 @@ def exchange_halos(hs, drop=True):
     for a, h in enumerate(hs):
         for s, _, _ in nbrs:
             if recv[a][s]:
-                h.ops.append(inb[a][s], recv[a][s])
+                if fixed:
+                    h.ops.append(inb[a][s], recv[a][s], stride=stride[a][s])
+                else:
+                    h.ops.append(inb[a][s], recv[a][s])
             h.cap_send[s] = _next_capacity(h.cap_send.get(s), send[a][s])
             h.cap_recv[s] = _next_capacity(h.cap_recv.get(s), recv[a][s])
         h.last_counts = (send[a][0], send[a][1], recv[a].get(0, 0), recv[a].get(1, 0))

@@ -129,7 +129,18 @@ class ElasticSolidsScheme(object):
     reference scheme hard-codes) or VelocityGradient3D (needed for 3-D runs)."""
 
     def __init__(self, elastic_solids, solids, dim, artificial_stress_eps=0.3,
-                 xsph_eps=0.5, alpha=1.0, beta=1.0):
+                 xsph_eps=0.5, alpha=1.0, beta=1.0, ghost_recompute=False):
+        """ghost_recompute: for slab-decomposed (multi-GPU) runs.  The second
+        group reads p and the artificial stress r_ij of its SOURCES, ghosts
+        included; both are per-particle functions of rho and s_ij, which the
+        ghost exchange carries (parallel.ELASTIC_HALO_PROPS).  With this flag the
+        two no-source equations that compute them form a group of their own over
+        ALL particles (real=False, like the EOS groups of the fluid schemes)
+        instead of the reference's mid-evaluation refresh of remote properties
+        (ParallelManager.update_remote_particle_properties,
+        pysph/parallel/parallel_manager.pyx:159-210): same values on the real
+        particles, one exchange per evaluation."""
+        self.ghost_recompute = ghost_recompute
         self.elastic_solids = list(elastic_solids)
         self.solids = list(solids)
         self.dim = dim
@@ -141,11 +152,14 @@ class ElasticSolidsScheme(object):
     def get_equations(self):
         everyone = self.solids + self.elastic_solids
         VG = VelocityGradient3D if self.dim == 3 else VelocityGradient2D
-        g1, g2 = [], []
+        g0, g1, g2 = [], [], []
         for es in self.elastic_solids:
-            g1.append(IsothermalEOS(es, sources=None))
+            # equations without sources run before the pair loops of their group
+            # (mako :50-58): hoisting these two in front of VG changes nothing
+            pre = g0 if self.ghost_recompute else g1
+            pre.append(IsothermalEOS(es, sources=None))
             g1.append(VG(dest=es, sources=everyone))
-            g1.append(MonaghanArtificialStress(
+            pre.append(MonaghanArtificialStress(
                 dest=es, sources=None, eps=self.artificial_stress_eps))
         for es in self.elastic_solids:
             g2.append(ContinuityEquation(dest=es, sources=everyone))
@@ -154,6 +168,8 @@ class ElasticSolidsScheme(object):
                 dest=es, sources=everyone, alpha=self.alpha, beta=self.beta))
             g2.append(HookesDeviatoricStressRate(dest=es, sources=None))
             g2.append(XSPHCorrection(dest=es, sources=[es], eps=self.xsph_eps))
+        if self.ghost_recompute:
+            return [Group(equations=g0, real=False), Group(equations=g1), Group(equations=g2)]
         return [Group(equations=g1), Group(equations=g2)]
 
     def setup_properties(self, particles, clean=True):

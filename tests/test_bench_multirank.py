@@ -65,7 +65,7 @@ def test_bench_dam_break_strong_scaling_path_two_ranks():
     assert abs(out['value'] * out['ms_per_step'] * 1e-3 - total) < 1e-6 * total
 
 
-def _run_two_ranks_collect(argv, fields):
+def _run_two_ranks_collect(argv, fields, one_problem=False):
     """two thread-ranks run one step of the workload; returns {gid: row} of the
     requested fields over both ranks, and the same from ONE domain"""
     import numpy as np
@@ -109,12 +109,16 @@ def _run_two_ranks_collect(argv, fields):
     assert not errors, errors[0]
     gid = np.concatenate([rows[0][0], rows[1][0]])
     val = np.concatenate([rows[0][1], rows[1][1]], 0)
-    # one domain: both cubes in one array
     args = bench.parse_args(argv + ['--gpus', '2'])
-    parts = [bench.build_workload(args, r, 2) for r in range(2)]
-    w1 = parts[0]
-    w1.arrays[0].append_parray(parts[1].arrays[0])
-    w1.arrays[0].set_num_real_particles(w1.arrays[0].get_number_of_particles())
+    if one_problem:
+        # strong scaling: the ranks hold the two slabs of what rank 0 of 1 holds whole
+        w1 = bench.build_workload(args, 0, 1)
+    else:
+        # one domain: both cubes in one array
+        parts = [bench.build_workload(args, r, 2) for r in range(2)]
+        w1 = parts[0]
+        w1.arrays[0].append_parray(parts[1].arrays[0])
+        w1.arrays[0].set_num_real_particles(w1.arrays[0].get_number_of_particles())
     ctx = dev.HipContext(0, torch.cuda.current_stream().cuda_stream)
     bench.apply_options(args, ctx)
     nnps, a_eval, halo, domain, step, _ = bench.setup(args, w1, 0, 1, None, ctx)
@@ -158,6 +162,44 @@ def test_cube_two_slabs_matches_one_domain_by_gid():
     b = val1[np.argsort(gid1)]
     for k in range(len(fields)):
         assert np.max(np.abs(a[:, k] - b[:, k])) / np.max(np.abs(b[:, k])) < 1e-10, fields[k]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('argv', [['--workload', 'elastic_block', '--n1', '24'],
+                                  ['--workload', 'elastic', '--rings-dx', '2e-3', '--rings-spacing', '0.02']],
+                         ids=['block', 'overlapping-shells'])
+def test_elastic_two_slabs_match_one_domain_by_gid(argv):
+    """The elastic set on N > 1: its second group reads p and the artificial
+    stress r_ij of ghost SOURCES; the halo carries rho, cs and s_ij and the two
+    no-source equations recompute p, r_ij on the ghosts
+    (ElasticSolidsScheme(ghost_recompute=True)) where the reference refreshes
+    remote properties in mid-evaluation (parallel_manager.pyx:159-210).  One body
+    cut in two at the quantile of x (second case: the two shells pushed into each
+    other so that the cut runs through material) against the whole on one rank."""
+    import numpy as np
+    fields = ['arho', 'au', 'av', 'aw', 'ax', 'ay', 'az', 'p', 'as00', 'as01', 'as02', 'as11', 'as12',
+              'as22', 'r00', 'r11', 'r22', 'v00', 'v11', 'v22']
+    gid, val, gid1, val1 = _run_two_ranks_collect(argv + ['--steps', '1', '--warmup', '0'], fields,
+                                                  one_problem=True)
+    assert gid.size == gid1.size and np.array_equal(np.sort(gid), np.sort(gid1))
+    a = val[np.argsort(gid)]
+    b = val1[np.argsort(gid1)]
+    import bench
+    for k, f in enumerate(fields):
+        group = [fields.index(g) for g in bench._scale_group(f) if g in fields]
+        scale = max(np.max(np.abs(b[:, j])) for j in group)
+        assert scale > 0, f
+        assert np.max(np.abs(a[:, k] - b[:, k])) / scale < 1e-10, f
+
+
+@pytest.mark.gpu
+def test_bench_elastic_strong_scaling_path_two_ranks():
+    out = _run_two_ranks(['--gpus', '2', '--workload', 'elastic', '--rings-dx', '2e-3', '--steps', '2',
+                          '--warmup', '1', '--no-cpu-baseline'])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'strong' and out['config']['parallelism'] == 'slab2'
+    import bench
+    total = bench.make_rings3d(2e-3)[0].get_number_of_particles()
+    assert abs(out['value'] * out['ms_per_step'] * 1e-3 - total) < 1e-6 * total
 
 
 @pytest.mark.gpu

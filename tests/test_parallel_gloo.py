@@ -65,14 +65,15 @@ class NumpyHaloOps(object):
             out[k * count:(k + 1) * count] = v
         return buf
 
-    def append(self, buf, count):
+    def append(self, buf, count, stride=None):
+        stride = count if stride is None else stride
         n0 = self.pa.get_number_of_particles()
         nreal = self.n_real()
         self.pa.resize(n0 + count)
         self.pa.set_num_real_particles(nreal)
         arr = buf.numpy()
         for k, p in enumerate(PROPS):
-            self.pa.properties[p][n0:] = arr[k * count:(k + 1) * count]
+            self.pa.properties[p][n0:] = arr[k * stride:k * stride + count]
         self.pa.properties['tag'][n0:] = 1  # Remote
 
     # -- migration ---------------------------------------------------------
@@ -112,6 +113,29 @@ class NumpyHaloOps(object):
 
     def coords(self):
         return self.pa.properties[self.axis][:self.n_real()].copy()
+
+
+class NumpyDirectHaloOps(NumpyHaloOps):
+    """... with the device-side selection + packing of sph_halo_select_pack: the
+    host never sees the counts, they travel in the headers of the messages"""
+
+    def select_pack(self, lo_cut, hi_cut, shifts, caps, bufs):
+        self.select(lo_cut, hi_cut)
+        for s in (0, 1):
+            if bufs[s] is None:
+                continue
+            cap, cnt = int(caps[s]), len(self._sel[s])
+            out = bufs[s].numpy()
+            if cnt <= cap:
+                rows = self.pack(s, cnt, shifts[s]).numpy()
+                for k in range(self.nprops):
+                    out[k * cap:k * cap + cnt] = rows[k * cnt:(k + 1) * cnt]
+            else:                    # what fits, as the device kernel does; the header says "incomplete"
+                for k, p in enumerate(PROPS):
+                    v = self.pa.properties[p][self._sel[s][:cap]]
+                    out[k * cap:(k + 1) * cap] = v + (shifts[s] if p == self.axis else 0.0)
+            out[self.nprops * cap] = float(cnt if cnt <= cap else -cnt)
+        self._sel = {}               # no index lists on the host side of this protocol
 
 
 def _worker(rank, world, port, periodic, out):
@@ -384,31 +408,37 @@ def _worker_protocols(rank, world, port, periodic, out):
         own = np.nonzero(x < 0.5)[0] if rank == 0 else np.nonzero(x >= 0.5)[0]
         lo, hi = (0.0, 0.5) if rank == 0 else (0.5, 1.0)
 
-        def build(protocol):
+        def build(protocol, ops=NumpyHaloOps):
             pa = ParticleArray(name='fluid', **{k: v[own].copy() for k, v in full.properties.items()})
             h = par.SlabHalo(pa, None, rank, world, axis=0, width=0.1, lo=lo, hi=hi,
-                             periodic=periodic, period=1.0, ops=NumpyHaloOps(pa, 0), dist=dist)
+                             periodic=periodic, period=1.0, ops=ops(pa, 0), dist=dist)
             h.protocol = protocol
             return pa, h
         pa_h, hh = build('handshake')
         pa_c, hc = build('capacity')
         pa_o, ho = build('capacity')
+        # the same two with selection + packing "on the device" (counts only in the headers)
+        pa_d, hd = build('capacity', NumpyDirectHaloOps)
+        pa_e, he = build('capacity', NumpyDirectHaloOps)
         log = []
         for step, width in enumerate((0.1, 0.1, 0.22, 0.05, 0.3, 0.3)):
-            for h in (hh, hc, ho):
+            for h in (hh, hc, ho, hd, he):
                 h.width = width
             hh.exchange()
             hc.exchange()
+            hd.exchange()
             if step:                 # capacities of 8 rows: every face overflows
-                ho.cap_send = {s: 8 for s in ho.cap_send}
-                ho.cap_recv = {s: 8 for s in ho.cap_recv}
+                for h in (ho, he):
+                    h.cap_send = {s: 8 for s in h.cap_send}
+                    h.cap_recv = {s: 8 for s in h.cap_recv}
             ho.exchange()
+            he.exchange()
             n = pa_h.get_number_of_particles()
-            assert pa_c.get_number_of_particles() == n == pa_o.get_number_of_particles()
-            for k in PROPS:
-                assert np.array_equal(pa_h.properties[k][:n], pa_c.properties[k][:n]), (step, k)
-                assert np.array_equal(pa_h.properties[k][:n], pa_o.properties[k][:n]), (step, k)
-            assert hh.last_counts == hc.last_counts == ho.last_counts
+            for pa in (pa_c, pa_o, pa_d, pa_e):
+                assert pa.get_number_of_particles() == n
+                for k in PROPS:
+                    assert np.array_equal(pa_h.properties[k][:n], pa.properties[k][:n]), (step, k)
+            assert hh.last_counts == hc.last_counts == ho.last_counts == hd.last_counts == he.last_counts
             log.append(hc.last_counts)
         # the handshake ran once (first exchange) under 'capacity', every time under 'handshake'
         assert hc.handshakes == 1 and hh.handshakes == 6 and ho.handshakes == 1
