@@ -54,48 +54,36 @@ for wdir in sorted(glob.glob(os.path.join(raw, '*'))):
         pass
 json.dump(lines, open(os.path.join(here, '%s_bench_lines.json' % tag), 'w'), indent=1)
 
-cube = os.path.join(raw, 'cube')
-per = defaultdict(lambda: defaultdict(list))
-for f in glob.glob(os.path.join(cube, 'pmc_*', '**', '*_counter_collection.csv'), recursive=True):
-    acc = defaultdict(float)          # (dispatch, kernel, counter) -> value
-    for r in csv.DictReader(open(f)):
-        k = short(r['Kernel_Name'])
-        if k:
-            acc[(r['Dispatch_Id'], k, r['Counter_Name'])] += float(r['Counter_Value'])
-    for (_, k, c), v in acc.items():
-        per[k][c].append(v)
-mean = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in per.items()}
-
-bench = lines.get('cube', {})
-n = bench.get('config', {}).get('particles_per_gpu', 0)
-out = {
-    'command': 'bash profiles/collect.sh %s  (rocprofv3 --pmc <one set> --kernel-trace '
-               '--output-format csv -- python bench.py --no-cpu-baseline --no-check --no-extras '
-               '--steps 3 --warmup 1; one pass per counter set)' % tag,
-    'particles': n,
-    'bench_line_same_box': bench,
-    'per_launch_mean': mean,
-}
-cal = {}
 KiB = 1024.0
-if n and 'k_nosrc' in mean and 'FETCH_SIZE' in mean['k_nosrc']:
-    cal['k_nosrc_fetch_B_per_particle (reads 8)'] = mean['k_nosrc']['FETCH_SIZE'] * KiB / n
-    cal['k_nosrc_write_B_per_particle (writes 16)'] = mean['k_nosrc']['WRITE_SIZE'] * KiB / n
-if n and 'k_cell_keys' in mean and 'FETCH_SIZE' in mean['k_cell_keys']:
-    cal['k_cell_keys_fetch_B_per_particle (reads 24)'] = mean['k_cell_keys']['FETCH_SIZE'] * KiB / n
-    cal['k_cell_keys_write_B_per_particle (writes 8)'] = mean['k_cell_keys']['WRITE_SIZE'] * KiB / n
-out['calibration'] = cal
-pk = [k for k in mean if k.startswith('k_pair_wave')]
-if n and pk and 'FETCH_SIZE' in mean[pk[0]]:
-    m = mean[pk[0]]
-    # gfx950: FETCH_SIZE reports half of wide coalesced reads (MI355X_MICROARCH.md, HBM
-    # section; reproduced by the calibration kernels above), WRITE_SIZE is exact
-    fetch = m['FETCH_SIZE'] * KiB * 2.0
-    write = m['WRITE_SIZE'] * KiB
-    tr = {'kernel': pk[0], 'fetch_bytes_corrected': fetch, 'write_bytes': write,
-          'bytes_per_launch': fetch + write, 'bytes_per_particle': (fetch + write) / n,
-          'algorithmic_bytes_per_particle': 160.0}
-    if 'TCC_HIT_sum' in m:
+
+
+def pmc_means(wdir):
+    """per-launch mean of every counter of every hot kernel of one workload"""
+    per = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(wdir, 'pmc_*', '**', '*_counter_collection.csv'), recursive=True):
+        acc = defaultdict(float)          # (dispatch, kernel, counter) -> value
+        for r in csv.DictReader(open(f)):
+            k = short(r['Kernel_Name'])
+            if k:
+                acc[(r['Dispatch_Id'], k, r['Counter_Name'])] += float(r['Counter_Value'])
+        for (_, k, c), v in acc.items():
+            per[k][c].append(v)
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in per.items()}
+
+
+def derive(m, n, algo=None):
+    """what the counters of one pair kernel say, per launch (n particles)"""
+    tr = {}
+    if 'FETCH_SIZE' in m and 'WRITE_SIZE' in m:
+        # gfx950: FETCH_SIZE reports half of wide coalesced reads (MI355X_MICROARCH.md, HBM
+        # section; reproduced by the calibration kernels), WRITE_SIZE is exact
+        fetch = m['FETCH_SIZE'] * KiB * 2.0
+        write = m['WRITE_SIZE'] * KiB
+        tr.update({'fetch_bytes_corrected': fetch, 'write_bytes': write, 'bytes_per_launch': fetch + write,
+                   'bytes_per_particle': (fetch + write) / n if n else None})
+        if algo:
+            tr['algorithmic_bytes_per_particle'] = algo
+    if 'TCC_HIT_sum' in m and 'TCC_MISS_sum' in m:
         tr['l2_hit_rate'] = m['TCC_HIT_sum'] / (m['TCC_HIT_sum'] + m['TCC_MISS_sum'])
     if 'GRBM_GUI_ACTIVE' in m:
         cyc = m['GRBM_GUI_ACTIVE'] / 8.0          # summed over the 8 XCDs
@@ -104,6 +92,8 @@ if n and pk and 'FETCH_SIZE' in mean[pk[0]]:
             tr['valu_busy'] = m['SQ_ACTIVE_INST_VALU'] * 4.0 / (cyc * 1024.0)
         if 'TA_BUSY_avr' in m:
             tr['ta_busy'] = m['TA_BUSY_avr'] / cyc
+        if 'TCP_PENDING_STALL_CYCLES_sum' in m:
+            tr['tcp_pending_stall_frac'] = m['TCP_PENDING_STALL_CYCLES_sum'] / 256.0 / cyc
         if 'TCP_TOTAL_CACHE_ACCESSES_sum' in m:
             tr['tcp_accesses_per_cu_cycle'] = m['TCP_TOTAL_CACHE_ACCESSES_sum'] / 256.0 / cyc
         if 'TCP_READ_TAGCONFLICT_STALL_CYCLES_sum' in m:
@@ -112,25 +102,56 @@ if n and pk and 'FETCH_SIZE' in mean[pk[0]]:
         # 128-B line requests of the CUs' L1s to the L2 (calibration: k_nosrc reads 8 B per
         # particle coalesced and counts 8/128 requests per particle, k_cell_keys 24/128)
         tr['l1_fill_bytes_per_launch'] = m['TCP_TCC_READ_REQ_sum'] * 128.0
-        tr['l1_fill_bytes_per_particle'] = m['TCP_TCC_READ_REQ_sum'] * 128.0 / n
+        tr['l1_fill_bytes_per_particle'] = m['TCP_TCC_READ_REQ_sum'] * 128.0 / n if n else None
         if 'GRBM_GUI_ACTIVE' in m:
             tr['l1_fill_bytes_per_cu_cycle'] = m['TCP_TCC_READ_REQ_sum'] * 128.0 / 256.0 / (m['GRBM_GUI_ACTIVE'] / 8.0)
-    for kk in ('k_nosrc', 'k_cell_keys'):
-        if n and kk in mean and 'TCP_TCC_READ_REQ_sum' in mean[kk]:
-            cal['%s_l1_line_requests_per_particle (x128 B)' % kk] = mean[kk]['TCP_TCC_READ_REQ_sum'] / n
     if 'SQ_INSTS_VALU' in m and 'SQ_WAVES' in m:
         tr['valu_insts_per_wave'] = m['SQ_INSTS_VALU'] / m['SQ_WAVES']
         tr['vmem_rd_per_wave'] = m['SQ_INSTS_VMEM_RD'] / m['SQ_WAVES']
-    out['pair_kernel'] = tr
-    json.dump({'config': {'n1': 159, 'variant': bench['config']['pair_variant'],
-                          'spatially_ordered': bench['config']['spatially_ordered'],
-                          'workload': 'cube', 'dtype': bench.get('dtype', 'f64')},
-               'bytes_per_launch': fetch + write,
-               'l1_fill_bytes_per_launch': tr.get('l1_fill_bytes_per_launch'),
-               'source': 'profiles/%s_pmc_summary.json: FETCH_SIZE x 2 + WRITE_SIZE of separate '
-                         'rocprofv3 --pmc passes of this command on another box, not measured in '
-                         'this run' % tag},
-              open(os.path.join(here, 'pmc_traffic.json'), 'w'), indent=1)
-json.dump(out, open(os.path.join(here, '%s_pmc_summary.json' % tag), 'w'), indent=1)
-print(json.dumps(out.get('pair_kernel', {}), indent=1))
-print(json.dumps(cal, indent=1))
+    return tr
+
+
+summary = {'command': 'bash profiles/collect.sh %s  (rocprofv3 --pmc <one set> --kernel-trace '
+                      '--output-format csv -- python bench.py --no-cpu-baseline --no-check --no-extras '
+                      '--steps 3 --warmup 1 [workload flags]; one pass per counter set)' % tag,
+           'workloads': {}}
+for w, bench in lines.items():
+    wdir = os.path.join(raw, w)
+    mean = pmc_means(wdir)
+    if not mean:
+        continue
+    n = bench.get('config', {}).get('particles_per_gpu', 0)
+    entry = {'particles': n, 'bench_line_same_box': bench, 'per_launch_mean': mean, 'pair_kernels': {}}
+    cal = {}
+    if n and 'k_nosrc' in mean and 'FETCH_SIZE' in mean['k_nosrc'] and w.startswith('cube'):
+        cal['k_nosrc_fetch_B_per_particle (reads 8)'] = mean['k_nosrc']['FETCH_SIZE'] * KiB / n
+        cal['k_nosrc_write_B_per_particle (writes 16)'] = mean['k_nosrc']['WRITE_SIZE'] * KiB / n
+    if n and 'k_cell_keys' in mean and 'FETCH_SIZE' in mean['k_cell_keys']:
+        cal['k_cell_keys_fetch_B_per_particle (reads 24)'] = mean['k_cell_keys']['FETCH_SIZE'] * KiB / n
+        cal['k_cell_keys_write_B_per_particle (writes 8)'] = mean['k_cell_keys']['WRITE_SIZE'] * KiB / n
+    for kk in ('k_nosrc', 'k_cell_keys'):
+        if n and kk in mean and 'TCP_TCC_READ_REQ_sum' in mean[kk]:
+            cal['%s_l1_line_requests_per_particle (x128 B)' % kk] = mean[kk]['TCP_TCC_READ_REQ_sum'] / n
+    entry['calibration'] = cal
+    for k in sorted(mean):
+        if k.startswith('k_pair_wave'):
+            algo = bench.get('roofline', {}).get('algorithmic_bytes_per_particle') if len(
+                [q for q in mean if q.startswith('k_pair_wave')]) == 1 else None
+            entry['pair_kernels'][k] = derive(mean[k], n, algo)
+    summary['workloads'][w] = entry
+    if w == 'cube' and entry['pair_kernels']:
+        tr = list(entry['pair_kernels'].values())[0]
+        if 'bytes_per_launch' in tr:
+            json.dump({'config': {'n1': 159, 'variant': bench['config']['pair_variant'],
+                                  'spatially_ordered': bench['config']['spatially_ordered'],
+                                  'workload': 'cube', 'dtype': bench.get('dtype', 'f64')},
+                       'bytes_per_launch': tr['bytes_per_launch'],
+                       'l1_fill_bytes_per_launch': tr.get('l1_fill_bytes_per_launch'),
+                       'source': 'profiles/%s_pmc_summary.json: FETCH_SIZE x 2 + WRITE_SIZE of separate '
+                                 'rocprofv3 --pmc passes of this command on another box, not measured in '
+                                 'this run' % tag},
+                      open(os.path.join(here, 'pmc_traffic.json'), 'w'), indent=1)
+json.dump(summary, open(os.path.join(here, '%s_pmc_summary.json' % tag), 'w'), indent=1)
+for w, e in summary['workloads'].items():
+    print(w, json.dumps(e['pair_kernels'], indent=1))
+    print(json.dumps(e['calibration'], indent=1))
