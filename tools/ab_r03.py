@@ -20,12 +20,14 @@ CASES = [
     ('rings f32', ['--workload', 'elastic', '--dtype', 'f32']),
 ]
 for dt in ('f64', 'f32'):
-    for pd in (0, 2, 3, 4):
-        for pad in (0, 16384, 24576, 45056):
-            if pd == 0 and pad == 0:
-                continue
-            CASES.append(('pipe %s depth=%d lds_pad=%d' % (dt, pd, pad),
-                          ['--dtype', dt, '--opt', 'pipe_depth=%d' % pd, '--opt', 'lds_pad=%d' % pad]))
+    for wg in (1, 2):
+        CASES.append(('lds %s tiles=%d' % (dt, wg), ['--dtype', dt, '--opt', 'lds_tiles=%d' % wg]))
+CASES.append(('lds dam 0.0087', ['--workload', 'dam_break', '--opt', 'lds_tiles=1']))
+CASES.append(('lds dam 0.0055', ['--workload', 'dam_break', '--dx', '0.0055', '--opt', 'lds_tiles=1']))
+CASES.append(('lds cube.py params', ['--params', 'cube', '--opt', 'lds_tiles=1']))
+CASES.append(('cube.py params', ['--params', 'cube']))
+CASES.append(('lds 100^3', ['--n1', '100', '--opt', 'lds_tiles=1']))
+CASES.append(('100^3', ['--n1', '100']))
 
 
 def main():
