@@ -134,7 +134,7 @@ int sph_ctx_destroy(sph_ctx *c)
     for (auto &H : c->halo)
         for (int s = 0; s < 2; s++) { H.flag[s].release(); H.pos[s].release(); H.list[s].release(); }
     for (DevBuf *b : {&c->dbgc, &c->gapq, &c->cub_tmp, &c->red_part, &c->red_out, &c->posh, &c->aux, &c->fposb, &c->dkeys, &c->dperm,
-                      &c->tmp_u32a, &c->tmp_u32b, &c->gen_state, &c->nlbuf, &c->lplan_tiles, &c->lplan_count, &c->lplan_fb})
+                      &c->tmp_u32a, &c->tmp_u32b, &c->gen_state, &c->nlbuf})
         b->release();
     for (auto &b : c->csr_start) b.release();
     for (auto &b : c->csr_nbrs) b.release();
@@ -279,7 +279,6 @@ int sph_set_option(sph_ctx *c, const char *key, long value)
     if (strcmp(key, "eos_fuse") == 0) { c->eos_fuse = value; return SPH_OK; }
     if (strcmp(key, "nl_reuse") == 0) { c->nl_reuse = value; c->nl.valid = false; return SPH_OK; }
     if (strcmp(key, "norm_masks") == 0) { c->norm_masks = value; return SPH_OK; }
-    if (strcmp(key, "lds_tiles") == 0) { c->lds_tiles = value; return SPH_OK; }
     sph_set_error("sph_set_option: unknown key '%s'", key);
     return SPH_ERR_ARG;
 }

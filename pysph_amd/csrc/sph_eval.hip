@@ -1145,49 +1145,6 @@ template <class Fam> static int launch_pair_fused(sph_ctx *c, int kk, const Pair
     uint32_t cf = a.src[0].flags;
     for (int j = 1; j < a.nsrc; j++) if (a.src[j].flags != cf) cf = 0;
     if (c->const_flags == 0) cf = 0;
-    if (c->lds_tiles && cf == Fam::CF0) {
-        // variant 7 (option lds_tiles): plan the workgroup tiles on the device, run them from LDS, then let the
-        // wave-tile kernel take whatever the planner could not place
-        const int nyb = (c->nc[1] + 1) / 2, nzb = (c->nc[2] + 1) / 2;
-        const size_t nblocks = (size_t)nyb * nzb;
-        const size_t max_tiles = nblocks * ((size_t)c->nc[0] * SPH_NSUB + 1);
-        SPH_TRY(c->lplan_tiles.reserve(max_tiles * sizeof(uint4)));
-        SPH_TRY(c->lplan_count.reserve(64));
-        SPH_TRY(c->lplan_fb.reserve(a.nd + 64));
-        HIP_TRY(hipMemsetAsync(c->lplan_count.ptr, 0, 4, c->stream));
-        HIP_TRY(hipMemsetAsync(c->lplan_fb.ptr, 0, a.nd, c->stream));
-        LdsPlanArgs pa;
-        memset(&pa, 0, sizeof pa);
-        pa.nsrc = a.nsrc;
-        for (int j = 0; j < a.nsrc; j++) pa.src_fine[j] = a.src[j].fine_start;
-        pa.dst_fine = a.d_fine_start;
-        for (int k = 0; k < 3; k++) pa.nc[k] = c->nc[k];
-        pa.tiles = c->lplan_tiles.as<uint4>();
-        pa.count = c->lplan_count.as<uint32_t>();
-        pa.fb = c->lplan_fb.as<unsigned char>();
-        pa.max_tiles = (uint32_t)max_tiles;
-        hipLaunchKernelGGL(k_lds_plan, dim3((unsigned)nblocks), dim3(64), 0, c->stream, pa);
-        LdsPlan plan = {c->lplan_tiles.as<uint4>(), c->lplan_count.as<uint32_t>(), c->lplan_fb.as<unsigned char>()};
-        int ncu = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-        const dim3 gl((unsigned)(ncu * (c->lds_tiles > 1 ? c->lds_tiles : 1))), bl(256);
-        switch (kk) {
-        case 1: hipLaunchKernelGGL((k_pair_lds<Fam, 1, FP32, Fam::CF0>), gl, bl, 0, c->stream, a, plan); break;
-        case 2: hipLaunchKernelGGL((k_pair_lds<Fam, 2, FP32, Fam::CF0>), gl, bl, 0, c->stream, a, plan); break;
-        case 3: hipLaunchKernelGGL((k_pair_lds<Fam, 3, FP32, Fam::CF0>), gl, bl, 0, c->stream, a, plan); break;
-        case 4: hipLaunchKernelGGL((k_pair_lds<Fam, 4, FP32, Fam::CF0>), gl, bl, 0, c->stream, a, plan); break;
-        }
-        PairArgs<Fam> fbk = a;
-        fbk.only_fb = c->lplan_fb.as<unsigned char>();
-        switch (kk) {
-        case 1: hipLaunchKernelGGL((k_pair_wave<Fam, 1, true, FP32, Fam::CF0>), g2, b2, (size_t)c->lds_pad, c->stream, fbk); break;
-        case 2: hipLaunchKernelGGL((k_pair_wave<Fam, 2, true, FP32, Fam::CF0>), g2, b2, (size_t)c->lds_pad, c->stream, fbk); break;
-        case 3: hipLaunchKernelGGL((k_pair_wave<Fam, 3, true, FP32, Fam::CF0>), g2, b2, (size_t)c->lds_pad, c->stream, fbk); break;
-        case 4: hipLaunchKernelGGL((k_pair_wave<Fam, 4, true, FP32, Fam::CF0>), g2, b2, (size_t)c->lds_pad, c->stream, fbk); break;
-        }
-        return SPH_OK;
-    }
 #define LAUNCHE(K)                                                                                                              \
     if (cf == Fam::CF0) hipLaunchKernelGGL((k_pair_wave<Fam, K, true, FP32, Fam::CF0>), g2, b2, (size_t)c->lds_pad, c->stream, a); \
     else hipLaunchKernelGGL((k_pair_wave<Fam, K, true, FP32, 0>), g2, b2, (size_t)c->lds_pad, c->stream, a)
@@ -1465,7 +1422,6 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
             a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
             a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
-            a.d_fine_start = D.fine_start.as<uint32_t>();
             a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
             a.nl = nullptr; a.nl_mode = nl_mode;
             if (nl_mode) a.nl = c->nlbuf.as<uint32_t>();

@@ -126,8 +126,6 @@ struct sph_ctx {
     long nl_reuse = 0;      // honour sph_group.nl_mode (neighbour lists kept between the pair passes of one evaluation): built,
                             // bit-identical, and measured SLOWER on MI355X (phase 1 overlaps other wavefronts' gathers)
     long norm_masks = 1;    // shift a row's hit bits down to the lane's first hit
-    long lds_tiles = 0;     // variant 7: EOS-fused WCSPH launches run as LDS-resident workgroup tiles (k_pair_lds); value = workgroups per CU launched
-    DevBuf lplan_tiles, lplan_count, lplan_fb;
     // neighbour lists kept by the last nl_mode-1 pair pass
     DevBuf nlbuf;
     struct { bool valid = false; unsigned long long epoch = 0; int dst = -1, src = -1; size_t start = 0, stop = 0, nd = 0; } nl;

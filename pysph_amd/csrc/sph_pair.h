@@ -20,7 +20,6 @@
 
 #include <hip/hip_runtime.h>
 #include <cstdint>
-#include <type_traits>
 
 #include "sphhip.h"
 #include "sph_kernels.h"
@@ -69,8 +68,6 @@ template <class Fam> struct PairArgs {
     uint32_t d_off, nd;
     const uint32_t *d_keys, *d_fkeys, *d_perm; // cell ids / fine keys of the sorted destinations, sorted -> original index
     const uint32_t *d_tile_order; // traversal order of the destination tiles (null: memory order)
-    const uint32_t *d_fine_start; // the destination array's own sub-bin table (variant 7: tiles are sub-bin ranges of its rows)
-    const unsigned char *only_fb; // variant 7's fallback launch of this kernel: only destinations flagged here take part
     uint32_t d_start, d_stop;
     int nc[3];
     double xmin[3];
@@ -339,8 +336,7 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     const bool valid = i < a.nd;
     const uint32_t ic = valid ? i : a.nd - 1;
     const uint32_t o = a.d_perm[ic];
-    const bool active = valid && o >= a.d_start && o < a.d_stop && (!a.only_fb || a.only_fb[ic]);
-    if (a.only_fb && !__any(active)) return; // nothing here was left to this launch
+    const bool active = valid && o >= a.d_start && o < a.d_stop;
     real4<T> pi;
     typename Fam::Dest D;
     // one record: fp32 records for Real = float (and for record_f32), else fp64
@@ -587,376 +583,3 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     if (active) Fam::finish(D, a, o);
 }
 
-
-// ---------------------------------------------------------------------------
-// variant 7: one WORKGROUP of four wavefronts per compact tile of destinations
-// -- the same x range [xa, xb) of sub-bins in the four rows of cells (y0, z0),
-// (y0+1, z0), (y0, z0+1), (y0+1, z0+1), one wavefront per row, at most 64
-// destinations each -- with EVERY candidate record of the tile (4 x 4 rows of
-// cells, x window widened by XWIN) staged ONCE into LDS.  Phase 1 builds the
-// same per-lane hit-mask slot lists as variant 6 from fp32 copies of the staged
-// positions; phase 2 gathers the records from LDS (ds_read_b128, four per pair
-// for the 64-byte EOS-fused records) instead of from global memory, so the
-// L2 -> L1 line fills that bound variant 6 (12.5 KB per particle) shrink to the
-// one coalesced staging pass (~0.5 KB per particle).  The price is occupancy:
-// the staged records take ~115 KB, one workgroup per CU, one wavefront per SIMD.
-// Workgroups are persistent (one per CU) and walk a tile list the planner
-// (k_lds_plan) built on the device; the planner keeps every tile within the LDS
-// capacity and flags destinations it cannot place (a sub-bin column with more
-// than 64 particles of one row, or a neighbourhood larger than the capacity) for
-// a fallback launch of variant 6 (PairArgs.only_fb).
-// Families: uniform h, records of NP 16-byte pieces with Raw / load_raw / decode
-// (the EOS-fused WCSPH family, fp64 and fp32).
-// ---------------------------------------------------------------------------
-#define LCAP 1800                        // candidate records one tile may stage
-#define LFSW 80                          // sub-bin table entries kept per staged row
-#define LMAXW (LFSW - 2 * XWIN - 4)      // widest tile, in sub-bins
-
-struct LdsPlan {
-    const uint4 *tiles;          // {y0 | z0 << 16, xa, xb, -}
-    const uint32_t *count;       // number of tiles
-    const unsigned char *fb;     // per sorted destination: 1 = left to the fallback launch
-};
-
-struct LdsPlanArgs {
-    int nsrc;
-    const uint32_t *src_fine[SPH_MAX_ARRAYS];
-    const uint32_t *dst_fine;
-    int nc[3];
-    uint4 *tiles;
-    uint32_t *count;
-    unsigned char *fb;
-    uint32_t max_tiles;
-};
-
-// One wavefront per block of 2 x 2 rows of cells: greedy sweep along x, every tile as wide as the
-// constraints allow (binary search; both constraints are monotone in the right edge).
-__global__ __launch_bounds__(64) void k_lds_plan(LdsPlanArgs a)
-{
-    const int t = threadIdx.x;
-    const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
-    const int nyb = (ncy + 1) / 2;
-    const int y0 = (int)(blockIdx.x % (uint32_t)nyb) * 2, z0 = (int)(blockIdx.x / (uint32_t)nyb) * 2;
-    const int nfx = ncx * SPH_NSUB;
-    // lane roles: staged row (t & 15) of source group (t >> 4); lanes 0..3 also count one destination row each
-    const int r16 = t & 15;
-    const int sy = y0 - 1 + (r16 & 3), sz = z0 - 1 + (r16 >> 2);
-    const bool srow_ok = sy >= 0 && sy < ncy && sz >= 0 && sz < ncz;
-    const uint32_t srowb = srow_ok ? (uint32_t)(ncx * (sy + ncy * sz)) * SPH_NSUB : 0u;
-    const int dy = y0 + (t & 1), dz = z0 + ((t >> 1) & 1);
-    const bool drow_ok = t < 4 && dy < ncy && dz < ncz;
-    const uint32_t drowb = drow_ok ? (uint32_t)(ncx * (dy + ncy * dz)) * SPH_NSUB : 0u;
-
-    // (largest destination count of one row, staged records of all sources) of the tile [xa, xb)
-    auto eval = [&](int xa, int xb, int &maxdest, int &staged, int &ndest) {
-        int dc = 0;
-        if (drow_ok) dc = (int)(a.dst_fine[drowb + xb] - a.dst_fine[drowb + xa]);
-        int sc = 0;
-        if (srow_ok) {
-            const int xlo = max(xa - XWIN, 0), xhi1 = min(xb - 1 + XWIN, nfx - 1) + 1;
-            for (int s = t >> 4; s < a.nsrc; s += 4) sc += (int)(a.src_fine[s][srowb + xhi1] - a.src_fine[s][srowb + xlo]);
-        }
-        int md = dc, nd = dc;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            md = max(md, __shfl_xor(md, o, 64));
-            nd += __shfl_xor(nd, o, 64);
-            sc += __shfl_xor(sc, o, 64);
-        }
-        maxdest = md; staged = sc; ndest = nd;
-    };
-
-    int xa = 0;
-    while (xa < nfx) {
-        int md, st, nd;
-        const int xmax = min(xa + LMAXW, nfx);
-        eval(xa, xa + 1, md, st, nd);
-        if (md > 64 || st > LCAP) {
-            // this column cannot be placed: its destinations go to the fallback launch
-            if (drow_ok) {
-                const uint32_t j0 = a.dst_fine[drowb + xa], j1 = a.dst_fine[drowb + xa + 1];
-                for (uint32_t j = j0; j < j1; j++) a.fb[j] = 1;
-            }
-            xa += 1;
-            continue;
-        }
-        int lo = xa + 1, hi = xmax; // invariant: [xa, lo) fits
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            eval(xa, mid, md, st, nd);
-            if (md <= 64 && st <= LCAP) lo = mid; else hi = mid - 1;
-        }
-        eval(xa, lo, md, st, nd);
-        if (nd > 0 && t == 0) {
-            const uint32_t slot = atomicAdd(a.count, 1u);
-            if (slot < a.max_tiles) a.tiles[slot] = make_uint4((uint32_t)y0 | ((uint32_t)z0 << 16), (uint32_t)xa, (uint32_t)lo, 0u);
-        }
-        xa = lo;
-    }
-}
-
-template <class Fam, int KK, bool F32, uint32_t CF>
-__global__ __launch_bounds__(256, 1) void k_pair_lds(PairArgs<Fam> a, LdsPlan plan)
-{
-    typedef typename Fam::Real T;
-    typedef typename Fam::Raw Raw;
-    constexpr int NP = sizeof(Raw) / 16;
-    typedef decltype(Raw().q[0]) piece_ref;
-    typedef typename std::remove_reference<piece_ref>::type piece_t;
-    static_assert(sizeof(piece_t) == 16, "records are made of 16-byte pieces");
-    constexpr int WCAP = WCAP_UH;
-    constexpr int TS = WCAP + 8;
-    __shared__ __attribute__((aligned(16))) piece_t P[NP][LCAP];
-    __shared__ __attribute__((aligned(16))) float tile_[4][3 * TS];
-    __shared__ unsigned long long smask_[4][WLQ][64];
-    __shared__ uint32_t sjb_[4][WLQ][64];
-    __shared__ uint32_t row_j0[16], row_off[17];
-    __shared__ unsigned short fsl[16][LFSW];
-
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int t = threadIdx.x & 63;
-    float *const tile = tile_[wv];
-    float *const tx = tile, *const ty = tile + TS, *const tz = tile + 2 * TS;
-    unsigned long long (*const smask)[64] = smask_[wv];
-    uint32_t (*const sjb)[64] = sjb_[wv];
-    const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
-    const int nfx = ncx * SPH_NSUB;
-    const double binw = a.cell_size * (1.0 / SPH_NSUB);
-
-    const uint32_t ntiles = *plan.count;
-    const uint32_t per = (ntiles + gridDim.x - 1) / gridDim.x;
-    const uint32_t tile_end = min(ntiles, (blockIdx.x + 1) * per);
-    for (uint32_t ti = blockIdx.x * per; ti < tile_end; ti++) {
-        const uint4 hd = plan.tiles[ti];
-        const int y0 = (int)(hd.x & 0xffffu), z0 = (int)(hd.x >> 16);
-        const int xa = (int)hd.y, xb = (int)hd.z;
-        const int xlo = max(xa - XWIN, 0), xhi = min(xb - 1 + XWIN, nfx - 1); // staged sub-bins of every row
-        // this wavefront's row of destinations
-        const int wy = y0 + (wv & 1), wz = z0 + (wv >> 1);
-        const bool wrow_ok = wy < ncy && wz < ncz;
-        uint32_t d0 = 0, d1 = 0;
-        if (wrow_ok) {
-            const uint32_t rowbD = (uint32_t)(ncx * (wy + ncy * wz)) * SPH_NSUB;
-            d0 = a.d_fine_start[rowbD + xa];
-            d1 = a.d_fine_start[rowbD + xb];
-        }
-        const bool wave_on = d1 > d0; // wave-uniform
-        const uint32_t i = d0 + (uint32_t)t;
-        const bool valid = wave_on && i < d1;
-        const uint32_t ic = valid ? i : (wave_on ? d0 : 0u);
-        uint32_t o = 0;
-        bool active = false;
-        real4<T> pi;
-        typename Fam::Dest D;
-        int cx = 0;
-        if (wave_on) {
-            o = a.d_perm[ic];
-            active = valid && o >= a.d_start && o < a.d_stop && !(plan.fb && plan.fb[ic]);
-            T sd_[Fam::NA];
-            Raw rr;
-            Fam::load_raw(a, a.d_off + ic, rr);
-            Fam::decode(a, rr, pi, sd_);
-            pi.w = (T)a.hu;
-            Fam::load(D, sd_, a, o);
-            const uint32_t fkey = a.d_fkeys[ic];
-            cx = (int)((fkey / SPH_NSUB) % (uint32_t)ncx) * SPH_NSUB + (int)(fkey % SPH_NSUB);
-        }
-        const T hi2 = (T)a.hr2u;
-        const T hi_r = (T)a.radius_scale * (T)a.hu;
-
-        for (int s = 0; s < a.nsrc; s++) {
-            const SrcDesc sd = a.src[s];
-            const uint32_t fl = CF ? CF : sd.flags;
-            __syncthreads(); // the previous tile / source is done with the staged records
-            // ---- stage: the 4 x 4 rows of cells around the tile, sub-bins [xlo, xhi] of each
-            if (threadIdx.x < 16) {
-                const int r = threadIdx.x;
-                const int yy = y0 - 1 + (r & 3), zz = z0 - 1 + (r >> 2);
-                uint32_t j0 = 0, j1 = 0;
-                if (yy >= 0 && yy < ncy && zz >= 0 && zz < ncz) {
-                    const uint32_t rowb = (uint32_t)(ncx * (yy + ncy * zz)) * SPH_NSUB;
-                    j0 = sd.fine_start[rowb + xlo];
-                    j1 = sd.fine_start[rowb + xhi + 1];
-                }
-                row_j0[r] = j0;
-                row_off[r + 1] = j1 - j0; // counts; turned into offsets below
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                uint32_t acc = 0;
-                row_off[0] = 0;
-                for (int r = 0; r < 16; r++) { acc += row_off[r + 1]; row_off[r + 1] = acc; }
-            }
-            {   // sub-bin tables of the staged rows, relative to each row's first staged record
-                const int nq = xhi - xlo + 2;
-                for (int k = threadIdx.x; k < 16 * LFSW; k += 256) {
-                    const int r = k / LFSW, q = k % LFSW;
-                    const int yy = y0 - 1 + (r & 3), zz = z0 - 1 + (r >> 2);
-                    unsigned short v = 0;
-                    if (q < nq && yy >= 0 && yy < ncy && zz >= 0 && zz < ncz) {
-                        const uint32_t rowb = (uint32_t)(ncx * (yy + ncy * zz)) * SPH_NSUB;
-                        v = (unsigned short)(sd.fine_start[rowb + xlo + q] - row_j0[r]);
-                    }
-                    fsl[r][q] = v;
-                }
-            }
-            __syncthreads();
-            {
-                const uint32_t total = min(row_off[16], (uint32_t)LCAP);
-                for (uint32_t k = threadIdx.x; k < total; k += 256) {
-                    int r = 0;
-#pragma unroll
-                    for (int q = 1; q < 16; q++) r += (k >= row_off[q]) ? 1 : 0;
-                    const uint32_t jg = sd.off + row_j0[r] + (k - row_off[r]);
-                    Raw rr;
-                    Fam::load_raw(a, jg, rr);
-#pragma unroll
-                    for (int p = 0; p < NP; p++) P[p][k] = rr.q[p];
-                }
-            }
-            __syncthreads();
-            if (!wave_on) continue; // (wave-uniform; the barriers above are all this wavefront owes the workgroup)
-
-            // ---- phase 1 + phase 2 of this wavefront, all from LDS
-            int cq = 0;
-            auto lds_record = [&](uint32_t j, real4<T> &pj, T (&sj)[Fam::NA]) {
-                Raw rr;
-#pragma unroll
-                for (int p = 0; p < NP; p++) rr.q[p] = P[p][j];
-                Fam::decode(a, rr, pj, sj);
-            };
-            auto phase2 = [&]() {
-                unsigned long long m = 0;
-                uint32_t jb = 0;
-                int q = 0;
-                if (cq > 0) { m = smask[0][t]; jb = sjb[0][t]; }
-                if (__any(m != 0)) {
-                    do {
-                        const bool has = m != 0;
-                        const uint32_t j = has ? jb + (uint32_t)__builtin_ctzll(m) : 0u;
-                        m &= m - 1;
-                        if (m == 0 && q + 1 < cq) { ++q; m = smask[q][t]; jb = sjb[q][t]; }
-                        real4<T> pj;
-                        T sj[Fam::NA];
-                        lds_record(j, pj, sj);
-                        const T r2 = r2_exact<T>(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-                        const bool pass = has && (r2 < hi2);
-                        Fam::template pair<KK, true>(D, pi, pj, r2, sj, fl, a, pass);
-                    } while (__any(m != 0));
-                }
-                cq = 0;
-            };
-
-            // x sub-bins this wavefront's destinations can reach
-            const unsigned long long actm = __ballot(active);
-            if (actm) {
-                const int cxa = __builtin_amdgcn_readlane(cx, __builtin_ctzll(actm));
-                const int cxb = __builtin_amdgcn_readlane(cx, 63 - __builtin_clzll(actm));
-                const int wa = max(cxa - XWIN, xlo), wb = min(cxb + XWIN, xhi);
-                const float oxf = (float)(binw * wa);
-                const double L = fmax(a.cell_size * (double)max((wb - wa) / SPH_NSUB + 2, 4), a.dom_extent);
-                const float slack = (float)(L * 1.5e-6);
-                const float hif = (float)hi_r * 1.000001f + slack;
-                const float hi2f = hif * hif;
-                const int mycl = max(cx - XWIN, wa) - xlo, mych = min(cx + XWIN, wb) + 1 - xlo;
-                // own position in the prefilter's fp32 frame (as k_pack rounds it: relative to the grid origin)
-                float fpx, fpy, fpz;
-                if constexpr (F32) { fpx = (float)pi.x; fpy = (float)pi.y; fpz = (float)pi.z; }
-                else { fpx = (float)((double)pi.x - a.xmin[0]); fpy = (float)((double)pi.y - a.xmin[1]); fpz = (float)((double)pi.z - a.xmin[2]); }
-                for (int dz = -1; dz <= 1; dz++)
-                    for (int dy = -1; dy <= 1; dy++) {
-                        const int yy = wy + dy, zz = wz + dz;
-                        if (yy < 0 || yy >= ncy || zz < 0 || zz >= ncz) continue;
-                        const int r16 = ((wv & 1) + 1 + dy) + 4 * ((wv >> 1) + 1 + dz);
-                        const float oyf = (float)(a.cell_size * (wy - 1)), ozf = (float)(a.cell_size * (wz - 1));
-                        const float fxs = fpx - oxf, fys = fpy - oyf, fzs = fpz - ozf;
-                        const f2 fx = {fxs, fxs}, fy = {fys, fys}, fz = {fzs, fzs};
-                        const uint32_t rb = row_off[r16];
-                        const uint32_t l0 = rb + fsl[r16][wa - xlo], l1 = rb + fsl[r16][wb + 1 - xlo];
-                        for (uint32_t tb = l0; tb < l1; tb += WCAP) {
-                            const int tn = (int)min((uint32_t)WCAP, l1 - tb);
-                            for (int k = t; k < tn + 8; k += 64) {
-                                float vx = 3.0e18f, vy = 3.0e18f, vz = 3.0e18f;
-                                if (k < tn) {
-                                    if constexpr (F32) {
-                                        const float4 q0 = *reinterpret_cast<const float4 *>(&P[0][tb + k]);
-                                        vx = q0.x - oxf; vy = q0.y - oyf; vz = q0.z - ozf;
-                                    } else {
-                                        const double2 q0 = *reinterpret_cast<const double2 *>(&P[0][tb + k]);
-                                        const double2 q1 = *reinterpret_cast<const double2 *>(&P[1][tb + k]);
-                                        vx = (float)(q0.x - a.xmin[0]) - oxf;
-                                        vy = (float)(q0.y - a.xmin[1]) - oyf;
-                                        vz = (float)(q1.x - a.xmin[2]) - ozf;
-                                    }
-                                }
-                                tx[k] = vx; ty[k] = vy; tz[k] = vz;
-                            }
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                            int s0 = 0, len = 0;
-                            if (active) {
-                                int lo = (int)(rb + fsl[r16][mycl] - tb), hi = (int)(rb + fsl[r16][mych] - tb);
-                                lo = max(lo, 0); hi = min(hi, tn);
-                                s0 = lo & ~1;
-                                len = hi - s0;
-                            }
-                            const int lenc = min(len, AMAXLEN);
-                            uint32_t wd[3] = {0u, 0u, 0u};
-#pragma unroll
-                            for (int gw = 0; gw < 3; gw++) {
-                                if (!__any(32 * gw < lenc)) break;
-                                uint32_t mm = 0;
-                                int g8 = 0;
-                                for (; g8 < 4 && __any(32 * gw + 8 * g8 < lenc); g8++) {
-                                    const float *tb0 = tile + (s0 + 32 * gw + 8 * g8);
-#pragma unroll
-                                    for (int p = 0; p < 4; p++) {
-                                        const f2 X = *reinterpret_cast<const f2 *>(tb0 + 2 * p);
-                                        const f2 Y = *reinterpret_cast<const f2 *>(tb0 + TS + 2 * p);
-                                        const f2 Z = *reinterpret_cast<const f2 *>(tb0 + 2 * TS + 2 * p);
-                                        const f2 ex = fx - X, ey = fy - Y, ez = fz - Z;
-                                        const f2 nthr = {-hi2f, -hi2f};
-                                        f2 d = __builtin_elementwise_fma(ex, ex, nthr);
-                                        d = __builtin_elementwise_fma(ey, ey, d);
-                                        d = __builtin_elementwise_fma(ez, ez, d);
-                                        mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.x), 31);
-                                        mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.y), 31);
-                                    }
-                                }
-                                if (g8 < 4) mm <<= 8 * (4 - g8);
-                                mm = __builtin_bitreverse32(mm);
-                                const int rem = lenc - 32 * gw;
-                                wd[gw] = rem >= 32 ? mm : (rem > 0 ? (mm & ((1u << rem) - 1u)) : 0u);
-                            }
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                            unsigned long long m0 = (unsigned long long)wd[0] | ((unsigned long long)wd[1] << 32);
-                            uint32_t m2 = wd[2];
-                            uint32_t jb0 = tb + (uint32_t)s0;
-                            if (__any(m2 != 0)) {
-                                const int sh = m0 ? __builtin_ctzll(m0) : (m2 ? 64 + __builtin_ctz(m2) : 0);
-                                if (sh >= 64) { m0 = (unsigned long long)(m2 >> (sh - 64)); m2 = 0; }
-                                else if (sh > 0) {
-                                    m0 = (m0 >> sh) | ((unsigned long long)m2 << (64 - sh));
-                                    m2 = sh >= 32 ? 0u : (m2 >> sh);
-                                }
-                                jb0 += (uint32_t)sh;
-                            }
-                            if (__any(cq + (m0 != 0) + (m2 != 0) > WLQ)) phase2();
-                            if (m0) { smask[cq][t] = m0; sjb[cq][t] = jb0; cq++; }
-                            if (m2) { smask[cq][t] = m2; sjb[cq][t] = jb0 + 64u; cq++; }
-                            if (__any(len > AMAXLEN)) { // rare: exact tail in place
-                                for (int k = AMAXLEN; k < len; k++) {
-                                    real4<T> pj;
-                                    T sj[Fam::NA];
-                                    lds_record(tb + (uint32_t)(s0 + k), pj, sj);
-                                    const T r2 = r2_exact<T>(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-                                    if (r2 < hi2) Fam::template pair<KK, true>(D, pi, pj, r2, sj, fl, a, true);
-                                }
-                            }
-                        }
-                    }
-                phase2();
-            }
-        }
-        if (active) Fam::finish(D, a, o);
-    }
-}

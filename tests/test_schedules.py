@@ -127,19 +127,3 @@ def test_normalised_masks_are_bit_identical(argv):
         assert np.array_equal(on[k], off[k]), k
 
 
-
-@pytest.mark.parametrize('argv', [['--n1', '64'], ['--n1', '64', '--no-reorder'], ['--n1', '64', '--dtype', 'f32'],
-                                  ['--workload', 'dam_break', '--dx', '0.03'],
-                                  ['--n1', '48', '--hdx', '1.7'], ['--n1', '40', '--hdx', '2.6']],
-                         ids=['cube', 'cube-unsorted', 'cube-fp32', 'dam-break', 'wide-kernel', 'all-fallback'])
-def test_lds_resident_tiles_match_wave_tiles(argv):
-    """option lds_tiles (variant 7): workgroup tiles with every candidate record
-    staged in LDS; 'wide-kernel' makes the planner narrow its tiles, 'all-fallback'
-    (125 particles per cell: no tile fits the LDS capacity) leaves every
-    destination to the wave-tile kernel"""
-    base, c0, r0 = _run(argv, {})
-    lds, c1, r1 = _run(argv, {'lds_tiles': 1})
-    assert c0['n_eos_fused'] > 0 and c1['n_eos_fused'] > 0
-    tol = 5e-5 if '--dtype' in argv else 1e-10
-    assert r1['parity_max_rel'] < tol and r1['parity_neighbour_count_mismatches'] == 0, r1
-    assert _max_rel(lds, base) < (1e-5 if '--dtype' in argv else 1e-13)

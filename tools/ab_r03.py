@@ -19,17 +19,6 @@ CASES = [
     ('rings f64', ['--workload', 'elastic']),
     ('rings f32', ['--workload', 'elastic', '--dtype', 'f32']),
 ]
-for dt in ('f64', 'f32'):
-    for wg in (1, 2):
-        CASES.append(('lds %s tiles=%d' % (dt, wg), ['--dtype', dt, '--opt', 'lds_tiles=%d' % wg]))
-CASES.append(('lds dam 0.0087', ['--workload', 'dam_break', '--opt', 'lds_tiles=1']))
-CASES.append(('lds dam 0.0055', ['--workload', 'dam_break', '--dx', '0.0055', '--opt', 'lds_tiles=1']))
-CASES.append(('lds cube.py params', ['--params', 'cube', '--opt', 'lds_tiles=1']))
-CASES.append(('cube.py params', ['--params', 'cube']))
-CASES.append(('lds 100^3', ['--n1', '100', '--opt', 'lds_tiles=1']))
-CASES.append(('100^3', ['--n1', '100']))
-
-
 def main():
     extra = sys.argv[1:]
     rows = []

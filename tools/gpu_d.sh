@@ -4,6 +4,6 @@ mkdir -p gpurun_out/r03d
 export TMPDIR=/tmp
 ( time timeout 900 python -m pytest tests/test_schedules.py -m gpu -q -k "lds_resident" ) > gpurun_out/r03d/pytest.log 2>&1
 tail -12 gpurun_out/r03d/pytest.log
-timeout 1500 python tools/ab_r03.py lds "cube f" "cube.py" "100^3" "dam 0" > gpurun_out/r03d/ab.log 2>&1
+timeout 1500 python tools/ab_r03.py "lds f" "cube f" > gpurun_out/r03d/ab.log 2>&1
 grep -v "^{" gpurun_out/r03d/ab.log | tail -30
 grep error gpurun_out/r03d/ab.log | head -5
