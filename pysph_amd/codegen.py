@@ -14,7 +14,7 @@ module does the analogous step for gfx950:
   hand-written families use -- cell-ordered records, fp32 prefilter, exact
   fp64 criterion, register accumulators, one write per output);
 * the struct is compiled by ``hipcc --offload-arch=gfx950`` into a shared
-  object of its own under ``pysph_amd/_gen/`` (cached by source hash) that
+  object of its own under ``pysph_amd/libsphhip_gen/`` (cached by source hash) that
   exports ``sphgen_launch``;
 * ``HipAccelerationEval`` hands that function pointer and the property / source
   lists to ``sph_eval_generated`` (include/sphhip.h).
@@ -44,7 +44,9 @@ import textwrap
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
-GEN_DIR = os.path.join(_HERE, '_gen')
+# the directory name sorts behind 'libsphhip.so' in an alphabetical listing of the loaded
+# libraries (a truncated listing then still shows the library itself)
+GEN_DIR = os.path.join(_HERE, 'libsphhip_gen')
 
 VEC_SYMBOLS = ('XIJ', 'VIJ', 'DWIJ', 'DWI', 'DWJ')
 SCALAR_SYMBOLS = ('R2IJ', 'RIJ', 'HIJ', 'RHOIJ', 'RHOIJ1', 'EPS', 'WIJ', 'WI',
