@@ -8,9 +8,16 @@
  *   ParallelManager.update's ghost refresh      pysph/parallel/parallel_manager.pyx:512-530
  *   remote_exchange_data (one Comm_Do per prop)  pysph/parallel/parallel_manager.pyx:159-210
  *   update_time_steps / _compute_bounds          pysph/parallel/parallel_manager.pyx:463, 937-945
- * with: select (device) -> counts to the <= 2 slab neighbours -> pack (device)
- * -> ncclGroupStart; ncclSend / ncclRecv; ncclGroupEnd -> append (device), all on
- * the context's stream, point-to-point over xGMI.
+ * with, on the context's stream and point-to-point over xGMI: the first exchange
+ * of an array -- select (device) -> counts to the <= 2 slab neighbours -> pack
+ * (device) -> ncclGroupStart; ncclSend / ncclRecv; ncclGroupEnd -> append
+ * (device); every later one -- selection + packing of both faces in one device
+ * pass into fixed-capacity messages sized from the count both ends saw last
+ * (sph_halo_select_pack; the row count travels in the message header) -> one
+ * NCCL group -> ONE small device->host copy of the headers -> append; a face
+ * that outgrew its capacity is repeated with the exact size.  The same
+ * protocol as pysph_amd/parallel.py (SPH_HALO_PROTOCOL=handshake forces the
+ * first form).
  *
  * Link: -lsphcomm -lsphhip (libsphcomm.so links librccl itself).  All functions
  * return SPH_OK (0) or a negative SPH_ERR_* code; sph_last_error() of

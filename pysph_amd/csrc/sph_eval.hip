@@ -465,14 +465,17 @@ template <class T> struct FamWCSPHE_T : FamWCSPH_T<T> {
             pj.x = r.q[0].x; pj.y = r.q[0].y; pj.z = r.q[0].z; pj.w = 0.f;
             s[0] = r.q[0].w; s[1] = r.q[1].x; s[2] = r.q[1].y; s[3] = r.q[1].w; rho = r.q[1].z;
         }
-        const T ratio = rho * (T)a.e_rho01;
-        const T r2 = ratio * ratio, r3 = r2 * ratio;
-        const T r7 = (r2 * r2) * r3;
-        const T p = (T)a.e_p0 + (T)a.e_B * (r7 - T(1.0));
         s[4] = rho;
-        s[5] = rho != T(0.0) ? p * fast_rcp(rho * rho) : T(0.0);
-        s[6] = (T)a.e_c0 * r3;
-        s[7] = p;
+        s[5] = s[6] = s[7] = T(0.0);
+        if (a.dflags & F_MOM) { // (launch-uniform) a continuity-only destination -- a dam break's walls -- reads neither
+            const T ratio = rho * (T)a.e_rho01;
+            const T r2 = ratio * ratio, r3 = r2 * ratio;
+            const T r7 = (r2 * r2) * r3;
+            const T p = (T)a.e_p0 + (T)a.e_B * (r7 - T(1.0));
+            s[5] = rho != T(0.0) ? p * fast_rcp(rho * rho) : T(0.0);
+            s[6] = (T)a.e_c0 * r3;
+            s[7] = p;
+        }
     }
     template <class A> static __device__ __forceinline__ void load_fused(const A &a, uint32_t jg, real4<T> &pj, T (&s)[8])
     {
@@ -1354,7 +1357,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         // rho: with gamma = 7 (powers by multiplication), uniform h and no tensile correction the pair kernel
         // recomputes them and the records shrink to 64 bytes (32 in fp32).
         const bool eosf = g->src_eos == 1 && c->eos_fuse && fam == FAM_WCSPH && c->pair_variant == 6 && c->uniform_h &&
-                          c->use_uniform_h && !(dflags & F_TENSILE) && (dflags & F_MOM) && g->eos_par[2] == 7.0 &&
+                          c->use_uniform_h && !(dflags & F_TENSILE) && g->eos_par[2] == 7.0 &&
                           g->eos_par[0] > 0.0 && !c->record_f32 && !c->wcsph_nr;
         if (eosf) pl.nr = 8; // doubles, or floats with arith_f32
         c->cur_eosf = eosf;
