@@ -98,6 +98,7 @@ template <class Fam> struct PairArgs {
 template <class F, class = void> struct fam_eosf { static constexpr bool value = false; };
 template <class F> struct fam_eosf<F, decltype((void)F::EOSF)> { static constexpr bool value = F::EOSF; };
 
+
 // ---------------------------------------------------------------------------
 // fast fp64 reciprocal / square root: hardware estimate (v_rcp_f64 / v_rsq_f64,
 // ~2^-26 relative) + SPH_NEWTON_STEPS Newton steps: one step leaves ~1e-14
