@@ -19,6 +19,9 @@ CASES = [
     ('rings f64', ['--workload', 'elastic']),
     ('rings f32', ['--workload', 'elastic', '--dtype', 'f32']),
 ]
+CASES += [(n + ' prefetch_records=1', a + ['--opt', 'prefetch_records=1']) for n, a in list(CASES)]
+
+
 def main():
     extra = sys.argv[1:]
     rows = []
