@@ -154,13 +154,6 @@ __global__ __launch_bounds__(256) void k_cell_keys(const double *__restrict__ x,
     idx[i] = (uint32_t)i;
 }
 
-// fine (sub-bin) keys of the sorted order -> cell ids
-__global__ __launch_bounds__(256) void k_coarse_keys(const uint32_t *__restrict__ fkeys, size_t n, uint32_t *__restrict__ keys)
-{
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) keys[i] = fkeys[i] / SPH_NSUB;
-}
-
 // one array's segment of the concatenated sort: strip the array tag, split into the array's own tables
 __global__ __launch_bounds__(256) void k_split_segment(const uint32_t *__restrict__ cat_keys, const uint32_t *__restrict__ cat_perm,
                                                        size_t n, uint32_t mask, uint32_t *__restrict__ fkeys,
