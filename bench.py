@@ -847,6 +847,7 @@ def run(args, rank, local_rank, world, dist):
             and args.dtype == 'f64' and not args.ablate:
         del nnps, a_eval, step      # free this workload's device state first (252^3 needs room)
         extra['secondary'] = secondary_runs(args, local_rank, tstream)
+        extra['time_stepping'] = time_stepping(local_rank, tstream)
     if not args.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(args.cpu_n1)
         if not args.no_extras and args.workload == 'cube' and args.n1 == 159:
@@ -856,6 +857,37 @@ def run(args, rank, local_rank, world, dist):
     if extra:
         out['extra'] = extra
     return out
+
+
+def time_stepping(local_rank, tstream, dx=0.0087, n_steps=30):
+    """The callers either side of the path: whole EPEC time steps
+    of the C2 dam break, everything device-resident -- per step two
+    nnps.update() + compute() evaluations, three WCSPHStep stage sweeps and the
+    adaptive time step from device reductions (pysph/sph/integrator.py:161-200,
+    401-420), particles re-ordered into cell order every 50 steps as the
+    reference's Solver does for its GPU backends.  Reported next to the
+    headline, not part of it."""
+    import torch
+    from pysph_amd import device as dev
+    from pysph_amd.examples import dam_break_3d as db
+    ctx = dev.HipContext(local_rank, tstream.cuda_stream)
+    try:
+        db.run(dx=dx, n_steps=3, ctx=ctx)                      # warm-up (buffers, generated code)
+        ctx.close()
+        ctx = dev.HipContext(local_rank, tstream.cuda_stream)
+        arrays, st = db.run(dx=dx, n_steps=n_steps, ctx=ctx)
+        n_fluid = arrays[0].get_number_of_particles()
+        return {'workload': 'C2 dam break dx %g, EPEC + WCSPHStep, adaptive dt, %d steps from rest' % (dx, n_steps),
+                'particles': st['particles'], 'fluid_particles': n_fluid,
+                'ms_per_time_step': st['wall_s'] / st['steps'] * 1e3,
+                'time_steps_per_s': st['steps_per_s'],
+                'particle_steps_per_s': st['particle_steps_per_s'],
+                'simulated_time': st['t']}
+    except Exception as e:
+        return {'error': '%s: %s' % (type(e).__name__, e)}
+    finally:
+        ctx.close()
+        torch.cuda.empty_cache()
 
 
 def family_ms(timers, steps):
