@@ -740,7 +740,7 @@ template <class T> struct FamElastic_T {
     typedef T Real; // arithmetic type of the pair loop
     static constexpr bool PRED = true; // see FamWCSPH
     static constexpr uint32_t CF0 = F_ECONT | F_ESTRESS | F_EAV | F_EXSPH; // flag set compiled as a constant (variant 6)
-    static constexpr int MINB = sizeof(T) == 4 ? 4 : 2; // wavefronts per SIMD the pair kernel is compiled for (VGPR budget)
+    static constexpr int MINB = sizeof(T) == 4 ? 3 : 2; // wavefronts per SIMD the pair kernel is compiled for (VGPR budget; fp32 at 4: 128 B of scratch, 1.94 against 1.88 ms on the rings)
     static constexpr int NA = 18; // u v w m rho cs | t00 t01 t02 t11 t12 t22 (= sigma/rho^2) | r00 r01 r02 r11 r12 r22
     static constexpr int NR = 22;
     struct Params {
