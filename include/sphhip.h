@@ -383,6 +383,10 @@ int sph_halo_append(sph_ctx *ctx, int array_id, int nprops, const int *props, co
 int sph_halo_select_pack(sph_ctx *ctx, int array_id, int axis, double lo_cut, double hi_cut, size_t upto,
                          int nprops, const int *props, const double *shift2, const size_t *cap2,
                          void *const *dst2);
+/* n <= 64 doubles, one from each DEVICE address, in one round trip (all copies
+ * on the context's stream, one synchronisation): the headers of the ghost
+ * messages, from which the host learns the counts.                          */
+int sph_read_values(sph_ctx *ctx, int n, const void *const *dev_ptrs, double *out);
 /* sph_halo_append from a message whose rows are `stride` doubles apart
  * (property k of row i at src[k * stride + i], stride >= count).            */
 int sph_halo_append_strided(sph_ctx *ctx, int array_id, int nprops, const int *props, const void *src_device,

@@ -141,24 +141,64 @@ struct DirectPack {
     double *dst[2];
 };
 
-__global__ __launch_bounds__(256) void k_halo_pack_direct(DirectPack a, const unsigned long long *__restrict__ flag,
-                                                          const unsigned long long *__restrict__ pos, size_t n)
+// pass 1: how many particles of each 256-particle block go to the low / high face (lo | hi << 32)
+__global__ __launch_bounds__(256) void k_halo_block_counts(const double *__restrict__ coord, size_t n, double p0, double p1,
+                                                           unsigned long long *__restrict__ blk)
 {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long f = flag[i], p = pos[i];
-    const size_t pl[2] = {(size_t)(p & 0xffffffffull), (size_t)(p >> 32)};
-    const bool on[2] = {(f & 1ull) != 0, (f >> 32) != 0};
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    bool lo = false, hi = false;
+    if (i < n) {
+        const double v = coord[i];
+        lo = v < p0;
+        hi = v >= p1;
+    }
+    const unsigned long long ml = __ballot(lo), mh = __ballot(hi);
+    __shared__ uint32_t cl[4], ch[4];
+    if ((threadIdx.x & 63) == 0) { cl[threadIdx.x >> 6] = (uint32_t)__popcll(ml); ch[threadIdx.x >> 6] = (uint32_t)__popcll(mh); }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        blk[blockIdx.x] = (unsigned long long)(cl[0] + cl[1] + cl[2] + cl[3]) | ((unsigned long long)(ch[0] + ch[1] + ch[2] + ch[3]) << 32);
+}
+
+// pass 2 (after the exclusive scan of the block counts): every block re-derives its flags, ranks its
+// particles inside the block with wavefront ballots -- ascending index, the same order a full scan gives --
+// and writes their rows straight into the messages; the last block writes the two headers.
+__global__ __launch_bounds__(256) void k_halo_pack_direct(DirectPack a, const double *__restrict__ coord, size_t n, double p0,
+                                                          double p1, const unsigned long long *__restrict__ blk,
+                                                          const unsigned long long *__restrict__ blkpos)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    bool on[2] = {false, false};
+    if (i < n) {
+        const double v = coord[i];
+        on[0] = v < p0;
+        on[1] = v >= p1;
+    }
+    __shared__ uint32_t wcnt[2][4];
+    unsigned long long m[2];
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-        if (on[s] && a.dst[s] && pl[s] < a.cap[s])
+        m[s] = __ballot(on[s]);
+        if (lane == 0) wcnt[s][wv] = (uint32_t)__popcll(m[s]);
+    }
+    __syncthreads();
+    const unsigned long long base = blkpos[blockIdx.x];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        uint32_t before = 0;
+        for (int w = 0; w < wv; w++) before += wcnt[s][w];
+        const size_t pl = (size_t)((s == 0) ? (base & 0xffffffffull) : (base >> 32)) + before +
+                          (size_t)__popcll(m[s] & ((1ull << lane) - 1ull));
+        if (on[s] && a.dst[s] && pl < a.cap[s])
             for (int k = 0; k < a.nprops; k++) {
                 double v = a.p[k][i];
                 if (k == a.axis_k) v += a.shift[s];
-                a.dst[s][(size_t)k * a.cap[s] + pl[s]] = v;
+                a.dst[s][(size_t)k * a.cap[s] + pl] = v;
             }
-        if (i == n - 1 && a.dst[s]) {
-            const size_t cnt = pl[s] + (on[s] ? 1 : 0);
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && a.dst[s]) {
+            const unsigned long long tot = base + blk[blockIdx.x];
+            const size_t cnt = (size_t)((s == 0) ? (tot & 0xffffffffull) : (tot >> 32));
             a.dst[s][(size_t)a.nprops * a.cap[s]] = cnt <= a.cap[s] ? (double)cnt : -(double)cnt;
         }
     }
@@ -198,15 +238,31 @@ extern "C" int sph_halo_select_pack(sph_ctx *c, int id, int axis, double lo_cut,
     }
     const double *coord = A.prop[SPH_X + axis];
     if (!coord) { sph_set_error("sph_halo_select_pack: no device coordinates"); return SPH_ERR_MISSING_PROP; }
-    SPH_TRY(H.flag[0].reserve((n + 1) * 8));
-    SPH_TRY(H.pos[0].reserve((n + 1) * 8));
-    unsigned long long *fl = H.flag[0].as<unsigned long long>(), *ps = H.pos[0].as<unsigned long long>();
-    hipLaunchKernelGGL(k_halo_flags, dim3(div_up(n, 256)), dim3(256), 0, c->stream, coord, n, 0, lo_cut, hi_cut, 0.0, fl);
+    // two passes over the coordinate and a scan of one counter per 256 particles (a scan of one flag per
+    // particle moved three times the bytes: 92 -> ~35 us at 4 M)
+    const unsigned nb = div_up(n, 256);
+    SPH_TRY(H.flag[1].reserve(((size_t)nb + 1) * 8));
+    SPH_TRY(H.pos[1].reserve(((size_t)nb + 1) * 8));
+    unsigned long long *blk = H.flag[1].as<unsigned long long>(), *bps = H.pos[1].as<unsigned long long>();
+    hipLaunchKernelGGL(k_halo_block_counts, dim3(nb), dim3(256), 0, c->stream, coord, n, lo_cut, hi_cut, blk);
     size_t tmp = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, fl, ps, (int)n, c->stream));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, blk, bps, (int)nb, c->stream));
     SPH_TRY(c->cub_tmp.reserve(tmp));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.ptr, tmp, fl, ps, (int)n, c->stream));
-    hipLaunchKernelGGL(k_halo_pack_direct, dim3(div_up(n, 256)), dim3(256), 0, c->stream, a, fl, ps, n);
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.ptr, tmp, blk, bps, (int)nb, c->stream));
+    hipLaunchKernelGGL(k_halo_pack_direct, dim3(nb), dim3(256), 0, c->stream, a, coord, n, lo_cut, hi_cut, blk, bps);
+    return SPH_OK;
+}
+
+// Small device -> host reads in one round trip (the headers of the ghost messages): n doubles, one from each
+// device address, all copies queued on the context's stream before the single synchronisation.
+extern "C" int sph_read_values(sph_ctx *c, int n, const void *const *dev_ptrs, double *out)
+{
+    if (!c || n < 0 || n > 64 || (n && (!dev_ptrs || !out))) { sph_set_error("sph_read_values: bad arguments (at most 64 values)"); return SPH_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    for (int k = 0; k < n; k++)
+        HIP_TRY(hipMemcpyAsync(c->pinned + k, dev_ptrs[k], sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < n; k++) out[k] = c->pinned[k];
     return SPH_OK;
 }
 

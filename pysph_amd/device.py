@@ -96,6 +96,7 @@ SIGNATURES = {
                                        C.c_int, C.POINTER(C.c_int), _PD, C.POINTER(C.c_size_t),
                                        C.POINTER(_P)]),
     'sph_nnps_set_h_range': (C.c_int, [_P, C.c_double, C.c_double]),
+    'sph_read_values': (C.c_int, [_P, C.c_int, C.POINTER(_P), _PD]),
     'sph_halo_remove_selected': (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
     'sph_prop_register': (C.c_int, [C.c_char_p]),
     'sph_eval_generated': (C.c_int, [_P, _P, _P, C.c_double, C.c_double]),

@@ -137,6 +137,24 @@ class DeviceHaloOps(object):
             self.ctx._h, self.id, self.nprops, self.props,
             C.c_void_p(buf.data_ptr()), count, count if stride is None else stride))
 
+    def message_buffer(self, key, size):
+        """the fixed-capacity message `key` (face, direction): one device buffer
+        kept from exchange to exchange while its capacity stays"""
+        cache = self.__dict__.setdefault('_messages', {})
+        t = cache.get(key)
+        if t is None or t.numel() != size:
+            t = cache[key] = self.torch.empty(size, dtype=self.torch.float64, device=self.device)
+        return t
+
+    def read_headers(self, tensors):
+        """the last element of each message, in ONE device->host round trip
+        (sph_read_values: all copies queued on the context's stream, one sync)"""
+        n = len(tensors)
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() + (t.numel() - 1) * 8 for t in tensors])
+        out = (C.c_double * n)()
+        dev._check(self.lib.sph_read_values(self.ctx._h, n, ptrs, out))
+        return [out[k] for k in range(n)]
+
     def select_pack(self, lo_cut, hi_cut, shifts, caps, bufs):
         """Both faces selected AND packed on the device, no host round trip:
         bufs[side] (or None) is a message of caps[side] * nprops + 1 doubles,
@@ -396,9 +414,14 @@ def exchange_halos(hs, drop=True):
         out, inb = [], []
         for a, h in enumerate(hs):
             npr, oa, ia = h.ops.nprops, {}, {}
+            persistent = getattr(h.ops, 'message_buffer', None)
             for s in sides:
-                oa[s] = h.ops.new_buffer(h.cap_send[s] * npr + 1, 1)
-                ia[s] = h.ops.new_buffer(h.cap_recv[s] * npr + 1, 1)
+                if persistent is not None:
+                    oa[s] = persistent(('send', s), h.cap_send[s] * npr + 1)
+                    ia[s] = persistent(('recv', s), h.cap_recv[s] * npr + 1)
+                else:
+                    oa[s] = h.ops.new_buffer(h.cap_send[s] * npr + 1, 1)
+                    ia[s] = h.ops.new_buffer(h.cap_recv[s] * npr + 1, 1)
             if device_pack:
                 # selection and packing of both faces in one device pass, the row
                 # counts stay on the device (headers of the messages)
@@ -423,8 +446,12 @@ def exchange_halos(hs, drop=True):
         # the ONE readback of the exchange: the row counts this rank packed and
         # the ones its peers packed (the host sizes the arrays with them)
         keys = [(a, s) for a in range(na) for s in sides]
-        hdr = torch.stack([out[a][s][-1] for a, s in keys] +
-                          [inb[a][s][-1] for a, s in keys]).cpu().tolist()
+        msgs = [out[a][s] for a, s in keys] + [inb[a][s] for a, s in keys]
+        if hasattr(ops0, 'read_headers'):
+            comm_sync('after_comm')     # (a context with a stream of its own: the receives are complete first)
+            hdr = ops0.read_headers(msgs)
+        else:
+            hdr = torch.stack([m[-1] for m in msgs]).cpu().tolist()
         sent = {k: int(v) for k, v in zip(keys, hdr[:len(keys)])}
         hdr = {k: int(v) for k, v in zip(keys, hdr[len(keys):])}
         for a, s in keys:

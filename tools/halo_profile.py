@@ -66,6 +66,45 @@ def main():
         for s in (0, 1):
             ops.append(inb[s], allc[1 - s])
         t = tick('append x2', t)
+    # the round-3 exchange, phase by phase: device-side select + pack, transfer of the
+    # fixed-capacity messages, header readback, strided append
+    acc3 = {}
+
+    def tick3(name, t0):
+        torch.cuda.synchronize()
+        acc3[name] = acc3.get(name, 0.0) + (time.perf_counter() - t0)
+        return time.perf_counter()
+    cap = {s: h.cap_send[s] for s in (0, 1)}
+    capr = {s: h.cap_recv[s] for s in (0, 1)}
+    shift_of = {s: shift for s, _, shift in h.neighbours()}
+    for _ in range(reps):
+        if domain is not None:
+            n = ops.n_real()
+            dev._check(ops.lib.sph_array_resize(ctx._h, ops.id, n, n))
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        ops.drop_ghosts(); t = tick3('drop', t)
+        out = {s: ops.message_buffer(('send', s), cap[s] * ops.nprops + 1) for s in (0, 1)}
+        inb = {s: ops.message_buffer(('recv', s), capr[s] * ops.nprops + 1) for s in (0, 1)}
+        t = tick3('buffers (kept from exchange to exchange)', t)
+        ops.select_pack(h.lo + h.width, h.hi - h.width, [shift_of[0], shift_of[1]], [cap[0], cap[1]],
+                        [out[0], out[1]]); t = tick3('select_pack (block counts, scan, pack)', t)
+        reqs = [dist.P2POp(dist.isend, out[s], 0) for s in (1, 0)] + [dist.P2POp(dist.irecv, inb[s], 0) for s in (0, 1)]
+        for wk in dist.batch_isend_irecv(reqs):
+            wk.wait()
+        t = tick3('send/recv of the capacity-sized messages', t)
+        hdr = ops.read_headers([out[0], out[1], inb[0], inb[1]])
+        t = tick3('header readback (sph_read_values)', t)
+        for s in (0, 1):
+            ops.append(inb[s], int(abs(hdr[2 + s])), stride=capr[s])
+        t = tick3('append x2 (strided)', t)
+    print('round-3 protocol (capacities %d / %d rows):' % (cap[0], cap[1]))
+    tot3 = 0.0
+    for k, v in acc3.items():
+        print('  %-40s %7.1f us' % (k, v / reps * 1e6))
+        tot3 += v / reps
+    print('  %-40s %7.1f us' % ('sum', tot3 * 1e6))
+    print('list-based protocol of round 2:')
     total = 0.0
     for k, v in acc.items():
         print('%-42s %7.1f us' % (k, v / reps * 1e6))
