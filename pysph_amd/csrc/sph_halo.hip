@@ -10,23 +10,56 @@
 
 #include <hipcub/hipcub.hpp>
 
-// one 64-bit flag per particle: bit 0 = selected for the low side, bit 32 = for the high side,
-// so that ONE exclusive scan yields both lists' positions (low word / high word)
-__global__ __launch_bounds__(256) void k_halo_flags(const double *__restrict__ coord, size_t n, int mode, double p0,
-                                                    double p1, double p2, unsigned long long *__restrict__ fl)
+// one 64-bit flag per particle: bit 0 = selected for the low side, bit 32 = for the high side (kept for
+// sph_halo_remove_selected), plus, per 256-particle block, how many particles go to each side (lo | hi << 32): the lists
+// are then built from a scan of one counter per BLOCK (k_halo_lists) instead of one flag per particle.
+__global__ __launch_bounds__(256) void k_halo_flags_counts(const double *__restrict__ coord, size_t n, int mode, double p0,
+                                                           double p1, double p2, unsigned long long *__restrict__ fl,
+                                                           unsigned long long *__restrict__ blk)
 {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double v = coord[i];
-    bool lo, hi;
-    if (mode == 0) {
-        lo = v < p0;
-        hi = v >= p1;
-    } else { // nnps_base.pyx:805-817
-        lo = (v - p0) <= p2;
-        hi = (p1 - v) <= p2;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    bool lo = false, hi = false;
+    if (i < n) {
+        const double v = coord[i];
+        if (mode == 0) { lo = v < p0; hi = v >= p1; }
+        else { lo = (v - p0) <= p2; hi = (p1 - v) <= p2; } // nnps_base.pyx:805-817
+        fl[i] = (lo ? 1ull : 0ull) | (hi ? 1ull << 32 : 0ull);
     }
-    fl[i] = (lo ? 1ull : 0ull) | (hi ? 1ull << 32 : 0ull);
+    const unsigned long long ml = __ballot(lo), mh = __ballot(hi);
+    __shared__ uint32_t cl[4], ch[4];
+    if ((threadIdx.x & 63) == 0) { cl[threadIdx.x >> 6] = (uint32_t)__popcll(ml); ch[threadIdx.x >> 6] = (uint32_t)__popcll(mh); }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        blk[blockIdx.x] = (unsigned long long)(cl[0] + cl[1] + cl[2] + cl[3]) | ((unsigned long long)(ch[0] + ch[1] + ch[2] + ch[3]) << 32);
+}
+
+// index lists of both sides, ascending (the order a scan of per-particle flags gives): rank inside the
+// block by wavefront ballots, block offset from the scanned block counters
+__global__ __launch_bounds__(256) void k_halo_lists(const unsigned long long *__restrict__ fl, size_t n,
+                                                    const unsigned long long *__restrict__ blkpos,
+                                                    uint32_t *__restrict__ list_lo, uint32_t *__restrict__ list_hi)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long f = i < n ? fl[i] : 0ull;
+    const bool on[2] = {(f & 1ull) != 0, (f >> 32) != 0};
+    __shared__ uint32_t wcnt[2][4];
+    unsigned long long m[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        m[s] = __ballot(on[s]);
+        if (lane == 0) wcnt[s][wv] = (uint32_t)__popcll(m[s]);
+    }
+    __syncthreads();
+    const unsigned long long base = blkpos[blockIdx.x];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        uint32_t before = 0;
+        for (int w = 0; w < wv; w++) before += wcnt[s][w];
+        const uint32_t pl = (uint32_t)((s == 0) ? (base & 0xffffffffull) : (base >> 32)) + before +
+                            (uint32_t)__popcll(m[s] & ((1ull << lane) - 1ull));
+        if (on[s]) (s == 0 ? list_lo : list_hi)[pl] = (uint32_t)i;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_box_wrap(double *__restrict__ coord, size_t n, double vmin, double vmax,
@@ -38,17 +71,6 @@ __global__ __launch_bounds__(256) void k_box_wrap(double *__restrict__ coord, si
     if (v < vmin) v = v + translate;
     if (v > vmax) v = v - translate;
     coord[i] = v;
-}
-
-__global__ __launch_bounds__(256) void k_halo_scatter(const unsigned long long *__restrict__ flag,
-                                                      const unsigned long long *__restrict__ pos, size_t n,
-                                                      uint32_t *__restrict__ list_lo, uint32_t *__restrict__ list_hi)
-{
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long f = flag[i], p = pos[i];
-    if (f & 1ull) list_lo[(uint32_t)p] = (uint32_t)i;
-    if (f >> 32) list_hi[(uint32_t)(p >> 32)] = (uint32_t)i;
 }
 
 __global__ __launch_bounds__(256) void k_list_scatter(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos,
@@ -104,17 +126,20 @@ extern "C" int sph_halo_select(sph_ctx *c, int id, int axis, int mode, double p0
     if (n == 0) return SPH_OK;
     const double *coord = A.prop[SPH_X + axis];
     if (!coord) { sph_set_error("sph_halo_select: no device coordinates"); return SPH_ERR_MISSING_PROP; }
+    const unsigned nb = div_up(n, 256);
     SPH_TRY(H.flag[0].reserve((n + 1) * 8));
-    SPH_TRY(H.pos[0].reserve((n + 1) * 8));
-    unsigned long long *fl = H.flag[0].as<unsigned long long>(), *ps = H.pos[0].as<unsigned long long>();
-    hipLaunchKernelGGL(k_halo_flags, dim3(div_up(n, 256)), dim3(256), 0, c->stream, coord, n, mode, p0, p1, p2, fl);
+    SPH_TRY(H.flag[1].reserve(((size_t)nb + 1) * 8));
+    SPH_TRY(H.pos[1].reserve(((size_t)nb + 1) * 8));
+    unsigned long long *fl = H.flag[0].as<unsigned long long>();
+    unsigned long long *blk = H.flag[1].as<unsigned long long>(), *bps = H.pos[1].as<unsigned long long>();
+    hipLaunchKernelGGL(k_halo_flags_counts, dim3(nb), dim3(256), 0, c->stream, coord, n, mode, p0, p1, p2, fl, blk);
     size_t tmp = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, fl, ps, (int)n, c->stream));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, blk, bps, (int)nb, c->stream));
     SPH_TRY(c->cub_tmp.reserve(tmp));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.ptr, tmp, fl, ps, (int)n, c->stream));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.ptr, tmp, blk, bps, (int)nb, c->stream));
     unsigned long long *pin = (unsigned long long *)c->pinned;
-    HIP_TRY(hipMemcpyAsync(pin, ps + (n - 1), 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(pin + 1, fl + (n - 1), 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(pin, bps + (nb - 1), 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(pin + 1, blk + (nb - 1), 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const unsigned long long tot = pin[0] + pin[1]; // no carry between the words: each count < 2^32
     H.count[0] = (size_t)(tot & 0xffffffffull);
@@ -124,8 +149,8 @@ extern "C" int sph_halo_select(sph_ctx *c, int id, int axis, int mode, double p0
         SPH_TRY(H.list[s].reserve((H.count[s] + 1) * 4));
     }
     if (H.count[0] + H.count[1])
-        hipLaunchKernelGGL(k_halo_scatter, dim3(div_up(n, 256)), dim3(256), 0, c->stream, fl, ps, n,
-                           H.list[0].as<uint32_t>(), H.list[1].as<uint32_t>());
+        hipLaunchKernelGGL(k_halo_lists, dim3(nb), dim3(256), 0, c->stream, fl, n, bps, H.list[0].as<uint32_t>(),
+                           H.list[1].as<uint32_t>());
     return SPH_OK;
 }
 
