@@ -129,3 +129,114 @@ def test_comm_library_self_periodic_exchange_matches_torch_path():
     assert comm.sph_allreduce(ctx._h, v, 3, 2) == 0 and list(v) == [1.5, -2.0, 7.0]
     assert comm.sph_comm_destroy(ctx._h) == 0
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_select_pack_equals_list_based_select_and_pack():
+    """sph_halo_select_pack (selection + packing of both faces in one device
+    pass, counts only in the message headers) against the list-based
+    sph_halo_select / sph_halo_pack: same rows in the same order, the header
+    carries the count, a capacity that is too small gives a NEGATIVE header,
+    an open face (NULL message) is left alone; sph_read_values returns the
+    headers in one round trip."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from pysph_amd import device as dev
+    from pysph_amd.particle_array import get_particle_array_wcsph
+    rng = np.random.default_rng(3)
+    n = 70001                               # ragged last block
+    pa = get_particle_array_wcsph(name='fluid', x=rng.uniform(0, 1, n), y=rng.uniform(0, 1, n),
+                                  z=rng.uniform(0, 1, n), u=rng.uniform(-1, 1, n), rho=rng.uniform(1, 2, n),
+                                  h=0.01 * np.ones(n), m=np.ones(n))
+    # torch fills the message buffers, the library packs into them: both on ONE stream (torch's default
+    # stream has the NULL handle, for which the library would create a stream of its own)
+    ts = torch.cuda.Stream()
+    torch.cuda.set_stream(ts)
+    ctx = dev.HipContext(0, ts.cuda_stream)
+    g = dev.attach(pa, ctx)
+    g.push()
+    lib = ctx.lib
+    names = ('x', 'y', 'z', 'u', 'rho', 'h', 'm')
+    props = (C.c_int * len(names))(*[dev.prop_id(p) for p in names])
+    npr = len(names)
+    lo_cut, hi_cut, shift = 0.07, 0.91, (0.5, -2.0)
+    counts = (C.c_size_t * 2)()
+    dev._check(lib.sph_halo_select(ctx._h, g.array_id, 0, 0, lo_cut, hi_cut, 0.0, 0, counts))
+    cnt = [int(counts[0]), int(counts[1])]
+    assert cnt == [int((pa.x < lo_cut).sum()), int((pa.x >= hi_cut).sum())] and min(cnt) > 1000
+    ref = []
+    for s in (0, 1):
+        buf = torch.empty(cnt[s] * npr, dtype=torch.float64, device='cuda')
+        dev._check(lib.sph_halo_pack(ctx._h, g.array_id, s, npr, props, 0, shift[s], C.c_void_p(buf.data_ptr())))
+        ref.append(buf.cpu().numpy().reshape(npr, cnt[s]))
+    # rows in ascending particle index, the axis coordinate shifted
+    idx = np.nonzero(pa.x < lo_cut)[0]
+    assert np.array_equal(ref[0][0], pa.x[idx] + shift[0]) and np.array_equal(ref[0][3], pa.u[idx])
+
+    def select_pack(caps, with_lo=True):
+        bufs = [torch.full((caps[s] * npr + 1,), -7.0, dtype=torch.float64, device='cuda') for s in (0, 1)]
+        sh = (C.c_double * 2)(*shift)
+        cp = (C.c_size_t * 2)(*caps)
+        ds = (C.c_void_p * 2)(bufs[0].data_ptr() if with_lo else None, bufs[1].data_ptr())
+        dev._check(lib.sph_halo_select_pack(ctx._h, g.array_id, 0, lo_cut, hi_cut, 0, npr, props, sh, cp, ds))
+        ptrs = (C.c_void_p * 2)(*[b.data_ptr() + caps[s] * npr * 8 for s, b in enumerate(bufs)])
+        hdr = (C.c_double * 2)()
+        dev._check(lib.sph_read_values(ctx._h, 2, ptrs, hdr))
+        return [b.cpu().numpy() for b in bufs], [hdr[0], hdr[1]]
+    caps = [cnt[0] + 500, cnt[1] + 37]
+    bufs, hdr = select_pack(caps)
+    assert hdr == [float(cnt[0]), float(cnt[1])]
+    for s in (0, 1):
+        rows = bufs[s][:-1].reshape(npr, caps[s])
+        assert np.array_equal(rows[:, :cnt[s]], ref[s]), s
+        assert np.all(rows[:, cnt[s]:] == -7.0)             # nothing written behind the rows
+        assert bufs[s][-1] == cnt[s]
+    # a capacity that is too small: negative header, what fits is the head of the list
+    small = [cnt[0] - 100, cnt[1] + 1]
+    bufs, hdr = select_pack(small)
+    assert hdr == [-float(cnt[0]), float(cnt[1])]
+    assert np.array_equal(bufs[0][:-1].reshape(npr, small[0]), ref[0][:, :small[0]])
+    # open low face: its message is not touched, the high face is complete
+    bufs, hdr = select_pack(caps, with_lo=False)
+    assert np.all(bufs[0] == -7.0) and hdr[1] == float(cnt[1])
+    assert np.array_equal(bufs[1][:-1].reshape(npr, caps[1])[:, :cnt[1]], ref[1])
+    # argument errors are errors, not overruns
+    with pytest.raises(dev.SphError):
+        dev._check(lib.sph_read_values(ctx._h, 65, None, None))
+    with pytest.raises(dev.SphError):
+        dev._check(lib.sph_halo_append_strided(ctx._h, g.array_id, npr, props, C.c_void_p(0), 10, 5))
+    ctx.close()
+    torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+@pytest.mark.gpu
+def test_fixed_h_and_bounds_skip_the_reduction_but_not_the_result():
+    """LinkedListNNPS(fixed_h=True) + nnps.bounds: sph_nnps_update takes the grid
+    from the caller and the h range from the first update (no min/max pass, no
+    round trip); the neighbour lists are those of the default path, also after
+    the particles moved inside the bounds."""
+    import numpy as np
+    from test_hip_parity import make_cube
+    from pysph_amd import device as dev
+    from pysph_amd.nnps import HipNNPS
+    pa, dx = make_cube(14)
+    pb, _ = make_cube(14)
+    ctx_a, ctx_b = dev.HipContext(0), dev.HipContext(0)
+    na = HipNNPS(3, [pa], radius_scale=2.0, ctx=ctx_a)
+    nb = HipNNPS(3, [pb], radius_scale=2.0, ctx=ctx_b, fixed_h=True)
+    assert nb._h_fixed
+    nb.bounds = (-0.2, -0.2, -0.2, 1.2, 1.2, 1.2)
+    rng = np.random.default_rng(0)
+    for step in range(3):
+        d = 0.3 * dx * rng.uniform(-1, 1, (3, pa.get_number_of_particles()))
+        for p in (pa, pb):
+            p.x += d[0]; p.y += d[1]; p.z += d[2]
+        na.update()
+        nb.update()
+        assert tuple(nb.xmin) == (-0.2, -0.2, -0.2) and nb.cell_size == na.cell_size
+        sa, ia = na.get_csr(0, 0)
+        sb, ib = nb.get_csr(0, 0)
+        assert np.array_equal(sa, sb) and np.array_equal(ia, ib)
+    ctx_a.close()
+    ctx_b.close()
