@@ -448,6 +448,10 @@ int sph_reduce_min(sph_ctx *ctx, int array_id, int prop, double *out);
  *   "eos_fuse"       0: ignore sph_group.src_eos (default 1)
  *   "nl_reuse"       1: honour sph_group.nl_mode (default 0: measured slower)
  *   "norm_masks"     0: hit masks are not shifted down to a lane's first hit (default 1)
+ *   "row_mod3"       order in which a wavefront visits its 3x3 rows of cells: 3 (default) = the row whose
+ *                    (y mod 3, z mod 3) equals the step, so that all wavefronts in flight walk rows of one
+ *                    residue class at a time and find each other's lines in L1 / L2; 1 / 2 = y / z only;
+ *                    0 = (dy, dz) order; 4 = (dy, dz) order rotated per tile.  Sums are taken in that order.
  *   profiling only:  "ablate", "count_iters", "dump_counters", "lds_pad",
  *                    "wcsph_nr"                        */
 int sph_set_option(sph_ctx *ctx, const char *key, long value);

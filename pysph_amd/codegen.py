@@ -1394,6 +1394,7 @@ class GeneratedFamily(object):
         A('    PairArgs<FamGen> a;')
         A('    memset(&a, 0, sizeof a);')
         A('    a.norm_masks = 1;')
+        A('    a.row_mod3 = 3;')
         A('    a.nsrc = g->nsrc;')
         A('    for (int j = 0; j < g->nsrc; j++) a.src[j] = {g->src_cell_start[j], g->src_off[j], g->src_flags[j], g->src_fine_start[j]};')
         A('    a.rec = g->rec; a.nrec = g->nrec; a.fpos = (const float4 *)g->fpos; a.dom_extent = g->dom_extent;')

@@ -259,6 +259,10 @@ int sph_set_option(sph_ctx *c, const char *key, long value)
         if (value < 0 || value > 4096) { sph_set_error("tile_block_rows out of range"); return SPH_ERR_ARG; }
         c->tile_block_rows = value; c->nnps_valid = false; return SPH_OK;
     }
+    if (strcmp(key, "row_mod3") == 0) {
+        if (value < 0 || value > 4) { sph_set_error("row_mod3 must be 0..4"); return SPH_ERR_ARG; }
+        c->row_mod3 = value; return SPH_OK;
+    }
     if (strcmp(key, "pack_group") == 0) { c->pack_group = value ? 1 : 0; c->pack_epoch++; return SPH_OK; }
     if (strcmp(key, "wcsph_nr") == 0) { c->wcsph_nr = value; return SPH_OK; }
     if (strcmp(key, "lds_pad") == 0) { c->lds_pad = value; return SPH_OK; }

@@ -590,7 +590,7 @@ template <class T> struct FamTVF_T {
     typedef T Real; // arithmetic type of the pair loop
     static constexpr bool PRED = true; // see FamWCSPH
     static constexpr uint32_t CF0 = F_TP | F_TVISC | F_TAS; // flag set compiled as a constant (variant 6)
-    static constexpr int MINB = sizeof(T) == 4 ? 4 : 3; // wavefronts per SIMD the pair kernel is compiled for (VGPR budget)
+    static constexpr int MINB = 4; // wavefronts per SIMD the pair kernel is compiled for (VGPR budget; fp64: 125-129 registers)
     static constexpr int NA = 12; // u v w uhat vhat what rho p V m Vj2 pad
     static constexpr int NR = 16; // x y z h + NA
     struct Params {
@@ -740,22 +740,29 @@ template <class T> struct FamElastic_T {
     typedef T Real; // arithmetic type of the pair loop
     static constexpr bool PRED = true; // see FamWCSPH
     static constexpr uint32_t CF0 = F_ECONT | F_ESTRESS | F_EAV | F_EXSPH; // flag set compiled as a constant (variant 6)
-    static constexpr int MINB = sizeof(T) == 4 ? 3 : 2; // wavefronts per SIMD the pair kernel is compiled for (VGPR budget; fp32 at 4: 128 B of scratch, 1.94 against 1.88 ms on the rings)
+    // wavefronts per SIMD the pair kernel is compiled for (VGPR budget): fp32 120 registers; fp64 215-227, and at 3
+    // (168 registers + 190 B of scratch) the rings take the same 2.99 ms
+    static constexpr int MINB = sizeof(T) == 4 ? 4 : 2;
     static constexpr int NA = 18; // u v w m rho cs | t00 t01 t02 t11 t12 t22 (= sigma/rho^2) | r00 r01 r02 r11 r12 r22
     static constexpr int NR = 22;
     struct Params {
         T wdeltap, n, alpha, beta, eps;
         double *arho, *au, *av, *aw, *ax, *ay, *az;
     };
+    // The destination's own tensors are NOT live in the pair loop: with S = sum_j m_j DWIJ and F = sum_j m_j f^n DWIJ,
+    //   sum_j m_j ((t_i + t_j) + f^n (r_i + r_j)) . DWIJ = t_i . S + r_i . F + sum_j m_j (t_j + f^n r_j) . DWIJ,
+    // so t_i, r_i (24 registers in fp64) wait in scratch until finish() and the loop carries S and F (12) instead.
     struct Dest {
         T u, v, w, rho, cs, t[6], r[6];
         T arho, au, av, aw, ax, ay, az;
+        T s[3], f[3];
     };
     template <class A> static __device__ __forceinline__ void load(Dest &D, const T *a, const A &, uint32_t)
     {
         D.u = a[0]; D.v = a[1]; D.w = a[2]; D.rho = a[4]; D.cs = a[5];
         for (int k = 0; k < 6; k++) { D.t[k] = a[6 + k]; D.r[k] = a[12 + k]; }
         D.arho = D.au = D.av = D.aw = D.ax = D.ay = D.az = T(0.0);
+        for (int k = 0; k < 3; k++) D.s[k] = D.f[k] = T(0.0);
     }
     template <int KK, bool UH, class A>
     static __device__ __forceinline__ void pair(Dest &D, const real4<T> &pi, const real4<T> &pj, T r2,
@@ -782,15 +789,14 @@ template <class T> struct FamElastic_T {
                 else if (a.p.n == T(1.0)) fab = f;
                 else fab = pow(f, a.p.n);
             }
-            const T a00 = D.t[0] + s[6] + fab * (D.r[0] + s[12]);
-            const T a01 = D.t[1] + s[7] + fab * (D.r[1] + s[13]);
-            const T a02 = D.t[2] + s[8] + fab * (D.r[2] + s[14]);
-            const T a11 = D.t[3] + s[9] + fab * (D.r[3] + s[15]);
-            const T a12 = D.t[4] + s[10] + fab * (D.r[4] + s[16]);
-            const T a22 = D.t[5] + s[11] + fab * (D.r[5] + s[17]);
-            D.au += mj * (a00 * dw0 + a01 * dw1 + a02 * dw2);
-            D.av += mj * (a01 * dw0 + a11 * dw1 + a12 * dw2);
-            D.aw += mj * (a02 * dw0 + a12 * dw1 + a22 * dw2);
+            const T m0 = mj * dw0, m1 = mj * dw1, m2 = mj * dw2;
+            D.s[0] += m0; D.s[1] += m1; D.s[2] += m2;
+            D.f[0] = fma(fab, m0, D.f[0]); D.f[1] = fma(fab, m1, D.f[1]); D.f[2] = fma(fab, m2, D.f[2]);
+            const T a00 = fma(fab, s[12], s[6]), a01 = fma(fab, s[13], s[7]), a02 = fma(fab, s[14], s[8]);
+            const T a11 = fma(fab, s[15], s[9]), a12 = fma(fab, s[16], s[10]), a22 = fma(fab, s[17], s[11]);
+            D.au += a00 * m0 + a01 * m1 + a02 * m2;
+            D.av += a01 * m0 + a11 * m1 + a12 * m2;
+            D.aw += a02 * m0 + a12 * m1 + a22 * m2;
         }
         if (fl & (F_EAV | F_EXSPH)) {
             const T rhoij = T(0.5) * (D.rho + s[4]);
@@ -815,6 +821,11 @@ template <class T> struct FamElastic_T {
     template <class A> static __device__ __forceinline__ void finish(Dest &D, const A &a, uint32_t o)
     {
         if (a.dflags & F_ECONT) a.p.arho[o] = D.arho;
+        if (a.dflags & F_ESTRESS) { // the destination's own share of the stress term
+            D.au += D.t[0] * D.s[0] + D.t[1] * D.s[1] + D.t[2] * D.s[2] + D.r[0] * D.f[0] + D.r[1] * D.f[1] + D.r[2] * D.f[2];
+            D.av += D.t[1] * D.s[0] + D.t[3] * D.s[1] + D.t[4] * D.s[2] + D.r[1] * D.f[0] + D.r[3] * D.f[1] + D.r[4] * D.f[2];
+            D.aw += D.t[2] * D.s[0] + D.t[4] * D.s[1] + D.t[5] * D.s[2] + D.r[2] * D.f[0] + D.r[4] * D.f[1] + D.r[5] * D.f[2];
+        }
         if (a.dflags & (F_ESTRESS | F_EAV)) { a.p.au[o] = D.au; a.p.av[o] = D.av; a.p.aw[o] = D.aw; }
         if (a.dflags & F_EXSPH) { a.p.ax[o] = D.ax + D.u; a.p.ay[o] = D.ay + D.v; a.p.az[o] = D.az + D.w; }
     }
@@ -1097,7 +1108,7 @@ template <class Fam> static int launch_pair(sph_ctx *c, int kk, const PairArgs<F
     const bool uh = c->uniform_h && c->use_uniform_h;
     constexpr bool FP32 = sizeof(typename Fam::Real) == 4;
     if (c->pair_variant == 6) {
-        dim3 g2(4 * div_up(a.nd, 256) / WPB), b2(64 * WPB);
+        dim3 g2(div_up(4 * div_up(a.nd, 256), WPB)), b2(64 * WPB);
         // equation flags as a compile-time constant when every source carries the same set
         uint32_t cf = a.src[0].flags;
         for (int j = 1; j < a.nsrc; j++) if (a.src[j].flags != cf) cf = 0;
@@ -1144,7 +1155,7 @@ template <class Fam> static int launch_pair_fused(sph_ctx *c, int kk, const Pair
 {
     if (a.nd == 0) return SPH_OK;
     constexpr bool FP32 = sizeof(typename Fam::Real) == 4;
-    dim3 g2(4 * div_up(a.nd, 256) / WPB), b2(64 * WPB);
+    dim3 g2(div_up(4 * div_up(a.nd, 256), WPB)), b2(64 * WPB);
     uint32_t cf = a.src[0].flags;
     for (int j = 1; j < a.nsrc; j++) if (a.src[j].flags != cf) cf = 0;
     if (c->const_flags == 0) cf = 0;
@@ -1191,6 +1202,13 @@ static void fill_common(sph_ctx *c, PairArgs<Fam> &a, const sph_kernel *K, doubl
     a.norm_masks = (int)c->norm_masks;
 }
 
+// traversal order of the destination's tiles (sph_nnps_update builds it; option tile_block_rows) and of a tile's rows
+template <class Fam> static void set_tile_order(sph_ctx *c, PairArgs<Fam> &a, const DevArray &D)
+{
+    a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
+    a.row_mod3 = (int)c->row_mod3;
+}
+
 static int ensure_out(sph_ctx *c, int id, std::initializer_list<int> props)
 {
     for (int p : props) SPH_TRY(sph_array_ensure_prop(c, id, p));
@@ -1232,10 +1250,10 @@ int nnps_csr_pair_kernel(sph_ctx *c, int src, int dst, uint32_t *count, const ui
     a.d_off = dest_is_src ? 0u : (uint32_t)S.n;
     a.nd = (uint32_t)D.n;
     a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
-    a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
+    set_tile_order(c, a, D);
     a.d_start = 0; a.d_stop = (uint32_t)D.n; a.dflags = 1u;
     a.p.count = count; a.p.start = start; a.p.nbrs = nbrs;
-    dim3 g2(4 * div_up(a.nd, 256) / WPB), b2(64 * WPB);
+    dim3 g2(div_up(4 * div_up(a.nd, 256), WPB)), b2(64 * WPB);
     if (uh) hipLaunchKernelGGL((k_pair_wave<FamNbr, 1, true, false, 1>), g2, b2, 0, c->stream, a);
     else hipLaunchKernelGGL((k_pair_wave<FamNbr, 1, false, false, 1>), g2, b2, 0, c->stream, a);
     return SPH_OK;
@@ -1424,7 +1442,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j], c->arr[srcs[j]].fine_start.as<uint32_t>()};
             a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
             a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
-            a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
+            set_tile_order(c, a, D);
             a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
             a.nl = nullptr; a.nl_mode = nl_mode;
             if (nl_mode) a.nl = c->nlbuf.as<uint32_t>();

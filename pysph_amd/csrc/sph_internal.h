@@ -112,6 +112,7 @@ struct sph_ctx {
     long arith_f32 = 0;     // hand-written families compute in fp32 (fp32 records, fp32 accumulators; BASELINE config 5)
     long record_f32 = 0;    // packed records in fp32 (inputs rounded, arithmetic fp64): aggregated kernel only
     long tile_block_rows = 8; // destination tiles are traversed in blocks of this many cell rows (y) through all z planes; 0: memory order
+    long row_mod3 = 3;        // the pair kernel visits a wavefront's 3x3 rows of cells in (y mod 3, z mod 3) order (PairArgs::row_mod3)
     double cur_dt = 0.0;    // dt of the sph_eval_group call being set up
     DevBuf csr_start[SPH_MAX_ARRAYS], csr_nbrs[SPH_MAX_ARRAYS]; // neighbour lists of generated loop_all families
     unsigned long long pack_epoch = 0;

@@ -460,16 +460,17 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
         // tiles gives the same results.  Particles move a fraction of a cell per step, so the order of the last
         // build stays good: rebuilt when the tile count or the grid changed and every 16th update.
         const bool want_tiles = c->tile_block_rows > 0 && c->nc[2] > 1 && n > 64 * SPH_TILE;
+        const int tsig = (int)c->tile_block_rows;
         const uint32_t nt_now = (uint32_t)div_up(n, SPH_TILE);
         if (want_tiles && A.n_tiles == nt_now && A.tile_grid[0] == c->nc[0] && A.tile_grid[1] == c->nc[1] &&
-            A.tile_grid[2] == c->nc[2] && A.tile_grid[3] == (int)c->tile_block_rows && ++A.tile_age < 16) {
+            A.tile_grid[2] == c->nc[2] && A.tile_grid[3] == tsig && ++A.tile_age < 16) {
             continue;
         }
         A.n_tiles = 0;
         if (want_tiles) {
             A.tile_age = 0;
-            A.tile_grid[0] = c->nc[0]; A.tile_grid[1] = c->nc[1]; A.tile_grid[2] = c->nc[2]; A.tile_grid[3] = (int)c->tile_block_rows;
-            const uint32_t nt = (uint32_t)div_up(n, SPH_TILE);
+            A.tile_grid[0] = c->nc[0]; A.tile_grid[1] = c->nc[1]; A.tile_grid[2] = c->nc[2]; A.tile_grid[3] = tsig;
+            const uint32_t nt = nt_now;
             SPH_TRY(A.tile_key.reserve((size_t)nt * 4 * 2));
             SPH_TRY(A.tile_id.reserve((size_t)nt * 4));
             SPH_TRY(A.tile_order.reserve((size_t)nt * 4));

@@ -68,6 +68,9 @@ template <class Fam> struct PairArgs {
     uint32_t d_off, nd;
     const uint32_t *d_keys, *d_fkeys, *d_perm; // cell ids / fine keys of the sorted destinations, sorted -> original index
     const uint32_t *d_tile_order; // traversal order of the destination tiles (null: memory order)
+    int row_mod3;      // order in which a wavefront visits its 3x3 rows of cells: bit 0 / bit 1 -- step (sy, sz) takes the
+                       // row whose y / z is congruent to the step modulo 3, so that ALL wavefronts in flight walk rows of
+                       // one residue class at a time (they share them in L2 / L1); 4 -- natural order rotated per wave tile
     uint32_t d_start, d_stop;
     int nc[3];
     double xmin[3];
@@ -331,9 +334,11 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     // 64-destination wave tiles inside the 256-destination tiles of the traversal order
     const uint32_t wt = xcd_tile(blockIdx.x, gridDim.x) * WPB + (uint32_t)wv;
     uint32_t dtile = wt >> 2;
+    if (dtile * 256u >= a.nd) return; // the grid is rounded up to whole workgroups
     if (a.d_tile_order) dtile = a.d_tile_order[dtile];
-    const uint32_t i = dtile * 256u + (wt & 3u) * 64u + t;
-    if (dtile * 256u + (wt & 3u) * 64u >= a.nd) return; // whole wavefront past the end
+    const uint32_t tbase = dtile * 256u + (wt & 3u) * 64u;
+    const uint32_t i = tbase + t;
+    if (tbase >= a.nd) return; // whole wavefront past the end
     const bool valid = i < a.nd;
     const uint32_t ic = valid ? i : a.nd - 1;
     const uint32_t o = a.d_perm[ic];
@@ -432,12 +437,21 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     // Sources outermost: a wavefront whose 64 destinations straddle a row
     // boundary does phase 1 once per row segment (only that segment's lanes
     // build masks) but ONE phase 2 per source for all its lanes together.
+    // Phase 2 has ONE call site per source, outside the row loops: a lane that
+    // runs out of slots (rare) makes the wavefront leave the loops with its
+    // position (row segment, row step, tile, part) saved, work the lists off and
+    // re-enter at that position, re-staging the tile it stopped in.  Nothing of
+    // phase 1 is live across phase 2 except that position (wave-uniform), which
+    // is what lets the register allocator give phase 2 the whole budget.
     for (int s = 0; s < a.nsrc; s++) {
     const SrcDesc sd = a.src[s];
     const uint32_t fl = CF ? CF : sd.flags;
-    for (int R = row_first; R <= row_last; R++) {
-        if (reuse) break; // the lists are in LDS already
-        if (a.ablate == 6) break; // profiling: prologue + finish only
+    int R = row_first, st = 0, part_resume = 0; // position in phase 1 (wave-uniform)
+    uint32_t tb_resume = 0;
+    bool resumed = false;
+    for (;;) {
+    bool more = false; // a lane is out of slots: phase 2 now, then back into the loops
+    for (; R <= row_last && !more && !reuse && a.ablate != 6; R++, st = 0) { // reuse: the lists are in LDS already; 6 (profiling): prologue + finish only
         const bool inseg = active && row == R;
         const unsigned long long segm = __ballot(inseg);
         if (!segm) continue;
@@ -463,110 +477,121 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
         const float hi2f = hif * hif;
         const int mycl = max(cx - XWIN, xa) - xa, mych = min(cx + XWIN, xb) + 1 - xa;
 
-        {
-            for (int dz = -1; dz <= 1; dz++)
-                for (int dy = -1; dy <= 1; dy++) {
-                    const int yy = cyR + dy, zz = czR + dz;
-                    if (yy < 0 || yy >= ncy || zz < 0 || zz >= ncz) continue;
-                    const uint32_t rowb = (uint32_t)(ncx * (yy + ncy * zz)) * SPH_NSUB; // fine index of the row's first sub-bin
-                    const uint32_t j0 = sd.fine_start[rowb + xa], j1 = sd.fine_start[rowb + xb + 1];
-                    const bool csl_ok = ncs <= WCSL && j1 - j0 < 65536u;
-                    for (uint32_t tb = j0; tb < j1; tb += WCAP) {
-                        const int tn = (int)min((uint32_t)WCAP, j1 - tb);
-                        if (a.dbg && t == 0) atomicAdd(a.dbg + 3, 1ull);
-                        if (csl_ok && tb == j0)
-                            for (int q = t; q < ncs; q += 64) csl[q] = (unsigned short)(sd.fine_start[rowb + xa + q] - j0);
-                        for (int k = t; k < tn + 8; k += 64) {
-                            float vx = 3.0e18f, vy = 3.0e18f, vz = 3.0e18f, vw = 0.f;
-                            if (k < tn) {
-                                const float4 fj = a.fpos[sd.off + tb + k];
-                                vx = fj.x - oxf; vy = fj.y - oyf; vz = fj.z - ozf;
-                                const float hjf = fj.w * 1.000001f + slack;
-                                vw = hjf * hjf;
-                            }
-                            tx[k] = vx; ty[k] = vy; tz[k] = vz;
-                            if (!UH) tw[k] = vw;
-                        }
-                        // the tile is private to this wavefront: its LDS accesses execute in
-                        // program order, the fence only keeps the compiler from reordering them
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        int s0 = 0, len = 0;
-                        if (inseg) {
-                            int lo, hi;
-                            if (csl_ok) { lo = (int)(j0 + csl[mycl] - tb); hi = (int)(j0 + csl[mych] - tb); }
-                            else { lo = (int)(sd.fine_start[rowb + xa + mycl] - tb); hi = (int)(sd.fine_start[rowb + xa + mych] - tb); }
-                            lo = max(lo, 0); hi = min(hi, tn);
-                            s0 = lo & ~1;
-                            len = hi - s0;
-                        }
-                        const int lenc = a.ablate == 7 ? 0 : min(len, AMAXLEN); // 7 (profiling): staging only
-                        // One sign bit per candidate: d = |x_i - x_j|^2 - thr^2 in packed fp32 FMAs,
-                        // shifted into a 32-bit word with v_alignbit (1 VALU per candidate).
-                        uint32_t wd[3] = {0u, 0u, 0u};
-#pragma unroll
-                        for (int gw = 0; gw < 3; gw++) {
-                            if (!__any(32 * gw < lenc)) break; // wave-uniform
-                            uint32_t mm = 0;
-                            int g8 = 0;
-                            for (; g8 < 4 && __any(32 * gw + 8 * g8 < lenc); g8++) {
-                                const float *tb0 = tile + (s0 + 32 * gw + 8 * g8); // one address, constant offsets below
-#pragma unroll
-                                for (int p = 0; p < 4; p++) {
-                                    const f2 X = *reinterpret_cast<const f2 *>(tb0 + 2 * p);
-                                    const f2 Y = *reinterpret_cast<const f2 *>(tb0 + TS + 2 * p);
-                                    const f2 Z = *reinterpret_cast<const f2 *>(tb0 + 2 * TS + 2 * p);
-                                    const f2 ex = fx - X, ey = fy - Y, ez = fz - Z;
-                                    f2 nthr = {-hi2f, -hi2f};
-                                    if (!UH) {
-                                        const f2 W = *reinterpret_cast<const f2 *>(tb0 + 3 * TS + 2 * p);
-                                        nthr.x = -fmaxf(hi2f, W.x); // r2 < hi^2 or r2 < hj^2
-                                        nthr.y = -fmaxf(hi2f, W.y);
-                                    }
-                                    f2 d = __builtin_elementwise_fma(ex, ex, nthr);
-                                    d = __builtin_elementwise_fma(ey, ey, d);
-                                    d = __builtin_elementwise_fma(ez, ez, d);
-                                    mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.x), 31);
-                                    mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.y), 31);
-                                }
-                            }
-                            if (g8 < 4) mm <<= 8 * (4 - g8);
-                            mm = __builtin_bitreverse32(mm); // bit b <-> candidate 32*gw + b
-                            // candidates beyond this lane's range (its own tail / other lanes' longer ranges)
-                            const int rem = lenc - 32 * gw;
-                            wd[gw] = rem >= 32 ? mm : (rem > 0 ? (mm & ((1u << rem) - 1u)) : 0u);
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // tile reads before the next tile's writes
-                        unsigned long long m0 = (unsigned long long)wd[0] | ((unsigned long long)wd[1] << 32);
-                        uint32_t m2 = wd[2];
-                        uint32_t jb0 = sd.off + tb + (uint32_t)s0;
-                        // Hits beyond bit 63 would cost a second slot although a lane's hits in one row
-                        // span less than 64 candidates: shift the 96 bits down to the lane's first hit
-                        // (wide windows only: QuinticSpline / radius_scale 3, where slots run out otherwise)
-                        if (a.norm_masks && __any(m2 != 0)) {
-                            const int sh = m0 ? __builtin_ctzll(m0) : (m2 ? 64 + __builtin_ctz(m2) : 0);
-                            if (sh >= 64) { m0 = (unsigned long long)(m2 >> (sh - 64)); m2 = 0; }
-                            else if (sh > 0) {
-                                m0 = (m0 >> sh) | ((unsigned long long)m2 << (64 - sh));
-                                m2 = sh >= 32 ? 0u : (m2 >> sh);
-                            }
-                            jb0 += (uint32_t)sh;
-                        }
-                        // a lane without room for this tile's slots: the wavefront works its lists off first (rare)
-                        if (__any(cq + (m0 != 0) + (m2 != 0) > WLQ)) { phase2(fl); unsaved = true; }
-                        if (m0) { smask[cq][t] = m0; sjb[cq][t] = jb0; cq++; }
-                        if (m2) { smask[cq][t] = m2; sjb[cq][t] = jb0 + 64u; cq++; }
-                        // rare: a lane's range is longer than AMAXLEN -> exact tail, in place
-                        if (__any(len > AMAXLEN)) {
-                            unsaved = true;
-                            for (int k = AMAXLEN; k < len; k++) do_pair(sd.off + tb + s0 + k, fl);
-                        }
+        for (; st < 9; st++) {
+            // row order (PairArgs::row_mod3)
+            const int st2 = a.row_mod3 == 4 ? (st + (int)(wt % 9u)) % 9 : st;
+            const int sy = st2 % 3 - 1, sz = st2 / 3 - 1;
+            const int dy = (a.row_mod3 & 1) ? (sy + 1 - cyR % 3 + 4) % 3 - 1 : sy;
+            const int dz = (a.row_mod3 & 2) ? (sz + 1 - czR % 3 + 4) % 3 - 1 : sz;
+            const int yy = cyR + dy, zz = czR + dz;
+            if (yy < 0 || yy >= ncy || zz < 0 || zz >= ncz) continue;
+            const uint32_t rowb = (uint32_t)(ncx * (yy + ncy * zz)) * SPH_NSUB; // fine index of the row's first sub-bin
+            const uint32_t j0 = sd.fine_start[rowb + xa], j1 = sd.fine_start[rowb + xb + 1];
+            const bool csl_ok = ncs <= WCSL && j1 - j0 < 65536u;
+            uint32_t tb = j0;
+            int part = 0;
+            if (resumed) { tb = tb_resume; part = part_resume; resumed = false; }
+            const bool csl_now = tb != j0; // re-entry in a later tile of the row: the fine_start slice is staged again
+            for (; tb < j1; tb += WCAP, part = 0) {
+                const int tn = (int)min((uint32_t)WCAP, j1 - tb);
+                if (a.dbg && t == 0) atomicAdd(a.dbg + 3, 1ull);
+                if (csl_ok && (tb == j0 || csl_now))
+                    for (int q = t; q < ncs; q += 64) csl[q] = (unsigned short)(sd.fine_start[rowb + xa + q] - j0);
+                for (int k = t; k < tn + 8; k += 64) {
+                    float vx = 3.0e18f, vy = 3.0e18f, vz = 3.0e18f, vw = 0.f;
+                    if (k < tn) {
+                        const float4 fj = a.fpos[sd.off + tb + k];
+                        vx = fj.x - oxf; vy = fj.y - oyf; vz = fj.z - ozf;
+                        const float hjf = fj.w * 1.000001f + slack;
+                        vw = hjf * hjf;
                     }
+                    tx[k] = vx; ty[k] = vy; tz[k] = vz;
+                    if (!UH) tw[k] = vw;
                 }
+                // the tile is private to this wavefront: its LDS accesses execute in
+                // program order, the fence only keeps the compiler from reordering them
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                int s0 = 0, len = 0;
+                if (inseg) {
+                    int lo, hi;
+                    if (csl_ok) { lo = (int)(j0 + csl[mycl] - tb); hi = (int)(j0 + csl[mych] - tb); }
+                    else { lo = (int)(sd.fine_start[rowb + xa + mycl] - tb); hi = (int)(sd.fine_start[rowb + xa + mych] - tb); }
+                    lo = max(lo, 0); hi = min(hi, tn);
+                    s0 = lo & ~1;
+                    len = hi - s0;
+                }
+                // A lane's range of this tile in parts of AMAXLEN candidates (one part unless the rows are
+                // unusually dense: a second part takes the same path, nothing is evaluated outside phase 2)
+                for (;; part++) {
+                    const int plen = len - AMAXLEN * part;
+                    const int ps0 = plen > 0 ? s0 + AMAXLEN * part : 0; // lanes without candidates in this part read the tile's start
+                    if (part > 0 && !__any(plen > 0)) break;
+                    const int lenc = a.ablate == 7 ? 0 : min(plen, AMAXLEN); // 7 (profiling): staging only
+                    // One sign bit per candidate: d = |x_i - x_j|^2 - thr^2 in packed fp32 FMAs,
+                    // shifted into a 32-bit word with v_alignbit (1 VALU per candidate).
+                    uint32_t wd[3] = {0u, 0u, 0u};
+#pragma unroll
+                    for (int gw = 0; gw < 3; gw++) {
+                        if (!__any(32 * gw < lenc)) break; // wave-uniform
+                        uint32_t mm = 0;
+                        int g8 = 0;
+                        for (; g8 < 4 && __any(32 * gw + 8 * g8 < lenc); g8++) {
+                            const float *tb0 = tile + (ps0 + 32 * gw + 8 * g8); // one address, constant offsets below
+#pragma unroll
+                            for (int p = 0; p < 4; p++) {
+                                const f2 X = *reinterpret_cast<const f2 *>(tb0 + 2 * p);
+                                const f2 Y = *reinterpret_cast<const f2 *>(tb0 + TS + 2 * p);
+                                const f2 Z = *reinterpret_cast<const f2 *>(tb0 + 2 * TS + 2 * p);
+                                const f2 ex = fx - X, ey = fy - Y, ez = fz - Z;
+                                f2 nthr = {-hi2f, -hi2f};
+                                if (!UH) {
+                                    const f2 W = *reinterpret_cast<const f2 *>(tb0 + 3 * TS + 2 * p);
+                                    nthr.x = -fmaxf(hi2f, W.x); // r2 < hi^2 or r2 < hj^2
+                                    nthr.y = -fmaxf(hi2f, W.y);
+                                }
+                                f2 d = __builtin_elementwise_fma(ex, ex, nthr);
+                                d = __builtin_elementwise_fma(ey, ey, d);
+                                d = __builtin_elementwise_fma(ez, ez, d);
+                                mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.x), 31);
+                                mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.y), 31);
+                            }
+                        }
+                        if (g8 < 4) mm <<= 8 * (4 - g8);
+                        mm = __builtin_bitreverse32(mm); // bit b <-> candidate 32*gw + b
+                        // candidates beyond this lane's range (its own tail / other lanes' longer ranges)
+                        const int rem = lenc - 32 * gw;
+                        wd[gw] = rem >= 32 ? mm : (rem > 0 ? (mm & ((1u << rem) - 1u)) : 0u);
+                    }
+                    unsigned long long m0 = (unsigned long long)wd[0] | ((unsigned long long)wd[1] << 32);
+                    uint32_t m2 = wd[2];
+                    uint32_t jb0 = sd.off + tb + (uint32_t)ps0;
+                    // Hits beyond bit 63 would cost a second slot although a lane's hits in one row
+                    // span less than 64 candidates: shift the 96 bits down to the lane's first hit
+                    // (wide windows only: QuinticSpline / radius_scale 3, where slots run out otherwise)
+                    if (a.norm_masks && __any(m2 != 0)) {
+                        const int sh = m0 ? __builtin_ctzll(m0) : (m2 ? 64 + __builtin_ctz(m2) : 0);
+                        if (sh >= 64) { m0 = (unsigned long long)(m2 >> (sh - 64)); m2 = 0; }
+                        else if (sh > 0) {
+                            m0 = (m0 >> sh) | ((unsigned long long)m2 << (64 - sh));
+                            m2 = sh >= 32 ? 0u : (m2 >> sh);
+                        }
+                        jb0 += (uint32_t)sh;
+                    }
+                    // a lane without room for this part's slots: leave, work the lists off, come back here (rare)
+                    if (__any(cq + (m0 != 0) + (m2 != 0) > WLQ)) { more = true; break; }
+                    if (m0) { smask[cq][t] = m0; sjb[cq][t] = jb0; cq++; }
+                    if (m2) { smask[cq][t] = m2; sjb[cq][t] = jb0 + 64u; cq++; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // tile reads before the next tile's writes
+                if (more) { tb_resume = tb; part_resume = part; break; }
+            }
+            if (more) break;
         }
+        if (more) break; // R and st keep their values
     }
     if (a.nl_mode == 1 && s == 0) {
         // keep the lists for the next pass of this evaluation over the same (destination, source)
-        if (unsaved) nlw[t] = NL_NONE;
+        if (unsaved || more) nlw[t] = NL_NONE;
         else {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             nlw[t] = (uint32_t)cq;
@@ -580,6 +605,10 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
         }
     }
     phase2(fl);
+    if (!more) break;
+    unsaved = true;
+    resumed = true;
+    }
     }
     if (active) Fam::finish(D, a, o);
 }

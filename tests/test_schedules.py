@@ -5,7 +5,9 @@
 * ``nl_reuse``  -- the second pair pass of an evaluation (TVF force, elastic
   rates) starts from the hit lists the first pass kept (sph_group.nl_mode);
   off by default: measured 2-6 % slower (DESIGN.md section 4);
-* ``norm_masks`` -- a row's hit bits shifted down to the lane's first hit.
+* ``norm_masks`` -- a row's hit bits shifted down to the lane's first hit;
+* ``row_mod3``  -- the order in which a wavefront visits its 3x3 rows of cells
+  (the sums of a destination are taken in that order: equal to rounding).
 
 Each is compared ON against OFF (to rounding where the arithmetic is regrouped,
 bit for bit where only the schedule differs) and against the oracle, and the
@@ -127,3 +129,29 @@ def test_normalised_masks_are_bit_identical(argv):
         assert np.array_equal(on[k], off[k]), k
 
 
+
+
+@pytest.mark.parametrize('argv', [['--workload', 'taylor_green', '--n1', '48'],
+                                  ['--n1', '64'],
+                                  ['--workload', 'dam_break', '--dx', '0.03'],
+                                  ['--workload', 'elastic', '--rings-dx', '1.6e-3']],
+                         ids=['taylor-green', 'cube', 'dam-break', 'rings'])
+def test_row_order_changes_the_summation_order_only(argv):
+    """every order visits the same 9 rows: identical neighbour counts, results
+    equal to rounding, each within the tolerance of the oracle"""
+    ref, _, r_ref = _run(argv, {'row_mod3': 0})
+    assert r_ref['parity_ok'] and r_ref['parity_neighbour_count_mismatches'] == 0
+    for mode in (1, 2, 3, 4):
+        out, _, res = _run(argv, {'row_mod3': mode})
+        assert res['parity_ok'], (mode, res)
+        assert res['parity_neighbour_count_mismatches'] == 0
+        assert _max_rel(out, ref) < 1e-10, mode
+
+
+def test_row_order_option_is_validated():
+    import torch
+    from pysph_amd import device as dev
+    ctx = dev.HipContext(0, torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(dev.SphError):
+        ctx.set_option('row_mod3', 5)
+    ctx.close()
