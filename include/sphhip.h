@@ -452,8 +452,9 @@ int sph_reduce_min(sph_ctx *ctx, int array_id, int prop, double *out);
  *                    (y mod 3, z mod 3) equals the step, so that all wavefronts in flight walk rows of one
  *                    residue class at a time and find each other's lines in L1 / L2; 1 / 2 = y / z only;
  *                    0 = (dy, dz) order; 4 = (dy, dz) order rotated per tile.  Sums are taken in that order.
- *   profiling only:  "ablate", "count_iters", "dump_counters", "lds_pad",
- *                    "wcsph_nr"                        */
+ *   profiling only:  "lds_pad", "wcsph_nr", and -- in a library built with
+ *                    `make PROFILING=1` only, an error otherwise -- "ablate",
+ *                    "count_iters" / "dump_counters"    */
 int sph_set_option(sph_ctx *ctx, const char *key, long value);
 
 /* ---------------------------------------------------------------------- */

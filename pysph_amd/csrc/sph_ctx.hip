@@ -266,6 +266,12 @@ int sph_set_option(sph_ctx *c, const char *key, long value)
     if (strcmp(key, "pack_group") == 0) { c->pack_group = value ? 1 : 0; c->pack_epoch++; return SPH_OK; }
     if (strcmp(key, "wcsph_nr") == 0) { c->wcsph_nr = value; return SPH_OK; }
     if (strcmp(key, "lds_pad") == 0) { c->lds_pad = value; return SPH_OK; }
+#ifndef SPH_PROFILING
+    if ((strcmp(key, "ablate") == 0 || strcmp(key, "count_iters") == 0) && value != 0) {
+        sph_set_error("option '%s': this libsphhip.so was built without the pair kernel's profiling hooks (make PROFILING=1)", key);
+        return SPH_ERR_ARG;
+    }
+#endif
     if (strcmp(key, "ablate") == 0) { c->ablate = value; return SPH_OK; }
     if (strcmp(key, "count_iters") == 0) {
         c->count_iters = value;

@@ -455,7 +455,7 @@ template <class T> struct FamWCSPHE_T : FamWCSPH_T<T> {
             r.q[0] = p[0]; r.q[1] = p[1];
         }
     }
-    template <class A> static __device__ __forceinline__ void decode(const A &a, const Raw &r, real4<T> &pj, T (&s)[8])
+    template <class A> static __device__ __forceinline__ void decode(const A &a, const Raw &r, uint32_t fl, real4<T> &pj, T (&s)[8])
     {
         T rho;
         if constexpr (sizeof(T) == 8) {
@@ -467,7 +467,8 @@ template <class T> struct FamWCSPHE_T : FamWCSPH_T<T> {
         }
         s[4] = rho;
         s[5] = s[6] = s[7] = T(0.0);
-        if (a.dflags & F_MOM) { // (launch-uniform) a continuity-only destination -- a dam break's walls -- reads neither
+        if (fl & F_MOM) { // the flags of this (destination, source): a compile-time constant in the common case; a
+                          // continuity-only destination -- a dam break's walls -- reads neither
             const T ratio = rho * (T)a.e_rho01;
             const T r2 = ratio * ratio, r3 = r2 * ratio;
             const T r7 = (r2 * r2) * r3;
@@ -477,11 +478,11 @@ template <class T> struct FamWCSPHE_T : FamWCSPH_T<T> {
             s[7] = p;
         }
     }
-    template <class A> static __device__ __forceinline__ void load_fused(const A &a, uint32_t jg, real4<T> &pj, T (&s)[8])
+    template <class A> static __device__ __forceinline__ void load_fused(const A &a, uint32_t jg, uint32_t fl, real4<T> &pj, T (&s)[8])
     {
         Raw r;
         load_raw(a, jg, r);
-        decode(a, r, pj, s);
+        decode(a, r, fl, pj, s);
     }
 };
 

@@ -271,6 +271,16 @@ __device__ __forceinline__ int wave_max_i32(int v)
     return __builtin_amdgcn_readfirstlane(v);
 }
 
+// profiling hooks of the pair kernel (options ablate / count_iters): compiled in only with -DSPH_PROFILING --
+// the two uniform values and their tests cost the phase-2 loop scalar registers it does not have
+#ifdef SPH_PROFILING
+#define ABLATE(a) ((a).ablate)
+#define DBGC(a) ((a).dbg)
+#else
+#define ABLATE(a) 0
+#define DBGC(a) ((unsigned long long *)nullptr)
+#endif
+
 #define AMAXLEN 96 // hit bits kept per row and lane; longer ranges take the slow tail
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -347,7 +357,7 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     typename Fam::Dest D;
     // one record: fp32 records for Real = float (and for record_f32), else fp64
     auto fetch = [&](uint32_t jg, uint32_t flags, real4<T> &pj, T (&sj)[Fam::NA]) {
-        if constexpr (fam_eosf<Fam>::value) Fam::load_fused(a, jg, pj, sj);
+        if constexpr (fam_eosf<Fam>::value) Fam::load_fused(a, jg, flags, pj, sj);
         else if constexpr (F32) load_record_f32<Fam, T>(reinterpret_cast<const float *>(a.rec) + (unsigned long long)jg * NR, pj, sj);
         else load_record<Fam, UH>(a.rec + (unsigned long long)jg * NR, flags, pj, sj);
     };
@@ -368,7 +378,7 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     const T hi_r = (T)a.radius_scale * pi.w;
     const T hi2 = UH ? (T)a.hr2u : hi_r * hi_r;
     const int row_first = __builtin_amdgcn_readfirstlane(row), row_last = __builtin_amdgcn_readlane(row, 63);
-    if (a.dbg && t == 0) atomicAdd(a.dbg + 2, 1ull);
+    if (DBGC(a) && t == 0) atomicAdd(DBGC(a) + 2, 1ull);
 
     // exact criterion + pair arithmetic for one candidate record (branching form)
     auto do_pair = [&](uint32_t jg, uint32_t flags) {
@@ -379,7 +389,7 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
         T hj2 = hi2;
         if (!UH) { hj2 = (T)a.radius_scale * pj.w; hj2 *= hj2; }
         const T r2 = r2_exact<T>(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-        if (((r2 < hi2) || (r2 < hj2)) && a.ablate != 1) Fam::template pair<KK, UH>(D, pi, pj, r2, sj, flags, a);
+        if (((r2 < hi2) || (r2 < hj2)) && ABLATE(a) != 1) Fam::template pair<KK, UH>(D, pi, pj, r2, sj, flags, a);
     };
 
     int cq = 0; // slots this lane holds
@@ -387,17 +397,17 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
         unsigned long long m = 0;
         uint32_t jb = 0;
         int q = 0;
-        if (cq > 0 && a.ablate != 2) { m = smask[0][t]; jb = sjb[0][t]; }
+        if (cq > 0 && ABLATE(a) != 2) { m = smask[0][t]; jb = sjb[0][t]; }
         const uint32_t self = a.d_off + ic;
         if (__any(m != 0)) {
-            if (a.dbg && t == 0) atomicAdd(a.dbg + 1, 1ull);
+            if (DBGC(a) && t == 0) atomicAdd(DBGC(a) + 1, 1ull);
             do {
-                if (a.dbg && t == 0) atomicAdd(a.dbg, 1ull);
+                if (DBGC(a) && t == 0) atomicAdd(DBGC(a), 1ull);
                 const bool has = m != 0;
                 uint32_t j = has ? jb + (uint32_t)__builtin_ctzll(m) : self;
                 m &= m - 1;
                 if (m == 0 && q + 1 < cq) { ++q; m = smask[q][t]; jb = sjb[q][t]; }
-                if (a.ablate == 3) j = self;
+                if (ABLATE(a) == 3) j = self;
                 if constexpr (Fam::PRED) {
                     real4<T> pj;
                     T sj[Fam::NA];
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
                     T hj2 = hi2;
                     if (!UH) { hj2 = (T)a.radius_scale * pj.w; hj2 *= hj2; }
                     const T r2 = r2_exact<T>(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-                    const bool pass = has && ((r2 < hi2) || (r2 < hj2)) && a.ablate != 1;
+                    const bool pass = has && ((r2 < hi2) || (r2 < hj2)) && ABLATE(a) != 1;
                     Fam::template pair<KK, UH>(D, pi, pj, r2, sj, flags, a, pass);
                 } else {
                     if (has) do_pair(j, flags);
@@ -451,7 +461,7 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     bool resumed = false;
     for (;;) {
     bool more = false; // a lane is out of slots: phase 2 now, then back into the loops
-    for (; R <= row_last && !more && !reuse && a.ablate != 6; R++, st = 0) { // reuse: the lists are in LDS already; 6 (profiling): prologue + finish only
+    for (; R <= row_last && !more && !reuse && ABLATE(a) != 6; R++, st = 0) { // reuse: the lists are in LDS already; 6 (profiling): prologue + finish only
         const bool inseg = active && row == R;
         const unsigned long long segm = __ballot(inseg);
         if (!segm) continue;
@@ -494,7 +504,7 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
             const bool csl_now = tb != j0; // re-entry in a later tile of the row: the fine_start slice is staged again
             for (; tb < j1; tb += WCAP, part = 0) {
                 const int tn = (int)min((uint32_t)WCAP, j1 - tb);
-                if (a.dbg && t == 0) atomicAdd(a.dbg + 3, 1ull);
+                if (DBGC(a) && t == 0) atomicAdd(DBGC(a) + 3, 1ull);
                 if (csl_ok && (tb == j0 || csl_now))
                     for (int q = t; q < ncs; q += 64) csl[q] = (unsigned short)(sd.fine_start[rowb + xa + q] - j0);
                 for (int k = t; k < tn + 8; k += 64) {
@@ -526,7 +536,7 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
                     const int plen = len - AMAXLEN * part;
                     const int ps0 = plen > 0 ? s0 + AMAXLEN * part : 0; // lanes without candidates in this part read the tile's start
                     if (part > 0 && !__any(plen > 0)) break;
-                    const int lenc = a.ablate == 7 ? 0 : min(plen, AMAXLEN); // 7 (profiling): staging only
+                    const int lenc = ABLATE(a) == 7 ? 0 : min(plen, AMAXLEN); // 7 (profiling): staging only
                     // One sign bit per candidate: d = |x_i - x_j|^2 - thr^2 in packed fp32 FMAs,
                     // shifted into a 32-bit word with v_alignbit (1 VALU per candidate).
                     uint32_t wd[3] = {0u, 0u, 0u};
