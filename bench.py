@@ -55,7 +55,7 @@ ELEMENTWISE_FLOOR = 1e-6     # element-wise parity: |b_i| floored at this fracti
 # ---------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------
-def make_cube(n1, x_offset=0.0, seed=1234, hdx=1.3, nx=None, vary_h=0.0, gid0=0):
+def make_cube(n1, x_offset=0.0, seed=1234, hdx=1.3, nx=None, vary_h=0.0, gid0=0, vary_m=0.0):
     """S-cube of SURVEY.md 8(d): jittered lattice, random velocities (so the
     artificial-viscosity branch is taken for about half of the pairs)."""
     from pysph_amd.particle_array import get_particle_array_wcsph
@@ -79,6 +79,8 @@ def make_cube(n1, x_offset=0.0, seed=1234, hdx=1.3, nx=None, vary_h=0.0, gid0=0)
         w=0.1 * db.c0 * rng.uniform(-1, 1, n))
     if vary_h:
         pa.h[:] = h * (1.0 + vary_h * rng.uniform(-1, 1, n))
+    if vary_m:
+        pa.m[:] = pa.m * (1.0 + vary_m * np.random.default_rng(seed + 7).uniform(-1, 1, n))
     pa.gid[:] = np.arange(gid0, gid0 + n, dtype=pa.gid.dtype)
     return pa, dx
 
@@ -209,7 +211,7 @@ def build_workload(args, rank, world):
     if args.workload == 'cube':
         hdx = args.hdx or (1.5 if args.params == 'cube' else 1.3)
         pa, dx = make_cube(n1, x_offset=float(rank), seed=1234 + rank, hdx=hdx,
-                           vary_h=args.vary_h, gid0=rank * n1 ** 3)
+                           vary_h=args.vary_h, gid0=rank * n1 ** 3, vary_m=args.vary_m)
         w.arrays = [pa]
         w.eqs = cube_equations(dx, hdx=hdx, params=args.params)
         w.kernel = K.CubicSpline(dim=3) if args.params == 'cube' else K.WendlandQuintic(dim=3)
@@ -520,6 +522,8 @@ def parse_args(argv=None):
     ap.add_argument('--params', default='db', choices=['db', 'cube'],
                     help='cube workload: dam_break_3d.py or cube.py parameter set')
     ap.add_argument('--hdx', type=float, default=0.0)
+    ap.add_argument('--vary-m', type=float, default=0.0, dest='vary_m',
+                    help='cube workload: m = m0 (1 +- vary_m U(-1,1)) (no uniform-mass records)')
     ap.add_argument('--vary-h', type=float, default=0.0, dest='vary_h',
                     help='cube workload: h = h0 (1 +- vary_h U(-1,1))')
     ap.add_argument('--dx', type=float, default=0.0087, help='dam_break spacing')

@@ -446,6 +446,12 @@ int sph_reduce_min(sph_ctx *ctx, int array_id, int prop, double *out);
  *                    group instead of once per destination that reads them.
  *                    Nothing else may modify the arrays in between.
  *   "eos_fuse"       0: ignore sph_group.src_eos (default 1)
+ *   "mass_fuse"      0: EOS-fused records always carry the mass (default 1: when every array read by a
+ *                    launch had ONE mass at the last sph_nnps_update -- the reduction that finds the
+ *                    bounds also looks at m once an evaluation could have used it, i.e. from the second
+ *                    step on -- the slot carries p / rho^2 and the mass is a constant of
+ *                    the source array; a later sph_array_push of m, or an update that skips the
+ *                    reduction (bounds + sph_nnps_set_h_range), falls back to the mass-carrying records)
  *   "nl_reuse"       1: honour sph_group.nl_mode (default 0: measured slower)
  *   "norm_masks"     0: hit masks are not shifted down to a lane's first hit (default 1)
  *   "row_mod3"       order in which a wavefront visits its 3x3 rows of cells: 3 (default) = the row whose
@@ -468,8 +474,9 @@ int sph_timer_reset(sph_ctx *ctx);
  * equation family: "pair_wcsph", "pair_density", "pair_tvf", "pair_vgrad",
  * "pair_elastic"; out: total ms and launches.  Launch counters (ms = 0, counted
  * whether or not timing is enabled): "n_eos_fused" (pair launches on the 64-byte
- * EOS-fused records), "n_nl_keep" / "n_nl_reuse" (launches that kept / started
- * from kept neighbour lists). */
+ * EOS-fused records), "n_mass_fused" (of those, on uniform-mass records),
+ * "n_nl_keep" / "n_nl_reuse" (launches that kept / started from kept neighbour
+ * lists). */
 int sph_timer_get(sph_ctx *ctx, const char *key, double *ms, long *count);
 
 #ifdef __cplusplus

@@ -220,6 +220,7 @@ int sph_array_push(sph_ctx *c, int id, int prop, const double *host, size_t offs
     // only after a sync; keep the call synchronous so Python may reuse `host`.
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (prop == SPH_X || prop == SPH_Y || prop == SPH_Z || prop == SPH_H) c->nnps_valid = false;
+    if (prop == SPH_M) A.m_known = false; // until the next sph_nnps_update has looked at the masses
     return SPH_OK;
 }
 
@@ -287,6 +288,7 @@ int sph_set_option(sph_ctx *c, const char *key, long value)
     if (strcmp(key, "const_flags") == 0) { c->const_flags = value; return SPH_OK; }
     if (strcmp(key, "invalidate_nnps") == 0) { c->nnps_valid = false; return SPH_OK; }
     if (strcmp(key, "eos_fuse") == 0) { c->eos_fuse = value; return SPH_OK; }
+    if (strcmp(key, "mass_fuse") == 0) { c->mass_fuse = value; return SPH_OK; }
     if (strcmp(key, "nl_reuse") == 0) { c->nl_reuse = value; c->nl.valid = false; return SPH_OK; }
     if (strcmp(key, "norm_masks") == 0) { c->norm_masks = value; return SPH_OK; }
     sph_set_error("sph_set_option: unknown key '%s'", key);
@@ -321,7 +323,7 @@ int sph_timer_get(sph_ctx *c, const char *key, double *ms, long *count)
 {
     static const char *names[T_COUNT] = {"nnps", "pack", "eos", "pair", "stage",
                                          "pair_none", "pair_wcsph", "pair_density", "pair_tvf", "pair_vgrad", "pair_elastic",
-                                         "n_eos_fused", "n_nl_keep", "n_nl_reuse"};
+                                         "n_eos_fused", "n_nl_keep", "n_nl_reuse", "n_mass_fused"};
     SPH_TRY(timer_drain(c));
     for (int i = 0; i < T_COUNT; i++)
         if (strcmp(key, names[i]) == 0) {

@@ -210,6 +210,7 @@ struct PackArgs {
                                   // 6: WCSPH, p and cs recomputed by the pair kernel [x y | z u | v w | rho m] (64 B);
                                   // 7: the same in fp32 [x-x0 y-y0 z-z0 u | v w rho m] (32 B)
                                   // (1, 2: aggregated kernel only)
+    int umass;                    // layouts 6 / 7: the last slot carries p / rho^2 (derived 1) instead of m
     float4 *fpos;                 // non-null: fp32 {x-xmin, y-ymin, z-zmin, radius_scale*h} for the prefilter tiles
     int lds_np;                   // 16-B pieces per record when the launch carries 256 * lds_np * 16 B of LDS, else 0
     double gmin[3];
@@ -278,12 +279,12 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
         int np;
         if (a.layout == 6) { // WCSPH with the EOS fused into the pair kernel: one 64-B half line per record
             pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, v[0]);
-            pc[2] = make_double2(v[1], v[2]); pc[3] = make_double2(v[4], v[3]);
+            pc[2] = make_double2(v[1], v[2]); pc[3] = make_double2(v[4], a.umass ? v[5] : v[3]); // [rho m], uniform mass: [rho p/rho^2]
             np = 4;
         } else if (a.layout == 7) {
             pc[0] = __builtin_bit_cast(double2, make_float4((float)(ph.x - a.gmin[0]), (float)(ph.y - a.gmin[1]),
                                                             (float)(ph.z - a.gmin[2]), (float)v[0]));
-            pc[1] = __builtin_bit_cast(double2, make_float4((float)v[1], (float)v[2], (float)v[4], (float)v[3]));
+            pc[1] = __builtin_bit_cast(double2, make_float4((float)v[1], (float)v[2], (float)v[4], (float)(a.umass ? v[5] : v[3])));
             np = 2;
         } else if (a.layout == 1) { // WCSPH [x y | z cs | u v | w m | rho tmpj] (+ [h p]: variable h / tensile correction)
             pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, v[6]);
@@ -438,8 +439,12 @@ typedef FamWCSPH_T<double> FamWCSPH;
 // and are recomputed per gathered record -- four 16-B pieces in ONE 64-B half line instead of five pieces
 // that straddle a 128-B line half of the time.  ~14 more VALU operations per pair, hidden under the gathers.
 // Arithmetic as k_nosrc's (TaitEOS, gamma = 7) and k_pack's p / rho^2.
-template <class T> struct FamWCSPHE_T : FamWCSPH_T<T> {
+// UM (uniform-mass records): every particle of a source array has the same mass (seen by the last sph_nnps_update),
+// so the record's eighth slot carries p / rho^2 as k_pack computes it for the 80-byte records and m is a constant of
+// the source: of the EOS only cs = c0 (rho/rho0)^3 is left in the loop (13 of its 17 instructions go).
+template <class T, bool UM = false> struct FamWCSPHE_T : FamWCSPH_T<T> {
     static constexpr bool EOSF = true;
+    static constexpr bool UMASS = UM;
     static constexpr int NR = 8;
     // one gathered record as it arrives (four / two 16-B pieces), and its decoding
     struct Raw {
@@ -455,7 +460,7 @@ template <class T> struct FamWCSPHE_T : FamWCSPH_T<T> {
             r.q[0] = p[0]; r.q[1] = p[1];
         }
     }
-    template <class A> static __device__ __forceinline__ void decode(const A &a, const Raw &r, uint32_t fl, real4<T> &pj, T (&s)[8])
+    template <class A> static __device__ __forceinline__ void decode(const A &a, const Raw &r, uint32_t fl, T mu, real4<T> &pj, T (&s)[8])
     {
         T rho;
         if constexpr (sizeof(T) == 8) {
@@ -467,6 +472,15 @@ template <class T> struct FamWCSPHE_T : FamWCSPH_T<T> {
         }
         s[4] = rho;
         s[5] = s[6] = s[7] = T(0.0);
+        if constexpr (UM) {
+            const T q = s[3]; // p / rho^2
+            s[3] = mu;
+            if (fl & F_MOM) {
+                const T ratio = rho * (T)a.e_rho01;
+                s[5] = q;
+                s[6] = (T)a.e_c0 * ((ratio * ratio) * ratio);
+            }
+        } else
         if (fl & F_MOM) { // the flags of this (destination, source): a compile-time constant in the common case; a
                           // continuity-only destination -- a dam break's walls -- reads neither
             const T ratio = rho * (T)a.e_rho01;
@@ -478,11 +492,11 @@ template <class T> struct FamWCSPHE_T : FamWCSPH_T<T> {
             s[7] = p;
         }
     }
-    template <class A> static __device__ __forceinline__ void load_fused(const A &a, uint32_t jg, uint32_t fl, real4<T> &pj, T (&s)[8])
+    template <class A> static __device__ __forceinline__ void load_fused(const A &a, uint32_t jg, uint32_t fl, T mu, real4<T> &pj, T (&s)[8])
     {
         Raw r;
         load_raw(a, jg, r);
-        decode(a, r, fl, pj, s);
+        decode(a, r, fl, mu, pj, s);
     }
 };
 
@@ -1092,11 +1106,17 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
     pa.layout = (c->pair_variant >= 3 && fam == FAM_WCSPH) ? 1 : (c->pair_variant >= 3 && (fam == FAM_DENSITY || fam == FAM_NBR) && pl.nr == 4) ? 2
               : (c->pair_variant >= 3 && fam == FAM_TVF && (pl.nr == 14 || pl.nr == 12)) ? 3 : 0;
     if (c->pair_variant >= 3 && (c->record_f32 || c->arith_f32)) pa.layout = 5;
+    pa.umass = 0;
     if (c->cur_eosf) {
         // p, cs (and p / rho^2) are recomputed by the pair kernel: not read here
         pa.layout = c->arith_f32 ? 7 : 6;
-        pa.src[5] = pa.src[6] = pa.src[7] = nullptr;
-        pa.derived = 0;
+        pa.src[5] = pa.src[6] = nullptr;
+        if (c->cur_umass) { // ... except p / rho^2, which takes the place of the (uniform) mass: derived 1 reads p
+            pa.umass = 1;
+        } else {
+            pa.src[7] = nullptr;
+            pa.derived = 0;
+        }
     }
     pa.lds_np = pack_pieces(pa);
     if (launch) hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), (size_t)pa.lds_np * 256 * 16, c->stream, pa);
@@ -1231,6 +1251,7 @@ int nnps_csr_pair_kernel(sph_ctx *c, int src, int dst, uint32_t *count, const ui
     const bool was_f32 = c->record_f32 != 0, was_a32 = c->arith_f32 != 0; // lists are exact: fp64 records always
     c->record_f32 = 0; c->arith_f32 = 0;
     c->cur_eosf = false;
+    c->cur_umass = false;
     c->cur_nrec = pl.nr;
     int rc = c->posh.reserve((total + 64) * sizeof(double) * pl.nr);
     if (rc == SPH_OK) rc = c->aux.reserve(64);
@@ -1379,6 +1400,15 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
                           c->use_uniform_h && !(dflags & F_TENSILE) && g->eos_par[2] == 7.0 &&
                           g->eos_par[0] > 0.0 && !c->record_f32 && !c->wcsph_nr;
         if (eosf) pl.nr = 8; // doubles, or floats with arith_f32
+        // ... and when every array read here had ONE mass at the last neighbour update, the record's mass slot
+        // carries p / rho^2 and most of the per-record EOS goes as well (FamWCSPHE_T<T, true>)
+        // (only with the equation flags as a compile-time constant: the run-time-flag kernel of a dam break's three
+        // sources is at its scalar-register limit and 1-3 % slower with a mass per source)
+        bool umass = eosf && c->mass_fuse && c->const_flags;
+        for (int j = 0; j < nsrcs && umass; j++) umass = sflags[j] == FamWCSPH::CF0;
+        if (umass) c->want_mrange = true; // the reduction of the neighbour updates from now on includes m (8 B per particle)
+        for (int j = 0; j < nsrcs && umass; j++) umass = c->arr[srcs[j]].m_known;
+        c->cur_umass = umass;
         c->cur_eosf = eosf;
         c->cur_nrec = pl.nr;
         const void *rec_was = c->posh.ptr, *fpos_was = c->fposb.ptr;
@@ -1390,7 +1420,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         {
             ScopedTimer tm(c, T_PACK);
             // a source must hold what ITS equations read; the destination's own record what all of them read
-            const int sig = pl.nr * 8 + (c->record_f32 ? 1 : 0) + (c->arith_f32 ? 2 : 0) + (eosf ? 4 : 0);
+            const int sig = pl.nr * 16 + (c->record_f32 ? 1 : 0) + (c->arith_f32 ? 2 : 0) + (eosf ? 4 : 0) + (umass ? 8 : 0);
             // The shared slots live in the same buffers every other unit packs into from offset 0:
             // a unit that does not share (another family, a single-destination call), or one whose
             // record layout differs from what the cache holds, overwrites them -- nothing cached survives.
@@ -1434,13 +1464,14 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         ScopedTimer tm(c, T_PAIR);
         ScopedTimer tmf(c, T_PAIR_FAM + fam);
         if (eosf) c->timers[T_N_EOSF].count++;
+        if (umass) c->timers[T_N_UMASS].count++;
         if (nl_mode == 1) c->timers[T_N_NLKEEP].count++;
         if (nl_mode == 2) c->timers[T_N_NLREUSE].count++;
         // the part of the launch arguments every family shares
         auto common = [&](auto &a) {
             fill_common(c, a, K, t);
             a.nsrc = nsrcs;
-            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j], c->arr[srcs[j]].fine_start.as<uint32_t>()};
+            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j], c->arr[srcs[j]].fine_start.as<uint32_t>(), c->arr[srcs[j]].m_value};
             a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
             a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
             set_tile_order(c, a, D);
@@ -1539,7 +1570,8 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             return launch_pair<F>(c, K->kind, a);
         };
         const bool f32 = c->arith_f32 != 0;
-        if (fam == FAM_WCSPH && eosf) SPH_TRY(f32 ? run_wcsph(FamWCSPHE_T<float>()) : run_wcsph(FamWCSPHE_T<double>()));
+        if (fam == FAM_WCSPH && eosf && umass) SPH_TRY(f32 ? run_wcsph(FamWCSPHE_T<float, true>()) : run_wcsph(FamWCSPHE_T<double, true>()));
+        else if (fam == FAM_WCSPH && eosf) SPH_TRY(f32 ? run_wcsph(FamWCSPHE_T<float>()) : run_wcsph(FamWCSPHE_T<double>()));
         else if (fam == FAM_WCSPH) SPH_TRY(f32 ? run_wcsph(FamWCSPH_T<float>()) : run_wcsph(FamWCSPH()));
         else if (fam == FAM_DENSITY) SPH_TRY(f32 ? run_density(FamDensity_T<float>()) : run_density(FamDensity()));
         else if (fam == FAM_VGRAD) SPH_TRY(f32 ? run_vgrad(FamVGrad_T<float>()) : run_vgrad(FamVGrad()));

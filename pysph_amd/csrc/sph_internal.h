@@ -52,6 +52,8 @@ struct DevArray {
     size_t n_tiles = 0;
     int tile_grid[4] = {0, 0, 0, 0};     // grid (ncx, ncy, ncz, block rows) the tile order was built for
     int tile_age = 0;                    // updates since the tile order was built
+    bool m_known = false;                // every particle had the same mass at the last sph_nnps_update that looked
+    double m_value = 0.0;                // ... this one (a push of m, or an update that skips the reduction, forgets it)
     int nnps_slot = -1;                  // position in the last sph_nnps_update list
     size_t perm_n = 0;                   // particles `perm` was built for (0: none / already applied)
 };
@@ -65,7 +67,7 @@ struct HaloState {
 
 // T_PAIR: every pair launch; T_PAIR_FAM + family (sph_eval.hip enum Family): the same launches per equation family
 // T_N_*: launch counters only (no time): pair launches on EOS-fused records, launches that kept / reused neighbour lists
-enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_STAGE, T_PAIR_FAM, T_N_EOSF = T_PAIR_FAM + 6, T_N_NLKEEP, T_N_NLREUSE, T_COUNT };
+enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_STAGE, T_PAIR_FAM, T_N_EOSF = T_PAIR_FAM + 6, T_N_NLKEEP, T_N_NLREUSE, T_N_UMASS, T_COUNT };
 
 struct Timer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -122,6 +124,9 @@ struct sph_ctx {
     long lds_pad = 0;       // profiling: extra dynamic LDS per pair-kernel workgroup (limits wavefronts per CU)
     int cur_nrec = 0;       // doubles per packed record of the pair launch being set up
     bool cur_eosf = false;  // the pair launch being set up reads the 64-byte WCSPH records (EOS recomputed per record)
+    bool cur_umass = false; // ... with p / rho^2 in the mass slot (every source array has one mass)
+    long mass_fuse = 1;     // allow that
+    bool want_mrange = false; // an evaluation could have used uniform-mass records: the next neighbour updates look at the masses
     long block_sorted_outputs = 0;
     long eos_fuse = 1;      // honour sph_group.src_eos (64-byte WCSPH records, p and cs recomputed from rho)
     long nl_reuse = 0;      // honour sph_group.nl_mode (neighbour lists kept between the pair passes of one evaluation): built,

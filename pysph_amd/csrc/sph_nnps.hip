@@ -34,13 +34,14 @@ __device__ inline double wave_max(double v)
     return v;
 }
 
-// part[block][8] = {xmin ymin zmin hmin xmax ymax zmax hmax}
+// part[block][8] = {xmin ymin zmin hmin xmax ymax zmax hmax}; partm[block][2] = {mmin mmax} of this array (m may be null)
 __global__ __launch_bounds__(256) void k_minmax(const double *__restrict__ x, const double *__restrict__ y,
                                                 const double *__restrict__ z, const double *__restrict__ h,
-                                                size_t n, double *__restrict__ part)
+                                                const double *__restrict__ m, size_t n, double *__restrict__ part,
+                                                double *__restrict__ partm)
 {
-    double mn[4] = {DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX};
-    double mx[4] = {-DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX};
+    double mn[5] = {DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX};
+    double mx[5] = {-DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX};
     const double *p[4] = {x, y, z, h};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
 #pragma unroll
@@ -49,25 +50,45 @@ __global__ __launch_bounds__(256) void k_minmax(const double *__restrict__ x, co
             mn[k] = fmin(mn[k], v);
             mx[k] = fmax(mx[k], v);
         }
+        if (m) { const double v = m[i]; mn[4] = fmin(mn[4], v); mx[4] = fmax(mx[4], v); }
     }
-    __shared__ double s[4][8];
+    __shared__ double s[4][10];
     int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < 5; k++) {
         double a = wave_min(mn[k]), b = wave_max(mx[k]);
-        if (lane == 0) { s[wv][k] = a; s[wv][4 + k] = b; }
+        if (lane == 0) {
+            if (k < 4) { s[wv][k] = a; s[wv][4 + k] = b; }
+            else { s[wv][8] = a; s[wv][9] = b; }
+        }
     }
     __syncthreads();
-    if (threadIdx.x < 8) {
+    if (threadIdx.x < 10) {
         int k = threadIdx.x;
+        const bool is_min = k < 4 || k == 8;
         double v = s[0][k];
-        for (int w = 1; w < 4; w++) v = (k < 4) ? fmin(v, s[w][k]) : fmax(v, s[w][k]);
-        part[(size_t)blockIdx.x * 8 + k] = v;
+        for (int w = 1; w < 4; w++) v = is_min ? fmin(v, s[w][k]) : fmax(v, s[w][k]);
+        if (k < 8) part[(size_t)blockIdx.x * 8 + k] = v;
+        else partm[(size_t)blockIdx.x * 2 + (k - 8)] = v;
     }
 }
 
-__global__ __launch_bounds__(512) void k_minmax_final(const double *__restrict__ part, int nblocks, double *__restrict__ out)
+struct BlockRanges { int first[SPH_MAX_ARRAYS + 1]; int narrays; }; // blocks [first[a], first[a+1]) belong to array a
+
+__global__ __launch_bounds__(512) void k_minmax_final(const double *__restrict__ part, int nblocks, double *__restrict__ out,
+                                                      const double *__restrict__ partm, BlockRanges br)
 {
+    static_assert(SPH_MAX_ARRAYS <= 8, "one wavefront of this block per array");
+    // the mass range of every array: wavefront a over the partials of array a -> out[8 + 2 a] = {mmin, mmax}
+    {
+        const int a = threadIdx.x >> 6, l = threadIdx.x & 63;
+        if (a < br.narrays) {
+            double lo = DBL_MAX, hi = -DBL_MAX;
+            for (int b = br.first[a] + l; b < br.first[a + 1]; b += 64) { lo = fmin(lo, partm[2 * b]); hi = fmax(hi, partm[2 * b + 1]); }
+            lo = wave_min(lo); hi = wave_max(hi);
+            if (l == 0) { out[8 + 2 * a] = lo; out[8 + 2 * a + 1] = hi; }
+        }
+    }
     // 64 groups of 8 lanes stride over the partials (the single-wavefront
     // version spent 35-70 us on a chain of dependent loads)
     __shared__ double s[64][8];
@@ -88,11 +109,18 @@ __global__ __launch_bounds__(512) void k_minmax_final(const double *__restrict__
 int nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *out8)
 {
     const int BLOCKS = 1024;
-    SPH_TRY(c->red_part.reserve((size_t)narrays * BLOCKS * 8 * sizeof(double)));
-    SPH_TRY(c->red_out.reserve(8 * sizeof(double)));
+    // partials: [narrays * BLOCKS][8] position / h, then [narrays * BLOCKS][2] mass; results: 8 + 2 per array
+    SPH_TRY(c->red_part.reserve((size_t)narrays * BLOCKS * 10 * sizeof(double)));
+    SPH_TRY(c->red_out.reserve((8 + 2 * SPH_MAX_ARRAYS) * sizeof(double)));
+    double *const partm = c->red_part.as<double>() + (size_t)narrays * BLOCKS * 8;
+    BlockRanges br;
+    int *const first = br.first;
+    br.narrays = narrays;
     int nb_total = 0;
     for (int a = 0; a < narrays; a++) {
         DevArray &A = c->arr[ids[a]];
+        first[a] = nb_total;
+        A.m_known = false;
         if (A.n == 0) continue;
         for (int p : {SPH_X, SPH_Y, SPH_Z, SPH_H})
             if (!A.prop[p]) {
@@ -101,18 +129,27 @@ int nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *out8)
             }
         int nb = (int)std::min<size_t>(BLOCKS, (A.n + 255) / 256);
         hipLaunchKernelGGL(k_minmax, dim3(nb), dim3(256), 0, c->stream, A.prop[SPH_X], A.prop[SPH_Y],
-                           A.prop[SPH_Z], A.prop[SPH_H], A.n, c->red_part.as<double>() + (size_t)nb_total * 8);
+                           A.prop[SPH_Z], A.prop[SPH_H], c->want_mrange ? (const double *)A.prop[SPH_M] : (const double *)nullptr, A.n,
+                           c->red_part.as<double>() + (size_t)nb_total * 8, partm + (size_t)nb_total * 2);
         nb_total += nb;
     }
+    first[narrays] = nb_total;
     if (nb_total == 0) {
         for (int k = 0; k < 4; k++) { out8[k] = DBL_MAX; out8[4 + k] = -DBL_MAX; }
         return SPH_OK;
     }
+    // the mass range of every array rides on the same kernel and round trip (uniform-mass records of the WCSPH pair kernel)
     hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(512), 0, c->stream, c->red_part.as<double>(), nb_total,
-                       c->red_out.as<double>());
-    HIP_TRY(hipMemcpyAsync(c->pinned, c->red_out.ptr, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                       c->red_out.as<double>(), partm, br);
+    HIP_TRY(hipMemcpyAsync(c->pinned, c->red_out.ptr, (8 + 2 * narrays) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(out8, c->pinned, 8 * sizeof(double));
+    for (int a = 0; a < narrays; a++) {
+        DevArray &A = c->arr[ids[a]];
+        const double lo = c->pinned[8 + 2 * a], hi = c->pinned[8 + 2 * a + 1];
+        A.m_known = c->want_mrange && A.n > 0 && A.prop[SPH_M] && lo == hi;
+        A.m_value = lo;
+    }
     return SPH_OK;
 }
 

@@ -54,6 +54,7 @@ struct SrcDesc {
     uint32_t off;    // offset of this source's segment in the packed buffers
     uint32_t flags;  // equations acting for this (dest, source) pair
     const uint32_t *fine_start; // first sorted position per x sub-bin (SPH_NSUB per cell)
+    double mu;       // the one mass of this source's particles (families with uniform-mass records, Fam::UMASS)
 };
 
 template <class Fam> struct PairArgs {
@@ -355,9 +356,10 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     const bool active = valid && o >= a.d_start && o < a.d_stop;
     real4<T> pi;
     typename Fam::Dest D;
+    T cur_mu = T(0.0); // mass of the source being read (uniform-mass records)
     // one record: fp32 records for Real = float (and for record_f32), else fp64
     auto fetch = [&](uint32_t jg, uint32_t flags, real4<T> &pj, T (&sj)[Fam::NA]) {
-        if constexpr (fam_eosf<Fam>::value) Fam::load_fused(a, jg, flags, pj, sj);
+        if constexpr (fam_eosf<Fam>::value) Fam::load_fused(a, jg, flags, cur_mu, pj, sj);
         else if constexpr (F32) load_record_f32<Fam, T>(reinterpret_cast<const float *>(a.rec) + (unsigned long long)jg * NR, pj, sj);
         else load_record<Fam, UH>(a.rec + (unsigned long long)jg * NR, flags, pj, sj);
     };
@@ -456,6 +458,7 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     for (int s = 0; s < a.nsrc; s++) {
     const SrcDesc sd = a.src[s];
     const uint32_t fl = CF ? CF : sd.flags;
+    cur_mu = (T)sd.mu;
     int R = row_first, st = 0, part_resume = 0; // position in phase 1 (wave-uniform)
     uint32_t tb_resume = 0;
     bool resumed = false;

@@ -6,6 +6,8 @@
   rates) starts from the hit lists the first pass kept (sph_group.nl_mode);
   off by default: measured 2-6 % slower (DESIGN.md section 4);
 * ``norm_masks`` -- a row's hit bits shifted down to the lane's first hit;
+* ``mass_fuse`` -- EOS-fused records whose mass slot carries p / rho^2 when every
+  source array has ONE mass (seen by the neighbour update's reduction);
 * ``row_mod3``  -- the order in which a wavefront visits its 3x3 rows of cells
   (the sums of a destination are taken in that order: equal to rounding).
 
@@ -49,7 +51,7 @@ def _run(argv, opts, steps=2):
         for f in w.fields:
             if f in pa.properties:
                 out[pa.name + '.' + f] = np.array(pa.get(f)[:nreal])
-    cnt = {k: ctx.timer_get(k)[1] for k in ('n_eos_fused', 'n_nl_keep', 'n_nl_reuse')}
+    cnt = {k: ctx.timer_get(k)[1] for k in ('n_eos_fused', 'n_nl_keep', 'n_nl_reuse', 'n_mass_fused')}
     res = bench.parity_check(w, host_in, nnps, domain,
                              bench.PARITY_TOL if args.dtype == 'f64' else 5e-5)
     del nnps, a_eval, step
@@ -157,4 +159,65 @@ def test_row_order_option_is_validated():
     ctx = dev.HipContext(0, torch.cuda.current_stream().cuda_stream)
     with pytest.raises(dev.SphError):
         ctx.set_option('row_mod3', 5)
+    ctx.close()
+
+
+@pytest.mark.parametrize('argv', [['--n1', '64'], ['--n1', '64', '--no-reorder'], ['--n1', '64', '--dtype', 'f32'],
+                                  ['--params', 'cube', '--n1', '48']],
+                         ids=['cube', 'cube-unsorted', 'cube-fp32', 'cube.py'])
+def test_uniform_mass_records_match_mass_carrying_records(argv):
+    on, c_on, r_on = _run(argv, {})
+    off, c_off, r_off = _run(argv, {'mass_fuse': 0})
+    assert 0 < c_on['n_mass_fused'] < c_on['n_eos_fused']   # from the second neighbour update on
+    assert c_off['n_mass_fused'] == 0 and c_off['n_eos_fused'] > 0
+    tol = 5e-5 if '--dtype' in argv else bench_tol()
+    assert r_on['parity_max_rel'] < tol and r_off['parity_max_rel'] < tol, (r_on, r_off)
+    assert r_on['parity_neighbour_count_mismatches'] == 0
+    assert _max_rel(on, off) < (1e-5 if '--dtype' in argv else 1e-13)
+
+
+def bench_tol():
+    import bench
+    return bench.PARITY_TOL
+
+
+@pytest.mark.parametrize('argv', [['--n1', '48', '--vary-m', '0.2'], ['--workload', 'dam_break', '--dx', '0.03']],
+                         ids=['masses-differ', 'run-time-flags'])
+def test_records_keep_the_mass_when_masses_differ_or_flags_are_not_constant(argv):
+    out, cnt, res = _run(argv, {})
+    assert cnt['n_eos_fused'] > 0 and cnt['n_mass_fused'] == 0 and res['parity_ok'], (cnt, res)
+    assert res['parity_neighbour_count_mismatches'] == 0
+
+
+def test_a_push_of_the_masses_forgets_their_uniformity():
+    """the reduction of the next neighbour update looks again; until then the
+    records carry the mass"""
+    import torch
+    import bench
+    from pysph_amd import device as dev
+    args = bench.parse_args(['--n1', '32', '--no-cpu-baseline', '--no-extras'])
+    ctx = dev.HipContext(0, torch.cuda.current_stream().cuda_stream)
+    w = bench.build_workload(args, 0, 1)
+    nnps, a_eval, halo, domain, step, ordered = bench.setup(args, w, 0, 1, None, ctx)
+    step()
+    step()
+    n1 = ctx.timer_get('n_mass_fused')[1]
+    assert n1 > 0
+    pa = w.arrays[0]
+    pa.gpu.pull('m')
+    m = np.array(pa.m)
+    m[::2] *= 1.5
+    pa.m[:] = m
+    pa.gpu.push('m')                       # not uniform any more, and no neighbour update since
+    a_eval.compute(0.0, 1e-5)
+    assert ctx.timer_get('n_mass_fused')[1] == n1
+    host_in = None
+    for a in w.arrays:
+        a.gpu.pull()
+    host_in = bench.copy_arrays(w.arrays)
+    step()                                 # the update's reduction sees two masses
+    assert ctx.timer_get('n_mass_fused')[1] == n1
+    res = bench.parity_check(w, host_in, nnps, domain, bench.PARITY_TOL)
+    assert res['parity_ok'], res
+    del nnps, a_eval, step
     ctx.close()
