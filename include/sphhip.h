@@ -451,7 +451,9 @@ int sph_reduce_min(sph_ctx *ctx, int array_id, int prop, double *out);
  *                    bounds also looks at m once an evaluation could have used it, i.e. from the second
  *                    step on -- the slot carries p / rho^2 and the mass is a constant of
  *                    the source array; a later sph_array_push of m, or an update that skips the
- *                    reduction (bounds + sph_nnps_set_h_range), falls back to the mass-carrying records)
+ *                    reduction (bounds + sph_nnps_set_h_range), falls back to the mass-carrying records;
+ *                    masses written through sph_array_device_ptr, or by a generated equation, AFTER the
+ *                    last update are seen by the next one -- as a changed h is by the uniform-h path)
  *   "nl_reuse"       1: honour sph_group.nl_mode (default 0: measured slower)
  *   "norm_masks"     0: hit masks are not shifted down to a lane's first hit (default 1)
  *   "row_mod3"       order in which a wavefront visits its 3x3 rows of cells: 3 (default) = the row whose

@@ -334,6 +334,7 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
             DevArray &A = c->arr[ids[a]];
             for (int p : {SPH_X, SPH_Y, SPH_Z, SPH_H})
                 if (A.n && !A.prop[p]) { sph_set_error("nnps: array %d has no device copy of x/y/z/h", ids[a]); return SPH_ERR_MISSING_PROP; }
+            A.m_known = false; // nobody looked at the masses (ghosts may have been appended since the last look)
         }
     } else {
         SPH_TRY(nnps_minmax(c, narrays, ids, mm));

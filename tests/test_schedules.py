@@ -181,8 +181,9 @@ def bench_tol():
     return bench.PARITY_TOL
 
 
-@pytest.mark.parametrize('argv', [['--n1', '48', '--vary-m', '0.2'], ['--workload', 'dam_break', '--dx', '0.03']],
-                         ids=['masses-differ', 'run-time-flags'])
+@pytest.mark.parametrize('argv', [['--n1', '48', '--vary-m', '0.2'], ['--workload', 'dam_break', '--dx', '0.03'],
+                                  ['--n1', '48', '--fixed-bounds']],
+                         ids=['masses-differ', 'run-time-flags', 'no-reduction'])
 def test_records_keep_the_mass_when_masses_differ_or_flags_are_not_constant(argv):
     out, cnt, res = _run(argv, {})
     assert cnt['n_eos_fused'] > 0 and cnt['n_mass_fused'] == 0 and res['parity_ok'], (cnt, res)
