@@ -108,7 +108,10 @@ typedef struct {
 } sph_equation;
 
 /* One (leaf) Group: pysph/sph/equation.py:457-561.  `pre/post/condition/
- * iterate/update_nnps` are host-side control and stay in the Python caller. */
+ * iterate/update_nnps` are host-side control and stay in the Python caller.
+ * ZERO-INITIALISE the struct (memset / `sph_group g = {0}`) before filling it:
+ * the optional promises at its end grow with the library, and a field left
+ * as stack garbage would be read as a promise.                              */
 typedef struct {
     int real;                  /* loop over real particles only */
     long start_idx;            /* D_START_IDX  (acceleration_eval_cython_helper.py:263-268) */
@@ -292,6 +295,7 @@ typedef struct sph_gen_args {
     double *dout[SPH_GEN_MAX_PROPS];        /* destination props read-modify-written */
     double par[SPH_GEN_MAX_PAR];
     double *state;                /* device copy of sph_gen_family.state (equation attributes the bodies write) */
+    int row_mod3, norm_masks;     /* the context options of the same names (row order / hit-mask normalisation of the pair kernel) */
 } sph_gen_args;
 
 typedef int (*sph_gen_launch_fn)(const sph_gen_args *);

@@ -1393,8 +1393,8 @@ class GeneratedFamily(object):
             len(din), len(dout), len(self.params)))
         A('    PairArgs<FamGen> a;')
         A('    memset(&a, 0, sizeof a);')
-        A('    a.norm_masks = 1;')
-        A('    a.row_mod3 = 3;')
+        A('    a.norm_masks = g->norm_masks;')
+        A('    a.row_mod3 = g->row_mod3;')
         A('    a.nsrc = g->nsrc;')
         A('    for (int j = 0; j < g->nsrc; j++) a.src[j] = {g->src_cell_start[j], g->src_off[j], g->src_flags[j], g->src_fine_start[j]};')
         A('    a.rec = g->rec; a.nrec = g->nrec; a.fpos = (const float4 *)g->fpos; a.dom_extent = g->dom_extent;')

@@ -44,7 +44,7 @@ struct SphComm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     DevBuf send[2], recv[2], cnt; // payloads per face, 4 counters (send lo/hi, recv lo/hi)
-    unsigned long long *h_cnt = nullptr; // pinned: 8 counters, then (as doubles) 4 message headers
+    unsigned long long *h_cnt = nullptr; // pinned, 16 words: [0..3] counters (sent lo/hi, received lo/hi), [4..7] (as doubles) the 4 message headers
     // fixed-capacity protocol: rows the messages of (array, face) are sized for; 0 = not known yet.
     // Both ends of a face derive them from the SAME count with the same rule, so they stay in step.
     size_t cap_send[SPH_MAX_ARRAYS][2] = {}, cap_recv[SPH_MAX_ARRAYS][2] = {};

@@ -243,6 +243,8 @@ int sph_array_device_ptr(sph_ctx *c, int id, int prop, void **dptr)
 {
     SPH_TRY(sph_array_ensure_prop(c, id, prop));
     *dptr = c->arr[id].prop[prop];
+    // whoever holds the raw pointer may write masses: the uniform-mass records wait for the next sph_nnps_update's look
+    if (prop == SPH_M) c->arr[id].m_known = false;
     return SPH_OK;
 }
 

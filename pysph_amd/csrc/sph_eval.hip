@@ -108,9 +108,17 @@ __global__ __launch_bounds__(256) void k_nosrc(EosArgs a)
         double r = a.rho[i];
         if (r < rho0) { r = rho0; a.rho[i] = r; }
         double ratio = r * (1.0 / rho0);
-        double tmp = pow(ratio, gamma);
+        double tmp, csr;
+        if (gamma == 7.0) { // as TaitEOS above: the EOS-fused pair kernel recomputes p, cs by the same multiplications
+            const double r2 = ratio * ratio;
+            csr = r2 * ratio;
+            tmp = (r2 * r2) * csr;
+        } else {
+            tmp = pow(ratio, gamma);
+            csr = pow(ratio, 0.5 * (gamma - 1.0));
+        }
         a.p[i] = (rho0 * c0 * c0 / gamma) * (tmp - 1.0);
-        a.cs[i] = c0 * pow(ratio, 0.5 * (gamma - 1.0));
+        a.cs[i] = c0 * csr;
         break;
     }
     case SPH_EQ_TVF_STATE_EQUATION: // transport_velocity.py:215-216
@@ -1283,8 +1291,8 @@ int nnps_csr_pair_kernel(sph_ctx *c, int src, int dst, uint32_t *count, const ui
 
 extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *g, double t, double dt)
 {
-    c->cur_dt = dt;
     if (!c || !K || !g) { sph_set_error("sph_eval_group: NULL argument"); return SPH_ERR_ARG; }
+    c->cur_dt = dt;
     if (g->neq > SPH_MAX_EQS) { sph_set_error("sph_eval_group: too many equations"); return SPH_ERR_ARG; }
     if (K->kind < 1 || K->kind > 4) { sph_set_error("sph_eval_group: unknown kernel kind %d", K->kind); return SPH_ERR_UNSUPPORTED; }
     HIP_TRY(hipSetDevice(c->device));
@@ -1674,6 +1682,7 @@ static int eval_generated_launches(sph_ctx *c, const sph_kernel *K, const sph_ge
         if (p < 0 || p >= SPH_PROP_COUNT) { sph_set_error("sph_eval_generated: bad output property %d", p); return SPH_ERR_ARG; }
         SPH_TRY(sph_array_ensure_prop(c, dst, p));
         g.dout[k] = D.prop[p];
+        if (p == SPH_M) D.m_known = false; // a generated body writes masses: uniform-mass records wait for the next look
     }
     for (int k = 0; k < f->n_din; k++) {
         int p = f->din[k];
@@ -1684,6 +1693,7 @@ static int eval_generated_launches(sph_ctx *c, const sph_kernel *K, const sph_ge
     g.d_start = (uint32_t)start; g.d_stop = (uint32_t)stop;
     g.nd = (uint32_t)D.n;
     g.sigma = K->fac; g.deltap = K->deltap; g.dim = K->dim;
+    g.row_mod3 = (int)c->row_mod3; g.norm_masks = (int)c->norm_masks;
     if (D.n == 0 || stop <= start) return SPH_OK;
 
     if (f->split_init) { // initialize for ALL particles before anything reads it as a source

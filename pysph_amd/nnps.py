@@ -26,8 +26,11 @@ _XYZH = ('x', 'y', 'z', 'h')
 class HipNNPS(object):
     def __init__(self, dim, particles, radius_scale=2.0, ghost_layers=1,
                  domain=None, fixed_h=False, cache=False, sort_gids=False,
-                 ctx=None, sync=True):
-        """`sync`: push x, y, z, h of every array from the host before each
+                 ctx=None, sync=True, h_range_reduce=None):
+        """`h_range_reduce`: with ``fixed_h`` in a multi-rank run, a callable
+        ``(hmin, hmax) -> (global hmin, global hmax)`` (e.g. a MIN/MAX
+        all-reduce): ghosts and migrants carry other ranks' smoothing lengths.
+        `sync`: push x, y, z, h of every array from the host before each
         ``update()`` (drop-in behaviour: the host owns the data).  With
         ``sync=False`` the positions already on the device are used
         (device-resident pipelines)."""
@@ -52,6 +55,8 @@ class HipNNPS(object):
         self.n_cells = 0
         self.bounds = None       # optional fixed global bounds (multi-GPU)
         self._h_fixed = False
+        self._h_range = None     # (hmin, hmax) of THIS neighbour search once fixed_h has seen them
+        self.h_range_reduce = h_range_reduce
         self.cell_size_override = -1.0
         if self.domain is not None:
             self.domain.set_particles(self.particles, self.radius_scale)
@@ -84,6 +89,13 @@ class HipNNPS(object):
             for h in self.helpers:
                 h._sync_size()
         ids = (C.c_int * self.narrays)(*[h.array_id for h in self.helpers])
+        # The known h range is state of THIS object, not of the (process-wide)
+        # context: every update hands the library its own range, or clears the
+        # one another HipNNPS on the same context may have left there.
+        if self._h_fixed:
+            dev._check(self.lib.sph_nnps_set_h_range(self.ctx._h, *self._h_range))
+        else:
+            dev._check(self.lib.sph_nnps_set_h_range(self.ctx._h, 0.0, -1.0))
         b = None
         if self.bounds is not None:
             b = (C.c_double * 6)(*self.bounds)
@@ -105,7 +117,12 @@ class HipNNPS(object):
             mm = (C.c_double * 8)()
             dev._check(self.lib.sph_nnps_minmax(self.ctx._h, self.narrays, ids, mm))
             if mm[7] >= mm[3]:
-                dev._check(self.lib.sph_nnps_set_h_range(self.ctx._h, mm[3], mm[7]))
+                lo, hi = mm[3], mm[7]
+                if self.h_range_reduce is not None:
+                    # slab-decomposed runs: ghosts and migrants carry the other
+                    # ranks' smoothing lengths, so the range must be the global one
+                    lo, hi = self.h_range_reduce(lo, hi)
+                self._h_range = (float(lo), float(hi))
                 self._h_fixed = True
         self.xmin = np.array(d8[2:5])
         self.xmax = np.array(d8[5:8])

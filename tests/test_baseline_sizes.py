@@ -27,6 +27,9 @@ pytestmark = pytest.mark.gpu
 # restatement against itself in a permuted particle order gives 3.5e-11 at 216 k
 # particles (tests/test_bench_launcher.py::test_elementwise_error_of_a_reordered_sum).
 ELEMENTWISE_BOUND = 1e-8
+# ... and where the sums cancel to zero (the Taylor-Green lattice) every particle sits
+# at the floor: the figure is the norm-wise error / floor, bounded by 1e-10 / 1e-6
+# (bench.ELEMENTWISE_TOL_CANCELLING); parity_check asserts each workload's own bound.
 
 
 def _case(argv):
@@ -89,6 +92,18 @@ def test_dam_break_4m_vs_oracle():
     assert res['parity_elementwise_max_rel'] < ELEMENTWISE_BOUND, res
 
 
+def test_dam_break_16m_one_gpu_vs_oracle():
+    """BASELINE config 4's workload (S-dam dx 0.0035) on ONE GPU -- the anchor
+    its 8-GPU strong-scaling number is divided by: 15.8 M fluid + 1.3 M boundary +
+    0.25 M obstacle on a ~4.6 M-cell grid (37 M fine_start entries per array, long
+    empty rows, packed indices beyond 2^24)."""
+    res, n, _ = _case(['--workload', 'dam_break', '--dx', '0.0035'])
+    assert n > 16e6
+    assert res['parity_neighbour_count_mismatches'] == 0, res
+    assert res['parity_max_rel'] < 1e-10, res
+    assert res['parity_elementwise_max_rel'] < ELEMENTWISE_BOUND and res['parity_ok'], res
+
+
 def test_taylor_green_4m_periodic_vs_oracle():
     """BASELINE config 3: 159^3 periodic TVF; the oracle runs on the ghosts of
     the host DomainManager, the device on those of HipDomainManager."""
@@ -97,6 +112,9 @@ def test_taylor_green_4m_periodic_vs_oracle():
     # every real destination's neighbour count, ghost images counted as sources
     assert res['parity_neighbour_count_mismatches'] == 0, res
     assert res['parity_max_rel'] < 1e-10, res
+    import bench
+    assert res['parity_elementwise_tolerance'] == bench.ELEMENTWISE_TOL_CANCELLING
+    assert res['parity_elementwise_max_rel'] < bench.ELEMENTWISE_TOL_CANCELLING and res['parity_ok'], res
 
 
 @pytest.mark.parametrize('extra', [[], ['--rings-spacing', '0.0405372']],
@@ -109,6 +127,8 @@ def test_rings_2m_vs_oracle(extra):
     assert 1.9e6 < n < 2.1e6
     assert res['parity_neighbour_count_mismatches'] == 0, res
     assert res['parity_max_rel'] < 1e-10, res
+    # no systematic cancellation in the rings' fields (seeded perturbation: every term acts)
+    assert res['parity_elementwise_max_rel'] < ELEMENTWISE_BOUND and res['parity_ok'], res
 
 
 def test_rings_2m_fp32_vs_oracle():
@@ -126,6 +146,7 @@ def test_elastic_2m_vs_oracle():
     assert n == 126 ** 3
     assert res['parity_neighbour_count_mismatches'] == 0, res
     assert res['parity_max_rel'] < 1e-10, res
+    assert res['parity_elementwise_max_rel'] < ELEMENTWISE_BOUND and res['parity_ok'], res
 
 
 def test_elastic_2m_fp32_vs_oracle():

@@ -240,3 +240,42 @@ def test_fixed_h_and_bounds_skip_the_reduction_but_not_the_result():
         assert np.array_equal(sa, sb) and np.array_equal(ia, ib)
     ctx_a.close()
     ctx_b.close()
+
+
+@pytest.mark.gpu
+def test_fixed_h_range_is_per_nnps_not_per_context():
+    """Two neighbour searches on ONE context (dev.get_context() is process-wide):
+    the h range a fixed_h search found must not leak into a later search over
+    other particles with other smoothing lengths (round-3 advisor finding: the
+    range was sticky context state, giving a stale cell size / uniform-h flag)."""
+    import numpy as np
+    from test_hip_parity import make_cube
+    from pysph_amd import device as dev
+    from pysph_amd.nnps import HipNNPS
+    ctx = dev.HipContext(0)
+    ref_ctx = dev.HipContext(0)
+    pa, dx = make_cube(12)
+    n1 = HipNNPS(3, [pa], radius_scale=2.0, ctx=ctx, fixed_h=True)
+    n1.update()
+    assert n1._h_fixed and n1._h_range[0] == n1._h_range[1]
+    # another problem on the same context: larger, NON-uniform h, not fixed
+    pb, _ = make_cube(10)
+    pc, _ = make_cube(10)
+    rng = np.random.default_rng(3)
+    hb = pb.h * (1.5 + 0.3 * rng.uniform(-1, 1, pb.get_number_of_particles()))
+    pb.h[:] = hb
+    pc.h[:] = hb
+    n2 = HipNNPS(3, [pb], radius_scale=2.0, ctx=ctx)
+    n3 = HipNNPS(3, [pc], radius_scale=2.0, ctx=ref_ctx)     # never saw a fixed range
+    for _ in range(2):
+        n2.update()
+        n3.update()
+        assert n2.cell_size == n3.cell_size and n2.hmin == n3.hmin
+        s2, i2 = n2.get_csr(0, 0)
+        s3, i3 = n3.get_csr(0, 0)
+        assert np.array_equal(s2, s3) and np.array_equal(i2, i3)
+    # ... and the fixed one still gets ITS range back on its next update
+    n1.update()
+    assert abs(n1.cell_size - 2.0 * float(pa.h[0])) < 1e-15
+    ctx.close()
+    ref_ctx.close()
