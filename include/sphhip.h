@@ -127,6 +127,12 @@ typedef struct {
      *   SPH_EQ_TAIT_EOS[_HG] equation over ALL its particles left them (the
      *   group before this one) -- the pair kernel may recompute them from rho
      *   instead of gathering them (64-byte records).
+     * src_eos = 2: p and V of every array this group's pair loops read are
+     *   p = p0 (rho / rho0 - b) and V = rho / m with eos_par = {p0, rho0, b, -}, as
+     *   SPH_EQ_TVF_STATE_EQUATION (the group before this one) and
+     *   SPH_EQ_TVF_SUMMATION_DENSITY (earlier in this evaluation), each over ALL
+     *   particles, left them -- the TVF force kernel may recompute both from rho
+     *   (80-byte records) when the arrays have one mass each.
      * nl_mode: reuse of the neighbour lists between the pair passes of one
      *   evaluation (the reference's NeighborCache, nnps_base.pyx:1144-1257):
      *   1 = a later group of this evaluation loops over the same (destination,

@@ -343,6 +343,21 @@ class _CGroup(object):
                 self.units.append(_GeneratedUnit(group, dest, custom, array_ids,
                                                  arrays, kernel_kind, self, skip))
 
+    def _combined_group(self):
+        """ONE sph_group holding the equations of every (hand-written) unit: a
+        group with several destinations goes to the library in one call, so
+        that it can run all of them in one launch over the merged cell order of
+        the arrays (sph_eval.hip: eval_group_merged) -- or, when that does not
+        apply, loop over the destinations itself with shared source records."""
+        units = self.units
+        total = sum(len(u.eqs) for u in units)
+        ceqs = (dev.SphEquation * max(total, 1))()
+        cg = dev.SphGroup()
+        cg.real = units[0].cg.real
+        cg.neq = total
+        cg.eqs = ceqs
+        return cg, ceqs
+
     def refresh_range(self):
         g = self.group
         dest = self._arrays[g.equations[0].dest] if g.equations else None
@@ -357,24 +372,42 @@ class _CGroup(object):
         start, stop = resolve(g.start_idx, 0), resolve(g.stop_idx, -1)
         for u in self.units:
             u.refresh(start, stop)
+        self._start_stop = (start, stop)
 
     def run(self, ev, t, dt):
-        # several destinations with hand-written kernels only: the library packs
-        # every source array once for the whole group (option pack_group)
-        # instead of once per destination that reads it
+        # several destinations with hand-written kernels only: ONE call for the
+        # whole group (the equations by value, as the units hold them now)
         shared = len(self.units) > 1 and all(isinstance(u, _BuiltinUnit) for u in self.units)
-        if shared:
-            ev.ctx.set_option('pack_group', 1)
-        try:
+        if not shared:
             for u in self.units:
                 u.run(ev, t, dt)
-        finally:
-            if shared:
-                ev.ctx.set_option('pack_group', 0)
+            return
+        if getattr(self, '_combined', None) is None:
+            self._combined = self._combined_group()
+        cg, ceqs = self._combined
+        i = 0
+        for u in self.units:
+            for k in range(len(u.eqs)):
+                ceqs[i] = u.ceqs[k]
+                i += 1
+        cg.start_idx, cg.stop_idx = self._start_stop
+        # the promises annotate_plan made for every unit hold for the group
+        u0 = self.units[0].cg
+        same = all(u.cg.src_eos == u0.src_eos and list(u.cg.eos_par) == list(u0.eos_par)
+                   for u in self.units)
+        cg.src_eos = u0.src_eos if same else 0
+        for k in range(4):
+            cg.eos_par[k] = u0.eos_par[k] if same else 0.0
+        cg.nl_mode = 0
+        dev._check(ev.lib.sph_eval_group(
+            ev.ctx._h, C.byref(ev.ckernel), C.byref(cg), t, dt))
 
 
 _TAIT_KINDS = (1, 2)            # SPH_EQ_TAIT_EOS, SPH_EQ_TAIT_EOS_HG
 _WCSPH_PAIR_KINDS = (3, 4, 5)   # SPH_EQ_CONTINUITY, SPH_EQ_MOMENTUM, SPH_EQ_XSPH
+_TVF_DENSITY_KIND = 7           # SPH_EQ_TVF_SUMMATION_DENSITY
+_TVF_STATE_KIND = 8             # SPH_EQ_TVF_STATE_EQUATION
+_TVF_FORCE_KINDS = (9, 10, 11, 12)  # pressure gradient, viscosity, artificial viscosity, artificial stress
 
 
 def _plain_leaf(g, cg):
@@ -454,6 +487,49 @@ def annotate_plan(plan):
                 u.cg.src_eos = 1
                 for k in range(4):
                     u.cg.eos_par[k] = par[k]
+    # -- TVF state fusion: [TVF SummationDensity | StateEquation | force group], each over ALL
+    #    particles (real=False, no range) of the arrays the force group reads: p and V = rho / m
+    #    are functions of rho when the force group runs (src_eos = 2, eos_par = p0 rho0 b)
+    for i in range(2, len(leaves)):
+        if not (plain[i] and plain[i - 1] and plain[i - 2]):
+            continue
+        (gd, cgd), (gs, cgs), (gf, cgf) = leaves[i - 2], leaves[i - 1], leaves[i]
+        if gd.real or gs.real or _ranged(gd) or _ranged(gs):
+            continue
+        dens = set()
+        ok = True
+        for u in cgd.units:
+            for k in range(len(u.eqs)):
+                if u.ceqs[k].kind != _TVF_DENSITY_KIND:
+                    ok = False
+                dens.add(u.ceqs[k].dest)
+        state = {}
+        for u in cgs.units:
+            for k in range(len(u.eqs)):
+                ce = u.ceqs[k]
+                if ce.kind != _TVF_STATE_KIND or u._const_params:
+                    ok = False
+                    break
+                par = (ce.par[0], ce.par[1], ce.par[2])
+                if state.setdefault(ce.dest, par) != par:
+                    ok = False
+        if not ok or not state or len(set(state.values())) != 1:
+            continue
+        par = list(state.values())[0]
+        for u in cgf.units:
+            used = set()
+            force = True
+            for k in range(len(u.eqs)):
+                ce = u.ceqs[k]
+                if ce.kind not in _TVF_FORCE_KINDS or ce.nsrc == 0:
+                    force = False
+                used.add(ce.dest)
+                used.update(ce.src[j] for j in range(ce.nsrc))
+            if force and used and used <= set(state) and used <= dens:
+                u.cg.src_eos = 2
+                for k in range(3):
+                    u.cg.eos_par[k] = par[k]
+                u.cg.eos_par[3] = 0.0
     # -- neighbour-list reuse ---------------------------------------------
     keeper = None                    # (key, unit, group) of the pass whose lists would be the kept ones
     for (g, cg), ok in zip(leaves, plain):

@@ -131,6 +131,11 @@ int sph_ctx_destroy(sph_ctx *c)
         A.tile_key.release(); A.tile_id.release(); A.tile_order.release();
         A.cell_start.release(); A.fkeys_sorted.release(); A.fine_start.release();
     }
+    {
+        DevArray &A = c->merged;
+        A.keys_sorted.release(); A.perm.release(); A.fkeys_sorted.release(); A.fine_start.release(); A.slot8.release();
+        A.tile_key.release(); A.tile_id.release(); A.tile_order.release();
+    }
     for (auto &H : c->halo)
         for (int s = 0; s < 2; s++) { H.flag[s].release(); H.pos[s].release(); H.list[s].release(); }
     for (DevBuf *b : {&c->dbgc, &c->gapq, &c->cub_tmp, &c->red_part, &c->red_out, &c->posh, &c->aux, &c->fposb, &c->dkeys, &c->dperm,
@@ -293,6 +298,7 @@ int sph_set_option(sph_ctx *c, const char *key, long value)
     if (strcmp(key, "mass_fuse") == 0) { c->mass_fuse = value; return SPH_OK; }
     if (strcmp(key, "nl_reuse") == 0) { c->nl_reuse = value; c->nl.valid = false; return SPH_OK; }
     if (strcmp(key, "norm_masks") == 0) { c->norm_masks = value; return SPH_OK; }
+    if (strcmp(key, "merge_arrays") == 0) { c->merge_arrays = value ? 1 : 0; c->nnps_valid = false; return SPH_OK; }
     sph_set_error("sph_set_option: unknown key '%s'", key);
     return SPH_ERR_ARG;
 }
@@ -325,7 +331,7 @@ int sph_timer_get(sph_ctx *c, const char *key, double *ms, long *count)
 {
     static const char *names[T_COUNT] = {"nnps", "pack", "eos", "pair", "stage",
                                          "pair_none", "pair_wcsph", "pair_density", "pair_tvf", "pair_vgrad", "pair_elastic",
-                                         "n_eos_fused", "n_nl_keep", "n_nl_reuse", "n_mass_fused"};
+                                         "n_eos_fused", "n_nl_keep", "n_nl_reuse", "n_mass_fused", "n_merged"};
     SPH_TRY(timer_drain(c));
     for (int i = 0; i < T_COUNT; i++)
         if (strcmp(key, names[i]) == 0) {

@@ -121,8 +121,9 @@ __global__ __launch_bounds__(256) void k_nosrc(EosArgs a)
         a.cs[i] = c0 * csr;
         break;
     }
-    case SPH_EQ_TVF_STATE_EQUATION: // transport_velocity.py:215-216
-        a.p[i] = a.par[0] * (a.rho[i] / a.par[1] - a.par[2]);
+    case SPH_EQ_TVF_STATE_EQUATION: // transport_velocity.py:215-216; rho / rho0 as rho * (1 / rho0), like TaitEOS above: the
+                                    // state-fused TVF pair kernel (FamTVFE_T) recomputes exactly this
+        a.p[i] = a.par[0] * (a.rho[i] * (1.0 / a.par[1]) - a.par[2]);
         break;
     case SPH_EQ_ISOTHERMAL_EOS: // basic_equations.py:175-176
         a.p[i] = a.par[2] + (a.par[1] * a.par[1]) * (a.rho[i] - a.par[0]);
@@ -217,6 +218,8 @@ struct PackArgs {
                                   // 4: generated, uniform h [x y z | aux...]; 5: fp32 records (floats, any family)
                                   // 6: WCSPH, p and cs recomputed by the pair kernel [x y | z u | v w | rho m] (64 B);
                                   // 7: the same in fp32 [x-x0 y-y0 z-z0 u | v w rho m] (32 B)
+                                  // 8 / 9: TVF, p and V recomputed from rho (fp64 80 B / fp32 48 B)
+                                  // 10 / 11: elastic rates without h and m (fp64 160 B / fp32 80 B)
                                   // (1, 2: aggregated kernel only)
     int umass;                    // layouts 6 / 7: the last slot carries p / rho^2 (derived 1) instead of m
     float4 *fpos;                 // non-null: fp32 {x-xmin, y-ymin, z-zmin, radius_scale*h} for the prefilter tiles
@@ -231,7 +234,8 @@ struct PackArgs {
 // the packed buffer: a whole block transposes them through (dynamic) LDS so that each store
 // instruction writes 1 KiB of whole lines instead of 64 pieces a record apart (k_pack 0.29 -> 0.22 ms
 // on the 4 M cube); the ragged last block, and launches without LDS, store per lane.
-__device__ __forceinline__ void emit_pieces(const PackArgs &a, size_t i, const double2 (&pc)[PACK_MAXP], int np)
+template <class PA>
+__device__ __forceinline__ void emit_pieces(const PA &a, size_t i, const double2 (&pc)[PACK_MAXP], int np)
 {
     extern __shared__ __attribute__((aligned(16))) double2 pack_lds[];
     double2 *const base = reinterpret_cast<double2 *>(a.rec);
@@ -294,6 +298,31 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
                                                             (float)(ph.z - a.gmin[2]), (float)v[0]));
             pc[1] = __builtin_bit_cast(double2, make_float4((float)v[1], (float)v[2], (float)v[4], (float)(a.umass ? v[5] : v[3])));
             np = 2;
+        } else if (a.layout == 8) { // TVF with the state equation fused: [x y | z rho | u v | w uhat | vhat what] (no artificial stress: 4 pieces)
+            pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, v[6]);
+            pc[2] = make_double2(v[0], v[1]); pc[3] = make_double2(v[2], v[3]);
+            pc[4] = make_double2(v[4], v[5]);
+            np = a.nr / 2;
+        } else if (a.layout == 9) { // the same in fp32: [x-x0 y-y0 z-z0 rho | u v w uhat | vhat what - -]
+            pc[0] = __builtin_bit_cast(double2, make_float4((float)(ph.x - a.gmin[0]), (float)(ph.y - a.gmin[1]),
+                                                            (float)(ph.z - a.gmin[2]), (float)v[6]));
+            pc[1] = __builtin_bit_cast(double2, make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]));
+            pc[2] = __builtin_bit_cast(double2, make_float4((float)v[4], (float)v[5], 0.f, 0.f));
+            np = a.nr / 4;
+        } else if (a.layout == 10) { // elastic, uniform h and mass: [x y | z u | v w | rho cs | t x6 | r x6]
+            pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, v[0]);
+            pc[2] = make_double2(v[1], v[2]); pc[3] = make_double2(v[4], v[5]);
+#pragma unroll
+            for (int q = 0; q < 6; q++) pc[4 + q] = make_double2(v[6 + 2 * q], v[7 + 2 * q]);
+            np = 10;
+        } else if (a.layout == 11) { // the same in fp32: [x y z u | v w rho cs | t t t t | t t r r | r r r r]
+            pc[0] = __builtin_bit_cast(double2, make_float4((float)(ph.x - a.gmin[0]), (float)(ph.y - a.gmin[1]),
+                                                            (float)(ph.z - a.gmin[2]), (float)v[0]));
+            pc[1] = __builtin_bit_cast(double2, make_float4((float)v[1], (float)v[2], (float)v[4], (float)v[5]));
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+                pc[2 + q] = __builtin_bit_cast(double2, make_float4((float)v[6 + 4 * q], (float)v[7 + 4 * q], (float)v[8 + 4 * q], (float)v[9 + 4 * q]));
+            np = 5;
         } else if (a.layout == 1) { // WCSPH [x y | z cs | u v | w m | rho tmpj] (+ [h p]: variable h / tensile correction)
             pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, v[6]);
             pc[2] = make_double2(v[0], v[1]); pc[3] = make_double2(v[2], v[3]);
@@ -339,6 +368,55 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
 #pragma unroll
         for (int k = 0; k < MAX_AUX; k++) if (k < a.na) dst[k] = v[k];
     }
+}
+
+// Records of the MERGED order (FamWCSPHM_T): thread p packs the particle at merged position p -- array slot[p], original
+// index perm[p] -- from ITS array's properties (pointer tables read per lane from the kernarg segment) into
+// [x y | z u | v w | +-rho p/rho^2] (fp32: [x-x0 y-y0 z-z0 u | v w +-rho p/rho^2]); the sign of rho is the array's class.
+// One launch for all arrays; consecutive merged positions are consecutive records, so whole blocks leave through LDS
+// as full lines like k_pack's.
+struct PackMArgs {
+    const uint32_t *perm;
+    const uint8_t *slot;
+    size_t n, off;                 // off = 0 (emit_pieces)
+    const double *prop[8][SPH_MAX_ARRAYS]; // x y z u v w rho p, per slot
+    uint32_t cls;                  // bit s: slot s is a class-1 array
+    double *rec;
+    float4 *fpos;
+    int f32, lds_np;
+    double gmin[3];
+    double hr;                     // radius_scale * h (uniform h)
+};
+
+__global__ __launch_bounds__(256) void k_pack_merged(PackMArgs a)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const uint32_t o = a.perm[i], sl = a.slot[i];
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const double *p = kernarg_read<const double *>(__builtin_offsetof(PackMArgs, prop) + ((size_t)k * SPH_MAX_ARRAYS + sl) * sizeof(double *));
+        v[k] = p[o];
+    }
+    const double rho = v[6];
+    const double q = rho != 0.0 ? v[7] * (1.0 / (rho * rho)) : 0.0; // tmpj = p*rhoj21, wc/basic.py:211,234 (as k_pack, derived 1)
+    const double srho = ((a.cls >> sl) & 1u) ? -rho : rho;
+    a.fpos[i] = make_float4((float)(v[0] - a.gmin[0]), (float)(v[1] - a.gmin[1]), (float)(v[2] - a.gmin[2]), (float)a.hr);
+    double2 pc[PACK_MAXP];
+#pragma unroll
+    for (int k = 0; k < PACK_MAXP; k++) pc[k] = make_double2(0.0, 0.0);
+    int np;
+    if (a.f32) {
+        pc[0] = __builtin_bit_cast(double2, make_float4((float)(v[0] - a.gmin[0]), (float)(v[1] - a.gmin[1]), (float)(v[2] - a.gmin[2]), (float)v[3]));
+        pc[1] = __builtin_bit_cast(double2, make_float4((float)v[4], (float)v[5], (float)srho, (float)q));
+        np = 2;
+    } else {
+        pc[0] = make_double2(v[0], v[1]); pc[1] = make_double2(v[2], v[3]);
+        pc[2] = make_double2(v[4], v[5]); pc[3] = make_double2(srho, q);
+        np = 4;
+    }
+    emit_pieces(a, i, pc, np);
 }
 
 template <class T> struct FamWCSPH_T {
@@ -505,6 +583,126 @@ template <class T, bool UM = false> struct FamWCSPHE_T : FamWCSPH_T<T> {
         Raw r;
         load_raw(a, jg, r);
         decode(a, r, fl, mu, pj, s);
+    }
+};
+
+// ---- the same equations over the MERGED order of all arrays of the grid (sph_ctx::merged): ONE record stream, one
+// phase 1 and one phase 2 per wavefront whatever the number of arrays, destinations of every array in one launch.
+// A dam break -- fluid <- {fluid, boundary, obstacle}, walls <- fluid -- is two CLASSES of arrays: which equations act for
+// a (destination, source) pair depends on the classes of the two particles only.  Records are the uniform-mass ones,
+// [x y | z u | v w | +-rho p/rho^2]: the SIGN of rho is the particle's class (rho > 0 always), the mass a constant of
+// the class.  The class table is the kernel's compile-time flag constant CF = f00 | f01 << 4 | f10 << 8 | f11 << 12
+// (f<destination class><source class>: F_CONT | F_MOM | F_XSPH bits), so every "does equation e act for this pair" is
+// a boolean expression of two sign bits, and the criterion stays a factor: a pair without equations adds exactly zero.
+// Reference semantics: per-source equation lists of pysph/sph/acceleration_eval.py:126-151 (here per class pair),
+// equations wc/basic.py:198-269, basic_equations.py:187-192,285-300.  Sums run over all arrays in cell order instead of
+// source by source (another association of the same terms).
+#define WCSPHM_CT(f00, f01, f10, f11) ((uint32_t)(f00) | ((uint32_t)(f01) << 4) | ((uint32_t)(f10) << 8) | ((uint32_t)(f11) << 12))
+template <class T> struct FamWCSPHM_T : FamWCSPHE_T<T, true> {
+    typedef FamWCSPHE_T<T, true> Base;
+    typedef typename Base::Raw Raw;
+    static constexpr bool MERGED = true;
+    // WCSPHScheme(fluids, solids): fluid <- fluid all three, fluid <- solid no XSPH, solid <- fluid continuity only
+    static constexpr uint32_t CF0 = WCSPHM_CT(F_CONT | F_MOM | F_XSPH, F_CONT | F_MOM, F_CONT, 0);
+    struct Params {
+        T c0, alpha, beta, gx, gy, gz, eps;
+        double mu1;                                // mass of the class-1 arrays (class 0: SrcDesc::mu)
+        uint32_t rng[SPH_MAX_ARRAYS][2];           // per slot: destination index range [start, stop) (empty: no destination)
+        double *out[SPH_MAX_ARRAYS][9];            // per slot: arho au av aw ax ay az dt_cfl dt_force
+    };
+    static __device__ __forceinline__ size_t rng_offset(uint32_t slot) { return __builtin_offsetof(Params, rng) + (size_t)slot * 8; }
+    struct Dest : Base::Dest { bool dc; };
+    template <class A> static __device__ __forceinline__ void load(Dest &D, const T *a, const A &A_, uint32_t o, uint32_t)
+    {
+        Base::load(D, a, A_, o);
+        D.dc = a[3] < T(0.0); // decode() left the class in the sign of the mass
+    }
+    template <class A> static __device__ __forceinline__ void decode(const A &a, const Raw &r, uint32_t, T mu, real4<T> &pj, T (&s)[8])
+    {
+        T rho, q;
+        if constexpr (sizeof(T) == 8) {
+            pj.x = r.q[0].x; pj.y = r.q[0].y; pj.z = r.q[1].x; pj.w = 0.0;
+            s[0] = r.q[1].y; s[1] = r.q[2].x; s[2] = r.q[2].y; q = r.q[3].y; rho = r.q[3].x;
+        } else {
+            pj.x = r.q[0].x; pj.y = r.q[0].y; pj.z = r.q[0].z; pj.w = 0.f;
+            s[0] = r.q[0].w; s[1] = r.q[1].x; s[2] = r.q[1].y; q = r.q[1].w; rho = r.q[1].z;
+        }
+        const bool c1 = rho < T(0.0);
+        s[3] = c1 ? -(T)a.p.mu1 : mu;          // +-m: the sign is the class
+        rho = fabs(rho);
+        s[4] = rho;
+        const T ratio = rho * (T)a.e_rho01;
+        s[5] = q;                               // p / rho^2 as k_pack_merged computed it from the stored p
+        s[6] = (T)a.e_c0 * ((ratio * ratio) * ratio);
+        s[7] = T(0.0);
+    }
+    template <class A> static __device__ __forceinline__ void load_fused(const A &a, uint32_t jg, uint32_t fl, T mu, real4<T> &pj, T (&s)[8])
+    {
+        Raw r;
+        Base::load_raw(a, jg, r);
+        decode(a, r, fl, mu, pj, s);
+    }
+    // does equation `bit` act for (destination class dc, source class sc)?  ct is a compile-time constant
+    static __device__ __forceinline__ bool acts(uint32_t ct, uint32_t bit, bool dc, bool sc)
+    {
+        const bool c00 = ct & bit, c01 = (ct >> 4) & bit, c10 = (ct >> 8) & bit, c11 = (ct >> 12) & bit;
+        return dc ? (sc ? c11 : c10) : (sc ? c01 : c00);
+    }
+    template <int KK, bool UH, class A>
+    static __device__ __forceinline__ void pair(Dest &D, const real4<T> &pi, const real4<T> &pj, T r2,
+                                                const T (&s)[8], uint32_t ct, const A &a, bool pass = true)
+    {
+        PairGeomT<T> g;
+        pair_geom<KK, UH>(g, pi, pj, r2, a);
+        const T tg = pair_gradfac<KK, UH>(g);
+        const T vij0 = D.u - s[0], vij1 = D.v - s[1], vij2 = D.w - s[2];
+        const T vdotx = vij0 * g.xij[0] + vij1 * g.xij[1] + vij2 * g.xij[2];
+        const bool sc = s[3] < T(0.0);
+        const T m = fabs(s[3]);
+        const bool on_c = pass && acts(ct, F_CONT, D.dc, sc), on_m = pass && acts(ct, F_MOM, D.dc, sc),
+                   on_x = pass && acts(ct, F_XSPH, D.dc, sc);
+        D.arho = fma((on_c ? m : T(0.0)) * tg, vdotx, D.arho); // basic_equations.py:187-192
+        const T rhoij = T(0.5) * (D.rho + s[4]);
+        const T wij = pair_w<KK, UH>(g);
+        // wc/basic.py:204-259
+        const T re = r2 + g.eps;
+        const T tt = fast_rcp(re * rhoij);
+        const T inv_re = rhoij * tt;
+        const T rhoij1 = re * tt;
+        const T hv = g.hij * vdotx;
+        const T muij = hv * inv_re;
+        const T cij = T(0.5) * (D.cs + s[6]);
+        T piij = (a.p.beta * muij - a.p.alpha * cij) * muij * rhoij1;
+        piij = vdotx < 0 ? piij : T(0.0);
+        const T dtc = fabs(hv * (g.rinv * g.rinv)) + a.p.c0;
+        D.dt_cfl = (r2 > T(1e-12) && on_m) ? fmax(dtc, D.dt_cfl) : D.dt_cfl;
+        const T ft = -(on_m ? m : T(0.0)) * ((D.tmpi + s[5]) + piij) * tg;
+        D.au = fma(ft, g.xij[0], D.au);
+        D.av = fma(ft, g.xij[1], D.av);
+        D.aw = fma(ft, g.xij[2], D.aw);
+        // basic_equations.py:290-295
+        const T tmp = -a.p.eps * (on_x ? m : T(0.0)) * wij * rhoij1;
+        D.ax = fma(tmp, vij0, D.ax);
+        D.ay = fma(tmp, vij1, D.ay);
+        D.az = fma(tmp, vij2, D.az);
+    }
+    template <class A> static __device__ __forceinline__ void finish(Dest &D, const A &a, uint32_t o, uint32_t slot)
+    {
+        // the equations with this lane's class as destination (class table row); its array's output pointers
+        const uint32_t ct = a.dflags;
+        const uint32_t row = D.dc ? ((ct >> 8) | (ct >> 12)) & 15u : (ct | (ct >> 4)) & 15u;
+        const size_t base = __builtin_offsetof(A, p) + __builtin_offsetof(Params, out) + (size_t)slot * (9 * sizeof(double *));
+        auto out = [&](int k) { return kernarg_read<double *>(base + (size_t)k * sizeof(double *)); };
+        if (row & F_CONT) out(0)[o] = D.arho;
+        if (row & F_MOM) { // post_loop wc/basic.py:261-271
+            const T au = D.au + a.p.gx, av = D.av + a.p.gy, aw = D.aw + a.p.gz;
+            out(1)[o] = au; out(2)[o] = av; out(3)[o] = aw;
+            out(7)[o] = D.dt_cfl;
+            out(8)[o] = au * au + av * av + aw * aw;
+        }
+        if (row & F_XSPH) { // post_loop basic_equations.py:297-300
+            out(4)[o] = D.ax + D.u; out(5)[o] = D.ay + D.v; out(6)[o] = D.az + D.w;
+        }
     }
 };
 
@@ -711,6 +909,40 @@ template <> __device__ __forceinline__ void load_record<FamTVF, true>(const doub
     if (fl & F_TAV) s[9] = r2[6].x;
 }
 
+// The same terms on records WITHOUT p and V (sph_group.src_eos = 2): the group before this one was TVF's StateEquation
+// over every particle of every array read here and its density summation ran earlier in the evaluation, so
+// p = p0 (rho / rho0 - b) and V = rho / m are functions of the gathered rho and the source array's ONE mass:
+// [x y | z rho | u v | w uhat | vhat what] -- 80 bytes, five 16-B pieces instead of six (four without the artificial
+// stress); fp32: [x y z rho | u v w uhat | vhat what - -], three pieces instead of four.  One reciprocal more per pair.
+template <class T> struct FamTVFE_T : FamTVF_T<T> {
+    static constexpr bool EOSF = true;
+    static constexpr int NA = 12;
+    template <class A> static __device__ __forceinline__ void load_fused(const A &a, uint32_t jg, uint32_t fl, T mu, real4<T> &pj, T (&s)[12])
+    {
+        T rho;
+        if constexpr (sizeof(T) == 8) {
+            const double2 *p = reinterpret_cast<const double2 *>(a.rec) + (unsigned long long)jg * (unsigned)(a.nrec >> 1);
+            const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+            pj.x = q0.x; pj.y = q0.y; pj.z = q1.x; pj.w = 0.0; rho = q1.y;
+            s[0] = q2.x; s[1] = q2.y; s[2] = q3.x; s[3] = q3.y; s[4] = s[5] = 0.0;
+            if (fl & F_TAS) { const double2 q4 = p[4]; s[4] = q4.x; s[5] = q4.y; }
+        } else {
+            const float4 *p = reinterpret_cast<const float4 *>(a.rec) + (unsigned long long)jg * (unsigned)(a.nrec >> 2);
+            const float4 q0 = p[0], q1 = p[1];
+            pj.x = q0.x; pj.y = q0.y; pj.z = q0.z; pj.w = 0.f; rho = q0.w;
+            s[0] = q1.x; s[1] = q1.y; s[2] = q1.z; s[3] = q1.w; s[4] = s[5] = 0.f;
+            if (fl & F_TAS) { const float4 q2 = p[2]; s[4] = q2.x; s[5] = q2.y; }
+        }
+        s[6] = rho;
+        s[7] = (T)a.e_p0 * (rho * (T)a.e_rho01 - (T)a.e_B); // StateEquation, as k_nosrc computes it
+        s[8] = T(0.0);
+        s[9] = mu;
+        const T vj = mu * fast_rcp(rho);                     // 1 / V_j with V = sum W = rho / m (transport_velocity.py:52-58): Vj2 = (m / rho)^2, :303-306
+        s[10] = vj * vj;
+        s[11] = T(0.0);
+    }
+};
+
 // ---- velocity gradient (basic_equations.py:63-148) -------------------------
 template <class T> struct FamVGrad_T {
     typedef T Real; // arithmetic type of the pair loop
@@ -854,6 +1086,37 @@ template <class T> struct FamElastic_T {
     }
 };
 typedef FamElastic_T<double> FamElastic;
+
+// The same terms on records without h and m (uniform h, ONE mass per source array -- seen by the neighbour update's
+// reduction, as for the WCSPH uniform-mass records): [x y | z u | v w | rho cs | t00 t01 | t02 t11 | t12 t22 | r00 r01 |
+// r02 r11 | r12 r22], 160 bytes = ten 16-B pieces instead of eleven; fp32 [x y z u | v w rho cs | t00 t01 t02 t11 |
+// t12 t22 r00 r01 | r02 r11 r12 r22], 80 bytes = five pieces instead of six.
+template <class T> struct FamElasticU_T : FamElastic_T<T> {
+    static constexpr bool EOSF = true; // own record decoding (load_fused)
+    static constexpr int NA = 18;
+    template <class A> static __device__ __forceinline__ void load_fused(const A &a, uint32_t jg, uint32_t, T mu, real4<T> &pj, T (&s)[18])
+    {
+        if constexpr (sizeof(T) == 8) {
+            const double2 *p = reinterpret_cast<const double2 *>(a.rec) + (unsigned long long)jg * 10;
+            double2 q[10];
+#pragma unroll
+            for (int k = 0; k < 10; k++) q[k] = p[k];
+            pj.x = q[0].x; pj.y = q[0].y; pj.z = q[1].x; pj.w = 0.0;
+            s[0] = q[1].y; s[1] = q[2].x; s[2] = q[2].y; s[3] = mu; s[4] = q[3].x; s[5] = q[3].y;
+#pragma unroll
+            for (int k = 0; k < 6; k++) { s[6 + 2 * k] = q[4 + k].x; s[7 + 2 * k] = q[4 + k].y; }
+        } else {
+            const float4 *p = reinterpret_cast<const float4 *>(a.rec) + (unsigned long long)jg * 5;
+            float4 q[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) q[k] = p[k];
+            pj.x = q[0].x; pj.y = q[0].y; pj.z = q[0].z; pj.w = 0.f;
+            s[0] = q[0].w; s[1] = q[1].x; s[2] = q[1].y; s[3] = mu; s[4] = q[1].z; s[5] = q[1].w;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { s[6 + 4 * k] = q[2 + k].x; s[7 + 4 * k] = q[2 + k].y; s[8 + 4 * k] = q[2 + k].z; s[9 + 4 * k] = q[2 + k].w; }
+        }
+    }
+};
 
 // ---------------------------------------------------------------------------
 // variant 0: per-lane walk over the 3x3 rows of cells (x-contiguous ranges)
@@ -1071,6 +1334,10 @@ static int pack_pieces(const PackArgs &pa)
     if (!pa.rec) return 0;
     if (pa.layout == 6) return 4;
     if (pa.layout == 7) return 2;
+    if (pa.layout == 8) return pa.nr / 2;
+    if (pa.layout == 9) return pa.nr / 4;
+    if (pa.layout == 10) return 10;
+    if (pa.layout == 11) return 5;
     if (pa.layout == 5) return (pa.nr % 4) ? 0 : pa.nr / 4;
     if (pa.nr % 2) return 0;
     return pa.nr / 2;
@@ -1125,6 +1392,12 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
             pa.src[7] = nullptr;
             pa.derived = 0;
         }
+    }
+    if (c->cur_elu) pa.layout = c->arith_f32 ? 11 : 10; // h and m are launch / source constants
+    if (c->cur_tvff) { // p and V are functions of rho (and the one mass): not read here
+        pa.layout = c->arith_f32 ? 9 : 8;
+        pa.src[7] = pa.src[8] = pa.src[9] = nullptr;
+        pa.derived = 0;
     }
     pa.lds_np = pack_pieces(pa);
     if (launch) hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), (size_t)pa.lds_np * 256 * 16, c->stream, pa);
@@ -1259,6 +1532,8 @@ int nnps_csr_pair_kernel(sph_ctx *c, int src, int dst, uint32_t *count, const ui
     const bool was_f32 = c->record_f32 != 0, was_a32 = c->arith_f32 != 0; // lists are exact: fp64 records always
     c->record_f32 = 0; c->arith_f32 = 0;
     c->cur_eosf = false;
+    c->cur_tvff = false;
+    c->cur_elu = false;
     c->cur_umass = false;
     c->cur_nrec = pl.nr;
     int rc = c->posh.reserve((total + 64) * sizeof(double) * pl.nr);
@@ -1289,6 +1564,184 @@ int nnps_csr_pair_kernel(sph_ctx *c, int src, int dst, uint32_t *count, const ui
     return SPH_OK;
 }
 
+// ---------------------------------------------------------------------------
+// A WCSPH group over several arrays as ONE launch on the merged order (sph_ctx::merged, FamWCSPHM_T): applicable
+// when the group is nothing but Continuity / Momentum / XSPH equations whose (destination, source) flag matrix is a
+// two-class table the library has a kernel for, over exactly the arrays of the grid, under the conditions of the
+// EOS-fused uniform-mass records (uniform h, sph_group.src_eos, gamma = 7, no tensile correction, one mass per class).
+// *done = false: not applicable, the caller takes the per-destination path.
+// ---------------------------------------------------------------------------
+static int eval_group_merged(sph_ctx *c, const sph_kernel *K, const sph_group *g, double t, bool *done)
+{
+    *done = false;
+    if (!c->merged_valid || !c->merge_arrays || !c->nnps_valid || c->pair_variant != 6 || c->ablate || c->count_iters) return SPH_OK;
+    if (!(g->src_eos == 1 && c->eos_fuse && c->mass_fuse && c->const_flags && c->uniform_h && c->use_uniform_h &&
+          g->eos_par[2] == 7.0 && g->eos_par[0] > 0.0 && !c->record_f32 && !c->wcsph_nr))
+        return SPH_OK;
+    const int na = c->narrays;
+    uint32_t F[SPH_MAX_ARRAYS][SPH_MAX_ARRAYS] = {};
+    const sph_equation *me = nullptr, *xe = nullptr;
+    for (int i = 0; i < g->neq; i++) {
+        const sph_equation &e = g->eqs[i];
+        uint32_t flag;
+        if (e.kind == SPH_EQ_CONTINUITY) flag = F_CONT;
+        else if (e.kind == SPH_EQ_MOMENTUM) flag = F_MOM;
+        else if (e.kind == SPH_EQ_XSPH) flag = F_XSPH;
+        else return SPH_OK;
+        if (e.nsrc <= 0 || e.dest < 0 || e.dest >= SPH_MAX_ARRAYS || !c->arr[e.dest].used || c->arr[e.dest].nnps_slot < 0) return SPH_OK;
+        if (e.kind == SPH_EQ_MOMENTUM) {
+            if (e.par[6] != 0.0) return SPH_OK; // tensile correction reads p of the neighbours
+            if (me && memcmp(me->par, e.par, 7 * sizeof(double)) != 0) return SPH_OK; // one parameter set per launch
+            me = &e;
+        }
+        if (e.kind == SPH_EQ_XSPH) {
+            if (xe && xe->par[0] != e.par[0]) return SPH_OK;
+            xe = &e;
+        }
+        const int ds = c->arr[e.dest].nnps_slot;
+        for (int k = 0; k < e.nsrc; k++) {
+            const int sid = e.src[k];
+            if (sid < 0 || sid >= SPH_MAX_ARRAYS || !c->arr[sid].used || c->arr[sid].nnps_slot < 0) return SPH_OK;
+            const int ss = c->arr[sid].nnps_slot;
+            if (F[ds][ss] & flag) return SPH_OK; // the same equation twice: the general path reports it
+            F[ds][ss] |= flag;
+        }
+    }
+    // every array of the grid is in the record stream: it must take part (an array without equations would act
+    // as a source of whatever its class says)
+    for (int a = 0; a < na; a++) {
+        bool used = false;
+        for (int b = 0; b < na; b++) used |= F[a][b] != 0 || F[b][a] != 0;
+        if (!used) return SPH_OK;
+    }
+    // two classes: arrays a, b are alike when they see and are seen by every array -- each other included -- the same way
+    auto alike = [&](int a, int b) {
+        if (F[a][a] != F[b][b] || F[a][b] != F[b][a] || F[a][a] != F[a][b]) return false;
+        for (int x = 0; x < na; x++)
+            if (x != a && x != b && (F[a][x] != F[b][x] || F[x][a] != F[x][b])) return false;
+        return true;
+    };
+    int cls[SPH_MAX_ARRAYS], rep[2] = {0, -1};
+    for (int a = 0; a < na; a++) {
+        if (a == rep[0] || alike(a, rep[0])) cls[a] = 0;
+        else if (rep[1] < 0 || alike(a, rep[1])) { cls[a] = 1; if (rep[1] < 0) rep[1] = a; }
+        else return SPH_OK;
+    }
+    if (rep[1] < 0) return SPH_OK; // one class of several arrays: the per-destination path has constant flags already
+    auto tab = [&](int i, int j) {
+        // an entry of the class table from two representatives (two DIFFERENT members when the class has them)
+        for (int a = 0; a < na; a++) for (int b = 0; b < na; b++)
+            if (cls[a] == i && cls[b] == j && (a != b || i != j)) return F[a][b];
+        return F[rep[i]][rep[j]];
+    };
+    uint32_t T4[2][2] = {{tab(0, 0), tab(0, 1)}, {tab(1, 0), tab(1, 1)}};
+    for (int a = 0; a < na; a++) for (int b = 0; b < na; b++) if (F[a][b] != T4[cls[a]][cls[b]]) return SPH_OK;
+    if (T4[1][1] > T4[0][0]) { // class 0 = the one with the richer self-interaction (the fluids)
+        for (int a = 0; a < na; a++) cls[a] ^= 1;
+        std::swap(T4[0][0], T4[1][1]); std::swap(T4[0][1], T4[1][0]);
+    }
+    const uint32_t ct = WCSPHM_CT(T4[0][0], T4[0][1], T4[1][0], T4[1][1]);
+    if (ct != FamWCSPHM_T<double>::CF0) return SPH_OK; // the class table the library has a kernel for (WCSPHScheme's)
+    // one mass per class, seen by the last neighbour update
+    c->want_mrange = true;
+    double mu[2] = {0.0, 0.0};
+    bool have[2] = {false, false};
+    for (int a = 0; a < na; a++) {
+        const DevArray &A = c->arr[c->ids[a]];
+        if (A.n == 0) continue;
+        if (!A.m_known) return SPH_OK;
+        if (have[cls[a]] && mu[cls[a]] != A.m_value) return SPH_OK;
+        mu[cls[a]] = A.m_value; have[cls[a]] = true;
+    }
+    DevArray &M = c->merged;
+    if (M.n == 0) { *done = true; return SPH_OK; }
+
+    // outputs and properties
+    static const int outp[9] = {SPH_ARHO, SPH_AU, SPH_AV, SPH_AW, SPH_AX, SPH_AY, SPH_AZ, SPH_DT_CFL, SPH_DT_FORCE};
+    static const int inp[8] = {SPH_X, SPH_Y, SPH_Z, SPH_U, SPH_V, SPH_W, SPH_RHO, SPH_P};
+    const bool f32 = c->arith_f32 != 0;
+    PackMArgs pa;
+    memset(&pa, 0, sizeof pa);
+    for (int a = 0; a < na; a++) {
+        const int id = c->ids[a];
+        DevArray &A = c->arr[id];
+        for (int k = 0; k < 8; k++) {
+            if (A.n && !A.prop[inp[k]]) return need_prop(c, id, inp[k], "pair loop");
+            pa.prop[k][a] = A.prop[inp[k]];
+        }
+        if (cls[a]) pa.cls |= 1u << a;
+    }
+    c->cur_eosf = true; c->cur_umass = true; c->cur_tvff = false; c->cur_elu = false;
+    c->cur_nrec = 8;
+    SPH_TRY(c->posh.reserve((M.n + 64) * (f32 ? 32 : 64)));
+    SPH_TRY(c->aux.reserve(64));
+    SPH_TRY(c->fposb.reserve((M.n + 64) * sizeof(float4)));
+    for (auto &pc : c->pack_cache) pc.epoch = 0; // the shared slots of the per-destination path are overwritten
+    {
+        ScopedTimer tm(c, T_PACK);
+        pa.perm = M.perm.as<uint32_t>(); pa.slot = M.slot8.as<uint8_t>();
+        pa.n = M.n; pa.off = 0;
+        pa.rec = c->posh.as<double>(); pa.fpos = c->fposb.as<float4>();
+        pa.f32 = f32 ? 1 : 0; pa.lds_np = f32 ? 2 : 4;
+        for (int k = 0; k < 3; k++) pa.gmin[k] = c->xmin[k];
+        pa.hr = c->radius_scale * c->h_uniform;
+        hipLaunchKernelGGL(k_pack_merged, dim3(div_up(M.n, 256)), dim3(256), (size_t)pa.lds_np * 256 * 16, c->stream, pa);
+    }
+    ScopedTimer tm(c, T_PAIR);
+    ScopedTimer tmf(c, T_PAIR_FAM + FAM_WCSPH);
+    c->timers[T_N_EOSF].count++; c->timers[T_N_UMASS].count++; c->timers[T_N_MERGED].count++;
+    auto run = [&](auto tag) -> int {
+        typedef decltype(tag) Fm;
+        PairArgs<Fm> a;
+        memset(&a, 0, sizeof a);
+        fill_common(c, a, K, t);
+        a.nsrc = 1;
+        a.src[0] = {nullptr, 0u, ct, M.fine_start.as<uint32_t>(), mu[0]};
+        a.d_off = 0; a.nd = (uint32_t)M.n;
+        a.d_keys = M.keys_sorted.as<uint32_t>(); a.d_fkeys = M.fkeys_sorted.as<uint32_t>(); a.d_perm = M.perm.as<uint32_t>();
+        a.d_slot = M.slot8.as<uint8_t>();
+        set_tile_order(c, a, M);
+        a.d_start = 0; a.d_stop = 0xffffffffu; a.dflags = ct;
+        a.e_rho01 = 1.0 / g->eos_par[0]; a.e_c0 = g->eos_par[1];
+        a.e_B = g->eos_par[0] * g->eos_par[1] * g->eos_par[1] / g->eos_par[2];
+        a.e_p0 = g->eos_par[3];
+        if (me) { a.p.c0 = me->par[0]; a.p.alpha = me->par[1]; a.p.beta = me->par[2]; a.p.gx = me->par[3]; a.p.gy = me->par[4]; a.p.gz = me->par[5]; }
+        if (xe) a.p.eps = xe->par[0];
+        a.p.mu1 = mu[1];
+        for (int s = 0; s < na; s++) {
+            const int id = c->ids[s];
+            DevArray &A = c->arr[id];
+            uint32_t row = 0;
+            for (int b = 0; b < na; b++) row |= F[s][b];
+            // NP_DEST / D_START_IDX (acceleration_eval_cython_helper.py:259-280), per destination array
+            size_t start = g->start_idx > 0 ? (size_t)g->start_idx : 0;
+            size_t stop = g->stop_idx >= 0 ? (size_t)g->stop_idx : (g->real ? A.n_real : A.n);
+            if (stop > A.n) stop = A.n;
+            if (!row || stop < start) start = stop = 0;
+            a.p.rng[s][0] = (uint32_t)start; a.p.rng[s][1] = (uint32_t)stop;
+            if (row & F_CONT) { SPH_TRY(ensure_out(c, id, {SPH_ARHO})); }
+            if (row & F_MOM) { SPH_TRY(ensure_out(c, id, {SPH_AU, SPH_AV, SPH_AW, SPH_DT_CFL, SPH_DT_FORCE})); }
+            if (row & F_XSPH) { SPH_TRY(ensure_out(c, id, {SPH_AX, SPH_AY, SPH_AZ})); }
+            for (int k = 0; k < 9; k++) a.p.out[s][k] = A.prop[outp[k]];
+        }
+        constexpr bool FP32 = sizeof(typename Fm::Real) == 4;
+        dim3 g2(div_up(4 * div_up(a.nd, 256), WPB)), b2(64 * WPB);
+#define LAUNCHM(KV) hipLaunchKernelGGL((k_pair_wave<Fm, KV, true, FP32, Fm::CF0>), g2, b2, (size_t)c->lds_pad, c->stream, a)
+        switch (K->kind) {
+        case 1: LAUNCHM(1); break;
+        case 2: LAUNCHM(2); break;
+        case 3: LAUNCHM(3); break;
+        case 4: LAUNCHM(4); break;
+        }
+#undef LAUNCHM
+        return SPH_OK;
+    };
+    SPH_TRY(f32 ? run(FamWCSPHM_T<float>()) : run(FamWCSPHM_T<double>()));
+    HIP_TRY(hipGetLastError());
+    *done = true;
+    return SPH_OK;
+}
+
 extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *g, double t, double dt)
 {
     if (!c || !K || !g) { sph_set_error("sph_eval_group: NULL argument"); return SPH_ERR_ARG; }
@@ -1297,6 +1750,11 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
     if (K->kind < 1 || K->kind > 4) { sph_set_error("sph_eval_group: unknown kernel kind %d", K->kind); return SPH_ERR_UNSUPPORTED; }
     HIP_TRY(hipSetDevice(c->device));
     if (!c->pack_group) c->pack_epoch++; // packed records are reused between the destinations of ONE group only (option pack_group)
+    {
+        bool done = false;
+        SPH_TRY(eval_group_merged(c, K, g, t, &done));
+        if (done) return SPH_OK;
+    }
 
     // destinations in first-appearance order (acceleration_eval.py:126-131)
     int dests[SPH_MAX_ARRAYS], ndest = 0;
@@ -1416,6 +1874,21 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         for (int j = 0; j < nsrcs && umass; j++) umass = sflags[j] == FamWCSPH::CF0;
         if (umass) c->want_mrange = true; // the reduction of the neighbour updates from now on includes m (8 B per particle)
         for (int j = 0; j < nsrcs && umass; j++) umass = c->arr[srcs[j]].m_known;
+        // TVF force pass after StateEquation + density summation (sph_group.src_eos = 2): p and V leave the records
+        // when every array read here has ONE mass (V = rho / m)
+        bool tvff = g->src_eos == 2 && c->eos_fuse && c->mass_fuse && fam == FAM_TVF && c->pair_variant == 6 && c->uniform_h &&
+                    c->use_uniform_h && !(dflags & F_TAV) && !c->record_f32 && g->eos_par[1] != 0.0;
+        if (tvff) c->want_mrange = true;
+        for (int j = 0; j < nsrcs && tvff; j++) tvff = c->arr[srcs[j]].m_known;
+        if (tvff && !dest_is_src) tvff = D.m_known;
+        if (tvff) pl.nr = c->arith_f32 ? ((dflags & F_TAS) ? 12 : 8) : ((dflags & F_TAS) ? 10 : 8);
+        // elastic rates: uniform h and ONE mass per source array -> neither travels in the records
+        bool elu = fam == FAM_ELASTIC && c->mass_fuse && c->pair_variant == 6 && c->uniform_h && c->use_uniform_h && !c->record_f32;
+        if (elu) c->want_mrange = true;
+        for (int j = 0; j < nsrcs && elu; j++) elu = c->arr[srcs[j]].m_known;
+        if (elu) pl.nr = 20; // doubles, or floats with arith_f32
+        c->cur_elu = elu;
+        c->cur_tvff = tvff;
         c->cur_umass = umass;
         c->cur_eosf = eosf;
         c->cur_nrec = pl.nr;
@@ -1428,7 +1901,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         {
             ScopedTimer tm(c, T_PACK);
             // a source must hold what ITS equations read; the destination's own record what all of them read
-            const int sig = pl.nr * 16 + (c->record_f32 ? 1 : 0) + (c->arith_f32 ? 2 : 0) + (eosf ? 4 : 0) + (umass ? 8 : 0);
+            const int sig = pl.nr * 32 + (c->record_f32 ? 1 : 0) + (c->arith_f32 ? 2 : 0) + (eosf ? 4 : 0) + (umass ? 8 : 0) + (tvff || elu ? 16 : 0);
             // The shared slots live in the same buffers every other unit packs into from offset 0:
             // a unit that does not share (another family, a single-destination call), or one whose
             // record layout differs from what the cache holds, overwrites them -- nothing cached survives.
@@ -1471,8 +1944,8 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         // 4. fused pair kernel, in the arithmetic type of the context (fp64, or fp32 with option arith_f32)
         ScopedTimer tm(c, T_PAIR);
         ScopedTimer tmf(c, T_PAIR_FAM + fam);
-        if (eosf) c->timers[T_N_EOSF].count++;
-        if (umass) c->timers[T_N_UMASS].count++;
+        if (eosf || tvff) c->timers[T_N_EOSF].count++;
+        if (umass || tvff || elu) c->timers[T_N_UMASS].count++;
         if (nl_mode == 1) c->timers[T_N_NLKEEP].count++;
         if (nl_mode == 2) c->timers[T_N_NLREUSE].count++;
         // the part of the launch arguments every family shares
@@ -1491,6 +1964,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
                 a.e_B = g->eos_par[0] * g->eos_par[1] * g->eos_par[1] / g->eos_par[2];
                 a.e_p0 = g->eos_par[3];
             }
+            if (tvff) { a.e_p0 = g->eos_par[0]; a.e_rho01 = 1.0 / g->eos_par[1]; a.e_B = g->eos_par[2]; } // StateEquation: p0 rho0 b
         };
         auto run_wcsph = [&](auto tag) -> int {
             typedef decltype(tag) F;
@@ -1556,7 +2030,8 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
                 SPH_TRY(ensure_out(c, dst, {SPH_AX, SPH_AY, SPH_AZ}));
                 a.p.ax = D.prop[SPH_AX]; a.p.ay = D.prop[SPH_AY]; a.p.az = D.prop[SPH_AZ];
             }
-            return launch_pair<F>(c, K->kind, a);
+            if constexpr (fam_eosf<F>::value) return launch_pair_fused<F>(c, K->kind, a);
+            else return launch_pair<F>(c, K->kind, a);
         };
         auto run_tvf = [&](auto tag) -> int {
             typedef decltype(tag) F;
@@ -1575,7 +2050,8 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
                 SPH_TRY(ensure_out(c, dst, {SPH_AUHAT, SPH_AVHAT, SPH_AWHAT}));
                 a.p.auhat = D.prop[SPH_AUHAT]; a.p.avhat = D.prop[SPH_AVHAT]; a.p.awhat = D.prop[SPH_AWHAT];
             }
-            return launch_pair<F>(c, K->kind, a);
+            if constexpr (fam_eosf<F>::value) return launch_pair_fused<F>(c, K->kind, a);
+            else return launch_pair<F>(c, K->kind, a);
         };
         const bool f32 = c->arith_f32 != 0;
         if (fam == FAM_WCSPH && eosf && umass) SPH_TRY(f32 ? run_wcsph(FamWCSPHE_T<float, true>()) : run_wcsph(FamWCSPHE_T<double, true>()));
@@ -1583,7 +2059,9 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         else if (fam == FAM_WCSPH) SPH_TRY(f32 ? run_wcsph(FamWCSPH_T<float>()) : run_wcsph(FamWCSPH()));
         else if (fam == FAM_DENSITY) SPH_TRY(f32 ? run_density(FamDensity_T<float>()) : run_density(FamDensity()));
         else if (fam == FAM_VGRAD) SPH_TRY(f32 ? run_vgrad(FamVGrad_T<float>()) : run_vgrad(FamVGrad()));
+        else if (fam == FAM_ELASTIC && elu) SPH_TRY(f32 ? run_elastic(FamElasticU_T<float>()) : run_elastic(FamElasticU_T<double>()));
         else if (fam == FAM_ELASTIC) SPH_TRY(f32 ? run_elastic(FamElastic_T<float>()) : run_elastic(FamElastic()));
+        else if (tvff) SPH_TRY(f32 ? run_tvf(FamTVFE_T<float>()) : run_tvf(FamTVFE_T<double>()));
         else SPH_TRY(f32 ? run_tvf(FamTVF_T<float>()) : run_tvf(FamTVF()));
     }
     HIP_TRY(hipGetLastError());

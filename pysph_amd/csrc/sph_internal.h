@@ -56,6 +56,7 @@ struct DevArray {
     double m_value = 0.0;                // ... this one (a push of m, or an update that skips the reduction, forgets it)
     int nnps_slot = -1;                  // position in the last sph_nnps_update list
     size_t perm_n = 0;                   // particles `perm` was built for (0: none / already applied)
+    DevBuf slot8;                        // merged order only (sph_ctx::merged): uint8 nnps slot of every particle's array
 };
 
 // ghost selection lists of one array (sph_halo.hip)
@@ -67,7 +68,7 @@ struct HaloState {
 
 // T_PAIR: every pair launch; T_PAIR_FAM + family (sph_eval.hip enum Family): the same launches per equation family
 // T_N_*: launch counters only (no time): pair launches on EOS-fused records, launches that kept / reused neighbour lists
-enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_STAGE, T_PAIR_FAM, T_N_EOSF = T_PAIR_FAM + 6, T_N_NLKEEP, T_N_NLREUSE, T_N_UMASS, T_COUNT };
+enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_STAGE, T_PAIR_FAM, T_N_EOSF = T_PAIR_FAM + 6, T_N_NLKEEP, T_N_NLREUSE, T_N_UMASS, T_N_MERGED, T_COUNT };
 
 struct Timer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -99,6 +100,13 @@ struct sph_ctx {
     long n_cells = 0;
     bool uniform_h = false; // hmin == hmax over all arrays
     double h_uniform = 0;
+    // ONE cell order over the particles of ALL arrays of the grid (several arrays only; option merge_arrays): the array's
+    // slot is the LEAST significant part of the sort key, so the particles of every array interleave per x sub-bin and a
+    // row of cells is one contiguous run of the merged order.  `merged` uses the DevArray fields fkeys_sorted, keys_sorted,
+    // perm (merged position -> original index in its own array), slot8, fine_start and the tile order; n = all particles.
+    DevArray merged;
+    bool merged_valid = false;
+    long merge_arrays = 1;
 
     // scratch
     DevBuf cub_tmp, red_part, red_out, posh, aux, fposb, dkeys, dperm, tmp_u32a, tmp_u32b, gen_state, gapq;
@@ -125,6 +133,8 @@ struct sph_ctx {
     int cur_nrec = 0;       // doubles per packed record of the pair launch being set up
     bool cur_eosf = false;  // the pair launch being set up reads the 64-byte WCSPH records (EOS recomputed per record)
     bool cur_umass = false; // ... with p / rho^2 in the mass slot (every source array has one mass)
+    bool cur_elu = false;   // ... the elastic-rates records without h and m (uniform h, one mass per source array)
+    bool cur_tvff = false;  // the pair launch being set up reads the state-fused TVF records (p and V recomputed from rho)
     long mass_fuse = 1;     // allow that
     bool want_mrange = false; // an evaluation could have used uniform-mass records: the next neighbour updates look at the masses
     long block_sorted_outputs = 0;

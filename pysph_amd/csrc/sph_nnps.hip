@@ -289,6 +289,43 @@ __global__ __launch_bounds__(256) void k_fill_gaps(const uint32_t *__restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------
+// ONE cell order over all arrays (sph_ctx::merged): the per-array orders merged by (fine key, slot).  Sorted
+// particle i of array a lands at its own rank plus, from every other array b, the number of b's particles in
+// front of it -- those with a smaller fine key, and for b < a those with the same one: two fine_start reads per
+// other array, monotonic in i (coalesced).  The merged fine_start is the sum of the arrays' tables.
+// ---------------------------------------------------------------------------
+struct MergeTabs { const uint32_t *fine_start[SPH_MAX_ARRAYS]; int narrays; };
+
+__global__ __launch_bounds__(256) void k_merge_scatter(const uint32_t *__restrict__ fkeys, const uint32_t *__restrict__ perm, size_t n,
+                                                       int a, MergeTabs t, uint32_t *__restrict__ m_fkeys,
+                                                       uint32_t *__restrict__ m_keys, uint32_t *__restrict__ m_perm,
+                                                       uint8_t *__restrict__ m_slot)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t f = fkeys[i];
+    size_t p = i;
+#pragma unroll
+    for (int b = 0; b < SPH_MAX_ARRAYS; b++)
+        if (b < t.narrays && b != a) p += t.fine_start[b][f + (b < a ? 1u : 0u)];
+    m_fkeys[p] = f;
+    m_keys[p] = f / SPH_NSUB;
+    m_perm[p] = perm[i];
+    m_slot[p] = (uint8_t)a;
+}
+
+__global__ __launch_bounds__(256) void k_merge_fine_start(MergeTabs t, size_t ntab, uint32_t *__restrict__ out)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ntab) return;
+    uint32_t s = 0;
+#pragma unroll
+    for (int b = 0; b < SPH_MAX_ARRAYS; b++)
+        if (b < t.narrays) s += t.fine_start[b][k];
+    out[k] = s;
+}
+
 __global__ __launch_bounds__(256) void k_fill_u32(uint32_t *p, size_t n, uint32_t v)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -307,6 +344,40 @@ extern "C" int sph_nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *
     if (!c || narrays < 1 || narrays > SPH_MAX_ARRAYS) { sph_set_error("sph_nnps_minmax: bad arguments"); return SPH_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
     return nnps_minmax(c, narrays, ids, out8);
+}
+
+// Traversal order of the 256-particle destination tiles of one (cell-sorted) array: only worth it when there is more than
+// one z plane of tiles.  The order is a permutation of the tile ids that only steers locality: any permutation of the same
+// nt tiles gives the same results.  Particles move a fraction of a cell per step, so the order of the last build stays
+// good: rebuilt when the tile count or the grid changed and every 16th update.
+static int nnps_tile_order(sph_ctx *c, DevArray &A, size_t n)
+{
+    const bool want_tiles = c->tile_block_rows > 0 && c->nc[2] > 1 && n > 64 * SPH_TILE;
+    const int tsig = (int)c->tile_block_rows;
+    const uint32_t nt_now = (uint32_t)div_up(n, SPH_TILE);
+    if (want_tiles && A.n_tiles == nt_now && A.tile_grid[0] == c->nc[0] && A.tile_grid[1] == c->nc[1] &&
+        A.tile_grid[2] == c->nc[2] && A.tile_grid[3] == tsig && ++A.tile_age < 16)
+        return SPH_OK;
+    A.n_tiles = 0;
+    if (want_tiles) {
+        A.tile_age = 0;
+        A.tile_grid[0] = c->nc[0]; A.tile_grid[1] = c->nc[1]; A.tile_grid[2] = c->nc[2]; A.tile_grid[3] = tsig;
+        const uint32_t nt = nt_now;
+        SPH_TRY(A.tile_key.reserve((size_t)nt * 4 * 2));
+        SPH_TRY(A.tile_id.reserve((size_t)nt * 4));
+        SPH_TRY(A.tile_order.reserve((size_t)nt * 4));
+        uint32_t *tk = A.tile_key.as<uint32_t>(), *tk2 = tk + nt;
+        hipLaunchKernelGGL(k_tile_keys, dim3(div_up(nt, 256)), dim3(256), 0, c->stream, A.keys_sorted.as<uint32_t>(), n, nt,
+                           c->nc[0], c->nc[1], c->nc[2], (int)c->tile_block_rows, tk, A.tile_id.as<uint32_t>());
+        size_t tb2 = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, tk, tk2, A.tile_id.as<uint32_t>(),
+                                                   A.tile_order.as<uint32_t>(), (int)nt, 0, 32, c->stream));
+        SPH_TRY(c->cub_tmp.reserve(tb2));
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.ptr, tb2, tk, tk2, A.tile_id.as<uint32_t>(),
+                                                   A.tile_order.as<uint32_t>(), (int)nt, 0, 32, c->stream));
+        A.n_tiles = nt;
+    }
+    return SPH_OK;
 }
 
 extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids, double radius_scale,
@@ -493,36 +564,32 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
         hipLaunchKernelGGL(k_coarse_start, dim3(div_up((size_t)n_cells_alloc + 1, 256)), dim3(256), 0, c->stream,
                            A.fine_start.as<uint32_t>(), (uint32_t)n_cells_alloc, A.cell_start.as<uint32_t>(),
                            c->gapq.as<uint32_t>());
-        // tile traversal order (only worth it when there is more than one z plane of tiles)
-        // The order is a permutation of the tile ids that only steers locality: any permutation of the same nt
-        // tiles gives the same results.  Particles move a fraction of a cell per step, so the order of the last
-        // build stays good: rebuilt when the tile count or the grid changed and every 16th update.
-        const bool want_tiles = c->tile_block_rows > 0 && c->nc[2] > 1 && n > 64 * SPH_TILE;
-        const int tsig = (int)c->tile_block_rows;
-        const uint32_t nt_now = (uint32_t)div_up(n, SPH_TILE);
-        if (want_tiles && A.n_tiles == nt_now && A.tile_grid[0] == c->nc[0] && A.tile_grid[1] == c->nc[1] &&
-            A.tile_grid[2] == c->nc[2] && A.tile_grid[3] == tsig && ++A.tile_age < 16) {
-            continue;
+        SPH_TRY(nnps_tile_order(c, A, n));
+    }
+    // the merged order of all arrays (one record stream per multi-array evaluation, sph_eval.hip)
+    c->merged_valid = false;
+    if (cat && c->merge_arrays && n_cat < (1ull << 32)) {
+        DevArray &M = c->merged;
+        M.n = M.n_real = n_cat;
+        SPH_TRY(M.fkeys_sorted.reserve((n_cat + 1) * 4));
+        SPH_TRY(M.keys_sorted.reserve((n_cat + 1) * 4));
+        SPH_TRY(M.perm.reserve((n_cat + 1) * 4));
+        SPH_TRY(M.slot8.reserve(n_cat + 64));
+        SPH_TRY(M.fine_start.reserve((n_fine + 1) * 4));
+        MergeTabs mt;
+        mt.narrays = narrays;
+        for (int a = 0; a < SPH_MAX_ARRAYS; a++) mt.fine_start[a] = a < narrays ? c->arr[ids[a]].fine_start.as<uint32_t>() : nullptr;
+        for (int a = 0; a < narrays; a++) {
+            DevArray &A = c->arr[ids[a]];
+            if (A.n == 0) continue;
+            hipLaunchKernelGGL(k_merge_scatter, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, A.fkeys_sorted.as<uint32_t>(),
+                               A.perm.as<uint32_t>(), A.n, a, mt, M.fkeys_sorted.as<uint32_t>(), M.keys_sorted.as<uint32_t>(),
+                               M.perm.as<uint32_t>(), M.slot8.as<uint8_t>());
         }
-        A.n_tiles = 0;
-        if (want_tiles) {
-            A.tile_age = 0;
-            A.tile_grid[0] = c->nc[0]; A.tile_grid[1] = c->nc[1]; A.tile_grid[2] = c->nc[2]; A.tile_grid[3] = tsig;
-            const uint32_t nt = nt_now;
-            SPH_TRY(A.tile_key.reserve((size_t)nt * 4 * 2));
-            SPH_TRY(A.tile_id.reserve((size_t)nt * 4));
-            SPH_TRY(A.tile_order.reserve((size_t)nt * 4));
-            uint32_t *tk = A.tile_key.as<uint32_t>(), *tk2 = tk + nt;
-            hipLaunchKernelGGL(k_tile_keys, dim3(div_up(nt, 256)), dim3(256), 0, c->stream, A.keys_sorted.as<uint32_t>(), n, nt,
-                               c->nc[0], c->nc[1], c->nc[2], (int)c->tile_block_rows, tk, A.tile_id.as<uint32_t>());
-            size_t tb2 = 0;
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, tk, tk2, A.tile_id.as<uint32_t>(),
-                                                       A.tile_order.as<uint32_t>(), (int)nt, 0, 32, c->stream));
-            SPH_TRY(c->cub_tmp.reserve(tb2));
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.ptr, tb2, tk, tk2, A.tile_id.as<uint32_t>(),
-                                                       A.tile_order.as<uint32_t>(), (int)nt, 0, 32, c->stream));
-            A.n_tiles = nt;
-        }
+        hipLaunchKernelGGL(k_merge_fine_start, dim3(div_up(n_fine + 1, 256)), dim3(256), 0, c->stream, mt, n_fine + 1,
+                           M.fine_start.as<uint32_t>());
+        SPH_TRY(nnps_tile_order(c, M, n_cat));
+        c->merged_valid = true;
     }
     HIP_TRY(hipGetLastError());
     c->nnps_valid = true;

@@ -68,6 +68,7 @@ template <class Fam> struct PairArgs {
     double dom_extent;  // largest grid extent: bounds the fp32 rounding of fpos
     uint32_t d_off, nd;
     const uint32_t *d_keys, *d_fkeys, *d_perm; // cell ids / fine keys of the sorted destinations, sorted -> original index
+    const uint8_t *d_slot; // merged order (families with MERGED): the array (nnps slot) of every sorted destination
     const uint32_t *d_tile_order; // traversal order of the destination tiles (null: memory order)
     int row_mod3;      // order in which a wavefront visits its 3x3 rows of cells: bit 0 / bit 1 -- step (sy, sz) takes the
                        // row whose y / z is congruent to the step modulo 3, so that ALL wavefronts in flight walk rows of
@@ -97,6 +98,21 @@ template <class Fam> struct PairArgs {
     double e_rho01, e_c0, e_B, e_p0;
     typename Fam::Params p;
 };
+
+// does the family run on the merged order of all arrays (destinations of several arrays in one launch; per-slot
+// destination ranges and output pointers in Fam::Params, read per lane with kernarg_read)?
+template <class F, class = void> struct fam_merged { static constexpr bool value = false; };
+template <class F> struct fam_merged<F, decltype((void)F::MERGED)> { static constexpr bool value = F::MERGED; };
+
+// A per-lane (dynamically indexed) read of the kernel's own by-value argument struct, straight from the kernarg
+// segment: `byte_offset` is the offset of the element inside the (single) kernel argument.  Indexing the by-value
+// struct itself with a lane-dependent index could make the compiler copy the table to scratch first.  Scalar V only.
+template <class V> __device__ __forceinline__ V kernarg_read(size_t byte_offset)
+{
+    typedef const char __attribute__((address_space(4))) *kptr;
+    const kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    return *reinterpret_cast<const V __attribute__((address_space(4))) *>(ka + byte_offset);
+}
 
 // does the family recompute p, cs from rho (64-byte WCSPH records)?
 template <class F, class = void> struct fam_eosf { static constexpr bool value = false; };
@@ -353,7 +369,17 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     const bool valid = i < a.nd;
     const uint32_t ic = valid ? i : a.nd - 1;
     const uint32_t o = a.d_perm[ic];
-    const bool active = valid && o >= a.d_start && o < a.d_stop;
+    uint32_t slot = 0;
+    bool active;
+    if constexpr (fam_merged<Fam>::value) {
+        // destinations of several arrays: this lane's array decides its index range (Group.real / start_idx / stop_idx;
+        // an array without equations as destination has an empty one) and, in finish(), where its results go
+        slot = a.d_slot[ic];
+        const unsigned long long rg = kernarg_read<unsigned long long>(__builtin_offsetof(PairArgs<Fam>, p) + Fam::rng_offset(slot));
+        active = valid && o >= (uint32_t)rg && o < (uint32_t)(rg >> 32);
+    } else {
+        active = valid && o >= a.d_start && o < a.d_stop;
+    }
     real4<T> pi;
     typename Fam::Dest D;
     T cur_mu = T(0.0); // mass of the source being read (uniform-mass records)
@@ -369,7 +395,8 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
         // (uniform h: the constant; p only for the tensile correction)
         fetch(a.d_off + ic, a.dflags, pi, sd_);
         if (UH) pi.w = (T)a.hu;
-        Fam::load(D, sd_, a, o);
+        if constexpr (fam_merged<Fam>::value) Fam::load(D, sd_, a, o, slot);
+        else Fam::load(D, sd_, a, o);
     }
     const uint32_t fkey = a.d_fkeys[ic];
     const uint32_t key = fkey / SPH_NSUB;
@@ -623,6 +650,9 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     resumed = true;
     }
     }
-    if (active) Fam::finish(D, a, o);
+    if (active) {
+        if constexpr (fam_merged<Fam>::value) Fam::finish(D, a, o, slot);
+        else Fam::finish(D, a, o);
+    }
 }
 

@@ -261,6 +261,7 @@ def test_fixed_h_range_is_per_nnps_not_per_context():
     # another problem on the same context: larger, NON-uniform h, not fixed
     pb, _ = make_cube(10)
     pc, _ = make_cube(10)
+    pb.name = 'other'            # a context mirrors ONE array per name
     rng = np.random.default_rng(3)
     hb = pb.h * (1.5 + 0.3 * rng.uniform(-1, 1, pb.get_number_of_particles()))
     pb.h[:] = hb

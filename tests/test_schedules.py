@@ -8,6 +8,9 @@
 * ``norm_masks`` -- a row's hit bits shifted down to the lane's first hit;
 * ``mass_fuse`` -- EOS-fused records whose mass slot carries p / rho^2 when every
   source array has ONE mass (seen by the neighbour update's reduction);
+* ``merge_arrays`` -- a WCSPH group over several arrays (a dam break) as ONE launch
+  over the merged cell order of all arrays, the per-source equation difference as
+  a class bit in the record (round 4);
 * ``row_mod3``  -- the order in which a wavefront visits its 3x3 rows of cells
   (the sums of a destination are taken in that order: equal to rounding).
 
@@ -51,7 +54,7 @@ def _run(argv, opts, steps=2):
         for f in w.fields:
             if f in pa.properties:
                 out[pa.name + '.' + f] = np.array(pa.get(f)[:nreal])
-    cnt = {k: ctx.timer_get(k)[1] for k in ('n_eos_fused', 'n_nl_keep', 'n_nl_reuse', 'n_mass_fused')}
+    cnt = {k: ctx.timer_get(k)[1] for k in ('n_eos_fused', 'n_nl_keep', 'n_nl_reuse', 'n_mass_fused', 'n_merged')}
     res = bench.parity_check(w, host_in, nnps, domain,
                              bench.PARITY_TOL if args.dtype == 'f64' else 5e-5)
     del nnps, a_eval, step
@@ -222,3 +225,74 @@ def test_a_push_of_the_masses_forgets_their_uniformity():
     assert res['parity_ok'], res
     del nnps, a_eval, step
     ctx.close()
+
+
+# ---------------------------------------------------------------------------
+# round 4: several arrays as ONE record stream (sph_ctx::merged, FamWCSPHM_T)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('argv', [['--workload', 'dam_break', '--dx', '0.03'],
+                                  ['--workload', 'dam_break', '--dx', '0.03', '--no-reorder'],
+                                  ['--workload', 'dam_break', '--dx', '0.02', '--dtype', 'f32']],
+                         ids=['dam-break', 'dam-break-unsorted', 'dam-break-fp32'])
+def test_merged_arrays_match_per_destination_path(argv):
+    """fluid <- {fluid, boundary, obstacle} and walls <- fluid in one launch over the
+    merged order against the per-destination launches: the same pairs (neighbour
+    counts exact on both), sums associated differently (all arrays in cell order
+    instead of source by source), so equal to rounding; both against the oracle."""
+    f32 = '--dtype' in argv
+    on, c_on, r_on = _run(argv, {}, steps=3)
+    off, c_off, r_off = _run(argv, {'merge_arrays': 0}, steps=3)
+    # the first evaluation has not seen the masses yet; from the second on ONE pair launch per evaluation (n_merged counts them)
+    assert c_on['n_merged'] == 2 and c_off['n_merged'] == 0, (c_on, c_off)
+    assert r_on['parity_neighbour_count_mismatches'] == 0 and r_off['parity_neighbour_count_mismatches'] == 0
+    if f32:
+        assert r_on['parity_max_rel'] < 5e-5 and r_off['parity_max_rel'] < 5e-5, (r_on, r_off)
+        assert _max_rel(on, off) < 5e-5
+    else:
+        assert r_on['parity_ok'] and r_off['parity_ok'], (r_on, r_off)
+        assert _max_rel(on, off) < 1e-13
+
+
+def test_merged_arrays_not_taken_without_the_promises():
+    """variable h (no 64-byte records) keeps the per-destination path"""
+    import bench
+    args = ['--workload', 'dam_break', '--dx', '0.03', '--opt', 'uniform_h=0']
+    out, cnt, res = _run(args, {}, steps=3)
+    assert cnt['n_merged'] == 0 and res['parity_ok'], (cnt, res)
+
+
+def test_merged_arrays_with_masses_per_class():
+    """walls of another (uniform) mass than the fluid: the class carries its mass;
+    walls whose masses differ among themselves: no uniform mass per class, the
+    per-destination path runs -- same results either way"""
+    import torch
+    import bench
+    from pysph_amd import device as dev
+
+    def run(scale_boundary, scale_obstacle):
+        args = bench.parse_args(['--workload', 'dam_break', '--dx', '0.03', '--no-cpu-baseline', '--no-extras'])
+        ctx = dev.HipContext(0, torch.cuda.current_stream().cuda_stream)
+        bench.apply_options(args, ctx)
+        w = bench.build_workload(args, 0, 1)
+        for a in w.arrays:
+            if a.name == 'boundary':
+                a.m[:] = a.m * scale_boundary
+            if a.name == 'obstacle':
+                a.m[:] = a.m * scale_obstacle
+        nnps, a_eval, halo, domain, step, ordered = bench.setup(args, w, 0, 1, None, ctx)
+        for a in w.arrays:
+            a.gpu.pull()
+        host_in = bench.copy_arrays(w.arrays)
+        for _ in range(3):
+            step()
+        n_merged = ctx.timer_get('n_merged')[1]
+        res = bench.parity_check(w, host_in, nnps, domain)
+        del nnps, a_eval, step
+        ctx.close()
+        torch.cuda.empty_cache()
+        return n_merged, res
+
+    n, res = run(1.25, 1.25)
+    assert n == 2 and res['parity_ok'], (n, res)
+    n, res = run(1.25, 0.75)
+    assert n == 0 and res['parity_ok'], (n, res)
