@@ -133,13 +133,13 @@ int sph_ctx_destroy(sph_ctx *c)
     }
     {
         DevArray &A = c->merged;
-        A.keys_sorted.release(); A.perm.release(); A.fkeys_sorted.release(); A.fine_start.release(); A.slot8.release();
+        A.keys_sorted.release(); A.perm.release(); A.fkeys_sorted.release(); A.fine_start.release(); A.slot8.release(); A.cell_start.release();
         A.tile_key.release(); A.tile_id.release(); A.tile_order.release();
     }
     for (auto &H : c->halo)
         for (int s = 0; s < 2; s++) { H.flag[s].release(); H.pos[s].release(); H.list[s].release(); }
     for (DevBuf *b : {&c->dbgc, &c->gapq, &c->cub_tmp, &c->red_part, &c->red_out, &c->posh, &c->aux, &c->fposb, &c->dkeys, &c->dperm,
-                      &c->tmp_u32a, &c->tmp_u32b, &c->gen_state, &c->nlbuf})
+                      &c->tmp_u32a, &c->tmp_u32b, &c->gen_state, &c->nlbuf, &c->splitcnt})
         b->release();
     for (auto &b : c->csr_start) b.release();
     for (auto &b : c->csr_nbrs) b.release();
@@ -299,6 +299,7 @@ int sph_set_option(sph_ctx *c, const char *key, long value)
     if (strcmp(key, "nl_reuse") == 0) { c->nl_reuse = value; c->nl.valid = false; return SPH_OK; }
     if (strcmp(key, "norm_masks") == 0) { c->norm_masks = value; return SPH_OK; }
     if (strcmp(key, "merge_arrays") == 0) { c->merge_arrays = value ? 1 : 0; c->nnps_valid = false; return SPH_OK; }
+    if (strcmp(key, "lazy_tables") == 0) { c->lazy_tables = value ? 1 : 0; c->nnps_valid = false; return SPH_OK; }
     sph_set_error("sph_set_option: unknown key '%s'", key);
     return SPH_ERR_ARG;
 }

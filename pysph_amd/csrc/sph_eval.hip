@@ -1521,6 +1521,7 @@ static int ensure_out(sph_ctx *c, int id, std::initializer_list<int> props)
 // sph_nnps_get_csr): count pass (count[nd] filled, start == nullptr) or fill pass (start[nd], nbrs filled).
 int nnps_csr_pair_kernel(sph_ctx *c, int src, int dst, uint32_t *count, const uint32_t *start, uint32_t *nbrs)
 {
+    SPH_TRY(nnps_need_tables(c));
     DevArray &S = c->arr[src], &D = c->arr[dst];
     if (D.n == 0) return SPH_OK;
     const bool uh = c->uniform_h && c->use_uniform_h;
@@ -1698,6 +1699,7 @@ static int eval_group_merged(sph_ctx *c, const sph_kernel *K, const sph_group *g
         a.nsrc = 1;
         a.src[0] = {nullptr, 0u, ct, M.fine_start.as<uint32_t>(), mu[0]};
         a.d_off = 0; a.nd = (uint32_t)M.n;
+        a.d_mu = mu[0];
         a.d_keys = M.keys_sorted.as<uint32_t>(); a.d_fkeys = M.fkeys_sorted.as<uint32_t>(); a.d_perm = M.perm.as<uint32_t>();
         a.d_slot = M.slot8.as<uint8_t>();
         set_tile_order(c, a, M);
@@ -1822,6 +1824,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         if (fam == FAM_NONE) continue;
         if (!c->nnps_valid) { sph_set_error("sph_eval_group: neighbour grid is stale; call sph_nnps_update"); return SPH_ERR_STATE; }
         if (D.nnps_slot < 0) { sph_set_error("destination array %d is not part of the neighbour grid", dst); return SPH_ERR_STATE; }
+        SPH_TRY(nnps_need_tables(c)); // the per-destination path reads every array's own cell order
         uint32_t dflags = 0;
         for (int j = 0; j < nsrcs; j++) {
             dflags |= sflags[j];
@@ -1877,7 +1880,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         // TVF force pass after StateEquation + density summation (sph_group.src_eos = 2): p and V leave the records
         // when every array read here has ONE mass (V = rho / m)
         bool tvff = g->src_eos == 2 && c->eos_fuse && c->mass_fuse && fam == FAM_TVF && c->pair_variant == 6 && c->uniform_h &&
-                    c->use_uniform_h && !(dflags & F_TAV) && !c->record_f32 && g->eos_par[1] != 0.0;
+                    c->use_uniform_h && !c->record_f32 && g->eos_par[1] != 0.0; // (the artificial viscosity's m_j is the source's one mass)
         if (tvff) c->want_mrange = true;
         for (int j = 0; j < nsrcs && tvff; j++) tvff = c->arr[srcs[j]].m_known;
         if (tvff && !dest_is_src) tvff = D.m_known;
@@ -1954,6 +1957,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             a.nsrc = nsrcs;
             for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j], c->arr[srcs[j]].fine_start.as<uint32_t>(), c->arr[srcs[j]].m_value};
             a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
+            a.d_mu = D.m_value;
             a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
             set_tile_order(c, a, D);
             a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
@@ -2229,6 +2233,7 @@ static int eval_generated_launches(sph_ctx *c, const sph_kernel *K, const sph_ge
         if (ns > 0) {
             if (!c->nnps_valid) { sph_set_error("sph_eval_generated: neighbour grid is stale; call sph_nnps_update"); return SPH_ERR_STATE; }
             if (D.nnps_slot < 0) { sph_set_error("destination array %d is not part of the neighbour grid", dst); return SPH_ERR_STATE; }
+            SPH_TRY(nnps_need_tables(c));
             size_t total = 0, off_of[SPH_MAX_ARRAYS];
             bool dest_is_src = false;
             for (int jj = 0; jj < ns; jj++) {

@@ -107,6 +107,11 @@ struct sph_ctx {
     DevArray merged;
     bool merged_valid = false;
     long merge_arrays = 1;
+    // ... built FIRST by sph_nnps_update (one stable sort of all arrays' keys); the per-array orders and tables are a
+    // stable compaction of it by slot, made when something first asks for them (nnps_need_tables)
+    bool tables_valid = true;
+    long lazy_tables = 1;
+    DevBuf splitcnt;
 
     // scratch
     DevBuf cub_tmp, red_part, red_out, posh, aux, fposb, dkeys, dperm, tmp_u32a, tmp_u32b, gen_state, gapq;
@@ -165,6 +170,7 @@ struct ScopedTimer {
 
 // nnps.hip
 int nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *out8);
+int nnps_need_tables(sph_ctx *c); // per-array cell orders / tables of a merged-first update, on first use
 int nnps_build_csr_device(sph_ctx *c, int src, int dst, DevBuf &start, DevBuf &nbrs, size_t *total);
 // eval.hip: the same lists through the wave-tile pair kernel (count pass: start == nullptr; fill pass: start, nbrs)
 int nnps_csr_pair_kernel(sph_ctx *c, int src, int dst, uint32_t *count, const uint32_t *start, uint32_t *nbrs);

@@ -173,7 +173,7 @@ struct GridDesc {
 __global__ __launch_bounds__(256) void k_cell_keys(const double *__restrict__ x, const double *__restrict__ y,
                                                    const double *__restrict__ z, size_t n, GridDesc g,
                                                    uint32_t *__restrict__ keys, uint32_t *__restrict__ idx,
-                                                   uint32_t tag = 0u)
+                                                   uint32_t tag, uint32_t idx_base)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_cell_keys(const double *__restrict__ x,
     cy = min(max(cy, 0), g.nc[1] - 1);
     cz = min(max(cz, 0), g.nc[2] - 1);
     keys[i] = ((uint32_t)(cx + g.nc[0] * (cy + g.nc[1] * cz)) * SPH_NSUB + (uint32_t)sub) | tag;
-    idx[i] = (uint32_t)i;
+    idx[i] = (uint32_t)i + idx_base; // position in the concatenation of all arrays (merged-first build), else the local index
 }
 
 // one array's segment of the concatenated sort: strip the array tag, split into the array's own tables
@@ -289,43 +289,6 @@ __global__ __launch_bounds__(256) void k_fill_gaps(const uint32_t *__restrict__ 
     }
 }
 
-// ---------------------------------------------------------------------------
-// ONE cell order over all arrays (sph_ctx::merged): the per-array orders merged by (fine key, slot).  Sorted
-// particle i of array a lands at its own rank plus, from every other array b, the number of b's particles in
-// front of it -- those with a smaller fine key, and for b < a those with the same one: two fine_start reads per
-// other array, monotonic in i (coalesced).  The merged fine_start is the sum of the arrays' tables.
-// ---------------------------------------------------------------------------
-struct MergeTabs { const uint32_t *fine_start[SPH_MAX_ARRAYS]; int narrays; };
-
-__global__ __launch_bounds__(256) void k_merge_scatter(const uint32_t *__restrict__ fkeys, const uint32_t *__restrict__ perm, size_t n,
-                                                       int a, MergeTabs t, uint32_t *__restrict__ m_fkeys,
-                                                       uint32_t *__restrict__ m_keys, uint32_t *__restrict__ m_perm,
-                                                       uint8_t *__restrict__ m_slot)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t f = fkeys[i];
-    size_t p = i;
-#pragma unroll
-    for (int b = 0; b < SPH_MAX_ARRAYS; b++)
-        if (b < t.narrays && b != a) p += t.fine_start[b][f + (b < a ? 1u : 0u)];
-    m_fkeys[p] = f;
-    m_keys[p] = f / SPH_NSUB;
-    m_perm[p] = perm[i];
-    m_slot[p] = (uint8_t)a;
-}
-
-__global__ __launch_bounds__(256) void k_merge_fine_start(MergeTabs t, size_t ntab, uint32_t *__restrict__ out)
-{
-    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= ntab) return;
-    uint32_t s = 0;
-#pragma unroll
-    for (int b = 0; b < SPH_MAX_ARRAYS; b++)
-        if (b < t.narrays) s += t.fine_start[b][k];
-    out[k] = s;
-}
-
 __global__ __launch_bounds__(256) void k_fill_u32(uint32_t *p, size_t n, uint32_t v)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -344,6 +307,183 @@ extern "C" int sph_nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *
     if (!c || narrays < 1 || narrays > SPH_MAX_ARRAYS) { sph_set_error("sph_nnps_minmax: bad arguments"); return SPH_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
     return nnps_minmax(c, narrays, ids, out8);
+}
+
+// ---------------------------------------------------------------------------
+// merged-first build (sph_nnps_update) and the per-array tables derived from it on demand
+// ---------------------------------------------------------------------------
+struct CatOff { uint32_t off[SPH_MAX_ARRAYS + 1]; int narrays; }; // first position of every array in the concatenation
+
+// The merged order straight from the ONE stable sort of all arrays' fine keys: the sorted value is the particle's
+// position in the concatenation of the arrays -> its slot and its original index there.
+__global__ __launch_bounds__(256) void k_merged_split(const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ svals, size_t n,
+                                                      CatOff co, uint32_t *__restrict__ fkeys, uint32_t *__restrict__ keys,
+                                                      uint32_t *__restrict__ perm, uint8_t *__restrict__ slot)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t f = skeys[i], gpos = svals[i];
+    uint32_t s = 0, base = 0;
+#pragma unroll
+    for (int b = 1; b < SPH_MAX_ARRAYS; b++)
+        if (b < co.narrays && gpos >= co.off[b]) { s = (uint32_t)b; base = co.off[b]; }
+    fkeys[i] = f;
+    keys[i] = f / SPH_NSUB;
+    perm[i] = gpos - base;
+    slot[i] = (uint8_t)s;
+}
+
+// Stable compaction of the merged order by slot = every array's own cell order: count per block of SPLIT_BLOCK merged
+// positions and slot, exclusive scan per slot over the blocks, scatter with the ranks re-derived from wavefront ballots.
+#define SPLIT_BLOCK 1024
+struct SplitOut { uint32_t *fkeys[SPH_MAX_ARRAYS], *keys[SPH_MAX_ARRAYS], *perm[SPH_MAX_ARRAYS]; int narrays; };
+
+__global__ __launch_bounds__(256) void k_slot_count(const uint8_t *__restrict__ slot, size_t n, int narrays, uint32_t nb,
+                                                    uint32_t *__restrict__ blockcnt)
+{
+    __shared__ uint32_t cnt[SPH_MAX_ARRAYS];
+    if (threadIdx.x < SPH_MAX_ARRAYS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int r = 0; r < SPLIT_BLOCK / 256; r++) {
+        const size_t p = (size_t)blockIdx.x * SPLIT_BLOCK + (size_t)r * 256 + threadIdx.x;
+        const int s = p < n ? (int)slot[p] : -1;
+        for (int b = 0; b < narrays; b++) {
+            const unsigned long long m = __ballot(s == b);
+            if (lane == 0 && m) atomicAdd(&cnt[b], (uint32_t)__builtin_popcountll(m));
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < narrays) blockcnt[(size_t)threadIdx.x * nb + blockIdx.x] = cnt[threadIdx.x];
+}
+
+// exclusive scan of row blockIdx.x (one slot) of blockcnt[narrays][nb], in place
+__global__ __launch_bounds__(1024) void k_slot_scan(uint32_t *__restrict__ blockcnt, uint32_t nb)
+{
+    __shared__ uint32_t ws[17];
+    uint32_t *row = blockcnt + (size_t)blockIdx.x * nb;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nb; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nb ? row[i] : 0u;
+        uint32_t x = v;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(x, o, 64); if (lane >= o) x += t; }
+        if (lane == 63) ws[wave] = x;
+        __syncthreads();
+        if (wave == 0) {
+            const uint32_t w = lane < 16 ? ws[lane] : 0u;
+            uint32_t y = w;
+            for (int o = 1; o < 16; o <<= 1) { const uint32_t t = __shfl_up(y, o, 64); if (lane >= o) y += t; }
+            if (lane < 16) ws[lane] = y - w;
+            if (lane == 15) ws[16] = y;
+        }
+        __syncthreads();
+        if (i < nb) row[i] = carry + ws[wave] + x - v;
+        carry += ws[16];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_slot_scatter(const uint8_t *__restrict__ slot, const uint32_t *__restrict__ fkeys,
+                                                      const uint32_t *__restrict__ perm, size_t n, uint32_t nb,
+                                                      const uint32_t *__restrict__ blockoff, SplitOut o)
+{
+    __shared__ uint32_t run[SPH_MAX_ARRAYS], wcnt[4][SPH_MAX_ARRAYS];
+    if ((int)threadIdx.x < o.narrays) run[threadIdx.x] = blockoff[(size_t)threadIdx.x * nb + blockIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    for (int r = 0; r < SPLIT_BLOCK / 256; r++) {
+        const size_t p = (size_t)blockIdx.x * SPLIT_BLOCK + (size_t)r * 256 + threadIdx.x;
+        const int s = p < n ? (int)slot[p] : -1;
+        uint32_t rank = 0;
+        for (int b = 0; b < o.narrays; b++) {
+            const unsigned long long m = __ballot(s == b);
+            if (lane == 0) wcnt[wave][b] = (uint32_t)__builtin_popcountll(m);
+            if (s == b) rank = (uint32_t)__builtin_popcountll(m & lt);
+        }
+        __syncthreads();
+        if (s >= 0) {
+            uint32_t pos = run[s] + rank;
+            for (int w = 0; w < wave; w++) pos += wcnt[w][s];
+            const uint32_t f = fkeys[p], q = perm[p];
+#pragma unroll
+            for (int b = 0; b < SPH_MAX_ARRAYS; b++)
+                if (s == b) { o.fkeys[b][pos] = f; o.keys[b][pos] = f / SPH_NSUB; o.perm[b][pos] = q; }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < o.narrays) run[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
+        __syncthreads();
+    }
+}
+
+static int nnps_tile_order(sph_ctx *c, DevArray &A, size_t n);
+
+static int nnps_reserve_tables(sph_ctx *c, DevArray &A)
+{
+    const size_t n = A.n, n_fine = (size_t)c->n_cells * SPH_NSUB;
+    SPH_TRY(A.keys_sorted.reserve((n + 1) * 4));
+    SPH_TRY(A.perm.reserve((n + 1) * 4));
+    SPH_TRY(A.fkeys_sorted.reserve((n + 1) * 4));
+    SPH_TRY(A.cell_start.reserve(((size_t)c->n_cells + 1) * 4));
+    SPH_TRY(A.fine_start.reserve((n_fine + 1) * 4));
+    return SPH_OK;
+}
+
+static void nnps_empty_tables(sph_ctx *c, DevArray &A)
+{
+    const size_t n_fine = (size_t)c->n_cells * SPH_NSUB;
+    hipLaunchKernelGGL(k_fill_u32, dim3(div_up((size_t)c->n_cells + 1, 256)), dim3(256), 0, c->stream, A.cell_start.as<uint32_t>(),
+                       (size_t)c->n_cells + 1, 0u);
+    hipLaunchKernelGGL(k_fill_u32, dim3(div_up(n_fine + 1, 256)), dim3(256), 0, c->stream, A.fine_start.as<uint32_t>(), n_fine + 1, 0u);
+}
+
+// fine_start / cell_start (and, `with_keys`, the cell ids) of one array from its sorted fine keys; its tile order
+static int nnps_finish_tables(sph_ctx *c, DevArray &A, bool with_keys)
+{
+    const size_t n = A.n, n_fine = (size_t)c->n_cells * SPH_NSUB;
+    hipLaunchKernelGGL(k_cell_start, dim3(div_up(n + 1, 256)), dim3(256), 0, c->stream, A.fkeys_sorted.as<uint32_t>(), n,
+                       (uint32_t)n_fine, A.fine_start.as<uint32_t>(), c->gapq.as<uint32_t>(),
+                       with_keys ? A.keys_sorted.as<uint32_t>() : (uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_fill_gaps, dim3(512), dim3(256), 0, c->stream, c->gapq.as<uint32_t>(), A.fine_start.as<uint32_t>());
+    hipLaunchKernelGGL(k_coarse_start, dim3(div_up((size_t)c->n_cells + 1, 256)), dim3(256), 0, c->stream,
+                       A.fine_start.as<uint32_t>(), (uint32_t)c->n_cells, A.cell_start.as<uint32_t>(), c->gapq.as<uint32_t>());
+    return nnps_tile_order(c, A, n);
+}
+
+// The per-array cell orders and tables of a merged-first update, built when first asked for (per-destination pair
+// paths, neighbour-list queries, reorder); a no-op otherwise.
+int nnps_need_tables(sph_ctx *c)
+{
+    if (!c->merged_valid || c->tables_valid) return SPH_OK;
+    DevArray &M = c->merged;
+    const int na = c->narrays;
+    const uint32_t nb = (uint32_t)div_up(M.n, SPLIT_BLOCK);
+    SPH_TRY(c->splitcnt.reserve((size_t)na * nb * 4 + 64));
+    SplitOut so;
+    memset(&so, 0, sizeof so);
+    so.narrays = na;
+    for (int a = 0; a < na; a++) {
+        DevArray &A = c->arr[c->ids[a]];
+        SPH_TRY(nnps_reserve_tables(c, A));
+        so.fkeys[a] = A.fkeys_sorted.as<uint32_t>(); so.keys[a] = A.keys_sorted.as<uint32_t>(); so.perm[a] = A.perm.as<uint32_t>();
+    }
+    if (M.n) {
+        uint32_t *bc = c->splitcnt.as<uint32_t>();
+        hipLaunchKernelGGL(k_slot_count, dim3(nb), dim3(256), 0, c->stream, M.slot8.as<uint8_t>(), M.n, na, nb, bc);
+        hipLaunchKernelGGL(k_slot_scan, dim3(na), dim3(1024), 0, c->stream, bc, nb);
+        hipLaunchKernelGGL(k_slot_scatter, dim3(nb), dim3(256), 0, c->stream, M.slot8.as<uint8_t>(), M.fkeys_sorted.as<uint32_t>(),
+                           M.perm.as<uint32_t>(), M.n, nb, bc, so);
+    }
+    for (int a = 0; a < na; a++) {
+        DevArray &A = c->arr[c->ids[a]];
+        if (A.n == 0) { nnps_empty_tables(c, A); continue; }
+        SPH_TRY(nnps_finish_tables(c, A, false));
+    }
+    HIP_TRY(hipGetLastError());
+    c->tables_valid = true;
+    return SPH_OK;
 }
 
 // Traversal order of the 256-particle destination tiles of one (cell-sorted) array: only worth it when there is more than
@@ -486,15 +626,27 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
     const size_t n_fine = (size_t)n_cells_alloc * SPH_NSUB;
     int end_bit = bits_for((long)n_fine);
 
-    // Several arrays (a dam break has three): ONE radix sort of all their keys, the array's slot in
-    // the bits above the cell key -- rocPRIM sorts fewer than 1 Mi keys with a merge sort of ~25
-    // launch pairs per array, which is what three separate sorts cost (nnps 0.40 ms of a 1.84-ms step)
-    size_t n_cat = 0, cat_off[SPH_MAX_ARRAYS] = {};
+    // Several arrays (a dam break has three): ONE radix sort of all their keys -- rocPRIM sorts fewer than 1 Mi keys
+    // with a merge sort of ~25 launch pairs per array, which is what three separate sorts cost.
+    //  * merged-first (option merge_arrays, default): the keys carry NO array tag.  The sort is stable and the arrays are
+    //    concatenated in slot order, so equal fine keys keep slot order: the sorted sequence IS the merged order of all
+    //    arrays (sph_ctx::merged) the multi-array pair kernel runs on; the sorted value (position in the concatenation)
+    //    gives slot and original index.  Per-array tables are derived from it only when something asks for them
+    //    (nnps_need_tables: per-destination pair paths, neighbour-list queries, reorder) -- a steady-state dam-break
+    //    step builds ONE fine_start table instead of four, with two sort bits less (a radix pass at 4 M particles).
+    //  * otherwise: the array's slot in the bits above the cell key, one segment of the sorted sequence per array.
+    size_t n_cat = 0, cat_off[SPH_MAX_ARRAYS + 1] = {};
     int tag_bits = 0, n_nonempty = 0;
     for (int a = 0; a < narrays; a++) { cat_off[a] = n_cat; n_cat += c->arr[ids[a]].n; n_nonempty += c->arr[ids[a]].n > 0; }
+    cat_off[narrays] = n_cat;
     while ((1 << tag_bits) < narrays) tag_bits++;
     const bool cat = n_nonempty > 1 && end_bit + tag_bits <= 32 && n_cat < (1ull << 31);
+    const bool merged_first = cat && c->merge_arrays;
     const size_t n_half = (n_cat + 63) & ~(size_t)63; // keys | values halves of the scratch buffers, 256-B aligned
+    if (!c->gapq.ptr) { // first use: the queue starts empty; afterwards k_coarse_start leaves it empty
+        SPH_TRY(c->gapq.reserve((4 + 3 * GAP_QUEUE) * 4));
+        HIP_TRY(hipMemsetAsync(c->gapq.ptr, 0, 16, c->stream));
+    }
     if (cat) {
         SPH_TRY(c->tmp_u32a.reserve((n_half + 64) * 4 * 2));
         SPH_TRY(c->tmp_u32b.reserve((n_half + 64) * 4 * 2));
@@ -504,36 +656,54 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
             if (A.n == 0) continue;
             hipLaunchKernelGGL(k_cell_keys, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, A.prop[SPH_X], A.prop[SPH_Y],
                                A.prop[SPH_Z], A.n, g, ck + cat_off[a], ci + cat_off[a],
-                               end_bit < 32 ? (uint32_t)a << end_bit : 0u);
+                               merged_first ? 0u : (end_bit < 32 ? (uint32_t)a << end_bit : 0u),
+                               merged_first ? (uint32_t)cat_off[a] : 0u);
         }
+        const int sort_bits = merged_first ? end_bit : end_bit + tag_bits;
         size_t tmp_bytes = 0;
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ck, cks, ci, cp, (int)n_cat, 0, end_bit + tag_bits,
-                                                   c->stream));
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ck, cks, ci, cp, (int)n_cat, 0, sort_bits, c->stream));
         SPH_TRY(c->cub_tmp.reserve(tmp_bytes));
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.ptr, tmp_bytes, ck, cks, ci, cp, (int)n_cat, 0,
-                                                   end_bit + tag_bits, c->stream));
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.ptr, tmp_bytes, ck, cks, ci, cp, (int)n_cat, 0, sort_bits, c->stream));
     }
-
+    c->merged_valid = false;
+    c->tables_valid = true;
     for (int a = 0; a < narrays; a++) {
         c->ids[a] = ids[a];
+        c->arr[ids[a]].nnps_slot = a;
+        c->arr[ids[a]].perm_n = c->arr[ids[a]].n;
+    }
+    if (merged_first) {
+        DevArray &M = c->merged;
+        M.n = M.n_real = n_cat;
+        SPH_TRY(M.fkeys_sorted.reserve((n_cat + 1) * 4));
+        SPH_TRY(M.keys_sorted.reserve((n_cat + 1) * 4));
+        SPH_TRY(M.perm.reserve((n_cat + 1) * 4));
+        SPH_TRY(M.slot8.reserve(n_cat + 64));
+        SPH_TRY(M.fine_start.reserve((n_fine + 1) * 4));
+        SPH_TRY(M.cell_start.reserve(((size_t)n_cells_alloc + 1) * 4));
+        CatOff co;
+        co.narrays = narrays;
+        for (int a = 0; a <= SPH_MAX_ARRAYS; a++) co.off[a] = (uint32_t)cat_off[a < narrays ? a : narrays];
+        const uint32_t *cks = c->tmp_u32b.as<uint32_t>();
+        hipLaunchKernelGGL(k_merged_split, dim3(div_up(n_cat, 256)), dim3(256), 0, c->stream, cks, cks + n_half, n_cat, co,
+                           M.fkeys_sorted.as<uint32_t>(), M.keys_sorted.as<uint32_t>(), M.perm.as<uint32_t>(), M.slot8.as<uint8_t>());
+        hipLaunchKernelGGL(k_cell_start, dim3(div_up(n_cat + 1, 256)), dim3(256), 0, c->stream, M.fkeys_sorted.as<uint32_t>(),
+                           n_cat, (uint32_t)n_fine, M.fine_start.as<uint32_t>(), c->gapq.as<uint32_t>(), (uint32_t *)nullptr);
+        hipLaunchKernelGGL(k_fill_gaps, dim3(512), dim3(256), 0, c->stream, c->gapq.as<uint32_t>(), M.fine_start.as<uint32_t>());
+        hipLaunchKernelGGL(k_coarse_start, dim3(div_up((size_t)n_cells_alloc + 1, 256)), dim3(256), 0, c->stream,
+                           M.fine_start.as<uint32_t>(), (uint32_t)n_cells_alloc, M.cell_start.as<uint32_t>(), c->gapq.as<uint32_t>());
+        SPH_TRY(nnps_tile_order(c, M, n_cat));
+        c->merged_valid = true;
+        c->tables_valid = false;
+        if (!c->lazy_tables) SPH_TRY(nnps_need_tables(c));
+    } else {
+    for (int a = 0; a < narrays; a++) {
         DevArray &A = c->arr[ids[a]];
-        A.nnps_slot = a;
-        A.perm_n = A.n;
         size_t n = A.n;
         SPH_TRY(A.keys.reserve((n + 1) * 4));
-        SPH_TRY(A.keys_sorted.reserve((n + 1) * 4));
         SPH_TRY(A.idx.reserve((n + 1) * 4));
-        SPH_TRY(A.perm.reserve((n + 1) * 4));
-        SPH_TRY(A.cell_start.reserve(((size_t)n_cells_alloc + 1) * 4));
-        SPH_TRY(A.fkeys_sorted.reserve((n + 1) * 4));
-        SPH_TRY(A.fine_start.reserve((n_fine + 1) * 4));
-        if (n == 0) {
-            hipLaunchKernelGGL(k_fill_u32, dim3(div_up(n_cells_alloc + 1, 256)), dim3(256), 0, c->stream,
-                               A.cell_start.as<uint32_t>(), (size_t)n_cells_alloc + 1, 0u);
-            hipLaunchKernelGGL(k_fill_u32, dim3(div_up(n_fine + 1, 256)), dim3(256), 0, c->stream,
-                               A.fine_start.as<uint32_t>(), n_fine + 1, 0u);
-            continue;
-        }
+        SPH_TRY(nnps_reserve_tables(c, A));
+        if (n == 0) { nnps_empty_tables(c, A); continue; }
         if (cat) {
             const uint32_t *cks = c->tmp_u32b.as<uint32_t>();
             hipLaunchKernelGGL(k_split_segment, dim3(div_up(n, 256)), dim3(256), 0, c->stream, cks + cat_off[a],
@@ -541,7 +711,7 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
                                A.fkeys_sorted.as<uint32_t>(), A.keys_sorted.as<uint32_t>(), A.perm.as<uint32_t>());
         } else {
         hipLaunchKernelGGL(k_cell_keys, dim3(div_up(n, 256)), dim3(256), 0, c->stream, A.prop[SPH_X], A.prop[SPH_Y],
-                           A.prop[SPH_Z], n, g, A.keys.as<uint32_t>(), A.idx.as<uint32_t>());
+                           A.prop[SPH_Z], n, g, A.keys.as<uint32_t>(), A.idx.as<uint32_t>(), 0u, 0u);
         size_t tmp_bytes = 0;
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, A.keys.as<uint32_t>(), A.fkeys_sorted.as<uint32_t>(),
                                                    A.idx.as<uint32_t>(), A.perm.as<uint32_t>(), (int)n, 0, end_bit,
@@ -551,45 +721,9 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
                                                    A.fkeys_sorted.as<uint32_t>(), A.idx.as<uint32_t>(),
                                                    A.perm.as<uint32_t>(), (int)n, 0, end_bit, c->stream));
         }
-        if (!c->gapq.ptr) { // first use: the queue starts empty; afterwards k_coarse_start leaves it empty
-            SPH_TRY(c->gapq.reserve((4 + 3 * GAP_QUEUE) * 4));
-            HIP_TRY(hipMemsetAsync(c->gapq.ptr, 0, 16, c->stream));
-        }
-        // the single-array path gets its cell ids (keys_sorted) from this kernel; the concatenated one has them already
-        hipLaunchKernelGGL(k_cell_start, dim3(div_up(n + 1, 256)), dim3(256), 0, c->stream,
-                           A.fkeys_sorted.as<uint32_t>(), n, (uint32_t)n_fine, A.fine_start.as<uint32_t>(),
-                           c->gapq.as<uint32_t>(), cat ? (uint32_t *)nullptr : A.keys_sorted.as<uint32_t>());
-        hipLaunchKernelGGL(k_fill_gaps, dim3(512), dim3(256), 0, c->stream, c->gapq.as<uint32_t>(),
-                           A.fine_start.as<uint32_t>());
-        hipLaunchKernelGGL(k_coarse_start, dim3(div_up((size_t)n_cells_alloc + 1, 256)), dim3(256), 0, c->stream,
-                           A.fine_start.as<uint32_t>(), (uint32_t)n_cells_alloc, A.cell_start.as<uint32_t>(),
-                           c->gapq.as<uint32_t>());
-        SPH_TRY(nnps_tile_order(c, A, n));
+        // the single-array path gets its cell ids (keys_sorted) from k_cell_start; the concatenated one has them already
+        SPH_TRY(nnps_finish_tables(c, A, !cat));
     }
-    // the merged order of all arrays (one record stream per multi-array evaluation, sph_eval.hip)
-    c->merged_valid = false;
-    if (cat && c->merge_arrays && n_cat < (1ull << 32)) {
-        DevArray &M = c->merged;
-        M.n = M.n_real = n_cat;
-        SPH_TRY(M.fkeys_sorted.reserve((n_cat + 1) * 4));
-        SPH_TRY(M.keys_sorted.reserve((n_cat + 1) * 4));
-        SPH_TRY(M.perm.reserve((n_cat + 1) * 4));
-        SPH_TRY(M.slot8.reserve(n_cat + 64));
-        SPH_TRY(M.fine_start.reserve((n_fine + 1) * 4));
-        MergeTabs mt;
-        mt.narrays = narrays;
-        for (int a = 0; a < SPH_MAX_ARRAYS; a++) mt.fine_start[a] = a < narrays ? c->arr[ids[a]].fine_start.as<uint32_t>() : nullptr;
-        for (int a = 0; a < narrays; a++) {
-            DevArray &A = c->arr[ids[a]];
-            if (A.n == 0) continue;
-            hipLaunchKernelGGL(k_merge_scatter, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, A.fkeys_sorted.as<uint32_t>(),
-                               A.perm.as<uint32_t>(), A.n, a, mt, M.fkeys_sorted.as<uint32_t>(), M.keys_sorted.as<uint32_t>(),
-                               M.perm.as<uint32_t>(), M.slot8.as<uint8_t>());
-        }
-        hipLaunchKernelGGL(k_merge_fine_start, dim3(div_up(n_fine + 1, 256)), dim3(256), 0, c->stream, mt, n_fine + 1,
-                           M.fine_start.as<uint32_t>());
-        SPH_TRY(nnps_tile_order(c, M, n_cat));
-        c->merged_valid = true;
     }
     HIP_TRY(hipGetLastError());
     c->nnps_valid = true;
@@ -621,6 +755,7 @@ extern "C" int sph_nnps_info(sph_ctx *c, double *d8, long *i4)
 extern "C" int sph_nnps_get_order(sph_ctx *c, int id, uint32_t *perm)
 {
     if (!c->nnps_valid || c->arr[id].nnps_slot < 0) { sph_set_error("sph_nnps_get_order: array not binned"); return SPH_ERR_STATE; }
+    SPH_TRY(nnps_need_tables(c));
     DevArray &A = c->arr[id];
     if (A.n == 0) return SPH_OK;
     HIP_TRY(hipMemcpyAsync(perm, A.perm.ptr, A.n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -686,6 +821,7 @@ extern "C" int sph_nnps_get_csr(sph_ctx *c, int src, int dst, uint32_t *start, s
         return SPH_ERR_ARG;
     }
     HIP_TRY(hipSetDevice(c->device));
+    SPH_TRY(nnps_need_tables(c));
     DevArray &S = c->arr[src], &D = c->arr[dst];
     size_t nd = D.n;
     // the caller sized `start` from ITS idea of the particle count; the device
@@ -744,6 +880,7 @@ int nnps_build_csr_device(sph_ctx *c, int src, int dst, DevBuf &start, DevBuf &n
         sph_set_error("neighbour lists: arrays %d/%d are not part of the current grid", src, dst);
         return SPH_ERR_ARG;
     }
+    SPH_TRY(nnps_need_tables(c));
     DevArray &S = c->arr[src], &D = c->arr[dst];
     const size_t nd = D.n;
     GridDesc g;
@@ -836,6 +973,7 @@ extern "C" int sph_nnps_reorder_array(sph_ctx *c, int id)
         return SPH_ERR_STATE;
     }
     HIP_TRY(hipSetDevice(c->device));
+    SPH_TRY(nnps_need_tables(c));
     DevArray &A = c->arr[id];
     if (A.n == 0) return SPH_OK;
     if (A.n_real != A.n) {

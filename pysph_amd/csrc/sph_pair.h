@@ -54,7 +54,7 @@ struct SrcDesc {
     uint32_t off;    // offset of this source's segment in the packed buffers
     uint32_t flags;  // equations acting for this (dest, source) pair
     const uint32_t *fine_start; // first sorted position per x sub-bin (SPH_NSUB per cell)
-    double mu;       // the one mass of this source's particles (families with uniform-mass records, Fam::UMASS)
+    double mu;       // the one mass of this source's particles (families with uniform-mass records)
 };
 
 template <class Fam> struct PairArgs {
@@ -67,6 +67,7 @@ template <class Fam> struct PairArgs {
     const float4 *fpos; // variant 3: fp32 grid-relative positions + radius_scale*h (prefilter only)
     double dom_extent;  // largest grid extent: bounds the fp32 rounding of fpos
     uint32_t d_off, nd;
+    double d_mu;     // the one mass of the destination array (uniform-mass records: decoding the destination's own record)
     const uint32_t *d_keys, *d_fkeys, *d_perm; // cell ids / fine keys of the sorted destinations, sorted -> original index
     const uint8_t *d_slot; // merged order (families with MERGED): the array (nnps slot) of every sorted destination
     const uint32_t *d_tile_order; // traversal order of the destination tiles (null: memory order)
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     }
     real4<T> pi;
     typename Fam::Dest D;
-    T cur_mu = T(0.0); // mass of the source being read (uniform-mass records)
+    T cur_mu = (T)a.d_mu; // mass of the array being read (uniform-mass records): the destination's own first, then each source's
     // one record: fp32 records for Real = float (and for record_f32), else fp64
     auto fetch = [&](uint32_t jg, uint32_t flags, real4<T> &pj, T (&sj)[Fam::NA]) {
         if constexpr (fam_eosf<Fam>::value) Fam::load_fused(a, jg, flags, cur_mu, pj, sj);

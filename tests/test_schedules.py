@@ -188,7 +188,9 @@ def bench_tol():
                                   ['--n1', '48', '--fixed-bounds']],
                          ids=['masses-differ', 'run-time-flags', 'no-reduction'])
 def test_records_keep_the_mass_when_masses_differ_or_flags_are_not_constant(argv):
-    out, cnt, res = _run(argv, {})
+    # (the per-destination path: since round 4 a dam break's group runs on the merged order of its arrays,
+    # where the flags are a compile-time class table -- tests above)
+    out, cnt, res = _run(argv, {'merge_arrays': 0})
     assert cnt['n_eos_fused'] > 0 and cnt['n_mass_fused'] == 0 and res['parity_ok'], (cnt, res)
     assert res['parity_neighbour_count_mismatches'] == 0
 
@@ -296,3 +298,23 @@ def test_merged_arrays_with_masses_per_class():
     assert n == 2 and res['parity_ok'], (n, res)
     n, res = run(1.25, 0.75)
     assert n == 0 and res['parity_ok'], (n, res)
+
+
+@pytest.mark.parametrize('argv,tol', [(['--workload', 'taylor_green', '--n1', '48'], 1e-10),
+                                      (['--workload', 'elastic', '--rings-dx', '1.6e-3'], 1e-13),
+                                      (['--workload', 'elastic_block', '--n1', '40'], 1e-13),
+                                      (['--workload', 'elastic', '--rings-dx', '1.6e-3', '--dtype', 'f32'], 5e-5)],
+                         ids=['taylor-green', 'rings', 'block', 'rings-fp32'])
+def test_state_fused_tvf_and_uniform_elastic_records(argv, tol):
+    """TVF force records without p and V (recomputed from rho and the one mass), elastic
+    rate records without h and m: against the full records (mass_fuse = 0) and the oracle.
+    Taylor-Green's lattice sums cancel, so record-level rounding shows at the 1e-11 level."""
+    on, c_on, r_on = _run(argv, {}, steps=3)
+    off, c_off, r_off = _run(argv, {'mass_fuse': 0}, steps=3)
+    assert c_on['n_mass_fused'] == 2 and c_off['n_mass_fused'] == 0, (c_on, c_off)
+    assert r_on['parity_neighbour_count_mismatches'] == 0
+    if '--dtype' in argv:
+        assert r_on['parity_max_rel'] < 5e-5 and r_off['parity_max_rel'] < 5e-5, (r_on, r_off)
+    else:
+        assert r_on['parity_ok'] and r_off['parity_ok'], (r_on, r_off)
+    assert _max_rel(on, off) < tol
