@@ -220,6 +220,7 @@ struct PackArgs {
                                   // 7: the same in fp32 [x-x0 y-y0 z-z0 u | v w rho m] (32 B)
                                   // 8 / 9: TVF, p and V recomputed from rho (fp64 80 B / fp32 48 B)
                                   // 10 / 11: elastic rates without h and m (fp64 160 B / fp32 80 B)
+                                  // 12 / 13: WCSPH with variable h, one mass per array, EOS recomputed (64 B / 32 B)
                                   // (1, 2: aggregated kernel only)
     int umass;                    // layouts 6 / 7: the last slot carries p / rho^2 (derived 1) instead of m
     float4 *fpos;                 // non-null: fp32 {x-xmin, y-ymin, z-zmin, radius_scale*h} for the prefilter tiles
@@ -309,6 +310,15 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
             pc[1] = __builtin_bit_cast(double2, make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]));
             pc[2] = __builtin_bit_cast(double2, make_float4((float)v[4], (float)v[5], 0.f, 0.f));
             np = a.nr / 4;
+        } else if (a.layout == 12) { // WCSPH, variable h, one mass, EOS recomputed: [x y | z h | u v | w rho]
+            pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, ph.w);
+            pc[2] = make_double2(v[0], v[1]); pc[3] = make_double2(v[2], v[4]);
+            np = 4;
+        } else if (a.layout == 13) { // the same in fp32: [x y z h | u v w rho]
+            pc[0] = __builtin_bit_cast(double2, make_float4((float)(ph.x - a.gmin[0]), (float)(ph.y - a.gmin[1]),
+                                                            (float)(ph.z - a.gmin[2]), (float)ph.w));
+            pc[1] = __builtin_bit_cast(double2, make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[4]));
+            np = 2;
         } else if (a.layout == 10) { // elastic, uniform h and mass: [x y | z u | v w | rho cs | t x6 | r x6]
             pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, v[0]);
             pc[2] = make_double2(v[1], v[2]); pc[3] = make_double2(v[4], v[5]);
@@ -583,6 +593,41 @@ template <class T, bool UM = false> struct FamWCSPHE_T : FamWCSPH_T<T> {
         Raw r;
         load_raw(a, jg, r);
         decode(a, r, fl, mu, pj, s);
+    }
+};
+
+// Variable h with ONE mass per source array: [x y | z h | u v | w rho] (fp32: [x y z h | u v w rho]) -- 64 bytes instead of
+// the 96-byte records with cs, m, p / rho^2 and p: the mass is a constant of the source, p, cs and p / rho^2 are the
+// Tait EOS of the gathered rho (as FamWCSPHE_T without the uniform-mass slot).  Run with UH = false.
+template <class T> struct FamWCSPHV_T : FamWCSPH_T<T> {
+    static constexpr bool EOSF = true;
+    static constexpr int NR = 8;
+    template <class A> static __device__ __forceinline__ void load_fused(const A &a, uint32_t jg, uint32_t fl, T mu, real4<T> &pj, T (&s)[8])
+    {
+        T rho;
+        if constexpr (sizeof(T) == 8) {
+            const double2 *p = reinterpret_cast<const double2 *>(a.rec) + (unsigned long long)jg * 4;
+            const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+            pj.x = q0.x; pj.y = q0.y; pj.z = q1.x; pj.w = q1.y;
+            s[0] = q2.x; s[1] = q2.y; s[2] = q3.x; rho = q3.y;
+        } else {
+            const float4 *p = reinterpret_cast<const float4 *>(a.rec) + (unsigned long long)jg * 2;
+            const float4 q0 = p[0], q1 = p[1];
+            pj.x = q0.x; pj.y = q0.y; pj.z = q0.z; pj.w = q0.w;
+            s[0] = q1.x; s[1] = q1.y; s[2] = q1.z; rho = q1.w;
+        }
+        s[3] = mu;
+        s[4] = rho;
+        s[5] = s[6] = s[7] = T(0.0);
+        if (fl & F_MOM) {
+            const T ratio = rho * (T)a.e_rho01;
+            const T r2 = ratio * ratio, r3 = r2 * ratio;
+            const T r7 = (r2 * r2) * r3;
+            const T p = (T)a.e_p0 + (T)a.e_B * (r7 - T(1.0));
+            s[5] = rho != T(0.0) ? p * fast_rcp(rho * rho) : T(0.0);
+            s[6] = (T)a.e_c0 * r3;
+            s[7] = p;
+        }
     }
 };
 
@@ -1338,6 +1383,8 @@ static int pack_pieces(const PackArgs &pa)
     if (pa.layout == 9) return pa.nr / 4;
     if (pa.layout == 10) return 10;
     if (pa.layout == 11) return 5;
+    if (pa.layout == 12) return 4;
+    if (pa.layout == 13) return 2;
     if (pa.layout == 5) return (pa.nr % 4) ? 0 : pa.nr / 4;
     if (pa.nr % 2) return 0;
     return pa.nr / 2;
@@ -1394,6 +1441,11 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
         }
     }
     if (c->cur_elu) pa.layout = c->arith_f32 ? 11 : 10; // h and m are launch / source constants
+    if (c->cur_eosv) { // p, cs, p / rho^2 recomputed, m a source constant: none of them read here
+        pa.layout = c->arith_f32 ? 13 : 12;
+        pa.src[3] = pa.src[5] = pa.src[6] = pa.src[7] = nullptr;
+        pa.derived = 0;
+    }
     if (c->cur_tvff) { // p and V are functions of rho (and the one mass): not read here
         pa.layout = c->arith_f32 ? 9 : 8;
         pa.src[7] = pa.src[8] = pa.src[9] = nullptr;
@@ -1453,7 +1505,7 @@ template <class Fam> static int launch_pair(sph_ctx *c, int kk, const PairArgs<F
 }
 
 // the EOS-fused WCSPH family: uniform h, variant 6 only (sph_eval_group checks)
-template <class Fam> static int launch_pair_fused(sph_ctx *c, int kk, const PairArgs<Fam> &a)
+template <class Fam, bool UHV = true> static int launch_pair_fused(sph_ctx *c, int kk, const PairArgs<Fam> &a)
 {
     if (a.nd == 0) return SPH_OK;
     constexpr bool FP32 = sizeof(typename Fam::Real) == 4;
@@ -1462,8 +1514,8 @@ template <class Fam> static int launch_pair_fused(sph_ctx *c, int kk, const Pair
     for (int j = 1; j < a.nsrc; j++) if (a.src[j].flags != cf) cf = 0;
     if (c->const_flags == 0) cf = 0;
 #define LAUNCHE(K)                                                                                                              \
-    if (cf == Fam::CF0) hipLaunchKernelGGL((k_pair_wave<Fam, K, true, FP32, Fam::CF0>), g2, b2, (size_t)c->lds_pad, c->stream, a); \
-    else hipLaunchKernelGGL((k_pair_wave<Fam, K, true, FP32, 0>), g2, b2, (size_t)c->lds_pad, c->stream, a)
+    if (cf == Fam::CF0) hipLaunchKernelGGL((k_pair_wave<Fam, K, UHV, FP32, Fam::CF0>), g2, b2, (size_t)c->lds_pad, c->stream, a); \
+    else hipLaunchKernelGGL((k_pair_wave<Fam, K, UHV, FP32, 0>), g2, b2, (size_t)c->lds_pad, c->stream, a)
     switch (kk) {
     case 1: LAUNCHE(1); break;
     case 2: LAUNCHE(2); break;
@@ -1533,6 +1585,7 @@ int nnps_csr_pair_kernel(sph_ctx *c, int src, int dst, uint32_t *count, const ui
     const bool was_f32 = c->record_f32 != 0, was_a32 = c->arith_f32 != 0; // lists are exact: fp64 records always
     c->record_f32 = 0; c->arith_f32 = 0;
     c->cur_eosf = false;
+    c->cur_eosv = false;
     c->cur_tvff = false;
     c->cur_elu = false;
     c->cur_umass = false;
@@ -1672,7 +1725,7 @@ static int eval_group_merged(sph_ctx *c, const sph_kernel *K, const sph_group *g
         }
         if (cls[a]) pa.cls |= 1u << a;
     }
-    c->cur_eosf = true; c->cur_umass = true; c->cur_tvff = false; c->cur_elu = false;
+    c->cur_eosf = true; c->cur_umass = true; c->cur_tvff = false; c->cur_elu = false; c->cur_eosv = false;
     c->cur_nrec = 8;
     SPH_TRY(c->posh.reserve((M.n + 64) * (f32 ? 32 : 64)));
     SPH_TRY(c->aux.reserve(64));
@@ -1877,6 +1930,14 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         for (int j = 0; j < nsrcs && umass; j++) umass = sflags[j] == FamWCSPH::CF0;
         if (umass) c->want_mrange = true; // the reduction of the neighbour updates from now on includes m (8 B per particle)
         for (int j = 0; j < nsrcs && umass; j++) umass = c->arr[srcs[j]].m_known;
+        // ... and with VARIABLE h the same promise plus one mass per source array gives 64-byte records [x y z h u v w rho]
+        bool eosv = !eosf && g->src_eos == 1 && c->eos_fuse && c->mass_fuse && fam == FAM_WCSPH && c->pair_variant == 6 &&
+                    !(c->uniform_h && c->use_uniform_h) && !(dflags & F_TENSILE) && g->eos_par[2] == 7.0 && g->eos_par[0] > 0.0 &&
+                    !c->record_f32 && !c->wcsph_nr;
+        if (eosv) c->want_mrange = true;
+        for (int j = 0; j < nsrcs && eosv; j++) eosv = c->arr[srcs[j]].m_known;
+        if (eosv) pl.nr = 8;
+        c->cur_eosv = eosv;
         // TVF force pass after StateEquation + density summation (sph_group.src_eos = 2): p and V leave the records
         // when every array read here has ONE mass (V = rho / m)
         bool tvff = g->src_eos == 2 && c->eos_fuse && c->mass_fuse && fam == FAM_TVF && c->pair_variant == 6 && c->uniform_h &&
@@ -1904,7 +1965,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         {
             ScopedTimer tm(c, T_PACK);
             // a source must hold what ITS equations read; the destination's own record what all of them read
-            const int sig = pl.nr * 32 + (c->record_f32 ? 1 : 0) + (c->arith_f32 ? 2 : 0) + (eosf ? 4 : 0) + (umass ? 8 : 0) + (tvff || elu ? 16 : 0);
+            const int sig = pl.nr * 32 + (c->record_f32 ? 1 : 0) + (c->arith_f32 ? 2 : 0) + (eosf ? 4 : 0) + (umass ? 8 : 0) + (tvff || elu || eosv ? 16 : 0);
             // The shared slots live in the same buffers every other unit packs into from offset 0:
             // a unit that does not share (another family, a single-destination call), or one whose
             // record layout differs from what the cache holds, overwrites them -- nothing cached survives.
@@ -1947,8 +2008,8 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         // 4. fused pair kernel, in the arithmetic type of the context (fp64, or fp32 with option arith_f32)
         ScopedTimer tm(c, T_PAIR);
         ScopedTimer tmf(c, T_PAIR_FAM + fam);
-        if (eosf || tvff) c->timers[T_N_EOSF].count++;
-        if (umass || tvff || elu) c->timers[T_N_UMASS].count++;
+        if (eosf || tvff || eosv) c->timers[T_N_EOSF].count++;
+        if (umass || tvff || elu || eosv) c->timers[T_N_UMASS].count++;
         if (nl_mode == 1) c->timers[T_N_NLKEEP].count++;
         if (nl_mode == 2) c->timers[T_N_NLREUSE].count++;
         // the part of the launch arguments every family shares
@@ -1963,7 +2024,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
             a.nl = nullptr; a.nl_mode = nl_mode;
             if (nl_mode) a.nl = c->nlbuf.as<uint32_t>();
-            if (eosf) {
+            if (eosf || eosv) {
                 a.e_rho01 = 1.0 / g->eos_par[0]; a.e_c0 = g->eos_par[1];
                 a.e_B = g->eos_par[0] * g->eos_par[1] * g->eos_par[1] / g->eos_par[2];
                 a.e_p0 = g->eos_par[3];
@@ -1988,7 +2049,8 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
                 SPH_TRY(ensure_out(c, dst, {SPH_AX, SPH_AY, SPH_AZ}));
                 a.p.ax = D.prop[SPH_AX]; a.p.ay = D.prop[SPH_AY]; a.p.az = D.prop[SPH_AZ];
             }
-            if constexpr (fam_eosf<F>::value) return launch_pair_fused<F>(c, K->kind, a);
+            if constexpr (std::is_same<F, FamWCSPHV_T<typename F::Real>>::value) return launch_pair_fused<F, false>(c, K->kind, a);
+            else if constexpr (fam_eosf<F>::value) return launch_pair_fused<F>(c, K->kind, a);
             else return launch_pair<F>(c, K->kind, a);
         };
         auto run_density = [&](auto tag) -> int {
@@ -2060,6 +2122,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         const bool f32 = c->arith_f32 != 0;
         if (fam == FAM_WCSPH && eosf && umass) SPH_TRY(f32 ? run_wcsph(FamWCSPHE_T<float, true>()) : run_wcsph(FamWCSPHE_T<double, true>()));
         else if (fam == FAM_WCSPH && eosf) SPH_TRY(f32 ? run_wcsph(FamWCSPHE_T<float>()) : run_wcsph(FamWCSPHE_T<double>()));
+        else if (fam == FAM_WCSPH && eosv) SPH_TRY(f32 ? run_wcsph(FamWCSPHV_T<float>()) : run_wcsph(FamWCSPHV_T<double>()));
         else if (fam == FAM_WCSPH) SPH_TRY(f32 ? run_wcsph(FamWCSPH_T<float>()) : run_wcsph(FamWCSPH()));
         else if (fam == FAM_DENSITY) SPH_TRY(f32 ? run_density(FamDensity_T<float>()) : run_density(FamDensity()));
         else if (fam == FAM_VGRAD) SPH_TRY(f32 ? run_vgrad(FamVGrad_T<float>()) : run_vgrad(FamVGrad()));

@@ -138,6 +138,7 @@ struct sph_ctx {
     int cur_nrec = 0;       // doubles per packed record of the pair launch being set up
     bool cur_eosf = false;  // the pair launch being set up reads the 64-byte WCSPH records (EOS recomputed per record)
     bool cur_umass = false; // ... with p / rho^2 in the mass slot (every source array has one mass)
+    bool cur_eosv = false;  // ... the 64-byte variable-h WCSPH records [x y z h u v w rho] (one mass per source array)
     bool cur_elu = false;   // ... the elastic-rates records without h and m (uniform h, one mass per source array)
     bool cur_tvff = false;  // the pair launch being set up reads the state-fused TVF records (p and V recomputed from rho)
     long mass_fuse = 1;     // allow that

@@ -94,10 +94,29 @@ def test_eos_fused_records_fp32():
     assert r_on['parity_neighbour_count_mismatches'] == 0
 
 
-def test_eos_not_fused_when_h_varies_or_tensile():
-    """the promise is there, the conditions of the 64-byte layout are not"""
-    out, cnt, res = _run(['--n1', '48', '--vary-h', '0.1'], {})
+def test_eos_not_fused_when_h_varies_and_masses_are_not_fused():
+    """the promise is there, the conditions of the 64-byte layouts are not (variable h needs
+    the one-mass-per-array records, switched off here)"""
+    out, cnt, res = _run(['--n1', '48', '--vary-h', '0.1'], {'mass_fuse': 0})
     assert cnt['n_eos_fused'] == 0 and res['parity_ok']
+
+
+@pytest.mark.parametrize('argv', [['--n1', '64', '--vary-h', '0.15'], ['--n1', '64', '--vary-h', '0.15', '--no-reorder'],
+                                  ['--n1', '64', '--vary-h', '0.15', '--dtype', 'f32']],
+                         ids=['variable-h', 'variable-h-unsorted', 'variable-h-fp32'])
+def test_variable_h_on_64_byte_records(argv):
+    """round 4: variable h with ONE mass per array -- [x y z h u v w rho], p, cs, p / rho^2 recomputed
+    from rho, m a constant of the source -- against the 96-byte records and the oracle"""
+    on, c_on, r_on = _run(argv, {}, steps=3)
+    off, c_off, r_off = _run(argv, {'mass_fuse': 0}, steps=3)
+    assert c_on['n_eos_fused'] == 2 and c_on['n_mass_fused'] == 2 and c_off['n_eos_fused'] == 0, (c_on, c_off)
+    assert r_on['parity_neighbour_count_mismatches'] == 0 and r_off['parity_neighbour_count_mismatches'] == 0
+    if '--dtype' in argv:
+        assert r_on['parity_max_rel'] < 5e-5 and r_off['parity_max_rel'] < 5e-5, (r_on, r_off)
+        assert _max_rel(on, off) < 5e-5
+    else:
+        assert r_on['parity_ok'] and r_off['parity_ok'], (r_on, r_off)
+        assert _max_rel(on, off) < 1e-13
 
 
 @pytest.mark.parametrize('argv', [['--workload', 'taylor_green', '--n1', '48'],
