@@ -8,7 +8,6 @@
 // neighbour is packed on the device and moved by a single RCCL send/recv.
 #include "sph_internal.h"
 
-#include <hipcub/hipcub.hpp>
 
 // one 64-bit flag per particle: bit 0 = selected for the low side, bit 32 = for the high side (kept for
 // sph_halo_remove_selected), plus, per 256-particle block, how many particles go to each side (lo | hi << 32): the lists
@@ -133,10 +132,7 @@ extern "C" int sph_halo_select(sph_ctx *c, int id, int axis, int mode, double p0
     unsigned long long *fl = H.flag[0].as<unsigned long long>();
     unsigned long long *blk = H.flag[1].as<unsigned long long>(), *bps = H.pos[1].as<unsigned long long>();
     hipLaunchKernelGGL(k_halo_flags_counts, dim3(nb), dim3(256), 0, c->stream, coord, n, mode, p0, p1, p2, fl, blk);
-    size_t tmp = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, blk, bps, (int)nb, c->stream));
-    SPH_TRY(c->cub_tmp.reserve(tmp));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.ptr, tmp, blk, bps, (int)nb, c->stream));
+    SPH_TRY(dev_scan_u64(c, blk, bps, nb, true));
     unsigned long long *pin = (unsigned long long *)c->pinned;
     HIP_TRY(hipMemcpyAsync(pin, bps + (nb - 1), 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(pin + 1, blk + (nb - 1), 8, hipMemcpyDeviceToHost, c->stream));
@@ -270,10 +266,7 @@ extern "C" int sph_halo_select_pack(sph_ctx *c, int id, int axis, double lo_cut,
     SPH_TRY(H.pos[1].reserve(((size_t)nb + 1) * 8));
     unsigned long long *blk = H.flag[1].as<unsigned long long>(), *bps = H.pos[1].as<unsigned long long>();
     hipLaunchKernelGGL(k_halo_block_counts, dim3(nb), dim3(256), 0, c->stream, coord, n, lo_cut, hi_cut, blk);
-    size_t tmp = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, blk, bps, (int)nb, c->stream));
-    SPH_TRY(c->cub_tmp.reserve(tmp));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.ptr, tmp, blk, bps, (int)nb, c->stream));
+    SPH_TRY(dev_scan_u64(c, blk, bps, nb, true));
     hipLaunchKernelGGL(k_halo_pack_direct, dim3(nb), dim3(256), 0, c->stream, a, coord, n, lo_cut, hi_cut, blk, bps);
     return SPH_OK;
 }
@@ -461,10 +454,7 @@ extern "C" int sph_halo_remove_selected(sph_ctx *c, int id, size_t *n_left)
     SPH_TRY(list.reserve((keepn + 1) * 4));
     hipLaunchKernelGGL(k_keep_flags, dim3(div_up(n, 256)), dim3(256), 0, c->stream,
                        H.flag[0].as<unsigned long long>(), H.nsel, n, keep.as<uint32_t>());
-    size_t tmpb = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpb, keep.as<uint32_t>(), pos.as<uint32_t>(), (int)n, c->stream));
-    SPH_TRY(c->cub_tmp.reserve(tmpb));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.ptr, tmpb, keep.as<uint32_t>(), pos.as<uint32_t>(), (int)n, c->stream));
+    SPH_TRY(dev_scan_u32(c, keep.as<uint32_t>(), pos.as<uint32_t>(), n, true));
     if (keepn)
         hipLaunchKernelGGL(k_list_scatter, dim3(div_up(n, 256)), dim3(256), 0, c->stream, keep.as<uint32_t>(),
                            pos.as<uint32_t>(), n, list.as<uint32_t>());

@@ -111,7 +111,7 @@ struct sph_ctx {
     // stable compaction of it by slot, made when something first asks for them (nnps_need_tables)
     bool tables_valid = true;
     long lazy_tables = 1;
-    DevBuf splitcnt;
+    DevBuf splitcnt, scan_part, bigq;
 
     // scratch
     DevBuf cub_tmp, red_part, red_out, posh, aux, fposb, dkeys, dperm, tmp_u32a, tmp_u32b, gen_state, gapq;
@@ -171,6 +171,8 @@ struct ScopedTimer {
 
 // nnps.hip
 int nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *out8);
+int dev_scan_u32(sph_ctx *c, const uint32_t *in, uint32_t *out, size_t n, bool exclusive); // prefix sums, hand-written (sph_nnps.hip)
+int dev_scan_u64(sph_ctx *c, const unsigned long long *in, unsigned long long *out, size_t n, bool exclusive);
 int nnps_need_tables(sph_ctx *c); // per-array cell orders / tables of a merged-first update, on first use
 int nnps_build_csr_device(sph_ctx *c, int src, int dst, DevBuf &start, DevBuf &nbrs, size_t *total);
 // eval.hip: the same lists through the wave-tile pair kernel (count pass: start == nullptr; fill pass: start, nbrs)

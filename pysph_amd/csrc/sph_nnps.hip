@@ -225,15 +225,16 @@ __global__ __launch_bounds__(256) void k_coarse_start(const uint32_t *__restrict
 #define SPH_TILE 256
 __global__ __launch_bounds__(256) void k_tile_keys(const uint32_t *__restrict__ skeys, size_t n, uint32_t n_tiles, int ncx,
                                                    int ncy, int ncz, int by, uint32_t *__restrict__ key,
-                                                   uint32_t *__restrict__ id)
+                                                   uint32_t *__restrict__ count)
 {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
     const uint32_t k = skeys[(size_t)t * SPH_TILE];
     const uint32_t row = k / (uint32_t)ncx;
     const uint32_t cy = row % (uint32_t)ncy, cz = row / (uint32_t)ncy;
-    key[t] = ((cy / (uint32_t)by) * (uint32_t)ncz + cz) * (uint32_t)by + cy % (uint32_t)by;
-    id[t] = t;
+    const uint32_t kk = ((cy / (uint32_t)by) * (uint32_t)ncz + cz) * (uint32_t)by + cy % (uint32_t)by;
+    key[t] = kk;
+    atomicAdd(&count[kk + 2], 1u); // the bin sort's count pass
 }
 
 // start[k] = first sorted position whose key >= k, for k in [0, ntab]: thread i
@@ -307,6 +308,225 @@ extern "C" int sph_nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *
     if (!c || narrays < 1 || narrays > SPH_MAX_ARRAYS) { sph_set_error("sph_nnps_minmax: bad arguments"); return SPH_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
     return nnps_minmax(c, narrays, ids, out8);
+}
+
+// ---------------------------------------------------------------------------
+// Hand-written prefix sums (dev_scan_u32 / _u64: the halo selection, the neighbour-list starts, the compaction below)
+// and a hand-written COUNTING sort for keys that are bin ids of a small table (the traversal order of the tiles):
+//   count   the key pass adds 1 to T[key + 2]                      (T: nbins + 2 entries, zeroed)
+//   scan    inclusive, in place: T[k + 1] = first position of bin k
+//   scatter pos = atomicAdd(&T[key + 1], 1): afterwards T[k] = first position of bin k for every k -- T IS fine_start
+//   fix     the atomics hand out the positions of a bin in arrival order: one thread per bin puts its (one to three)
+//           particles into ascending index order, i.e. the order a stable sort gives -- deterministic, bit-identical
+//           between runs and to the radix sort this replaces -- and writes the sorted keys / cell ids / cell_start (and,
+//           for the merged order of several arrays, slot and local index) on the way.  Bins of more than BIN_SMALL
+//           particles (dense cells, coincident particles) are queued for one workgroup each (rank by counting).
+// The PARTICLE sort stays a radix sort (hipCUB Onesweep): the counting sort through the fine_start table was built and
+// measured for it too -- bit-identical results, no library kernel, and slower: with ~2 particles per x sub-bin and the
+// particles nearly in cell order, a wavefront's 64 table updates hit one or two 128-byte lines and the L2 serialises
+// them (4 M atomics: 112 us in the key pass + 176 us in the scatter against 120 us for three radix passes;
+// profiles/r04_binsort_vs_radix.txt).
+// ---------------------------------------------------------------------------
+#define SCAN_ITEMS 16
+#define SCAN_BLOCK (256 * SCAN_ITEMS)
+
+template <class T> __device__ __forceinline__ T wave_incl_scan(T x, int lane)
+{
+    for (int o = 1; o < 64; o <<= 1) { const T t = __shfl_up(x, o, 64); if (lane >= o) x += t; }
+    return x;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_scan_partials(const T *__restrict__ in, size_t n, T *__restrict__ partial)
+{
+    const size_t base = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    T sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) if (base + (size_t)k * 256 < n) sum += in[base + (size_t)k * 256];
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    __shared__ T ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// exclusive scan of the block partials, in place: one workgroup walks them 1024 at a time
+template <class T> __global__ __launch_bounds__(1024) void k_scan_spine(T *__restrict__ part, uint32_t nb)
+{
+    __shared__ T ws[17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T carry = 0;
+    for (uint32_t base = 0; base < nb; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const T v = i < nb ? part[i] : T(0);
+        const T x = wave_incl_scan<T>(v, lane);
+        if (lane == 63) ws[wave] = x;
+        __syncthreads();
+        if (wave == 0) {
+            const T w = lane < 16 ? ws[lane] : T(0);
+            const T y = wave_incl_scan<T>(w, lane);
+            if (lane < 16) ws[lane] = y - w;
+            if (lane == 15) ws[16] = y;
+        }
+        __syncthreads();
+        if (i < nb) part[i] = carry + ws[wave] + x - v;
+        carry += ws[16];
+        __syncthreads();
+    }
+}
+
+// out[i] = partial[block] + scan of the block's items (inclusive, or exclusive), SCAN_ITEMS rounds of 256 coalesced
+// items with the running total carried; in == out allowed (an item is read before it is written, by the same thread)
+template <class T>
+__global__ __launch_bounds__(256) void k_scan_apply(const T *in, T *out, size_t n, const T *__restrict__ partial, int exclusive)
+{
+    __shared__ T ws[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T carry = partial[blockIdx.x];
+    for (int r = 0; r < SCAN_ITEMS; r++) {
+        const size_t i = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)r * 256 + threadIdx.x;
+        const T v = i < n ? in[i] : T(0);
+        const T x = wave_incl_scan<T>(v, lane);
+        if (lane == 63) ws[r & 1][wave] = x;
+        __syncthreads();
+        T off = carry;
+        for (int w = 0; w < wave; w++) off += ws[r & 1][w];
+        if (i < n) out[i] = off + x - (exclusive ? v : T(0));
+        carry += ws[r & 1][0] + ws[r & 1][1] + ws[r & 1][2] + ws[r & 1][3];
+    }
+}
+
+// prefix sums of n counters (device-wide, three launches); in == out allowed
+template <class T> static int dev_scan(sph_ctx *c, const T *in, T *out, size_t n, bool exclusive)
+{
+    if (n == 0) return SPH_OK;
+    const uint32_t nblk = (uint32_t)div_up(n, SCAN_BLOCK);
+    SPH_TRY(c->scan_part.reserve(((size_t)nblk + 64) * sizeof(T)));
+    T *part = c->scan_part.as<T>();
+    hipLaunchKernelGGL(k_scan_partials<T>, dim3(nblk), dim3(256), 0, c->stream, in, n, part);
+    hipLaunchKernelGGL(k_scan_spine<T>, dim3(1), dim3(1024), 0, c->stream, part, nblk);
+    hipLaunchKernelGGL(k_scan_apply<T>, dim3(nblk), dim3(256), 0, c->stream, in, out, n, (const T *)part, exclusive ? 1 : 0);
+    return SPH_OK;
+}
+int dev_scan_u32(sph_ctx *c, const uint32_t *in, uint32_t *out, size_t n, bool exclusive) { return dev_scan<uint32_t>(c, in, out, n, exclusive); }
+int dev_scan_u64(sph_ctx *c, const unsigned long long *in, unsigned long long *out, size_t n, bool exclusive)
+{
+    return dev_scan<unsigned long long>(c, in, out, n, exclusive);
+}
+
+// pos = T[key + 1]++ ; perm[pos] = position of the particle in the key array
+__global__ __launch_bounds__(256) void k_bin_scatter(const uint32_t *__restrict__ keys, size_t n, uint32_t *__restrict__ table,
+                                                     uint32_t *__restrict__ perm)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pos = atomicAdd(&table[keys[i] + 1], 1u);
+    perm[pos] = (uint32_t)i;
+}
+
+#define BIN_SMALL 64     // bins up to this size: insertion sort by their thread (arrival order is nearly index order)
+#define BIN_QUEUE 65536  // larger ones: one workgroup each (a full queue falls back to the thread)
+struct BinFixArgs {
+    const uint32_t *table;   // nbins + 1 first positions
+    uint32_t nbins, nsub;    // nsub: bins per cell (cell_start[c] = table[c * nsub]); 0: no cells
+    uint32_t *perm;          // sorted position -> position in the key array; rewritten to the local index when slot != null
+    uint32_t *fkeys, *keys;  // optional: sorted fine keys / cell ids
+    uint32_t *cell_start;    // optional (nsub > 0): nbins / nsub + 1 entries
+    uint8_t *slot;           // optional: array slot of every sorted particle (merged order)
+    struct { uint32_t off[SPH_MAX_ARRAYS + 1]; int narrays; } co;
+    uint32_t *bigq;          // [0] count, then bin ids
+};
+
+__device__ __forceinline__ void bin_emit(const BinFixArgs &a, uint32_t k, uint32_t j, uint32_t g)
+{
+    if (a.fkeys) a.fkeys[j] = k;
+    if (a.keys) a.keys[j] = k / SPH_NSUB;
+    if (a.slot) {
+        uint32_t s = 0, base = 0;
+#pragma unroll
+        for (int b = 1; b < SPH_MAX_ARRAYS; b++)
+            if (b < a.co.narrays && g >= a.co.off[b]) { s = (uint32_t)b; base = a.co.off[b]; }
+        a.slot[j] = (uint8_t)s;
+        a.perm[j] = g - base;
+    } else {
+        a.perm[j] = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bin_fix(BinFixArgs a)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > a.nbins) return;
+    const uint32_t lo = a.table[k];
+    if (a.nsub && a.cell_start && k % a.nsub == 0) a.cell_start[k / a.nsub] = lo;
+    if (k == a.nbins) return;
+    const uint32_t hi = a.table[k + 1], cnt = hi - lo;
+    if (cnt == 0) return;
+    if (cnt > BIN_SMALL) {
+        const uint32_t q = atomicAdd(&a.bigq[0], 1u);
+        if (q < BIN_QUEUE) { a.bigq[1 + q] = k; return; }
+    }
+    if (cnt <= 4) { // the common case in registers
+        uint32_t v[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) v[t] = (uint32_t)t < cnt ? a.perm[lo + t] : 0xffffffffu;
+#define CSWAP(i, j) { const uint32_t x = min(v[i], v[j]), y = max(v[i], v[j]); v[i] = x; v[j] = y; }
+        CSWAP(0, 1) CSWAP(2, 3) CSWAP(0, 2) CSWAP(1, 3) CSWAP(1, 2)
+#undef CSWAP
+#pragma unroll
+        for (int t = 0; t < 4; t++) if ((uint32_t)t < cnt) bin_emit(a, k, lo + t, v[t]);
+        return;
+    }
+    for (uint32_t i = lo + 1; i < hi; i++) { // insertion sort in place
+        const uint32_t x = a.perm[i];
+        uint32_t j = i;
+        while (j > lo && a.perm[j - 1] > x) { a.perm[j] = a.perm[j - 1]; j--; }
+        a.perm[j] = x;
+    }
+    for (uint32_t i = lo; i < hi; i++) bin_emit(a, k, i, a.perm[i]);
+}
+
+// queued bins: rank by counting, one workgroup per bin; `scratch` holds a copy of the bin's entries (n entries available)
+__global__ __launch_bounds__(256) void k_bin_fix_big(BinFixArgs a, uint32_t *__restrict__ scratch)
+{
+    const uint32_t nq = min(a.bigq[0], (uint32_t)BIN_QUEUE);
+    for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
+        const uint32_t k = a.bigq[1 + q];
+        const uint32_t lo = a.table[k], hi = a.table[k + 1];
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) scratch[i] = a.perm[i];
+        __syncthreads();
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            const uint32_t x = scratch[i];
+            uint32_t rank = 0;
+            for (uint32_t j = lo; j < hi; j++) rank += scratch[j] < x;
+            bin_emit(a, k, lo + rank, x);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_reset_u32(uint32_t *p) { p[0] = 0u; }
+
+// Sort n keys < nbins through `table` (nbins + 2 entries; the count pass -- k_tile_keys or k_bin_count -- has run on the
+// zeroed table): leaves table[k] = first sorted position of bin k (k <= nbins) and fills the BinFixArgs outputs.
+static int nnps_bin_sort_finish(sph_ctx *c, const uint32_t *keys, size_t n, BinFixArgs fa, uint32_t *table)
+{
+    SPH_TRY(dev_scan_u32(c, table, table, (size_t)fa.nbins + 2, false));
+    SPH_TRY(c->bigq.reserve((1 + BIN_QUEUE) * 4));
+    SPH_TRY(c->tmp_u32b.reserve((n + 64) * 4));
+    hipLaunchKernelGGL(k_reset_u32, dim3(1), dim3(1), 0, c->stream, c->bigq.as<uint32_t>());
+    hipLaunchKernelGGL(k_bin_scatter, dim3(div_up(n, 256)), dim3(256), 0, c->stream, keys, n, table, fa.perm);
+    fa.table = table;
+    fa.bigq = c->bigq.as<uint32_t>();
+    hipLaunchKernelGGL(k_bin_fix, dim3(div_up((size_t)fa.nbins + 1, 256)), dim3(256), 0, c->stream, fa);
+    hipLaunchKernelGGL(k_bin_fix_big, dim3(256), dim3(256), 0, c->stream, fa, c->tmp_u32b.as<uint32_t>());
+    return SPH_OK;
+}
+
+__global__ __launch_bounds__(256) void k_bin_count(const uint32_t *__restrict__ keys, size_t n, uint32_t *__restrict__ count)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&count[keys[i] + 2], 1u);
 }
 
 // ---------------------------------------------------------------------------
@@ -506,15 +726,19 @@ static int nnps_tile_order(sph_ctx *c, DevArray &A, size_t n)
         SPH_TRY(A.tile_key.reserve((size_t)nt * 4 * 2));
         SPH_TRY(A.tile_id.reserve((size_t)nt * 4));
         SPH_TRY(A.tile_order.reserve((size_t)nt * 4));
-        uint32_t *tk = A.tile_key.as<uint32_t>(), *tk2 = tk + nt;
+        // keys = traversal rank of the tile's row (< ncy * ncz rounded up to whole blocks of rows): the same counting sort
+        const uint32_t by = (uint32_t)c->tile_block_rows;
+        const uint32_t nrow_keys = ((uint32_t)c->nc[1] + by - 1) / by * by * (uint32_t)c->nc[2];
+        SPH_TRY(A.tile_id.reserve(((size_t)nrow_keys + 2) * 4));
+        uint32_t *tk = A.tile_key.as<uint32_t>(), *tt = A.tile_id.as<uint32_t>();
+        HIP_TRY(hipMemsetAsync(tt, 0, ((size_t)nrow_keys + 2) * 4, c->stream));
         hipLaunchKernelGGL(k_tile_keys, dim3(div_up(nt, 256)), dim3(256), 0, c->stream, A.keys_sorted.as<uint32_t>(), n, nt,
-                           c->nc[0], c->nc[1], c->nc[2], (int)c->tile_block_rows, tk, A.tile_id.as<uint32_t>());
-        size_t tb2 = 0;
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, tk, tk2, A.tile_id.as<uint32_t>(),
-                                                   A.tile_order.as<uint32_t>(), (int)nt, 0, 32, c->stream));
-        SPH_TRY(c->cub_tmp.reserve(tb2));
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.ptr, tb2, tk, tk2, A.tile_id.as<uint32_t>(),
-                                                   A.tile_order.as<uint32_t>(), (int)nt, 0, 32, c->stream));
+                           c->nc[0], c->nc[1], c->nc[2], (int)c->tile_block_rows, tk, tt);
+        BinFixArgs fa;
+        memset(&fa, 0, sizeof fa);
+        fa.nbins = nrow_keys; fa.nsub = 0;
+        fa.perm = A.tile_order.as<uint32_t>();
+        SPH_TRY(nnps_bin_sort_finish(c, tk, nt, fa, tt));
         A.n_tiles = nt;
     }
     return SPH_OK;
@@ -898,10 +1122,7 @@ int nnps_build_csr_device(sph_ctx *c, int src, int dst, DevBuf &start, DevBuf &n
     hipLaunchKernelGGL(k_csr<false>, dim3(div_up(nd, 256)), dim3(256), 0, c->stream, D.prop[SPH_X], D.prop[SPH_Y],
                        D.prop[SPH_Z], D.prop[SPH_H], nd, S.prop[SPH_X], S.prop[SPH_Y], S.prop[SPH_Z], S.prop[SPH_H],
                        S.perm.as<uint32_t>(), S.cell_start.as<uint32_t>(), g, c->radius_scale, cnt, (uint32_t *)nullptr);
-    size_t tb = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, start.as<uint32_t>(), (int)(nd + 1), c->stream));
-    SPH_TRY(c->cub_tmp.reserve(tb));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.ptr, tb, cnt, start.as<uint32_t>(), (int)(nd + 1), c->stream));
+    SPH_TRY(dev_scan_u32(c, cnt, start.as<uint32_t>(), nd + 1, true));
     uint32_t *pin = (uint32_t *)c->pinned;
     HIP_TRY(hipMemcpyAsync(pin, start.as<uint32_t>() + nd, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
