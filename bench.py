@@ -682,7 +682,7 @@ def setup(args, w, rank, world, dist, ctx):
     h_reduce = None
     if world > 1:
         from pysph_amd.parallel import allreduce_scalars
-        dev_t = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+        dev_t = getattr(halo.halos[0].ops, 'device', None)   # where the transport's tensors live (as SlabDecomposition.rebalance)
 
         def h_reduce(lo, hi):
             # the known h range of a fixed_h run is the GLOBAL one: ghosts and

@@ -446,7 +446,8 @@ template <class T> struct FamWCSPH_T {
     template <class A> static __device__ __forceinline__ void load(Dest &D, const T *a, const A &, uint32_t)
     {
         D.u = a[0]; D.v = a[1]; D.w = a[2]; D.rho = a[4]; D.tmpi = a[5]; D.cs = a[6]; D.p = a[7];
-        D.arho = D.au = D.av = D.aw = D.ax = D.ay = D.az = D.dt_cfl = T(0.0);
+        D.arho = D.au = D.av = D.aw = D.ax = D.ay = D.az = T(0.0);
+        D.dt_cfl = T(-1.0); // running max of |h v.x / r2| over the pairs; -1: none yet (finish)
     }
     // The algebra below is the reference's (cited per term) regrouped so that a
     // pair costs one rsqrt and one reciprocal:  DWIJ = tg*XIJ  =>
@@ -480,12 +481,15 @@ template <class T> struct FamWCSPH_T {
                 const T inv_re = rhoij * tt;
                 rhoij1 = re * tt;
                 const T hv = g.hij * vdotx;
-                const T muij = hv * inv_re;
+                // the viscosity acts for approaching pairs only (vdotx < 0; h > 0): muij from min(hv, 0) is exactly
+                // zero otherwise and takes piij with it
+                const T muij = raw_min(hv, T(0.0)) * inv_re;
                 const T cij = T(0.5) * (D.cs + s[6]);
-                T piij = (a.p.beta * muij - a.p.alpha * cij) * muij * rhoij1;
-                piij = vdotx < 0 ? piij : T(0.0);
-                const T dtc = fabs(hv * (g.rinv * g.rinv)) + a.p.c0;
-                D.dt_cfl = (r2 > T(1e-12) && pass) ? fmax(dtc, D.dt_cfl) : D.dt_cfl;
+                const T piij = (a.p.beta * muij - a.p.alpha * cij) * muij * rhoij1;
+                // dt_cfl = max_j (|h v.x / r2| + c0) = max_j |h v.x / r2| + c0 (rounding is monotonic): the running
+                // maximum starts at -1 (no pair yet), finish() adds c0 once
+                const T dtv = fabs(hv * (g.rinv * g.rinv));
+                D.dt_cfl = raw_max(D.dt_cfl, (r2 > T(1e-12) && pass) ? dtv : T(-1.0));
                 const T tmpj = s[5];
                 T tmp = D.tmpi + tmpj;
                 if (fl & F_TENSILE) {
@@ -520,7 +524,7 @@ template <class T> struct FamWCSPH_T {
         if (a.dflags & F_MOM) { // post_loop wc/basic.py:261-271
             T au = D.au + a.p.gx, av = D.av + a.p.gy, aw = D.aw + a.p.gz;
             a.p.au[o] = au; a.p.av[o] = av; a.p.aw[o] = aw;
-            a.p.dt_cfl[o] = D.dt_cfl;
+            a.p.dt_cfl[o] = D.dt_cfl < T(0.0) ? T(0.0) : D.dt_cfl + a.p.c0;
             a.p.dt_force[o] = au * au + av * av + aw * aw;
         }
         if (a.dflags & F_XSPH) { // post_loop basic_equations.py:297-300
@@ -715,12 +719,11 @@ template <class T> struct FamWCSPHM_T : FamWCSPHE_T<T, true> {
         const T inv_re = rhoij * tt;
         const T rhoij1 = re * tt;
         const T hv = g.hij * vdotx;
-        const T muij = hv * inv_re;
+        const T muij = raw_min(hv, T(0.0)) * inv_re; // approaching pairs only, as FamWCSPH_T::pair
         const T cij = T(0.5) * (D.cs + s[6]);
-        T piij = (a.p.beta * muij - a.p.alpha * cij) * muij * rhoij1;
-        piij = vdotx < 0 ? piij : T(0.0);
-        const T dtc = fabs(hv * (g.rinv * g.rinv)) + a.p.c0;
-        D.dt_cfl = (r2 > T(1e-12) && on_m) ? fmax(dtc, D.dt_cfl) : D.dt_cfl;
+        const T piij = (a.p.beta * muij - a.p.alpha * cij) * muij * rhoij1;
+        const T dtv = fabs(hv * (g.rinv * g.rinv));
+        D.dt_cfl = raw_max(D.dt_cfl, (r2 > T(1e-12) && on_m) ? dtv : T(-1.0));
         const T ft = -(on_m ? m : T(0.0)) * ((D.tmpi + s[5]) + piij) * tg;
         D.au = fma(ft, g.xij[0], D.au);
         D.av = fma(ft, g.xij[1], D.av);
@@ -742,7 +745,7 @@ template <class T> struct FamWCSPHM_T : FamWCSPHE_T<T, true> {
         if (row & F_MOM) { // post_loop wc/basic.py:261-271
             const T au = D.au + a.p.gx, av = D.av + a.p.gy, aw = D.aw + a.p.gz;
             out(1)[o] = au; out(2)[o] = av; out(3)[o] = aw;
-            out(7)[o] = D.dt_cfl;
+            out(7)[o] = D.dt_cfl < T(0.0) ? T(0.0) : D.dt_cfl + a.p.c0;
             out(8)[o] = au * au + av * av + aw * aw;
         }
         if (row & F_XSPH) { // post_loop basic_equations.py:297-300

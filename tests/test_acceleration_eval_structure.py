@@ -192,3 +192,68 @@ def test_tvf_and_elastic_second_passes_reuse_the_first_pass_lists():
     # a neighbour update between the passes: nothing is kept
     g2u = Group(equations=[SummationDensity('w', ['w'])], real=False, update_nnps=True)
     assert [n for grp in _modes(_plan([w], [g2u, g1])) for _, n in grp] == [0, 0]
+
+
+def test_tvf_force_group_gets_the_state_promise():
+    """round 4: [TVF SummationDensity | StateEquation | force group], each over all
+    particles: p and V = rho / m are functions of rho when the force group runs
+    (sph_group.src_eos = 2, eos_par = p0 rho0 b) -- and not when a link is missing"""
+    from pysph_amd.equations import (Group, MomentumEquationPressureGradient, StateEquation,
+                                     TVFSummationDensity)
+    from pysph_amd.particle_array import get_particle_array_tvf_fluid
+    from pysph_amd.scheme import TVFScheme
+    f = get_particle_array_tvf_fluid(name='fluid', x=np.zeros(2))
+    groups = TVFScheme(['fluid'], [], dim=3, rho0=2.0, c0=10.0, nu=0.01, p0=100.0,
+                       pb=100.0, h0=0.1).get_equations()
+    plan = _plan([f], groups, kernel_kind=3)
+    u = plan[-1][1].units[0]
+    assert u.cg.src_eos == 2 and list(u.cg.eos_par)[:3] == [100.0, 2.0, 1.0]
+    assert [e for grp in _modes(plan)[:-1] for e, _ in grp] == [0, 0]
+    dens = Group(equations=[TVFSummationDensity('fluid', ['fluid'])], real=False)
+    state = Group(equations=[StateEquation('fluid', None, p0=100.0, rho0=2.0, b=1.0)], real=False)
+    force = Group(equations=[MomentumEquationPressureGradient('fluid', ['fluid'], pb=100.0)])
+    assert _plan([f], [dens, state, force], 3)[-1][1].units[0].cg.src_eos == 2
+    state_real = Group(equations=[StateEquation('fluid', None, p0=100.0, rho0=2.0, b=1.0)], real=True)
+    dens_real = Group(equations=[TVFSummationDensity('fluid', ['fluid'])], real=True)
+    for gl in ([state, force],                      # no density summation in this evaluation
+               [dens, state_real, force],           # the state equation skips the ghosts
+               [dens_real, state, force],           # the density summation skips the ghosts
+               [dens, state, Group(equations=[TVFSummationDensity('fluid', ['fluid'])], real=False), force]):
+        assert _plan([f], gl, 3)[-1][1].units[-1].cg.src_eos != 2, gl
+
+
+def test_a_group_with_several_destinations_goes_to_the_library_in_one_call():
+    """round 4: the dam break's rate group (boundary, obstacle, fluid destinations) is ONE
+    sph_eval_group call carrying every unit's equations and the promises they share, so that
+    the library can run it as one launch over the merged order of the arrays"""
+    from pysph_amd.examples import dam_break_3d as db
+    arrays = db.create_particles(0.2)
+    plan = _plan(arrays, db.create_scheme(0.2).get_equations())
+    cg = plan[-1][1]
+    assert len(cg.units) == 3
+    calls = []
+
+    class Lib(object):
+        def sph_eval_group(self, ctx, kernel, group, t, dt):
+            g = group._obj
+            calls.append((g.neq, g.src_eos, list(g.eos_par), g.real, g.start_idx, g.stop_idx,
+                          [(g.eqs[i].kind, g.eqs[i].dest, g.eqs[i].nsrc) for i in range(g.neq)]))
+            return 0
+
+    class Ev(object):
+        lib = Lib()
+        ckernel = None
+
+        class ctx(object):
+            _h = None
+    import ctypes
+    Ev.ckernel = ctypes.c_int(0)
+    cg.refresh_range()
+    cg.run(Ev, 0.0, 1e-5)
+    assert len(calls) == 1
+    neq, src_eos, eos_par, real, start, stop, eqs = calls[0]
+    assert neq == sum(len(u.eqs) for u in cg.units) == 5 and src_eos == 1
+    assert eos_par == [db.ro, db.c0, db.gamma, 0.0] and real == 1 and (start, stop) == (0, -1)
+    # boundary <- fluid, obstacle <- fluid (continuity), then the fluid's three equations
+    assert [(k, n) for k, _, n in eqs] == [(3, 1), (3, 1), (3, 3), (4, 3), (5, 1)]
+    assert len(set(d for _, d, _ in eqs)) == 3
