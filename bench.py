@@ -126,7 +126,7 @@ def make_taylor_green(n1, x_offset=0.0):
     return pa, dx
 
 
-def make_rings3d(dx, spacing=0.041, seed=7):
+def make_rings3d(dx, spacing=0.041, seed=7, perturb=True):
     """S-rings3d of SURVEY.md 8(d) (BASELINE config 5): the colliding rings of
     pysph/examples/solid_mech/rings.py:20-80 taken to 3-D -- two hollow spheres
     (inner radius 0.03, outer 0.04) on a lattice, centres 2 x `spacing` apart
@@ -136,7 +136,10 @@ def make_rings3d(dx, spacing=0.041, seed=7):
     rate but the velocity-gradient one vanishes inside a body; a seeded
     perturbation (rho +-1 %, velocities +-0.01 cs on top of the approach
     speed, deviatoric stresses +-1e-3 E) makes every term of the equation set
-    act, tension included (the artificial-stress eigen-decomposition)."""
+    act, tension included (the artificial-stress eigen-decomposition).
+    `perturb=False`: the state rings.py starts from (uniform density, no stress,
+    the approach speed only) -- no particle in tension, the artificial stress
+    r_ij is zero everywhere and the rates kernel does not gather it."""
     from pysph_amd import kernels as K
     from pysph_amd.solid_mech import get_particle_array_elastic_dynamics
     E, nu, rho0, hdx = 1e7, 0.3975, 1.0, 1.5     # rings.py:21-28
@@ -156,15 +159,17 @@ def make_rings3d(dx, spacing=0.041, seed=7):
     rng = np.random.default_rng(seed)
     pa = get_particle_array_elastic_dynamics(
         name='solid', x=x + spacing, y=y, z=z, h=h0 * np.ones(n),
-        m=rho0 * dx ** 3 * np.ones(n), rho=rho0 * (1 + 0.01 * rng.uniform(-1, 1, n)),
+        m=rho0 * dx ** 3 * np.ones(n),
+        rho=rho0 * (1 + (0.01 if perturb else 0.0) * rng.uniform(-1, 1, n)),
         constants=dict(E=E, nu=nu, rho_ref=rho0, n=4,
                        wdeltap=float(kernel.kernel(rij=dx, h=h0))))
     cs = float(pa.cs[0])
-    pa.u[:] = cs * 0.059 * side + 0.01 * cs * rng.uniform(-1, 1, n)   # rings.py:76-77
-    pa.v[:] = 0.01 * cs * rng.uniform(-1, 1, n)
-    pa.w[:] = 0.01 * cs * rng.uniform(-1, 1, n)
+    amp = 0.01 if perturb else 0.0
+    pa.u[:] = cs * 0.059 * side + amp * cs * rng.uniform(-1, 1, n)   # rings.py:76-77
+    pa.v[:] = amp * cs * rng.uniform(-1, 1, n)
+    pa.w[:] = amp * cs * rng.uniform(-1, 1, n)
     for c in ('s00', 's01', 's02', 's11', 's12', 's22'):
-        pa.get(c)[:] = 1e-3 * E * rng.uniform(-1, 1, n)
+        pa.get(c)[:] = (1e-3 if perturb else 0.0) * E * rng.uniform(-1, 1, n)
     pa.gid[:] = np.arange(n, dtype=pa.gid.dtype)
     return pa, kernel
 
@@ -316,7 +321,7 @@ def build_workload(args, rank, world):
     elif args.workload == 'elastic':
         from pysph_amd.solid_mech import ElasticSolidsScheme
         spacing = args.rings_spacing if args.rings_spacing > 0 else 0.041
-        pa, kernel = make_rings3d(args.rings_dx, spacing=spacing)
+        pa, kernel = make_rings3d(args.rings_dx, spacing=spacing, perturb=not args.rings_unperturbed)
         pa = cut_slab(w, pa, rank, world, kernel.radius_scale * 1.5 * args.rings_dx)
         w.arrays = [pa]
         w.kernel = kernel
@@ -553,6 +558,8 @@ def parse_args(argv=None):
                     help='arithmetic type of the pair kernels')
     ap.add_argument('--variant', type=int, default=6)
     ap.add_argument('--ablate', type=int, default=0, help='profiling only')
+    ap.add_argument('--rings-unperturbed', action='store_true', dest='rings_unperturbed',
+                    help='--workload elastic: the state rings.py starts from (no stress, no particle in tension)')
     ap.add_argument('--opt', action='append', default=[], help='key=value library option')
     ap.add_argument('--no-reorder', action='store_true',
                     help='skip Solver.reorder_particles() before timing')
@@ -804,7 +811,7 @@ def run(args, rank, local_rank, world, dist):
     # HBM bytes per launch of the dominant kernel come from a separate
     # rocprofv3 --pmc run of this same command (profiles/); only quoted when
     # the configuration matches the profiled one, else null
-    traffic, traffic_source, l1_fill = None, None, None
+    traffic, traffic_source, l1_fill, traffic_box_ms = None, None, None, None
     try:
         pt = json.load(open(os.path.join(REPO, 'profiles', 'pmc_traffic.json')))
         c = pt['config']
@@ -814,6 +821,7 @@ def run(args, rank, local_rank, world, dist):
                 and world == 1 and args.params == 'db' and not args.vary_h:
             traffic = pt['bytes_per_launch']
             l1_fill = pt.get('l1_fill_bytes_per_launch')
+            traffic_box_ms = pt.get('profiled_box_kernel_ms')
             traffic_source = pt.get('source', 'profiles/pmc_traffic.json: separate rocprofv3 --pmc '
                                               'passes of this command, not measured in this run')
     except Exception:
@@ -855,6 +863,8 @@ def run(args, rank, local_rank, world, dist):
             'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
             'traffic_source': traffic_source,
+            # the counters come from another box of the pool: that box's own kernel time, next to this run's avg_kernel_ms
+            'traffic_profiled_kernel_ms': traffic_box_ms,
             'algorithmic_bytes_per_particle': algo_pair,
             'avg_kernel_ms': pair_avg_s * 1e3,
             'pair_kernel_ms_per_step': pair_step_s * 1e3,
@@ -863,6 +873,7 @@ def run(args, rank, local_rank, world, dist):
             'l2_to_l1': None if not l1_fill or pair_avg_s <= 0 else {
                 'bytes_per_launch': l1_fill, 'achieved': l1_fill / pair_avg_s / 1e12,
                 'peak': L2_PEAK_TBS, 'unit': 'TB/s', 'frac': l1_fill / pair_avg_s / 1e12 / L2_PEAK_TBS,
+                'frac_on_profiled_box': None if not traffic_box_ms else l1_fill / (traffic_box_ms * 1e-3) / 1e12 / L2_PEAK_TBS,
                 'source': 'TCP_TCC_READ_REQ x 128 B of the profiled run (profiles/), this run\'s kernel time'},
         },
         'kernel_ms_per_step': {k: v[0] / args.steps for k, v in timers.items() if k not in PAIR_FAMILIES},
@@ -955,6 +966,8 @@ def secondary_runs(args, local_rank, tstream):
         ('C3 Taylor-Green 159^3 TVF', dict(workload='taylor_green', n1=159), True),
         ('C5 S-rings3d 2 M fp32', dict(workload='elastic', dtype='f32'), True),
         ('C5 S-rings3d 2 M fp64', dict(workload='elastic'), True),
+        ('C5 S-rings3d 2 M fp32 from rings.py\'s initial state (no stress yet: r_ij = 0, not gathered)',
+         dict(workload='elastic', dtype='f32', rings_unperturbed=True), True),
         ('100^3', dict(n1=100), False),
         ('252^3', dict(n1=252), False),
         ('159^3 unsorted', dict(no_reorder=True), False),

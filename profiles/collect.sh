@@ -6,7 +6,7 @@
 #                                          --kernel-trace only, as the pool requires)
 # profiles/summarize.py condenses the raw CSVs into profiles/.
 set -u
-TAG=${1:-r03}; shift || true
+TAG=${1:-r04}; shift || true
 ROOT=$(pwd)
 export TMPDIR=/tmp
 cd /tmp
@@ -57,6 +57,8 @@ else
     run_one rings 2 --workload elastic
     run_one rings_f32 0 --workload elastic --dtype f32
     run_one dam_break 0 --workload dam_break
-    run_one dam_break_4m 0 --workload dam_break --dx 0.0055
+    run_one dam_break_4m 2 --workload dam_break --dx 0.0055
+    run_one dam_break_16m 0 --workload dam_break --dx 0.0035
+    run_one cube_vh 0 --vary-h 0.15
 fi
 du -sh "$ROOT/gpurun_out/$TAG"

@@ -148,6 +148,9 @@ for w, bench in lines.items():
                                   'workload': 'cube', 'dtype': bench.get('dtype', 'f64')},
                        'bytes_per_launch': tr['bytes_per_launch'],
                        'l1_fill_bytes_per_launch': tr.get('l1_fill_bytes_per_launch'),
+                       # the pair kernel's live HIP-event mean of the un-profiled bench run on the box the counters
+                       # were taken on (same call): bench.py quotes it next to its own kernel time
+                       'profiled_box_kernel_ms': bench.get('roofline', {}).get('avg_kernel_ms'),
                        'source': 'profiles/%s_pmc_summary.json: FETCH_SIZE x 2 + WRITE_SIZE of separate '
                                  'rocprofv3 --pmc passes of this command on another box, not measured in '
                                  'this run' % tag},

@@ -129,7 +129,7 @@ int sph_ctx_destroy(sph_ctx *c)
         for (auto &p : A.prop) if (p) (void)hipFree(p);
         A.keys.release(); A.keys_sorted.release(); A.idx.release(); A.perm.release();
         A.tile_key.release(); A.tile_id.release(); A.tile_order.release();
-        A.cell_start.release(); A.fkeys_sorted.release(); A.fine_start.release();
+        A.cell_start.release(); A.fkeys_sorted.release(); A.fine_start.release(); A.tflag.release();
     }
     {
         DevArray &A = c->merged;
@@ -186,6 +186,7 @@ int sph_array_resize(sph_ctx *c, int id, size_t n, size_t n_real)
         A.cap = ncap;
     }
     if (n != A.n) c->nnps_valid = false;
+    if (n > A.n) A.tflag_valid = false; // new particles (ghosts, migrants): their r_ij were not looked at
     A.n = n;
     A.n_real = n_real;
     return SPH_OK;
@@ -226,6 +227,7 @@ int sph_array_push(sph_ctx *c, int id, int prop, const double *host, size_t offs
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (prop == SPH_X || prop == SPH_Y || prop == SPH_Z || prop == SPH_H) c->nnps_valid = false;
     if (prop == SPH_M) A.m_known = false; // until the next sph_nnps_update has looked at the masses
+    if (prop >= SPH_R00 && prop <= SPH_R22) A.tflag_valid = false;
     return SPH_OK;
 }
 
@@ -250,6 +252,7 @@ int sph_array_device_ptr(sph_ctx *c, int id, int prop, void **dptr)
     *dptr = c->arr[id].prop[prop];
     // whoever holds the raw pointer may write masses: the uniform-mass records wait for the next sph_nnps_update's look
     if (prop == SPH_M) c->arr[id].m_known = false;
+    if (prop >= SPH_R00 && prop <= SPH_R22) c->arr[id].tflag_valid = false;
     return SPH_OK;
 }
 
@@ -299,6 +302,7 @@ int sph_set_option(sph_ctx *c, const char *key, long value)
     if (strcmp(key, "nl_reuse") == 0) { c->nl_reuse = value; c->nl.valid = false; return SPH_OK; }
     if (strcmp(key, "norm_masks") == 0) { c->norm_masks = value; return SPH_OK; }
     if (strcmp(key, "merge_arrays") == 0) { c->merge_arrays = value ? 1 : 0; c->nnps_valid = false; return SPH_OK; }
+    if (strcmp(key, "tension_flag") == 0) { c->tension_flag = value ? 1 : 0; return SPH_OK; }
     if (strcmp(key, "lazy_tables") == 0) { c->lazy_tables = value ? 1 : 0; c->nnps_valid = false; return SPH_OK; }
     sph_set_error("sph_set_option: unknown key '%s'", key);
     return SPH_ERR_ARG;
@@ -332,7 +336,7 @@ int sph_timer_get(sph_ctx *c, const char *key, double *ms, long *count)
 {
     static const char *names[T_COUNT] = {"nnps", "pack", "eos", "pair", "stage",
                                          "pair_none", "pair_wcsph", "pair_density", "pair_tvf", "pair_vgrad", "pair_elastic",
-                                         "n_eos_fused", "n_nl_keep", "n_nl_reuse", "n_mass_fused", "n_merged"};
+                                         "n_eos_fused", "n_nl_keep", "n_nl_reuse", "n_mass_fused", "n_merged", "n_tension_flag"};
     SPH_TRY(timer_drain(c));
     for (int i = 0; i < T_COUNT; i++)
         if (strcmp(key, names[i]) == 0) {

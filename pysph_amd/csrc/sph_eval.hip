@@ -43,6 +43,7 @@ struct EosArgs {
     double *rho, *p, *cs;
     size_t start, stop;
     double *q[SPH_PROP_COUNT]; // every device property of the destination (elastic equations)
+    uint32_t *tflag;           // MonaghanArtificialStress: set to 1 when any r_ij is non-zero (DevArray::tflag), or null
 };
 
 // Symmetric 3x3 eigen-decomposition by cyclic Jacobi rotations.  The reference
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(256) void k_nosrc(EosArgs a)
             for (int k = 0; k < 3; k++) lam[k] *= sc;
         }
         for (int k = 0; k < 3; k++) rd[k] = lam[k] > 0 ? -a.par[0] * lam[k] * rhoi21 : 0.0;
+        if (a.tflag && (rd[0] != 0.0 || rd[1] != 0.0 || rd[2] != 0.0)) *a.tflag = 1u; // a particle in tension: r_ij != 0
         // transform_diag_inv: R diag(rd) R^T  (linalg3.pyx:220-234)
         double Rab[3][3];
         for (int r = 0; r < 3; r++)
@@ -1051,6 +1053,7 @@ template <class T> struct FamElastic_T {
     struct Params {
         T wdeltap, n, alpha, beta, eps;
         double *arho, *au, *av, *aw, *ax, *ay, *az;
+        const uint32_t *tension; // FamElasticU_T: the source array's "a particle is in tension" word, or null (always gather r_ij)
     };
     // The destination's own tensors are NOT live in the pair loop: with S = sum_j m_j DWIJ and F = sum_j m_j f^n DWIJ,
     //   sum_j m_j ((t_i + t_j) + f^n (r_i + r_j)) . DWIJ = t_i . S + r_i . F + sum_j m_j (t_j + f^n r_j) . DWIJ,
@@ -1140,15 +1143,24 @@ typedef FamElastic_T<double> FamElastic;
 // r02 r11 | r12 r22], 160 bytes = ten 16-B pieces instead of eleven; fp32 [x y z u | v w rho cs | t00 t01 t02 t11 |
 // t12 t22 r00 r01 | r02 r11 r12 r22], 80 bytes = five pieces instead of six.
 template <class T> struct FamElasticU_T : FamElastic_T<T> {
-    static constexpr bool EOSF = true; // own record decoding (load_fused)
+    static constexpr bool EOSF = true;  // own record decoding (load_fused)
+    static constexpr bool TOKEN = true; // wave token: 1 = gather the r_ij, 0 = no particle of the source is in tension (r_ij = 0:
+                                        // MonaghanArtificialStress, solid_mech/basic.py:170-242, leaves them zero under compression)
     static constexpr int NA = 18;
-    template <class A> static __device__ __forceinline__ void load_fused(const A &a, uint32_t jg, uint32_t, T mu, real4<T> &pj, T (&s)[18])
+    template <class A> static __device__ __forceinline__ uint32_t wave_token(const A &a)
+    {
+        return a.p.tension ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*a.p.tension) : 1u;
+    }
+    template <class A> static __device__ __forceinline__ void load_fused(const A &a, uint32_t jg, uint32_t, T mu, real4<T> &pj, T (&s)[18],
+                                                                         uint32_t with_r = 1u)
     {
         if constexpr (sizeof(T) == 8) {
             const double2 *p = reinterpret_cast<const double2 *>(a.rec) + (unsigned long long)jg * 10;
             double2 q[10];
 #pragma unroll
-            for (int k = 0; k < 10; k++) q[k] = p[k];
+            for (int k = 0; k < 7; k++) q[k] = p[k];
+            if (with_r) { q[7] = p[7]; q[8] = p[8]; q[9] = p[9]; }
+            else q[7] = q[8] = q[9] = make_double2(0.0, 0.0);
             pj.x = q[0].x; pj.y = q[0].y; pj.z = q[1].x; pj.w = 0.0;
             s[0] = q[1].y; s[1] = q[2].x; s[2] = q[2].y; s[3] = mu; s[4] = q[3].x; s[5] = q[3].y;
 #pragma unroll
@@ -1157,7 +1169,9 @@ template <class T> struct FamElasticU_T : FamElastic_T<T> {
             const float4 *p = reinterpret_cast<const float4 *>(a.rec) + (unsigned long long)jg * 5;
             float4 q[5];
 #pragma unroll
-            for (int k = 0; k < 5; k++) q[k] = p[k];
+            for (int k = 0; k < 4; k++) q[k] = p[k];
+            if (with_r) q[4] = p[4];
+            else { q[4] = make_float4(0.f, 0.f, 0.f, 0.f); q[3].z = 0.f; q[3].w = 0.f; }
             pj.x = q[0].x; pj.y = q[0].y; pj.z = q[0].z; pj.w = 0.f;
             s[0] = q[0].w; s[1] = q[1].x; s[2] = q[1].y; s[3] = mu; s[4] = q[1].z; s[5] = q[1].w;
 #pragma unroll
@@ -1265,6 +1279,14 @@ static int run_nosrc(sph_ctx *c, const sph_equation &e, size_t start, size_t sto
     for (int k = 0; k < SPH_PROP_COUNT; k++) a.q[k] = A.prop[k];
     a.rho = A.prop[SPH_RHO];
     a.p = A.prop[SPH_P];
+    a.tflag = nullptr;
+    if (e.kind == SPH_EQ_MONAGHAN_ART_STRESS) {
+        // "no particle in tension" for the rates kernel: valid when this launch covers every particle of the array
+        SPH_TRY(A.tflag.reserve(64));
+        HIP_TRY(hipMemsetAsync(A.tflag.ptr, 0, 4, c->stream));
+        a.tflag = A.tflag.as<uint32_t>();
+        A.tflag_valid = start == 0 && stop == A.n;
+    }
     ScopedTimer tm(c, T_EOS);
     hipLaunchKernelGGL(k_nosrc, dim3(div_up(stop - start, 256)), dim3(256), 0, c->stream, a);
     return SPH_OK;
@@ -2088,6 +2110,11 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             const sph_equation *se = eq_of[SPH_EQ_MOMENTUM_WITH_STRESS], *ae = eq_of[SPH_EQ_MONAGHAN_ART_VISCOSITY],
                                *xe = eq_of[SPH_EQ_XSPH];
             if (se) { a.p.wdeltap = se->par[0]; a.p.n = se->par[1]; }
+            a.p.tension = nullptr;
+            if (elu && c->tension_flag && nsrcs == 1 && c->arr[srcs[0]].tflag_valid && c->arr[srcs[0]].tflag.ptr) {
+                a.p.tension = c->arr[srcs[0]].tflag.as<uint32_t>();
+                c->timers[T_N_TFLAG].count++;
+            }
             if (ae) { a.p.alpha = ae->par[0]; a.p.beta = ae->par[1]; }
             if (xe) a.p.eps = xe->par[0];
             if (dflags & F_ECONT) { SPH_TRY(ensure_out(c, dst, {SPH_ARHO})); a.p.arho = D.prop[SPH_ARHO]; }
@@ -2231,6 +2258,7 @@ static int eval_generated_launches(sph_ctx *c, const sph_kernel *K, const sph_ge
         SPH_TRY(sph_array_ensure_prop(c, dst, p));
         g.dout[k] = D.prop[p];
         if (p == SPH_M) D.m_known = false; // a generated body writes masses: uniform-mass records wait for the next look
+        if (p >= SPH_R00 && p <= SPH_R22) D.tflag_valid = false;
     }
     for (int k = 0; k < f->n_din; k++) {
         int p = f->din[k];

@@ -56,6 +56,10 @@ struct DevArray {
     double m_value = 0.0;                // ... this one (a push of m, or an update that skips the reduction, forgets it)
     int nnps_slot = -1;                  // position in the last sph_nnps_update list
     size_t perm_n = 0;                   // particles `perm` was built for (0: none / already applied)
+    // "no particle of this array is in tension": a device word the artificial-stress kernel (k_nosrc) sets to 1 when
+    // any r_ij is non-zero; valid while that kernel covered every particle and nothing wrote r_ij since
+    DevBuf tflag;
+    bool tflag_valid = false;
     DevBuf slot8;                        // merged order only (sph_ctx::merged): uint8 nnps slot of every particle's array
 };
 
@@ -68,7 +72,7 @@ struct HaloState {
 
 // T_PAIR: every pair launch; T_PAIR_FAM + family (sph_eval.hip enum Family): the same launches per equation family
 // T_N_*: launch counters only (no time): pair launches on EOS-fused records, launches that kept / reused neighbour lists
-enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_STAGE, T_PAIR_FAM, T_N_EOSF = T_PAIR_FAM + 6, T_N_NLKEEP, T_N_NLREUSE, T_N_UMASS, T_N_MERGED, T_COUNT };
+enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_STAGE, T_PAIR_FAM, T_N_EOSF = T_PAIR_FAM + 6, T_N_NLKEEP, T_N_NLREUSE, T_N_UMASS, T_N_MERGED, T_N_TFLAG, T_COUNT };
 
 struct Timer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -107,6 +111,7 @@ struct sph_ctx {
     DevArray merged;
     bool merged_valid = false;
     long merge_arrays = 1;
+    long tension_flag = 1;  // elastic rates: r_ij gathered only when the source array's tension word says so
     // ... built FIRST by sph_nnps_update (one stable sort of all arrays' keys); the per-array orders and tables are a
     // stable compaction of it by slot, made when something first asks for them (nnps_need_tables)
     bool tables_valid = true;

@@ -115,6 +115,11 @@ template <class V> __device__ __forceinline__ V kernarg_read(size_t byte_offset)
     return *reinterpret_cast<const V __attribute__((address_space(4))) *>(ka + byte_offset);
 }
 
+// does the family read a wave-uniform word once per wavefront and hand it to every record decode (Fam::wave_token,
+// load_fused(..., token))?  (elastic rates: "no particle of the source array is in tension")
+template <class F, class = void> struct fam_token { static constexpr bool value = false; };
+template <class F> struct fam_token<F, decltype((void)F::TOKEN)> { static constexpr bool value = F::TOKEN; };
+
 // does the family recompute p, cs from rho (64-byte WCSPH records)?
 template <class F, class = void> struct fam_eosf { static constexpr bool value = false; };
 template <class F> struct fam_eosf<F, decltype((void)F::EOSF)> { static constexpr bool value = F::EOSF; };
@@ -400,10 +405,13 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     }
     real4<T> pi;
     typename Fam::Dest D;
+    uint32_t wtok = 0;
+    if constexpr (fam_token<Fam>::value) wtok = Fam::wave_token(a);
     T cur_mu = (T)a.d_mu; // mass of the array being read (uniform-mass records): the destination's own first, then each source's
     // one record: fp32 records for Real = float (and for record_f32), else fp64
     auto fetch = [&](uint32_t jg, uint32_t flags, real4<T> &pj, T (&sj)[Fam::NA]) {
-        if constexpr (fam_eosf<Fam>::value) Fam::load_fused(a, jg, flags, cur_mu, pj, sj);
+        if constexpr (fam_token<Fam>::value) Fam::load_fused(a, jg, flags, cur_mu, pj, sj, wtok);
+        else if constexpr (fam_eosf<Fam>::value) Fam::load_fused(a, jg, flags, cur_mu, pj, sj);
         else if constexpr (F32) load_record_f32<Fam, T>(reinterpret_cast<const float *>(a.rec) + (unsigned long long)jg * NR, pj, sj);
         else load_record<Fam, UH>(a.rec + (unsigned long long)jg * NR, flags, pj, sj);
     };

@@ -54,7 +54,7 @@ def _run(argv, opts, steps=2):
         for f in w.fields:
             if f in pa.properties:
                 out[pa.name + '.' + f] = np.array(pa.get(f)[:nreal])
-    cnt = {k: ctx.timer_get(k)[1] for k in ('n_eos_fused', 'n_nl_keep', 'n_nl_reuse', 'n_mass_fused', 'n_merged')}
+    cnt = {k: ctx.timer_get(k)[1] for k in ('n_eos_fused', 'n_nl_keep', 'n_nl_reuse', 'n_mass_fused', 'n_merged', 'n_tension_flag')}
     res = bench.parity_check(w, host_in, nnps, domain,
                              bench.PARITY_TOL if args.dtype == 'f64' else 5e-5)
     del nnps, a_eval, step
@@ -337,3 +337,27 @@ def test_state_fused_tvf_and_uniform_elastic_records(argv, tol):
     else:
         assert r_on['parity_ok'] and r_off['parity_ok'], (r_on, r_off)
     assert _max_rel(on, off) < tol
+
+
+@pytest.mark.parametrize('argv', [['--workload', 'elastic', '--rings-dx', '1.6e-3', '--rings-unperturbed'],
+                                  ['--workload', 'elastic', '--rings-dx', '1.6e-3'],
+                                  ['--workload', 'elastic', '--rings-dx', '1.6e-3', '--rings-unperturbed', '--dtype', 'f32']],
+                         ids=['no-tension', 'tension', 'no-tension-fp32'])
+def test_artificial_stress_is_gathered_only_under_tension(argv):
+    """the rates kernel reads a device word the artificial-stress kernel sets when any r_ij is non-zero
+    and skips the r_ij pieces of every record otherwise: bit-identical to always gathering them, with
+    (perturbed rings) and without (rings.py's initial state) particles in tension"""
+    on, c_on, r_on = _run(argv, {}, steps=3)
+    off, c_off, r_off = _run(argv, {'tension_flag': 0}, steps=3)
+    assert c_on['n_tension_flag'] == 2 and c_off['n_tension_flag'] == 0, (c_on, c_off)
+    if '--dtype' in argv:
+        assert r_on['parity_max_rel'] < 5e-5, r_on
+    else:
+        assert r_on['parity_ok'], r_on
+    assert r_on['parity_neighbour_count_mismatches'] == 0
+    for k in on:
+        assert np.array_equal(on[k], off[k]), k
+    if '--rings-unperturbed' in argv:
+        assert not np.any(on['solid.r00']) and not np.any(on['solid.r12'])
+    else:
+        assert np.any(on['solid.r00'])
