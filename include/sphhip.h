@@ -464,6 +464,13 @@ int sph_reduce_min(sph_ctx *ctx, int array_id, int prop, double *out);
  *                    reduction (bounds + sph_nnps_set_h_range), falls back to the mass-carrying records;
  *                    masses written through sph_array_device_ptr, or by a generated equation, AFTER the
  *                    last update are seen by the next one -- as a changed h is by the uniform-h path)
+ *   "merge_arrays"   0: never run a multi-array WCSPH group as one launch over the merged cell order of all arrays
+ *                    (default 1: taken when the group's (destination, source) equation matrix is the two-class table
+ *                    of WCSPHScheme(fluids, solids), under the conditions of the uniform-mass EOS-fused records;
+ *                    sph_nnps_update then sorts all arrays' keys once -- that sorted sequence is the merged order --
+ *                    and derives per-array tables only on demand; "lazy_tables" 0 builds them at every update)
+ *   "tension_flag"   0: the elastic rates always gather the artificial stress r_ij (default 1: only while the word the
+ *                    MonaghanArtificialStress kernel sets says a particle of the source array is in tension)
  *   "nl_reuse"       1: honour sph_group.nl_mode (default 0: measured slower)
  *   "norm_masks"     0: hit masks are not shifted down to a lane's first hit (default 1)
  *   "row_mod3"       order in which a wavefront visits its 3x3 rows of cells: 3 (default) = the row whose
@@ -486,7 +493,8 @@ int sph_timer_reset(sph_ctx *ctx);
  * equation family: "pair_wcsph", "pair_density", "pair_tvf", "pair_vgrad",
  * "pair_elastic"; out: total ms and launches.  Launch counters (ms = 0, counted
  * whether or not timing is enabled): "n_eos_fused" (pair launches on the 64-byte
- * EOS-fused records), "n_mass_fused" (of those, on uniform-mass records),
+ * EOS-fused records), "n_mass_fused" (launches on records that rely on one mass per array), "n_merged" (group
+ * evaluations run as one launch over the merged order), "n_tension_flag" (elastic rate launches that read the tension word),
  * "n_nl_keep" / "n_nl_reuse" (launches that kept / started from kept neighbour
  * lists). */
 int sph_timer_get(sph_ctx *ctx, const char *key, double *ms, long *count);
