@@ -558,6 +558,10 @@ def parse_args(argv=None):
                     help='arithmetic type of the pair kernels')
     ap.add_argument('--variant', type=int, default=6)
     ap.add_argument('--ablate', type=int, default=0, help='profiling only')
+    ap.add_argument('--overlap-halo', action='store_true', dest='overlap_halo',
+                    help='slab runs whose evaluation can be split (one array, WCSPH): post the ghost transfers, run the '
+                         'neighbour update and the interior wave tiles, then the ghosts and the face tiles '
+                         '(default: the plain exchange -> neighbour update -> evaluation order; DESIGN.md section 6)')
     ap.add_argument('--rings-unperturbed', action='store_true', dest='rings_unperturbed',
                     help='--workload elastic: the state rings.py starts from (no stress, no particle in tension)')
     ap.add_argument('--opt', action='append', default=[], help='key=value library option')
@@ -726,11 +730,33 @@ def setup(args, w, rank, world, dist, ctx):
         pad = nnps.cell_size
         nnps.bounds = tuple(nnps.xmin - pad) + tuple(nnps.xmax + pad)
 
+    # Slab runs whose evaluation can be split around the arrival of the ghosts (one particle array, hand-written
+    # kernels, pair loops over real particles: the cube) overlap the exchange with the neighbour update of the real
+    # particles and the interior part of the pair loops
+    ce = a_eval.c_acceleration_eval
+    overlap = (halo is not None and domain is None and args.overlap_halo
+               and hasattr(halo, 'exchange_begin') and ce.can_split())
+    if overlap:
+        nnps.set_extend(w.halo_width, 0.0, 0.0)
+    w.overlap_halo = bool(overlap)
+
     def step():
         if domain is not None:
             nnps.update_domain()        # periodic (and, with a slab, remote) ghosts rebuilt every step
+        elif overlap:
+            st = halo.exchange_begin()
+            if st is not None:          # transfers posted: everything that needs no ghosts runs now
+                nnps.set_ghost_faces(0, *halo.faces())
+                nnps.update()
+                ce.compute_begin(0.0, 1e-5)
+                halo.exchange_finish(st)
+                nnps.update_ghosts(0, *halo.faces())
+                ce.compute_end(0.0, 1e-5)
+                return
         elif halo is not None:
             halo.exchange()
+        if overlap:
+            nnps.set_ghost_faces(-1)    # (an exchange that completed in one piece: the plain order)
         nnps.update()
         a_eval.compute(0.0, 1e-5)
     return nnps, a_eval, halo, domain, step, ordered
@@ -855,6 +881,7 @@ def run(args, rank, local_rank, world, dist):
             'parallelism': 'slab%d' % world if world > 1 else ('slab1-self-exchange' if halo is not None else 'single'),
             'rccl_ranks': world if dist is not None else 0,
             'fixed_bounds': bool(args.fixed_bounds),
+            'halo_overlap': bool(getattr(w, 'overlap_halo', False)),
         },
         'roofline': {
             'bound': 'hbm', 'kernel': 'k_pair_%s<%s,%s>' % (
@@ -1043,7 +1070,8 @@ def multi_rank_parity(args, rank, local_rank, world, dist, tstream):
     apply_options(a2, ctx)
     w = build_workload(a2, rank, world)
     nnps, a_eval, halo, domain, step, _ = setup(a2, w, rank, world, dist, ctx)
-    step()
+    for _ in range(3):      # the third evaluation runs the steady-state exchange (overlapped where the workload allows)
+        step()
     fields = list(w.fields)
     gathered = []
     for pa in w.arrays:

@@ -142,6 +142,12 @@ typedef struct {
     int src_eos;
     double eos_par[4];
     int nl_mode;
+    /* phase (ghost split, single-array groups): 0 = the whole group; 1 = the part that needs no ghosts, called
+     * after sph_nnps_update and BEFORE the ghosts arrive (equations without sources over the particles present,
+     * records of the real particles packed, pair loops of the wavefronts whose candidates cannot include a ghost);
+     * 2 = the rest, after sph_nnps_update_ghosts (equations without sources over the new particles, ghost records,
+     * the remaining wavefronts).  1 and 2 of one group must follow each other with only phase calls in between.   */
+    int phase;
 } sph_group;
 
 /* ---------------------------------------------------------------------- */
@@ -199,6 +205,25 @@ int sph_nnps_update(sph_ctx *ctx, int dim, int narrays, const int *array_ids,
  * given as well the whole min/max pass and its device->host round trip.
  * hmax < 0 forgets the range.                                                */
 int sph_nnps_set_h_range(sph_ctx *ctx, double hmin, double hmax);
+/* Ghost split -- overlapping the ghost exchange of a slab-decomposed run with the evaluation
+ * (ParallelManager.update, pysph/parallel/parallel_manager.pyx:512-530, is serial in the reference):
+ *   sph_nnps_set_extend   the computed bounds are widened by ext[k] on both sides of axis k before the 1 % padding
+ *                         (the halo width along the slab axis: the grid of the REAL particles must hold the ghosts
+ *                         that arrive later; ghosts outside the grid are clamped into its outermost cells, which
+ *                         costs candidates, never neighbours);
+ *   sph_nnps_update       then runs while the ghosts are still in flight (the arrays hold their real particles);
+ *   sph_nnps_update_ghosts  after the ghosts were appended: bins the particles behind the ones the update saw into
+ *                         ghost-only tables on the same grid; pair evaluations read them as a second source segment
+ *                         of their array.  `axis`, `lo`, `hi`: every ghost has coordinate < lo or >= hi along `axis`
+ *                         (the slab faces; -inf / +inf for an open face) -- with axis 0 wavefronts whose candidate
+ *                         windows stay inside [lo, hi) skip the ghost segments, and sph_group.phase can split an
+ *                         evaluation into the part that needs no ghosts and the rest.                             */
+int sph_nnps_set_extend(sph_ctx *ctx, double ex, double ey, double ez);
+/* The slab faces along `axis` outside which this rank's ghosts lie (coordinate < lo or >= hi; -inf / +inf: open face;
+ * axis -1: none).  Named BEFORE sph_nnps_update so that the first half of a split evaluation already knows which
+ * wavefronts can reach a ghost.                                                                                  */
+int sph_nnps_set_ghost_faces(sph_ctx *ctx, int axis, double lo, double hi);
+int sph_nnps_update_ghosts(sph_ctx *ctx, int axis, double lo, double hi);
 /* d8: cell_size hmin xmin[3] xmax[3];  i4: ncx ncy ncz n_cells             */
 int sph_nnps_info(sph_ctx *ctx, double *d8, long *i4);
 /* min/max of x,y,z,h over the listed arrays, no padding (out: 8 doubles
@@ -494,7 +519,8 @@ int sph_timer_reset(sph_ctx *ctx);
  * "pair_elastic"; out: total ms and launches.  Launch counters (ms = 0, counted
  * whether or not timing is enabled): "n_eos_fused" (pair launches on the 64-byte
  * EOS-fused records), "n_mass_fused" (launches on records that rely on one mass per array), "n_merged" (group
- * evaluations run as one launch over the merged order), "n_tension_flag" (elastic rate launches that read the tension word),
+ * evaluations run as one launch over the merged order), "n_tension_flag" (elastic rate launches that read the tension word), "n_phase2" (pair launches of the second half of a
+ * split evaluation: sph_group.phase 2),
  * "n_nl_keep" / "n_nl_reuse" (launches that kept / started from kept neighbour
  * lists). */
 int sph_timer_get(sph_ctx *ctx, const char *key, double *ms, long *count);

@@ -228,9 +228,13 @@ class _BuiltinUnit(object):
             self.ceqs[i].par[k] = float(_get(self._arrays[dest], cname)[0])
         self.cg.start_idx, self.cg.stop_idx = start, stop
 
-    def run(self, ev, t, dt):
-        dev._check(ev.lib.sph_eval_group(
-            ev.ctx._h, C.byref(ev.ckernel), C.byref(self.cg), t, dt))
+    def run(self, ev, t, dt, phase=0):
+        self.cg.phase = phase
+        try:
+            dev._check(ev.lib.sph_eval_group(
+                ev.ctx._h, C.byref(ev.ckernel), C.byref(self.cg), t, dt))
+        finally:
+            self.cg.phase = 0
 
 
 class _GeneratedUnit(object):
@@ -624,6 +628,47 @@ class HipAccelerationEval(object):
             self._run(entry, t, dt)
         if self.sync == 'auto':
             self.pull_outputs()
+
+    # -- an evaluation in two halves around the arrival of the ghosts ---------
+    def can_split(self):
+        """May `compute` run as `compute_begin` (before the ghosts of a slab
+        exchange arrive) + `compute_end` (after `nnps.update_ghosts()`)?  Yes for
+        a device-resident plan of plain leaf groups with hand-written kernels
+        over ONE particle array whose pair loops visit real particles only
+        (ghosts are sources, never destinations): equations without sources run
+        over the particles present in each half, the pair loops of the wavefronts
+        that cannot reach a ghost run in the first half, the others in the
+        second (sph_group.phase)."""
+        if self.sync != 'manual' or len(self.particle_arrays) != 1:
+            return False
+        pair_groups = []
+        for k, (g, item) in enumerate(self.plan):
+            if isinstance(item, list) or not _plain_leaf(g, item) or _ranged(g):
+                return False
+            for u in item.units:
+                if u.has_pair:
+                    if not g.real:
+                        return False
+                    pair_groups.append(k)
+        # nothing may read what a pair loop writes before the SECOND half has completed it for the particles near the
+        # faces: exactly one group with pair loops, and it is the last one (equations without sources of that group run
+        # before its loops).  WCSPH's [EOS | rates] qualifies; the elastic set (stress rates from the velocity gradient
+        # of the same evaluation) does not.
+        return len(set(pair_groups)) == 1 and pair_groups[0] == len(self.plan) - 1
+
+    def compute_begin(self, t, dt):
+        if not self.can_split():
+            raise RuntimeError('this evaluation cannot be split around the ghost exchange (can_split())')
+        self._phase(1, t, dt)
+
+    def compute_end(self, t, dt):
+        self._phase(2, t, dt)
+
+    def _phase(self, phase, t, dt):
+        for g, item in self.plan:
+            item.refresh_range()
+            for u in item.units:
+                u.run(self, t, dt, phase)
 
     # -- data movement --------------------------------------------------------
     def push_inputs(self):

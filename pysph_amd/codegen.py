@@ -1393,6 +1393,7 @@ class GeneratedFamily(object):
             len(din), len(dout), len(self.params)))
         A('    PairArgs<FamGen> a;')
         A('    memset(&a, 0, sizeof a);')
+        A('    a.gfx_lo = -0x7fffffff; a.gfx_hi = 0x7fffffff; // no ghost split for generated families')
         A('    a.norm_masks = g->norm_masks;')
         A('    a.row_mod3 = g->row_mod3;')
         A('    a.nsrc = g->nsrc;')

@@ -130,6 +130,7 @@ int sph_ctx_destroy(sph_ctx *c)
         A.keys.release(); A.keys_sorted.release(); A.idx.release(); A.perm.release();
         A.tile_key.release(); A.tile_id.release(); A.tile_order.release();
         A.cell_start.release(); A.fkeys_sorted.release(); A.fine_start.release(); A.tflag.release();
+        A.g_keys.release(); A.g_fkeys.release(); A.g_perm.release(); A.g_fine_start.release(); A.g_cell_start.release();
     }
     {
         DevArray &A = c->merged;
@@ -226,7 +227,7 @@ int sph_array_push(sph_ctx *c, int id, int prop, const double *host, size_t offs
     // only after a sync; keep the call synchronous so Python may reuse `host`.
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (prop == SPH_X || prop == SPH_Y || prop == SPH_Z || prop == SPH_H) c->nnps_valid = false;
-    if (prop == SPH_M) A.m_known = false; // until the next sph_nnps_update has looked at the masses
+    if (prop == SPH_M) { A.m_known = false; A.m_mixed_ghosts = false; } // until the next sph_nnps_update has looked at the masses
     if (prop >= SPH_R00 && prop <= SPH_R22) A.tflag_valid = false;
     return SPH_OK;
 }
@@ -336,7 +337,7 @@ int sph_timer_get(sph_ctx *c, const char *key, double *ms, long *count)
 {
     static const char *names[T_COUNT] = {"nnps", "pack", "eos", "pair", "stage",
                                          "pair_none", "pair_wcsph", "pair_density", "pair_tvf", "pair_vgrad", "pair_elastic",
-                                         "n_eos_fused", "n_nl_keep", "n_nl_reuse", "n_mass_fused", "n_merged", "n_tension_flag"};
+                                         "n_eos_fused", "n_nl_keep", "n_nl_reuse", "n_mass_fused", "n_merged", "n_tension_flag", "n_phase2"};
     SPH_TRY(timer_drain(c));
     for (int i = 0; i < T_COUNT; i++)
         if (strcmp(key, names[i]) == 0) {

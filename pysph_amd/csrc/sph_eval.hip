@@ -1283,9 +1283,9 @@ static int run_nosrc(sph_ctx *c, const sph_equation &e, size_t start, size_t sto
     if (e.kind == SPH_EQ_MONAGHAN_ART_STRESS) {
         // "no particle in tension" for the rates kernel: valid when this launch covers every particle of the array
         SPH_TRY(A.tflag.reserve(64));
-        HIP_TRY(hipMemsetAsync(A.tflag.ptr, 0, 4, c->stream));
+        if (start == 0) HIP_TRY(hipMemsetAsync(A.tflag.ptr, 0, 4, c->stream)); // (a phase-2 launch over the ghosts only adds to the word)
         a.tflag = A.tflag.as<uint32_t>();
-        A.tflag_valid = start == 0 && stop == A.n;
+        A.tflag_valid = (start == 0 && stop == A.n) || (A.tflag_valid && start <= A.n_binned && stop == A.n);
     }
     ScopedTimer tm(c, T_EOS);
     hipLaunchKernelGGL(k_nosrc, dim3(div_up(stop - start, 256)), dim3(256), 0, c->stream, a);
@@ -1418,14 +1418,17 @@ static int pack_pieces(const PackArgs &pa)
 // `launch` false: validate only (the records of this array are already in the packed buffer, see
 // the pack cache in sph_eval_group)
 static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fam, uint32_t flags, bool dest_only = false,
-                      bool launch = true)
+                      bool launch = true, int seg = 0)
 {
     DevArray &A = c->arr[id];
-    if (A.n == 0) return SPH_OK;
+    // seg 0: the particles sph_nnps_update binned, through their cell order; seg 1: the ghosts binned after it
+    // (sph_nnps_update_ghosts), through theirs, behind the first segment's records
+    const size_t nseg = seg ? A.g_n : A.n_binned;
+    if (nseg == 0) return SPH_OK;
     PackArgs pa;
-    pa.perm = A.perm.as<uint32_t>();
-    pa.n = A.n;
-    pa.off = off;
+    pa.perm = seg ? A.g_perm.as<uint32_t>() : A.perm.as<uint32_t>();
+    pa.n = nseg;
+    pa.off = off + (seg ? A.n_binned : 0);
     pa.x = A.prop[SPH_X]; pa.y = A.prop[SPH_Y]; pa.z = A.prop[SPH_Z]; pa.h = A.prop[SPH_H];
     pa.na = pl.na;
     for (int k = 0; k < MAX_AUX; k++) {
@@ -1477,7 +1480,7 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
         pa.derived = 0;
     }
     pa.lds_np = pack_pieces(pa);
-    if (launch) hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), (size_t)pa.lds_np * 256 * 16, c->stream, pa);
+    if (launch) hipLaunchKernelGGL(k_pack, dim3(div_up(nseg, 256)), dim3(256), (size_t)pa.lds_np * 256 * 16, c->stream, pa);
     return SPH_OK;
 }
 
@@ -1579,6 +1582,9 @@ static void fill_common(sph_ctx *c, PairArgs<Fam> &a, const sph_kernel *K, doubl
     a.epsu = 0.01 * a.hu * a.hu;
     a.hr2u = (c->radius_scale * c->h_uniform) * (c->radius_scale * c->h_uniform);
     a.norm_masks = (int)c->norm_masks;
+    a.face_mode = 0;
+    a.gfx_lo = c->gfx_lo; // (no faces named: -/+ INT_MAX, no face wavefronts)
+    a.gfx_hi = c->gfx_hi;
 }
 
 // traversal order of the destination's tiles (sph_nnps_update builds it; option tile_block_rows) and of a tile's rows
@@ -1601,6 +1607,9 @@ int nnps_csr_pair_kernel(sph_ctx *c, int src, int dst, uint32_t *count, const ui
     SPH_TRY(nnps_need_tables(c));
     DevArray &S = c->arr[src], &D = c->arr[dst];
     if (D.n == 0) return SPH_OK;
+    // ghost split: the source's ghosts are its second segment; the destinations are the particles the update binned (the
+    // ghosts behind them have no lists: the callers zero their counts)
+    if (count && D.n > D.n_binned) HIP_TRY(hipMemsetAsync(count + D.n_binned, 0, (D.n - D.n_binned) * 4, c->stream));
     const bool uh = c->uniform_h && c->use_uniform_h;
     const bool dest_is_src = src == dst;
     const size_t total = S.n + (dest_is_src ? 0 : D.n);
@@ -1619,8 +1628,9 @@ int nnps_csr_pair_kernel(sph_ctx *c, int src, int dst, uint32_t *count, const ui
     if (rc == SPH_OK) rc = c->aux.reserve(64);
     if (rc == SPH_OK) rc = c->fposb.reserve((total + 64) * sizeof(float4));
     for (auto &pc : c->pack_cache) pc.epoch = 0;
-    if (rc == SPH_OK) rc = pack_array(c, src, 0, pl, FAM_NBR, 1u, false);
-    if (rc == SPH_OK && !dest_is_src) rc = pack_array(c, dst, S.n, pl, FAM_NBR, 1u, true);
+    if (rc == SPH_OK) rc = pack_array(c, src, 0, pl, FAM_NBR, 1u, false, true, 0);
+    if (rc == SPH_OK && S.g_n > 0) rc = pack_array(c, src, 0, pl, FAM_NBR, 1u, false, true, 1);
+    if (rc == SPH_OK && !dest_is_src) rc = pack_array(c, dst, S.n, pl, FAM_NBR, 1u, true, true, 0);
     c->record_f32 = was_f32; c->arith_f32 = was_a32;
     if (rc != SPH_OK) return rc;
     sph_kernel K;
@@ -1630,9 +1640,10 @@ int nnps_csr_pair_kernel(sph_ctx *c, int src, int dst, uint32_t *count, const ui
     fill_common(c, a, &K, 0.0);
     a.ablate = 0; a.dbg = nullptr;
     a.nsrc = 1;
-    a.src[0] = {S.cell_start.as<uint32_t>(), 0u, 1u, S.fine_start.as<uint32_t>()};
+    a.src[0] = {S.cell_start.as<uint32_t>(), 0u, 1u, S.fine_start.as<uint32_t>(), 0.0, 0u};
+    if (S.g_n > 0) a.src[a.nsrc++] = {S.g_cell_start.as<uint32_t>(), (uint32_t)S.n_binned, 1u, S.g_fine_start.as<uint32_t>(), 0.0, 1u};
     a.d_off = dest_is_src ? 0u : (uint32_t)S.n;
-    a.nd = (uint32_t)D.n;
+    a.nd = (uint32_t)D.n_binned;
     a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
     set_tile_order(c, a, D);
     a.d_start = 0; a.d_stop = (uint32_t)D.n; a.dflags = 1u;
@@ -1654,6 +1665,7 @@ static int eval_group_merged(sph_ctx *c, const sph_kernel *K, const sph_group *g
 {
     *done = false;
     if (!c->merged_valid || !c->merge_arrays || !c->nnps_valid || c->pair_variant != 6 || c->ablate || c->count_iters) return SPH_OK;
+    if (g->phase != 0 || c->ghosts_binned) return SPH_OK; // ghost segments: the per-destination path reads them as extra sources
     if (!(g->src_eos == 1 && c->eos_fuse && c->mass_fuse && c->const_flags && c->uniform_h && c->use_uniform_h &&
           g->eos_par[2] == 7.0 && g->eos_par[0] > 0.0 && !c->record_f32 && !c->wcsph_nr))
         return SPH_OK;
@@ -1845,6 +1857,11 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         for (int j = 0; j < ndest; j++) seen |= dests[j] == d;
         if (!seen) dests[ndest++] = d;
     }
+    const int phase = g->phase;
+    if (phase < 0 || phase > 2 || (phase != 0 && ndest != 1)) {
+        sph_set_error("sph_eval_group: phase %d needs a group with one destination array", phase);
+        return SPH_ERR_ARG;
+    }
     for (int di = 0; di < ndest; di++) {
         const int dst = dests[di];
         DevArray &D = c->arr[dst];
@@ -1853,12 +1870,13 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         size_t stop = g->stop_idx >= 0 ? (size_t)g->stop_idx : (g->real ? D.n_real : D.n);
         if (stop > D.n) stop = D.n;
 
-        // 1. equations without sources run first (mako :50-58)
+        // 1. equations without sources run first (mako :50-58); phase 2: over the particles that arrived since phase 1
+        const size_t ns_start = phase == 2 ? std::max(start, D.n_binned) : start;
         for (int i = 0; i < g->neq; i++) {
             const sph_equation &e = g->eqs[i];
             if (e.dest != dst || e.nsrc != 0) continue;
             if (!is_nosrc_kind(e.kind)) { sph_set_error("equation kind %d needs sources", e.kind); return SPH_ERR_UNSUPPORTED; }
-            SPH_TRY(run_nosrc(c, e, start, stop));
+            SPH_TRY(run_nosrc(c, e, ns_start, stop));
             c->pack_cache[dst].epoch = 0; // its properties changed: records packed for an earlier destination are stale
         }
 
@@ -1934,6 +1952,22 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             d_off = goff[dst];
         }
         if (total >= (1ull << 32)) { sph_set_error("too many particles for 32-bit packed indices"); return SPH_ERR_ARG; }
+        // ghost split (sph_nnps_update_ghosts): arrays whose ghosts were binned after the real particles carry them as a
+        // second record segment and a second source; the destinations are the particles the update binned
+        bool any_ghosts = false;
+        for (int j = 0; j < nsrcs; j++) any_ghosts |= c->arr[srcs[j]].g_n > 0;
+        any_ghosts |= D.g_n > 0;
+        if (phase != 0 && !(nsrcs == 1 && srcs[0] == dst && !share)) {
+            sph_set_error("sph_eval_group: phases need a group over ONE array (destination == its only source)");
+            return SPH_ERR_UNSUPPORTED;
+        }
+        if ((any_ghosts || phase != 0) && c->pair_variant != 6) {
+            sph_set_error("ghost segments (sph_nnps_update_ghosts) need pair_variant 6");
+            return SPH_ERR_UNSUPPORTED;
+        }
+        if (!dest_is_src && D.n_binned != D.n) {
+            // a destination-only array is read through its own records only: its ghosts are no destinations
+        }
         PackPlan pl = pack_plan(fam);
         // compact 80-B WCSPH records when neither h nor p of a neighbour is read
         if (c->pair_variant >= 3 && fam == FAM_WCSPH && c->uniform_h && c->use_uniform_h && !(dflags & F_TENSILE)) pl.nr = c->wcsph_nr ? (int)c->wcsph_nr : 10;
@@ -1982,9 +2016,12 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         c->cur_eosf = eosf;
         c->cur_nrec = pl.nr;
         const void *rec_was = c->posh.ptr, *fpos_was = c->fposb.ptr;
-        SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * (c->pair_variant >= 2 ? pl.nr : 4)));
-        SPH_TRY(c->aux.reserve((total + 64) * sizeof(double) * pl.na));
-        if (c->pair_variant >= 3) SPH_TRY(c->fposb.reserve((total + 64) * sizeof(float4)));
+        // phase 1 leaves room for the ghosts phase 2 packs behind the real particles' records (the array's capacity bounds
+        // them); phase 2 keeps what phase 1 packed should the buffers have to grow after all
+        const size_t total_res = phase == 1 ? std::max(total, D.cap) : total;
+        SPH_TRY(c->posh.reserve((total_res + 64) * sizeof(double) * (c->pair_variant >= 2 ? pl.nr : 4), phase == 2, c->stream));
+        SPH_TRY(c->aux.reserve((total_res + 64) * sizeof(double) * pl.na));
+        if (c->pair_variant >= 3) SPH_TRY(c->fposb.reserve((total_res + 64) * sizeof(float4), phase == 2, c->stream));
         if (c->posh.ptr != rec_was || c->fposb.ptr != fpos_was) // the buffers moved: nothing packed earlier is there
             for (auto &pc : c->pack_cache) pc.epoch = 0;
         {
@@ -2003,7 +2040,9 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             auto pack_once = [&](int id, size_t off, uint32_t fl, bool dest_only) -> int {
                 PackCache &pc = c->pack_cache[id];
                 const bool hit = share && pc.epoch == c->pack_epoch && pc.fam == fam && pc.sig == sig;
-                SPH_TRY(pack_array(c, id, off, pl, fam, fl, dest_only, !hit)); // a hit still validates
+                // phase 1: the particles present (the real ones); phase 2: the ghosts that arrived since; else both segments
+                if (phase != 2) SPH_TRY(pack_array(c, id, off, pl, fam, fl, dest_only, !hit, 0)); // a hit still validates
+                if (phase != 1 && c->arr[id].g_n > 0) SPH_TRY(pack_array(c, id, off, pl, fam, fl, dest_only, !hit, 1));
                 pc.epoch = share ? c->pack_epoch : 0; pc.fam = fam; pc.sig = sig;
                 return SPH_OK;
             };
@@ -2015,7 +2054,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         // the wave-tile kernel, same grid.  A pass that keeps its lists (1) records what they belong to; a pass
         // that wants them (2) gets them only if that record matches -- otherwise it runs its own phase 1.
         int nl_mode = 0;
-        if (c->nl_reuse && c->pair_variant == 6 && nsrcs == 1 && g->nl_mode && !c->ablate) {
+        if (c->nl_reuse && c->pair_variant == 6 && nsrcs == 1 && g->nl_mode && !c->ablate && !any_ghosts && phase == 0) {
             const size_t n_wt = (size_t)4 * div_up(D.n, 256);
             if (g->nl_mode == 1) {
                 SPH_TRY(c->nlbuf.reserve(n_wt * NLW * sizeof(uint32_t)));
@@ -2033,16 +2072,32 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         // 4. fused pair kernel, in the arithmetic type of the context (fp64, or fp32 with option arith_f32)
         ScopedTimer tm(c, T_PAIR);
         ScopedTimer tmf(c, T_PAIR_FAM + fam);
+        if (phase == 2) c->timers[T_N_PHASE2].count++;
         if (eosf || tvff || eosv) c->timers[T_N_EOSF].count++;
         if (umass || tvff || elu || eosv) c->timers[T_N_UMASS].count++;
         if (nl_mode == 1) c->timers[T_N_NLKEEP].count++;
         if (nl_mode == 2) c->timers[T_N_NLREUSE].count++;
         // the part of the launch arguments every family shares
+        {
+            int nseg = nsrcs;
+            for (int j = 0; j < nsrcs; j++) nseg += c->arr[srcs[j]].g_n > 0 && phase != 1;
+            if (nseg > SPH_MAX_ARRAYS) { sph_set_error("too many source segments (%d arrays with ghost segments)", nsrcs); return SPH_ERR_UNSUPPORTED; }
+        }
         auto common = [&](auto &a) {
             fill_common(c, a, K, t);
-            a.nsrc = nsrcs;
-            for (int j = 0; j < nsrcs; j++) a.src[j] = {c->arr[srcs[j]].cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j], c->arr[srcs[j]].fine_start.as<uint32_t>(), c->arr[srcs[j]].m_value};
-            a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n;
+            a.nsrc = 0;
+            for (int j = 0; j < nsrcs; j++) {
+                const DevArray &S = c->arr[srcs[j]];
+                a.src[a.nsrc++] = {S.cell_start.as<uint32_t>(), (uint32_t)off_of[j], sflags[j], S.fine_start.as<uint32_t>(), S.m_value, 0u};
+            }
+            for (int j = 0; j < nsrcs && phase != 1; j++) { // the ghost segments, after every array's first segment
+                const DevArray &S = c->arr[srcs[j]];
+                if (S.g_n == 0) continue;
+                a.src[a.nsrc++] = {S.g_cell_start.as<uint32_t>(), (uint32_t)(off_of[j] + S.n_binned), sflags[j],
+                                   S.g_fine_start.as<uint32_t>(), S.m_value, 1u};
+            }
+            a.face_mode = phase;
+            a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n_binned;
             a.d_mu = D.m_value;
             a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();
             set_tile_order(c, a, D);
@@ -2327,6 +2382,7 @@ static int eval_generated_launches(sph_ctx *c, const sph_kernel *K, const sph_ge
         if (ns > 0) {
             if (!c->nnps_valid) { sph_set_error("sph_eval_generated: neighbour grid is stale; call sph_nnps_update"); return SPH_ERR_STATE; }
             if (D.nnps_slot < 0) { sph_set_error("destination array %d is not part of the neighbour grid", dst); return SPH_ERR_STATE; }
+            if (c->ghosts_binned) { sph_set_error("generated families do not read ghost segments (ghost split): use the plain exchange -> sph_nnps_update order"); return SPH_ERR_UNSUPPORTED; }
             SPH_TRY(nnps_need_tables(c));
             size_t total = 0, off_of[SPH_MAX_ARRAYS];
             bool dest_is_src = false;

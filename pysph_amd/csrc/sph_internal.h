@@ -56,6 +56,13 @@ struct DevArray {
     double m_value = 0.0;                // ... this one (a push of m, or an update that skips the reduction, forgets it)
     int nnps_slot = -1;                  // position in the last sph_nnps_update list
     size_t perm_n = 0;                   // particles `perm` was built for (0: none / already applied)
+    // Ghost split (sph_nnps_update_ghosts): the tables above cover the first n_binned particles (the real ones: the
+    // update ran before the ghosts of this step arrived); the g_n ghosts behind them are binned on the same grid
+    // into tables of their own and read by the pair kernels as a second source segment of the array.
+    size_t n_binned = 0, g_n = 0;
+    bool m_mixed_ghosts = false;         // ghosts with another mass than the real particles' one were seen: no uniform-mass records
+    int g_mcheck = 0;                    // ghost binnings until the next look at the ghosts' masses
+    DevBuf g_keys, g_fkeys, g_perm, g_fine_start, g_cell_start;
     // "no particle of this array is in tension": a device word the artificial-stress kernel (k_nosrc) sets to 1 when
     // any r_ij is non-zero; valid while that kernel covered every particle and nothing wrote r_ij since
     DevBuf tflag;
@@ -72,7 +79,7 @@ struct HaloState {
 
 // T_PAIR: every pair launch; T_PAIR_FAM + family (sph_eval.hip enum Family): the same launches per equation family
 // T_N_*: launch counters only (no time): pair launches on EOS-fused records, launches that kept / reused neighbour lists
-enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_STAGE, T_PAIR_FAM, T_N_EOSF = T_PAIR_FAM + 6, T_N_NLKEEP, T_N_NLREUSE, T_N_UMASS, T_N_MERGED, T_N_TFLAG, T_COUNT };
+enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_STAGE, T_PAIR_FAM, T_N_EOSF = T_PAIR_FAM + 6, T_N_NLKEEP, T_N_NLREUSE, T_N_UMASS, T_N_MERGED, T_N_TFLAG, T_N_PHASE2, T_COUNT };
 
 struct Timer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -116,6 +123,14 @@ struct sph_ctx {
     // stable compaction of it by slot, made when something first asks for them (nnps_need_tables)
     bool tables_valid = true;
     long lazy_tables = 1;
+    // ghost split: the grid is padded by `extend` on both sides of every axis (the real particles' bounds must hold the
+    // ghosts that arrive later); ghosts have a fine x index <= gfx_lo or >= gfx_hi (wavefronts whose candidate windows
+    // stay inside never read a ghost segment)
+    double extend[3] = {0.0, 0.0, 0.0};
+    int gfx_lo = -0x7fffffff, gfx_hi = 0x7fffffff;
+    int face_axis = -1;      // sph_nnps_set_ghost_faces: the slab axis (-1: none) and the faces outside which ghosts lie
+    double face_lo = 0.0, face_hi = 0.0;
+    bool ghosts_binned = false;
     DevBuf splitcnt, scan_part, bigq;
 
     // scratch

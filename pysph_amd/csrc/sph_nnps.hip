@@ -147,7 +147,7 @@ int nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *out8)
     for (int a = 0; a < narrays; a++) {
         DevArray &A = c->arr[ids[a]];
         const double lo = c->pinned[8 + 2 * a], hi = c->pinned[8 + 2 * a + 1];
-        A.m_known = c->want_mrange && A.n > 0 && A.prop[SPH_M] && lo == hi;
+        A.m_known = c->want_mrange && A.n > 0 && A.prop[SPH_M] && lo == hi && !A.m_mixed_ghosts;
         A.m_value = lo;
     }
     return SPH_OK;
@@ -432,6 +432,7 @@ struct BinFixArgs {
     uint32_t *perm;          // sorted position -> position in the key array; rewritten to the local index when slot != null
     uint32_t *fkeys, *keys;  // optional: sorted fine keys / cell ids
     uint32_t *cell_start;    // optional (nsub > 0): nbins / nsub + 1 entries
+    uint32_t perm_base;      // added to every perm entry (slot == null): the sorted keys describe particles perm_base ... of an array
     uint8_t *slot;           // optional: array slot of every sorted particle (merged order)
     struct { uint32_t off[SPH_MAX_ARRAYS + 1]; int narrays; } co;
     uint32_t *bigq;          // [0] count, then bin ids
@@ -449,7 +450,7 @@ __device__ __forceinline__ void bin_emit(const BinFixArgs &a, uint32_t k, uint32
         a.slot[j] = (uint8_t)s;
         a.perm[j] = g - base;
     } else {
-        a.perm[j] = g;
+        a.perm[j] = g + a.perm_base;
     }
 }
 
@@ -507,6 +508,12 @@ __global__ __launch_bounds__(256) void k_bin_fix_big(BinFixArgs a, uint32_t *__r
 
 __global__ void k_reset_u32(uint32_t *p) { p[0] = 0u; }
 
+__global__ __launch_bounds__(256) void k_mass_differs(const double *__restrict__ m, size_t n, double mu, uint32_t *__restrict__ flag)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && m[i] != mu) *flag = 1u;
+}
+
 // Sort n keys < nbins through `table` (nbins + 2 entries; the count pass -- k_tile_keys or k_bin_count -- has run on the
 // zeroed table): leaves table[k] = first sorted position of bin k (k <= nbins) and fills the BinFixArgs outputs.
 static int nnps_bin_sort_finish(sph_ctx *c, const uint32_t *keys, size_t n, BinFixArgs fa, uint32_t *table)
@@ -521,6 +528,28 @@ static int nnps_bin_sort_finish(sph_ctx *c, const uint32_t *keys, size_t n, BinF
     hipLaunchKernelGGL(k_bin_fix, dim3(div_up((size_t)fa.nbins + 1, 256)), dim3(256), 0, c->stream, fa);
     hipLaunchKernelGGL(k_bin_fix_big, dim3(256), dim3(256), 0, c->stream, fa, c->tmp_u32b.as<uint32_t>());
     return SPH_OK;
+}
+
+// fine keys of a (small) set of particles + the counting sort's count pass
+__global__ __launch_bounds__(256) void k_cell_keys_count(const double *__restrict__ x, const double *__restrict__ y,
+                                                         const double *__restrict__ z, size_t n, GridDesc g,
+                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ count)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double ux = (x[i] - g.xmin[0]) / g.cell_size;
+    int cx = (int)floor(ux);
+    int cy = (int)floor((y[i] - g.xmin[1]) / g.cell_size);
+    int cz = (int)floor((z[i] - g.xmin[2]) / g.cell_size);
+    int sub = (int)floor((ux - (double)cx) * SPH_NSUB);
+    if (cx < 0) { cx = 0; sub = 0; }
+    if (cx > g.nc[0] - 1) { cx = g.nc[0] - 1; sub = SPH_NSUB - 1; }
+    sub = min(max(sub, 0), SPH_NSUB - 1);
+    cy = min(max(cy, 0), g.nc[1] - 1);
+    cz = min(max(cz, 0), g.nc[2] - 1);
+    const uint32_t key = (uint32_t)(cx + g.nc[0] * (cy + g.nc[1] * cz)) * SPH_NSUB + (uint32_t)sub;
+    keys[i] = key;
+    atomicAdd(&count[key + 2], 1u);
 }
 
 __global__ __launch_bounds__(256) void k_bin_count(const uint32_t *__restrict__ keys, size_t n, uint32_t *__restrict__ count)
@@ -744,6 +773,19 @@ static int nnps_tile_order(sph_ctx *c, DevArray &A, size_t n)
     return SPH_OK;
 }
 
+// fine x index (cell * SPH_NSUB + sub-bin along a row) beyond which ghosts lie, from the slab faces the host named
+// (sph_nnps_set_ghost_faces) and the grid of the current update
+static void nnps_face_planes(sph_ctx *c)
+{
+    c->gfx_lo = -0x7fffffff; c->gfx_hi = 0x7fffffff; // no faces named: no wavefront is a face wavefront
+    if (c->face_axis < 0) return;
+    if (c->face_axis != 0) { c->gfx_lo = 0x7fffffff; c->gfx_hi = -0x7fffffff; return; } // rows run along x: every wavefront may see ghosts
+    const double binw = c->cell_size / SPH_NSUB;
+    const double flo = floor((c->face_lo - c->xmin[0]) / binw), fhi = floor((c->face_hi - c->xmin[0]) / binw);
+    c->gfx_lo = !(flo > -1e9) ? -0x7fffffff : (flo > 1e9 ? 0x7fffffff : (int)flo); // ghosts: fx <= gfx_lo ...
+    c->gfx_hi = !(fhi < 1e9) ? 0x7fffffff : (fhi < -1e9 ? -0x7fffffff : (int)fhi);  // ... or fx >= gfx_hi
+}
+
 extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids, double radius_scale,
                                double cell_size_in, const double *bounds)
 {
@@ -790,6 +832,10 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
     // NNPS._compute_bounds (nnps_base.pyx:1520-1575)
     double xmax = fmax(mm[4], -1e100), ymax = fmax(mm[5], -1e100), zmax = fmax(mm[6], -1e100);
     double xmin = fmin(mm[0], 1e100), ymin = fmin(mm[1], 1e100), zmin = fmin(mm[2], 1e100);
+    // ghost split: room for the ghosts that arrive after this update (sph_nnps_set_extend)
+    xmin -= c->extend[0]; xmax += c->extend[0];
+    ymin -= c->extend[1]; ymax += c->extend[1];
+    zmin -= c->extend[2]; zmax += c->extend[2];
     double lx = xmax - xmin, ly = ymax - ymin, lz = zmax - zmin;
     xmin -= lx * 0.01; ymin -= ly * 0.01; zmin -= lz * 0.01;
     xmax += lx * 0.01; ymax += ly * 0.01; zmax += lz * 0.01;
@@ -891,10 +937,14 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
     }
     c->merged_valid = false;
     c->tables_valid = true;
+    c->ghosts_binned = false;
+    nnps_face_planes(c); // ghost split: where this step's ghosts will lie (known before they arrive)
     for (int a = 0; a < narrays; a++) {
         c->ids[a] = ids[a];
         c->arr[ids[a]].nnps_slot = a;
         c->arr[ids[a]].perm_n = c->arr[ids[a]].n;
+        c->arr[ids[a]].n_binned = c->arr[ids[a]].n;
+        c->arr[ids[a]].g_n = 0;
     }
     if (merged_first) {
         DevArray &M = c->merged;
@@ -959,6 +1009,86 @@ extern "C" int sph_nnps_set_h_range(sph_ctx *c, double hmin, double hmax)
 {
     if (!c || (hmax >= 0.0 && hmin > hmax)) { sph_set_error("sph_nnps_set_h_range: bad arguments"); return SPH_ERR_ARG; }
     c->h_known[0] = hmin; c->h_known[1] = hmax;
+    return SPH_OK;
+}
+
+extern "C" int sph_nnps_set_extend(sph_ctx *c, double ex, double ey, double ez)
+{
+    if (!c || ex < 0.0 || ey < 0.0 || ez < 0.0) { sph_set_error("sph_nnps_set_extend: bad arguments"); return SPH_ERR_ARG; }
+    c->extend[0] = ex; c->extend[1] = ey; c->extend[2] = ez;
+    return SPH_OK;
+}
+
+extern "C" int sph_nnps_set_ghost_faces(sph_ctx *c, int axis, double lo, double hi)
+{
+    if (!c || axis < -1 || axis > 2) { sph_set_error("sph_nnps_set_ghost_faces: bad arguments"); return SPH_ERR_ARG; }
+    c->face_axis = axis; c->face_lo = lo; c->face_hi = hi;
+    if (c->n_cells > 0) nnps_face_planes(c);
+    return SPH_OK;
+}
+
+// The particles that arrived behind the ones the last sph_nnps_update binned (the ghosts of this step), on the same
+// grid, into tables of their own: the hand-written counting sort (few keys; rocPRIM would take its ~25-launch merge sort).
+extern "C" int sph_nnps_update_ghosts(sph_ctx *c, int axis, double lo, double hi)
+{
+    if (!c || axis < 0 || axis > 2) { sph_set_error("sph_nnps_update_ghosts: bad arguments"); return SPH_ERR_ARG; }
+    if (c->n_cells <= 0 || c->narrays < 1) { sph_set_error("sph_nnps_update_ghosts: call sph_nnps_update first"); return SPH_ERR_STATE; }
+    HIP_TRY(hipSetDevice(c->device));
+    ScopedTimer tm(c, T_NNPS);
+    // the grid must still describe the real particles: nothing but appends since the update
+    for (int a = 0; a < c->narrays; a++) {
+        DevArray &A = c->arr[c->ids[a]];
+        if (A.nnps_slot != a || A.n < A.n_binned || A.n_real > A.n_binned) {
+            sph_set_error("sph_nnps_update_ghosts: array %d changed other than by appended ghosts since sph_nnps_update", c->ids[a]);
+            return SPH_ERR_STATE;
+        }
+    }
+    GridDesc g;
+    for (int k = 0; k < 3; k++) { g.xmin[k] = c->xmin[k]; g.nc[k] = c->nc[k]; }
+    g.cell_size = c->cell_size;
+    const size_t n_fine = (size_t)c->n_cells * SPH_NSUB;
+    for (int a = 0; a < c->narrays; a++) {
+        DevArray &A = c->arr[c->ids[a]];
+        const size_t ng = A.n - A.n_binned;
+        A.g_n = ng;
+        if (ng == 0) continue;
+        SPH_TRY(A.g_keys.reserve((ng + 1) * 4));
+        SPH_TRY(A.g_fkeys.reserve((ng + 1) * 4));
+        SPH_TRY(A.g_perm.reserve((ng + 1) * 4));
+        SPH_TRY(A.g_fine_start.reserve((n_fine + 2) * 4));
+        SPH_TRY(A.g_cell_start.reserve(((size_t)c->n_cells + 1) * 4));
+        uint32_t *T = A.g_fine_start.as<uint32_t>();
+        HIP_TRY(hipMemsetAsync(T, 0, (n_fine + 2) * 4, c->stream));
+        const size_t nb = A.n_binned;
+        hipLaunchKernelGGL(k_cell_keys_count, dim3(div_up(ng, 256)), dim3(256), 0, c->stream, A.prop[SPH_X] + nb, A.prop[SPH_Y] + nb,
+                           A.prop[SPH_Z] + nb, ng, g, A.g_keys.as<uint32_t>(), T);
+        BinFixArgs fa;
+        memset(&fa, 0, sizeof fa);
+        fa.nbins = (uint32_t)n_fine; fa.nsub = SPH_NSUB;
+        fa.perm = A.g_perm.as<uint32_t>(); fa.fkeys = A.g_fkeys.as<uint32_t>();
+        fa.cell_start = A.g_cell_start.as<uint32_t>();
+        fa.perm_base = (uint32_t)nb; // original index of ghost k is n_binned + k
+        SPH_TRY(nnps_bin_sort_finish(c, A.g_keys.as<uint32_t>(), ng, fa, T));
+        // The uniform-mass records rest on what the update saw of the REAL particles' masses; ghosts are other ranks'
+        // particles.  Look at theirs now and then (masses are constants of the motion): a ghost with another mass switches
+        // the array back to mass-carrying records for good (until its masses are pushed again).
+        if (A.m_known && A.prop[SPH_M] && --A.g_mcheck < 0) {
+            A.g_mcheck = 64;
+            SPH_TRY(c->bigq.reserve((1 + BIN_QUEUE) * 4));
+            uint32_t *flag = c->bigq.as<uint32_t>(); // (the queue counter: idle between the sorts)
+            hipLaunchKernelGGL(k_reset_u32, dim3(1), dim3(1), 0, c->stream, flag);
+            hipLaunchKernelGGL(k_mass_differs, dim3(div_up(ng, 256)), dim3(256), 0, c->stream, A.prop[SPH_M] + nb, ng, A.m_value, flag);
+            uint32_t *pin = (uint32_t *)c->pinned;
+            HIP_TRY(hipMemcpyAsync(pin, flag, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (pin[0]) { A.m_known = false; A.m_mixed_ghosts = true; }
+        }
+    }
+    c->face_axis = axis; c->face_lo = lo; c->face_hi = hi;
+    nnps_face_planes(c);
+    HIP_TRY(hipGetLastError());
+    c->ghosts_binned = true;
+    c->nnps_valid = true; // the appends invalidated it; reals and ghosts are both binned again
     return SPH_OK;
 }
 
@@ -1063,6 +1193,7 @@ extern "C" int sph_nnps_get_csr(sph_ctx *c, int src, int dst, uint32_t *start, s
     // variant 6 (default): the lists come from the wave-tile pair kernel itself (nnps_csr_pair_kernel);
     // variant 0 keeps the plain per-particle 27-cell walk as the independent cross-check
     const bool wave = c->pair_variant == 6;
+    if (!wave && c->ghosts_binned) { sph_set_error("sph_nnps_get_csr: the per-particle cell walk (pair_variant 0) does not read ghost segments"); return SPH_ERR_UNSUPPORTED; }
     if (!nbrs) {
         if (nd && wave) SPH_TRY(nnps_csr_pair_kernel(c, src, dst, d_start, nullptr, nullptr));
         else if (nd)
@@ -1117,6 +1248,7 @@ int nnps_build_csr_device(sph_ctx *c, int src, int dst, DevBuf &start, DevBuf &n
     uint32_t *cnt = c->tmp_u32a.as<uint32_t>();
     HIP_TRY(hipMemsetAsync(cnt + nd, 0, 4, c->stream));
     const bool wave = c->pair_variant == 6;
+    if (!wave && c->ghosts_binned) { sph_set_error("neighbour lists: the per-particle cell walk (pair_variant 0) does not read ghost segments"); return SPH_ERR_UNSUPPORTED; }
     if (wave) SPH_TRY(nnps_csr_pair_kernel(c, src, dst, cnt, nullptr, nullptr));
     else
     hipLaunchKernelGGL(k_csr<false>, dim3(div_up(nd, 256)), dim3(256), 0, c->stream, D.prop[SPH_X], D.prop[SPH_Y],

@@ -55,6 +55,7 @@ struct SrcDesc {
     uint32_t flags;  // equations acting for this (dest, source) pair
     const uint32_t *fine_start; // first sorted position per x sub-bin (SPH_NSUB per cell)
     double mu;       // the one mass of this source's particles (families with uniform-mass records)
+    uint32_t ghost;  // 1: the ghost segment of an array (sph_nnps_update_ghosts): read by face wavefronts only
 };
 
 template <class Fam> struct PairArgs {
@@ -71,6 +72,9 @@ template <class Fam> struct PairArgs {
     const uint32_t *d_keys, *d_fkeys, *d_perm; // cell ids / fine keys of the sorted destinations, sorted -> original index
     const uint8_t *d_slot; // merged order (families with MERGED): the array (nnps slot) of every sorted destination
     const uint32_t *d_tile_order; // traversal order of the destination tiles (null: memory order)
+    // ghost split: ghosts have a fine x index <= gfx_lo or >= gfx_hi; a wavefront whose candidate windows stay inside is
+    // an INTERIOR one (it skips ghost segments); face_mode 1 = interior wavefronts only, 2 = the others only, 0 = all
+    int face_mode, gfx_lo, gfx_hi;
     int row_mod3;      // order in which a wavefront visits its 3x3 rows of cells: bit 0 / bit 1 -- step (sy, sz) takes the
                        // row whose y / z is congruent to the step modulo 3, so that ALL wavefronts in flight walk rows of
                        // one residue class at a time (they share them in L2 / L1); 4 -- natural order rotated per wave tile
@@ -403,6 +407,22 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     } else {
         active = valid && o >= a.d_start && o < a.d_stop;
     }
+    const uint32_t fkey = a.d_fkeys[ic];
+    const uint32_t key = fkey / SPH_NSUB;
+    const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
+    const int row = key / ncx;
+    const int cx = (int)(key % ncx) * SPH_NSUB + (int)(fkey % SPH_NSUB); // x sub-bin along the row
+    bool facew = true; // may this wavefront's candidate windows hold ghosts?  (wave-uniform)
+    if (a.face_mode != 0 || a.gfx_lo > -0x7fffffff || a.gfx_hi < 0x7fffffff) {
+        int mn = active ? cx : 0x7fffffff, mx = active ? cx : -0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mn = min(mn, __shfl_xor(mn, o, 64)); mx = max(mx, __shfl_xor(mx, o, 64)); }
+        mn = __builtin_amdgcn_readfirstlane(mn); mx = __builtin_amdgcn_readfirstlane(mx);
+        facew = mn <= mx && (mn - XWIN <= a.gfx_lo || mx + XWIN >= a.gfx_hi);
+        if (mn > mx && !a.nl_mode) return;         // no active destination in this wavefront
+        if (a.face_mode == 1 && facew) return;     // the part that needs no ghosts
+        if (a.face_mode == 2 && !facew) return;    // the rest
+    }
     real4<T> pi;
     typename Fam::Dest D;
     uint32_t wtok = 0;
@@ -424,11 +444,6 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
         if constexpr (fam_merged<Fam>::value) Fam::load(D, sd_, a, o, slot);
         else Fam::load(D, sd_, a, o);
     }
-    const uint32_t fkey = a.d_fkeys[ic];
-    const uint32_t key = fkey / SPH_NSUB;
-    const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
-    const int row = key / ncx;
-    const int cx = (int)(key % ncx) * SPH_NSUB + (int)(fkey % SPH_NSUB); // x sub-bin along the row
     const int nfx = ncx * SPH_NSUB;
     const T hi_r = (T)a.radius_scale * pi.w;
     const T hi2 = UH ? (T)a.hr2u : hi_r * hi_r;
@@ -510,6 +525,7 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     // is what lets the register allocator give phase 2 the whole budget.
     for (int s = 0; s < a.nsrc; s++) {
     const SrcDesc sd = a.src[s];
+    if (sd.ghost && !facew) continue; // interior wavefront: none of its candidates can be a ghost
     const uint32_t fl = CF ? CF : sd.flags;
     cur_mu = (T)sd.mu;
     int R = row_first, st = 0, part_resume = 0; // position in phase 1 (wave-uniform)

@@ -40,7 +40,7 @@ class SphGroup(C.Structure):
                 # optional promises about this group inside one evaluation
                 # (include/sphhip.h; set by acceleration_eval.annotate_plan)
                 ('src_eos', C.c_int), ('eos_par', C.c_double * 4),
-                ('nl_mode', C.c_int)]
+                ('nl_mode', C.c_int), ('phase', C.c_int)]
 
 
 # every symbol include/sphhip.h declares, with its ctypes signature
@@ -96,6 +96,9 @@ SIGNATURES = {
                                        C.c_int, C.POINTER(C.c_int), _PD, C.POINTER(C.c_size_t),
                                        C.POINTER(_P)]),
     'sph_nnps_set_h_range': (C.c_int, [_P, C.c_double, C.c_double]),
+    'sph_nnps_set_extend': (C.c_int, [_P, C.c_double, C.c_double, C.c_double]),
+    'sph_nnps_update_ghosts': (C.c_int, [_P, C.c_int, C.c_double, C.c_double]),
+    'sph_nnps_set_ghost_faces': (C.c_int, [_P, C.c_int, C.c_double, C.c_double]),
     'sph_read_values': (C.c_int, [_P, C.c_int, C.POINTER(_P), _PD]),
     'sph_halo_remove_selected': (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
     'sph_prop_register': (C.c_int, [C.c_char_p]),

@@ -129,6 +129,26 @@ class HipNNPS(object):
         self.ncells_per_dim = np.array(i4[0:3], dtype=np.int32)
         self.n_cells = int(i4[3])
 
+    def set_extend(self, ex=0.0, ey=0.0, ez=0.0):
+        """widen the computed bounds on both sides of every axis (before the
+        reference's 1 % padding): the grid of an `update()` that runs while the
+        ghosts of a slab exchange are still in flight must hold them"""
+        dev._check(self.lib.sph_nnps_set_extend(self.ctx._h, float(ex), float(ey), float(ez)))
+
+    def set_ghost_faces(self, axis=-1, lo=-float('inf'), hi=float('inf')):
+        """name the slab faces outside which this rank's ghosts lie BEFORE `update()`:
+        the first half of a split evaluation then leaves the wavefronts that can
+        reach a ghost to the second half (axis -1: no faces)"""
+        dev._check(self.lib.sph_nnps_set_ghost_faces(self.ctx._h, int(axis), float(lo), float(hi)))
+
+    def update_ghosts(self, axis=0, lo=-float('inf'), hi=float('inf')):
+        """bin the particles that arrived behind the ones the last `update()` saw
+        (the ghosts of this step) on the same grid, into tables of their own: the
+        second half of a neighbour update that overlaps the ghost exchange.
+        `lo`, `hi`: the slab faces along `axis` (every ghost lies outside [lo, hi))."""
+        self._csr_key = None
+        dev._check(self.lib.sph_nnps_update_ghosts(self.ctx._h, int(axis), float(lo), float(hi)))
+
     def get_csr(self, src_index, dst_index):
         """(start[nd+1], nbrs) with each list sorted ascending.  nd is the
         DEVICE particle count of the destination (it holds the ghosts of a

@@ -155,6 +155,27 @@ class DeviceHaloOps(object):
         dev._check(self.lib.sph_read_values(self.ctx._h, n, ptrs, out))
         return [out[k] for k in range(n)]
 
+    def read_headers_overlapped(self, tensors, works):
+        """the same headers WITHOUT waiting for what the context's stream still has
+        queued (the part of the evaluation that runs while the ghosts are in
+        flight): a side stream waits for the transfers, gathers the headers and
+        copies them to pinned memory; the host waits for that copy only."""
+        torch = self.torch
+        side = self.__dict__.get('_side')
+        if side is None:
+            side = self._side = torch.cuda.Stream(self.device)
+            self._hdr_pin = torch.empty(64, dtype=torch.float64).pin_memory()
+        n = len(tensors)
+        with torch.cuda.stream(side):
+            for w in works:
+                w.wait()                     # stream-level: the side stream runs after the transfers
+            h = torch.stack([t[-1] for t in tensors])
+            self._hdr_pin[:n].copy_(h, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        ev.synchronize()
+        return self._hdr_pin[:n].tolist()
+
     def select_pack(self, lo_cut, hi_cut, shifts, caps, bufs):
         """Both faces selected AND packed on the device, no host round trip:
         bufs[side] (or None) is a message of caps[side] * nprops + 1 doubles,
@@ -336,7 +357,38 @@ def _next_capacity(cap, count):
 
 
 def exchange_halos(hs, drop=True):
-    """Ghost refresh of the arrays `hs` (SlabHalo objects of ONE rank, same slab).
+    """Ghost refresh of the arrays `hs`: see _exchange_steps (run to completion)."""
+    for _ in _exchange_steps(hs, drop, False):
+        pass
+
+
+def exchange_halos_begin(hs, drop=True):
+    """The first half of a ghost refresh: ghosts dropped, both faces selected and
+    packed, the point-to-point transfers POSTED -- and control back to the caller,
+    who can run whatever needs no ghosts (the neighbour update of the real
+    particles, the interior part of the evaluation) before
+    `exchange_halos_finish`.  Only the steady-state protocol splits (fixed-capacity
+    messages packed on the device); the first exchange and the handshake
+    protocol complete here.  Returns the state to hand to the second half."""
+    steps = _exchange_steps(hs, drop, True)
+    try:
+        next(steps)
+        return steps
+    except StopIteration:
+        return None
+
+
+def exchange_halos_finish(steps):
+    """The second half: wait for the transfers (the host only for the message
+    headers, read on a side stream), append the ghosts behind the real particles."""
+    if steps is not None:
+        for _ in steps:
+            pass
+
+
+def _exchange_steps(hs, drop, overlap):
+    """Ghost refresh of the arrays `hs` (SlabHalo objects of ONE rank, same slab),
+    as a generator: with `overlap` it yields once, after the transfers were posted.
 
     'capacity' protocol (default): every face carries ONE fixed-size message per
     array -- [nprops][count] rows packed at its start, the row count in its last
@@ -442,12 +494,24 @@ def exchange_halos(hs, drop=True):
         comm_sync('before_comm')
         reqs = [dist.P2POp(dist.isend, out[a][s], peer) for s, peer, _ in send_order for a in range(na)]
         reqs += [dist.P2POp(dist.irecv, inb[a][s], peer) for s, peer, _ in recv_order for a in range(na)]
-        run(reqs)
-        # the ONE readback of the exchange: the row counts this rank packed and
-        # the ones its peers packed (the host sizes the arrays with them)
+        split = overlap and device_pack and hasattr(ops0, 'read_headers_overlapped') and \
+            ops0._shares_torch_stream()
         keys = [(a, s) for a in range(na) for s in sides]
         msgs = [out[a][s] for a, s in keys] + [inb[a][s] for a, s in keys]
-        if hasattr(ops0, 'read_headers'):
+        if split:
+            works = list(dist.batch_isend_irecv(reqs)) if reqs else []
+            yield 'posted'              # the caller's ghost-free work goes here
+            hdr_early = ops0.read_headers_overlapped(msgs, works)
+            for w in works:
+                w.wait()                # stream-level: what follows on the context's stream runs after the transfers
+        else:
+            hdr_early = None
+            run(reqs)
+        # the ONE readback of the exchange: the row counts this rank packed and
+        # the ones its peers packed (the host sizes the arrays with them)
+        if hdr_early is not None:
+            hdr = hdr_early
+        elif hasattr(ops0, 'read_headers'):
             comm_sync('after_comm')     # (a context with a stream of its own: the receives are complete first)
             hdr = ops0.read_headers(msgs)
         else:
@@ -528,6 +592,21 @@ class SlabDecomposition(object):
         """Ghost refresh of ALL arrays with one batch of point-to-point transfers
         (a dam break has three arrays): see exchange_halos."""
         exchange_halos(self.halos, drop=drop)
+
+    def faces(self):
+        """(lo, hi) along the slab axis outside which every ghost of this rank
+        lies; -inf / +inf for a face without a neighbour"""
+        h = self.halos[0]
+        sides = [s for s, _, _ in h.neighbours()]
+        return (h.lo if 0 in sides else -float('inf'), h.hi if 1 in sides else float('inf'))
+
+    def exchange_begin(self, drop=True):
+        """post the ghost transfers and return (exchange_halos_begin); the ghosts
+        are there after `exchange_finish(state)`"""
+        return exchange_halos_begin(self.halos, drop=drop)
+
+    def exchange_finish(self, state):
+        exchange_halos_finish(state)
 
     def update(self):
         self.migrate()

@@ -65,7 +65,7 @@ def test_bench_dam_break_strong_scaling_path_two_ranks():
     assert abs(out['value'] * out['ms_per_step'] * 1e-3 - total) < 1e-6 * total
 
 
-def _run_two_ranks_collect(argv, fields, one_problem=False):
+def _run_two_ranks_collect(argv, fields, one_problem=False, nsteps=1, counters=None):
     """two thread-ranks run one step of the workload; returns {gid: row} of the
     requested fields over both ranks, and the same from ONE domain"""
     import numpy as np
@@ -85,7 +85,10 @@ def _run_two_ranks_collect(argv, fields, one_problem=False):
                 bench.apply_options(args, ctx)
                 w = bench.build_workload(args, rank, 2)
                 nnps, a_eval, halo, domain, step, _ = bench.setup(args, w, rank, 2, hub.view(rank), ctx)
-                step()
+                for _ in range(nsteps):
+                    step()
+                if counters is not None:
+                    counters[rank] = (bool(getattr(w, 'overlap_halo', False)), ctx.timer_get('n_phase2')[1])
                 pa = w.arrays[0]
                 pa.gpu.sync_host()
                 n = pa.get_number_of_particles(True)
@@ -162,6 +165,29 @@ def test_cube_two_slabs_matches_one_domain_by_gid():
     b = val1[np.argsort(gid1)]
     for k in range(len(fields)):
         assert np.max(np.abs(a[:, k] - b[:, k])) / np.max(np.abs(b[:, k])) < 1e-10, fields[k]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('extra,split', [(['--overlap-halo'], True), ([], False), (['--overlap-halo', '--vary-h', '0.1'], True),
+                                         (['--overlap-halo', '--dtype', 'f32'], True)],
+                         ids=['overlapped', 'plain', 'overlapped-variable-h', 'overlapped-fp32'])
+def test_cube_two_slabs_overlapped_exchange_matches_one_domain(extra, split):
+    """round 4: the ghost exchange overlapped with the evaluation -- transfers posted, neighbour update and interior
+    wave tiles of the real particles, THEN the ghosts appended, binned into tables of their own and read as a second
+    source segment by the face tiles (sph_group.phase 1 / 2) -- against one domain, gid by gid; the third step runs the
+    steady-state protocol (the first exchange is a counts handshake and completes in one piece)"""
+    import numpy as np
+    fields = ['arho', 'au', 'av', 'aw', 'ax', 'ay', 'az', 'dt_cfl']
+    cnt = {}
+    gid, val, gid1, val1 = _run_two_ranks_collect(['--n1', '24', '--steps', '1', '--warmup', '0'] + extra, fields,
+                                                  nsteps=3, counters=cnt)
+    for r in (0, 1):
+        assert cnt[r][0] == split and (cnt[r][1] >= 2) == split, cnt   # (the set-up exchanges already sized the messages)
+    a = val[np.argsort(gid)]
+    b = val1[np.argsort(gid1)]
+    tol = 5e-5 if '--dtype' in extra else 1e-10
+    for k in range(len(fields)):
+        assert np.max(np.abs(a[:, k] - b[:, k])) / np.max(np.abs(b[:, k])) < tol, fields[k]
 
 
 @pytest.mark.gpu
