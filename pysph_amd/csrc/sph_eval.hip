@@ -140,6 +140,18 @@ __global__ __launch_bounds__(256) void k_nosrc(EosArgs a)
         S[0][1] = S[1][0] = q[SPH_S01][i];
         S[0][2] = S[2][0] = q[SPH_S02][i];
         S[1][2] = S[2][1] = q[SPH_S12][i];
+        // Gershgorin: every eigenvalue <= max_i (S_ii + sum_{j != i} |S_ij|).  When that bound is not positive no principal
+        // stress is tensile, every rd below would be zero and R = 0: no eigen-decomposition (most particles of a body under
+        // compression; an eigenvalue the reference's solver would round to +1e-17 of the stress scale is all this can miss)
+        {
+            const double g0 = S[0][0] + fabs(S[0][1]) + fabs(S[0][2]), g1 = S[1][1] + fabs(S[0][1]) + fabs(S[1][2]),
+                         g2 = S[2][2] + fabs(S[0][2]) + fabs(S[1][2]);
+            if (fmax(g0, fmax(g1, g2)) <= 0.0) {
+                q[SPH_R00][i] = 0.0; q[SPH_R11][i] = 0.0; q[SPH_R22][i] = 0.0;
+                q[SPH_R12][i] = 0.0; q[SPH_R02][i] = 0.0; q[SPH_R01][i] = 0.0;
+                break;
+            }
+        }
         // same scaling as linalg3.eigen_decomposition (:520-536): tiny matrices stay accurate
         double sc = 0.0;
         for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) sc += fabs(S[r][cc]);

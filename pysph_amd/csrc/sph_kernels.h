@@ -14,6 +14,24 @@
 
 template <int KIND> struct SphKernel;
 
+// max / min as ONE instruction: fmax()/fmin() compile to a canonicalising v_max x, x in front of the v_max proper
+// (IEEE mode, signalling-NaN quieting); the operands here are results of arithmetic, canonical already
+__device__ __forceinline__ double raw_max(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double raw_min(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float raw_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ float raw_min(float a, float b) { return fminf(a, b); }
+
+
 // kernels.py:73-79: fac = self.fac*h1 | *h1*h1 | *h1*h1*h1
 template <class R> __device__ __forceinline__ R kernel_norm(R sigma, R h1, int dim)
 {
@@ -68,18 +86,20 @@ template <> struct SphKernel<3> { // QuinticSpline
     template <bool INSUP = false, class R> static __device__ __forceinline__ R dwq(R) { return R(0); }
     template <bool INSUP = false, class R> static __device__ __forceinline__ R w(R q)
     {
-        R t3 = R(3) - q, t2 = R(2) - q, t1 = R(1) - q;
+        // the branches q <= 2, q <= 1 of kernels.py:1120-1140 as max(., 0): a term beyond its knot is exactly zero,
+        // so the value is the reference's bit for bit, without two compare-and-select pairs
+        R t3 = R(3) - q, t2 = raw_max(R(2) - q, R(0)), t1 = raw_max(R(1) - q, R(0));
         R v = t3 * t3 * t3 * t3 * t3;
-        if (q <= R(2)) v -= R(6) * t2 * t2 * t2 * t2 * t2;
-        if (q <= R(1)) v += R(15) * t1 * t1 * t1 * t1 * t1;
+        v -= R(6) * t2 * t2 * t2 * t2 * t2;
+        v += R(15) * t1 * t1 * t1 * t1 * t1;
         return (!INSUP && q > R(3)) ? R(0) : v;
     }
     template <bool INSUP = false, class R> static __device__ __forceinline__ R dw(R q)
     {
-        R t3 = R(3) - q, t2 = R(2) - q, t1 = R(1) - q;
+        R t3 = R(3) - q, t2 = raw_max(R(2) - q, R(0)), t1 = raw_max(R(1) - q, R(0));
         R v = R(-5) * t3 * t3 * t3 * t3;
-        if (q <= R(2)) v += R(30) * t2 * t2 * t2 * t2;
-        if (q <= R(1)) v -= R(75) * t1 * t1 * t1 * t1;
+        v += R(30) * t2 * t2 * t2 * t2;
+        v -= R(75) * t1 * t1 * t1 * t1;
         return (!INSUP && q > R(3)) ? R(0) : v;
     }
 };

@@ -141,23 +141,6 @@ template <class F> struct fam_eosf<F, decltype((void)F::EOSF)> { static constexp
 #ifndef SPH_NEWTON_STEPS
 #define SPH_NEWTON_STEPS 1
 #endif
-// max / min as ONE instruction: fmax()/fmin() compile to a canonicalising v_max x, x in front of the v_max proper
-// (IEEE mode, signalling-NaN quieting); the operands here are results of arithmetic, canonical already
-__device__ __forceinline__ double raw_max(double a, double b)
-{
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ double raw_min(double a, double b)
-{
-    double r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float raw_max(float a, float b) { return fmaxf(a, b); }
-__device__ __forceinline__ float raw_min(float a, float b) { return fminf(a, b); }
-
 __device__ __forceinline__ double fast_rcp(double d)
 {
     double x = __builtin_amdgcn_rcp(d);
