@@ -144,9 +144,9 @@ typedef struct {
     int nl_mode;
     /* phase (ghost split, single-array groups): 0 = the whole group; 1 = the part that needs no ghosts, called
      * after sph_nnps_update and BEFORE the ghosts arrive (equations without sources over the particles present,
-     * records of the real particles packed, pair loops of the wavefronts whose candidates cannot include a ghost);
-     * 2 = the rest, after sph_nnps_update_ghosts (equations without sources over the new particles, ghost records,
-     * the remaining wavefronts).  1 and 2 of one group must follow each other with only phase calls in between.   */
+     * records of the real particles packed and -- option split_pair -- the pair loops of the wavefronts whose
+     * candidates cannot include a ghost); 2 = the rest, after sph_nnps_update_ghosts (equations without sources
+     * over the new particles, ghost records, the pair loops not run yet).  1 and 2 of one group must follow each other with only phase calls in between.   */
     int phase;
 } sph_group;
 
@@ -494,6 +494,9 @@ int sph_reduce_min(sph_ctx *ctx, int array_id, int prop, double *out);
  *                    of WCSPHScheme(fluids, solids), under the conditions of the uniform-mass EOS-fused records;
  *                    sph_nnps_update then sorts all arrays' keys once -- that sorted sequence is the merged order --
  *                    and derives per-array tables only on demand; "lazy_tables" 0 builds them at every update)
+ *   "split_pair"     split evaluations (sph_group.phase): 0 (default) = phase 1 prepares (equations without sources,
+ *                    records of the particles present), phase 2 launches every wave tile with the ghost segments
+ *                    guarded per wavefront; 1 = the interior wave tiles already in phase 1, the face tiles in phase 2
  *   "tension_flag"   0: the elastic rates always gather the artificial stress r_ij (default 1: only while the word the
  *                    MonaghanArtificialStress kernel sets says a particle of the source array is in tension)
  *   "nl_reuse"       1: honour sph_group.nl_mode (default 0: measured slower)

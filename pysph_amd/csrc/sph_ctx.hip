@@ -303,6 +303,7 @@ int sph_set_option(sph_ctx *c, const char *key, long value)
     if (strcmp(key, "nl_reuse") == 0) { c->nl_reuse = value; c->nl.valid = false; return SPH_OK; }
     if (strcmp(key, "norm_masks") == 0) { c->norm_masks = value; return SPH_OK; }
     if (strcmp(key, "merge_arrays") == 0) { c->merge_arrays = value ? 1 : 0; c->nnps_valid = false; return SPH_OK; }
+    if (strcmp(key, "split_pair") == 0) { c->split_pair = value ? 1 : 0; return SPH_OK; }
     if (strcmp(key, "tension_flag") == 0) { c->tension_flag = value ? 1 : 0; return SPH_OK; }
     if (strcmp(key, "lazy_tables") == 0) { c->lazy_tables = value ? 1 : 0; c->nnps_valid = false; return SPH_OK; }
     sph_set_error("sph_set_option: unknown key '%s'", key);

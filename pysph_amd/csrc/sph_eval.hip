@@ -2081,6 +2081,11 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             c->nl.valid = c->nl.valid && !(g->nl_mode == 1); // a keeping pass that could not keep: nothing to reuse
         }
 
+        // Split evaluations (sph_group.phase): by default the first half only prepares (equations without sources, records
+        // of the particles present) and the second half launches EVERY wave tile once the ghosts are in -- the ghost
+        // segments guarded per wavefront; option split_pair 1: the interior tiles in the first half, the face tiles in
+        // the second (hides a transfer longer than the neighbour update + packing; costs a second, sparse launch)
+        if (phase == 1 && !c->split_pair) continue;
         // 4. fused pair kernel, in the arithmetic type of the context (fp64, or fp32 with option arith_f32)
         ScopedTimer tm(c, T_PAIR);
         ScopedTimer tmf(c, T_PAIR_FAM + fam);
@@ -2108,7 +2113,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
                 a.src[a.nsrc++] = {S.g_cell_start.as<uint32_t>(), (uint32_t)(off_of[j] + S.n_binned), sflags[j],
                                    S.g_fine_start.as<uint32_t>(), S.m_value, 1u};
             }
-            a.face_mode = phase;
+            a.face_mode = c->split_pair ? phase : 0;
             a.d_off = (uint32_t)d_off; a.nd = (uint32_t)D.n_binned;
             a.d_mu = D.m_value;
             a.d_keys = D.keys_sorted.as<uint32_t>(); a.d_fkeys = D.fkeys_sorted.as<uint32_t>(); a.d_perm = D.perm.as<uint32_t>();

@@ -118,6 +118,7 @@ struct sph_ctx {
     DevArray merged;
     bool merged_valid = false;
     long merge_arrays = 1;
+    long split_pair = 0;    // split evaluations: 1 = interior wave tiles in phase 1, face tiles in phase 2 (default: all tiles in phase 2)
     long tension_flag = 1;  // elastic rates: r_ij gathered only when the source array's tension word says so
     // ... built FIRST by sph_nnps_update (one stable sort of all arrays' keys); the per-array orders and tables are a
     // stable compaction of it by slot, made when something first asks for them (nnps_need_tables)

@@ -169,13 +169,16 @@ def test_cube_two_slabs_matches_one_domain_by_gid():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('extra,split', [(['--overlap-halo'], True), ([], False), (['--overlap-halo', '--vary-h', '0.1'], True),
-                                         (['--overlap-halo', '--dtype', 'f32'], True)],
-                         ids=['overlapped', 'plain', 'overlapped-variable-h', 'overlapped-fp32'])
+                                         (['--overlap-halo', '--dtype', 'f32'], True),
+                                         (['--overlap-halo', '--opt', 'split_pair=1'], True),
+                                         (['--overlap-halo', '--opt', 'split_pair=1', '--vary-h', '0.1'], True)],
+                         ids=['overlapped', 'plain', 'overlapped-variable-h', 'overlapped-fp32',
+                              'overlapped-split-pair', 'overlapped-split-pair-variable-h'])
 def test_cube_two_slabs_overlapped_exchange_matches_one_domain(extra, split):
-    """round 4: the ghost exchange overlapped with the evaluation -- transfers posted, neighbour update and interior
-    wave tiles of the real particles, THEN the ghosts appended, binned into tables of their own and read as a second
-    source segment by the face tiles (sph_group.phase 1 / 2) -- against one domain, gid by gid; the third step runs the
-    steady-state protocol (the first exchange is a counts handshake and completes in one piece)"""
+    """round 4: the ghost exchange overlapped with the evaluation -- transfers posted; neighbour update, EOS and records
+    of the real particles (option split_pair: and their interior wave tiles); THEN the ghosts appended, binned into
+    tables of their own and read as a second source segment by the wave tiles that can reach them (sph_group.phase
+    1 / 2) -- against one domain, gid by gid"""
     import numpy as np
     fields = ['arho', 'au', 'av', 'aw', 'ax', 'ay', 'az', 'dt_cfl']
     cnt = {}
