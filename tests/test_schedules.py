@@ -361,3 +361,48 @@ def test_artificial_stress_is_gathered_only_under_tension(argv):
         assert not np.any(on['solid.r00']) and not np.any(on['solid.r12'])
     else:
         assert np.any(on['solid.r00'])
+
+
+def test_merged_arrays_with_an_empty_array():
+    """a dam break whose obstacle array holds no particle (the reference's with_obstacle=False keeps the
+    equations but an application may also drain an array): the merged order skips it, results as on the
+    per-destination path"""
+    import torch
+    import bench
+    from pysph_amd import device as dev
+
+    def run(opts):
+        args = bench.parse_args(['--workload', 'dam_break', '--dx', '0.03', '--no-cpu-baseline', '--no-extras'])
+        ctx = dev.HipContext(0, torch.cuda.current_stream().cuda_stream)
+        bench.apply_options(args, ctx)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        w = bench.build_workload(args, 0, 1)
+        k = [a.name for a in w.arrays].index('obstacle')
+        w.arrays[k] = w.arrays[k].extract_particles(np.arange(0), name='obstacle')   # the array stays, without particles
+        assert w.arrays[k].get_number_of_particles() == 0
+        nnps, a_eval, halo, domain, step, ordered = bench.setup(args, w, 0, 1, None, ctx)
+        for a in w.arrays:
+            a.gpu.pull()
+        host_in = bench.copy_arrays(w.arrays)
+        for _ in range(3):
+            step()
+        n_merged = ctx.timer_get('n_merged')[1]
+        out = {}
+        for pa in w.arrays:
+            n = pa.get_number_of_particles(True)
+            if n:
+                pa.gpu.pull('arho', 'au', 'av', 'aw', 'ax', 'ay', 'az')
+                for f in ('arho', 'au', 'ax'):
+                    out[pa.name + '.' + f] = np.array(pa.get(f)[:n])
+        res = bench.parity_check(w, host_in, nnps, domain)
+        del nnps, a_eval, step
+        ctx.close()
+        torch.cuda.empty_cache()
+        return n_merged, out, res
+
+    n_on, on, r_on = run({})
+    n_off, off, r_off = run({'merge_arrays': 0})
+    assert n_on == 2 and n_off == 0, (n_on, n_off)
+    assert r_on['parity_ok'] and r_off['parity_ok'], (r_on, r_off)
+    assert _max_rel(on, off) < 1e-13
