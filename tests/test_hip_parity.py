@@ -771,8 +771,9 @@ def test_randomised_configurations_vs_oracle(oracle, seed):
             assert e < TOL, (seed, dim, n, kname, varh, clustered, variant, pa.name, prop, e)
 
 
+@pytest.mark.parametrize('resident', [False, True], ids=['host-owned', 'device-resident-2nd-eval'])
 @pytest.mark.parametrize('seed', list(range(int(os.environ.get('SPH_FUZZ_SEEDS', '8')))))
-def test_randomised_tvf_and_elastic_vs_oracle(oracle, seed):
+def test_randomised_tvf_and_elastic_vs_oracle(oracle, seed, resident):
     """The same differential idea for the other two hand-written equation sets:
     TVF (QuinticSpline / Gaussian, optional artificial viscosity) and the
     elastic-solid set (CubicSpline / WendlandQuintic, 2-D or 3-D), random
@@ -833,12 +834,27 @@ def test_randomised_tvf_and_elastic_vs_oracle(oracle, seed):
     oev.set_nnps(onn)
     oev.compute(0.0, 1e-5)
     variant = int(rng.choice([0, 6, 6]))
-    a_eval, nnps, ctx = make_eval([pa], eqs, kernel, dim, variant)
-    a_eval.compute(0.0, 1e-5)
+    if resident:
+        # round 4: the SECOND evaluation on device-resident state -- TVF force records without p and V, elastic rate
+        # records without h and m, the tension word -- (both equation sets are idempotent on their inputs)
+        variant = 6
+        a_eval, nnps, ctx = make_eval([pa], eqs, kernel, dim, variant, sync='manual')
+        pa.gpu.push()
+        nnps.sync = False
+        nnps.update()
+        a_eval.compute(0.0, 1e-5)
+        nnps.update()
+        a_eval.compute(0.0, 1e-5)
+        if varh == 0.0:
+            assert ctx.timer_get('n_mass_fused')[1] > 0, 'the one-mass-per-array records did not engage'
+        a_eval.c_acceleration_eval.pull_outputs()
+    else:
+        a_eval, nnps, ctx = make_eval([pa], eqs, kernel, dim, variant)
+        a_eval.compute(0.0, 1e-5)
     for prop in outs:
         if prop in pa.properties:
             e = rel_err(pa.properties[prop], ref[0].properties[prop])
-            assert e < TOL, (seed, which, dim, n1, type(kernel).__name__, varh, variant, prop, e)
+            assert e < TOL, (seed, which, dim, n1, type(kernel).__name__, varh, variant, resident, prop, e)
 
 
 @pytest.mark.parametrize('case', ['wcsph_cube_varh', 'tvf_cube', 'wcsph_dam_dx0.1', 'elastic_3d',
