@@ -1913,3 +1913,66 @@ def test_randomised_device_resident_second_evaluation_vs_oracle(oracle, seed):
             upto = a.size if prop in ('p', 'cs', 'rho') else nreal
             e = rel_err(a[:upto], b[:upto])
             assert e < TOL, (seed, dim, sizes, kname, varh, mass_mode, took, pa.name, prop, e)
+
+
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('SPH_FUZZ_SEEDS', '12')))))
+def test_randomised_ghost_segments_vs_oracle(oracle, seed):
+    """Round 4, ghost split (sph_nnps_update_ghosts): the neighbour update bins the REAL particles, the ghosts
+    that "arrive" afterwards are binned on the same grid into tables of their own and read by the pair kernel
+    as a second source segment -- guarded per wavefront when they lie beyond slab faces along x, unguarded
+    along another axis, with the grid widened for them or not (ghosts outside it are clamped into its
+    outermost cells).  One evaluation and the neighbour counts against the oracle on reals + ghosts."""
+    from pysph_amd import device as dev
+    from pysph_amd import kernels as K
+    from pysph_amd.particle_array import get_particle_array_wcsph
+    rng = np.random.default_rng(7000 + seed)
+    nreal = int(rng.choice([300, 2500, 7000]))
+    ng = int(rng.choice([1, nreal // 10, nreal // 3]))
+    axis = int(rng.choice([0, 0, 1, 2]))
+    varh = float(rng.choice([0.0, 0.0, 0.2]))
+    extend = bool(rng.integers(0, 2))
+    spacing = (1.0 / nreal) ** (1.0 / 3.0)
+    width = 2.6 * spacing * (1 + varh)
+    c = rng.uniform(0, 1, (nreal + ng, 3))
+    # ghosts: beyond the faces [0, 1) of `axis`, within the halo width (both sides)
+    side = rng.integers(0, 2, ng)
+    c[nreal:, axis] = np.where(side == 0, -width * rng.uniform(0, 1, ng), 1.0 + width * rng.uniform(0, 1, ng))
+    n = nreal + ng
+    pa = get_particle_array_wcsph(
+        name='fluid', x=c[:, 0], y=c[:, 1], z=c[:, 2], h=1.3 * spacing * (1 + varh * rng.uniform(-1, 1, n)),
+        m=spacing ** 3 * np.ones(n), rho=1000.0 * (1 + 0.02 * rng.uniform(-1, 1, n)), u=rng.uniform(-1, 1, n),
+        v=rng.uniform(-1, 1, n), w=rng.uniform(-1, 1, n))
+    pa.set_num_real_particles(nreal)
+    eqs = cube_equations(spacing)
+    kernel = K.WendlandQuintic(dim=3)
+    ref = _copy_arrays([pa])
+    onn = oracle.OracleNNPS(3, ref, radius_scale=2.0)
+    onn.update()
+    oev = oracle.OracleEval(ref, eqs, kernel, nthreads=4)
+    oev.set_nnps(onn)
+    oev.compute(0.0, 1e-5)
+    a_eval, nnps, ctx = make_eval([pa], eqs, kernel, 3, 6, sync='manual')
+    lib, h = ctx.lib, pa.gpu
+    pa.gpu.push()
+    nnps.sync = False
+    for rep in range(2):               # the second round runs on the records that need a look at the masses
+        # the step as a slab rank sees it: only the real particles are there when the neighbour update runs ...
+        dev._check(lib.sph_array_resize(ctx._h, h.array_id, nreal, nreal))
+        nnps.set_extend(*([width if extend and k == axis else 0.0 for k in range(3)]))
+        nnps.set_ghost_faces(axis, 0.0, 1.0)
+        nnps.update()
+        # ... then the ghosts arrive behind them (their rows are still in the buffers: same capacity)
+        dev._check(lib.sph_array_resize(ctx._h, h.array_id, n, nreal))
+        nnps.update_ghosts(axis, 0.0, 1.0)
+        a_eval.compute(0.0, 1e-5)
+    a_eval.c_acceleration_eval.pull_outputs()
+    pa.gpu.pull('p', 'cs')
+    s1 = nnps.get_csr_start(0, 0)
+    s2, _ = onn.get_csr(0, 0)
+    assert np.array_equal(np.diff(s1.astype(np.int64))[:nreal], np.diff(s2.astype(np.int64))[:nreal]), seed
+    assert not np.any(np.diff(s1.astype(np.int64))[nreal:])      # ghosts have no lists
+    for prop in WC_OUT:
+        a, b = np.asarray(pa.properties[prop]), np.asarray(ref[0].properties[prop])
+        upto = n if prop in ('p', 'cs', 'rho') else nreal
+        e = rel_err(a[:upto], b[:upto])
+        assert e < TOL, (seed, nreal, ng, axis, varh, extend, prop, e)
