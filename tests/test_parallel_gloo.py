@@ -371,6 +371,16 @@ def _worker_fused(rank, world, port, periodic, out):
                                 ops_factory=lambda pa, ax, p: NumpyHaloOps(pa, ax), dist=dist)
         dec.exchange()
         dec.exchange()           # idempotent
+        # the two-phase form (round 4): transports whose device primitives cannot overlap (this numpy stand-in has no
+        # streams) complete in the first half; same ghosts either way
+        st = dec.exchange_begin()
+        assert st is None
+        dec.exchange_finish(st)
+        flo, fhi = dec.faces()
+        if not periodic:
+            assert (flo, fhi) == ((-float('inf'), 0.5) if rank == 0 else (0.5, float('inf')))
+        else:
+            assert (flo, fhi) == (lo, hi)
         for pa, ref in ((a, a2), (b, b2)):
             h = SlabHalo(ref, None, rank, world, axis=0, width=width, lo=lo, hi=hi,
                          periodic=periodic, period=1.0, ops=NumpyHaloOps(ref, 0), dist=dist)
