@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256) void k_mass_differs(const double *__restrict__
     if (i < n && m[i] != mu) *flag = 1u;
 }
 
-// Sort n keys < nbins through `table` (nbins + 2 entries; the count pass -- k_tile_keys or k_bin_count -- has run on the
+// Sort n keys < nbins through `table` (nbins + 2 entries; the count pass -- k_tile_keys, k_cell_keys_count -- has run on the
 // zeroed table): leaves table[k] = first sorted position of bin k (k <= nbins) and fills the BinFixArgs outputs.
 static int nnps_bin_sort_finish(sph_ctx *c, const uint32_t *keys, size_t n, BinFixArgs fa, uint32_t *table)
 {
@@ -552,11 +552,6 @@ __global__ __launch_bounds__(256) void k_cell_keys_count(const double *__restric
     atomicAdd(&count[key + 2], 1u);
 }
 
-__global__ __launch_bounds__(256) void k_bin_count(const uint32_t *__restrict__ keys, size_t n, uint32_t *__restrict__ count)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(&count[keys[i] + 2], 1u);
-}
 
 // ---------------------------------------------------------------------------
 // merged-first build (sph_nnps_update) and the per-array tables derived from it on demand
