@@ -34,16 +34,29 @@ __device__ inline double wave_max(double v)
     return v;
 }
 
+struct BlockRanges { int first[SPH_MAX_ARRAYS + 1]; int narrays; }; // blocks [first[a], first[a+1]) belong to array a
+
+// several arrays in ONE launch (a dam break has three: three short launches and their gaps cost more than the passes)
+struct MinMaxMulti {
+    const double *x[SPH_MAX_ARRAYS], *y[SPH_MAX_ARRAYS], *z[SPH_MAX_ARRAYS], *h[SPH_MAX_ARRAYS], *m[SPH_MAX_ARRAYS];
+    size_t n[SPH_MAX_ARRAYS];
+    BlockRanges br;
+};
+
 // part[block][8] = {xmin ymin zmin hmin xmax ymax zmax hmax}; partm[block][2] = {mmin mmax} of this array (m may be null)
-__global__ __launch_bounds__(256) void k_minmax(const double *__restrict__ x, const double *__restrict__ y,
-                                                const double *__restrict__ z, const double *__restrict__ h,
-                                                const double *__restrict__ m, size_t n, double *__restrict__ part,
-                                                double *__restrict__ partm)
+__global__ __launch_bounds__(256) void k_minmax(MinMaxMulti t, double *__restrict__ part, double *__restrict__ partm)
 {
+    // this block's array (wave-uniform) and its share of it
+    int a = 0;
+    for (int k = 1; k < SPH_MAX_ARRAYS; k++) if (k < t.br.narrays && (int)blockIdx.x >= t.br.first[k]) a = k;
+    const double *__restrict__ x = t.x[a], *__restrict__ y = t.y[a], *__restrict__ z = t.z[a], *__restrict__ h = t.h[a];
+    const double *__restrict__ m = t.m[a];
+    const size_t n = t.n[a];
+    const size_t lb = blockIdx.x - t.br.first[a], nba = t.br.first[a + 1] - t.br.first[a];
     double mn[5] = {DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX};
     double mx[5] = {-DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX};
     const double *p[4] = {x, y, z, h};
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = lb * blockDim.x + threadIdx.x; i < n; i += nba * blockDim.x) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             double v = p[k][i];
@@ -73,7 +86,6 @@ __global__ __launch_bounds__(256) void k_minmax(const double *__restrict__ x, co
     }
 }
 
-struct BlockRanges { int first[SPH_MAX_ARRAYS + 1]; int narrays; }; // blocks [first[a], first[a+1]) belong to array a
 
 __global__ __launch_bounds__(512) void k_minmax_final(const double *__restrict__ part, int nblocks, double *__restrict__ out,
                                                       const double *__restrict__ partm, BlockRanges br)
@@ -117,6 +129,8 @@ int nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *out8)
     int *const first = br.first;
     br.narrays = narrays;
     int nb_total = 0;
+    MinMaxMulti mt;
+    memset(&mt, 0, sizeof mt);
     for (int a = 0; a < narrays; a++) {
         DevArray &A = c->arr[ids[a]];
         first[a] = nb_total;
@@ -128,12 +142,15 @@ int nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *out8)
                 return SPH_ERR_MISSING_PROP;
             }
         int nb = (int)std::min<size_t>(BLOCKS, (A.n + 255) / 256);
-        hipLaunchKernelGGL(k_minmax, dim3(nb), dim3(256), 0, c->stream, A.prop[SPH_X], A.prop[SPH_Y],
-                           A.prop[SPH_Z], A.prop[SPH_H], c->want_mrange ? (const double *)A.prop[SPH_M] : (const double *)nullptr, A.n,
-                           c->red_part.as<double>() + (size_t)nb_total * 8, partm + (size_t)nb_total * 2);
+        mt.x[a] = A.prop[SPH_X]; mt.y[a] = A.prop[SPH_Y]; mt.z[a] = A.prop[SPH_Z]; mt.h[a] = A.prop[SPH_H];
+        mt.m[a] = c->want_mrange ? A.prop[SPH_M] : nullptr;
+        mt.n[a] = A.n;
         nb_total += nb;
     }
     first[narrays] = nb_total;
+    for (int a = narrays + 1; a <= SPH_MAX_ARRAYS; a++) first[a] = nb_total;
+    mt.br = br;
+    if (nb_total) hipLaunchKernelGGL(k_minmax, dim3(nb_total), dim3(256), 0, c->stream, mt, c->red_part.as<double>(), partm);
     if (nb_total == 0) {
         for (int k = 0; k < 4; k++) { out8[k] = DBL_MAX; out8[4 + k] = -DBL_MAX; }
         return SPH_OK;
@@ -189,6 +206,36 @@ __global__ __launch_bounds__(256) void k_cell_keys(const double *__restrict__ x,
     cz = min(max(cz, 0), g.nc[2] - 1);
     keys[i] = ((uint32_t)(cx + g.nc[0] * (cy + g.nc[1] * cz)) * SPH_NSUB + (uint32_t)sub) | tag;
     idx[i] = (uint32_t)i + idx_base; // position in the concatenation of all arrays (merged-first build), else the local index
+}
+
+// the same for the concatenation of several arrays in ONE launch (merged-first build): block b belongs to array a with
+// first[a] <= b < first[a + 1]; keys and values land at the array's offset in the concatenation, the value is the
+// particle's position there
+struct KeysMulti {
+    const double *x[SPH_MAX_ARRAYS], *y[SPH_MAX_ARRAYS], *z[SPH_MAX_ARRAYS];
+    uint32_t n[SPH_MAX_ARRAYS], off[SPH_MAX_ARRAYS], first[SPH_MAX_ARRAYS + 1];
+    int narrays;
+};
+__global__ __launch_bounds__(256) void k_cell_keys_multi(KeysMulti t, GridDesc g, uint32_t *__restrict__ keys, uint32_t *__restrict__ idx)
+{
+    int a = 0;
+    for (int k = 1; k < SPH_MAX_ARRAYS; k++) if (k < t.narrays && blockIdx.x >= t.first[k]) a = k;
+    const size_t i = (size_t)(blockIdx.x - t.first[a]) * blockDim.x + threadIdx.x;
+    if (i >= t.n[a]) return;
+    const double *__restrict__ x = t.x[a], *__restrict__ y = t.y[a], *__restrict__ z = t.z[a];
+    const double ux = (x[i] - g.xmin[0]) / g.cell_size;
+    int cx = (int)floor(ux);
+    int cy = (int)floor((y[i] - g.xmin[1]) / g.cell_size);
+    int cz = (int)floor((z[i] - g.xmin[2]) / g.cell_size);
+    int sub = (int)floor((ux - (double)cx) * SPH_NSUB);
+    if (cx < 0) { cx = 0; sub = 0; }
+    if (cx > g.nc[0] - 1) { cx = g.nc[0] - 1; sub = SPH_NSUB - 1; }
+    sub = min(max(sub, 0), SPH_NSUB - 1);
+    cy = min(max(cy, 0), g.nc[1] - 1);
+    cz = min(max(cz, 0), g.nc[2] - 1);
+    const size_t o = (size_t)t.off[a] + i;
+    keys[o] = (uint32_t)(cx + g.nc[0] * (cy + g.nc[1] * cz)) * SPH_NSUB + (uint32_t)sub;
+    idx[o] = (uint32_t)o;
 }
 
 // one array's segment of the concatenated sort: strip the array tag, split into the array's own tables
@@ -916,13 +963,26 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
         SPH_TRY(c->tmp_u32a.reserve((n_half + 64) * 4 * 2));
         SPH_TRY(c->tmp_u32b.reserve((n_half + 64) * 4 * 2));
         uint32_t *ck = c->tmp_u32a.as<uint32_t>(), *ci = ck + n_half, *cks = c->tmp_u32b.as<uint32_t>(), *cp = cks + n_half;
+        if (merged_first) { // one launch for all arrays
+            KeysMulti km;
+            memset(&km, 0, sizeof km);
+            km.narrays = narrays;
+            uint32_t nbk = 0;
+            for (int a = 0; a < narrays; a++) {
+                DevArray &A = c->arr[ids[a]];
+                km.x[a] = A.prop[SPH_X]; km.y[a] = A.prop[SPH_Y]; km.z[a] = A.prop[SPH_Z];
+                km.n[a] = (uint32_t)A.n; km.off[a] = (uint32_t)cat_off[a]; km.first[a] = nbk;
+                nbk += div_up(A.n, 256);
+            }
+            for (int a = narrays; a <= SPH_MAX_ARRAYS; a++) km.first[a] = nbk;
+            hipLaunchKernelGGL(k_cell_keys_multi, dim3(nbk), dim3(256), 0, c->stream, km, g, ck, ci);
+        } else
         for (int a = 0; a < narrays; a++) {
             DevArray &A = c->arr[ids[a]];
             if (A.n == 0) continue;
             hipLaunchKernelGGL(k_cell_keys, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, A.prop[SPH_X], A.prop[SPH_Y],
                                A.prop[SPH_Z], A.n, g, ck + cat_off[a], ci + cat_off[a],
-                               merged_first ? 0u : (end_bit < 32 ? (uint32_t)a << end_bit : 0u),
-                               merged_first ? (uint32_t)cat_off[a] : 0u);
+                               end_bit < 32 ? (uint32_t)a << end_bit : 0u, 0u);
         }
         const int sort_bits = merged_first ? end_bit : end_bit + tag_bits;
         size_t tmp_bytes = 0;
