@@ -140,13 +140,15 @@ int sph_ctx_destroy(sph_ctx *c)
     for (auto &H : c->halo)
         for (int s = 0; s < 2; s++) { H.flag[s].release(); H.pos[s].release(); H.list[s].release(); }
     for (DevBuf *b : {&c->dbgc, &c->gapq, &c->cub_tmp, &c->red_part, &c->red_out, &c->posh, &c->aux, &c->fposb, &c->dkeys, &c->dperm,
-                      &c->tmp_u32a, &c->tmp_u32b, &c->gen_state, &c->nlbuf, &c->splitcnt, &c->scan_part, &c->bigq})
+                      &c->tmp_u32a, &c->tmp_u32b, &c->gen_state, &c->nlbuf, &c->splitcnt, &c->scan_part, &c->bigq, &c->sort_tab})
         b->release();
     for (auto &b : c->csr_start) b.release();
     for (auto &b : c->csr_nbrs) b.release();
     for (auto &t : c->timers)
         for (auto &pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->pin_async) (void)hipHostFree(c->pin_async);
+    if (c->lag_ev) (void)hipEventDestroy(c->lag_ev);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SPH_OK;
@@ -188,6 +190,8 @@ int sph_array_resize(sph_ctx *c, int id, size_t n, size_t n_real)
     }
     if (n != A.n) c->nnps_valid = false;
     if (n > A.n) A.tflag_valid = false; // new particles (ghosts, migrants): their r_ij were not looked at
+    if (n > A.n) sph_mark_grown(A);     // ... nor their h and m
+    if (n < A.n) sph_mark_removed(A, n);
     A.n = n;
     A.n_real = n_real;
     return SPH_OK;
@@ -213,6 +217,7 @@ int sph_array_ensure_prop(sph_ctx *c, int id, int prop)
     A.cap = cap;
     HIP_TRY(hipMalloc((void **)&A.prop[prop], cap * sizeof(double)));
     HIP_TRY(hipMemsetAsync(A.prop[prop], 0, cap * sizeof(double), c->stream));
+    sph_mark_written(A, prop);
     return SPH_OK;
 }
 
@@ -227,7 +232,8 @@ int sph_array_push(sph_ctx *c, int id, int prop, const double *host, size_t offs
     // only after a sync; keep the call synchronous so Python may reuse `host`.
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (prop == SPH_X || prop == SPH_Y || prop == SPH_Z || prop == SPH_H) c->nnps_valid = false;
-    if (prop == SPH_M) { A.m_known = false; A.m_mixed_ghosts = false; } // until the next sph_nnps_update has looked at the masses
+    if (prop == SPH_M) A.m_mixed_ghosts = false;
+    sph_mark_written(A, prop); // h / m: until the next sph_nnps_update has looked at them
     if (prop >= SPH_R00 && prop <= SPH_R22) A.tflag_valid = false;
     return SPH_OK;
 }
@@ -251,8 +257,8 @@ int sph_array_device_ptr(sph_ctx *c, int id, int prop, void **dptr)
 {
     SPH_TRY(sph_array_ensure_prop(c, id, prop));
     *dptr = c->arr[id].prop[prop];
-    // whoever holds the raw pointer may write masses: the uniform-mass records wait for the next sph_nnps_update's look
-    if (prop == SPH_M) c->arr[id].m_known = false;
+    // whoever holds the raw pointer may write h or m at any time: every neighbour update looks at them from now on
+    if (prop == SPH_M || prop == SPH_H) { c->arr[id].raw_hm = true; sph_mark_written(c->arr[id], prop); }
     if (prop >= SPH_R00 && prop <= SPH_R22) c->arr[id].tflag_valid = false;
     return SPH_OK;
 }
@@ -306,6 +312,11 @@ int sph_set_option(sph_ctx *c, const char *key, long value)
     if (strcmp(key, "split_pair") == 0) { c->split_pair = value ? 1 : 0; return SPH_OK; }
     if (strcmp(key, "tension_flag") == 0) { c->tension_flag = value ? 1 : 0; return SPH_OK; }
     if (strcmp(key, "lazy_tables") == 0) { c->lazy_tables = value ? 1 : 0; c->nnps_valid = false; return SPH_OK; }
+    if (strcmp(key, "async_update") == 0) { c->async_update = value ? 1 : 0; return SPH_OK; }
+    if (strcmp(key, "sort_lbits") == 0) { // 0: adaptive; 9..11: fixed low key bits of the particle sort (profiling)
+        if (value != 0 && (value < 9 || value > 11)) { sph_set_error("sort_lbits must be 0 or 9..11"); return SPH_ERR_ARG; }
+        c->sort_lbits = (int)value; c->hand_sort = value == 0; return SPH_OK;
+    }
     sph_set_error("sph_set_option: unknown key '%s'", key);
     return SPH_ERR_ARG;
 }
@@ -338,7 +349,7 @@ int sph_timer_get(sph_ctx *c, const char *key, double *ms, long *count)
 {
     static const char *names[T_COUNT] = {"nnps", "pack", "eos", "pair", "stage",
                                          "pair_none", "pair_wcsph", "pair_density", "pair_tvf", "pair_vgrad", "pair_elastic",
-                                         "n_eos_fused", "n_nl_keep", "n_nl_reuse", "n_mass_fused", "n_merged", "n_tension_flag", "n_phase2"};
+                                         "n_eos_fused", "n_nl_keep", "n_nl_reuse", "n_mass_fused", "n_merged", "n_tension_flag", "n_phase2", "n_async"};
     SPH_TRY(timer_drain(c));
     for (int i = 0; i < T_COUNT; i++)
         if (strcmp(key, names[i]) == 0) {

@@ -2043,6 +2043,10 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             // The shared slots live in the same buffers every other unit packs into from offset 0:
             // a unit that does not share (another family, a single-destination call), or one whose
             // record layout differs from what the cache holds, overwrites them -- nothing cached survives.
+            // a split evaluation: the second half must read the layout the first half packed -- when what is known of the
+            // masses changed in between (a ghost with another mass: sph_nnps_update_ghosts), it packs both segments again
+            if (phase == 1) c->phase_sig = sig;
+            const bool repack = phase == 2 && c->phase_sig != sig;
             bool keep = share;
             if (share)
                 for (auto &pc : c->pack_cache)
@@ -2053,7 +2057,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
                 PackCache &pc = c->pack_cache[id];
                 const bool hit = share && pc.epoch == c->pack_epoch && pc.fam == fam && pc.sig == sig;
                 // phase 1: the particles present (the real ones); phase 2: the ghosts that arrived since; else both segments
-                if (phase != 2) SPH_TRY(pack_array(c, id, off, pl, fam, fl, dest_only, !hit, 0)); // a hit still validates
+                if (phase != 2 || repack) SPH_TRY(pack_array(c, id, off, pl, fam, fl, dest_only, !hit, 0)); // a hit still validates
                 if (phase != 1 && c->arr[id].g_n > 0) SPH_TRY(pack_array(c, id, off, pl, fam, fl, dest_only, !hit, 1));
                 pc.epoch = share ? c->pack_epoch : 0; pc.fam = fam; pc.sig = sig;
                 return SPH_OK;
@@ -2329,7 +2333,7 @@ static int eval_generated_launches(sph_ctx *c, const sph_kernel *K, const sph_ge
         if (p < 0 || p >= SPH_PROP_COUNT) { sph_set_error("sph_eval_generated: bad output property %d", p); return SPH_ERR_ARG; }
         SPH_TRY(sph_array_ensure_prop(c, dst, p));
         g.dout[k] = D.prop[p];
-        if (p == SPH_M) D.m_known = false; // a generated body writes masses: uniform-mass records wait for the next look
+        sph_mark_written(D, p); // a generated body writes h or m: the next neighbour update looks at them again
         if (p >= SPH_R00 && p <= SPH_R22) D.tflag_valid = false;
     }
     for (int k = 0; k < f->n_din; k++) {

@@ -402,8 +402,14 @@ extern "C" int sph_halo_image(sph_ctx *c, int id, int side, int nprops, const in
         }
     }
     const size_t n0 = c->arr[id].n;
+    // images are copies of the array's own particles: a property among `props` keeps its range (and its cleanliness)
+    bool has_h = false, has_m = false;
+    for (int k = 0; k < nprops; k++) { has_h |= props[k] == SPH_H; has_m |= props[k] == SPH_M; }
+    const bool hd = c->arr[id].h_dirty, md = c->arr[id].m_dirty, mk = c->arr[id].m_known;
     SPH_TRY(sph_array_resize(c, id, n0 + cnt, c->arr[id].n_real)); // may move the property buffers
     DevArray &A = c->arr[id];
+    if (has_h && n0 > 0) A.h_dirty = hd;
+    if (has_m && n0 > 0) { A.m_dirty = md; A.m_known = mk; }
     PropList L;
     for (int k = 0; k < nprops; k++) {
         const int p = props[k];
@@ -472,6 +478,7 @@ extern "C" int sph_halo_remove_selected(sph_ctx *c, int id, size_t *n_left)
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipFree(tmp));
     keep.release(); pos.release(); list.release();
+    sph_mark_removed(A, keepn);
     A.n = A.n_real = keepn;
     H.count[0] = H.count[1] = 0;
     c->nnps_valid = false;

@@ -52,8 +52,20 @@ struct DevArray {
     size_t n_tiles = 0;
     int tile_grid[4] = {0, 0, 0, 0};     // grid (ncx, ncy, ncz, block rows) the tile order was built for
     int tile_age = 0;                    // updates since the tile order was built
-    bool m_known = false;                // every particle had the same mass at the last sph_nnps_update that looked
-    double m_value = 0.0;                // ... this one (a push of m, or an update that skips the reduction, forgets it)
+    bool m_known = false;                // every particle has the same mass: the last look found one value and nothing wrote m since
+    double m_value = 0.0;                // ... this one
+    // What the neighbour update knows about h and m WITHOUT looking: the range its last reduction found (`*_seen`), valid
+    // while nothing that can write the property ran since (`*_dirty`: every entry point that writes h / m, appends
+    // particles from outside, or hands out the raw pointer sets it -- sph_mark_written / _grown / _removed below).
+    // Clean ranges let sph_nnps_update skip the reduction of h and m and, with them, the device->host round trip.
+    bool h_dirty = true, m_dirty = true, h_seen = false, m_seen = false;
+    bool raw_hm = false;                 // a raw device pointer to h or m was handed out: writes through it cannot be tracked
+    unsigned hm_writes = 0;              // writes of h / m (sph_mark_written) so far
+    // ghost split: what sph_nnps_update knew when it binned the real particles (sph_nnps_update_ghosts verifies the ghosts
+    // that arrived since against it, every time)
+    bool m_known_binned = false, h_clean_binned = false, m_clean_binned = false;
+    unsigned hm_writes_binned = 0;
+    double h_lo = 0.0, h_hi = 0.0, m_lo = 0.0, m_hi = 0.0;
     int nnps_slot = -1;                  // position in the last sph_nnps_update list
     size_t perm_n = 0;                   // particles `perm` was built for (0: none / already applied)
     // Ghost split (sph_nnps_update_ghosts): the tables above cover the first n_binned particles (the real ones: the
@@ -61,7 +73,6 @@ struct DevArray {
     // into tables of their own and read by the pair kernels as a second source segment of the array.
     size_t n_binned = 0, g_n = 0;
     bool m_mixed_ghosts = false;         // ghosts with another mass than the real particles' one were seen: no uniform-mass records
-    int g_mcheck = 0;                    // ghost binnings until the next look at the ghosts' masses
     DevBuf g_keys, g_fkeys, g_perm, g_fine_start, g_cell_start;
     // "no particle of this array is in tension": a device word the artificial-stress kernel (k_nosrc) sets to 1 when
     // any r_ij is non-zero; valid while that kernel covered every particle and nothing wrote r_ij since
@@ -79,7 +90,7 @@ struct HaloState {
 
 // T_PAIR: every pair launch; T_PAIR_FAM + family (sph_eval.hip enum Family): the same launches per equation family
 // T_N_*: launch counters only (no time): pair launches on EOS-fused records, launches that kept / reused neighbour lists
-enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_STAGE, T_PAIR_FAM, T_N_EOSF = T_PAIR_FAM + 6, T_N_NLKEEP, T_N_NLREUSE, T_N_UMASS, T_N_MERGED, T_N_TFLAG, T_N_PHASE2, T_COUNT };
+enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_STAGE, T_PAIR_FAM, T_N_EOSF = T_PAIR_FAM + 6, T_N_NLKEEP, T_N_NLREUSE, T_N_UMASS, T_N_MERGED, T_N_TFLAG, T_N_PHASE2, T_N_ASYNC, T_COUNT };
 
 struct Timer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -91,6 +102,31 @@ struct Timer {
 struct PackCache {
     unsigned long long epoch = 0;
     int fam = -1, sig = 0;
+};
+
+// property `prop` of the array is (or may be) written
+static inline void sph_mark_written(DevArray &A, int prop)
+{
+    if (prop == SPH_H) { A.h_dirty = true; A.hm_writes++; }
+    if (prop == SPH_M) { A.m_dirty = true; A.m_known = false; A.hm_writes++; }
+}
+// particles with values from outside (other ranks' ghosts, host appends) arrive
+static inline void sph_mark_grown(DevArray &A) { A.h_dirty = A.m_dirty = true; A.m_known = false; }
+// particles leave: a range of ONE value stays what it is while a particle is left, any other range may shrink
+static inline void sph_mark_removed(DevArray &A, size_t n_left)
+{
+    if (!(A.h_seen && A.h_lo == A.h_hi && n_left > 0)) A.h_dirty = true;
+    if (!(A.m_seen && A.m_lo == A.m_hi && n_left > 0)) { A.m_dirty = true; A.m_known = false; }
+}
+
+// a cell grid in the reference's arithmetic (nnps_base.pyx:942-978,1520-1575, linked_list_nnps.pyx:293-343)
+struct GridHost {
+    double cell_size = 0, hmin = 0, xmin[3] = {}, xmax[3] = {};
+    int nc[3] = {1, 1, 1};
+    long n_cells = 0;       // as the reference reports it (dim-aware)
+    long n_cells_alloc = 0; // ncx * ncy * ncz: what the tables are sized for
+    bool uniform_h = false;
+    double h_uniform = 0;
 };
 
 struct sph_ctx {
@@ -118,6 +154,7 @@ struct sph_ctx {
     DevArray merged;
     bool merged_valid = false;
     long merge_arrays = 1;
+    int phase_sig = -1;     // record layout the first half of a split evaluation packed (the second half repacks when its own differs)
     long split_pair = 0;    // split evaluations: 1 = interior wave tiles in phase 1, face tiles in phase 2 (default: all tiles in phase 2)
     long tension_flag = 1;  // elastic rates: r_ij gathered only when the source array's tension word says so
     // ... built FIRST by sph_nnps_update (one stable sort of all arrays' keys); the per-array orders and tables are a
@@ -133,6 +170,31 @@ struct sph_ctx {
     double face_lo = 0.0, face_hi = 0.0;
     bool ghosts_binned = false;
     DevBuf splitcnt, scan_part, bigq;
+    // The hand-written particle sort (sph_nnps.hip): bucket histogram / starts / cursors, ticket words
+    DevBuf sort_tab;
+    size_t sort_tab_entries = 0;  // buckets the tables were zeroed for
+    int sort_lbits = 0;           // low key bits sorted inside a bucket (adapted to the largest bucket of the previous sort)
+    double sort_bkmax = 0;        // largest bucket of the last sort whose figure has arrived
+    long hand_sort = 1;           // option: 0 = profiling aid, the bucket size is not adapted
+    // The update without a device->host round trip (option async_update, default 1).  When h and m are known without
+    // looking (DevArray::h_dirty / m_dirty) only the bounds of the positions are missing for the grid -- and ANY grid
+    // whose cells are at least radius_scale * hmax wide gives the same neighbours (particles outside it are clamped into
+    // its outermost cells).  Such an update bins on the grid of the PREVIOUS update's bounds (they arrived long ago) in
+    // the same pass that reduces this update's bounds; those travel to `pin_async` behind an event nobody waits for.
+    // The grid REPORTED (sph_nnps_info: cell_size, xmin, xmax, n_cells -- the reference's values, exactly) is computed
+    // from this update's bounds when somebody asks.
+    long async_update = 1;
+    struct {
+        bool valid = false;      // pin_async holds (or will hold, once `ev` has passed) the bounds of the last update
+        bool pending = false;    // ... behind `ev`
+        int dim = 0, narrays = 0, ids[SPH_MAX_ARRAYS] = {};
+        double radius_scale = 0, cell_size_in = 0, extend[3] = {}, hr[2] = {};
+    } lag;
+    hipEvent_t lag_ev = nullptr;
+    double *pin_async = nullptr;  // pinned: 64 doubles
+    GridHost rep;                 // the reported grid of the last update
+    bool rep_valid = false;       // ... computed (else: from pin_async on demand)
+    long n_async_updates = 0;     // updates that ran without a round trip (sph_timer_get "n_async")
 
     // scratch
     DevBuf cub_tmp, red_part, red_out, posh, aux, fposb, dkeys, dperm, tmp_u32a, tmp_u32b, gen_state, gapq;
@@ -191,7 +253,7 @@ struct ScopedTimer {
 };
 
 // nnps.hip
-int nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *out8);
+int nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *out8, int mm); // mm: 1 positions | 2 h | 4 m
 int dev_scan_u32(sph_ctx *c, const uint32_t *in, uint32_t *out, size_t n, bool exclusive); // prefix sums, hand-written (sph_nnps.hip)
 int dev_scan_u64(sph_ctx *c, const unsigned long long *in, unsigned long long *out, size_t n, bool exclusive);
 int nnps_need_tables(sph_ctx *c); // per-array cell orders / tables of a merged-first update, on first use

@@ -14,14 +14,12 @@
 // conditions) is computed on the host in the reference's exact arithmetic.
 #include "sph_internal.h"
 
-#include <hipcub/hipcub.hpp>
-
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
 
 // ---------------------------------------------------------------------------
-// min/max of x, y, z, h
+// bounds (min/max of x, y, z, h, m), fine keys and the bucket histogram of the sort: ONE pass over the positions
 // ---------------------------------------------------------------------------
 __device__ inline double wave_min(double v)
 {
@@ -34,145 +32,6 @@ __device__ inline double wave_max(double v)
     return v;
 }
 
-struct BlockRanges { int first[SPH_MAX_ARRAYS + 1]; int narrays; }; // blocks [first[a], first[a+1]) belong to array a
-
-// several arrays in ONE launch (a dam break has three: three short launches and their gaps cost more than the passes)
-struct MinMaxMulti {
-    const double *x[SPH_MAX_ARRAYS], *y[SPH_MAX_ARRAYS], *z[SPH_MAX_ARRAYS], *h[SPH_MAX_ARRAYS], *m[SPH_MAX_ARRAYS];
-    size_t n[SPH_MAX_ARRAYS];
-    BlockRanges br;
-};
-
-// part[block][8] = {xmin ymin zmin hmin xmax ymax zmax hmax}; partm[block][2] = {mmin mmax} of this array (m may be null)
-__global__ __launch_bounds__(256) void k_minmax(MinMaxMulti t, double *__restrict__ part, double *__restrict__ partm)
-{
-    // this block's array (wave-uniform) and its share of it
-    int a = 0;
-    for (int k = 1; k < SPH_MAX_ARRAYS; k++) if (k < t.br.narrays && (int)blockIdx.x >= t.br.first[k]) a = k;
-    const double *__restrict__ x = t.x[a], *__restrict__ y = t.y[a], *__restrict__ z = t.z[a], *__restrict__ h = t.h[a];
-    const double *__restrict__ m = t.m[a];
-    const size_t n = t.n[a];
-    const size_t lb = blockIdx.x - t.br.first[a], nba = t.br.first[a + 1] - t.br.first[a];
-    double mn[5] = {DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX};
-    double mx[5] = {-DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX};
-    const double *p[4] = {x, y, z, h};
-    for (size_t i = lb * blockDim.x + threadIdx.x; i < n; i += nba * blockDim.x) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            double v = p[k][i];
-            mn[k] = fmin(mn[k], v);
-            mx[k] = fmax(mx[k], v);
-        }
-        if (m) { const double v = m[i]; mn[4] = fmin(mn[4], v); mx[4] = fmax(mx[4], v); }
-    }
-    __shared__ double s[4][10];
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        double a = wave_min(mn[k]), b = wave_max(mx[k]);
-        if (lane == 0) {
-            if (k < 4) { s[wv][k] = a; s[wv][4 + k] = b; }
-            else { s[wv][8] = a; s[wv][9] = b; }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 10) {
-        int k = threadIdx.x;
-        const bool is_min = k < 4 || k == 8;
-        double v = s[0][k];
-        for (int w = 1; w < 4; w++) v = is_min ? fmin(v, s[w][k]) : fmax(v, s[w][k]);
-        if (k < 8) part[(size_t)blockIdx.x * 8 + k] = v;
-        else partm[(size_t)blockIdx.x * 2 + (k - 8)] = v;
-    }
-}
-
-
-__global__ __launch_bounds__(512) void k_minmax_final(const double *__restrict__ part, int nblocks, double *__restrict__ out,
-                                                      const double *__restrict__ partm, BlockRanges br)
-{
-    static_assert(SPH_MAX_ARRAYS <= 8, "one wavefront of this block per array");
-    // the mass range of every array: wavefront a over the partials of array a -> out[8 + 2 a] = {mmin, mmax}
-    {
-        const int a = threadIdx.x >> 6, l = threadIdx.x & 63;
-        if (a < br.narrays) {
-            double lo = DBL_MAX, hi = -DBL_MAX;
-            for (int b = br.first[a] + l; b < br.first[a + 1]; b += 64) { lo = fmin(lo, partm[2 * b]); hi = fmax(hi, partm[2 * b + 1]); }
-            lo = wave_min(lo); hi = wave_max(hi);
-            if (l == 0) { out[8 + 2 * a] = lo; out[8 + 2 * a + 1] = hi; }
-        }
-    }
-    // 64 groups of 8 lanes stride over the partials (the single-wavefront
-    // version spent 35-70 us on a chain of dependent loads)
-    __shared__ double s[64][8];
-    const int k = threadIdx.x & 7, g = threadIdx.x >> 3;
-    double v = (k < 4) ? DBL_MAX : -DBL_MAX;
-    for (int b = g; b < nblocks; b += 64) {
-        double w = part[(size_t)b * 8 + k];
-        v = (k < 4) ? fmin(v, w) : fmax(v, w);
-    }
-    s[g][k] = v;
-    __syncthreads();
-    if (threadIdx.x < 8) {
-        for (int q = 1; q < 64; q++) v = (k < 4) ? fmin(v, s[q][k]) : fmax(v, s[q][k]);
-        out[k] = v;
-    }
-}
-
-int nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *out8)
-{
-    const int BLOCKS = 1024;
-    // partials: [narrays * BLOCKS][8] position / h, then [narrays * BLOCKS][2] mass; results: 8 + 2 per array
-    SPH_TRY(c->red_part.reserve((size_t)narrays * BLOCKS * 10 * sizeof(double)));
-    SPH_TRY(c->red_out.reserve((8 + 2 * SPH_MAX_ARRAYS) * sizeof(double)));
-    double *const partm = c->red_part.as<double>() + (size_t)narrays * BLOCKS * 8;
-    BlockRanges br;
-    int *const first = br.first;
-    br.narrays = narrays;
-    int nb_total = 0;
-    MinMaxMulti mt;
-    memset(&mt, 0, sizeof mt);
-    for (int a = 0; a < narrays; a++) {
-        DevArray &A = c->arr[ids[a]];
-        first[a] = nb_total;
-        A.m_known = false;
-        if (A.n == 0) continue;
-        for (int p : {SPH_X, SPH_Y, SPH_Z, SPH_H})
-            if (!A.prop[p]) {
-                sph_set_error("nnps: array %d has no device copy of x/y/z/h", ids[a]);
-                return SPH_ERR_MISSING_PROP;
-            }
-        int nb = (int)std::min<size_t>(BLOCKS, (A.n + 255) / 256);
-        mt.x[a] = A.prop[SPH_X]; mt.y[a] = A.prop[SPH_Y]; mt.z[a] = A.prop[SPH_Z]; mt.h[a] = A.prop[SPH_H];
-        mt.m[a] = c->want_mrange ? A.prop[SPH_M] : nullptr;
-        mt.n[a] = A.n;
-        nb_total += nb;
-    }
-    first[narrays] = nb_total;
-    for (int a = narrays + 1; a <= SPH_MAX_ARRAYS; a++) first[a] = nb_total;
-    mt.br = br;
-    if (nb_total) hipLaunchKernelGGL(k_minmax, dim3(nb_total), dim3(256), 0, c->stream, mt, c->red_part.as<double>(), partm);
-    if (nb_total == 0) {
-        for (int k = 0; k < 4; k++) { out8[k] = DBL_MAX; out8[4 + k] = -DBL_MAX; }
-        return SPH_OK;
-    }
-    // the mass range of every array rides on the same kernel and round trip (uniform-mass records of the WCSPH pair kernel)
-    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(512), 0, c->stream, c->red_part.as<double>(), nb_total,
-                       c->red_out.as<double>(), partm, br);
-    HIP_TRY(hipMemcpyAsync(c->pinned, c->red_out.ptr, (8 + 2 * narrays) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    memcpy(out8, c->pinned, 8 * sizeof(double));
-    for (int a = 0; a < narrays; a++) {
-        DevArray &A = c->arr[ids[a]];
-        const double lo = c->pinned[8 + 2 * a], hi = c->pinned[8 + 2 * a + 1];
-        A.m_known = c->want_mrange && A.n > 0 && A.prop[SPH_M] && lo == hi && !A.m_mixed_ghosts;
-        A.m_value = lo;
-    }
-    return SPH_OK;
-}
-
-// ---------------------------------------------------------------------------
-// cell keys, sort, cell ranges
-// ---------------------------------------------------------------------------
 struct GridDesc {
     double xmin[3];
     double cell_size;
@@ -185,72 +44,385 @@ struct GridDesc {
 // Cells stay the reference's (cell id = key / SPH_NSUB, cell_start per cell);
 // the sub-bins only order the particles of a cell along x, so that a pair
 // kernel can cut a destination's candidate range in a row of cells from three
-// whole cells to its x window (fine_start per sub-bin).  Costs no extra radix
-// pass (18 + 3 bits at 4 M particles).
-__global__ __launch_bounds__(256) void k_cell_keys(const double *__restrict__ x, const double *__restrict__ y,
-                                                   const double *__restrict__ z, size_t n, GridDesc g,
-                                                   uint32_t *__restrict__ keys, uint32_t *__restrict__ idx,
-                                                   uint32_t tag, uint32_t idx_base)
+// whole cells to its x window (fine_start per sub-bin).
+// A particle outside the grid is clamped into its outermost cells: neighbours
+// are found by the distance criterion, and two particles closer than a cell size
+// stay in adjacent (or the same) cells under the clamp.
+__device__ __forceinline__ uint32_t fine_key(double x, double y, double z, const GridDesc &g)
 {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double ux = (x[i] - g.xmin[0]) / g.cell_size;
+    const double ux = (x - g.xmin[0]) / g.cell_size;
     int cx = (int)floor(ux);
-    int cy = (int)floor((y[i] - g.xmin[1]) / g.cell_size);
-    int cz = (int)floor((z[i] - g.xmin[2]) / g.cell_size);
+    int cy = (int)floor((y - g.xmin[1]) / g.cell_size);
+    int cz = (int)floor((z - g.xmin[2]) / g.cell_size);
     int sub = (int)floor((ux - (double)cx) * SPH_NSUB);
     if (cx < 0) { cx = 0; sub = 0; }
     if (cx > g.nc[0] - 1) { cx = g.nc[0] - 1; sub = SPH_NSUB - 1; }
     sub = min(max(sub, 0), SPH_NSUB - 1);
     cy = min(max(cy, 0), g.nc[1] - 1);
     cz = min(max(cz, 0), g.nc[2] - 1);
-    keys[i] = ((uint32_t)(cx + g.nc[0] * (cy + g.nc[1] * cz)) * SPH_NSUB + (uint32_t)sub) | tag;
-    idx[i] = (uint32_t)i + idx_base; // position in the concatenation of all arrays (merged-first build), else the local index
+    return (uint32_t)(cx + g.nc[0] * (cy + g.nc[1] * cz)) * SPH_NSUB + (uint32_t)sub;
 }
 
-// the same for the concatenation of several arrays in ONE launch (merged-first build): block b belongs to array a with
-// first[a] <= b < first[a + 1]; keys and values land at the array's offset in the concatenation, the value is the
-// particle's position there
-struct KeysMulti {
-    const double *x[SPH_MAX_ARRAYS], *y[SPH_MAX_ARRAYS], *z[SPH_MAX_ARRAYS];
-    uint32_t n[SPH_MAX_ARRAYS], off[SPH_MAX_ARRAYS], first[SPH_MAX_ARRAYS + 1];
+// The particle sort, hand-written for gfx950 (it replaces hipCUB's Onesweep passes and their memsets):
+//   fine key = hi : lo, lo = the `lbits` (9..11) low bits.  A BUCKET = the particles of one hi value = 2^lbits
+//   consecutive fine keys = 2^(lbits - 3) consecutive cells of a row.
+//   k_bin_keys        one pass over x, y, z (+ h, m when they have to be looked at): the min/max partials of this update,
+//                     the fine key of every particle and the bucket histogram G (wavefront-aggregated atomics: the 64
+//                     consecutive particles of a spatially coherent array hit one or two buckets)
+//   k_bin_finish      one workgroup: the partials reduced, G scanned into the bucket starts, G and the cursors left
+//                     zeroed for the next sort (no memset anywhere)
+//   k_bucket_scatter  (key, index) pairs into their bucket in arrival order (wavefront-aggregated cursor atomics)
+//   k_bucket_sort     one workgroup per bucket: counting sort by lo in LDS, every bin put into ascending index order
+//                     (= what a stable sort gives: deterministic, bit-identical to the radix sort it replaces) and --
+//                     the scan of a bucket's histogram IS its slice of fine_start -- the cell tables and the merged
+//                     order's slot / index split written on the way
+// Four launches per neighbour update.
+#define SORT_LMIN 9
+#define SORT_LMAX 11
+#define SORT_BK_CAP 3840   // (lo, index) pairs a bucket's workgroup stages in LDS (four workgroups per CU: 4 x 38.6 KB); a larger bucket is sorted in global memory
+#define SORT_BIN_SMALL 32  // bins up to this size: insertion sort by one thread (arrival order is nearly index order)
+#define SORT_BIGQ 128      // larger ones: queued, ranked by counting by the whole workgroup (an LDS-staged bucket has at most 124)
+#define SORT_BS 512        // threads of a k_bucket_sort workgroup
+enum { MM_XYZ = 1, MM_H = 2, MM_M = 4 };
+#define MM_OUT_BKMAX 40    // out[]: 8 global values, 4 per array, the largest bucket of the previous sort
+#define MM_OUT_N 41
+
+struct BinArrays {   // the arrays of one update, concatenated in slot order
+    const double *x[SPH_MAX_ARRAYS], *y[SPH_MAX_ARRAYS], *z[SPH_MAX_ARRAYS], *h[SPH_MAX_ARRAYS], *m[SPH_MAX_ARRAYS];
+    uint32_t n[SPH_MAX_ARRAYS], off[SPH_MAX_ARRAYS]; // particles, first position in the concatenation
+    uint32_t first[SPH_MAX_ARRAYS + 1];               // workgroups [first[a], first[a + 1]) belong to array a
     int narrays;
 };
-__global__ __launch_bounds__(256) void k_cell_keys_multi(KeysMulti t, GridDesc g, uint32_t *__restrict__ keys, uint32_t *__restrict__ idx)
+struct BinWork {
+    uint32_t *keys;              // fine key of every particle of the concatenation (null: bounds only)
+    uint32_t *G, *bstart, *cur;  // bucket histogram (zero on entry and on exit), bucket starts [nbuckets + 1], cursors (zeroed here)
+    uint32_t *ticket;            // [1] largest bucket of the previous sort (read and reset by k_bin_finish)
+    double *part, *parta;        // partials per workgroup: [8] {xmin ymin zmin hmin xmax ymax zmax hmax}, [4] {hmin hmax mmin mmax} of its array
+    double *out;                 // [0..7] as part, [8 + 4 a ..] {mmin mmax hmin hmax} of array a, [MM_OUT_BKMAX]
+    uint32_t nbuckets;
+    int lbits, mm;
+};
+
+template <class T> __device__ __forceinline__ T wave_incl_scan(T x, int lane)
 {
+    for (int o = 1; o < 64; o <<= 1) { const T t = __shfl_up(x, o, 64); if (lane >= o) x += t; }
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_bin_keys(BinArrays t, GridDesc g, BinWork w)
+{
+    // this workgroup's array (uniform) and its share of it
     int a = 0;
     for (int k = 1; k < SPH_MAX_ARRAYS; k++) if (k < t.narrays && blockIdx.x >= t.first[k]) a = k;
-    const size_t i = (size_t)(blockIdx.x - t.first[a]) * blockDim.x + threadIdx.x;
-    if (i >= t.n[a]) return;
     const double *__restrict__ x = t.x[a], *__restrict__ y = t.y[a], *__restrict__ z = t.z[a];
-    const double ux = (x[i] - g.xmin[0]) / g.cell_size;
-    int cx = (int)floor(ux);
-    int cy = (int)floor((y[i] - g.xmin[1]) / g.cell_size);
-    int cz = (int)floor((z[i] - g.xmin[2]) / g.cell_size);
-    int sub = (int)floor((ux - (double)cx) * SPH_NSUB);
-    if (cx < 0) { cx = 0; sub = 0; }
-    if (cx > g.nc[0] - 1) { cx = g.nc[0] - 1; sub = SPH_NSUB - 1; }
-    sub = min(max(sub, 0), SPH_NSUB - 1);
-    cy = min(max(cy, 0), g.nc[1] - 1);
-    cz = min(max(cz, 0), g.nc[2] - 1);
-    const size_t o = (size_t)t.off[a] + i;
-    keys[o] = (uint32_t)(cx + g.nc[0] * (cy + g.nc[1] * cz)) * SPH_NSUB + (uint32_t)sub;
-    idx[o] = (uint32_t)o;
+    const double *__restrict__ h = (w.mm & MM_H) ? t.h[a] : nullptr, *__restrict__ m = (w.mm & MM_M) ? t.m[a] : nullptr;
+    const uint32_t n = t.n[a], lb = blockIdx.x - t.first[a], nba = t.first[a + 1] - t.first[a];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool mmx = (w.mm & MM_XYZ) != 0;
+    double mn[5] = {DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX};
+    double mx[5] = {-DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for (size_t i0 = (size_t)lb * 256; i0 < n; i0 += (size_t)nba * 256) { // the trip count is uniform over the workgroup
+        const size_t i = i0 + threadIdx.x;
+        const bool valid = i < n;
+        double px = 0, py = 0, pz = 0;
+        if (valid) { px = x[i]; py = y[i]; pz = z[i]; }
+        if (valid && mmx) {
+            mn[0] = fmin(mn[0], px); mx[0] = fmax(mx[0], px);
+            mn[1] = fmin(mn[1], py); mx[1] = fmax(mx[1], py);
+            mn[2] = fmin(mn[2], pz); mx[2] = fmax(mx[2], pz);
+        }
+        if (valid && h) { const double v = h[i]; mn[3] = fmin(mn[3], v); mx[3] = fmax(mx[3], v); }
+        if (valid && m) { const double v = m[i]; mn[4] = fmin(mn[4], v); mx[4] = fmax(mx[4], v); }
+        if (w.keys) {
+            uint32_t key = 0;
+            if (valid) { key = fine_key(px, py, pz, g); w.keys[(size_t)t.off[a] + i] = key; }
+            const uint32_t d = key >> w.lbits;
+            unsigned long long todo = __ballot(valid);
+            while (todo) { // one atomic per bucket the wavefront's particles hit
+                const int l = __builtin_ctzll(todo);
+                const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)d, l);
+                const unsigned long long mk = __ballot(valid && d == dl);
+                if (lane == l) atomicAdd(&w.G[dl], (uint32_t)__builtin_popcountll(mk));
+                todo &= ~mk;
+            }
+        }
+    }
+    __shared__ double s[4][10];
+    if (w.mm) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const double lo = wave_min(mn[k]), hi = wave_max(mx[k]);
+            if (lane == 0) {
+                if (k < 4) { s[wv][k] = lo; s[wv][4 + k] = hi; }
+                else { s[wv][8] = lo; s[wv][9] = hi; }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 10) {
+            const int k = threadIdx.x;
+            const bool is_min = k < 4 || k == 8;
+            double v = s[0][k];
+            for (int q = 1; q < 4; q++) v = is_min ? fmin(v, s[q][k]) : fmax(v, s[q][k]);
+            if (k < 8) w.part[(size_t)blockIdx.x * 8 + k] = v;
+            if (k == 3) w.parta[(size_t)blockIdx.x * 4 + 0] = v;
+            if (k == 7) w.parta[(size_t)blockIdx.x * 4 + 1] = v;
+            if (k >= 8) w.parta[(size_t)blockIdx.x * 4 + 2 + (k - 8)] = v;
+        }
+    }
 }
 
-// one array's segment of the concatenated sort: strip the array tag, split into the array's own tables
-__global__ __launch_bounds__(256) void k_split_segment(const uint32_t *__restrict__ cat_keys, const uint32_t *__restrict__ cat_perm,
-                                                       size_t n, uint32_t mask, uint32_t *__restrict__ fkeys,
-                                                       uint32_t *__restrict__ keys, uint32_t *__restrict__ perm)
+// One workgroup after k_bin_keys: the partials reduced, the bucket histogram G scanned into the bucket starts, G and the
+// cursors left zeroed for the next sort.  (A kernel of its own rather than the last workgroup of k_bin_keys behind a
+// ticket: the agent-scope fence that pattern needs writes back an XCD's L2 once per wavefront -- measured 200 us at 4 M.)
+__global__ __launch_bounds__(1024) void k_bin_finish(BinArrays t, BinWork w, uint32_t nblk, int have_keys)
 {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t f = cat_keys[i] & mask;
-    fkeys[i] = f;
-    keys[i] = f / SPH_NSUB;
-    perm[i] = cat_perm[i];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (w.mm) {
+        __shared__ double sred[128][8];
+        const int k = threadIdx.x & 7, gq = threadIdx.x >> 3;
+        double v = (k < 4) ? DBL_MAX : -DBL_MAX;
+#pragma unroll 8
+        for (uint32_t b = gq; b < nblk; b += 128) { // (independent loads: unrolled, they are in flight together)
+            const double q = w.part[(size_t)b * 8 + k];
+            v = (k < 4) ? fmin(v, q) : fmax(v, q);
+        }
+        sred[gq][k] = v;
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            for (int q = 1; q < 128; q++) v = (k < 4) ? fmin(v, sred[q][k]) : fmax(v, sred[q][k]);
+            w.out[k] = v;
+        }
+        // the h and m range of every array: one wavefront per array
+        if (wv < t.narrays) {
+            const int a2 = wv;
+            double hl = DBL_MAX, hh = -DBL_MAX, ml = DBL_MAX, mh = -DBL_MAX;
+#pragma unroll 8
+            for (uint32_t b = t.first[a2] + lane; b < t.first[a2 + 1]; b += 64) {
+                hl = fmin(hl, w.parta[(size_t)b * 4 + 0]); hh = fmax(hh, w.parta[(size_t)b * 4 + 1]);
+                ml = fmin(ml, w.parta[(size_t)b * 4 + 2]); mh = fmax(mh, w.parta[(size_t)b * 4 + 3]);
+            }
+            hl = wave_min(hl); hh = wave_max(hh); ml = wave_min(ml); mh = wave_max(mh);
+            if (lane == 0) { w.out[8 + 4 * a2] = ml; w.out[9 + 4 * a2] = mh; w.out[10 + 4 * a2] = hl; w.out[11 + 4 * a2] = hh; }
+        }
+    }
+    if (threadIdx.x == 0) { w.out[MM_OUT_BKMAX] = (double)w.ticket[1]; w.ticket[1] = 0u; }
+    if (have_keys) { // bucket starts = exclusive scan of G; G and the cursors zeroed
+        __shared__ uint32_t ws[16];
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < w.nbuckets; base += 1024 * 8) {
+            uint32_t v[8], sum = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint32_t idx = base + threadIdx.x * 8 + q;
+                v[q] = idx < w.nbuckets ? w.G[idx] : 0u;
+                sum += v[q];
+            }
+            const uint32_t incl = wave_incl_scan<uint32_t>(sum, lane);
+            if (lane == 63) ws[wv] = incl;
+            __syncthreads();
+            uint32_t off = carry + incl - sum, tot = 0;
+            for (int q = 0; q < 16; q++) { if (q < wv) off += ws[q]; tot += ws[q]; }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint32_t idx = base + threadIdx.x * 8 + q;
+                if (idx < w.nbuckets) { w.bstart[idx] = off; off += v[q]; w.G[idx] = 0u; w.cur[idx] = 0u; }
+            }
+            carry += tot;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) w.bstart[w.nbuckets] = carry;
+    }
 }
 
+// (key, index) pairs into their buckets, in arrival order.  SCAT_ITEMS keys per thread: the cursor atomics of a
+// wavefront's rounds are in flight together (one key per thread left the kernel waiting on one round trip per wavefront).
+#define SCAT_ITEMS 4
+__global__ __launch_bounds__(256) void k_bucket_scatter(const uint32_t *__restrict__ keys, uint32_t n, int lbits,
+                                                        const uint32_t *__restrict__ bstart, uint32_t *__restrict__ cur,
+                                                        uint2 *__restrict__ pairs)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const uint32_t i0 = blockIdx.x * (256u * SCAT_ITEMS) + threadIdx.x;
+    uint32_t key[SCAT_ITEMS], rank[SCAT_ITEMS], base[SCAT_ITEMS], bs[SCAT_ITEMS];
+    int leader[SCAT_ITEMS];
+#pragma unroll
+    for (int q = 0; q < SCAT_ITEMS; q++) { const uint32_t i = i0 + q * 256u; key[q] = i < n ? keys[i] : 0u; }
+#pragma unroll
+    for (int q = 0; q < SCAT_ITEMS; q++) {
+        const bool valid = i0 + q * 256u < n;
+        const uint32_t d = key[q] >> lbits;
+        unsigned long long todo = __ballot(valid);
+        uint32_t cnt = 0;
+        leader[q] = lane; rank[q] = 0; base[q] = 0;
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)d, l);
+            const unsigned long long mk = __ballot(valid && d == dl);
+            if (valid && d == dl) { leader[q] = l; rank[q] = (uint32_t)__builtin_popcountll(mk & lt); cnt = (uint32_t)__builtin_popcountll(mk); }
+            todo &= ~mk;
+        }
+        bs[q] = valid ? bstart[d] : 0u;
+        if (valid && lane == leader[q]) base[q] = atomicAdd(&cur[d], cnt); // every group's leader at once
+    }
+#pragma unroll
+    for (int q = 0; q < SCAT_ITEMS; q++) {
+        const uint32_t i = i0 + q * 256u;
+        const uint32_t b = __shfl(base[q], leader[q], 64);
+        if (i < n) pairs[(size_t)bs[q] + b + rank[q]] = make_uint2(key[q], i);
+    }
+}
+
+struct CatOff { uint32_t off[SPH_MAX_ARRAYS + 1]; int narrays; }; // first position of every array in the concatenation
+
+struct BucketOut {
+    uint32_t *fkeys, *keys, *perm; // sorted fine keys, cell ids (optional), sorted position -> index (in its own array when slot != null)
+    uint8_t *slot;                 // merged order of several arrays: the array slot of every sorted particle (else null)
+    CatOff co;
+    uint32_t *fine_start, *cell_start;
+    uint32_t n_fine, n_cells;
+    uint2 *scratch;                // n entries (big bins)
+    uint32_t *bkmax;               // largest bucket (atomicMax)
+};
+
+__global__ __launch_bounds__(SORT_BS) void k_bucket_sort(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ bstart, int lbits,
+                                                         BucketOut o)
+{
+    constexpr int NW = SORT_BS / 64, PT = (SORT_BK_CAP + SORT_BS - 1) / SORT_BS; // wavefronts; pairs a thread holds of an LDS-staged bucket
+    __shared__ uint32_t tab[1 << SORT_LMAX];
+    __shared__ uint2 stage[SORT_BK_CAP];
+    __shared__ uint32_t ws[NW], bigq[SORT_BIGQ], nbig;
+    const uint32_t tid = threadIdx.x, NL = 1u << lbits, mask = NL - 1u;
+    const int lane = tid & 63, wv = tid >> 6;
+    const uint32_t base = bstart[blockIdx.x], s = bstart[blockIdx.x + 1] - base;
+    if (s == 0) { // an empty bucket (the air of a dam break's tank): its slice of the tables is one value
+        const size_t f0 = (size_t)blockIdx.x * NL;
+        for (uint32_t k = tid; k < NL; k += SORT_BS) {
+            const size_t fk = f0 + k;
+            if (fk <= o.n_fine) { o.fine_start[fk] = base; if (fk % SPH_NSUB == 0) o.cell_start[fk / SPH_NSUB] = base; }
+        }
+        return;
+    }
+    const bool lds = s <= SORT_BK_CAP;
+    uint2 mine[PT]; // (the loads of an LDS-staged bucket are issued together and serve both sweeps)
+    if (lds) {
+#pragma unroll
+        for (int q = 0; q < PT; q++) { const uint32_t i = tid + q * SORT_BS; mine[q] = i < s ? pairs[(size_t)base + i] : make_uint2(0u, 0u); }
+    }
+    for (uint32_t k = tid; k < NL; k += SORT_BS) tab[k] = 0u;
+    if (tid == 0) nbig = 0u;
+    __syncthreads();
+    if (lds) {
+#pragma unroll
+        for (int q = 0; q < PT; q++) if (tid + q * SORT_BS < s) atomicAdd(&tab[mine[q].x & mask], 1u);
+    } else {
+        for (uint32_t i = tid; i < s; i += SORT_BS) atomicAdd(&tab[pairs[(size_t)base + i].x & mask], 1u);
+    }
+    __syncthreads();
+    { // exclusive scan of the bin counts: NL / SORT_BS consecutive bins per thread
+        const uint32_t per = NL / SORT_BS;
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) { v[q] = q < per ? tab[tid * per + q] : 0u; sum += v[q]; }
+        const uint32_t incl = wave_incl_scan<uint32_t>(sum, lane);
+        if (lane == 63) ws[wv] = incl;
+        __syncthreads();
+        uint32_t off = incl - sum;
+        for (int q = 0; q < wv; q++) off += ws[q];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) if (q < per) { tab[tid * per + q] = off; off += v[q]; }
+    }
+    __syncthreads();
+    // this bucket's slice of the tables: fine_start[k] = first sorted position whose key >= k (the last bucket holds the
+    // end entry fine_start[n_fine]), cell_start[c] = fine_start[c * SPH_NSUB]
+    const size_t fk0 = (size_t)blockIdx.x * NL;
+    for (uint32_t k = tid; k < NL; k += SORT_BS) {
+        const size_t fk = fk0 + k;
+        if (fk <= o.n_fine) {
+            const uint32_t v = base + tab[k];
+            o.fine_start[fk] = v;
+            if (fk % SPH_NSUB == 0) o.cell_start[fk / SPH_NSUB] = v;
+        }
+    }
+    __syncthreads();
+    if (lds) {
+#pragma unroll
+        for (int q = 0; q < PT; q++)
+            if (tid + q * SORT_BS < s) {
+                const uint32_t lo = mine[q].x & mask, pos = atomicAdd(&tab[lo], 1u);
+                stage[pos] = make_uint2(lo, mine[q].y);
+            }
+    } else {
+        for (uint32_t i = tid; i < s; i += SORT_BS) {
+            const uint2 p = pairs[(size_t)base + i];
+            const uint32_t lo = p.x & mask, pos = atomicAdd(&tab[lo], 1u);
+            o.fkeys[(size_t)base + pos] = lo; o.perm[(size_t)base + pos] = p.y;
+        }
+    }
+    __syncthreads();
+    // every bin into ascending index order (tab[k] is now the END of bin k)
+    for (uint32_t k = tid; k < NL; k += SORT_BS) {
+        const uint32_t b0 = k ? tab[k - 1] : 0u, b1 = tab[k], c = b1 - b0;
+        if (c < 2) continue;
+        if (c > SORT_BIN_SMALL) {
+            const uint32_t q = atomicAdd(&nbig, 1u);
+            if (q < SORT_BIGQ) { bigq[q] = k; continue; }
+        }
+        if (lds) {
+            for (uint32_t i = b0 + 1; i < b1; i++) {
+                const uint32_t xv = stage[i].y;
+                uint32_t j = i;
+                while (j > b0 && stage[j - 1].y > xv) { stage[j].y = stage[j - 1].y; j--; }
+                stage[j].y = xv;
+            }
+        } else {
+            uint32_t *pm = o.perm + base;
+            for (uint32_t i = b0 + 1; i < b1; i++) {
+                const uint32_t xv = pm[i];
+                uint32_t j = i;
+                while (j > b0 && pm[j - 1] > xv) { pm[j] = pm[j - 1]; j--; }
+                pm[j] = xv;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t nq = min(nbig, (uint32_t)SORT_BIGQ);
+    for (uint32_t q = 0; q < nq; q++) { // dense bins (coincident particles): rank by counting
+        const uint32_t k = bigq[q], b0 = k ? tab[k - 1] : 0u, c = tab[k] - b0;
+        uint2 *scr = o.scratch + base + b0;
+        for (uint32_t i = tid; i < c; i += SORT_BS) scr[i] = make_uint2(k, lds ? stage[b0 + i].y : o.perm[(size_t)base + b0 + i]);
+        __syncthreads();
+        for (uint32_t i = tid; i < c; i += SORT_BS) {
+            const uint32_t xv = scr[i].y;
+            uint32_t r = 0;
+            for (uint32_t j = 0; j < c; j++) r += scr[j].y < xv;
+            if (lds) stage[b0 + r].y = xv; else o.perm[(size_t)base + b0 + r] = xv;
+        }
+        __syncthreads();
+    }
+    for (uint32_t p = tid; p < s; p += SORT_BS) {
+        const size_t j = (size_t)base + p;
+        const uint32_t lo = lds ? stage[p].x : o.fkeys[j], gpos = lds ? stage[p].y : o.perm[j];
+        const uint32_t fk = (uint32_t)fk0 + lo;
+        o.fkeys[j] = fk;
+        if (o.keys) o.keys[j] = fk / SPH_NSUB;
+        if (o.slot) {
+            uint32_t sl = 0, sb = 0;
+#pragma unroll
+            for (int b = 1; b < SPH_MAX_ARRAYS; b++)
+                if (b < o.co.narrays && gpos >= o.co.off[b]) { sl = (uint32_t)b; sb = o.co.off[b]; }
+            o.slot[j] = (uint8_t)sl;
+            o.perm[j] = gpos - sb;
+        } else {
+            o.perm[j] = gpos;
+        }
+    }
+    if (tid == 0 && s) atomicMax(o.bkmax, s);
+}
+
+// ---------------------------------------------------------------------------
+// cell ranges of a sorted key sequence (the per-array tables derived from the merged order), tile order
+// ---------------------------------------------------------------------------
 // cell_start[c] = fine_start[c * SPH_NSUB]
 // Runs after k_fill_gaps: also empties the gap queue for its next user (the queue is empty between uses).
 __global__ __launch_bounds__(256) void k_coarse_start(const uint32_t *__restrict__ fine_start, uint32_t n_cells,
@@ -350,11 +522,244 @@ static int bits_for(long n_cells)
     return b;
 }
 
+// ---------------------------------------------------------------------------
+// host side of the pass above
+// ---------------------------------------------------------------------------
+#define BIN_BLOCKS 1536   // workgroups of one k_bin_keys launch (all arrays together): six per CU
+
+static int bin_arrays(sph_ctx *c, int narrays, const int *ids, BinArrays *ba, size_t *n_cat, uint32_t *nblocks)
+{
+    memset(ba, 0, sizeof *ba);
+    ba->narrays = narrays;
+    size_t total = 0;
+    for (int a = 0; a < narrays; a++) total += c->arr[ids[a]].n;
+    if (total >= (1ull << 31)) { sph_set_error("nnps: %zu particles (the sorted index is 31 bits wide)", total); return SPH_ERR_ARG; }
+    uint32_t nb = 0, off = 0;
+    for (int a = 0; a < narrays; a++) {
+        DevArray &A = c->arr[ids[a]];
+        ba->first[a] = nb;
+        ba->off[a] = off;
+        ba->n[a] = (uint32_t)A.n;
+        off += (uint32_t)A.n;
+        if (A.n == 0) continue;
+        for (int p : {SPH_X, SPH_Y, SPH_Z, SPH_H})
+            if (!A.prop[p]) {
+                sph_set_error("nnps: array %d has no device copy of x/y/z/h", ids[a]);
+                return SPH_ERR_MISSING_PROP;
+            }
+        ba->x[a] = A.prop[SPH_X]; ba->y[a] = A.prop[SPH_Y]; ba->z[a] = A.prop[SPH_Z]; ba->h[a] = A.prop[SPH_H];
+        ba->m[a] = A.prop[SPH_M];
+        // the array's share of the launch, at least one workgroup, at most one per 256 particles
+        size_t share = (size_t)((double)BIN_BLOCKS * (double)A.n / (double)total);
+        share = std::max<size_t>(1, std::min<size_t>(share, (A.n + 255) / 256));
+        nb += (uint32_t)share;
+    }
+    for (int a = narrays; a <= SPH_MAX_ARRAYS; a++) ba->first[a] = nb;
+    *n_cat = total;
+    *nblocks = nb;
+    return SPH_OK;
+}
+
+// tables of the sort: [G: cap][bstart: cap + 1][cur: cap][words: 4]; G and the largest-bucket word must be zero between sorts
+static int sort_tables(sph_ctx *c, uint32_t nbuckets, BinWork *w)
+{
+    const size_t cap = std::max<size_t>(c->sort_tab_entries, 1024);
+    if (!c->sort_tab.ptr || nbuckets + 1 > cap) {
+        size_t ncap = std::max<size_t>((size_t)nbuckets + 1 + nbuckets / 4, 1024);
+        DevBuf nb_;
+        SPH_TRY(nb_.reserve((3 * ncap + 8) * 4));
+        HIP_TRY(hipMemsetAsync(nb_.ptr, 0, nb_.bytes, c->stream));
+        if (c->sort_tab.ptr) { HIP_TRY(hipStreamSynchronize(c->stream)); c->sort_tab.release(); }
+        c->sort_tab = nb_;
+        c->sort_tab_entries = ncap;
+    }
+    uint32_t *t = c->sort_tab.as<uint32_t>();
+    const size_t e = c->sort_tab_entries;
+    w->G = t; w->bstart = t + e; w->cur = t + 2 * e + 1; w->ticket = t + 3 * e + 4;
+    w->nbuckets = nbuckets;
+    return SPH_OK;
+}
+
+// One k_bin_keys launch: `mm` = what to reduce (MM_*), `keys` = null (bounds only) or the key buffer of the concatenation.
+// The reduced values land in c->red_out (device); the caller copies them where it wants them.
+static int launch_bin_keys(sph_ctx *c, const BinArrays &ba, uint32_t nblocks, const GridDesc &g, int mm, uint32_t *keys, uint32_t nbuckets,
+                           int lbits)
+{
+    BinWork w;
+    memset(&w, 0, sizeof w);
+    SPH_TRY(sort_tables(c, keys ? nbuckets : 1, &w));
+    SPH_TRY(c->red_part.reserve((size_t)nblocks * 12 * sizeof(double)));
+    SPH_TRY(c->red_out.reserve(64 * sizeof(double)));
+    w.keys = keys;
+    w.part = c->red_part.as<double>();
+    w.parta = w.part + (size_t)nblocks * 8;
+    w.out = c->red_out.as<double>();
+    w.lbits = lbits;
+    w.mm = mm;
+    hipLaunchKernelGGL(k_bin_keys, dim3(nblocks), dim3(256), 0, c->stream, ba, g, w);
+    hipLaunchKernelGGL(k_bin_finish, dim3(1), dim3(1024), 0, c->stream, ba, w, nblocks, keys ? 1 : 0);
+    return SPH_OK;
+}
+
+// what a look at h / m found, per array
+static void note_ranges(sph_ctx *c, int narrays, const int *ids, const double *out, int mm)
+{
+    for (int a = 0; a < narrays; a++) {
+        DevArray &A = c->arr[ids[a]];
+        if ((mm & MM_H) && !A.raw_hm) { A.h_seen = true; A.h_dirty = false; A.h_lo = out[10 + 4 * a]; A.h_hi = out[11 + 4 * a]; }
+        if (mm & MM_M) {
+            A.m_lo = out[8 + 4 * a]; A.m_hi = out[9 + 4 * a];
+            if (!A.raw_hm) { A.m_seen = A.prop[SPH_M] != nullptr; A.m_dirty = false; }
+            A.m_known = c->want_mrange && A.n > 0 && A.prop[SPH_M] && A.m_lo == A.m_hi && !A.m_mixed_ghosts;
+            A.m_value = A.m_lo;
+        }
+    }
+}
+
+// bounds (and h / m ranges) of the arrays, synchronously: out8 = {xmin ymin zmin hmin xmax ymax zmax hmax}
+int nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *out8, int mm)
+{
+    BinArrays ba;
+    size_t n_cat = 0;
+    uint32_t nblocks = 0;
+    SPH_TRY(bin_arrays(c, narrays, ids, &ba, &n_cat, &nblocks));
+    if (nblocks == 0) {
+        for (int k = 0; k < 4; k++) { out8[k] = DBL_MAX; out8[4 + k] = -DBL_MAX; }
+        return SPH_OK;
+    }
+    GridDesc g;
+    memset(&g, 0, sizeof g);
+    SPH_TRY(launch_bin_keys(c, ba, nblocks, g, mm, nullptr, 0, SORT_LMAX));
+    HIP_TRY(hipMemcpyAsync(c->pinned, c->red_out.ptr, MM_OUT_N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(out8, c->pinned, 8 * sizeof(double));
+    note_ranges(c, narrays, ids, c->pinned, mm);
+    return SPH_OK;
+}
+
 extern "C" int sph_nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *out8)
 {
     if (!c || narrays < 1 || narrays > SPH_MAX_ARRAYS) { sph_set_error("sph_nnps_minmax: bad arguments"); return SPH_ERR_ARG; }
+    for (int a = 0; a < narrays; a++)
+        if (ids[a] < 0 || ids[a] >= SPH_MAX_ARRAYS || !c->arr[ids[a]].used) { sph_set_error("sph_nnps_minmax: array id %d not registered", ids[a]); return SPH_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
-    return nnps_minmax(c, narrays, ids, out8);
+    return nnps_minmax(c, narrays, ids, out8, MM_XYZ | MM_H | (c->want_mrange ? MM_M : 0));
+}
+
+// The grid of a set of bounds in the reference's arithmetic.  mm = {xmin ymin zmin hmin xmax ymax zmax hmax}.
+static int grid_from_minmax(const sph_ctx *c, int dim, double radius_scale, double cell_size_in, const double *bounds, const double *mm,
+                            GridHost *G)
+{
+    // DomainManager._compute_cell_size_for_binning (nnps_base.pyx:942-978)
+    double hmax = -1.0, hmin = DBL_MAX;
+    if (mm[7] > hmax) hmax = mm[7];
+    if (mm[3] < hmin) hmin = mm[3];
+    double cell_size = radius_scale * hmax;
+    G->hmin = radius_scale * hmin;
+    if (cell_size < 1e-6) cell_size = 1.0;
+    if (cell_size_in > 0) cell_size = cell_size_in;
+    G->uniform_h = (hmin == hmax);
+    G->h_uniform = hmax;
+
+    // NNPS._compute_bounds (nnps_base.pyx:1520-1575)
+    double xmax = fmax(mm[4], -1e100), ymax = fmax(mm[5], -1e100), zmax = fmax(mm[6], -1e100);
+    double xmin = fmin(mm[0], 1e100), ymin = fmin(mm[1], 1e100), zmin = fmin(mm[2], 1e100);
+    // ghost split: room for the ghosts that arrive after this update (sph_nnps_set_extend)
+    xmin -= c->extend[0]; xmax += c->extend[0];
+    ymin -= c->extend[1]; ymax += c->extend[1];
+    zmin -= c->extend[2]; zmax += c->extend[2];
+    double lx = xmax - xmin, ly = ymax - ymin, lz = zmax - zmin;
+    xmin -= lx * 0.01; ymin -= ly * 0.01; zmin -= lz * 0.01;
+    xmax += lx * 0.01; ymax += ly * 0.01; zmax += lz * 0.01;
+    const double eps = 1e-12;
+    if (fabs(xmax - xmin) < eps && fabs(ymax - ymin) < eps && fabs(zmax - zmin) < eps) {
+        xmin -= 0.5; xmax += 0.5;
+        ymin -= 0.5; ymax += 0.5;
+        zmin -= 0.5; zmax += 0.5;
+    }
+    if (bounds) {
+        xmin = bounds[0]; ymin = bounds[1]; zmin = bounds[2];
+        xmax = bounds[3]; ymax = bounds[4]; zmax = bounds[5];
+    }
+
+    // LinkedListNNPS._get_number_of_cells (linked_list_nnps.pyx:293-326)
+    double cell_size1 = 1. / cell_size;
+    int ncx = (int)ceil(cell_size1 * (xmax - xmin));
+    int ncy = (int)ceil(cell_size1 * (ymax - ymin));
+    int ncz = (int)ceil(cell_size1 * (zmax - zmin));
+    if (ncx < 0 || ncy < 0 || ncz < 0) {
+        sph_set_error("LinkedListNNPS: Number of cells is negative (%d, %d, %d).", ncx, ncy, ncz);
+        return SPH_ERR_CELLS;
+    }
+    ncx = ncx == 0 ? 1 : ncx;
+    ncy = ncy == 0 ? 1 : ncy;
+    ncz = ncz == 0 ? 1 : ncz;
+    long n_cells = ncx;
+    if (dim == 2) n_cells = (long)ncx * ncy;
+    if (dim == 3) n_cells = (long)ncx * ncy * ncz;
+    // _count_occupied_cells (:328-343)
+    if (n_cells < 0 || n_cells > (1L << 28)) {
+        sph_set_error("ERROR: LinkedListNNPS requires too many cells (%ld).", n_cells);
+        return SPH_ERR_CELLS;
+    }
+    // The reference indexes head[] with the full 3-D flattened id even when
+    // dim < 3; particles of a dim<3 problem lie in one z (and y) plane so the
+    // id stays < n_cells.  Keys here use the same flattening; the table is
+    // sized for the full product so that a stray plane cannot overflow it.
+    long n_cells_alloc = (long)ncx * ncy * ncz;
+    if (n_cells_alloc > (1L << 28)) {
+        sph_set_error("ERROR: LinkedListNNPS requires too many cells (%ld).", n_cells_alloc);
+        return SPH_ERR_CELLS;
+    }
+    G->cell_size = cell_size;
+    G->xmin[0] = xmin; G->xmin[1] = ymin; G->xmin[2] = zmin;
+    G->xmax[0] = xmax; G->xmax[1] = ymax; G->xmax[2] = zmax;
+    G->nc[0] = ncx; G->nc[1] = ncy; G->nc[2] = ncz;
+    G->n_cells = n_cells;
+    G->n_cells_alloc = n_cells_alloc;
+    return SPH_OK;
+}
+
+// low key bits sorted inside a bucket: buckets of about half the LDS stage on average, corrected by the largest bucket
+// the previous sort saw (a sparse grid -- the tank of a dam break -- has far fewer occupied keys than keys)
+static int sort_choose_lbits(sph_ctx *c, size_t n, size_t n_fine)
+{
+    int lb = c->sort_lbits;
+    if (lb < SORT_LMIN || lb > SORT_LMAX) {
+        const double per_key = (double)n / (double)std::max<size_t>(n_fine, 1);
+        lb = SORT_LMAX;
+        while (lb > SORT_LMIN && per_key * (double)(1u << lb) > 0.6 * SORT_BK_CAP) lb--;
+    } else if (c->hand_sort) {
+        if (c->sort_bkmax > SORT_BK_CAP && lb > SORT_LMIN) lb--;
+        else if (c->sort_bkmax > 0 && c->sort_bkmax * 4 <= SORT_BK_CAP && lb < SORT_LMAX) lb++;
+        c->sort_bkmax = 0; // one correction per measurement
+    }
+    c->sort_lbits = lb;
+    return lb;
+}
+
+struct SortDest { DevArray *T; bool merged; CatOff co; };
+
+// keys (already in c->tmp_u32a) -> sorted order + tables of T
+static int sort_finish(sph_ctx *c, size_t n, size_t n_fine, long n_cells, int lbits, uint32_t nbuckets, const SortDest &d)
+{
+    BinWork w;
+    SPH_TRY(sort_tables(c, nbuckets, &w));
+    DevArray &T = *d.T;
+    uint2 *pairs = c->tmp_u32b.as<uint2>();
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(div_up(n, 256 * SCAT_ITEMS)), dim3(256), 0, c->stream, c->tmp_u32a.as<uint32_t>(), (uint32_t)n, lbits,
+                       (const uint32_t *)w.bstart, w.cur, pairs);
+    BucketOut o;
+    memset(&o, 0, sizeof o);
+    o.fkeys = T.fkeys_sorted.as<uint32_t>(); o.keys = T.keys_sorted.as<uint32_t>(); o.perm = T.perm.as<uint32_t>();
+    o.slot = d.merged ? T.slot8.as<uint8_t>() : nullptr;
+    o.co = d.co;
+    o.fine_start = T.fine_start.as<uint32_t>(); o.cell_start = T.cell_start.as<uint32_t>();
+    o.n_fine = (uint32_t)n_fine; o.n_cells = (uint32_t)n_cells;
+    o.scratch = c->tmp_u32a.as<uint2>();
+    o.bkmax = w.ticket + 1;
+    hipLaunchKernelGGL(k_bucket_sort, dim3(nbuckets), dim3(SORT_BS), 0, c->stream, (const uint2 *)pairs, (const uint32_t *)w.bstart, lbits, o);
+    return SPH_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -376,12 +781,6 @@ extern "C" int sph_nnps_minmax(sph_ctx *c, int narrays, const int *ids, double *
 // ---------------------------------------------------------------------------
 #define SCAN_ITEMS 16
 #define SCAN_BLOCK (256 * SCAN_ITEMS)
-
-template <class T> __device__ __forceinline__ T wave_incl_scan(T x, int lane)
-{
-    for (int o = 1; o < 64; o <<= 1) { const T t = __shfl_up(x, o, 64); if (lane >= o) x += t; }
-    return x;
-}
 
 template <class T>
 __global__ __launch_bounds__(256) void k_scan_partials(const T *__restrict__ in, size_t n, T *__restrict__ partial)
@@ -555,10 +954,17 @@ __global__ __launch_bounds__(256) void k_bin_fix_big(BinFixArgs a, uint32_t *__r
 
 __global__ void k_reset_u32(uint32_t *p) { p[0] = 0u; }
 
-__global__ __launch_bounds__(256) void k_mass_differs(const double *__restrict__ m, size_t n, double mu, uint32_t *__restrict__ flag)
+// ghosts against what the update knew of the real particles: bit 0 = a mass other than mu, bit 1 = an h outside [hlo, hhi]
+__global__ __launch_bounds__(256) void k_ghost_hm_check(const double *__restrict__ h, const double *__restrict__ m, size_t n, double hlo,
+                                                        double hhi, double mu, uint32_t *__restrict__ flag)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && m[i] != mu) *flag = 1u;
+    if (i >= n) return;
+    uint32_t f = 0;
+    const double hv = h[i];
+    if (!(hv >= hlo && hv <= hhi)) f |= 2u;
+    if (m && m[i] != mu) f |= 1u;
+    if (f) atomicOr(flag, f);
 }
 
 // Sort n keys < nbins through `table` (nbins + 2 entries; the count pass -- k_tile_keys, k_cell_keys_count -- has run on the
@@ -603,27 +1009,6 @@ __global__ __launch_bounds__(256) void k_cell_keys_count(const double *__restric
 // ---------------------------------------------------------------------------
 // merged-first build (sph_nnps_update) and the per-array tables derived from it on demand
 // ---------------------------------------------------------------------------
-struct CatOff { uint32_t off[SPH_MAX_ARRAYS + 1]; int narrays; }; // first position of every array in the concatenation
-
-// The merged order straight from the ONE stable sort of all arrays' fine keys: the sorted value is the particle's
-// position in the concatenation of the arrays -> its slot and its original index there.
-__global__ __launch_bounds__(256) void k_merged_split(const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ svals, size_t n,
-                                                      CatOff co, uint32_t *__restrict__ fkeys, uint32_t *__restrict__ keys,
-                                                      uint32_t *__restrict__ perm, uint8_t *__restrict__ slot)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t f = skeys[i], gpos = svals[i];
-    uint32_t s = 0, base = 0;
-#pragma unroll
-    for (int b = 1; b < SPH_MAX_ARRAYS; b++)
-        if (b < co.narrays && gpos >= co.off[b]) { s = (uint32_t)b; base = co.off[b]; }
-    fkeys[i] = f;
-    keys[i] = f / SPH_NSUB;
-    perm[i] = gpos - base;
-    slot[i] = (uint8_t)s;
-}
-
 // Stable compaction of the merged order by slot = every array's own cell order: count per block of SPLIT_BLOCK merged
 // positions and slot, exclusive scan per slot over the blocks, scatter with the ranks re-derived from wavefront ballots.
 #define SPLIT_BLOCK 1024
@@ -711,9 +1096,9 @@ __global__ __launch_bounds__(256) void k_slot_scatter(const uint8_t *__restrict_
 
 static int nnps_tile_order(sph_ctx *c, DevArray &A, size_t n);
 
-static int nnps_reserve_tables(sph_ctx *c, DevArray &A)
+static int nnps_reserve_tables(sph_ctx *c, DevArray &A, size_t n)
 {
-    const size_t n = A.n, n_fine = (size_t)c->n_cells * SPH_NSUB;
+    const size_t n_fine = (size_t)c->n_cells * SPH_NSUB;
     SPH_TRY(A.keys_sorted.reserve((n + 1) * 4));
     SPH_TRY(A.perm.reserve((n + 1) * 4));
     SPH_TRY(A.fkeys_sorted.reserve((n + 1) * 4));
@@ -731,9 +1116,10 @@ static void nnps_empty_tables(sph_ctx *c, DevArray &A)
 }
 
 // fine_start / cell_start (and, `with_keys`, the cell ids) of one array from its sorted fine keys; its tile order
+// (the first n_binned particles: ghosts appended after the update live in tables of their own)
 static int nnps_finish_tables(sph_ctx *c, DevArray &A, bool with_keys)
 {
-    const size_t n = A.n, n_fine = (size_t)c->n_cells * SPH_NSUB;
+    const size_t n = A.n_binned, n_fine = (size_t)c->n_cells * SPH_NSUB;
     hipLaunchKernelGGL(k_cell_start, dim3(div_up(n + 1, 256)), dim3(256), 0, c->stream, A.fkeys_sorted.as<uint32_t>(), n,
                        (uint32_t)n_fine, A.fine_start.as<uint32_t>(), c->gapq.as<uint32_t>(),
                        with_keys ? A.keys_sorted.as<uint32_t>() : (uint32_t *)nullptr);
@@ -757,7 +1143,7 @@ int nnps_need_tables(sph_ctx *c)
     so.narrays = na;
     for (int a = 0; a < na; a++) {
         DevArray &A = c->arr[c->ids[a]];
-        SPH_TRY(nnps_reserve_tables(c, A));
+        SPH_TRY(nnps_reserve_tables(c, A, A.n_binned));
         so.fkeys[a] = A.fkeys_sorted.as<uint32_t>(); so.keys[a] = A.keys_sorted.as<uint32_t>(); so.perm[a] = A.perm.as<uint32_t>();
     }
     if (M.n) {
@@ -769,7 +1155,7 @@ int nnps_need_tables(sph_ctx *c)
     }
     for (int a = 0; a < na; a++) {
         DevArray &A = c->arr[c->ids[a]];
-        if (A.n == 0) { nnps_empty_tables(c, A); continue; }
+        if (A.n_binned == 0) { nnps_empty_tables(c, A); continue; }
         SPH_TRY(nnps_finish_tables(c, A, false));
     }
     HIP_TRY(hipGetLastError());
@@ -828,6 +1214,31 @@ static void nnps_face_planes(sph_ctx *c)
     c->gfx_hi = !(fhi < 1e9) ? 0x7fffffff : (fhi < -1e9 ? -0x7fffffff : (int)fhi);  // ... or fx >= gfx_hi
 }
 
+// the bounds the last update sent to pin_async have arrived
+static int lag_wait(sph_ctx *c)
+{
+    if (c->lag.pending) {
+        HIP_TRY(hipEventSynchronize(c->lag_ev));
+        c->lag.pending = false;
+        c->sort_bkmax = c->pin_async[MM_OUT_BKMAX];
+    }
+    return SPH_OK;
+}
+
+// the grid the reference would report for the last update (exact; the binning grid of an update without a round trip
+// is the one of the update before)
+static int nnps_reported_grid(sph_ctx *c)
+{
+    if (c->rep_valid) return SPH_OK;
+    SPH_TRY(lag_wait(c));
+    double mm[8];
+    memcpy(mm, c->pin_async, sizeof mm);
+    mm[3] = c->lag.hr[0]; mm[7] = c->lag.hr[1];
+    SPH_TRY(grid_from_minmax(c, c->lag.dim, c->lag.radius_scale, c->lag.cell_size_in, nullptr, mm, &c->rep));
+    c->rep_valid = true;
+    return SPH_OK;
+}
+
 extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids, double radius_scale,
                                double cell_size_in, const double *bounds)
 {
@@ -844,91 +1255,95 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
             return SPH_ERR_ARG;
         }
     }
-    double mm[8];
-    if (bounds && c->h_known[1] >= 0.0) {
-        // the grid is given and the h range known (sph_nnps_set_h_range): no reduction, no round trip
+    if (!c->pin_async) {
+        HIP_TRY(hipHostMalloc((void **)&c->pin_async, 64 * sizeof(double), hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&c->lag_ev, hipEventDisableTiming));
+    }
+    BinArrays ba;
+    size_t n_cat = 0;
+    uint32_t nblocks = 0;
+    SPH_TRY(bin_arrays(c, narrays, ids, &ba, &n_cat, &nblocks));
+
+    // What is known without looking (DevArray::h_dirty / m_dirty).  h: the range the caller gave (sph_nnps_set_h_range), or
+    // the union of the arrays' clean ranges; m: only looked at once an evaluation could have used one mass per array.
+    const bool h_given = c->h_known[1] >= 0.0;
+    bool h_clean = true, m_clean = true;
+    double hr[2] = {DBL_MAX, -DBL_MAX};
+    for (int a = 0; a < narrays; a++) {
+        DevArray &A = c->arr[ids[a]];
+        if (A.n == 0) continue;
+        if (A.raw_hm || A.h_dirty || !A.h_seen) h_clean = false;
+        else { hr[0] = fmin(hr[0], A.h_lo); hr[1] = fmax(hr[1], A.h_hi); }
+        if (c->want_mrange && A.prop[SPH_M] && (A.raw_hm || A.m_dirty || !A.m_seen)) m_clean = false;
+    }
+    if (h_given) { hr[0] = c->h_known[0]; hr[1] = c->h_known[1]; }
+    const bool have_h = h_given || h_clean;
+    const bool lag_match = c->lag.valid && c->lag.dim == dim && c->lag.narrays == narrays && c->lag.radius_scale == radius_scale &&
+                           c->lag.cell_size_in == cell_size_in && memcmp(c->lag.ids, ids, narrays * sizeof(int)) == 0 &&
+                           memcmp(c->lag.extend, c->extend, sizeof c->extend) == 0;
+    // the three ways through: no look at all (bounds given), bounds of the previous update (no round trip), a look now
+    const bool no_look = bounds && have_h && m_clean;
+    const bool lagged = !no_look && !bounds && c->async_update && have_h && m_clean && lag_match && n_cat > 0;
+
+    double mm[8] = {DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX};
+    int mm_async = 0; // what k_bin_keys reduces next to computing the keys
+    if (no_look) {
         for (int k = 0; k < 3; k++) { mm[k] = bounds[k]; mm[4 + k] = bounds[3 + k]; }
-        mm[3] = c->h_known[0]; mm[7] = c->h_known[1];
-        for (int a = 0; a < narrays; a++) {
-            DevArray &A = c->arr[ids[a]];
-            for (int p : {SPH_X, SPH_Y, SPH_Z, SPH_H})
-                if (A.n && !A.prop[p]) { sph_set_error("nnps: array %d has no device copy of x/y/z/h", ids[a]); return SPH_ERR_MISSING_PROP; }
-            A.m_known = false; // nobody looked at the masses (ghosts may have been appended since the last look)
-        }
+        c->lag.valid = false;
+    } else if (lagged) {
+        SPH_TRY(lag_wait(c));
+        memcpy(mm, c->pin_async, sizeof mm);
+        mm_async = MM_XYZ;
+        c->n_async_updates++;
+        c->timers[T_N_ASYNC].count++;
     } else {
-        SPH_TRY(nnps_minmax(c, narrays, ids, mm));
-        if (c->h_known[1] >= 0.0) { mm[3] = c->h_known[0]; mm[7] = c->h_known[1]; }
+        const int look = (bounds ? 0 : MM_XYZ) | (have_h ? 0 : MM_H) | (m_clean ? 0 : MM_M);
+        SPH_TRY(nnps_minmax(c, narrays, ids, mm, look));
+        if (!(look & MM_H)) { mm[3] = hr[0]; mm[7] = hr[1]; }
+        else if (h_given) { /* never: have_h */ }
+        if (bounds) for (int k = 0; k < 3; k++) { mm[k] = bounds[k]; mm[4 + k] = bounds[3 + k]; }
+        if (!h_given && (look & MM_H)) {
+            hr[0] = DBL_MAX; hr[1] = -DBL_MAX;
+            for (int a = 0; a < narrays; a++) {
+                DevArray &A = c->arr[ids[a]];
+                if (A.n == 0) continue;
+                hr[0] = fmin(hr[0], c->pinned[10 + 4 * a]); hr[1] = fmax(hr[1], c->pinned[11 + 4 * a]);
+            }
+        }
+        // these bounds are what the next update may bin on
+        memcpy(c->pin_async, mm, sizeof mm);
+        c->pin_async[MM_OUT_BKMAX] = c->pinned[MM_OUT_BKMAX];
+        c->sort_bkmax = c->pinned[MM_OUT_BKMAX];
+        c->lag.valid = !bounds;
+        c->lag.pending = false;
     }
+    mm[3] = hr[0]; mm[7] = hr[1];
+    // masses: an update that did not look keeps what the last look found while nothing wrote m (m_dirty)
+    for (int a = 0; a < narrays; a++) {
+        DevArray &A = c->arr[ids[a]];
+        if (!c->want_mrange || !A.prop[SPH_M] || A.n == 0) { A.m_known = false; continue; }
+        if (!A.raw_hm && !A.m_dirty && A.m_seen) { A.m_known = A.m_lo == A.m_hi && !A.m_mixed_ghosts; A.m_value = A.m_lo; }
+    }
+    c->lag.dim = dim; c->lag.narrays = narrays; c->lag.radius_scale = radius_scale; c->lag.cell_size_in = cell_size_in;
+    memcpy(c->lag.ids, ids, narrays * sizeof(int));
+    memcpy(c->lag.extend, c->extend, sizeof c->extend);
+    c->lag.hr[0] = hr[0]; c->lag.hr[1] = hr[1];
 
-    // DomainManager._compute_cell_size_for_binning (nnps_base.pyx:942-978)
-    double hmax = -1.0, hmin = DBL_MAX;
-    if (mm[7] > hmax) hmax = mm[7];
-    if (mm[3] < hmin) hmin = mm[3];
-    double cell_size = radius_scale * hmax;
-    c->hmin = radius_scale * hmin;
-    if (cell_size < 1e-6) cell_size = 1.0;
-    if (cell_size_in > 0) cell_size = cell_size_in;
-    c->uniform_h = (hmin == hmax);
-    c->h_uniform = hmax;
-
-    // NNPS._compute_bounds (nnps_base.pyx:1520-1575)
-    double xmax = fmax(mm[4], -1e100), ymax = fmax(mm[5], -1e100), zmax = fmax(mm[6], -1e100);
-    double xmin = fmin(mm[0], 1e100), ymin = fmin(mm[1], 1e100), zmin = fmin(mm[2], 1e100);
-    // ghost split: room for the ghosts that arrive after this update (sph_nnps_set_extend)
-    xmin -= c->extend[0]; xmax += c->extend[0];
-    ymin -= c->extend[1]; ymax += c->extend[1];
-    zmin -= c->extend[2]; zmax += c->extend[2];
-    double lx = xmax - xmin, ly = ymax - ymin, lz = zmax - zmin;
-    xmin -= lx * 0.01; ymin -= ly * 0.01; zmin -= lz * 0.01;
-    xmax += lx * 0.01; ymax += ly * 0.01; zmax += lz * 0.01;
-    const double eps = 1e-12;
-    if (fabs(xmax - xmin) < eps && fabs(ymax - ymin) < eps && fabs(zmax - zmin) < eps) {
-        xmin -= 0.5; xmax += 0.5;
-        ymin -= 0.5; ymax += 0.5;
-        zmin -= 0.5; zmax += 0.5;
-    }
-    if (bounds) {
-        xmin = bounds[0]; ymin = bounds[1]; zmin = bounds[2];
-        xmax = bounds[3]; ymax = bounds[4]; zmax = bounds[5];
-    }
-
-    // LinkedListNNPS._get_number_of_cells (linked_list_nnps.pyx:293-326)
-    double cell_size1 = 1. / cell_size;
-    int ncx = (int)ceil(cell_size1 * (xmax - xmin));
-    int ncy = (int)ceil(cell_size1 * (ymax - ymin));
-    int ncz = (int)ceil(cell_size1 * (zmax - zmin));
-    if (ncx < 0 || ncy < 0 || ncz < 0) {
-        sph_set_error("LinkedListNNPS: Number of cells is negative (%d, %d, %d).", ncx, ncy, ncz);
-        return SPH_ERR_CELLS;
-    }
-    ncx = ncx == 0 ? 1 : ncx;
-    ncy = ncy == 0 ? 1 : ncy;
-    ncz = ncz == 0 ? 1 : ncz;
-    long n_cells = ncx;
-    if (dim == 2) n_cells = (long)ncx * ncy;
-    if (dim == 3) n_cells = (long)ncx * ncy * ncz;
-    // _count_occupied_cells (:328-343)
-    if (n_cells < 0 || n_cells > (1L << 28)) {
-        sph_set_error("ERROR: LinkedListNNPS requires too many cells (%ld).", n_cells);
-        return SPH_ERR_CELLS;
-    }
-    // The reference indexes head[] with the full 3-D flattened id even when
-    // dim < 3; particles of a dim<3 problem lie in one z (and y) plane so the
-    // id stays < n_cells.  Keys here use the same flattening; the table is
-    // sized for the full product so that a stray plane cannot overflow it.
-    long n_cells_alloc = (long)ncx * ncy * ncz;
-    if (n_cells_alloc > (1L << 28)) {
-        sph_set_error("ERROR: LinkedListNNPS requires too many cells (%ld).", n_cells_alloc);
-        return SPH_ERR_CELLS;
-    }
+    GridHost G;
+    SPH_TRY(grid_from_minmax(c, dim, radius_scale, cell_size_in, bounds, mm, &G));
+    c->rep_valid = !lagged;
+    if (!lagged) c->rep = G;
+    c->hmin = G.hmin;
+    c->uniform_h = G.uniform_h;
+    c->h_uniform = G.h_uniform;
+    const double cell_size = G.cell_size;
+    const long n_cells_alloc = G.n_cells_alloc;
 
     c->dim = dim;
     c->narrays = narrays;
     c->radius_scale = radius_scale;
     c->cell_size = cell_size;
-    c->xmin[0] = xmin; c->xmin[1] = ymin; c->xmin[2] = zmin;
-    c->xmax[0] = xmax; c->xmax[1] = ymax; c->xmax[2] = zmax;
-    c->nc[0] = ncx; c->nc[1] = ncy; c->nc[2] = ncz;
+    for (int k = 0; k < 3; k++) { c->xmin[k] = G.xmin[k]; c->xmax[k] = G.xmax[k]; c->nc[k] = G.nc[k]; }
     c->n_cells = n_cells_alloc;
     for (auto &A : c->arr) A.nnps_slot = -1;
 
@@ -936,59 +1351,20 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
     for (int k = 0; k < 3; k++) { g.xmin[k] = c->xmin[k]; g.nc[k] = c->nc[k]; }
     g.cell_size = cell_size;
     const size_t n_fine = (size_t)n_cells_alloc * SPH_NSUB;
-    int end_bit = bits_for((long)n_fine);
 
-    // Several arrays (a dam break has three): ONE radix sort of all their keys -- rocPRIM sorts fewer than 1 Mi keys
-    // with a merge sort of ~25 launch pairs per array, which is what three separate sorts cost.
-    //  * merged-first (option merge_arrays, default): the keys carry NO array tag.  The sort is stable and the arrays are
-    //    concatenated in slot order, so equal fine keys keep slot order: the sorted sequence IS the merged order of all
-    //    arrays (sph_ctx::merged) the multi-array pair kernel runs on; the sorted value (position in the concatenation)
-    //    gives slot and original index.  Per-array tables are derived from it only when something asks for them
-    //    (nnps_need_tables: per-destination pair paths, neighbour-list queries, reorder) -- a steady-state dam-break
-    //    step builds ONE fine_start table instead of four, with two sort bits less (a radix pass at 4 M particles).
-    //  * otherwise: the array's slot in the bits above the cell key, one segment of the sorted sequence per array.
-    size_t n_cat = 0, cat_off[SPH_MAX_ARRAYS + 1] = {};
-    int tag_bits = 0, n_nonempty = 0;
-    for (int a = 0; a < narrays; a++) { cat_off[a] = n_cat; n_cat += c->arr[ids[a]].n; n_nonempty += c->arr[ids[a]].n > 0; }
-    cat_off[narrays] = n_cat;
-    while ((1 << tag_bits) < narrays) tag_bits++;
-    const bool cat = n_nonempty > 1 && end_bit + tag_bits <= 32 && n_cat < (1ull << 31);
-    const bool merged_first = cat && c->merge_arrays;
-    const size_t n_half = (n_cat + 63) & ~(size_t)63; // keys | values halves of the scratch buffers, 256-B aligned
+    // Several arrays (a dam break has three): ONE sort of all their keys.
+    //  * merged-first (option merge_arrays, default): the arrays are concatenated in slot order and the sort is stable, so
+    //    equal fine keys keep slot order: the sorted sequence IS the merged order of all arrays (sph_ctx::merged) the
+    //    multi-array pair kernel runs on; the sorted value (position in the concatenation) gives slot and original index.
+    //    Per-array tables are derived from it only when something asks for them (nnps_need_tables: per-destination pair
+    //    paths, neighbour-list queries, reorder) -- a steady-state dam-break step builds ONE fine_start table.
+    //  * otherwise (option merge_arrays 0, or one array): every array sorted into its own tables.
+    int n_nonempty = 0;
+    for (int a = 0; a < narrays; a++) n_nonempty += c->arr[ids[a]].n > 0;
+    const bool merged_first = n_nonempty > 1 && c->merge_arrays;
     if (!c->gapq.ptr) { // first use: the queue starts empty; afterwards k_coarse_start leaves it empty
         SPH_TRY(c->gapq.reserve((4 + 3 * GAP_QUEUE) * 4));
         HIP_TRY(hipMemsetAsync(c->gapq.ptr, 0, 16, c->stream));
-    }
-    if (cat) {
-        SPH_TRY(c->tmp_u32a.reserve((n_half + 64) * 4 * 2));
-        SPH_TRY(c->tmp_u32b.reserve((n_half + 64) * 4 * 2));
-        uint32_t *ck = c->tmp_u32a.as<uint32_t>(), *ci = ck + n_half, *cks = c->tmp_u32b.as<uint32_t>(), *cp = cks + n_half;
-        if (merged_first) { // one launch for all arrays
-            KeysMulti km;
-            memset(&km, 0, sizeof km);
-            km.narrays = narrays;
-            uint32_t nbk = 0;
-            for (int a = 0; a < narrays; a++) {
-                DevArray &A = c->arr[ids[a]];
-                km.x[a] = A.prop[SPH_X]; km.y[a] = A.prop[SPH_Y]; km.z[a] = A.prop[SPH_Z];
-                km.n[a] = (uint32_t)A.n; km.off[a] = (uint32_t)cat_off[a]; km.first[a] = nbk;
-                nbk += div_up(A.n, 256);
-            }
-            for (int a = narrays; a <= SPH_MAX_ARRAYS; a++) km.first[a] = nbk;
-            hipLaunchKernelGGL(k_cell_keys_multi, dim3(nbk), dim3(256), 0, c->stream, km, g, ck, ci);
-        } else
-        for (int a = 0; a < narrays; a++) {
-            DevArray &A = c->arr[ids[a]];
-            if (A.n == 0) continue;
-            hipLaunchKernelGGL(k_cell_keys, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, A.prop[SPH_X], A.prop[SPH_Y],
-                               A.prop[SPH_Z], A.n, g, ck + cat_off[a], ci + cat_off[a],
-                               end_bit < 32 ? (uint32_t)a << end_bit : 0u, 0u);
-        }
-        const int sort_bits = merged_first ? end_bit : end_bit + tag_bits;
-        size_t tmp_bytes = 0;
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ck, cks, ci, cp, (int)n_cat, 0, sort_bits, c->stream));
-        SPH_TRY(c->cub_tmp.reserve(tmp_bytes));
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.ptr, tmp_bytes, ck, cks, ci, cp, (int)n_cat, 0, sort_bits, c->stream));
     }
     c->merged_valid = false;
     c->tables_valid = true;
@@ -1000,59 +1376,64 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
         c->arr[ids[a]].perm_n = c->arr[ids[a]].n;
         c->arr[ids[a]].n_binned = c->arr[ids[a]].n;
         c->arr[ids[a]].g_n = 0;
-    }
-    if (merged_first) {
-        DevArray &M = c->merged;
-        M.n = M.n_real = n_cat;
-        SPH_TRY(M.fkeys_sorted.reserve((n_cat + 1) * 4));
-        SPH_TRY(M.keys_sorted.reserve((n_cat + 1) * 4));
-        SPH_TRY(M.perm.reserve((n_cat + 1) * 4));
-        SPH_TRY(M.slot8.reserve(n_cat + 64));
-        SPH_TRY(M.fine_start.reserve((n_fine + 1) * 4));
-        SPH_TRY(M.cell_start.reserve(((size_t)n_cells_alloc + 1) * 4));
-        CatOff co;
-        co.narrays = narrays;
-        for (int a = 0; a <= SPH_MAX_ARRAYS; a++) co.off[a] = (uint32_t)cat_off[a < narrays ? a : narrays];
-        const uint32_t *cks = c->tmp_u32b.as<uint32_t>();
-        hipLaunchKernelGGL(k_merged_split, dim3(div_up(n_cat, 256)), dim3(256), 0, c->stream, cks, cks + n_half, n_cat, co,
-                           M.fkeys_sorted.as<uint32_t>(), M.keys_sorted.as<uint32_t>(), M.perm.as<uint32_t>(), M.slot8.as<uint8_t>());
-        hipLaunchKernelGGL(k_cell_start, dim3(div_up(n_cat + 1, 256)), dim3(256), 0, c->stream, M.fkeys_sorted.as<uint32_t>(),
-                           n_cat, (uint32_t)n_fine, M.fine_start.as<uint32_t>(), c->gapq.as<uint32_t>(), (uint32_t *)nullptr);
-        hipLaunchKernelGGL(k_fill_gaps, dim3(512), dim3(256), 0, c->stream, c->gapq.as<uint32_t>(), M.fine_start.as<uint32_t>());
-        hipLaunchKernelGGL(k_coarse_start, dim3(div_up((size_t)n_cells_alloc + 1, 256)), dim3(256), 0, c->stream,
-                           M.fine_start.as<uint32_t>(), (uint32_t)n_cells_alloc, M.cell_start.as<uint32_t>(), c->gapq.as<uint32_t>());
-        SPH_TRY(nnps_tile_order(c, M, n_cat));
-        c->merged_valid = true;
-        c->tables_valid = false;
-        if (!c->lazy_tables) SPH_TRY(nnps_need_tables(c));
-    } else {
-    for (int a = 0; a < narrays; a++) {
         DevArray &A = c->arr[ids[a]];
-        size_t n = A.n;
-        SPH_TRY(A.keys.reserve((n + 1) * 4));
-        SPH_TRY(A.idx.reserve((n + 1) * 4));
-        SPH_TRY(nnps_reserve_tables(c, A));
-        if (n == 0) { nnps_empty_tables(c, A); continue; }
-        if (cat) {
-            const uint32_t *cks = c->tmp_u32b.as<uint32_t>();
-            hipLaunchKernelGGL(k_split_segment, dim3(div_up(n, 256)), dim3(256), 0, c->stream, cks + cat_off[a],
-                               cks + n_half + cat_off[a], n, end_bit < 32 ? (1u << end_bit) - 1u : 0xffffffffu,
-                               A.fkeys_sorted.as<uint32_t>(), A.keys_sorted.as<uint32_t>(), A.perm.as<uint32_t>());
-        } else {
-        hipLaunchKernelGGL(k_cell_keys, dim3(div_up(n, 256)), dim3(256), 0, c->stream, A.prop[SPH_X], A.prop[SPH_Y],
-                           A.prop[SPH_Z], n, g, A.keys.as<uint32_t>(), A.idx.as<uint32_t>(), 0u, 0u);
-        size_t tmp_bytes = 0;
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, A.keys.as<uint32_t>(), A.fkeys_sorted.as<uint32_t>(),
-                                                   A.idx.as<uint32_t>(), A.perm.as<uint32_t>(), (int)n, 0, end_bit,
-                                                   c->stream));
-        SPH_TRY(c->cub_tmp.reserve(tmp_bytes));
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.ptr, tmp_bytes, A.keys.as<uint32_t>(),
-                                                   A.fkeys_sorted.as<uint32_t>(), A.idx.as<uint32_t>(),
-                                                   A.perm.as<uint32_t>(), (int)n, 0, end_bit, c->stream));
-        }
-        // the single-array path gets its cell ids (keys_sorted) from k_cell_start; the concatenated one has them already
-        SPH_TRY(nnps_finish_tables(c, A, !cat));
+        A.m_known_binned = A.m_known; A.hm_writes_binned = A.hm_writes;
+        A.h_clean_binned = !A.raw_hm && !A.h_dirty && A.h_seen; A.m_clean_binned = !A.raw_hm && !A.m_dirty && A.m_seen;
     }
+    SPH_TRY(c->tmp_u32a.reserve((n_cat + 64) * 8));
+    SPH_TRY(c->tmp_u32b.reserve((n_cat + 64) * 8));
+    const int lbits = sort_choose_lbits(c, n_cat, n_fine);
+    const uint32_t nbuckets = (uint32_t)(n_fine >> lbits) + 1u;
+    bool reduced = false; // mm_async has ridden on a launch
+    if (merged_first || n_nonempty == 1) {
+        DevArray *T = &c->merged;
+        if (!merged_first)
+            for (int a = 0; a < narrays; a++) if (c->arr[ids[a]].n) T = &c->arr[ids[a]];
+        if (merged_first) { T->n = T->n_real = n_cat; SPH_TRY(T->slot8.reserve(n_cat + 64)); }
+        SPH_TRY(nnps_reserve_tables(c, *T, n_cat));
+        SPH_TRY(launch_bin_keys(c, ba, nblocks, g, mm_async, c->tmp_u32a.as<uint32_t>(), nbuckets, lbits));
+        reduced = true;
+        SortDest d;
+        d.T = T; d.merged = merged_first;
+        d.co.narrays = narrays;
+        for (int a = 0; a <= SPH_MAX_ARRAYS; a++) d.co.off[a] = a < narrays ? ba.off[a] : (uint32_t)n_cat;
+        SPH_TRY(sort_finish(c, n_cat, n_fine, n_cells_alloc, lbits, nbuckets, d));
+        SPH_TRY(nnps_tile_order(c, *T, n_cat));
+        if (merged_first) {
+            c->merged_valid = true;
+            c->tables_valid = false;
+            if (!c->lazy_tables) SPH_TRY(nnps_need_tables(c));
+        }
+        for (int a = 0; a < narrays; a++) { // the empty arrays next to the one that was sorted
+            DevArray &A = c->arr[ids[a]];
+            if (A.n || merged_first) continue;
+            SPH_TRY(nnps_reserve_tables(c, A, 0));
+            nnps_empty_tables(c, A);
+        }
+    } else {
+        for (int a = 0; a < narrays; a++) {
+            DevArray &A = c->arr[ids[a]];
+            SPH_TRY(nnps_reserve_tables(c, A, A.n));
+            if (A.n == 0) { nnps_empty_tables(c, A); continue; }
+            BinArrays b1;
+            size_t n1 = 0;
+            uint32_t nb1 = 0;
+            SPH_TRY(bin_arrays(c, 1, &ids[a], &b1, &n1, &nb1));
+            SPH_TRY(launch_bin_keys(c, b1, nb1, g, 0, c->tmp_u32a.as<uint32_t>(), nbuckets, lbits));
+            SortDest d;
+            d.T = &A; d.merged = false;
+            d.co.narrays = 1;
+            for (int k = 0; k <= SPH_MAX_ARRAYS; k++) d.co.off[k] = k ? (uint32_t)n1 : 0u;
+            SPH_TRY(sort_finish(c, n1, n_fine, n_cells_alloc, lbits, nbuckets, d));
+            SPH_TRY(nnps_tile_order(c, A, n1));
+        }
+    }
+    if (lagged) {
+        if (!reduced && nblocks) SPH_TRY(launch_bin_keys(c, ba, nblocks, g, mm_async, nullptr, 0, lbits));
+        // this update's bounds: on their way, nobody waits
+        HIP_TRY(hipMemcpyAsync(c->pin_async, c->red_out.ptr, MM_OUT_N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(c->lag_ev, c->stream));
+        c->lag.pending = true;
     }
     HIP_TRY(hipGetLastError());
     c->nnps_valid = true;
@@ -1124,19 +1505,46 @@ extern "C" int sph_nnps_update_ghosts(sph_ctx *c, int axis, double lo, double hi
         fa.cell_start = A.g_cell_start.as<uint32_t>();
         fa.perm_base = (uint32_t)nb; // original index of ghost k is n_binned + k
         SPH_TRY(nnps_bin_sort_finish(c, A.g_keys.as<uint32_t>(), ng, fa, T));
-        // The uniform-mass records rest on what the update saw of the REAL particles' masses; ghosts are other ranks'
-        // particles.  Look at theirs now and then (masses are constants of the motion): a ghost with another mass switches
-        // the array back to mass-carrying records for good (until its masses are pushed again).
-        if (A.m_known && A.prop[SPH_M] && --A.g_mcheck < 0) {
-            A.g_mcheck = 64;
-            SPH_TRY(c->bigq.reserve((1 + BIN_QUEUE) * 4));
-            uint32_t *flag = c->bigq.as<uint32_t>(); // (the queue counter: idle between the sorts)
-            hipLaunchKernelGGL(k_reset_u32, dim3(1), dim3(1), 0, c->stream, flag);
-            hipLaunchKernelGGL(k_mass_differs, dim3(div_up(ng, 256)), dim3(256), 0, c->stream, A.prop[SPH_M] + nb, ng, A.m_value, flag);
+    }
+    // Everything the update decided from the REAL particles -- the cell size and the uniform-h path from their h range, the
+    // one-mass-per-array records from their masses -- must hold for the ghosts too: they are other ranks' particles.
+    // Checked every time, on the device, one word per array back: a ghost with another mass switches the array to
+    // mass-carrying records (the second half of a split evaluation repacks the real particles' records then); a ghost
+    // whose h lies outside the range the grid was built for is an error (fixed_h with the global range avoids it).
+    {
+        SPH_TRY(c->bigq.reserve((1 + BIN_QUEUE) * 4));
+        uint32_t *flags = c->bigq.as<uint32_t>(); // (the bin-sort queue: idle between the sorts)
+        hipLaunchKernelGGL(k_fill_u32, dim3(1), dim3(256), 0, c->stream, flags, (size_t)SPH_MAX_ARRAYS, 0u);
+        bool any = false;
+        for (int a = 0; a < c->narrays; a++) {
+            DevArray &A = c->arr[c->ids[a]];
+            if (A.g_n == 0) continue;
+            any = true;
+            const size_t nb = A.n_binned;
+            hipLaunchKernelGGL(k_ghost_hm_check, dim3(div_up(A.g_n, 256)), dim3(256), 0, c->stream, A.prop[SPH_H] + nb,
+                               A.m_known_binned && A.prop[SPH_M] ? A.prop[SPH_M] + nb : (const double *)nullptr, A.g_n,
+                               c->lag.hr[0], c->lag.hr[1], A.m_value, flags + a);
+        }
+        if (any) {
             uint32_t *pin = (uint32_t *)c->pinned;
-            HIP_TRY(hipMemcpyAsync(pin, flag, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(pin, flags, SPH_MAX_ARRAYS * 4, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            if (pin[0]) { A.m_known = false; A.m_mixed_ghosts = true; }
+            for (int a = 0; a < c->narrays; a++) {
+                DevArray &A = c->arr[c->ids[a]];
+                if (A.g_n == 0) continue;
+                if (pin[a] & 2u) {
+                    sph_set_error("sph_nnps_update_ghosts: a ghost of array %d has a smoothing length outside [%g, %g], the range the "
+                                  "grid of this update was built for (fixed_h with the global h range covers other ranks' particles)",
+                                  c->ids[a], c->lag.hr[0], c->lag.hr[1]);
+                    return SPH_ERR_STATE;
+                }
+                const bool untouched = A.hm_writes == A.hm_writes_binned; // nothing but the append since the update
+                if (A.m_known_binned) {
+                    if (pin[a] & 1u) { A.m_known = false; A.m_mixed_ghosts = true; }
+                    else { A.m_known = true; if (untouched && A.m_clean_binned) A.m_dirty = false; }
+                }
+                if (untouched && A.h_clean_binned) A.h_dirty = false; // inside the range: the range of the union is the same
+            }
         }
     }
     c->face_axis = axis; c->face_lo = lo; c->face_hi = hi;
@@ -1149,15 +1557,16 @@ extern "C" int sph_nnps_update_ghosts(sph_ctx *c, int axis, double lo, double hi
 
 extern "C" int sph_nnps_info(sph_ctx *c, double *d8, long *i4)
 {
-    if (!c->nnps_valid) { sph_set_error("sph_nnps_info: call sph_nnps_update first"); return SPH_ERR_STATE; }
-    d8[0] = c->cell_size; d8[1] = c->hmin;
-    for (int k = 0; k < 3; k++) { d8[2 + k] = c->xmin[k]; d8[5 + k] = c->xmax[k]; }
-    i4[0] = c->nc[0]; i4[1] = c->nc[1]; i4[2] = c->nc[2];
+    if (c->nnps_epoch == 0) { sph_set_error("sph_nnps_info: call sph_nnps_update first"); return SPH_ERR_STATE; }
+    // the reference's values for the particles of the last update -- of an update without a round trip they are computed
+    // now, from the bounds it sent on their way (the grid it BINNED on is the one of the update before)
+    SPH_TRY(nnps_reported_grid(c));
+    const GridHost &G = c->rep;
+    d8[0] = G.cell_size; d8[1] = G.hmin;
+    for (int k = 0; k < 3; k++) { d8[2 + k] = G.xmin[k]; d8[5 + k] = G.xmax[k]; }
+    i4[0] = G.nc[0]; i4[1] = G.nc[1]; i4[2] = G.nc[2];
     // n_cells as the reference reports it (dim-aware, linked_list_nnps.pyx:321-325)
-    long ncells = c->nc[0];
-    if (c->dim == 2) ncells = (long)c->nc[0] * c->nc[1];
-    if (c->dim == 3) ncells = (long)c->nc[0] * c->nc[1] * c->nc[2];
-    i4[3] = ncells;
+    i4[3] = G.n_cells;
     return SPH_OK;
 }
 
@@ -1189,9 +1598,10 @@ __global__ __launch_bounds__(256) void k_csr(const double *__restrict__ dx, cons
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nd) return;
     double x = dx[i], y = dy[i], z = dz[i];
-    int cx = (int)floor((x - g.xmin[0]) / g.cell_size);
-    int cy = (int)floor((y - g.xmin[1]) / g.cell_size);
-    int cz = (int)floor((z - g.xmin[2]) / g.cell_size);
+    // (clamped like the keys: a particle outside the grid lives in its outermost cells)
+    int cx = min(max((int)floor((x - g.xmin[0]) / g.cell_size), 0), g.nc[0] - 1);
+    int cy = min(max((int)floor((y - g.xmin[1]) / g.cell_size), 0), g.nc[1] - 1);
+    int cz = min(max((int)floor((z - g.xmin[2]) / g.cell_size), 0), g.nc[2] - 1);
     double hi2 = radius_scale * dh[i];
     hi2 *= hi2;
     uint32_t count = 0;

@@ -655,9 +655,7 @@ class HipDeviceHelper(object):
                 pid = prop_id(name)
                 if pid < 0:
                     continue
-                dptr = _P()
-                _check(self.lib.sph_array_device_ptr(self.ctx._h, self.array_id, pid,
-                                                     C.byref(dptr)))
+                _check(self.lib.sph_array_ensure_prop(self.ctx._h, self.array_id, pid))
                 col = np.ascontiguousarray(arr[lo * st + k:hi * st:st] if st > 1 else arr[lo:hi])
                 _check(self.lib.sph_array_push(self.ctx._h, self.array_id, pid,
                                                col.ctypes.data_as(_PD), lo, hi - lo))

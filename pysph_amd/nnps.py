@@ -48,11 +48,9 @@ class HipNNPS(object):
         self.lib = self.ctx.lib
         self.helpers = [dev.attach(pa, self.ctx) for pa in self.particles]
         self.src_index = self.dst_index = 0
-        self.cell_size = self.hmin = 0.0
-        self.xmin = np.zeros(3)
-        self.xmax = np.zeros(3)
-        self.ncells_per_dim = np.ones(3, dtype=np.int32)
-        self.n_cells = 0
+        self._grid = None        # (cell_size, hmin, xmin, xmax, ncells_per_dim, n_cells) of the last update, read on demand
+        self._extend = (0.0, 0.0, 0.0)   # state of THIS object, handed to the library by every update()
+        self._faces = (-1, -float('inf'), float('inf'))
         self.bounds = None       # optional fixed global bounds (multi-GPU)
         self._h_fixed = False
         self._h_range = None     # (hmin, hmax) of THIS neighbour search once fixed_h has seen them
@@ -99,16 +97,19 @@ class HipNNPS(object):
         b = None
         if self.bounds is not None:
             b = (C.c_double * 6)(*self.bounds)
+        # ... and so are the ghost-split settings (the grid's extra room, the slab faces)
+        dev._check(self.lib.sph_nnps_set_extend(self.ctx._h, *self._extend))
+        dev._check(self.lib.sph_nnps_set_ghost_faces(self.ctx._h, *self._faces))
         rc = self.lib.sph_nnps_update(self.ctx._h, self.dim, self.narrays, ids,
                                       self.radius_scale,
                                       self.cell_size_override, b)
         if rc == -3:  # SPH_ERR_CELLS -> the reference raises RuntimeError
             raise RuntimeError(self.lib.sph_last_error().decode())
         dev._check(rc)
-        d8 = (C.c_double * 8)()
-        i4 = (C.c_long * 4)()
-        dev._check(self.lib.sph_nnps_info(self.ctx._h, d8, i4))
-        self.cell_size, self.hmin = d8[0], d8[1]
+        # cell_size, xmin, xmax, n_cells ... are read from the library when
+        # somebody looks at them (properties below): a steady-state update()
+        # makes no device->host round trip
+        self._grid = None
         if self.fixed_h and not self._h_fixed:
             # fixed_h (linked_list_nnps.pyx:54): the smoothing lengths never
             # change, so the range found by this first update stays: later updates
@@ -116,30 +117,50 @@ class HipNNPS(object):
             # its device->host round trip)
             mm = (C.c_double * 8)()
             dev._check(self.lib.sph_nnps_minmax(self.ctx._h, self.narrays, ids, mm))
-            if mm[7] >= mm[3]:
-                lo, hi = mm[3], mm[7]
-                if self.h_range_reduce is not None:
-                    # slab-decomposed runs: ghosts and migrants carry the other
-                    # ranks' smoothing lengths, so the range must be the global one
-                    lo, hi = self.h_range_reduce(lo, hi)
+            lo, hi = mm[3], mm[7]          # (+max, -max) of an empty rank
+            if self.h_range_reduce is not None:
+                # slab-decomposed runs: ghosts and migrants carry the other
+                # ranks' smoothing lengths, so the range must be the global
+                # one; a collective, so every rank takes part on its first
+                # update -- an empty rank contributes the neutral element
+                lo, hi = self.h_range_reduce(lo, hi)
+            if hi >= lo:
                 self._h_range = (float(lo), float(hi))
                 self._h_fixed = True
-        self.xmin = np.array(d8[2:5])
-        self.xmax = np.array(d8[5:8])
-        self.ncells_per_dim = np.array(i4[0:3], dtype=np.int32)
-        self.n_cells = int(i4[3])
+
+    def _read_grid(self):
+        if self._grid is None:
+            d8 = (C.c_double * 8)()
+            i4 = (C.c_long * 4)()
+            rc = self.lib.sph_nnps_info(self.ctx._h, d8, i4)
+            if rc == -3:   # an update without a round trip reports a bad cell count when its bounds are looked at
+                raise RuntimeError(self.lib.sph_last_error().decode())
+            dev._check(rc)
+            self._grid = (d8[0], d8[1], np.array(d8[2:5]), np.array(d8[5:8]),
+                          np.array(i4[0:3], dtype=np.int32), int(i4[3]))
+        return self._grid
+
+    # attributes of nnps_base.pxd:279-371, the reference's values for the particles of the last update()
+    cell_size = property(lambda self: self._read_grid()[0])
+    hmin = property(lambda self: self._read_grid()[1])
+    xmin = property(lambda self: self._read_grid()[2])
+    xmax = property(lambda self: self._read_grid()[3])
+    ncells_per_dim = property(lambda self: self._read_grid()[4])
+    n_cells = property(lambda self: self._read_grid()[5])
 
     def set_extend(self, ex=0.0, ey=0.0, ez=0.0):
         """widen the computed bounds on both sides of every axis (before the
         reference's 1 % padding): the grid of an `update()` that runs while the
-        ghosts of a slab exchange are still in flight must hold them"""
-        dev._check(self.lib.sph_nnps_set_extend(self.ctx._h, float(ex), float(ey), float(ez)))
+        ghosts of a slab exchange are still in flight must hold them.  State of
+        this object: every `update()` hands it to the library."""
+        self._extend = (float(ex), float(ey), float(ez))
 
     def set_ghost_faces(self, axis=-1, lo=-float('inf'), hi=float('inf')):
         """name the slab faces outside which this rank's ghosts lie BEFORE `update()`:
         the first half of a split evaluation then leaves the wavefronts that can
-        reach a ghost to the second half (axis -1: no faces)"""
-        dev._check(self.lib.sph_nnps_set_ghost_faces(self.ctx._h, int(axis), float(lo), float(hi)))
+        reach a ghost to the second half (axis -1: no faces).  State of this
+        object, as `set_extend`."""
+        self._faces = (int(axis), float(lo), float(hi))
 
     def update_ghosts(self, axis=0, lo=-float('inf'), hi=float('inf')):
         """bin the particles that arrived behind the ones the last `update()` saw
@@ -147,6 +168,9 @@ class HipNNPS(object):
         second half of a neighbour update that overlaps the ghost exchange.
         `lo`, `hi`: the slab faces along `axis` (every ghost lies outside [lo, hi))."""
         self._csr_key = None
+        if self._faces[0] >= 0 and (int(axis), float(lo), float(hi)) != self._faces:
+            raise ValueError('update_ghosts: the slab faces %r differ from those named before update() %r'
+                             % ((axis, lo, hi), self._faces))
         dev._check(self.lib.sph_nnps_update_ghosts(self.ctx._h, int(axis), float(lo), float(hi)))
 
     def get_csr(self, src_index, dst_index):

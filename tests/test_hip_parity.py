@@ -1915,6 +1915,30 @@ def test_randomised_device_resident_second_evaluation_vs_oracle(oracle, seed):
             assert e < TOL, (seed, dim, sizes, kname, varh, mass_mode, took, pa.name, prop, e)
 
 
+def test_ghost_outside_the_h_range_of_the_update_is_rejected():
+    """the cell size and the uniform-h path of an update rest on the h range of the particles it saw: a ghost
+    binned afterwards with a larger h would lose neighbours silently -- it is an error (advisor, round 4)"""
+    from pysph_amd import device as dev
+    from pysph_amd.nnps import HipNNPS
+    from pysph_amd.particle_array import get_particle_array_wcsph
+    rng = np.random.default_rng(5)
+    n, nreal = 600, 500
+    c = rng.uniform(0, 1, (n, 3))
+    c[nreal:, 0] += 1.0
+    h = 0.1 * np.ones(n)
+    h[-1] = 0.13
+    pa = get_particle_array_wcsph(name='fluid', x=c[:, 0], y=c[:, 1], z=c[:, 2], h=h, m=np.ones(n), rho=np.ones(n))
+    pa.set_num_real_particles(nreal)
+    ctx = dev.HipContext(0)
+    dev.attach(pa, ctx).push()
+    dev._check(ctx.lib.sph_array_resize(ctx._h, pa.gpu.array_id, nreal, nreal))
+    nnps = HipNNPS(3, [pa], radius_scale=2.0, ctx=ctx, sync=False)
+    dev._check(ctx.lib.sph_array_resize(ctx._h, pa.gpu.array_id, n, nreal))
+    with pytest.raises(dev.SphError, match='smoothing length outside'):
+        nnps.update_ghosts(0, 0.0, 1.0)
+    ctx.close()
+
+
 @pytest.mark.parametrize('seed', list(range(int(os.environ.get('SPH_FUZZ_SEEDS', '12')))))
 def test_randomised_ghost_segments_vs_oracle(oracle, seed):
     """Round 4, ghost split (sph_nnps_update_ghosts): the neighbour update bins the REAL particles, the ghosts
@@ -1955,6 +1979,10 @@ def test_randomised_ghost_segments_vs_oracle(oracle, seed):
     lib, h = ctx.lib, pa.gpu
     pa.gpu.push()
     nnps.sync = False
+    if varh:
+        # ghosts are other ranks' particles: the update that bins the real ones must know the GLOBAL h range (a slab
+        # run: fixed_h + h_range_reduce) -- since round 5 sph_nnps_update_ghosts rejects a ghost outside the range
+        nnps._h_fixed, nnps._h_range = True, (float(pa.h.min()), float(pa.h.max()))
     for rep in range(2):               # the second round runs on the records that need a look at the masses
         # the step as a slab rank sees it: only the real particles are there when the neighbour update runs ...
         dev._check(lib.sph_array_resize(ctx._h, h.array_id, nreal, nreal))

@@ -1,0 +1,178 @@
+"""The hand-written particle sort of the neighbour update (round 5:
+k_bin_keys / k_bucket_scatter / k_bucket_sort, csrc/sph_nnps.hip) and the
+update without a device->host round trip (bounds of the previous update,
+DevArray::h_dirty / m_dirty).
+
+The sort must give what a STABLE sort of the fine keys gives (the order inside
+a key is ascending particle index: linked_list_nnps.pyx:235-291 visits a cell's
+particles in a fixed order, and the sums of a destination are taken in cell
+order) for every bucket shape: LDS-staged buckets, buckets beyond the LDS stage
+(sorted in global memory), bins of more than 32 particles (ranked by counting),
+more such bins than the queue holds, several arrays in one merged order.  The
+tables that fall out of it are compared with a host restatement."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from pysph_amd.particle_array import get_particle_array
+
+pytestmark = pytest.mark.gpu
+
+NSUB = 8
+
+
+def _ctx():
+    from pysph_amd import device as dev
+    return dev.HipContext(0)
+
+
+def host_fine_keys(pa, nn):
+    """csrc/sph_nnps.hip fine_key on the host (same arithmetic, fp64)"""
+    xmin, cs, nc = nn.xmin, nn.cell_size, nn.ncells_per_dim
+    ux = (np.asarray(pa.x) - xmin[0]) / cs
+    cx = np.floor(ux).astype(np.int64)
+    cy = np.floor((np.asarray(pa.y) - xmin[1]) / cs).astype(np.int64)
+    cz = np.floor((np.asarray(pa.z) - xmin[2]) / cs).astype(np.int64)
+    sub = np.floor((ux - cx) * NSUB).astype(np.int64)
+    lo, hi = cx < 0, cx > nc[0] - 1
+    cx = np.clip(cx, 0, nc[0] - 1)
+    sub = np.where(lo, 0, np.where(hi, NSUB - 1, np.clip(sub, 0, NSUB - 1)))
+    cy = np.clip(cy, 0, nc[1] - 1)
+    cz = np.clip(cz, 0, nc[2] - 1)
+    return (cx + nc[0] * (cy + nc[1] * cz)) * NSUB + sub
+
+
+def check_order(nn, arrays):
+    for i, pa in enumerate(arrays):
+        n = pa.get_number_of_particles()
+        if n == 0:
+            continue
+        keys = host_fine_keys(pa, nn)
+        want = np.argsort(keys, kind='stable')
+        got = nn.get_spatially_ordered_indices(i)
+        assert np.array_equal(got, want.astype(np.uint32)), (pa.name, n)
+
+
+def cloud(n, seed, name='a', box=1.0, h=0.05):
+    rng = np.random.default_rng(seed)
+    x, y, z = rng.random((3, n)) * box
+    return get_particle_array(name=name, x=x, y=y, z=z, h=h * np.ones(n), m=np.ones(n))
+
+
+@pytest.mark.parametrize('n,box,h', [(1, 1.0, 0.1), (63, 1.0, 0.1), (5000, 1.0, 0.05), (200000, 1.0, 0.01),
+                                     (30000, 0.2, 0.05),     # a handful of cells: one bucket far beyond the LDS stage
+                                     (300000, 4.0, 0.011)],  # many buckets, sparse keys
+                         ids=['one', 'wave-1', '5k', '200k', 'one-bucket', 'sparse'])
+def test_sorted_order_is_the_stable_order(n, box, h):
+    from pysph_amd.nnps import HipNNPS
+    pa = cloud(n, n, box=box, h=h)
+    nn = HipNNPS(3, [pa], radius_scale=2.0, ctx=_ctx())
+    check_order(nn, [pa])
+
+
+def test_dense_bins_and_coincident_particles():
+    """one bin of 3000 coincident particles (ranked by counting), 150 bins of 40
+    (more than the queue of big bins holds: the rest by insertion), on top of a cloud"""
+    from pysph_amd.nnps import HipNNPS
+    rng = np.random.default_rng(11)
+    base = cloud(20000, 1, h=0.03)
+    xs, ys, zs = [np.asarray(base.x)], [np.asarray(base.y)], [np.asarray(base.z)]
+    xs.append(np.full(3000, 0.5)); ys.append(np.full(3000, 0.5)); zs.append(np.full(3000, 0.5))
+    for _ in range(150):
+        p = rng.random(3) * 0.05 + 0.2      # 150 piles inside one or two cells
+        xs.append(np.full(40, p[0])); ys.append(np.full(40, p[1])); zs.append(np.full(40, p[2]))
+    x, y, z = np.concatenate(xs), np.concatenate(ys), np.concatenate(zs)
+    order = rng.permutation(x.size)          # the piles scattered over the index range
+    pa = get_particle_array(name='a', x=x[order], y=y[order], z=z[order], h=0.03 * np.ones(x.size))
+    for lbits in (0, 9, 11):
+        ctx = _ctx()
+        ctx.set_option('sort_lbits', lbits)
+        nn = HipNNPS(3, [pa], radius_scale=2.0, ctx=ctx)
+        check_order(nn, [pa])
+
+
+@pytest.mark.parametrize('merge', [1, 0])
+def test_several_arrays_one_empty(merge):
+    from pysph_amd.nnps import HipNNPS
+    arrays = [cloud(40000, 2, 'fluid', h=0.02), get_particle_array(name='none', x=np.zeros(0)),
+              cloud(9000, 3, 'solid', h=0.02), cloud(100, 4, 'obstacle', box=0.3, h=0.02)]
+    ctx = _ctx()
+    ctx.set_option('merge_arrays', merge)
+    nn = HipNNPS(3, arrays, radius_scale=2.0, ctx=ctx)
+    check_order(nn, arrays)
+    # ... and the neighbour lists that come out of the tables, against brute force for a few particles
+    for (s, d) in ((0, 2), (2, 0), (3, 0), (0, 0)):
+        start, nbrs = nn.get_csr(s, d)
+        src, dst = arrays[s], arrays[d]
+        for i in (0, dst.get_number_of_particles() // 2, dst.get_number_of_particles() - 1):
+            r2 = (src.x - dst.x[i]) ** 2 + (src.y - dst.y[i]) ** 2 + (src.z - dst.z[i]) ** 2
+            want = np.nonzero((r2 < (2.0 * dst.h[i]) ** 2) | (r2 < (2.0 * src.h) ** 2))[0]
+            assert np.array_equal(nbrs[start[i]:start[i + 1]], want), (s, d, i)
+
+
+def _moved(pa, seed, amp):
+    rng = np.random.default_rng(seed)
+    for f in 'xyz':
+        getattr(pa, f)[:] = getattr(pa, f) + amp * (rng.random(pa.x.size) - 0.5)
+
+
+@pytest.mark.parametrize('narr', [1, 3], ids=['one-array', 'merged'])
+def test_update_without_round_trip_reports_the_exact_grid_and_the_same_neighbours(narr):
+    """Device-resident positions move between updates; h and m are not written.
+    From the second update on no update waits for the device (`n_async`), the
+    grid it REPORTS is the reference's for the new positions (equal to a fresh
+    neighbour search's), and the neighbour lists are the same sets -- also for
+    particles that left the box of the previous update (clamped into the
+    outermost cells)."""
+    from pysph_amd import device as dev
+    from pysph_amd.nnps import HipNNPS
+    arrays = [cloud(30000, 5, 'fluid', h=0.03), cloud(5000, 6, 'solid', h=0.03),
+              cloud(50, 7, 'obstacle', box=0.2, h=0.03)][:narr]
+    ctx = _ctx()
+    ctx.timer_enable(True)
+    for a in arrays:
+        dev.attach(a, ctx).push()
+    nn = HipNNPS(3, arrays, radius_scale=2.0, ctx=ctx, sync=False)
+    for step in range(3):
+        for a in arrays:
+            _moved(a, 100 + step, 0.02 if step < 2 else 0.3)     # the last move throws particles far outside
+            a.gpu.push('x', 'y', 'z')
+        nn.update()
+        fresh_ctx = _ctx()
+        copies = [get_particle_array(name=a.name, x=a.x.copy(), y=a.y.copy(), z=a.z.copy(), h=a.h.copy(), m=a.m.copy())
+                  for a in arrays]
+        fresh = HipNNPS(3, copies, radius_scale=2.0, ctx=fresh_ctx)       # host data pushed, looked at: the exact grid
+        assert nn.cell_size == fresh.cell_size and nn.n_cells == fresh.n_cells
+        assert np.array_equal(nn.xmin, fresh.xmin) and np.array_equal(nn.xmax, fresh.xmax)
+        assert np.array_equal(nn.ncells_per_dim, fresh.ncells_per_dim)
+        for (s, d) in ((0, 0), (narr - 1, 0), (0, narr - 1)):
+            a0, a1 = nn.get_csr(s, d)
+            b0, b1 = fresh.get_csr(s, d)
+            assert np.array_equal(a0, b0) and np.array_equal(a1, b1), (step, s, d)
+        fresh_ctx.close()
+    assert ctx.timer_get('n_async')[1] == 3
+    # a write of h: the next update looks again (and finds the new cell size)
+    arrays[0].h[:] = 0.04
+    arrays[0].gpu.push('h')
+    nn.update()
+    assert ctx.timer_get('n_async')[1] == 3
+    assert nn.cell_size == 2.0 * 0.04
+    nn.update()
+    assert ctx.timer_get('n_async')[1] == 4
+    ctx.close()
+
+
+def test_async_update_can_be_switched_off():
+    from pysph_amd import device as dev
+    from pysph_amd.nnps import HipNNPS
+    pa = cloud(5000, 8)
+    ctx = _ctx()
+    ctx.set_option('async_update', 0)
+    ctx.timer_enable(True)
+    dev.attach(pa, ctx).push()
+    nn = HipNNPS(3, [pa], radius_scale=2.0, ctx=ctx, sync=False)
+    nn.update()
+    nn.update()
+    assert ctx.timer_get('n_async')[1] == 0
+    ctx.close()

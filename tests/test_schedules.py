@@ -203,9 +203,18 @@ def bench_tol():
     return bench.PARITY_TOL
 
 
-@pytest.mark.parametrize('argv', [['--n1', '48', '--vary-m', '0.2'], ['--workload', 'dam_break', '--dx', '0.03'],
-                                  ['--n1', '48', '--fixed-bounds']],
-                         ids=['masses-differ', 'run-time-flags', 'no-reduction'])
+def test_fixed_bounds_updates_still_learn_the_masses():
+    """an update that needs no bounds (given) and no h range (known) still looks
+    at the masses ONCE when an evaluation could use one mass per array, and keeps
+    what it found while nothing writes m (round 5: DevArray::m_dirty) -- until
+    round 4 such updates forgot the masses and ran on mass-carrying records"""
+    out, cnt, res = _run(['--n1', '48', '--fixed-bounds'], {})
+    assert cnt['n_mass_fused'] > 0 and res['parity_ok'], (cnt, res)
+    assert res['parity_neighbour_count_mismatches'] == 0
+
+
+@pytest.mark.parametrize('argv', [['--n1', '48', '--vary-m', '0.2'], ['--workload', 'dam_break', '--dx', '0.03']],
+                         ids=['masses-differ', 'run-time-flags'])
 def test_records_keep_the_mass_when_masses_differ_or_flags_are_not_constant(argv):
     # (the per-destination path: since round 4 a dam break's group runs on the merged order of its arrays,
     # where the flags are a compile-time class table -- tests above)

@@ -21,8 +21,8 @@ if f:
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     print('pair launches (us):', [round((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3) for r in rows[-12:]])
     allr = sorted(csv.DictReader(open(f[0])), key=lambda r: int(r['Start_Timestamp']))
-    # one steady-state step: kernels between the last two k_halo_block_counts / k_minmax launches
-    idx = [i for i, r in enumerate(allr) if 'k_minmax_final' in r['Kernel_Name']]
+    # one steady-state step: kernels between the last two k_bin_keys launches
+    idx = [i for i, r in enumerate(allr) if 'k_bin_keys' in r['Kernel_Name']]
     if len(idx) >= 3:
         a, b = idx[-3], idx[-2]
         t0 = int(allr[a]['Start_Timestamp'])
