@@ -775,6 +775,7 @@ def timed(steps, warmup, step, barrier, ctx):
     elapsed = time.perf_counter() - t0
     ctx.timer_enable(False)
     timers = {k: ctx.timer_get(k) for k in ('nnps', 'pack', 'eos', 'pair') + PAIR_FAMILIES}
+    timers['n_async'] = ctx.timer_get('n_async')     # neighbour updates that made no device->host round trip
     return elapsed, timers
 
 
@@ -903,7 +904,8 @@ def run(args, rank, local_rank, world, dist):
                 'frac_on_profiled_box': None if not traffic_box_ms else l1_fill / (traffic_box_ms * 1e-3) / 1e12 / L2_PEAK_TBS,
                 'source': 'TCP_TCC_READ_REQ x 128 B of the profiled run (profiles/), this run\'s kernel time'},
         },
-        'kernel_ms_per_step': {k: v[0] / args.steps for k, v in timers.items() if k not in PAIR_FAMILIES},
+        'kernel_ms_per_step': {k: v[0] / args.steps for k, v in timers.items() if k not in PAIR_FAMILIES and k != 'n_async'},
+        'nnps_updates_without_round_trip': timers['n_async'][1],
         'pair_ms_per_family': family_ms(timers, args.steps),
         'fp64_valu': None if not pairs else {
             'pairs_per_launch': pairs,
@@ -922,6 +924,7 @@ def run(args, rank, local_rank, world, dist):
             and args.dtype == 'f64' and not args.ablate:
         del nnps, a_eval, step      # free this workload's device state first (252^3 needs room)
         extra['secondary'] = secondary_runs(args, local_rank, tstream)
+        extra['step_vs_n'] = step_vs_n(args, local_rank, tstream)
         extra['time_stepping'] = time_stepping(local_rank, tstream)
     if not args.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(args.cpu_n1)
@@ -1049,6 +1052,40 @@ def secondary_runs(args, local_rank, tstream):
             ctx.close()
             torch.cuda.empty_cache()
     return res
+
+
+def step_vs_n(args, local_rank, tstream, sides=(63, 79, 100, 126, 159)):
+    """ms per step and per class (nnps / pack / eos / pair) of the headline cube at
+    0.25 / 0.5 / 1 / 2 / 4 M particles: what is left of a step when the pair kernel
+    shrinks is the latency-bound bookkeeping around it (round 5: the hand-written
+    sort, no device->host round trip) -- and what a rank of a strong-scaling run
+    pays.  Timing only (the sizes with a parity check are in extra.secondary)."""
+    import copy
+    import torch
+    from pysph_amd import device as dev
+    rows = {}
+    for n1 in sides:
+        a2 = copy.copy(args)
+        a2.n1 = n1
+        ctx = dev.HipContext(local_rank, tstream.cuda_stream)
+        apply_options(a2, ctx)
+        try:
+            w = build_workload(a2, 0, 1)
+            nnps, a_eval, halo, domain, step, ordered = setup(a2, w, 0, 1, None, ctx)
+            steps = 10
+            elapsed, timers = timed(steps, 3, step, torch.cuda.synchronize, ctx)
+            n = sum(a.get_number_of_particles(True) for a in w.arrays)
+            rows['%d^3' % n1] = {'particles': n, 'ms_per_step': elapsed / steps * 1e3,
+                                 'particle_updates_per_s': n * steps / elapsed,
+                                 'kernel_ms_per_step': {k: timers[k][0] / steps for k in ('nnps', 'pack', 'eos', 'pair')},
+                                 'updates_without_round_trip': timers['n_async'][1]}
+            del nnps, a_eval, step, w
+        except Exception as e:
+            rows['%d^3' % n1] = {'error': '%s: %s' % (type(e).__name__, e)}
+        finally:
+            ctx.close()
+            torch.cuda.empty_cache()
+    return rows
 
 
 def multi_rank_parity(args, rank, local_rank, world, dist, tstream):

@@ -528,6 +528,14 @@ int sph_timer_reset(sph_ctx *ctx);
  * lists). */
 int sph_timer_get(sph_ctx *ctx, const char *key, double *ms, long *count);
 
+/* ABI self-description: the size of a struct of this header ("sph_kernel", "sph_equation", "sph_group",
+ * "sph_gen_family", "sph_gen_args") and the offset of one of its fields AS THIS LIBRARY WAS COMPILED, so that a
+ * binding written in another language (the ctypes Structures of pysph_amd/device.py) can
+ * check its own layout against the library it loaded instead of trusting a copy of this file.  -1: unknown name.
+ * No reference counterpart (Cython reads the C headers at build time).  */
+long sph_abi_sizeof(const char *struct_name);
+long sph_abi_offsetof(const char *struct_name, const char *field);
+
 #ifdef __cplusplus
 }
 #endif

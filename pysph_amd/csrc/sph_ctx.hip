@@ -3,6 +3,7 @@
 // Replaces the reference's DeviceHelper (pysph/base/device_helper.py:47-672:
 // push/pull/resize of `pa.gpu`) with an explicit host<->HIP buffer table:
 // the Python host keeps owning the numpy buffers and decides when to move data.
+#include <cstddef>
 #include <cstdlib>
 #include "sph_internal.h"
 
@@ -322,6 +323,44 @@ int sph_set_option(sph_ctx *c, const char *key, long value)
 }
 
 int sph_timer_enable(sph_ctx *c, int on) { c->timers_on = on != 0; return SPH_OK; }
+
+// ---- ABI self-description ---------------------------------------------------
+struct AbiField { const char *st, *field; long off; };
+#define ABI_F(S, F) {#S, #F, (long)offsetof(S, F)}
+static const AbiField ABI_FIELDS[] = {
+    ABI_F(sph_kernel, kind), ABI_F(sph_kernel, dim), ABI_F(sph_kernel, fac), ABI_F(sph_kernel, radius_scale), ABI_F(sph_kernel, deltap),
+    ABI_F(sph_equation, kind), ABI_F(sph_equation, dest), ABI_F(sph_equation, nsrc), ABI_F(sph_equation, src), ABI_F(sph_equation, par),
+    ABI_F(sph_group, real), ABI_F(sph_group, start_idx), ABI_F(sph_group, stop_idx), ABI_F(sph_group, neq), ABI_F(sph_group, eqs),
+    ABI_F(sph_group, src_eos), ABI_F(sph_group, eos_par), ABI_F(sph_group, nl_mode), ABI_F(sph_group, phase),
+    ABI_F(sph_gen_family, launch), ABI_F(sph_gen_family, dest), ABI_F(sph_gen_family, nsrc), ABI_F(sph_gen_family, src),
+    ABI_F(sph_gen_family, src_flags), ABI_F(sph_gen_family, n_sprops), ABI_F(sph_gen_family, sprops), ABI_F(sph_gen_family, n_din),
+    ABI_F(sph_gen_family, din), ABI_F(sph_gen_family, n_dout), ABI_F(sph_gen_family, dout), ABI_F(sph_gen_family, npar),
+    ABI_F(sph_gen_family, par), ABI_F(sph_gen_family, real), ABI_F(sph_gen_family, start_idx), ABI_F(sph_gen_family, stop_idx),
+    ABI_F(sph_gen_family, split_init), ABI_F(sph_gen_family, loop_all), ABI_F(sph_gen_family, also_pair), ABI_F(sph_gen_family, init_pair),
+    ABI_F(sph_gen_family, nstate), ABI_F(sph_gen_family, state),
+    ABI_F(sph_gen_args, stream), ABI_F(sph_gen_args, rec), ABI_F(sph_gen_args, mode), ABI_F(sph_gen_args, par), ABI_F(sph_gen_args, state),
+    ABI_F(sph_gen_args, row_mod3),
+};
+#undef ABI_F
+
+long sph_abi_sizeof(const char *name)
+{
+    if (!name) return -1;
+    if (!strcmp(name, "sph_kernel")) return (long)sizeof(sph_kernel);
+    if (!strcmp(name, "sph_equation")) return (long)sizeof(sph_equation);
+    if (!strcmp(name, "sph_group")) return (long)sizeof(sph_group);
+    if (!strcmp(name, "sph_gen_family")) return (long)sizeof(sph_gen_family);
+    if (!strcmp(name, "sph_gen_args")) return (long)sizeof(sph_gen_args);
+    return -1;
+}
+
+long sph_abi_offsetof(const char *name, const char *field)
+{
+    if (!name || !field) return -1;
+    for (const AbiField &f : ABI_FIELDS)
+        if (!strcmp(f.st, name) && !strcmp(f.field, field)) return f.off;
+    return -1;
+}
 
 static int timer_drain(sph_ctx *c)
 {

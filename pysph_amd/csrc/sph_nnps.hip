@@ -525,7 +525,7 @@ static int bits_for(long n_cells)
 // ---------------------------------------------------------------------------
 // host side of the pass above
 // ---------------------------------------------------------------------------
-#define BIN_BLOCKS 1536   // workgroups of one k_bin_keys launch (all arrays together): six per CU
+#define BIN_BLOCKS 2048   // workgroups of one k_bin_keys launch (all arrays together): eight per CU (1536 measured 25 % slower)
 
 static int bin_arrays(sph_ctx *c, int narrays, const int *ids, BinArrays *ba, size_t *n_cat, uint32_t *nblocks)
 {

@@ -48,6 +48,8 @@ _P = C.c_void_p
 _PD = C.POINTER(C.c_double)
 _PU = C.POINTER(C.c_uint32)
 SIGNATURES = {
+    'sph_abi_sizeof': (C.c_long, [C.c_char_p]),
+    'sph_abi_offsetof': (C.c_long, [C.c_char_p, C.c_char_p]),
     'sph_ctx_create': (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
     'sph_ctx_destroy': (C.c_int, [_P]),
     'sph_ctx_synchronize': (C.c_int, [_P]),

@@ -27,6 +27,38 @@ def test_library_exports_every_declared_symbol():
     dev.load_library()  # binds restype/argtypes for all of them
 
 
+def test_ctypes_structures_match_the_library_they_are_loaded_against():
+    """every ctypes Structure the product passes across the boundary has the
+    size, the field order and the field offsets of the C struct AS THE LOADED
+    LIBRARY WAS COMPILED (sph_abi_sizeof / sph_abi_offsetof), and the stub
+    printed in INTEGRATION.md section 3 -- executed, not read -- has them too"""
+    from pysph_amd import device as dev
+    lib = dev.load_library()
+    pairs = {'sph_kernel': dev.SphKernel, 'sph_equation': dev.SphEquation, 'sph_group': dev.SphGroup,
+             'sph_gen_family': dev.SphGenFamily}
+    assert lib.sph_abi_sizeof(b'no_such_struct') == -1
+    assert lib.sph_abi_offsetof(b'sph_group', b'no_such_field') == -1
+
+    def check(cname, st):
+        assert ctypes.sizeof(st) == lib.sph_abi_sizeof(cname.encode()), cname
+        for fname, _ in st._fields_:
+            off = lib.sph_abi_offsetof(cname.encode(), fname.encode())
+            assert off == getattr(st, fname).offset, (cname, fname, off)
+    for cname, st in pairs.items():
+        check(cname, st)
+    assert lib.sph_abi_sizeof(b'sph_gen_args') > 0
+    # the stub of INTEGRATION.md: the first python block after the section-3 heading
+    text = open(os.path.join(REPO, 'INTEGRATION.md')).read()
+    sec = text[text.index('## 3. The ctypes stub'):]
+    code = sec[sec.index('```python') + 9:]
+    code = code[:code.index('```')]
+    decl = code[:code.index('ctx = C.c_void_p()')].replace('lib = C.CDLL("libsphhip.so")', '')
+    ns = {}
+    exec(decl, ns)
+    for cname in ('sph_kernel', 'sph_equation', 'sph_group'):
+        check(cname, ns[cname])
+
+
 def test_property_and_enum_tables_agree():
     from pysph_amd import device as dev
     from pysph_amd import equations as E
