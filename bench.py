@@ -61,6 +61,11 @@ ELEMENTWISE_FLOOR = 1e-6     # element-wise parity: |b_i| floored at this fracti
 #    every particle sits at the floor, so the figure is the norm-wise error / floor and its bound 1e-10 / 1e-6 = 1e-4.
 ELEMENTWISE_TOL = 1e-8
 ELEMENTWISE_TOL_CANCELLING = PARITY_TOL / ELEMENTWISE_FLOOR
+# fp32 arithmetic (tolerance 5e-5 norm-wise against the fp64 oracle): every particle judged against its own value
+# floored at a thousandth of the field's scale, bound = norm-wise tolerance / floor
+PARITY_TOL_F32 = 5e-5
+ELEMENTWISE_FLOOR_F32 = 1e-3
+ELEMENTWISE_TOL_F32 = PARITY_TOL_F32 / ELEMENTWISE_FLOOR_F32
 
 
 # ---------------------------------------------------------------------------
@@ -403,7 +408,7 @@ def cpu_baseline(n1=100, target_seconds=15.0):
                       'schedule(dynamic,64), %d threads)' % (n1, n, reps, cores)}
 
 
-def field_error(a, b, scale_fields, elementwise=False):
+def field_error(a, b, scale_fields, elementwise=False, floor=None):
     """max|a-b| / max|b|, the components of one vector (`scale_fields`) sharing
     their scale -- a component that vanishes by symmetry, the y force of a
     lattice, has no scale of its own; absolute when the scale is zero.  A NaN or
@@ -427,15 +432,16 @@ def field_error(a, b, scale_fields, elementwise=False):
         return err
     if scale == 0.0:
         return err, err
-    ew = float(np.max(d / np.maximum(np.abs(b), ELEMENTWISE_FLOOR * scale)))
+    ew = float(np.max(d / np.maximum(np.abs(b), (ELEMENTWISE_FLOOR if floor is None else floor) * scale)))
     return err, (ew if np.isfinite(ew) else 1e300)
 
 
 def parity_check(w, host_in, nnps, domain, tol=PARITY_TOL, ew_tol='auto'):
     """`parity_ok` = norm-wise error < tol AND element-wise error < ew_tol AND no
     neighbour-count mismatch.  ew_tol 'auto': the workload's bound (`Workload.ew_tol`,
-    see ELEMENTWISE_TOL) for fp64 tolerances, None (reported, not asserted) for the
-    fp32 tolerance -- an fp32 value judged against a 1e-6 floor says nothing.
+    see ELEMENTWISE_TOL) for fp64 tolerances; for the fp32 tolerance the floor is
+    ELEMENTWISE_FLOOR_F32 = 1e-3 of the field's scale (an fp32 value judged against
+    a 1e-6 floor says nothing) and the bound ELEMENTWISE_TOL_F32 = tol / floor.
 
     Device results of the state the timed loop ran on vs the CPU oracle on
     the SAME inputs (tests/ and this leg are the only users of oracle/): every
@@ -461,6 +467,8 @@ def parity_check(w, host_in, nnps, domain, tol=PARITY_TOL, ew_tol='auto'):
     t_oracle = time.perf_counter() - t0
     worst, worst_field = 0.0, None
     worst_ew, worst_ew_field = 0.0, None
+    f32 = tol > PARITY_TOL
+    floor = ELEMENTWISE_FLOOR_F32 if f32 else ELEMENTWISE_FLOOR
     for pa, pr in zip(w.arrays, ref):
         nreal = pr.get_number_of_particles(True)
         if nreal == 0:
@@ -472,17 +480,17 @@ def parity_check(w, host_in, nnps, domain, tol=PARITY_TOL, ew_tol='auto'):
             err, ew = field_error(
                 np.asarray(pa.get(f))[:nreal], np.asarray(pr.get(f))[:nreal],
                 [np.asarray(pr.get(g))[:nreal] for g in _scale_group(f) if g in pr.properties],
-                elementwise=True)
+                elementwise=True, floor=floor)
             if err > worst:
                 worst, worst_field = err, '%s.%s' % (pa.name, f)
             if ew > worst_ew:
                 worst_ew, worst_ew_field = ew, '%s.%s' % (pa.name, f)
     if ew_tol == 'auto':
-        ew_tol = w.ew_tol if tol <= PARITY_TOL else None
+        ew_tol = w.ew_tol if not f32 else ELEMENTWISE_TOL_F32
     out = {'parity_max_rel': worst, 'parity_worst_field': worst_field,
            'parity_elementwise_max_rel': worst_ew,
            'parity_elementwise_worst_field': worst_ew_field,
-           'parity_elementwise_floor': ELEMENTWISE_FLOOR,
+           'parity_elementwise_floor': floor,
            'parity_elementwise_tolerance': ew_tol,
            'parity_tolerance': tol,
            'parity_ok': bool(worst < tol and (ew_tol is None or worst_ew < ew_tol)),
@@ -570,6 +578,8 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-check', action='store_true', help='skip the oracle parity check')
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary configurations')
+    ap.add_argument('--no-counters', action='store_true', dest='no_counters',
+                    help='do not re-run under rocprofv3 --pmc for roofline.traffic (replay profiles/pmc_traffic.json)')
     ap.add_argument('--cpu-n1', type=int, default=100)
     ap.add_argument('--fixed-bounds', action='store_true', dest='fixed_bounds',
                     help='hand nnps.update() the grid bounds and the (constant) h range instead of '
@@ -853,6 +863,25 @@ def run(args, rank, local_rank, world, dist):
                                               'passes of this command, not measured in this run')
     except Exception:
         traffic = None
+    # ... unless rocprofv3 is on this box: then the counters are taken in THIS run (three short child runs)
+    measured_kernel = None
+    if world == 1 and not args.no_counters and not args.ablate:
+        wl_flags = ['--workload', args.workload, '--n1', str(args.n1), '--dtype', args.dtype, '--params', args.params,
+                    '--dx', repr(args.dx), '--variant', str(args.variant)]
+        if args.vary_h:
+            wl_flags += ['--vary-h', repr(args.vary_h)]
+        if args.no_reorder:
+            wl_flags += ['--no-reorder']
+        for kv in args.opt:
+            wl_flags += ['--opt', kv]
+        cm = counters_in_this_run(wl_flags)
+        if cm:
+            traffic, l1_fill = cm['bytes_per_launch'], cm['l1_fill_bytes_per_launch']
+            traffic_box_ms, measured_kernel = cm['kernel_ms_under_counters'], cm['kernel']
+            traffic_source = ('measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCP_TCC_READ_REQ_sum '
+                              '--kernel-trace, one 3-step child run of this command per counter set on this box, '
+                              'per-launch mean of this kernel; FETCH_SIZE x 2 (gfx950: 64 B counted per 128-B request, '
+                              'MI355X_MICROARCH.md) + WRITE_SIZE')
     pair_avg_s = pair_ms / max(pair_launches, 1) * 1e-3
     # several pair launches per step for multi-destination sets: bytes of ONE
     # step / total pair-kernel time of one step
@@ -885,13 +914,15 @@ def run(args, rank, local_rank, world, dist):
             'halo_overlap': bool(getattr(w, 'overlap_halo', False)),
         },
         'roofline': {
-            'bound': 'hbm', 'kernel': 'k_pair_%s<%s,%s>' % (
+            # the kernel's name as rocprofv3 prints it when the counters were taken in this run
+            'bound': 'hbm', 'kernel': measured_kernel or 'k_pair_%s<%s,%s>' % (
                 {0: 'direct', 2: 'wg', 3: 'agg', 6: 'wave'}[args.variant], fam,
                 type(w.kernel).__name__),
             'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
             'traffic_source': traffic_source,
-            # the counters come from another box of the pool: that box's own kernel time, next to this run's avg_kernel_ms
+            # the kernel's mean duration in the run the counters come from (a child run of this command on this box, or --
+            # replayed counters -- another box of the pool), next to this run's avg_kernel_ms
             'traffic_profiled_kernel_ms': traffic_box_ms,
             'algorithmic_bytes_per_particle': algo_pair,
             'avg_kernel_ms': pair_avg_s * 1e3,
@@ -902,7 +933,7 @@ def run(args, rank, local_rank, world, dist):
                 'bytes_per_launch': l1_fill, 'achieved': l1_fill / pair_avg_s / 1e12,
                 'peak': L2_PEAK_TBS, 'unit': 'TB/s', 'frac': l1_fill / pair_avg_s / 1e12 / L2_PEAK_TBS,
                 'frac_on_profiled_box': None if not traffic_box_ms else l1_fill / (traffic_box_ms * 1e-3) / 1e12 / L2_PEAK_TBS,
-                'source': 'TCP_TCC_READ_REQ x 128 B of the profiled run (profiles/), this run\'s kernel time'},
+                'source': 'TCP_TCC_READ_REQ x 128 B of the run the counters come from (roofline.traffic_source), this run\'s kernel time'},
         },
         'kernel_ms_per_step': {k: v[0] / args.steps for k, v in timers.items() if k not in PAIR_FAMILIES and k != 'n_async'},
         'nnps_updates_without_round_trip': timers['n_async'][1],
@@ -968,6 +999,61 @@ def time_stepping(local_rank, tstream, dx=0.0087, n_steps=30):
         torch.cuda.empty_cache()
 
 
+def counters_in_this_run(argv_workload, timeout_s=240):
+    """HBM-side bytes of the dominant pair kernel MEASURED IN THIS RUN: bench.py
+    re-executes itself (same workload flags, 3 steps) under `rocprofv3 --pmc <one
+    set> --kernel-trace`, one child per counter set as the guide prescribes
+    (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass; --pmc only
+    with --kernel-trace), and reads the per-dispatch counters of the pair kernel
+    with the largest total duration.  gfx950 correction of the same guide:
+    FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read -> x 2;
+    WRITE_SIZE as reported (both in KiB).  Returns None when rocprofv3 is not on
+    the box or a pass fails -- the caller then replays profiles/pmc_traffic.json
+    and says so."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if os.environ.get('SPH_BENCH_CHILD') or not shutil.which('rocprofv3'):
+        return None
+    if any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ):   # this run is being profiled itself
+        return None
+    env = dict(os.environ, SPH_BENCH_CHILD='1', TMPDIR='/tmp')
+    child = [sys.executable, os.path.join(REPO, 'bench.py'), '--no-cpu-baseline', '--no-check', '--no-extras',
+             '--steps', '3', '--warmup', '1'] + argv_workload
+    vals, kname, kms = {}, None, None
+    for cset in ('FETCH_SIZE', 'WRITE_SIZE', 'TCP_TCC_READ_REQ_sum'):
+        d = tempfile.mkdtemp(prefix='sph_pmc_', dir='/tmp')
+        try:
+            subprocess.run(['rocprofv3', '--pmc', cset, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'run', '--'] + child,
+                           cwd='/tmp', env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            f = glob.glob(os.path.join(d, '**', '*_counter_collection.csv'), recursive=True)
+            per = {}                       # kernel -> {dispatch: value}
+            for r in csv.DictReader(open(f[0])):
+                if 'k_pair_wave' in r['Kernel_Name'] and 'FamNbr' not in r['Kernel_Name'] and r['Counter_Name'] == cset:
+                    per.setdefault(r['Kernel_Name'], {}).setdefault(r['Dispatch_Id'], 0.0)
+                    per[r['Kernel_Name']][r['Dispatch_Id']] += float(r['Counter_Value'])
+            if not per:
+                return None
+            # the kernel of the steady state: the one with the most dispatches (warm-up launches of other layouts are fewer)
+            k = max(per, key=lambda q: len(per[q]))
+            v = list(per[k].values())
+            vals[cset] = sum(v) / len(v)
+            kname = kname or k
+            tr = glob.glob(os.path.join(d, '**', '*_kernel_trace.csv'), recursive=True)
+            if tr and kms is None:
+                du = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-6
+                      for r in csv.DictReader(open(tr[0])) if r['Kernel_Name'] == k]
+                kms = sum(du) / len(du) if du else None
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {'kernel': kname, 'bytes_per_launch': vals['FETCH_SIZE'] * 1024.0 * 2.0 + vals['WRITE_SIZE'] * 1024.0,
+            'fetch_bytes_corrected': vals['FETCH_SIZE'] * 1024.0 * 2.0, 'write_bytes': vals['WRITE_SIZE'] * 1024.0,
+            'l1_fill_bytes_per_launch': vals['TCP_TCC_READ_REQ_sum'] * 128.0, 'kernel_ms_under_counters': kms}
+
+
 def family_ms(timers, steps):
     """pair-kernel ms per step of every equation family that ran"""
     return {k[5:]: v[0] / steps for k, v in timers.items()
@@ -996,8 +1082,9 @@ def secondary_runs(args, local_rank, tstream):
         ('C3 Taylor-Green 159^3 TVF', dict(workload='taylor_green', n1=159), True),
         ('C5 S-rings3d 2 M fp32', dict(workload='elastic', dtype='f32'), True),
         ('C5 S-rings3d 2 M fp64', dict(workload='elastic'), True),
-        ('C5 S-rings3d 2 M fp32 from rings.py\'s initial state (no stress yet: r_ij = 0, not gathered)',
-         dict(workload='elastic', dtype='f32', rings_unperturbed=True), True),
+        # TIMING ONLY: at rest every output field of this state is (almost) identically zero, a parity figure would be vacuous
+        ('C5 S-rings3d 2 M fp32 from rings.py\'s initial state (timing only; no stress yet: r_ij = 0, not gathered)',
+         dict(workload='elastic', dtype='f32', rings_unperturbed=True), False),
         ('100^3', dict(n1=100), False),
         ('252^3', dict(n1=252), False),
         ('159^3 unsorted', dict(no_reorder=True), False),

@@ -382,6 +382,13 @@ class _CGroup(object):
         # several destinations with hand-written kernels only: ONE call for the
         # whole group (the equations by value, as the units hold them now)
         shared = len(self.units) > 1 and all(isinstance(u, _BuiltinUnit) for u in self.units)
+        if shared:
+            # ... and only when ONE set of promises describes every destination: units that were promised
+            # different things (or a neighbour-list mode, which belongs to one (destination, source) pair) keep
+            # their own calls -- a combined call would have to drop what differs
+            u0 = self.units[0].cg
+            shared = all(u.cg.src_eos == u0.src_eos and list(u.cg.eos_par) == list(u0.eos_par) and u.cg.nl_mode == 0
+                         for u in self.units)
         if not shared:
             for u in self.units:
                 u.run(ev, t, dt)
@@ -395,14 +402,13 @@ class _CGroup(object):
                 ceqs[i] = u.ceqs[k]
                 i += 1
         cg.start_idx, cg.stop_idx = self._start_stop
-        # the promises annotate_plan made for every unit hold for the group
+        # the promises annotate_plan made for every unit (the same for all: checked above) hold for the group
         u0 = self.units[0].cg
-        same = all(u.cg.src_eos == u0.src_eos and list(u.cg.eos_par) == list(u0.eos_par)
-                   for u in self.units)
-        cg.src_eos = u0.src_eos if same else 0
+        cg.src_eos = u0.src_eos
         for k in range(4):
-            cg.eos_par[k] = u0.eos_par[k] if same else 0.0
+            cg.eos_par[k] = u0.eos_par[k]
         cg.nl_mode = 0
+        cg.phase = 0
         dev._check(ev.lib.sph_eval_group(
             ev.ctx._h, C.byref(ev.ckernel), C.byref(cg), t, dt))
 

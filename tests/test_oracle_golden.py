@@ -3,6 +3,8 @@ executing the reference's own Python classes (tests/golden/make_golden.py).
 
 Bar: BIT-EXACT.  The oracle is compiled without fp contraction and the
 goldens are CPython float arithmetic, so every output must be identical."""
+import os
+
 import numpy as np
 import pytest
 
@@ -105,6 +107,44 @@ def test_oracle_kernels_bitwise(oracle):
             # host-side numpy helpers agree to rounding
             assert np.allclose(k.kernel(rij=r, h=h), g[key + 'w'],
                                rtol=1e-12, atol=1e-30)
+
+
+def test_oracle_kernels_vs_compiled_reference(oracle):
+    """A second, COMPILED pin of the kernels: the reference's own
+    pysph/base/c_kernels.pyx (what its Cython backend evaluates; no cyarray
+    dependency) built by oracle/build_ref.sh into oracle/_ref/ from where it
+    lies.  The C oracle must give bit-identical W, dW/dq and gradients for
+    random (r, h, xij) incl. r = 0, r on the support radius and beyond it."""
+    import importlib.util
+    import glob
+    from conftest import REPO
+    so = glob.glob(os.path.join(REPO, 'oracle', '_ref', 'c_kernels*.so'))
+    if not so:
+        pytest.skip('oracle/_ref/c_kernels not built (needs /root/reference: oracle/build_ref.sh)')
+    spec = importlib.util.spec_from_file_location('c_kernels', so[0])
+    ck = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ck)
+    from pysph_amd import kernels as K
+    rng = np.random.default_rng(42)
+    for cls, dims in ((K.CubicSpline, (1, 2, 3)), (K.WendlandQuintic, (2, 3)),
+                      (K.QuinticSpline, (1, 2, 3)), (K.Gaussian, (1, 2, 3))):
+        for dim in dims:
+            k = cls(dim=dim)
+            ref = getattr(ck, cls.__name__)(dim=dim, fac=k.fac, radius_scale=k.radius_scale)
+            assert ref.py_get_deltap() == k.get_deltap()
+            h = rng.uniform(0.05, 2.0, 400)
+            q = np.concatenate([rng.uniform(0, 1.2 * k.radius_scale, 394), [0.0, 1.0, 2.0, 3.0, k.radius_scale, 1e-13]])
+            for i in range(h.size):
+                r = float(q[i] * h[i])
+                d = rng.normal(size=3)
+                d[dim:] = 0.0
+                nd = float(np.sqrt(d @ d))
+                xij = (d / nd * r) if nd > 0 else d
+                assert oracle.kernel_w(k, r, h[i]) == ref.py_kernel(xij, r, h[i]), (cls.__name__, dim, r, h[i])
+                assert oracle.kernel_dwdq(k, r, h[i]) == ref.py_dwdq(r, h[i]), (cls.__name__, dim, r, h[i])
+                g = np.zeros(3)
+                ref.py_gradient(xij, r, h[i], g)
+                assert oracle.kernel_gradient(k, list(xij), r, h[i]) == list(g), (cls.__name__, dim, r, h[i])
 
 
 def test_wendland_w0_analytic():
