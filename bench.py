@@ -211,6 +211,17 @@ class Workload(object):
     halo_width = 0.0
 
 
+def _dam_weights(arrays, args):
+    """work per particle for the slab cut of a dam break (--slab-weight-solid, default 0.25: a boundary /
+    obstacle particle is a destination of the continuity equation over the fluid only, and most of them have no
+    fluid neighbour; 1: equal particle counts)"""
+    ws = float(args.slab_weight_solid)
+    return np.concatenate([np.full(a.get_number_of_particles(), 1.0 if a.name == 'fluid' else ws) for a in arrays])
+
+
+_DAM_CACHE = {}     # --emulate-rank: the whole tank, built once for all emulated ranks of one invocation
+
+
 def cut_slab(w, pa, rank, world, halo_width):
     """N > 1, ONE problem (strong scaling): this rank's slab of `pa` along x,
     cut at the quantiles of x (equal particle counts)"""
@@ -252,7 +263,9 @@ def build_workload(args, rank, world):
         w.fields = ('arho', 'au', 'av', 'aw', 'ax', 'ay', 'az', 'p', 'cs')
     elif args.workload == 'dam_break':
         from pysph_amd.examples import dam_break_3d as db
-        arrays = db.create_particles(args.dx)
+        cached = _DAM_CACHE.get(args.dx) if args.emulate_rank else None
+        arrays = [a.extract_particles(np.arange(a.get_number_of_particles()), name=a.name) for a in cached] \
+            if cached else db.create_particles(args.dx)
         gid0 = 0
         # the example starts from rest at uniform density, where every pair
         # term but gravity vanishes: give the fluid the S-cube's seeded
@@ -268,11 +281,34 @@ def build_workload(args, rank, world):
                 for c in 'uvw':
                     a.get(c)[:] = 0.1 * db.c0 * rng.uniform(-1, 1, n)
         lo, hi = -1e30, 1e30
-        if world > 1:
+        if args.emulate_rank and not cached:
+            _DAM_CACHE.clear()
+            _DAM_CACHE[args.dx] = [a.extract_particles(np.arange(a.get_number_of_particles()), name=a.name) for a in arrays]
+        if args.emulate_rank:
+            # ONE rank of an N-rank strong-scaling run WITHOUT the other ranks: this rank's slab of the tank (cut at the
+            # quantiles of x like `--gpus N`) and, behind its real particles, the ghost layers its two neighbours
+            # would send (their particles within the halo width of the faces).  Times what a rank computes per step;
+            # the exchange that delivers the ghosts is measured separately (--self-slab).
+            from pysph_amd.parallel import slab_bounds
+            er, ew = args.emulate_rank
+            cuts = slab_bounds(np.concatenate([a.x for a in arrays]), ew, weights=_dam_weights(arrays, args))
+            elo = -1e30 if er == 0 else float(cuts[er])
+            ehi = 1e30 if er == ew - 1 else float(cuts[er + 1])
+            width = db.create_kernel().radius_scale * 1.3 * args.dx
+            cut = []
+            for a in arrays:
+                real = np.nonzero((a.x >= elo) & (a.x < ehi))[0]
+                ghost = np.nonzero(((a.x >= elo - width) & (a.x < elo)) | ((a.x >= ehi) & (a.x < ehi + width)))[0]
+                b = a.extract_particles(np.concatenate([real, ghost]), name=a.name)
+                b.set_num_real_particles(real.size)
+                cut.append(b)
+            arrays = cut
+            w.scaling = 'strong'
+        elif world > 1:
             # C4: ONE tank cut into `world` slabs along x at the quantiles of
             # all particles' x (equal counts: the fluid fills 38 % of the tank)
             from pysph_amd.parallel import slab_bounds
-            cuts = slab_bounds(np.concatenate([a.x for a in arrays]), world)
+            cuts = slab_bounds(np.concatenate([a.x for a in arrays]), world, weights=_dam_weights(arrays, args))
             lo = -1e30 if rank == 0 else float(cuts[rank])
             hi = 1e30 if rank == world - 1 else float(cuts[rank + 1])
             arrays = [a.extract_particles(np.nonzero((a.x >= lo) & (a.x < hi))[0],
@@ -285,6 +321,9 @@ def build_workload(args, rank, world):
         w.name = ('3D dam break (dam_break_3d.py geometry), dx=%g: %s' % (
             dx, ', '.join('%s %d' % (a.name, a.get_number_of_particles())
                           for a in arrays)))
+        if args.emulate_rank:
+            w.name += ' -- rank %d of %d emulated: %s real particles + the ghost layers of its neighbours' % (
+                args.emulate_rank[0], args.emulate_rank[1], sum(a.get_number_of_particles(True) for a in arrays))
         w.halo_width = w.kernel.radius_scale * 1.3 * dx
         # solids <- fluid continuity: x,y,z,h,u,v,w read (56 B), arho written (8 B): SURVEY 8(d)
         w.algo_solid = 64.0
@@ -586,10 +625,26 @@ def parse_args(argv=None):
                          'reducing them every update: LinkedListNNPS(fixed_h=True) plus bounds a '
                          'stepping host knows from its own reductions; removes the min/max pass and '
                          'its device->host round trip from the step (reported in config)')
+    ap.add_argument('--slab-weight-solid', type=float, default=0.25, dest='slab_weight_solid',
+                    help='dam_break over several ranks: work of a boundary / obstacle particle relative to a fluid '
+                         'particle when the slab faces are cut (1: equal particle counts)')
+    ap.add_argument('--halo-protocol', default='padded', dest='halo_protocol', choices=['padded', 'capacity', 'handshake'],
+                    help='ghost exchange of slab runs: padded (default) = fixed-capacity messages appended whole, NaN padding '
+                         'rows behind the ghosts, no device->host round trip; capacity = the same messages, the row counts '
+                         'read back every exchange; handshake = counts all_gather before exactly sized messages')
+    ap.add_argument('--emulate-rank', default=None, dest='emulate_rank', metavar='r/N',
+                    help='dam_break on ONE GPU: rank r of an N-rank strong-scaling run, its slab plus the ghost layers '
+                         'its neighbours would send, built locally (no communication): what a rank computes per step')
     ap.add_argument('--self-slab', action='store_true', dest='self_slab',
                     help='taylor_green on ONE GPU through the N>1 code path: the periodic x axis '
                          'is a slab whose two faces are exchanged with this rank itself over RCCL')
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.emulate_rank:
+        r, n = (int(v) for v in str(args.emulate_rank).split('/'))
+        if not (0 <= r < n) or args.workload != 'dam_break':
+            ap.error('--emulate-rank r/N needs 0 <= r < N and --workload dam_break')
+        args.emulate_rank = (r, n)
+    return args
 
 
 def _free_port():
@@ -693,7 +748,8 @@ def setup(args, w, rank, world, dist, ctx):
                  'elastic_block': ELASTIC_HALO_PROPS}.get(args.workload, WCSPH_HALO_PROPS)
         halo = SlabDecomposition(w.arrays, ctx, rank, world, axis=0,
                                  width=w.halo_width, lo=lo, hi=hi, props=props,
-                                 periodic=periodic, period=period, dist=dist)
+                                 periodic=periodic, period=period, dist=dist,
+                                 protocol=os.environ.get('SPH_HALO_PROTOCOL', args.halo_protocol))
     domain = None
     if w.domain_kw is not None:
         from pysph_amd.domain import HipDomainManager
@@ -710,8 +766,12 @@ def setup(args, w, rank, world, dist, ctx):
             # migrants bring the other ranks' smoothing lengths
             return (allreduce_scalars([lo], 'min', dist=dist, device=dev_t)[0],
                     allreduce_scalars([hi], 'max', dist=dist, device=dev_t)[0])
+    # the overlapped exchange bins the real particles BEFORE the ghosts arrive: the cell size and the uniform-h
+    # decision of that update must rest on the GLOBAL h range (the particles of this benchmark keep their h), as
+    # sph_nnps_update_ghosts checks since round 5
     nnps = HipNNPS(3, w.arrays, radius_scale=w.kernel.radius_scale, ctx=ctx,
-                   sync=False, domain=domain, fixed_h=bool(args.fixed_bounds),
+                   sync=False, domain=domain,
+                   fixed_h=bool(args.fixed_bounds) or (halo is not None and args.overlap_halo),
                    h_range_reduce=h_reduce)
     a_eval.set_nnps(nnps)
     ordered = False
@@ -956,6 +1016,8 @@ def run(args, rank, local_rank, world, dist):
         del nnps, a_eval, step      # free this workload's device state first (252^3 needs room)
         extra['secondary'] = secondary_runs(args, local_rank, tstream)
         extra['step_vs_n'] = step_vs_n(args, local_rank, tstream)
+        t1 = extra['secondary'].get('C4 dam break dx 0.0035 (16 M) on one GPU', {}).get('ms_per_step')
+        extra['projected_strong_scaling_8'] = projected_strong_scaling(args, local_rank, tstream, t_one_gpu_ms=t1)
         extra['time_stepping'] = time_stepping(local_rank, tstream)
     if not args.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(args.cpu_n1)
@@ -1173,6 +1235,88 @@ def step_vs_n(args, local_rank, tstream, sides=(63, 79, 100, 126, 159)):
             ctx.close()
             torch.cuda.empty_cache()
     return rows
+
+
+def projected_strong_scaling(args, local_rank, tstream, world=8, dx=0.0035, t_one_gpu_ms=None):
+    """BASELINE config 4 (the 16 M dam break over 8 GPUs) projected from ONE GPU:
+    every rank's slab + the ghost layers its neighbours would send is built
+    locally (`--emulate-rank r/8`) and timed (nnps.update + compute: what that
+    rank computes per step), the exchange that delivers the ghosts is taken from
+    the slab transport measured on this GPU (`--self-slab` against the plain step
+    at a rank's particle count: select + pack + RCCL send/recv to itself + header
+    round trip + append).  projected speed-up = t(1 GPU) / max_r (t_r + exchange).
+    A PROJECTION, not a measurement: no byte crosses xGMI here."""
+    import copy
+    import torch
+    from pysph_amd import device as dev
+    out = {'world': world, 'dx': dx, 'ranks': {}}
+    t_max, n_max = 0.0, 0
+    for r in range(world):
+        a2 = copy.copy(args)
+        a2.workload, a2.dx, a2.emulate_rank = 'dam_break', dx, (r, world)
+        ctx = dev.HipContext(local_rank, tstream.cuda_stream)
+        apply_options(a2, ctx)
+        try:
+            w = build_workload(a2, 0, 1)
+            nnps, a_eval, halo, domain, step, ordered = setup(a2, w, 0, 1, None, ctx)
+            steps = 10
+            elapsed, timers = timed(steps, 3, step, torch.cuda.synchronize, ctx)
+            nreal = sum(a.get_number_of_particles(True) for a in w.arrays)
+            nall = sum(a.get_number_of_particles() for a in w.arrays)
+            ms = elapsed / steps * 1e3
+            out['ranks'][str(r)] = {'real_particles': nreal, 'ghost_particles': nall - nreal, 'ms_per_step': ms,
+                                    'kernel_ms_per_step': {k: timers[k][0] / steps for k in ('nnps', 'pack', 'eos', 'pair')}}
+            if ms > t_max:
+                t_max, n_max = ms, nreal
+            del nnps, a_eval, step, w
+        except Exception as e:
+            out['ranks'][str(r)] = {'error': '%s: %s' % (type(e).__name__, e)}
+        finally:
+            ctx.close()
+            torch.cuda.empty_cache()
+    _DAM_CACHE.clear()
+    # the exchange: slab transport on this GPU at about a rank's particle count (cube of the same size)
+    n1 = max(32, int(round(n_max ** (1.0 / 3.0)))) if n_max else 130
+    ex = {}
+    own_group = False
+    for name, flag in (('plain', False), ('self_slab', True)):
+        a2 = copy.copy(args)
+        a2.workload, a2.n1, a2.self_slab, a2.emulate_rank = 'cube', n1, flag, None
+        ctx = dev.HipContext(local_rank, tstream.cuda_stream)
+        apply_options(a2, ctx)
+        try:
+            w = build_workload(a2, 0, 1)
+            dist = None
+            if flag:
+                import torch.distributed as dist
+                if not dist.is_initialized():
+                    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+                    os.environ.setdefault('MASTER_PORT', str(_free_port()))
+                    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', local_rank))
+                    own_group = True
+            nnps, a_eval, halo, domain, step, ordered = setup(a2, w, 0, 1, dist, ctx)
+            elapsed, timers = timed(10, 3, step, torch.cuda.synchronize, ctx)
+            ex[name] = elapsed / 10 * 1e3
+            del nnps, a_eval, step, w, halo
+        except Exception as e:
+            ex[name] = None
+            ex[name + '_error'] = '%s: %s' % (type(e).__name__, e)
+        finally:
+            ctx.close()
+            torch.cuda.empty_cache()
+    if own_group:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    out['exchange_stand_in'] = {'cube_side': n1, 'ms_per_step': ex}
+    if ex.get('plain') and ex.get('self_slab'):
+        out['exchange_ms'] = max(ex['self_slab'] - ex['plain'], 0.0)
+    out['slowest_rank_ms'] = t_max
+    if t_one_gpu_ms and t_max > 0 and out.get('exchange_ms') is not None:
+        out['t_one_gpu_ms'] = t_one_gpu_ms
+        out['projected_speedup'] = t_one_gpu_ms / (t_max + out['exchange_ms'])
+        out['projected_speedup_free_exchange'] = t_one_gpu_ms / t_max
+    return out
 
 
 def multi_rank_parity(args, rank, local_rank, world, dist, tstream):

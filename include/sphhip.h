@@ -424,6 +424,17 @@ int sph_halo_select_pack(sph_ctx *ctx, int array_id, int axis, double lo_cut, do
 int sph_read_values(sph_ctx *ctx, int n, const void *const *dev_ptrs, double *out);
 /* sph_halo_append from a message whose rows are `stride` doubles apart
  * (property k of row i at src[k * stride + i], stride >= count).            */
+/* The same message appended WITHOUT a device->host round trip (round 5): all `cap` rows go behind the particles, the
+ * first |header| of them are the ghosts, the rest PADDING ROWS with NaN in every listed property -- inert on the whole
+ * path (bounds, keys, distance tests; ghosts are never destinations), so the host needs no count to size anything.
+ * h_promise / m_promise (NaN: none): every ghost is promised to carry this smoothing length / mass (the ONE value of the
+ * array on every rank, established collectively by the caller); then the neighbour update keeps what it knows of h and m.
+ * flag_word: a DEVICE uint32 the kernel ORs into -- bit 0: the message was incomplete (negative header), bit 1: a ghost
+ * broke a promise; the caller reads it when convenient (pysph_amd/parallel.py: one exchange later, with the counts).
+ * Replaces the recv side of ParallelManager.remote_exchange_data (parallel_manager.pyx:159-210), whose counts travel over
+ * MPI to the host first. */
+int sph_halo_append_padded(sph_ctx *ctx, int array_id, int nprops, const int *props, const void *src_device, size_t cap,
+                           double h_promise, double m_promise, void *flag_word);
 int sph_halo_append_strided(sph_ctx *ctx, int array_id, int nprops, const int *props, const void *src_device,
                             size_t count, size_t stride);
 

@@ -366,6 +366,64 @@ extern "C" int sph_halo_append_strided(sph_ctx *c, int id, int nprops, const int
     return SPH_OK;
 }
 
+// Rows of a fixed-capacity message appended WITHOUT the host knowing how many there are: all `cap` rows of the message
+// go behind the particles; the first |header| of them are the ghosts, the rest are PADDING ROWS with NaN in every listed
+// property.  A NaN position is inert everywhere on the path: fmin / fmax of the bounds skip it, its key is spread over
+// the grid (fine_key_of), no distance test against it is true, and ghosts are never destinations.  flag (device word,
+// sticky): bit 0 = the message was incomplete (negative header: more rows than its capacity), bit 1 = a ghost's h or m
+// differs from the promised one.
+__global__ __launch_bounds__(256) void k_halo_append_padded(PropList L, const double *__restrict__ src, size_t n0, size_t cap,
+                                                            int nprops, int k_h, int k_m, double h_promise, double m_promise,
+                                                            uint32_t *__restrict__ flag)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    const int k = blockIdx.y;
+    const double hdr = src[(size_t)nprops * cap];
+    const size_t count = (size_t)fmin(fabs(hdr), (double)cap);
+    if (i == 0 && k == 0 && hdr < 0.0) atomicOr(flag, 1u);
+    double v = __builtin_nan("");
+    if (i < count) {
+        v = src[(size_t)k * cap + i];
+        if ((k == k_h && h_promise == h_promise && v != h_promise) || (k == k_m && m_promise == m_promise && v != m_promise)) atomicOr(flag, 2u);
+    }
+    L.p[k][n0 + i] = v;
+}
+
+extern "C" int sph_halo_append_padded(sph_ctx *c, int id, int nprops, const int *props, const void *src, size_t cap,
+                                      double h_promise, double m_promise, void *flag_word)
+{
+    if (!c || id < 0 || id >= SPH_MAX_ARRAYS || nprops < 1 || nprops > SPH_PROP_COUNT || !props || !src || !flag_word) {
+        sph_set_error("sph_halo_append_padded: bad arguments");
+        return SPH_ERR_ARG;
+    }
+    if (cap == 0) return SPH_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    size_t n0 = c->arr[id].n;
+    int k_h = -1, k_m = -1;
+    for (int k = 0; k < nprops; k++) {
+        SPH_TRY(sph_array_ensure_prop(c, id, props[k]));
+        if (props[k] == SPH_H) k_h = k;
+        if (props[k] == SPH_M) k_m = k;
+    }
+    // what the neighbour update knows of h and m stays valid when every ghost is promised to carry the array's ONE value
+    // (checked on the device, bit 1 of the flag word): the round-trip-free update goes on
+    DevArray &A0 = c->arr[id];
+    const bool keep_h = k_h >= 0 && h_promise == h_promise && !A0.raw_hm && !A0.h_dirty && A0.h_seen && A0.h_lo == h_promise && A0.h_hi == h_promise;
+    const bool keep_m = k_m >= 0 && m_promise == m_promise && !A0.raw_hm && !A0.m_dirty && A0.m_seen && A0.m_lo == m_promise && A0.m_hi == m_promise;
+    const bool mk = A0.m_known;
+    SPH_TRY(sph_array_resize(c, id, n0 + cap, A0.n_real));
+    DevArray &A = c->arr[id];
+    if (keep_h) A.h_dirty = false;
+    if (keep_m) { A.m_dirty = false; A.m_known = mk; }
+    PropList L;
+    for (int k = 0; k < nprops; k++) { L.p[k] = A.prop[props[k]]; L.what[k] = 0; }
+    hipLaunchKernelGGL(k_halo_append_padded, dim3(div_up(cap, 256), nprops), dim3(256), 0, c->stream, L, (const double *)src, n0, cap,
+                       nprops, k_h, k_m, h_promise, m_promise, (uint32_t *)flag_word);
+    c->nnps_valid = false;
+    return SPH_OK;
+}
+
 __global__ __launch_bounds__(256) void k_halo_image_multi(PropList L, const uint32_t *__restrict__ list, size_t count,
                                                           double val, size_t n0)
 {

@@ -175,6 +175,7 @@ struct sph_ctx {
     size_t sort_tab_entries = 0;  // buckets the tables were zeroed for
     int sort_lbits = 0;           // low key bits sorted inside a bucket (adapted to the largest bucket of the previous sort)
     double sort_bkmax = 0;        // largest bucket of the last sort whose figure has arrived
+    double sort_over = 0;         // ... and its particles in buckets beyond the LDS stage
     long hand_sort = 1;           // option: 0 = profiling aid, the bucket size is not adapted
     // The update without a device->host round trip (option async_update, default 1).  When h and m are known without
     // looking (DevArray::h_dirty / m_dirty) only the bounds of the positions are missing for the grid -- and ANY grid

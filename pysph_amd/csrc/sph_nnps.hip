@@ -62,6 +62,16 @@ __device__ __forceinline__ uint32_t fine_key(double x, double y, double z, const
     cz = min(max(cz, 0), g.nc[2] - 1);
     return (uint32_t)(cx + g.nc[0] * (cy + g.nc[1] * cz)) * SPH_NSUB + (uint32_t)sub;
 }
+// ... of particle i: a NaN position (a padding row of sph_halo_append_padded: never anybody's neighbour) gets a key that
+// depends on i only, spread over the whole table, so that the padding rows do not pile up in one bin
+__device__ __forceinline__ uint32_t fine_key_of(double x, double y, double z, const GridDesc &g, size_t i)
+{
+    if (x != x || y != y || z != z) {
+        const unsigned long long n_fine = (unsigned long long)g.nc[0] * g.nc[1] * g.nc[2] * SPH_NSUB;
+        return (uint32_t)(((unsigned long long)i * 2654435761ull) % n_fine);
+    }
+    return fine_key(x, y, z, g);
+}
 
 // The particle sort, hand-written for gfx950 (it replaces hipCUB's Onesweep passes and their memsets):
 //   fine key = hi : lo, lo = the `lbits` (9..11) low bits.  A BUCKET = the particles of one hi value = 2^lbits
@@ -84,8 +94,9 @@ __device__ __forceinline__ uint32_t fine_key(double x, double y, double z, const
 #define SORT_BIGQ 128      // larger ones: queued, ranked by counting by the whole workgroup (an LDS-staged bucket has at most 124)
 #define SORT_BS 512        // threads of a k_bucket_sort workgroup
 enum { MM_XYZ = 1, MM_H = 2, MM_M = 4 };
-#define MM_OUT_BKMAX 40    // out[]: 8 global values, 4 per array, the largest bucket of the previous sort
-#define MM_OUT_N 41
+#define MM_OUT_BKMAX 40    // out[]: 8 global values, 4 per array, the largest bucket of the previous sort,
+#define MM_OUT_OVER 41     // ... the particles it had in buckets beyond the LDS stage
+#define MM_OUT_N 42
 
 struct BinArrays {   // the arrays of one update, concatenated in slot order
     const double *x[SPH_MAX_ARRAYS], *y[SPH_MAX_ARRAYS], *z[SPH_MAX_ARRAYS], *h[SPH_MAX_ARRAYS], *m[SPH_MAX_ARRAYS];
@@ -96,7 +107,7 @@ struct BinArrays {   // the arrays of one update, concatenated in slot order
 struct BinWork {
     uint32_t *keys;              // fine key of every particle of the concatenation (null: bounds only)
     uint32_t *G, *bstart, *cur;  // bucket histogram (zero on entry and on exit), bucket starts [nbuckets + 1], cursors (zeroed here)
-    uint32_t *ticket;            // [1] largest bucket of the previous sort (read and reset by k_bin_finish)
+    uint32_t *ticket;            // [1] largest bucket of the previous sort, [2] its particles in buckets beyond the LDS stage (read and reset by k_bin_finish)
     double *part, *parta;        // partials per workgroup: [8] {xmin ymin zmin hmin xmax ymax zmax hmax}, [4] {hmin hmax mmin mmax} of its array
     double *out;                 // [0..7] as part, [8 + 4 a ..] {mmin mmax hmin hmax} of array a, [MM_OUT_BKMAX]
     uint32_t nbuckets;
@@ -135,16 +146,20 @@ __global__ __launch_bounds__(256) void k_bin_keys(BinArrays t, GridDesc g, BinWo
         if (valid && m) { const double v = m[i]; mn[4] = fmin(mn[4], v); mx[4] = fmax(mx[4], v); }
         if (w.keys) {
             uint32_t key = 0;
-            if (valid) { key = fine_key(px, py, pz, g); w.keys[(size_t)t.off[a] + i] = key; }
+            if (valid) { key = fine_key_of(px, py, pz, g, i); w.keys[(size_t)t.off[a] + i] = key; }
             const uint32_t d = key >> w.lbits;
             unsigned long long todo = __ballot(valid);
-            while (todo) { // one atomic per bucket the wavefront's particles hit
+            uint32_t cnt = 0; // this lane leads a group of `cnt` particles of one bucket
+            while (todo) {
                 const int l = __builtin_ctzll(todo);
                 const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)d, l);
                 const unsigned long long mk = __ballot(valid && d == dl);
-                if (lane == l) atomicAdd(&w.G[dl], (uint32_t)__builtin_popcountll(mk));
+                if (lane == l) cnt = (uint32_t)__builtin_popcountll(mk);
                 todo &= ~mk;
             }
+            // one atomic per bucket the wavefront's particles hit, all of them in ONE instruction (particles in no
+            // spatial order make 64 groups: 64 single-lane atomic instructions cost 0.35 ms at 4 M)
+            if (cnt) atomicAdd(&w.G[d], cnt);
         }
     }
     __shared__ double s[4][10];
@@ -205,7 +220,10 @@ __global__ __launch_bounds__(1024) void k_bin_finish(BinArrays t, BinWork w, uin
             if (lane == 0) { w.out[8 + 4 * a2] = ml; w.out[9 + 4 * a2] = mh; w.out[10 + 4 * a2] = hl; w.out[11 + 4 * a2] = hh; }
         }
     }
-    if (threadIdx.x == 0) { w.out[MM_OUT_BKMAX] = (double)w.ticket[1]; w.ticket[1] = 0u; }
+    if (threadIdx.x == 0) {
+        w.out[MM_OUT_BKMAX] = (double)w.ticket[1]; w.ticket[1] = 0u;
+        w.out[MM_OUT_OVER] = (double)w.ticket[2]; w.ticket[2] = 0u;
+    }
     if (have_keys) { // bucket starts = exclusive scan of G; G and the cursors zeroed
         __shared__ uint32_t ws[16];
         uint32_t carry = 0;
@@ -282,7 +300,7 @@ struct BucketOut {
     uint32_t *fine_start, *cell_start;
     uint32_t n_fine, n_cells;
     uint2 *scratch;                // n entries (big bins)
-    uint32_t *bkmax;               // largest bucket (atomicMax)
+    uint32_t *bkmax;               // [0] largest bucket (atomicMax), [1] particles in buckets beyond the LDS stage
 };
 
 __global__ __launch_bounds__(SORT_BS) void k_bucket_sort(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ bstart, int lbits,
@@ -417,7 +435,7 @@ __global__ __launch_bounds__(SORT_BS) void k_bucket_sort(const uint2 *__restrict
             o.perm[j] = gpos;
         }
     }
-    if (tid == 0 && s) atomicMax(o.bkmax, s);
+    if (tid == 0) { atomicMax(o.bkmax, s); if (!lds) atomicAdd(o.bkmax + 1, s); }
 }
 
 // ---------------------------------------------------------------------------
@@ -730,9 +748,12 @@ static int sort_choose_lbits(sph_ctx *c, size_t n, size_t n_fine)
         lb = SORT_LMAX;
         while (lb > SORT_LMIN && per_key * (double)(1u << lb) > 0.6 * SORT_BK_CAP) lb--;
     } else if (c->hand_sort) {
-        if (c->sort_bkmax > SORT_BK_CAP && lb > SORT_LMIN) lb--;
+        // smaller buckets only when a good part of the particles sat in buckets beyond the LDS stage (a few dense
+        // buckets -- the walls of a tank in a sparse grid -- are cheaper in global memory than twice the buckets)
+        if (c->sort_over > 0.1 * (double)n && lb > SORT_LMIN) lb--;
         else if (c->sort_bkmax > 0 && c->sort_bkmax * 4 <= SORT_BK_CAP && lb < SORT_LMAX) lb++;
         c->sort_bkmax = 0; // one correction per measurement
+        c->sort_over = 0;
     }
     c->sort_lbits = lb;
     return lb;
@@ -1221,6 +1242,7 @@ static int lag_wait(sph_ctx *c)
         HIP_TRY(hipEventSynchronize(c->lag_ev));
         c->lag.pending = false;
         c->sort_bkmax = c->pin_async[MM_OUT_BKMAX];
+        c->sort_over = c->pin_async[MM_OUT_OVER];
     }
     return SPH_OK;
 }
@@ -1313,7 +1335,9 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
         // these bounds are what the next update may bin on
         memcpy(c->pin_async, mm, sizeof mm);
         c->pin_async[MM_OUT_BKMAX] = c->pinned[MM_OUT_BKMAX];
+        c->pin_async[MM_OUT_OVER] = c->pinned[MM_OUT_OVER];
         c->sort_bkmax = c->pinned[MM_OUT_BKMAX];
+        c->sort_over = c->pinned[MM_OUT_OVER];
         c->lag.valid = !bounds;
         c->lag.pending = false;
     }

@@ -176,6 +176,55 @@ class DeviceHaloOps(object):
         ev.synchronize()
         return self._hdr_pin[:n].tolist()
 
+    # -- the exchange without a device->host round trip ('padded' protocol) ----
+    def append_padded(self, buf, cap, h_promise, m_promise):
+        """all `cap` rows of a fixed-capacity message behind the particles: the
+        first |header| are the ghosts, the rest NaN padding rows (inert on the whole
+        path); the host learns the count an exchange later (sph_halo_append_padded)"""
+        dev._check(self.lib.sph_halo_append_padded(
+            self.ctx._h, self.id, self.nprops, self.props, C.c_void_p(buf.data_ptr()), int(cap),
+            float(h_promise), float(m_promise), C.c_void_p(self.flag_word().data_ptr())))
+
+    def flag_word(self):
+        """device word sph_halo_append_padded ORs into (bit 0: incomplete message, bit 1: broken promise)"""
+        t = self.__dict__.get('_flag')
+        if t is None:
+            t = self._flag = self.torch.zeros(2, dtype=self.torch.int32, device=self.device)
+        return t
+
+    def queue_headers(self, tensors):
+        """the last element of each message and the flag word on their way to pinned
+        memory, behind an event nobody waits for now: `collect_headers` an exchange later"""
+        torch = self.torch
+        n = len(tensors)
+        pin = self.__dict__.get('_hdr_pin2')
+        if pin is None or pin.numel() < n + 1:
+            pin = self._hdr_pin2 = torch.empty(max(n + 1, 64), dtype=torch.float64).pin_memory()
+        vals = torch.stack([t[-1] for t in tensors] + [self.flag_word()[0].to(torch.float64)])
+        pin[:n + 1].copy_(vals, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return (ev, n)
+
+    def collect_headers(self, handle):
+        ev, n = handle
+        ev.synchronize()
+        vals = self._hdr_pin2[:n + 1].tolist()
+        return vals[:n], int(vals[n])
+
+    def hm_range(self):
+        """(hmin, hmax, mmin, mmax) of the real particles (set-up only: one round trip each)"""
+        out = []
+        for prop, fn in (('h', self.lib.sph_reduce_min), ('h', self.lib.sph_reduce_max),
+                         ('m', self.lib.sph_reduce_min), ('m', self.lib.sph_reduce_max)):
+            v = C.c_double()
+            if self.n_real() == 0 or dev.prop_id(prop) not in list(self.props):
+                out.append(float('inf') if fn is self.lib.sph_reduce_min else -float('inf'))
+                continue
+            dev._check(fn(self.ctx._h, self.id, dev.prop_id(prop), C.byref(v)))
+            out.append(v.value)
+        return out
+
     def select_pack(self, lo_cut, hi_cut, shifts, caps, bufs):
         """Both faces selected AND packed on the device, no host round trip:
         bufs[side] (or None) is a message of caps[side] * nprops + 1 doubles,
@@ -237,7 +286,7 @@ class SlabHalo(object):
 
     def __init__(self, pa, ctx, rank, world, axis, width, lo, hi,
                  props=WCSPH_HALO_PROPS, periodic=False, period=0.0,
-                 ops=None, dist=None):
+                 ops=None, dist=None, protocol=None):
         if dist is None:
             import torch.distributed as dist
         self.dist = dist
@@ -254,9 +303,16 @@ class SlabHalo(object):
         # messages with the row count in their last element, sized from the
         # count both ends saw in the previous exchange; 'handshake' = counts
         # all_gather before exactly-sized messages (always used the first time)
-        self.protocol = os.environ.get('SPH_HALO_PROTOCOL', 'capacity')
+        # 'padded' = 'capacity' without the readback: the receiver appends every row of a message, the rows behind the
+        # ghosts as NaN padding, and learns the counts an exchange later (_exchange_padded)
+        self.protocol = protocol or os.environ.get('SPH_HALO_PROTOCOL', 'capacity')
         self.cap_send, self.cap_recv = {}, {}
         self.handshakes = 0               # exchanges that needed the counts round
+        # 'padded' protocol: the promises every ghost keeps (NaN: none), what the last padded exchange left to collect
+        self.h_promise = self.m_promise = float('nan')
+        self.promised = False
+        self.padded_pending = None
+        self.padded_exchanges = 0
 
     def neighbours(self):
         """[(side, peer rank, coordinate shift applied to what we SEND)]"""
@@ -403,14 +459,23 @@ def _exchange_steps(hs, drop, overlap):
     faces talk to the same peer), arrays in the same order on both sides."""
     h0 = hs[0]
     dist, ops0, world, na = h0.dist, h0.ops, h0.world, len(hs)
+    nbrs = h0.neighbours()
+    sides = [s for s, _, _ in nbrs]
+    if nbrs and drop and not overlap and h0.protocol == 'padded' and all(
+            hasattr(h.ops, 'append_padded') and hasattr(h.ops, 'select_pack') and h.promised and
+            getattr(h.ops, '_shares_torch_stream', lambda: True)() and
+            all(h.cap_send.get(s) is not None and h.cap_recv.get(s) is not None for s in sides) for h in hs):
+        _exchange_padded(hs, nbrs)
+        return
+    _padded_collect(hs)           # (a padded exchange may be outstanding: its counts size this one)
     for h in hs:
         if drop:
             h.ops.drop_ghosts()
-    nbrs = h0.neighbours()
     if not nbrs:
         return
-    sides = [s for s, _, _ in nbrs]
-    fixed = h0.protocol == 'capacity' and all(
+    if h0.protocol == 'padded' and not all(h.promised for h in hs):
+        _establish_promises(hs)   # collective; this exchange goes the counted way anyway
+    fixed = h0.protocol in ('capacity', 'padded') and all(
         h.cap_send.get(s) is not None and h.cap_recv.get(s) is not None for h in hs for s in sides)
     # with fixed-capacity messages and device-side packing the host never sees
     # the selection: the counts come back with the headers
@@ -555,6 +620,109 @@ def _exchange_steps(hs, drop, overlap):
         h.last_counts = (send[a][0], send[a][1], recv[a].get(0, 0), recv[a].get(1, 0))
 
 
+def _establish_promises(hs):
+    """'padded' protocol, once: does every rank hold ONE smoothing length and ONE
+    mass per array?  (min/max over the ranks of each array's own range.)  Then
+    every ghost is promised to carry them, and the neighbour update keeps what it
+    knows of h and m across the appends (no look, no round trip); sph_halo_append_padded
+    checks the promise on the device."""
+    h0 = hs[0]
+    lo, hi = [], []
+    for h in hs:
+        r = h.ops.hm_range() if hasattr(h.ops, 'hm_range') else [float('inf'), -float('inf')] * 2
+        lo += [r[0], r[2]]
+        hi += [r[1], r[3]]
+    dev_t = getattr(h0.ops, 'device', None)
+    glo = allreduce_scalars(lo, 'min', dist=h0.dist, device=dev_t)
+    ghi = allreduce_scalars(hi, 'max', dist=h0.dist, device=dev_t)
+    for a, h in enumerate(hs):
+        h.h_promise = glo[2 * a] if glo[2 * a] == ghi[2 * a] else float('nan')
+        h.m_promise = glo[2 * a + 1] if glo[2 * a + 1] == ghi[2 * a + 1] else float('nan')
+        h.promised = True
+
+
+def _padded_collect(hs):
+    """what the last 'padded' exchange sent on its way -- the row counts both ends
+    packed and the device flag word -- read now, one exchange later: capacities
+    follow the counts (the same rule on both ends of a face, from the same pair),
+    an incomplete message or a broken promise is an error (the step that used the
+    ghosts is invalid; it cannot be repaired after the fact)."""
+    h0 = hs[0]
+    pend = h0.padded_pending
+    if pend is None:
+        return
+    h0.padded_pending = None
+    handle, keys = pend
+    vals, flag = h0.ops.collect_headers(handle)
+    nk = len(keys)
+    sent = {k: int(v) for k, v in zip(keys, vals[:nk])}
+    recv = {k: int(v) for k, v in zip(keys, vals[nk:])}
+    for a, h in enumerate(hs):
+        sides = sorted(set(s for aa, s in keys if aa == a))
+        h.last_counts = tuple(abs(sent.get((a, s), 0)) for s in (0, 1)) + tuple(abs(recv.get((a, s), 0)) for s in (0, 1))
+        for s in sides:
+            h.cap_send[s] = _next_capacity(h.cap_send.get(s), abs(sent[(a, s)]))
+            h.cap_recv[s] = _next_capacity(h.cap_recv.get(s), abs(recv[(a, s)]))
+    bad = [k for k in keys if sent[k] < 0 or recv[k] < 0]
+    if bad or flag & 1:
+        raise RuntimeError('padded ghost exchange: a face outgrew its message capacity in ONE exchange %r (counts %r / %r): '
+                           'the ghosts of the last step were incomplete.  SPH_HALO_PROTOCOL=capacity repeats such faces '
+                           'at the price of a device->host round trip per exchange' % (bad, sent, recv))
+    if flag & 2:
+        raise RuntimeError('padded ghost exchange: a ghost arrived with a smoothing length or mass other than the one promised '
+                           'for its array (h or m was written on some rank after the promise was made): the last step '
+                           'ran on wrong record layouts')
+
+
+def _exchange_padded(hs, nbrs):
+    """Ghost refresh with NO device->host round trip ('padded' protocol, steady state):
+    fixed-capacity messages packed on the device as in 'capacity', but the receiver
+    appends ALL rows of a message -- the ghosts and, behind them, NaN padding rows
+    that are inert on the whole path -- so nothing has to be counted before the
+    neighbour update and the evaluation are queued.  Counts and flags follow one
+    exchange later (_padded_collect)."""
+    h0 = hs[0]
+    dist, ops0, na = h0.dist, h0.ops, len(hs)
+    sides = [s for s, _, _ in nbrs]
+    _padded_collect(hs)
+    for h in hs:
+        h.ops.drop_ghosts()
+    shift_of = {s: shift for s, _, shift in nbrs}
+    send_order = sorted(nbrs, key=lambda nb: -nb[0])
+    recv_order = sorted(nbrs, key=lambda nb: nb[0])
+    out, inb = [], []
+    for a, h in enumerate(hs):
+        npr, oa, ia = h.ops.nprops, {}, {}
+        for s in sides:
+            oa[s] = h.ops.message_buffer(('send', s), h.cap_send[s] * npr + 1)
+            ia[s] = h.ops.message_buffer(('recv', s), h.cap_recv[s] * npr + 1)
+        h.ops.select_pack(h.lo + h.width, h.hi - h.width,
+                          [shift_of.get(0, 0.0), shift_of.get(1, 0.0)],
+                          [h.cap_send.get(0, 0), h.cap_send.get(1, 0)],
+                          [oa.get(0), oa.get(1)])
+        out.append(oa)
+        inb.append(ia)
+    for h in hs:
+        f = getattr(h.ops, 'before_comm', None)
+        if f is not None:
+            f()
+    reqs = [dist.P2POp(dist.isend, out[a][s], peer) for s, peer, _ in send_order for a in range(na)]
+    reqs += [dist.P2POp(dist.irecv, inb[a][s], peer) for s, peer, _ in recv_order for a in range(na)]
+    if reqs:
+        for w in dist.batch_isend_irecv(reqs):
+            w.wait()                  # stream-level for device transports: nothing here blocks the host
+    for h in hs:
+        f = getattr(h.ops, 'after_comm', None)
+        if f is not None:
+            f()
+    keys = [(a, s) for a in range(na) for s in sides]
+    for a, h in enumerate(hs):
+        for s, _, _ in nbrs:          # lo side first: deterministic
+            h.ops.append_padded(inb[a][s], h.cap_recv[s], h.h_promise, h.m_promise)
+        h.padded_exchanges += 1
+    h0.padded_pending = (ops0.queue_headers([out[a][s] for a, s in keys] + [inb[a][s] for a, s in keys]), keys)
+
+
 class SlabDecomposition(object):
     """All particle arrays of one rank: what ``ParallelManager.update()``
     (parallel_manager.pyx:512-530) does before an acceleration evaluation --
@@ -564,7 +732,7 @@ class SlabDecomposition(object):
 
     def __init__(self, arrays, ctx, rank, world, axis, width, lo, hi,
                  props=WCSPH_HALO_PROPS, periodic=False, period=0.0,
-                 ops_factory=None, dist=None):
+                 ops_factory=None, dist=None, protocol=None):
         if dist is None:
             import torch.distributed as dist
         self.dist = dist
@@ -575,7 +743,7 @@ class SlabDecomposition(object):
             ops = ops_factory(pa, axis, p) if ops_factory else None
             self.halos.append(SlabHalo(pa, ctx, rank, world, axis, width, lo,
                                        hi, props=p, periodic=periodic,
-                                       period=period, ops=ops, dist=dist))
+                                       period=period, ops=ops, dist=dist, protocol=protocol))
 
     @property
     def lo(self):
@@ -660,6 +828,11 @@ class SlabDecomposition(object):
             rounds += 1
             if total == 0 or rounds > self.world:
                 break
+        # the faces moved: the ghost counts of the next exchange have nothing to do with the last ones -- every rank
+        # (rebalance is collective) sizes its messages anew with a counted exchange
+        for h in self.halos:
+            h.cap_send.clear()
+            h.cap_recv.clear()
         return faces, rounds
 
 
@@ -707,11 +880,22 @@ def allreduce_scalars(values, op, dist=None, device=None):
     return [float(v) for v in t.cpu()]
 
 
-def slab_bounds(coord, world):
+def slab_bounds(coord, world, weights=None):
     """Equal-particle-count slab faces along one axis (the
     dam-break fluid fills 38 % of the tank, geometric slabs would idle):
-    returns world+1 ascending cut positions from the quantiles of `coord`."""
+    returns world+1 ascending cut positions from the quantiles of `coord`.
+    `weights` (one per particle): equal WORK instead of equal count -- a fluid
+    particle of a dam break costs several boundary particles
+    (`SlabDecomposition.rebalance(weights=...)` is the run-time counterpart)."""
     import numpy as np
-    q = np.quantile(np.asarray(coord), np.linspace(0.0, 1.0, world + 1))
+    coord = np.asarray(coord)
+    if weights is None:
+        q = np.quantile(coord, np.linspace(0.0, 1.0, world + 1))
+    else:
+        order = np.argsort(coord, kind='stable')
+        cw = np.cumsum(np.asarray(weights, dtype=np.float64)[order])
+        targets = cw[-1] * np.linspace(0.0, 1.0, world + 1)
+        idx = np.minimum(np.searchsorted(cw, targets, side='left'), coord.size - 1)
+        q = coord[order][idx].astype(np.float64)
     q[0], q[-1] = -np.inf, np.inf
     return q

@@ -402,6 +402,119 @@ def test_fused_two_array_exchange_equals_per_array(tmp_path, periodic):
     assert n0.min() > 0 and n1.min() > 0
 
 
+class NumpyPaddedHaloOps(NumpyDirectHaloOps):
+    """... and with the receive side of sph_halo_append_padded: every row of a
+    message is appended, the rows behind the ghosts as NaN; counts and the flag
+    word are looked at one exchange later"""
+
+    def message_buffer(self, key, size):
+        cache = self.__dict__.setdefault('_messages', {})
+        t = cache.get(key)
+        if t is None or t.numel() != size:
+            t = cache[key] = torch.zeros(size, dtype=torch.float64)
+        return t
+
+    def append_padded(self, buf, cap, h_promise, m_promise):
+        arr = buf.numpy()
+        hdr = arr[self.nprops * cap]
+        count = int(min(abs(hdr), cap))
+        self.flag = getattr(self, 'flag', 0) | (1 if hdr < 0 else 0)
+        n0 = self.pa.get_number_of_particles()
+        nreal = self.n_real()
+        self.pa.resize(n0 + cap)
+        self.pa.set_num_real_particles(nreal)
+        for k, p in enumerate(PROPS):
+            col = np.full(cap, np.nan)
+            col[:count] = arr[k * cap:k * cap + count]
+            if p == 'h' and h_promise == h_promise and np.any(col[:count] != h_promise):
+                self.flag |= 2
+            if p == 'm' and m_promise == m_promise and np.any(col[:count] != m_promise):
+                self.flag |= 2
+            self.pa.properties[p][n0:] = col
+        self.pa.properties['tag'][n0:] = 1
+
+    def queue_headers(self, tensors):
+        return [float(t[-1]) for t in tensors], getattr(self, 'flag', 0)
+
+    def collect_headers(self, handle):
+        return handle
+
+    def hm_range(self):
+        n = self.n_real()
+        if n == 0:
+            return [np.inf, -np.inf, np.inf, -np.inf]
+        h, m = self.pa.properties['h'][:n], self.pa.properties['m'][:n]
+        return [h.min(), h.max(), m.min(), m.max()]
+
+
+def _worker_padded(rank, world, port, periodic, out):
+    """the 'padded' protocol against the counted one: after every exchange the
+    first rows behind the real particles are the same ghosts, the rows behind
+    them NaN; counts arrive one exchange late and move the capacities on both
+    ends alike; an overflowing face is an error one exchange later"""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import pysph_amd.parallel as par
+        from test_hip_parity import make_cube
+        from pysph_amd.particle_array import ParticleArray
+        full, dx = make_cube(12)
+        x = full.x
+        own = np.nonzero(x < 0.5)[0] if rank == 0 else np.nonzero(x >= 0.5)[0]
+        lo, hi = (0.0, 0.5) if rank == 0 else (0.5, 1.0)
+
+        def build(protocol, ops):
+            pa = ParticleArray(name='fluid', **{k: v[own].copy() for k, v in full.properties.items()})
+            h = par.SlabHalo(pa, None, rank, world, axis=0, width=0.1, lo=lo, hi=hi,
+                             periodic=periodic, period=1.0, ops=ops(pa, 0), dist=dist, protocol=protocol)
+            return pa, h
+        pa_c, hc = build('capacity', NumpyDirectHaloOps)
+        pa_p, hp = build('padded', NumpyPaddedHaloOps)
+        log = []
+        for step, width in enumerate((0.1, 0.1, 0.12, 0.05, 0.15, 0.15)):
+            hc.width = hp.width = width
+            hc.exchange()
+            hp.exchange()
+            nr = pa_c.get_number_of_particles(True)
+            nc = pa_c.get_number_of_particles()
+            npad = pa_p.get_number_of_particles()
+            assert npad >= nc
+            # every face's message is appended whole: its ghosts, then its padding rows
+            live = ~np.isnan(pa_p.properties['x'][:npad])
+            assert live[:nr].all() and live.sum() == nc
+            for k in PROPS:
+                assert np.array_equal(pa_c.properties[k][:nc], pa_p.properties[k][:npad][live]), (step, k)
+                assert np.all(np.isnan(pa_p.properties[k][:npad][~live])), (step, k)
+            log.append((hp.padded_exchanges, npad - nc))
+        assert hp.handshakes == 1 and hp.padded_exchanges == 5
+        assert hp.h_promise == hp.h_promise and hp.m_promise == hp.m_promise     # the cube has one h and one m
+        # counts arrived one exchange late
+        par._padded_collect([hp])
+        assert hp.last_counts == hc.last_counts
+        # a face that outgrows its capacity in ONE exchange: loud, one exchange later
+        hp.cap_send = {s: 8 for s in hp.cap_send}
+        hp.cap_recv = {s: 8 for s in hp.cap_recv}
+        hp.exchange()
+        try:
+            hp.exchange()
+            raised = False
+        except RuntimeError as e:
+            raised = 'outgrew its message capacity' in str(e)
+        assert raised
+        np.save(out % rank, np.array(log))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('periodic', [False, True])
+def test_padded_protocol_equals_capacity_protocol(tmp_path, periodic):
+    out = str(tmp_path / 'padded_%d.npy')
+    mp.spawn(_worker_padded, args=(2, _free_port(), periodic, out), nprocs=2, join=True)
+    a = np.load(out % 0)
+    assert a.shape == (6, 2) and a[-1, 0] == 5 and a[1:, 1].min() > 0
+
+
 def _worker_protocols(rank, world, port, periodic, out):
     """the fixed-capacity ghost messages against the counts handshake: same ghost
     rows after every exchange while the slab faces (and so the counts) move;
