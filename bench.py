@@ -629,8 +629,8 @@ def parse_args(argv=None):
                     help='dam_break over several ranks: work of a boundary / obstacle particle relative to a fluid '
                          'particle when the slab faces are cut (1: equal particle counts)')
     ap.add_argument('--halo-protocol', default='padded', dest='halo_protocol', choices=['padded', 'capacity', 'handshake'],
-                    help='ghost exchange of slab runs: padded (default) = fixed-capacity messages appended whole, NaN padding '
-                         'rows behind the ghosts, no device->host round trip; capacity = the same messages, the row counts '
+                    help='ghost exchange of slab runs: padded (default) = fixed-capacity messages appended whole, padding '
+                         'rows parked far away behind the ghosts, no device->host round trip; capacity = the same messages, the row counts '
                          'read back every exchange; handshake = counts all_gather before exactly sized messages')
     ap.add_argument('--emulate-rank', default=None, dest='emulate_rank', metavar='r/N',
                     help='dam_break on ONE GPU: rank r of an N-rank strong-scaling run, its slab plus the ghost layers '
@@ -896,7 +896,7 @@ def run(args, rank, local_rank, world, dist):
         pairs = nnps.count_neighbors(0, 0)
     pair_ms, pair_launches = timers['pair']
     n_total = n_local * world          # real particles only (ghosts are extra work)
-    if w.scaling == 'strong':
+    if w.scaling == 'strong' and dist is not None:
         tn = torch.tensor([float(n_local)], dtype=torch.float64, device='cuda')
         dist.all_reduce(tn, op=dist.ReduceOp.SUM)
         n_total = int(tn.item())
@@ -1249,7 +1249,7 @@ def projected_strong_scaling(args, local_rank, tstream, world=8, dx=0.0035, t_on
     import copy
     import torch
     from pysph_amd import device as dev
-    out = {'world': world, 'dx': dx, 'ranks': {}}
+    out = {'world': world, 'dx': dx, 'slab_weight_solid': args.slab_weight_solid, 'halo_protocol': args.halo_protocol, 'ranks': {}}
     t_max, n_max = 0.0, 0
     for r in range(world):
         a2 = copy.copy(args)
@@ -1265,6 +1265,7 @@ def projected_strong_scaling(args, local_rank, tstream, world=8, dx=0.0035, t_on
             nall = sum(a.get_number_of_particles() for a in w.arrays)
             ms = elapsed / steps * 1e3
             out['ranks'][str(r)] = {'real_particles': nreal, 'ghost_particles': nall - nreal, 'ms_per_step': ms,
+                                    'real_per_array': {a.name: a.get_number_of_particles(True) for a in w.arrays},
                                     'kernel_ms_per_step': {k: timers[k][0] / steps for k in ('nnps', 'pack', 'eos', 'pair')}}
             if ms > t_max:
                 t_max, n_max = ms, nreal
@@ -1297,6 +1298,7 @@ def projected_strong_scaling(args, local_rank, tstream, world=8, dx=0.0035, t_on
             nnps, a_eval, halo, domain, step, ordered = setup(a2, w, 0, 1, dist, ctx)
             elapsed, timers = timed(10, 3, step, torch.cuda.synchronize, ctx)
             ex[name] = elapsed / 10 * 1e3
+            ex[name + '_kernels'] = sum(timers[k][0] for k in ('nnps', 'pack', 'eos', 'pair')) / 10
             del nnps, a_eval, step, w, halo
         except Exception as e:
             ex[name] = None
@@ -1310,7 +1312,10 @@ def projected_strong_scaling(args, local_rank, tstream, world=8, dx=0.0035, t_on
         dist.destroy_process_group()
     out['exchange_stand_in'] = {'cube_side': n1, 'ms_per_step': ex}
     if ex.get('plain') and ex.get('self_slab'):
-        out['exchange_ms'] = max(ex['self_slab'] - ex['plain'], 0.0)
+        # what the slab transport adds to a step, and the part of it that is NOT the neighbour update / records / pair
+        # loops of the extra (ghost) particles -- those a rank's emulated step above already contains
+        out['self_slab_minus_plain_ms'] = max(ex['self_slab'] - ex['plain'], 0.0)
+        out['exchange_ms'] = max(out['self_slab_minus_plain_ms'] - max(ex['self_slab_kernels'] - ex['plain_kernels'], 0.0), 0.0)
     out['slowest_rank_ms'] = t_max
     if t_one_gpu_ms and t_max > 0 and out.get('exchange_ms') is not None:
         out['t_one_gpu_ms'] = t_one_gpu_ms

@@ -425,8 +425,10 @@ int sph_read_values(sph_ctx *ctx, int n, const void *const *dev_ptrs, double *ou
 /* sph_halo_append from a message whose rows are `stride` doubles apart
  * (property k of row i at src[k * stride + i], stride >= count).            */
 /* The same message appended WITHOUT a device->host round trip (round 5): all `cap` rows go behind the particles, the
- * first |header| of them are the ghosts, the rest PADDING ROWS with NaN in every listed property -- inert on the whole
- * path (bounds, keys, distance tests; ghosts are never destinations), so the host needs no count to size anything.
+ * first |header| of them are the ghosts, the rest PADDING ROWS parked at x = y = z = 1e18 with every other listed property
+ * zero -- inert on the whole path (the bounds and keys of sph_nnps_update skip / spread positions beyond 1e17, every
+ * distance test fails by 1e36, ghosts are never destinations) and finite everywhere -- so the host needs no count to
+ * size anything.  Real coordinates must stay below 1e17 in magnitude.
  * h_promise / m_promise (NaN: none): every ghost is promised to carry this smoothing length / mass (the ONE value of the
  * array on every rank, established collectively by the caller); then the neighbour update keeps what it knows of h and m.
  * flag_word: a DEVICE uint32 the kernel ORs into -- bit 0: the message was incomplete (negative header), bit 1: a ghost

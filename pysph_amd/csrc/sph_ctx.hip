@@ -141,7 +141,7 @@ int sph_ctx_destroy(sph_ctx *c)
     for (auto &H : c->halo)
         for (int s = 0; s < 2; s++) { H.flag[s].release(); H.pos[s].release(); H.list[s].release(); }
     for (DevBuf *b : {&c->dbgc, &c->gapq, &c->cub_tmp, &c->red_part, &c->red_out, &c->posh, &c->aux, &c->fposb, &c->dkeys, &c->dperm,
-                      &c->tmp_u32a, &c->tmp_u32b, &c->gen_state, &c->nlbuf, &c->splitcnt, &c->scan_part, &c->bigq, &c->sort_tab})
+                      &c->tmp_u32a, &c->tmp_u32b, &c->gen_state, &c->nlbuf, &c->splitcnt, &c->scan_part, &c->bigq, &c->sort_tab, &c->xflag})
         b->release();
     for (auto &b : c->csr_start) b.release();
     for (auto &b : c->csr_nbrs) b.release();

@@ -410,6 +410,7 @@ struct PackMArgs {
     int f32, lds_np;
     double gmin[3];
     double hr;                     // radius_scale * h (uniform h)
+    uint32_t *rho_flag;            // device word: set to 1 when a density is not positive (the class bit is the SIGN of rho)
 };
 
 __global__ __launch_bounds__(256) void k_pack_merged(PackMArgs a)
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(256) void k_pack_merged(PackMArgs a)
     const double rho = v[6];
     const double q = rho != 0.0 ? v[7] * (1.0 / (rho * rho)) : 0.0; // tmpj = p*rhoj21, wc/basic.py:211,234 (as k_pack, derived 1)
     const double srho = ((a.cls >> sl) & 1u) ? -rho : rho;
+    if (!(rho > 0.0)) atomicOr(a.rho_flag, 1u); // rho <= 0 (or NaN): this record's class bit is not to be trusted
     a.fpos[i] = make_float4((float)(v[0] - a.gmin[0]), (float)(v[1] - a.gmin[1]), (float)(v[2] - a.gmin[2]), (float)a.hr);
     double2 pc[PACK_MAXP];
 #pragma unroll
@@ -1677,6 +1679,7 @@ static int eval_group_merged(sph_ctx *c, const sph_kernel *K, const sph_group *g
 {
     *done = false;
     if (!c->merged_valid || !c->merge_arrays || !c->nnps_valid || c->pair_variant != 6 || c->ablate || c->count_iters) return SPH_OK;
+    if (c->merge_blocked || !c->xflag.ptr) return SPH_OK; // a non-positive density was seen: the sign of rho cannot carry the class
     if (g->phase != 0 || c->ghosts_binned) return SPH_OK; // ghost segments: the per-destination path reads them as extra sources
     if (!(g->src_eos == 1 && c->eos_fuse && c->mass_fuse && c->const_flags && c->uniform_h && c->use_uniform_h &&
           g->eos_par[2] == 7.0 && g->eos_par[0] > 0.0 && !c->record_f32 && !c->wcsph_nr))
@@ -1788,6 +1791,7 @@ static int eval_group_merged(sph_ctx *c, const sph_kernel *K, const sph_group *g
         pa.f32 = f32 ? 1 : 0; pa.lds_np = f32 ? 2 : 4;
         for (int k = 0; k < 3; k++) pa.gmin[k] = c->xmin[k];
         pa.hr = c->radius_scale * c->h_uniform;
+        pa.rho_flag = c->xflag.as<uint32_t>();
         hipLaunchKernelGGL(k_pack_merged, dim3(div_up(M.n, 256)), dim3(256), (size_t)pa.lds_np * 256 * 16, c->stream, pa);
     }
     ScopedTimer tm(c, T_PAIR);

@@ -367,11 +367,13 @@ extern "C" int sph_halo_append_strided(sph_ctx *c, int id, int nprops, const int
 }
 
 // Rows of a fixed-capacity message appended WITHOUT the host knowing how many there are: all `cap` rows of the message
-// go behind the particles; the first |header| of them are the ghosts, the rest are PADDING ROWS with NaN in every listed
-// property.  A NaN position is inert everywhere on the path: fmin / fmax of the bounds skip it, its key is spread over
-// the grid (fine_key_of), no distance test against it is true, and ghosts are never destinations.  flag (device word,
-// sticky): bit 0 = the message was incomplete (negative header: more rows than its capacity), bit 1 = a ghost's h or m
-// differs from the promised one.
+// go behind the particles; the first |header| of them are the ghosts, the rest are PADDING ROWS: parked at
+// x = y = z = SPH_PARKED (1e18, far outside any domain), every other listed property zero.  A parked row is inert on the
+// whole path and FINITE everywhere (the pair kernels multiply failed candidates by zero, a NaN would poison the sums):
+// the bounds reduction and the keys of sph_nnps_update skip / spread it (|x| >= SPH_PARKED_MIN), the fp32 prefilter and
+// every exact distance test fail against it by 1e36, and ghosts are never destinations.  flag (device word, sticky):
+// bit 0 = the message was incomplete (negative header: more rows than its capacity), bit 1 = a ghost's h or m differs
+// from the promised one.
 __global__ __launch_bounds__(256) void k_halo_append_padded(PropList L, const double *__restrict__ src, size_t n0, size_t cap,
                                                             int nprops, int k_h, int k_m, double h_promise, double m_promise,
                                                             uint32_t *__restrict__ flag)
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(256) void k_halo_append_padded(PropList L, const do
     const double hdr = src[(size_t)nprops * cap];
     const size_t count = (size_t)fmin(fabs(hdr), (double)cap);
     if (i == 0 && k == 0 && hdr < 0.0) atomicOr(flag, 1u);
-    double v = __builtin_nan("");
+    double v = L.what[k] ? SPH_PARKED : 0.0;
     if (i < count) {
         v = src[(size_t)k * cap + i];
         if ((k == k_h && h_promise == h_promise && v != h_promise) || (k == k_m && m_promise == m_promise && v != m_promise)) atomicOr(flag, 2u);
@@ -417,7 +419,7 @@ extern "C" int sph_halo_append_padded(sph_ctx *c, int id, int nprops, const int 
     if (keep_h) A.h_dirty = false;
     if (keep_m) { A.m_dirty = false; A.m_known = mk; }
     PropList L;
-    for (int k = 0; k < nprops; k++) { L.p[k] = A.prop[props[k]]; L.what[k] = 0; }
+    for (int k = 0; k < nprops; k++) { L.p[k] = A.prop[props[k]]; L.what[k] = props[k] == SPH_X || props[k] == SPH_Y || props[k] == SPH_Z; }
     hipLaunchKernelGGL(k_halo_append_padded, dim3(div_up(cap, 256), nprops), dim3(256), 0, c->stream, L, (const double *)src, n0, cap,
                        nprops, k_h, k_m, h_promise, m_promise, (uint32_t *)flag_word);
     c->nnps_valid = false;

@@ -104,6 +104,10 @@ struct PackCache {
     int fam = -1, sig = 0;
 };
 
+// padding rows of sph_halo_append_padded: parked far outside any domain, skipped by the bounds and spread by the keys
+#define SPH_PARKED 1e18
+#define SPH_PARKED_MIN 1e17
+
 // property `prop` of the array is (or may be) written
 static inline void sph_mark_written(DevArray &A, int prop)
 {
@@ -155,6 +159,12 @@ struct sph_ctx {
     bool merged_valid = false;
     long merge_arrays = 1;
     int phase_sig = -1;     // record layout the first half of a split evaluation packed (the second half repacks when its own differs)
+    // The merged records carry a particle's class in the SIGN of rho.  k_pack_merged raises this device word when it meets a
+    // density that is not positive; the neighbour updates carry the word to the host with their bounds (no round trip of
+    // its own): the update that sees it returns an error -- the evaluations since the density went bad ran with wrong
+    // classes -- and the context takes the per-destination path from then on.
+    DevBuf xflag;
+    bool merge_blocked = false;
     long split_pair = 0;    // split evaluations: 1 = interior wave tiles in phase 1, face tiles in phase 2 (default: all tiles in phase 2)
     long tension_flag = 1;  // elastic rates: r_ij gathered only when the source array's tension word says so
     // ... built FIRST by sph_nnps_update (one stable sort of all arrays' keys); the per-array orders and tables are a

@@ -62,11 +62,12 @@ __device__ __forceinline__ uint32_t fine_key(double x, double y, double z, const
     cz = min(max(cz, 0), g.nc[2] - 1);
     return (uint32_t)(cx + g.nc[0] * (cy + g.nc[1] * cz)) * SPH_NSUB + (uint32_t)sub;
 }
-// ... of particle i: a NaN position (a padding row of sph_halo_append_padded: never anybody's neighbour) gets a key that
-// depends on i only, spread over the whole table, so that the padding rows do not pile up in one bin
+// ... of particle i: a parked position (a padding row of sph_halo_append_padded: never anybody's neighbour) gets a key
+// that depends on i only, spread over the whole table, so that the padding rows do not pile up in one bin
+__device__ __forceinline__ bool is_parked(double x) { return fabs(x) >= SPH_PARKED_MIN; }
 __device__ __forceinline__ uint32_t fine_key_of(double x, double y, double z, const GridDesc &g, size_t i)
 {
-    if (x != x || y != y || z != z) {
+    if (is_parked(x)) {
         const unsigned long long n_fine = (unsigned long long)g.nc[0] * g.nc[1] * g.nc[2] * SPH_NSUB;
         return (uint32_t)(((unsigned long long)i * 2654435761ull) % n_fine);
     }
@@ -96,7 +97,8 @@ __device__ __forceinline__ uint32_t fine_key_of(double x, double y, double z, co
 enum { MM_XYZ = 1, MM_H = 2, MM_M = 4 };
 #define MM_OUT_BKMAX 40    // out[]: 8 global values, 4 per array, the largest bucket of the previous sort,
 #define MM_OUT_OVER 41     // ... the particles it had in buckets beyond the LDS stage
-#define MM_OUT_N 42
+#define MM_OUT_XFLAG 42    // the context's device flag word (sph_ctx::xflag: a non-positive density met by the merged records)
+#define MM_OUT_N 43
 
 struct BinArrays {   // the arrays of one update, concatenated in slot order
     const double *x[SPH_MAX_ARRAYS], *y[SPH_MAX_ARRAYS], *z[SPH_MAX_ARRAYS], *h[SPH_MAX_ARRAYS], *m[SPH_MAX_ARRAYS];
@@ -109,7 +111,8 @@ struct BinWork {
     uint32_t *G, *bstart, *cur;  // bucket histogram (zero on entry and on exit), bucket starts [nbuckets + 1], cursors (zeroed here)
     uint32_t *ticket;            // [1] largest bucket of the previous sort, [2] its particles in buckets beyond the LDS stage (read and reset by k_bin_finish)
     double *part, *parta;        // partials per workgroup: [8] {xmin ymin zmin hmin xmax ymax zmax hmax}, [4] {hmin hmax mmin mmax} of its array
-    double *out;                 // [0..7] as part, [8 + 4 a ..] {mmin mmax hmin hmax} of array a, [MM_OUT_BKMAX]
+    double *out;                 // [0..7] as part, [8 + 4 a ..] {mmin mmax hmin hmax} of array a, [MM_OUT_BKMAX ...]
+    const uint32_t *xflag;       // the context's flag word, copied to out[MM_OUT_XFLAG]
     uint32_t nbuckets;
     int lbits, mm;
 };
@@ -137,13 +140,14 @@ __global__ __launch_bounds__(256) void k_bin_keys(BinArrays t, GridDesc g, BinWo
         const bool valid = i < n;
         double px = 0, py = 0, pz = 0;
         if (valid) { px = x[i]; py = y[i]; pz = z[i]; }
-        if (valid && mmx) {
+        const bool counts = valid && !is_parked(px); // padding rows (sph_halo_append_padded) are nobody's bounds, h or m
+        if (counts && mmx) {
             mn[0] = fmin(mn[0], px); mx[0] = fmax(mx[0], px);
             mn[1] = fmin(mn[1], py); mx[1] = fmax(mx[1], py);
             mn[2] = fmin(mn[2], pz); mx[2] = fmax(mx[2], pz);
         }
-        if (valid && h) { const double v = h[i]; mn[3] = fmin(mn[3], v); mx[3] = fmax(mx[3], v); }
-        if (valid && m) { const double v = m[i]; mn[4] = fmin(mn[4], v); mx[4] = fmax(mx[4], v); }
+        if (counts && h) { const double v = h[i]; mn[3] = fmin(mn[3], v); mx[3] = fmax(mx[3], v); }
+        if (counts && m) { const double v = m[i]; mn[4] = fmin(mn[4], v); mx[4] = fmax(mx[4], v); }
         if (w.keys) {
             uint32_t key = 0;
             if (valid) { key = fine_key_of(px, py, pz, g, i); w.keys[(size_t)t.off[a] + i] = key; }
@@ -223,26 +227,37 @@ __global__ __launch_bounds__(1024) void k_bin_finish(BinArrays t, BinWork w, uin
     if (threadIdx.x == 0) {
         w.out[MM_OUT_BKMAX] = (double)w.ticket[1]; w.ticket[1] = 0u;
         w.out[MM_OUT_OVER] = (double)w.ticket[2]; w.ticket[2] = 0u;
+        w.out[MM_OUT_XFLAG] = (double)*w.xflag;
     }
     if (have_keys) { // bucket starts = exclusive scan of G; G and the cursors zeroed
+        // 32 consecutive buckets per thread and round (one round up to 32 Ki buckets: the loads of a round are in flight
+        // together; a sparse grid -- the slab of a dam break's tank -- has tens of thousands of buckets)
         __shared__ uint32_t ws[16];
+        constexpr int PT = 32;
         uint32_t carry = 0;
-        for (uint32_t base = 0; base < w.nbuckets; base += 1024 * 8) {
-            uint32_t v[8], sum = 0;
+        for (uint32_t base = 0; base < w.nbuckets; base += 1024 * PT) {
+            uint32_t v[PT], sum = 0;
+            const uint32_t i0 = base + threadIdx.x * PT;
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const uint32_t idx = base + threadIdx.x * 8 + q;
-                v[q] = idx < w.nbuckets ? w.G[idx] : 0u;
-                sum += v[q];
+            for (int q = 0; q < PT; q += 4) {
+                if (i0 + q + 3 < w.nbuckets) { // (tables are 16-byte aligned, i0 a multiple of 32)
+                    const uint4 t4 = *reinterpret_cast<const uint4 *>(w.G + i0 + q);
+                    v[q] = t4.x; v[q + 1] = t4.y; v[q + 2] = t4.z; v[q + 3] = t4.w;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[q + r] = i0 + q + r < w.nbuckets ? w.G[i0 + q + r] : 0u;
+                }
             }
+#pragma unroll
+            for (int q = 0; q < PT; q++) sum += v[q];
             const uint32_t incl = wave_incl_scan<uint32_t>(sum, lane);
             if (lane == 63) ws[wv] = incl;
             __syncthreads();
             uint32_t off = carry + incl - sum, tot = 0;
             for (int q = 0; q < 16; q++) { if (q < wv) off += ws[q]; tot += ws[q]; }
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const uint32_t idx = base + threadIdx.x * 8 + q;
+            for (int q = 0; q < PT; q++) {
+                const uint32_t idx = i0 + q;
                 if (idx < w.nbuckets) { w.bstart[idx] = off; off += v[q]; w.G[idx] = 0u; w.cur[idx] = 0u; }
             }
             carry += tot;
@@ -303,124 +318,111 @@ struct BucketOut {
     uint32_t *bkmax;               // [0] largest bucket (atomicMax), [1] particles in buckets beyond the LDS stage
 };
 
-__global__ __launch_bounds__(SORT_BS) void k_bucket_sort(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ bstart, int lbits,
-                                                         BucketOut o)
+// One unit of the bucket sort: the `cnt_all` pairs at `src` whose low key bits lie in the sub-range [k_lo, k_hi) of the
+// bucket's 2^lbits bins (the whole bucket: [0, NL)) -- counted, scanned, scattered into the LDS stage, every bin put into
+// ascending index order, emitted at `out0` + their rank.  WHOLE: the unit is the whole bucket and fits the stage (its
+// pairs are loaded once into registers and serve both sweeps); else the pairs are filtered from the bucket twice.
+// Returns the number of pairs of the unit.  All threads of the workgroup call it together.
+template <int BS, int CAP, bool WHOLE>
+__device__ __forceinline__ uint32_t bucket_unit(const uint2 *__restrict__ src, uint32_t cnt_all, uint32_t k_lo, uint32_t k_hi, uint32_t NL,
+                                                uint32_t mask, size_t fk0, uint32_t out0, const BucketOut &o, uint32_t *tab, uint2 *stage,
+                                                uint32_t *ws, uint32_t *bigq, uint32_t *nbig, bool &overflow)
 {
-    constexpr int NW = SORT_BS / 64, PT = (SORT_BK_CAP + SORT_BS - 1) / SORT_BS; // wavefronts; pairs a thread holds of an LDS-staged bucket
-    __shared__ uint32_t tab[1 << SORT_LMAX];
-    __shared__ uint2 stage[SORT_BK_CAP];
-    __shared__ uint32_t ws[NW], bigq[SORT_BIGQ], nbig;
-    const uint32_t tid = threadIdx.x, NL = 1u << lbits, mask = NL - 1u;
+    constexpr int NW = BS / 64, PT = (CAP + BS - 1) / BS, PB = (1 << SORT_LMAX) / BS; // wavefronts; pairs / bins per thread
+    const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    const uint32_t base = bstart[blockIdx.x], s = bstart[blockIdx.x + 1] - base;
-    if (s == 0) { // an empty bucket (the air of a dam break's tank): its slice of the tables is one value
-        const size_t f0 = (size_t)blockIdx.x * NL;
-        for (uint32_t k = tid; k < NL; k += SORT_BS) {
-            const size_t fk = f0 + k;
-            if (fk <= o.n_fine) { o.fine_start[fk] = base; if (fk % SPH_NSUB == 0) o.cell_start[fk / SPH_NSUB] = base; }
-        }
-        return;
-    }
-    const bool lds = s <= SORT_BK_CAP;
-    uint2 mine[PT]; // (the loads of an LDS-staged bucket are issued together and serve both sweeps)
-    if (lds) {
+    uint2 mine[PT];
+    if (WHOLE) {
 #pragma unroll
-        for (int q = 0; q < PT; q++) { const uint32_t i = tid + q * SORT_BS; mine[q] = i < s ? pairs[(size_t)base + i] : make_uint2(0u, 0u); }
+        for (int q = 0; q < PT; q++) { const uint32_t i = tid + q * BS; mine[q] = i < cnt_all ? src[i] : make_uint2(0u, 0u); }
     }
-    for (uint32_t k = tid; k < NL; k += SORT_BS) tab[k] = 0u;
-    if (tid == 0) nbig = 0u;
+    for (uint32_t k = tid; k < NL; k += BS) tab[k] = 0u;
+    if (tid == 0) *nbig = 0u;
     __syncthreads();
-    if (lds) {
+    if (WHOLE) {
 #pragma unroll
-        for (int q = 0; q < PT; q++) if (tid + q * SORT_BS < s) atomicAdd(&tab[mine[q].x & mask], 1u);
+        for (int q = 0; q < PT; q++) if (tid + q * BS < cnt_all) atomicAdd(&tab[mine[q].x & mask], 1u);
     } else {
-        for (uint32_t i = tid; i < s; i += SORT_BS) atomicAdd(&tab[pairs[(size_t)base + i].x & mask], 1u);
+        for (uint32_t i = tid; i < cnt_all; i += BS) { const uint32_t lo = src[i].x & mask; if (lo >= k_lo && lo < k_hi) atomicAdd(&tab[lo], 1u); }
     }
     __syncthreads();
-    { // exclusive scan of the bin counts: NL / SORT_BS consecutive bins per thread
-        const uint32_t per = NL / SORT_BS;
-        uint32_t v[4], sum = 0;
+    uint32_t total;
+    { // exclusive scan of the bin counts: NL / BS consecutive bins per thread
+        const uint32_t per = NL / BS;
+        uint32_t v[PB], sum = 0;
 #pragma unroll
-        for (uint32_t q = 0; q < 4; q++) { v[q] = q < per ? tab[tid * per + q] : 0u; sum += v[q]; }
+        for (uint32_t q = 0; q < PB; q++) { v[q] = q < per ? tab[tid * per + q] : 0u; sum += v[q]; }
         const uint32_t incl = wave_incl_scan<uint32_t>(sum, lane);
         if (lane == 63) ws[wv] = incl;
         __syncthreads();
         uint32_t off = incl - sum;
-        for (int q = 0; q < wv; q++) off += ws[q];
+        total = 0;
+        for (int q = 0; q < NW; q++) { if (q < wv) off += ws[q]; total += ws[q]; }
 #pragma unroll
-        for (uint32_t q = 0; q < 4; q++) if (q < per) { tab[tid * per + q] = off; off += v[q]; }
+        for (uint32_t q = 0; q < PB; q++) if (q < per) { tab[tid * per + q] = off; off += v[q]; }
     }
     __syncthreads();
-    // this bucket's slice of the tables: fine_start[k] = first sorted position whose key >= k (the last bucket holds the
-    // end entry fine_start[n_fine]), cell_start[c] = fine_start[c * SPH_NSUB]
-    const size_t fk0 = (size_t)blockIdx.x * NL;
-    for (uint32_t k = tid; k < NL; k += SORT_BS) {
+    // the unit's slice of the tables: fine_start[k] = first sorted position whose key >= k (the bucket that holds key
+    // n_fine writes the end entry), cell_start[c] = fine_start[c * SPH_NSUB]
+    for (uint32_t k = k_lo + tid; k < k_hi; k += BS) {
         const size_t fk = fk0 + k;
         if (fk <= o.n_fine) {
-            const uint32_t v = base + tab[k];
+            const uint32_t v = out0 + tab[k];
             o.fine_start[fk] = v;
             if (fk % SPH_NSUB == 0) o.cell_start[fk / SPH_NSUB] = v;
         }
     }
+    overflow = total > (uint32_t)CAP; // (uniform: every thread has the same total)
+    if (overflow) return total;       // the caller splits the unit further, or sorts it in global memory
     __syncthreads();
-    if (lds) {
+    if (WHOLE) {
 #pragma unroll
         for (int q = 0; q < PT; q++)
-            if (tid + q * SORT_BS < s) {
+            if (tid + q * BS < cnt_all) {
                 const uint32_t lo = mine[q].x & mask, pos = atomicAdd(&tab[lo], 1u);
                 stage[pos] = make_uint2(lo, mine[q].y);
             }
     } else {
-        for (uint32_t i = tid; i < s; i += SORT_BS) {
-            const uint2 p = pairs[(size_t)base + i];
-            const uint32_t lo = p.x & mask, pos = atomicAdd(&tab[lo], 1u);
-            o.fkeys[(size_t)base + pos] = lo; o.perm[(size_t)base + pos] = p.y;
+        for (uint32_t i = tid; i < cnt_all; i += BS) {
+            const uint2 p = src[i];
+            const uint32_t lo = p.x & mask;
+            if (lo >= k_lo && lo < k_hi) { const uint32_t pos = atomicAdd(&tab[lo], 1u); stage[pos] = make_uint2(lo, p.y); }
         }
     }
     __syncthreads();
     // every bin into ascending index order (tab[k] is now the END of bin k)
-    for (uint32_t k = tid; k < NL; k += SORT_BS) {
-        const uint32_t b0 = k ? tab[k - 1] : 0u, b1 = tab[k], c = b1 - b0;
+    for (uint32_t k = k_lo + tid; k < k_hi; k += BS) {
+        const uint32_t b0 = k > k_lo ? tab[k - 1] : 0u, b1 = tab[k], c = b1 - b0;
         if (c < 2) continue;
         if (c > SORT_BIN_SMALL) {
-            const uint32_t q = atomicAdd(&nbig, 1u);
+            const uint32_t q = atomicAdd(nbig, 1u);
             if (q < SORT_BIGQ) { bigq[q] = k; continue; }
         }
-        if (lds) {
-            for (uint32_t i = b0 + 1; i < b1; i++) {
-                const uint32_t xv = stage[i].y;
-                uint32_t j = i;
-                while (j > b0 && stage[j - 1].y > xv) { stage[j].y = stage[j - 1].y; j--; }
-                stage[j].y = xv;
-            }
-        } else {
-            uint32_t *pm = o.perm + base;
-            for (uint32_t i = b0 + 1; i < b1; i++) {
-                const uint32_t xv = pm[i];
-                uint32_t j = i;
-                while (j > b0 && pm[j - 1] > xv) { pm[j] = pm[j - 1]; j--; }
-                pm[j] = xv;
-            }
+        for (uint32_t i = b0 + 1; i < b1; i++) {
+            const uint32_t xv = stage[i].y;
+            uint32_t j = i;
+            while (j > b0 && stage[j - 1].y > xv) { stage[j].y = stage[j - 1].y; j--; }
+            stage[j].y = xv;
         }
     }
     __syncthreads();
-    const uint32_t nq = min(nbig, (uint32_t)SORT_BIGQ);
+    const uint32_t nq = min(*nbig, (uint32_t)SORT_BIGQ);
     for (uint32_t q = 0; q < nq; q++) { // dense bins (coincident particles): rank by counting
-        const uint32_t k = bigq[q], b0 = k ? tab[k - 1] : 0u, c = tab[k] - b0;
-        uint2 *scr = o.scratch + base + b0;
-        for (uint32_t i = tid; i < c; i += SORT_BS) scr[i] = make_uint2(k, lds ? stage[b0 + i].y : o.perm[(size_t)base + b0 + i]);
+        const uint32_t k = bigq[q], b0 = k > k_lo ? tab[k - 1] : 0u, c = tab[k] - b0;
+        uint2 *scr = o.scratch + out0 + b0;
+        for (uint32_t i = tid; i < c; i += BS) scr[i] = stage[b0 + i];
         __syncthreads();
-        for (uint32_t i = tid; i < c; i += SORT_BS) {
+        for (uint32_t i = tid; i < c; i += BS) {
             const uint32_t xv = scr[i].y;
             uint32_t r = 0;
             for (uint32_t j = 0; j < c; j++) r += scr[j].y < xv;
-            if (lds) stage[b0 + r].y = xv; else o.perm[(size_t)base + b0 + r] = xv;
+            stage[b0 + r].y = xv;
         }
         __syncthreads();
     }
-    for (uint32_t p = tid; p < s; p += SORT_BS) {
-        const size_t j = (size_t)base + p;
-        const uint32_t lo = lds ? stage[p].x : o.fkeys[j], gpos = lds ? stage[p].y : o.perm[j];
+    for (uint32_t p = tid; p < total; p += BS) {
+        const size_t j = (size_t)out0 + p;
+        const uint32_t lo = stage[p].x, gpos = stage[p].y;
         const uint32_t fk = (uint32_t)fk0 + lo;
         o.fkeys[j] = fk;
         if (o.keys) o.keys[j] = fk / SPH_NSUB;
@@ -435,7 +437,120 @@ __global__ __launch_bounds__(SORT_BS) void k_bucket_sort(const uint2 *__restrict
             o.perm[j] = gpos;
         }
     }
-    if (tid == 0) { atomicMax(o.bkmax, s); if (!lds) atomicAdd(o.bkmax + 1, s); }
+    return total;
+}
+
+// The pairs of [k_lo, k_hi) sorted in GLOBAL memory (a sub-range that still exceeds the stage after splitting: thousands of
+// particles in a few cells): the output arrays themselves are the stage.  tab[] holds the exclusive starts of the bins
+// of the sub-range (bucket_unit left them there).
+template <int BS>
+__device__ __forceinline__ void bucket_unit_global(const uint2 *__restrict__ src, uint32_t cnt_all, uint32_t k_lo, uint32_t k_hi, uint32_t mask,
+                                                   size_t fk0, uint32_t out0, uint32_t total, const BucketOut &o, uint32_t *tab,
+                                                   uint32_t *bigq, uint32_t *nbig)
+{
+    const uint32_t tid = threadIdx.x;
+    __syncthreads();
+    for (uint32_t i = tid; i < cnt_all; i += BS) {
+        const uint2 p = src[i];
+        const uint32_t lo = p.x & mask;
+        if (lo >= k_lo && lo < k_hi) { const uint32_t pos = atomicAdd(&tab[lo], 1u); o.fkeys[(size_t)out0 + pos] = lo; o.perm[(size_t)out0 + pos] = p.y; }
+    }
+    __syncthreads();
+    uint32_t *pm = o.perm + out0;
+    for (uint32_t k = k_lo + tid; k < k_hi; k += BS) {
+        const uint32_t b0 = k > k_lo ? tab[k - 1] : 0u, b1 = tab[k], c = b1 - b0;
+        if (c < 2) continue;
+        if (c > SORT_BIN_SMALL) {
+            const uint32_t q = atomicAdd(nbig, 1u);
+            if (q < SORT_BIGQ) { bigq[q] = k; continue; }
+        }
+        for (uint32_t i = b0 + 1; i < b1; i++) {
+            const uint32_t xv = pm[i];
+            uint32_t j = i;
+            while (j > b0 && pm[j - 1] > xv) { pm[j] = pm[j - 1]; j--; }
+            pm[j] = xv;
+        }
+    }
+    __syncthreads();
+    const uint32_t nq = min(*nbig, (uint32_t)SORT_BIGQ);
+    for (uint32_t q = 0; q < nq; q++) {
+        const uint32_t k = bigq[q], b0 = k > k_lo ? tab[k - 1] : 0u, c = tab[k] - b0;
+        uint2 *scr = o.scratch + out0 + b0;
+        for (uint32_t i = tid; i < c; i += BS) scr[i] = make_uint2(k, pm[b0 + i]);
+        __syncthreads();
+        for (uint32_t i = tid; i < c; i += BS) {
+            const uint32_t xv = scr[i].y;
+            uint32_t r = 0;
+            for (uint32_t j = 0; j < c; j++) r += scr[j].y < xv;
+            pm[b0 + r] = xv;
+        }
+        __syncthreads();
+    }
+    for (uint32_t p = tid; p < total; p += BS) {
+        const size_t j = (size_t)out0 + p;
+        const uint32_t lo = o.fkeys[j], gpos = o.perm[j];
+        const uint32_t fk = (uint32_t)fk0 + lo;
+        o.fkeys[j] = fk;
+        if (o.keys) o.keys[j] = fk / SPH_NSUB;
+        if (o.slot) {
+            uint32_t sl = 0, sb = 0;
+#pragma unroll
+            for (int b = 1; b < SPH_MAX_ARRAYS; b++)
+                if (b < o.co.narrays && gpos >= o.co.off[b]) { sl = (uint32_t)b; sb = o.co.off[b]; }
+            o.slot[j] = (uint8_t)sl;
+            o.perm[j] = gpos - sb;
+        } else {
+            o.perm[j] = gpos;
+        }
+    }
+}
+
+// `bpb` consecutive buckets per workgroup: 1 on a dense grid (as many workgroups as buckets); more on a sparse one, whose
+// tens of thousands of mostly EMPTY buckets would otherwise each cost a workgroup dispatch.  512 threads and a 3840-pair
+// stage: four workgroups per CU.  A bucket beyond the stage (the walls of a tank) is split into sub-ranges of its bins
+// that fit (each filtered from the bucket's pairs), and only a sub-range that still does not fit -- thousands of
+// particles in a few cells -- is sorted in global memory.
+// (MULTI: the one-bucket kernel keeps its 32 registers, the loop costs the other one 64 + spills)
+template <bool MULTI, int BS, int CAP>
+__global__ __launch_bounds__(BS, 8) void k_bucket_sort(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ bstart, int lbits,
+                                                       BucketOut o, uint32_t nbuckets, uint32_t bpb)
+{
+    __shared__ uint32_t tab[1 << SORT_LMAX];
+    __shared__ uint2 stage[CAP];
+    __shared__ uint32_t ws[BS / 64], bigq[SORT_BIGQ], nbig;
+    const uint32_t tid = threadIdx.x, NL = 1u << lbits, mask = NL - 1u;
+    const uint32_t bk0 = MULTI ? blockIdx.x * bpb : blockIdx.x, bk1 = MULTI ? min(nbuckets, (blockIdx.x + 1) * bpb) : blockIdx.x + 1;
+    for (uint32_t bk = bk0; bk < bk1; bk++) {
+        const uint32_t base = bstart[bk], s = bstart[bk + 1] - base;
+        const size_t fk0 = (size_t)bk * NL;
+        if (s == 0) { // an empty bucket (the air of a dam break's tank): its slice of the tables is one value
+            for (uint32_t k = tid; k < NL; k += BS) {
+                const size_t fk = fk0 + k;
+                if (fk <= o.n_fine) { o.fine_start[fk] = base; if (fk % SPH_NSUB == 0) o.cell_start[fk / SPH_NSUB] = base; }
+            }
+            continue;
+        }
+        bool over = false;
+        if (s <= (uint32_t)CAP) {
+            bucket_unit<BS, CAP, true>(pairs + base, s, 0u, NL, NL, mask, fk0, base, o, tab, stage, ws, bigq, &nbig, over);
+        } else {
+            // sub-ranges of the bins: as many as would fit the stage 1.5 times over if the pairs were spread evenly
+            uint32_t parts = 2;
+            while (parts < NL && (size_t)parts * CAP * 2 < (size_t)3 * s) parts *= 2;
+            const uint32_t width = NL / parts;
+            uint32_t done = 0;
+            for (uint32_t r = 0; r < parts; r++) {
+                __syncthreads();
+                const uint32_t t = bucket_unit<BS, CAP, false>(pairs + base, s, r * width, (r + 1) * width, NL, mask, fk0, base + done, o, tab,
+                                                               stage, ws, bigq, &nbig, over);
+                if (over) bucket_unit_global<BS>(pairs + base, s, r * width, (r + 1) * width, mask, fk0, base + done, t, o, tab, bigq, &nbig);
+                done += t;
+            }
+            if (tid == 0) atomicAdd(o.bkmax + 1, s);
+        }
+        if (tid == 0) atomicMax(o.bkmax, s);
+        if (MULTI) __syncthreads(); // the LDS tables serve the workgroup's next bucket
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -612,6 +727,11 @@ static int launch_bin_keys(sph_ctx *c, const BinArrays &ba, uint32_t nblocks, co
     w.part = c->red_part.as<double>();
     w.parta = w.part + (size_t)nblocks * 8;
     w.out = c->red_out.as<double>();
+    if (!c->xflag.ptr) {
+        SPH_TRY(c->xflag.reserve(16));
+        HIP_TRY(hipMemsetAsync(c->xflag.ptr, 0, 16, c->stream));
+    }
+    w.xflag = c->xflag.as<uint32_t>();
     w.lbits = lbits;
     w.mm = mm;
     hipLaunchKernelGGL(k_bin_keys, dim3(nblocks), dim3(256), 0, c->stream, ba, g, w);
@@ -738,23 +858,16 @@ static int grid_from_minmax(const sph_ctx *c, int dim, double radius_scale, doub
     return SPH_OK;
 }
 
-// low key bits sorted inside a bucket: buckets of about half the LDS stage on average, corrected by the largest bucket
-// the previous sort saw (a sparse grid -- the tank of a dam break -- has far fewer occupied keys than keys)
+// low key bits sorted inside a bucket: the most the tables allow (a bucket costs its workgroup ~13 us of latency whatever
+// its size, so fewer and larger buckets win) unless the MEAN bucket would not fit the stage (dense grids: wide kernels).
+// Feedback from the largest bucket of the previous sort was tried and removed: the walls of a sparse tank drove the
+// bucket size down for everybody (47 k buckets instead of 12 k: 0.27 -> 0.40 ms).
 static int sort_choose_lbits(sph_ctx *c, size_t n, size_t n_fine)
 {
-    int lb = c->sort_lbits;
-    if (lb < SORT_LMIN || lb > SORT_LMAX) {
-        const double per_key = (double)n / (double)std::max<size_t>(n_fine, 1);
-        lb = SORT_LMAX;
-        while (lb > SORT_LMIN && per_key * (double)(1u << lb) > 0.6 * SORT_BK_CAP) lb--;
-    } else if (c->hand_sort) {
-        // smaller buckets only when a good part of the particles sat in buckets beyond the LDS stage (a few dense
-        // buckets -- the walls of a tank in a sparse grid -- are cheaper in global memory than twice the buckets)
-        if (c->sort_over > 0.1 * (double)n && lb > SORT_LMIN) lb--;
-        else if (c->sort_bkmax > 0 && c->sort_bkmax * 4 <= SORT_BK_CAP && lb < SORT_LMAX) lb++;
-        c->sort_bkmax = 0; // one correction per measurement
-        c->sort_over = 0;
-    }
+    if (!c->hand_sort && c->sort_lbits >= SORT_LMIN && c->sort_lbits <= SORT_LMAX) return c->sort_lbits; // option sort_lbits
+    const double per_key = (double)n / (double)std::max<size_t>(n_fine, 1);
+    int lb = SORT_LMAX;
+    while (lb > SORT_LMIN && per_key * (double)(1u << lb) > 0.6 * SORT_BK_CAP) lb--;
     c->sort_lbits = lb;
     return lb;
 }
@@ -779,7 +892,15 @@ static int sort_finish(sph_ctx *c, size_t n, size_t n_fine, long n_cells, int lb
     o.n_fine = (uint32_t)n_fine; o.n_cells = (uint32_t)n_cells;
     o.scratch = c->tmp_u32a.as<uint2>();
     o.bkmax = w.ticket + 1;
-    hipLaunchKernelGGL(k_bucket_sort, dim3(nbuckets), dim3(SORT_BS), 0, c->stream, (const uint2 *)pairs, (const uint32_t *)w.bstart, lbits, o);
+    // (a second shape -- 128 threads, a 1024-pair stage, ten workgroups per CU -- was built for grids whose buckets hold a
+    // few hundred particles, the end slab of a dam-break tank: same 150 us as this one there, a bucket's cost is its passes
+    // over the 2^lbits table entries, which a smaller workgroup only walks longer; removed)
+    const uint32_t bpb = std::min<uint32_t>(16u, std::max<uint32_t>(1u, nbuckets / 4096u));
+    const uint2 *pp = (const uint2 *)pairs;
+    const uint32_t *bs = (const uint32_t *)w.bstart;
+    const dim3 grid(div_up(nbuckets, bpb));
+    if (bpb > 1) hipLaunchKernelGGL((k_bucket_sort<true, SORT_BS, SORT_BK_CAP>), grid, dim3(SORT_BS), 0, c->stream, pp, bs, lbits, o, nbuckets, bpb);
+    else hipLaunchKernelGGL((k_bucket_sort<false, SORT_BS, SORT_BK_CAP>), grid, dim3(SORT_BS), 0, c->stream, pp, bs, lbits, o, nbuckets, 1u);
     return SPH_OK;
 }
 
@@ -1235,6 +1356,17 @@ static void nnps_face_planes(sph_ctx *c)
     c->gfx_hi = !(fhi < 1e9) ? 0x7fffffff : (fhi < -1e9 ? -0x7fffffff : (int)fhi);  // ... or fx >= gfx_hi
 }
 
+// the merged records met a density that is not positive (sph_ctx::xflag): loud, once; the merged path stays off
+static int nnps_rho_flag(sph_ctx *c)
+{
+    if (c->merge_blocked) return SPH_OK;
+    c->merge_blocked = true;
+    sph_set_error("a density <= 0 (or NaN) reached the one-launch WCSPH path, whose records carry the particle's class in the "
+                  "sign of rho: the evaluations since then ran with wrong classes.  The context takes the per-destination "
+                  "path from now on (option merge_arrays 0 from the start avoids the encoding)");
+    return SPH_ERR_STATE;
+}
+
 // the bounds the last update sent to pin_async have arrived
 static int lag_wait(sph_ctx *c)
 {
@@ -1243,6 +1375,7 @@ static int lag_wait(sph_ctx *c)
         c->lag.pending = false;
         c->sort_bkmax = c->pin_async[MM_OUT_BKMAX];
         c->sort_over = c->pin_async[MM_OUT_OVER];
+        if (c->pin_async[MM_OUT_XFLAG] != 0.0) SPH_TRY(nnps_rho_flag(c));
     }
     return SPH_OK;
 }
@@ -1338,6 +1471,7 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
         c->pin_async[MM_OUT_OVER] = c->pinned[MM_OUT_OVER];
         c->sort_bkmax = c->pinned[MM_OUT_BKMAX];
         c->sort_over = c->pinned[MM_OUT_OVER];
+        if (nblocks && c->pinned[MM_OUT_XFLAG] != 0.0) SPH_TRY(nnps_rho_flag(c));
         c->lag.valid = !bounds;
         c->lag.pending = false;
     }

@@ -179,8 +179,9 @@ class DeviceHaloOps(object):
     # -- the exchange without a device->host round trip ('padded' protocol) ----
     def append_padded(self, buf, cap, h_promise, m_promise):
         """all `cap` rows of a fixed-capacity message behind the particles: the
-        first |header| are the ghosts, the rest NaN padding rows (inert on the whole
-        path); the host learns the count an exchange later (sph_halo_append_padded)"""
+        first |header| are the ghosts, the rest padding rows parked at 1e18 (inert on
+        the whole path); the host learns the count an exchange later
+        (sph_halo_append_padded)"""
         dev._check(self.lib.sph_halo_append_padded(
             self.ctx._h, self.id, self.nprops, self.props, C.c_void_p(buf.data_ptr()), int(cap),
             float(h_promise), float(m_promise), C.c_void_p(self.flag_word().data_ptr())))
@@ -304,7 +305,7 @@ class SlabHalo(object):
         # count both ends saw in the previous exchange; 'handshake' = counts
         # all_gather before exactly-sized messages (always used the first time)
         # 'padded' = 'capacity' without the readback: the receiver appends every row of a message, the rows behind the
-        # ghosts as NaN padding, and learns the counts an exchange later (_exchange_padded)
+        # ghosts as padding parked far outside the domain, and learns the counts an exchange later (_exchange_padded)
         self.protocol = protocol or os.environ.get('SPH_HALO_PROTOCOL', 'capacity')
         self.cap_send, self.cap_recv = {}, {}
         self.handshakes = 0               # exchanges that needed the counts round
@@ -677,8 +678,8 @@ def _padded_collect(hs):
 def _exchange_padded(hs, nbrs):
     """Ghost refresh with NO device->host round trip ('padded' protocol, steady state):
     fixed-capacity messages packed on the device as in 'capacity', but the receiver
-    appends ALL rows of a message -- the ghosts and, behind them, NaN padding rows
-    that are inert on the whole path -- so nothing has to be counted before the
+    appends ALL rows of a message -- the ghosts and, behind them, padding rows parked
+    far outside the domain that are inert on the whole path -- so nothing has to be counted before the
     neighbour update and the evaluation are queued.  Counts and flags follow one
     exchange later (_padded_collect)."""
     h0 = hs[0]

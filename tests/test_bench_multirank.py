@@ -175,7 +175,7 @@ def test_cube_two_slabs_matches_one_domain_by_gid():
                          ids=['cube', 'cube-variable-h', 'dam-break-three-arrays'])
 def test_padded_exchange_runs_without_round_trips_and_matches_one_domain(argv, one):
     """round 5, the 'padded' ghost exchange (default of bench.py): from the second exchange on the receiver appends
-    whole fixed-capacity messages -- NaN padding rows behind the ghosts -- so neither the exchange nor the neighbour
+    whole fixed-capacity messages -- padding rows parked far outside the domain behind the ghosts -- so neither the exchange nor the neighbour
     update that follows waits for the device (counts and flags are read one exchange later); with ONE h and ONE mass
     per array on every rank the appends keep what the update knows of h and m (uniform-mass records stay).  Results
     against one domain, gid by gid."""

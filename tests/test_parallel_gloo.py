@@ -404,7 +404,7 @@ def test_fused_two_array_exchange_equals_per_array(tmp_path, periodic):
 
 class NumpyPaddedHaloOps(NumpyDirectHaloOps):
     """... and with the receive side of sph_halo_append_padded: every row of a
-    message is appended, the rows behind the ghosts as NaN; counts and the flag
+    message is appended, the rows behind the ghosts parked at 1e18; counts and the flag
     word are looked at one exchange later"""
 
     def message_buffer(self, key, size):
@@ -424,7 +424,7 @@ class NumpyPaddedHaloOps(NumpyDirectHaloOps):
         self.pa.resize(n0 + cap)
         self.pa.set_num_real_particles(nreal)
         for k, p in enumerate(PROPS):
-            col = np.full(cap, np.nan)
+            col = np.full(cap, 1e18 if p in 'xyz' else 0.0)
             col[:count] = arr[k * cap:k * cap + count]
             if p == 'h' and h_promise == h_promise and np.any(col[:count] != h_promise):
                 self.flag |= 2
@@ -450,7 +450,7 @@ class NumpyPaddedHaloOps(NumpyDirectHaloOps):
 def _worker_padded(rank, world, port, periodic, out):
     """the 'padded' protocol against the counted one: after every exchange the
     first rows behind the real particles are the same ghosts, the rows behind
-    them NaN; counts arrive one exchange late and move the capacities on both
+    them parked far away; counts arrive one exchange late and move the capacities on both
     ends alike; an overflowing face is an error one exchange later"""
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -481,11 +481,11 @@ def _worker_padded(rank, world, port, periodic, out):
             npad = pa_p.get_number_of_particles()
             assert npad >= nc
             # every face's message is appended whole: its ghosts, then its padding rows
-            live = ~np.isnan(pa_p.properties['x'][:npad])
+            live = np.abs(pa_p.properties['x'][:npad]) < 1e17
             assert live[:nr].all() and live.sum() == nc
             for k in PROPS:
                 assert np.array_equal(pa_c.properties[k][:nc], pa_p.properties[k][:npad][live]), (step, k)
-                assert np.all(np.isnan(pa_p.properties[k][:npad][~live])), (step, k)
+                assert np.all(pa_p.properties[k][:npad][~live] == (1e18 if k in 'xyz' else 0.0)), (step, k)
             log.append((hp.padded_exchanges, npad - nc))
         assert hp.handshakes == 1 and hp.padded_exchanges == 5
         assert hp.h_promise == hp.h_promise and hp.m_promise == hp.m_promise     # the cube has one h and one m

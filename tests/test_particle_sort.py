@@ -67,8 +67,10 @@ def cloud(n, seed, name='a', box=1.0, h=0.05):
 def test_sorted_order_is_the_stable_order(n, box, h):
     from pysph_amd.nnps import HipNNPS
     pa = cloud(n, n, box=box, h=h)
-    nn = HipNNPS(3, [pa], radius_scale=2.0, ctx=_ctx())
+    ctx = _ctx()
+    nn = HipNNPS(3, [pa], radius_scale=2.0, ctx=ctx)
     check_order(nn, [pa])
+    ctx.close()
 
 
 def test_dense_bins_and_coincident_particles():
@@ -85,11 +87,12 @@ def test_dense_bins_and_coincident_particles():
     x, y, z = np.concatenate(xs), np.concatenate(ys), np.concatenate(zs)
     order = rng.permutation(x.size)          # the piles scattered over the index range
     pa = get_particle_array(name='a', x=x[order], y=y[order], z=z[order], h=0.03 * np.ones(x.size))
-    for lbits in (0, 9, 11):
+    for lbits in (0, 9, 11):         # (11: the piles' bucket is split into sub-ranges; the 3000-pile goes to global memory)
         ctx = _ctx()
         ctx.set_option('sort_lbits', lbits)
         nn = HipNNPS(3, [pa], radius_scale=2.0, ctx=ctx)
         check_order(nn, [pa])
+        ctx.close()
 
 
 @pytest.mark.parametrize('merge', [1, 0])

@@ -291,6 +291,38 @@ def test_merged_arrays_not_taken_without_the_promises():
     assert cnt['n_merged'] == 0 and res['parity_ok'], (cnt, res)
 
 
+def test_merged_records_refuse_a_density_that_is_not_positive():
+    """the merged records carry a particle's class in the SIGN of rho: a density <= 0 would change its class silently.
+    k_pack_merged raises a device word, the next neighbour updates carry it to the host with their bounds, and the
+    update that sees it fails loudly and switches the context to the per-destination path (round 5)"""
+    import torch
+    import bench
+    from pysph_amd import device as dev
+    args = bench.parse_args(['--workload', 'dam_break', '--dx', '0.03', '--no-cpu-baseline', '--no-extras'])
+    ctx = dev.HipContext(0, torch.cuda.current_stream().cuda_stream)
+    bench.apply_options(args, ctx)
+    w = bench.build_workload(args, 0, 1)
+    nnps, a_eval, halo, domain, step, ordered = bench.setup(args, w, 0, 1, None, ctx)
+    for _ in range(3):
+        step()
+    n0 = ctx.timer_get('n_merged')[1]
+    assert n0 == 2
+    fluid = w.arrays[0]
+    fluid.gpu.pull('rho')
+    fluid.rho[7] = -fluid.rho[7]
+    fluid.gpu.push('rho')
+    with pytest.raises(dev.SphError, match='density <= 0'):
+        for _ in range(4):          # the evaluation that packs it, then at most two updates until the word has arrived
+            step()
+    n1 = ctx.timer_get('n_merged')[1]
+    for _ in range(2):              # from now on the per-destination path
+        step()
+    assert ctx.timer_get('n_merged')[1] == n1
+    del nnps, a_eval, step
+    ctx.close()
+    torch.cuda.empty_cache()
+
+
 def test_merged_arrays_with_masses_per_class():
     """walls of another (uniform) mass than the fluid: the class carries its mass;
     walls whose masses differ among themselves: no uniform mass per class, the

@@ -17,4 +17,4 @@ for n in ('rank0', 'rank3', 'rank7', 'plain142', 'slab142_padded', 'slab142_capa
         print(n, 'FAILED', e); print(open('gpurun_out/r05d/%s.err' % n).read()[-800:])
 PY
 bash tools/prof_one.sh r05d selfslab_padded --self-slab --n1 142 2>&1 | tail -22
-bash tools/prof_one.sh r05d unsorted --no-reorder 2>&1 | tail -14
+
