@@ -280,6 +280,9 @@ def build_workload(args, rank, world):
                 a.rho[:] = a.rho * (1 + 0.01 * rng.uniform(-1, 1, n))
                 for c in 'uvw':
                     a.get(c)[:] = 0.1 * db.c0 * rng.uniform(-1, 1, n)
+            if args.vary_h:
+                # --vary-h: every particle its own smoothing length (a dam break with evolving h: the variable-h records)
+                a.h[:] = a.h * (1 + args.vary_h * np.random.default_rng(977 + len(a.name)).uniform(-1, 1, n))
         lo, hi = -1e30, 1e30
         if args.emulate_rank and not cached:
             _DAM_CACHE.clear()
@@ -324,7 +327,7 @@ def build_workload(args, rank, world):
         if args.emulate_rank:
             w.name += ' -- rank %d of %d emulated: %s real particles + the ghost layers of its neighbours' % (
                 args.emulate_rank[0], args.emulate_rank[1], sum(a.get_number_of_particles(True) for a in arrays))
-        w.halo_width = w.kernel.radius_scale * 1.3 * dx
+        w.halo_width = w.kernel.radius_scale * 1.3 * dx * (1.0 + args.vary_h)
         # solids <- fluid continuity: x,y,z,h,u,v,w read (56 B), arho written (8 B): SURVEY 8(d)
         w.algo_solid = 64.0
         w.slab = (lo, hi, False, 0.0)

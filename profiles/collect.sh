@@ -6,7 +6,7 @@
 #                                          --kernel-trace only, as the pool requires)
 # profiles/summarize.py condenses the raw CSVs into profiles/.
 set -u
-TAG=${1:-r04}; shift || true
+TAG=${1:-r05}; shift || true
 ROOT=$(pwd)
 export TMPDIR=/tmp
 cd /tmp
@@ -44,7 +44,7 @@ run_one() {   # name, pmc (0/1/2), bench args...
     find "$OUT" -name "*_agent_info.csv" -delete
     # counter CSVs of every kernel of every launch are large; keep the hot kernels only
     for f in $(find "$OUT" -name "*_counter_collection.csv"); do
-        (head -1 "$f"; grep -E "k_pair|k_pack|k_nosrc|k_cell_keys|k_cell_start" "$f") > "$f.tmp" && mv "$f.tmp" "$f"
+        (head -1 "$f"; grep -E "k_pair|k_pack|k_nosrc|k_bin_keys|k_bucket" "$f") > "$f.tmp" && mv "$f.tmp" "$f"
     done
     find "$OUT" -name "*_kernel_trace.csv" -path "*pmc_*" -delete
 }

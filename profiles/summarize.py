@@ -21,7 +21,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 here = os.path.dirname(os.path.abspath(__file__))
 raw = os.path.join(os.path.dirname(here), 'gpurun_out', tag)
 
-KERNELS = ('k_pair_wave', 'k_pack', 'k_nosrc', 'k_cell_keys', 'k_cell_start')
+KERNELS = ('k_pair_wave', 'k_pack', 'k_nosrc', 'k_bin_keys', 'k_bucket_scatter', 'k_bucket_sort')
 
 
 def short(name):
@@ -126,10 +126,10 @@ for w, bench in lines.items():
     if n and 'k_nosrc' in mean and 'FETCH_SIZE' in mean['k_nosrc'] and w.startswith('cube'):
         cal['k_nosrc_fetch_B_per_particle (reads 8)'] = mean['k_nosrc']['FETCH_SIZE'] * KiB / n
         cal['k_nosrc_write_B_per_particle (writes 16)'] = mean['k_nosrc']['WRITE_SIZE'] * KiB / n
-    if n and 'k_cell_keys' in mean and 'FETCH_SIZE' in mean['k_cell_keys']:
-        cal['k_cell_keys_fetch_B_per_particle (reads 24)'] = mean['k_cell_keys']['FETCH_SIZE'] * KiB / n
-        cal['k_cell_keys_write_B_per_particle (writes 8)'] = mean['k_cell_keys']['WRITE_SIZE'] * KiB / n
-    for kk in ('k_nosrc', 'k_cell_keys'):
+    if n and 'k_bin_keys' in mean and 'FETCH_SIZE' in mean['k_bin_keys']:
+        cal['k_bin_keys_fetch_B_per_particle (reads 24)'] = mean['k_bin_keys']['FETCH_SIZE'] * KiB / n
+        cal['k_bin_keys_write_B_per_particle (writes 4)'] = mean['k_bin_keys']['WRITE_SIZE'] * KiB / n
+    for kk in ('k_nosrc', 'k_bin_keys'):
         if n and kk in mean and 'TCP_TCC_READ_REQ_sum' in mean[kk]:
             cal['%s_l1_line_requests_per_particle (x128 B)' % kk] = mean[kk]['TCP_TCC_READ_REQ_sum'] / n
     entry['calibration'] = cal

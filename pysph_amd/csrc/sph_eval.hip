@@ -403,7 +403,8 @@ struct PackMArgs {
     const uint32_t *perm;
     const uint8_t *slot;
     size_t n, off;                 // off = 0 (emit_pieces)
-    const double *prop[8][SPH_MAX_ARRAYS]; // x y z u v w rho p, per slot
+    const double *prop[9][SPH_MAX_ARRAYS]; // x y z u v w rho p h, per slot (h: variable-h records only)
+    int vh;                        // 1: variable h -- records [x y | z h | u v | w +-rho], p / rho^2 recomputed by the pair kernel
     uint32_t cls;                  // bit s: slot s is a class-1 array
     double *rec;
     float4 *fpos;
@@ -428,12 +429,23 @@ __global__ __launch_bounds__(256) void k_pack_merged(PackMArgs a)
     const double q = rho != 0.0 ? v[7] * (1.0 / (rho * rho)) : 0.0; // tmpj = p*rhoj21, wc/basic.py:211,234 (as k_pack, derived 1)
     const double srho = ((a.cls >> sl) & 1u) ? -rho : rho;
     if (!(rho > 0.0)) atomicOr(a.rho_flag, 1u); // rho <= 0 (or NaN): this record's class bit is not to be trusted
-    a.fpos[i] = make_float4((float)(v[0] - a.gmin[0]), (float)(v[1] - a.gmin[1]), (float)(v[2] - a.gmin[2]), (float)a.hr);
+    double hp = 0.0;
+    if (a.vh) hp = kernarg_read<const double *>(__builtin_offsetof(PackMArgs, prop) + ((size_t)8 * SPH_MAX_ARRAYS + sl) * sizeof(double *))[o];
+    a.fpos[i] = make_float4((float)(v[0] - a.gmin[0]), (float)(v[1] - a.gmin[1]), (float)(v[2] - a.gmin[2]),
+                            a.vh ? (float)(a.hr * hp) : (float)a.hr); // hr: radius_scale * h, or radius_scale alone with variable h
     double2 pc[PACK_MAXP];
 #pragma unroll
     for (int k = 0; k < PACK_MAXP; k++) pc[k] = make_double2(0.0, 0.0);
     int np;
-    if (a.f32) {
+    if (a.vh && a.f32) {
+        pc[0] = __builtin_bit_cast(double2, make_float4((float)(v[0] - a.gmin[0]), (float)(v[1] - a.gmin[1]), (float)(v[2] - a.gmin[2]), (float)hp));
+        pc[1] = __builtin_bit_cast(double2, make_float4((float)v[3], (float)v[4], (float)v[5], (float)srho));
+        np = 2;
+    } else if (a.vh) {
+        pc[0] = make_double2(v[0], v[1]); pc[1] = make_double2(v[2], hp);
+        pc[2] = make_double2(v[3], v[4]); pc[3] = make_double2(v[5], srho);
+        np = 4;
+    } else if (a.f32) {
         pc[0] = __builtin_bit_cast(double2, make_float4((float)(v[0] - a.gmin[0]), (float)(v[1] - a.gmin[1]), (float)(v[2] - a.gmin[2]), (float)v[3]));
         pc[1] = __builtin_bit_cast(double2, make_float4((float)v[4], (float)v[5], (float)srho, (float)q));
         np = 2;
@@ -767,6 +779,38 @@ template <class T> struct FamWCSPHM_T : FamWCSPHE_T<T, true> {
         if (row & F_XSPH) { // post_loop basic_equations.py:297-300
             out(4)[o] = D.ax + D.u; out(5)[o] = D.ay + D.v; out(6)[o] = D.az + D.w;
         }
+    }
+};
+
+// ... and with VARIABLE h (round 5): records [x y | z h | u v | w +-rho] (fp32 [x y z h | u v w +-rho]) as FamWCSPHV_T's
+// with the class in the sign of rho; p / rho^2 and cs are the Tait EOS of the gathered rho.  Run with UH = false.
+template <class T> struct FamWCSPHMV_T : FamWCSPHM_T<T> {
+    typedef FamWCSPHM_T<T> Base;
+    template <class A> static __device__ __forceinline__ void load_fused(const A &a, uint32_t jg, uint32_t, T mu, real4<T> &pj, T (&s)[8])
+    {
+        T rho;
+        if constexpr (sizeof(T) == 8) {
+            const double2 *p = reinterpret_cast<const double2 *>(a.rec) + (unsigned long long)jg * 4;
+            const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+            pj.x = q0.x; pj.y = q0.y; pj.z = q1.x; pj.w = q1.y;
+            s[0] = q2.x; s[1] = q2.y; s[2] = q3.x; rho = q3.y;
+        } else {
+            const float4 *p = reinterpret_cast<const float4 *>(a.rec) + (unsigned long long)jg * 2;
+            const float4 q0 = p[0], q1 = p[1];
+            pj.x = q0.x; pj.y = q0.y; pj.z = q0.z; pj.w = q0.w;
+            s[0] = q1.x; s[1] = q1.y; s[2] = q1.z; rho = q1.w;
+        }
+        const bool c1 = rho < T(0.0);
+        s[3] = c1 ? -(T)a.p.mu1 : mu; // +-m: the sign is the class
+        rho = fabs(rho);
+        s[4] = rho;
+        const T ratio = rho * (T)a.e_rho01;
+        const T r2 = ratio * ratio, r3 = r2 * ratio;
+        const T r7 = (r2 * r2) * r3;
+        const T p = (T)a.e_p0 + (T)a.e_B * (r7 - T(1.0));
+        s[5] = rho != T(0.0) ? p * fast_rcp(rho * rho) : T(0.0);
+        s[6] = (T)a.e_c0 * r3;
+        s[7] = T(0.0);
     }
 };
 
@@ -1681,9 +1725,10 @@ static int eval_group_merged(sph_ctx *c, const sph_kernel *K, const sph_group *g
     if (!c->merged_valid || !c->merge_arrays || !c->nnps_valid || c->pair_variant != 6 || c->ablate || c->count_iters) return SPH_OK;
     if (c->merge_blocked || !c->xflag.ptr) return SPH_OK; // a non-positive density was seen: the sign of rho cannot carry the class
     if (g->phase != 0 || c->ghosts_binned) return SPH_OK; // ghost segments: the per-destination path reads them as extra sources
-    if (!(g->src_eos == 1 && c->eos_fuse && c->mass_fuse && c->const_flags && c->uniform_h && c->use_uniform_h &&
+    if (!(g->src_eos == 1 && c->eos_fuse && c->mass_fuse && c->const_flags &&
           g->eos_par[2] == 7.0 && g->eos_par[0] > 0.0 && !c->record_f32 && !c->wcsph_nr))
         return SPH_OK;
+    const bool vh = !(c->uniform_h && c->use_uniform_h); // variable h: FamWCSPHMV_T on records that carry h (round 5)
     const int na = c->narrays;
     uint32_t F[SPH_MAX_ARRAYS][SPH_MAX_ARRAYS] = {};
     const sph_equation *me = nullptr, *xe = nullptr;
@@ -1764,20 +1809,20 @@ static int eval_group_merged(sph_ctx *c, const sph_kernel *K, const sph_group *g
 
     // outputs and properties
     static const int outp[9] = {SPH_ARHO, SPH_AU, SPH_AV, SPH_AW, SPH_AX, SPH_AY, SPH_AZ, SPH_DT_CFL, SPH_DT_FORCE};
-    static const int inp[8] = {SPH_X, SPH_Y, SPH_Z, SPH_U, SPH_V, SPH_W, SPH_RHO, SPH_P};
+    static const int inp[9] = {SPH_X, SPH_Y, SPH_Z, SPH_U, SPH_V, SPH_W, SPH_RHO, SPH_P, SPH_H};
     const bool f32 = c->arith_f32 != 0;
     PackMArgs pa;
     memset(&pa, 0, sizeof pa);
     for (int a = 0; a < na; a++) {
         const int id = c->ids[a];
         DevArray &A = c->arr[id];
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < 9; k++) {
             if (A.n && !A.prop[inp[k]]) return need_prop(c, id, inp[k], "pair loop");
             pa.prop[k][a] = A.prop[inp[k]];
         }
         if (cls[a]) pa.cls |= 1u << a;
     }
-    c->cur_eosf = true; c->cur_umass = true; c->cur_tvff = false; c->cur_elu = false; c->cur_eosv = false;
+    c->cur_eosf = !vh; c->cur_umass = !vh; c->cur_tvff = false; c->cur_elu = false; c->cur_eosv = vh;
     c->cur_nrec = 8;
     SPH_TRY(c->posh.reserve((M.n + 64) * (f32 ? 32 : 64)));
     SPH_TRY(c->aux.reserve(64));
@@ -1790,7 +1835,8 @@ static int eval_group_merged(sph_ctx *c, const sph_kernel *K, const sph_group *g
         pa.rec = c->posh.as<double>(); pa.fpos = c->fposb.as<float4>();
         pa.f32 = f32 ? 1 : 0; pa.lds_np = f32 ? 2 : 4;
         for (int k = 0; k < 3; k++) pa.gmin[k] = c->xmin[k];
-        pa.hr = c->radius_scale * c->h_uniform;
+        pa.vh = vh ? 1 : 0;
+        pa.hr = vh ? c->radius_scale : c->radius_scale * c->h_uniform;
         pa.rho_flag = c->xflag.as<uint32_t>();
         hipLaunchKernelGGL(k_pack_merged, dim3(div_up(M.n, 256)), dim3(256), (size_t)pa.lds_np * 256 * 16, c->stream, pa);
     }
@@ -1834,7 +1880,8 @@ static int eval_group_merged(sph_ctx *c, const sph_kernel *K, const sph_group *g
         }
         constexpr bool FP32 = sizeof(typename Fm::Real) == 4;
         dim3 g2(div_up(4 * div_up(a.nd, 256), WPB)), b2(64 * WPB);
-#define LAUNCHM(KV) hipLaunchKernelGGL((k_pair_wave<Fm, KV, true, FP32, Fm::CF0>), g2, b2, (size_t)c->lds_pad, c->stream, a)
+        constexpr bool UHM = !std::is_base_of<FamWCSPHMV_T<typename Fm::Real>, Fm>::value; // uniform h unless the family carries h
+#define LAUNCHM(KV) hipLaunchKernelGGL((k_pair_wave<Fm, KV, UHM, FP32, Fm::CF0>), g2, b2, (size_t)c->lds_pad, c->stream, a)
         switch (K->kind) {
         case 1: LAUNCHM(1); break;
         case 2: LAUNCHM(2); break;
@@ -1844,7 +1891,8 @@ static int eval_group_merged(sph_ctx *c, const sph_kernel *K, const sph_group *g
 #undef LAUNCHM
         return SPH_OK;
     };
-    SPH_TRY(f32 ? run(FamWCSPHM_T<float>()) : run(FamWCSPHM_T<double>()));
+    if (vh) SPH_TRY(f32 ? run(FamWCSPHMV_T<float>()) : run(FamWCSPHMV_T<double>()));
+    else SPH_TRY(f32 ? run(FamWCSPHM_T<float>()) : run(FamWCSPHM_T<double>()));
     HIP_TRY(hipGetLastError());
     *done = true;
     return SPH_OK;

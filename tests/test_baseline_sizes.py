@@ -48,6 +48,7 @@ def _case(argv):
     step()
     step()          # the second evaluation runs on buffers the first one sized
     res = bench.parity_check(w, host_in, nnps, domain)
+    res['n_merged'] = ctx.timer_get('n_merged')[1]
     n = sum(a.get_number_of_particles() for a in w.arrays)
     del nnps, a_eval, step
     ctx.close()
@@ -90,6 +91,16 @@ def test_dam_break_4m_vs_oracle():
     assert res['parity_neighbour_count_mismatches'] == 0, res
     assert res['parity_max_rel'] < 1e-10, res
     assert res['parity_elementwise_max_rel'] < ELEMENTWISE_BOUND, res
+
+
+def test_dam_break_4m_variable_h_runs_merged_vs_oracle():
+    """round 5: the same tank with every particle carrying its own h (+-15 %) still runs its rate group as ONE launch
+    over the merged order (FamWCSPHMV_T) from the second evaluation on"""
+    res, n, _ = _case(['--workload', 'dam_break', '--dx', '0.0055', '--vary-h', '0.15'])
+    assert n > 4.6e6 and res['n_merged'] >= 1, res
+    assert res['parity_neighbour_count_mismatches'] == 0, res
+    assert res['parity_max_rel'] < 1e-10, res
+    assert res['parity_elementwise_max_rel'] < ELEMENTWISE_BOUND and res['parity_ok'], res
 
 
 def test_dam_break_16m_one_gpu_vs_oracle():

@@ -283,12 +283,29 @@ def test_merged_arrays_match_per_destination_path(argv):
         assert _max_rel(on, off) < 1e-13
 
 
+def test_merged_arrays_with_variable_h_match_per_destination_path():
+    """round 5: a dam break whose particles carry their own h runs its rate group as ONE launch too
+    (FamWCSPHMV_T: records [x y | z h | u v | w +-rho], p / rho^2 and cs recomputed from the gathered rho)"""
+    argv = ['--workload', 'dam_break', '--dx', '0.03', '--vary-h', '0.15']
+    on, c_on, r_on = _run(argv, {}, steps=3)
+    off, c_off, r_off = _run(argv, {'merge_arrays': 0}, steps=3)
+    assert c_on['n_merged'] == 2 and c_off['n_merged'] == 0, (c_on, c_off)
+    assert r_on['parity_ok'] and r_off['parity_ok'], (r_on, r_off)
+    assert r_on['parity_neighbour_count_mismatches'] == 0
+    assert _max_rel(on, off) < 1e-13
+    on32, c32, r32 = _run(argv + ['--dtype', 'f32'], {}, steps=3)
+    assert c32['n_merged'] == 2 and r32['parity_max_rel'] < 5e-5, (c32, r32)
+
+
 def test_merged_arrays_not_taken_without_the_promises():
-    """variable h (no 64-byte records) keeps the per-destination path"""
+    """without the EOS promise (option eos_fuse 0) there are no 64-byte records and the per-destination path runs;
+    the uniform-h specialisation switched off (option uniform_h 0) takes the variable-h merged family since round 5"""
     import bench
-    args = ['--workload', 'dam_break', '--dx', '0.03', '--opt', 'uniform_h=0']
-    out, cnt, res = _run(args, {}, steps=3)
+    args = ['--workload', 'dam_break', '--dx', '0.03']
+    out, cnt, res = _run(args, {'eos_fuse': 0}, steps=3)
     assert cnt['n_merged'] == 0 and res['parity_ok'], (cnt, res)
+    out, cnt, res = _run(args + ['--opt', 'uniform_h=0'], {}, steps=3)
+    assert cnt['n_merged'] == 2 and res['parity_ok'], (cnt, res)
 
 
 def test_merged_records_refuse_a_density_that_is_not_positive():
