@@ -212,7 +212,7 @@ class Workload(object):
 
 
 def _dam_weights(arrays, args):
-    """work per particle for the slab cut of a dam break (--slab-weight-solid, default 0.25: a boundary /
+    """work per particle for the slab cut of a dam break (--slab-weight-solid, default 0.5: a boundary /
     obstacle particle is a destination of the continuity equation over the fluid only, and most of them have no
     fluid neighbour; 1: equal particle counts)"""
     ws = float(args.slab_weight_solid)
@@ -628,7 +628,7 @@ def parse_args(argv=None):
                          'reducing them every update: LinkedListNNPS(fixed_h=True) plus bounds a '
                          'stepping host knows from its own reductions; removes the min/max pass and '
                          'its device->host round trip from the step (reported in config)')
-    ap.add_argument('--slab-weight-solid', type=float, default=0.25, dest='slab_weight_solid',
+    ap.add_argument('--slab-weight-solid', type=float, default=0.5, dest='slab_weight_solid',
                     help='dam_break over several ranks: work of a boundary / obstacle particle relative to a fluid '
                          'particle when the slab faces are cut (1: equal particle counts)')
     ap.add_argument('--halo-protocol', default='padded', dest='halo_protocol', choices=['padded', 'capacity', 'handshake'],

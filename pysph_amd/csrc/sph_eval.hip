@@ -428,7 +428,9 @@ __global__ __launch_bounds__(256) void k_pack_merged(PackMArgs a)
     const double rho = v[6];
     const double q = rho != 0.0 ? v[7] * (1.0 / (rho * rho)) : 0.0; // tmpj = p*rhoj21, wc/basic.py:211,234 (as k_pack, derived 1)
     const double srho = ((a.cls >> sl) & 1u) ? -rho : rho;
-    if (!(rho > 0.0)) atomicOr(a.rho_flag, 1u); // rho <= 0 (or NaN): this record's class bit is not to be trusted
+    // rho <= 0 (or NaN): this record's class bit is not to be trusted (padding rows of sph_halo_append_padded, parked far
+    // outside the domain with rho = 0, are nobody's neighbour)
+    if (!(rho > 0.0) && fabs(v[0]) < SPH_PARKED_MIN) atomicOr(a.rho_flag, 1u);
     double hp = 0.0;
     if (a.vh) hp = kernarg_read<const double *>(__builtin_offsetof(PackMArgs, prop) + ((size_t)8 * SPH_MAX_ARRAYS + sl) * sizeof(double *))[o];
     a.fpos[i] = make_float4((float)(v[0] - a.gmin[0]), (float)(v[1] - a.gmin[1]), (float)(v[2] - a.gmin[2]),

@@ -892,9 +892,11 @@ static int sort_finish(sph_ctx *c, size_t n, size_t n_fine, long n_cells, int lb
     o.n_fine = (uint32_t)n_fine; o.n_cells = (uint32_t)n_cells;
     o.scratch = c->tmp_u32a.as<uint2>();
     o.bkmax = w.ticket + 1;
-    // (a second shape -- 128 threads, a 1024-pair stage, ten workgroups per CU -- was built for grids whose buckets hold a
-    // few hundred particles, the end slab of a dam-break tank: same 150 us as this one there, a bucket's cost is its passes
-    // over the 2^lbits table entries, which a smaller workgroup only walks longer; removed)
+    // Two variants for grids whose buckets hold a few hundred particles (the end slab of a dam-break tank: 11.8 k buckets
+    // of 250, 24.5 M table entries for 2.9 M particles) were built, measured and removed: a small workgroup shape (128
+    // threads, 1024-pair stage, ten per CU: the same 150 us) and one WAVEFRONT per small bucket with LDS areas of its own and
+    // no barrier (0.258 -> 0.326 ms there, slower on every other workload too).  What such a grid pays for is its TABLE --
+    // 98 MB of fine_start + cell_start written per update for 24 MB of keys --, not the buckets' barrier chains.
     const uint32_t bpb = std::min<uint32_t>(16u, std::max<uint32_t>(1u, nbuckets / 4096u));
     const uint2 *pp = (const uint2 *)pairs;
     const uint32_t *bs = (const uint32_t *)w.bstart;
