@@ -986,10 +986,43 @@ __global__ __launch_bounds__(256) void k_scan_apply(const T *in, T *out, size_t 
     }
 }
 
-// prefix sums of n counters (device-wide, three launches); in == out allowed
+// up to 64 Ki counters: ONE workgroup (1024 threads, 16 consecutive items each per round, the loads of a round in flight
+// together) instead of the three launches below -- the block counters of a ghost selection (n / 256 of them), the bins
+// of the tile order: launch gaps, not bytes
+template <class T> __global__ __launch_bounds__(1024) void k_scan_small(const T *in, T *out, uint32_t n, int exclusive)
+{
+    __shared__ T ws[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int PT = 16;
+    T carry = 0;
+    for (uint32_t base = 0; base < n; base += 1024 * PT) {
+        T v[PT], sum = 0;
+        const uint32_t i0 = base + threadIdx.x * PT;
+#pragma unroll
+        for (int q = 0; q < PT; q++) { v[q] = i0 + q < n ? in[i0 + q] : T(0); sum += v[q]; }
+        const T incl = wave_incl_scan<T>(sum, lane);
+        if (lane == 63) ws[wv] = incl;
+        __syncthreads();
+        T off = carry + incl - sum, tot = 0;
+        for (int q = 0; q < 16; q++) { if (q < wv) off += ws[q]; tot += ws[q]; }
+#pragma unroll
+        for (int q = 0; q < PT; q++) {
+            if (i0 + q < n) out[i0 + q] = exclusive ? off : off + v[q];
+            off += v[q];
+        }
+        carry += tot;
+        __syncthreads();
+    }
+}
+
+// prefix sums of n counters (device-wide, three launches; one for up to 64 Ki); in == out allowed
 template <class T> static int dev_scan(sph_ctx *c, const T *in, T *out, size_t n, bool exclusive)
 {
     if (n == 0) return SPH_OK;
+    if (n <= 65536) {
+        hipLaunchKernelGGL(k_scan_small<T>, dim3(1), dim3(1024), 0, c->stream, in, out, (uint32_t)n, exclusive ? 1 : 0);
+        return SPH_OK;
+    }
     const uint32_t nblk = (uint32_t)div_up(n, SCAN_BLOCK);
     SPH_TRY(c->scan_part.reserve(((size_t)nblk + 64) * sizeof(T)));
     T *part = c->scan_part.as<T>();
