@@ -1142,6 +1142,8 @@ def secondary_runs(args, local_rank, tstream):
     cases = [
         ('C2 dam break dx 0.0087', dict(workload='dam_break', dx=0.0087), True),
         ('dam break dx 0.0055 (4 M fluid)', dict(workload='dam_break', dx=0.0055), True),
+        # the same tank with every particle carrying its own h: the merged one-launch path on variable-h records (round 5)
+        ('dam break dx 0.0055, h +-15 %', dict(workload='dam_break', dx=0.0055, vary_h=0.15), True),
         # BASELINE config 4's workload on ONE GPU: the N = 1 anchor of its 8-GPU strong-scaling number
         ('C4 dam break dx 0.0035 (16 M) on one GPU', dict(workload='dam_break', dx=0.0035), True),
         ('C3 Taylor-Green 159^3 TVF', dict(workload='taylor_green', n1=159), True),
