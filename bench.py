@@ -212,9 +212,11 @@ class Workload(object):
 
 
 def _dam_weights(arrays, args):
-    """work per particle for the slab cut of a dam break (--slab-weight-solid, default 0.5: a boundary /
-    obstacle particle is a destination of the continuity equation over the fluid only, and most of them have no
-    fluid neighbour; 1: equal particle counts)"""
+    """work per particle for the slab cut of a dam break (--slab-weight-solid; default 1: equal particle counts.
+    A boundary / obstacle particle is a destination of the continuity equation over the fluid only, which argues for
+    less -- measured on the emulated ranks of the 17 M tank it does not pay: the end slab that holds most of them also
+    holds the sparsest grid, whose neighbour update costs 0.25 ms against 0.11: slowest rank 1.77 / 1.65 / 1.53 / 1.42 ms
+    at weight 0.25 / 0.5 / 0.75 / 1)"""
     ws = float(args.slab_weight_solid)
     return np.concatenate([np.full(a.get_number_of_particles(), 1.0 if a.name == 'fluid' else ws) for a in arrays])
 
@@ -628,7 +630,7 @@ def parse_args(argv=None):
                          'reducing them every update: LinkedListNNPS(fixed_h=True) plus bounds a '
                          'stepping host knows from its own reductions; removes the min/max pass and '
                          'its device->host round trip from the step (reported in config)')
-    ap.add_argument('--slab-weight-solid', type=float, default=0.5, dest='slab_weight_solid',
+    ap.add_argument('--slab-weight-solid', type=float, default=1.0, dest='slab_weight_solid',
                     help='dam_break over several ranks: work of a boundary / obstacle particle relative to a fluid '
                          'particle when the slab faces are cut (1: equal particle counts)')
     ap.add_argument('--halo-protocol', default='padded', dest='halo_protocol', choices=['padded', 'capacity', 'handshake'],
