@@ -1929,11 +1929,13 @@ int nnps_build_csr_device(sph_ctx *c, int src, int dst, DevBuf &start, DevBuf &n
 // ---------------------------------------------------------------------------
 // physical reorder into cell order
 // ---------------------------------------------------------------------------
+// dst[i] = src[perm[i]] for i < n, 0 for n <= i < cap (the slack behind the particles stays zero without a memset)
 __global__ __launch_bounds__(256) void k_gather_f64(const double *__restrict__ src, const uint32_t *__restrict__ perm,
-                                                    size_t n, double *__restrict__ dst)
+                                                    size_t n, size_t cap, double *__restrict__ dst)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[perm[i]];
+    else if (i < cap) dst[i] = 0.0;
 }
 
 // DeviceHelper.align(indices) (pysph/base/device_helper.py:241-288): new particle i
@@ -1955,11 +1957,10 @@ extern "C" int sph_array_permute(sph_ctx *c, int id, const uint32_t *indices, si
         HIP_TRY(hipMemcpyAsync(c->aux.ptr, indices, n_new * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         double *tmp = nullptr;
         HIP_TRY(hipMalloc((void **)&tmp, A.cap * sizeof(double)));
-        HIP_TRY(hipMemsetAsync(tmp, 0, A.cap * sizeof(double), c->stream));
         for (int p = 0; p < SPH_PROP_COUNT; p++) {
             if (!A.prop[p]) continue;
-            hipLaunchKernelGGL(k_gather_f64, dim3(div_up(n_new, 256)), dim3(256), 0, c->stream, A.prop[p],
-                               c->aux.as<uint32_t>(), n_new, tmp);
+            hipLaunchKernelGGL(k_gather_f64, dim3(div_up(A.cap, 256)), dim3(256), 0, c->stream, A.prop[p],
+                               c->aux.as<uint32_t>(), n_new, A.cap, tmp);
             double *old = A.prop[p];
             A.prop[p] = tmp;
             tmp = old;
@@ -1995,11 +1996,10 @@ extern "C" int sph_nnps_reorder_array(sph_ctx *c, int id)
     }
     double *tmp = nullptr;
     HIP_TRY(hipMalloc((void **)&tmp, A.cap * sizeof(double)));
-    HIP_TRY(hipMemsetAsync(tmp, 0, A.cap * sizeof(double), c->stream));
     for (int p = 0; p < SPH_PROP_COUNT; p++) {
         if (!A.prop[p]) continue;
-        hipLaunchKernelGGL(k_gather_f64, dim3(div_up(A.n, 256)), dim3(256), 0, c->stream, A.prop[p], A.perm.as<uint32_t>(),
-                           A.n, tmp);
+        hipLaunchKernelGGL(k_gather_f64, dim3(div_up(A.cap, 256)), dim3(256), 0, c->stream, A.prop[p], A.perm.as<uint32_t>(),
+                           A.n, A.cap, tmp);
         double *old = A.prop[p];
         A.prop[p] = tmp;
         tmp = old;
