@@ -68,6 +68,8 @@ struct DevArray {
     double h_lo = 0.0, h_hi = 0.0, m_lo = 0.0, m_hi = 0.0;
     int nnps_slot = -1;                  // position in the last sph_nnps_update list
     size_t perm_n = 0;                   // particles `perm` was built for (0: none / already applied)
+    size_t perm_direct_n = 0;            // ... and `perm` is this array's own cell order written by the last sort (not a lazily derived one)
+    bool unordered = false;              // the array lies in memory in no spatial order (the key pass said so): visited through perm
     // Ghost split (sph_nnps_update_ghosts): the tables above cover the first n_binned particles (the real ones: the
     // update ran before the ghosts of this step arrived); the g_n ghosts behind them are binned on the same grid
     // into tables of their own and read by the pair kernels as a second source segment of the array.
@@ -186,6 +188,11 @@ struct sph_ctx {
     int sort_lbits = 0;           // low key bits sorted inside a bucket (adapted to the largest bucket of the previous sort)
     double sort_bkmax = 0;        // largest bucket of the last sort whose figure has arrived
     double sort_over = 0;         // ... and its particles in buckets beyond the LDS stage
+    double sort_groups = 0;       // atomic groups of the last key pass (n / 64 * 1..2 in cell order, n in no order)
+    bool last_keys_via = false;   // ... which visited its array through the previous cell order
+    size_t last_keys_n = 0;       // ... over this many particles of
+    const DevArray *last_keys_array = nullptr; // ... this (single) array
+    long via_unordered = 1;       // option: 0 = never visit through the previous order
     long hand_sort = 1;           // option: 0 = profiling aid, the bucket size is not adapted
     // The update without a device->host round trip (option async_update, default 1).  When h and m are known without
     // looking (DevArray::h_dirty / m_dirty) only the bounds of the positions are missing for the grid -- and ANY grid

@@ -98,12 +98,18 @@ enum { MM_XYZ = 1, MM_H = 2, MM_M = 4 };
 #define MM_OUT_BKMAX 40    // out[]: 8 global values, 4 per array, the largest bucket of the previous sort,
 #define MM_OUT_OVER 41     // ... the particles it had in buckets beyond the LDS stage
 #define MM_OUT_XFLAG 42    // the context's device flag word (sph_ctx::xflag: a non-positive density met by the merged records)
-#define MM_OUT_N 43
+#define MM_OUT_GROUPS 43   // atomic groups k_bin_keys formed (one per bucket a wavefront's 64 particles hit): n / 64 * 1..2 for
+                           // particles in cell order, n for particles in no spatial order
+#define MM_OUT_N 44
 
 struct BinArrays {   // the arrays of one update, concatenated in slot order
     const double *x[SPH_MAX_ARRAYS], *y[SPH_MAX_ARRAYS], *z[SPH_MAX_ARRAYS], *h[SPH_MAX_ARRAYS], *m[SPH_MAX_ARRAYS];
     uint32_t n[SPH_MAX_ARRAYS], off[SPH_MAX_ARRAYS]; // particles, first position in the concatenation
     uint32_t first[SPH_MAX_ARRAYS + 1];               // workgroups [first[a], first[a + 1]) belong to array a
+    // (optional) the order in which an array's particles are VISITED: thread t takes particle via[t] -- the previous
+    // update's cell order for an array that lies in memory in no spatial order, so that a wavefront's 64 particles are
+    // neighbours again and hit one or two buckets (DevArray::unordered)
+    const uint32_t *via[SPH_MAX_ARRAYS];
     int narrays;
 };
 struct BinWork {
@@ -111,6 +117,7 @@ struct BinWork {
     uint32_t *G, *bstart, *cur;  // bucket histogram (zero on entry and on exit), bucket starts [nbuckets + 1], cursors (zeroed here)
     uint32_t *ticket;            // [1] largest bucket of the previous sort, [2] its particles in buckets beyond the LDS stage (read and reset by k_bin_finish)
     double *part, *parta;        // partials per workgroup: [8] {xmin ymin zmin hmin xmax ymax zmax hmax}, [4] {hmin hmax mmin mmax} of its array
+    uint32_t *grp;               // ... and its count of atomic groups
     double *out;                 // [0..7] as part, [8 + 4 a ..] {mmin mmax hmin hmax} of array a, [MM_OUT_BKMAX ...]
     const uint32_t *xflag;       // the context's flag word, copied to out[MM_OUT_XFLAG]
     uint32_t nbuckets;
@@ -131,26 +138,29 @@ __global__ __launch_bounds__(256) void k_bin_keys(BinArrays t, GridDesc g, BinWo
     const double *__restrict__ x = t.x[a], *__restrict__ y = t.y[a], *__restrict__ z = t.z[a];
     const double *__restrict__ h = (w.mm & MM_H) ? t.h[a] : nullptr, *__restrict__ m = (w.mm & MM_M) ? t.m[a] : nullptr;
     const uint32_t n = t.n[a], lb = blockIdx.x - t.first[a], nba = t.first[a + 1] - t.first[a];
+    const uint32_t *__restrict__ via = t.via[a];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const bool mmx = (w.mm & MM_XYZ) != 0;
+    uint32_t ngroups = 0; // (wave-uniform)
     double mn[5] = {DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX};
     double mx[5] = {-DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX};
     for (size_t i0 = (size_t)lb * 256; i0 < n; i0 += (size_t)nba * 256) { // the trip count is uniform over the workgroup
         const size_t i = i0 + threadIdx.x;
         const bool valid = i < n;
         double px = 0, py = 0, pz = 0;
-        if (valid) { px = x[i]; py = y[i]; pz = z[i]; }
+        const size_t j = valid && via ? (size_t)via[i] : i; // the particle this thread takes
+        if (valid) { px = x[j]; py = y[j]; pz = z[j]; }
         const bool counts = valid && !is_parked(px); // padding rows (sph_halo_append_padded) are nobody's bounds, h or m
         if (counts && mmx) {
             mn[0] = fmin(mn[0], px); mx[0] = fmax(mx[0], px);
             mn[1] = fmin(mn[1], py); mx[1] = fmax(mx[1], py);
             mn[2] = fmin(mn[2], pz); mx[2] = fmax(mx[2], pz);
         }
-        if (counts && h) { const double v = h[i]; mn[3] = fmin(mn[3], v); mx[3] = fmax(mx[3], v); }
-        if (counts && m) { const double v = m[i]; mn[4] = fmin(mn[4], v); mx[4] = fmax(mx[4], v); }
+        if (counts && h) { const double v = h[j]; mn[3] = fmin(mn[3], v); mx[3] = fmax(mx[3], v); }
+        if (counts && m) { const double v = m[j]; mn[4] = fmin(mn[4], v); mx[4] = fmax(mx[4], v); }
         if (w.keys) {
             uint32_t key = 0;
-            if (valid) { key = fine_key_of(px, py, pz, g, i); w.keys[(size_t)t.off[a] + i] = key; }
+            if (valid) { key = fine_key_of(px, py, pz, g, j); w.keys[(size_t)t.off[a] + i] = key; }
             const uint32_t d = key >> w.lbits;
             unsigned long long todo = __ballot(valid);
             uint32_t cnt = 0; // this lane leads a group of `cnt` particles of one bucket
@@ -160,6 +170,7 @@ __global__ __launch_bounds__(256) void k_bin_keys(BinArrays t, GridDesc g, BinWo
                 const unsigned long long mk = __ballot(valid && d == dl);
                 if (lane == l) cnt = (uint32_t)__builtin_popcountll(mk);
                 todo &= ~mk;
+                ngroups++;
             }
             // one atomic per bucket the wavefront's particles hit, all of them in ONE instruction (particles in no
             // spatial order make 64 groups: 64 single-lane atomic instructions cost 0.35 ms at 4 M)
@@ -167,6 +178,12 @@ __global__ __launch_bounds__(256) void k_bin_keys(BinArrays t, GridDesc g, BinWo
         }
     }
     __shared__ double s[4][10];
+    if (w.keys) { // this workgroup's atomic groups: one plain store (8 k same-address atomics cost 70 us at 4 M)
+        __shared__ uint32_t sgrp[4];
+        if (lane == 0) sgrp[wv] = ngroups;
+        __syncthreads();
+        if (threadIdx.x == 0) w.grp[blockIdx.x] = sgrp[0] + sgrp[1] + sgrp[2] + sgrp[3];
+    }
     if (w.mm) {
 #pragma unroll
         for (int k = 0; k < 5; k++) {
@@ -229,6 +246,17 @@ __global__ __launch_bounds__(1024) void k_bin_finish(BinArrays t, BinWork w, uin
         w.out[MM_OUT_OVER] = (double)w.ticket[2]; w.ticket[2] = 0u;
         w.out[MM_OUT_XFLAG] = (double)*w.xflag;
     }
+    if (have_keys) { // atomic groups of the key pass, summed over its workgroups
+        __shared__ uint32_t sg[16];
+        uint32_t gsum = 0;
+        for (uint32_t b = threadIdx.x; b < nblk; b += 1024) gsum += w.grp[b];
+        for (int o2 = 32; o2 > 0; o2 >>= 1) gsum += __shfl_xor(gsum, o2, 64);
+        if (lane == 0) sg[wv] = gsum;
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t tot = 0; for (int q = 0; q < 16; q++) tot += sg[q]; w.out[MM_OUT_GROUPS] = (double)tot; }
+    } else if (threadIdx.x == 0) {
+        w.out[MM_OUT_GROUPS] = 0.0;
+    }
     if (have_keys) { // bucket starts = exclusive scan of G; G and the cursors zeroed
         // 32 consecutive buckets per thread and round (one round up to 32 Ki buckets: the loads of a round are in flight
         // together; a sparse grid -- the slab of a dam break's tank -- has tens of thousands of buckets)
@@ -270,9 +298,10 @@ __global__ __launch_bounds__(1024) void k_bin_finish(BinArrays t, BinWork w, uin
 // (key, index) pairs into their buckets, in arrival order.  SCAT_ITEMS keys per thread: the cursor atomics of a
 // wavefront's rounds are in flight together (one key per thread left the kernel waiting on one round trip per wavefront).
 #define SCAT_ITEMS 4
+// via (optional, one array): the particle thread t stands for is via[t] (k_bin_keys visited them in that order)
 __global__ __launch_bounds__(256) void k_bucket_scatter(const uint32_t *__restrict__ keys, uint32_t n, int lbits,
                                                         const uint32_t *__restrict__ bstart, uint32_t *__restrict__ cur,
-                                                        uint2 *__restrict__ pairs)
+                                                        uint2 *__restrict__ pairs, const uint32_t *__restrict__ via)
 {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
@@ -302,7 +331,7 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(const uint32_t *__restri
     for (int q = 0; q < SCAT_ITEMS; q++) {
         const uint32_t i = i0 + q * 256u;
         const uint32_t b = __shfl(base[q], leader[q], 64);
-        if (i < n) pairs[(size_t)bs[q] + b + rank[q]] = make_uint2(key[q], i);
+        if (i < n) pairs[(size_t)bs[q] + b + rank[q]] = make_uint2(key[q], via ? via[i] : i);
     }
 }
 
@@ -721,11 +750,12 @@ static int launch_bin_keys(sph_ctx *c, const BinArrays &ba, uint32_t nblocks, co
     BinWork w;
     memset(&w, 0, sizeof w);
     SPH_TRY(sort_tables(c, keys ? nbuckets : 1, &w));
-    SPH_TRY(c->red_part.reserve((size_t)nblocks * 12 * sizeof(double)));
+    SPH_TRY(c->red_part.reserve((size_t)nblocks * 13 * sizeof(double)));
     SPH_TRY(c->red_out.reserve(64 * sizeof(double)));
     w.keys = keys;
     w.part = c->red_part.as<double>();
     w.parta = w.part + (size_t)nblocks * 8;
+    w.grp = reinterpret_cast<uint32_t *>(w.part + (size_t)nblocks * 12);
     w.out = c->red_out.as<double>();
     if (!c->xflag.ptr) {
         SPH_TRY(c->xflag.reserve(16));
@@ -872,7 +902,7 @@ static int sort_choose_lbits(sph_ctx *c, size_t n, size_t n_fine)
     return lb;
 }
 
-struct SortDest { DevArray *T; bool merged; CatOff co; };
+struct SortDest { DevArray *T; bool merged; CatOff co; const uint32_t *via = nullptr; };
 
 // keys (already in c->tmp_u32a) -> sorted order + tables of T
 static int sort_finish(sph_ctx *c, size_t n, size_t n_fine, long n_cells, int lbits, uint32_t nbuckets, const SortDest &d)
@@ -882,7 +912,7 @@ static int sort_finish(sph_ctx *c, size_t n, size_t n_fine, long n_cells, int lb
     DevArray &T = *d.T;
     uint2 *pairs = c->tmp_u32b.as<uint2>();
     hipLaunchKernelGGL(k_bucket_scatter, dim3(div_up(n, 256 * SCAT_ITEMS)), dim3(256), 0, c->stream, c->tmp_u32a.as<uint32_t>(), (uint32_t)n, lbits,
-                       (const uint32_t *)w.bstart, w.cur, pairs);
+                       (const uint32_t *)w.bstart, w.cur, pairs, d.via);
     BucketOut o;
     memset(&o, 0, sizeof o);
     o.fkeys = T.fkeys_sorted.as<uint32_t>(); o.keys = T.keys_sorted.as<uint32_t>(); o.perm = T.perm.as<uint32_t>();
@@ -1410,6 +1440,7 @@ static int lag_wait(sph_ctx *c)
         c->lag.pending = false;
         c->sort_bkmax = c->pin_async[MM_OUT_BKMAX];
         c->sort_over = c->pin_async[MM_OUT_OVER];
+        c->sort_groups = c->pin_async[MM_OUT_GROUPS];
         if (c->pin_async[MM_OUT_XFLAG] != 0.0) SPH_TRY(nnps_rho_flag(c));
     }
     return SPH_OK;
@@ -1504,6 +1535,8 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
         memcpy(c->pin_async, mm, sizeof mm);
         c->pin_async[MM_OUT_BKMAX] = c->pinned[MM_OUT_BKMAX];
         c->pin_async[MM_OUT_OVER] = c->pinned[MM_OUT_OVER];
+        c->pin_async[MM_OUT_GROUPS] = c->pinned[MM_OUT_GROUPS];
+        c->sort_groups = c->pinned[MM_OUT_GROUPS];
         c->sort_bkmax = c->pinned[MM_OUT_BKMAX];
         c->sort_over = c->pinned[MM_OUT_OVER];
         if (nblocks && c->pinned[MM_OUT_XFLAG] != 0.0) SPH_TRY(nnps_rho_flag(c));
@@ -1584,14 +1617,26 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
             for (int a = 0; a < narrays; a++) if (c->arr[ids[a]].n) T = &c->arr[ids[a]];
         if (merged_first) { T->n = T->n_real = n_cat; SPH_TRY(T->slot8.reserve(n_cat + 64)); }
         SPH_TRY(nnps_reserve_tables(c, *T, n_cat));
+        // An array that lies in memory in NO spatial order (the previous key pass, run in memory order, formed more than
+        // n / 8 atomic groups: every lane its own bucket) is visited in the cell order of the previous update instead:
+        // a wavefront's 64 particles are neighbours again -- gathers for the positions instead of 4 M atomics per pass.
+        // Sticky until the array is reordered or resized (a pass run in cell order says nothing about the memory order).
+        const uint32_t *via = nullptr;
+        if (!merged_first) {
+            if (!c->last_keys_via && c->last_keys_n > 0 && c->last_keys_array == T && c->sort_groups > (double)c->last_keys_n / 8.0) T->unordered = true;
+            if (c->via_unordered && T->unordered && T->perm_direct_n == T->n) via = T->perm.as<uint32_t>();
+            for (int a = 0; a < narrays; a++) if (&c->arr[ids[a]] == T) ba.via[a] = via;
+        }
         SPH_TRY(launch_bin_keys(c, ba, nblocks, g, mm_async, c->tmp_u32a.as<uint32_t>(), nbuckets, lbits));
+        c->last_keys_via = via != nullptr; c->last_keys_n = merged_first ? 0 : n_cat; c->last_keys_array = merged_first ? nullptr : T;
         reduced = true;
         SortDest d;
-        d.T = T; d.merged = merged_first;
+        d.T = T; d.merged = merged_first; d.via = via;
         d.co.narrays = narrays;
         for (int a = 0; a <= SPH_MAX_ARRAYS; a++) d.co.off[a] = a < narrays ? ba.off[a] : (uint32_t)n_cat;
         SPH_TRY(sort_finish(c, n_cat, n_fine, n_cells_alloc, lbits, nbuckets, d));
         SPH_TRY(nnps_tile_order(c, *T, n_cat));
+        if (!merged_first) T->perm_direct_n = n_cat;
         if (merged_first) {
             c->merged_valid = true;
             c->tables_valid = false;
@@ -1619,6 +1664,8 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
             for (int k = 0; k <= SPH_MAX_ARRAYS; k++) d.co.off[k] = k ? (uint32_t)n1 : 0u;
             SPH_TRY(sort_finish(c, n1, n_fine, n_cells_alloc, lbits, nbuckets, d));
             SPH_TRY(nnps_tile_order(c, A, n1));
+            A.perm_direct_n = n1;
+            c->last_keys_n = 0; // (several arrays: no single pass to judge)
         }
     }
     if (lagged) {
@@ -1969,6 +2016,7 @@ extern "C" int sph_array_permute(sph_ctx *c, int id, const uint32_t *indices, si
         HIP_TRY(hipFree(tmp));
     }
     A.perm_n = 0;
+    A.perm_direct_n = 0; A.unordered = false; // another memory order
     c->nnps_valid = false;
     return sph_array_resize(c, id, n_new, n_real_new);
 }
@@ -2007,6 +2055,7 @@ extern "C" int sph_nnps_reorder_array(sph_ctx *c, int id)
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipFree(tmp));
     A.perm_n = 0;
+    A.perm_direct_n = 0; A.unordered = false; // the array lies in cell order now
     c->nnps_valid = false;
     return SPH_OK;
 }

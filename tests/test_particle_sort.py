@@ -166,6 +166,30 @@ def test_update_without_round_trip_reports_the_exact_grid_and_the_same_neighbour
     ctx.close()
 
 
+def test_array_in_no_spatial_order_is_visited_in_the_previous_cell_order():
+    """an array that lies in memory in random order makes every lane of the key pass its own atomic group; from the third
+    update on (the figure travels with the bounds) the passes visit it through the previous update's cell order instead.
+    Same sorted order either way (ascending index inside a key), also after the particles moved."""
+    from pysph_amd import device as dev
+    from pysph_amd.nnps import HipNNPS
+    pa = cloud(150000, 21, h=0.012)             # random positions in index order = no spatial order
+    orders = {}
+    for via in (1, 0):
+        ctx = _ctx()
+        ctx.set_option('via_unordered', via)
+        dev.attach(pa, ctx).push()
+        nn = HipNNPS(3, [pa], radius_scale=2.0, ctx=ctx, sync=False)
+        got = []
+        for step in range(5):
+            nn.update()
+            check_order(nn, [pa])
+            got.append(nn.get_spatially_ordered_indices(0).copy())
+        orders[via] = got
+        ctx.close()
+    for a, b in zip(orders[0], orders[1]):
+        assert np.array_equal(a, b)
+
+
 def test_async_update_can_be_switched_off():
     from pysph_amd import device as dev
     from pysph_amd.nnps import HipNNPS
