@@ -507,6 +507,13 @@ int sph_reduce_min(sph_ctx *ctx, int array_id, int prop, double *out);
  *                    of WCSPHScheme(fluids, solids), under the conditions of the uniform-mass EOS-fused records;
  *                    sph_nnps_update then sorts all arrays' keys once -- that sorted sequence is the merged order --
  *                    and derives per-array tables only on demand; "lazy_tables" 0 builds them at every update)
+ *   "async_update"   0: every sph_nnps_update reduces the bounds and waits for them (default 1: an update that knows h
+ *                    and m without looking -- nothing wrote them since the last reduction -- bins on the grid of the
+ *                    PREVIOUS update's bounds while reducing its own, with no device->host round trip; sph_nnps_info
+ *                    returns the reference's exact values for the current particles either way)
+ *   "via_unordered"  0: the key passes of the sort always run in memory order (default 1: an array found to lie in
+ *                    memory in no spatial order is visited in the previous update's cell order)
+ *   "sort_lbits"     9..11: fixed low key bits of the particle sort's buckets (0: from the mean density; tests)
  *   "split_pair"     split evaluations (sph_group.phase): 0 (default) = phase 1 prepares (equations without sources,
  *                    records of the particles present), phase 2 launches every wave tile with the ghost segments
  *                    guarded per wavefront; 1 = the interior wave tiles already in phase 1, the face tiles in phase 2
@@ -538,7 +545,7 @@ int sph_timer_reset(sph_ctx *ctx);
  * evaluations run as one launch over the merged order), "n_tension_flag" (elastic rate launches that read the tension word), "n_phase2" (pair launches of the second half of a
  * split evaluation: sph_group.phase 2),
  * "n_nl_keep" / "n_nl_reuse" (launches that kept / started from kept neighbour
- * lists). */
+ * lists), "n_async" (neighbour updates that made no device->host round trip). */
 int sph_timer_get(sph_ctx *ctx, const char *key, double *ms, long *count);
 
 /* ABI self-description: the size of a struct of this header ("sph_kernel", "sph_equation", "sph_group",

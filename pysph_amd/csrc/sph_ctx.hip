@@ -315,7 +315,7 @@ int sph_set_option(sph_ctx *c, const char *key, long value)
     if (strcmp(key, "lazy_tables") == 0) { c->lazy_tables = value ? 1 : 0; c->nnps_valid = false; return SPH_OK; }
     if (strcmp(key, "async_update") == 0) { c->async_update = value ? 1 : 0; return SPH_OK; }
     if (strcmp(key, "via_unordered") == 0) { c->via_unordered = value ? 1 : 0; return SPH_OK; }
-    if (strcmp(key, "sort_lbits") == 0) { // 0: adaptive; 9..11: fixed low key bits of the particle sort (profiling)
+    if (strcmp(key, "sort_lbits") == 0) { // 0: from the mean density; 9..11: fixed low key bits of the particle sort (profiling / tests)
         if (value != 0 && (value < 9 || value > 11)) { sph_set_error("sort_lbits must be 0 or 9..11"); return SPH_ERR_ARG; }
         c->sort_lbits = (int)value; c->hand_sort = value == 0; return SPH_OK;
     }

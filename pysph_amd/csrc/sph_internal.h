@@ -185,15 +185,13 @@ struct sph_ctx {
     // The hand-written particle sort (sph_nnps.hip): bucket histogram / starts / cursors, ticket words
     DevBuf sort_tab;
     size_t sort_tab_entries = 0;  // buckets the tables were zeroed for
-    int sort_lbits = 0;           // low key bits sorted inside a bucket (adapted to the largest bucket of the previous sort)
-    double sort_bkmax = 0;        // largest bucket of the last sort whose figure has arrived
-    double sort_over = 0;         // ... and its particles in buckets beyond the LDS stage
+    int sort_lbits = 0;           // low key bits sorted inside a bucket (chosen from the mean density, or fixed by option sort_lbits)
     double sort_groups = 0;       // atomic groups of the last key pass (n / 64 * 1..2 in cell order, n in no order)
     bool last_keys_via = false;   // ... which visited its array through the previous cell order
     size_t last_keys_n = 0;       // ... over this many particles of
     const DevArray *last_keys_array = nullptr; // ... this (single) array
     long via_unordered = 1;       // option: 0 = never visit through the previous order
-    long hand_sort = 1;           // option: 0 = profiling aid, the bucket size is not adapted
+    long hand_sort = 1;           // 0: option sort_lbits fixed the bucket size (profiling / tests)
     // The update without a device->host round trip (option async_update, default 1).  When h and m are known without
     // looking (DevArray::h_dirty / m_dirty) only the bounds of the positions are missing for the grid -- and ANY grid
     // whose cells are at least radius_scale * hmax wide gives the same neighbours (particles outside it are clamped into

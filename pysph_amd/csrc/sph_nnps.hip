@@ -95,8 +95,7 @@ __device__ __forceinline__ uint32_t fine_key_of(double x, double y, double z, co
 #define SORT_BIGQ 128      // larger ones: queued, ranked by counting by the whole workgroup (an LDS-staged bucket has at most 124)
 #define SORT_BS 512        // threads of a k_bucket_sort workgroup
 enum { MM_XYZ = 1, MM_H = 2, MM_M = 4 };
-#define MM_OUT_BKMAX 40    // out[]: 8 global values, 4 per array, the largest bucket of the previous sort,
-#define MM_OUT_OVER 41     // ... the particles it had in buckets beyond the LDS stage
+// out[]: 8 global values, 4 per array, then
 #define MM_OUT_XFLAG 42    // the context's device flag word (sph_ctx::xflag: a non-positive density met by the merged records)
 #define MM_OUT_GROUPS 43   // atomic groups k_bin_keys formed (one per bucket a wavefront's 64 particles hit): n / 64 * 1..2 for
                            // particles in cell order, n for particles in no spatial order
@@ -115,10 +114,9 @@ struct BinArrays {   // the arrays of one update, concatenated in slot order
 struct BinWork {
     uint32_t *keys;              // fine key of every particle of the concatenation (null: bounds only)
     uint32_t *G, *bstart, *cur;  // bucket histogram (zero on entry and on exit), bucket starts [nbuckets + 1], cursors (zeroed here)
-    uint32_t *ticket;            // [1] largest bucket of the previous sort, [2] its particles in buckets beyond the LDS stage (read and reset by k_bin_finish)
     double *part, *parta;        // partials per workgroup: [8] {xmin ymin zmin hmin xmax ymax zmax hmax}, [4] {hmin hmax mmin mmax} of its array
     uint32_t *grp;               // ... and its count of atomic groups
-    double *out;                 // [0..7] as part, [8 + 4 a ..] {mmin mmax hmin hmax} of array a, [MM_OUT_BKMAX ...]
+    double *out;                 // [0..7] as part, [8 + 4 a ..] {mmin mmax hmin hmax} of array a, [MM_OUT_XFLAG ...]
     const uint32_t *xflag;       // the context's flag word, copied to out[MM_OUT_XFLAG]
     uint32_t nbuckets;
     int lbits, mm;
@@ -241,11 +239,7 @@ __global__ __launch_bounds__(1024) void k_bin_finish(BinArrays t, BinWork w, uin
             if (lane == 0) { w.out[8 + 4 * a2] = ml; w.out[9 + 4 * a2] = mh; w.out[10 + 4 * a2] = hl; w.out[11 + 4 * a2] = hh; }
         }
     }
-    if (threadIdx.x == 0) {
-        w.out[MM_OUT_BKMAX] = (double)w.ticket[1]; w.ticket[1] = 0u;
-        w.out[MM_OUT_OVER] = (double)w.ticket[2]; w.ticket[2] = 0u;
-        w.out[MM_OUT_XFLAG] = (double)*w.xflag;
-    }
+    if (threadIdx.x == 0) w.out[MM_OUT_XFLAG] = (double)*w.xflag;
     if (have_keys) { // atomic groups of the key pass, summed over its workgroups
         __shared__ uint32_t sg[16];
         uint32_t gsum = 0;
@@ -344,7 +338,6 @@ struct BucketOut {
     uint32_t *fine_start, *cell_start;
     uint32_t n_fine, n_cells;
     uint2 *scratch;                // n entries (big bins)
-    uint32_t *bkmax;               // [0] largest bucket (atomicMax), [1] particles in buckets beyond the LDS stage
 };
 
 // One unit of the bucket sort: the `cnt_all` pairs at `src` whose low key bits lie in the sub-range [k_lo, k_hi) of the
@@ -575,9 +568,7 @@ __global__ __launch_bounds__(BS, 8) void k_bucket_sort(const uint2 *__restrict__
                 if (over) bucket_unit_global<BS>(pairs + base, s, r * width, (r + 1) * width, mask, fk0, base + done, t, o, tab, bigq, &nbig);
                 done += t;
             }
-            if (tid == 0) atomicAdd(o.bkmax + 1, s);
         }
-        if (tid == 0) atomicMax(o.bkmax, s);
         if (MULTI) __syncthreads(); // the LDS tables serve the workgroup's next bucket
     }
 }
@@ -722,7 +713,7 @@ static int bin_arrays(sph_ctx *c, int narrays, const int *ids, BinArrays *ba, si
     return SPH_OK;
 }
 
-// tables of the sort: [G: cap][bstart: cap + 1][cur: cap][words: 4]; G and the largest-bucket word must be zero between sorts
+// tables of the sort: [G: cap][bstart: cap + 1][cur: cap]; G must be zero between sorts (k_bin_finish leaves it so)
 static int sort_tables(sph_ctx *c, uint32_t nbuckets, BinWork *w)
 {
     const size_t cap = std::max<size_t>(c->sort_tab_entries, 1024);
@@ -737,7 +728,7 @@ static int sort_tables(sph_ctx *c, uint32_t nbuckets, BinWork *w)
     }
     uint32_t *t = c->sort_tab.as<uint32_t>();
     const size_t e = c->sort_tab_entries;
-    w->G = t; w->bstart = t + e; w->cur = t + 2 * e + 1; w->ticket = t + 3 * e + 4;
+    w->G = t; w->bstart = t + e; w->cur = t + 2 * e + 1;
     w->nbuckets = nbuckets;
     return SPH_OK;
 }
@@ -921,7 +912,6 @@ static int sort_finish(sph_ctx *c, size_t n, size_t n_fine, long n_cells, int lb
     o.fine_start = T.fine_start.as<uint32_t>(); o.cell_start = T.cell_start.as<uint32_t>();
     o.n_fine = (uint32_t)n_fine; o.n_cells = (uint32_t)n_cells;
     o.scratch = c->tmp_u32a.as<uint2>();
-    o.bkmax = w.ticket + 1;
     // Two variants for grids whose buckets hold a few hundred particles (the end slab of a dam-break tank: 11.8 k buckets
     // of 250, 24.5 M table entries for 2.9 M particles) were built, measured and removed: a small workgroup shape (128
     // threads, 1024-pair stage, ten per CU: the same 150 us) and one WAVEFRONT per small bucket with LDS areas of its own and
@@ -1438,8 +1428,6 @@ static int lag_wait(sph_ctx *c)
     if (c->lag.pending) {
         HIP_TRY(hipEventSynchronize(c->lag_ev));
         c->lag.pending = false;
-        c->sort_bkmax = c->pin_async[MM_OUT_BKMAX];
-        c->sort_over = c->pin_async[MM_OUT_OVER];
         c->sort_groups = c->pin_async[MM_OUT_GROUPS];
         if (c->pin_async[MM_OUT_XFLAG] != 0.0) SPH_TRY(nnps_rho_flag(c));
     }
@@ -1533,12 +1521,8 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
         }
         // these bounds are what the next update may bin on
         memcpy(c->pin_async, mm, sizeof mm);
-        c->pin_async[MM_OUT_BKMAX] = c->pinned[MM_OUT_BKMAX];
-        c->pin_async[MM_OUT_OVER] = c->pinned[MM_OUT_OVER];
         c->pin_async[MM_OUT_GROUPS] = c->pinned[MM_OUT_GROUPS];
         c->sort_groups = c->pinned[MM_OUT_GROUPS];
-        c->sort_bkmax = c->pinned[MM_OUT_BKMAX];
-        c->sort_over = c->pinned[MM_OUT_OVER];
         if (nblocks && c->pinned[MM_OUT_XFLAG] != 0.0) SPH_TRY(nnps_rho_flag(c));
         c->lag.valid = !bounds;
         c->lag.pending = false;
