@@ -353,6 +353,9 @@ typedef struct sph_gen_family {
                                   * 2 = nothing else follows (the last mode-3 launch runs post_loop)      */
     int nstate;                  /* equation attributes the device code assigns (self.x = ...): in/out    */
     double state[SPH_GEN_MAX_STATE];
+    sph_gen_launch_fn launch_f32; /* the same family compiled with float arithmetic (fp32 records, fp32 accumulators),
+                                  * or NULL: taken for the pair launch under option arith_f32 -- the fp32 mode of the
+                                  * reference's generated GPU code (acceleration_eval_gpu_helper.py:281-283,437-441) */
 } sph_gen_family;
 
 /* initialize -> no-source loops -> per-source pair loops -> post_loop of one
@@ -482,7 +485,9 @@ int sph_reduce_min(sph_ctx *ctx, int array_id, int prop, double *out);
  *   "uniform_h"      0/1: allow the hmin == hmax specialisation (default 1)
  *   "arith_f32"      0/1: pair loops in fp32 arithmetic on fp32 records (the
  *                    reference's GPU backends without --use-double,
- *                    acceleration_eval_gpu_helper.py:281-283); default 0
+ *                    acceleration_eval_gpu_helper.py:281-283); default 0.
+ *                    Generated families: the pair launch of those that carry
+ *                    a float build (sph_gen_family.launch_f32)
  *   "record_f32"     0/1: fp32 records, fp64 arithmetic; default 0
  *   "const_flags"    0/1: equation-flag set compiled as a constant when it is
  *                    the family's usual one (default 1)

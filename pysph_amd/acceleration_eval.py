@@ -285,8 +285,22 @@ class _GeneratedUnit(object):
             self.cf.par[k] = v
         self.cf.start_idx, self.cf.stop_idx = start, stop
 
+    def _float_build(self, ev):
+        """option arith_f32: the pair launch of this family runs its float build
+        (codegen.source_f32), compiled / loaded the first time the option is seen"""
+        f = self.fam
+        if f.abs_src_pos and ev.ctx.options.get('record_f32'):
+            raise RuntimeError(
+                "generated family '%s' reads a neighbour's absolute position (s_x[s_idx]); fp32 records "
+                "(option record_f32) hold positions relative to the grid origin" % f.name)
+        if ev.ctx.options.get('arith_f32') and not self.cf.launch_f32 and f.sources and f.bodies['loop'] \
+                and not f.abs_src_pos:
+            self._lib32 = f.flavour_f32().load()
+            self.cf.launch_f32 = C.cast(self._lib32.sphgen_launch, C.c_void_p).value
+
     def run(self, ev, t, dt):
         f = self.fam
+        self._float_build(ev)
         for k, v in enumerate(f.state_values()):
             self.cf.state[k] = v
         dev._check(ev.lib.sph_eval_generated(

@@ -38,6 +38,7 @@ from collections import OrderedDict
 import hashlib
 import inspect
 import os
+import re
 import subprocess
 import textwrap
 
@@ -936,6 +937,61 @@ def build_deferred(jobs=None):
     return len(unique)
 
 
+_F32_LITERAL = re.compile(r'(?<![\w.])((?:\d+\.\d*|\.\d+)(?:[eE][+-]?\d+)?|\d+[eE][+-]?\d+)(?![\w.])')
+_F32_VIEW = (
+    '#define SPHGEN_F32 1\n'
+    '// fp64 memory read as float operands (scalar parameters, whole source arrays of loop_all / initialize_pair)\n'
+    'struct GenF32View {\n'
+    '    const double *p;\n'
+    '    __device__ __forceinline__ float operator[](long i) const { return (float)p[i]; }\n'
+    '};\n')
+
+
+def source_f32(src):
+    """The family's source with its ARITHMETIC in float: the fp32 mode of the
+    reference's generated GPU code (acceleration_eval_gpu_helper.py:281-283,
+    437-441 casts every array and scalar to float32 when use_double is off).
+    Particle arrays stay fp64 in memory (values narrowed on load, widened on
+    store), the records of the pair loop are fp32 (option record_f32 layout),
+    every local, pair symbol, kernel evaluation, literal and accumulator is
+    float.  Text-level: the emitted skeleton is regular, the interface parts
+    (Params, the fp64 record reader, the launch wrapper) are kept as they are."""
+    out, keep = [], None
+    for ln in src.split('\n'):
+        st = ln.strip()
+        if keep is None:
+            if st == 'struct Params {':
+                keep = '    };'
+            elif st.startswith('template <> __device__ __forceinline__ void load_record<FamGen, true>'):
+                keep = '}'
+            elif st.startswith('extern "C" int sphgen_kernel_kind'):
+                keep = '\0'                     # to the end: the launch wrapper
+        if keep is not None:
+            out.append(ln)
+            if ln == keep:
+                keep = None
+            continue
+        if st.startswith('#') or st.startswith('//'):
+            out.append(ln)
+            if st == '#include <cstring>':
+                out.append(_F32_VIEW)
+            continue
+        m = re.match(r'^(\s*)const double \*(PAR|S_\w+) = (a\.p\.[\w\[\]\.]+); \(void\)\2;$', ln)
+        if m:
+            out.append('%sconst GenF32View %s{%s}; (void)%s;' % (m.group(1), m.group(2), m.group(3), m.group(2)))
+            continue
+        ln = ln.replace('((double)d_idx)', '@IDX_D@').replace('((double)o)', '@IDX_O@')
+        ln = re.sub(r'\bdouble4\b', 'float4', ln)
+        ln = re.sub(r'\bdouble\b', 'float', ln)
+        ln = re.sub(r'\bPairGeom\b', 'PairGeomT<float>', ln)
+        ln = re.sub(r'\b(a\.k\.sigma|a\.k\.deltap|a\.hu)\b', r'((float)\1)', ln)
+        ln = re.sub(r'\b(M_PI|M_1_PI|M_2_SQRTPI|M_PI_2)\b', r'((float)\1)', ln)
+        ln = _F32_LITERAL.sub(r'\1f', ln)
+        ln = ln.replace('@IDX_D@', '((double)d_idx)').replace('@IDX_O@', '((double)o)')
+        out.append(ln)
+    return '\n'.join(out)
+
+
 class GeneratedFamily(object):
     """All equations of one group acting on one destination, generated."""
 
@@ -966,6 +1022,7 @@ class GeneratedFamily(object):
                     self.sources.append(s)
                     self.src_flags[s] = 0
                 self.src_flags[s] |= 1 << k
+        self.abs_src_pos = False
         self.helpers = OrderedDict()    # name -> _HelperBody, in dependency order
         self.sym_written = set()        # pair symbols some equation assigns to
         self.raw_dest = set()           # destination properties also read at a run-time index
@@ -1042,6 +1099,10 @@ class GeneratedFamily(object):
 
     def src_prop(self, prop):
         if prop in ('x', 'y', 'z', 'h'):
+            if prop != 'h':
+                # a body reads a neighbour's ABSOLUTE position (not XIJ): fp32 records hold positions
+                # relative to the grid origin, so this family keeps fp64 records
+                self.abs_src_pos = True
             return {'x': 'pj.x', 'y': 'pj.y', 'z': 'pj.z', 'h': 's_h'}[prop]
         if prop not in self.sprops:
             self.sprops.append(prop)
@@ -1432,10 +1493,15 @@ class GeneratedFamily(object):
         A('    } else {')
         A('        if (g->nrec != (g->rec_f32 ? ((4 + FamGen::NA + 3) & ~3) : g->uniform_h ? %d : FamGen::NR)) return -1002;' % nrc)
         A('        dim3 grid(4 * ((a.nd + 255) / 256) / WPB), block(64 * WPB);')
+        A('#ifdef SPHGEN_F32   // Real = float reads fp32 records only')
+        A('        if (!g->rec_f32) return -1003;')
+        A('#endif')
         A('        if (g->rec_f32 && g->uniform_h) hipLaunchKernelGGL((k_pair_wave<FamGen, %d, true, true>), grid, block, 0, st, a);' % self.kernel_kind)
         A('        else if (g->rec_f32) hipLaunchKernelGGL((k_pair_wave<FamGen, %d, false, true>), grid, block, 0, st, a);' % self.kernel_kind)
+        A('#ifndef SPHGEN_F32')
         A('        else if (g->uniform_h) hipLaunchKernelGGL((k_pair_wave<FamGen, %d, true>), grid, block, 0, st, a);' % self.kernel_kind)
         A('        else hipLaunchKernelGGL((k_pair_wave<FamGen, %d, false>), grid, block, 0, st, a);' % self.kernel_kind)
+        A('#endif')
         A('    }')
         A('    return (int)hipGetLastError();')
         A('}')
@@ -1501,6 +1567,20 @@ class GeneratedFamily(object):
                 break
         os.replace(so + '.tmp', so)
         return so
+
+    def flavour_f32(self):
+        """the same family with float arithmetic (`source_f32`): its own content
+        address, built and cached like the fp64 one"""
+        if getattr(self, '_f32', None) is None:
+            import copy
+            f = copy.copy(self)
+            f.source = source_f32(self.source)
+            f.hash = hashlib.sha1((f.source + _skeleton_digest()).encode()).hexdigest()[:16]
+            f.name = self.name + '_f32'
+            f.lib = None
+            f._f32 = f
+            self._f32 = f
+        return self._f32
 
     def load(self):
         if self.lib is None:

@@ -338,7 +338,7 @@ static const AbiField ABI_FIELDS[] = {
     ABI_F(sph_gen_family, din), ABI_F(sph_gen_family, n_dout), ABI_F(sph_gen_family, dout), ABI_F(sph_gen_family, npar),
     ABI_F(sph_gen_family, par), ABI_F(sph_gen_family, real), ABI_F(sph_gen_family, start_idx), ABI_F(sph_gen_family, stop_idx),
     ABI_F(sph_gen_family, split_init), ABI_F(sph_gen_family, loop_all), ABI_F(sph_gen_family, also_pair), ABI_F(sph_gen_family, init_pair),
-    ABI_F(sph_gen_family, nstate), ABI_F(sph_gen_family, state),
+    ABI_F(sph_gen_family, nstate), ABI_F(sph_gen_family, state), ABI_F(sph_gen_family, launch_f32),
     ABI_F(sph_gen_args, stream), ABI_F(sph_gen_args, rec), ABI_F(sph_gen_args, mode), ABI_F(sph_gen_args, par), ABI_F(sph_gen_args, state),
     ABI_F(sph_gen_args, row_mod3),
 };

@@ -2453,6 +2453,7 @@ static int eval_generated_launches(sph_ctx *c, const sph_kernel *K, const sph_ge
             q.dflags = 0;
         }
         q.skip_post = last ? 0 : 1;
+        bool a32 = false;
 
         if (ns > 0) {
             if (!c->nnps_valid) { sph_set_error("sph_eval_generated: neighbour grid is stale; call sph_nnps_update"); return SPH_ERR_STATE; }
@@ -2474,10 +2475,13 @@ static int eval_generated_launches(sph_ctx *c, const sph_kernel *K, const sph_ge
             // whole 16-byte pieces; under uniform h the records drop h: [x y z | aux...]
             const bool compact = q.uniform_h != 0;
             const int na_fam = ((na + 1) & ~1) < 2 ? 2 : ((na + 1) & ~1); // FamGen::NA
-            const int nr = c->record_f32 ? ((4 + na_fam + 3) & ~3) /* floats */
+            // option arith_f32: the family's float build (fp32 records, arithmetic and accumulators), when the host gave one
+            a32 = c->arith_f32 && f->launch_f32 != nullptr;
+            const bool rf32 = c->record_f32 || a32;
+            const int nr = rf32 ? ((4 + na_fam + 3) & ~3) /* floats */
                          : compact ? ((3 + na + 1) & ~1) : 4 + ((na + 1) & ~1);
-            const int layout = c->record_f32 ? 5 : (compact ? 4 : 0);
-            q.rec_f32 = c->record_f32 ? 1 : 0;
+            const int layout = rf32 ? 5 : (compact ? 4 : 0);
+            q.rec_f32 = rf32 ? 1 : 0;
             SPH_TRY(c->posh.reserve((total + 64) * sizeof(double) * nr));
             for (auto &pc : c->pack_cache) pc.epoch = 0; // the generated family's records overwrite the shared WCSPH slots
             SPH_TRY(c->aux.reserve(64));
@@ -2521,7 +2525,7 @@ static int eval_generated_launches(sph_ctx *c, const sph_kernel *K, const sph_ge
             q.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
         }
         ScopedTimer tm(c, ns > 0 ? T_PAIR : T_EOS);
-        int rc = f->launch(&q);
+        int rc = (a32 ? f->launch_f32 : f->launch)(&q);
         if (rc != 0) { sph_set_error("generated family launch failed (code %d)", rc); return SPH_ERR_HIP; }
         return SPH_OK;
     };

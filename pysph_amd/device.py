@@ -191,7 +191,7 @@ class SphGenFamily(C.Structure):
                 ('stop_idx', C.c_long), ('split_init', C.c_int),
                 ('loop_all', C.c_int), ('also_pair', C.c_int),
                 ('init_pair', C.c_int), ('nstate', C.c_int),
-                ('state', C.c_double * 16)]
+                ('state', C.c_double * 16), ('launch_f32', C.c_void_p)]
 
 
 class HipContext(object):
@@ -210,6 +210,7 @@ class HipContext(object):
         self.stream = stream
         self.device = device
         self._ids = {}
+        self.options = {}
 
     def array_id(self, name, owner=None):
         """Device slot of the particle array called `name`.  A context mirrors
@@ -239,6 +240,7 @@ class HipContext(object):
 
     def set_option(self, key, value):
         _check(self.lib.sph_set_option(self._h, key.encode(), int(value)))
+        self.options[key] = int(value)      # host mirror (what the generated families are built for)
 
     # timers ----------------------------------------------------------
     def timer_enable(self, on=True):

@@ -21,7 +21,9 @@ def main():
     from pysph_amd.equations import Group
     n = 0
 
-    def plan(arrays, eqs, kernel):
+    f32_all = os.environ.get('SPHGEN_PREBUILD_F32') == 'all'     # compile shake-out of the float builds of EVERY family
+
+    def plan(arrays, eqs, kernel, f32=False):
         count = 0
         a = AccelerationEval(arrays, eqs, kernel)
         ids = dict((pa.name, i) for i, pa in enumerate(arrays))
@@ -29,6 +31,11 @@ def main():
         for g in a.equation_groups:
             cg = _CGroup(g, ids, amap, K.kernel_id(kernel))
             count += sum(hasattr(u, 'fam') for u in cg.units)
+            if f32 or f32_all:        # the float builds the option arith_f32 launches (tests that set it)
+                for u in cg.units:
+                    if hasattr(u, 'fam'):
+                        u.fam.flavour_f32().load()
+                        count += 1
         return count
 
     g = load_golden('tvf_wall.npz')
@@ -43,6 +50,9 @@ def main():
     for kname in ('CubicSpline', 'WendlandQuintic', 'QuinticSpline', 'Gaussian'):
         arrays, eqs, dim, _ = T._random_generated_case(7)
         n += plan(arrays, eqs, getattr(K, kname)(dim=3))
+    for case in T.F32_GENERATED_CASES:      # the float builds of test_generated_families_fp32_arithmetic_vs_python
+        arrays, eqs, kernel, dim, _ = T._f32_generated_case(case)
+        n += plan(arrays, eqs, kernel, f32=True)
     n += plan([T._image_case()], T._image_equations(), K.CubicSpline(dim=1))
     for kname in ('CubicSpline', 'WendlandQuintic', 'QuinticSpline', 'Gaussian'):
         gp, geqs, gk = T._gradh_case(kname)

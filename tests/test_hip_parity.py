@@ -1576,6 +1576,85 @@ def test_randomised_generated_families_vs_python(oracle, seed):
                 assert np.abs(got - want).max() <= TOL * scale, (seed, dim, kname, pa.name, prop)
 
 
+F32_GENERATED_CASES = ['custom-0', 'custom-0.15', 'wcsph', 'random-0', 'random-3', 'random-7', 'random-9']
+
+
+def _f32_generated_case(case):
+    from pysph_amd import kernels as K
+    if case.startswith('custom-'):
+        arrays, eqs = _custom_setup(float(case[7:]))
+        return arrays, eqs, K.CubicSpline(dim=3), 3, ('p', 'e', 'q', 'gx', 'gy', 'gz')
+    if case.startswith('random-'):
+        arrays, eqs, dim, kname = _random_generated_case(int(case[7:]))
+        return arrays, eqs, getattr(K, kname)(dim=dim), dim, ('p', 'e', 'q', 'gx', 'gy', 'gz')
+    from custom_equations import PyContinuity, PyMomentum, PyXSPH
+    from pysph_amd.equations import Group
+    pa, dx = make_cube(14)
+    rng = np.random.default_rng(3)
+    for f in 'uvw':
+        pa.properties[f][:] = rng.uniform(-1, 1, pa.x.size)
+    pa.rho[:] = 1000.0 * (1 + 0.01 * rng.uniform(-1, 1, pa.x.size))
+    pa.p[:] = 1e3 * rng.uniform(0, 1, pa.x.size)
+    kw = dict(c0=32.85, alpha=0.25, beta=0.1, gz=-9.81, tensile_correction=False)
+    eqs = [Group(equations=[PyContinuity(dest='fluid', sources=['fluid']),
+                            PyMomentum(dest='fluid', sources=['fluid'], **kw),
+                            PyXSPH(dest='fluid', sources=['fluid'], eps=0.5)])]
+    return [pa], eqs, K.WendlandQuintic(dim=3), 3, WC_OUT
+
+
+def _wcsph_hand_equations():
+    """the library equations the Python bodies of the 'wcsph' case restate (run by the C oracle: py_eval has no WDP)"""
+    from pysph_amd.equations import ContinuityEquation, Group, MomentumEquation, XSPHCorrection
+    kw = dict(c0=32.85, alpha=0.25, beta=0.1, gz=-9.81, tensile_correction=False)
+    return [Group(equations=[ContinuityEquation(dest='fluid', sources=['fluid']),
+                             MomentumEquation(dest='fluid', sources=['fluid'], **kw),
+                             XSPHCorrection(dest='fluid', sources=['fluid'], eps=0.5)])]
+
+
+@pytest.mark.parametrize('case', F32_GENERATED_CASES)
+def test_generated_families_fp32_arithmetic_vs_python(oracle, case):
+    """Option arith_f32 for GENERATED families: the pair
+    launch runs the family's float build -- `codegen.source_f32`: fp32 records,
+    every local / pair symbol / kernel value / literal / accumulator a float,
+    arrays narrowed on load and widened on store -- as the reference's generated
+    OpenCL / CUDA code does without --use-double
+    (acceleration_eval_gpu_helper.py:281-283,437-441).  Checked against the same
+    Python bodies run in fp64 by oracle/py_eval.py at 5e-5 of each field's
+    maximum (the tolerance of the hand-written fp32 families), on the made-up
+    equations of tests/custom_equations.py (uniform and per-particle h, two
+    sources, no-source equations with parameters) and on WCSPH written as
+    Python bodies (against the C oracle running the library equations they
+    restate); and it must really be another precision."""
+    from oracle.py_eval import PyEval
+    arrays, eqs, kernel, dim, outs = _f32_generated_case(case)
+    ref = _copy_arrays(arrays)
+    for r, a in zip(ref, arrays):
+        r.constants = dict((k, v.copy()) for k, v in getattr(a, 'constants', {}).items())
+    a_eval, nnps, ctx = make_eval(arrays, eqs, kernel, dim)
+    ctx.set_option('arith_f32', 1)
+    a_eval.compute(0.25, 1e-3)
+    onn = oracle.OracleNNPS(dim, ref, radius_scale=kernel.radius_scale)
+    onn.update()
+    if case == 'wcsph':
+        oev = oracle.OracleEval(ref, _wcsph_hand_equations(), kernel, nthreads=4)
+        oev.set_nnps(onn)
+        oev.compute(0.25, 1e-3)
+    else:
+        PyEval(ref, eqs, kernel, onn).compute(0.25, 1e-3)
+    worst = 0.0
+    for pa, pr in zip(arrays, ref):
+        for prop in outs:
+            got, want = pa.properties[prop], pr.properties[prop]
+            if got.size:
+                scale = max(np.abs(want).max(), 1e-300)
+                e = np.abs(got - want).max() / scale
+                worst = max(worst, e)
+                assert e <= 5e-5, (case, pa.name, prop, e)
+    print('generated arith_f32 %s: max err %.3e of the field maximum' % (case, worst))
+    if any(pa.get_number_of_particles() > 4 for pa in arrays):
+        assert worst > 1e-10, 'the float build was not the one that ran'
+
+
 def _image_case():
     from pysph_amd.particle_array import get_particle_array
     rng = np.random.default_rng(2)
