@@ -162,67 +162,86 @@ struct DirectPack {
     double *dst[2];
 };
 
-// pass 1: how many particles of each 256-particle block go to the low / high face (lo | hi << 32)
-__global__ __launch_bounds__(256) void k_halo_block_counts(const double *__restrict__ coord, size_t n, double p0, double p1,
+// pass 1: how many particles of each CHUNK (q256 x 256 consecutive particles, one workgroup) go to the low / high face
+// (lo | hi << 32).  The chunk grows with n so that there are at most HALO_MAX_CHUNKS of them: pass 2 then finds a
+// chunk's first list position by summing the counters before it (<= 16 MB of L2 reads over the whole launch) and no
+// scan launches stand between the two passes.
+#define HALO_MAX_CHUNKS 2048
+__global__ __launch_bounds__(256) void k_halo_chunk_counts(const double *__restrict__ coord, size_t n, double p0, double p1, int q256,
                                                            unsigned long long *__restrict__ blk)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    bool lo = false, hi = false;
-    if (i < n) {
-        const double v = coord[i];
-        lo = v < p0;
-        hi = v >= p1;
+    const size_t first = (size_t)blockIdx.x * 256 * q256;
+    uint32_t cl = 0, ch = 0; // (wave-uniform)
+    for (int q = 0; q < q256; q++) {
+        const size_t i = first + (size_t)q * 256 + threadIdx.x;
+        bool lo = false, hi = false;
+        if (i < n) {
+            const double v = coord[i];
+            lo = v < p0;
+            hi = v >= p1;
+        }
+        cl += (uint32_t)__popcll(__ballot(lo));
+        ch += (uint32_t)__popcll(__ballot(hi));
     }
-    const unsigned long long ml = __ballot(lo), mh = __ballot(hi);
-    __shared__ uint32_t cl[4], ch[4];
-    if ((threadIdx.x & 63) == 0) { cl[threadIdx.x >> 6] = (uint32_t)__popcll(ml); ch[threadIdx.x >> 6] = (uint32_t)__popcll(mh); }
+    __shared__ uint32_t sl[4], sh[4];
+    if ((threadIdx.x & 63) == 0) { sl[threadIdx.x >> 6] = cl; sh[threadIdx.x >> 6] = ch; }
     __syncthreads();
     if (threadIdx.x == 0)
-        blk[blockIdx.x] = (unsigned long long)(cl[0] + cl[1] + cl[2] + cl[3]) | ((unsigned long long)(ch[0] + ch[1] + ch[2] + ch[3]) << 32);
+        blk[blockIdx.x] = (unsigned long long)(sl[0] + sl[1] + sl[2] + sl[3]) | ((unsigned long long)(sh[0] + sh[1] + sh[2] + sh[3]) << 32);
 }
 
-// pass 2 (after the exclusive scan of the block counts): every block re-derives its flags, ranks its
-// particles inside the block with wavefront ballots -- ascending index, the same order a full scan gives --
-// and writes their rows straight into the messages; the last block writes the two headers.
+// pass 2: every workgroup sums the counters of the chunks before its own, re-derives its flags, ranks its particles
+// with wavefront ballots -- ascending index, the same order a full scan gives -- and writes their rows straight into
+// the messages; the last workgroup writes the two headers.
 __global__ __launch_bounds__(256) void k_halo_pack_direct(DirectPack a, const double *__restrict__ coord, size_t n, double p0,
-                                                          double p1, const unsigned long long *__restrict__ blk,
-                                                          const unsigned long long *__restrict__ blkpos)
+                                                          double p1, int q256, const unsigned long long *__restrict__ blk)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    bool on[2] = {false, false};
-    if (i < n) {
-        const double v = coord[i];
-        on[0] = v < p0;
-        on[1] = v >= p1;
-    }
+    __shared__ uint32_t sbase[2][4];
     __shared__ uint32_t wcnt[2][4];
-    unsigned long long m[2];
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-        m[s] = __ballot(on[s]);
-        if (lane == 0) wcnt[s][wv] = (uint32_t)__popcll(m[s]);
+    {
+        uint32_t bl = 0, bh = 0;
+        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256) { const unsigned long long v = blk[b]; bl += (uint32_t)v; bh += (uint32_t)(v >> 32); }
+        for (int o = 32; o > 0; o >>= 1) { bl += __shfl_xor(bl, o, 64); bh += __shfl_xor(bh, o, 64); }
+        if (lane == 0) { sbase[0][wv] = bl; sbase[1][wv] = bh; }
     }
     __syncthreads();
-    const unsigned long long base = blkpos[blockIdx.x];
+    size_t run[2]; // list position of this chunk's next selected particle, per face (uniform over the workgroup)
+    for (int s = 0; s < 2; s++) run[s] = (size_t)sbase[s][0] + sbase[s][1] + sbase[s][2] + sbase[s][3];
+    const size_t first = (size_t)blockIdx.x * 256 * q256;
+    for (int q = 0; q < q256; q++) {
+        const size_t i = first + (size_t)q * 256 + threadIdx.x;
+        bool on[2] = {false, false};
+        if (i < n) {
+            const double v = coord[i];
+            on[0] = v < p0;
+            on[1] = v >= p1;
+        }
+        unsigned long long m[2];
+        __syncthreads(); // (the previous trip's wcnt has been read)
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
-        uint32_t before = 0;
-        for (int w = 0; w < wv; w++) before += wcnt[s][w];
-        const size_t pl = (size_t)((s == 0) ? (base & 0xffffffffull) : (base >> 32)) + before +
-                          (size_t)__popcll(m[s] & ((1ull << lane) - 1ull));
-        if (on[s] && a.dst[s] && pl < a.cap[s])
-            for (int k = 0; k < a.nprops; k++) {
-                double v = a.p[k][i];
-                if (k == a.axis_k) v += a.shift[s];
-                a.dst[s][(size_t)k * a.cap[s] + pl] = v;
-            }
-        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && a.dst[s]) {
-            const unsigned long long tot = base + blk[blockIdx.x];
-            const size_t cnt = (size_t)((s == 0) ? (tot & 0xffffffffull) : (tot >> 32));
-            a.dst[s][(size_t)a.nprops * a.cap[s]] = cnt <= a.cap[s] ? (double)cnt : -(double)cnt;
+        for (int s = 0; s < 2; s++) {
+            m[s] = __ballot(on[s]);
+            if (lane == 0) wcnt[s][wv] = (uint32_t)__popcll(m[s]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            uint32_t before = 0;
+            for (int w = 0; w < wv; w++) before += wcnt[s][w];
+            const size_t pl = run[s] + before + (size_t)__popcll(m[s] & ((1ull << lane) - 1ull));
+            if (on[s] && a.dst[s] && pl < a.cap[s])
+                for (int k = 0; k < a.nprops; k++) {
+                    double v = a.p[k][i];
+                    if (k == a.axis_k) v += a.shift[s];
+                    a.dst[s][(size_t)k * a.cap[s] + pl] = v;
+                }
+            run[s] += wcnt[s][0] + wcnt[s][1] + wcnt[s][2] + wcnt[s][3];
         }
     }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        for (int s = 0; s < 2; s++)
+            if (a.dst[s]) a.dst[s][(size_t)a.nprops * a.cap[s]] = run[s] <= a.cap[s] ? (double)run[s] : -(double)run[s];
 }
 
 extern "C" int sph_halo_select_pack(sph_ctx *c, int id, int axis, double lo_cut, double hi_cut, size_t upto, int nprops,
@@ -259,15 +278,14 @@ extern "C" int sph_halo_select_pack(sph_ctx *c, int id, int axis, double lo_cut,
     }
     const double *coord = A.prop[SPH_X + axis];
     if (!coord) { sph_set_error("sph_halo_select_pack: no device coordinates"); return SPH_ERR_MISSING_PROP; }
-    // two passes over the coordinate and a scan of one counter per 256 particles (a scan of one flag per
-    // particle moved three times the bytes: 92 -> ~35 us at 4 M)
-    const unsigned nb = div_up(n, 256);
+    // two passes over the coordinate, TWO launches: one counter per chunk of the array, summed by the packing
+    // workgroups themselves (round 4: a counter per 256 particles and a three-launch scan between the passes)
+    const int q256 = (int)div_up(n, (size_t)256 * HALO_MAX_CHUNKS);
+    const unsigned nb = div_up(n, (size_t)256 * q256);
     SPH_TRY(H.flag[1].reserve(((size_t)nb + 1) * 8));
-    SPH_TRY(H.pos[1].reserve(((size_t)nb + 1) * 8));
-    unsigned long long *blk = H.flag[1].as<unsigned long long>(), *bps = H.pos[1].as<unsigned long long>();
-    hipLaunchKernelGGL(k_halo_block_counts, dim3(nb), dim3(256), 0, c->stream, coord, n, lo_cut, hi_cut, blk);
-    SPH_TRY(dev_scan_u64(c, blk, bps, nb, true));
-    hipLaunchKernelGGL(k_halo_pack_direct, dim3(nb), dim3(256), 0, c->stream, a, coord, n, lo_cut, hi_cut, blk, bps);
+    unsigned long long *blk = H.flag[1].as<unsigned long long>();
+    hipLaunchKernelGGL(k_halo_chunk_counts, dim3(nb), dim3(256), 0, c->stream, coord, n, lo_cut, hi_cut, q256, blk);
+    hipLaunchKernelGGL(k_halo_pack_direct, dim3(nb), dim3(256), 0, c->stream, a, coord, n, lo_cut, hi_cut, q256, blk);
     return SPH_OK;
 }
 

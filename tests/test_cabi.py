@@ -164,7 +164,8 @@ def test_comm_library_self_periodic_exchange_matches_torch_path():
 
 
 @pytest.mark.gpu
-def test_select_pack_equals_list_based_select_and_pack():
+@pytest.mark.parametrize('n', [70001, 1300007], ids=['one-chunk-trip', 'three-chunk-trips'])
+def test_select_pack_equals_list_based_select_and_pack(n):
     """sph_halo_select_pack (selection + packing of both faces in one device
     pass, counts only in the message headers) against the list-based
     sph_halo_select / sph_halo_pack: same rows in the same order, the header
@@ -177,7 +178,7 @@ def test_select_pack_equals_list_based_select_and_pack():
     from pysph_amd import device as dev
     from pysph_amd.particle_array import get_particle_array_wcsph
     rng = np.random.default_rng(3)
-    n = 70001                               # ragged last block
+    # (ragged last block; the larger array takes several 256-particle trips per chunk counter)
     pa = get_particle_array_wcsph(name='fluid', x=rng.uniform(0, 1, n), y=rng.uniform(0, 1, n),
                                   z=rng.uniform(0, 1, n), u=rng.uniform(-1, 1, n), rho=rng.uniform(1, 2, n),
                                   h=0.01 * np.ones(n), m=np.ones(n))
