@@ -2018,6 +2018,74 @@ def test_ghost_outside_the_h_range_of_the_update_is_rejected():
     ctx.close()
 
 
+@pytest.mark.parametrize('merge', [1, 0], ids=['merged-first', 'per-array'])
+def test_ghost_segments_three_arrays_lazy_tables_vs_oracle(oracle, merge):
+    """The ghost split with SEVERAL arrays: the neighbour update bins the real particles of the dam-break
+    tank's three arrays in one merged order (per-array tables are lazy), the ghosts of every array arrive behind them
+    and are binned into segments of their own, and the evaluation -- which cannot take the one-launch merged path
+    with ghost segments -- asks for the per-array tables: they must cover the particles that were BINNED (n_binned),
+    not the arrays' present sizes.  Real particles of all three arrays against the oracle on reals + ghosts, neighbour
+    counts included; twice, so that the second round runs on kept buffers."""
+    from pysph_amd import device as dev
+    from pysph_amd.examples import dam_break_3d as db
+    dx = 0.07
+    full = db.create_particles(dx)
+    _perturb(full, 11, db.c0, db.ro, dx)
+    kernel = db.create_kernel()
+    eqs = db.create_scheme(dx).get_equations()
+    width = kernel.radius_scale * db.hdx * dx
+    cut = float(np.median(np.concatenate([a.x for a in full])))
+    arrays, nreal = [], []
+    for a in full:                  # this rank: x < cut; its ghosts: the next halo width
+        real = np.nonzero(a.x < cut)[0]
+        ghost = np.nonzero((a.x >= cut) & (a.x < cut + width))[0]
+        b = a.extract_particles(np.concatenate([real, ghost]), name=a.name)
+        b.set_num_real_particles(real.size)
+        arrays.append(b)
+        nreal.append(int(real.size))
+    assert sum(a.get_number_of_particles() - r for a, r in zip(arrays, nreal)) > 100 and min(nreal) >= 0
+    ref = _copy_arrays(arrays)
+    onn = oracle.OracleNNPS(3, ref, radius_scale=kernel.radius_scale)
+    onn.update()
+    oev = oracle.OracleEval(ref, eqs, kernel, nthreads=4)
+    oev.set_nnps(onn)
+    oev.compute(0.0, 1e-5)
+    a_eval, nnps, ctx = make_eval(arrays, eqs, kernel, 3, 6, sync='manual')
+    ctx.set_option('merge_arrays', merge)
+    ctx.set_option('lazy_tables', 1)
+    lib = ctx.lib
+    for a in arrays:
+        a.gpu.push()
+    nnps.sync = False
+    for rep in range(2):
+        for a, r in zip(arrays, nreal):
+            dev._check(lib.sph_array_resize(ctx._h, a.gpu.array_id, r, r))
+        nnps.set_ghost_faces(0, -1e30, cut)
+        nnps.update()
+        for a, r in zip(arrays, nreal):
+            dev._check(lib.sph_array_resize(ctx._h, a.gpu.array_id, a.get_number_of_particles(), r))
+        nnps.update_ghosts(0, -1e30, cut)
+        a_eval.compute(0.0, 1e-5)
+    a_eval.c_acceleration_eval.pull_outputs()
+    for i, (a, r) in enumerate(zip(arrays, nreal)):
+        for j in range(len(arrays)):
+            s1 = nnps.get_csr_start(j, i)
+            s2, _ = onn.get_csr(j, i)
+            assert np.array_equal(np.diff(s1.astype(np.int64))[:r], np.diff(s2.astype(np.int64))[:r]), (a.name, j)
+    checked = 0
+    for a, q, r in zip(arrays, ref, nreal):
+        for prop in WC_OUT:
+            if prop in ('p', 'cs', 'rho') or prop not in a.properties:
+                continue
+            want = np.asarray(q.properties[prop])[:r]
+            if r and np.abs(want).max() > 0:
+                e = rel_err(np.asarray(a.properties[prop])[:r], want)
+                assert e < TOL, (a.name, prop, e)
+                checked += 1
+    assert checked >= 8
+    ctx.close()
+
+
 @pytest.mark.parametrize('seed', list(range(int(os.environ.get('SPH_FUZZ_SEEDS', '12')))))
 def test_randomised_ghost_segments_vs_oracle(oracle, seed):
     """Round 4, ghost split (sph_nnps_update_ghosts): the neighbour update bins the REAL particles, the ghosts
