@@ -668,13 +668,6 @@ __global__ __launch_bounds__(256) void k_fill_u32(uint32_t *p, size_t n, uint32_
     if (i < n) p[i] = v;
 }
 
-static int bits_for(long n_cells)
-{
-    int b = 1;
-    while ((1L << b) < n_cells) b++;
-    return b;
-}
-
 // ---------------------------------------------------------------------------
 // host side of the pass above
 // ---------------------------------------------------------------------------
