@@ -60,6 +60,56 @@ def test_wall_equations_translate_build_and_export():
     fam.build()
 
 
+def test_float_build_of_a_family():
+    """`codegen.source_f32` (option arith_f32 for generated families): the arithmetic of the emitted source in
+    float, the interface parts untouched, a binary of its own that cross-compiles and exports the launch entry."""
+    import re
+    from pysph_amd.codegen import GeneratedFamily, source_f32
+    from custom_equations import KitchenSink, PyMomentum
+    from pysph_amd.particle_array import get_particle_array
+    pa = get_particle_array(name='fluid', x=np.zeros(3), constants=dict(coef=np.array([1.25, -0.5])),
+                            additional_props=['q', 'gx', 'gy', 'gz', 'e', 'au', 'av', 'aw', 'p', 'cs', 'dt_cfl', 'dt_force'])
+    arrays = {'fluid': pa}
+    for eqs in ([KitchenSink('fluid', ['fluid'], a=0.3, b=0.05, flag=True)],
+                [PyMomentum(dest='fluid', sources=['fluid'], c0=10.0, alpha=0.25, beta=0.1, gz=-9.81,
+                            tensile_correction=True)]):
+        fam = GeneratedFamily('fluid', eqs, arrays, 2, 'cg_f32')
+        f32 = fam.flavour_f32()
+        assert f32 is fam.flavour_f32() and f32.hash != fam.hash and f32.source == source_f32(fam.source)
+        src = f32.source
+
+        def block(text, first, last):
+            i = text.index(first)
+            return text[i:text.index(last, i) + len(last)]
+        # kept as they are: Params (fp64 pointers), the fp64 record reader, the launch wrapper
+        for first, last in (('    struct Params {', '\n    };'),
+                            ('template <> __device__ __forceinline__ void load_record<FamGen, true>', '\n}\n'),
+                            ('extern "C" int sphgen_kernel_kind', 'return (int)hipGetLastError();\n}')):
+            assert block(src, first, last) == block(fam.source, first, last)
+        # everything else computes in float: no double left outside those blocks (index casts aside), literals suffixed
+        rest = src
+        for first, last in (('    struct Params {', '\n    };'),
+                            ('template <> __device__ __forceinline__ void load_record<FamGen, true>', '\n}\n'),
+                            ('extern "C" int sphgen_kernel_kind', 'return (int)hipGetLastError();\n}'),
+                            ('struct GenF32View {', '};')):
+            rest = rest.replace(block(rest, first, last), '')
+        rest = rest.replace('((double)d_idx)', '').replace('((double)o)', '')
+        code = '\n'.join(ln.split('//')[0] for ln in rest.splitlines())
+        assert not re.search(r'\bdouble\b', code), re.findall(r'.*\bdouble\b.*', code)[:3]
+        assert 'typedef float Real;' in src and 'PairGeomT<float> g;' in src and 'const GenF32View PAR{a.p.par};' in src
+        assert not re.search(r'(?<![\w.])\d+\.\d*(?:[eE][+-]?\d+)?(?![\w.f])', code)       # no double literal left
+        lib = C.CDLL(f32.build())
+        assert lib.sphgen_kernel_kind() == 2 and hasattr(lib, 'sphgen_launch')
+    # a pair body that reads a neighbour's ABSOLUTE position keeps fp64 records (fp32 records are origin-relative)
+    from pysph_amd.equations import Equation
+
+    class AbsPos(Equation):
+        def loop(self, d_idx, s_idx, d_q, s_x, s_m):
+            d_q[d_idx] += s_m[s_idx] * s_x[s_idx]
+    assert GeneratedFamily('fluid', [AbsPos('fluid', ['fluid'])], arrays, 2, 'cg_abs').abs_src_pos
+    assert not fam.abs_src_pos
+
+
 def test_translation_details():
     from pysph_amd.codegen import GeneratedFamily
     from pysph_amd.equations import Equation
