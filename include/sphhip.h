@@ -456,6 +456,29 @@ int sph_halo_remove_selected(sph_ctx *ctx, int array_id, size_t *n_left);
  * v < vmin -> v + translate; v > vmax -> v - translate
  * (CPUDomainManager._box_wrap_periodic, pysph/base/nnps_base.pyx:699-748).   */
 int sph_domain_box_wrap(sph_ctx *ctx, int array_id, int axis, double vmin, double vmax, double translate);
+/* The periodic images of one axis (CPUDomainManager._create_ghosts_periodic,
+ * pysph/base/nnps_base.pyx:751-940; selection rule :805-817, shift :841-856)
+ * WITHOUT a device->host round trip: every particle present (n of them) within
+ * `width` of the low face `lo` gets an image shifted by +shift, within `width`
+ * of the high face `hi` one shifted by -shift, in ascending particle index, into
+ * FIXED capacities behind the particles: rows [n, n + cap[0]) and [n + cap[0],
+ * n + cap[0] + cap[1]).  The array grows by cap[0] + cap[1] (n_real unchanged);
+ * rows behind the counts are parked like the padding rows of
+ * sph_halo_append_padded (inert on the whole path).  `props`: the properties
+ * the images carry (x, y and z among them).  The two counts stay on the device
+ * (negated when they exceed their capacity: images are then MISSING);
+ * sph_domain_counts_queue sends the counts of all calls so far towards pinned
+ * memory, sph_domain_counts_collect returns them -- an update later, when the
+ * copy has long completed -- as out[array_id * 6 + axis * 2 + side]
+ * (SPH_MAX_ARRAYS * 6 doubles); the caller sizes the next capacities from them
+ * and treats a negative one as an error of the step that used the images.   */
+int sph_domain_images_padded(sph_ctx *ctx, int array_id, int axis, double lo, double hi, double width, double shift,
+                             const size_t cap[2], int nprops, const int *props);
+int sph_domain_counts_queue(sph_ctx *ctx);
+int sph_domain_counts_collect(sph_ctx *ctx, double *out);
+/* 1 and the range of h of the array when it is known WITHOUT looking (found by
+ * the last neighbour update or reduction, nothing wrote h since), else 0.    */
+int sph_array_h_known(sph_ctx *ctx, int array_id, double *hmin, double *hmax);
 /* Ids of the properties that currently have device storage: out[cap], *n
  * receives the count (at most SPH_PROP_COUNT); SPH_ERR_ARG if cap is too
  * small.                                                                    */

@@ -141,7 +141,7 @@ int sph_ctx_destroy(sph_ctx *c)
     for (auto &H : c->halo)
         for (int s = 0; s < 2; s++) { H.flag[s].release(); H.pos[s].release(); H.list[s].release(); }
     for (DevBuf *b : {&c->dbgc, &c->gapq, &c->cub_tmp, &c->red_part, &c->red_out, &c->posh, &c->aux, &c->fposb, &c->dkeys, &c->dperm,
-                      &c->tmp_u32a, &c->tmp_u32b, &c->gen_state, &c->nlbuf, &c->splitcnt, &c->scan_part, &c->bigq, &c->sort_tab, &c->xflag})
+                      &c->tmp_u32a, &c->tmp_u32b, &c->gen_state, &c->nlbuf, &c->splitcnt, &c->scan_part, &c->bigq, &c->sort_tab, &c->xflag, &c->dom_counts})
         b->release();
     for (auto &b : c->csr_start) b.release();
     for (auto &b : c->csr_nbrs) b.release();
@@ -150,6 +150,8 @@ int sph_ctx_destroy(sph_ctx *c)
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pin_async) (void)hipHostFree(c->pin_async);
     if (c->lag_ev) (void)hipEventDestroy(c->lag_ev);
+    if (c->dom_pin) (void)hipHostFree(c->dom_pin);
+    if (c->dom_ev) (void)hipEventDestroy(c->dom_ev);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SPH_OK;
@@ -193,6 +195,7 @@ int sph_array_resize(sph_ctx *c, int id, size_t n, size_t n_real)
     if (n > A.n) A.tflag_valid = false; // new particles (ghosts, migrants): their r_ij were not looked at
     if (n > A.n) sph_mark_grown(A);     // ... nor their h and m
     if (n < A.n) sph_mark_removed(A, n);
+    if (n <= n_real) A.has_padding = false; // (ghosts dropped: the padding rows went with them)
     A.n = n;
     A.n_real = n_real;
     return SPH_OK;

@@ -21,7 +21,11 @@ __global__ __launch_bounds__(256) void k_halo_flags_counts(const double *__restr
     if (i < n) {
         const double v = coord[i];
         if (mode == 0) { lo = v < p0; hi = v >= p1; }
-        else { lo = (v - p0) <= p2; hi = (p1 - v) <= p2; } // nnps_base.pyx:805-817
+        else { // nnps_base.pyx:805-817; a parked padding row (sph_halo_append_padded) is nobody's image
+            const bool live = fabs(v) < SPH_PARKED_MIN;
+            lo = live && (v - p0) <= p2;
+            hi = live && (p1 - v) <= p2;
+        }
         fl[i] = (lo ? 1ull : 0ull) | (hi ? 1ull << 32 : 0ull);
     }
     const unsigned long long ml = __ballot(lo), mh = __ballot(hi);
@@ -167,19 +171,29 @@ struct DirectPack {
 // chunk's first list position by summing the counters before it (<= 16 MB of L2 reads over the whole launch) and no
 // scan launches stand between the two passes.
 #define HALO_MAX_CHUNKS 2048
-__global__ __launch_bounds__(256) void k_halo_chunk_counts(const double *__restrict__ coord, size_t n, double p0, double p1, int q256,
-                                                           unsigned long long *__restrict__ blk)
+// which face(s) a particle at coordinate v belongs to.  BOX = false (slab faces): lo: v < p0, hi: v >= p1.  BOX = true
+// (periodic box, nnps_base.pyx:805-817): lo: (v - p0) <= p2, hi: (p1 - v) <= p2 -- the rule of k_halo_flags_counts; a
+// parked padding row is nobody's image
+template <bool BOX> __device__ __forceinline__ void face_rule(double v, double p0, double p1, double p2, bool &lo, bool &hi)
+{
+    if (!BOX) { lo = v < p0; hi = v >= p1; }
+    else {
+        const bool live = fabs(v) < SPH_PARKED_MIN;
+        lo = live && (v - p0) <= p2;
+        hi = live && (p1 - v) <= p2;
+    }
+}
+
+template <bool BOX>
+__global__ __launch_bounds__(256) void k_halo_chunk_counts(const double *__restrict__ coord, size_t n, double p0, double p1, double p2,
+                                                           int q256, unsigned long long *__restrict__ blk)
 {
     const size_t first = (size_t)blockIdx.x * 256 * q256;
     uint32_t cl = 0, ch = 0; // (wave-uniform)
     for (int q = 0; q < q256; q++) {
         const size_t i = first + (size_t)q * 256 + threadIdx.x;
         bool lo = false, hi = false;
-        if (i < n) {
-            const double v = coord[i];
-            lo = v < p0;
-            hi = v >= p1;
-        }
+        if (i < n) face_rule<BOX>(coord[i], p0, p1, p2, lo, hi);
         cl += (uint32_t)__popcll(__ballot(lo));
         ch += (uint32_t)__popcll(__ballot(hi));
     }
@@ -284,7 +298,7 @@ extern "C" int sph_halo_select_pack(sph_ctx *c, int id, int axis, double lo_cut,
     const unsigned nb = div_up(n, (size_t)256 * q256);
     SPH_TRY(H.flag[1].reserve(((size_t)nb + 1) * 8));
     unsigned long long *blk = H.flag[1].as<unsigned long long>();
-    hipLaunchKernelGGL(k_halo_chunk_counts, dim3(nb), dim3(256), 0, c->stream, coord, n, lo_cut, hi_cut, q256, blk);
+    hipLaunchKernelGGL(k_halo_chunk_counts<false>, dim3(nb), dim3(256), 0, c->stream, coord, n, lo_cut, hi_cut, 0.0, q256, blk);
     hipLaunchKernelGGL(k_halo_pack_direct, dim3(nb), dim3(256), 0, c->stream, a, coord, n, lo_cut, hi_cut, q256, blk);
     return SPH_OK;
 }
@@ -438,10 +452,193 @@ extern "C" int sph_halo_append_padded(sph_ctx *c, int id, int nprops, const int 
     if (keep_m) { A.m_dirty = false; A.m_known = mk; }
     PropList L;
     for (int k = 0; k < nprops; k++) { L.p[k] = A.prop[props[k]]; L.what[k] = props[k] == SPH_X || props[k] == SPH_Y || props[k] == SPH_Z; }
+    A.has_padding = true;
     hipLaunchKernelGGL(k_halo_append_padded, dim3(div_up(cap, 256), nprops), dim3(256), 0, c->stream, L, (const double *)src, n0, cap,
                        nprops, k_h, k_m, h_promise, m_promise, (uint32_t *)flag_word);
     c->nnps_valid = false;
     return SPH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Periodic images of one axis WITHOUT a device->host round trip (round 5).  The list-based update (sph_halo_select +
+// 2 x sph_halo_image) reads the two counts back per axis because the host owns the array sizes; here the images go
+// into FIXED capacities behind the particles present -- rows [n, n + cap0) for the low face's images, [n + cap0,
+// n + cap0 + cap1) for the high face's -- in ascending particle index as before, the rows behind the counts PARKED
+// (sph_halo_append_padded's inert padding: x = y = z = 1e18, everything else 0).  The counts stay on the device
+// (negated when they exceed their capacity: images are then missing) and reach the host one update later
+// (sph_domain_counts_queue / _collect), where the capacities follow them.
+// ---------------------------------------------------------------------------
+// pass 2: the two index lists (ascending particle index, clipped at their capacities) and the two counts
+__global__ __launch_bounds__(256) void k_domain_lists(const double *__restrict__ coord, size_t n, double p0, double p1, double p2,
+                                                      int q256, size_t cap0, size_t cap1, const unsigned long long *__restrict__ blk,
+                                                      uint32_t *__restrict__ list_lo, uint32_t *__restrict__ list_hi,
+                                                      double *__restrict__ counts)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ uint32_t sbase[2][4];
+    __shared__ uint32_t wcnt[2][4];
+    {
+        uint32_t bl = 0, bh = 0;
+        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256) { const unsigned long long v = blk[b]; bl += (uint32_t)v; bh += (uint32_t)(v >> 32); }
+        for (int o = 32; o > 0; o >>= 1) { bl += __shfl_xor(bl, o, 64); bh += __shfl_xor(bh, o, 64); }
+        if (lane == 0) { sbase[0][wv] = bl; sbase[1][wv] = bh; }
+    }
+    __syncthreads();
+    size_t run[2];
+    for (int s = 0; s < 2; s++) run[s] = (size_t)sbase[s][0] + sbase[s][1] + sbase[s][2] + sbase[s][3];
+    const size_t first = (size_t)blockIdx.x * 256 * q256;
+    const size_t cap[2] = {cap0, cap1};
+    for (int q = 0; q < q256; q++) {
+        const size_t i = first + (size_t)q * 256 + threadIdx.x;
+        bool on[2] = {false, false};
+        if (i < n) face_rule<true>(coord[i], p0, p1, p2, on[0], on[1]);
+        unsigned long long m[2];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            m[s] = __ballot(on[s]);
+            if (lane == 0) wcnt[s][wv] = (uint32_t)__popcll(m[s]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            uint32_t before = 0;
+            for (int w = 0; w < wv; w++) before += wcnt[s][w];
+            const size_t pl = run[s] + before + (size_t)__popcll(m[s] & ((1ull << lane) - 1ull));
+            if (on[s] && pl < cap[s]) (s == 0 ? list_lo : list_hi)[pl] = (uint32_t)i;
+            run[s] += wcnt[s][0] + wcnt[s][1] + wcnt[s][2] + wcnt[s][3];
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        for (int s = 0; s < 2; s++) counts[s] = run[s] <= cap[s] ? (double)run[s] : -(double)run[s];
+}
+
+// pass 3: every row of the two capacities, every property (blockIdx.y): an image of the listed particle -- the low face's
+// images move up by the period, the high face's down (nnps_base.pyx:841-856) -- or, behind the count, a parked row
+__global__ __launch_bounds__(256) void k_domain_images(PropList L, size_t n, size_t cap0, size_t cap1, double shift,
+                                                       const uint32_t *__restrict__ list_lo, const uint32_t *__restrict__ list_hi,
+                                                       const double *__restrict__ counts)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap0 + cap1) return;
+    const int s = i < cap0 ? 0 : 1;
+    const size_t r = s == 0 ? i : i - cap0, cap = s == 0 ? cap0 : cap1;
+    const size_t count = (size_t)fmin(fabs(counts[s]), (double)cap);
+    const int k = blockIdx.y, what = L.what[k];
+    double v;
+    if (r < count) {
+        v = L.p[k][(s == 0 ? list_lo : list_hi)[r]];
+        if (what == 1) v += s == 0 ? shift : -shift;
+    } else {
+        v = what ? SPH_PARKED : 0.0;
+    }
+    L.p[k][n + i] = v;
+}
+
+extern "C" int sph_domain_images_padded(sph_ctx *c, int id, int axis, double lo, double hi, double width, double shift,
+                                        const size_t *cap2, int nprops, const int *props)
+{
+    if (!c || id < 0 || id >= SPH_MAX_ARRAYS || axis < 0 || axis > 2 || !cap2 || nprops < 1 || nprops > SPH_PROP_COUNT || !props) {
+        sph_set_error("sph_domain_images_padded: bad arguments");
+        return SPH_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->dom_counts.ptr) {
+        SPH_TRY(c->dom_counts.reserve(SPH_MAX_ARRAYS * 6 * sizeof(double)));
+        HIP_TRY(hipMemsetAsync(c->dom_counts.ptr, 0, SPH_MAX_ARRAYS * 6 * sizeof(double), c->stream));
+    }
+    double *counts = c->dom_counts.as<double>() + (size_t)id * 6 + axis * 2;
+    const size_t n = c->arr[id].n, cap0 = cap2[0], cap1 = cap2[1];
+    if (n + cap0 + cap1 >= (1ull << 32)) { sph_set_error("sph_domain_images_padded: too many particles"); return SPH_ERR_ARG; }
+    bool has_h = false, has_m = false, has_x = false;
+    for (int k = 0; k < nprops; k++) {
+        const int p = props[k];
+        if (p < 0 || p >= SPH_PROP_COUNT || !c->arr[id].prop[p]) {
+            sph_set_error("sph_domain_images_padded: array %d has no device property %d", id, p);
+            return SPH_ERR_MISSING_PROP;
+        }
+        has_h |= p == SPH_H; has_m |= p == SPH_M; has_x |= p == SPH_X + axis;
+    }
+    if (!has_x || !c->arr[id].prop[SPH_X] || !c->arr[id].prop[SPH_Y] || !c->arr[id].prop[SPH_Z]) {
+        sph_set_error("sph_domain_images_padded: the positions must be among the imaged properties");
+        return SPH_ERR_ARG;
+    }
+    if (n == 0 || cap0 + cap1 == 0) { // nothing to image (or no room): zero counts
+        HIP_TRY(hipMemsetAsync(counts, 0, 2 * sizeof(double), c->stream));
+        if (n == 0) return SPH_OK;
+    }
+    // images (and padding rows) are copies of the array's own particles: h and m keep their range and their cleanliness
+    const bool hd = c->arr[id].h_dirty, md = c->arr[id].m_dirty, mk = c->arr[id].m_known;
+    SPH_TRY(sph_array_resize(c, id, n + cap0 + cap1, c->arr[id].n_real)); // may move the property buffers
+    DevArray &A = c->arr[id];
+    if (has_h) A.h_dirty = hd;
+    if (has_m) { A.m_dirty = md; A.m_known = mk; }
+    A.has_padding = true;
+    PropList L;
+    bool all_pos = true;
+    for (int k = 0; k < nprops; k++) {
+        const int p = props[k];
+        L.p[k] = A.prop[p];
+        // 1: the axis coordinate (shifted in an image), 2: another coordinate (both parked in a padding row), 0: the rest
+        L.what[k] = p == SPH_X + axis ? 1 : ((p == SPH_X || p == SPH_Y || p == SPH_Z) ? 2 : 0);
+    }
+    for (int q = 0; q < 3; q++) { bool in = false; for (int k = 0; k < nprops; k++) in |= props[k] == SPH_X + q; all_pos &= in; }
+    if (!all_pos) { sph_set_error("sph_domain_images_padded: x, y and z must all be among the imaged properties"); return SPH_ERR_ARG; }
+    HaloState &H = c->halo[id];
+    H.count[0] = H.count[1] = 0; // the host does not learn the counts: no list-based call may follow
+    H.nsel = 0;
+    const double *coord = A.prop[SPH_X + axis];
+    const int q256 = (int)div_up(n, (size_t)256 * HALO_MAX_CHUNKS);
+    const unsigned nb = div_up(n, (size_t)256 * q256);
+    SPH_TRY(H.flag[1].reserve(((size_t)nb + 1) * 8));
+    unsigned long long *blk = H.flag[1].as<unsigned long long>();
+    SPH_TRY(H.list[0].reserve((cap0 + 1) * 4));
+    SPH_TRY(H.list[1].reserve((cap1 + 1) * 4));
+    hipLaunchKernelGGL(k_halo_chunk_counts<true>, dim3(nb), dim3(256), 0, c->stream, coord, n, lo, hi, width, q256, blk);
+    hipLaunchKernelGGL(k_domain_lists, dim3(nb), dim3(256), 0, c->stream, coord, n, lo, hi, width, q256, cap0, cap1, blk,
+                       H.list[0].as<uint32_t>(), H.list[1].as<uint32_t>(), counts);
+    if (cap0 + cap1)
+        hipLaunchKernelGGL(k_domain_images, dim3(div_up(cap0 + cap1, 256), nprops), dim3(256), 0, c->stream, L, n, cap0, cap1, shift,
+                           H.list[0].as<uint32_t>(), H.list[1].as<uint32_t>(), counts);
+    c->nnps_valid = false;
+    return SPH_OK;
+}
+
+// the image counts of every sph_domain_images_padded call so far on their way to pinned memory, behind an event nobody
+// waits for now ...
+extern "C" int sph_domain_counts_queue(sph_ctx *c)
+{
+    if (!c) { sph_set_error("sph_domain_counts_queue: NULL context"); return SPH_ERR_ARG; }
+    if (!c->dom_counts.ptr) return SPH_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->dom_pin) HIP_TRY(hipHostMalloc((void **)&c->dom_pin, SPH_MAX_ARRAYS * 6 * sizeof(double), hipHostMallocDefault));
+    if (!c->dom_ev) HIP_TRY(hipEventCreateWithFlags(&c->dom_ev, hipEventDisableTiming));
+    HIP_TRY(hipMemcpyAsync(c->dom_pin, c->dom_counts.ptr, SPH_MAX_ARRAYS * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(c->dom_ev, c->stream));
+    c->dom_queued = true;
+    return SPH_OK;
+}
+
+// ... and read an update later: out[array * 6 + axis * 2 + side], negative = that face's images did not fit
+extern "C" int sph_domain_counts_collect(sph_ctx *c, double *out)
+{
+    if (!c || !out) { sph_set_error("sph_domain_counts_collect: bad arguments"); return SPH_ERR_ARG; }
+    if (!c->dom_queued) { sph_set_error("sph_domain_counts_collect: nothing was queued"); return SPH_ERR_STATE; }
+    HIP_TRY(hipEventSynchronize(c->dom_ev));
+    for (int k = 0; k < SPH_MAX_ARRAYS * 6; k++) out[k] = c->dom_pin[k];
+    c->dom_queued = false;
+    return SPH_OK;
+}
+
+// the h range of an array when it is known WITHOUT looking (seen by a neighbour update or a reduction and not written
+// since): 1 and the range, else 0
+extern "C" int sph_array_h_known(sph_ctx *c, int id, double *hmin, double *hmax)
+{
+    if (!c || id < 0 || id >= SPH_MAX_ARRAYS || !hmin || !hmax) return 0;
+    const DevArray &A = c->arr[id];
+    if (!A.used || !A.h_seen || A.h_dirty) return 0;
+    *hmin = A.h_lo; *hmax = A.h_hi;
+    return 1;
 }
 
 __global__ __launch_bounds__(256) void k_halo_image_multi(PropList L, const uint32_t *__restrict__ list, size_t count,

@@ -59,6 +59,8 @@ struct DevArray {
     // particles from outside, or hands out the raw pointer sets it -- sph_mark_written / _grown / _removed below).
     // Clean ranges let sph_nnps_update skip the reduction of h and m and, with them, the device->host round trip.
     bool h_dirty = true, m_dirty = true, h_seen = false, m_seen = false;
+    bool has_padding = false;            // parked padding rows may sit behind the real particles (sph_halo_append_padded,
+                                         // sph_domain_images_padded): the next neighbour update gives them cells of their own
     bool raw_hm = false;                 // a raw device pointer to h or m was handed out: writes through it cannot be tracked
     unsigned hm_writes = 0;              // writes of h / m (sph_mark_written) so far
     // ghost split: what sph_nnps_update knew when it binned the real particles (sph_nnps_update_ghosts verifies the ghosts
@@ -206,6 +208,12 @@ struct sph_ctx {
         int dim = 0, narrays = 0, ids[SPH_MAX_ARRAYS] = {};
         double radius_scale = 0, cell_size_in = 0, extend[3] = {}, hr[2] = {};
     } lag;
+    long park_cells = 0;          // cells behind the grid's own in the tables of the last update: where parked rows are binned
+    // image counts of sph_domain_images_padded: device words [array][axis][side], their pinned copy and its event
+    DevBuf dom_counts;
+    double *dom_pin = nullptr;    // pinned: SPH_MAX_ARRAYS * 6 doubles
+    hipEvent_t dom_ev = nullptr;
+    bool dom_queued = false;
     hipEvent_t lag_ev = nullptr;
     double *pin_async = nullptr;  // pinned: 64 doubles
     GridHost rep;                 // the reported grid of the last update

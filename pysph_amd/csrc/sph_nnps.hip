@@ -36,6 +36,9 @@ struct GridDesc {
     double xmin[3];
     double cell_size;
     int nc[3];
+    // PARKING bins behind the grid's own in the tables (or none): where parked padding rows are binned -- cells no
+    // destination visits, at the end of the cell order (wavefronts made of them find no active destination)
+    uint32_t park_base, park_bins;
 };
 
 // nnps_base.pxd:39-57 real_to_int = <int>floor(real_val/step), flatten_raw :83-96
@@ -62,14 +65,18 @@ __device__ __forceinline__ uint32_t fine_key(double x, double y, double z, const
     cz = min(max(cz, 0), g.nc[2] - 1);
     return (uint32_t)(cx + g.nc[0] * (cy + g.nc[1] * cz)) * SPH_NSUB + (uint32_t)sub;
 }
-// ... of particle i: a parked position (a padding row of sph_halo_append_padded: never anybody's neighbour) gets a key
-// that depends on i only, spread over the whole table, so that the padding rows do not pile up in one bin
+// ... of particle i: a parked position (a padding row of sph_halo_append_padded / sph_domain_images_padded: never
+// anybody's neighbour) gets a key that depends on i only, spread over the parking bins behind the grid (no pile-up in one
+// bin; measured: spread over the grid's own cells the 1.3 % padding rows of Taylor-Green cost its pair passes 2.6 % --
+// idle lanes in every destination tile, a candidate more in every row) or, without parking bins, over the whole table
 __device__ __forceinline__ bool is_parked(double x) { return fabs(x) >= SPH_PARKED_MIN; }
 __device__ __forceinline__ uint32_t fine_key_of(double x, double y, double z, const GridDesc &g, size_t i)
 {
     if (is_parked(x)) {
+        const unsigned long long h = (unsigned long long)i * 2654435761ull;
+        if (g.park_bins) return g.park_base + (uint32_t)(h % g.park_bins);
         const unsigned long long n_fine = (unsigned long long)g.nc[0] * g.nc[1] * g.nc[2] * SPH_NSUB;
-        return (uint32_t)(((unsigned long long)i * 2654435761ull) % n_fine);
+        return (uint32_t)(h % n_fine);
     }
     return fine_key(x, y, z, g);
 }
@@ -603,7 +610,8 @@ __global__ __launch_bounds__(256) void k_tile_keys(const uint32_t *__restrict__ 
     if (t >= n_tiles) return;
     const uint32_t k = skeys[(size_t)t * SPH_TILE];
     const uint32_t row = k / (uint32_t)ncx;
-    const uint32_t cy = row % (uint32_t)ncy, cz = row / (uint32_t)ncy;
+    // (a tile of parked padding rows lies in the parking cells behind the grid: ordered with the last plane)
+    const uint32_t cy = row % (uint32_t)ncy, cz = min(row / (uint32_t)ncy, (uint32_t)ncz - 1u);
     const uint32_t kk = ((cy / (uint32_t)by) * (uint32_t)ncz + cz) * (uint32_t)by + cy % (uint32_t)by;
     key[t] = kk;
     atomicAdd(&count[kk + 2], 1u); // the bin sort's count pass
@@ -1180,17 +1188,7 @@ __global__ __launch_bounds__(256) void k_cell_keys_count(const double *__restric
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double ux = (x[i] - g.xmin[0]) / g.cell_size;
-    int cx = (int)floor(ux);
-    int cy = (int)floor((y[i] - g.xmin[1]) / g.cell_size);
-    int cz = (int)floor((z[i] - g.xmin[2]) / g.cell_size);
-    int sub = (int)floor((ux - (double)cx) * SPH_NSUB);
-    if (cx < 0) { cx = 0; sub = 0; }
-    if (cx > g.nc[0] - 1) { cx = g.nc[0] - 1; sub = SPH_NSUB - 1; }
-    sub = min(max(sub, 0), SPH_NSUB - 1);
-    cy = min(max(cy, 0), g.nc[1] - 1);
-    cz = min(max(cz, 0), g.nc[2] - 1);
-    const uint32_t key = (uint32_t)(cx + g.nc[0] * (cy + g.nc[1] * cz)) * SPH_NSUB + (uint32_t)sub;
+    const uint32_t key = fine_key_of(x[i], y[i], z[i], g, i);
     keys[i] = key;
     atomicAdd(&count[key + 2], 1u);
 }
@@ -1550,10 +1548,19 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
     c->n_cells = n_cells_alloc;
     for (auto &A : c->arr) A.nnps_slot = -1;
 
+    // parked padding rows (an array that took a padded ghost message or padded images since its ghosts were last dropped)
+    // are binned into PARKING cells behind the grid's own: the tables are sized for both, nothing else knows
+    bool padding = false;
+    for (int a = 0; a < narrays; a++) padding |= c->arr[ids[a]].has_padding && c->arr[ids[a]].n > 0;
+    const long park_cells = padding ? (long)std::min<size_t>(std::max<size_t>(n_cat / 64, 512), 1u << 16) : 0;
+    const long n_cells_tab = n_cells_alloc + park_cells;
+    c->park_cells = park_cells;
+    c->n_cells = n_cells_tab;
     GridDesc g;
     for (int k = 0; k < 3; k++) { g.xmin[k] = c->xmin[k]; g.nc[k] = c->nc[k]; }
     g.cell_size = cell_size;
-    const size_t n_fine = (size_t)n_cells_alloc * SPH_NSUB;
+    g.park_base = (uint32_t)(n_cells_alloc * SPH_NSUB); g.park_bins = (uint32_t)(park_cells * SPH_NSUB);
+    const size_t n_fine = (size_t)n_cells_tab * SPH_NSUB;
 
     // Several arrays (a dam break has three): ONE sort of all their keys.
     //  * merged-first (option merge_arrays, default): the arrays are concatenated in slot order and the sort is stable, so
@@ -1611,7 +1618,7 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
         d.T = T; d.merged = merged_first; d.via = via;
         d.co.narrays = narrays;
         for (int a = 0; a <= SPH_MAX_ARRAYS; a++) d.co.off[a] = a < narrays ? ba.off[a] : (uint32_t)n_cat;
-        SPH_TRY(sort_finish(c, n_cat, n_fine, n_cells_alloc, lbits, nbuckets, d));
+        SPH_TRY(sort_finish(c, n_cat, n_fine, n_cells_tab, lbits, nbuckets, d));
         SPH_TRY(nnps_tile_order(c, *T, n_cat));
         if (!merged_first) T->perm_direct_n = n_cat;
         if (merged_first) {
@@ -1639,7 +1646,7 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
             d.T = &A; d.merged = false;
             d.co.narrays = 1;
             for (int k = 0; k <= SPH_MAX_ARRAYS; k++) d.co.off[k] = k ? (uint32_t)n1 : 0u;
-            SPH_TRY(sort_finish(c, n1, n_fine, n_cells_alloc, lbits, nbuckets, d));
+            SPH_TRY(sort_finish(c, n1, n_fine, n_cells_tab, lbits, nbuckets, d));
             SPH_TRY(nnps_tile_order(c, A, n1));
             A.perm_direct_n = n1;
             c->last_keys_n = 0; // (several arrays: no single pass to judge)
@@ -1699,6 +1706,7 @@ extern "C" int sph_nnps_update_ghosts(sph_ctx *c, int axis, double lo, double hi
     GridDesc g;
     for (int k = 0; k < 3; k++) { g.xmin[k] = c->xmin[k]; g.nc[k] = c->nc[k]; }
     g.cell_size = c->cell_size;
+    g.park_base = (uint32_t)((c->n_cells - c->park_cells) * SPH_NSUB); g.park_bins = (uint32_t)(c->park_cells * SPH_NSUB);
     const size_t n_fine = (size_t)c->n_cells * SPH_NSUB;
     for (int a = 0; a < c->narrays; a++) {
         DevArray &A = c->arr[c->ids[a]];
@@ -1870,6 +1878,7 @@ extern "C" int sph_nnps_get_csr(sph_ctx *c, int src, int dst, uint32_t *start, s
     GridDesc g;
     for (int k = 0; k < 3; k++) { g.xmin[k] = c->xmin[k]; g.nc[k] = c->nc[k]; }
     g.cell_size = c->cell_size;
+    g.park_base = g.park_bins = 0;
     SPH_TRY(c->tmp_u32a.reserve((nd + 1) * 4));
     uint32_t *d_start = c->tmp_u32a.as<uint32_t>();
     // variant 6 (default): the lists come from the wave-tile pair kernel itself (nnps_csr_pair_kernel);
@@ -1923,6 +1932,7 @@ int nnps_build_csr_device(sph_ctx *c, int src, int dst, DevBuf &start, DevBuf &n
     GridDesc g;
     for (int k = 0; k < 3; k++) { g.xmin[k] = c->xmin[k]; g.nc[k] = c->nc[k]; }
     g.cell_size = c->cell_size;
+    g.park_base = g.park_bins = 0;
     SPH_TRY(start.reserve((nd + 2) * 4));
     SPH_TRY(c->tmp_u32a.reserve((nd + 2) * 4));
     *total = 0;

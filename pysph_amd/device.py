@@ -82,6 +82,11 @@ SIGNATURES = {
                                   C.POINTER(C.c_size_t)]),
     'sph_domain_box_wrap': (C.c_int, [_P, C.c_int, C.c_int, C.c_double,
                                       C.c_double, C.c_double]),
+    'sph_domain_images_padded': (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                          C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_int)]),
+    'sph_domain_counts_queue': (C.c_int, [_P]),
+    'sph_domain_counts_collect': (C.c_int, [_P, _PD]),
+    'sph_array_h_known': (C.c_int, [_P, C.c_int, _PD, _PD]),
     'sph_array_props': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.c_int,
                                   C.POINTER(C.c_int)]),
     'sph_halo_pack': (C.c_int, [_P, C.c_int, C.c_int, C.c_int,

@@ -28,6 +28,7 @@ Mirror (reflecting) boundaries (``mirror_in_x/y/z``,
 ``x + 2*(plane - x)`` and the normal velocity component negated.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -161,9 +162,17 @@ class HipDomainManager(_DomainBase):
         processing the axes one after the other, nnps_base.pyx:751-940)."""
         ctx = kw.pop('ctx', None)
         self.slab = kw.pop('slab', None)
+        # 'padded' (default): the periodic images of a steady-state update are made without a device->host round trip
+        # (fixed capacities sized from the previous update's counts, sph_domain_images_padded); 'counted': every axis
+        # reads its two counts back (the list-based update of rounds 3-4; always used for mirror axes and for the
+        # first update, which establishes the capacities)
+        self.protocol = kw.pop('protocol', os.environ.get('SPH_DOMAIN_PROTOCOL', 'padded'))
         _DomainBase.__init__(self, *args, **kw)
         self.ctx = ctx or dev.get_context()
         self.lib = self.ctx.lib
+        self._caps = None           # {(helper index, axis): [cap_lo, cap_hi]} once a counted update has run
+        self._queued = False        # counts of the last padded update are on their way to the host
+        self.padded_updates = 0
 
     def set_particles(self, particles, radius_scale):
         _DomainBase.set_particles(self, particles, radius_scale)
@@ -179,6 +188,47 @@ class HipDomainManager(_DomainBase):
             h.ghost_owner = 'domain+slab' if self.slab is not None else 'domain'
             h.managed = True
 
+    def _hmax_known(self):
+        """max h over the arrays when every array's range is known without looking (nothing wrote h since the last
+        neighbour update / reduction saw it), else None"""
+        best = None
+        lo, hi = C.c_double(), C.c_double()
+        for h in self.helpers:
+            if h.get_number_of_particles(True) == 0:
+                continue
+            if not self.lib.sph_array_h_known(self.ctx._h, h.array_id, C.byref(lo), C.byref(hi)):
+                return None
+            best = hi.value if best is None else max(best, hi.value)
+        return best
+
+    @staticmethod
+    def _capacity(count):
+        # a face's image count is QUANTISED for a lattice (Taylor-Green starts as one): when a lattice plane drifts
+        # across the threshold a whole layer -- a quarter of a four-layer face -- enters at once.  Half of the count as
+        # headroom; the parked rows it leaves cost the sort and the record packing their share and nothing else (they
+        # are binned into parking cells no destination visits)
+        return int(count) + int(count) // 2 + 1024
+
+    def _collect_counts(self):
+        """counts of the last padded update, read now (an update later): the capacities follow them; images that did
+        not fit are an error of the step that used them"""
+        out = (C.c_double * (dev.MAX_ARRAYS * 6))()
+        dev._check(self.lib.sph_domain_counts_collect(self.ctx._h, out))
+        self._queued = False
+        for (k, ax), caps in self._caps.items():
+            aid = self.helpers[k].array_id
+            for side in (0, 1):
+                cnt = out[aid * 6 + ax * 2 + side]
+                if cnt < 0:
+                    self._caps = None
+                    raise RuntimeError(
+                        "periodic images of array '%s', axis %d: %d rows did not fit their capacity of %d -- the last "
+                        "evaluation ran with images missing (SPH_DOMAIN_PROTOCOL=counted sizes every update exactly)"
+                        % (self.helpers[k]._pa.name, ax, int(-cnt), caps[side]))
+                cnt = int(cnt)
+                if cnt + cnt // 3 + 512 > caps[side] or 2 * cnt + 4096 < caps[side]:
+                    caps[side] = self._capacity(cnt)
+
     def _hmax(self):
         ids = (C.c_int * len(self.helpers))(*[h.array_id for h in self.helpers])
         out = (C.c_double * 8)()
@@ -191,10 +241,20 @@ class HipDomainManager(_DomainBase):
             return
         lib, ctx = self.lib, self.ctx._h
         slab_axis = self.slab.axis if self.slab is not None else -1
+        if self._queued:
+            self._collect_counts()
         for h in self.helpers:
             nreal = h.get_number_of_particles(True)
             dev._check(lib.sph_array_resize(ctx, h.array_id, nreal, nreal))
-        cs = self.radius_scale * self._hmax()
+        # a steady-state periodic update needs nothing from the device: h is known while nothing wrote it, the image
+        # capacities come from the counts of the previous update
+        hmax = self._hmax_known() if (self.protocol == 'padded' and self._caps is not None
+                                      and not any(self.mirror)) else None
+        padded = hmax is not None
+        if not padded:
+            self._caps = None
+            hmax = self._hmax()
+        cs = self.radius_scale * hmax
         self.cell_size = 1.0 if cs < 1e-6 else cs
         width = self.n_layers * self.cell_size
         for h in self.helpers:
@@ -205,7 +265,8 @@ class HipDomainManager(_DomainBase):
                                                        self.translate[ax]))
         if self.slab is not None:
             self.slab.exchange(drop=False)     # remote ghosts along the slab axis first
-        for h in self.helpers:
+        new_caps = {}
+        for k, h in enumerate(self.helpers):
             aid = h.array_id
             props = h.device_props()
             nprops = len(props)
@@ -214,10 +275,18 @@ class HipDomainManager(_DomainBase):
                 if not self.periodic[ax] or ax == slab_axis:
                     continue
                 lo, hi = self.lims[ax]
+                if padded:
+                    # both faces' images of all particles present, into the capacities of this (array, axis): no counts
+                    # come back now (sph_domain_images_padded)
+                    cp = (C.c_size_t * 2)(*self._caps[(k, ax)])
+                    dev._check(lib.sph_domain_images_padded(ctx, aid, ax, lo, hi, width, self.translate[ax], cp,
+                                                            nprops, pr))
+                    continue
                 counts = (C.c_size_t * 2)()
                 n_all = h.get_number_of_particles()
                 dev._check(lib.sph_halo_select(ctx, aid, ax, 1, lo, hi, width,
                                                n_all, counts))
+                new_caps[(k, ax)] = [self._capacity(counts[0]), self._capacity(counts[1])]
                 # both sides were selected among the n_all particles present
                 # before either side's images exist (nnps_base.pyx:805-856)
                 for side, shift in ((0, self.translate[ax]),
@@ -237,3 +306,9 @@ class HipDomainManager(_DomainBase):
                     if counts[side]:
                         dev._check(lib.sph_halo_image(ctx, aid, side, nprops, pr, ax,
                                                       1, plane, None))
+        if padded:
+            dev._check(lib.sph_domain_counts_queue(ctx))
+            self._queued = True
+            self.padded_updates += 1
+        elif self.protocol == 'padded' and not any(self.mirror):
+            self._caps = new_caps

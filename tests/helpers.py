@@ -158,3 +158,18 @@ class _ThreadDistRank(object):
 
     def barrier(self):
         self.hub.barrier.wait()
+
+
+def live_rows(pa, prop='x'):
+    """property `prop` of every row the DEVICE array holds that is a particle: the padding rows of the round-trip-free
+    ghost protocols (sph_halo_append_padded, sph_domain_images_padded) are parked at 1e18 and skipped"""
+    import numpy as np
+    from pysph_amd import device as dev
+    g = pa.gpu
+    n = g.get_number_of_particles()
+    out = {}
+    for q in ('x', prop):
+        b = np.empty(n)
+        dev._check(g.lib.sph_array_pull(g.ctx._h, g.array_id, dev.prop_id(q), b.ctypes.data_as(dev._PD), 0, n))
+        out[q] = b
+    return out[prop][np.abs(out['x']) < 1e17]

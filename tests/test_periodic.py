@@ -3,7 +3,7 @@ pysph/base/tests/test_domain_manager.py:100-118, test_periodic_nnps.py)."""
 import numpy as np
 import pytest
 
-from helpers import rel_err
+from helpers import live_rows, rel_err
 
 
 def lattice(n1, dim=3, hdx=1.0, name='fluid', jitter=0.0, seed=3):
@@ -163,7 +163,8 @@ def test_device_domain_manager_matches_host(oracle):
     nnps.update_domain()       # again: ghosts are dropped and rebuilt
     nnps.update()
     a_eval.compute(0.0, 1e-4)
-    assert pa.gpu.get_number_of_particles() == ref[0].get_number_of_particles()
+    # (updates after the first make the images into fixed capacities: count the rows that are particles)
+    assert live_rows(pa).size == ref[0].get_number_of_particles()
     pa.gpu.pull('x', 'rho', 'V', 'p', 'au', 'av', 'aw', 'auhat', 'avhat', 'awhat')
     assert abs(pa.x[3] - 0.996) < 1e-15
     for prop in ('rho', 'V', 'p', 'au', 'av', 'aw', 'auhat', 'avhat', 'awhat'):
@@ -389,6 +390,72 @@ def test_device_periodic_3d_flag_combinations(axes):
             inner &= np.abs(pa.properties[ax][:nreal]) < 0.5 - 3.2 * 1.5 * dx
     assert inner.any()
     assert np.max(np.abs(1.0 / pa.V[:nreal][inner] - dx ** 3)) < 0.5e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('axes', ['xyz', 'xy'])
+def test_device_periodic_update_without_round_trip_equals_counted_update(axes):
+    """Round 5: from its second update on the device domain manager makes the periodic images without a device->host
+    round trip -- h known without looking, both faces' images of an axis appended into fixed capacities sized from
+    the previous update's counts, the rows behind the counts parked (sph_domain_images_padded).  Same live ghosts in
+    the same order as the counted (list-based) update, so the densities of a moving jittered lattice are
+    BIT-IDENTICAL between the two protocols update after update, particles crossing the faces included; the
+    neighbour updates in between make no round trip either; capacities that are too small are an error, one update
+    late."""
+    from pysph_amd import device as dev
+    from pysph_amd import kernels as K
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.domain import HipDomainManager
+    from pysph_amd.equations import Group, TVFSummationDensity
+    from pysph_amd.nnps import HipNNPS
+    kernel = K.QuinticSpline(dim=3)
+    kw = {}
+    for ax in axes:
+        kw.update({ax + 'min': 0.0, ax + 'max': 1.0, 'periodic_in_' + ax: True})
+    runs = {}
+    for protocol in ('padded', 'counted'):
+        pa, dx = lattice(16, dim=3, hdx=1.2)
+        rng = np.random.default_rng(5)
+        for q in 'xyz':
+            pa.properties[q] += 0.2 * dx * rng.uniform(-1, 1, pa.x.size)
+        ctx = dev.HipContext(0)
+        ctx.timer_enable(True)
+        dev.attach(pa, ctx).push()
+        a_eval = AccelerationEval([pa], [Group(equations=[TVFSummationDensity('fluid', ['fluid'])])], kernel)
+        SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+        dom = HipDomainManager(ctx=ctx, protocol=protocol, **kw)
+        nnps = HipNNPS(3, [pa], radius_scale=kernel.radius_scale, ctx=ctx, domain=dom, sync=False)
+        a_eval.set_nnps(nnps)
+        nreal = pa.gpu.get_number_of_particles(True)
+        out, live = [], []
+        for step in range(5):
+            if step:
+                for q, amp in zip('xyz', (0.45, -0.3, 0.2)):        # a drift: particles leave through the faces
+                    pa.properties[q][:nreal] += amp * dx
+                pa.gpu.push('x', 'y', 'z')
+                nnps.update_domain()        # ghosts dropped, particles wrapped, images made again
+                nnps.update()
+            a_eval.compute(0.0, 0.1)
+            pa.gpu.pull('V')
+            out.append(pa.V[:nreal].copy())
+            # the live rows (real particles, then the images), in order
+            live.append(np.stack([live_rows(pa, q) for q in 'xyz']))
+        runs[protocol] = (out, live, dom.padded_updates, ctx.timer_get('n_async')[1], dom)
+    for a, b in zip(runs['padded'][0], runs['counted'][0]):
+        assert np.array_equal(a, b)
+    for a, b in zip(runs['padded'][1], runs['counted'][1]):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert not np.array_equal(runs['padded'][1][0], runs['padded'][1][2])      # (the ghost set really changed)
+    assert runs['padded'][2] == 4 and runs['counted'][2] == 0
+    assert runs['padded'][3] >= 3           # neighbour updates without a round trip
+    # capacities that are too small: the images do not fit, the update after says so
+    dom = runs['padded'][4]
+    dom._collect_counts()               # (the counts of the last update: the capacities would follow them)
+    for key in dom._caps:
+        dom._caps[key] = [8, 8]
+    dom.update()
+    with pytest.raises(RuntimeError, match='did not fit'):
+        dom.update()
 
 
 # ---------------------------------------------------------------------------
