@@ -1002,6 +1002,7 @@ def run(args, rank, local_rank, world, dist):
         },
         'kernel_ms_per_step': {k: v[0] / args.steps for k, v in timers.items() if k not in PAIR_FAMILIES and k != 'n_async'},
         'nnps_updates_without_round_trip': timers['n_async'][1],
+        'periodic_updates_without_round_trip': None if domain is None else int(getattr(domain, 'padded_updates', 0)),
         'pair_ms_per_family': family_ms(timers, args.steps),
         'fp64_valu': None if not pairs else {
             'pairs_per_launch': pairs,
