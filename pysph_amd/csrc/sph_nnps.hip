@@ -38,7 +38,7 @@ struct GridDesc {
     int nc[3];
     // PARKING bins behind the grid's own in the tables (or none): where parked padding rows are binned -- cells no
     // destination visits, at the end of the cell order (wavefronts made of them find no active destination)
-    uint32_t park_base, park_bins;
+    uint32_t park_base, park_bins, park_n; // first parking bin, their number, rows of the index range that maps onto them
 };
 
 // nnps_base.pxd:39-57 real_to_int = <int>floor(real_val/step), flatten_raw :83-96
@@ -73,10 +73,13 @@ __device__ __forceinline__ bool is_parked(double x) { return fabs(x) >= SPH_PARK
 __device__ __forceinline__ uint32_t fine_key_of(double x, double y, double z, const GridDesc &g, size_t i)
 {
     if (is_parked(x)) {
-        const unsigned long long h = (unsigned long long)i * 2654435761ull;
-        if (g.park_bins) return g.park_base + (uint32_t)(h % g.park_bins);
+        // parking bins IN INDEX ORDER (row i of park_n -> bin i * park_bins / park_n): padding rows that are neighbours in
+        // memory stay neighbours in the cell order -- hashed over the bins (the first version) every one of them was a
+        // random 8-byte gather for the record packing and an atomic group of its own for the sort: Taylor-Green's 0.5 M
+        // padding rows cost 0.15 ms of packing and tipped the array into the "no spatial order" traversal
+        if (g.park_bins) return g.park_base + (uint32_t)(((unsigned long long)i * g.park_bins) / max(g.park_n, 1u)) % g.park_bins;
         const unsigned long long n_fine = (unsigned long long)g.nc[0] * g.nc[1] * g.nc[2] * SPH_NSUB;
-        return (uint32_t)(h % n_fine);
+        return (uint32_t)(((unsigned long long)i * 2654435761ull) % n_fine);
     }
     return fine_key(x, y, z, g);
 }
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void k_bin_keys(BinArrays t, GridDesc g, BinWo
         if (counts && m) { const double v = m[j]; mn[4] = fmin(mn[4], v); mx[4] = fmax(mx[4], v); }
         if (w.keys) {
             uint32_t key = 0;
-            if (valid) { key = fine_key_of(px, py, pz, g, j); w.keys[(size_t)t.off[a] + i] = key; }
+            if (valid) { key = fine_key_of(px, py, pz, g, (size_t)t.off[a] + j); w.keys[(size_t)t.off[a] + i] = key; }
             const uint32_t d = key >> w.lbits;
             unsigned long long todo = __ballot(valid);
             uint32_t cnt = 0; // this lane leads a group of `cnt` particles of one bucket
@@ -610,8 +613,18 @@ __global__ __launch_bounds__(256) void k_tile_keys(const uint32_t *__restrict__ 
     if (t >= n_tiles) return;
     const uint32_t k = skeys[(size_t)t * SPH_TILE];
     const uint32_t row = k / (uint32_t)ncx;
-    // (a tile of parked padding rows lies in the parking cells behind the grid: ordered with the last plane)
-    const uint32_t cy = row % (uint32_t)ncy, cz = min(row / (uint32_t)ncy, (uint32_t)ncz - 1u);
+    // A tile of parked padding rows lies in the parking cells behind the grid and has no work: such tiles are dealt over
+    // the whole traversal (a key that depends on the tile index only).  Left together at the end of the order they are the
+    // LAST XCD's contiguous share of the launch (xcd_tile): one of eight XCDs idle, +6 % on Taylor-Green's pair passes
+    // with 9 % padding rows.
+    if (row >= (uint32_t)ncy * (uint32_t)ncz) {
+        const uint32_t nkeys = ((uint32_t)ncy + (uint32_t)by - 1u) / (uint32_t)by * (uint32_t)by * (uint32_t)ncz;
+        const uint32_t kp = (uint32_t)(((unsigned long long)t * 2654435761ull) % nkeys);
+        key[t] = kp;
+        atomicAdd(&count[kp + 2], 1u);
+        return;
+    }
+    const uint32_t cy = row % (uint32_t)ncy, cz = row / (uint32_t)ncy;
     const uint32_t kk = ((cy / (uint32_t)by) * (uint32_t)ncz + cz) * (uint32_t)by + cy % (uint32_t)by;
     key[t] = kk;
     atomicAdd(&count[kk + 2], 1u); // the bin sort's count pass
@@ -1552,14 +1565,14 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
     // are binned into PARKING cells behind the grid's own: the tables are sized for both, nothing else knows
     bool padding = false;
     for (int a = 0; a < narrays; a++) padding |= c->arr[ids[a]].has_padding && c->arr[ids[a]].n > 0;
-    const long park_cells = padding ? (long)std::min<size_t>(std::max<size_t>(n_cat / 64, 512), 1u << 16) : 0;
+    const long park_cells = padding ? (long)std::min<size_t>(std::max<size_t>(n_cat / 64, 512), 1u << 18) : 0;
     const long n_cells_tab = n_cells_alloc + park_cells;
     c->park_cells = park_cells;
     c->n_cells = n_cells_tab;
     GridDesc g;
     for (int k = 0; k < 3; k++) { g.xmin[k] = c->xmin[k]; g.nc[k] = c->nc[k]; }
     g.cell_size = cell_size;
-    g.park_base = (uint32_t)(n_cells_alloc * SPH_NSUB); g.park_bins = (uint32_t)(park_cells * SPH_NSUB);
+    g.park_base = (uint32_t)(n_cells_alloc * SPH_NSUB); g.park_bins = (uint32_t)(park_cells * SPH_NSUB); g.park_n = (uint32_t)n_cat;
     const size_t n_fine = (size_t)n_cells_tab * SPH_NSUB;
 
     // Several arrays (a dam break has three): ONE sort of all their keys.
@@ -1707,6 +1720,7 @@ extern "C" int sph_nnps_update_ghosts(sph_ctx *c, int axis, double lo, double hi
     for (int k = 0; k < 3; k++) { g.xmin[k] = c->xmin[k]; g.nc[k] = c->nc[k]; }
     g.cell_size = c->cell_size;
     g.park_base = (uint32_t)((c->n_cells - c->park_cells) * SPH_NSUB); g.park_bins = (uint32_t)(c->park_cells * SPH_NSUB);
+    g.park_n = 1; // (set per array below: the ghost segment's own row count)
     const size_t n_fine = (size_t)c->n_cells * SPH_NSUB;
     for (int a = 0; a < c->narrays; a++) {
         DevArray &A = c->arr[c->ids[a]];
@@ -1721,6 +1735,7 @@ extern "C" int sph_nnps_update_ghosts(sph_ctx *c, int axis, double lo, double hi
         uint32_t *T = A.g_fine_start.as<uint32_t>();
         HIP_TRY(hipMemsetAsync(T, 0, (n_fine + 2) * 4, c->stream));
         const size_t nb = A.n_binned;
+        g.park_n = (uint32_t)ng;
         hipLaunchKernelGGL(k_cell_keys_count, dim3(div_up(ng, 256)), dim3(256), 0, c->stream, A.prop[SPH_X] + nb, A.prop[SPH_Y] + nb,
                            A.prop[SPH_Z] + nb, ng, g, A.g_keys.as<uint32_t>(), T);
         BinFixArgs fa;
@@ -1878,7 +1893,7 @@ extern "C" int sph_nnps_get_csr(sph_ctx *c, int src, int dst, uint32_t *start, s
     GridDesc g;
     for (int k = 0; k < 3; k++) { g.xmin[k] = c->xmin[k]; g.nc[k] = c->nc[k]; }
     g.cell_size = c->cell_size;
-    g.park_base = g.park_bins = 0;
+    g.park_base = g.park_bins = g.park_n = 0;
     SPH_TRY(c->tmp_u32a.reserve((nd + 1) * 4));
     uint32_t *d_start = c->tmp_u32a.as<uint32_t>();
     // variant 6 (default): the lists come from the wave-tile pair kernel itself (nnps_csr_pair_kernel);
@@ -1932,7 +1947,7 @@ int nnps_build_csr_device(sph_ctx *c, int src, int dst, DevBuf &start, DevBuf &n
     GridDesc g;
     for (int k = 0; k < 3; k++) { g.xmin[k] = c->xmin[k]; g.nc[k] = c->nc[k]; }
     g.cell_size = c->cell_size;
-    g.park_base = g.park_bins = 0;
+    g.park_base = g.park_bins = g.park_n = 0;
     SPH_TRY(start.reserve((nd + 2) * 4));
     SPH_TRY(c->tmp_u32a.reserve((nd + 2) * 4));
     *total = 0;

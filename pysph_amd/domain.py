@@ -162,11 +162,14 @@ class HipDomainManager(_DomainBase):
         processing the axes one after the other, nnps_base.pyx:751-940)."""
         ctx = kw.pop('ctx', None)
         self.slab = kw.pop('slab', None)
-        # 'padded' (default): the periodic images of a steady-state update are made without a device->host round trip
-        # (fixed capacities sized from the previous update's counts, sph_domain_images_padded); 'counted': every axis
-        # reads its two counts back (the list-based update of rounds 3-4; always used for mirror axes and for the
-        # first update, which establishes the capacities)
-        self.protocol = kw.pop('protocol', os.environ.get('SPH_DOMAIN_PROTOCOL', 'padded'))
+        # 'counted' (default): every periodic axis reads its two image counts back (exact sizes, four device->host round
+        # trips per update).  'padded' (opt-in): a steady-state update makes the images without a round trip, into fixed
+        # capacities sized from the previous update's counts plus `headroom` (sph_domain_images_padded) -- 2 % faster on
+        # Taylor-Green at 4 M, but an image count that grows by more than the headroom within ONE update is an error one
+        # update late, and for a lattice the counts are quantised: when a lattice plane drifts across the threshold a
+        # whole layer (a third of a three-layer face) enters at once.  headroom 0.5 covers that and costs what it saves.
+        self.protocol = kw.pop('protocol', os.environ.get('SPH_DOMAIN_PROTOCOL', 'counted'))
+        self.headroom = float(kw.pop('headroom', os.environ.get('SPH_DOMAIN_HEADROOM', '0.125')))
         _DomainBase.__init__(self, *args, **kw)
         self.ctx = ctx or dev.get_context()
         self.lib = self.ctx.lib
@@ -201,13 +204,10 @@ class HipDomainManager(_DomainBase):
             best = hi.value if best is None else max(best, hi.value)
         return best
 
-    @staticmethod
-    def _capacity(count):
-        # a face's image count is QUANTISED for a lattice (Taylor-Green starts as one): when a lattice plane drifts
-        # across the threshold a whole layer -- a quarter of a four-layer face -- enters at once.  Half of the count as
-        # headroom; the parked rows it leaves cost the sort and the record packing their share and nothing else (they
-        # are binned into parking cells no destination visits)
-        return int(count) + int(count) // 2 + 1024
+    def _capacity(self, count):
+        # the parked rows behind the count cost the sort and the record packing their share and the pair passes a little
+        # (empty destination tiles): measured on Taylor-Green, 9 % padding rows = +0.15 ms, 2 % = nothing
+        return int(count) + int(int(count) * self.headroom) + 1024
 
     def _collect_counts(self):
         """counts of the last padded update, read now (an update later): the capacities follow them; images that did
@@ -226,7 +226,8 @@ class HipDomainManager(_DomainBase):
                         "evaluation ran with images missing (SPH_DOMAIN_PROTOCOL=counted sizes every update exactly)"
                         % (self.helpers[k]._pa.name, ax, int(-cnt), caps[side]))
                 cnt = int(cnt)
-                if cnt + cnt // 3 + 512 > caps[side] or 2 * cnt + 4096 < caps[side]:
+                if cnt + int(cnt * self.headroom * 0.6) + 512 > caps[side] or \
+                        cnt + int(cnt * self.headroom * 2) + 4096 < caps[side]:
                     caps[side] = self._capacity(cnt)
 
     def _hmax(self):
