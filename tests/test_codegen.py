@@ -110,6 +110,20 @@ def test_float_build_of_a_family():
     assert not fam.abs_src_pos
 
 
+def test_float_literal_rewrite_touches_only_floating_literals():
+    """the literal pass of `source_f32`: floating literals get the float suffix, nothing else is touched (integers,
+    flag masks, identifiers with digits, array sizes, member names, already-suffixed literals)"""
+    from pysph_amd.codegen import _F32_LITERAL
+    cases = [('x = 0.5 * y;', 'x = 0.5f * y;'), ('a = 1e-12;', 'a = 1e-12f;'), ('b = 2.;', 'b = 2.f;'),
+             ('c = .25 + 1.0e+3;', 'c = .25f + 1.0e+3f;'), ('d = 3.5E-2 - 7;', 'd = 3.5E-2f - 7;'),
+             ('if (fl & 4u) {', 'if (fl & 4u) {'), ('double s00 = D.d_s00;', 'double s00 = D.d_s00;'),
+             ('m[((w * 1) + 2)] = x1e5;', 'm[((w * 1) + 2)] = x1e5;'), ('v = a.k.dim * 3;', 'v = a.k.dim * 3;'),
+             ('t = pj.x - 0.0;', 't = pj.x - 0.0f;'), ('u = d_amat__10 + 10.0;', 'u = d_amat__10 + 10.0f;'),
+             ('w = q[2] * 1.5f;', 'w = q[2] * 1.5f;'), ('k = 0x1f + 1;', 'k = 0x1f + 1;')]
+    for src, want in cases:
+        assert _F32_LITERAL.sub(r'\1f', src) == want, src
+
+
 def test_translation_details():
     from pysph_amd.codegen import GeneratedFamily
     from pysph_amd.equations import Equation
