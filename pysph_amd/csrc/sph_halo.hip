@@ -559,10 +559,9 @@ extern "C" int sph_domain_images_padded(sph_ctx *c, int id, int axis, double lo,
         }
         has_h |= p == SPH_H; has_m |= p == SPH_M; has_x |= p == SPH_X + axis;
     }
-    if (!has_x || !c->arr[id].prop[SPH_X] || !c->arr[id].prop[SPH_Y] || !c->arr[id].prop[SPH_Z]) {
-        sph_set_error("sph_domain_images_padded: the positions must be among the imaged properties");
-        return SPH_ERR_ARG;
-    }
+    bool all_pos = has_x;
+    for (int q = 0; q < 3; q++) { bool in = false; for (int k = 0; k < nprops; k++) in |= props[k] == SPH_X + q; all_pos &= in; }
+    if (!all_pos) { sph_set_error("sph_domain_images_padded: x, y and z must all be among the imaged properties"); return SPH_ERR_ARG; }
     if (n == 0 || cap0 + cap1 == 0) { // nothing to image (or no room): zero counts
         HIP_TRY(hipMemsetAsync(counts, 0, 2 * sizeof(double), c->stream));
         if (n == 0) return SPH_OK;
@@ -575,15 +574,12 @@ extern "C" int sph_domain_images_padded(sph_ctx *c, int id, int axis, double lo,
     if (has_m) { A.m_dirty = md; A.m_known = mk; }
     A.has_padding = true;
     PropList L;
-    bool all_pos = true;
     for (int k = 0; k < nprops; k++) {
         const int p = props[k];
         L.p[k] = A.prop[p];
         // 1: the axis coordinate (shifted in an image), 2: another coordinate (both parked in a padding row), 0: the rest
         L.what[k] = p == SPH_X + axis ? 1 : ((p == SPH_X || p == SPH_Y || p == SPH_Z) ? 2 : 0);
     }
-    for (int q = 0; q < 3; q++) { bool in = false; for (int k = 0; k < nprops; k++) in |= props[k] == SPH_X + q; all_pos &= in; }
-    if (!all_pos) { sph_set_error("sph_domain_images_padded: x, y and z must all be among the imaged properties"); return SPH_ERR_ARG; }
     HaloState &H = c->halo[id];
     H.count[0] = H.count[1] = 0; // the host does not learn the counts: no list-based call may follow
     H.nsel = 0;
@@ -636,7 +632,7 @@ extern "C" int sph_array_h_known(sph_ctx *c, int id, double *hmin, double *hmax)
 {
     if (!c || id < 0 || id >= SPH_MAX_ARRAYS || !hmin || !hmax) return 0;
     const DevArray &A = c->arr[id];
-    if (!A.used || !A.h_seen || A.h_dirty) return 0;
+    if (!A.used || !A.h_seen || A.h_dirty || A.raw_hm) return 0; // (a raw pointer to h was handed out: writes are not tracked)
     *hmin = A.h_lo; *hmax = A.h_hi;
     return 1;
 }
