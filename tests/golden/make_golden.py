@@ -126,6 +126,34 @@ def case_wcsph_dam():
              meta=dict(dx=dx))
 
 
+def case_wcsph_dam_varh():
+    """The mini dam break again with EVERY particle its own smoothing length (h +- 15 % in all three arrays): the
+    scenario of the one-launch variable-h family (round 5) -- several arrays AND the `or` of the neighbour criterion AND
+    HIJ-dependent kernels in one case.  No neighbour lists stored (wcsph_dam_dx0.1 and wcsph_cube_varh pin those)."""
+    rng = np.random.default_rng(20250926)
+    dx = 0.1
+    arrays = []
+    for pa in db.create_particles(dx):
+        n = pa.get_number_of_particles()
+        props = {k: pa.properties[k].copy() for k in WC_IN}
+        props['rho'] = db.ro * (1 + 0.02 * rng.uniform(-1, 1, n))
+        props['h'] = props['h'] * (1 + 0.15 * rng.uniform(-1, 1, n))
+        if pa.name == 'fluid':
+            for k in 'xyz':
+                props[k] = props[k] + 0.1 * dx * rng.uniform(-1, 1, n)
+            for k in 'uvw':
+                props[k] = 0.1 * db.c0 * rng.uniform(-1, 1, n)
+        for k in WC_OUT:
+            props[k] = rng.uniform(-1, 1, n)  # garbage: must be overwritten
+        arrays.append((pa.name, props, n))
+    s = WCSPHScheme(['fluid'], ['boundary', 'obstacle'], dim=3, rho0=db.ro,
+                    c0=db.c0, h0=dx * db.hdx, hdx=db.hdx, gz=-9.81,
+                    alpha=db.alpha, beta=db.beta, gamma=db.gamma,
+                    hg_correction=True, tensile_correction=False)
+    run_case('wcsph_dam_varh.npz', arrays, s.get_equations(),
+             WendlandQuintic(dim=3), 3, meta=dict(dx=dx))
+
+
 def case_wcsph_cube_varh():
     """8^3 jittered cube, variable h (exercises the `or` of the neighbour
     criterion), CubicSpline, tensile correction + beta != 0, summation density,
@@ -460,6 +488,6 @@ def case_steppers():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['kernels', 'sd_1d', 'wcsph_cube_varh', 'tvf_cube',
-                             'wcsph_dam', 'steppers', 'elastic_2d', 'elastic_3d']
+                             'wcsph_dam', 'wcsph_dam_varh', 'steppers', 'elastic_2d', 'elastic_3d']
     for w in which:
         globals()['case_' + w]()

@@ -17,7 +17,7 @@ TVF_OUT = ['rho', 'V', 'p', 'au', 'av', 'aw', 'auhat', 'avhat', 'awhat']
 
 def golden_case(name, g, wall_equations=None):
     """(equations, kernel, dim, output props) matching make_golden.py."""
-    if name == 'wcsph_dam_dx0.1':
+    if name in ('wcsph_dam_dx0.1', 'wcsph_dam_varh'):
         dx = float(g['meta/dx'])
         s = db.create_scheme(dx)
         return s.get_equations(), K.WendlandQuintic(dim=3), 3, WC_OUT

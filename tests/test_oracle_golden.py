@@ -11,7 +11,9 @@ import pytest
 from conftest import load_golden, arrays_from_golden
 from helpers import golden_case
 
-CASES = ['sd_1d_line', 'wcsph_cube_varh', 'tvf_cube', 'wcsph_dam_dx0.1',
+# (wcsph_dam_varh, round 5: three arrays AND per-particle h -- what the one-launch variable-h family is checked against
+# through this oracle at the BASELINE sizes)
+CASES = ['sd_1d_line', 'wcsph_cube_varh', 'tvf_cube', 'wcsph_dam_dx0.1', 'wcsph_dam_varh',
          'elastic_2d', 'elastic_3d']
 
 
