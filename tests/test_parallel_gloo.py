@@ -152,12 +152,8 @@ def _worker(rank, world, port, periodic, out):
         n = full.get_number_of_particles()
         gid = np.arange(n)
         x = full.x
-        lo, hi = (0.0, 0.5) if rank == 0 else (0.5, 1.0)
-        if periodic:      # make the wrap meaningful: domain [0,1) periodic in x
-            pass
-        own = np.nonzero((x >= lo) & (x < hi) if rank else (x < hi))[0]
-        if rank == world - 1:
-            own = np.nonzero(x >= lo)[0]
+        lo, hi = rank / float(world), (rank + 1) / float(world)    # equal slabs; the end slabs are open outwards
+        own = np.nonzero(((x >= lo) | (rank == 0)) & ((x < hi) | (rank == world - 1)))[0]
         pa = ParticleArray(name='fluid', **{k: v[own].copy() for k, v in
                                             full.properties.items()})
         kernel = K.WendlandQuintic(dim=3)
@@ -203,13 +199,16 @@ def _worker_migrate(rank, world, port, out):
         full, dx = make_cube(14)
         n = full.get_number_of_particles()
         x = full.x
-        own = np.nonzero(x < 0.3)[0] if rank == 0 else np.nonzero(x >= 0.3)[0]
+        # two ranks: cut at 0.3 for slabs [0, .5) [.5, 1]; three: cuts at 0.2 / 0.5 for thirds -- the middle rank both
+        # gives (to its lower neighbour) and takes (from its upper one)
+        wrong = {2: [-1e30, 0.3, 1e30], 3: [-1e30, 0.2, 0.5, 1e30]}[world]
+        own = np.nonzero((x >= wrong[rank]) & (x < wrong[rank + 1]))[0]
         props = {k: v[own].copy() for k, v in full.properties.items()}
         props['e0'] = own.astype(np.float64)        # global id rides along
         pa = ParticleArray(name='fluid', **props)
         kernel = K.WendlandQuintic(dim=3)
         width = kernel.radius_scale * 1.3 * dx
-        lo, hi = (0.0, 0.5) if rank == 0 else (0.5, 1.0)
+        lo, hi = rank / float(world), (rank + 1) / float(world)
         dec = SlabDecomposition([pa], None, rank, world, axis=0, width=width,
                                 lo=lo, hi=hi,
                                 ops_factory=lambda a, ax, p: NumpyHaloOps(a, ax),
@@ -217,17 +216,21 @@ def _worker_migrate(rank, world, port, out):
         dec.update()
         nreal = pa.get_number_of_particles(True)
         xr = pa.x[:nreal]
-        assert (xr < 0.5).all() if rank == 0 else (xr >= 0.5).all()
+        assert ((xr >= lo) | (rank == 0)).all() and ((xr < hi) | (rank == world - 1)).all()
         moved = dec.halos[0].last_migrated
-        assert (moved[3] > 0) if rank == 0 else (moved[0] > 0)
-        # lopsided on purpose -> rebalance moves the face to the median
-        dec.halos[0].lo, dec.halos[0].hi = (0.0, 0.8) if rank == 0 else (0.8, 1.0)
+        if rank > 0:
+            assert moved[0] > 0             # gave particles to the lower neighbour
+        if rank < world - 1:
+            assert moved[3] > 0             # ... and took some from the upper one
+        # lopsided on purpose -> rebalance moves the faces to the quantiles
+        lop = {2: [0.0, 0.8, 1.0], 3: [0.0, 0.6, 0.8, 1.0]}[world]
+        dec.halos[0].lo, dec.halos[0].hi = lop[rank], lop[rank + 1]
         dec.update()
         n_before = pa.get_number_of_particles(True)
         faces, rounds = dec.rebalance(nbins=512)
         dec.exchange()
         nreal = pa.get_number_of_particles(True)
-        assert abs(nreal - n // 2) <= 0.02 * n, (n_before, nreal)
+        assert abs(nreal - n // world) <= 0.02 * n, (n_before, nreal)
         nn = orc.OracleNNPS(3, [pa], 2.0)
         nn.update()
         ev = orc.OracleEval([pa], cube_equations(dx), kernel)
@@ -240,12 +243,13 @@ def _worker_migrate(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_two_rank_migration_and_rebalance(tmp_path, oracle):
+@pytest.mark.parametrize('world', [2, 3])
+def test_two_rank_migration_and_rebalance(tmp_path, oracle, world):
     from test_hip_parity import make_cube, cube_equations
     from helpers import rel_err
     from pysph_amd import kernels as K
     out = str(tmp_path / 'mig%d.npz')
-    mp.spawn(_worker_migrate, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker_migrate, args=(world, _free_port(), out), nprocs=world, join=True)
     full, dx = make_cube(14)
     kernel = K.WendlandQuintic(dim=3)
     nn = oracle.OracleNNPS(3, [full], 2.0)
@@ -254,7 +258,7 @@ def test_two_rank_migration_and_rebalance(tmp_path, oracle):
     ev.set_nnps(nn)
     ev.compute(0.0, 1e-5)
     gids = []
-    for r in range(2):
+    for r in range(world):
         d = np.load(out % r)
         gids.append(d['gid'])
         for k in ('arho', 'au', 'av', 'aw', 'ax', 'ay', 'az'):
@@ -272,13 +276,15 @@ def _free_port():
     return p
 
 
+@pytest.mark.parametrize('world', [2, 3])
 @pytest.mark.parametrize('periodic', [False, True])
-def test_two_rank_halo_matches_single_domain(tmp_path, oracle, periodic):
+def test_two_rank_halo_matches_single_domain(tmp_path, oracle, periodic, world):
+    """(... and with three ranks, where the middle one has two different peers: ranks 1..6 of an 8-GPU run)"""
     from test_hip_parity import make_cube, cube_equations
     from helpers import rel_err
     from pysph_amd import kernels as K
     out = str(tmp_path / 'rank%d.npz')
-    mp.spawn(_worker, args=(2, _free_port(), periodic, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), periodic, out), nprocs=world, join=True)
     full, dx = make_cube(14)
     nfull = full.get_number_of_particles()
     kernel = K.WendlandQuintic(dim=3)
@@ -297,7 +303,7 @@ def test_two_rank_halo_matches_single_domain(tmp_path, oracle, periodic):
     ev.compute(0.0, 1e-5)
     seen = 0
     gmax = 0.0
-    for r in range(2):
+    for r in range(world):
         d = np.load(out % r)
         gid = d['gid']
         seen += gid.size
@@ -358,7 +364,7 @@ def _worker_fused(rank, world, port, periodic, out):
         full, dx = make_cube(12)
         x = full.x
         lo, hi = (0.0, 0.5) if rank == 0 else (0.5, 1.0)
-        own = np.nonzero((x >= lo) & (x < hi))[0]
+        own = np.nonzero(((x >= lo) | (rank == 0)) & ((x < hi) | (rank == world - 1)))[0]     # (the end slabs are open outwards)
         odd, even = own[own % 2 == 1], own[own % 2 == 0]
 
         def make(idx, name):
@@ -461,8 +467,10 @@ def _worker_padded(rank, world, port, periodic, out):
         from pysph_amd.particle_array import ParticleArray
         full, dx = make_cube(12)
         x = full.x
-        own = np.nonzero(x < 0.5)[0] if rank == 0 else np.nonzero(x >= 0.5)[0]
-        lo, hi = (0.0, 0.5) if rank == 0 else (0.5, 1.0)
+        # `world` equal slabs of the unit cube: with three ranks the middle one talks to two DIFFERENT peers (what
+        # ranks 1..6 of an 8-GPU run do), with two periodic ranks both faces of a rank talk to the same peer
+        lo, hi = rank / float(world), (rank + 1) / float(world)
+        own = np.nonzero(((x >= lo) | (rank == 0)) & ((x < hi) | (rank == world - 1)))[0]     # (the end slabs are open outwards)
 
         def build(protocol, ops):
             pa = ParticleArray(name='fluid', **{k: v[own].copy() for k, v in full.properties.items()})
@@ -507,12 +515,14 @@ def _worker_padded(rank, world, port, periodic, out):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('world', [2, 3])
 @pytest.mark.parametrize('periodic', [False, True])
-def test_padded_protocol_equals_capacity_protocol(tmp_path, periodic):
+def test_padded_protocol_equals_capacity_protocol(tmp_path, periodic, world):
     out = str(tmp_path / 'padded_%d.npy')
-    mp.spawn(_worker_padded, args=(2, _free_port(), periodic, out), nprocs=2, join=True)
-    a = np.load(out % 0)
-    assert a.shape == (6, 2) and a[-1, 0] == 5 and a[1:, 1].min() > 0
+    mp.spawn(_worker_padded, args=(world, _free_port(), periodic, out), nprocs=world, join=True)
+    for rank in range(world):
+        a = np.load(out % rank)
+        assert a.shape == (6, 2) and a[-1, 0] == 5 and a[1:, 1].min() > 0
 
 
 def _worker_protocols(rank, world, port, periodic, out):
@@ -528,8 +538,8 @@ def _worker_protocols(rank, world, port, periodic, out):
         from pysph_amd.particle_array import ParticleArray
         full, dx = make_cube(12)
         x = full.x
-        own = np.nonzero(x < 0.5)[0] if rank == 0 else np.nonzero(x >= 0.5)[0]
-        lo, hi = (0.0, 0.5) if rank == 0 else (0.5, 1.0)
+        lo, hi = rank / float(world), (rank + 1) / float(world)     # equal slabs (three ranks: two different peers)
+        own = np.nonzero(((x >= lo) | (rank == 0)) & ((x < hi) | (rank == world - 1)))[0]     # (the end slabs are open outwards)
 
         def build(protocol, ops=NumpyHaloOps):
             pa = ParticleArray(name='fluid', **{k: v[own].copy() for k, v in full.properties.items()})
@@ -573,17 +583,18 @@ def _worker_protocols(rank, world, port, periodic, out):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('world', [2, 3])
 @pytest.mark.parametrize('periodic', [False, True])
-def test_capacity_protocol_equals_handshake(tmp_path, periodic):
+def test_capacity_protocol_equals_handshake(tmp_path, periodic, world):
     out = str(tmp_path / 'proto_%d.npy')
-    mp.spawn(_worker_protocols, args=(2, _free_port(), periodic, out), nprocs=2, join=True)
-    a, b = np.load(out % 0), np.load(out % 1)
-    assert a.shape == (6, 4) and a[:, :2].sum() > 0
-    if periodic:
-        # what rank 0 sent through its lo face arrived at rank 1's hi face, and so on
-        assert np.array_equal(a[:, 0], b[:, 3]) and np.array_equal(a[:, 1], b[:, 2])
-    else:
-        assert np.array_equal(a[:, 1], b[:, 2]) and np.array_equal(b[:, 0], a[:, 3])
+    mp.spawn(_worker_protocols, args=(world, _free_port(), periodic, out), nprocs=world, join=True)
+    logs = [np.load(out % r) for r in range(world)]      # per exchange: (sent lo, sent hi, received lo, received hi)
+    assert logs[0].shape == (6, 4) and logs[0][:, :2].sum() > 0
+    for r in range(world):
+        up = (r + 1) % world
+        if r + 1 < world or periodic:
+            # what rank r sent through its hi face arrived at its upper neighbour's lo face, and back
+            assert np.array_equal(logs[r][:, 1], logs[up][:, 2]) and np.array_equal(logs[up][:, 0], logs[r][:, 3])
 
 
 def test_capacity_rule_is_symmetric_and_stable():
