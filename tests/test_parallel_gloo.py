@@ -363,7 +363,7 @@ def _worker_fused(rank, world, port, periodic, out):
         from pysph_amd.particle_array import ParticleArray
         full, dx = make_cube(12)
         x = full.x
-        lo, hi = (0.0, 0.5) if rank == 0 else (0.5, 1.0)
+        lo, hi = rank / float(world), (rank + 1) / float(world)
         own = np.nonzero(((x >= lo) | (rank == 0)) & ((x < hi) | (rank == world - 1)))[0]     # (the end slabs are open outwards)
         odd, even = own[own % 2 == 1], own[own % 2 == 0]
 
@@ -384,7 +384,7 @@ def _worker_fused(rank, world, port, periodic, out):
         dec.exchange_finish(st)
         flo, fhi = dec.faces()
         if not periodic:
-            assert (flo, fhi) == ((-float('inf'), 0.5) if rank == 0 else (0.5, float('inf')))
+            assert (flo, fhi) == (-float('inf') if rank == 0 else lo, float('inf') if rank == world - 1 else hi)
         else:
             assert (flo, fhi) == (lo, hi)
         for pa, ref in ((a, a2), (b, b2)):
@@ -399,13 +399,13 @@ def _worker_fused(rank, world, port, periodic, out):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('world', [2, 3])
 @pytest.mark.parametrize('periodic', [False, True])
-def test_fused_two_array_exchange_equals_per_array(tmp_path, periodic):
-    port = 29600 + (os.getpid() % 200) + (7 if periodic else 0)
+def test_fused_two_array_exchange_equals_per_array(tmp_path, periodic, world):
     out = str(tmp_path / 'f%d.npy')
-    mp.spawn(_worker_fused, args=(2, port, periodic, out), nprocs=2, join=True)
-    n0, n1 = np.load(out % 0), np.load(out % 1)
-    assert n0.min() > 0 and n1.min() > 0
+    mp.spawn(_worker_fused, args=(world, _free_port(), periodic, out), nprocs=world, join=True)
+    for r in range(world):
+        assert np.load(out % r).min() > 0
 
 
 class NumpyPaddedHaloOps(NumpyDirectHaloOps):
