@@ -64,7 +64,7 @@ class AnyArray(object):
         def __contains__(self,k): return True
         def __getitem__(self,k): return np.zeros(2)
     properties=_P(); constants={}; stride={}
-seen=set(); ok=[]; bad=collections.OrderedDict(); cons=[]
+seen=set(); ok=[]; bad=collections.OrderedDict(); cons=[]; builds=[]
 for mod_ in mods:
     for name,cls in inspect.getmembers(mod_, inspect.isclass):
         if not issubclass(cls,Equation) or cls is Equation or cls in seen or cls.__module__!=mod_.__name__: continue
@@ -96,10 +96,20 @@ for mod_ in mods:
             cons.append((cls.__module__+'.'+name, str(e)[:60])); continue
         try:
             fam_ = GeneratedFamily('fluid',[eq],{'fluid':AnyArray()},2,'c'); ok.append(cls.__module__+'.'+name)
-            if os.environ.get('CENSUS_BUILD'):
+            if os.environ.get('CENSUS_BUILD') == 'f32':       # the float build of every family (codegen.source_f32): compiled below
+                builds.append((cls.__module__+'.'+name, fam_))
+            elif os.environ.get('CENSUS_BUILD'):
                 try: fam_.build()
                 except Exception as e: bad[cls.__module__+'.'+name] = 'BUILD ' + str(e)[-400:]
         except CodegenError as e: bad[cls.__module__+'.'+name]=str(e)[:160]
         except Exception as e: bad[cls.__module__+'.'+name]='EXC '+type(e).__name__+': '+str(e)[:120]
+if builds:
+    from concurrent.futures import ThreadPoolExecutor
+    def _b(item):
+        try: item[1].flavour_f32().build(); return None
+        except Exception as e: return (item[0], 'BUILD f32 ' + str(e)[-600:])
+    with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as pool:
+        for r in pool.map(_b, builds):
+            if r: bad[r[0]] = r[1]
 print(json.dumps({'ok': ok, 'bad': bad, 'construct_failed': [c[0] for c in cons],
                   'import_failed': [f[0] for f in impfail]}))
