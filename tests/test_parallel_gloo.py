@@ -515,7 +515,7 @@ def _worker_padded(rank, world, port, periodic, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 4])
 @pytest.mark.parametrize('periodic', [False, True])
 def test_padded_protocol_equals_capacity_protocol(tmp_path, periodic, world):
     out = str(tmp_path / 'padded_%d.npy')
