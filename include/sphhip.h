@@ -185,6 +185,14 @@ int sph_array_push(sph_ctx *ctx, int array_id, int prop, const double *host, siz
 int sph_array_pull(sph_ctx *ctx, int array_id, int prop, double *host, size_t offset, size_t n);
 /* Raw device pointer of a property (device-resident pipelines, RCCL halos). */
 int sph_array_device_ptr(sph_ctx *ctx, int array_id, int prop, void **dptr);
+/* n rows of one property set to `value`, starting at particle `offset` (the ghost
+ * rows of a promised-uniform h / m that did not travel: the reference sends every
+ * property of a remote particle, parallel_manager.pyx:159-210).               */
+int sph_array_fill(sph_ctx *ctx, int array_id, int prop, double value, size_t offset, size_t n);
+/* The caller wrote `prop` through a raw pointer, or no longer trusts what the
+ * library knows of it: for h / m the next sph_nnps_update looks at the values
+ * again, for x / y / z it does not bin on the previous update's bounds.        */
+int sph_array_mark_written(sph_ctx *ctx, int array_id, int prop);
 
 /* ---------------------------------------------------------------------- */
 /* neighbour search                                                         */
@@ -421,6 +429,17 @@ int sph_halo_append(sph_ctx *ctx, int array_id, int nprops, const int *props, co
 int sph_halo_select_pack(sph_ctx *ctx, int array_id, int axis, double lo_cut, double hi_cut, size_t upto,
                          int nprops, const int *props, const double *shift2, const size_t *cap2,
                          void *const *dst2);
+/* ... when every particle of the array is PROMISED to have ONE smoothing length
+ * h_promise and / or ONE mass m_promise (NaN: no promise; established by the
+ * caller over all ranks): such a property need not be among `props` -- the
+ * receiver writes the promised value into its ghost rows (sph_halo_append_padded,
+ * sph_array_fill) and a WCSPH ghost travels as 7 doubles instead of the 9 of
+ * ParallelManager.remote_exchange_data (parallel_manager.pyx:159-210) -- and every
+ * SELECTED row is checked against the promise here, on the sender's side: a row
+ * that breaks it adds 0.5 to the header of its message (|header| = count + 0.5). */
+int sph_halo_select_pack_promised(sph_ctx *ctx, int array_id, int axis, double lo_cut, double hi_cut, size_t upto,
+                                  int nprops, const int *props, const double *shift2, const size_t *cap2,
+                                  void *const *dst2, double h_promise, double m_promise);
 /* n <= 64 doubles, one from each DEVICE address, in one round trip (all copies
  * on the context's stream, one synchronisation): the headers of the ghost
  * messages, from which the host learns the counts.                          */
@@ -434,8 +453,10 @@ int sph_read_values(sph_ctx *ctx, int n, const void *const *dev_ptrs, double *ou
  * size anything.  Real coordinates must stay below 1e17 in magnitude.
  * h_promise / m_promise (NaN: none): every ghost is promised to carry this smoothing length / mass (the ONE value of the
  * array on every rank, established collectively by the caller); then the neighbour update keeps what it knows of h and m.
+ * A promised property that is NOT among `props` did not travel: the promised value is written into all `cap` rows.
  * flag_word: a DEVICE uint32 the kernel ORs into -- bit 0: the message was incomplete (negative header), bit 1: a ghost
- * broke a promise; the caller reads it when convenient (pysph_amd/parallel.py: one exchange later, with the counts).
+ * broke a promise; the caller reads it when convenient (pysph_amd/parallel.py: with the counts, once the evaluation that
+ * uses the ghosts is queued -- verify_halos -- and repeats an incomplete face the counted way).
  * Replaces the recv side of ParallelManager.remote_exchange_data (parallel_manager.pyx:159-210), whose counts travel over
  * MPI to the host first. */
 int sph_halo_append_padded(sph_ctx *ctx, int array_id, int nprops, const int *props, const void *src_device, size_t cap,

@@ -236,6 +236,9 @@ int sph_array_push(sph_ctx *c, int id, int prop, const double *host, size_t offs
     // only after a sync; keep the call synchronous so Python may reuse `host`.
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (prop == SPH_X || prop == SPH_Y || prop == SPH_Z || prop == SPH_H) c->nnps_valid = false;
+    // positions from the host may lie anywhere (a restart, a translated body): the next neighbour update does not bin on
+    // the grid of the previous update's bounds but looks at the particles first
+    if (prop == SPH_X || prop == SPH_Y || prop == SPH_Z) c->lag.valid = false;
     if (prop == SPH_M) A.m_mixed_ghosts = false;
     sph_mark_written(A, prop); // h / m: until the next sph_nnps_update has looked at them
     if (prop >= SPH_R00 && prop <= SPH_R22) A.tflag_valid = false;
@@ -254,6 +257,45 @@ int sph_array_pull(sph_ctx *c, int id, int prop, double *host, size_t offset, si
     if (n == 0) return SPH_OK;
     HIP_TRY(hipMemcpyAsync(host, A.prop[prop] + offset, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+// n rows of one property set to `value`, from row `offset` on (ghost rows whose promised-uniform h / m did not travel,
+// pysph_amd/parallel.py).  A value the neighbour update already knows as the array's ONE h / m leaves that knowledge valid.
+__global__ __launch_bounds__(256) static void k_fill_f64(double *__restrict__ p, size_t n, double v)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+int sph_array_fill(sph_ctx *c, int id, int prop, double value, size_t offset, size_t n)
+{
+    SPH_TRY(sph_array_ensure_prop(c, id, prop));
+    DevArray &A = c->arr[id];
+    if (offset + n > A.n) { sph_set_error("sph_array_fill: %zu+%zu > n=%zu", offset, n, A.n); return SPH_ERR_ARG; }
+    if (n == 0) return SPH_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, A.prop[prop] + offset, n, value);
+    if (prop == SPH_X || prop == SPH_Y || prop == SPH_Z || prop == SPH_H) c->nnps_valid = false;
+    const bool same_h = prop == SPH_H && A.h_seen && !A.h_dirty && A.h_lo == value && A.h_hi == value;
+    const bool same_m = prop == SPH_M && A.m_seen && !A.m_dirty && A.m_lo == value && A.m_hi == value;
+    if (!same_h && !same_m) sph_mark_written(A, prop);
+    if (prop >= SPH_R00 && prop <= SPH_R22) A.tflag_valid = false;
+    return SPH_OK;
+}
+
+// "property `prop` of the array was written behind the library's back" / "do not trust what you know of it": for h and m
+// the next neighbour update looks at the values again (one update with a device->host round trip)
+int sph_array_mark_written(sph_ctx *c, int id, int prop)
+{
+    SPH_TRY(check_array(c, id, "sph_array_mark_written"));
+    if (prop < 0 || prop >= SPH_PROP_COUNT) { sph_set_error("sph_array_mark_written: bad property %d", prop); return SPH_ERR_ARG; }
+    DevArray &A = c->arr[id];
+    sph_mark_written(A, prop);
+    if (prop == SPH_X || prop == SPH_Y || prop == SPH_Z || prop == SPH_H) c->nnps_valid = false;
+    if (prop == SPH_X || prop == SPH_Y || prop == SPH_Z) c->lag.valid = false;
+    if (prop == SPH_M) A.m_mixed_ghosts = false;
+    if (prop >= SPH_R00 && prop <= SPH_R22) A.tflag_valid = false;
     return SPH_OK;
 }
 

@@ -165,6 +165,14 @@ struct DirectPack {
     size_t cap[2];
     double *dst[2];
 };
+// promised-uniform h / m that do NOT travel (sph_halo_select_pack_promised): every selected row is checked against the
+// promise on the SENDER's side, in pass 1; a chunk with a row that breaks it sets bit 31 (low face) / bit 63 (high
+// face) of its counter word, the workgroup that writes the headers adds 0.5 to the header of such a face
+struct PromiseCheck {
+    const double *h, *m; // null: no promise for that property
+    double h_promise, m_promise;
+};
+#define HALO_CNT_MASK 0x7fffffffull
 
 // pass 1: how many particles of each CHUNK (q256 x 256 consecutive particles, one workgroup) go to the low / high face
 // (lo | hi << 32).  The chunk grows with n so that there are at most HALO_MAX_CHUNKS of them: pass 2 then finds a
@@ -186,22 +194,33 @@ template <bool BOX> __device__ __forceinline__ void face_rule(double v, double p
 
 template <bool BOX>
 __global__ __launch_bounds__(256) void k_halo_chunk_counts(const double *__restrict__ coord, size_t n, double p0, double p1, double p2,
-                                                           int q256, unsigned long long *__restrict__ blk)
+                                                           int q256, unsigned long long *__restrict__ blk, PromiseCheck pc = PromiseCheck{})
 {
     const size_t first = (size_t)blockIdx.x * 256 * q256;
     uint32_t cl = 0, ch = 0; // (wave-uniform)
+    bool bl = false, bh = false; // a selected row of this wavefront breaks the promise (wave-uniform)
     for (int q = 0; q < q256; q++) {
         const size_t i = first + (size_t)q * 256 + threadIdx.x;
         bool lo = false, hi = false;
         if (i < n) face_rule<BOX>(coord[i], p0, p1, p2, lo, hi);
         cl += (uint32_t)__popcll(__ballot(lo));
         ch += (uint32_t)__popcll(__ballot(hi));
+        if (pc.h || pc.m) {
+            bool bad = false;
+            if (lo || hi) bad = (pc.h && pc.h[i] != pc.h_promise) || (pc.m && pc.m[i] != pc.m_promise);
+            bl = bl || __any(bad && lo);
+            bh = bh || __any(bad && hi);
+        }
     }
     __shared__ uint32_t sl[4], sh[4];
-    if ((threadIdx.x & 63) == 0) { sl[threadIdx.x >> 6] = cl; sh[threadIdx.x >> 6] = ch; }
+    if ((threadIdx.x & 63) == 0) { sl[threadIdx.x >> 6] = cl | (bl ? 0x80000000u : 0u); sh[threadIdx.x >> 6] = ch | (bh ? 0x80000000u : 0u); }
     __syncthreads();
-    if (threadIdx.x == 0)
-        blk[blockIdx.x] = (unsigned long long)(sl[0] + sl[1] + sl[2] + sl[3]) | ((unsigned long long)(sh[0] + sh[1] + sh[2] + sh[3]) << 32);
+    if (threadIdx.x == 0) {
+        const uint32_t tl = (sl[0] & 0x7fffffffu) + (sl[1] & 0x7fffffffu) + (sl[2] & 0x7fffffffu) + (sl[3] & 0x7fffffffu);
+        const uint32_t th = (sh[0] & 0x7fffffffu) + (sh[1] & 0x7fffffffu) + (sh[2] & 0x7fffffffu) + (sh[3] & 0x7fffffffu);
+        const uint32_t xl = (sl[0] | sl[1] | sl[2] | sl[3]) & 0x80000000u, xh = (sh[0] | sh[1] | sh[2] | sh[3]) & 0x80000000u;
+        blk[blockIdx.x] = (unsigned long long)(tl | xl) | ((unsigned long long)(th | xh) << 32);
+    }
 }
 
 // pass 2: every workgroup sums the counters of the chunks before its own, re-derives its flags, ranks its particles
@@ -214,14 +233,25 @@ __global__ __launch_bounds__(256) void k_halo_pack_direct(DirectPack a, const do
     __shared__ uint32_t sbase[2][4];
     __shared__ uint32_t wcnt[2][4];
     {
-        uint32_t bl = 0, bh = 0;
-        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256) { const unsigned long long v = blk[b]; bl += (uint32_t)v; bh += (uint32_t)(v >> 32); }
-        for (int o = 32; o > 0; o >>= 1) { bl += __shfl_xor(bl, o, 64); bh += __shfl_xor(bh, o, 64); }
-        if (lane == 0) { sbase[0][wv] = bl; sbase[1][wv] = bh; }
+        // (bit 31 of each half: "a selected row of the chunk breaks the h / m promise" -- ORed, not summed; the workgroup of
+        // the last chunk, which writes the headers, looks at its own chunk's word as well)
+        uint32_t bl = 0, bh = 0, xl = 0, xh = 0;
+        const uint32_t upto_b = blockIdx.x + (blockIdx.x == gridDim.x - 1 ? 1u : 0u);
+        for (uint32_t b = threadIdx.x; b < upto_b; b += 256) {
+            const unsigned long long v = blk[b];
+            if (b < blockIdx.x) { bl += (uint32_t)(v & HALO_CNT_MASK); bh += (uint32_t)((v >> 32) & HALO_CNT_MASK); }
+            xl |= (uint32_t)(v >> 31) & 1u; xh |= (uint32_t)(v >> 63) & 1u;
+        }
+        for (int o = 32; o > 0; o >>= 1) { bl += __shfl_xor(bl, o, 64); bh += __shfl_xor(bh, o, 64); xl |= __shfl_xor(xl, o, 64); xh |= __shfl_xor(xh, o, 64); }
+        if (lane == 0) { sbase[0][wv] = bl | (xl << 31); sbase[1][wv] = bh | (xh << 31); }
     }
     __syncthreads();
     size_t run[2]; // list position of this chunk's next selected particle, per face (uniform over the workgroup)
-    for (int s = 0; s < 2; s++) run[s] = (size_t)sbase[s][0] + sbase[s][1] + sbase[s][2] + sbase[s][3];
+    bool broken[2];
+    for (int s = 0; s < 2; s++) {
+        run[s] = (size_t)(sbase[s][0] & 0x7fffffffu) + (sbase[s][1] & 0x7fffffffu) + (sbase[s][2] & 0x7fffffffu) + (sbase[s][3] & 0x7fffffffu);
+        broken[s] = ((sbase[s][0] | sbase[s][1] | sbase[s][2] | sbase[s][3]) >> 31) != 0u;
+    }
     const size_t first = (size_t)blockIdx.x * 256 * q256;
     for (int q = 0; q < q256; q++) {
         const size_t i = first + (size_t)q * 256 + threadIdx.x;
@@ -255,11 +285,26 @@ __global__ __launch_bounds__(256) void k_halo_pack_direct(DirectPack a, const do
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
         for (int s = 0; s < 2; s++)
-            if (a.dst[s]) a.dst[s][(size_t)a.nprops * a.cap[s]] = run[s] <= a.cap[s] ? (double)run[s] : -(double)run[s];
+            if (a.dst[s]) {
+                const double cnt = (double)run[s] + (broken[s] ? 0.5 : 0.0); // + 0.5: a selected row breaks the h / m promise
+                a.dst[s][(size_t)a.nprops * a.cap[s]] = run[s] <= a.cap[s] ? cnt : -cnt;
+            }
 }
 
 extern "C" int sph_halo_select_pack(sph_ctx *c, int id, int axis, double lo_cut, double hi_cut, size_t upto, int nprops,
                                     const int *props, const double *shift2, const size_t *cap2, void *const *dst2)
+{
+    const double nan = __builtin_nan("");
+    return sph_halo_select_pack_promised(c, id, axis, lo_cut, hi_cut, upto, nprops, props, shift2, cap2, dst2, nan, nan);
+}
+
+// ... with the promise check of the round-trip-free exchange on the SENDER's side: h_promise / m_promise (NaN: none) are
+// the ONE smoothing length / mass every particle of the array is promised to have -- then h / m need not be among the
+// packed properties (the receiver writes the promised value into its ghost rows, sph_halo_append_padded), and every
+// selected row is compared with the promise here: a row that breaks it adds 0.5 to its message's header.
+extern "C" int sph_halo_select_pack_promised(sph_ctx *c, int id, int axis, double lo_cut, double hi_cut, size_t upto, int nprops,
+                                             const int *props, const double *shift2, const size_t *cap2, void *const *dst2,
+                                             double h_promise, double m_promise)
 {
     if (!c || id < 0 || id >= SPH_MAX_ARRAYS || axis < 0 || axis > 2 || nprops < 1 || nprops > 32 || !props || !shift2 ||
         !cap2 || !dst2) {
@@ -298,7 +343,15 @@ extern "C" int sph_halo_select_pack(sph_ctx *c, int id, int axis, double lo_cut,
     const unsigned nb = div_up(n, (size_t)256 * q256);
     SPH_TRY(H.flag[1].reserve(((size_t)nb + 1) * 8));
     unsigned long long *blk = H.flag[1].as<unsigned long long>();
-    hipLaunchKernelGGL(k_halo_chunk_counts<false>, dim3(nb), dim3(256), 0, c->stream, coord, n, lo_cut, hi_cut, 0.0, q256, blk);
+    PromiseCheck pc;
+    pc.h = h_promise == h_promise ? A.prop[SPH_H] : nullptr;
+    pc.m = m_promise == m_promise ? A.prop[SPH_M] : nullptr;
+    pc.h_promise = h_promise; pc.m_promise = m_promise;
+    if ((h_promise == h_promise && !pc.h) || (m_promise == m_promise && !pc.m)) {
+        sph_set_error("sph_halo_select_pack_promised: array %d has no device h / m to check the promise against", id);
+        return SPH_ERR_MISSING_PROP;
+    }
+    hipLaunchKernelGGL(k_halo_chunk_counts<false>, dim3(nb), dim3(256), 0, c->stream, coord, n, lo_cut, hi_cut, 0.0, q256, blk, pc);
     hipLaunchKernelGGL(k_halo_pack_direct, dim3(nb), dim3(256), 0, c->stream, a, coord, n, lo_cut, hi_cut, q256, blk);
     return SPH_OK;
 }
@@ -408,11 +461,18 @@ extern "C" int sph_halo_append_strided(sph_ctx *c, int id, int nprops, const int
 // from the promised one.
 __global__ __launch_bounds__(256) void k_halo_append_padded(PropList L, const double *__restrict__ src, size_t n0, size_t cap,
                                                             int nprops, int k_h, int k_m, double h_promise, double m_promise,
-                                                            uint32_t *__restrict__ flag)
+                                                            uint32_t *__restrict__ flag, double *__restrict__ fill_h, double *__restrict__ fill_m)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cap) return;
     const int k = blockIdx.y;
+    if (k >= nprops) {
+        // a promised property that did not travel: every row (ghost or padding) gets the promised value -- the array's
+        // range stays the ONE value whatever looks at it
+        if (k == nprops && fill_h) fill_h[n0 + i] = h_promise;
+        if (k == nprops + 1 && fill_m) fill_m[n0 + i] = m_promise;
+        return;
+    }
     const double hdr = src[(size_t)nprops * cap];
     const size_t count = (size_t)fmin(fabs(hdr), (double)cap);
     if (i == 0 && k == 0 && hdr < 0.0) atomicOr(flag, 1u);
@@ -443,18 +503,31 @@ extern "C" int sph_halo_append_padded(sph_ctx *c, int id, int nprops, const int 
     // what the neighbour update knows of h and m stays valid when every ghost is promised to carry the array's ONE value
     // (checked on the device, bit 1 of the flag word): the round-trip-free update goes on
     DevArray &A0 = c->arr[id];
-    const bool keep_h = k_h >= 0 && h_promise == h_promise && !A0.raw_hm && !A0.h_dirty && A0.h_seen && A0.h_lo == h_promise && A0.h_hi == h_promise;
-    const bool keep_m = k_m >= 0 && m_promise == m_promise && !A0.raw_hm && !A0.m_dirty && A0.m_seen && A0.m_lo == m_promise && A0.m_hi == m_promise;
-    const bool mk = A0.m_known;
+    // (a promised property that is not in the message did not travel: it is written into the rows below)
+    // An array that holds NOTHING when the first message arrives (a rank without obstacle particles, a slab the fluid has
+    // not reached) has an empty range: whatever is promised IS its range from here on -- without this such an array was
+    // "mass unknown" for ever (its padding rows are not particles), every neighbour update of the rank looked at h and m
+    // (a round trip) and its dam-break evaluation left the one-launch merged path.
+    const bool empty0 = A0.n == 0;
+    const bool keep_h = h_promise == h_promise && !A0.raw_hm && (empty0 || (!A0.h_dirty && A0.h_seen && A0.h_lo == h_promise && A0.h_hi == h_promise));
+    const bool keep_m = m_promise == m_promise && !A0.raw_hm && (empty0 || (!A0.m_dirty && A0.m_seen && A0.m_lo == m_promise && A0.m_hi == m_promise));
+    const bool fill_h = k_h < 0 && h_promise == h_promise, fill_m = k_m < 0 && m_promise == m_promise;
+    if (fill_h) SPH_TRY(sph_array_ensure_prop(c, id, SPH_H));
+    if (fill_m) SPH_TRY(sph_array_ensure_prop(c, id, SPH_M));
+    const bool mk = A0.m_known || empty0;
     SPH_TRY(sph_array_resize(c, id, n0 + cap, A0.n_real));
     DevArray &A = c->arr[id];
-    if (keep_h) A.h_dirty = false;
-    if (keep_m) { A.m_dirty = false; A.m_known = mk; }
+    if (keep_h) { A.h_dirty = false; if (empty0) { A.h_seen = true; A.h_lo = A.h_hi = h_promise; } }
+    if (keep_m) {
+        A.m_dirty = false; A.m_known = mk;
+        if (empty0) { A.m_seen = true; A.m_lo = A.m_hi = m_promise; A.m_value = m_promise; }
+    }
     PropList L;
     for (int k = 0; k < nprops; k++) { L.p[k] = A.prop[props[k]]; L.what[k] = props[k] == SPH_X || props[k] == SPH_Y || props[k] == SPH_Z; }
     A.has_padding = true;
-    hipLaunchKernelGGL(k_halo_append_padded, dim3(div_up(cap, 256), nprops), dim3(256), 0, c->stream, L, (const double *)src, n0, cap,
-                       nprops, k_h, k_m, h_promise, m_promise, (uint32_t *)flag_word);
+    hipLaunchKernelGGL(k_halo_append_padded, dim3(div_up(cap, 256), nprops + 2), dim3(256), 0, c->stream, L, (const double *)src, n0, cap,
+                       nprops, k_h, k_m, h_promise, m_promise, (uint32_t *)flag_word, fill_h ? A.prop[SPH_H] : nullptr,
+                       fill_m ? A.prop[SPH_M] : nullptr);
     c->nnps_valid = false;
     return SPH_OK;
 }

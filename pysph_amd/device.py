@@ -104,6 +104,11 @@ SIGNATURES = {
     'sph_halo_select_pack': (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_size_t,
                                        C.c_int, C.POINTER(C.c_int), _PD, C.POINTER(C.c_size_t),
                                        C.POINTER(_P)]),
+    'sph_halo_select_pack_promised': (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_size_t,
+                                                C.c_int, C.POINTER(C.c_int), _PD, C.POINTER(C.c_size_t),
+                                                C.POINTER(_P), C.c_double, C.c_double]),
+    'sph_array_fill': (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_size_t, C.c_size_t]),
+    'sph_array_mark_written': (C.c_int, [_P, C.c_int, C.c_int]),
     'sph_nnps_set_h_range': (C.c_int, [_P, C.c_double, C.c_double]),
     'sph_nnps_set_extend': (C.c_int, [_P, C.c_double, C.c_double, C.c_double]),
     'sph_nnps_update_ghosts': (C.c_int, [_P, C.c_int, C.c_double, C.c_double]),

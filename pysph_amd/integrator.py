@@ -107,12 +107,23 @@ class Integrator(object):
 
     def compute_accelerations(self, index=0, update_nnps=True):
         """integrator.py:274-286."""
+        pm = self.parallel_manager
         if update_nnps:
-            if self.parallel_manager:
-                self.parallel_manager.update()
+            if pm:
+                pm.update()
             self.nnps.update()
         c = self.c_integrator
         self.acceleration_evals[index].compute(c.t, c.dt)
+        # The reference counts its ghosts first and never evaluates on incomplete ones
+        # (parallel_manager.pyx:1085-1157).  The round-trip-free exchange appends fixed-capacity
+        # messages and learns the counts afterwards: they are read HERE, with the evaluation queued and
+        # nothing having consumed it yet -- a face that had outgrown its message has been repeated the
+        # counted way by verify(), and the update + evaluation (which only read the particles' state and
+        # overwrite their own results) run again.
+        verify = getattr(pm, 'verify', None) if (pm and update_nnps) else None
+        while verify is not None and not verify():
+            self.nnps.update()
+            self.acceleration_evals[index].compute(c.t, c.dt)
 
     def initial_acceleration(self, t, dt):
         self.acceleration_evals[0].compute(t, dt)

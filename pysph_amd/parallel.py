@@ -133,9 +133,12 @@ class DeviceHaloOps(object):
     def append(self, buf, count, stride=None):
         """`stride`: rows of a fixed-capacity message (property k of row i at
         buf[k * stride + i])"""
+        n0 = self.gpu.get_number_of_particles()
         dev._check(self.lib.sph_halo_append_strided(
             self.ctx._h, self.id, self.nprops, self.props,
             C.c_void_p(buf.data_ptr()), count, count if stride is None else stride))
+        for p, v in self.__dict__.get('fill', ()):      # promised h / m did not travel
+            dev._check(self.lib.sph_array_fill(self.ctx._h, self.id, p, v, n0, count))
 
     def message_buffer(self, key, size):
         """the fixed-capacity message `key` (face, direction): one device buffer
@@ -177,41 +180,76 @@ class DeviceHaloOps(object):
         return self._hdr_pin[:n].tolist()
 
     # -- the exchange without a device->host round trip ('padded' protocol) ----
-    def append_padded(self, buf, cap, h_promise, m_promise):
+    def append_padded(self, buf, cap, h_promise, m_promise, flags=None, slot=0):
         """all `cap` rows of a fixed-capacity message behind the particles: the
         first |header| are the ghosts, the rest padding rows parked at 1e18 (inert on
-        the whole path); the host learns the count an exchange later
-        (sph_halo_append_padded)"""
+        the whole path); the host learns the count after the evaluation was queued
+        (sph_halo_append_padded).  `flags` / `slot`: the flag words of the exchange
+        (ONE tensor for all its arrays, `flag_words` of the first) and this array's
+        word in it.  A promised h / m that is not among the message's properties is
+        written into the rows by the library (it did not travel)."""
+        flags = self.flag_words(slot + 1) if flags is None else flags
         dev._check(self.lib.sph_halo_append_padded(
             self.ctx._h, self.id, self.nprops, self.props, C.c_void_p(buf.data_ptr()), int(cap),
-            float(h_promise), float(m_promise), C.c_void_p(self.flag_word().data_ptr())))
+            float(h_promise), float(m_promise), C.c_void_p(flags.data_ptr() + 4 * int(slot))))
 
-    def flag_word(self):
-        """device word sph_halo_append_padded ORs into (bit 0: incomplete message, bit 1: broken promise)"""
+    def flag_words(self, n=1):
+        """device words sph_halo_append_padded ORs into, one per array of the exchange
+        (bit 0: incomplete message, bit 1: a ghost broke the promise of its array)"""
         t = self.__dict__.get('_flag')
-        if t is None:
-            t = self._flag = self.torch.zeros(2, dtype=self.torch.int32, device=self.device)
+        if t is None or t.numel() < n:
+            t = self._flag = self.torch.zeros(max(n, 8), dtype=self.torch.int32, device=self.device)
         return t
 
-    def queue_headers(self, tensors):
-        """the last element of each message and the flag word on their way to pinned
-        memory, behind an event nobody waits for now: `collect_headers` an exchange later"""
+    def queue_headers(self, tensors, nflags=1):
+        """the header of each message and the `nflags` flag words on their way to pinned
+        memory behind an event: `collect_headers` waits for that event only (it was recorded
+        right behind the transfers, so a host that has queued the evaluation since does not
+        drain the stream)"""
         torch = self.torch
         n = len(tensors)
         pin = self.__dict__.get('_hdr_pin2')
-        if pin is None or pin.numel() < n + 1:
-            pin = self._hdr_pin2 = torch.empty(max(n + 1, 64), dtype=torch.float64).pin_memory()
-        vals = torch.stack([t[-1] for t in tensors] + [self.flag_word()[0].to(torch.float64)])
-        pin[:n + 1].copy_(vals, non_blocking=True)
+        if pin is None or pin.numel() < n + nflags:
+            pin = self._hdr_pin2 = torch.empty(max(n + nflags, 64), dtype=torch.float64).pin_memory()
+        vals = torch.cat([torch.stack([t[-1] for t in tensors]),
+                          self.flag_words(nflags)[:nflags].to(torch.float64)])
+        pin[:n + nflags].copy_(vals, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
-        return (ev, n)
+        return (ev, n, nflags)
 
     def collect_headers(self, handle):
-        ev, n = handle
+        ev, n, nflags = handle
         ev.synchronize()
-        vals = self._hdr_pin2[:n + 1].tolist()
-        return vals[:n], int(vals[n])
+        vals = self._hdr_pin2[:n + nflags].tolist()
+        return vals[:n], [int(v) for v in vals[n:]]
+
+    def clear_flags(self):
+        if self.__dict__.get('_flag') is not None:
+            self._flag.zero_()
+
+    def mark_hm_written(self):
+        """what the neighbour update knows of this array's h and m is void (a ghost
+        arrived with other values than promised): its next update looks again"""
+        for p in ('h', 'm'):
+            dev._check(self.lib.sph_array_mark_written(self.ctx._h, self.id, dev.prop_id(p)))
+
+    # -- promised-uniform h / m do not travel ------------------------------------
+    def set_promise(self, h_promise, m_promise, send=True):
+        """the properties of this array's messages from now on: without h / m where the
+        ranks hold ONE value of it (`send` False keeps them in the messages: the receiver
+        then checks every ghost against the promise instead of the sender every row it
+        packs).  Rows appended through `append` get the promised values written in."""
+        full = self.__dict__.setdefault('_full_props', list(self.props))
+        keep = [p for p in full if send or not (
+            (p == dev.prop_id('h') and h_promise == h_promise) or
+            (p == dev.prop_id('m') and m_promise == m_promise))]
+        self.nprops = len(keep)
+        self.props = (C.c_int * self.nprops)(*keep)
+        self._messages = {}
+        self.fill = [(dev.prop_id('h'), float(h_promise)), (dev.prop_id('m'), float(m_promise))]
+        self.fill = [(p, v) for p, v in self.fill if v == v and p in full and p not in keep]
+        self.promise = (float(h_promise), float(m_promise))
 
     def hm_range(self):
         """(hmin, hmax, mmin, mmax) of the real particles (set-up only: one round trip each)"""
@@ -229,14 +267,19 @@ class DeviceHaloOps(object):
     def select_pack(self, lo_cut, hi_cut, shifts, caps, bufs):
         """Both faces selected AND packed on the device, no host round trip:
         bufs[side] (or None) is a message of caps[side] * nprops + 1 doubles,
-        rows laid out [nprops][cap], the row count (negative: more than cap) in
-        its last element (sph_halo_select_pack)."""
+        rows laid out [nprops][cap], the row count (negative: more than cap; + 0.5: a
+        packed row carries another h / m than promised) in its last element
+        (sph_halo_select_pack_promised)."""
         sh = (C.c_double * 2)(float(shifts[0]), float(shifts[1]))
         cp = (C.c_size_t * 2)(int(caps[0]), int(caps[1]))
         ds = (C.c_void_p * 2)(*[b.data_ptr() if b is not None else None for b in bufs])
-        dev._check(self.lib.sph_halo_select_pack(
+        nan = float('nan')
+        hp, mp = self.__dict__.get('promise', (nan, nan))
+        fill = dict(self.__dict__.get('fill', ()))
+        dev._check(self.lib.sph_halo_select_pack_promised(
             self.ctx._h, self.id, self.axis, float(lo_cut), float(hi_cut), 0,
-            self.nprops, self.props, sh, cp, ds))
+            self.nprops, self.props, sh, cp, ds,
+            hp if dev.prop_id('h') in fill else nan, mp if dev.prop_id('m') in fill else nan))
 
     # -- migration of owned particles (every device property travels) -------
     def all_props(self):
@@ -287,7 +330,7 @@ class SlabHalo(object):
 
     def __init__(self, pa, ctx, rank, world, axis, width, lo, hi,
                  props=WCSPH_HALO_PROPS, periodic=False, period=0.0,
-                 ops=None, dist=None, protocol=None):
+                 ops=None, dist=None, protocol=None, promise=True, send_promised=False):
         if dist is None:
             import torch.distributed as dist
         self.dist = dist
@@ -311,9 +354,16 @@ class SlabHalo(object):
         self.handshakes = 0               # exchanges that needed the counts round
         # 'padded' protocol: the promises every ghost keeps (NaN: none), what the last padded exchange left to collect
         self.h_promise = self.m_promise = float('nan')
-        self.promised = False
+        self.promise = promise            # False: no promises are made (h and m travel, every neighbour update looks at them)
+        self.send_promised = send_promised  # True: promised h / m travel all the same (the receiver checks them)
+        self.promised = not promise       # the promises stand (or none are wanted)
+        self.padded_ok = None             # can every rank run the round-trip-free exchange?  (agreed collectively with the
+                                          # promises; without promises each rank decides for itself: the two protocols send
+                                          # the same messages)
         self.padded_pending = None
         self.padded_exchanges = 0
+        self.repaired_exchanges = 0       # exchanges `verify_halos` found incomplete and repeated the counted way
+        self.recv_rows = {}
 
     def neighbours(self):
         """[(side, peer rank, coordinate shift applied to what we SEND)]"""
@@ -405,12 +455,49 @@ def _capacity(count):
     return ((count + count // 4 + 4096 + 1023) // 1024) * 1024
 
 
-def _next_capacity(cap, count):
+def _capacity_tight(count):
+    """... once the count has been steady: a sixteenth of headroom + 1024 rows (a face
+    that outgrows it anyway is repeated by the counted exchange: `verify_halos`)"""
+    return ((count + count // 16 + 1024 + 1023) // 1024) * 1024
+
+
+STEADY_EXCHANGES = 8     # exchanges a face's count must stay within 1/64 of itself before its messages shrink
+
+
+def _next_capacity(cap, count, hist=None):
     """the SAME rule on both ends of a face (sender: the count it sent;
-    receiver: the count in the header), so the two stay in step without talking"""
+    receiver: the count in the header), so the two stay in step without talking.
+    `hist` (a list [previous count, steady exchanges, tight?], updated in place;
+    both ends keep one per face and direction and feed it the same counts) lets
+    the capacity ADAPT: after STEADY_EXCHANGES exchanges whose count moved by less
+    than 1/64 the message shrinks to `_capacity_tight`; a count that then comes
+    within 1/32 + 512 rows of that capacity returns it to the generous rule."""
+    tight = False
+    if hist is not None:
+        prev, steady, tight = hist
+        steady = steady + 1 if (prev is not None and abs(count - prev) <= max(prev // 64, 16)) else 0
+        if tight and (count > cap or count + count // 32 + 512 > cap):
+            tight, steady = False, 0
+        elif not tight and steady >= STEADY_EXCHANGES and cap is not None and count <= cap:
+            tight = True
+        hist[:] = [count, steady, tight]
+    if tight:
+        want = _capacity_tight(count)
+        # (never grow into the tight size: a tight face only ever shrinks or stays)
+        return want if cap is None or want < cap or count > cap else cap
     if cap is None or count > cap or count + count // 8 + 1024 > cap or 4 * count + 16384 < cap:
         return _capacity(count)
     return cap
+
+
+def _track_capacities(h, s, sent, received):
+    """capacities of face `s` of halo `h` after an exchange that sent / received
+    these many rows (None: that direction did not run)"""
+    hist = h.__dict__.setdefault('cap_hist', {})
+    if sent is not None:
+        h.cap_send[s] = _next_capacity(h.cap_send.get(s), sent, hist.setdefault(('send', s), [None, 0, False]))
+    if received is not None:
+        h.cap_recv[s] = _next_capacity(h.cap_recv.get(s), received, hist.setdefault(('recv', s), [None, 0, False]))
 
 
 def exchange_halos(hs, drop=True):
@@ -462,9 +549,13 @@ def _exchange_steps(hs, drop, overlap):
     dist, ops0, world, na = h0.dist, h0.ops, h0.world, len(hs)
     nbrs = h0.neighbours()
     sides = [s for s, _, _ in nbrs]
+    if len(nbrs) == 2 and world > 2 and h0.hi - h0.lo < h0.width:
+        # the ghost layer of a neighbour would have to reach THROUGH this slab into the next one: ghosts come from the
+        # two adjacent slabs only (the reference's Zoltan exchange has no such limit, parallel_manager.pyx:1159-1243)
+        raise RuntimeError('slab %d is %.6g wide, thinner than the ghost layer (%.6g): use fewer ranks or re-balance'
+                           % (h0.rank, h0.hi - h0.lo, h0.width))
     if nbrs and drop and not overlap and h0.protocol == 'padded' and all(
-            hasattr(h.ops, 'append_padded') and hasattr(h.ops, 'select_pack') and h.promised and
-            getattr(h.ops, '_shares_torch_stream', lambda: True)() and
+            h.promised and _padded_eligible(h) and
             all(h.cap_send.get(s) is not None and h.cap_recv.get(s) is not None for s in sides) for h in hs):
         _exchange_padded(hs, nbrs)
         return
@@ -474,7 +565,7 @@ def _exchange_steps(hs, drop, overlap):
             h.ops.drop_ghosts()
     if not nbrs:
         return
-    if h0.protocol == 'padded' and not all(h.promised for h in hs):
+    if h0.protocol == 'padded' and h0.promise and not all(h.promised for h in hs):
         _establish_promises(hs)   # collective; this exchange goes the counted way anyway
     fixed = h0.protocol in ('capacity', 'padded') and all(
         h.cap_send.get(s) is not None and h.cap_recv.get(s) is not None for h in hs for s in sides)
@@ -582,6 +673,9 @@ def _exchange_steps(hs, drop, overlap):
             hdr = ops0.read_headers(msgs)
         else:
             hdr = torch.stack([m[-1] for m in msgs]).cpu().tolist()
+        broken = sorted(set(k[0] for k, v in zip(keys + keys, hdr) if v != int(v)))
+        if broken:                      # a packed row carries another h / m than the one promised (and not sent)
+            raise RuntimeError(PROMISE_ERROR % [getattr(getattr(hs[a].ops, 'pa', None), 'name', a) for a in broken])
         sent = {k: int(v) for k, v in zip(keys, hdr[:len(keys)])}
         hdr = {k: int(v) for k, v in zip(keys, hdr[len(keys):])}
         for a, s in keys:
@@ -616,23 +710,31 @@ def _exchange_steps(hs, drop, overlap):
                     h.ops.append(inb[a][s], recv[a][s], stride=stride[a][s])
                 else:
                     h.ops.append(inb[a][s], recv[a][s])
-            h.cap_send[s] = _next_capacity(h.cap_send.get(s), send[a][s])
-            h.cap_recv[s] = _next_capacity(h.cap_recv.get(s), recv[a][s])
+            _track_capacities(h, s, send[a][s], recv[a][s])
         h.last_counts = (send[a][0], send[a][1], recv[a].get(0, 0), recv[a].get(1, 0))
 
 
 def _establish_promises(hs):
-    """'padded' protocol, once: does every rank hold ONE smoothing length and ONE
-    mass per array?  (min/max over the ranks of each array's own range.)  Then
-    every ghost is promised to carry them, and the neighbour update keeps what it
-    knows of h and m across the appends (no look, no round trip); sph_halo_append_padded
-    checks the promise on the device."""
+    """'padded' protocol, once (and again after every `rebalance`): does every rank
+    hold ONE smoothing length and ONE mass per array?  (min/max over the ranks of
+    each array's own range.)  Then every ghost is promised to carry them: the
+    neighbour update keeps what it knows of h and m across the appends (no look, no
+    round trip), and -- `send_promised=False`, the default -- the promised
+    properties do not TRAVEL: the messages shrink from 9 to 7 properties for a
+    WCSPH ghost, the receiver writes the promised values into the rows, the SENDER
+    checks every row it packs against the promise (header + 0.5 otherwise:
+    `verify_halos`).  Also agreed here, collectively: whether EVERY rank can run the
+    round-trip-free exchange (kernels and transport on one stream); one that cannot
+    makes all of them take the counted one."""
     h0 = hs[0]
     lo, hi = [], []
     for h in hs:
         r = h.ops.hm_range() if hasattr(h.ops, 'hm_range') else [float('inf'), -float('inf')] * 2
         lo += [r[0], r[2]]
         hi += [r[1], r[3]]
+    can = all(hasattr(h.ops, 'append_padded') and hasattr(h.ops, 'select_pack') and
+              getattr(h.ops, '_shares_torch_stream', lambda: True)() for h in hs)
+    lo.append(1.0 if can else 0.0)
     dev_t = getattr(h0.ops, 'device', None)
     glo = allreduce_scalars(lo, 'min', dist=h0.dist, device=dev_t)
     ghi = allreduce_scalars(hi, 'max', dist=h0.dist, device=dev_t)
@@ -640,39 +742,165 @@ def _establish_promises(hs):
         h.h_promise = glo[2 * a] if glo[2 * a] == ghi[2 * a] else float('nan')
         h.m_promise = glo[2 * a + 1] if glo[2 * a + 1] == ghi[2 * a + 1] else float('nan')
         h.promised = True
+        h.padded_ok = glo[-1] > 0.5
+        if hasattr(h.ops, 'set_promise'):
+            h.ops.set_promise(h.h_promise, h.m_promise, send=h.send_promised or not h.padded_ok)
+        if hasattr(h.ops, 'clear_flags'):
+            h.ops.clear_flags()       # (what an earlier promise's check left behind)
+        # message sizes may have changed with the property list
+        h.cap_send.clear()
+        h.cap_recv.clear()
+        h.__dict__.pop('cap_hist', None)
 
 
-def _padded_collect(hs):
-    """what the last 'padded' exchange sent on its way -- the row counts both ends
-    packed and the device flag word -- read now, one exchange later: capacities
-    follow the counts (the same rule on both ends of a face, from the same pair),
-    an incomplete message or a broken promise is an error (the step that used the
-    ghosts is invalid; it cannot be repaired after the fact)."""
+def _padded_eligible(h):
+    if h.padded_ok is None:
+        h.padded_ok = bool(hasattr(h.ops, 'append_padded') and hasattr(h.ops, 'select_pack') and
+                           getattr(h.ops, '_shares_torch_stream', lambda: True)())
+    return h.padded_ok
+
+
+class GhostsIncomplete(RuntimeError):
+    """a 'padded' ghost exchange was found incomplete too late to repair"""
+
+
+def _padded_headers(hs):
+    """the counts and flags of the outstanding 'padded' exchange (None: there is
+    none): waits for the event recorded right behind its transfers.  Returns
+    (keys, sent, recv, flags, out, inb) with the raw header values."""
     h0 = hs[0]
     pend = h0.padded_pending
     if pend is None:
-        return
+        return None
     h0.padded_pending = None
-    handle, keys = pend
-    vals, flag = h0.ops.collect_headers(handle)
+    handle, keys, out, inb = pend
+    vals, flags = h0.ops.collect_headers(handle)
     nk = len(keys)
-    sent = {k: int(v) for k, v in zip(keys, vals[:nk])}
-    recv = {k: int(v) for k, v in zip(keys, vals[nk:])}
+    sent = dict(zip(keys, vals[:nk]))
+    recv = dict(zip(keys, vals[nk:]))
     for a, h in enumerate(hs):
         sides = sorted(set(s for aa, s in keys if aa == a))
-        h.last_counts = tuple(abs(sent.get((a, s), 0)) for s in (0, 1)) + tuple(abs(recv.get((a, s), 0)) for s in (0, 1))
+        h.last_counts = tuple(int(abs(sent.get((a, s), 0))) for s in (0, 1)) + \
+            tuple(int(abs(recv.get((a, s), 0))) for s in (0, 1))
         for s in sides:
-            h.cap_send[s] = _next_capacity(h.cap_send.get(s), abs(sent[(a, s)]))
-            h.cap_recv[s] = _next_capacity(h.cap_recv.get(s), abs(recv[(a, s)]))
+            _track_capacities(h, s, int(abs(sent[(a, s)])), int(abs(recv[(a, s)])))
+    return keys, sent, recv, flags, out, inb
+
+
+def _broken_promise(hs, sent, recv, flags):
+    """arrays of which a row travelled (or was packed) with another h / m than promised"""
+    bad = set(a for (a, s), v in list(sent.items()) + list(recv.items()) if v != int(v))
+    bad |= set(a for a, f in enumerate(flags) if f & 2)
+    return sorted(bad)
+
+
+PROMISE_ERROR = ('padded ghost exchange: array %r carries a smoothing length or mass other than the ONE value '
+                 'promised for it when the exchange was set up (h or m was written afterwards).  Write h / m before '
+                 'the first exchange, call SlabDecomposition.renew_promises() on every rank after writing them, or '
+                 'construct the decomposition with promise=False')
+
+
+def _padded_collect(hs):
+    """what the last 'padded' exchange left to collect, when nobody asked
+    `verify_halos` before the next exchange starts: capacities follow the counts;
+    an incomplete message or a broken promise is an error NOW (the evaluation
+    that used those ghosts has been consumed).  Callers that verify after queueing
+    the evaluation (Integrator.compute_accelerations, bench.py) never get here
+    with anything wrong."""
+    got = _padded_headers(hs)
+    if got is None:
+        return
+    keys, sent, recv, flags, _, _ = got
     bad = [k for k in keys if sent[k] < 0 or recv[k] < 0]
-    if bad or flag & 1:
-        raise RuntimeError('padded ghost exchange: a face outgrew its message capacity in ONE exchange %r (counts %r / %r): '
-                           'the ghosts of the last step were incomplete.  SPH_HALO_PROTOCOL=capacity repeats such faces '
-                           'at the price of a device->host round trip per exchange' % (bad, sent, recv))
-    if flag & 2:
-        raise RuntimeError('padded ghost exchange: a ghost arrived with a smoothing length or mass other than the one promised '
-                           'for its array (h or m was written on some rank after the promise was made): the last step '
-                           'ran on wrong record layouts')
+    if bad or any(f & 1 for f in flags):
+        raise GhostsIncomplete(
+            'padded ghost exchange: a face outgrew its message capacity in ONE exchange %r (counts %r / %r) and '
+            'nobody verified the ghosts before the next exchange: the last evaluation ran on incomplete ghosts.  '
+            'Call SlabDecomposition.verify() after queueing the evaluation (it repeats such a face with a counted '
+            'exchange and says so; Integrator.compute_accelerations does), or SPH_HALO_PROTOCOL=capacity' % (bad, sent, recv))
+    broken = _broken_promise(hs, sent, recv, flags)
+    if broken:
+        raise RuntimeError(PROMISE_ERROR % [getattr(getattr(hs[a].ops, 'pa', None), 'name', a) for a in broken])
+
+
+def verify_halos(hs):
+    """Were the ghosts of the last exchange complete?  To be called AFTER the
+    neighbour update and the evaluation that use them were queued and BEFORE
+    anything consumes the evaluation's results (Integrator.compute_accelerations
+    does; the reference never evaluates on incomplete ghosts,
+    parallel_manager.pyx:1085-1157, it counts first).  The 'padded' protocol appends
+    fixed-capacity messages without knowing their counts; the counts were queued
+    to pinned memory right behind the transfers, so reading them here waits for
+    the TRANSFERS only -- the host stays one evaluation ahead of the device
+    instead of two, it does not drain the stream.
+
+    True: nothing to repair.  False: a face had outgrown its capacity; the two
+    ranks of that face (both read the negative header, nobody else is involved)
+    have repeated it with exactly sized messages -- point-to-point, the counted
+    way -- and rebuilt the ghost rows of the arrays concerned: the caller repeats
+    `nnps.update()` and the evaluation (both only read the real particles' state
+    and overwrite their own results).  A ghost that broke the promise of its
+    array's ONE h / m raises: the sender's properties have to be looked at again
+    collectively (`SlabDecomposition.renew_promises`)."""
+    got = _padded_headers(hs)
+    if got is None:
+        return True
+    keys, sent, recv, flags, out, inb = got
+    h0 = hs[0]
+    broken = _broken_promise(hs, sent, recv, flags)
+    if broken:
+        raise RuntimeError(PROMISE_ERROR % [getattr(getattr(hs[a].ops, 'pa', None), 'name', a) for a in broken])
+    over_send = [k for k in keys if sent[k] < 0]
+    over_recv = [k for k in keys if recv[k] < 0]
+    if not over_send and not over_recv:
+        return True
+    dist = h0.dist
+    nbrs = h0.neighbours()
+    shift_of = {s: shift for s, _, shift in nbrs}
+    send_order = sorted(nbrs, key=lambda nb: -nb[0])
+    recv_order = sorted(nbrs, key=lambda nb: nb[0])
+    na = len(hs)
+    xo, xi = {}, {}
+    for a in sorted(set(a for a, _ in over_send)):
+        h = hs[a]
+        h.ops.select(h.lo + h.width, h.hi - h.width)       # the index lists of the faces, this time (real particles only)
+    for a, s in over_send:
+        xo[(a, s)] = hs[a].ops.pack(s, int(-sent[(a, s)]), shift_of[s])
+    for a, s in over_recv:
+        xi[(a, s)] = hs[a].ops.new_buffer(int(-recv[(a, s)]), hs[a].ops.nprops)
+    for h in hs:
+        f = getattr(h.ops, 'before_comm', None)
+        if f is not None:
+            f()
+    reqs = [dist.P2POp(dist.isend, xo[(a, s)], peer) for s, peer, _ in send_order for a in range(na) if (a, s) in xo]
+    reqs += [dist.P2POp(dist.irecv, xi[(a, s)], peer) for s, peer, _ in recv_order for a in range(na) if (a, s) in xi]
+    if reqs:
+        for w in dist.batch_isend_irecv(reqs):
+            w.wait()
+    for h in hs:
+        f = getattr(h.ops, 'after_comm', None)
+        if f is not None:
+            f()
+    # the ghost rows of an array that received an incomplete face are rebuilt: its complete faces from their
+    # messages (still in their buffers), the repeated one from the exactly sized message
+    for a in sorted(set(a for a, _ in over_recv)):
+        h = hs[a]
+        h.ops.drop_ghosts()
+        for s, _, _ in nbrs:
+            if (a, s) in xi:
+                h.ops.append(xi[(a, s)], int(-recv[(a, s)]))
+            else:
+                h.ops.append_padded(inb[a][s], h.recv_rows[s], h.h_promise, h.m_promise, _flag_words(hs), a)
+    if hasattr(h0.ops, 'clear_flags'):
+        h0.ops.clear_flags()
+    for h in hs:
+        h.repaired_exchanges += 1
+    return False
+
+
+def _flag_words(hs):
+    f = getattr(hs[0].ops, 'flag_words', None)
+    return f(len(hs)) if f is not None else None
 
 
 def _exchange_padded(hs, nbrs):
@@ -680,8 +908,8 @@ def _exchange_padded(hs, nbrs):
     fixed-capacity messages packed on the device as in 'capacity', but the receiver
     appends ALL rows of a message -- the ghosts and, behind them, padding rows parked
     far outside the domain that are inert on the whole path -- so nothing has to be counted before the
-    neighbour update and the evaluation are queued.  Counts and flags follow one
-    exchange later (_padded_collect)."""
+    neighbour update and the evaluation are queued.  Counts and flags are read by
+    `verify_halos` once those are queued (or, unverified, at the next exchange)."""
     h0 = hs[0]
     dist, ops0, na = h0.dist, h0.ops, len(hs)
     sides = [s for s, _, _ in nbrs]
@@ -717,11 +945,14 @@ def _exchange_padded(hs, nbrs):
         if f is not None:
             f()
     keys = [(a, s) for a in range(na) for s in sides]
+    flags = _flag_words(hs)           # ONE set of flag words for all arrays of the exchange, a word per array
     for a, h in enumerate(hs):
+        h.recv_rows = dict(h.cap_recv)    # rows each face's message was appended with (a repair re-appends them)
         for s, _, _ in nbrs:          # lo side first: deterministic
-            h.ops.append_padded(inb[a][s], h.cap_recv[s], h.h_promise, h.m_promise)
+            h.ops.append_padded(inb[a][s], h.cap_recv[s], h.h_promise, h.m_promise, flags, a)
         h.padded_exchanges += 1
-    h0.padded_pending = (ops0.queue_headers([out[a][s] for a, s in keys] + [inb[a][s] for a, s in keys]), keys)
+    msgs = [out[a][s] for a, s in keys] + [inb[a][s] for a, s in keys]
+    h0.padded_pending = (ops0.queue_headers(msgs, na), keys, out, inb)
 
 
 class SlabDecomposition(object):
@@ -733,7 +964,7 @@ class SlabDecomposition(object):
 
     def __init__(self, arrays, ctx, rank, world, axis, width, lo, hi,
                  props=WCSPH_HALO_PROPS, periodic=False, period=0.0,
-                 ops_factory=None, dist=None, protocol=None):
+                 ops_factory=None, dist=None, protocol=None, promise=True, send_promised=False):
         if dist is None:
             import torch.distributed as dist
         self.dist = dist
@@ -744,7 +975,8 @@ class SlabDecomposition(object):
             ops = ops_factory(pa, axis, p) if ops_factory else None
             self.halos.append(SlabHalo(pa, ctx, rank, world, axis, width, lo,
                                        hi, props=p, periodic=periodic,
-                                       period=period, ops=ops, dist=dist, protocol=protocol))
+                                       period=period, ops=ops, dist=dist, protocol=protocol,
+                                       promise=promise, send_promised=send_promised))
 
     @property
     def lo(self):
@@ -761,6 +993,20 @@ class SlabDecomposition(object):
         """Ghost refresh of ALL arrays with one batch of point-to-point transfers
         (a dam break has three arrays): see exchange_halos."""
         exchange_halos(self.halos, drop=drop)
+
+    def verify(self):
+        """True when the ghosts of the last exchange were complete; False after an
+        incomplete face was repeated the counted way -- repeat the neighbour update
+        and the evaluation then (`verify_halos`)."""
+        return verify_halos(self.halos)
+
+    def renew_promises(self):
+        """COLLECTIVE: look at every array's h and m range again (after h or m was
+        written) and agree anew on what the ghosts are promised to carry; the next
+        exchange is a counted one."""
+        _padded_collect(self.halos)
+        if self.halos[0].promise:
+            _establish_promises(self.halos)
 
     def faces(self):
         """(lo, hi) along the slab axis outside which every ghost of this rank
@@ -790,6 +1036,9 @@ class SlabDecomposition(object):
         import numpy as np
         dist = self.dist
         ops0 = self.halos[0].ops
+        # an outstanding 'padded' exchange is settled first: its counts belong to the OLD faces and must not size
+        # the messages of the new ones
+        _padded_collect(self.halos)
         coords = [h.ops.coords() for h in self.halos]
         lmin = min([c.min() for c in coords if c.size] or [float('inf')])
         lmax = max([c.max() for c in coords if c.size] or [-float('inf')])
@@ -834,6 +1083,7 @@ class SlabDecomposition(object):
         for h in self.halos:
             h.cap_send.clear()
             h.cap_recv.clear()
+            h.__dict__.pop('cap_hist', None)
         return faces, rounds
 
 
@@ -860,6 +1110,11 @@ class HipParallelManager(object):
             self.dec.exchange()
         else:
             self.dec.update()
+
+    def verify(self):
+        """Integrator.compute_accelerations asks this once the evaluation is queued:
+        False = the ghosts were incomplete and have been repaired, evaluate again"""
+        return self.dec.verify()
 
     def reduce_max(self, values):
         return allreduce_scalars(values, 'max', dist=self.dist, device=self._device)

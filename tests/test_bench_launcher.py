@@ -11,18 +11,24 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_gpus_flag_spawns_ranks():
+import pytest
+
+
+@pytest.mark.parametrize('n', [2, 8])
+def test_gpus_flag_spawns_ranks(n):
+    """(8: the launch the driver's scaling run makes -- eight processes rendezvous on 127.0.0.1)"""
     env = dict(os.environ)
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     env['SPH_BENCH_DRYRUN'] = '1'
-    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2',
+    env['OMP_NUM_THREADS'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', str(n),
                         '--steps', '1', '--warmup', '0'], env=env, stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, universal_newlines=True, timeout=300)
+                       stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
     out = json.loads(line)
-    assert out == {'dryrun': True, 'n_gpus': 2, 'rank_sum': 3.0}
+    assert out == {'dryrun': True, 'n_gpus': n, 'rank_sum': n * (n + 1) / 2.0}
 
 
 def test_world_size_must_match_gpus():

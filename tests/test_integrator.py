@@ -248,6 +248,140 @@ def test_epec_steps_two_slab_ranks_match_single_domain():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('tight', [False, True])
+def test_dam_break_epec_two_slab_ranks_padded_exchange_under_motion(monkeypatch, tight):
+    """What BASELINE config 4 does, small: the THREE-array dam break (dx 0.06) cut in
+    two slabs, 40 EPEC steps through HipParallelManager on the round-trip-free
+    ('padded') exchange and the merged one-launch evaluation, with the fluid moving:
+    the front's lattice plane crosses the slab face (rank 1 owns no fluid at the
+    start and gets it by migration; its fluid ghost count for rank 0 jumps from
+    nothing to a plane), a re-balance moves the face, and -- `tight` -- capacities
+    without headroom make exactly that plane outgrow its message: verify() repeats
+    the face the counted way and the evaluation runs again (the reference counts
+    first and never evaluates on incomplete ghosts, parallel_manager.pyx:1085-1157;
+    recipe of the comparison: parallel/tests/example_test_case.py:143-166).  Same
+    particle state as one domain, matched by global id."""
+    import threading
+    import torch
+    from helpers import ThreadDist
+    import pysph_amd.parallel as par
+    from pysph_amd import device as dev
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.examples import dam_break_3d as db
+    from pysph_amd.integrator import EPECIntegrator, WCSPHStep, setup_integrator
+    from pysph_amd.nnps import HipNNPS
+    from pysph_amd.particle_array import ParticleArray
+    dx = 0.06
+    full = db.create_particles(dx)
+    g0 = 0
+    for a in full:
+        n = a.get_number_of_particles()
+        a.add_property('e0', data=np.arange(g0, g0 + n, dtype=np.float64))
+        g0 += n
+    fl = full[0]
+    fl.u[:] = 4.0                   # the column moves towards +x: its front plane (x = 1.2) crosses the face at 1.23
+    eqs = db.create_scheme(dx).get_equations()
+    kernel = db.create_kernel()
+    dt = 0.125 * db.hdx * dx / (1.1 * db.c0)
+    nsteps = 40
+    cut = 1.23
+    PROPS = ('x', 'y', 'z', 'u', 'v', 'w', 'rho', 'au', 'av', 'aw', 'arho')
+    if tight:
+        monkeypatch.setattr(par, '_capacity', lambda c: ((c + 8 + 7) // 8) * 8)
+        monkeypatch.setattr(par, '_capacity_tight', lambda c: ((c + 8 + 7) // 8) * 8)
+
+    def run(arrays, ctx, pm_factory=None):
+        for a in arrays:
+            dev.attach(a, ctx).push()
+        a_eval = AccelerationEval(arrays, eqs, kernel)
+        SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+        nnps = HipNNPS(3, arrays, radius_scale=kernel.radius_scale, ctx=ctx, sync=False)
+        a_eval.set_nnps(nnps)
+        integ = EPECIntegrator(fluid=WCSPHStep())
+        setup_integrator(integ, a_eval, nnps)
+        pm = None
+        if pm_factory:
+            pm = pm_factory(arrays, ctx)
+            integ.set_parallel_manager(pm)
+        t = 0.0
+        for _ in range(nsteps):
+            integ.step(t, dt)
+            t += dt
+        out = {}
+        for a in arrays:
+            a.gpu.managed = True
+            a.gpu.sync_host()
+            nr = a.get_number_of_particles(True)
+            out[a.name] = dict((k, a.properties[k][:nr].copy()) for k in PROPS + ('e0',))
+        return out, pm, ctx.timer_get('n_merged')[1]
+
+    def copy_of(a, idx=None):
+        props = {k: (v.copy() if idx is None else v[idx].copy()) for k, v in a.properties.items()}
+        return ParticleArray(name=a.name, **props)
+
+    ref, _, _ = run([copy_of(a) for a in full], dev.HipContext(0))
+    hub = ThreadDist(2)
+    results, errors = {}, []
+
+    def rank_main(rank):
+        try:
+            ts = torch.cuda.Stream()
+            with torch.cuda.stream(ts):
+                arrays = [copy_of(a, np.nonzero(a.x < cut)[0] if rank == 0 else np.nonzero(a.x >= cut)[0]) for a in full]
+                ctx = dev.HipContext(0, ts.cuda_stream)
+                ctx.timer_enable(True)
+                lo, hi = (-1e30, cut) if rank == 0 else (cut, 1e30)
+
+                def pmf(arrs, ctx_):
+                    dec = par.SlabDecomposition(arrs, ctx_, rank, 2, axis=0, width=2.0 * db.hdx * dx * 1.05,
+                                                lo=lo, hi=hi, dist=hub.view(rank), protocol='padded')
+                    return par.HipParallelManager(dec, rebalance_every=31)
+                out, pm, n_merged = run(arrays, ctx, pmf)
+                hs = pm.dec.halos
+                results[rank] = (out, [h.padded_exchanges for h in hs], [h.repaired_exchanges for h in hs],
+                                 [h.last_migrated for h in hs], pm.count, n_merged, (hs[0].lo, hs[0].hi),
+                                 [list(h.ops.props) for h in hs])
+        except Exception:
+            import traceback
+            errors.append(traceback.format_exc())
+            try:
+                hub.barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t_ in threads:
+        t_.start()
+    for t_ in threads:
+        t_.join(900)
+    assert not errors, errors[0]
+    fluid_on_1 = results[1][0]['fluid']['e0'].size
+    assert fluid_on_1 > 0                            # the front crossed the face: rank 1 owns fluid now
+    for name in ('fluid', 'boundary', 'obstacle'):
+        order = np.argsort(ref[name]['e0'])
+        gids = []
+        for r in range(2):
+            out = results[r][0][name]
+            gid = out['e0'].astype(np.int64) - int(ref[name]['e0'].min())
+            gids.append(gid)
+            for k in PROPS:
+                e = rel_err(out[k], ref[name][k][order][gid], scale=max(np.abs(ref[name][k]).max(), 1e-300))
+                assert e < 1e-9, (name, r, k, e)
+        assert (np.sort(np.concatenate(gids)) == np.arange(ref[name]['e0'].size)).all(), name
+    for r in range(2):
+        _, padded, repaired, _, count, n_merged, faces, props = results[r]
+        assert count == 2 * nsteps
+        assert min(padded) >= 2 * nsteps - 8, padded          # the steady state IS the round-trip-free exchange
+        assert n_merged >= 2 * nsteps - 8                     # ... on the merged one-launch evaluation
+        assert all(dev.prop_id('h') not in p and dev.prop_id('m') not in p for p in props)   # promised h, m do not travel
+        if tight:
+            assert sum(repaired) >= 1, repaired               # the plane that crossed outgrew its message: repaired
+        else:
+            assert sum(repaired) == 0, repaired
+    assert results[0][6][1] != cut                            # the re-balance moved the face
+
+
+@pytest.mark.gpu
 def test_dam_break_time_loop_runs_and_stays_physical():
     """The example's device-resident time loop (EPEC + adaptive dt + periodic
     reordering) on the config-1 geometry at a coarse spacing: the column

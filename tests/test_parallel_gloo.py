@@ -29,10 +29,13 @@ PROPS = ('x', 'y', 'z', 'u', 'v', 'w', 'rho', 'h', 'm')
 class NumpyHaloOps(object):
     """Test double with the interface of pysph_amd.parallel.DeviceHaloOps."""
 
-    def __init__(self, pa, axis):
+    def __init__(self, pa, axis, props=None):
         self.pa = pa
         self.axis = 'xyz'[axis]
-        self.nprops = len(PROPS)
+        self.all_halo_props = list(props or PROPS)
+        self.props = list(self.all_halo_props)   # what a message carries (set_promise may take h / m out)
+        self.nprops = len(self.props)
+        self.fill = []
         self._sel = {}
 
     def n_real(self):
@@ -58,7 +61,7 @@ class NumpyHaloOps(object):
         buf = self.new_buffer(count)
         idx = self._sel[side]
         out = buf.numpy()
-        for k, p in enumerate(PROPS):
+        for k, p in enumerate(self.props):
             v = self.pa.properties[p][idx]
             if p == self.axis:
                 v = v + shift
@@ -72,8 +75,10 @@ class NumpyHaloOps(object):
         self.pa.resize(n0 + count)
         self.pa.set_num_real_particles(nreal)
         arr = buf.numpy()
-        for k, p in enumerate(PROPS):
+        for k, p in enumerate(self.props):
             self.pa.properties[p][n0:] = arr[k * stride:k * stride + count]
+        for p, v in self.fill:              # promised h / m did not travel
+            self.pa.properties[p][n0:] = v
         self.pa.properties['tag'][n0:] = 1  # Remote
 
     # -- migration ---------------------------------------------------------
@@ -131,10 +136,13 @@ class NumpyDirectHaloOps(NumpyHaloOps):
                 for k in range(self.nprops):
                     out[k * cap:k * cap + cnt] = rows[k * cnt:(k + 1) * cnt]
             else:                    # what fits, as the device kernel does; the header says "incomplete"
-                for k, p in enumerate(PROPS):
+                for k, p in enumerate(self.props):
                     v = self.pa.properties[p][self._sel[s][:cap]]
                     out[k * cap:(k + 1) * cap] = v + (shifts[s] if p == self.axis else 0.0)
-            out[self.nprops * cap] = float(cnt if cnt <= cap else -cnt)
+            # the sender checks every selected row against a promise that does not travel (+ 0.5 in the header)
+            broken = any(np.any(self.pa.properties[p][self._sel[s]] != v) for p, v in self.fill)
+            hdr = cnt + (0.5 if broken else 0.0)
+            out[self.nprops * cap] = float(hdr if cnt <= cap else -hdr)
         self._sel = {}               # no index lists on the host side of this protocol
 
 
@@ -420,30 +428,52 @@ class NumpyPaddedHaloOps(NumpyDirectHaloOps):
             t = cache[key] = torch.zeros(size, dtype=torch.float64)
         return t
 
-    def append_padded(self, buf, cap, h_promise, m_promise):
+    def flag_words(self, n=1):
+        f = self.__dict__.setdefault('_flags', [])
+        while len(f) < n:
+            f.append(0)
+        return f
+
+    def clear_flags(self):
+        self._flags = [0] * len(self.__dict__.get('_flags', []))
+
+    def append_padded(self, buf, cap, h_promise, m_promise, flags=None, slot=0):
+        flags = self.flag_words(slot + 1) if flags is None else flags
         arr = buf.numpy()
         hdr = arr[self.nprops * cap]
         count = int(min(abs(hdr), cap))
-        self.flag = getattr(self, 'flag', 0) | (1 if hdr < 0 else 0)
+        flags[slot] |= (1 if hdr < 0 else 0)
         n0 = self.pa.get_number_of_particles()
         nreal = self.n_real()
         self.pa.resize(n0 + cap)
         self.pa.set_num_real_particles(nreal)
-        for k, p in enumerate(PROPS):
+        for k, p in enumerate(self.props):
             col = np.full(cap, 1e18 if p in 'xyz' else 0.0)
             col[:count] = arr[k * cap:k * cap + count]
             if p == 'h' and h_promise == h_promise and np.any(col[:count] != h_promise):
-                self.flag |= 2
+                flags[slot] |= 2
             if p == 'm' and m_promise == m_promise and np.any(col[:count] != m_promise):
-                self.flag |= 2
+                flags[slot] |= 2
             self.pa.properties[p][n0:] = col
+        for p, v in self.fill:          # a promised property that did not travel: written into ALL rows
+            self.pa.properties[p][n0:] = v
         self.pa.properties['tag'][n0:] = 1
 
-    def queue_headers(self, tensors):
-        return [float(t[-1]) for t in tensors], getattr(self, 'flag', 0)
+    def queue_headers(self, tensors, nflags=1):
+        return [float(t[-1]) for t in tensors], list(self.flag_words(nflags)[:nflags])
 
     def collect_headers(self, handle):
         return handle
+
+    def mark_hm_written(self):
+        pass
+
+    def set_promise(self, h_promise, m_promise, send=True):
+        self.props = [p for p in self.all_halo_props if send or not ((p == 'h' and h_promise == h_promise) or
+                                                                     (p == 'm' and m_promise == m_promise))]
+        self.nprops = len(self.props)
+        self.fill = [(p, v) for p, v in (('h', h_promise), ('m', m_promise)) if v == v and p not in self.props]
+        self._messages = {}
 
     def hm_range(self):
         n = self.n_real()
@@ -456,8 +486,12 @@ class NumpyPaddedHaloOps(NumpyDirectHaloOps):
 def _worker_padded(rank, world, port, periodic, out):
     """the 'padded' protocol against the counted one: after every exchange the
     first rows behind the real particles are the same ghosts, the rows behind
-    them parked far away; counts arrive one exchange late and move the capacities on both
-    ends alike; an overflowing face is an error one exchange later"""
+    them parked far away; the promised h and m do not travel (7 of 9 properties)
+    and are written into the rows by the receiver; counts are read by `verify_halos`
+    once the evaluation would have been queued and move the capacities on both ends
+    alike; a face that outgrew its capacity is REPEATED by verify (the two ranks of
+    the face only), unverified it is an error at the next exchange; a row that
+    breaks the promise is an error at verify"""
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -480,10 +514,8 @@ def _worker_padded(rank, world, port, periodic, out):
         pa_c, hc = build('capacity', NumpyDirectHaloOps)
         pa_p, hp = build('padded', NumpyPaddedHaloOps)
         log = []
-        for step, width in enumerate((0.1, 0.1, 0.12, 0.05, 0.15, 0.15)):
-            hc.width = hp.width = width
-            hc.exchange()
-            hp.exchange()
+
+        def same_ghosts(step):
             nr = pa_c.get_number_of_particles(True)
             nc = pa_c.get_number_of_particles()
             npad = pa_p.get_number_of_particles()
@@ -493,21 +525,40 @@ def _worker_padded(rank, world, port, periodic, out):
             assert live[:nr].all() and live.sum() == nc
             for k in PROPS:
                 assert np.array_equal(pa_c.properties[k][:nc], pa_p.properties[k][:npad][live]), (step, k)
-                assert np.all(pa_p.properties[k][:npad][~live] == (1e18 if k in 'xyz' else 0.0)), (step, k)
-            log.append((hp.padded_exchanges, npad - nc))
-        assert hp.handshakes == 1 and hp.padded_exchanges == 5
+                parked = 1e18 if k in 'xyz' else (hp.h_promise if k == 'h' else hp.m_promise if k == 'm' else 0.0)
+                assert np.all(pa_p.properties[k][:npad][~live] == parked), (step, k)
+            return npad - nc
+        for step, width in enumerate((0.1, 0.1, 0.12, 0.05, 0.15, 0.15)):
+            hc.width = hp.width = width
+            hc.exchange()
+            hp.exchange()
+            assert par.verify_halos([hp])            # (the evaluation would be queued before this)
+            log.append((hp.padded_exchanges, same_ghosts(step)))
+        assert hp.handshakes == 1 and hp.padded_exchanges == 5 and hp.repaired_exchanges == 0
         assert hp.h_promise == hp.h_promise and hp.m_promise == hp.m_promise     # the cube has one h and one m
-        # counts arrived one exchange late
-        par._padded_collect([hp])
+        assert hp.ops.props == [p for p in PROPS if p not in ('h', 'm')]         # ... which do not travel
         assert hp.last_counts == hc.last_counts
-        # a face that outgrows its capacity in ONE exchange: loud, one exchange later
+        # a face that outgrows its capacity in ONE exchange: verify repeats it the counted way -- same ghosts after
+        hp.cap_send = {s: 8 for s in hp.cap_send}
+        hp.cap_recv = {s: 8 for s in hp.cap_recv}
+        hc.exchange()
+        hp.exchange()
+        assert not par.verify_halos([hp])
+        assert hp.repaired_exchanges == 1
+        same_ghosts('repaired')
+        assert par.verify_halos([hp])                # nothing outstanding: nothing to do
+        hc.exchange()
+        hp.exchange()                                # capacities followed the counts: complete again
+        assert par.verify_halos([hp])
+        same_ghosts('after repair')
+        # ... unverified: loud at the next exchange
         hp.cap_send = {s: 8 for s in hp.cap_send}
         hp.cap_recv = {s: 8 for s in hp.cap_recv}
         hp.exchange()
         try:
             hp.exchange()
             raised = False
-        except RuntimeError as e:
+        except par.GhostsIncomplete as e:
             raised = 'outgrew its message capacity' in str(e)
         assert raised
         np.save(out % rank, np.array(log))
@@ -523,6 +574,77 @@ def test_padded_protocol_equals_capacity_protocol(tmp_path, periodic, world):
     for rank in range(world):
         a = np.load(out % rank)
         assert a.shape == (6, 2) and a[-1, 0] == 5 and a[1:, 1].min() > 0
+
+
+def _worker_promises(rank, world, port, send_promised, out):
+    """TWO arrays through one padded exchange: the flag words are per array (the
+    round-5 exchange looked at the first array's word only); a row of the SECOND
+    array that breaks its promise is found -- by the receiver's check when the
+    promised properties travel, by the sender's when they do not -- and verify
+    names the array; renew_promises (collective) repairs the contract"""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import pysph_amd.parallel as par
+        from test_hip_parity import make_cube
+        from pysph_amd.particle_array import ParticleArray
+        full, dx = make_cube(12)
+        x = full.x
+        lo, hi = rank / float(world), (rank + 1) / float(world)
+        own = np.nonzero(((x >= lo) | (rank == 0)) & ((x < hi) | (rank == world - 1)))[0]
+        odd, even = own[own % 2 == 1], own[own % 2 == 0]
+
+        def make(idx, name):
+            return ParticleArray(name=name, **{k: v[idx].copy() for k, v in full.properties.items()})
+        a, b = make(odd, 'a'), make(even, 'b')
+        dec = par.SlabDecomposition([a, b], None, rank, world, axis=0, width=2.6 * dx, lo=lo, hi=hi,
+                                    ops_factory=lambda pa, ax, p: NumpyPaddedHaloOps(pa, ax), dist=dist,
+                                    protocol='padded', send_promised=send_promised)
+        for _ in range(3):
+            dec.exchange()
+            assert dec.verify()
+        assert dec.halos[1].padded_exchanges == 2
+        assert (len(dec.halos[1].ops.props) == 9) == send_promised
+        # rank 0 writes h of ONE particle of array b next to its upper face
+        if rank == 0:
+            nr = b.get_number_of_particles(True)
+            i = int(np.argmax(b.x[:nr]))
+            b.h[i] *= 1.5
+        dec.exchange()
+        seen = ''
+        try:
+            dec.verify()
+        except RuntimeError as e:
+            seen = str(e)
+        if send_promised:
+            # the receiver's check: rank 1 finds it in the word of array 1
+            assert ("['b']" in seen) == (rank == 1), (rank, seen)
+        else:
+            # the sender's check travels in the header: both ends of the face see it
+            assert ("['b']" in seen) == (rank in (0, 1)), (rank, seen)
+        # every rank looks at its ranges again: no promise for b's h any more, its h travels, the exchange goes on
+        dec.renew_promises()
+        for _ in range(3):
+            dec.exchange()
+            assert dec.verify()
+        hb = dec.halos[1]
+        assert hb.h_promise != hb.h_promise and hb.m_promise == hb.m_promise
+        assert 'h' in hb.ops.props and (('m' in hb.ops.props) == send_promised)
+        if rank == 1:
+            ng = b.get_number_of_particles()
+            assert np.sum(b.h[:ng] == 1.5 * full.h[0]) == 1      # the odd one arrived as a ghost with ITS h
+        np.save(out % rank, np.array([dec.halos[0].padded_exchanges, dec.halos[1].padded_exchanges]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('send_promised', [False, True])
+def test_padded_promises_are_checked_per_array(tmp_path, send_promised):
+    out = str(tmp_path / 'prom_%d.npy')
+    mp.spawn(_worker_promises, args=(3, _free_port(), send_promised, out), nprocs=3, join=True)
+    for rank in range(3):
+        assert np.load(out % rank).min() >= 4
 
 
 def _worker_protocols(rank, world, port, periodic, out):
@@ -619,6 +741,34 @@ def test_capacity_rule_is_symmetric_and_stable():
         resized += new != cap
         cap = new
     assert overflowed == 0 and 0 < resized < 12
+
+
+def test_capacity_adapts_to_a_steady_count():
+    """with a history both ends of a face keep (fed the same counts) the messages
+    SHRINK once the count has been steady: 25 % + 4096 rows of headroom -> 1/16 + 1024;
+    a count that comes close to the tight capacity returns the face to the generous
+    rule before it overflows; two ends fed the same sequence stay in step"""
+    from pysph_amd.parallel import STEADY_EXCHANGES, _capacity, _capacity_tight, _next_capacity
+    rng = np.random.default_rng(3)
+    seq = [115000 + int(rng.integers(-300, 300)) for _ in range(30)]             # a dam-break face at rest
+    seq += [115000 + 400 * k for k in range(1, 40)]                               # the front arrives
+    seq += [131000] * 20
+    ends = []
+    for _ in range(2):
+        cap, hist, caps = None, [None, 0, False], []
+        for c in seq:
+            cap = _next_capacity(cap, c, hist)
+            caps.append(cap)
+        ends.append(caps)
+    assert ends[0] == ends[1]
+    caps = ends[0]
+    assert caps[0] == _capacity(seq[0])
+    assert caps[STEADY_EXCHANGES + 1] == _capacity_tight(seq[STEADY_EXCHANGES + 1]) < caps[0]
+    assert all(c >= n for c, n in zip([caps[0]] + caps[:-1], seq))               # the capacity in force always held the count
+    assert caps[29] * 8 * 7 < 0.8 * caps[0] * 8 * 9                               # tight AND without h, m: < 80 % of the bytes... of round 5
+    assert caps[-1] == _capacity_tight(131000)                                    # steady again: tight again
+    # without a history: the rule of the counted protocol, unchanged
+    assert _next_capacity(None, 1000) == _capacity(1000)
 
 
 def test_null_stream_handle_is_not_a_shared_stream():
