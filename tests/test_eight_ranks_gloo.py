@@ -28,7 +28,7 @@ WORLD = 8
 ARGV = {
     'cube': ['--workload', 'cube', '--n1', '8'],
     'dam_break': ['--workload', 'dam_break', '--dx', '0.05'],
-    'elastic_block': ['--workload', 'elastic_block', '--n1', '20'],
+    'elastic_block': ['--workload', 'elastic_block', '--n1', '32'],
 }
 
 
