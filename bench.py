@@ -624,7 +624,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary configurations')
     ap.add_argument('--no-counters', action='store_true', dest='no_counters',
                     help='do not re-run under rocprofv3 --pmc for roofline.traffic (replay profiles/pmc_traffic.json)')
-    ap.add_argument('--cpu-n1', type=int, default=100)
+    ap.add_argument('--cpu-n1', type=int, default=0, help='side of the CPU baseline sample (0: the workload\'s own size)')
     ap.add_argument('--fixed-bounds', action='store_true', dest='fixed_bounds',
                     help='hand nnps.update() the grid bounds and the (constant) h range instead of '
                          'reducing them every update: LinkedListNNPS(fixed_h=True) plus bounds a '
@@ -1032,11 +1032,13 @@ def run(args, rank, local_rank, world, dist):
         extra['projected_strong_scaling_8'] = projected_strong_scaling(args, local_rank, tstream, t_one_gpu_ms=t1)
         extra['time_stepping'] = time_stepping(local_rank, tstream)
     if not args.no_cpu_baseline and world == 1:
-        out['cpu_baseline'] = cpu_baseline(args.cpu_n1)
-        if not args.no_extras and args.workload == 'cube' and args.n1 == 159:
-            # the same baseline on the headline size itself
-            b4 = cpu_baseline(159, target_seconds=4.0)
-            extra['cpu_baseline_159'] = {k: b4[k] for k in ('value', 'cores', 'sample')}
+        # on the size of the reported workload itself (159^3 for the headline line: ~1.1 s per pass on the box's cores);
+        # --cpu-n1 overrides the sample
+        n_cpu = args.cpu_n1 or (args.n1 if args.workload == 'cube' else 100)
+        out['cpu_baseline'] = cpu_baseline(n_cpu, target_seconds=12.0)
+        if not args.no_extras and args.workload == 'cube' and n_cpu != 100:
+            b1 = cpu_baseline(100, target_seconds=4.0)      # (the 1 M sample of the earlier rounds' lines)
+            extra['cpu_baseline_100'] = {k: b1[k] for k in ('value', 'cores', 'sample')}
     if extra:
         out['extra'] = extra
     return out
@@ -1278,8 +1280,27 @@ def projected_strong_scaling(args, local_rank, tstream, world=8, dx=0.0035, t_on
             nreal = sum(a.get_number_of_particles(True) for a in w.arrays)
             nall = sum(a.get_number_of_particles() for a in w.arrays)
             ms = elapsed / steps * 1e3
+            # what this rank RECEIVES per exchange, face by face and array by array, as the round-trip-free protocol sends
+            # it in its steady state: rows = the capacity of a steady face (pysph_amd.parallel._capacity_tight: the count
+            # + 1/16 + 1024, in units of 1024), 7 doubles per row (x y z u v w rho: the promised-uniform h and m do not
+            # travel) + the header.  Round 5 sent 9 doubles x (count + 1/4 + 4096) rows.
+            from pysph_amd.parallel import _capacity, _capacity_tight
+            faces = {}
+            for a in w.arrays:
+                nr, nt = a.get_number_of_particles(True), a.get_number_of_particles()
+                gx = np.asarray(a.x[nr:nt])
+                mid = 0.5 * (float(np.min(a.x[:nr])) + float(np.max(a.x[:nr]))) if nr else 0.0
+                cnt = [int(np.sum(gx < mid)), int(np.sum(gx >= mid))]
+                faces[a.name] = {'ghosts': cnt,
+                                 'message_bytes': [(_capacity_tight(c) * 7 + 1) * 8 if c or (r > 0 if s == 0 else r < world - 1) else 0
+                                                   for s, c in enumerate(cnt)],
+                                 'message_bytes_round5': [(_capacity(c) * 9 + 1) * 8 if c or (r > 0 if s == 0 else r < world - 1) else 0
+                                                          for s, c in enumerate(cnt)]}
             out['ranks'][str(r)] = {'real_particles': nreal, 'ghost_particles': nall - nreal, 'ms_per_step': ms,
                                     'real_per_array': {a.name: a.get_number_of_particles(True) for a in w.arrays},
+                                    'received_per_face': faces,
+                                    'bytes_per_face': [sum(f['message_bytes'][s] for f in faces.values()) for s in (0, 1)],
+                                    'bytes_per_face_round5': [sum(f['message_bytes_round5'][s] for f in faces.values()) for s in (0, 1)],
                                     'kernel_ms_per_step': {k: timers[k][0] / steps for k in ('nnps', 'pack', 'eos', 'pair')}}
             if ms > t_max:
                 t_max, n_max = ms, nreal
@@ -1333,8 +1354,30 @@ def projected_strong_scaling(args, local_rank, tstream, world=8, dx=0.0035, t_on
     out['slowest_rank_ms'] = t_max
     if t_one_gpu_ms and t_max > 0 and out.get('exchange_ms') is not None:
         out['t_one_gpu_ms'] = t_one_gpu_ms
-        out['projected_speedup'] = t_one_gpu_ms / (t_max + out['exchange_ms'])
         out['projected_speedup_free_exchange'] = t_one_gpu_ms / t_max
+        # The stand-in's "transfer" is a device copy; a real face crosses ONE xGMI link per direction (send and receive at
+        # the same time, the two faces of a rank on two different links: the slower face sets the time).  The plain order
+        # does not hide it: step = rank + local exchange work (selection, packing, RCCL launch, append: the stand-in's
+        # figure) + bytes of the larger face / link rate + a link latency.  MI355X_MICROARCH.md: 153.6 GB/s peak per
+        # link and direction; RCCL point-to-point reaches 45-75 GB/s of it on messages of a few MB.
+        LINK_LATENCY_MS = 0.010
+        ok = [v for v in out['ranks'].values() if 'ms_per_step' in v]
+        face_bytes = max(max(v['bytes_per_face']) for v in ok)
+        face_bytes5 = max(max(v['bytes_per_face_round5']) for v in ok)
+        out['largest_face_message_bytes'] = face_bytes
+        out['largest_face_message_bytes_round5_protocol'] = face_bytes5
+        out['link_model'] = 'step = max_r(rank_ms) + exchange_ms (one-GPU stand-in: select + pack + RCCL launch + append) + ' \
+                            'largest face bytes / rate + %.0f us; nothing overlapped' % (LINK_LATENCY_MS * 1e3)
+        out['projected_speedup_with_link'] = {}
+        for gbs in (45, 60, 75):
+            t_link = face_bytes / (gbs * 1e9) * 1e3 + LINK_LATENCY_MS
+            out['projected_speedup_with_link']['%d GB/s' % gbs] = {
+                'transfer_ms': t_link, 'step_ms': t_max + out['exchange_ms'] + t_link,
+                'speedup': t_one_gpu_ms / (t_max + out['exchange_ms'] + t_link),
+                'speedup_round5_messages': t_one_gpu_ms / (t_max + out['exchange_ms'] + face_bytes5 / (gbs * 1e9) * 1e3 + LINK_LATENCY_MS)}
+        # the headline of the projection: 60 GB/s per direction
+        out['projected_speedup'] = out['projected_speedup_with_link']['60 GB/s']['speedup']
+        out['projected_speedup_stand_in_transfer'] = t_one_gpu_ms / (t_max + out['exchange_ms'])
     return out
 
 

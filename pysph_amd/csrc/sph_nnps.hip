@@ -1783,7 +1783,13 @@ extern "C" int sph_nnps_update_ghosts(sph_ctx *c, int axis, double lo, double hi
                     if (pin[a] & 1u) { A.m_known = false; A.m_mixed_ghosts = true; }
                     else { A.m_known = true; if (untouched && A.m_clean_binned) A.m_dirty = false; }
                 }
-                if (untouched && A.h_clean_binned) A.h_dirty = false; // inside the range: the range of the union is the same
+                if (untouched && A.h_clean_binned) {
+                    // the ghosts were checked against the range the GRID was built for (the union over the arrays, or the
+                    // caller's): this array's own range is known again, widened to that one (a superset: an array whose
+                    // ONE smoothing length differs from the others' is no longer "one value" once foreign ghosts joined)
+                    A.h_dirty = false;
+                    A.h_lo = fmin(A.h_lo, c->lag.hr[0]); A.h_hi = fmax(A.h_hi, c->lag.hr[1]);
+                }
             }
         }
     }

@@ -110,6 +110,9 @@ class HipNNPS(object):
         # somebody looks at them (properties below): a steady-state update()
         # makes no device->host round trip
         self._grid = None
+        # the library holds ONE grid per context: remember which update of the context this object's attributes belong to
+        self.ctx._nnps_updates = getattr(self.ctx, '_nnps_updates', 0) + 1
+        self._update_no = self.ctx._nnps_updates
         if self.fixed_h and not self._h_fixed:
             # fixed_h (linked_list_nnps.pyx:54): the smoothing lengths never
             # change, so the range found by this first update stays: later updates
@@ -129,7 +132,16 @@ class HipNNPS(object):
                 self._h_fixed = True
 
     def _read_grid(self):
+        """cell_size, hmin, xmin, xmax, ncells_per_dim, n_cells of THIS object's last
+        update(), read from the library on first use.  Can raise: a bad cell count
+        of an update that made no round trip is reported here (or by the next
+        update, whichever comes first), and the library keeps one grid per context
+        -- after another neighbour search updated the same context this object's
+        grid is gone."""
         if self._grid is None:
+            if getattr(self, '_update_no', None) != getattr(self.ctx, '_nnps_updates', None):
+                raise RuntimeError('the grid attributes of this neighbour search are those of its last update(); another '
+                                   'search has updated the same context since (one grid per context): update() again')
             d8 = (C.c_double * 8)()
             i4 = (C.c_long * 4)()
             rc = self.lib.sph_nnps_info(self.ctx._h, d8, i4)

@@ -488,6 +488,6 @@ def case_steppers():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['kernels', 'sd_1d', 'wcsph_cube_varh', 'tvf_cube',
-                             'wcsph_dam', 'wcsph_dam_varh', 'steppers', 'elastic_2d', 'elastic_3d']
+                             'wcsph_dam', 'wcsph_dam_varh', 'steppers', 'elastic_2d', 'elastic_3d', 'tvf_wall']
     for w in which:
         globals()['case_' + w]()

@@ -173,3 +173,25 @@ def live_rows(pa, prop='x'):
         dev._check(g.lib.sph_array_pull(g.ctx._h, g.array_id, dev.prop_id(q), b.ctypes.data_as(dev._PD), 0, n))
         out[q] = b
     return out[prop][np.abs(out['x']) < 1e17]
+
+
+class _DeviceView(object):
+    """n doubles at a raw device address, for torch.as_tensor (__cuda_array_interface__)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {'shape': (int(n),), 'typestr': '<f8', 'data': (int(ptr), False), 'version': 2}
+
+
+def device_add(pa, prop, delta, n=None):
+    """property `prop` of the DEVICE copy of `pa` += delta (host array, first n rows), written in place on the device
+    through the property's raw pointer -- what a device-resident mover (a stage kernel) does; a host push of positions
+    would make the next neighbour update look at the particles first (positions from the host may lie anywhere).  The
+    host copy is updated alike."""
+    import torch
+    g = pa.gpu
+    n = len(delta) if n is None else n
+    g.ctx.synchronize()
+    t = torch.as_tensor(_DeviceView(g.device_ptr(prop), n), device=torch.device('cuda', g.ctx.device))
+    t += torch.from_numpy(np.ascontiguousarray(delta[:n], dtype=np.float64)).to(t.device)
+    torch.cuda.synchronize()
+    pa.properties[prop][:n] += delta[:n]

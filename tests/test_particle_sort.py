@@ -114,10 +114,16 @@ def test_several_arrays_one_empty(merge):
             assert np.array_equal(nbrs[start[i]:start[i + 1]], want), (s, d, i)
 
 
-def _moved(pa, seed, amp):
+def _moved(pa, seed, amp, on_device=False):
+    """(on_device: in place in device memory, as a stage kernel moves particles; the host copy follows)"""
+    from helpers import device_add
     rng = np.random.default_rng(seed)
     for f in 'xyz':
-        getattr(pa, f)[:] = getattr(pa, f) + amp * (rng.random(pa.x.size) - 0.5)
+        d = amp * (rng.random(pa.x.size) - 0.5)
+        if on_device:
+            device_add(pa, f, d)
+        else:
+            getattr(pa, f)[:] = getattr(pa, f) + d
 
 
 @pytest.mark.parametrize('narr', [1, 3], ids=['one-array', 'merged'])
@@ -139,8 +145,7 @@ def test_update_without_round_trip_reports_the_exact_grid_and_the_same_neighbour
     nn = HipNNPS(3, arrays, radius_scale=2.0, ctx=ctx, sync=False)
     for step in range(3):
         for a in arrays:
-            _moved(a, 100 + step, 0.02 if step < 2 else 0.3)     # the last move throws particles far outside
-            a.gpu.push('x', 'y', 'z')
+            _moved(a, 100 + step, 0.02 if step < 2 else 0.3, on_device=True)     # the last move throws particles far outside
         nn.update()
         fresh_ctx = _ctx()
         copies = [get_particle_array(name=a.name, x=a.x.copy(), y=a.y.copy(), z=a.z.copy(), h=a.h.copy(), m=a.m.copy())
@@ -163,6 +168,75 @@ def test_update_without_round_trip_reports_the_exact_grid_and_the_same_neighbour
     assert nn.cell_size == 2.0 * 0.04
     nn.update()
     assert ctx.timer_get('n_async')[1] == 4
+    ctx.close()
+
+
+def test_evaluation_after_particles_left_the_box_of_the_previous_update_vs_oracle(oracle):
+    """the update that bins on the PREVIOUS update's bounds (no round trip) clamps particles that left that box into its
+    outermost cells: the evaluation on that grid equals the oracle's on the reference's own grid -- every field and the
+    neighbour count of every particle (the lagged path had only been compared with a fresh HipNNPS)."""
+    from helpers import rel_err
+    from pysph_amd import device as dev
+    from pysph_amd import kernels as K
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.nnps import HipNNPS
+    from test_hip_parity import cube_equations, make_cube
+    pa, dx = make_cube(22)
+    eqs = cube_equations(dx)
+    kernel = K.WendlandQuintic(dim=3)
+    ctx = _ctx()
+    ctx.timer_enable(True)
+    dev.attach(pa, ctx).push()
+    a_eval = AccelerationEval([pa], eqs, kernel)
+    SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+    nn = HipNNPS(3, [pa], radius_scale=2.0, ctx=ctx, sync=False)
+    a_eval.set_nnps(nn)
+    nn.update()
+    a_eval.compute(0.0, 1e-5)
+    for step, amp in enumerate((0.01, 0.3, 0.02)):           # the second move throws particles far outside the old box
+        _moved(pa, 300 + step, amp, on_device=True)
+        nn.update()
+        a_eval.compute(0.0, 1e-5)
+        ref = pa.extract_particles(np.arange(pa.get_number_of_particles()), name='fluid')
+        onn = oracle.OracleNNPS(3, [ref], 2.0)
+        onn.update()
+        oev = oracle.OracleEval([ref], eqs, kernel, nthreads=4)
+        oev.set_nnps(onn)
+        oev.compute(0.0, 1e-5)
+        pa.gpu.pull('arho', 'au', 'av', 'aw', 'ax', 'ay', 'az', 'p', 'cs', 'dt_cfl')
+        for f in ('arho', 'au', 'av', 'aw', 'ax', 'ay', 'az', 'p', 'cs', 'dt_cfl'):
+            assert rel_err(pa.get(f), ref.get(f)) < 1e-10, (step, f)
+        start = nn.get_csr_start(0, 0)
+        want = np.array([len(onn.get_nearest_particles(0, 0, i)) for i in range(0, ref.get_number_of_particles(), 97)])
+        assert np.array_equal(np.diff(start.astype(np.int64))[::97], want), step
+    assert ctx.timer_get('n_async')[1] == 3                  # none of the three updates looked at the particles first
+    ctx.close()
+
+
+def test_too_many_cells_after_an_update_without_round_trip_is_raised_by_the_next_update():
+    """linked_list_nnps.pyx:307-343 raises inside update() when the grid needs more than 2^28 cells.  An update that bins on
+    the previous update's bounds learns its own bounds late: the error comes when the grid attributes are read or --
+    nobody reads them in a stepping loop -- from the NEXT update, which would have to bin on that grid (never silently on
+    a clamped one for more than the one update)."""
+    from pysph_amd import device as dev
+    from pysph_amd.nnps import HipNNPS
+    pa = cloud(20000, 9, h=0.002)                # cells of 0.004: a unit box has 250^3 = 1.6e7 of them
+    ctx = _ctx()
+    ctx.timer_enable(True)
+    dev.attach(pa, ctx).push()
+    nn = HipNNPS(3, [pa], radius_scale=2.0, ctx=ctx, sync=False)
+    nn.update()
+    _moved(pa, 1, 0.001, on_device=True)
+    nn.update()
+    from helpers import device_add
+    far = np.zeros(pa.x.size)
+    far[:10] = 5.0                               # ten particles leave: a 6 x 6 x 6 box of 0.004 cells is 3.4e9 cells
+    for f in 'xyz':
+        device_add(pa, f, far)
+    nn.update()                                  # bins on the old box (the ten are clamped into its outermost cells) ...
+    assert ctx.timer_get('n_async')[1] == 3      # (the constructor made the first, looked-at update)
+    with pytest.raises(RuntimeError, match='too many cells'):
+        nn.update()                              # ... and the next update reports what that one found
     ctx.close()
 
 

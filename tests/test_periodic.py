@@ -432,9 +432,9 @@ def test_device_periodic_update_without_round_trip_equals_counted_update(axes):
         out, live = [], []
         for step in range(5):
             if step:
-                for q, amp in zip('xyz', (0.45, -0.3, 0.2)):        # a drift: particles leave through the faces
-                    pa.properties[q][:nreal] += amp * dx
-                pa.gpu.push('x', 'y', 'z')
+                from helpers import device_add
+                for q, amp in zip('xyz', (0.45, -0.3, 0.2)):        # a drift (on the device, as a stage kernel moves
+                    device_add(pa, q, np.full(nreal, amp * dx))     # particles): they leave through the faces
                 nnps.update_domain()        # ghosts dropped, particles wrapped, images made again
                 nnps.update()
             a_eval.compute(0.0, 0.1)
