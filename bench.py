@@ -624,6 +624,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary configurations')
     ap.add_argument('--no-counters', action='store_true', dest='no_counters',
                     help='do not re-run under rocprofv3 --pmc for roofline.traffic (replay profiles/pmc_traffic.json)')
+    ap.add_argument('--image-all-props', action='store_true', help='periodic images carry every device property (the reference\'s copy) instead of the evaluation\'s inputs')
     ap.add_argument('--cpu-n1', type=int, default=0, help='side of the CPU baseline sample (0: the workload\'s own size)')
     ap.add_argument('--fixed-bounds', action='store_true', dest='fixed_bounds',
                     help='hand nnps.update() the grid bounds and the (constant) h range instead of '
@@ -761,6 +762,9 @@ def setup(args, w, rank, world, dist, ctx):
         domain = HipDomainManager(ctx=ctx, slab=halo, **w.domain_kw)
     a_eval = AccelerationEval(w.arrays, w.eqs, w.kernel)
     SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+    if domain is not None and not args.image_all_props:
+        # an image carries what the evaluation reads (a dozen of a Taylor-Green particle's ~35 device properties)
+        domain.set_image_props(a_eval.c_acceleration_eval.inputs)
     h_reduce = None
     if world > 1:
         from pysph_amd.parallel import allreduce_scalars
@@ -837,7 +841,7 @@ def setup(args, w, rank, world, dist, ctx):
         # the round-trip-free exchange learns its ghost counts HERE, with the evaluation queued (the host waits for the
         # transfers only); a face that had outgrown its message was repeated the counted way and the evaluation runs
         # again (as Integrator.compute_accelerations does; never on a benchmark whose particles do not move)
-        while halo is not None and not halo.verify():
+        while not all([v.verify() for v in (halo, domain) if v is not None]):
             nnps.update()
             a_eval.compute(0.0, 1e-5)
     return nnps, a_eval, halo, domain, step, ordered

@@ -274,16 +274,23 @@ __device__ __forceinline__ void emit_pieces(const PA &a, size_t i, const double2
     }
 }
 
+// LAYOUT >= 0: the record layout as a compile-time constant (the hot layouts of the hand-written families: the layout
+// switch folds away, the piece count is a constant, and the record never passes through a dynamically indexed local array
+// -- the one-kernel-for-all form kept 32 B per lane in scratch); -1: PackArgs::layout at run time (every other layout).
+template <int LAYOUT>
 __global__ __launch_bounds__(256) void k_pack(PackArgs a)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     uint32_t o = a.perm[i];
+    const int layout = LAYOUT >= 0 ? LAYOUT : a.layout;
     double4 ph;
     ph.x = a.x[o]; ph.y = a.y[o]; ph.z = a.z[o]; ph.w = a.h[o];
     double v[MAX_AUX];
+    // (compile-time layouts read the slots their record holds: WCSPH u v w m rho tmpj cs p = 0..7, elastic 0..17 + p)
+    constexpr int NV = (LAYOUT == 6 || LAYOUT == 7 || LAYOUT == 12 || LAYOUT == 13) ? 8 : MAX_AUX;
 #pragma unroll
-    for (int k = 0; k < MAX_AUX; k++) v[k] = ((k < a.na || (a.derived == 3 && k == 18) || (a.derived == 4 && k == 4)) && a.src[k]) ? a.src[k][o] : 0.0;
+    for (int k = 0; k < MAX_AUX; k++) v[k] = (k < NV && (k < a.na || (a.derived == 3 && k == 18) || (a.derived == 4 && k == 4)) && a.src[k]) ? a.src[k][o] : 0.0;
     if (a.derived == 1) v[5] = v[4] != 0.0 ? v[7] * (1.0 / (v[4] * v[4])) : 0.0; // tmpj = p*rhoj21, wc/basic.py:211,234
     if (a.derived == 2) { double Vj = 1. / v[8]; v[10] = Vj * Vj; } // Vj2, transport_velocity.py:303-306
     if (a.derived == 4) v[3] = v[3] / v[4]; // m/rho, basic_equations.py:103,139 (VelocityGradient tmp)
@@ -304,42 +311,42 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
 #pragma unroll
         for (int q = 0; q < PACK_MAXP; q++) pc[q] = make_double2(0.0, 0.0);
         int np;
-        if (a.layout == 6) { // WCSPH with the EOS fused into the pair kernel: one 64-B half line per record
+        if (layout == 6) { // WCSPH with the EOS fused into the pair kernel: one 64-B half line per record
             pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, v[0]);
             pc[2] = make_double2(v[1], v[2]); pc[3] = make_double2(v[4], a.umass ? v[5] : v[3]); // [rho m], uniform mass: [rho p/rho^2]
             np = 4;
-        } else if (a.layout == 7) {
+        } else if (layout == 7) {
             pc[0] = __builtin_bit_cast(double2, make_float4((float)(ph.x - a.gmin[0]), (float)(ph.y - a.gmin[1]),
                                                             (float)(ph.z - a.gmin[2]), (float)v[0]));
             pc[1] = __builtin_bit_cast(double2, make_float4((float)v[1], (float)v[2], (float)v[4], (float)(a.umass ? v[5] : v[3])));
             np = 2;
-        } else if (a.layout == 8) { // TVF with the state equation fused: [x y | z rho | u v | w uhat | vhat what] (no artificial stress: 4 pieces)
+        } else if (layout == 8) { // TVF with the state equation fused: [x y | z rho | u v | w uhat | vhat what] (no artificial stress: 4 pieces)
             pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, v[6]);
             pc[2] = make_double2(v[0], v[1]); pc[3] = make_double2(v[2], v[3]);
             pc[4] = make_double2(v[4], v[5]);
             np = a.nr / 2;
-        } else if (a.layout == 9) { // the same in fp32: [x-x0 y-y0 z-z0 rho | u v w uhat | vhat what - -]
+        } else if (layout == 9) { // the same in fp32: [x-x0 y-y0 z-z0 rho | u v w uhat | vhat what - -]
             pc[0] = __builtin_bit_cast(double2, make_float4((float)(ph.x - a.gmin[0]), (float)(ph.y - a.gmin[1]),
                                                             (float)(ph.z - a.gmin[2]), (float)v[6]));
             pc[1] = __builtin_bit_cast(double2, make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]));
             pc[2] = __builtin_bit_cast(double2, make_float4((float)v[4], (float)v[5], 0.f, 0.f));
             np = a.nr / 4;
-        } else if (a.layout == 12) { // WCSPH, variable h, one mass, EOS recomputed: [x y | z h | u v | w rho]
+        } else if (layout == 12) { // WCSPH, variable h, one mass, EOS recomputed: [x y | z h | u v | w rho]
             pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, ph.w);
             pc[2] = make_double2(v[0], v[1]); pc[3] = make_double2(v[2], v[4]);
             np = 4;
-        } else if (a.layout == 13) { // the same in fp32: [x y z h | u v w rho]
+        } else if (layout == 13) { // the same in fp32: [x y z h | u v w rho]
             pc[0] = __builtin_bit_cast(double2, make_float4((float)(ph.x - a.gmin[0]), (float)(ph.y - a.gmin[1]),
                                                             (float)(ph.z - a.gmin[2]), (float)ph.w));
             pc[1] = __builtin_bit_cast(double2, make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[4]));
             np = 2;
-        } else if (a.layout == 10) { // elastic, uniform h and mass: [x y | z u | v w | rho cs | t x6 | r x6]
+        } else if (layout == 10) { // elastic, uniform h and mass: [x y | z u | v w | rho cs | t x6 | r x6]
             pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, v[0]);
             pc[2] = make_double2(v[1], v[2]); pc[3] = make_double2(v[4], v[5]);
 #pragma unroll
             for (int q = 0; q < 6; q++) pc[4 + q] = make_double2(v[6 + 2 * q], v[7 + 2 * q]);
             np = 10;
-        } else if (a.layout == 11) { // the same in fp32: [x y z u | v w rho cs | t t t t | t t r r | r r r r]
+        } else if (layout == 11) { // the same in fp32: [x y z u | v w rho cs | t t t t | t t r r | r r r r]
             pc[0] = __builtin_bit_cast(double2, make_float4((float)(ph.x - a.gmin[0]), (float)(ph.y - a.gmin[1]),
                                                             (float)(ph.z - a.gmin[2]), (float)v[0]));
             pc[1] = __builtin_bit_cast(double2, make_float4((float)v[1], (float)v[2], (float)v[4], (float)v[5]));
@@ -347,12 +354,12 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
             for (int q = 0; q < 3; q++)
                 pc[2 + q] = __builtin_bit_cast(double2, make_float4((float)v[6 + 4 * q], (float)v[7 + 4 * q], (float)v[8 + 4 * q], (float)v[9 + 4 * q]));
             np = 5;
-        } else if (a.layout == 1) { // WCSPH [x y | z cs | u v | w m | rho tmpj] (+ [h p]: variable h / tensile correction)
+        } else if (layout == 1) { // WCSPH [x y | z cs | u v | w m | rho tmpj] (+ [h p]: variable h / tensile correction)
             pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, v[6]);
             pc[2] = make_double2(v[0], v[1]); pc[3] = make_double2(v[2], v[3]);
             pc[4] = make_double2(v[4], v[5]); pc[5] = make_double2(ph.w, v[7]);
             np = a.nr / 2;
-        } else if (a.layout == 5) { // fp32 records [x-x0 y-y0 z-z0 h | aux...] (option record_f32), a.nr floats
+        } else if (layout == 5) { // fp32 records [x-x0 y-y0 z-z0 h | aux...] (option record_f32), a.nr floats
             float w[4 + MAX_AUX];
             w[0] = (float)(ph.x - a.gmin[0]); w[1] = (float)(ph.y - a.gmin[1]); w[2] = (float)(ph.z - a.gmin[2]);
             w[3] = (float)ph.w;
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
             for (int q = 0; q < (4 + MAX_AUX) / 4; q++)
                 pc[q] = __builtin_bit_cast(double2, make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]));
             np = a.nr / 4;
-        } else if (a.layout == 4) { // generated families under uniform h: [x y z | aux...] (h is a launch constant)
+        } else if (layout == 4) { // generated families under uniform h: [x y z | aux...] (h is a launch constant)
             double w[3 + MAX_AUX + 1];
             w[0] = ph.x; w[1] = ph.y; w[2] = ph.z;
 #pragma unroll
@@ -370,13 +377,13 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
 #pragma unroll
             for (int q = 0; q < (3 + MAX_AUX + 1) / 2; q++) pc[q] = make_double2(w[2 * q], w[2 * q + 1]);
             np = (a.nr + 1) / 2;
-        } else if (a.layout == 3) { // TVF under uniform h: [x y | z rho | u v | w p | Vj2 what | uhat vhat] (+ [m -] with artificial viscosity)
+        } else if (layout == 3) { // TVF under uniform h: [x y | z rho | u v | w p | Vj2 what | uhat vhat] (+ [m -] with artificial viscosity)
             pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, v[6]);
             pc[2] = make_double2(v[0], v[1]); pc[3] = make_double2(v[2], v[7]);
             pc[4] = make_double2(v[10], v[5]); pc[5] = make_double2(v[3], v[4]);
             pc[6] = make_double2(v[9], 0.0);
             np = a.nr > 12 ? 7 : 6;
-        } else if (a.layout == 2) { // compact density records [x y z m] (uniform h)
+        } else if (layout == 2) { // compact density records [x y z m] (uniform h)
             pc[0] = make_double2(ph.x, ph.y); pc[1] = make_double2(ph.z, v[0]);
             np = 2;
         } else { // [x y z h | aux...]
@@ -414,6 +421,8 @@ struct PackMArgs {
     uint32_t *rho_flag;            // device word: set to 1 when a density is not positive (the class bit is the SIGN of rho)
 };
 
+// (F32, VH: PackMArgs::f32 / vh as compile-time constants -- the piece count of the record is then one too)
+template <bool F32, bool VH>
 __global__ __launch_bounds__(256) void k_pack_merged(PackMArgs a)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -432,22 +441,22 @@ __global__ __launch_bounds__(256) void k_pack_merged(PackMArgs a)
     // outside the domain with rho = 0, are nobody's neighbour)
     if (!(rho > 0.0) && fabs(v[0]) < SPH_PARKED_MIN) atomicOr(a.rho_flag, 1u);
     double hp = 0.0;
-    if (a.vh) hp = kernarg_read<const double *>(__builtin_offsetof(PackMArgs, prop) + ((size_t)8 * SPH_MAX_ARRAYS + sl) * sizeof(double *))[o];
+    if (VH) hp = kernarg_read<const double *>(__builtin_offsetof(PackMArgs, prop) + ((size_t)8 * SPH_MAX_ARRAYS + sl) * sizeof(double *))[o];
     a.fpos[i] = make_float4((float)(v[0] - a.gmin[0]), (float)(v[1] - a.gmin[1]), (float)(v[2] - a.gmin[2]),
-                            a.vh ? (float)(a.hr * hp) : (float)a.hr); // hr: radius_scale * h, or radius_scale alone with variable h
+                            VH ? (float)(a.hr * hp) : (float)a.hr); // hr: radius_scale * h, or radius_scale alone with variable h
     double2 pc[PACK_MAXP];
 #pragma unroll
     for (int k = 0; k < PACK_MAXP; k++) pc[k] = make_double2(0.0, 0.0);
     int np;
-    if (a.vh && a.f32) {
+    if (VH && F32) {
         pc[0] = __builtin_bit_cast(double2, make_float4((float)(v[0] - a.gmin[0]), (float)(v[1] - a.gmin[1]), (float)(v[2] - a.gmin[2]), (float)hp));
         pc[1] = __builtin_bit_cast(double2, make_float4((float)v[3], (float)v[4], (float)v[5], (float)srho));
         np = 2;
-    } else if (a.vh) {
+    } else if (VH) {
         pc[0] = make_double2(v[0], v[1]); pc[1] = make_double2(v[2], hp);
         pc[2] = make_double2(v[3], v[4]); pc[3] = make_double2(v[5], srho);
         np = 4;
-    } else if (a.f32) {
+    } else if (F32) {
         pc[0] = __builtin_bit_cast(double2, make_float4((float)(v[0] - a.gmin[0]), (float)(v[1] - a.gmin[1]), (float)(v[2] - a.gmin[2]), (float)v[3]));
         pc[1] = __builtin_bit_cast(double2, make_float4((float)v[4], (float)v[5], (float)srho, (float)q));
         np = 2;
@@ -1477,6 +1486,22 @@ static int pack_pieces(const PackArgs &pa)
 
 // `launch` false: validate only (the records of this array are already in the packed buffer, see
 // the pack cache in sph_eval_group)
+// k_pack with the layout as a compile-time constant where the library has an instantiation
+static void launch_pack(sph_ctx *c, const PackArgs &pa, size_t n)
+{
+    const dim3 g(div_up(n, 256)), b(256);
+    const size_t lds = (size_t)pa.lds_np * 256 * 16;
+    switch (pa.rec ? pa.layout : -1) {
+    case 6: hipLaunchKernelGGL(k_pack<6>, g, b, lds, c->stream, pa); break;
+    case 7: hipLaunchKernelGGL(k_pack<7>, g, b, lds, c->stream, pa); break;
+    case 10: hipLaunchKernelGGL(k_pack<10>, g, b, lds, c->stream, pa); break;
+    case 11: hipLaunchKernelGGL(k_pack<11>, g, b, lds, c->stream, pa); break;
+    case 12: hipLaunchKernelGGL(k_pack<12>, g, b, lds, c->stream, pa); break;
+    case 13: hipLaunchKernelGGL(k_pack<13>, g, b, lds, c->stream, pa); break;
+    default: hipLaunchKernelGGL(k_pack<-1>, g, b, lds, c->stream, pa); break;
+    }
+}
+
 static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fam, uint32_t flags, bool dest_only = false,
                       bool launch = true, int seg = 0)
 {
@@ -1540,7 +1565,7 @@ static int pack_array(sph_ctx *c, int id, size_t off, const PackPlan &pl, int fa
         pa.derived = 0;
     }
     pa.lds_np = pack_pieces(pa);
-    if (launch) hipLaunchKernelGGL(k_pack, dim3(div_up(nseg, 256)), dim3(256), (size_t)pa.lds_np * 256 * 16, c->stream, pa);
+    if (launch) launch_pack(c, pa, nseg);
     return SPH_OK;
 }
 
@@ -1840,7 +1865,12 @@ static int eval_group_merged(sph_ctx *c, const sph_kernel *K, const sph_group *g
         pa.vh = vh ? 1 : 0;
         pa.hr = vh ? c->radius_scale : c->radius_scale * c->h_uniform;
         pa.rho_flag = c->xflag.as<uint32_t>();
-        hipLaunchKernelGGL(k_pack_merged, dim3(div_up(M.n, 256)), dim3(256), (size_t)pa.lds_np * 256 * 16, c->stream, pa);
+        const dim3 pg(div_up(M.n, 256)), pb(256);
+        const size_t plds = (size_t)pa.lds_np * 256 * 16;
+        if (f32 && vh) hipLaunchKernelGGL((k_pack_merged<true, true>), pg, pb, plds, c->stream, pa);
+        else if (f32) hipLaunchKernelGGL((k_pack_merged<true, false>), pg, pb, plds, c->stream, pa);
+        else if (vh) hipLaunchKernelGGL((k_pack_merged<false, true>), pg, pb, plds, c->stream, pa);
+        else hipLaunchKernelGGL((k_pack_merged<false, false>), pg, pb, plds, c->stream, pa);
     }
     ScopedTimer tm(c, T_PAIR);
     ScopedTimer tmf(c, T_PAIR_FAM + FAM_WCSPH);
@@ -2324,7 +2354,7 @@ static int pack_generic(sph_ctx *c, int id, size_t off, int nprops, const int *p
     for (int k = 0; k < 3; k++) pa.gmin[k] = c->xmin[k];
     pa.radius_scale = c->radius_scale;
     pa.lds_np = pack_pieces(pa);
-    hipLaunchKernelGGL(k_pack, dim3(div_up(A.n, 256)), dim3(256), (size_t)pa.lds_np * 256 * 16, c->stream, pa);
+    launch_pack(c, pa, A.n);
     return SPH_OK;
 }
 

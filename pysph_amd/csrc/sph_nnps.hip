@@ -13,6 +13,7 @@
 // The grid itself (bounds, 1 % padding, cell size, cells per dimension, error
 // conditions) is computed on the host in the reference's exact arithmetic.
 #include "sph_internal.h"
+#include "sph_kernels.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -35,6 +36,12 @@ __device__ inline double wave_max(double v)
 struct GridDesc {
     double xmin[3];
     double cell_size;
+    // 1 / (a cell wider than cell_size by 4 ulp): the BINNING cell.  A cell coordinate is floor((x - xmin) * inv_cell) --
+    // one multiplication where the reference divides (nnps_base.pxd:39-57; three fp64 divisions were 45 of k_bin_keys'
+    // ~310 instructions per 64 particles).  Any monotone map onto cells at least radius_scale * hmax wide finds the same
+    // neighbours (section 3 of DESIGN.md); the reference's own cell ids are what sph_nnps_info REPORTS, computed apart.
+    // Every site that derives a cell from a position uses cell_coord() below.
+    double inv_cell;
     int nc[3];
     // PARKING bins behind the grid's own in the tables (or none): where parked padding rows are binned -- cells no
     // destination visits, at the end of the cell order (wavefronts made of them find no active destination)
@@ -51,12 +58,20 @@ struct GridDesc {
 // A particle outside the grid is clamped into its outermost cells: neighbours
 // are found by the distance criterion, and two particles closer than a cell size
 // stay in adjacent (or the same) cells under the clamp.
+static inline void grid_set_cell(GridDesc &g, double cell_size)
+{
+    g.cell_size = cell_size;
+    g.inv_cell = cell_size > 0.0 ? (1.0 / cell_size) * (1.0 - 4.0 * DBL_EPSILON) : 0.0;
+}
+// position -> (unclamped) cell coordinate along one axis, in units of the binning cell
+__device__ __forceinline__ double cell_coord(double v, double vmin, const GridDesc &g) { return (v - vmin) * g.inv_cell; }
+
 __device__ __forceinline__ uint32_t fine_key(double x, double y, double z, const GridDesc &g)
 {
-    const double ux = (x - g.xmin[0]) / g.cell_size;
+    const double ux = cell_coord(x, g.xmin[0], g);
     int cx = (int)floor(ux);
-    int cy = (int)floor((y - g.xmin[1]) / g.cell_size);
-    int cz = (int)floor((z - g.xmin[2]) / g.cell_size);
+    int cy = (int)floor(cell_coord(y, g.xmin[1], g));
+    int cz = (int)floor(cell_coord(z, g.xmin[2], g));
     int sub = (int)floor((ux - (double)cx) * SPH_NSUB);
     if (cx < 0) { cx = 0; sub = 0; }
     if (cx > g.nc[0] - 1) { cx = g.nc[0] - 1; sub = SPH_NSUB - 1; }
@@ -159,13 +174,14 @@ __global__ __launch_bounds__(256) void k_bin_keys(BinArrays t, GridDesc g, BinWo
         const size_t j = valid && via ? (size_t)via[i] : i; // the particle this thread takes
         if (valid) { px = x[j]; py = y[j]; pz = z[j]; }
         const bool counts = valid && !is_parked(px); // padding rows (sph_halo_append_padded) are nobody's bounds, h or m
+        // (raw_min / raw_max: ONE v_min_f64 / v_max_f64 each; fmin / fmax put a canonicalising v_max x, x in front)
         if (counts && mmx) {
-            mn[0] = fmin(mn[0], px); mx[0] = fmax(mx[0], px);
-            mn[1] = fmin(mn[1], py); mx[1] = fmax(mx[1], py);
-            mn[2] = fmin(mn[2], pz); mx[2] = fmax(mx[2], pz);
+            mn[0] = raw_min(mn[0], px); mx[0] = raw_max(mx[0], px);
+            mn[1] = raw_min(mn[1], py); mx[1] = raw_max(mx[1], py);
+            mn[2] = raw_min(mn[2], pz); mx[2] = raw_max(mx[2], pz);
         }
-        if (counts && h) { const double v = h[j]; mn[3] = fmin(mn[3], v); mx[3] = fmax(mx[3], v); }
-        if (counts && m) { const double v = m[j]; mn[4] = fmin(mn[4], v); mx[4] = fmax(mx[4], v); }
+        if (counts && h) { const double v = h[j]; mn[3] = raw_min(mn[3], v); mx[3] = raw_max(mx[3], v); }
+        if (counts && m) { const double v = m[j]; mn[4] = raw_min(mn[4], v); mx[4] = raw_max(mx[4], v); }
         if (w.keys) {
             uint32_t key = 0;
             if (valid) { key = fine_key_of(px, py, pz, g, (size_t)t.off[a] + j); w.keys[(size_t)t.off[a] + i] = key; }
@@ -1409,8 +1425,11 @@ static void nnps_face_planes(sph_ctx *c)
     c->gfx_lo = -0x7fffffff; c->gfx_hi = 0x7fffffff; // no faces named: no wavefront is a face wavefront
     if (c->face_axis < 0) return;
     if (c->face_axis != 0) { c->gfx_lo = 0x7fffffff; c->gfx_hi = -0x7fffffff; return; } // rows run along x: every wavefront may see ghosts
-    const double binw = c->cell_size / SPH_NSUB;
-    const double flo = floor((c->face_lo - c->xmin[0]) / binw), fhi = floor((c->face_hi - c->xmin[0]) / binw);
+    // the fine x index of the face planes by the keys' own (monotone) map: a ghost at x < face_lo has an index <= the
+    // plane's, one at x >= face_hi an index >= the plane's
+    GridDesc g;
+    grid_set_cell(g, c->cell_size);
+    const double flo = floor((c->face_lo - c->xmin[0]) * g.inv_cell * SPH_NSUB), fhi = floor((c->face_hi - c->xmin[0]) * g.inv_cell * SPH_NSUB);
     c->gfx_lo = !(flo > -1e9) ? -0x7fffffff : (flo > 1e9 ? 0x7fffffff : (int)flo); // ghosts: fx <= gfx_lo ...
     c->gfx_hi = !(fhi < 1e9) ? 0x7fffffff : (fhi < -1e9 ? -0x7fffffff : (int)fhi);  // ... or fx >= gfx_hi
 }
@@ -1571,7 +1590,7 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
     c->n_cells = n_cells_tab;
     GridDesc g;
     for (int k = 0; k < 3; k++) { g.xmin[k] = c->xmin[k]; g.nc[k] = c->nc[k]; }
-    g.cell_size = cell_size;
+    grid_set_cell(g, cell_size);
     g.park_base = (uint32_t)(n_cells_alloc * SPH_NSUB); g.park_bins = (uint32_t)(park_cells * SPH_NSUB); g.park_n = (uint32_t)n_cat;
     const size_t n_fine = (size_t)n_cells_tab * SPH_NSUB;
 
@@ -1718,7 +1737,7 @@ extern "C" int sph_nnps_update_ghosts(sph_ctx *c, int axis, double lo, double hi
     }
     GridDesc g;
     for (int k = 0; k < 3; k++) { g.xmin[k] = c->xmin[k]; g.nc[k] = c->nc[k]; }
-    g.cell_size = c->cell_size;
+    grid_set_cell(g, c->cell_size);
     g.park_base = (uint32_t)((c->n_cells - c->park_cells) * SPH_NSUB); g.park_bins = (uint32_t)(c->park_cells * SPH_NSUB);
     g.park_n = 1; // (set per array below: the ghost segment's own row count)
     const size_t n_fine = (size_t)c->n_cells * SPH_NSUB;
@@ -1845,9 +1864,9 @@ __global__ __launch_bounds__(256) void k_csr(const double *__restrict__ dx, cons
     if (i >= nd) return;
     double x = dx[i], y = dy[i], z = dz[i];
     // (clamped like the keys: a particle outside the grid lives in its outermost cells)
-    int cx = min(max((int)floor((x - g.xmin[0]) / g.cell_size), 0), g.nc[0] - 1);
-    int cy = min(max((int)floor((y - g.xmin[1]) / g.cell_size), 0), g.nc[1] - 1);
-    int cz = min(max((int)floor((z - g.xmin[2]) / g.cell_size), 0), g.nc[2] - 1);
+    int cx = min(max((int)floor(cell_coord(x, g.xmin[0], g)), 0), g.nc[0] - 1);
+    int cy = min(max((int)floor(cell_coord(y, g.xmin[1], g)), 0), g.nc[1] - 1);
+    int cz = min(max((int)floor(cell_coord(z, g.xmin[2], g)), 0), g.nc[2] - 1);
     double hi2 = radius_scale * dh[i];
     hi2 *= hi2;
     uint32_t count = 0;
@@ -1898,7 +1917,7 @@ extern "C" int sph_nnps_get_csr(sph_ctx *c, int src, int dst, uint32_t *start, s
     }
     GridDesc g;
     for (int k = 0; k < 3; k++) { g.xmin[k] = c->xmin[k]; g.nc[k] = c->nc[k]; }
-    g.cell_size = c->cell_size;
+    grid_set_cell(g, c->cell_size);
     g.park_base = g.park_bins = g.park_n = 0;
     SPH_TRY(c->tmp_u32a.reserve((nd + 1) * 4));
     uint32_t *d_start = c->tmp_u32a.as<uint32_t>();
@@ -1952,7 +1971,7 @@ int nnps_build_csr_device(sph_ctx *c, int src, int dst, DevBuf &start, DevBuf &n
     const size_t nd = D.n;
     GridDesc g;
     for (int k = 0; k < 3; k++) { g.xmin[k] = c->xmin[k]; g.nc[k] = c->nc[k]; }
-    g.cell_size = c->cell_size;
+    grid_set_cell(g, c->cell_size);
     g.park_base = g.park_bins = g.park_n = 0;
     SPH_TRY(start.reserve((nd + 2) * 4));
     SPH_TRY(c->tmp_u32a.reserve((nd + 2) * 4));

@@ -162,20 +162,52 @@ class HipDomainManager(_DomainBase):
         processing the axes one after the other, nnps_base.pyx:751-940)."""
         ctx = kw.pop('ctx', None)
         self.slab = kw.pop('slab', None)
-        # 'counted' (default): every periodic axis reads its two image counts back (exact sizes, four device->host round
-        # trips per update).  'padded' (opt-in): a steady-state update makes the images without a round trip, into fixed
-        # capacities sized from the previous update's counts plus `headroom` (sph_domain_images_padded) -- 2 % faster on
-        # Taylor-Green at 4 M, but an image count that grows by more than the headroom within ONE update is an error one
-        # update late, and for a lattice the counts are quantised: when a lattice plane drifts across the threshold a
-        # whole layer (a third of a three-layer face) enters at once.  headroom 0.5 covers that and costs what it saves.
-        self.protocol = kw.pop('protocol', os.environ.get('SPH_DOMAIN_PROTOCOL', 'counted'))
+        # 'padded' (default since round 6): a steady-state update makes the images without a device->host round trip,
+        # into fixed capacities sized from the previous update's counts plus `headroom` (sph_domain_images_padded); the
+        # counts are read by `verify()` once the evaluation that uses the images is QUEUED (the host waits for the image
+        # kernels only) and images that did not fit -- for a lattice the counts are quantised: a plane that drifts across
+        # the threshold brings a whole layer at once -- are made again by a counted update before anything consumes the
+        # evaluation (Integrator.compute_accelerations and bench.py repeat it then).  Unverified, images that did not fit
+        # are an error of the next update.  'counted': every periodic axis reads its two image counts back (exact sizes,
+        # four round trips per update; the reference's own order of things, nnps_base.pyx:751-940).
+        self.protocol = kw.pop('protocol', os.environ.get('SPH_DOMAIN_PROTOCOL', 'padded'))
         self.headroom = float(kw.pop('headroom', os.environ.get('SPH_DOMAIN_HEADROOM', '0.125')))
+        # the properties an image carries: None = every device property of the array (what the reference copies,
+        # nnps_base.pyx:828-856); {array name: names} = those only (set_image_props: an evaluator's inputs -- a dozen
+        # of the ~35 properties of a Taylor-Green particle; the rest of an image's row is undefined)
+        self.image_props = kw.pop('image_props', None)
         _DomainBase.__init__(self, *args, **kw)
         self.ctx = ctx or dev.get_context()
         self.lib = self.ctx.lib
         self._caps = None           # {(helper index, axis): [cap_lo, cap_hi]} once a counted update has run
         self._queued = False        # counts of the last padded update are on their way to the host
         self.padded_updates = 0
+        self.repaired_updates = 0   # padded updates whose images did not fit: made again, counted (verify)
+
+    def set_image_props(self, mapping):
+        """restrict the images to the properties somebody reads: {array name: property names}, e.g. the `inputs` of the
+        compiled acceleration evaluator; x, y, z, h, m always travel"""
+        self.image_props = {k: sorted(set(v) | set(('x', 'y', 'z', 'h', 'm'))) for k, v in dict(mapping).items()}
+
+    def _props_of(self, helper):
+        have = helper.device_props()
+        if self.image_props is None or helper._pa.name not in self.image_props:
+            return have
+        want = set(dev.prop_id(p) for p in self.image_props[helper._pa.name])
+        return [p for p in have if p in want]
+
+    def verify(self):
+        """True when the images of the last update were complete; False after images that did not fit their capacities
+        were made again by a counted update -- repeat the neighbour update and the evaluation then.  To be called with
+        the evaluation queued and nothing having consumed it (as SlabDecomposition.verify)."""
+        if not self._queued:
+            return True
+        if self._collect_counts(raise_on_overflow=False):
+            return True
+        self.repaired_updates += 1
+        self._caps = None
+        self.update()               # counted (no capacities): exact sizes; box-wrapping again changes nothing
+        return False
 
     def set_particles(self, particles, radius_scale):
         _DomainBase.set_particles(self, particles, radius_scale)
@@ -209,9 +241,9 @@ class HipDomainManager(_DomainBase):
         # (empty destination tiles): measured on Taylor-Green, 9 % padding rows = +0.15 ms, 2 % = nothing
         return int(count) + int(int(count) * self.headroom) + 1024
 
-    def _collect_counts(self):
-        """counts of the last padded update, read now (an update later): the capacities follow them; images that did
-        not fit are an error of the step that used them"""
+    def _collect_counts(self, raise_on_overflow=True):
+        """counts of the last padded update, read now: the capacities follow them.  Images that did not fit: False
+        (verify repairs them) or, unverified at the next update, an error of the step that used them"""
         out = (C.c_double * (dev.MAX_ARRAYS * 6))()
         dev._check(self.lib.sph_domain_counts_collect(self.ctx._h, out))
         self._queued = False
@@ -221,14 +253,18 @@ class HipDomainManager(_DomainBase):
                 cnt = out[aid * 6 + ax * 2 + side]
                 if cnt < 0:
                     self._caps = None
+                    if not raise_on_overflow:
+                        return False
                     raise RuntimeError(
-                        "periodic images of array '%s', axis %d: %d rows did not fit their capacity of %d -- the last "
-                        "evaluation ran with images missing (SPH_DOMAIN_PROTOCOL=counted sizes every update exactly)"
+                        "periodic images of array '%s', axis %d: %d rows did not fit their capacity of %d and nobody "
+                        "verified the update -- the last evaluation ran with images missing (call verify() once the "
+                        "evaluation is queued: it makes them again; SPH_DOMAIN_PROTOCOL=counted sizes every update exactly)"
                         % (self.helpers[k]._pa.name, ax, int(-cnt), caps[side]))
                 cnt = int(cnt)
                 if cnt + int(cnt * self.headroom * 0.6) + 512 > caps[side] or \
                         cnt + int(cnt * self.headroom * 2) + 4096 < caps[side]:
                     caps[side] = self._capacity(cnt)
+        return True
 
     def _hmax(self):
         ids = (C.c_int * len(self.helpers))(*[h.array_id for h in self.helpers])
@@ -269,7 +305,7 @@ class HipDomainManager(_DomainBase):
         new_caps = {}
         for k, h in enumerate(self.helpers):
             aid = h.array_id
-            props = h.device_props()
+            props = self._props_of(h)
             nprops = len(props)
             pr = (C.c_int * max(nprops, 1))(*props)
             for ax in range(3):

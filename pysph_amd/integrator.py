@@ -120,8 +120,11 @@ class Integrator(object):
         # nothing having consumed it yet -- a face that had outgrown its message has been repeated the
         # counted way by verify(), and the update + evaluation (which only read the particles' state and
         # overwrite their own results) run again.
-        verify = getattr(pm, 'verify', None) if (pm and update_nnps) else None
-        while verify is not None and not verify():
+        checks = [getattr(pm, 'verify', None) if pm else None,
+                  # ... and the periodic images of a device domain manager made without a round trip (update_domain)
+                  getattr(getattr(self.nnps, 'domain', None), 'verify', None)]
+        checks = [v for v in checks if v is not None and update_nnps]
+        while not all([v() for v in checks]):
             self.nnps.update()
             self.acceleration_evals[index].compute(c.t, c.dt)
 

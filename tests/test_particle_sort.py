@@ -30,10 +30,13 @@ def _ctx():
 def host_fine_keys(pa, nn):
     """csrc/sph_nnps.hip fine_key on the host (same arithmetic, fp64)"""
     xmin, cs, nc = nn.xmin, nn.cell_size, nn.ncells_per_dim
-    ux = (np.asarray(pa.x) - xmin[0]) / cs
+    # cell_coord(): ONE multiplication by the reciprocal of a binning cell 4 ulp wider than the reference's (round 6; the
+    # reference divides by cell_size, nnps_base.pxd:39-57 -- its own cell ids are what the grid attributes report)
+    inv = (1.0 / cs) * (1.0 - 4.0 * np.finfo(np.float64).eps)
+    ux = (np.asarray(pa.x) - xmin[0]) * inv
     cx = np.floor(ux).astype(np.int64)
-    cy = np.floor((np.asarray(pa.y) - xmin[1]) / cs).astype(np.int64)
-    cz = np.floor((np.asarray(pa.z) - xmin[2]) / cs).astype(np.int64)
+    cy = np.floor((np.asarray(pa.y) - xmin[1]) * inv).astype(np.int64)
+    cz = np.floor((np.asarray(pa.z) - xmin[2]) * inv).astype(np.int64)
     sub = np.floor((ux - cx) * NSUB).astype(np.int64)
     lo, hi = cx < 0, cx > nc[0] - 1
     cx = np.clip(cx, 0, nc[0] - 1)

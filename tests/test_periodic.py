@@ -460,6 +460,63 @@ def test_device_periodic_update_without_round_trip_equals_counted_update(axes):
         dom.update()
 
 
+@pytest.mark.gpu
+def test_default_periodic_update_repairs_images_that_did_not_fit():
+    """Round 6: the round-trip-free periodic update is the DEFAULT.  Its capacities follow the previous update's counts
+    with some headroom -- which a lattice plane drifting across an image threshold overruns at scale (a whole layer
+    enters at once; here: capacities of count + 8 rows make a 16^2 plane do it).  verify(), called with the
+    evaluation queued, makes the missing images by a counted update and says so; the evaluation then runs again: the
+    densities equal the counted protocol's update after update.  Images restricted to what the evaluation
+    reads (set_image_props) give the same densities."""
+    from helpers import device_add
+    from pysph_amd import device as dev
+    from pysph_amd import kernels as K
+    from pysph_amd.acceleration_eval import AccelerationEval, SPHCompiler
+    from pysph_amd.domain import HipDomainManager
+    from pysph_amd.equations import Group, TVFSummationDensity
+    from pysph_amd.nnps import HipNNPS
+    kernel = K.QuinticSpline(dim=3)
+    kw = {}
+    for ax in 'xyz':
+        kw.update({ax + 'min': 0.0, ax + 'max': 1.0, 'periodic_in_' + ax: True})
+    runs = {}
+    for mode in ('default', 'restricted', 'counted'):
+        pa, dx = lattice(16, dim=3, hdx=1.2)
+        ctx = dev.HipContext(0)
+        dev.attach(pa, ctx).push()
+        a_eval = AccelerationEval([pa], [Group(equations=[TVFSummationDensity('fluid', ['fluid'])])], kernel)
+        SPHCompiler(a_eval, ctx=ctx, sync='manual').compile()
+        dom = HipDomainManager(ctx=ctx, **(dict(kw, protocol='counted') if mode == 'counted' else kw))
+        assert dom.protocol == ('counted' if mode == 'counted' else 'padded')
+        if mode == 'restricted':
+            dom.set_image_props(a_eval.c_acceleration_eval.inputs)
+        dom._capacity = lambda count: int(count) + 8
+        nnps = HipNNPS(3, [pa], radius_scale=kernel.radius_scale, ctx=ctx, domain=dom, sync=False)
+        a_eval.set_nnps(nnps)
+        nreal = pa.gpu.get_number_of_particles(True)
+        out = []
+        for step in range(6):
+            if step:
+                for q, amp in zip('xyz', (0.45, -0.3, 0.2)):        # the exact lattice drifts: whole planes cross the thresholds
+                    device_add(pa, q, np.full(nreal, amp * dx))
+                nnps.update_domain()
+                nnps.update()
+            a_eval.compute(0.0, 0.1)
+            while not dom.verify():
+                nnps.update()
+                a_eval.compute(0.0, 0.1)
+            pa.gpu.pull('V')
+            out.append(pa.V[:nreal].copy())
+        runs[mode] = (out, dom.padded_updates, dom.repaired_updates, len(dom._props_of(dom.helpers[0])))
+    for mode in ('default', 'restricted'):
+        for a, b in zip(runs[mode][0], runs['counted'][0]):
+            # (same image SETS; a repaired step sorts its particles on another binning grid -- the bounds of its own first
+            # update instead of the previous step's -- and sums in another order: equal to rounding)
+            assert np.max(np.abs(a - b)) <= 1e-13 * np.max(np.abs(b)), mode
+        assert runs[mode][1] >= 3 and runs[mode][2] >= 1, runs[mode][1:]       # padded updates; at least one was repaired
+    assert runs['restricted'][3] < runs['default'][3]
+
+
 # ---------------------------------------------------------------------------
 # pysph/base/tests/test_domain_manager.py: periodic box, every property of a
 # ghost is the property of its original; box wrapping of particles that left
