@@ -201,6 +201,7 @@ def make_elastic(n1):
 
 class Workload(object):
     """particle arrays + equations + kernel (+ periodic domain) of one rank"""
+    ghost_parts = None    # --emulate-rank: per array, the ghost rows a rank's neighbours would send (appended by setup)
     domain_kw = None      # HipDomainManager arguments (periodic workloads)
     scaling = 'weak'
     algo_pair = ALGO_BYTES_PAIR   # algorithmic bytes of the pair passes of one evaluation, per real particle of arrays[0]
@@ -300,14 +301,31 @@ def build_workload(args, rank, world):
             elo = -1e30 if er == 0 else float(cuts[er])
             ehi = 1e30 if er == ew - 1 else float(cuts[er + 1])
             width = db.create_kernel().radius_scale * 1.3 * args.dx
-            cut = []
+            cut, ghosts_of = [], []
             for a in arrays:
                 real = np.nonzero((a.x >= elo) & (a.x < ehi))[0]
                 ghost = np.nonzero(((a.x >= elo - width) & (a.x < elo)) | ((a.x >= ehi) & (a.x < ehi + width)))[0]
-                b = a.extract_particles(np.concatenate([real, ghost]), name=a.name)
-                b.set_num_real_particles(real.size)
+                if args.self_slab:
+                    # --self-slab: no ghosts are built here -- the rank gets them through the slab transport itself, as its
+                    # own periodic neighbour (its low-face particles arrive beyond its high face and the other way round: as
+                    # many ghosts per array and face as the real neighbours would send, through the real selection, packing,
+                    # RCCL send / recv and append of every array): what a rank's exchange costs LOCALLY, everything but the link
+                    ghost = ghost[:0]
+                # the ghosts go behind the real particles AFTER the device-side reorder of `setup` (which drops every row
+                # behind the real particles -- round 5's emulated ranks ran WITHOUT their ghosts after it: their step
+                # times, 1.33-1.38 ms, left the ghosts' share of the neighbour update, the records and the pair loops out)
+                b = a.extract_particles(real, name=a.name)
+                # (as they arrive: the low face's ghosts, then the high face's, each in its sender's cell order)
+                def cell_order(idx):
+                    cx, cy, cz = (np.floor(a.get(q)[idx] / width).astype(np.int64) for q in 'xyz')
+                    return idx[np.lexsort((a.x[idx], cx, cy, cz))]
+                gh = a.extract_particles(np.concatenate([cell_order(ghost[a.x[ghost] < elo]), cell_order(ghost[a.x[ghost] >= ehi])]),
+                                         name=a.name)
+                gh.tag[:] = 1
                 cut.append(b)
+                ghosts_of.append(gh)
             arrays = cut
+            w.ghost_parts = ghosts_of
             w.scaling = 'strong'
         elif world > 1:
             # C4: ONE tank cut into `world` slabs along x at the quantiles of
@@ -333,6 +351,11 @@ def build_workload(args, rank, world):
         # solids <- fluid continuity: x,y,z,h,u,v,w read (56 B), arho written (8 B): SURVEY 8(d)
         w.algo_solid = 64.0
         w.slab = (lo, hi, False, 0.0)
+        if args.emulate_rank and args.self_slab:
+            if args.emulate_rank[0] in (0, args.emulate_rank[1] - 1):
+                raise SystemExit('--emulate-rank with --self-slab needs an interior rank (two faces)')
+            w.slab = (elo, ehi, True, ehi - elo)
+            args.no_check = True
         w.fields = ('arho', 'au', 'av', 'aw', 'ax', 'ay', 'az', 'p', 'cs')
     elif args.workload == 'taylor_green':
         from pysph_amd.scheme import TVFScheme
@@ -797,6 +820,12 @@ def setup(args, w, rank, world, dist, ctx):
                 halo.exchange()
             nnps.update()
         ordered = True
+    if getattr(w, 'ghost_parts', None):
+        # --emulate-rank: the ghost layers of the two neighbours, behind the (re-ordered) real particles
+        for a, gh in zip(w.arrays, w.ghost_parts):
+            if gh.get_number_of_particles():
+                a.gpu.append_parray(gh, align=True)
+        nnps.update()
 
     if args.fixed_bounds:
         # the particles of this benchmark do not move: the box of one full update
@@ -1315,46 +1344,52 @@ def projected_strong_scaling(args, local_rank, tstream, world=8, dx=0.0035, t_on
             ctx.close()
             torch.cuda.empty_cache()
     _DAM_CACHE.clear()
-    # the exchange: slab transport on this GPU at about a rank's particle count (cube of the same size)
-    n1 = max(32, int(round(n_max ** (1.0 / 3.0)))) if n_max else 130
+    # the exchange, LOCAL part: an interior rank of the same tank whose ghosts come through the slab transport itself (the
+    # rank as its own periodic neighbour: the selection + packing of every array, the RCCL send / recv to itself, the
+    # appends, on the round-trip-free protocol) against the same rank with its ghosts in place.  Round 5 took this
+    # figure from a one-array cube of a rank's size; the dam break's three arrays make three times the launches.
     ex = {}
     own_group = False
-    for name, flag in (('plain', False), ('self_slab', True)):
+    r_mid = world // 2
+    try:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', str(_free_port()))
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', local_rank))
+            own_group = True
         a2 = copy.copy(args)
-        a2.workload, a2.n1, a2.self_slab, a2.emulate_rank = 'cube', n1, flag, None
+        a2.workload, a2.dx, a2.emulate_rank, a2.self_slab = 'dam_break', dx, (r_mid, world), True
         ctx = dev.HipContext(local_rank, tstream.cuda_stream)
         apply_options(a2, ctx)
         try:
             w = build_workload(a2, 0, 1)
-            dist = None
-            if flag:
-                import torch.distributed as dist
-                if not dist.is_initialized():
-                    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-                    os.environ.setdefault('MASTER_PORT', str(_free_port()))
-                    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', local_rank))
-                    own_group = True
             nnps, a_eval, halo, domain, step, ordered = setup(a2, w, 0, 1, dist, ctx)
-            elapsed, timers = timed(10, 3, step, torch.cuda.synchronize, ctx)
-            ex[name] = elapsed / 10 * 1e3
-            ex[name + '_kernels'] = sum(timers[k][0] for k in ('nnps', 'pack', 'eos', 'pair')) / 10
+            elapsed, timers = timed(10, 4, step, torch.cuda.synchronize, ctx)
+            ex['self_slab'] = elapsed / 10 * 1e3
+            ex['self_slab_kernels'] = sum(timers[k][0] for k in ('nnps', 'pack', 'eos', 'pair')) / 10
+            ex['padded_exchanges'] = [h.padded_exchanges for h in halo.halos]
+            ex['ghosts'] = [a.gpu.get_number_of_particles() - a.gpu.get_number_of_particles(True) for a in w.arrays]
+            ex['properties_per_ghost'] = [int(h.ops.nprops) for h in halo.halos]
             del nnps, a_eval, step, w, halo
-        except Exception as e:
-            ex[name] = None
-            ex[name + '_error'] = '%s: %s' % (type(e).__name__, e)
         finally:
             ctx.close()
             torch.cuda.empty_cache()
+    except Exception as e:
+        ex['self_slab'] = None
+        ex['self_slab_error'] = '%s: %s' % (type(e).__name__, e)
+    _DAM_CACHE.clear()
     if own_group:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
-    out['exchange_stand_in'] = {'cube_side': n1, 'ms_per_step': ex}
+    ex['plain'] = out['ranks'].get(str(r_mid), {}).get('ms_per_step')
+    ex['plain_kernels'] = sum(out['ranks'].get(str(r_mid), {}).get('kernel_ms_per_step', {}).values()) or None
+    out['exchange_stand_in'] = {'rank': r_mid, 'what': 'dam break dx %g, rank %d of %d as its own periodic neighbour over RCCL' % (dx, r_mid, world),
+                                'ms_per_step': ex}
     if ex.get('plain') and ex.get('self_slab'):
-        # what the slab transport adds to a step, and the part of it that is NOT the neighbour update / records / pair
-        # loops of the extra (ghost) particles -- those a rank's emulated step above already contains
-        out['self_slab_minus_plain_ms'] = max(ex['self_slab'] - ex['plain'], 0.0)
-        out['exchange_ms'] = max(out['self_slab_minus_plain_ms'] - max(ex['self_slab_kernels'] - ex['plain_kernels'], 0.0), 0.0)
+        # what the slab transport adds to the step of a rank that already holds (and computes with) its ghosts
+        out['exchange_ms'] = max(ex['self_slab'] - ex['plain'], 0.0)
     out['slowest_rank_ms'] = t_max
     if t_one_gpu_ms and t_max > 0 and out.get('exchange_ms') is not None:
         out['t_one_gpu_ms'] = t_one_gpu_ms
@@ -1370,7 +1405,7 @@ def projected_strong_scaling(args, local_rank, tstream, world=8, dx=0.0035, t_on
         face_bytes5 = max(max(v['bytes_per_face_round5']) for v in ok)
         out['largest_face_message_bytes'] = face_bytes
         out['largest_face_message_bytes_round5_protocol'] = face_bytes5
-        out['link_model'] = 'step = max_r(rank_ms) + exchange_ms (one-GPU stand-in: select + pack + RCCL launch + append) + ' \
+        out['link_model'] = 'step = max_r(rank_ms) + exchange_ms (measured on this GPU: select + pack + RCCL launch + append of all three arrays) + ' \
                             'largest face bytes / rate + %.0f us; nothing overlapped' % (LINK_LATENCY_MS * 1e3)
         out['projected_speedup_with_link'] = {}
         for gbs in (45, 60, 75):

@@ -444,6 +444,13 @@ int sph_halo_select_pack_promised(sph_ctx *ctx, int array_id, int axis, double l
  * on the context's stream, one synchronisation): the headers of the ghost
  * messages, from which the host learns the counts.                          */
 int sph_read_values(sph_ctx *ctx, int n, const void *const *dev_ptrs, double *out);
+/* ... and WITHOUT the round trip: one launch gathers the n <= 48 doubles and nflags
+ * uint32 flag words (as doubles, behind them; n + nflags <= 64) into host_out,
+ * PAGE-LOCKED host memory the device can write; the caller records an event
+ * behind it and reads the values when that has passed (the counts of the
+ * round-trip-free ghost exchange, read once the evaluation is queued).         */
+int sph_queue_values(sph_ctx *ctx, int n, const void *const *dev_ptrs, int nflags, const void *flag_words,
+                     double *host_out);
 /* sph_halo_append from a message whose rows are `stride` doubles apart
  * (property k of row i at src[k * stride + i], stride >= count).            */
 /* The same message appended WITHOUT a device->host round trip (round 5): all `cap` rows go behind the particles, the
@@ -461,6 +468,9 @@ int sph_read_values(sph_ctx *ctx, int n, const void *const *dev_ptrs, double *ou
  * MPI to the host first. */
 int sph_halo_append_padded(sph_ctx *ctx, int array_id, int nprops, const int *props, const void *src_device, size_t cap,
                            double h_promise, double m_promise, void *flag_word);
+/* ... the messages of both faces of the array in ONE launch: the rows of src_device, then those of src2_device (NULL / 0: none). */
+int sph_halo_append_padded2(sph_ctx *ctx, int array_id, int nprops, const int *props, const void *src_device, size_t cap,
+                            const void *src2_device, size_t cap2, double h_promise, double m_promise, void *flag_word);
 int sph_halo_append_strided(sph_ctx *ctx, int array_id, int nprops, const int *props, const void *src_device,
                             size_t count, size_t stride);
 

@@ -130,6 +130,7 @@ int sph_ctx_destroy(sph_ctx *c)
         for (auto &p : A.prop) if (p) (void)hipFree(p);
         A.keys.release(); A.keys_sorted.release(); A.idx.release(); A.perm.release();
         A.tile_key.release(); A.tile_id.release(); A.tile_order.release();
+        A.dlist.release(); A.dl_cnt.release(); A.ctile_key.release(); A.ctile_id.release(); A.ctile_order.release();
         A.cell_start.release(); A.fkeys_sorted.release(); A.fine_start.release(); A.tflag.release();
         A.g_keys.release(); A.g_fkeys.release(); A.g_perm.release(); A.g_fine_start.release(); A.g_cell_start.release();
     }
@@ -137,6 +138,7 @@ int sph_ctx_destroy(sph_ctx *c)
         DevArray &A = c->merged;
         A.keys_sorted.release(); A.perm.release(); A.fkeys_sorted.release(); A.fine_start.release(); A.slot8.release(); A.cell_start.release();
         A.tile_key.release(); A.tile_id.release(); A.tile_order.release();
+        A.dlist.release(); A.dl_cnt.release(); A.ctile_key.release(); A.ctile_id.release(); A.ctile_order.release();
     }
     for (auto &H : c->halo)
         for (int s = 0; s < 2; s++) { H.flag[s].release(); H.pos[s].release(); H.list[s].release(); }
@@ -354,6 +356,7 @@ int sph_set_option(sph_ctx *c, const char *key, long value)
     if (strcmp(key, "mass_fuse") == 0) { c->mass_fuse = value; return SPH_OK; }
     if (strcmp(key, "nl_reuse") == 0) { c->nl_reuse = value; c->nl.valid = false; return SPH_OK; }
     if (strcmp(key, "norm_masks") == 0) { c->norm_masks = value; return SPH_OK; }
+    if (strcmp(key, "dest_list") == 0) { c->dest_list = value < 0 ? 0 : (value > 2 ? 2 : value); c->nnps_valid = false; return SPH_OK; }
     if (strcmp(key, "merge_arrays") == 0) { c->merge_arrays = value ? 1 : 0; c->nnps_valid = false; return SPH_OK; }
     if (strcmp(key, "split_pair") == 0) { c->split_pair = value ? 1 : 0; return SPH_OK; }
     if (strcmp(key, "tension_flag") == 0) { c->tension_flag = value ? 1 : 0; return SPH_OK; }
@@ -434,7 +437,7 @@ int sph_timer_get(sph_ctx *c, const char *key, double *ms, long *count)
 {
     static const char *names[T_COUNT] = {"nnps", "pack", "eos", "pair", "stage",
                                          "pair_none", "pair_wcsph", "pair_density", "pair_tvf", "pair_vgrad", "pair_elastic",
-                                         "n_eos_fused", "n_nl_keep", "n_nl_reuse", "n_mass_fused", "n_merged", "n_tension_flag", "n_phase2", "n_async"};
+                                         "n_eos_fused", "n_nl_keep", "n_nl_reuse", "n_mass_fused", "n_merged", "n_tension_flag", "n_phase2", "n_async", "n_dest_list"};
     SPH_TRY(timer_drain(c));
     for (int i = 0; i < T_COUNT; i++)
         if (strcmp(key, names[i]) == 0) {

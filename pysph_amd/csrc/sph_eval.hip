@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a)
     ph.x = a.x[o]; ph.y = a.y[o]; ph.z = a.z[o]; ph.w = a.h[o];
     double v[MAX_AUX];
     // (compile-time layouts read the slots their record holds: WCSPH u v w m rho tmpj cs p = 0..7, elastic 0..17 + p)
-    constexpr int NV = (LAYOUT == 6 || LAYOUT == 7 || LAYOUT == 12 || LAYOUT == 13) ? 8 : MAX_AUX;
+    constexpr int NV = (LAYOUT == 6 || LAYOUT == 7 || LAYOUT == 12 || LAYOUT == 13) ? 8 : (LAYOUT == 2 ? 1 : (LAYOUT == 3 || LAYOUT == 8 || LAYOUT == 9) ? 11 : MAX_AUX);
 #pragma unroll
     for (int k = 0; k < MAX_AUX; k++) v[k] = (k < NV && (k < a.na || (a.derived == 3 && k == 18) || (a.derived == 4 && k == 4)) && a.src[k]) ? a.src[k][o] : 0.0;
     if (a.derived == 1) v[5] = v[4] != 0.0 ? v[7] * (1.0 / (v[4] * v[4])) : 0.0; // tmpj = p*rhoj21, wc/basic.py:211,234
@@ -1492,6 +1492,10 @@ static void launch_pack(sph_ctx *c, const PackArgs &pa, size_t n)
     const dim3 g(div_up(n, 256)), b(256);
     const size_t lds = (size_t)pa.lds_np * 256 * 16;
     switch (pa.rec ? pa.layout : -1) {
+    case 2: hipLaunchKernelGGL(k_pack<2>, g, b, lds, c->stream, pa); break;
+    case 3: hipLaunchKernelGGL(k_pack<3>, g, b, lds, c->stream, pa); break;
+    case 8: hipLaunchKernelGGL(k_pack<8>, g, b, lds, c->stream, pa); break;
+    case 9: hipLaunchKernelGGL(k_pack<9>, g, b, lds, c->stream, pa); break;
     case 6: hipLaunchKernelGGL(k_pack<6>, g, b, lds, c->stream, pa); break;
     case 7: hipLaunchKernelGGL(k_pack<7>, g, b, lds, c->stream, pa); break;
     case 10: hipLaunchKernelGGL(k_pack<10>, g, b, lds, c->stream, pa); break;
@@ -1677,6 +1681,15 @@ template <class Fam> static void set_tile_order(sph_ctx *c, PairArgs<Fam> &a, co
 {
     a.d_tile_order = D.n_tiles ? D.tile_order.as<uint32_t>() : nullptr;
     a.row_mod3 = (int)c->row_mod3;
+}
+// the destinations of this launch are exactly the real particles of D's order: wave tiles from D.dlist (no idle ghost lanes)
+template <class Fam> static void use_dest_list(sph_ctx *c, PairArgs<Fam> &a, const DevArray &D)
+{
+    if (!c->dest_list || c->pair_variant != 6 || D.dlist_n == 0 || a.nl_mode || a.face_mode) return;
+    a.d_list = D.dlist.as<uint32_t>();
+    a.nd = (uint32_t)D.dlist_n;
+    c->timers[T_N_DLIST].count++; // (pair launches whose wave tiles came from the list: sph_timer_get "n_dest_list")
+    a.d_tile_order = D.n_ctiles ? D.ctile_order.as<uint32_t>() : nullptr;
 }
 
 static int ensure_out(sph_ctx *c, int id, std::initializer_list<int> props)
@@ -1909,6 +1922,14 @@ static int eval_group_merged(sph_ctx *c, const sph_kernel *K, const sph_group *g
             if (row & F_MOM) { SPH_TRY(ensure_out(c, id, {SPH_AU, SPH_AV, SPH_AW, SPH_DT_CFL, SPH_DT_FORCE})); }
             if (row & F_XSPH) { SPH_TRY(ensure_out(c, id, {SPH_AX, SPH_AY, SPH_AZ})); }
             for (int k = 0; k < 9; k++) a.p.out[s][k] = A.prop[outp[k]];
+        }
+        {   // every destination range is [0, n_real) of its array (or empty): the wave tiles are the real particles' ones
+            bool all_real = true;
+            for (int s = 0; s < na; s++) {
+                const DevArray &A = c->arr[c->ids[s]];
+                all_real &= (a.p.rng[s][0] == 0 && a.p.rng[s][1] == (uint32_t)A.n_real) || A.n == 0;
+            }
+            if (all_real) use_dest_list(c, a, M);
         }
         constexpr bool FP32 = sizeof(typename Fm::Real) == 4;
         dim3 g2(div_up(4 * div_up(a.nd, 256), WPB)), b2(64 * WPB);
@@ -2209,6 +2230,8 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             a.d_start = (uint32_t)start; a.d_stop = (uint32_t)stop; a.dflags = dflags;
             a.nl = nullptr; a.nl_mode = nl_mode;
             if (nl_mode) a.nl = c->nlbuf.as<uint32_t>();
+            // Group.real = True without start / stop: the destinations are the real particles
+            if (start == 0 && stop == D.n_real && D.n_binned == D.n && !any_ghosts) use_dest_list(c, a, D);
             if (eosf || eosv) {
                 a.e_rho01 = 1.0 / g->eos_par[0]; a.e_c0 = g->eos_par[1];
                 a.e_B = g->eos_par[0] * g->eos_par[1] * g->eos_par[1] / g->eos_par[2];

@@ -356,6 +356,31 @@ extern "C" int sph_halo_select_pack_promised(sph_ctx *c, int id, int axis, doubl
     return SPH_OK;
 }
 
+// The headers of the ghost messages and the flag words of an exchange on their way to the host WITHOUT a round trip: one
+// launch gathers n doubles (one from each device address) and nflags uint32 words (as doubles, behind them) straight into
+// `host_out` -- page-locked host memory the device can write (torch's pinned tensors, hipHostMalloc) -- and the caller
+// records an event behind it.  (torch.stack + cat + copy_ were four launches and 19 us per exchange.)
+struct GatherPtrs { const double *p[48]; };
+__global__ void k_gather_to_host(GatherPtrs g, int n, const uint32_t *__restrict__ flags, int nflags, double *__restrict__ out)
+{
+    const int t = threadIdx.x;
+    if (t < n) out[t] = *g.p[t];
+    else if (t < n + nflags) out[t] = (double)flags[t - n];
+}
+extern "C" int sph_queue_values(sph_ctx *c, int n, const void *const *dev_ptrs, int nflags, const void *flag_words, double *host_out)
+{
+    if (!c || n < 0 || n > 48 || nflags < 0 || n + nflags > 64 || (n && !dev_ptrs) || (nflags && !flag_words) || !host_out) {
+        sph_set_error("sph_queue_values: bad arguments (at most 48 values + flag words up to 64 in all)");
+        return SPH_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    GatherPtrs g;
+    for (int k = 0; k < 48; k++) g.p[k] = k < n ? (const double *)dev_ptrs[k] : nullptr;
+    hipLaunchKernelGGL(k_gather_to_host, dim3(1), dim3(64), 0, c->stream, g, n, (const uint32_t *)flag_words, nflags, host_out);
+    HIP_TRY(hipGetLastError());
+    return SPH_OK;
+}
+
 // Small device -> host reads in one round trip (the headers of the ghost messages): n doubles, one from each
 // device address, all copies queued on the context's stream before the single synchronisation.
 extern "C" int sph_read_values(sph_ctx *c, int n, const void *const *dev_ptrs, double *out)
@@ -459,12 +484,14 @@ extern "C" int sph_halo_append_strided(sph_ctx *c, int id, int nprops, const int
 // every exact distance test fail against it by 1e36, and ghosts are never destinations.  flag (device word, sticky):
 // bit 0 = the message was incomplete (negative header: more rows than its capacity), bit 1 = a ghost's h or m differs
 // from the promised one.
-__global__ __launch_bounds__(256) void k_halo_append_padded(PropList L, const double *__restrict__ src, size_t n0, size_t cap,
+__global__ __launch_bounds__(256) void k_halo_append_padded(PropList L, const double *__restrict__ src0, size_t n0, size_t cap0,
                                                             int nprops, int k_h, int k_m, double h_promise, double m_promise,
-                                                            uint32_t *__restrict__ flag, double *__restrict__ fill_h, double *__restrict__ fill_m)
+                                                            uint32_t *__restrict__ flag, double *__restrict__ fill_h, double *__restrict__ fill_m,
+                                                            const double *__restrict__ src1 = nullptr, size_t cap1 = 0)
 {
+    // rows [n0, n0 + cap0) take message 0, rows [n0 + cap0, n0 + cap0 + cap1) message 1 (the other face's: ONE launch)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cap) return;
+    if (i >= cap0 + cap1) return;
     const int k = blockIdx.y;
     if (k >= nprops) {
         // a promised property that did not travel: every row (ghost or padding) gets the promised value -- the array's
@@ -473,12 +500,15 @@ __global__ __launch_bounds__(256) void k_halo_append_padded(PropList L, const do
         if (k == nprops + 1 && fill_m) fill_m[n0 + i] = m_promise;
         return;
     }
+    const bool second = i >= cap0;
+    const double *__restrict__ src = second ? src1 : src0;
+    const size_t cap = second ? cap1 : cap0, r = second ? i - cap0 : i;
     const double hdr = src[(size_t)nprops * cap];
     const size_t count = (size_t)fmin(fabs(hdr), (double)cap);
-    if (i == 0 && k == 0 && hdr < 0.0) atomicOr(flag, 1u);
+    if (r == 0 && k == 0 && hdr < 0.0) atomicOr(flag, 1u);
     double v = L.what[k] ? SPH_PARKED : 0.0;
-    if (i < count) {
-        v = src[(size_t)k * cap + i];
+    if (r < count) {
+        v = src[(size_t)k * cap + r];
         if ((k == k_h && h_promise == h_promise && v != h_promise) || (k == k_m && m_promise == m_promise && v != m_promise)) atomicOr(flag, 2u);
     }
     L.p[k][n0 + i] = v;
@@ -487,10 +517,19 @@ __global__ __launch_bounds__(256) void k_halo_append_padded(PropList L, const do
 extern "C" int sph_halo_append_padded(sph_ctx *c, int id, int nprops, const int *props, const void *src, size_t cap,
                                       double h_promise, double m_promise, void *flag_word)
 {
-    if (!c || id < 0 || id >= SPH_MAX_ARRAYS || nprops < 1 || nprops > SPH_PROP_COUNT || !props || !src || !flag_word) {
+    return sph_halo_append_padded2(c, id, nprops, props, src, cap, nullptr, 0, h_promise, m_promise, flag_word);
+}
+
+// ... the messages of BOTH faces of an array in one launch: the rows of `src` first, those of `src2` (may be NULL / 0 rows)
+// behind them -- the order two calls give
+extern "C" int sph_halo_append_padded2(sph_ctx *c, int id, int nprops, const int *props, const void *src, size_t cap,
+                                       const void *src2, size_t cap2, double h_promise, double m_promise, void *flag_word)
+{
+    if (!c || id < 0 || id >= SPH_MAX_ARRAYS || nprops < 1 || nprops > SPH_PROP_COUNT || !props || (cap && !src) || (cap2 && !src2) || !flag_word) {
         sph_set_error("sph_halo_append_padded: bad arguments");
         return SPH_ERR_ARG;
     }
+    if (cap == 0 && cap2 != 0) { src = src2; cap = cap2; src2 = nullptr; cap2 = 0; }
     if (cap == 0) return SPH_OK;
     HIP_TRY(hipSetDevice(c->device));
     size_t n0 = c->arr[id].n;
@@ -515,7 +554,7 @@ extern "C" int sph_halo_append_padded(sph_ctx *c, int id, int nprops, const int 
     if (fill_h) SPH_TRY(sph_array_ensure_prop(c, id, SPH_H));
     if (fill_m) SPH_TRY(sph_array_ensure_prop(c, id, SPH_M));
     const bool mk = A0.m_known || empty0;
-    SPH_TRY(sph_array_resize(c, id, n0 + cap, A0.n_real));
+    SPH_TRY(sph_array_resize(c, id, n0 + cap + cap2, A0.n_real));
     DevArray &A = c->arr[id];
     if (keep_h) { A.h_dirty = false; if (empty0) { A.h_seen = true; A.h_lo = A.h_hi = h_promise; } }
     if (keep_m) {
@@ -525,9 +564,9 @@ extern "C" int sph_halo_append_padded(sph_ctx *c, int id, int nprops, const int 
     PropList L;
     for (int k = 0; k < nprops; k++) { L.p[k] = A.prop[props[k]]; L.what[k] = props[k] == SPH_X || props[k] == SPH_Y || props[k] == SPH_Z; }
     A.has_padding = true;
-    hipLaunchKernelGGL(k_halo_append_padded, dim3(div_up(cap, 256), nprops + 2), dim3(256), 0, c->stream, L, (const double *)src, n0, cap,
+    hipLaunchKernelGGL(k_halo_append_padded, dim3(div_up(cap + cap2, 256), nprops + 2), dim3(256), 0, c->stream, L, (const double *)src, n0, cap,
                        nprops, k_h, k_m, h_promise, m_promise, (uint32_t *)flag_word, fill_h ? A.prop[SPH_H] : nullptr,
-                       fill_m ? A.prop[SPH_M] : nullptr);
+                       fill_m ? A.prop[SPH_M] : nullptr, (const double *)src2, cap2);
     c->nnps_valid = false;
     return SPH_OK;
 }

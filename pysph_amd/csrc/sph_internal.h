@@ -52,6 +52,18 @@ struct DevArray {
     size_t n_tiles = 0;
     int tile_grid[4] = {0, 0, 0, 0};     // grid (ncx, ncy, ncz, block rows) the tile order was built for
     int tile_age = 0;                    // updates since the tile order was built
+    // The REAL particles of the cell order (round 6): dlist[g] = sorted position of the g-th particle that is not a ghost /
+    // image / padding row (original index < n_real of its array), ascending.  Built by the neighbour update when an array
+    // holds rows behind its real particles; pair launches whose destinations are exactly the real particles
+    // (Group.real = True, no start / stop) take their wave tiles from it: 64 consecutive REAL particles per wavefront
+    // instead of 64 consecutive positions of which the ghosts are idle lanes (a slab rank of the 16 M dam break: 9.6 % of
+    // the positions; Taylor-Green's periodic images: 20 %).  ctile_*: the traversal order of those tiles.
+    DevBuf dlist, dl_cnt;
+    size_t dlist_n = 0;                  // entries of dlist (0: none -- every position is a destination candidate)
+    DevBuf ctile_key, ctile_id, ctile_order;
+    size_t n_ctiles = 0;
+    int ctile_grid[4] = {0, 0, 0, 0};
+    int ctile_age = 0;
     bool m_known = false;                // every particle has the same mass: the last look found one value and nothing wrote m since
     double m_value = 0.0;                // ... this one
     // What the neighbour update knows about h and m WITHOUT looking: the range its last reduction found (`*_seen`), valid
@@ -94,7 +106,7 @@ struct HaloState {
 
 // T_PAIR: every pair launch; T_PAIR_FAM + family (sph_eval.hip enum Family): the same launches per equation family
 // T_N_*: launch counters only (no time): pair launches on EOS-fused records, launches that kept / reused neighbour lists
-enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_STAGE, T_PAIR_FAM, T_N_EOSF = T_PAIR_FAM + 6, T_N_NLKEEP, T_N_NLREUSE, T_N_UMASS, T_N_MERGED, T_N_TFLAG, T_N_PHASE2, T_N_ASYNC, T_COUNT };
+enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_STAGE, T_PAIR_FAM, T_N_EOSF = T_PAIR_FAM + 6, T_N_NLKEEP, T_N_NLREUSE, T_N_UMASS, T_N_MERGED, T_N_TFLAG, T_N_PHASE2, T_N_ASYNC, T_N_DLIST, T_COUNT };
 
 struct Timer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -254,6 +266,7 @@ struct sph_ctx {
     long eos_fuse = 1;      // honour sph_group.src_eos (64-byte WCSPH records, p and cs recomputed from rho)
     long nl_reuse = 0;      // honour sph_group.nl_mode (neighbour lists kept between the pair passes of one evaluation): built,
                             // bit-identical, and measured SLOWER on MI355X (phase 1 overlaps other wavefronts' gathers)
+    long dest_list = 1;     // pair launches over the real particles take their wave tiles from DevArray::dlist
     long norm_masks = 1;    // shift a row's hit bits down to the lane's first hit
     // neighbour lists kept by the last nl_mode-1 pair pass
     DevBuf nlbuf;

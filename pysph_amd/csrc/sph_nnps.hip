@@ -92,7 +92,10 @@ __device__ __forceinline__ uint32_t fine_key_of(double x, double y, double z, co
         // memory stay neighbours in the cell order -- hashed over the bins (the first version) every one of them was a
         // random 8-byte gather for the record packing and an atomic group of its own for the sort: Taylor-Green's 0.5 M
         // padding rows cost 0.15 ms of packing and tipped the array into the "no spatial order" traversal
-        if (g.park_bins) return g.park_base + (uint32_t)(((unsigned long long)i * g.park_bins) / max(g.park_n, 1u)) % g.park_bins;
+        // ... ONE row per bin (row i -> bin i mod park_bins; round 5 mapped row i of park_n to bin i * park_bins / park_n,
+        // 8 consecutive rows per bin: the 10 k padding rows behind a face's ghosts then fell into ONE sort bucket of 1024
+        // bins, beyond its LDS stage -- k_bucket_sort 33 -> 76 us on a slab rank of the 16 M dam break)
+        if (g.park_bins) return g.park_base + (uint32_t)(i % g.park_bins);
         const unsigned long long n_fine = (unsigned long long)g.nc[0] * g.nc[1] * g.nc[2] * SPH_NSUB;
         return (uint32_t)(((unsigned long long)i * 2654435761ull) % n_fine);
     }
@@ -621,13 +624,14 @@ __global__ __launch_bounds__(256) void k_coarse_start(const uint32_t *__restrict
 // the reuse distance of a row down to a few hundred KB.  Results do not depend
 // on the order.
 #define SPH_TILE 256
+// (dlist, optional: tile t is the destinations dlist[t * SPH_TILE ...] -- DevArray::dlist -- instead of those positions)
 __global__ __launch_bounds__(256) void k_tile_keys(const uint32_t *__restrict__ skeys, size_t n, uint32_t n_tiles, int ncx,
                                                    int ncy, int ncz, int by, uint32_t *__restrict__ key,
-                                                   uint32_t *__restrict__ count)
+                                                   uint32_t *__restrict__ count, const uint32_t *__restrict__ dlist = nullptr)
 {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
-    const uint32_t k = skeys[(size_t)t * SPH_TILE];
+    const uint32_t k = skeys[dlist ? (size_t)dlist[(size_t)t * SPH_TILE] : (size_t)t * SPH_TILE];
     const uint32_t row = k / (uint32_t)ncx;
     // A tile of parked padding rows lies in the parking cells behind the grid and has no work: such tiles are dealt over
     // the whole traversal (a key that depends on the tile index only).  Left together at the end of the order they are the
@@ -1384,38 +1388,143 @@ int nnps_need_tables(sph_ctx *c)
 // one z plane of tiles.  The order is a permutation of the tile ids that only steers locality: any permutation of the same
 // nt tiles gives the same results.  Particles move a fraction of a cell per step, so the order of the last build stays
 // good: rebuilt when the tile count or the grid changed and every 16th update.
-static int nnps_tile_order(sph_ctx *c, DevArray &A, size_t n)
+// (one traversal order: of the position tiles, or -- `compact` -- of the tiles of the real-particle list DevArray::dlist)
+struct TileOrd { DevBuf *key, *id, *order; size_t *n_tiles; int *grid, *age; };
+static int nnps_tile_order_of(sph_ctx *c, DevArray &A, size_t n, TileOrd T, const uint32_t *dlist)
 {
     const bool want_tiles = c->tile_block_rows > 0 && c->nc[2] > 1 && n > 64 * SPH_TILE;
     const int tsig = (int)c->tile_block_rows;
     const uint32_t nt_now = (uint32_t)div_up(n, SPH_TILE);
-    if (want_tiles && A.n_tiles == nt_now && A.tile_grid[0] == c->nc[0] && A.tile_grid[1] == c->nc[1] &&
-        A.tile_grid[2] == c->nc[2] && A.tile_grid[3] == tsig && ++A.tile_age < 16)
+    if (want_tiles && *T.n_tiles == nt_now && T.grid[0] == c->nc[0] && T.grid[1] == c->nc[1] &&
+        T.grid[2] == c->nc[2] && T.grid[3] == tsig && ++*T.age < 16)
         return SPH_OK;
-    A.n_tiles = 0;
+    *T.n_tiles = 0;
     if (want_tiles) {
-        A.tile_age = 0;
-        A.tile_grid[0] = c->nc[0]; A.tile_grid[1] = c->nc[1]; A.tile_grid[2] = c->nc[2]; A.tile_grid[3] = tsig;
+        *T.age = 0;
+        T.grid[0] = c->nc[0]; T.grid[1] = c->nc[1]; T.grid[2] = c->nc[2]; T.grid[3] = tsig;
         const uint32_t nt = nt_now;
-        SPH_TRY(A.tile_key.reserve((size_t)nt * 4 * 2));
-        SPH_TRY(A.tile_id.reserve((size_t)nt * 4));
-        SPH_TRY(A.tile_order.reserve((size_t)nt * 4));
+        SPH_TRY(T.key->reserve((size_t)nt * 4 * 2));
+        SPH_TRY(T.id->reserve((size_t)nt * 4));
+        SPH_TRY(T.order->reserve((size_t)nt * 4));
         // keys = traversal rank of the tile's row (< ncy * ncz rounded up to whole blocks of rows): the same counting sort
         const uint32_t by = (uint32_t)c->tile_block_rows;
         const uint32_t nrow_keys = ((uint32_t)c->nc[1] + by - 1) / by * by * (uint32_t)c->nc[2];
-        SPH_TRY(A.tile_id.reserve(((size_t)nrow_keys + 2) * 4));
-        uint32_t *tk = A.tile_key.as<uint32_t>(), *tt = A.tile_id.as<uint32_t>();
+        SPH_TRY(T.id->reserve(((size_t)nrow_keys + 2) * 4));
+        uint32_t *tk = T.key->as<uint32_t>(), *tt = T.id->as<uint32_t>();
         HIP_TRY(hipMemsetAsync(tt, 0, ((size_t)nrow_keys + 2) * 4, c->stream));
         hipLaunchKernelGGL(k_tile_keys, dim3(div_up(nt, 256)), dim3(256), 0, c->stream, A.keys_sorted.as<uint32_t>(), n, nt,
-                           c->nc[0], c->nc[1], c->nc[2], (int)c->tile_block_rows, tk, tt);
+                           c->nc[0], c->nc[1], c->nc[2], (int)c->tile_block_rows, tk, tt, dlist);
         BinFixArgs fa;
         memset(&fa, 0, sizeof fa);
         fa.nbins = nrow_keys; fa.nsub = 0;
-        fa.perm = A.tile_order.as<uint32_t>();
+        fa.perm = T.order->as<uint32_t>();
         SPH_TRY(nnps_bin_sort_finish(c, tk, nt, fa, tt));
-        A.n_tiles = nt;
+        *T.n_tiles = nt;
     }
     return SPH_OK;
+}
+static int nnps_tile_order(sph_ctx *c, DevArray &A, size_t n)
+{
+    return nnps_tile_order_of(c, A, n, TileOrd{&A.tile_key, &A.tile_id, &A.tile_order, &A.n_tiles, A.tile_grid, &A.tile_age}, nullptr);
+}
+
+// ---------------------------------------------------------------------------
+// The real particles of a cell order (DevArray::dlist).  Position p of the order holds original index perm[p] of the
+// array in slot slot[p] (one array: slot 0); it is REAL when that index lies below the array's n_real -- ghosts, periodic
+// images and parked padding rows all lie behind.  Two launches in the pattern of sph_halo_select_pack: one counter per
+// chunk, then every workgroup sums the counters before its own and ranks its positions with wavefront ballots.
+// ---------------------------------------------------------------------------
+struct RealTest {
+    const uint32_t *perm;
+    const uint8_t *slot; // null: one array
+    uint32_t nreal[SPH_MAX_ARRAYS];
+    int narrays;
+};
+__device__ __forceinline__ bool real_at(const RealTest &r, size_t p)
+{
+    const uint32_t s = r.slot ? r.slot[p] : 0u;
+    uint32_t nr = r.nreal[0];
+#pragma unroll
+    for (int k = 1; k < SPH_MAX_ARRAYS; k++) nr = (k < r.narrays && s == (uint32_t)k) ? r.nreal[k] : nr;
+    return r.perm[p] < nr;
+}
+#define DLIST_MAX_CHUNKS 2048
+__global__ __launch_bounds__(256) void k_dlist_counts(RealTest r, size_t n, int q256, uint32_t *__restrict__ blk)
+{
+    const size_t first = (size_t)blockIdx.x * 256 * q256;
+    uint32_t cnt = 0; // (wave-uniform)
+    for (int q = 0; q < q256; q++) {
+        const size_t p = first + (size_t)q * 256 + threadIdx.x;
+        cnt += (uint32_t)__popcll(__ballot(p < n && real_at(r, p)));
+    }
+    __shared__ uint32_t sc[4];
+    if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = sc[0] + sc[1] + sc[2] + sc[3];
+}
+__global__ __launch_bounds__(256) void k_dlist_fill(RealTest r, size_t n, int q256, const uint32_t *__restrict__ blk,
+                                                    uint32_t *__restrict__ dlist)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ uint32_t sbase[4], wcnt[4];
+    {
+        uint32_t b0 = 0;
+        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256) b0 += blk[b];
+        for (int o = 32; o > 0; o >>= 1) b0 += __shfl_xor(b0, o, 64);
+        if (lane == 0) sbase[wv] = b0;
+    }
+    __syncthreads();
+    size_t run = (size_t)sbase[0] + sbase[1] + sbase[2] + sbase[3];
+    const size_t first = (size_t)blockIdx.x * 256 * q256;
+    for (int q = 0; q < q256; q++) {
+        const size_t p = first + (size_t)q * 256 + threadIdx.x;
+        const bool on = p < n && real_at(r, p);
+        const unsigned long long m = __ballot(on);
+        __syncthreads(); // (the previous trip's wcnt has been read)
+        if (lane == 0) wcnt[wv] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0;
+        for (int w = 0; w < wv; w++) before += wcnt[w];
+        if (on) dlist[run + before + (size_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)p;
+        run += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    }
+}
+
+// dlist of the order T (the merged one over `narrays` arrays, or one array's own): built when some array holds rows behind
+// its real particles, dropped otherwise
+static int nnps_dest_list(sph_ctx *c, DevArray &T, bool merged, int narrays, const int *ids, size_t n_cat)
+{
+    T.dlist_n = 0; // (the tile order of the list keeps its age: rebuilt when the list's length or the grid changes, and every 16th update)
+    if (!c->dest_list || n_cat == 0) return SPH_OK;
+    RealTest r;
+    memset(&r, 0, sizeof r);
+    size_t n_real = 0;
+    bool ghosts = false;
+    for (int a = 0; a < narrays; a++) {
+        const DevArray &A = c->arr[ids[a]];
+        if (!merged && A.n == 0) continue;
+        r.nreal[merged ? a : 0] = (uint32_t)A.n_real;
+        n_real += A.n_real;
+        ghosts |= A.n > A.n_real;
+    }
+    if (!ghosts || n_real == 0) return SPH_OK;
+    // Worth its two passes (~22 us at 5 M positions) where the rows behind the real particles are a large share of the
+    // order: Taylor-Green's periodic images (20 %: force pass 3.32 -> 3.07 ms).  A slab rank of the 16 M dam break (9.6 %
+    // ghosts) gains 0.02 ms on its pair launch -- a wave tile with idle ghost lanes ends early -- and pays 0.02 for the
+    // list: option dest_list 1 (default) builds it from one eighth of the positions on, 2 always, 0 never.
+    if (c->dest_list == 1 && (n_cat - n_real) * 8 < n_cat) return SPH_OK;
+    r.narrays = merged ? narrays : 1;
+    r.perm = T.perm.as<uint32_t>();
+    r.slot = merged ? T.slot8.as<uint8_t>() : nullptr;
+    const int q256 = (int)div_up(n_cat, (size_t)256 * DLIST_MAX_CHUNKS);
+    const unsigned nb = div_up(n_cat, (size_t)256 * q256);
+    SPH_TRY(T.dl_cnt.reserve(((size_t)nb + 1) * 4));
+    SPH_TRY(T.dlist.reserve((n_real + 64) * 4));
+    hipLaunchKernelGGL(k_dlist_counts, dim3(nb), dim3(256), 0, c->stream, r, n_cat, q256, T.dl_cnt.as<uint32_t>());
+    hipLaunchKernelGGL(k_dlist_fill, dim3(nb), dim3(256), 0, c->stream, r, n_cat, q256, T.dl_cnt.as<uint32_t>(), T.dlist.as<uint32_t>());
+    T.dlist_n = n_real;
+    return nnps_tile_order_of(c, T, n_real, TileOrd{&T.ctile_key, &T.ctile_id, &T.ctile_order, &T.n_ctiles, T.ctile_grid, &T.ctile_age},
+                              T.dlist.as<uint32_t>());
 }
 
 // fine x index (cell * SPH_NSUB + sub-bin along a row) beyond which ghosts lie, from the slab faces the host named
@@ -1611,6 +1720,8 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
     c->merged_valid = false;
     c->tables_valid = true;
     c->ghosts_binned = false;
+    c->merged.dlist_n = 0;
+    for (int a = 0; a < narrays; a++) c->arr[ids[a]].dlist_n = 0;
     nnps_face_planes(c); // ghost split: where this step's ghosts will lie (known before they arrive)
     for (int a = 0; a < narrays; a++) {
         c->ids[a] = ids[a];
@@ -1652,6 +1763,7 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
         for (int a = 0; a <= SPH_MAX_ARRAYS; a++) d.co.off[a] = a < narrays ? ba.off[a] : (uint32_t)n_cat;
         SPH_TRY(sort_finish(c, n_cat, n_fine, n_cells_tab, lbits, nbuckets, d));
         SPH_TRY(nnps_tile_order(c, *T, n_cat));
+        SPH_TRY(nnps_dest_list(c, *T, merged_first, narrays, ids, n_cat));
         if (!merged_first) T->perm_direct_n = n_cat;
         if (merged_first) {
             c->merged_valid = true;
@@ -1680,6 +1792,7 @@ extern "C" int sph_nnps_update(sph_ctx *c, int dim, int narrays, const int *ids,
             for (int k = 0; k <= SPH_MAX_ARRAYS; k++) d.co.off[k] = k ? (uint32_t)n1 : 0u;
             SPH_TRY(sort_finish(c, n1, n_fine, n_cells_tab, lbits, nbuckets, d));
             SPH_TRY(nnps_tile_order(c, A, n1));
+            SPH_TRY(nnps_dest_list(c, A, false, 1, &ids[a], n1));
             A.perm_direct_n = n1;
             c->last_keys_n = 0; // (several arrays: no single pass to judge)
         }

@@ -72,6 +72,9 @@ template <class Fam> struct PairArgs {
     const uint32_t *d_keys, *d_fkeys, *d_perm; // cell ids / fine keys of the sorted destinations, sorted -> original index
     const uint8_t *d_slot; // merged order (families with MERGED): the array (nnps slot) of every sorted destination
     const uint32_t *d_tile_order; // traversal order of the destination tiles (null: memory order)
+    const uint32_t *d_list;       // (optional) the destinations: lane t of wave tile w takes sorted position d_list[64 w + t], nd =
+                                  // the length of the list (DevArray::dlist: the real particles of the order, ascending) -- wave
+                                  // tiles without idle ghost lanes; null: position 64 w + t itself
     // ghost split: ghosts have a fine x index <= gfx_lo or >= gfx_hi; a wavefront whose candidate windows stay inside is
     // an INTERIOR one (it skips ghost segments); face_mode 1 = interior wavefronts only, 2 = the others only, 0 = all
     int face_mode, gfx_lo, gfx_hi;
@@ -377,7 +380,8 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     const uint32_t i = tbase + t;
     if (tbase >= a.nd) return; // whole wavefront past the end
     const bool valid = i < a.nd;
-    const uint32_t ic = valid ? i : a.nd - 1;
+    uint32_t ic = valid ? i : a.nd - 1;
+    if (a.d_list) ic = a.d_list[ic]; // the destination's sorted position (ascending over the lanes either way)
     const uint32_t o = a.d_perm[ic];
     uint32_t slot = 0;
     bool active;

@@ -99,6 +99,8 @@ SIGNATURES = {
                                   _P, C.c_size_t]),
     'sph_halo_append_padded': (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int), _P, C.c_size_t,
                                         C.c_double, C.c_double, _P]),
+    'sph_halo_append_padded2': (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int), _P, C.c_size_t, _P, C.c_size_t,
+                                         C.c_double, C.c_double, _P]),
     'sph_halo_append_strided': (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int),
                                           _P, C.c_size_t, C.c_size_t]),
     'sph_halo_select_pack': (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_size_t,
@@ -108,6 +110,7 @@ SIGNATURES = {
                                                 C.c_int, C.POINTER(C.c_int), _PD, C.POINTER(C.c_size_t),
                                                 C.POINTER(_P), C.c_double, C.c_double]),
     'sph_array_fill': (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_size_t, C.c_size_t]),
+    'sph_queue_values': (C.c_int, [_P, C.c_int, C.POINTER(_P), C.c_int, _P, _P]),
     'sph_array_mark_written': (C.c_int, [_P, C.c_int, C.c_int]),
     'sph_nnps_set_h_range': (C.c_int, [_P, C.c_double, C.c_double]),
     'sph_nnps_set_extend': (C.c_int, [_P, C.c_double, C.c_double, C.c_double]),

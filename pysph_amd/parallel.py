@@ -193,6 +193,20 @@ class DeviceHaloOps(object):
             self.ctx._h, self.id, self.nprops, self.props, C.c_void_p(buf.data_ptr()), int(cap),
             float(h_promise), float(m_promise), C.c_void_p(flags.data_ptr() + 4 * int(slot))))
 
+    def append_padded_faces(self, bufs, caps, h_promise, m_promise, flags, slot):
+        """the messages of all faces of this array (lo face first) in ONE launch (sph_halo_append_padded2)"""
+        bufs, caps = list(bufs), [int(c) for c in caps]
+        if len(bufs) > 2:
+            raise ValueError('an array has at most two faces')
+        while len(bufs) < 2:
+            bufs.append(None)
+            caps.append(0)
+        dev._check(self.lib.sph_halo_append_padded2(
+            self.ctx._h, self.id, self.nprops, self.props,
+            C.c_void_p(bufs[0].data_ptr()) if bufs[0] is not None else None, caps[0],
+            C.c_void_p(bufs[1].data_ptr()) if bufs[1] is not None else None, caps[1],
+            float(h_promise), float(m_promise), C.c_void_p(flags.data_ptr() + 4 * int(slot))))
+
     def flag_words(self, n=1):
         """device words sph_halo_append_padded ORs into, one per array of the exchange
         (bit 0: incomplete message, bit 1: a ghost broke the promise of its array)"""
@@ -209,11 +223,20 @@ class DeviceHaloOps(object):
         torch = self.torch
         n = len(tensors)
         pin = self.__dict__.get('_hdr_pin2')
-        if pin is None or pin.numel() < n + nflags:
-            pin = self._hdr_pin2 = torch.empty(max(n + nflags, 64), dtype=torch.float64).pin_memory()
-        vals = torch.cat([torch.stack([t[-1] for t in tensors]),
-                          self.flag_words(nflags)[:nflags].to(torch.float64)])
-        pin[:n + nflags].copy_(vals, non_blocking=True)
+        if pin is None:
+            pin = self._hdr_pin2 = torch.empty(64, dtype=torch.float64).pin_memory()
+        if n <= 48 and n + nflags <= 64 and self._shares_torch_stream():
+            # ONE launch writes the headers and the flag words into the pinned buffer (sph_queue_values)
+            ptrs = (C.c_void_p * n)(*[t.data_ptr() + (t.numel() - 1) * 8 for t in tensors])
+            dev._check(self.lib.sph_queue_values(self.ctx._h, n, ptrs, nflags,
+                                                 C.c_void_p(self.flag_words(nflags).data_ptr()),
+                                                 C.c_void_p(pin.data_ptr())))
+        else:
+            if pin.numel() < n + nflags:
+                pin = self._hdr_pin2 = torch.empty(n + nflags, dtype=torch.float64).pin_memory()
+            vals = torch.cat([torch.stack([t[-1] for t in tensors]),
+                              self.flag_words(nflags)[:nflags].to(torch.float64)])
+            pin[:n + nflags].copy_(vals, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         return (ev, n, nflags)
@@ -545,6 +568,12 @@ def _exchange_steps(hs, drop, overlap):
     messages.  Between one pair of ranks messages match in posting order: sends
     hi-face first, receives lo-face first (periodic axis with <= 2 ranks: both
     faces talk to the same peer), arrays in the same order on both sides."""
+    if hs and hs[0].protocol == 'padded' and hs[0].promise and hs[0].neighbours() and not all(h.promised for h in hs):
+        _padded_collect(_active(hs))
+        _establish_promises(hs)   # collective, over ALL arrays; the exchange after it goes the counted way
+    hs = _active(hs)              # (arrays that hold no particle on ANY rank take no part)
+    if not hs:
+        return
     h0 = hs[0]
     dist, ops0, world, na = h0.dist, h0.ops, h0.world, len(hs)
     nbrs = h0.neighbours()
@@ -565,8 +594,6 @@ def _exchange_steps(hs, drop, overlap):
             h.ops.drop_ghosts()
     if not nbrs:
         return
-    if h0.protocol == 'padded' and h0.promise and not all(h.promised for h in hs):
-        _establish_promises(hs)   # collective; this exchange goes the counted way anyway
     fixed = h0.protocol in ('capacity', 'padded') and all(
         h.cap_send.get(s) is not None and h.cap_recv.get(s) is not None for h in hs for s in sides)
     # with fixed-capacity messages and device-side packing the host never sees
@@ -742,6 +769,11 @@ def _establish_promises(hs):
         h.h_promise = glo[2 * a] if glo[2 * a] == ghi[2 * a] else float('nan')
         h.m_promise = glo[2 * a + 1] if glo[2 * a + 1] == ghi[2 * a + 1] else float('nan')
         h.promised = True
+        # an array without a single particle on ANY rank (a dam break without its obstacle; min = +inf, max = -inf) takes no
+        # part in the exchanges until the promises are renewed: its empty messages would leave nothing but padding rows
+        # behind, an array "with rows but no mass" that keeps the rank off the one-launch merged evaluation and makes every
+        # neighbour update look at h and m
+        h.skip = hasattr(h.ops, 'hm_range') and glo[2 * a] > ghi[2 * a] and glo[2 * a + 1] > ghi[2 * a + 1]
         h.padded_ok = glo[-1] > 0.5
         if hasattr(h.ops, 'set_promise'):
             h.ops.set_promise(h.h_promise, h.m_promise, send=h.send_promised or not h.padded_ok)
@@ -758,6 +790,10 @@ def _padded_eligible(h):
         h.padded_ok = bool(hasattr(h.ops, 'append_padded') and hasattr(h.ops, 'select_pack') and
                            getattr(h.ops, '_shares_torch_stream', lambda: True)())
     return h.padded_ok
+
+
+def _active(hs):
+    return [h for h in hs if not getattr(h, 'skip', False)]
 
 
 class GhostsIncomplete(RuntimeError):
@@ -807,7 +843,8 @@ def _padded_collect(hs):
     that used those ghosts has been consumed).  Callers that verify after queueing
     the evaluation (Integrator.compute_accelerations, bench.py) never get here
     with anything wrong."""
-    got = _padded_headers(hs)
+    hs = _active(hs)
+    got = _padded_headers(hs) if hs else None
     if got is None:
         return
     keys, sent, recv, flags, _, _ = got
@@ -842,7 +879,8 @@ def verify_halos(hs):
     and overwrite their own results).  A ghost that broke the promise of its
     array's ONE h / m raises: the sender's properties have to be looked at again
     collectively (`SlabDecomposition.renew_promises`)."""
-    got = _padded_headers(hs)
+    hs = _active(hs)
+    got = _padded_headers(hs) if hs else None
     if got is None:
         return True
     keys, sent, recv, flags, out, inb = got
@@ -919,24 +957,33 @@ def _exchange_padded(hs, nbrs):
     shift_of = {s: shift for s, _, shift in nbrs}
     send_order = sorted(nbrs, key=lambda nb: -nb[0])
     recv_order = sorted(nbrs, key=lambda nb: nb[0])
-    out, inb = [], []
+    # ONE message per face and direction: the arrays' messages ([nprops][capacity] rows + header each) back to back in one
+    # buffer -- 2 sends + 2 receives per exchange whatever the number of arrays (a dam break's three were 12 point-to-point
+    # operations for torch to queue; both ends derive the same layout from the capacities they share)
+    out, inb = [{} for _ in hs], [{} for _ in hs]
+    face_out, face_in = {}, {}
+    for s in sides:
+        so = [h.cap_send[s] * h.ops.nprops + 1 for h in hs]
+        si = [h.cap_recv[s] * h.ops.nprops + 1 for h in hs]
+        face_out[s] = ops0.message_buffer(('face-send', s), sum(so))
+        face_in[s] = ops0.message_buffer(('face-recv', s), sum(si))
+        oo = oi = 0
+        for a in range(na):
+            out[a][s] = face_out[s][oo:oo + so[a]]
+            inb[a][s] = face_in[s][oi:oi + si[a]]
+            oo += so[a]
+            oi += si[a]
     for a, h in enumerate(hs):
-        npr, oa, ia = h.ops.nprops, {}, {}
-        for s in sides:
-            oa[s] = h.ops.message_buffer(('send', s), h.cap_send[s] * npr + 1)
-            ia[s] = h.ops.message_buffer(('recv', s), h.cap_recv[s] * npr + 1)
         h.ops.select_pack(h.lo + h.width, h.hi - h.width,
                           [shift_of.get(0, 0.0), shift_of.get(1, 0.0)],
                           [h.cap_send.get(0, 0), h.cap_send.get(1, 0)],
-                          [oa.get(0), oa.get(1)])
-        out.append(oa)
-        inb.append(ia)
+                          [out[a].get(0), out[a].get(1)])
     for h in hs:
         f = getattr(h.ops, 'before_comm', None)
         if f is not None:
             f()
-    reqs = [dist.P2POp(dist.isend, out[a][s], peer) for s, peer, _ in send_order for a in range(na)]
-    reqs += [dist.P2POp(dist.irecv, inb[a][s], peer) for s, peer, _ in recv_order for a in range(na)]
+    reqs = [dist.P2POp(dist.isend, face_out[s], peer) for s, peer, _ in send_order]
+    reqs += [dist.P2POp(dist.irecv, face_in[s], peer) for s, peer, _ in recv_order]
     if reqs:
         for w in dist.batch_isend_irecv(reqs):
             w.wait()                  # stream-level for device transports: nothing here blocks the host
@@ -948,8 +995,12 @@ def _exchange_padded(hs, nbrs):
     flags = _flag_words(hs)           # ONE set of flag words for all arrays of the exchange, a word per array
     for a, h in enumerate(hs):
         h.recv_rows = dict(h.cap_recv)    # rows each face's message was appended with (a repair re-appends them)
-        for s, _, _ in nbrs:          # lo side first: deterministic
-            h.ops.append_padded(inb[a][s], h.cap_recv[s], h.h_promise, h.m_promise, flags, a)
+        if hasattr(h.ops, 'append_padded_faces'):
+            h.ops.append_padded_faces([inb[a][s] for s, _, _ in nbrs], [h.cap_recv[s] for s, _, _ in nbrs],
+                                      h.h_promise, h.m_promise, flags, a)
+        else:
+            for s, _, _ in nbrs:      # lo side first: deterministic
+                h.ops.append_padded(inb[a][s], h.cap_recv[s], h.h_promise, h.m_promise, flags, a)
         h.padded_exchanges += 1
     msgs = [out[a][s] for a, s in keys] + [inb[a][s] for a, s in keys]
     h0.padded_pending = (ops0.queue_headers(msgs, na), keys, out, inb)
@@ -1006,7 +1057,7 @@ class SlabDecomposition(object):
         exchange is a counted one."""
         _padded_collect(self.halos)
         if self.halos[0].promise:
-            _establish_promises(self.halos)
+            _establish_promises(self.halos)     # (also decides anew which arrays are empty everywhere)
 
     def faces(self):
         """(lo, hi) along the slab axis outside which every ghost of this rank
@@ -1027,12 +1078,19 @@ class SlabDecomposition(object):
         self.migrate()
         self.exchange()
 
-    def rebalance(self, nbins=4096, weights=None):
+    def rebalance(self, nbins=4096, weights=None, cost=None):
         """Move the slab faces so that every rank owns about the same number
         of real particles (optionally weighted per array, e.g. fluid particles
         cost more than boundary ones): global histogram of the slab-axis
         coordinate (all_reduce SUM), faces at its quantiles, then migrate until
-        every particle is home (a particle moves one slab per round)."""
+        every particle is home (a particle moves one slab per round).
+
+        `cost` (seconds this rank spent computing per step, MEASURED: device
+        timers, HipParallelManager(cost_fn=...)): equal TIME instead of equal
+        count -- every particle of this rank weighs cost / n_local, so a rank that
+        was slow per particle (the end slab of a dam-break tank: a sparse grid,
+        most of the wall particles) gives particles away.  The reference balances
+        by Zoltan's object weights (parallel_manager.pyx:577-640)."""
         import numpy as np
         dist = self.dist
         ops0 = self.halos[0].ops
@@ -1048,8 +1106,12 @@ class SlabDecomposition(object):
                                  device=getattr(ops0, 'device', None))[0]
         span = max(gmax - gmin, 1e-300)
         hist = np.zeros(nbins)
+        per_particle = 1.0
+        if cost is not None:
+            nw = sum((1.0 if weights is None else float(weights[k])) * c.size for k, c in enumerate(coords))
+            per_particle = float(cost) / nw if nw > 0 else 0.0
         for k, c in enumerate(coords):
-            w = 1.0 if weights is None else float(weights[k])
+            w = per_particle * (1.0 if weights is None else float(weights[k]))
             if c.size:
                 b = np.minimum(((c - gmin) / span * nbins).astype(np.int64),
                                nbins - 1)
@@ -1095,18 +1157,23 @@ class HipParallelManager(object):
     all-reduces, with an optional re-balance every ``rebalance_every`` updates
     (the reference's ``lb_freq``)."""
 
-    def __init__(self, decomposition, rebalance_every=0, weights=None):
+    def __init__(self, decomposition, rebalance_every=0, weights=None, cost_fn=None):
+        """cost_fn: a callable returning the seconds THIS rank spent computing since its
+        last call (e.g. `device_cost_fn(ctx)`: the library's kernel timers); the
+        re-balance then equalises measured time instead of particle counts"""
         self.dec = decomposition
         self.dist = decomposition.dist
         self.rebalance_every = int(rebalance_every)
         self.weights = weights
+        self.cost_fn = cost_fn
         self.count = 0
         self._device = getattr(decomposition.halos[0].ops, 'device', None)
 
     def update(self):
         self.count += 1
         if self.rebalance_every and self.count % self.rebalance_every == 0:
-            self.dec.rebalance(weights=self.weights)
+            cost = self.cost_fn() if self.cost_fn is not None else None
+            self.dec.rebalance(weights=self.weights, cost=cost)
             self.dec.exchange()
         else:
             self.dec.update()
@@ -1121,6 +1188,18 @@ class HipParallelManager(object):
 
     def reduce_min(self, values):
         return allreduce_scalars(values, 'min', dist=self.dist, device=self._device)
+
+
+def device_cost_fn(ctx, keys=('nnps', 'pack', 'eos', 'pair', 'stage')):
+    """seconds of kernel time the context has spent since the last call (the
+    library's event timers, switched on here): HipParallelManager(cost_fn=...)"""
+    ctx.timer_enable(True)
+
+    def cost():
+        t = sum(ctx.timer_get(k)[0] for k in keys) * 1e-3
+        ctx.timer_reset()
+        return t
+    return cost
 
 
 def allreduce_scalars(values, op, dist=None, device=None):

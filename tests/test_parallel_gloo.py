@@ -324,6 +324,44 @@ def test_two_rank_halo_matches_single_domain(tmp_path, oracle, periodic, world):
     assert gmax == full.dt_cfl[:nfull].max()      # all_reduce(MAX) of the dt input
 
 
+def _worker_cost(rank, world, port, out):
+    """rebalance(cost=...): rank 0 reports three times the time per particle of the others -- the faces move so that the
+    measured TIME is equal, i.e. rank 0 keeps about a third of the particles per unit of the others' share"""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from test_hip_parity import make_cube
+        from pysph_amd.parallel import SlabDecomposition
+        from pysph_amd.particle_array import ParticleArray
+        full, dx = make_cube(16)
+        x = full.x
+        lo, hi = rank / float(world), (rank + 1) / float(world)
+        own = np.nonzero(((x >= lo) | (rank == 0)) & ((x < hi) | (rank == world - 1)))[0]
+        pa = ParticleArray(name='fluid', **{k: v[own].copy() for k, v in full.properties.items()})
+        dec = SlabDecomposition([pa], None, rank, world, axis=0, width=2.6 * dx, lo=lo, hi=hi,
+                                ops_factory=lambda a, ax, p: NumpyHaloOps(a, ax), dist=dist)
+        dec.update()
+        n0 = pa.get_number_of_particles(True)
+        dec.rebalance(nbins=512, cost=(3.0 if rank == 0 else 1.0) * n0 * 1e-9)
+        dec.exchange()
+        np.save(out % rank, np.array([n0, pa.get_number_of_particles(True)]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rebalance_by_measured_time(tmp_path):
+    out = str(tmp_path / 'cost%d.npy')
+    mp.spawn(_worker_cost, args=(3, _free_port(), out), nprocs=3, join=True)
+    n = [np.load(out % r) for r in range(3)]
+    total = sum(v[0] for v in n)
+    assert sum(v[1] for v in n) == total                      # nobody lost
+    # the measured cost belongs to the REGION a rank held: the first third of the cube weighs 3 per particle, the rest 1;
+    # thirds of that total (5 n / 9 each) are 5/27, 7/27 and 15/27 of the particles (a lattice plane of 256 either way)
+    for got, share in zip(n, (5, 7, 15)):
+        assert abs(got[1] - share * total / 27.0) < 300, [v[1] for v in n]
+
+
 def test_slab_bounds_equal_counts():
     from pysph_amd.parallel import slab_bounds
     rng = np.random.default_rng(0)

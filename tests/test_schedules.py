@@ -54,7 +54,8 @@ def _run(argv, opts, steps=2):
         for f in w.fields:
             if f in pa.properties:
                 out[pa.name + '.' + f] = np.array(pa.get(f)[:nreal])
-    cnt = {k: ctx.timer_get(k)[1] for k in ('n_eos_fused', 'n_nl_keep', 'n_nl_reuse', 'n_mass_fused', 'n_merged', 'n_tension_flag')}
+    cnt = {k: ctx.timer_get(k)[1] for k in ('n_eos_fused', 'n_nl_keep', 'n_nl_reuse', 'n_mass_fused', 'n_merged', 'n_tension_flag',
+                                            'n_dest_list')}
     res = bench.parity_check(w, host_in, nnps, domain,
                              bench.PARITY_TOL if args.dtype == 'f64' else 5e-5)
     del nnps, a_eval, step
@@ -156,6 +157,22 @@ def test_normalised_masks_are_bit_identical(argv):
         assert np.array_equal(on[k], off[k]), k
 
 
+
+
+def test_wave_tiles_of_the_real_particles_are_bit_identical():
+    """round 6 (option dest_list): a pair launch whose destinations are exactly the real particles takes its wave tiles
+    from the list of real positions the neighbour update made -- 64 consecutive REAL particles per wavefront instead of 64
+    consecutive positions of the cell order, of which a periodic box's images (here 40 % of the rows) are idle lanes.
+    Which wavefront serves a destination changes; its candidates, their order and every sum do not: bit-identical.  The
+    density pass (Group.real = False: every row is a destination) does not take the list."""
+    argv = ['--workload', 'taylor_green', '--n1', '40']
+    on, c_on, r_on = _run(argv, {'dest_list': 2})
+    auto, c_auto, r_auto = _run(argv, {})
+    off, c_off, r_off = _run(argv, {'dest_list': 0})
+    assert r_on['parity_ok'] and r_off['parity_ok'] and r_on['parity_neighbour_count_mismatches'] == 0
+    assert c_on['n_dest_list'] == 2 and c_auto['n_dest_list'] == 2 and c_off['n_dest_list'] == 0     # the force pass of two steps
+    for k in on:
+        assert np.array_equal(on[k], off[k]) and np.array_equal(auto[k], off[k]), k
 
 
 @pytest.mark.parametrize('argv', [['--workload', 'taylor_green', '--n1', '48'],
