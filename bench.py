@@ -876,10 +876,15 @@ def setup(args, w, rank, world, dist, ctx):
     return nnps, a_eval, halo, domain, step, ordered
 
 
-def timed(steps, warmup, step, barrier, ctx):
+def timed(steps, warmup, step, barrier, ctx, breakdown_steps=6):
+    """W warm-up steps, then EXACTLY `steps` timed ones between barrier + synchronize.  In the timed region the library
+    times the PAIR launches only (HIP events on the launch stream: roofline.achieved comes from them); the per-class
+    breakdown (nnps / pack / eos, the pair families) is taken in a few extra steps AFTER the timed region with every
+    class timed -- the event markers around each region cost the stream ~5 us each, eight per step were 2 % of the
+    headline step (round 5 timed every class inside the timed region)."""
     for _ in range(warmup):
         step()
-    ctx.timer_enable(True)
+    ctx.timer_enable(2)
     ctx.timer_reset()
     barrier()
     t0 = time.perf_counter()
@@ -887,9 +892,20 @@ def timed(steps, warmup, step, barrier, ctx):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    ctx.timer_enable(False)
-    timers = {k: ctx.timer_get(k) for k in ('nnps', 'pack', 'eos', 'pair') + PAIR_FAMILIES}
-    timers['n_async'] = ctx.timer_get('n_async')     # neighbour updates that made no device->host round trip
+    pair = ctx.timer_get('pair')
+    n_async = ctx.timer_get('n_async')               # neighbour updates that made no device->host round trip
+    ctx.timer_enable(1)
+    ctx.timer_reset()
+    nb = max(1, min(breakdown_steps, steps))
+    for _ in range(nb):
+        step()
+    barrier()
+    ctx.timer_enable(0)
+    scale = float(steps) / nb                        # (reported per `steps`, like the pair figure)
+    timers = {k: (ctx.timer_get(k)[0] * scale, int(round(ctx.timer_get(k)[1] * scale)))
+              for k in ('nnps', 'pack', 'eos') + PAIR_FAMILIES}
+    timers['pair'] = pair
+    timers['n_async'] = n_async
     return elapsed, timers
 
 

@@ -594,6 +594,9 @@ int sph_set_option(sph_ctx *ctx, const char *key, long value);
 /* acceleration_eval_cython.mako:14-144): accumulated hipEvent time per     */
 /* kernel class since the last reset.                                       */
 /* ---------------------------------------------------------------------- */
+/* on = 1: every kernel class is timed (an event pair around each region); 2: the pair
+ * launches only (T_PAIR) -- the event markers themselves cost the stream a few
+ * microseconds each; 0: off.                                                   */
 int sph_timer_enable(sph_ctx *ctx, int on);
 int sph_timer_reset(sph_ctx *ctx);
 /* keys: "nnps", "pack", "eos", "pair", "stage"; the pair launches once more per

@@ -503,7 +503,15 @@ template <class T> struct FamWCSPH_T {
                                                 const T (&s)[NA], uint32_t fl, const A &a, bool pass = true)
     {
         PairGeomT<T> g;
-        pair_geom<KK, UH>(g, pi, pj, r2, a);
+        // (one transcendental per pair where the momentum equation acts: pair_geom_mom)
+        constexpr bool MRG = SPH_MERGED_RSQ && sizeof(T) == 8 && KK != 4;
+        T tt_m = T(0.0);
+        if constexpr (MRG) {
+            if (fl & F_MOM) tt_m = pair_geom_mom<KK, UH>(g, pi, pj, r2, T(0.5) * (D.rho + s[4]), a);
+            else pair_geom<KK, UH>(g, pi, pj, r2, a);
+        } else {
+            pair_geom<KK, UH>(g, pi, pj, r2, a);
+        }
         const T tg = pair_gradfac<KK, UH>(g);
         const T vij0 = D.u - s[0], vij1 = D.v - s[1], vij2 = D.w - s[2]; // VIJ equation.py:214-223
         const T vdotx = vij0 * g.xij[0] + vij1 * g.xij[1] + vij2 * g.xij[2];
@@ -516,7 +524,7 @@ template <class T> struct FamWCSPH_T {
             if (fl & (F_XSPH | F_TENSILE)) wij = pair_w<KK, UH>(g);
             if (fl & F_MOM) { // wc/basic.py:204-259
                 const T re = r2 + g.eps;
-                const T tt = fast_rcp(re * rhoij);
+                const T tt = MRG ? tt_m : fast_rcp(re * rhoij);
                 const T inv_re = rhoij * tt;
                 rhoij1 = re * tt;
                 const T hv = g.hij * vdotx;
@@ -741,7 +749,10 @@ template <class T> struct FamWCSPHM_T : FamWCSPHE_T<T, true> {
                                                 const T (&s)[8], uint32_t ct, const A &a, bool pass = true)
     {
         PairGeomT<T> g;
-        pair_geom<KK, UH>(g, pi, pj, r2, a);
+        constexpr bool MRG = SPH_MERGED_RSQ && sizeof(T) == 8 && KK != 4;
+        T tt_m = T(0.0);
+        if constexpr (MRG) tt_m = pair_geom_mom<KK, UH>(g, pi, pj, r2, T(0.5) * (D.rho + s[4]), a);
+        else pair_geom<KK, UH>(g, pi, pj, r2, a);
         const T tg = pair_gradfac<KK, UH>(g);
         const T vij0 = D.u - s[0], vij1 = D.v - s[1], vij2 = D.w - s[2];
         const T vdotx = vij0 * g.xij[0] + vij1 * g.xij[1] + vij2 * g.xij[2];
@@ -754,7 +765,7 @@ template <class T> struct FamWCSPHM_T : FamWCSPHE_T<T, true> {
         const T wij = pair_w<KK, UH>(g);
         // wc/basic.py:204-259
         const T re = r2 + g.eps;
-        const T tt = fast_rcp(re * rhoij);
+        const T tt = MRG ? tt_m : fast_rcp(re * rhoij);
         const T inv_re = rhoij * tt;
         const T rhoij1 = re * tt;
         const T hv = g.hij * vdotx;

@@ -278,6 +278,7 @@ struct sph_ctx {
 
     // timers
     bool timers_on = false;
+    int timer_mask = 1;     // 1: every class; 2: the pair launches only (sph_timer_enable)
     Timer timers[T_COUNT];
 };
 

@@ -221,6 +221,42 @@ __device__ __forceinline__ void pair_geom(PairGeomT<T> &g, const real4<T> &pi, c
     }
     g.q = g.rij * g.h1;
 }
+// The same with ONE transcendental for the pair (fp64): the momentum equation needs 1 / ((r2 + eps) rhoij) next to
+// r = sqrt(r2) and 1 / r.  With P = (r2 + eps) rhoij:  t = rsqrt(r2 P^2) = 1 / (r P)  =>  1/r = t P,  r = r2 (1/r),
+// 1/P = t r -- v_rsq_f64 + one Newton step instead of v_rsq_f64 + v_rcp_f64 + a step each (the transcendentals issue at a
+// quarter of the fp64 rate).  r2 is clamped to 1e-300 first: coincident particles get r ~ 1e-150 (below every r > 1e-12
+// guard) and still the exact 1/P.  rho_ij: RHOIJ of equation.py:196; returns tt = 1 / ((r2 + eps) rhoij).
+#ifndef SPH_MERGED_RSQ
+#define SPH_MERGED_RSQ 0 // measured (profiles/r06_ab_tables.txt): 1.818-1.836 ms against 1.825-1.842 on the 4 M cube, 2.114 against 2.097 on the 4 M dam break -- nothing; off
+#endif
+template <int KK, bool UH, class A>
+__device__ __forceinline__ double pair_geom_mom(PairGeomT<double> &g, const double4 &pi, const double4 &pj, double r2, double rhoij, const A &a)
+{
+    typedef double T;
+    g.xij[0] = pi.x - pj.x; g.xij[1] = pi.y - pj.y; g.xij[2] = pi.z - pj.z;
+    g.r2 = r2;
+    if (UH) {
+        g.hij = (T)a.hu; g.h1 = (T)a.h1u; g.fac = (T)a.facu; g.eps = (T)a.epsu;
+    } else {
+        g.hij = T(0.5) * (pi.w + pj.w);
+        g.h1 = fast_rcp(g.hij);
+        g.fac = kernel_norm((T)a.k.sigma, g.h1, a.k.dim);
+        g.eps = T(0.01) * g.hij * g.hij;
+    }
+    const T P = (r2 + g.eps) * rhoij;
+    const T r2c = raw_max(r2, 1e-300);
+    const T aa = r2c * (P * P);
+    const T y = __builtin_amdgcn_rsq(aa);
+    T gg = aa * y, hh = 0.5 * y;
+    const T rr = fma(-hh, gg, 0.5);
+    hh = fma(hh, rr, hh);
+    const T t = hh + hh;            // 1 / (r P)
+    g.rinv = t * P;
+    g.rij = r2c * g.rinv;
+    g.q = g.rij * g.h1;
+    return t * g.rij;               // 1 / P
+}
+
 template <int KK, bool UH, class T> __device__ __forceinline__ T pair_w(const PairGeomT<T> &g) { return SphKernel<KK>::template w<UH>(g.q) * g.fac; }
 // GRADH(XIJ, RIJ, h) = dW/dh (kernels.py gradient_h, e.g. :138-163): -fac*h1*(dw*q + w*dim)
 template <int KK, bool UH, class T> __device__ __forceinline__ T pair_gradh(const PairGeomT<T> &g, int dim)

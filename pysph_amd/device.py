@@ -17,7 +17,8 @@ import numpy as np
 from .particle_array import get_npy
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsphhip.so')
+# (SPH_LIBRARY: another build of the same sources, for A/B measurements of compile-time switches)
+LIB_PATH = os.environ.get('SPH_LIBRARY') or os.path.join(_HERE, 'libsphhip.so')
 
 MAX_ARRAYS = 8
 MAX_PAR = 16

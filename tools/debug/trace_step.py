@@ -3,7 +3,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # last occurrence of the pair kernel -> walk back to the previous one
-idx = [i for i, r in enumerate(rows) if 'k_pair_wave' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'k_pair_wave' in r['Kernel_Name'] and 'FamNbr' not in r['Kernel_Name']]
 i1, i0 = idx[-1], idx[-2]
 t0 = int(rows[i0]['End_Timestamp'])
 prev_end = t0
