@@ -366,6 +366,7 @@ class SlabHalo(object):
         self.ops = ops or DeviceHaloOps(pa, ctx, props, axis)
         self.last_counts = (0, 0, 0, 0)   # sent lo/hi, received lo/hi
         self.last_migrated = (0, 0, 0, 0)
+        self.total_migrated = 0           # particles this rank has handed over since the start
         # ghost exchange protocol (exchange_halos): 'capacity' = fixed-size
         # messages with the row count in their last element, sized from the
         # count both ends saw in the previous exchange; 'handshake' = counts
@@ -469,6 +470,7 @@ class SlabHalo(object):
                 ops.append_real(in_buf[s], recv_cnt[s])
         self.last_migrated = (n_lo, n_hi, recv_cnt.get(0, 0),
                               recv_cnt.get(1, 0))
+        self.total_migrated += n_lo + n_hi
         return n_lo + n_hi
 
 

@@ -132,3 +132,128 @@ def test_bench_workloads_on_eight_ranks_match_one_domain(tmp_path, oracle, workl
         per_rank = [sum(d[a.name + '/gid'].size for a in w1.arrays) for d in ranks]
         assert max(per_rank) - min(per_rank) <= 600, per_rank      # (a lattice plane of the tank holds ~460 particles)
     assert all(int(d[w1.arrays[0].name + '/ghosts'][0]) > 0 for d in ranks[:4])
+
+
+# ---------------------------------------------------------------------------
+# The protocol UNDER MOTION on CPU ranks: what tests/test_integrator.py runs with two thread-ranks on a GPU, here
+# with three gloo processes, the oracle as the evaluator and the numpy double as the device.
+# ---------------------------------------------------------------------------
+def _worker_motion(rank, world, port, out, nsteps, tight):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['OMP_NUM_THREADS'] = '1'
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import pysph_amd.parallel as par
+        from oracle import oracle as orc
+        from oracle import steppers
+        from pysph_amd.examples import dam_break_3d as db
+        from test_parallel_gloo import NumpyPaddedHaloOps
+        dx = 0.08
+        if tight:      # capacities without headroom: the lattice plane that crosses a face outgrows its message
+            par._capacity = lambda c: ((c + 8 + 7) // 8) * 8
+            par._capacity_tight = par._capacity
+        full = db.create_particles(dx)
+        g0 = 0
+        for a in full:
+            n = a.get_number_of_particles()
+            a.add_property('e0', data=np.arange(g0, g0 + n, dtype=np.float64))
+            g0 += n
+        full[0].u[:] = 4.0
+        cuts = par.slab_bounds(np.concatenate([a.x for a in full]), world)
+        lo, hi = float(cuts[rank]), float(cuts[rank + 1])
+        arrays = [a.extract_particles(np.nonzero((a.x >= lo) & (a.x < hi))[0], name=a.name) for a in full]
+        eqs = db.create_scheme(dx).get_equations()
+        kernel = db.create_kernel()
+        dec = par.SlabDecomposition(arrays, None, rank, world, axis=0, width=2.0 * db.hdx * dx * 1.05,
+                                    lo=max(lo, -1e30), hi=min(hi, 1e30), dist=dist, protocol='padded',
+                                    ops_factory=lambda pa, ax, p: NumpyPaddedHaloOps(pa, ax))
+        pm = par.HipParallelManager(dec, rebalance_every=25)
+        dt = 0.125 * db.hdx * dx / (1.1 * db.c0)
+        outs = ('arho', 'au', 'av', 'aw', 'ax', 'ay', 'az', 'p', 'cs', 'dt_cfl', 'dt_force')
+
+        def evaluate(t):
+            live = [a.extract_particles(np.nonzero(np.abs(a.x) < 1e17)[0], name=a.name) for a in arrays]
+            for b, a in zip(live, arrays):
+                b.set_num_real_particles(a.get_number_of_particles(True))
+            nn = orc.OracleNNPS(3, live, kernel.radius_scale)
+            nn.update()
+            ev = orc.OracleEval(live, eqs, kernel, nthreads=1)
+            ev.set_nnps(nn)
+            ev.compute(t, dt)
+            for b, a in zip(live, arrays):
+                nr = a.get_number_of_particles(True)
+                for f in outs:
+                    if f in a.properties:
+                        a.properties[f][:nr] = b.properties[f][:nr]
+
+        def accel(t):          # Integrator.compute_accelerations
+            pm.update()
+            evaluate(t)
+            while not pm.verify():
+                evaluate(t)
+        fluid = arrays[0]
+        t = 0.0
+        for _ in range(nsteps):          # EPECIntegrator.one_timestep with WCSPHStep (integrator.py:401-420)
+            steppers.wcsph_initialize(fluid)
+            accel(t)
+            steppers.wcsph_stage(fluid, dt, 1)
+            accel(t)
+            steppers.wcsph_stage(fluid, dt, 2)
+            t += dt
+        res = {}
+        for a in arrays:
+            nr = a.get_number_of_particles(True)
+            for f in ('e0', 'x', 'y', 'z', 'u', 'v', 'w', 'rho', 'au', 'av', 'aw', 'arho'):
+                res[a.name + '/' + f] = a.properties[f][:nr].copy()
+        hs = dec.halos
+        res['stats'] = np.array([sum(h.padded_exchanges for h in hs), sum(h.repaired_exchanges for h in hs),
+                                 sum(h.total_migrated for h in hs), pm.count])
+        np.savez(out % rank, **res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('tight', [False, True])
+def test_three_ranks_step_the_dam_break_through_the_padded_exchange(tmp_path, oracle, tight):
+    """30 EPEC steps of the three-array dam break on three slab ranks (gloo), the round-trip-free exchange verified
+    after every evaluation, particles migrating, a re-balance on the way, the front's lattice plane crossing a face --
+    with capacities without headroom (`tight`) that plane outgrows its message and is repaired.  Same state as one
+    domain stepped by the oracle, gid by gid."""
+    from helpers import rel_err
+    from oracle import steppers
+    from pysph_amd.examples import dam_break_3d as db
+    world, nsteps, dx = 3, 30, 0.08
+    out = str(tmp_path / 'm%d.npz')
+    mp.spawn(_worker_motion, args=(world, _free_port(), out, nsteps, tight), nprocs=world, join=True)
+    full = db.create_particles(dx)
+    g0 = 0
+    for a in full:
+        n = a.get_number_of_particles()
+        a.add_property('e0', data=np.arange(g0, g0 + n, dtype=np.float64))
+        g0 += n
+    full[0].u[:] = 4.0
+    eqs = db.create_scheme(dx).get_equations()
+    kernel = db.create_kernel()
+    dt = 0.125 * db.hdx * dx / (1.1 * db.c0)
+    nn = oracle.OracleNNPS(3, full, kernel.radius_scale)
+    ev = oracle.OracleEval(full, eqs, kernel, nthreads=4)
+    ev.set_nnps(nn)
+    t = 0.0
+    for _ in range(nsteps):
+        steppers.epec_step([full[0]], nn, ev, t, dt)
+        t += dt
+    ranks = [np.load(out % r) for r in range(world)]
+    for a in full:
+        gids = np.concatenate([d[a.name + '/e0'] for d in ranks]).astype(np.int64)
+        base = int(a.e0.min()) if a.get_number_of_particles() else 0
+        assert np.array_equal(np.sort(gids), np.arange(base, base + a.get_number_of_particles())), a.name
+        for f in ('x', 'y', 'z', 'u', 'v', 'w', 'rho', 'au', 'av', 'aw', 'arho'):
+            got = np.concatenate([d[a.name + '/' + f] for d in ranks])
+            e = rel_err(got, a.get(f)[gids - base], scale=max(np.abs(a.get(f)).max(), 1e-300))
+            assert e < 1e-9, (a.name, f, e)
+    stats = np.array([d['stats'] for d in ranks])
+    assert stats[:, 3].min() == 2 * nsteps                    # pm.update() before every evaluation
+    assert stats[:, 0].sum() > 2 * nsteps                     # ... nearly all of them through the padded exchange
+    assert stats[:, 2].sum() > 0                              # particles migrated (the column moves, the faces moved)
+    assert (stats[:, 1].sum() > 0) == tight, stats            # repaired exactly where the capacities had no headroom
