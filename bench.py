@@ -773,6 +773,10 @@ def setup(args, w, rank, world, dist, ctx):
         from pysph_amd.parallel import (ELASTIC_HALO_PROPS, SlabDecomposition,
                                         TVF_HALO_PROPS, WCSPH_HALO_PROPS)
         lo, hi, periodic, period = w.slab
+        if os.environ.get('SPH_HALO_TRANSPORT') == 'sphcomm' and dist is not None and not hasattr(dist, 'hub'):
+            # (opt-in) point-to-point transfers straight on RCCL on the context's stream, collectives on torch.distributed
+            from pysph_amd.parallel import SphCommTransport
+            dist = SphCommTransport(ctx, dist, rank, world)
         props = {'taylor_green': TVF_HALO_PROPS, 'elastic': ELASTIC_HALO_PROPS,
                  'elastic_block': ELASTIC_HALO_PROPS}.get(args.workload, WCSPH_HALO_PROPS)
         halo = SlabDecomposition(w.arrays, ctx, rank, world, axis=0,

@@ -59,6 +59,15 @@ int sph_halo_exchange(sph_ctx *ctx, int array_id, int axis, double lo, double hi
 int sph_halo_exchange_all(int n, sph_ctx **ctxs, int array_id, int axis, const double *lo, const double *hi,
                           double width, int periodic, double period, int nprops, const int *props, int drop,
                           size_t *counts4);
+/* One NCCL group of point-to-point transfers of DEVICE doubles on the context's
+ * stream: nsend sends (buffer, count, peer rank), then nrecv receives -- the
+ * batch of ParallelManager.remote_exchange_data's transfers
+ * (pysph/parallel/parallel_manager.pyx:159-210) for a caller that packs and
+ * appends itself (pysph_amd/parallel.py with SPH_HALO_TRANSPORT=sphcomm: the
+ * round-trip-free exchange without torch.distributed's stream hand-over).     */
+int sph_comm_sendrecv(sph_ctx *ctx, int nsend, const void *const *sendbufs, const size_t *sendcounts,
+                      const int *sendpeers, int nrecv, void *const *recvbufs, const size_t *recvcounts,
+                      const int *recvpeers);
 /* In-place MIN (op 0) / MAX (1) / SUM (2) of nvals <= 64 host doubles over all
  * ranks: the time-step and bounds reductions.                                */
 int sph_allreduce(sph_ctx *ctx, double *vals, int nvals, int op);

@@ -16,8 +16,8 @@ run_one() {   # name, pmc (0/1/2), bench args...
     local OUT=$ROOT/gpurun_out/$TAG/$NAME
     mkdir -p "$OUT"
     local BENCH="python $ROOT/bench.py --no-cpu-baseline --no-check --no-extras --no-counters $*"
-    $BENCH --steps 10 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
-    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o runc -- $BENCH --steps 10 --warmup 3 > "$OUT/stats.log" 2>&1
+    $BENCH --steps 32 --warmup 6 > "$OUT/bench.json" 2> "$OUT/bench.err"
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o runc -- $BENCH --steps 32 --warmup 6 > "$OUT/stats.log" 2>&1
     if [ "$PMC" = 2 ]; then
         for SET in "FETCH_SIZE" "WRITE_SIZE" \
                    "GRBM_GUI_ACTIVE TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum" \

@@ -106,6 +106,34 @@ int sph_comm_init_all(int ndev, sph_ctx **ctxs)
     return SPH_OK;
 }
 
+// One NCCL group of point-to-point transfers of device doubles on the CONTEXT'S stream: what the Python transport hands
+// to torch.distributed.batch_isend_irecv, without the process group's stream hand-over in front of and behind the RCCL
+// kernel (measured on a slab rank of the 16 M dam break: ~30 us + ~16 us of idle stream per exchange).  Sends are posted
+// in the order given, then the receives: between one pair of ranks messages match in posting order.
+int sph_comm_sendrecv(sph_ctx *c, int nsend, const void *const *sendbufs, const size_t *sendcounts, const int *sendpeers,
+                      int nrecv, void *const *recvbufs, const size_t *recvcounts, const int *recvpeers)
+{
+    if (!c || !c->comm || nsend < 0 || nrecv < 0 || (nsend && (!sendbufs || !sendcounts || !sendpeers)) ||
+        (nrecv && (!recvbufs || !recvcounts || !recvpeers))) {
+        sph_set_error("sph_comm_sendrecv: bad arguments (or no communicator: sph_comm_init_rank first)");
+        return SPH_ERR_ARG;
+    }
+    SphComm *m = comm_of(c);
+    for (int k = 0; k < nsend; k++)
+        if (sendpeers[k] < 0 || sendpeers[k] >= m->world) { sph_set_error("sph_comm_sendrecv: peer %d of %d ranks", sendpeers[k], m->world); return SPH_ERR_ARG; }
+    for (int k = 0; k < nrecv; k++)
+        if (recvpeers[k] < 0 || recvpeers[k] >= m->world) { sph_set_error("sph_comm_sendrecv: peer %d of %d ranks", recvpeers[k], m->world); return SPH_ERR_ARG; }
+    if (nsend + nrecv == 0) return SPH_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    NCCL_TRY(ncclGroupStart());
+    for (int k = 0; k < nsend; k++)
+        NCCL_TRY_IN_GROUP(ncclSend(sendbufs[k], sendcounts[k], ncclDouble, sendpeers[k], m->comm, c->stream));
+    for (int k = 0; k < nrecv; k++)
+        NCCL_TRY_IN_GROUP(ncclRecv(recvbufs[k], recvcounts[k], ncclDouble, recvpeers[k], m->comm, c->stream));
+    NCCL_TRY(ncclGroupEnd());
+    return SPH_OK;
+}
+
 int sph_comm_destroy(sph_ctx *c)
 {
     if (!c || !c->comm) return SPH_OK;

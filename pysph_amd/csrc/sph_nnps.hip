@@ -156,6 +156,7 @@ template <class T> __device__ __forceinline__ T wave_incl_scan(T x, int lane)
     return x;
 }
 
+#define BIN_U 4 // trips of k_bin_keys whose position loads are in flight together
 __global__ __launch_bounds__(256) void k_bin_keys(BinArrays t, GridDesc g, BinWork w)
 {
     // this workgroup's array (uniform) and its share of it
@@ -170,12 +171,30 @@ __global__ __launch_bounds__(256) void k_bin_keys(BinArrays t, GridDesc g, BinWo
     uint32_t ngroups = 0; // (wave-uniform)
     double mn[5] = {DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX};
     double mx[5] = {-DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX};
-    for (size_t i0 = (size_t)lb * 256; i0 < n; i0 += (size_t)nba * 256) { // the trip count is uniform over the workgroup
+    // BIN_U trips at a time: their position loads (3 x BIN_U per lane) are in flight together -- one trip at a time the
+    // kernel was a chain of memory latencies (52 us at 4 M, no shorter at 2.4 M)
+    for (size_t ib = (size_t)lb * 256; ib < n; ib += (size_t)nba * 256 * BIN_U) { // the trip count is uniform over the workgroup
+        double qx[BIN_U], qy[BIN_U], qz[BIN_U];
+        size_t qj[BIN_U];
+#pragma unroll
+        for (int u = 0; u < BIN_U; u++) {
+            const size_t i = ib + (size_t)u * nba * 256 + threadIdx.x;
+            const bool valid = i < n;
+            qj[u] = valid && via ? (size_t)via[i] : i; // the particle this thread takes
+        }
+#pragma unroll
+        for (int u = 0; u < BIN_U; u++) {
+            const bool valid = ib + (size_t)u * nba * 256 + threadIdx.x < n;
+            qx[u] = valid ? x[qj[u]] : 0.0; qy[u] = valid ? y[qj[u]] : 0.0; qz[u] = valid ? z[qj[u]] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < BIN_U; u++) {
+        const size_t i0 = ib + (size_t)u * nba * 256;
+        if (i0 >= n) break; // (uniform)
         const size_t i = i0 + threadIdx.x;
         const bool valid = i < n;
-        double px = 0, py = 0, pz = 0;
-        const size_t j = valid && via ? (size_t)via[i] : i; // the particle this thread takes
-        if (valid) { px = x[j]; py = y[j]; pz = z[j]; }
+        const double px = qx[u], py = qy[u], pz = qz[u];
+        const size_t j = qj[u];
         const bool counts = valid && !is_parked(px); // padding rows (sph_halo_append_padded) are nobody's bounds, h or m
         // (raw_min / raw_max: ONE v_min_f64 / v_max_f64 each; fmin / fmax put a canonicalising v_max x, x in front)
         if (counts && mmx) {
@@ -202,6 +221,7 @@ __global__ __launch_bounds__(256) void k_bin_keys(BinArrays t, GridDesc g, BinWo
             // one atomic per bucket the wavefront's particles hit, all of them in ONE instruction (particles in no
             // spatial order make 64 groups: 64 single-lane atomic instructions cost 0.35 ms at 4 M)
             if (cnt) atomicAdd(&w.G[d], cnt);
+        }
         }
     }
     __shared__ double s[4][10];

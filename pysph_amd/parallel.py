@@ -1192,6 +1192,62 @@ class HipParallelManager(object):
         return allreduce_scalars(values, 'min', dist=self.dist, device=self._device)
 
 
+class SphCommTransport(object):
+    """`dist` for SlabHalo / SlabDecomposition with the POINT-TO-POINT transfers on
+    libsphcomm.so -- ncclSend / ncclRecv in one group on the context's own stream
+    (`sph_comm_sendrecv`) -- and everything else (the few collectives of set-up,
+    migration and re-balancing) on torch.distributed.  Opt-in
+    (`bench.py`: SPH_HALO_TRANSPORT=sphcomm): the process group's stream hand-over
+    around its RCCL kernel costs a slab rank ~45 us of idle stream per exchange.
+    The kernels, the messages and the protocol are the same; needs the context
+    to run on torch's current stream like the torch transport's fast path."""
+
+    class P2POp(object):
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    isend, irecv = 'isend', 'irecv'
+
+    def __init__(self, ctx, torch_dist, rank, world):
+        import torch
+        self.ctx, self.td = ctx, torch_dist
+        self.ReduceOp = torch_dist.ReduceOp
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libsphcomm.so')
+        self.lib = C.CDLL(path)
+        self.lib.sph_comm_sendrecv.restype = C.c_int
+        ident = (C.c_ubyte * 128)()
+        if rank == 0:
+            dev._check(self.lib.sph_comm_unique_id(ident))
+        t = torch.tensor(list(ident), dtype=torch.uint8, device=torch.device('cuda', ctx.device))
+        if world > 1:
+            torch_dist.broadcast(t, src=0)
+        ident = (C.c_ubyte * 128)(*[int(v) for v in t.cpu()])
+        dev._check(self.lib.sph_comm_init_rank(C.c_void_p(ctx._h.value if hasattr(ctx._h, 'value') else ctx._h), rank, world, ident))
+
+    def batch_isend_irecv(self, reqs):
+        sends = [r for r in reqs if r.op == 'isend']
+        recvs = [r for r in reqs if r.op == 'irecv']
+
+        def arrays(rs):
+            n = len(rs)
+            return ((C.c_void_p * max(n, 1))(*[r.tensor.data_ptr() for r in rs]),
+                    (C.c_size_t * max(n, 1))(*[r.tensor.numel() for r in rs]),
+                    (C.c_int * max(n, 1))(*[int(r.peer) for r in rs]))
+        sb, sc, sp = arrays(sends)
+        rb, rc, rp = arrays(recvs)
+        h = self.ctx._h
+        dev._check(self.lib.sph_comm_sendrecv(C.c_void_p(h.value if hasattr(h, 'value') else h), len(sends), sb, sc, sp,
+                                              len(recvs), rb, rc, rp))
+        return []                      # ordered by the stream itself: nothing to wait for
+
+    def close(self):
+        h = self.ctx._h
+        self.lib.sph_comm_destroy(C.c_void_p(h.value if hasattr(h, 'value') else h))
+
+    def __getattr__(self, name):       # all_gather_into_tensor, all_reduce, barrier, ...: torch.distributed
+        return getattr(self.td, name)
+
+
 def device_cost_fn(ctx, keys=('nnps', 'pack', 'eos', 'pair', 'stage')):
     """seconds of kernel time the context has spent since the last call (the
     library's event timers, switched on here): HipParallelManager(cost_fn=...)"""

@@ -175,6 +175,20 @@ def test_wave_tiles_of_the_real_particles_are_bit_identical():
         assert np.array_equal(on[k], off[k]) and np.array_equal(auto[k], off[k]), k
 
 
+def test_wave_tiles_of_the_real_particles_on_the_merged_order():
+    """... and on the merged order of a dam break's three arrays: a slab rank (`--emulate-rank`: real particles + the ghost
+    layers its two neighbours send, 18 % of the rows at this size) evaluated with the list forced on, left to the rule
+    (>= 1/8 of the rows: on) and off -- bit-identical, checked against the oracle, ONE merged launch either way."""
+    argv = ['--workload', 'dam_break', '--dx', '0.04', '--emulate-rank', '1/3']
+    on, c_on, r_on = _run(argv, {'dest_list': 2})
+    off, c_off, r_off = _run(argv, {'dest_list': 0})
+    assert r_on['parity_ok'] and r_off['parity_ok'] and r_on['parity_neighbour_count_mismatches'] == 0
+    assert c_on['n_merged'] == 2 and c_off['n_merged'] == 2
+    assert c_on['n_dest_list'] == 2 and c_off['n_dest_list'] == 0
+    for k in on:
+        assert np.array_equal(on[k], off[k]), k
+
+
 @pytest.mark.parametrize('argv', [['--workload', 'taylor_green', '--n1', '48'],
                                   ['--n1', '64'],
                                   ['--workload', 'dam_break', '--dx', '0.03'],
