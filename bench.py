@@ -269,6 +269,10 @@ def build_workload(args, rank, world):
         cached = _DAM_CACHE.get(args.dx) if args.emulate_rank else None
         arrays = [a.extract_particles(np.arange(a.get_number_of_particles()), name=a.name) for a in cached] \
             if cached else db.create_particles(args.dx)
+        if args.emulate_rank and not cached:
+            # (the tank as created -- BEFORE the seeded perturbation below, which every use applies itself)
+            _DAM_CACHE.clear()
+            _DAM_CACHE[args.dx] = [a.extract_particles(np.arange(a.get_number_of_particles()), name=a.name) for a in arrays]
         gid0 = 0
         # the example starts from rest at uniform density, where every pair
         # term but gravity vanishes: give the fluid the S-cube's seeded
@@ -287,9 +291,6 @@ def build_workload(args, rank, world):
                 # --vary-h: every particle its own smoothing length (a dam break with evolving h: the variable-h records)
                 a.h[:] = a.h * (1 + args.vary_h * np.random.default_rng(977 + len(a.name)).uniform(-1, 1, n))
         lo, hi = -1e30, 1e30
-        if args.emulate_rank and not cached:
-            _DAM_CACHE.clear()
-            _DAM_CACHE[args.dx] = [a.extract_particles(np.arange(a.get_number_of_particles()), name=a.name) for a in arrays]
         if args.emulate_rank:
             # ONE rank of an N-rank strong-scaling run WITHOUT the other ranks: this rank's slab of the tank (cut at the
             # quantiles of x like `--gpus N`) and, behind its real particles, the ghost layers its two neighbours
@@ -601,8 +602,12 @@ def _scale_group(f):
 
 def copy_arrays(arrays):
     """pristine host copies (same particle order) for the oracle"""
-    return [a.extract_particles(np.arange(a.get_number_of_particles()), name=a.name)
-            for a in arrays]
+    out = []
+    for a in arrays:
+        b = a.extract_particles(np.arange(a.get_number_of_particles()), name=a.name)
+        b.set_num_real_particles(a.get_number_of_particles(True))     # (--emulate-rank: ghosts behind the real particles)
+        out.append(b)
+    return out
 
 
 # ---------------------------------------------------------------------------
@@ -773,10 +778,15 @@ def setup(args, w, rank, world, dist, ctx):
         from pysph_amd.parallel import (ELASTIC_HALO_PROPS, SlabDecomposition,
                                         TVF_HALO_PROPS, WCSPH_HALO_PROPS)
         lo, hi, periodic, period = w.slab
-        if os.environ.get('SPH_HALO_TRANSPORT') == 'sphcomm' and dist is not None and not hasattr(dist, 'hub'):
-            # (opt-in) point-to-point transfers straight on RCCL on the context's stream, collectives on torch.distributed
+        if os.environ.get('SPH_HALO_TRANSPORT', 'sphcomm') == 'sphcomm' and dist is not None and not hasattr(dist, 'hub'):
+            # the point-to-point transfers straight on RCCL on the context's stream (libsphcomm.so: sph_comm_sendrecv),
+            # the few collectives on torch.distributed: the process group's stream hand-over around its RCCL kernel cost a
+            # slab rank of the 16 M dam break 0.09 ms per exchange.  SPH_HALO_TRANSPORT=torch: batch_isend_irecv.
             from pysph_amd.parallel import SphCommTransport
-            dist = SphCommTransport(ctx, dist, rank, world)
+            try:
+                dist = w.transport = SphCommTransport(ctx, dist, rank, world)
+            except Exception as e:      # (the same on every rank: they share the build)
+                sys.stderr.write('bench: libsphcomm transport unavailable (%s): torch.distributed point-to-point\n' % e)
         props = {'taylor_green': TVF_HALO_PROPS, 'elastic': ELASTIC_HALO_PROPS,
                  'elastic_block': ELASTIC_HALO_PROPS}.get(args.workload, WCSPH_HALO_PROPS)
         halo = SlabDecomposition(w.arrays, ctx, rank, world, axis=0,
@@ -947,6 +957,8 @@ def run(args, rank, local_rank, world, dist):
             a.gpu.pull()
         host_in = copy_arrays(w.arrays)
     elapsed, timers = timed(args.steps, args.warmup, step, barrier, ctx)
+    extra['halo_transport'] = None if halo is None else (
+        'libsphcomm (ncclSend/Recv on the context stream)' if getattr(w, 'transport', None) is not None else 'torch.distributed')
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

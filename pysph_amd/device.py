@@ -272,6 +272,9 @@ class HipContext(object):
 
     def close(self):
         if self._h:
+            t = self.__dict__.pop('_transport', None)
+            if t is not None:       # a libsphcomm communicator goes before its context (sphcomm.h)
+                t.close()
             self.lib.sph_ctx_destroy(self._h)
             self._h = _P()
 

@@ -1223,6 +1223,7 @@ class SphCommTransport(object):
             torch_dist.broadcast(t, src=0)
         ident = (C.c_ubyte * 128)(*[int(v) for v in t.cpu()])
         dev._check(self.lib.sph_comm_init_rank(C.c_void_p(ctx._h.value if hasattr(ctx._h, 'value') else ctx._h), rank, world, ident))
+        ctx._transport = self          # (HipContext.close destroys the communicator before the context)
 
     def batch_isend_irecv(self, reqs):
         sends = [r for r in reqs if r.op == 'isend']
@@ -1242,7 +1243,8 @@ class SphCommTransport(object):
 
     def close(self):
         h = self.ctx._h
-        self.lib.sph_comm_destroy(C.c_void_p(h.value if hasattr(h, 'value') else h))
+        if h:
+            self.lib.sph_comm_destroy(C.c_void_p(h.value if hasattr(h, 'value') else h))
 
     def __getattr__(self, name):       # all_gather_into_tensor, all_reduce, barrier, ...: torch.distributed
         return getattr(self.td, name)

@@ -273,3 +273,50 @@ def test_bench_taylor_green_path_two_ranks():
                           '--warmup', '1', '--no-cpu-baseline'])
     assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'slab2'
     assert out['config']['particles_per_gpu'] == 20 ** 3
+
+
+@pytest.mark.gpu
+def test_direct_rccl_transport_equals_torch_transport_on_one_rank():
+    """round 6: the point-to-point transfers of the ghost exchange straight on RCCL on the context's stream
+    (SphCommTransport -> libsphcomm.so sph_comm_sendrecv; the default of `bench.py --gpus N`) against
+    torch.distributed's batch_isend_irecv: a self-periodic slab (world size 1: both faces talk to the same peer, the
+    message-order case) gets the same ghosts and the same results, through the round-trip-free protocol."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import bench
+    from pysph_amd import device as dev
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29641')
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    res = {}
+    try:
+        for transport in ('torch', 'sphcomm'):
+            os.environ['SPH_HALO_TRANSPORT'] = transport
+            args = bench.parse_args(['--n1', '40', '--self-slab', '--no-cpu-baseline', '--no-extras'])
+            ts = torch.cuda.Stream()
+            with torch.cuda.stream(ts):
+                ctx = dev.HipContext(0, ts.cuda_stream)
+                bench.apply_options(args, ctx)
+                w = bench.build_workload(args, 0, 1)
+                nnps, a_eval, halo, domain, step, _ = bench.setup(args, w, 0, 1, dist, ctx)
+                assert (getattr(w, 'transport', None) is not None) == (transport == 'sphcomm')
+                for _ in range(4):
+                    step()
+                pa = w.arrays[0]
+                pa.gpu.sync_host()
+                n, nr = pa.gpu.get_number_of_particles(), pa.gpu.get_number_of_particles(True)
+                res[transport] = ({f: np.array(pa.get(f, only_real_particles=False)[:n]) for f in ('x', 'u', 'rho', 'au', 'arho', 'ax')},
+                                  n, nr, halo.halos[0].padded_exchanges)
+                del nnps, a_eval, step, halo
+                ctx.close()
+    finally:
+        os.environ.pop('SPH_HALO_TRANSPORT', None)
+        if own:
+            dist.destroy_process_group()
+    a, b = res['torch'], res['sphcomm']
+    assert a[1:3] == b[1:3] and a[1] > a[2] and b[3] >= 3
+    for f in a[0]:
+        assert np.array_equal(a[0][f], b[0][f]), f

@@ -180,11 +180,11 @@ def test_wave_tiles_of_the_real_particles_on_the_merged_order():
     layers its two neighbours send, 18 % of the rows at this size) evaluated with the list forced on, left to the rule
     (>= 1/8 of the rows: on) and off -- bit-identical, checked against the oracle, ONE merged launch either way."""
     argv = ['--workload', 'dam_break', '--dx', '0.04', '--emulate-rank', '1/3']
-    on, c_on, r_on = _run(argv, {'dest_list': 2})
-    off, c_off, r_off = _run(argv, {'dest_list': 0})
+    on, c_on, r_on = _run(argv, {'dest_list': 2}, steps=3)
+    off, c_off, r_off = _run(argv, {'dest_list': 0}, steps=3)
     assert r_on['parity_ok'] and r_off['parity_ok'] and r_on['parity_neighbour_count_mismatches'] == 0
-    assert c_on['n_merged'] == 2 and c_off['n_merged'] == 2
-    assert c_on['n_dest_list'] == 2 and c_off['n_dest_list'] == 0
+    assert c_on['n_merged'] == 2 and c_off['n_merged'] == 2       # (from the second evaluation on: the masses have been seen)
+    assert c_on['n_dest_list'] >= 2 and c_off['n_dest_list'] == 0
     for k in on:
         assert np.array_equal(on[k], off[k]), k
 
