@@ -209,6 +209,7 @@ class Workload(object):
     fields = ()           # output properties the parity checks compare
     ew_tol = ELEMENTWISE_TOL  # asserted element-wise bound (fp64 runs), see ELEMENTWISE_TOL
     slab = None           # (lo, hi, periodic, period) of this rank's slab
+    slab_axis = 0         # ... along this axis
     halo_width = 0.0
 
 
@@ -298,14 +299,16 @@ def build_workload(args, rank, world):
             # the exchange that delivers the ghosts is measured separately (--self-slab).
             from pysph_amd.parallel import slab_bounds
             er, ew = args.emulate_rank
-            cuts = slab_bounds(np.concatenate([a.x for a in arrays]), ew, weights=_dam_weights(arrays, args))
+            sc = 'xyz'[args.slab_axis]      # the slab axis (--slab-axis)
+            cuts = slab_bounds(np.concatenate([a.get(sc, only_real_particles=False) for a in arrays]), ew, weights=_dam_weights(arrays, args))
             elo = -1e30 if er == 0 else float(cuts[er])
             ehi = 1e30 if er == ew - 1 else float(cuts[er + 1])
             width = db.create_kernel().radius_scale * 1.3 * args.dx
             cut, ghosts_of = [], []
             for a in arrays:
-                real = np.nonzero((a.x >= elo) & (a.x < ehi))[0]
-                ghost = np.nonzero(((a.x >= elo - width) & (a.x < elo)) | ((a.x >= ehi) & (a.x < ehi + width)))[0]
+                ac = a.get(sc, only_real_particles=False)
+                real = np.nonzero((ac >= elo) & (ac < ehi))[0]
+                ghost = np.nonzero(((ac >= elo - width) & (ac < elo)) | ((ac >= ehi) & (ac < ehi + width)))[0]
                 if args.self_slab:
                     # --self-slab: no ghosts are built here -- the rank gets them through the slab transport itself, as its
                     # own periodic neighbour (its low-face particles arrive beyond its high face and the other way round: as
@@ -320,7 +323,7 @@ def build_workload(args, rank, world):
                 def cell_order(idx):
                     cx, cy, cz = (np.floor(a.get(q)[idx] / width).astype(np.int64) for q in 'xyz')
                     return idx[np.lexsort((a.x[idx], cx, cy, cz))]
-                gh = a.extract_particles(np.concatenate([cell_order(ghost[a.x[ghost] < elo]), cell_order(ghost[a.x[ghost] >= ehi])]),
+                gh = a.extract_particles(np.concatenate([cell_order(ghost[ac[ghost] < elo]), cell_order(ghost[ac[ghost] >= ehi])]),
                                          name=a.name)
                 gh.tag[:] = 1
                 cut.append(b)
@@ -332,10 +335,11 @@ def build_workload(args, rank, world):
             # C4: ONE tank cut into `world` slabs along x at the quantiles of
             # all particles' x (equal counts: the fluid fills 38 % of the tank)
             from pysph_amd.parallel import slab_bounds
-            cuts = slab_bounds(np.concatenate([a.x for a in arrays]), world, weights=_dam_weights(arrays, args))
+            sc = 'xyz'[args.slab_axis]
+            cuts = slab_bounds(np.concatenate([a.get(sc, only_real_particles=False) for a in arrays]), world, weights=_dam_weights(arrays, args))
             lo = -1e30 if rank == 0 else float(cuts[rank])
             hi = 1e30 if rank == world - 1 else float(cuts[rank + 1])
-            arrays = [a.extract_particles(np.nonzero((a.x >= lo) & (a.x < hi))[0],
+            arrays = [a.extract_particles(np.nonzero((a.get(sc, only_real_particles=False) >= lo) & (a.get(sc, only_real_particles=False) < hi))[0],
                                           name=a.name) for a in arrays]
             w.scaling = 'strong'
         w.arrays = arrays
@@ -352,6 +356,7 @@ def build_workload(args, rank, world):
         # solids <- fluid continuity: x,y,z,h,u,v,w read (56 B), arho written (8 B): SURVEY 8(d)
         w.algo_solid = 64.0
         w.slab = (lo, hi, False, 0.0)
+        w.slab_axis = args.slab_axis
         if args.emulate_rank and args.self_slab:
             if args.emulate_rank[0] in (0, args.emulate_rank[1] - 1):
                 raise SystemExit('--emulate-rank with --self-slab needs an interior rank (two faces)')
@@ -652,6 +657,10 @@ def parse_args(argv=None):
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary configurations')
     ap.add_argument('--no-counters', action='store_true', dest='no_counters',
                     help='do not re-run under rocprofv3 --pmc for roofline.traffic (replay profiles/pmc_traffic.json)')
+    ap.add_argument('--slab-axis', type=int, default=0, choices=(0, 1, 2), dest='slab_axis',
+                    help='dam break: the axis the tank is cut along.  Measured on emulated ranks of the 17.3 M tank: cut along '
+                         'y (whole rows of cells along x, 14 %% ghosts, every rank the same mix of arrays) an interior rank '
+                         'takes 1.42 ms against 1.35 cut along x (rows of ~50 particles, 10 %% ghosts): x stays the default')
     ap.add_argument('--image-all-props', action='store_true', help='periodic images carry every device property (the reference\'s copy) instead of the evaluation\'s inputs')
     ap.add_argument('--cpu-n1', type=int, default=0, help='side of the CPU baseline sample (0: the workload\'s own size)')
     ap.add_argument('--fixed-bounds', action='store_true', dest='fixed_bounds',
@@ -789,7 +798,7 @@ def setup(args, w, rank, world, dist, ctx):
                 sys.stderr.write('bench: libsphcomm transport unavailable (%s): torch.distributed point-to-point\n' % e)
         props = {'taylor_green': TVF_HALO_PROPS, 'elastic': ELASTIC_HALO_PROPS,
                  'elastic_block': ELASTIC_HALO_PROPS}.get(args.workload, WCSPH_HALO_PROPS)
-        halo = SlabDecomposition(w.arrays, ctx, rank, world, axis=0,
+        halo = SlabDecomposition(w.arrays, ctx, rank, world, axis=w.slab_axis,
                                  width=w.halo_width, lo=lo, hi=hi, props=props,
                                  periodic=periodic, period=period, dist=dist,
                                  protocol=os.environ.get('SPH_HALO_PROTOCOL', args.halo_protocol))

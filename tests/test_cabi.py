@@ -101,7 +101,7 @@ def test_comm_library_exports_every_declared_symbol():
     text = open(os.path.join(REPO, 'include', 'sphcomm.h')).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
     names = sorted(set(re.findall(r'\b(sph_[a-z0-9_]+)\s*\(', text)))
-    assert names == ['sph_allreduce', 'sph_comm_destroy', 'sph_comm_init_all', 'sph_comm_init_rank',
+    assert names == ['sph_allreduce', 'sph_comm_destroy', 'sph_comm_init_all', 'sph_comm_init_rank', 'sph_comm_sendrecv',
                      'sph_comm_unique_id', 'sph_halo_exchange', 'sph_halo_exchange_all']
     from pysph_amd import device as dev
     dev.load_library()                       # libsphhip.so first (libsphcomm links it)
