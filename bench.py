@@ -987,6 +987,12 @@ def run(args, rank, local_rank, world, dist):
         n_total = int(tn.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total * args.steps / elapsed
+    if getattr(w, 'transport', None) is not None:
+        # the library's own RCCL communicator goes while every rank is still here (before torch's process group)
+        torch.cuda.synchronize()
+        ctx.__dict__.pop('_transport', None)
+        w.transport.close()
+        w.transport = None
     if rank != 0:
         return None
 
