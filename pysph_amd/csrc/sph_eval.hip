@@ -471,7 +471,10 @@ __global__ __launch_bounds__(256) void k_pack_merged(PackMArgs a)
 template <class T> struct FamWCSPH_T {
     typedef T Real; // arithmetic type of the pair loop
     static constexpr uint32_t CF0 = F_CONT | F_MOM | F_XSPH; // flag set compiled as a constant (variant 6)
-    static constexpr int MINB = 4; // wavefronts per SIMD the pair kernel is compiled for (VGPR budget)
+#ifndef SPH_WCSPH_MINB
+#define SPH_WCSPH_MINB 4
+#endif
+    static constexpr int MINB = SPH_WCSPH_MINB; // wavefronts per SIMD the pair kernel is compiled for (VGPR budget)
     static constexpr int NA = 8; // u v w m rho tmpj(=p/rho^2) cs p
     static constexpr int NR = 12; // x y z h + NA (128-B padded records measured slower: larger L2 footprint)
     struct Params {

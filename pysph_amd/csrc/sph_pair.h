@@ -371,8 +371,14 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 //   Measured on the 4 M cube against the 256-thread workgroup version of the
 //   same schedule (barriers around every shared row tile): see DESIGN.md.
 // ---------------------------------------------------------------------------
-#define WLQ 10      // slots per lane (9 rows of cells + one spare; a lane out of slots flushes its wavefront's phase 2 early)
-#define WCAP_UH 184 // candidates per LDS tile piece (a wavefront's row range is ~105 for WCSPH, ~125 for TVF);
+#ifndef SPH_WLQ
+#define SPH_WLQ 10
+#endif
+#ifndef SPH_WCAP_UH
+#define SPH_WCAP_UH 184
+#endif
+#define WLQ SPH_WLQ // slots per lane (9 rows of cells + one spare; a lane out of slots flushes its wavefront's phase 2 early)
+#define WCAP_UH SPH_WCAP_UH // candidates per LDS tile piece (a wavefront's row range is ~105 for WCSPH, ~125 for TVF);
 #define WCAP_VH 136 // variable h keeps a fourth plane (the candidates' own radii): same 2304 B
 #define WCSL 96     // fine_start entries of one row segment kept in LDS (16-bit, relative to the segment start)
 #define NLW (64 * (1 + 3 * WLQ)) // 32-bit words one wave tile keeps for the neighbour-list reuse
