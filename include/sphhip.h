@@ -514,6 +514,12 @@ int sph_array_h_known(sph_ctx *ctx, int array_id, double *hmin, double *hmax);
  * receives the count (at most SPH_PROP_COUNT); SPH_ERR_ARG if cap is too
  * small.                                                                    */
 int sph_array_props(sph_ctx *ctx, int array_id, int *out, int cap, int *n);
+/* Histogram (nbins uint32 counters, HOST memory) of coordinate `axis` of the array's
+ * real particles over [vmin, vmin + span): what a re-balancing of the slab
+ * decomposition needs of the particles (the reference hands Zoltan every object,
+ * pysph/parallel/parallel_manager.pyx:577-640).  One device->host copy of nbins
+ * words; re-balancing is rare.                                                */
+int sph_coord_histogram(sph_ctx *ctx, int array_id, int axis, double vmin, double span, int nbins, uint32_t *host_out);
 
 /* ---------------------------------------------------------------------- */
 /* integrator stage sweeps (the caller either side of the hot path)         */

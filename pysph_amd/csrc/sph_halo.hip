@@ -900,6 +900,43 @@ extern "C" int sph_domain_box_wrap(sph_ctx *c, int id, int axis, double vmin, do
     return SPH_OK;
 }
 
+// Histogram of one coordinate of the REAL particles over [vmin, vmin + span) in nbins bins (the last bin holds the upper
+// edge): the re-balancing of a slab decomposition needs the distribution of the particles along the slab axis, not the
+// particles (SlabDecomposition.rebalance pulled every coordinate to the host before).
+__global__ __launch_bounds__(256) void k_coord_histogram(const double *__restrict__ coord, size_t n, double vmin, double inv_w, int nbins,
+                                                         uint32_t *__restrict__ hist)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = coord[i];
+    if (!(fabs(v) < SPH_PARKED_MIN)) return;
+    int b = (int)floor((v - vmin) * inv_w);
+    b = min(max(b, 0), nbins - 1);
+    atomicAdd(&hist[b], 1u);
+}
+
+extern "C" int sph_coord_histogram(sph_ctx *c, int id, int axis, double vmin, double span, int nbins, uint32_t *host_out)
+{
+    if (!c || id < 0 || id >= SPH_MAX_ARRAYS || axis < 0 || axis > 2 || nbins < 1 || nbins > (1 << 20) || !(span > 0.0) || !host_out) {
+        sph_set_error("sph_coord_histogram: bad arguments");
+        return SPH_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    DevArray &A = c->arr[id];
+    memset(host_out, 0, (size_t)nbins * 4);
+    if (A.n_real == 0) return SPH_OK;
+    if (!A.prop[SPH_X + axis]) { sph_set_error("sph_coord_histogram: no device coordinates"); return SPH_ERR_MISSING_PROP; }
+    HaloState &H = c->halo[id];
+    SPH_TRY(H.pos[0].reserve((size_t)nbins * 4));
+    uint32_t *hist = H.pos[0].as<uint32_t>();
+    HIP_TRY(hipMemsetAsync(hist, 0, (size_t)nbins * 4, c->stream));
+    hipLaunchKernelGGL(k_coord_histogram, dim3(div_up(A.n_real, 256)), dim3(256), 0, c->stream, A.prop[SPH_X + axis], A.n_real, vmin,
+                       (double)nbins / span, nbins, hist);
+    HIP_TRY(hipMemcpyAsync(host_out, hist, (size_t)nbins * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
 extern "C" int sph_array_props(sph_ctx *c, int id, int *out, int cap, int *n)
 {
     if (!c || id < 0 || id >= SPH_MAX_ARRAYS || !out || !n) { sph_set_error("sph_array_props: bad arguments"); return SPH_ERR_ARG; }

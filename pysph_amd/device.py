@@ -111,6 +111,7 @@ SIGNATURES = {
                                                 C.c_int, C.POINTER(C.c_int), _PD, C.POINTER(C.c_size_t),
                                                 C.POINTER(_P), C.c_double, C.c_double]),
     'sph_array_fill': (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_size_t, C.c_size_t]),
+    'sph_coord_histogram': (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_uint32)]),
     'sph_queue_values': (C.c_int, [_P, C.c_int, C.POINTER(_P), C.c_int, _P, _P]),
     'sph_array_mark_written': (C.c_int, [_P, C.c_int, C.c_int]),
     'sph_nnps_set_h_range': (C.c_int, [_P, C.c_double, C.c_double]),

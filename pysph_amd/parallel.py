@@ -332,9 +332,28 @@ class DeviceHaloOps(object):
         n = self.gpu.get_number_of_particles()
         dev._check(self.lib.sph_array_resize(self.ctx._h, self.id, n, n))
 
+    def coord_range(self):
+        """(min, max) of the real particles' coordinate along the slab axis (device reductions)"""
+        if self.n_real() == 0:
+            return float('inf'), -float('inf')
+        lo, hi = C.c_double(), C.c_double()
+        p = dev.prop_id('xyz'[self.axis])
+        dev._check(self.lib.sph_reduce_min(self.ctx._h, self.id, p, C.byref(lo)))
+        dev._check(self.lib.sph_reduce_max(self.ctx._h, self.id, p, C.byref(hi)))
+        return lo.value, hi.value
+
+    def histogram(self, vmin, span, nbins):
+        """counts of the real particles per bin of the slab-axis coordinate (sph_coord_histogram: the particles stay on
+        the device, nbins words come back)"""
+        import numpy as np
+        out = np.zeros(nbins, dtype=np.uint32)
+        dev._check(self.lib.sph_coord_histogram(self.ctx._h, self.id, self.axis, float(vmin), float(span), int(nbins),
+                                                out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out.astype(np.float64)
+
     def coords(self):
         """host copy of the real particles' coordinate along the slab axis
-        (re-balancing only; every k steps)"""
+        (test doubles and diagnostics; re-balancing uses `histogram`)"""
         import numpy as np
         n = self.n_real()
         out = np.empty(n)
@@ -1099,9 +1118,18 @@ class SlabDecomposition(object):
         # an outstanding 'padded' exchange is settled first: its counts belong to the OLD faces and must not size
         # the messages of the new ones
         _padded_collect(self.halos)
-        coords = [h.ops.coords() for h in self.halos]
-        lmin = min([c.min() for c in coords if c.size] or [float('inf')])
-        lmax = max([c.max() for c in coords if c.size] or [-float('inf')])
+        on_device = all(hasattr(h.ops, 'histogram') and hasattr(h.ops, 'coord_range') for h in self.halos)
+        coords = None
+        if on_device:
+            rng = [h.ops.coord_range() for h in self.halos]
+            counts = [h.ops.n_real() for h in self.halos]
+            lmin = min(r[0] for r in rng)
+            lmax = max(r[1] for r in rng)
+        else:
+            coords = [h.ops.coords() for h in self.halos]
+            counts = [c.size for c in coords]
+            lmin = min([c.min() for c in coords if c.size] or [float('inf')])
+            lmax = max([c.max() for c in coords if c.size] or [-float('inf')])
         gmin = -allreduce_scalars([-lmin], 'max', dist=dist,
                                   device=getattr(ops0, 'device', None))[0]
         gmax = allreduce_scalars([lmax], 'max', dist=dist,
@@ -1110,14 +1138,19 @@ class SlabDecomposition(object):
         hist = np.zeros(nbins)
         per_particle = 1.0
         if cost is not None:
-            nw = sum((1.0 if weights is None else float(weights[k])) * c.size for k, c in enumerate(coords))
+            nw = sum((1.0 if weights is None else float(weights[k])) * n for k, n in enumerate(counts))
             per_particle = float(cost) / nw if nw > 0 else 0.0
-        for k, c in enumerate(coords):
+        for k, h in enumerate(self.halos):
             w = per_particle * (1.0 if weights is None else float(weights[k]))
-            if c.size:
-                b = np.minimum(((c - gmin) / span * nbins).astype(np.int64),
-                               nbins - 1)
-                hist += w * np.bincount(b, minlength=nbins)
+            if on_device:
+                if counts[k]:
+                    hist += w * h.ops.histogram(gmin, span, nbins)
+            else:
+                c = coords[k]
+                if c.size:
+                    b = np.minimum(((c - gmin) / span * nbins).astype(np.int64),
+                                   nbins - 1)
+                    hist += w * np.bincount(b, minlength=nbins)
         import torch
         t = torch.tensor(hist, dtype=torch.float64,
                          device=getattr(ops0, 'device', None))

@@ -313,3 +313,35 @@ def test_fixed_h_range_is_per_nnps_not_per_context():
     assert abs(n1.cell_size - 2.0 * float(pa.h[0])) < 1e-15
     ctx.close()
     ref_ctx.close()
+
+
+@pytest.mark.gpu
+def test_coordinate_histogram_matches_numpy():
+    """sph_coord_histogram (the re-balancing of a slab decomposition looks at the distribution of the real particles along
+    the slab axis on the device; `SlabDecomposition.rebalance` pulled every coordinate to the host before): equal to
+    numpy's bincount of the same binning rule, ghosts and parked padding rows not counted."""
+    import numpy as np
+    from pysph_amd import device as dev
+    from pysph_amd.parallel import DeviceHaloOps, WCSPH_HALO_PROPS
+    from pysph_amd.particle_array import get_particle_array_wcsph
+    rng = np.random.default_rng(11)
+    n = 50000
+    x = np.concatenate([rng.uniform(0.0, 1.228, n), rng.uniform(0.0, 3.22, n // 5)])
+    pa = get_particle_array_wcsph(name='fluid', x=x, y=rng.random(x.size), z=rng.random(x.size))
+    pa.tag[-1000:] = 1                       # the last thousand are ghosts
+    pa.x[-500:] = 1e18                       # ... half of them parked padding rows
+    pa.align_particles() if hasattr(pa, 'align_particles') else None
+    pa.set_num_real_particles(x.size - 1000)
+    ctx = dev.HipContext(0)
+    dev.attach(pa, ctx).push()
+    ops = DeviceHaloOps(pa, ctx, WCSPH_HALO_PROPS, 0)
+    nr = ops.n_real()
+    assert nr == x.size - 1000
+    lo, hi = ops.coord_range()
+    assert lo == pa.x[:nr].min() and hi == pa.x[:nr].max()
+    nbins = 512
+    got = ops.histogram(lo, hi - lo, nbins)
+    b = np.minimum(np.floor((pa.x[:nr] - lo) * (nbins / (hi - lo))).astype(np.int64), nbins - 1)
+    want = np.bincount(b, minlength=nbins)
+    assert got.sum() == nr and np.array_equal(got, want)
+    ctx.close()
