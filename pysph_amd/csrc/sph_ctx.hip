@@ -131,6 +131,7 @@ int sph_ctx_destroy(sph_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (auto &A : c->arr) {
         for (auto &p : A.prop) if (p) (void)hipFree(p);
+        if (A.spare) (void)hipFree(A.spare);
         A.keys.release(); A.keys_sorted.release(); A.idx.release(); A.perm.release();
         A.tile_key.release(); A.tile_id.release(); A.tile_order.release();
         A.dlist.release(); A.dl_cnt.release(); A.ctile_key.release(); A.ctile_id.release(); A.ctile_order.release();

@@ -94,6 +94,8 @@ struct DevArray {
     // any r_ij is non-zero; valid while that kernel covered every particle and nothing wrote r_ij since
     DevBuf tflag;
     bool tflag_valid = false;
+    double *spare = nullptr;             // one more property-sized buffer: the compaction of sph_halo_remove_selected rotates through it
+    size_t spare_cap = 0;                // ... holding this many doubles
     DevBuf slot8;                        // merged order only (sph_ctx::merged): uint8 nnps slot of every particle's array
 };
 

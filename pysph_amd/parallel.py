@@ -318,6 +318,10 @@ class DeviceHaloOps(object):
             self.axis, float(shift), C.c_void_p(buf.data_ptr())))
         return buf, len(ids)
 
+    def axis_row(self):
+        """row of the slab-axis coordinate in a `pack_all` buffer"""
+        return list(self.all_props()).index(dev.prop_id('xyz'[self.axis]))
+
     def remove_selected(self):
         left = C.c_size_t(0)
         dev._check(self.lib.sph_halo_remove_selected(self.ctx._h, self.id,
@@ -386,6 +390,8 @@ class SlabHalo(object):
         self.last_counts = (0, 0, 0, 0)   # sent lo/hi, received lo/hi
         self.last_migrated = (0, 0, 0, 0)
         self.total_migrated = 0           # particles this rank has handed over since the start
+        self.track_excursion = False      # migrate() measures how far its leavers had strayed (one more readback)
+        self.max_excursion = 0.0
         # ghost exchange protocol (exchange_halos): 'capacity' = fixed-size
         # messages with the row count in their last element, sized from the
         # count both ends saw in the previous exchange; 'handshake' = counts
@@ -480,8 +486,16 @@ class SlabHalo(object):
                                 self.hi if 1 in sides else inf)
         send_cnt = {0: n_lo, 1: n_hi}
         out_buf, nprops = {}, None
+        self.max_excursion = 0.0
         for s, _, shift in nbrs:
             out_buf[s], nprops = ops.pack_all(s, send_cnt[s], shift)
+            if send_cnt[s] and self.track_excursion and hasattr(ops, 'axis_row'):
+                # how far beyond its face the farthest leaver had travelled (lazy migration: HipParallelManager)
+                k, cnt = ops.axis_row(), send_cnt[s]
+                row = out_buf[s][k * cnt:(k + 1) * cnt] - shift
+                face = self.lo if s == 0 else self.hi
+                far = float((face - row).max()) if s == 0 else float((row - face).max())
+                self.max_excursion = max(self.max_excursion, far)
         ops.remove_selected()
         in_buf, recv_cnt = self._swap(nbrs, send_cnt, out_buf, nprops)
         for s, _, _ in nbrs:
@@ -1192,15 +1206,34 @@ class HipParallelManager(object):
     all-reduces, with an optional re-balance every ``rebalance_every`` updates
     (the reference's ``lb_freq``)."""
 
-    def __init__(self, decomposition, rebalance_every=0, weights=None, cost_fn=None):
+    def __init__(self, decomposition, rebalance_every=0, weights=None, cost_fn=None, migrate_every=1, margin=0.0):
         """cost_fn: a callable returning the seconds THIS rank spent computing since its
         last call (e.g. `device_cost_fn(ctx)`: the library's kernel timers); the
-        re-balance then equalises measured time instead of particle counts"""
+        re-balance then equalises measured time instead of particle counts.
+
+        migrate_every = K > 1 (LAZY migration): ownership changes hands every K-th update
+        only.  The reference migrates before every evaluation
+        (parallel_manager.pyx:512-530); here a migration costs the host two round trips
+        (the counts of the leavers, the counts of the arrivals), after which every launch
+        of the update is exposed to the launch latency -- the one part of a stepping
+        rank's update that the round-trip-free exchange and neighbour update do not
+        cover.  Between migrations a particle that crossed a face stays with its old
+        rank; that is the same computation as long as the ghost layers reach `margin`
+        farther than the kernel support: construct the decomposition with width =
+        radius_scale * hmax + margin.  Every migration measures how far its leavers had
+        strayed (max over the ranks); more than `margin` is an error -- the evaluations
+        since the previous migration may have missed neighbours."""
         self.dec = decomposition
         self.dist = decomposition.dist
         self.rebalance_every = int(rebalance_every)
         self.weights = weights
         self.cost_fn = cost_fn
+        self.migrate_every = max(1, int(migrate_every))
+        self.margin = float(margin)
+        self.max_excursion = 0.0          # the farthest a leaver had strayed at any migration so far
+        if self.migrate_every > 1:
+            for h in decomposition.halos:
+                h.track_excursion = True
         self.count = 0
         self._device = getattr(decomposition.halos[0].ops, 'device', None)
 
@@ -1210,8 +1243,18 @@ class HipParallelManager(object):
             cost = self.cost_fn() if self.cost_fn is not None else None
             self.dec.rebalance(weights=self.weights, cost=cost)
             self.dec.exchange()
-        else:
+        elif self.count % self.migrate_every == 0:
             self.dec.update()
+            if self.migrate_every > 1:
+                far = max(h.max_excursion for h in self.dec.halos)
+                far = allreduce_scalars([far], 'max', dist=self.dist, device=self._device)[0]   # (every rank or none raises)
+                self.max_excursion = max(self.max_excursion, far)
+                if far > self.margin:
+                    raise RuntimeError('lazy migration: a particle had travelled %.6g beyond its slab when it was handed over, '
+                                       'the ghost layers reach only %.6g beyond the kernel support: migrate more often '
+                                       '(migrate_every) or widen them (margin)' % (far, self.margin))
+        else:
+            self.dec.exchange()
 
     def verify(self):
         """Integrator.compute_accelerations asks this once the evaluation is queued:

@@ -248,8 +248,8 @@ def test_epec_steps_two_slab_ranks_match_single_domain():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('tight', [False, True])
-def test_dam_break_epec_two_slab_ranks_padded_exchange_under_motion(monkeypatch, tight):
+@pytest.mark.parametrize('tight,lazy', [(False, 0), (True, 0), (False, 5)], ids=['roomy', 'tight', 'lazy-migration'])
+def test_dam_break_epec_two_slab_ranks_padded_exchange_under_motion(monkeypatch, tight, lazy):
     """What BASELINE config 4 does, small: the THREE-array dam break (dx 0.06) cut in
     two slabs, 40 EPEC steps through HipParallelManager on the round-trip-free
     ('padded') exchange and the merged one-launch evaluation, with the fluid moving:
@@ -259,8 +259,10 @@ def test_dam_break_epec_two_slab_ranks_padded_exchange_under_motion(monkeypatch,
     without headroom make exactly that plane outgrow its message: verify() repeats
     the face the counted way and the evaluation runs again (the reference counts
     first and never evaluates on incomplete ghosts, parallel_manager.pyx:1085-1157;
-    recipe of the comparison: parallel/tests/example_test_case.py:143-166).  Same
-    particle state as one domain, matched by global id."""
+    recipe of the comparison: parallel/tests/example_test_case.py:143-166).  `lazy`:
+    ownership changes hands every fifth update only (HipParallelManager(migrate_every,
+    margin): the ghost layers a quarter of the support wider, strays computed by their
+    old rank meanwhile).  Same particle state as one domain, matched by global id."""
     import threading
     import torch
     from helpers import ThreadDist
@@ -333,14 +335,16 @@ def test_dam_break_epec_two_slab_ranks_padded_exchange_under_motion(monkeypatch,
                 lo, hi = (-1e30, cut) if rank == 0 else (cut, 1e30)
 
                 def pmf(arrs, ctx_):
-                    dec = par.SlabDecomposition(arrs, ctx_, rank, 2, axis=0, width=2.0 * db.hdx * dx * 1.05,
+                    support = 2.0 * db.hdx * dx
+                    margin = (0.25 if lazy else 0.05) * support
+                    dec = par.SlabDecomposition(arrs, ctx_, rank, 2, axis=0, width=support + margin,
                                                 lo=lo, hi=hi, dist=hub.view(rank), protocol='padded')
-                    return par.HipParallelManager(dec, rebalance_every=31)
+                    return par.HipParallelManager(dec, rebalance_every=31, migrate_every=lazy or 1, margin=margin)
                 out, pm, n_merged = run(arrays, ctx, pmf)
                 hs = pm.dec.halos
                 results[rank] = (out, [h.padded_exchanges for h in hs], [h.repaired_exchanges for h in hs],
                                  [h.last_migrated for h in hs], pm.count, n_merged, (hs[0].lo, hs[0].hi),
-                                 [list(h.ops.props) for h in hs])
+                                 [list(h.ops.props) for h in hs], pm.max_excursion / (2.0 * db.hdx * dx))
         except Exception:
             import traceback
             errors.append(traceback.format_exc())
@@ -369,7 +373,7 @@ def test_dam_break_epec_two_slab_ranks_padded_exchange_under_motion(monkeypatch,
                 assert e < 1e-9, (name, r, k, e)
         assert (np.sort(np.concatenate(gids)) == np.arange(ref[name]['e0'].size)).all(), name
     for r in range(2):
-        _, padded, repaired, _, count, n_merged, faces, props = results[r]
+        _, padded, repaired, _, count, n_merged, faces, props, strayed = results[r]
         assert count == 2 * nsteps
         assert min(padded) >= 2 * nsteps - 8, padded          # the steady state IS the round-trip-free exchange
         assert n_merged >= 2 * nsteps - 8                     # ... on the merged one-launch evaluation
@@ -379,6 +383,8 @@ def test_dam_break_epec_two_slab_ranks_padded_exchange_under_motion(monkeypatch,
         else:
             assert sum(repaired) == 0, repaired
     assert results[0][6][1] != cut                            # the re-balance moved the face
+    if lazy:
+        assert 0.0 < max(results[r][8] for r in range(2)) < 0.25   # leavers had strayed, by less than the margin
 
 
 @pytest.mark.gpu

@@ -98,6 +98,9 @@ class NumpyHaloOps(object):
             out[k * count:(k + 1) * count] = v
         return buf, len(names)
 
+    def axis_row(self):
+        return self.all_props().index(self.axis)
+
     def remove_selected(self):
         gone = np.concatenate([self._sel[0], self._sel[1]])
         keep = np.setdiff1d(np.arange(self.pa.get_number_of_particles()), gone)
