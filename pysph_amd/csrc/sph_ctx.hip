@@ -360,6 +360,7 @@ int sph_set_option(sph_ctx *c, const char *key, long value)
     if (strcmp(key, "mass_fuse") == 0) { c->mass_fuse = value; return SPH_OK; }
     if (strcmp(key, "nl_reuse") == 0) { c->nl_reuse = value; c->nl.valid = false; return SPH_OK; }
     if (strcmp(key, "norm_masks") == 0) { c->norm_masks = value; return SPH_OK; }
+    if (strcmp(key, "row_lds") == 0) { c->row_lds = value; return SPH_OK; }
     if (strcmp(key, "dest_list") == 0) { c->dest_list = value < 0 ? 0 : (value > 2 ? 2 : value); c->nnps_valid = false; return SPH_OK; }
     if (strcmp(key, "merge_arrays") == 0) { c->merge_arrays = value ? 1 : 0; c->nnps_valid = false; return SPH_OK; }
     if (strcmp(key, "split_pair") == 0) { c->split_pair = value ? 1 : 0; return SPH_OK; }
@@ -441,7 +442,7 @@ int sph_timer_get(sph_ctx *c, const char *key, double *ms, long *count)
 {
     static const char *names[T_COUNT] = {"nnps", "pack", "eos", "pair", "stage",
                                          "pair_none", "pair_wcsph", "pair_density", "pair_tvf", "pair_vgrad", "pair_elastic",
-                                         "n_eos_fused", "n_nl_keep", "n_nl_reuse", "n_mass_fused", "n_merged", "n_tension_flag", "n_phase2", "n_async", "n_dest_list"};
+                                         "n_eos_fused", "n_nl_keep", "n_nl_reuse", "n_mass_fused", "n_merged", "n_tension_flag", "n_phase2", "n_async", "n_dest_list", "n_row_lds"};
     SPH_TRY(timer_drain(c));
     for (int i = 0; i < T_COUNT; i++)
         if (strcmp(key, names[i]) == 0) {

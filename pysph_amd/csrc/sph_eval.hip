@@ -1234,11 +1234,14 @@ template <class T> struct FamElasticU_T : FamElastic_T<T> {
     {
         return a.p.tension ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*a.p.tension) : 1u;
     }
-    template <class A> static __device__ __forceinline__ void load_fused(const A &a, uint32_t jg, uint32_t, T mu, real4<T> &pj, T (&s)[18],
-                                                                         uint32_t with_r = 1u)
+    // 16-B pieces of one record, and the record decoded from wherever its pieces are (the packed buffer, or the LDS copy
+    // of a row tile: k_pair_rowlds)
+    static constexpr int PIECES = sizeof(T) == 8 ? 10 : 5;
+    static constexpr bool ROWLDS = true;
+    typedef typename std::conditional<sizeof(T) == 8, double2, float4>::type Piece;
+    template <class P> static __device__ __forceinline__ void decode(P p, T mu, real4<T> &pj, T (&s)[18], uint32_t with_r)
     {
         if constexpr (sizeof(T) == 8) {
-            const double2 *p = reinterpret_cast<const double2 *>(a.rec) + (unsigned long long)jg * 10;
             double2 q[10];
 #pragma unroll
             for (int k = 0; k < 7; k++) q[k] = p[k];
@@ -1249,7 +1252,6 @@ template <class T> struct FamElasticU_T : FamElastic_T<T> {
 #pragma unroll
             for (int k = 0; k < 6; k++) { s[6 + 2 * k] = q[4 + k].x; s[7 + 2 * k] = q[4 + k].y; }
         } else {
-            const float4 *p = reinterpret_cast<const float4 *>(a.rec) + (unsigned long long)jg * 5;
             float4 q[5];
 #pragma unroll
             for (int k = 0; k < 4; k++) q[k] = p[k];
@@ -1260,6 +1262,11 @@ template <class T> struct FamElasticU_T : FamElastic_T<T> {
 #pragma unroll
             for (int k = 0; k < 3; k++) { s[6 + 4 * k] = q[2 + k].x; s[7 + 4 * k] = q[2 + k].y; s[8 + 4 * k] = q[2 + k].z; s[9 + 4 * k] = q[2 + k].w; }
         }
+    }
+    template <class A> static __device__ __forceinline__ void load_fused(const A &a, uint32_t jg, uint32_t, T mu, real4<T> &pj, T (&s)[18],
+                                                                         uint32_t with_r = 1u)
+    {
+        decode(reinterpret_cast<const Piece *>(a.rec) + (unsigned long long)jg * PIECES, mu, pj, s, with_r);
     }
 };
 
@@ -1644,6 +1651,23 @@ template <class Fam, bool UHV = true> static int launch_pair_fused(sph_ctx *c, i
     uint32_t cf = a.src[0].flags;
     for (int j = 1; j < a.nsrc; j++) if (a.src[j].flags != cf) cf = 0;
     if (c->const_flags == 0) cf = 0;
+    if constexpr (fam_rowlds<Fam>::value && UHV) {
+        if (c->row_lds && !a.nl_mode && !a.face_mode) { // the experiment of round 6: source records of a row tile in LDS
+            dim3 g1(4 * div_up(a.nd, 256)), b1(64);
+#define LAUNCHL(K)                                                                                              \
+            if (cf == Fam::CF0) hipLaunchKernelGGL((k_pair_rowlds<Fam, K, Fam::CF0>), g1, b1, 0, c->stream, a); \
+            else hipLaunchKernelGGL((k_pair_rowlds<Fam, K, 0>), g1, b1, 0, c->stream, a)
+            switch (kk) {
+            case 1: LAUNCHL(1); break;
+            case 2: LAUNCHL(2); break;
+            case 3: LAUNCHL(3); break;
+            case 4: LAUNCHL(4); break;
+            }
+#undef LAUNCHL
+            c->timers[T_N_ROWLDS].count++;
+            return SPH_OK;
+        }
+    }
 #define LAUNCHE(K)                                                                                                              \
     if (cf == Fam::CF0) hipLaunchKernelGGL((k_pair_wave<Fam, K, UHV, FP32, Fam::CF0>), g2, b2, (size_t)c->lds_pad, c->stream, a); \
     else hipLaunchKernelGGL((k_pair_wave<Fam, K, UHV, FP32, 0>), g2, b2, (size_t)c->lds_pad, c->stream, a)
@@ -2189,7 +2213,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         // the wave-tile kernel, same grid.  A pass that keeps its lists (1) records what they belong to; a pass
         // that wants them (2) gets them only if that record matches -- otherwise it runs its own phase 1.
         int nl_mode = 0;
-        if (c->nl_reuse && c->pair_variant == 6 && nsrcs == 1 && g->nl_mode && !c->ablate && !any_ghosts && phase == 0) {
+        if (c->nl_reuse && !c->row_lds && c->pair_variant == 6 && nsrcs == 1 && g->nl_mode && !c->ablate && !any_ghosts && phase == 0) {
             const size_t n_wt = (size_t)4 * div_up(D.n, 256);
             if (g->nl_mode == 1) {
                 SPH_TRY(c->nlbuf.reserve(n_wt * NLW * sizeof(uint32_t)));

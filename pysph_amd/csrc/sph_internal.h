@@ -108,7 +108,7 @@ struct HaloState {
 
 // T_PAIR: every pair launch; T_PAIR_FAM + family (sph_eval.hip enum Family): the same launches per equation family
 // T_N_*: launch counters only (no time): pair launches on EOS-fused records, launches that kept / reused neighbour lists
-enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_STAGE, T_PAIR_FAM, T_N_EOSF = T_PAIR_FAM + 6, T_N_NLKEEP, T_N_NLREUSE, T_N_UMASS, T_N_MERGED, T_N_TFLAG, T_N_PHASE2, T_N_ASYNC, T_N_DLIST, T_COUNT };
+enum TimerKey { T_NNPS, T_PACK, T_EOS, T_PAIR, T_STAGE, T_PAIR_FAM, T_N_EOSF = T_PAIR_FAM + 6, T_N_NLKEEP, T_N_NLREUSE, T_N_UMASS, T_N_MERGED, T_N_TFLAG, T_N_PHASE2, T_N_ASYNC, T_N_DLIST, T_N_ROWLDS, T_COUNT };
 
 struct Timer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -268,6 +268,7 @@ struct sph_ctx {
     long eos_fuse = 1;      // honour sph_group.src_eos (64-byte WCSPH records, p and cs recomputed from rho)
     long nl_reuse = 0;      // honour sph_group.nl_mode (neighbour lists kept between the pair passes of one evaluation): built,
                             // bit-identical, and measured SLOWER on MI355X (phase 1 overlaps other wavefronts' gathers)
+    long row_lds = 0;       // experiment: k_pair_rowlds for the families that have it (the elastic rates on uniform-h records)
     long dest_list = 1;     // pair launches over the real particles take their wave tiles from DevArray::dlist
     long norm_masks = 1;    // shift a row's hit bits down to the lane's first hit
     // neighbour lists kept by the last nl_mode-1 pair pass

@@ -727,3 +727,189 @@ __global__ __launch_bounds__(64 * WPB, Fam::MINB) void k_pair_wave(PairArgs<Fam>
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// k_pair_rowlds (round 6, an experiment behind the option "row_lds"): the same two phases, but a row tile's source
+// RECORDS are staged in LDS next to its fp32 positions -- one coalesced copy of consecutive 16-B pieces -- and the
+// tile's hits are evaluated from LDS right behind its phase 1, instead of being listed for ONE phase 2 over all nine
+// rows that gathers every hit's pieces from L1.  For families whose phase 2 is bound by those gathers (the elastic
+// rates: ten 16-B pieces per hit, TA 81 % busy, VALU 42 %): a candidate of a row tile is hit by ~3 of the
+// wavefront's 64 destinations, so the tile costs one third of the L1 traffic, all of it coalesced.  The price: the
+// wavefront runs nine short pair loops (per loop: as many trips as its busiest lane has hits in THAT row) instead
+// of one long one.  Uniform h, one part per tile (WCAP_L <= AMAXLEN), no neighbour-list reuse, no split launches.
+// Measured: DESIGN.md section 4, profiles/r06_ab_tables.txt.
+// ---------------------------------------------------------------------------
+template <class F, class = void> struct fam_rowlds { static constexpr bool value = false; };
+template <class F> struct fam_rowlds<F, decltype((void)F::ROWLDS)> { static constexpr bool value = F::ROWLDS; };
+
+#ifndef SPH_WCAP_L
+#define SPH_WCAP_L 96
+#endif
+#define WCAP_L SPH_WCAP_L
+
+template <class Fam, int KK, uint32_t CF = 0>
+__global__ __launch_bounds__(64, Fam::MINB) void k_pair_rowlds(PairArgs<Fam> a)
+{
+    typedef typename Fam::Real T;
+    typedef typename Fam::Piece Piece;
+    constexpr int NP = Fam::PIECES;
+    constexpr int TS = WCAP_L + 8;
+    static_assert(WCAP_L <= AMAXLEN && WCAP_L % 8 == 0, "one part per tile");
+    __shared__ __attribute__((aligned(16))) float tile[3 * TS];
+    __shared__ unsigned short csl[WCSL];
+    __shared__ __attribute__((aligned(16))) Piece recs[WCAP_L * NP];
+    float *const tx = tile, *const ty = tile + TS, *const tz = tile + 2 * TS;
+
+    const int t = threadIdx.x & 63;
+    const uint32_t wt = xcd_tile(blockIdx.x, gridDim.x);
+    uint32_t dtile = wt >> 2;
+    if (dtile * 256u >= a.nd) return;
+    if (a.d_tile_order) dtile = a.d_tile_order[dtile];
+    const uint32_t tbase = dtile * 256u + (wt & 3u) * 64u;
+    const uint32_t i = tbase + t;
+    if (tbase >= a.nd) return;
+    const bool valid = i < a.nd;
+    uint32_t ic = valid ? i : a.nd - 1;
+    if (a.d_list) ic = a.d_list[ic];
+    const uint32_t o = a.d_perm[ic];
+    const bool active = valid && o >= a.d_start && o < a.d_stop;
+    const uint32_t fkey = a.d_fkeys[ic];
+    const uint32_t key = fkey / SPH_NSUB;
+    const int ncx = a.nc[0], ncy = a.nc[1], ncz = a.nc[2];
+    const int row = key / ncx;
+    const int cx = (int)(key % ncx) * SPH_NSUB + (int)(fkey % SPH_NSUB);
+    if (!__any(active)) return;
+    bool facew = true;
+    if (a.gfx_lo > -0x7fffffff || a.gfx_hi < 0x7fffffff) {
+        int mn = active ? cx : 0x7fffffff, mx = active ? cx : -0x7fffffff;
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) { mn = min(mn, __shfl_xor(mn, o2, 64)); mx = max(mx, __shfl_xor(mx, o2, 64)); }
+        mn = __builtin_amdgcn_readfirstlane(mn); mx = __builtin_amdgcn_readfirstlane(mx);
+        facew = mn - XWIN <= a.gfx_lo || mx + XWIN >= a.gfx_hi;
+    }
+    real4<T> pi;
+    typename Fam::Dest D;
+    uint32_t wtok = 1u;
+    if constexpr (fam_token<Fam>::value) wtok = Fam::wave_token(a);
+    {
+        T sd_[Fam::NA];
+        Fam::decode(reinterpret_cast<const Piece *>(a.rec) + (unsigned long long)(a.d_off + ic) * NP, (T)a.d_mu, pi, sd_, wtok);
+        pi.w = (T)a.hu;
+        Fam::load(D, sd_, a, o);
+    }
+    const int nfx = ncx * SPH_NSUB;
+    const T hi_r = (T)a.radius_scale * pi.w;
+    const T hi2 = (T)a.hr2u;
+    const int row_first = __builtin_amdgcn_readfirstlane(row), row_last = __builtin_amdgcn_readlane(row, 63);
+    const float4 fpi = a.fpos[a.d_off + ic];
+
+    for (int s = 0; s < a.nsrc; s++) {
+        const SrcDesc sd = a.src[s];
+        if (sd.ghost && !facew) continue;
+        const uint32_t fl = CF ? CF : sd.flags;
+        const T mu = (T)sd.mu;
+        for (int R = row_first; R <= row_last; R++) {
+            const bool inseg = active && row == R;
+            const unsigned long long segm = __ballot(inseg);
+            if (!segm) continue;
+            const int cxa = __builtin_amdgcn_readlane(cx, __builtin_ctzll(segm));
+            const int cxb = __builtin_amdgcn_readlane(cx, 63 - __builtin_clzll(segm));
+            const int cyR = R % ncy, czR = R / ncy;
+            const int xa = max(cxa - XWIN, 0), xb = min(cxb + XWIN, nfx - 1);
+            const int ncs = xb - xa + 2;
+            const double binw = a.cell_size * (1.0 / SPH_NSUB);
+            const float oxf = (float)(binw * xa);
+            const float oyf = (float)(a.cell_size * (cyR - 1));
+            const float ozf = (float)(a.cell_size * (czR - 1));
+            const double L = fmax(a.cell_size * (double)max((xb - xa) / SPH_NSUB + 2, 4), a.dom_extent);
+            const float slack = (float)(L * 1.5e-6);
+            const float fxs = fpi.x - oxf, fys = fpi.y - oyf, fzs = fpi.z - ozf;
+            const f2 fx = {fxs, fxs}, fy = {fys, fys}, fz = {fzs, fzs};
+            const float hif = (float)hi_r * 1.000001f + slack;
+            const float hi2f = hif * hif;
+            const int mycl = max(cx - XWIN, xa) - xa, mych = min(cx + XWIN, xb) + 1 - xa;
+            for (int st = 0; st < 9; st++) {
+                const int sy = st % 3 - 1, sz = st / 3 - 1;
+                const int dy = (a.row_mod3 & 1) ? (sy + 1 - cyR % 3 + 4) % 3 - 1 : sy;
+                const int dz = (a.row_mod3 & 2) ? (sz + 1 - czR % 3 + 4) % 3 - 1 : sz;
+                const int yy = cyR + dy, zz = czR + dz;
+                if (yy < 0 || yy >= ncy || zz < 0 || zz >= ncz) continue;
+                const uint32_t rowb = (uint32_t)(ncx * (yy + ncy * zz)) * SPH_NSUB;
+                const uint32_t j0 = sd.fine_start[rowb + xa], j1 = sd.fine_start[rowb + xb + 1];
+                const bool csl_ok = ncs <= WCSL && j1 - j0 < 65536u;
+                for (uint32_t tb = j0; tb < j1; tb += WCAP_L) {
+                    const int tn = (int)min((uint32_t)WCAP_L, j1 - tb);
+                    if (csl_ok && tb == j0)
+                        for (int q = t; q < ncs; q += 64) csl[q] = (unsigned short)(sd.fine_start[rowb + xa + q] - j0);
+                    for (int k = t; k < tn + 8; k += 64) {
+                        float vx = 3.0e18f, vy = 3.0e18f, vz = 3.0e18f;
+                        if (k < tn) {
+                            const float4 fj = a.fpos[sd.off + tb + k];
+                            vx = fj.x - oxf; vy = fj.y - oyf; vz = fj.z - ozf;
+                        }
+                        tx[k] = vx; ty[k] = vy; tz[k] = vz;
+                    }
+                    { // the tile's records: consecutive pieces of the packed buffer, lane after lane
+                        const Piece *g = reinterpret_cast<const Piece *>(a.rec) + (unsigned long long)(sd.off + tb) * NP;
+                        const int npc = tn * NP;
+                        for (int k = t; k < npc; k += 64) recs[k] = g[k];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    int s0 = 0, len = 0;
+                    if (inseg) {
+                        int lo, hi;
+                        if (csl_ok) { lo = (int)(j0 + csl[mycl] - tb); hi = (int)(j0 + csl[mych] - tb); }
+                        else { lo = (int)(sd.fine_start[rowb + xa + mycl] - tb); hi = (int)(sd.fine_start[rowb + xa + mych] - tb); }
+                        lo = max(lo, 0); hi = min(hi, tn);
+                        s0 = lo & ~1;
+                        len = max(hi - s0, 0);
+                    }
+                    uint32_t wd[3] = {0u, 0u, 0u};
+#pragma unroll
+                    for (int gw = 0; gw < 3; gw++) {
+                        if (!__any(32 * gw < len)) break;
+                        uint32_t mm = 0;
+                        int g8 = 0;
+                        for (; g8 < 4 && __any(32 * gw + 8 * g8 < len); g8++) {
+                            const float *tb0 = tile + ((len > 0 ? s0 : 0) + 32 * gw + 8 * g8);
+#pragma unroll
+                            for (int p = 0; p < 4; p++) {
+                                const f2 X = *reinterpret_cast<const f2 *>(tb0 + 2 * p);
+                                const f2 Y = *reinterpret_cast<const f2 *>(tb0 + TS + 2 * p);
+                                const f2 Z = *reinterpret_cast<const f2 *>(tb0 + 2 * TS + 2 * p);
+                                const f2 ex = fx - X, ey = fy - Y, ez = fz - Z;
+                                const f2 nthr = {-hi2f, -hi2f};
+                                f2 d = __builtin_elementwise_fma(ex, ex, nthr);
+                                d = __builtin_elementwise_fma(ey, ey, d);
+                                d = __builtin_elementwise_fma(ez, ez, d);
+                                mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.x), 31);
+                                mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.y), 31);
+                            }
+                        }
+                        if (g8 < 4) mm <<= 8 * (4 - g8);
+                        mm = __builtin_bitreverse32(mm);
+                        const int rem = len - 32 * gw;
+                        wd[gw] = rem >= 32 ? mm : (rem > 0 ? (mm & ((1u << rem) - 1u)) : 0u);
+                    }
+                    // this tile's hits, from LDS
+                    unsigned long long m0 = (unsigned long long)wd[0] | ((unsigned long long)wd[1] << 32);
+                    uint32_t m2 = wd[2];
+                    while (__any((m0 | m2) != 0)) {
+                        const bool has = (m0 | m2) != 0;
+                        int j = 0;
+                        if (m0) { j = s0 + __builtin_ctzll(m0); m0 &= m0 - 1; }
+                        else if (m2) { j = s0 + 64 + __builtin_ctz(m2); m2 &= m2 - 1; }
+                        real4<T> pj;
+                        T sj[Fam::NA];
+                        Fam::decode(recs + j * NP, mu, pj, sj, wtok);
+                        const T r2 = r2_exact<T>(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+                        const bool pass = has && r2 < hi2;
+                        Fam::template pair<KK, true>(D, pi, pj, r2, sj, fl, a, pass);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+            }
+        }
+    }
+    if (active) Fam::finish(D, a, o);
+}

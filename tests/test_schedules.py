@@ -55,7 +55,7 @@ def _run(argv, opts, steps=2):
             if f in pa.properties:
                 out[pa.name + '.' + f] = np.array(pa.get(f)[:nreal])
     cnt = {k: ctx.timer_get(k)[1] for k in ('n_eos_fused', 'n_nl_keep', 'n_nl_reuse', 'n_mass_fused', 'n_merged', 'n_tension_flag',
-                                            'n_dest_list')}
+                                            'n_dest_list', 'n_row_lds')}
     res = bench.parity_check(w, host_in, nnps, domain,
                              bench.PARITY_TOL if args.dtype == 'f64' else 5e-5)
     del nnps, a_eval, step
@@ -450,6 +450,25 @@ def test_artificial_stress_is_gathered_only_under_tension(argv):
         assert not np.any(on['solid.r00']) and not np.any(on['solid.r12'])
     else:
         assert np.any(on['solid.r00'])
+
+
+@pytest.mark.parametrize('argv,tol', [(['--workload', 'elastic', '--rings-dx', '1.6e-3'], 1e-12),
+                                      (['--workload', 'elastic', '--rings-dx', '1.6e-3', '--rings-unperturbed'], 1e-12),
+                                      (['--workload', 'elastic_block', '--n1', '40'], 1e-12),
+                                      (['--workload', 'elastic', '--rings-dx', '1.6e-3', '--dtype', 'f32'], 5e-5)],
+                         ids=['rings', 'rings-no-tension', 'block', 'rings-fp32'])
+def test_row_tiles_of_source_records_in_lds(argv, tol):
+    """option row_lds (k_pair_rowlds: the elastic rates evaluate a row tile's hits from an LDS copy of its records,
+    tile after tile): the same pairs in another order -- against the default kernel and the oracle"""
+    on, c_on, r_on = _run(argv, {'row_lds': 1}, steps=3)
+    off, c_off, r_off = _run(argv, {}, steps=3)
+    assert c_on['n_row_lds'] >= 2 and c_off['n_row_lds'] == 0, (c_on, c_off)
+    assert r_on['parity_neighbour_count_mismatches'] == 0
+    if '--dtype' in argv:
+        assert r_on['parity_max_rel'] < 5e-5, r_on
+    else:
+        assert r_on['parity_ok'], r_on
+    assert _max_rel(on, off) < tol
 
 
 def test_merged_arrays_with_an_empty_array():
