@@ -586,6 +586,12 @@ int sph_reduce_min(sph_ctx *ctx, int array_id, int prop, double *out);
  *                    MonaghanArtificialStress kernel sets says a particle of the source array is in tension)
  *   "nl_reuse"       1: honour sph_group.nl_mode (default 0: measured slower)
  *   "norm_masks"     0: hit masks are not shifted down to a lane's first hit (default 1)
+ *   "dest_list"      pair launches over the REAL particles of an array take their wave tiles from a list of the
+ *                    real particles' sorted positions: 1 (default) = when ghosts / images / padding rows are at
+ *                    least 1/8 of the rows, 2 = always, 0 = never (every row of the cell order gets a lane)
+ *   "row_lds"        1: the elastic rates on uniform-h records evaluate a row tile's hits from an LDS copy of its
+ *                    records, tile after tile (default 0: measured 45 % slower); same pairs,
+ *                    another summation order
  *   "row_mod3"       order in which a wavefront visits its 3x3 rows of cells: 3 (default) = the row whose
  *                    (y mod 3, z mod 3) equals the step, so that all wavefronts in flight walk rows of one
  *                    residue class at a time and find each other's lines in L1 / L2; 1 / 2 = y / z only;
