@@ -101,18 +101,18 @@ def make_cube(n1, x_offset=0.0, seed=1234, hdx=1.3, nx=None, vary_h=0.0, gid0=0,
     return pa, dx
 
 
-def cube_equations(dx, hdx=1.3, params='db'):
+def cube_equations(dx, hdx=1.3, params='db', gamma=None):
     """'db': dam_break_3d.py parameters; 'cube': the reference's own benchmark
     example (pysph/examples/cube.py:40-55: alpha 0.5, c0 10, hdx 1.5)."""
     from pysph_amd.scheme import WCSPHScheme
     from pysph_amd.examples import dam_break_3d as db
     if params == 'cube':
         s = WCSPHScheme(['fluid'], [], dim=3, rho0=db.ro, c0=10.0, h0=hdx * dx,
-                        hdx=hdx, gz=-9.81, alpha=0.5, beta=0.0, gamma=7.0)
+                        hdx=hdx, gz=-9.81, alpha=0.5, beta=0.0, gamma=gamma or 7.0)
     else:
         s = WCSPHScheme(['fluid'], [], dim=3, rho0=db.ro, c0=db.c0, h0=hdx * dx,
                         hdx=hdx, gz=-9.81, alpha=db.alpha, beta=db.beta,
-                        gamma=db.gamma)
+                        gamma=gamma or db.gamma)
     return s.get_equations()
 
 
@@ -250,7 +250,7 @@ def build_workload(args, rank, world):
         pa, dx = make_cube(n1, x_offset=float(rank), seed=1234 + rank, hdx=hdx,
                            vary_h=args.vary_h, gid0=rank * n1 ** 3, vary_m=args.vary_m)
         w.arrays = [pa]
-        w.eqs = cube_equations(dx, hdx=hdx, params=args.params)
+        w.eqs = cube_equations(dx, hdx=hdx, params=args.params, gamma=args.gamma)
         w.kernel = K.CubicSpline(dim=3) if args.params == 'cube' else K.WendlandQuintic(dim=3)
         w.name = ('S-cube WCSPH %s parameter set (%s, hdx %g), %d^3 = %d particles per GPU, '
                   'jitter 0.1dx, seed 1234%s' % (
@@ -344,7 +344,10 @@ def build_workload(args, rank, world):
             w.scaling = 'strong'
         w.arrays = arrays
         dx = args.dx
-        w.eqs = db.create_scheme(dx).get_equations()
+        scheme = db.create_scheme(dx)
+        if args.gamma:
+            scheme.gamma = args.gamma
+        w.eqs = scheme.get_equations()
         w.kernel = db.create_kernel()
         w.name = ('3D dam break (dam_break_3d.py geometry), dx=%g: %s' % (
             dx, ', '.join('%s %d' % (a.name, a.get_number_of_particles())
@@ -639,6 +642,8 @@ def parse_args(argv=None):
     ap.add_argument('--vary-h', type=float, default=0.0, dest='vary_h',
                     help='cube workload: h = h0 (1 +- vary_h U(-1,1))')
     ap.add_argument('--dx', type=float, default=0.0087, help='dam_break spacing')
+    ap.add_argument('--gamma', type=float, default=None,
+                    help='cube / dam_break: exponent of the Tait EOS (default: the examples\' 7)')
     ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'],
                     help='arithmetic type of the pair kernels')
     ap.add_argument('--variant', type=int, default=6)
@@ -1021,6 +1026,8 @@ def run(args, rank, local_rank, world, dist):
                     '--dx', repr(args.dx), '--variant', str(args.variant)]
         if args.vary_h:
             wl_flags += ['--vary-h', repr(args.vary_h)]
+        if args.gamma:
+            wl_flags += ['--gamma', repr(args.gamma)]
         if args.no_reorder:
             wl_flags += ['--no-reorder']
         for kv in args.opt:

@@ -92,10 +92,8 @@ __global__ __launch_bounds__(256) void k_nosrc(EosArgs a)
         double rho0 = a.par[0], c0 = a.par[1], gamma = a.par[2], p0 = a.par[3];
         double ratio = a.rho[i] * (1.0 / rho0);
         double tmp, csr;
-        if (gamma == 7.0) { // the usual water exponent: ratio^7 and ratio^3 by multiplication (two pow() calls made this kernel compute-bound)
-            const double r2 = ratio * ratio;
-            csr = r2 * ratio;
-            tmp = (r2 * r2) * csr;
+        if (tait_gk(gamma) >= 0) { // odd integer exponents (7: water): the powers by multiplication (two pow() calls made this kernel compute-bound)
+            tait_powers(ratio, tait_gk(gamma), tmp, csr);
         } else {
             tmp = pow(ratio, gamma);
             csr = pow(ratio, 0.5 * (gamma - 1.0));
@@ -110,10 +108,8 @@ __global__ __launch_bounds__(256) void k_nosrc(EosArgs a)
         if (r < rho0) { r = rho0; a.rho[i] = r; }
         double ratio = r * (1.0 / rho0);
         double tmp, csr;
-        if (gamma == 7.0) { // as TaitEOS above: the EOS-fused pair kernel recomputes p, cs by the same multiplications
-            const double r2 = ratio * ratio;
-            csr = r2 * ratio;
-            tmp = (r2 * r2) * csr;
+        if (tait_gk(gamma) >= 0) { // as TaitEOS above: the EOS-fused pair kernel recomputes p, cs by the same multiplications
+            tait_powers(ratio, tait_gk(gamma), tmp, csr);
         } else {
             tmp = pow(ratio, gamma);
             csr = pow(ratio, 0.5 * (gamma - 1.0));
@@ -628,14 +624,14 @@ template <class T, bool UM = false> struct FamWCSPHE_T : FamWCSPH_T<T> {
             if (fl & F_MOM) {
                 const T ratio = rho * (T)a.e_rho01;
                 s[5] = q;
-                s[6] = (T)a.e_c0 * ((ratio * ratio) * ratio);
+                s[6] = (T)a.e_c0 * tait_cs_power(ratio, a.e_gk);
             }
         } else
         if (fl & F_MOM) { // the flags of this (destination, source): a compile-time constant in the common case; a
                           // continuity-only destination -- a dam break's walls -- reads neither
             const T ratio = rho * (T)a.e_rho01;
-            const T r2 = ratio * ratio, r3 = r2 * ratio;
-            const T r7 = (r2 * r2) * r3;
+            T r7, r3; // (ratio^gamma, ratio^((gamma - 1) / 2): named for the usual exponent)
+            tait_powers(ratio, a.e_gk, r7, r3);
             const T p = (T)a.e_p0 + (T)a.e_B * (r7 - T(1.0));
             s[5] = rho != T(0.0) ? p * fast_rcp(rho * rho) : T(0.0);
             s[6] = (T)a.e_c0 * r3;
@@ -675,8 +671,8 @@ template <class T> struct FamWCSPHV_T : FamWCSPH_T<T> {
         s[5] = s[6] = s[7] = T(0.0);
         if (fl & F_MOM) {
             const T ratio = rho * (T)a.e_rho01;
-            const T r2 = ratio * ratio, r3 = r2 * ratio;
-            const T r7 = (r2 * r2) * r3;
+            T r7, r3; // (ratio^gamma, ratio^((gamma - 1) / 2): named for the usual exponent)
+            tait_powers(ratio, a.e_gk, r7, r3);
             const T p = (T)a.e_p0 + (T)a.e_B * (r7 - T(1.0));
             s[5] = rho != T(0.0) ? p * fast_rcp(rho * rho) : T(0.0);
             s[6] = (T)a.e_c0 * r3;
@@ -732,7 +728,7 @@ template <class T> struct FamWCSPHM_T : FamWCSPHE_T<T, true> {
         s[4] = rho;
         const T ratio = rho * (T)a.e_rho01;
         s[5] = q;                               // p / rho^2 as k_pack_merged computed it from the stored p
-        s[6] = (T)a.e_c0 * ((ratio * ratio) * ratio);
+        s[6] = (T)a.e_c0 * tait_cs_power(ratio, a.e_gk);
         s[7] = T(0.0);
     }
     template <class A> static __device__ __forceinline__ void load_fused(const A &a, uint32_t jg, uint32_t fl, T mu, real4<T> &pj, T (&s)[8])
@@ -830,8 +826,8 @@ template <class T> struct FamWCSPHMV_T : FamWCSPHM_T<T> {
         rho = fabs(rho);
         s[4] = rho;
         const T ratio = rho * (T)a.e_rho01;
-        const T r2 = ratio * ratio, r3 = r2 * ratio;
-        const T r7 = (r2 * r2) * r3;
+        T r7, r3;
+        tait_powers(ratio, a.e_gk, r7, r3);
         const T p = (T)a.e_p0 + (T)a.e_B * (r7 - T(1.0));
         s[5] = rho != T(0.0) ? p * fast_rcp(rho * rho) : T(0.0);
         s[6] = (T)a.e_c0 * r3;
@@ -1804,7 +1800,7 @@ static int eval_group_merged(sph_ctx *c, const sph_kernel *K, const sph_group *g
     if (c->merge_blocked || !c->xflag.ptr) return SPH_OK; // a non-positive density was seen: the sign of rho cannot carry the class
     if (g->phase != 0 || c->ghosts_binned) return SPH_OK; // ghost segments: the per-destination path reads them as extra sources
     if (!(g->src_eos == 1 && c->eos_fuse && c->mass_fuse && c->const_flags &&
-          g->eos_par[2] == 7.0 && g->eos_par[0] > 0.0 && !c->record_f32 && !c->wcsph_nr))
+          tait_gk(g->eos_par[2]) >= 0 && g->eos_par[0] > 0.0 && !c->record_f32 && !c->wcsph_nr))
         return SPH_OK;
     const bool vh = !(c->uniform_h && c->use_uniform_h); // variable h: FamWCSPHMV_T on records that carry h (round 5)
     const int na = c->narrays;
@@ -1941,6 +1937,7 @@ static int eval_group_merged(sph_ctx *c, const sph_kernel *K, const sph_group *g
         a.d_start = 0; a.d_stop = 0xffffffffu; a.dflags = ct;
         a.e_rho01 = 1.0 / g->eos_par[0]; a.e_c0 = g->eos_par[1];
         a.e_B = g->eos_par[0] * g->eos_par[1] * g->eos_par[1] / g->eos_par[2];
+        a.e_gk = tait_gk(g->eos_par[2]);
         a.e_p0 = g->eos_par[3];
         if (me) { a.p.c0 = me->par[0]; a.p.alpha = me->par[1]; a.p.beta = me->par[2]; a.p.gx = me->par[3]; a.p.gy = me->par[4]; a.p.gz = me->par[5]; }
         if (xe) a.p.eps = xe->par[0];
@@ -2133,7 +2130,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         // rho: with gamma = 7 (powers by multiplication), uniform h and no tensile correction the pair kernel
         // recomputes them and the records shrink to 64 bytes (32 in fp32).
         const bool eosf = g->src_eos == 1 && c->eos_fuse && fam == FAM_WCSPH && c->pair_variant == 6 && c->uniform_h &&
-                          c->use_uniform_h && !(dflags & F_TENSILE) && g->eos_par[2] == 7.0 &&
+                          c->use_uniform_h && !(dflags & F_TENSILE) && tait_gk(g->eos_par[2]) >= 0 &&
                           g->eos_par[0] > 0.0 && !c->record_f32 && !c->wcsph_nr;
         if (eosf) pl.nr = 8; // doubles, or floats with arith_f32
         // ... and when every array read here had ONE mass at the last neighbour update, the record's mass slot
@@ -2146,7 +2143,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         for (int j = 0; j < nsrcs && umass; j++) umass = c->arr[srcs[j]].m_known;
         // ... and with VARIABLE h the same promise plus one mass per source array gives 64-byte records [x y z h u v w rho]
         bool eosv = !eosf && g->src_eos == 1 && c->eos_fuse && c->mass_fuse && fam == FAM_WCSPH && c->pair_variant == 6 &&
-                    !(c->uniform_h && c->use_uniform_h) && !(dflags & F_TENSILE) && g->eos_par[2] == 7.0 && g->eos_par[0] > 0.0 &&
+                    !(c->uniform_h && c->use_uniform_h) && !(dflags & F_TENSILE) && tait_gk(g->eos_par[2]) >= 0 && g->eos_par[0] > 0.0 &&
                     !c->record_f32 && !c->wcsph_nr;
         if (eosv) c->want_mrange = true;
         for (int j = 0; j < nsrcs && eosv; j++) eosv = c->arr[srcs[j]].m_known;
@@ -2273,6 +2270,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             if (eosf || eosv) {
                 a.e_rho01 = 1.0 / g->eos_par[0]; a.e_c0 = g->eos_par[1];
                 a.e_B = g->eos_par[0] * g->eos_par[1] * g->eos_par[1] / g->eos_par[2];
+        a.e_gk = tait_gk(g->eos_par[2]);
                 a.e_p0 = g->eos_par[3];
             }
             if (tvff) { a.e_p0 = g->eos_par[0]; a.e_rho01 = 1.0 / g->eos_par[1]; a.e_B = g->eos_par[2]; } // StateEquation: p0 rho0 b

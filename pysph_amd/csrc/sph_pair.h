@@ -58,6 +58,28 @@ struct SrcDesc {
     uint32_t ghost;  // 1: the ghost segment of an array (sph_nnps_update_ghosts): read by face wavefronts only
 };
 
+// Powers of the Tait EOS (wc/basic.py:60-65: p = p0 + B ((rho/rho0)^gamma - 1), cs = c0 (rho/rho0)^((gamma-1)/2)) for the odd
+// integer exponents gamma = 2 gk + 1 = 1, 3, 5, 7 by multiplication -- ONE spelling for k_nosrc and for every record
+// decoder that recomputes p and cs, so that the fused and the gathered forms agree to the bit.  gk is wave-uniform.
+static __host__ __device__ inline int tait_gk(double gamma)
+{
+    return gamma == 7.0 ? 3 : gamma == 5.0 ? 2 : gamma == 3.0 ? 1 : gamma == 1.0 ? 0 : -1;
+}
+template <class T> __device__ __forceinline__ T tait_cs_power(T ratio, int gk) // ratio^gk
+{
+    if (gk == 3) return (ratio * ratio) * ratio;
+    if (gk == 2) return ratio * ratio;
+    return gk == 1 ? ratio : T(1.0);
+}
+template <class T> __device__ __forceinline__ void tait_powers(T ratio, int gk, T &rg, T &rk) // ratio^(2 gk + 1), ratio^gk
+{
+    const T r2 = ratio * ratio;
+    if (gk == 3) { rk = r2 * ratio; rg = (r2 * r2) * rk; }
+    else if (gk == 2) { rk = r2; rg = (r2 * r2) * ratio; }
+    else if (gk == 1) { rk = ratio; rg = r2 * ratio; }
+    else { rk = T(1.0); rg = ratio; }
+}
+
 template <class Fam> struct PairArgs {
     int nsrc;
     SrcDesc src[SPH_MAX_ARRAYS];
@@ -104,6 +126,7 @@ template <class Fam> struct PairArgs {
     int norm_masks;  // 1: a row's 96 hit bits are shifted down to the lane's first hit before they become slots
     // Tait EOS of the records' density (families with EOSF: p and cs are not gathered but recomputed)
     double e_rho01, e_c0, e_B, e_p0;
+    int e_gk;                   // Tait exponent gamma = 2 e_gk + 1 (1, 3, 5, 7): powers by multiplication (tait_powers)
     typename Fam::Params p;
 };
 

@@ -87,6 +87,28 @@ def test_eos_fused_records_match_gathered_records(argv):
     assert _max_rel(on, off) < 1e-13
 
 
+@pytest.mark.parametrize('gamma', [1.0, 3.0, 5.0])
+@pytest.mark.parametrize('argv', [['--n1', '48'], ['--n1', '48', '--vary-h', '0.15'], ['--workload', 'dam_break', '--dx', '0.03']],
+                         ids=['cube', 'variable-h', 'dam-break-merged'])
+def test_eos_fused_records_with_other_odd_exponents(argv, gamma):
+    """TaitEOS with gamma = 1, 3, 5 (wc/basic.py:60-65): the powers by multiplication like 7's, in k_nosrc and in every
+    record decoder alike -- the fused, the uniform-mass and the merged records are taken and agree with the gathered p / cs
+    and with the oracle's pow()"""
+    argv = argv + ['--gamma', repr(gamma)]
+    on, c_on, r_on = _run(argv, {}, steps=3)
+    off, c_off, r_off = _run(argv, {'eos_fuse': 0}, steps=3)
+    assert c_on['n_eos_fused'] > 0 and c_off['n_eos_fused'] == 0, (c_on, c_off)
+    if 'dam_break' in argv:
+        assert c_on['n_merged'] > 0, c_on
+    assert r_on['parity_ok'] and r_off['parity_ok'], (r_on, r_off)
+    assert _max_rel(on, off) < 1e-13
+
+
+def test_eos_is_not_fused_for_an_exponent_without_integer_powers():
+    out, cnt, res = _run(['--n1', '48', '--gamma', '1.4'], {}, steps=3)
+    assert cnt['n_eos_fused'] == 0 and res['parity_ok'], (cnt, res)
+
+
 def test_eos_fused_records_fp32():
     on, c_on, r_on = _run(['--n1', '64', '--dtype', 'f32'], {})
     off, c_off, r_off = _run(['--n1', '64', '--dtype', 'f32'], {'eos_fuse': 0})
