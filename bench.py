@@ -796,11 +796,23 @@ def setup(args, w, rank, world, dist, ctx):
             # the point-to-point transfers straight on RCCL on the context's stream (libsphcomm.so: sph_comm_sendrecv),
             # the few collectives on torch.distributed: the process group's stream hand-over around its RCCL kernel cost a
             # slab rank of the 16 M dam break 0.09 ms per exchange.  SPH_HALO_TRANSPORT=torch: batch_isend_irecv.
-            from pysph_amd.parallel import SphCommTransport
+            from pysph_amd.parallel import SphCommTransport, allreduce_scalars
+            torch_dist, transport = dist, None
             try:
-                dist = w.transport = SphCommTransport(ctx, dist, rank, world)
-            except Exception as e:      # (the same on every rank: they share the build)
-                sys.stderr.write('bench: libsphcomm transport unavailable (%s): torch.distributed point-to-point\n' % e)
+                transport = SphCommTransport(ctx, dist, rank, world)
+            except Exception as e:
+                sys.stderr.write('bench: libsphcomm transport unavailable on rank %d (%s)\n' % (rank, e))
+            # every rank or none: the ranks of one exchange must speak through the same communicator
+            import torch
+            ok = allreduce_scalars([1.0 if transport is not None else 0.0], 'min', dist=torch_dist,
+                                   device=torch.device('cuda', torch.cuda.current_device()) if torch_dist.get_backend() == 'nccl' else None)[0]
+            if ok >= 1.0:
+                dist = w.transport = transport
+            else:
+                if transport is not None:
+                    transport.close()
+                if rank == 0:
+                    sys.stderr.write('bench: point-to-point transfers through torch.distributed\n')
         props = {'taylor_green': TVF_HALO_PROPS, 'elastic': ELASTIC_HALO_PROPS,
                  'elastic_block': ELASTIC_HALO_PROPS}.get(args.workload, WCSPH_HALO_PROPS)
         halo = SlabDecomposition(w.arrays, ctx, rank, world, axis=w.slab_axis,

@@ -1272,9 +1272,10 @@ class SphCommTransport(object):
     """`dist` for SlabHalo / SlabDecomposition with the POINT-TO-POINT transfers on
     libsphcomm.so -- ncclSend / ncclRecv in one group on the context's own stream
     (`sph_comm_sendrecv`) -- and everything else (the few collectives of set-up,
-    migration and re-balancing) on torch.distributed.  Opt-in
-    (`bench.py`: SPH_HALO_TRANSPORT=sphcomm): the process group's stream hand-over
-    around its RCCL kernel costs a slab rank ~45 us of idle stream per exchange.
+    migration and re-balancing) on torch.distributed.  The default of
+    `bench.py --gpus N` (SPH_HALO_TRANSPORT=torch selects the process group's
+    batch_isend_irecv): the process group's stream hand-over around its RCCL
+    kernel costs a slab rank ~45 us of idle stream per exchange.
     The kernels, the messages and the protocol are the same; needs the context
     to run on torch's current stream like the torch transport's fast path."""
 
