@@ -606,7 +606,10 @@ template <class T, bool UM = false> struct FamWCSPHE_T : FamWCSPH_T<T> {
             r.q[0] = p[0]; r.q[1] = p[1];
         }
     }
-    template <class A> static __device__ __forceinline__ void decode(const A &a, const Raw &r, uint32_t fl, T mu, real4<T> &pj, T (&s)[8])
+    // gk: the exponent gamma = 2 gk + 1 -- the constant 3 here (water: the compiler folds the powers), the launch
+    // argument in FamWCSPHEG_T below
+    template <class A> static __device__ __forceinline__ void decode(const A &a, const Raw &r, uint32_t fl, T mu, real4<T> &pj, T (&s)[8],
+                                                                     int gk = 3)
     {
         T rho;
         if constexpr (sizeof(T) == 8) {
@@ -624,14 +627,14 @@ template <class T, bool UM = false> struct FamWCSPHE_T : FamWCSPH_T<T> {
             if (fl & F_MOM) {
                 const T ratio = rho * (T)a.e_rho01;
                 s[5] = q;
-                s[6] = (T)a.e_c0 * tait_cs_power(ratio, a.e_gk);
+                s[6] = (T)a.e_c0 * tait_cs_power(ratio, gk);
             }
         } else
         if (fl & F_MOM) { // the flags of this (destination, source): a compile-time constant in the common case; a
                           // continuity-only destination -- a dam break's walls -- reads neither
             const T ratio = rho * (T)a.e_rho01;
             T r7, r3; // (ratio^gamma, ratio^((gamma - 1) / 2): named for the usual exponent)
-            tait_powers(ratio, a.e_gk, r7, r3);
+            tait_powers(ratio, gk, r7, r3);
             const T p = (T)a.e_p0 + (T)a.e_B * (r7 - T(1.0));
             s[5] = rho != T(0.0) ? p * fast_rcp(rho * rho) : T(0.0);
             s[6] = (T)a.e_c0 * r3;
@@ -643,6 +646,18 @@ template <class T, bool UM = false> struct FamWCSPHE_T : FamWCSPH_T<T> {
         Raw r;
         load_raw(a, jg, r);
         decode(a, r, fl, mu, pj, s);
+    }
+};
+
+// ... with the exponent as a launch argument (gamma = 1, 3, 5: PairArgs::e_gk).  A family of its own because the select
+// costs the water kernels 1.3-2 % of their time when they carry it (profiles/r06_ab_tables.txt).
+template <class T, bool UM = false> struct FamWCSPHEG_T : FamWCSPHE_T<T, UM> {
+    typedef FamWCSPHE_T<T, UM> Base;
+    template <class A> static __device__ __forceinline__ void load_fused(const A &a, uint32_t jg, uint32_t fl, T mu, real4<T> &pj, T (&s)[8])
+    {
+        typename Base::Raw r;
+        Base::load_raw(a, jg, r);
+        Base::decode(a, r, fl, mu, pj, s, a.e_gk);
     }
 };
 
@@ -672,7 +687,7 @@ template <class T> struct FamWCSPHV_T : FamWCSPH_T<T> {
         if (fl & F_MOM) {
             const T ratio = rho * (T)a.e_rho01;
             T r7, r3; // (ratio^gamma, ratio^((gamma - 1) / 2): named for the usual exponent)
-            tait_powers(ratio, a.e_gk, r7, r3);
+            tait_powers(ratio, 3, r7, r3); // (gamma = 7 only: sph_eval_group checks)
             const T p = (T)a.e_p0 + (T)a.e_B * (r7 - T(1.0));
             s[5] = rho != T(0.0) ? p * fast_rcp(rho * rho) : T(0.0);
             s[6] = (T)a.e_c0 * r3;
@@ -728,7 +743,7 @@ template <class T> struct FamWCSPHM_T : FamWCSPHE_T<T, true> {
         s[4] = rho;
         const T ratio = rho * (T)a.e_rho01;
         s[5] = q;                               // p / rho^2 as k_pack_merged computed it from the stored p
-        s[6] = (T)a.e_c0 * tait_cs_power(ratio, a.e_gk);
+        s[6] = (T)a.e_c0 * tait_cs_power(ratio, 3); // (gamma = 7 only: sph_eval_group checks)
         s[7] = T(0.0);
     }
     template <class A> static __device__ __forceinline__ void load_fused(const A &a, uint32_t jg, uint32_t fl, T mu, real4<T> &pj, T (&s)[8])
@@ -827,7 +842,7 @@ template <class T> struct FamWCSPHMV_T : FamWCSPHM_T<T> {
         s[4] = rho;
         const T ratio = rho * (T)a.e_rho01;
         T r7, r3;
-        tait_powers(ratio, a.e_gk, r7, r3);
+        tait_powers(ratio, 3, r7, r3); // (gamma = 7 only: sph_eval_group checks)
         const T p = (T)a.e_p0 + (T)a.e_B * (r7 - T(1.0));
         s[5] = rho != T(0.0) ? p * fast_rcp(rho * rho) : T(0.0);
         s[6] = (T)a.e_c0 * r3;
@@ -1800,7 +1815,7 @@ static int eval_group_merged(sph_ctx *c, const sph_kernel *K, const sph_group *g
     if (c->merge_blocked || !c->xflag.ptr) return SPH_OK; // a non-positive density was seen: the sign of rho cannot carry the class
     if (g->phase != 0 || c->ghosts_binned) return SPH_OK; // ghost segments: the per-destination path reads them as extra sources
     if (!(g->src_eos == 1 && c->eos_fuse && c->mass_fuse && c->const_flags &&
-          tait_gk(g->eos_par[2]) >= 0 && g->eos_par[0] > 0.0 && !c->record_f32 && !c->wcsph_nr))
+          tait_gk(g->eos_par[2]) == 3 && g->eos_par[0] > 0.0 && !c->record_f32 && !c->wcsph_nr)) // (gamma = 7: the merged decoders fold it)
         return SPH_OK;
     const bool vh = !(c->uniform_h && c->use_uniform_h); // variable h: FamWCSPHMV_T on records that carry h (round 5)
     const int na = c->narrays;
@@ -2143,7 +2158,7 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
         for (int j = 0; j < nsrcs && umass; j++) umass = c->arr[srcs[j]].m_known;
         // ... and with VARIABLE h the same promise plus one mass per source array gives 64-byte records [x y z h u v w rho]
         bool eosv = !eosf && g->src_eos == 1 && c->eos_fuse && c->mass_fuse && fam == FAM_WCSPH && c->pair_variant == 6 &&
-                    !(c->uniform_h && c->use_uniform_h) && !(dflags & F_TENSILE) && tait_gk(g->eos_par[2]) >= 0 && g->eos_par[0] > 0.0 &&
+                    !(c->uniform_h && c->use_uniform_h) && !(dflags & F_TENSILE) && tait_gk(g->eos_par[2]) == 3 && g->eos_par[0] > 0.0 &&
                     !c->record_f32 && !c->wcsph_nr;
         if (eosv) c->want_mrange = true;
         for (int j = 0; j < nsrcs && eosv; j++) eosv = c->arr[srcs[j]].m_known;
@@ -2369,8 +2384,11 @@ extern "C" int sph_eval_group(sph_ctx *c, const sph_kernel *K, const sph_group *
             else return launch_pair<F>(c, K->kind, a);
         };
         const bool f32 = c->arith_f32 != 0;
-        if (fam == FAM_WCSPH && eosf && umass) SPH_TRY(f32 ? run_wcsph(FamWCSPHE_T<float, true>()) : run_wcsph(FamWCSPHE_T<double, true>()));
-        else if (fam == FAM_WCSPH && eosf) SPH_TRY(f32 ? run_wcsph(FamWCSPHE_T<float>()) : run_wcsph(FamWCSPHE_T<double>()));
+        const bool g7 = tait_gk(g->eos_par[2]) == 3; // the usual exponent: kernels that fold it
+        if (fam == FAM_WCSPH && eosf && umass && g7) SPH_TRY(f32 ? run_wcsph(FamWCSPHE_T<float, true>()) : run_wcsph(FamWCSPHE_T<double, true>()));
+        else if (fam == FAM_WCSPH && eosf && g7) SPH_TRY(f32 ? run_wcsph(FamWCSPHE_T<float>()) : run_wcsph(FamWCSPHE_T<double>()));
+        else if (fam == FAM_WCSPH && eosf && umass) SPH_TRY(f32 ? run_wcsph(FamWCSPHEG_T<float, true>()) : run_wcsph(FamWCSPHEG_T<double, true>()));
+        else if (fam == FAM_WCSPH && eosf) SPH_TRY(f32 ? run_wcsph(FamWCSPHEG_T<float>()) : run_wcsph(FamWCSPHEG_T<double>()));
         else if (fam == FAM_WCSPH && eosv) SPH_TRY(f32 ? run_wcsph(FamWCSPHV_T<float>()) : run_wcsph(FamWCSPHV_T<double>()));
         else if (fam == FAM_WCSPH) SPH_TRY(f32 ? run_wcsph(FamWCSPH_T<float>()) : run_wcsph(FamWCSPH()));
         else if (fam == FAM_DENSITY) SPH_TRY(f32 ? run_density(FamDensity_T<float>()) : run_density(FamDensity()));
