@@ -917,14 +917,28 @@ def setup(args, w, rank, world, dist, ctx):
 
 
 def timed(steps, warmup, step, barrier, ctx, breakdown_steps=6):
-    """W warm-up steps, then EXACTLY `steps` timed ones between barrier + synchronize.  In the timed region the library
-    times the PAIR launches only (HIP events on the launch stream: roofline.achieved comes from them); the per-class
-    breakdown (nnps / pack / eos, the pair families) is taken in a few extra steps AFTER the timed region with every
-    class timed -- the event markers around each region cost the stream ~5 us each, eight per step were 2 % of the
-    headline step (round 5 timed every class inside the timed region)."""
+    """The per-class breakdown, W warm-up steps, then EXACTLY `steps` timed ones between barrier + synchronize.  In the
+    timed region the library times the PAIR launches only (HIP events on the launch stream: roofline.achieved comes from
+    them); the per-class breakdown (nnps / pack / eos, the pair families) is taken in a few extra steps with every class
+    timed -- the event markers around each region cost the stream ~5 us each, eight per step were 2 % of the headline step
+    (round 5 timed every class inside the timed region).  Round 6 takes those steps BEFORE the warm-up instead of behind
+    the timed region: the GPU's clock needs ~40 steps of load (80 ms) to settle after the idle seconds of the set-up and
+    the CPU oracle -- the same 20 timed steps take 2.11 ms each behind 5 warm-up steps, 2.06 behind 11, 2.035 behind 40
+     --, and steps that have to run anyway may as well run there.  Their class figures carry that
+    ramp (a few per cent high); the run's very first step, which allocates inside the timed classes, is not among them."""
+    ctx.timer_enable(1)
+    step()                                           # the first step of a run allocates (outputs, record buffers, tables)
+    ctx.timer_reset()                                # inside the timed classes: not part of the breakdown
+    nb = max(1, min(breakdown_steps, steps))
+    for _ in range(nb):
+        step()
+    barrier()
+    scale = float(steps) / nb                        # (reported per `steps`, like the pair figure)
+    timers = {k: (ctx.timer_get(k)[0] * scale, int(round(ctx.timer_get(k)[1] * scale)))
+              for k in ('nnps', 'pack', 'eos') + PAIR_FAMILIES}
+    ctx.timer_enable(2)
     for _ in range(warmup):
         step()
-    ctx.timer_enable(2)
     ctx.timer_reset()
     barrier()
     t0 = time.perf_counter()
@@ -932,20 +946,9 @@ def timed(steps, warmup, step, barrier, ctx, breakdown_steps=6):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    pair = ctx.timer_get('pair')
-    n_async = ctx.timer_get('n_async')               # neighbour updates that made no device->host round trip
-    ctx.timer_enable(1)
-    ctx.timer_reset()
-    nb = max(1, min(breakdown_steps, steps))
-    for _ in range(nb):
-        step()
-    barrier()
+    timers['pair'] = ctx.timer_get('pair')
+    timers['n_async'] = ctx.timer_get('n_async')     # neighbour updates that made no device->host round trip
     ctx.timer_enable(0)
-    scale = float(steps) / nb                        # (reported per `steps`, like the pair figure)
-    timers = {k: (ctx.timer_get(k)[0] * scale, int(round(ctx.timer_get(k)[1] * scale)))
-              for k in ('nnps', 'pack', 'eos') + PAIR_FAMILIES}
-    timers['pair'] = pair
-    timers['n_async'] = n_async
     return elapsed, timers
 
 
