@@ -916,7 +916,10 @@ def setup(args, w, rank, world, dist, ctx):
     return nnps, a_eval, halo, domain, step, ordered
 
 
-def timed(steps, warmup, step, barrier, ctx, breakdown_steps=6):
+SETTLE_MS = 100.0    # load after which the clock has settled: the warm-up of the extras, never of the headline
+
+
+def timed(steps, warmup, step, barrier, ctx, breakdown_steps=6, settle_ms=0.0):
     """The per-class breakdown, W warm-up steps, then EXACTLY `steps` timed ones between barrier + synchronize.  In the
     timed region the library times the PAIR launches only (HIP events on the launch stream: roofline.achieved comes from
     them); the per-class breakdown (nnps / pack / eos, the pair families) is taken in a few extra steps with every class
@@ -928,6 +931,9 @@ def timed(steps, warmup, step, barrier, ctx, breakdown_steps=6):
     ramp (a few per cent high); the run's very first step, which allocates inside the timed classes, is not among them."""
     ctx.timer_enable(1)
     step()                                           # the first step of a run allocates (outputs, record buffers, tables)
+    if settle_ms:
+        barrier()
+    t_begin = time.perf_counter()
     ctx.timer_reset()                                # inside the timed classes: not part of the breakdown
     nb = max(1, min(breakdown_steps, steps))
     for _ in range(nb):
@@ -939,6 +945,12 @@ def timed(steps, warmup, step, barrier, ctx, breakdown_steps=6):
     ctx.timer_enable(2)
     for _ in range(warmup):
         step()
+    if settle_ms:                                    # (extras only: steady-state figures whatever the size of the step)
+        barrier()
+        while (time.perf_counter() - t_begin) * 1e3 < settle_ms:
+            for _ in range(4):
+                step()
+            barrier()
     ctx.timer_reset()
     barrier()
     t0 = time.perf_counter()
@@ -1286,7 +1298,7 @@ def secondary_runs(args, local_rank, tstream):
                 for a in w.arrays:
                     a.gpu.pull()
                 host_in = copy_arrays(w.arrays)
-            elapsed, timers = timed(steps, warmup, step, torch.cuda.synchronize, ctx)
+            elapsed, timers = timed(steps, warmup, step, torch.cuda.synchronize, ctx, settle_ms=SETTLE_MS)
             n = sum(a.get_number_of_particles(True) for a in w.arrays)
             n_fluid = w.arrays[0].get_number_of_particles(True)
             pair_step_s = timers['pair'][0] / steps * 1e-3
@@ -1340,7 +1352,7 @@ def step_vs_n(args, local_rank, tstream, sides=(63, 79, 100, 126, 159)):
             w = build_workload(a2, 0, 1)
             nnps, a_eval, halo, domain, step, ordered = setup(a2, w, 0, 1, None, ctx)
             steps = 10
-            elapsed, timers = timed(steps, 3, step, torch.cuda.synchronize, ctx)
+            elapsed, timers = timed(steps, 3, step, torch.cuda.synchronize, ctx, settle_ms=SETTLE_MS)
             n = sum(a.get_number_of_particles(True) for a in w.arrays)
             rows['%d^3' % n1] = {'particles': n, 'ms_per_step': elapsed / steps * 1e3,
                                  'particle_updates_per_s': n * steps / elapsed,
@@ -1378,7 +1390,7 @@ def projected_strong_scaling(args, local_rank, tstream, world=8, dx=0.0035, t_on
             w = build_workload(a2, 0, 1)
             nnps, a_eval, halo, domain, step, ordered = setup(a2, w, 0, 1, None, ctx)
             steps = 10
-            elapsed, timers = timed(steps, 3, step, torch.cuda.synchronize, ctx)
+            elapsed, timers = timed(steps, 3, step, torch.cuda.synchronize, ctx, settle_ms=SETTLE_MS)
             nreal = sum(a.get_number_of_particles(True) for a in w.arrays)
             nall = sum(a.get_number_of_particles() for a in w.arrays)
             ms = elapsed / steps * 1e3
@@ -1434,7 +1446,7 @@ def projected_strong_scaling(args, local_rank, tstream, world=8, dx=0.0035, t_on
         try:
             w = build_workload(a2, 0, 1)
             nnps, a_eval, halo, domain, step, ordered = setup(a2, w, 0, 1, dist, ctx)
-            elapsed, timers = timed(10, 4, step, torch.cuda.synchronize, ctx)
+            elapsed, timers = timed(10, 4, step, torch.cuda.synchronize, ctx, settle_ms=SETTLE_MS)
             ex['self_slab'] = elapsed / 10 * 1e3
             ex['self_slab_kernels'] = sum(timers[k][0] for k in ('nnps', 'pack', 'eos', 'pair')) / 10
             ex['padded_exchanges'] = [h.padded_exchanges for h in halo.halos]
