@@ -714,6 +714,8 @@ def launch_command(args_list, gpus, port=None):
 
 def main():
     args = parse_args()
+    # (the host driver of this pool supports dmabuf IPC only: RCCL between processes needs it whoever launched the ranks)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # start the ranks ourselves: one process per GPU, RCCL over xGMI
         env = dict(os.environ)
