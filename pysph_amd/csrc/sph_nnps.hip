@@ -933,15 +933,23 @@ static int grid_from_minmax(const sph_ctx *c, int dim, double radius_scale, doub
     return SPH_OK;
 }
 
-// low key bits sorted inside a bucket: the most the tables allow (a bucket costs its workgroup ~13 us of latency whatever
-// its size, so fewer and larger buckets win) unless the MEAN bucket would not fit the stage (dense grids: wide kernels).
+// low key bits sorted inside a bucket.  Round 5 took the most the tables allow unless the MEAN bucket would not fit the
+// stage ("a bucket costs its workgroup ~13 us of latency whatever its size, so fewer and larger buckets win").  Round 6
+// measured the other side (tools/debug/lbits2.sh, nnps ms at 9 / 10 / 11 bits): the 4 M cube 0.145 / 0.154 / 0.204, the
+// 1 M cube 0.075 / 0.088 / 0.135, a 2.4 M-row slab rank of the 17.3 M tank 0.123 / 0.132 / 0.160 -- few large buckets
+// leave the chip idle and spill the stage in the dense part of a sparse grid -- but the 4.65 M tank 0.214 / 0.190 / 0.189
+// and the 17.3 M one 0.588 / 0.502 / 0.491: what costs there is the NUMBER of buckets, the empty ones of a tank that is
+// 60 % air included (tables, the scan, one workgroup each).  So: the fewest bits that keep the bucket count under
+// SORT_NB_MAX, then fewer still if the mean bucket would not fit the stage (dense grids: wide kernels).
 // Feedback from the largest bucket of the previous sort was tried and removed: the walls of a sparse tank drove the
 // bucket size down for everybody (47 k buckets instead of 12 k: 0.27 -> 0.40 ms).
+#define SORT_NB_MAX 6144
 static int sort_choose_lbits(sph_ctx *c, size_t n, size_t n_fine)
 {
     if (!c->hand_sort && c->sort_lbits >= SORT_LMIN && c->sort_lbits <= SORT_LMAX) return c->sort_lbits; // option sort_lbits
     const double per_key = (double)n / (double)std::max<size_t>(n_fine, 1);
-    int lb = SORT_LMAX;
+    int lb = SORT_LMIN;
+    while (lb < SORT_LMAX && (n_fine >> lb) > SORT_NB_MAX) lb++;
     while (lb > SORT_LMIN && per_key * (double)(1u << lb) > 0.6 * SORT_BK_CAP) lb--;
     c->sort_lbits = lb;
     return lb;
