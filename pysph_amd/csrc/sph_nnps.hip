@@ -732,7 +732,10 @@ __global__ __launch_bounds__(256) void k_fill_u32(uint32_t *p, size_t n, uint32_
 // ---------------------------------------------------------------------------
 // host side of the pass above
 // ---------------------------------------------------------------------------
-#define BIN_BLOCKS 2048   // workgroups of one k_bin_keys launch (all arrays together): eight per CU (1536 measured 25 % slower)
+#ifndef BIN_BLOCKS
+#define BIN_BLOCKS 2048
+#endif
+// BIN_BLOCKS: workgroups of one k_bin_keys launch (all arrays together): eight per CU (1536 measured 25 % slower)
 
 static int bin_arrays(sph_ctx *c, int narrays, const int *ids, BinArrays *ba, size_t *n_cat, uint32_t *nblocks)
 {
