@@ -578,7 +578,8 @@ int sph_reduce_min(sph_ctx *ctx, int array_id, int prop, double *out);
  *                    returns the reference's exact values for the current particles either way)
  *   "via_unordered"  0: the key passes of the sort always run in memory order (default 1: an array found to lie in
  *                    memory in no spatial order is visited in the previous update's cell order)
- *   "sort_lbits"     9..11: fixed low key bits of the particle sort's buckets (0: from the mean density; tests)
+ *   "sort_lbits"     9..11: fixed low key bits of the particle sort's buckets (0: the fewest that keep the bucket count
+ *                    under 6144, fewer if the mean bucket would not fit its stage; tests)
  *   "split_pair"     split evaluations (sph_group.phase): 0 (default) = phase 1 prepares (equations without sources,
  *                    records of the particles present), phase 2 launches every wave tile with the ghost segments
  *                    guarded per wavefront; 1 = the interior wave tiles already in phase 1, the face tiles in phase 2
