@@ -921,14 +921,14 @@ def setup(args, w, rank, world, dist, ctx):
 SETTLE_MS = 100.0    # load after which the clock has settled: the warm-up of the extras, never of the headline
 
 
-def timed(steps, warmup, step, barrier, ctx, breakdown_steps=6, settle_ms=0.0):
+def timed(steps, warmup, step, barrier, ctx, breakdown_steps=None, settle_ms=0.0):
     """The per-class breakdown, W warm-up steps, then EXACTLY `steps` timed ones between barrier + synchronize.  In the
     timed region the library times the PAIR launches only (HIP events on the launch stream: roofline.achieved comes from
-    them); the per-class breakdown (nnps / pack / eos, the pair families) is taken in a few extra steps with every class
+    them); the per-class breakdown (nnps / pack / eos, the pair families) is taken in `steps` extra steps with every class
     timed -- the event markers around each region cost the stream ~5 us each, eight per step were 2 % of the headline step
     (round 5 timed every class inside the timed region).  Round 6 takes those steps BEFORE the warm-up instead of behind
     the timed region: the GPU's clock needs ~40 steps of load (80 ms) to settle after the idle seconds of the set-up and
-    the CPU oracle -- the same 20 timed steps take 2.11 ms each behind 5 warm-up steps, 2.06 behind 11, 2.035 behind 40
+    the CPU oracle -- the same 20 timed steps take 2.11 ms each behind 5 warm-up steps, 2.06 behind 11, 2.04 behind 20, 2.035 behind 40
      --, and steps that have to run anyway may as well run there.  Their class figures carry that
     ramp (a few per cent high); the run's very first step, which allocates inside the timed classes, is not among them."""
     ctx.timer_enable(1)
@@ -937,7 +937,7 @@ def timed(steps, warmup, step, barrier, ctx, breakdown_steps=6, settle_ms=0.0):
         barrier()
     t_begin = time.perf_counter()
     ctx.timer_reset()                                # inside the timed classes: not part of the breakdown
-    nb = max(1, min(breakdown_steps, steps))
+    nb = max(1, min(breakdown_steps or steps, steps))   # as many steps as the timed region: the class figures are not extrapolated
     for _ in range(nb):
         step()
     barrier()
