@@ -2,7 +2,7 @@
 steps through HipParallelManager on the padded exchange with lazy migration and periodic re-balancing -- hundreds of steps,
 the column collapsing through the face.  No reference run (summation order amplifies over hundreds of steps): the
 invariants instead -- every global id owned exactly once, nothing non-finite, the counters of what the protocol did.
-    python tools/soak_two_ranks.py [dx] [steps] [migrate_every] [rebalance_every]"""
+    python tools/soak_two_ranks.py [dx] [steps] [migrate_every] [rebalance_every]      (SOAK_TIGHT=1: capacities without headroom)"""
 import os, sys, threading, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, 'tests'))
@@ -21,6 +21,9 @@ dx = float(sys.argv[1]) if len(sys.argv) > 1 else 0.04
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 lazy = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 reb = int(sys.argv[4]) if len(sys.argv) > 4 else 50
+if os.environ.get('SOAK_TIGHT') == '1':
+    # capacities without headroom: every growth of a face's count outgrows its message and is repaired by verify()
+    par._capacity = par._capacity_tight = lambda c: ((c + 8 + 7) // 8) * 8
 full = db.create_particles(dx)
 g0 = 0
 for a in full:
