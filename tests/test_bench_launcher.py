@@ -144,3 +144,33 @@ def test_rings3d_workload_is_the_named_configuration():
     x, y, z = np.meshgrid(g, g, g, indexing='ij', sparse=True)
     d = x * x + y * y + z * z
     assert abs(2 * np.count_nonzero((d >= 0.03 ** 2) & (d < 0.04 ** 2)) - 2.0e6) < 1e4
+
+
+def test_timed_region_is_exactly_k_steps_behind_the_breakdown_and_the_warm_up():
+    """bench.timed: the run's first step (dropped from the class figures), K breakdown steps with every class timed,
+    W warm-up steps and EXACTLY K timed steps with the pair launches timed only -- in that order"""
+    import bench
+
+    log = []
+
+    class Ctx(object):
+        def timer_enable(self, on):
+            log.append(('enable', on))
+
+        def timer_reset(self):
+            log.append(('reset',))
+
+        def timer_get(self, key):
+            return (1.0, 1)
+
+    def step():
+        log.append(('step',))
+
+    def barrier():
+        log.append(('barrier',))
+
+    elapsed, timers = bench.timed(5, 2, step, barrier, Ctx())
+    assert elapsed >= 0.0 and 'pair' in timers and 'nnps' in timers and 'n_async' in timers
+    names = [e[0] + (str(e[1]) if len(e) > 1 else '') for e in log]
+    assert names == (['enable1', 'step', 'reset'] + ['step'] * 5 + ['barrier', 'enable2'] + ['step'] * 2 +
+                     ['reset', 'barrier'] + ['step'] * 5 + ['barrier', 'enable0']), names
