@@ -477,8 +477,11 @@ int sph_halo_append_strided(sph_ctx *ctx, int array_id, int nprops, const int *p
 /* Remove the particles of the last sph_halo_select (both sides) from the
  * array -- particles that migrated to a neighbouring slab, after their
  * properties were packed with sph_halo_pack (ParallelManager's exported
- * particles, pysph/parallel/parallel_manager.pyx:1085-1157).  Stable
- * compaction of every device property; requires n == n_real (ghosts dropped).
+ * particles, pysph/parallel/parallel_manager.pyx:1085-1157).  When fewer
+ * than a quarter of the particles leave, the kept rows at the end of the
+ * array move into the holes (as the reference's removal does with the ends
+ * of its property arrays; option "fill_holes" 0: never); otherwise a stable
+ * compaction of every device property.  Requires n == n_real (ghosts dropped).
  * Afterwards n = n_real = *n_left.  Received particles are appended with
  * sph_halo_append and made real with sph_array_resize(n, n).                 */
 int sph_halo_remove_selected(sph_ctx *ctx, int array_id, size_t *n_left);
@@ -590,6 +593,7 @@ int sph_reduce_min(sph_ctx *ctx, int array_id, int prop, double *out);
  *   "dest_list"      pair launches over the REAL particles of an array take their wave tiles from a list of the
  *                    real particles' sorted positions: 1 (default) = when ghosts / images / padding rows are at
  *                    least 1/8 of the rows, 2 = always, 0 = never (every row of the cell order gets a lane)
+ *   "fill_holes"     0: sph_halo_remove_selected always compacts stably (default 1: see there)
  *   "row_lds"        1: the elastic rates on uniform-h records evaluate a row tile's hits from an LDS copy of its
  *                    records, tile after tile (default 0: measured 45 % slower); same pairs,
  *                    another summation order

@@ -361,6 +361,7 @@ int sph_set_option(sph_ctx *c, const char *key, long value)
     if (strcmp(key, "nl_reuse") == 0) { c->nl_reuse = value; c->nl.valid = false; return SPH_OK; }
     if (strcmp(key, "norm_masks") == 0) { c->norm_masks = value; return SPH_OK; }
     if (strcmp(key, "row_lds") == 0) { c->row_lds = value; return SPH_OK; }
+    if (strcmp(key, "fill_holes") == 0) { c->fill_holes = value ? 1 : 0; return SPH_OK; }
     if (strcmp(key, "dest_list") == 0) { c->dest_list = value < 0 ? 0 : (value > 2 ? 2 : value); c->nnps_valid = false; return SPH_OK; }
     if (strcmp(key, "merge_arrays") == 0) { c->merge_arrays = value ? 1 : 0; c->nnps_valid = false; return SPH_OK; }
     if (strcmp(key, "split_pair") == 0) { c->split_pair = value ? 1 : 0; return SPH_OK; }

@@ -840,6 +840,46 @@ __global__ __launch_bounds__(256) void k_compact_f64(const double *__restrict__ 
     dst[i] = src[list[i]];
 }
 
+// Few leavers among many particles: the kept rows of the tail [keepn, n) move into the holes the leavers left below keepn
+// (what the reference's own removal does: ParticleArray.remove_particles hands the indices to the property arrays'
+// `remove`, which copies elements from the end into the removed slots -- particle_array.pyx remove_particles).  Work and
+// launches no longer grow with the particles that STAY: four small launches instead of a full scan and one compaction
+// launch per property (~40 launches, 0.17 ms at 1 M particles with 35 properties).
+__global__ __launch_bounds__(256) void k_tail_keep(const unsigned long long *__restrict__ fl, size_t nsel, size_t keepn, size_t gone,
+                                                   uint32_t *__restrict__ keep)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > gone) return;
+    const size_t r = keepn + i;
+    keep[i] = (i == gone || (r < nsel && fl[r])) ? 0u : 1u; // (one entry more: the scan's total)
+}
+
+__global__ __launch_bounds__(256) void k_tail_list(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, size_t gone,
+                                                   uint32_t keepn, uint32_t *__restrict__ filler)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < gone && keep[i]) filler[pos[i]] = keepn + (uint32_t)i;
+}
+
+struct FillArgs {
+    double *p[SPH_PROP_COUNT];
+    int np;
+};
+
+__global__ __launch_bounds__(256) void k_fill_holes(FillArgs a, const uint32_t *__restrict__ list0, uint32_t c0,
+                                                    const uint32_t *__restrict__ list1, uint32_t keepn,
+                                                    const uint32_t *__restrict__ filler, const uint32_t *__restrict__ pos, uint32_t gone)
+{
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= pos[gone]) return; // the kept rows of the tail = the holes below keepn
+    // the holes: the entries below keepn of the two ascending selection lists, the low face's first
+    uint32_t lo = 0, hi = c0;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (list0[mid] < keepn) lo = mid + 1; else hi = mid; }
+    const uint32_t hole = j < lo ? list0[j] : list1[j - lo];
+    const uint32_t src = filler[j];
+    for (int p = blockIdx.y; p < a.np; p += gridDim.y) a.p[p][hole] = a.p[p][src];
+}
+
 // Particles that left this rank's slab (ParallelManager's "exported" particles,
 // pysph/parallel/parallel_manager.pyx:1085-1157 remove_particles after the
 // lb_exchange_data send): stable compaction of every device property.
@@ -855,6 +895,28 @@ extern "C" int sph_halo_remove_selected(sph_ctx *c, int id, size_t *n_left)
     if (n_left) *n_left = n - gone;
     if (gone == 0 || n == 0) return SPH_OK;
     const size_t keepn = n - gone;
+    if (c->fill_holes && gone * 4 < n && H.nsel <= n) {
+        SPH_TRY(c->tmp_u32a.reserve((gone + 64) * 4));
+        SPH_TRY(c->tmp_u32b.reserve((gone + 64) * 4));
+        SPH_TRY(c->dkeys.reserve((gone + 64) * 4));
+        uint32_t *keep = c->tmp_u32a.as<uint32_t>(), *pos = c->tmp_u32b.as<uint32_t>(), *filler = c->dkeys.as<uint32_t>();
+        hipLaunchKernelGGL(k_tail_keep, dim3(div_up(gone + 1, 256)), dim3(256), 0, c->stream, H.flag[0].as<unsigned long long>(),
+                           H.nsel, keepn, gone, keep);
+        SPH_TRY(dev_scan_u32(c, keep, pos, gone + 1, true));
+        hipLaunchKernelGGL(k_tail_list, dim3(div_up(gone, 256)), dim3(256), 0, c->stream, keep, pos, gone, (uint32_t)keepn, filler);
+        FillArgs fa;
+        fa.np = 0;
+        for (int p = 0; p < SPH_PROP_COUNT; p++) if (A.prop[p]) fa.p[fa.np++] = A.prop[p];
+        if (fa.np)
+            hipLaunchKernelGGL(k_fill_holes, dim3(div_up(gone, 256), (unsigned)std::min(fa.np, 16)), dim3(256), 0, c->stream, fa,
+                               H.list[0].as<uint32_t>(), (uint32_t)H.count[0], H.list[1].as<uint32_t>(), (uint32_t)keepn, filler, pos,
+                               (uint32_t)gone);
+        sph_mark_removed(A, keepn);
+        A.n = A.n_real = keepn;
+        H.count[0] = H.count[1] = 0;
+        c->nnps_valid = false;
+        return SPH_OK;
+    }
     // keep flags -> positions -> list of kept indices (ascending: order is preserved).  Scratch of the context and a
     // spare property buffer of the array that stay allocated: round 5 allocated and freed four device buffers and drained
     // the stream in here, ~1 ms per migration at 1 M particles (tools/stepping_selfslab.py).

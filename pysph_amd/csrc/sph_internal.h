@@ -268,6 +268,7 @@ struct sph_ctx {
     long eos_fuse = 1;      // honour sph_group.src_eos (64-byte WCSPH records, p and cs recomputed from rho)
     long nl_reuse = 0;      // honour sph_group.nl_mode (neighbour lists kept between the pair passes of one evaluation): built,
                             // bit-identical, and measured SLOWER on MI355X (phase 1 overlaps other wavefronts' gathers)
+    long fill_holes = 1;    // sph_halo_remove_selected moves the tail's kept rows into the holes when few particles leave (0: always the stable compaction)
     long row_lds = 0;       // experiment: k_pair_rowlds for the families that have it (the elastic rates on uniform-h records)
     long dest_list = 1;     // pair launches over the real particles take their wave tiles from DevArray::dlist
     long norm_masks = 1;    // shift a row's hit bits down to the lane's first hit

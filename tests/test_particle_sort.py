@@ -280,3 +280,50 @@ def test_async_update_can_be_switched_off():
     nn.update()
     assert ctx.timer_get('n_async')[1] == 0
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('frac', [0.0005, 0.02, 0.2, 0.6], ids=['a-few', '2-percent', 'a-fifth', 'most'])
+def test_removal_of_the_leavers_moves_tail_rows_into_the_holes(frac):
+    """sph_halo_remove_selected (parallel_manager.pyx:1085-1157: the exported particles leave): with few leavers the
+    kept rows of the tail move into the holes (option fill_holes, the default; what the reference's own removal does
+    with the ends of its property arrays), with many the stable compaction runs -- either way exactly the kept
+    particles remain, every property of a row with it; fill_holes = 0 keeps their order"""
+    import torch
+    from pysph_amd import device as dev
+    from pysph_amd.parallel import DeviceHaloOps, WCSPH_HALO_PROPS
+    from pysph_amd.particle_array import get_particle_array_wcsph
+    rng = np.random.default_rng(5)
+    n = 20000
+    x = rng.uniform(0.0, 1.0, n)
+    lo, hi = frac / 2, 1.0 - frac / 2
+
+    def run(fill):
+        pa = get_particle_array_wcsph(name='fluid', x=x.copy(), y=rng.uniform(size=n), z=np.zeros(n), h=0.01 * np.ones(n),
+                                      m=np.ones(n), rho=np.arange(n, dtype=np.float64))
+        pa.u[:] = 2.0 * np.arange(n)
+        ctx = dev.HipContext(0, torch.cuda.current_stream().cuda_stream)
+        ctx.set_option('fill_holes', fill)
+        ops = DeviceHaloOps(pa, ctx, WCSPH_HALO_PROPS, 0)
+        ops.gpu.push()
+        n_lo, n_hi = ops.select(lo, hi)
+        assert n_lo == int((x < lo).sum()) and n_hi == int((x >= hi).sum())
+        left = ops.remove_selected()
+        pa.gpu.sync_host()                                      # (the host copy follows the device's row count)
+        nr = pa.get_number_of_particles(True)
+        out = dict((k, np.array(pa.get(k)[:nr])) for k in ('x', 'rho', 'u'))
+        ctx.close()
+        return left, out
+
+    keep = (x >= lo) & (x < hi)
+    for fill in (1, 0):
+        left, out = run(fill)
+        assert left == int(keep.sum()) == out['x'].size
+        ids = out['rho'].astype(np.int64)                       # rho carries the original index
+        assert np.array_equal(np.sort(ids), np.nonzero(keep)[0])
+        assert np.array_equal(out['x'], x[ids]) and np.array_equal(out['u'], 2.0 * ids)
+        if fill == 0 or frac >= 0.25:
+            assert np.array_equal(ids, np.nonzero(keep)[0])     # stable
+        else:
+            moved = int((ids != np.arange(left)).sum())
+            assert 0 < moved <= n - left                         # only holes were filled, every other row stayed where it was
