@@ -19,7 +19,7 @@ os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER
 torch.cuda.set_device(0)
 dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
 n1 = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-for every in (1, 4, 16):
+for every in ([int(os.environ['ONLY_EVERY'])] if os.environ.get('ONLY_EVERY') else (1, 4, 16)):
     ts = torch.cuda.Stream(); torch.cuda.set_stream(ts)
     ctx = dev.HipContext(0, ts.cuda_stream)
     pa, dx = bench.make_cube(n1)
