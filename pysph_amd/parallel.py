@@ -507,6 +507,81 @@ class SlabHalo(object):
         return n_lo + n_hi
 
 
+def migrate_halos(hs):
+    """`SlabHalo.migrate` for all arrays of a rank together (a dam break has three):
+    the leavers of every array are selected, packed and removed, then ONE tiny
+    all_gather carries every array's counts and ONE batch of point-to-point transfers
+    every array's rows -- per array that was a host round trip and a transfer group
+    each (parallel_manager.pyx:1085-1157 sends all arrays' exported particles in one
+    exchange as well).  Returns the number of particles that left this rank."""
+    h0 = hs[0]
+    dist = h0.dist
+    for h in hs:
+        h.ops.drop_ghosts()
+    nbrs = h0.neighbours()
+    if not nbrs:
+        return 0
+    sides = [s for s, _, _ in nbrs]
+    inf = float('inf')
+    send_cnt, out_buf, nprops = [], [], []
+    for h in hs:
+        ops = h.ops
+        n_lo, n_hi = ops.select(h.lo if 0 in sides else -inf, h.hi if 1 in sides else inf)
+        cnt = {0: n_lo, 1: n_hi}
+        bufs, npr = {}, None
+        h.max_excursion = 0.0
+        for s, _, shift in nbrs:
+            bufs[s], npr = ops.pack_all(s, cnt[s], shift)
+            if cnt[s] and h.track_excursion and hasattr(ops, 'axis_row'):
+                k = ops.axis_row()
+                row = bufs[s][k * cnt[s]:(k + 1) * cnt[s]] - shift
+                face = h.lo if s == 0 else h.hi
+                far = float((face - row).max()) if s == 0 else float((row - face).max())
+                h.max_excursion = max(h.max_excursion, far)
+        ops.remove_selected()
+        send_cnt.append(cnt)
+        out_buf.append(bufs)
+        nprops.append(npr)
+    ops0 = h0.ops
+    sync = getattr(ops0, 'before_comm', None)
+    if sync is not None:
+        sync()
+    na, world = len(hs), h0.world
+    mine = ops0.int_tensor([c[s] for c in send_cnt for s in (0, 1)])
+    allc = ops0.int_tensor([0] * (2 * na * world))
+    dist.all_gather_into_tensor(allc, mine)
+    allc = [int(v) for v in allc.cpu()]
+    # what a peer sends to me: its hi list if it is my lo neighbour, else its lo list
+    recv_cnt = [{s: allc[2 * na * peer + 2 * a + (1 - s)] for s, peer, _ in nbrs} for a in range(na)]
+    in_buf = [{s: hs[a].ops.new_buffer(recv_cnt[a][s], nprops[a]) for s, _, _ in nbrs} for a in range(na)]
+    # Between one pair of ranks messages match in posting order: sends hi-face first, receives lo-face first (a periodic
+    # axis with <= 2 ranks has both faces talk to the SAME peer), the arrays in their order inside each face.
+    reqs = []
+    for s, peer, _ in sorted(nbrs, key=lambda nb: -nb[0]):
+        for a in range(na):
+            if send_cnt[a][s]:
+                reqs.append(dist.P2POp(dist.isend, out_buf[a][s], peer))
+    for s, peer, _ in sorted(nbrs, key=lambda nb: nb[0]):
+        for a in range(na):
+            if recv_cnt[a][s]:
+                reqs.append(dist.P2POp(dist.irecv, in_buf[a][s], peer))
+    if reqs:
+        for w in dist.batch_isend_irecv(reqs):
+            w.wait()
+    sync = getattr(ops0, 'after_comm', None)
+    if sync is not None:
+        sync()
+    left = 0
+    for a, h in enumerate(hs):
+        for s, _, _ in nbrs:
+            if recv_cnt[a][s]:
+                h.ops.append_real(in_buf[a][s], recv_cnt[a][s])
+        h.last_migrated = (send_cnt[a][0], send_cnt[a][1], recv_cnt[a].get(0, 0), recv_cnt[a].get(1, 0))
+        h.total_migrated += send_cnt[a][0] + send_cnt[a][1]
+        left += send_cnt[a][0] + send_cnt[a][1]
+    return left
+
+
 def _capacity(count):
     """rows a fixed-size ghost message is sized for, from the count both ends of
     the face saw last: a quarter of headroom + 4096 rows, in units of 1024"""
@@ -1073,7 +1148,9 @@ class SlabDecomposition(object):
         return self.halos[0].hi
 
     def migrate(self):
-        return sum(h.migrate() for h in self.halos)
+        """every array's leavers in ONE counts handshake and ONE batch of transfers
+        (`migrate_halos`; round 5: one of each per array)"""
+        return migrate_halos(self.halos)
 
     def exchange(self, drop=True):
         """Ghost refresh of ALL arrays with one batch of point-to-point transfers
