@@ -474,6 +474,17 @@ int sph_halo_append_padded2(sph_ctx *ctx, int array_id, int nprops, const int *p
 int sph_halo_append_strided(sph_ctx *ctx, int array_id, int nprops, const int *props, const void *src_device,
                             size_t count, size_t stride);
 
+/* sph_halo_append for MIGRANTS under a promise (the particles a neighbouring slab hands over,
+ * pysph/parallel/parallel_manager.pyx:1085-1157, in a run whose ranks agreed that this array's h
+ * and / or m is ONE value everywhere; NaN: no promise for that property): what the neighbour update
+ * knows of h and m survives the append -- the update after a migration makes no device->host round
+ * trip, like the one after sph_halo_append_padded -- and every arriving row is checked on the
+ * device: one that carries another h or m sets bit 1 of *flag_word_device (the word
+ * sph_halo_append_padded uses; sticky, read with the headers of the next exchange).  h and m must
+ * be among `props` to be kept.                                                                  */
+int sph_halo_append_promised(sph_ctx *ctx, int array_id, int nprops, const int *props, const void *src_device,
+                             size_t count, double h_promise, double m_promise, void *flag_word_device);
+
 /* Remove the particles of the last sph_halo_select (both sides) from the
  * array -- particles that migrated to a neighbouring slab, after their
  * properties were packed with sph_halo_pack (ParallelManager's exported

@@ -495,6 +495,54 @@ extern "C" int sph_halo_append_strided(sph_ctx *c, int id, int nprops, const int
     return SPH_OK;
 }
 
+// Migrants under a promise (round 6): the rows of sph_halo_append whose h / m are promised to be the array's ONE value
+// (the ranks agreed on it: SlabDecomposition's promises).  What the neighbour update knows of h and m then survives
+// the append -- the update after a migration stays without a device->host round trip, as the one after a padded ghost
+// append does -- and every arriving row is checked on the device: a row with another h or m sets bit 1 of the flag
+// word the padded exchange reads with its headers (sticky; the caller raises).
+__global__ __launch_bounds__(256) void k_promise_check(const double *__restrict__ hcol, const double *__restrict__ mcol, size_t count,
+                                                       double h_promise, double m_promise, uint32_t *__restrict__ flag)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const bool bad = (hcol && hcol[i] != h_promise) || (mcol && mcol[i] != m_promise);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 2u);
+}
+
+extern "C" int sph_halo_append_promised(sph_ctx *c, int id, int nprops, const int *props, const void *src, size_t count,
+                                        double h_promise, double m_promise, void *flag_word)
+{
+    if (!c || id < 0 || id >= SPH_MAX_ARRAYS || nprops < 1 || !props || !flag_word) { sph_set_error("sph_halo_append_promised: bad arguments"); return SPH_ERR_ARG; }
+    if (count == 0) return SPH_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int k_h = -1, k_m = -1;
+    for (int k = 0; k < nprops; k++) {
+        if (props[k] == SPH_H) k_h = k;
+        if (props[k] == SPH_M) k_m = k;
+    }
+    const DevArray &A0 = c->arr[id];
+    const bool empty0 = A0.n == 0;
+    // (a promised property must TRAVEL here: these are real particles, nothing is written in their place)
+    const bool keep_h = k_h >= 0 && h_promise == h_promise && !A0.raw_hm &&
+                        (empty0 || (!A0.h_dirty && A0.h_seen && A0.h_lo == h_promise && A0.h_hi == h_promise));
+    const bool keep_m = k_m >= 0 && m_promise == m_promise && !A0.raw_hm &&
+                        (empty0 || (!A0.m_dirty && A0.m_seen && A0.m_lo == m_promise && A0.m_hi == m_promise));
+    const bool mk = A0.m_known || empty0;
+    SPH_TRY(sph_halo_append_strided(c, id, nprops, props, src, count, count));
+    DevArray &A = c->arr[id];
+    if (keep_h) { A.h_dirty = false; if (empty0) { A.h_seen = true; A.h_lo = A.h_hi = h_promise; } }
+    if (keep_m) {
+        A.m_dirty = false; A.m_known = mk;
+        if (empty0) { A.m_seen = true; A.m_lo = A.m_hi = m_promise; A.m_value = m_promise; }
+    }
+    if (keep_h || keep_m) {
+        const double *base = (const double *)src;
+        hipLaunchKernelGGL(k_promise_check, dim3(div_up(count, 256)), dim3(256), 0, c->stream, keep_h ? base + (size_t)k_h * count : nullptr,
+                           keep_m ? base + (size_t)k_m * count : nullptr, count, h_promise, m_promise, (uint32_t *)flag_word);
+    }
+    return SPH_OK;
+}
+
 // Rows of a fixed-capacity message appended WITHOUT the host knowing how many there are: all `cap` rows of the message
 // go behind the particles; the first |header| of them are the ghosts, the rest are PADDING ROWS: parked at
 // x = y = z = SPH_PARKED (1e18, far outside any domain), every other listed property zero.  A parked row is inert on the

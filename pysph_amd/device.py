@@ -104,6 +104,8 @@ SIGNATURES = {
                                          C.c_double, C.c_double, _P]),
     'sph_halo_append_strided': (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int),
                                           _P, C.c_size_t, C.c_size_t]),
+    'sph_halo_append_promised': (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int), _P, C.c_size_t,
+                                           C.c_double, C.c_double, _P]),
     'sph_halo_select_pack': (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_size_t,
                                        C.c_int, C.POINTER(C.c_int), _PD, C.POINTER(C.c_size_t),
                                        C.POINTER(_P)]),

@@ -328,11 +328,23 @@ class DeviceHaloOps(object):
                                                      C.byref(left)))
         return int(left.value)
 
-    def append_real(self, buf, count):
+    def append_real(self, buf, count, flags=None, slot=0):
+        """migrants become real particles of this array.  With the flag words of the
+        exchange (`flags`, `slot`) and a promise in place (`set_promise`) the library
+        keeps what it knows of h and m and checks the arrivals against the promise on the
+        device (sph_halo_append_promised): the neighbour update after the migration makes
+        no device->host round trip."""
         ids = self.all_props()
-        dev._check(self.lib.sph_halo_append(
-            self.ctx._h, self.id, len(ids), (C.c_int * len(ids))(*ids),
-            C.c_void_p(buf.data_ptr()), count))
+        nan = float('nan')
+        hp, mp = self.__dict__.get('promise', (nan, nan))
+        if flags is not None and (hp == hp or mp == mp):
+            dev._check(self.lib.sph_halo_append_promised(
+                self.ctx._h, self.id, len(ids), (C.c_int * len(ids))(*ids), C.c_void_p(buf.data_ptr()), count,
+                hp, mp, C.c_void_p(flags.data_ptr() + 4 * int(slot))))
+        else:
+            dev._check(self.lib.sph_halo_append(
+                self.ctx._h, self.id, len(ids), (C.c_int * len(ids))(*ids),
+                C.c_void_p(buf.data_ptr()), count))
         n = self.gpu.get_number_of_particles()
         dev._check(self.lib.sph_array_resize(self.ctx._h, self.id, n, n))
 
@@ -572,10 +584,18 @@ def migrate_halos(hs):
     if sync is not None:
         sync()
     left = 0
+    # the flag words the padded exchange reads with its headers: an arrival that breaks its array's promise shows there
+    flags = _flag_words(hs) if (h0.promise and getattr(h0, 'padded_ok', False)) else None
+    code = getattr(h0.ops.append_real, '__code__', None)
+    if flags is not None and (code is None or 'flags' not in code.co_varnames):
+        flags = None        # (primitives without the promised append: the plain one)
     for a, h in enumerate(hs):
         for s, _, _ in nbrs:
             if recv_cnt[a][s]:
-                h.ops.append_real(in_buf[a][s], recv_cnt[a][s])
+                if flags is not None:
+                    h.ops.append_real(in_buf[a][s], recv_cnt[a][s], flags, a)
+                else:
+                    h.ops.append_real(in_buf[a][s], recv_cnt[a][s])
         h.last_migrated = (send_cnt[a][0], send_cnt[a][1], recv_cnt[a].get(0, 0), recv_cnt[a].get(1, 0))
         h.total_migrated += send_cnt[a][0] + send_cnt[a][1]
         left += send_cnt[a][0] + send_cnt[a][1]

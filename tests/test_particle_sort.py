@@ -327,3 +327,52 @@ def test_removal_of_the_leavers_moves_tail_rows_into_the_holes(frac):
         else:
             moved = int((ids != np.arange(left)).sum())
             assert 0 < moved <= n - left                         # only holes were filled, every other row stayed where it was
+
+
+@pytest.mark.gpu
+def test_migrants_under_a_promise_keep_the_update_without_round_trip():
+    """sph_halo_append_promised (the arrivals of a migration, parallel_manager.pyx:1085-1157, in a run whose ranks
+    agreed on ONE h and m per array): the neighbour update after it still bins on the previous update's bounds (a plain
+    append makes it look at h and m first), and an arrival that carries another h (or, where the library holds the
+    array's one mass, another m) sets bit 1 of the flag word"""
+    import torch
+    from pysph_amd import device as dev
+    from pysph_amd.nnps import HipNNPS
+    from pysph_amd.parallel import DeviceHaloOps, WCSPH_HALO_PROPS
+    pa = cloud(20000, 11, h=0.02)
+    pa.m[:] = 0.5
+    ctx = _ctx()
+    ctx.timer_enable(True)
+    ops = DeviceHaloOps(pa, ctx, WCSPH_HALO_PROPS, 0)
+    ops.gpu.push()
+    ops.set_promise(0.02, 0.5)
+    nn = HipNNPS(3, [pa], radius_scale=2.0, ctx=ctx, sync=False)
+    nn.update()
+    nn.update()
+    base = ctx.timer_get('n_async')[1]
+    ids = list(ops.all_props())
+    kx, kh, km = [ids.index(dev.prop_id(p)) for p in ('x', 'h', 'm')]
+
+    def arrivals(count, h):
+        buf = torch.zeros(len(ids) * count, dtype=torch.float64, device='cuda')
+        rows = buf.view(len(ids), count)
+        rows[kx] = torch.linspace(0.1, 0.9, count, dtype=torch.float64)
+        rows[kh] = h
+        rows[km] = 0.5
+        return buf
+
+    flags = ops.flag_words(1)
+    ops.append_real(arrivals(50, 0.02), 50, flags, 0)         # the promised h: what the library knows survives
+    nn.update()
+    assert ctx.timer_get('n_async')[1] == base + 1
+    assert int(flags[0].item()) == 0
+    ops.append_real(arrivals(50, 0.02), 50)                    # the plain append: h and m are unknown again
+    nn.update()
+    assert ctx.timer_get('n_async')[1] == base + 1
+    nn.update()
+    assert ctx.timer_get('n_async')[1] == base + 2
+    ops.append_real(arrivals(7, 0.03), 7, flags, 0)            # arrivals with another smoothing length
+    torch.cuda.synchronize()
+    assert int(flags[0].item()) & 2
+    assert pa.gpu.get_number_of_particles(True) == 20000 + 107
+    ctx.close()
