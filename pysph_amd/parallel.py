@@ -95,6 +95,9 @@ class DeviceHaloOps(object):
         return self.torch.tensor(values, dtype=self.torch.int64,
                                  device=self.device)
 
+    def empty_ints(self, n):
+        return self.torch.empty(int(n), dtype=self.torch.int64, device=self.device)
+
     # -- ordering between this context's HIP stream and the transport -------
     # RCCL orders its work after (and `work.wait()` orders it before) torch's
     # CURRENT stream.  When the context runs on that very stream (bench.py and
@@ -560,7 +563,8 @@ def migrate_halos(hs):
         sync()
     na, world = len(hs), h0.world
     mine = ops0.int_tensor([c[s] for c in send_cnt for s in (0, 1)])
-    allc = ops0.int_tensor([0] * (2 * na * world))
+    empty = getattr(ops0, 'empty_ints', None)        # (no host->device copy for a buffer that is overwritten)
+    allc = empty(2 * na * world) if empty is not None else ops0.int_tensor([0] * (2 * na * world))
     dist.all_gather_into_tensor(allc, mine)
     allc = [int(v) for v in allc.cpu()]
     # what a peer sends to me: its hi list if it is my lo neighbour, else its lo list
