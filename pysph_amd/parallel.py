@@ -539,6 +539,7 @@ def migrate_halos(hs):
     sides = [s for s, _, _ in nbrs]
     inf = float('inf')
     send_cnt, out_buf, nprops = [], [], []
+    fars = []
     for h in hs:
         ops = h.ops
         n_lo, n_hi = ops.select(h.lo if 0 in sides else -inf, h.hi if 1 in sides else inf)
@@ -548,16 +549,24 @@ def migrate_halos(hs):
         for s, _, shift in nbrs:
             bufs[s], npr = ops.pack_all(s, cnt[s], shift)
             if cnt[s] and h.track_excursion and hasattr(ops, 'axis_row'):
+                # how far beyond its face the farthest leaver had travelled (lazy migration: HipParallelManager); the
+                # maxima stay where they were computed until all arrays are through: ONE read for all of them
                 k = ops.axis_row()
                 row = bufs[s][k * cnt[s]:(k + 1) * cnt[s]] - shift
                 face = h.lo if s == 0 else h.hi
-                far = float((face - row).max()) if s == 0 else float((row - face).max())
-                h.max_excursion = max(h.max_excursion, far)
+                fars.append((h, (face - row).max() if s == 0 else (row - face).max()))
         ops.remove_selected()
         send_cnt.append(cnt)
         out_buf.append(bufs)
         nprops.append(npr)
     ops0 = h0.ops
+    if fars:
+        vals = [f for _, f in fars]
+        if hasattr(vals[0], 'device'):              # torch scalars (on the device: one transfer for all of them)
+            import torch
+            vals = torch.stack(vals).cpu().tolist()
+        for (h, _), v in zip(fars, vals):
+            h.max_excursion = max(h.max_excursion, float(v))
     sync = getattr(ops0, 'before_comm', None)
     if sync is not None:
         sync()
